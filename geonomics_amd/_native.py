@@ -1,0 +1,447 @@
+"""ctypes binding of libgnxhip.so (include/gnx_hip.h).
+
+The product has no CPU fallback: loading fails loudly if the shared library is
+missing, and creating a device state fails if there is no HIP device.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgnxhip.so')
+
+# enums (include/gnx_hip.h)
+DIST = {'lognormal': 0, 'wald': 1, 'levy': 2}
+MATE_UNIFORM, MATE_NEAREST, MATE_INVERSE = 0, 1, 2
+SURF_NONE, SURF_MIXTURE, SURF_UNIMODAL = 0, 1, 2
+(F_X, F_Y, F_AGE, F_SEX, F_ID, F_E, F_Z, F_FIT, F_GROW, F_GENO) = range(10)
+(R_N, R_NPAIRS, R_K, R_D, R_COUNTS) = range(5)
+KERNELS = ['move', 'sort', 'permute', 'find_mates', 'pairs', 'offspring',
+           'crossover', 'phenotype', 'density', 'death', 'compact']
+
+EXPORTS = [
+    'gnx_create', 'gnx_destroy', 'gnx_last_error', 'gnx_words_per_hom',
+    'gnx_set_stream', 'gnx_synchronize', 'gnx_upload_rasters',
+    'gnx_upload_layer', 'gnx_set_species_params', 'gnx_upload_population',
+    'gnx_init_population', 'gnx_set_recomb_paths', 'gnx_set_trait',
+    'gnx_set_dominance', 'gnx_set_deleterious', 'gnx_upload_genomes',
+    'gnx_assign_genomes', 'gnx_set_z', 'gnx_age', 'gnx_move',
+    'gnx_pop_dynamics', 'gnx_step', 'gnx_counts', 'gnx_step_index',
+    'gnx_set_step_index', 'gnx_mutate', 'gnx_download', 'gnx_download_genomes',
+    'gnx_download_raster', 'gnx_spatial_diff_stats', 'gnx_op_move',
+    'gnx_op_move_draws', 'gnx_op_find_pairs', 'gnx_op_crossover',
+    'gnx_op_dispersal', 'gnx_op_density', 'gnx_density_lattice_dims',
+    'gnx_op_death_probs', 'gnx_op_mortality', 'gnx_profiling',
+    'gnx_kernel_time',
+]
+
+
+class Config(C.Structure):
+    _fields_ = [('W', C.c_int32), ('H', C.c_int32), ('n_layers', C.c_int32),
+                ('L', C.c_int32), ('n_traits', C.c_int32),
+                ('cap_inds', C.c_int64), ('cap_rows', C.c_int64),
+                ('seed', C.c_uint64), ('device', C.c_int32),
+                ('reserved', C.c_int32)]
+
+
+class SpeciesParams(C.Structure):
+    _fields_ = [
+        ('b', C.c_double), ('R', C.c_double), ('n_births_lambda', C.c_double),
+        ('n_births_fixed', C.c_int32), ('sexed', C.c_int32),
+        ('p_male', C.c_double), ('mating_radius', C.c_double),
+        ('mate_mode', C.c_int32), ('repro_age', C.c_int32 * 2),
+        ('max_age', C.c_int32), ('d_min', C.c_double), ('d_max', C.c_double),
+        ('window_width', C.c_double), ('move', C.c_int32),
+        ('dir_mu', C.c_double), ('dir_kappa', C.c_double),
+        ('move_distr', C.c_int32), ('move_p1', C.c_double),
+        ('move_p2', C.c_double), ('disp_distr', C.c_int32),
+        ('disp_p1', C.c_double), ('disp_p2', C.c_double),
+        ('move_surf', C.c_int32), ('move_surf_layer', C.c_int32),
+        ('move_surf_kappa', C.c_double), ('disp_surf', C.c_int32),
+        ('disp_surf_layer', C.c_int32), ('disp_surf_kappa', C.c_double),
+        ('res_ratio', C.c_double * 2), ('K_layer', C.c_int32),
+        ('pad0', C.c_int32), ('K_factor', C.c_double)]
+
+
+_lib = None
+
+
+def load():
+    """Load libgnxhip.so; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            'geonomics_amd: %s is missing - build it with '
+            '`python -m geonomics_amd.build` (hipcc, gfx950). There is no CPU '
+            'fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.gnx_last_error.restype = C.c_char_p
+    lib.gnx_step_index.restype = C.c_int64
+    lib.gnx_destroy.restype = None
+    _lib = lib
+    return lib
+
+
+def _ptr(a, ctype):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+def _arr(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+class GnxError(RuntimeError):
+    pass
+
+
+class Device:
+    """One device-resident Species state (opaque gnx_state handle)."""
+
+    def __init__(self, W, H, n_layers, L=0, n_traits=0, cap_inds=1024,
+                 cap_rows=None, seed=0, device=0):
+        self.lib = load()
+        self.cfg = Config(W=W, H=H, n_layers=n_layers, L=L, n_traits=n_traits,
+                          cap_inds=int(cap_inds),
+                          cap_rows=int(cap_inds if cap_rows is None else cap_rows),
+                          seed=int(seed) & 0xFFFFFFFFFFFFFFFF, device=device)
+        self.h = C.c_void_p()
+        self.W, self.H, self.n_layers, self.L = W, H, n_layers, L
+        self.n_traits = n_traits
+        self.W64 = self.lib.gnx_words_per_hom(L) if L > 0 else 0
+        rc = self.lib.gnx_create(C.byref(self.cfg), C.byref(self.h))
+        if rc:
+            raise GnxError(self.lib.gnx_last_error().decode())
+
+    def close(self):
+        if getattr(self, 'h', None) is not None and self.h:
+            self.lib.gnx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            raise GnxError(self.lib.gnx_last_error().decode())
+
+    # -- setup ---------------------------------------------------------------
+    def upload_rasters(self, rasts):
+        r = _arr(rasts, np.float32)
+        assert r.shape == (self.n_layers, self.H, self.W), r.shape
+        self._chk(self.lib.gnx_upload_rasters(self.h, _ptr(r, C.c_float)))
+
+    def upload_layer(self, layer, rast):
+        r = _arr(rast, np.float32)
+        assert r.shape == (self.H, self.W)
+        self._chk(self.lib.gnx_upload_layer(self.h, int(layer), _ptr(r, C.c_float)))
+
+    def set_species_params(self, sp):
+        self.sp = sp
+        self._chk(self.lib.gnx_set_species_params(self.h, C.byref(sp)))
+
+    def upload_population(self, x, y, age, sex, ids):
+        x = _arr(x, np.float32)
+        n = x.size
+        y = _arr(y, np.float32)
+        age = _arr(age, np.int32)
+        sex = _arr(sex, np.uint8)
+        ids = _arr(ids, np.int64)
+        assert y.size == n and age.size == n and sex.size == n and ids.size == n
+        self._chk(self.lib.gnx_upload_population(
+            self.h, C.c_int64(n), _ptr(x, C.c_float), _ptr(y, C.c_float),
+            _ptr(age, C.c_int32), _ptr(sex, C.c_uint8), _ptr(ids, C.c_int64)))
+
+    def init_population(self, n):
+        self._chk(self.lib.gnx_init_population(self.h, C.c_int64(n)))
+
+    def set_recomb_paths(self, paths_packed):
+        p = _arr(paths_packed, np.uint64)
+        assert p.ndim == 2 and p.shape[1] == self.W64, (p.shape, self.W64)
+        self._chk(self.lib.gnx_set_recomb_paths(self.h, p.shape[0],
+                                                _ptr(p, C.c_uint64)))
+
+    def set_trait(self, t, loci, alpha, layer, phi, gamma, univ_adv):
+        loci = _arr(loci, np.int32)
+        alpha = _arr(alpha, np.float64)
+        assert loci.size == alpha.size
+        phi_rast = None
+        phi_s = 0.0
+        if np.ndim(phi) == 2:
+            phi_rast = _arr(phi, np.float32)
+            assert phi_rast.shape == (self.H, self.W)
+        else:
+            phi_s = float(phi)
+        self._chk(self.lib.gnx_set_trait(
+            self.h, int(t), int(loci.size), _ptr(loci, C.c_int32),
+            _ptr(alpha, C.c_double), int(layer), C.c_double(phi_s),
+            _ptr(phi_rast, C.c_float), C.c_double(float(gamma)),
+            int(bool(univ_adv))))
+
+    def set_dominance(self, dom):
+        d = None if dom is None else _arr(dom, np.uint8)
+        self._chk(self.lib.gnx_set_dominance(self.h, _ptr(d, C.c_uint8)))
+
+    def set_deleterious(self, loci, s):
+        loci = _arr(loci, np.int32)
+        s = _arr(s, np.float64)
+        self._chk(self.lib.gnx_set_deleterious(self.h, int(loci.size),
+                                               _ptr(loci, C.c_int32),
+                                               _ptr(s, C.c_double)))
+
+    def upload_genomes(self, geno):
+        g = _arr(geno, np.uint64)
+        assert g.shape == (self.N, 2, self.W64), (g.shape, self.N, self.W64)
+        self._chk(self.lib.gnx_upload_genomes(self.h, _ptr(g, C.c_uint64)))
+
+    def assign_genomes(self, n_per_site):
+        n = _arr(n_per_site, np.int32)
+        assert n.size == self.L
+        self._chk(self.lib.gnx_assign_genomes(self.h, _ptr(n, C.c_int32)))
+
+    def set_z(self):
+        self._chk(self.lib.gnx_set_z(self.h))
+
+    # -- stepping ------------------------------------------------------------
+    def age(self):
+        self._chk(self.lib.gnx_age(self.h))
+
+    def move(self):
+        self._chk(self.lib.gnx_move(self.h))
+
+    def pop_dynamics(self, burn, with_selection):
+        self._chk(self.lib.gnx_pop_dynamics(self.h, int(bool(burn)),
+                                            int(bool(with_selection))))
+
+    def step(self, burn, with_selection):
+        self._chk(self.lib.gnx_step(self.h, int(bool(burn)),
+                                    int(bool(with_selection))))
+
+    def counts(self):
+        n, b, d = C.c_int64(), C.c_int64(), C.c_int64()
+        self._chk(self.lib.gnx_counts(self.h, C.byref(n), C.byref(b), C.byref(d)))
+        return n.value, b.value, d.value
+
+    @property
+    def N(self):
+        return self.counts()[0]
+
+    @property
+    def step_index(self):
+        return self.lib.gnx_step_index(self.h)
+
+    @step_index.setter
+    def step_index(self, v):
+        self._chk(self.lib.gnx_set_step_index(self.h, C.c_int64(int(v))))
+
+    def synchronize(self):
+        self._chk(self.lib.gnx_synchronize(self.h))
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.lib.gnx_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def mutate(self, slots, loci, homs):
+        slots = _arr(slots, np.int64)
+        loci = _arr(loci, np.int32)
+        homs = _arr(homs, np.uint8)
+        self._chk(self.lib.gnx_mutate(self.h, int(slots.size),
+                                      _ptr(slots, C.c_int64),
+                                      _ptr(loci, C.c_int32),
+                                      _ptr(homs, C.c_uint8)))
+
+    # -- read-back -----------------------------------------------------------
+    _FIELD_DT = {F_X: np.float32, F_Y: np.float32, F_AGE: np.int32,
+                 F_SEX: np.uint8, F_ID: np.int64, F_FIT: np.float32,
+                 F_GROW: np.int32}
+
+    def download(self, field):
+        n = self.N
+        if field == F_E:
+            out = np.empty((self.n_layers, n), dtype=np.float32)
+        elif field == F_Z:
+            out = np.empty((self.n_traits, n), dtype=np.float32)
+        elif field == F_GENO:
+            out = np.empty((n, 2, self.W64), dtype=np.uint64)
+        else:
+            out = np.empty(n, dtype=self._FIELD_DT[field])
+        if out.size:
+            self._chk(self.lib.gnx_download(self.h, field,
+                                            out.ctypes.data_as(C.c_void_p),
+                                            C.c_int64(out.nbytes)))
+        return out
+
+    def download_genomes(self, slots):
+        slots = _arr(slots, np.int64)
+        out = np.empty((slots.size, 2, self.W64), dtype=np.uint64)
+        if slots.size:
+            self._chk(self.lib.gnx_download_genomes(
+                self.h, C.c_int64(slots.size), _ptr(slots, C.c_int64),
+                _ptr(out, C.c_uint64)))
+        return out
+
+    def download_raster(self, which):
+        out = np.empty((self.H, self.W), dtype=np.float64)
+        self._chk(self.lib.gnx_download_raster(self.h, which, _ptr(out, C.c_double)))
+        return out
+
+    def spatial_diff_stats(self):
+        m, s = C.c_double(), C.c_double()
+        self._chk(self.lib.gnx_spatial_diff_stats(self.h, C.byref(m), C.byref(s)))
+        return m.value, s.value
+
+    # -- operator-level (tests) ----------------------------------------------
+    def op_move(self, theta, dist):
+        t = _arr(theta, np.float32)
+        d = _arr(dist, np.float32)
+        assert t.size == self.N and d.size == self.N
+        self._chk(self.lib.gnx_op_move(self.h, _ptr(t, C.c_float), _ptr(d, C.c_float)))
+
+    def op_move_draws(self):
+        n = self.N
+        t = np.empty(n, np.float32)
+        d = np.empty(n, np.float32)
+        self._chk(self.lib.gnx_op_move_draws(self.h, _ptr(t, C.c_float),
+                                             _ptr(d, C.c_float)))
+        return t, d
+
+    def op_find_pairs(self, keep=None):
+        n = self.N
+        k = None if keep is None else _arr(keep, np.uint8)
+        mate = np.empty(n, np.int32)
+        pairs = np.empty((max(n, 1), 2), np.int32)
+        npairs = C.c_int64()
+        self._chk(self.lib.gnx_op_find_pairs(self.h, _ptr(k, C.c_uint8),
+                                             _ptr(mate, C.c_int32),
+                                             _ptr(pairs, C.c_int32),
+                                             C.byref(npairs)))
+        return mate, pairs[:npairs.value].copy()
+
+    def op_crossover(self, parent_slots, keys, start_homs):
+        p = _arr(parent_slots, np.int32)
+        k = _arr(keys, np.int32)
+        s = _arr(start_homs, np.uint8)
+        B = p.shape[0]
+        assert p.shape == (B, 2) and k.shape == (B, 2) and s.shape == (B, 2)
+        self._chk(self.lib.gnx_op_crossover(self.h, C.c_int64(B),
+                                            _ptr(p, C.c_int32),
+                                            _ptr(k, C.c_int32),
+                                            _ptr(s, C.c_uint8)))
+
+    def op_dispersal(self, mid_x, mid_y, theta, dist):
+        mx = _arr(mid_x, np.float32)
+        my = _arr(mid_y, np.float32)
+        th = _arr(theta, np.float32)
+        ds = _arr(dist, np.float32)
+        A, B = th.shape
+        ox = np.empty(B, np.float32)
+        oy = np.empty(B, np.float32)
+        used = np.empty(B, np.int32)
+        self._chk(self.lib.gnx_op_dispersal(
+            self.h, C.c_int64(B), int(A), _ptr(mx, C.c_float),
+            _ptr(my, C.c_float), _ptr(th, C.c_float), _ptr(ds, C.c_float),
+            _ptr(ox, C.c_float), _ptr(oy, C.c_float), _ptr(used, C.c_int32)))
+        return ox, oy, used
+
+    def lattice_dims(self):
+        jx, jy = C.c_int32(), C.c_int32()
+        self._chk(self.lib.gnx_density_lattice_dims(self.h, C.byref(jx), C.byref(jy)))
+        return jx.value, jy.value
+
+    def op_density(self, x, y, want_raster=True):
+        x = _arr(x, np.float32)
+        y = _arr(y, np.float32)
+        jx, jy = self.lattice_dims()
+        nodes = np.empty((jy, jx), np.float64)
+        rast = np.empty((self.H, self.W), np.float64) if want_raster else None
+        self._chk(self.lib.gnx_op_density(self.h, C.c_int64(x.size),
+                                          _ptr(x, C.c_float), _ptr(y, C.c_float),
+                                          _ptr(nodes, C.c_double),
+                                          _ptr(rast, C.c_double)))
+        return nodes, rast
+
+    def op_death_probs(self, with_selection, nodes_N, nodes_pairs=None):
+        nN = _arr(nodes_N, np.float64)
+        nP = None if nodes_pairs is None else _arr(nodes_pairs, np.float64)
+        n = self.N
+        p = np.empty(n, np.float64)
+        d = np.empty(n, np.float64)
+        self._chk(self.lib.gnx_op_death_probs(self.h, int(bool(with_selection)),
+                                              _ptr(nN, C.c_double),
+                                              _ptr(nP, C.c_double),
+                                              _ptr(p, C.c_double),
+                                              _ptr(d, C.c_double)))
+        return p, d
+
+    def op_mortality(self, dead):
+        d = _arr(dead, np.uint8)
+        assert d.size == self.N
+        self._chk(self.lib.gnx_op_mortality(self.h, _ptr(d, C.c_uint8)))
+
+    # -- measurement ---------------------------------------------------------
+    def profiling(self, on):
+        self._chk(self.lib.gnx_profiling(self.h, int(bool(on))))
+
+    def kernel_times(self):
+        out = {}
+        for k, name in enumerate(KERNELS):
+            ms, n, by = C.c_double(), C.c_int64(), C.c_double()
+            self._chk(self.lib.gnx_kernel_time(self.h, k, C.byref(ms), C.byref(n),
+                                               C.byref(by)))
+            out[name] = dict(ms=ms.value, launches=n.value, bytes=by.value)
+        return out
+
+
+def default_species_params(**kw):
+    """SpeciesParams with the parameters-file template defaults
+    (sim/params.py SPP_PARAMS)."""
+    sp = SpeciesParams()
+    sp.b = 0.2
+    sp.R = 0.5
+    sp.n_births_lambda = 1
+    sp.n_births_fixed = 1
+    sp.sexed = 0
+    sp.p_male = 0.5
+    sp.mating_radius = 10
+    sp.mate_mode = MATE_UNIFORM
+    sp.repro_age[0] = 0
+    sp.repro_age[1] = 0
+    sp.max_age = -1
+    sp.d_min = 0
+    sp.d_max = 1
+    sp.window_width = -1
+    sp.move = 1
+    sp.dir_mu = 0
+    sp.dir_kappa = 0
+    sp.move_distr = DIST['lognormal']
+    sp.move_p1 = 0.01
+    sp.move_p2 = 0.5
+    sp.disp_distr = DIST['lognormal']
+    sp.disp_p1 = -1
+    sp.disp_p2 = 0.05
+    sp.move_surf = SURF_NONE
+    sp.move_surf_layer = 0
+    sp.move_surf_kappa = 12
+    sp.disp_surf = SURF_NONE
+    sp.disp_surf_layer = 0
+    sp.disp_surf_kappa = 12
+    sp.res_ratio[0] = 1
+    sp.res_ratio[1] = 1
+    sp.K_layer = 0
+    sp.K_factor = 1
+    for k, v in kw.items():
+        if k == 'repro_age':
+            sp.repro_age[0], sp.repro_age[1] = v
+        elif k == 'res_ratio':
+            sp.res_ratio[0], sp.res_ratio[1] = v
+        else:
+            if not hasattr(sp, k):
+                raise AttributeError(k)
+            setattr(sp, k, v)
+    return sp

@@ -1,0 +1,933 @@
+// C-ABI of libgnxhip.so (include/gnx_hip.h): state management, uploads,
+// downloads and the host-side orchestration of one time step.
+#include <cmath>
+#include <cstdarg>
+#include <algorithm>
+#include "gnx_internal.h"
+#include "gnx_rng.h"
+
+// ---------------------------------------------------------------- errors
+static thread_local char g_err[1024] = "";
+
+void gnx_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* gnx_last_error(void) { return g_err; }
+
+extern "C" int gnx_words_per_hom(int32_t L) {
+  int w = (L + 63) / 64;
+  return ((w + 15) / 16) * 16;
+}
+
+// ---------------------------------------------------------------- timers
+void gnx_time_begin(gnx_state* h) {
+  if (h->profiling) (void)hipEventRecord(h->ev0, h->stream);
+}
+
+void gnx_time_end(gnx_state* h, int kernel, double bytes) {
+  if (!h->profiling) return;
+  (void)hipEventRecord(h->ev1, h->stream);
+  (void)hipEventSynchronize(h->ev1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, h->ev0, h->ev1);
+  h->timers[kernel].ms += ms;
+  h->timers[kernel].launches += 1;
+  h->timers[kernel].bytes += bytes;
+}
+
+GnxTraitTab gnx_trait_tab(const gnx_state* h) {
+  GnxTraitTab T;
+  memset(&T, 0, sizeof(T));
+  T.n_traits = h->cfg.n_traits;
+  for (int t = 0; t < h->cfg.n_traits; ++t) {
+    const GnxTrait& r = h->traits[t];
+    T.n_loci[t] = r.n_loci;
+    T.loci[t] = r.loci;
+    T.alpha[t] = r.alpha;
+    T.layer[t] = r.layer;
+    T.phi[t] = r.phi;
+    T.phi_rast[t] = r.phi_rast;
+    T.gamma[t] = r.gamma;
+    T.univ_adv[t] = r.univ_adv;
+  }
+  return T;
+}
+
+// ---------------------------------------------------------------- alloc helpers
+template <typename T>
+static int dalloc(T** p, size_t n) {
+  *p = nullptr;
+  if (n == 0) n = 1;
+  HIPCHK(hipMalloc((void**)p, n * sizeof(T)));
+  return 0;
+}
+
+static int alloc_soa(GnxSoA* s, int64_t cap, int n_layers, int n_traits) {
+  GNXCHK(dalloc(&s->x, cap));
+  GNXCHK(dalloc(&s->y, cap));
+  GNXCHK(dalloc(&s->age, cap));
+  GNXCHK(dalloc(&s->sex, cap));
+  GNXCHK(dalloc(&s->id, cap));
+  GNXCHK(dalloc(&s->e, cap * std::max(n_layers, 1)));
+  GNXCHK(dalloc(&s->z, cap * std::max(n_traits, 1)));
+  GNXCHK(dalloc(&s->fit, cap));
+  GNXCHK(dalloc(&s->grow, cap));
+  return 0;
+}
+
+static void free_soa(GnxSoA* s) {
+  (void)hipFree(s->x);
+  (void)hipFree(s->y);
+  (void)hipFree(s->age);
+  (void)hipFree(s->sex);
+  (void)hipFree(s->id);
+  (void)hipFree(s->e);
+  (void)hipFree(s->z);
+  (void)hipFree(s->fit);
+  (void)hipFree(s->grow);
+}
+
+// ---------------------------------------------------------------- lifecycle
+extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
+  *out = nullptr;
+  if (cfg->W <= 0 || cfg->H <= 0 || cfg->n_layers <= 0 || cfg->n_layers > GNX_MAX_LAYERS ||
+      cfg->n_traits < 0 || cfg->n_traits > GNX_MAX_TRAITS || cfg->cap_inds <= 0 || cfg->L < 0 ||
+      cfg->cap_inds > 0x7fffff00ll || cfg->cap_rows > 0x7fffff00ll) {
+    gnx_set_error("gnx_create: invalid configuration");
+    return 1;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    gnx_set_error("gnx_create: no HIP device available (this library has no CPU fallback)");
+    return 1;
+  }
+  HIPCHK(hipSetDevice(cfg->device));
+  gnx_state* h = new gnx_state();
+  h->cfg = *cfg;
+  if (cfg->L == 0) h->cfg.cap_rows = 0;
+  h->W64 = cfg->L > 0 ? gnx_words_per_hom(cfg->L) : 0;
+  const int64_t cap = cfg->cap_inds;
+  HIPCHK(hipStreamCreate(&h->stream));
+  h->own_stream = true;
+  HIPCHK(hipEventCreate(&h->ev0));
+  HIPCHK(hipEventCreate(&h->ev1));
+  for (int k = 0; k < 2; ++k) GNXCHK(alloc_soa(&h->soa[k], cap, cfg->n_layers, cfg->n_traits));
+  GNXCHK(dalloc(&h->rast, (size_t)cfg->n_layers * cfg->W * cfg->H));
+  if (cfg->L > 0) {
+    GNXCHK(dalloc(&h->G, (size_t)h->cfg.cap_rows * 2 * h->W64));
+    GNXCHK(dalloc(&h->free_rows, (size_t)h->cfg.cap_rows));
+  }
+  for (int k = 0; k < 2; ++k) {
+    GNXCHK(dalloc(&h->key[k], cap));
+    GNXCHK(dalloc(&h->perm[k], cap));
+  }
+  GNXCHK(dalloc(&h->mate, cap));
+  GNXCHK(dalloc(&h->flag, cap + 1));
+  GNXCHK(dalloc(&h->flag2, cap + 1));
+  GNXCHK(dalloc(&h->scan, cap + 1));
+  GNXCHK(dalloc(&h->pairs, cap * 2));
+  GNXCHK(dalloc(&h->nbirths, cap + 1));
+  GNXCHK(dalloc(&h->boff, cap + 1));
+  GNXCHK(dalloc(&h->off_pair, cap));
+  GNXCHK(dalloc(&h->off_parent, cap * 2));
+  GNXCHK(dalloc(&h->off_keys, cap * 2));
+  GNXCHK(dalloc(&h->off_start, cap * 2));
+  GNXCHK(dalloc(&h->keep_in, cap));
+  GNXCHK(dalloc(&h->inj_a, cap * GNX_DISP_ATTEMPTS));
+  GNXCHK(dalloc(&h->inj_b, cap * GNX_DISP_ATTEMPTS));
+  GNXCHK(dalloc(&h->mid_x, cap));
+  GNXCHK(dalloc(&h->mid_y, cap));
+  GNXCHK(dalloc(&h->p_death, cap));
+  GNXCHK(dalloc(&h->d_cell, cap));
+  GNXCHK(dalloc(&h->dead_in, cap));
+  GNXCHK(dalloc(&h->nmax_bits, 1));
+  GNXCHK(dalloc(&h->red, 8));
+  GNXCHK(gnx_prim_sort_bytes((size_t)cap, 32, &h->sort_tmp_bytes));
+  HIPCHK(hipMalloc(&h->sort_tmp, std::max<size_t>(h->sort_tmp_bytes, 16)));
+  GNXCHK(gnx_prim_scan_bytes((size_t)cap + 1, &h->scan_tmp_bytes));
+  HIPCHK(hipMalloc(&h->scan_tmp, std::max<size_t>(h->scan_tmp_bytes, 16)));
+  HIPCHK(hipHostMalloc((void**)&h->h_pin, 16 * sizeof(int64_t)));
+  *out = h;
+  return 0;
+}
+
+extern "C" void gnx_destroy(gnx_state* h) {
+  if (!h) return;
+  (void)hipStreamSynchronize(h->stream);
+  for (int k = 0; k < 2; ++k) {
+    free_soa(&h->soa[k]);
+    (void)hipFree(h->key[k]);
+    (void)hipFree(h->perm[k]);
+    (void)hipFree(h->counts_rast[k]);
+  }
+  void* ptrs[] = {h->rast, h->G, h->free_rows, h->paths, h->bp_off, h->bp_loci, h->dom,
+                  h->delet_loci, h->delet_s, h->cell_start, h->sort_tmp, h->scan_tmp, h->mate,
+                  h->flag, h->flag2, h->scan, h->pairs, h->nbirths, h->boff, h->off_pair,
+                  h->off_parent, h->off_keys, h->off_start, h->keep_in, h->inj_a, h->inj_b,
+                  h->mid_x, h->mid_y, h->p_death, h->d_cell, h->dead_in, h->nmax_bits, h->red,
+                  h->lat.areas, h->lat.cprime, h->spl_N.c, h->spl_P.c, h->bin_partials, h->nodes};
+  for (void* p : ptrs) (void)hipFree(p);
+  for (int t = 0; t < GNX_MAX_TRAITS; ++t) {
+    (void)hipFree(h->traits[t].loci);
+    (void)hipFree(h->traits[t].alpha);
+    (void)hipFree(h->traits[t].phi_rast);
+  }
+  (void)hipHostFree(h->h_pin);
+  (void)hipEventDestroy(h->ev0);
+  (void)hipEventDestroy(h->ev1);
+  if (h->own_stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+extern "C" int gnx_set_stream(gnx_state* h, void* hip_stream) {
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->own_stream) (void)hipStreamDestroy(h->stream);
+  h->stream = (hipStream_t)hip_stream;
+  h->own_stream = false;
+  return 0;
+}
+
+extern "C" int gnx_synchronize(gnx_state* h) {
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// ---------------------------------------------------------------- setup
+extern "C" int gnx_upload_rasters(gnx_state* h, const float* rasts) {
+  size_t n = (size_t)h->cfg.n_layers * h->cfg.W * h->cfg.H;
+  HIPCHK(hipMemcpyAsync(h->rast, rasts, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+extern "C" int gnx_upload_layer(gnx_state* h, int32_t layer, const float* rast) {
+  if (layer < 0 || layer >= h->cfg.n_layers) {
+    gnx_set_error("gnx_upload_layer: bad layer %d", layer);
+    return 1;
+  }
+  size_t n = (size_t)h->cfg.W * h->cfg.H;
+  HIPCHK(hipMemcpyAsync(h->rast + layer * n, rast, n * sizeof(float), hipMemcpyHostToDevice,
+                        h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// density lattice geometry (utils/spatial.py:101-130,270-319): nodes at j*hww,
+// j = 0..J-1, J-1 = largest even j with j*hww < dim + ww
+static int lattice_nodes(int dim, double ww) {
+  double hww = ww / 2.0;
+  double last_edge = 0, last_inner = 0;
+  // np.arange(0, d+ww, ww) and np.arange(hww, d+hww, ww)
+  int ne = (int)ceil((dim + ww) / ww);
+  last_edge = (ne - 1) * ww;
+  int ni = (int)ceil(((dim + hww) - hww) / ww);
+  last_inner = hww + (ni - 1) * ww;
+  double last = std::max(last_edge, last_inner);
+  return (int)llround(last / hww) + 1;
+}
+
+static int setup_lattice(gnx_state* h) {
+  const gnx_config& c = h->cfg;
+  double ww = h->sp.window_width;
+  if (!(ww > 0)) ww = std::nearbyint(0.1 * std::max(c.W, c.H));   // python round (half-even)
+  if (!(ww > 0)) ww = 1;
+  GnxLattice& L = h->lat;
+  (void)hipFree(L.areas);
+  (void)hipFree(L.cprime);
+  (void)hipFree(h->spl_N.c);
+  (void)hipFree(h->spl_P.c);
+  (void)hipFree(h->bin_partials);
+  (void)hipFree(h->nodes);
+  L.hww = ww / 2.0;
+  L.Jx = lattice_nodes(c.W, ww);
+  L.Jy = lattice_nodes(c.H, ww);
+  L.nbx = L.Jx;
+  L.nby = L.Jy;
+  const int64_t nn = (int64_t)L.Jx * L.Jy;
+  std::vector<double> areas(nn);
+  for (int i = 0; i < L.Jy; ++i)
+    for (int j = 0; j < L.Jx; ++j) {
+      double cx = j * L.hww, cy = i * L.hww;
+      double ax = std::min(cx + L.hww, (double)c.W) - std::max(cx - L.hww, 0.0);
+      double ay = std::min(cy + L.hww, (double)c.H) - std::max(cy - L.hww, 0.0);
+      double a = std::max(ax, 0.0) * std::max(ay, 0.0);
+      if (a == 0) a = 0.0001;
+      areas[(int64_t)i * L.Jx + j] = a;
+    }
+  int Jm = std::max(L.Jx, L.Jy);
+  std::vector<double> cp(Jm + 1, 0.0);
+  if (Jm > 1) cp[1] = 0.25;
+  for (int k = 2; k < Jm; ++k) cp[k] = 1.0 / (4.0 - cp[k - 1]);
+  GNXCHK(dalloc(&L.areas, nn));
+  GNXCHK(dalloc(&L.cprime, Jm + 1));
+  GNXCHK(dalloc(&h->spl_N.c, 4 * nn));
+  GNXCHK(dalloc(&h->spl_P.c, 4 * nn));
+  GNXCHK(dalloc(&h->nodes, nn));
+  size_t nb = (size_t)L.nbx * L.nby;
+  size_t parts = nb * sizeof(int32_t) <= 48 * 1024 ? 512 : 1;
+  GNXCHK(dalloc(&h->bin_partials, nb * parts));
+  HIPCHK(hipMemcpy(L.areas, areas.data(), nn * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(L.cprime, cp.data(), (Jm + 1) * sizeof(double), hipMemcpyHostToDevice));
+  h->spl_N.valid = h->spl_P.valid = false;
+  return 0;
+}
+
+static int setup_hash_grid(gnx_state* h) {
+  const gnx_config& c = h->cfg;
+  double r = h->sp.mating_radius;
+  double cs = r > 0 ? r * (1.0 + 1e-9) : 8.0;
+  // bound the number of cells (<= 2048 per axis)
+  cs = std::max(cs, std::max(c.W, c.H) / 2048.0);
+  h->cs = cs;
+  h->inv_cs = 1.0 / cs;
+  h->ncx = std::max(1, (int)ceil(c.W / cs));
+  h->ncy = std::max(1, (int)ceil(c.H / cs));
+  int64_t ncells = (int64_t)h->ncx * h->ncy;
+  int bits = 1;
+  while ((1ll << bits) < ncells) bits++;
+  h->key_bits = bits;
+  (void)hipFree(h->cell_start);
+  GNXCHK(dalloc(&h->cell_start, ncells + 1));
+  return 0;
+}
+
+extern "C" int gnx_set_species_params(gnx_state* h, const gnx_species_params* p) {
+  if (p->K_layer < 0 || p->K_layer >= h->cfg.n_layers ||
+      (p->move_surf && (p->move_surf_layer < 0 || p->move_surf_layer >= h->cfg.n_layers)) ||
+      (p->disp_surf && (p->disp_surf_layer < 0 || p->disp_surf_layer >= h->cfg.n_layers))) {
+    gnx_set_error("gnx_set_species_params: layer index out of range");
+    return 1;
+  }
+  if (p->n_births_fixed && (p->n_births_lambda < 0 || p->n_births_lambda != floor(p->n_births_lambda))) {
+    gnx_set_error("gnx_set_species_params: n_births_fixed needs an integer lambda");
+    return 1;
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->sp = *p;
+  h->have_sp = true;
+  GNXCHK(setup_lattice(h));
+  GNXCHK(setup_hash_grid(h));
+  if (!h->counts_rast[0]) {
+    GNXCHK(dalloc(&h->counts_rast[0], (size_t)h->cfg.W * h->cfg.H));
+    GNXCHK(dalloc(&h->counts_rast[1], (size_t)h->cfg.W * h->cfg.H));
+  }
+  return 0;
+}
+
+static int need_params(gnx_state* h) {
+  if (!h->have_sp) {
+    gnx_set_error("species parameters not set (gnx_set_species_params)");
+    return 1;
+  }
+  return 0;
+}
+
+extern "C" int gnx_upload_population(gnx_state* h, int64_t N, const float* x, const float* y,
+                                     const int32_t* age, const uint8_t* sex, const int64_t* id) {
+  if (N > h->cfg.cap_inds) {
+    gnx_set_error("gnx_upload_population: N %lld > cap_inds %lld", (long long)N,
+                  (long long)h->cfg.cap_inds);
+    return 1;
+  }
+  for (int64_t i = 0; i < N; ++i) {
+    if (!(x[i] >= 0 && x[i] < h->cfg.W && y[i] >= 0 && y[i] < h->cfg.H)) {
+      gnx_set_error("gnx_upload_population: individual %lld at (%g, %g) is off the landscape",
+                    (long long)i, (double)x[i], (double)y[i]);
+      return 1;
+    }
+  }
+  GnxSoA s = h->soa[h->cur];
+  hipStream_t st = h->stream;
+  HIPCHK(hipMemcpyAsync(s.x, x, N * sizeof(float), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(s.y, y, N * sizeof(float), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(s.age, age, N * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(s.sex, sex, N * sizeof(uint8_t), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(s.id, id, N * sizeof(int64_t), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemsetAsync(s.grow, 0xff, N * sizeof(int32_t), st));
+  HIPCHK(hipMemsetAsync(s.fit, 0, N * sizeof(float), st));
+  HIPCHK(hipStreamSynchronize(st));
+  h->N = N;
+  int64_t mx = -1;
+  for (int64_t i = 0; i < N; ++i) mx = std::max(mx, id[i]);
+  h->max_id = mx;
+  h->genomes_assigned = false;
+  // environment values (Species._set_e at creation, structs/species.py:3318)
+  GNXCHK(gnx_l_gather_e(h, 0, N));
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+
+extern "C" int gnx_init_population(gnx_state* h, int64_t N) {
+  if (N > h->cfg.cap_inds) {
+    gnx_set_error("gnx_init_population: N > cap_inds");
+    return 1;
+  }
+  h->genomes_assigned = false;
+  GNXCHK(gnx_l_init_population(h, N));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// ---------------------------------------------------------------- genomic architecture
+extern "C" int gnx_set_recomb_paths(gnx_state* h, int32_t n, const uint64_t* paths) {
+  if (h->cfg.L == 0 || n <= 0) {
+    gnx_set_error("gnx_set_recomb_paths: species has no genome or n <= 0");
+    return 1;
+  }
+  const int W64 = h->W64, L = h->cfg.L;
+  (void)hipFree(h->paths);
+  (void)hipFree(h->bp_off);
+  (void)hipFree(h->bp_loci);
+  h->paths = nullptr;
+  h->bp_off = h->bp_loci = nullptr;
+  // breakpoint CSR: loci where the path switches homologue
+  std::vector<int32_t> off(n + 1, 0), loci;
+  int max_bp = 0;
+  for (int k = 0; k < n; ++k) {
+    const uint64_t* p = paths + (size_t)k * W64;
+    int prev = 0, cnt = 0;
+    for (int l = 0; l < L; ++l) {
+      int b = (int)((p[l >> 6] >> (l & 63)) & 1ull);
+      if (b != prev) {
+        loci.push_back(l);
+        cnt++;
+      }
+      prev = b;
+    }
+    off[k + 1] = (int32_t)loci.size();
+    max_bp = std::max(max_bp, cnt);
+  }
+  h->sparse_paths = max_bp <= GNX_SPARSE_MAX_BP;
+  h->n_paths = n;
+  // padding bits beyond L must be zero so children keep zero padding
+  std::vector<uint64_t> clean(paths, paths + (size_t)n * W64);
+  for (int k = 0; k < n; ++k)
+    for (int l = L; l < W64 * 64; ++l) clean[(size_t)k * W64 + (l >> 6)] &= ~(1ull << (l & 63));
+  GNXCHK(dalloc(&h->paths, (size_t)n * W64));
+  GNXCHK(dalloc(&h->bp_off, n + 1));
+  GNXCHK(dalloc(&h->bp_loci, loci.size()));
+  HIPCHK(hipMemcpy(h->paths, clean.data(), (size_t)n * W64 * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->bp_off, off.data(), (n + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (!loci.empty())
+    HIPCHK(hipMemcpy(h->bp_loci, loci.data(), loci.size() * sizeof(int32_t),
+                     hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int gnx_set_trait(gnx_state* h, int32_t t, int32_t n_loci, const int32_t* loci,
+                             const double* alpha, int32_t layer, double phi,
+                             const float* phi_rast, double gamma, int32_t univ_adv) {
+  if (t < 0 || t >= h->cfg.n_traits || n_loci <= 0 || layer < 0 || layer >= h->cfg.n_layers) {
+    gnx_set_error("gnx_set_trait: bad trait index, locus count or layer");
+    return 1;
+  }
+  for (int j = 0; j < n_loci; ++j)
+    if (loci[j] < 0 || loci[j] >= h->cfg.L) {
+      gnx_set_error("gnx_set_trait: locus %d out of range", loci[j]);
+      return 1;
+    }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  GnxTrait& r = h->traits[t];
+  (void)hipFree(r.loci);
+  (void)hipFree(r.alpha);
+  (void)hipFree(r.phi_rast);
+  r.phi_rast = nullptr;
+  GNXCHK(dalloc(&r.loci, n_loci));
+  GNXCHK(dalloc(&r.alpha, n_loci));
+  HIPCHK(hipMemcpy(r.loci, loci, n_loci * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(r.alpha, alpha, n_loci * sizeof(double), hipMemcpyHostToDevice));
+  if (phi_rast) {
+    size_t n = (size_t)h->cfg.W * h->cfg.H;
+    GNXCHK(dalloc(&r.phi_rast, n));
+    HIPCHK(hipMemcpy(r.phi_rast, phi_rast, n * sizeof(float), hipMemcpyHostToDevice));
+  }
+  r.n_loci = n_loci;
+  r.layer = layer;
+  r.phi = phi;
+  r.gamma = gamma;
+  r.univ_adv = univ_adv;
+  return 0;
+}
+
+extern "C" int gnx_set_dominance(gnx_state* h, const uint8_t* dom) {
+  HIPCHK(hipStreamSynchronize(h->stream));
+  (void)hipFree(h->dom);
+  h->dom = nullptr;
+  if (!dom) return 0;
+  bool any = false;
+  for (int l = 0; l < h->cfg.L; ++l) any = any || dom[l];
+  if (!any) return 0;       // GenomicArchitecture._use_dom (structs/genome.py:555)
+  GNXCHK(dalloc(&h->dom, h->cfg.L));
+  HIPCHK(hipMemcpy(h->dom, dom, h->cfg.L, hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int gnx_set_deleterious(gnx_state* h, int32_t n, const int32_t* loci,
+                                   const double* s) {
+  HIPCHK(hipStreamSynchronize(h->stream));
+  (void)hipFree(h->delet_loci);
+  (void)hipFree(h->delet_s);
+  h->delet_loci = nullptr;
+  h->delet_s = nullptr;
+  h->n_delet = 0;
+  if (n <= 0) return 0;
+  for (int j = 0; j < n; ++j)
+    if (loci[j] < 0 || loci[j] >= h->cfg.L) {
+      gnx_set_error("gnx_set_deleterious: locus out of range");
+      return 1;
+    }
+  GNXCHK(dalloc(&h->delet_loci, n));
+  GNXCHK(dalloc(&h->delet_s, n));
+  HIPCHK(hipMemcpy(h->delet_loci, loci, n * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->delet_s, s, n * sizeof(double), hipMemcpyHostToDevice));
+  h->n_delet = n;
+  return 0;
+}
+
+static int need_genome(gnx_state* h) {
+  if (h->cfg.L == 0) {
+    gnx_set_error("species has no genome (L == 0)");
+    return 1;
+  }
+  return 0;
+}
+
+extern "C" int gnx_upload_genomes(gnx_state* h, const uint64_t* geno) {
+  GNXCHK(need_genome(h));
+  GNXCHK(gnx_l_assign_genomes(h, nullptr));     // rows 0..N-1 in slot order
+  const size_t rowb = (size_t)2 * h->W64 * 8;
+  // zero the padding bits beyond L
+  std::vector<uint64_t> tmp(geno, geno + (size_t)h->N * 2 * h->W64);
+  for (int64_t r = 0; r < h->N * 2; ++r)
+    for (int l = h->cfg.L; l < h->W64 * 64; ++l)
+      tmp[(size_t)r * h->W64 + (l >> 6)] &= ~(1ull << (l & 63));
+  HIPCHK(hipMemcpyAsync(h->G, tmp.data(), (size_t)h->N * rowb, hipMemcpyHostToDevice,
+                        h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->cfg.n_traits > 0) GNXCHK(gnx_l_phenotype(h, 0, h->N));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+extern "C" int gnx_assign_genomes(gnx_state* h, const int32_t* n_per_site) {
+  GNXCHK(need_genome(h));
+  int32_t* d = nullptr;
+  GNXCHK(dalloc(&d, h->cfg.L));
+  HIPCHK(hipMemcpy(d, n_per_site, h->cfg.L * sizeof(int32_t), hipMemcpyHostToDevice));
+  int r = gnx_l_assign_genomes(h, d);
+  if (!r && h->cfg.n_traits > 0) r = gnx_l_phenotype(h, 0, h->N);
+  (void)hipStreamSynchronize(h->stream);
+  (void)hipFree(d);
+  return r;
+}
+
+extern "C" int gnx_set_z(gnx_state* h) {
+  GNXCHK(need_genome(h));
+  if (!h->genomes_assigned) {
+    gnx_set_error("gnx_set_z: genomes not assigned");
+    return 1;
+  }
+  GNXCHK(gnx_l_phenotype(h, 0, h->N));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// ---------------------------------------------------------------- step
+extern "C" int gnx_age(gnx_state* h) { return gnx_l_age(h); }
+
+extern "C" int gnx_move(gnx_state* h) {
+  GNXCHK(need_params(h));
+  return gnx_l_move(h, false, nullptr, nullptr, nullptr, nullptr, true);
+}
+
+static int check_recomb_ready(gnx_state* h, bool burn) {
+  if (!burn && h->cfg.L > 0 && h->genomes_assigned && h->n_paths == 0) {
+    gnx_set_error("recombination paths not set (gnx_set_recomb_paths)");
+    return 1;
+  }
+  for (int t = 0; t < h->cfg.n_traits; ++t)
+    if (h->traits[t].n_loci == 0) {
+      gnx_set_error("trait %d not set (gnx_set_trait)", t);
+      return 1;
+    }
+  return 0;
+}
+
+extern "C" int gnx_pop_dynamics(gnx_state* h, int32_t burn, int32_t with_selection) {
+  GNXCHK(need_params(h));
+  GNXCHK(check_recomb_ready(h, burn != 0));
+  int64_t P = 0, B = 0, D = 0;
+  // 1. mating pairs (cell-sorted population)
+  GNXCHK(gnx_l_sort_by_cell(h));
+  GNXCHK(gnx_l_find_pairs(h, nullptr, &P));
+  // 2. n_pairs density of pair midpoints (ops/demography.py:60-91)
+  if (P > 0)
+    GNXCHK(gnx_l_density(h, P, h->mid_x, h->mid_y, &h->spl_P, nullptr));
+  else
+    h->spl_P.valid = false;
+  // 3. births: dispersal, crossover, phenotype
+  GNXCHK(gnx_l_mate(h, burn != 0, false, 0, &B));
+  // 4. N density of everyone incl. offspring (structs/species.py:845-882)
+  GnxSoA s = h->soa[h->cur];
+  GNXCHK(gnx_l_density(h, h->N, s.x, s.y, &h->spl_N, nullptr));
+  // 5-6. d at each individual's cell, fitness, death probability
+  GNXCHK(gnx_l_death_probs(h, with_selection != 0 && !burn));
+  // 7. mortality
+  GNXCHK(gnx_l_mortality(h, nullptr, &D));
+  h->last_births = B;
+  h->last_deaths = D;
+  return 0;
+}
+
+extern "C" int gnx_step(gnx_state* h, int32_t burn, int32_t with_selection) {
+  GNXCHK(need_params(h));
+  if (h->sp.move)
+    GNXCHK(gnx_l_move(h, true, nullptr, nullptr, nullptr, nullptr, true));
+  else
+    GNXCHK(gnx_l_age(h));
+  GNXCHK(gnx_pop_dynamics(h, burn, with_selection));
+  h->step += 1;
+  return 0;
+}
+
+extern "C" int gnx_counts(gnx_state* h, int64_t* N, int64_t* births, int64_t* deaths) {
+  if (N) *N = h->N;
+  if (births) *births = h->last_births;
+  if (deaths) *deaths = h->last_deaths;
+  return 0;
+}
+
+extern "C" int64_t gnx_step_index(gnx_state* h) { return h->step; }
+extern "C" int gnx_set_step_index(gnx_state* h, int64_t step) {
+  h->step = step;
+  return 0;
+}
+
+extern "C" int gnx_mutate(gnx_state* h, int32_t n, const int64_t* slot, const int32_t* locus,
+                          const uint8_t* hom) {
+  GNXCHK(need_genome(h));
+  if (n <= 0) return 0;
+  for (int i = 0; i < n; ++i)
+    if (slot[i] < 0 || slot[i] >= h->N || locus[i] < 0 || locus[i] >= h->cfg.L || hom[i] > 1) {
+      gnx_set_error("gnx_mutate: entry %d out of range", i);
+      return 1;
+    }
+  int64_t* ds;
+  int32_t* dl;
+  uint8_t* dh;
+  GNXCHK(dalloc(&ds, n));
+  GNXCHK(dalloc(&dl, n));
+  GNXCHK(dalloc(&dh, n));
+  HIPCHK(hipMemcpy(ds, slot, n * sizeof(int64_t), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dl, locus, n * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dh, hom, n, hipMemcpyHostToDevice));
+  int r = gnx_l_mutate(h, n, ds, dl, dh);
+  (void)hipStreamSynchronize(h->stream);
+  (void)hipFree(ds);
+  (void)hipFree(dl);
+  (void)hipFree(dh);
+  return r;
+}
+
+// ---------------------------------------------------------------- read-back
+extern "C" int gnx_download(gnx_state* h, int32_t field, void* dst, int64_t dst_bytes) {
+  GnxSoA s = h->soa[h->cur];
+  const int64_t N = h->N, cap = h->cfg.cap_inds;
+  const void* src = nullptr;
+  int64_t elt = 0, planes = 1;
+  switch (field) {
+    case GNX_F_X: src = s.x; elt = 4; break;
+    case GNX_F_Y: src = s.y; elt = 4; break;
+    case GNX_F_AGE: src = s.age; elt = 4; break;
+    case GNX_F_SEX: src = s.sex; elt = 1; break;
+    case GNX_F_ID: src = s.id; elt = 8; break;
+    case GNX_F_E: src = s.e; elt = 4; planes = h->cfg.n_layers; break;
+    case GNX_F_Z: src = s.z; elt = 4; planes = h->cfg.n_traits; break;
+    case GNX_F_FIT: src = s.fit; elt = 4; break;
+    case GNX_F_GROW: src = s.grow; elt = 4; break;
+    case GNX_F_GENO: {
+      GNXCHK(need_genome(h));
+      int64_t need = N * 2 * h->W64 * 8;
+      if (dst_bytes < need) {
+        gnx_set_error("gnx_download: buffer too small (%lld < %lld)", (long long)dst_bytes,
+                      (long long)need);
+        return 1;
+      }
+      if (N == 0) return 0;
+      uint64_t* tmp;
+      GNXCHK(dalloc(&tmp, (size_t)N * 2 * h->W64));
+      int r = gnx_l_gather_genomes(h, N, nullptr, tmp);
+      if (!r) {
+        hipError_t e = hipMemcpyAsync(dst, tmp, need, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) {
+          gnx_set_error("gnx_download: %s", hipGetErrorString(e));
+          r = 1;
+        }
+      }
+      (void)hipFree(tmp);
+      return r;
+    }
+    default:
+      gnx_set_error("gnx_download: unknown field %d", field);
+      return 1;
+  }
+  if (dst_bytes < N * elt * planes) {
+    gnx_set_error("gnx_download: buffer too small");
+    return 1;
+  }
+  for (int64_t p = 0; p < planes; ++p)
+    HIPCHK(hipMemcpyAsync((char*)dst + p * N * elt, (const char*)src + p * cap * elt, N * elt,
+                          hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+extern "C" int gnx_download_genomes(gnx_state* h, int64_t n, const int64_t* slots,
+                                    uint64_t* dst) {
+  GNXCHK(need_genome(h));
+  if (n <= 0) return 0;
+  for (int64_t i = 0; i < n; ++i)
+    if (slots[i] < 0 || slots[i] >= h->N) {
+      gnx_set_error("gnx_download_genomes: slot out of range");
+      return 1;
+    }
+  int64_t* ds;
+  uint64_t* tmp;
+  GNXCHK(dalloc(&ds, n));
+  GNXCHK(dalloc(&tmp, (size_t)n * 2 * h->W64));
+  HIPCHK(hipMemcpy(ds, slots, n * sizeof(int64_t), hipMemcpyHostToDevice));
+  int r = gnx_l_gather_genomes(h, n, ds, tmp);
+  if (!r) {
+    hipError_t e = hipMemcpyAsync(dst, tmp, (size_t)n * 2 * h->W64 * 8, hipMemcpyDeviceToHost,
+                                  h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) {
+      gnx_set_error("gnx_download_genomes: %s", hipGetErrorString(e));
+      r = 1;
+    }
+  }
+  (void)hipFree(ds);
+  (void)hipFree(tmp);
+  return r;
+}
+
+extern "C" int gnx_download_raster(gnx_state* h, int32_t which, double* dst) {
+  GNXCHK(need_params(h));
+  size_t cells = (size_t)h->cfg.W * h->cfg.H;
+  if (which == GNX_R_COUNTS) {
+    std::vector<int32_t> tmp(cells);
+    if (!h->counts_init) {
+      gnx_set_error("count raster not initialised (gnx_spatial_diff_stats)");
+      return 1;
+    }
+    HIPCHK(hipMemcpy(tmp.data(), h->counts_rast[h->counts_cur], cells * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < cells; ++i) dst[i] = tmp[i];
+    return 0;
+  }
+  double* d;
+  GNXCHK(dalloc(&d, cells));
+  int r = gnx_l_raster(h, which, d);
+  if (!r) {
+    hipError_t e = hipMemcpyAsync(dst, d, cells * 8, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) {
+      gnx_set_error("gnx_download_raster: %s", hipGetErrorString(e));
+      r = 1;
+    }
+  }
+  (void)hipFree(d);
+  return r;
+}
+
+extern "C" int gnx_spatial_diff_stats(gnx_state* h, double* mean, double* sd) {
+  GNXCHK(need_params(h));
+  return gnx_l_spatial_diff(h, mean, sd);
+}
+
+// ---------------------------------------------------------------- operator-level entry points
+extern "C" int gnx_op_move(gnx_state* h, const float* theta, const float* dist) {
+  GNXCHK(need_params(h));
+  int64_t N = h->N;
+  HIPCHK(hipMemcpyAsync(h->inj_a, theta, N * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->inj_b, dist, N * 4, hipMemcpyHostToDevice, h->stream));
+  GNXCHK(gnx_l_move(h, false, h->inj_a, h->inj_b, nullptr, nullptr, true));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+extern "C" int gnx_op_move_draws(gnx_state* h, float* theta, float* dist) {
+  GNXCHK(need_params(h));
+  int64_t N = h->N;
+  GNXCHK(gnx_l_move(h, false, nullptr, nullptr, h->inj_a, h->inj_b, false));
+  HIPCHK(hipMemcpyAsync(theta, h->inj_a, N * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(dist, h->inj_b, N * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+extern "C" int gnx_op_find_pairs(gnx_state* h, const uint8_t* keep, int32_t* mate,
+                                 int32_t* pairs, int64_t* n_pairs) {
+  GNXCHK(need_params(h));
+  int64_t N = h->N;
+  // NB: sorts the population by hash cell first; slot order changes
+  GNXCHK(gnx_l_sort_by_cell(h));
+  const uint8_t* dk = nullptr;
+  if (keep) {
+    // keep[] is given in the caller's slot order == order before the sort;
+    // permute it with the sort permutation
+    std::vector<int32_t> perm(N);
+    HIPCHK(hipMemcpyAsync(perm.data(), h->perm[1], N * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<uint8_t> k2(N);
+    for (int64_t i = 0; i < N; ++i) k2[i] = keep[perm[i]];
+    HIPCHK(hipMemcpy(h->keep_in, k2.data(), N, hipMemcpyHostToDevice));
+    dk = h->keep_in;
+  }
+  int64_t P = 0;
+  GNXCHK(gnx_l_find_pairs(h, dk, &P));
+  if (mate) HIPCHK(hipMemcpy(mate, h->mate, N * 4, hipMemcpyDeviceToHost));
+  if (pairs && P > 0) HIPCHK(hipMemcpy(pairs, h->pairs, P * 8, hipMemcpyDeviceToHost));
+  *n_pairs = P;
+  return 0;
+}
+
+extern "C" int gnx_op_crossover(gnx_state* h, int64_t B, const int32_t* parent_slots,
+                                const int32_t* keys, const uint8_t* start_homs) {
+  GNXCHK(need_genome(h));
+  if (!h->genomes_assigned || h->n_paths == 0) {
+    gnx_set_error("gnx_op_crossover: genomes / recombination paths not set");
+    return 1;
+  }
+  if (B <= 0) return 0;
+  if (h->N + B > h->cfg.cap_inds) {
+    gnx_set_error("gnx_op_crossover: capacity exceeded");
+    return 2;
+  }
+  for (int64_t k = 0; k < 2 * B; ++k)
+    if (parent_slots[k] < 0 || parent_slots[k] >= h->N || keys[k] < 0 || keys[k] >= h->n_paths ||
+        start_homs[k] > 1) {
+      gnx_set_error("gnx_op_crossover: entry %lld out of range", (long long)k);
+      return 1;
+    }
+  HIPCHK(hipMemcpyAsync(h->off_parent, parent_slots, 2 * B * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->off_keys, keys, 2 * B * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->off_start, start_homs, 2 * B, hipMemcpyHostToDevice, h->stream));
+  int64_t births = 0;
+  GNXCHK(gnx_l_mate(h, false, true, B, &births));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+extern "C" int gnx_op_dispersal(gnx_state* h, int64_t B, int32_t A, const float* mid_x,
+                                const float* mid_y, const float* theta, const float* dist,
+                                float* out_x, float* out_y, int32_t* attempt_used) {
+  GNXCHK(need_params(h));
+  if (B > h->cfg.cap_inds || A > GNX_DISP_ATTEMPTS * 4 || A < 1) {
+    gnx_set_error("gnx_op_dispersal: B or A out of range");
+    return 1;
+  }
+  float *dmx, *dmy, *dth, *dds, *dox, *doy;
+  int32_t* du;
+  GNXCHK(dalloc(&dmx, B));
+  GNXCHK(dalloc(&dmy, B));
+  GNXCHK(dalloc(&dth, (size_t)A * B));
+  GNXCHK(dalloc(&dds, (size_t)A * B));
+  GNXCHK(dalloc(&dox, B));
+  GNXCHK(dalloc(&doy, B));
+  GNXCHK(dalloc(&du, B));
+  HIPCHK(hipMemcpy(dmx, mid_x, B * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dmy, mid_y, B * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dth, theta, (size_t)A * B * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dds, dist, (size_t)A * B * 4, hipMemcpyHostToDevice));
+  int r = gnx_l_dispersal_inject(h, B, A, dmx, dmy, dth, dds, dox, doy, du);
+  (void)hipStreamSynchronize(h->stream);
+  if (!r) {
+    (void)hipMemcpy(out_x, dox, B * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(out_y, doy, B * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(attempt_used, du, B * 4, hipMemcpyDeviceToHost);
+  }
+  for (void* p : {(void*)dmx, (void*)dmy, (void*)dth, (void*)dds, (void*)dox, (void*)doy, (void*)du})
+    (void)hipFree(p);
+  return r;
+}
+
+extern "C" int gnx_density_lattice_dims(gnx_state* h, int32_t* Jx, int32_t* Jy) {
+  GNXCHK(need_params(h));
+  *Jx = h->lat.Jx;
+  *Jy = h->lat.Jy;
+  return 0;
+}
+
+extern "C" int gnx_op_density(gnx_state* h, int64_t n, const float* x, const float* y,
+                              double* node_vals, double* raster) {
+  GNXCHK(need_params(h));
+  float *dx, *dy;
+  GNXCHK(dalloc(&dx, n));
+  GNXCHK(dalloc(&dy, n));
+  HIPCHK(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dy, y, n * 4, hipMemcpyHostToDevice));
+  int r = gnx_l_density(h, n, dx, dy, &h->spl_N, nullptr);
+  (void)hipStreamSynchronize(h->stream);
+  (void)hipFree(dx);
+  (void)hipFree(dy);
+  if (r) return r;
+  if (node_vals)
+    HIPCHK(hipMemcpy(node_vals, h->spl_N.c, (size_t)h->lat.Jx * h->lat.Jy * 8,
+                     hipMemcpyDeviceToHost));
+  if (raster) return gnx_download_raster(h, GNX_R_N, raster);
+  return 0;
+}
+
+extern "C" int gnx_op_death_probs(gnx_state* h, int32_t with_selection, const double* nodes_N,
+                                  const double* nodes_pairs, double* p_death,
+                                  double* d_at_cell) {
+  GNXCHK(need_params(h));
+  size_t nn = (size_t)h->lat.Jx * h->lat.Jy;
+  HIPCHK(hipMemcpy(h->nodes, nodes_N, nn * 8, hipMemcpyHostToDevice));
+  GNXCHK(gnx_l_density(h, 0, nullptr, nullptr, &h->spl_N, h->nodes));
+  if (nodes_pairs) {
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->nodes, nodes_pairs, nn * 8, hipMemcpyHostToDevice));
+    GNXCHK(gnx_l_density(h, 0, nullptr, nullptr, &h->spl_P, h->nodes));
+  } else {
+    h->spl_P.valid = false;
+  }
+  GNXCHK(gnx_l_death_probs(h, with_selection != 0));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (p_death) HIPCHK(hipMemcpy(p_death, h->p_death, h->N * 8, hipMemcpyDeviceToHost));
+  if (d_at_cell) HIPCHK(hipMemcpy(d_at_cell, h->d_cell, h->N * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int gnx_op_mortality(gnx_state* h, const uint8_t* dead) {
+  HIPCHK(hipMemcpy(h->dead_in, dead, h->N, hipMemcpyHostToDevice));
+  int64_t D = 0;
+  GNXCHK(gnx_l_mortality(h, h->dead_in, &D));
+  h->last_deaths = D;
+  return 0;
+}
+
+// ---------------------------------------------------------------- measurement
+extern "C" int gnx_profiling(gnx_state* h, int32_t on) {
+  h->profiling = on != 0;
+  for (int k = 0; k < GNX_K_COUNT; ++k) h->timers[k] = GnxKernelTimer();
+  return 0;
+}
+
+extern "C" int gnx_kernel_time(gnx_state* h, int32_t kernel, double* ms, int64_t* launches,
+                               double* algorithmic_bytes) {
+  if (kernel < 0 || kernel >= GNX_K_COUNT) {
+    gnx_set_error("gnx_kernel_time: bad kernel id");
+    return 1;
+  }
+  if (ms) *ms = h->timers[kernel].ms;
+  if (launches) *launches = h->timers[kernel].launches;
+  if (algorithmic_bytes) *algorithmic_bytes = h->timers[kernel].bytes;
+  h->timers[kernel] = GnxKernelTimer();
+  return 0;
+}

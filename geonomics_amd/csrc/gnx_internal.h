@@ -1,0 +1,228 @@
+// Internal state and launcher declarations of libgnxhip.so (not part of the ABI).
+#pragma once
+#include <cstring>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+#include <hip/hip_runtime.h>
+#include "../../include/gnx_hip.h"
+
+#define GNX_MAX_TRAITS 16
+#define GNX_MAX_LAYERS 16
+#define GNX_DISP_ATTEMPTS 8
+#define GNX_SPARSE_MAX_BP 24     // paths with more switches than this use bit masks
+
+void gnx_set_error(const char* fmt, ...);
+
+#define HIPCHK(expr)                                                          \
+  do {                                                                        \
+    hipError_t _e = (expr);                                                   \
+    if (_e != hipSuccess) {                                                   \
+      gnx_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),    \
+                    __FILE__, __LINE__);                                      \
+      return 1;                                                               \
+    }                                                                         \
+  } while (0)
+
+#define GNXCHK(expr)                                                          \
+  do {                                                                        \
+    int _r = (expr);                                                          \
+    if (_r) return _r;                                                        \
+  } while (0)
+
+struct GnxTrait {
+  int n_loci = 0;
+  int32_t* loci = nullptr;     // device [n_loci]
+  double* alpha = nullptr;     // device [n_loci]
+  int layer = 0;
+  double phi = 0;
+  float* phi_rast = nullptr;   // device [H][W] or null
+  double gamma = 1;
+  int univ_adv = 0;
+};
+
+// Per-trait table handed to kernels by value
+struct GnxTraitTab {
+  int n_traits;
+  int n_loci[GNX_MAX_TRAITS];
+  const int32_t* loci[GNX_MAX_TRAITS];
+  const double* alpha[GNX_MAX_TRAITS];
+  int layer[GNX_MAX_TRAITS];
+  double phi[GNX_MAX_TRAITS];
+  const float* phi_rast[GNX_MAX_TRAITS];
+  double gamma[GNX_MAX_TRAITS];
+  int univ_adv[GNX_MAX_TRAITS];
+};
+
+// Struct-of-arrays view of the population (one of the two ping-pong copies)
+struct GnxSoA {
+  float* x;
+  float* y;
+  int32_t* age;
+  uint8_t* sex;
+  int64_t* id;
+  float* e;        // [n_layers][cap]
+  float* z;        // [n_traits][cap]
+  float* fit;
+  int32_t* grow;   // genome row, -1 before genomes are assigned
+};
+
+// Density lattice (utils/spatial.py _DensityGridStack restated)
+struct GnxLattice {
+  int Jx = 0, Jy = 0;     // nodes per axis
+  int nbx = 0, nby = 0;   // half-window bins per axis (= J)
+  double hww = 0;         // half window width = node spacing
+  double* areas = nullptr;     // device [Jy][Jx]
+  double* cprime = nullptr;    // device [max(Jx,Jy)] Thomas factors
+};
+
+// spline coefficient set for one density field: V, Mx, My, Mxy, each [Jy][Jx]
+struct GnxSpline {
+  double* c = nullptr;   // device [4][Jy*Jx]
+  bool valid = false;
+};
+
+struct GnxKernelTimer {
+  double ms = 0;
+  int64_t launches = 0;
+  double bytes = 0;
+};
+
+struct gnx_state {
+  gnx_config cfg{};
+  gnx_species_params sp{};
+  bool have_sp = false;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int W64 = 0;                 // u64 words per homologue
+  int64_t N = 0;
+  int64_t max_id = -1;
+  int64_t step = 0;            // global step counter (RNG addressing)
+  int64_t last_births = 0, last_deaths = 0;
+
+  GnxSoA soa[2]{};
+  int cur = 0;
+
+  // genomes
+  uint64_t* G = nullptr;       // [cap_rows][2][W64]
+  int32_t* free_rows = nullptr;
+  int64_t n_free = 0;
+  bool genomes_assigned = false;
+
+  // landscape
+  float* rast = nullptr;       // [n_layers][H][W]
+
+  // recombination paths
+  int n_paths = 0;
+  uint64_t* paths = nullptr;   // [n_paths][W64]
+  int32_t* bp_off = nullptr;   // [n_paths+1]
+  int32_t* bp_loci = nullptr;
+  bool sparse_paths = false;
+
+  // traits etc
+  GnxTrait traits[GNX_MAX_TRAITS];
+  uint8_t* dom = nullptr;
+  int n_delet = 0;
+  int32_t* delet_loci = nullptr;
+  double* delet_s = nullptr;
+
+  // hash grid for neighbour search
+  double cs = 1, inv_cs = 1;
+  int ncx = 1, ncy = 1, key_bits = 1;
+  uint32_t* key[2]{};
+  int32_t* perm[2]{};
+  int32_t* cell_start = nullptr;
+  void* sort_tmp = nullptr;
+  size_t sort_tmp_bytes = 0;
+  void* scan_tmp = nullptr;
+  size_t scan_tmp_bytes = 0;
+
+  // pairing / mating scratch (capacity cap_inds)
+  int32_t* mate = nullptr;
+  int32_t* flag = nullptr;
+  int32_t* flag2 = nullptr;
+  int32_t* scan = nullptr;
+  int32_t* pairs = nullptr;      // [cap][2] slots
+  int32_t* nbirths = nullptr;
+  int32_t* boff = nullptr;
+  int32_t* off_pair = nullptr;
+  int32_t* off_parent = nullptr; // [cap][2] parent slots
+  int32_t* off_keys = nullptr;   // [cap][2]
+  uint8_t* off_start = nullptr;  // [cap][2]
+  uint8_t* keep_in = nullptr;
+  float* inj_a = nullptr;        // injected draws (theta)
+  float* inj_b = nullptr;        // injected draws (dist)
+  float* mid_x = nullptr;        // pair midpoints
+  float* mid_y = nullptr;
+  int64_t n_pairs = 0;
+
+  // density
+  GnxLattice lat;
+  GnxSpline spl_N, spl_P;
+  int32_t* bin_partials = nullptr;   // [n_blocks][nby*nbx]
+  int n_bin_blocks = 0;
+  double* nodes = nullptr;           // [Jy][Jx] scratch node values
+  unsigned long long* nmax_bits = nullptr;
+  double* p_death = nullptr;         // [cap]
+  double* d_cell = nullptr;          // [cap]
+  uint8_t* dead_in = nullptr;
+  int32_t* counts_rast[2]{};         // per-cell individual counts (burn-in test)
+  int counts_cur = 0;
+  bool counts_init = false;
+  double* red = nullptr;             // small reduction scratch [8]
+
+  // pinned host scratch for read-backs
+  int64_t* h_pin = nullptr;          // [16]
+
+  // profiling
+  bool profiling = false;
+  GnxKernelTimer timers[GNX_K_COUNT];
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+GnxTraitTab gnx_trait_tab(const gnx_state* h);
+
+// RAII-less scoped timer helpers (events on h->stream)
+void gnx_time_begin(gnx_state* h);
+void gnx_time_end(gnx_state* h, int kernel, double bytes);
+
+// ---- launchers (gnx_kernels_*.hip) ---------------------------------------
+int gnx_l_init_population(gnx_state* h, int64_t N);
+int gnx_l_gather_e(gnx_state* h, int64_t first, int64_t n);
+int gnx_l_age(gnx_state* h);
+int gnx_l_move(gnx_state* h, bool inc_age, const float* inj_theta, const float* inj_dist,
+               float* out_theta, float* out_dist, bool apply);
+int gnx_l_sort_by_cell(gnx_state* h);
+int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out);
+int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* births_out);
+int gnx_l_dispersal_inject(gnx_state* h, int64_t B, int A, const float* d_mx, const float* d_my,
+                           const float* d_theta, const float* d_dist, float* d_ox, float* d_oy,
+                           int32_t* d_used);
+int gnx_l_crossover(gnx_state* h, int64_t first_slot, int64_t B);
+int gnx_l_phenotype(gnx_state* h, int64_t first_slot, int64_t n);
+int gnx_l_assign_genomes(gnx_state* h, const int32_t* d_n_per_site);
+int gnx_l_mutate(gnx_state* h, int n, const int64_t* d_slot, const int32_t* d_locus,
+                 const uint8_t* d_hom);
+int gnx_l_density(gnx_state* h, int64_t n, const float* d_x, const float* d_y, GnxSpline* spl,
+                  const double* d_nodes_override);
+int gnx_l_raster(gnx_state* h, int which, double* d_out);
+int gnx_l_death_probs(gnx_state* h, bool with_selection);
+int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_out);
+int gnx_l_spatial_diff(gnx_state* h, double* mean, double* sd);
+int gnx_l_gather_genomes(gnx_state* h, int64_t n, const int64_t* d_slots, uint64_t* d_out);
+
+// rocPRIM wrappers (gnx_prim.hip)
+int gnx_prim_sort_bytes(size_t n, int bits, size_t* bytes);
+int gnx_prim_sort(void* tmp, size_t bytes, const uint32_t* kin, uint32_t* kout, const int32_t* vin,
+                  int32_t* vout, size_t n, int bits, hipStream_t s);
+int gnx_prim_scan_bytes(size_t n, size_t* bytes);
+int gnx_prim_scan(void* tmp, size_t bytes, const int32_t* in, int32_t* out, size_t n,
+                  hipStream_t s);
+
+static inline int gnx_grid(int64_t n, int block, int max_blocks = 1 << 20) {
+  int64_t g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > max_blocks) g = max_blocks;
+  return (int)g;
+}

@@ -1,0 +1,495 @@
+// Density estimation, density-dependent death probabilities, fitness,
+// mortality and stream compaction.
+//
+// Density (utils/spatial.py:34-146,270-360): the union of the reference's four
+// offset window grids is a regular lattice of spacing hww = ww/2; node j's
+// window covers the two half-window bins j-1 and j.  So: count individuals into
+// half-window bins (LDS histograms -> per-block partials, no global atomics),
+// sum 2x2 bins per node, divide by the window area inside the landscape, then
+// interpolate.  The reference interpolates with scipy's Clough-Tocher
+// griddata(method='cubic'), which is not reproducible off qhull; the build uses
+// the natural bicubic spline through the same nodes (tolerance: DESIGN.md).
+// All density arithmetic is f64 so it matches the numpy oracle to ~1e-12.
+#include "gnx_internal.h"
+#include "gnx_rng.h"
+
+#define BIN_BLOCKS 512
+
+// ---------------------------------------------------------------- bins
+__global__ void __launch_bounds__(256)
+k_bins(int64_t n, const float* x, const float* y, double inv_hww, int nbx, int nby,
+       int32_t* partials) {
+  extern __shared__ int32_t lds_hist[];
+  const int nb = nbx * nby;
+  for (int k = threadIdx.x; k < nb; k += blockDim.x) lds_hist[k] = 0;
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    int hx = min(nbx - 1, (int)floor((double)x[i] * inv_hww));
+    int hy = min(nby - 1, (int)floor((double)y[i] * inv_hww));
+    atomicAdd(&lds_hist[hy * nbx + hx], 1);
+  }
+  __syncthreads();
+  int32_t* out = partials + (int64_t)blockIdx.x * nb;
+  for (int k = threadIdx.x; k < nb; k += blockDim.x) out[k] = lds_hist[k];
+}
+
+// variant for lattices too large for LDS: global atomics into partials[0]
+__global__ void k_bins_global(int64_t n, const float* x, const float* y, double inv_hww, int nbx,
+                              int nby, int32_t* hist) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int hx = min(nbx - 1, (int)floor((double)x[i] * inv_hww));
+  int hy = min(nby - 1, (int)floor((double)y[i] * inv_hww));
+  atomicAdd(&hist[hy * nbx + hx], 1);
+}
+
+// node value = (sum of the 2x2 half-window bins around the node) / area
+__global__ void k_nodes(int Jx, int Jy, int nbx, int n_part, const int32_t* partials,
+                        const double* areas, double* V) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Jx * Jy) return;
+  int i = idx / Jx, j = idx - i * Jx;
+  const int nb = nbx * Jy;     // nby == Jy
+  long long cnt = 0;
+  for (int di = -1; di <= 0; ++di)
+    for (int dj = -1; dj <= 0; ++dj) {
+      int ii = i + di, jj = j + dj;
+      if (ii < 0 || jj < 0) continue;
+      int b = ii * nbx + jj;
+      for (int p = 0; p < n_part; ++p) cnt += partials[(int64_t)p * nb + b];
+    }
+  V[idx] = (double)cnt / areas[idx];
+}
+
+// natural-cubic-spline second derivatives along one axis of a [Jy][Jx] field.
+// One thread per line; Thomas algorithm with host-precomputed factors cp[].
+// along_x: lines are rows (stride 1 inside a line); else columns (stride Jx).
+__global__ void k_spline_m(int Jx, int Jy, int along_x, double h, const double* cp,
+                           const double* V, double* M) {
+  int line = blockIdx.x * blockDim.x + threadIdx.x;
+  int n_lines = along_x ? Jy : Jx;
+  if (line >= n_lines) return;
+  int J = along_x ? Jx : Jy;
+  int64_t stride = along_x ? 1 : Jx;
+  int64_t base = along_x ? (int64_t)line * Jx : line;
+  M[base] = 0.0;
+  M[base + (int64_t)(J - 1) * stride] = 0.0;
+  if (J <= 2) return;
+  const double s = 6.0 / (h * h);
+  // forward sweep on the (J-2) interior unknowns of  m[k-1] + 4 m[k] + m[k+1] = d[k];
+  // cp[k] = c'_k, and d'_k is stored in M
+  double dprev = 0.0;
+  for (int k = 1; k <= J - 2; ++k) {
+    double d = s * (V[base + (k - 1) * stride] - 2.0 * V[base + k * stride] +
+                    V[base + (k + 1) * stride]);
+    double denom = (k == 1) ? 4.0 : 4.0 - cp[k - 1];
+    double dp = (k == 1) ? d / denom : (d - dprev) / denom;
+    M[base + k * stride] = dp;
+    dprev = dp;
+  }
+  for (int k = J - 3; k >= 1; --k)
+    M[base + k * stride] -= cp[k] * M[base + (k + 1) * stride];
+}
+
+struct SplineC {
+  const double* V;
+  const double* Mx;
+  const double* My;
+  const double* Mxy;
+  int Jx, Jy;
+  double hww, inv_hww;
+};
+
+__device__ __forceinline__ double spl1(double v0, double v1, double m0, double m1, double t,
+                                       double h2_6) {
+  double a = 1.0 - t;
+  return a * v0 + t * v1 + ((a * a * a - a) * m0 + (t * t * t - t) * m1) * h2_6;
+}
+
+__device__ __forceinline__ double spline_eval(const SplineC& S, double px, double py) {
+  double fx = px * S.inv_hww, fy = py * S.inv_hww;
+  int j = min(max((int)floor(fx), 0), S.Jx - 2);
+  int i = min(max((int)floor(fy), 0), S.Jy - 2);
+  double tx = fx - j, ty = fy - i;
+  double h2_6 = S.hww * S.hww / 6.0;
+  int64_t a = (int64_t)i * S.Jx + j, b = a + S.Jx;
+  double v0 = spl1(S.V[a], S.V[a + 1], S.Mx[a], S.Mx[a + 1], tx, h2_6);
+  double m0 = spl1(S.My[a], S.My[a + 1], S.Mxy[a], S.Mxy[a + 1], tx, h2_6);
+  double v1 = spl1(S.V[b], S.V[b + 1], S.Mx[b], S.Mx[b + 1], tx, h2_6);
+  double m1 = spl1(S.My[b], S.My[b + 1], S.Mxy[b], S.Mxy[b + 1], tx, h2_6);
+  return spl1(v0, v1, m0, m1, ty, h2_6);
+}
+
+static SplineC make_splinec(const gnx_state* h, const GnxSpline& s) {
+  SplineC c;
+  int64_t n = (int64_t)h->lat.Jx * h->lat.Jy;
+  c.V = s.c;
+  c.Mx = s.c + n;
+  c.My = s.c + 2 * n;
+  c.Mxy = s.c + 3 * n;
+  c.Jx = h->lat.Jx;
+  c.Jy = h->lat.Jy;
+  c.hww = h->lat.hww;
+  c.inv_hww = 1.0 / h->lat.hww;
+  return c;
+}
+
+// counts n points into bins, builds node densities and the spline coefficients
+int gnx_l_density(gnx_state* h, int64_t n, const float* d_x, const float* d_y, GnxSpline* spl,
+                  const double* d_nodes_override) {
+  const GnxLattice& L = h->lat;
+  const int nb = L.nbx * L.nby;
+  const int64_t nn = (int64_t)L.Jx * L.Jy;
+  double* V = spl->c;
+  gnx_time_begin(h);
+  if (d_nodes_override) {
+    HIPCHK(hipMemcpyAsync(V, d_nodes_override, nn * sizeof(double), hipMemcpyDeviceToDevice,
+                          h->stream));
+  } else {
+    int n_part;
+    if ((size_t)nb * sizeof(int32_t) <= 48 * 1024) {
+      n_part = (int)std::min<int64_t>(BIN_BLOCKS, std::max<int64_t>(1, (n + 255) / 256));
+      if (n == 0) {
+        n_part = 1;
+        HIPCHK(hipMemsetAsync(h->bin_partials, 0, (size_t)nb * sizeof(int32_t), h->stream));
+      } else {
+        hipLaunchKernelGGL(k_bins, dim3(n_part), dim3(256), (size_t)nb * sizeof(int32_t), h->stream,
+                           n, d_x, d_y, 1.0 / L.hww, L.nbx, L.nby, h->bin_partials);
+      }
+    } else {
+      n_part = 1;
+      HIPCHK(hipMemsetAsync(h->bin_partials, 0, (size_t)nb * sizeof(int32_t), h->stream));
+      if (n > 0)
+        hipLaunchKernelGGL(k_bins_global, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, n, d_x,
+                           d_y, 1.0 / L.hww, L.nbx, L.nby, h->bin_partials);
+    }
+    hipLaunchKernelGGL(k_nodes, dim3(gnx_grid(nn, 128)), dim3(128), 0, h->stream, L.Jx, L.Jy, L.nbx,
+                       n_part, h->bin_partials, L.areas, V);
+  }
+  double* Mx = V + nn;
+  double* My = V + 2 * nn;
+  double* Mxy = V + 3 * nn;
+  hipLaunchKernelGGL(k_spline_m, dim3(gnx_grid(L.Jy, 64)), dim3(64), 0, h->stream, L.Jx, L.Jy, 1,
+                     L.hww, L.cprime, V, Mx);
+  hipLaunchKernelGGL(k_spline_m, dim3(gnx_grid(L.Jx, 64)), dim3(64), 0, h->stream, L.Jx, L.Jy, 0,
+                     L.hww, L.cprime, V, My);
+  hipLaunchKernelGGL(k_spline_m, dim3(gnx_grid(L.Jy, 64)), dim3(64), 0, h->stream, L.Jx, L.Jy, 1,
+                     L.hww, L.cprime, My, Mxy);
+  gnx_time_end(h, GNX_K_DENSITY, (double)n * 8.0);
+  HIPCHK(hipGetLastError());
+  spl->valid = true;
+  return 0;
+}
+
+// ---------------------------------------------------------------- rasters
+// max over all cells of N (needed by _calc_dNdt's clip, ops/demography.py:116)
+__global__ void __launch_bounds__(256)
+k_nmax(SplineC S, int W, int H, unsigned long long* out_bits) {
+  __shared__ double red[256];
+  double m = 0.0;
+  const int64_t total = (int64_t)W * H;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += stride) {
+    int cy = (int)(c / W), cx = (int)(c - (int64_t)cy * W);
+    double v = spline_eval(S, cx + 0.5, cy + 0.5);
+    m = fmax(m, v);
+  }
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  // non-negative doubles order like their bit patterns
+  if (threadIdx.x == 0) atomicMax(out_bits, (unsigned long long)__double_as_longlong(red[0]));
+}
+
+struct DemP {
+  double R, b, lam, d_min, d_max, K_factor;
+  int K_layer, W, H;
+  int have_pairs;
+};
+
+// d at one cell (ops/demography.py:95-172, in the reference's order of
+// operations): dNdt = R(1-N/K)N clipped to >= -Nmax, NaN/inf -> -Nmax;
+// N_b = b*lambda*n_pairs; N_d = N_b - dNdt; d = N_d/N, NaN -> 0, clip.
+__device__ __forceinline__ double d_at_cell(const DemP& P, double N, double npairs, double K,
+                                            double nmax) {
+  double dNdt = P.R * (1.0 - (N / K)) * N;
+  dNdt = fmax(dNdt, -nmax);                    // np.clip(a_min=-N.max()); NaN propagates
+  if (isnan(dNdt) || isinf(dNdt)) dNdt = -nmax;
+  double N_b = P.b * P.lam * npairs;
+  double N_d = N_b - dNdt;
+  double d = N_d / N;
+  if (isnan(d)) d = 0.0;
+  return fmin(fmax(d, P.d_min), P.d_max);
+}
+
+__device__ __forceinline__ double clip_fmax_nan(double v, double lo) {
+  // np.clip propagates NaN; fmax would drop it
+  return isnan(v) ? v : fmax(v, lo);
+}
+
+__global__ void k_raster(int which, SplineC SN, SplineC SP, DemP P, const float* rast,
+                         const unsigned long long* nmax_bits, double* out) {
+  int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= (int64_t)P.W * P.H) return;
+  int cy = (int)(c / P.W), cx = (int)(c - (int64_t)cy * P.W);
+  double px = cx + 0.5, py = cy + 0.5;
+  double K = (double)rast[((int64_t)P.K_layer * P.H + cy) * P.W + cx] * P.K_factor;
+  if (which == GNX_R_K) {
+    out[c] = K;
+    return;
+  }
+  double N = fmax(spline_eval(SN, px, py), 0.0);
+  if (which == GNX_R_N) {
+    out[c] = N;
+    return;
+  }
+  double np_ = P.have_pairs ? fmax(spline_eval(SP, px, py), 0.0) : 0.0;
+  if (which == GNX_R_NPAIRS) {
+    out[c] = np_;
+    return;
+  }
+  double nmax = __longlong_as_double((long long)*nmax_bits);
+  out[c] = d_at_cell(P, N, np_, K, nmax);
+}
+
+static DemP make_demp(const gnx_state* h) {
+  DemP P;
+  P.R = h->sp.R;
+  P.b = h->sp.b;
+  P.lam = h->sp.n_births_lambda;
+  P.d_min = h->sp.d_min;
+  P.d_max = h->sp.d_max;
+  P.K_factor = h->sp.K_factor;
+  P.K_layer = h->sp.K_layer;
+  P.W = h->cfg.W;
+  P.H = h->cfg.H;
+  P.have_pairs = h->spl_P.valid ? 1 : 0;
+  return P;
+}
+
+int gnx_l_raster(gnx_state* h, int which, double* d_out) {
+  if (which != GNX_R_K && !h->spl_N.valid) {
+    gnx_set_error("density rasters are available after the first pop_dynamics call");
+    return 3;
+  }
+  SplineC SN = make_splinec(h, h->spl_N), SP = make_splinec(h, h->spl_P);
+  int64_t cells = (int64_t)h->cfg.W * h->cfg.H;
+  hipLaunchKernelGGL(k_raster, dim3(gnx_grid(cells, 256)), dim3(256), 0, h->stream, which, SN, SP,
+                     make_demp(h), h->rast, h->nmax_bits, d_out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- death probabilities
+struct DeathP {
+  int64_t N, cap;
+  int n_layers, with_selection, max_age, n_delet, W64;
+};
+
+// ops/demography.py:305-321 + ops/selection.py:51-125: d at the individual's
+// cell; w = clip(prod_t 1 - phi_t |e^(not univ_adv) - z_t|^gamma_t, >= 0.001)
+// x prod_del (1 - s_l (g_l0 + g_l1)); p = 1 - (1 - d) w; age > max_age => 1.
+__global__ void __launch_bounds__(256)
+k_death_probs(DeathP Q, DemP P, SplineC SN, SplineC SP, GnxSoA s, const float* rast,
+              GnxTraitTab T, const int32_t* delet_loci, const double* delet_s,
+              const unsigned long long* G, const unsigned long long* nmax_bits, double* p_death,
+              double* d_cell) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Q.N) return;
+  int cx = (int)s.x[i], cy = (int)s.y[i];
+  double px = cx + 0.5, py = cy + 0.5;
+  double K = (double)rast[((int64_t)P.K_layer * P.H + cy) * P.W + cx] * P.K_factor;
+  double N = fmax(spline_eval(SN, px, py), 0.0);
+  double np_ = P.have_pairs ? fmax(spline_eval(SP, px, py), 0.0) : 0.0;
+  double nmax = __longlong_as_double((long long)*nmax_bits);
+  double d = d_at_cell(P, N, np_, K, nmax);
+  d_cell[i] = d;
+  double p = d;
+  if (Q.with_selection) {
+    double w = 1.0;
+    if (T.n_traits > 0) {
+      for (int t = 0; t < T.n_traits; ++t) {
+        double e = (double)s.e[(int64_t)T.layer[t] * Q.cap + i];
+        if (T.univ_adv[t]) e = 1.0;                    // e ** 0
+        double z = (double)s.z[(int64_t)t * Q.cap + i];
+        double phi = T.phi_rast[t] ? (double)T.phi_rast[t][(int64_t)cy * P.W + cx] : T.phi[t];
+        w *= 1.0 - phi * pow(fabs(e - z), T.gamma[t]);
+      }
+      w = fmax(w, 0.001);
+    }
+    if (Q.n_delet > 0) {
+      const unsigned long long* r0 = G + (int64_t)s.grow[i] * 2 * Q.W64;
+      const unsigned long long* r1 = r0 + Q.W64;
+      for (int k = 0; k < Q.n_delet; ++k) {
+        int l = delet_loci[k];
+        int cnt = (int)((r0[l >> 6] >> (l & 63)) & 1ull) + (int)((r1[l >> 6] >> (l & 63)) & 1ull);
+        w *= 1.0 - (double)cnt * delet_s[k];
+      }
+    }
+    s.fit[i] = (float)w;
+    p = 1.0 - (1.0 - d) * w;
+  }
+  if (Q.max_age >= 0 && s.age[i] > Q.max_age) p = 1.0;
+  p_death[i] = p;
+}
+
+int gnx_l_death_probs(gnx_state* h, bool with_selection) {
+  int64_t N = h->N;
+  if (N == 0) return 0;
+  SplineC SN = make_splinec(h, h->spl_N), SP = make_splinec(h, h->spl_P);
+  int64_t cells = (int64_t)h->cfg.W * h->cfg.H;
+  gnx_time_begin(h);
+  HIPCHK(hipMemsetAsync(h->nmax_bits, 0, sizeof(unsigned long long), h->stream));
+  hipLaunchKernelGGL(k_nmax, dim3(gnx_grid(cells, 256, 2048)), dim3(256), 0, h->stream, SN,
+                     h->cfg.W, h->cfg.H, h->nmax_bits);
+  DeathP Q;
+  Q.N = N;
+  Q.cap = h->cfg.cap_inds;
+  Q.n_layers = h->cfg.n_layers;
+  Q.with_selection = with_selection ? 1 : 0;
+  Q.max_age = h->sp.max_age;
+  Q.n_delet = with_selection ? h->n_delet : 0;
+  Q.W64 = h->W64;
+  hipLaunchKernelGGL(k_death_probs, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, Q,
+                     make_demp(h), SN, SP, h->soa[h->cur], h->rast, gnx_trait_tab(h),
+                     h->delet_loci, h->delet_s, (const unsigned long long*)h->G, h->nmax_bits,
+                     h->p_death, h->d_cell);
+  gnx_time_end(h, GNX_K_DEATH, (double)N * (28.0 + 8.0 * h->cfg.n_traits));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- mortality + compaction
+// _do_mortality (ops/demography.py:175-180): dead ~ Bernoulli(p_death).
+__global__ void k_alive(int64_t N, const double* p_death, const uint8_t* dead_in,
+                        const int64_t* id, long long step, unsigned long long seed,
+                        int32_t* alive) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  bool dead;
+  if (dead_in) {
+    dead = dead_in[i] != 0;
+  } else {
+    uint4 r = gnx_rand4(seed, (unsigned long long)id[i], step, OP_DEATH, 0);
+    dead = (double)gnx_u01(r.x) < p_death[i];
+  }
+  alive[i] = dead ? 0 : 1;
+}
+
+// Stable compaction of the SoA (survivors keep their relative order); genome
+// rows are NOT moved: the dead's rows are pushed on the free stack.
+__global__ void k_compact(int64_t N, int64_t cap, const int32_t* alive, const int32_t* scan,
+                          GnxSoA a, GnxSoA b, int n_layers, int n_traits, int32_t* free_rows,
+                          int64_t n_free, int has_rows) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int64_t k = scan[i];              // survivors before i
+  if (alive[i]) {
+    b.x[k] = a.x[i];
+    b.y[k] = a.y[i];
+    b.age[k] = a.age[i];
+    b.sex[k] = a.sex[i];
+    b.id[k] = a.id[i];
+    b.fit[k] = a.fit[i];
+    b.grow[k] = a.grow[i];
+    for (int l = 0; l < n_layers; ++l) b.e[(int64_t)l * cap + k] = a.e[(int64_t)l * cap + i];
+    for (int t = 0; t < n_traits; ++t) b.z[(int64_t)t * cap + k] = a.z[(int64_t)t * cap + i];
+  } else if (has_rows) {
+    int64_t dead_rank = i - k;
+    free_rows[n_free + dead_rank] = a.grow[i];
+  }
+}
+
+int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_out) {
+  int64_t N = h->N;
+  *deaths_out = 0;
+  if (N == 0) return 0;
+  const gnx_config& c = h->cfg;
+  GnxSoA a = h->soa[h->cur], b = h->soa[h->cur ^ 1];
+  gnx_time_begin(h);
+  hipLaunchKernelGGL(k_alive, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, h->p_death,
+                     d_dead_inject, a.id, h->step, c.seed, h->flag);
+  HIPCHK(hipMemsetAsync(h->flag + N, 0, sizeof(int32_t), h->stream));
+  GNXCHK(gnx_prim_scan(h->scan_tmp, h->scan_tmp_bytes, h->flag, h->scan, (size_t)N + 1,
+                       h->stream));
+  int has_rows = (h->genomes_assigned && c.L > 0) ? 1 : 0;
+  hipLaunchKernelGGL(k_compact, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, c.cap_inds,
+                     h->flag, h->scan, a, b, c.n_layers, c.n_traits, h->free_rows, h->n_free,
+                     has_rows);
+  HIPCHK(hipMemcpyAsync(h->h_pin, h->scan + N, sizeof(int32_t), hipMemcpyDeviceToHost,
+                        h->stream));
+  gnx_time_end(h, GNX_K_COMPACT, (double)N * (16.0 + 2.0 * (33.0 + 4.0 * c.n_layers +
+                                                             4.0 * c.n_traits)));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  int64_t survivors = *(int32_t*)h->h_pin;
+  int64_t deaths = N - survivors;
+  if (has_rows) h->n_free += deaths;
+  h->N = survivors;
+  h->cur ^= 1;
+  *deaths_out = deaths;
+  return 0;
+}
+
+// ---------------------------------------------------------------- burn-in spatial tester
+// SpatialTester.update (sim/burnin.py:44-59): per-cell counts, diff to the
+// previous counts, mean and std (population std, np.std) of the diff raster.
+__global__ void k_cell_counts(int64_t N, const float* x, const float* y, int W, int32_t* counts) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  atomicAdd(&counts[(int64_t)((int)y[i]) * W + (int)x[i]], 1);
+}
+
+__global__ void __launch_bounds__(256)
+k_diff_stats(int64_t cells, const int32_t* now, const int32_t* prev, double* red) {
+  __shared__ double s1[256], s2[256];
+  double a = 0.0, b = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += stride) {
+    double d = (double)(now[c] - prev[c]);
+    a += d;
+    b += d * d;
+  }
+  s1[threadIdx.x] = a;
+  s2[threadIdx.x] = b;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      s1[threadIdx.x] += s1[threadIdx.x + s];
+      s2[threadIdx.x] += s2[threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    atomicAdd(&red[0], s1[0]);
+    atomicAdd(&red[1], s2[0]);
+  }
+}
+
+int gnx_l_spatial_diff(gnx_state* h, double* mean, double* sd) {
+  int64_t cells = (int64_t)h->cfg.W * h->cfg.H;
+  int nowi = h->counts_cur ^ 1, prev = h->counts_cur;
+  if (!h->counts_init) {
+    HIPCHK(hipMemsetAsync(h->counts_rast[prev], 0, cells * sizeof(int32_t), h->stream));
+    h->counts_init = true;
+  }
+  HIPCHK(hipMemsetAsync(h->counts_rast[nowi], 0, cells * sizeof(int32_t), h->stream));
+  HIPCHK(hipMemsetAsync(h->red, 0, 2 * sizeof(double), h->stream));
+  if (h->N > 0)
+    hipLaunchKernelGGL(k_cell_counts, dim3(gnx_grid(h->N, 256)), dim3(256), 0, h->stream, h->N,
+                       h->soa[h->cur].x, h->soa[h->cur].y, h->cfg.W, h->counts_rast[nowi]);
+  hipLaunchKernelGGL(k_diff_stats, dim3(gnx_grid(cells, 256, 1024)), dim3(256), 0, h->stream, cells,
+                     h->counts_rast[nowi], h->counts_rast[prev], h->red);
+  double r[2];
+  HIPCHK(hipMemcpyAsync(r, h->red, sizeof(r), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  double m = r[0] / (double)cells;
+  double var = r[1] / (double)cells - m * m;
+  *mean = m;
+  *sd = var > 0 ? sqrt(var) : 0.0;
+  h->counts_cur = nowi;
+  return 0;
+}

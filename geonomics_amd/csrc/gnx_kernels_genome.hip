@@ -1,0 +1,255 @@
+// Genome kernels: bitmask crossover (the dominant byte mover of the step),
+// phenotype at birth, starting genomes, point mutations, genome gathers.
+//
+// Genome layout in HBM: G[row][hom][W64] u64, little-endian bits, bit l of
+// homologue h == Individual.g[l, h] (structs/individual.py:103-104).  W64 is
+// padded to a multiple of 16 words so every homologue starts on a 128-byte line
+// and splits into whole 16-byte chunks.  Individuals reference rows through
+// GnxSoA.grow; survivors' rows are never moved.
+#include "gnx_internal.h"
+#include "gnx_rng.h"
+
+typedef unsigned long long u64;
+
+struct alignas(16) u64x2 {
+  u64 a, b;
+};
+
+// ---------------------------------------------------------------- crossover
+// ops/mating.py:130-214.  For gamete p in {0,1} of an offspring:
+//   gamete[l] = parent_p.g[l, path_{k_p}[l] XOR s_p]
+// i.e. with m = path ^ (-s):  gamete = (hom0 & ~m) | (hom1 & m), 128 bits per
+// lane per iteration.  child hom 0 <- parent pair[0], hom 1 <- pair[1] (:169).
+//
+// One work item = one 16-byte chunk of one gamete; a thread owns UNROLL chunks
+// spaced one block apart so 3*UNROLL independent 16-byte loads are in flight.
+//
+// DENSE : masks are read from the bit-packed path table (any recombination map).
+// SPARSE: masks are rebuilt from the path's short breakpoint list (<= 24
+//         switches); a chunk whose mask is all 0 / all 1 loads only the one
+//         homologue it copies, which halves the read traffic when crossovers
+//         are rare (r = 1/L).
+template <bool SPARSE>
+__global__ void __launch_bounds__(256)
+k_crossover(int64_t B, int W16, const u64x2* __restrict__ G, u64x2* __restrict__ Gout,
+            const int32_t* __restrict__ grow, int64_t first_slot,
+            const int32_t* __restrict__ off_parent, const int32_t* __restrict__ off_keys,
+            const uint8_t* __restrict__ off_start, const u64x2* __restrict__ paths,
+            const int32_t* __restrict__ bp_off, const int32_t* __restrict__ bp_loci) {
+  const int64_t total = B * 2 * (int64_t)W16;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+    const int64_t gam = g / W16;
+    const int c = (int)(g - gam * W16);
+    const int64_t k = gam >> 1;
+    const int p = (int)(gam & 1);
+    const int prow = grow[off_parent[2 * k + p]];
+    const int key = off_keys[2 * k + p];
+    const u64 s = off_start[2 * k + p] ? ~0ull : 0ull;
+    const int crow = grow[first_slot + k];
+    const u64x2* h0 = G + ((int64_t)prow * 2 + 0) * W16;
+    const u64x2* h1 = G + ((int64_t)prow * 2 + 1) * W16;
+    u64x2 m;
+    if (SPARSE) {
+      // mask bits of loci [128c, 128c+128): parity of switches at or before l
+      const int lo = c * 128;
+      u64 par = 0;
+      m.a = 0;
+      m.b = 0;
+      for (int q = bp_off[key]; q < bp_off[key + 1]; ++q) {
+        const int bpl = bp_loci[q];
+        if (bpl < lo) {
+          par ^= ~0ull;
+        } else if (bpl < lo + 64) {
+          m.a ^= ~0ull << (bpl - lo);
+          m.b ^= ~0ull;
+        } else if (bpl < lo + 128) {
+          m.b ^= ~0ull << (bpl - lo - 64);
+        } else {
+          break;     // loci ascending
+        }
+      }
+      m.a ^= par ^ s;
+      m.b ^= par ^ s;
+    } else {
+      m = paths[(int64_t)key * W16 + c];
+      m.a ^= s;
+      m.b ^= s;
+    }
+    u64x2 out;
+    if (SPARSE && (m.a | m.b) == 0ull) {
+      out = h0[c];
+    } else if (SPARSE && (m.a & m.b) == ~0ull) {
+      out = h1[c];
+    } else {
+      const u64x2 a = h0[c];
+      const u64x2 b = h1[c];
+      out.a = (a.a & ~m.a) | (b.a & m.a);
+      out.b = (a.b & ~m.b) | (b.b & m.b);
+    }
+    Gout[((int64_t)crow * 2 + p) * W16 + c] = out;
+  }
+}
+
+int gnx_l_crossover(gnx_state* h, int64_t first_slot, int64_t B) {
+  if (B == 0) return 0;
+  const int W16 = h->W64 / 2;
+  const int64_t total = B * 2 * (int64_t)W16;
+  // enough blocks to fill 256 CUs x 8 waves/SIMD, grid-stride beyond that
+  int grid = gnx_grid(total, 256, 256 * 64);
+  GnxSoA s = h->soa[h->cur];
+  gnx_time_begin(h);
+  if (h->sparse_paths)
+    hipLaunchKernelGGL(k_crossover<true>, dim3(grid), dim3(256), 0, h->stream, B, W16,
+                       (const u64x2*)h->G, (u64x2*)h->G, s.grow, first_slot, h->off_parent,
+                       h->off_keys, h->off_start, (const u64x2*)h->paths, h->bp_off, h->bp_loci);
+  else
+    hipLaunchKernelGGL(k_crossover<false>, dim3(grid), dim3(256), 0, h->stream, B, W16,
+                       (const u64x2*)h->G, (u64x2*)h->G, s.grow, first_slot, h->off_parent,
+                       h->off_keys, h->off_start, (const u64x2*)h->paths, h->bp_off, h->bp_loci);
+  // algorithmic bytes per birth: 4 parental homologues + 2 masks
+  // read, 2 homologues written = 8 * L/8 = L bytes (padded row width used here)
+  gnx_time_end(h, GNX_K_CROSSOVER, (double)B * 8.0 * (double)h->W64 * 8.0);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- phenotype
+// ops/selection.py:22-48: gt_l = (g[l,0] + g[l,1]) / 2 at the trait's loci
+// (x (1 + dom_l), capped at 1, if any dominance); z = 0.5 + sum gt_l alpha_l for
+// polygenic traits, z = gt_0 for monogenic ones.  f64 accumulate, f32 store.
+__global__ void k_phenotype(int64_t first, int64_t n, int64_t cap, int W64, const u64* G,
+                            const int32_t* grow, GnxTraitTab T, const uint8_t* dom, float* z) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  int64_t slot = first + k;
+  const u64* r0 = G + (int64_t)grow[slot] * 2 * W64;
+  const u64* r1 = r0 + W64;
+  for (int t = 0; t < T.n_traits; ++t) {
+    const int nl = T.n_loci[t];
+    double acc = 0.0, g0 = 0.0;
+    for (int j = 0; j < nl; ++j) {
+      int l = T.loci[t][j];
+      int a = (int)((r0[l >> 6] >> (l & 63)) & 1ull);
+      int b = (int)((r1[l >> 6] >> (l & 63)) & 1ull);
+      double gt = 0.5 * (double)(a + b);
+      if (dom) gt = fmin(gt * (1.0 + (double)dom[l]), 1.0);
+      if (j == 0) g0 = gt;
+      acc = acc + gt * T.alpha[t][j];
+    }
+    z[(int64_t)t * cap + slot] = (float)(nl > 1 ? 0.5 + acc : g0);
+  }
+}
+
+int gnx_l_phenotype(gnx_state* h, int64_t first_slot, int64_t n) {
+  if (n == 0 || h->cfg.n_traits == 0) return 0;
+  GnxSoA s = h->soa[h->cur];
+  gnx_time_begin(h);
+  hipLaunchKernelGGL(k_phenotype, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, first_slot, n,
+                     h->cfg.cap_inds, h->W64, (const u64*)h->G, s.grow, gnx_trait_tab(h), h->dom,
+                     s.z);
+  gnx_time_end(h, GNX_K_PHENOTYPE, (double)n * 4.0 * h->cfg.n_traits);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- starting genomes
+// _make_starting_mutations (structs/genome.py:1108-1157): per site exactly
+// n_l of the 2N homologues carry a 1.  Selection sampling (Knuth 3.4.2 S) over
+// homologue index q = 2*ind + hom: take iff (u_q * (2N - q)) >> 32 < n_l - taken.
+// One lane per site, one wavefront per 64-site word: __ballot of the 64 lanes'
+// decisions IS the u64 genome word (row of individual q/2, homologue q%2).
+__global__ void __launch_bounds__(256)
+k_assign_genomes(int64_t N, int L, int W64, u64* G, const int32_t* grow,
+                 const int32_t* n_per_site, unsigned long long site_seed) {
+  const int lane = threadIdx.x & 63;
+  const int64_t word = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (word >= W64) return;          // uniform per wave
+  const int64_t site = word * 64 + lane;
+  const bool live = site < L;
+  int remaining = live ? n_per_site[site] : 0;
+  const int64_t twoN = 2 * N;
+  for (int64_t q = 0; q < twoN; ++q) {
+    bool take = false;
+    if (remaining > 0) {
+      unsigned int u = gnx_site_hash(site_seed, (u64)site, (u64)q);
+      take = (int64_t)(((u64)u * (u64)(twoN - q)) >> 32) < (int64_t)remaining;
+    }
+    remaining -= take ? 1 : 0;
+    u64 w = __ballot(take);
+    if (lane == 0) G[((int64_t)grow[q >> 1] * 2 + (q & 1)) * W64 + word] = w;
+  }
+}
+
+__global__ void k_assign_rows(int64_t N, int64_t cap_rows, int32_t* grow, int32_t* free_rows) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) grow[i] = (int32_t)i;
+  // free stack: rows N..cap_rows-1, popped from the top (highest index first)
+  if (i < cap_rows - N) free_rows[i] = (int32_t)(cap_rows - 1 - i);
+}
+
+int gnx_l_assign_genomes(gnx_state* h, const int32_t* d_n_per_site) {
+  const gnx_config& c = h->cfg;
+  int64_t N = h->N;
+  if (N > c.cap_rows) {
+    gnx_set_error("cap_rows %lld < N %lld", (long long)c.cap_rows, (long long)N);
+    return 2;
+  }
+  GnxSoA s = h->soa[h->cur];
+  int64_t m = N > c.cap_rows - N ? N : c.cap_rows - N;
+  hipLaunchKernelGGL(k_assign_rows, dim3(gnx_grid(m, 256)), dim3(256), 0, h->stream, N, c.cap_rows,
+                     s.grow, h->free_rows);
+  h->n_free = c.cap_rows - N;
+  if (N > 0 && d_n_per_site) {
+    int64_t threads = (int64_t)h->W64 * 64;
+    hipLaunchKernelGGL(k_assign_genomes, dim3(gnx_grid(threads, 256)), dim3(256), 0, h->stream, N,
+                       c.L, h->W64, (u64*)h->G, s.grow, d_n_per_site, gnx_site_seed(c.seed));
+  }
+  HIPCHK(hipGetLastError());
+  h->genomes_assigned = true;
+  return 0;
+}
+
+// ---------------------------------------------------------------- mutation
+// ops/mutation.py:62-131: set allele 1 at (locus, homologue) of the chosen
+// offspring.
+__global__ void k_mutate(int n, int W64, u64* G, const int32_t* grow, const int64_t* slot,
+                         const int32_t* locus, const uint8_t* hom) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int l = locus[i];
+  u64* w = G + ((int64_t)grow[slot[i]] * 2 + hom[i]) * W64 + (l >> 6);
+  atomicOr(w, 1ull << (l & 63));
+}
+
+int gnx_l_mutate(gnx_state* h, int n, const int64_t* d_slot, const int32_t* d_locus,
+                 const uint8_t* d_hom) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_mutate, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, n, h->W64,
+                     (u64*)h->G, h->soa[h->cur].grow, d_slot, d_locus, d_hom);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- genome gather
+__global__ void k_gather_genomes(int64_t n, int W16, const u64x2* G, const int32_t* grow,
+                                 const int64_t* slots, u64x2* out) {
+  const int64_t total = n * 2 * (int64_t)W16;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+    int64_t k = g / (2 * W16);
+    int64_t c = g - k * 2 * W16;
+    int64_t slot = slots ? slots[k] : k;
+    out[g] = G[(int64_t)grow[slot] * 2 * W16 + c];
+  }
+}
+
+int gnx_l_gather_genomes(gnx_state* h, int64_t n, const int64_t* d_slots, uint64_t* d_out) {
+  if (n == 0) return 0;
+  const int W16 = h->W64 / 2;
+  hipLaunchKernelGGL(k_gather_genomes, dim3(gnx_grid(n * 2 * W16, 256, 256 * 32)), dim3(256), 0,
+                     h->stream, n, W16, (const u64x2*)h->G, h->soa[h->cur].grow, d_slots,
+                     (u64x2*)d_out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,809 @@
+// Population kernels: initial placement, ageing, movement (+ environment
+// gather), spatial sort, mate search over a cell list, pair filtering and
+// offspring records.  gfx950 only (64-wide wavefronts are assumed).
+#include "gnx_internal.h"
+#include "gnx_rng.h"
+
+// ---------------------------------------------------------------- helpers
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m));
+  return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m));
+  return v;
+}
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ long long readlane_ll(long long v, int lane) {
+  int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), lane);
+  int hi = __builtin_amdgcn_readlane((int)(v >> 32), lane);
+  return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+// ---------------------------------------------------------------- init
+// _make_individual (structs/individual.py:213-219): x,y ~ U(0,dim), clipped to
+// dim-0.001; sex ~ Bernoulli(0.5); age 0; ids 0..N-1.
+__global__ void k_init_population(int64_t N, GnxSoA s, int cap, float Wf, float Hf, float xmax,
+                                  float ymax, unsigned long long seed) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  uint4 r = gnx_rand4(seed, (unsigned long long)i, 0, OP_INIT, 0);
+  float x = fminf(gnx_u01(r.x) * Wf, xmax);
+  float y = fminf(gnx_u01(r.y) * Hf, ymax);
+  s.x[i] = x;
+  s.y[i] = y;
+  s.age[i] = 0;
+  s.sex[i] = gnx_u01(r.z) < 0.5f ? 1 : 0;
+  s.id[i] = i;
+  s.fit[i] = 1.0f;
+  s.grow[i] = -1;
+}
+
+__global__ void k_gather_e(int64_t first, int64_t n, GnxSoA s, int64_t cap, const float* rast,
+                           int n_layers, int W, int H) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  int64_t i = first + k;
+  int cx = (int)s.x[i], cy = (int)s.y[i];
+  for (int l = 0; l < n_layers; ++l)
+    s.e[(int64_t)l * cap + i] = rast[((int64_t)l * H + cy) * W + cx];
+}
+
+int gnx_l_gather_e(gnx_state* h, int64_t first, int64_t n) {
+  if (n == 0) return 0;
+  const gnx_config& c = h->cfg;
+  hipLaunchKernelGGL(k_gather_e, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, first, n,
+                     h->soa[h->cur], c.cap_inds, h->rast, c.n_layers, c.W, c.H);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int gnx_l_init_population(gnx_state* h, int64_t N) {
+  const gnx_config& c = h->cfg;
+  GnxSoA s = h->soa[h->cur];
+  float xmax = (float)(c.W - 0.001), ymax = (float)(c.H - 0.001);
+  hipLaunchKernelGGL(k_init_population, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, s,
+                     (int)c.cap_inds, (float)c.W, (float)c.H, xmax, ymax, c.seed);
+  hipLaunchKernelGGL(k_gather_e, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, (int64_t)0, N, s,
+                     c.cap_inds, h->rast, c.n_layers, c.W, c.H);
+  HIPCHK(hipGetLastError());
+  h->N = N;
+  h->max_id = N - 1;
+  return 0;
+}
+
+// ---------------------------------------------------------------- age
+__global__ void k_age(int64_t N, int32_t* age) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) age[i] += 1;
+}
+
+int gnx_l_age(gnx_state* h) {
+  if (h->N == 0) return 0;
+  hipLaunchKernelGGL(k_age, dim3(gnx_grid(h->N, 256)), dim3(256), 0, h->stream, h->N,
+                     h->soa[h->cur].age);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- movement
+struct MoveP {
+  int64_t N, cap;
+  int W, H, n_layers;
+  float xmax, ymax;          // dim - 0.001 (ops/movement.py:90-92)
+  float rrx, rry;            // Landscape._res_ratio
+  int distr;
+  float p1, p2, mu, kappa;
+  int surf, surf_layer;
+  float surf_kappa;
+  int inc_age, apply;
+  long long step;
+  unsigned long long seed;
+};
+
+__constant__ float c_queen_dirs[8] = {-2.35619449019234492885f, -1.57079632679489661923f,
+                                      -0.78539816339744830962f, 3.14159265358979323846f,
+                                      0.0f, 2.35619449019234492885f,
+                                      1.57079632679489661923f, 0.78539816339744830962f};
+__constant__ int c_queen_dy[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+__constant__ int c_queen_dx[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
+
+// direction from a conductance surface, sampled on the fly from the generating
+// process of the reference's per-cell LUT (utils/spatial.py:365-461): 8 queen
+// neighbours on the zero-embedded raster, weights = value / sum (1/8 each if the
+// sum is 0); mixture: pick a bearing ~ weights then von Mises(kappa) about it;
+// unimodal: von Mises about the arithmetic mean of the arg-max bearings.
+__device__ __forceinline__ float surf_direction(const float* rast, int W, int H, int cx, int cy,
+                                                int mode, float kappa, GnxStream& s) {
+  float n[8];
+  float sum = 0.f, mx = -1.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    int yy = cy + c_queen_dy[k], xx = cx + c_queen_dx[k];
+    float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? rast[(int64_t)yy * W + xx] : 0.f;
+    n[k] = v;
+    sum += v;
+    mx = fmaxf(mx, v);
+  }
+  float loc;
+  if (mode == GNX_SURF_MIXTURE) {
+    float u = gnx_u01(s.next());
+    int pick = 7;
+    if (sum > 0.f) {
+      float t = u * sum, c = 0.f;
+      pick = -1;
+      int last = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        c += n[k];
+        if (n[k] > 0.f) last = k;
+        if (pick < 0 && t < c) pick = k;
+      }
+      if (pick < 0) pick = last;
+    } else {
+      pick = min(7, (int)(u * 8.0f));
+    }
+    loc = c_queen_dirs[pick];
+  } else {
+    float acc = 0.f;
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (n[k] == mx) {
+        acc += c_queen_dirs[k];
+        cnt++;
+      }
+    loc = acc / (float)cnt;
+  }
+  return loc + gnx_vonmises(s, 0.0f, kappa);
+}
+
+// ops/movement.py:34-95 + Species._set_e (structs/species.py:913-922).
+// Optionally increments age first (Species._set_age_stage, :567-569).
+__global__ void __launch_bounds__(256)
+k_move(MoveP P, GnxSoA s, const float* rast, const float* inj_theta, const float* inj_dist,
+       float* out_theta, float* out_dist) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.N) return;
+  float x = s.x[i], y = s.y[i];
+  unsigned long long id = (unsigned long long)s.id[i];
+  float theta, dist;
+  if (inj_theta) {
+    theta = inj_theta[i];
+    dist = inj_dist[i];
+  } else {
+    if (P.surf != GNX_SURF_NONE) {
+      GnxStream st(P.seed, id, P.step, OP_MOVE_SURF);
+      theta = surf_direction(rast + (int64_t)P.surf_layer * P.H * P.W, P.W, P.H, (int)x, (int)y,
+                             P.surf, P.surf_kappa, st);
+    } else {
+      GnxStream st(P.seed, id, P.step, OP_MOVE_DIR);
+      theta = gnx_vonmises(st, P.mu, P.kappa);
+    }
+    dist = gnx_distance(P.distr, P.p1, P.p2, gnx_rand4(P.seed, id, P.step, OP_MOVE_DIST, 0));
+  }
+  if (out_theta) {
+    out_theta[i] = theta;
+    out_dist[i] = dist;
+  }
+  if (!P.apply) return;
+  float dx = cosf(theta) * dist;
+  float dy = sinf(theta) * dist;
+  if (P.rrx != 1.0f) dx *= P.rrx;
+  if (P.rry != 1.0f) dy *= P.rry;
+  float nx = fminf(fmaxf(x + dx, 0.0f), P.xmax);
+  float ny = fminf(fmaxf(y + dy, 0.0f), P.ymax);
+  s.x[i] = nx;
+  s.y[i] = ny;
+  if (P.inc_age) s.age[i] += 1;
+  int cx = (int)nx, cy = (int)ny;
+  for (int l = 0; l < P.n_layers; ++l)
+    s.e[(int64_t)l * P.cap + i] = rast[((int64_t)l * P.H + cy) * P.W + cx];
+}
+
+int gnx_l_move(gnx_state* h, bool inc_age, const float* inj_theta, const float* inj_dist,
+               float* out_theta, float* out_dist, bool apply) {
+  if (h->N == 0) return 0;
+  const gnx_config& c = h->cfg;
+  const gnx_species_params& sp = h->sp;
+  MoveP P;
+  P.N = h->N;
+  P.cap = c.cap_inds;
+  P.W = c.W;
+  P.H = c.H;
+  P.n_layers = c.n_layers;
+  P.xmax = (float)(c.W - 0.001);
+  P.ymax = (float)(c.H - 0.001);
+  P.rrx = (float)sp.res_ratio[0];
+  P.rry = (float)sp.res_ratio[1];
+  P.distr = sp.move_distr;
+  P.p1 = (float)sp.move_p1;
+  P.p2 = (float)sp.move_p2;
+  P.mu = (float)sp.dir_mu;
+  P.kappa = (float)sp.dir_kappa;
+  P.surf = sp.move_surf;
+  P.surf_layer = sp.move_surf_layer;
+  P.surf_kappa = (float)sp.move_surf_kappa;
+  P.inc_age = inc_age ? 1 : 0;
+  P.apply = apply ? 1 : 0;
+  P.step = h->step;
+  P.seed = c.seed;
+  gnx_time_begin(h);
+  hipLaunchKernelGGL(k_move, dim3(gnx_grid(h->N, 256)), dim3(256), 0, h->stream, P,
+                     h->soa[h->cur], h->rast, inj_theta, inj_dist, out_theta, out_dist);
+  // per individual: x,y rw 16 + id 8 + age rw 8 + e store 4*n_lyr + raster gathers 4*n_lyr
+  // (+36 for the 3x3 conductance neighbourhood)
+  gnx_time_end(h, GNX_K_MOVE,
+               (double)h->N * (32.0 + 8.0 * c.n_layers + (sp.move_surf ? 36.0 : 0.0)));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- spatial sort
+__global__ void k_keys(int64_t N, const float* x, const float* y, double inv_cs, int ncx, int ncy,
+                       uint32_t* key, int32_t* idx) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int cx = min(ncx - 1, (int)((double)x[i] * inv_cs));
+  int cy = min(ncy - 1, (int)((double)y[i] * inv_cs));
+  key[i] = (uint32_t)(cy * ncx + cx);
+  idx[i] = (int32_t)i;
+}
+
+__global__ void k_permute(int64_t N, int64_t cap, const int32_t* perm, GnxSoA a, GnxSoA b,
+                          int n_layers, int n_traits) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int64_t j = perm[i];
+  b.x[i] = a.x[j];
+  b.y[i] = a.y[j];
+  b.age[i] = a.age[j];
+  b.sex[i] = a.sex[j];
+  b.id[i] = a.id[j];
+  b.fit[i] = a.fit[j];
+  b.grow[i] = a.grow[j];
+  for (int l = 0; l < n_layers; ++l) b.e[(int64_t)l * cap + i] = a.e[(int64_t)l * cap + j];
+  for (int t = 0; t < n_traits; ++t) b.z[(int64_t)t * cap + i] = a.z[(int64_t)t * cap + j];
+}
+
+// cell_start[c] = first sorted slot whose key >= c; cell_start[ncells] = N
+__global__ void k_cell_bounds(int64_t N, const uint32_t* key, int32_t* cell_start, int ncells) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int k = (int)key[i];
+  int prev = (i == 0) ? -1 : (int)key[i - 1];
+  for (int c = prev + 1; c <= k; ++c) cell_start[c] = (int32_t)i;
+  if (i == N - 1)
+    for (int c = k + 1; c <= ncells; ++c) cell_start[c] = (int32_t)N;
+}
+
+// Stable sort of the whole SoA by hash cell (cell size >= mating radius).
+// Stability + deterministic inputs make slot order, hence offspring ids,
+// reproducible run to run.
+int gnx_l_sort_by_cell(gnx_state* h) {
+  int64_t N = h->N;
+  if (N == 0) return 0;
+  const gnx_config& c = h->cfg;
+  GnxSoA a = h->soa[h->cur], b = h->soa[h->cur ^ 1];
+  gnx_time_begin(h);
+  hipLaunchKernelGGL(k_keys, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, a.x, a.y,
+                     h->inv_cs, h->ncx, h->ncy, h->key[0], h->perm[0]);
+  GNXCHK(gnx_prim_sort(h->sort_tmp, h->sort_tmp_bytes, h->key[0], h->key[1], h->perm[0],
+                       h->perm[1], (size_t)N, h->key_bits, h->stream));
+  gnx_time_end(h, GNX_K_SORT, (double)N * 40.0);
+  gnx_time_begin(h);
+  hipLaunchKernelGGL(k_permute, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, c.cap_inds,
+                     h->perm[1], a, b, c.n_layers, c.n_traits);
+  hipLaunchKernelGGL(k_cell_bounds, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, h->key[1],
+                     h->cell_start, h->ncx * h->ncy);
+  gnx_time_end(h, GNX_K_PERMUTE,
+               (double)N * 2.0 * (33.0 + 4.0 * c.n_layers + 4.0 * c.n_traits));
+  HIPCHK(hipGetLastError());
+  h->cur ^= 1;
+  return 0;
+}
+
+// ---------------------------------------------------------------- mate search
+// Species._get_mating_pairs / _KDTree._get_mating_pairs (structs/species.py:
+// 2157-2215; utils/spatial.py:191-245) on a cell list instead of a KD-tree.
+//
+// One wavefront owns 64 consecutive cell-sorted focal individuals.  For every
+// cell row that any of its lanes neighbours, the candidates of cells
+// [min cx - 1, max cx + 1] form ONE contiguous range of the sorted arrays; the
+// wave loads it 64 candidates at a time (coalesced) and broadcasts each
+// candidate with v_readlane, so every lane tests the same candidate against its
+// own focal individual with no divergence.  Cells are >= mating_radius wide, so
+// every neighbour within the radius lies in the scanned ranges; extra
+// candidates simply fail the distance test (dx*dx + dy*dy <= r*r in f32, the
+// same expression the oracle evaluates).
+//
+// Mate choice is independent of candidate order: uniform = smallest
+// pair_hash(focal id, candidate id); nearest = smallest d2; inverse-distance =
+// smallest -ln(u)/(r-d).  Ties break on the smaller id.
+template <int MODE>
+__global__ void __launch_bounds__(256)
+k_find_mates(int64_t N, const float* __restrict__ x, const float* __restrict__ y,
+             const int64_t* __restrict__ id, const uint32_t* __restrict__ key,
+             const int32_t* __restrict__ cell_start, int ncx, int ncy, float r, float r2,
+             unsigned long long pair_seed, int32_t* __restrict__ mate) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t i = wave * 64 + lane;
+  const bool act = i < N;
+  float fx = 0.f, fy = 0.f;
+  long long fid = 0;
+  int cx = 0, cy = 0;
+  if (act) {
+    fx = x[i];
+    fy = y[i];
+    fid = id[i];
+    int k = (int)key[i];
+    cy = k / ncx;
+    cx = k - cy * ncx;
+  }
+  int cymin = __builtin_amdgcn_readfirstlane(wave_min_i(act ? cy : 0x7fffffff));
+  int cymax = __builtin_amdgcn_readfirstlane(wave_max_i(act ? cy : -0x7fffffff));
+  if (cymin > cymax) return;     // wave has no active lane (uniform)
+
+  unsigned long long best_h = ~0ull;
+  float best_f = 3.4e38f;
+  long long best_id = 0x7fffffffffffffffll;
+  int best_slot = -1;
+
+  const int ry0 = max(cymin - 1, 0), ry1 = min(cymax + 1, ncy - 1);
+  for (int ry = ry0; ry <= ry1; ++ry) {
+    bool near = act && (cy - ry <= 1) && (ry - cy <= 1);
+    int lo = __builtin_amdgcn_readfirstlane(wave_min_i(near ? cx - 1 : 0x7fffffff));
+    int hi = __builtin_amdgcn_readfirstlane(wave_max_i(near ? cx + 1 : -0x7fffffff));
+    if (lo > hi) continue;
+    lo = max(lo, 0);
+    hi = min(hi, ncx - 1);
+    const int s = cell_start[ry * ncx + lo];
+    const int e = cell_start[ry * ncx + hi + 1];
+    for (int base = s; base < e; base += 64) {
+      const int j = base + lane;
+      const bool v = j < e;
+      float ox_l = v ? x[j] : 0.f;
+      float oy_l = v ? y[j] : 0.f;
+      long long oid_l = v ? id[j] : 0;
+      const int cnt = min(64, e - base);
+      for (int t = 0; t < cnt; ++t) {
+        const float ox = readlane_f(ox_l, t);
+        const float oy = readlane_f(oy_l, t);
+        const long long oid = readlane_ll(oid_l, t);
+        const int oj = base + t;
+        const float dx = ox - fx, dy = oy - fy;
+        const float d2 = dx * dx + dy * dy;
+        if (near && d2 <= r2 && (int64_t)oj != i) {
+          if (MODE == GNX_MATE_UNIFORM) {
+            unsigned long long hsh = gnx_pair_hash(pair_seed, (unsigned long long)fid,
+                                                   (unsigned long long)oid);
+            if (hsh < best_h || (hsh == best_h && oid < best_id)) {
+              best_h = hsh;
+              best_id = oid;
+              best_slot = oj;
+            }
+          } else if (MODE == GNX_MATE_NEAREST) {
+            if (d2 < best_f || (d2 == best_f && oid < best_id)) {
+              best_f = d2;
+              best_id = oid;
+              best_slot = oj;
+            }
+          } else {
+            if (d2 > 0.f) {
+              unsigned long long hsh = gnx_pair_hash(pair_seed, (unsigned long long)fid,
+                                                     (unsigned long long)oid);
+              float u = gnx_u01((unsigned int)(hsh >> 32));
+              float kf = -logf(u) / (r - sqrtf(d2));
+              if (kf < best_f || (kf == best_f && oid < best_id)) {
+                best_f = kf;
+                best_id = oid;
+                best_slot = oj;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  if (act) mate[i] = best_slot;
+}
+
+// Bernoulli(b) thinning (structs/species.py:2210-2214), sex filter
+// (ops/mating.py:41-55), reproductive-age filter (:79-104).
+__global__ void k_pair_flags(int64_t N, const int32_t* focal, const int32_t* mate,
+                             const uint8_t* keep_in, GnxSoA s, float b, int sexed, int ra_f,
+                             int ra_m, long long step, unsigned long long seed, int32_t* flag) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int m = mate[i];
+  int f = 0;
+  if (m >= 0) {
+    const int fo = focal ? focal[i] : (int)i;
+    bool keep;
+    if (keep_in) {
+      keep = keep_in[i] != 0;
+    } else {
+      uint4 r = gnx_rand4(seed, (unsigned long long)s.id[i], step, OP_PAIR_KEEP, 0);
+      keep = gnx_u01(r.x) < b;
+    }
+    bool ok = keep;
+    if (sexed) ok = ok && (s.sex[fo] == 0) && (s.sex[m] == 1);
+    ok = ok && (s.age[fo] >= ra_f) && (s.age[m] >= ra_m);
+    f = ok ? 1 : 0;
+  }
+  flag[i] = f;
+}
+
+// unordered-pair de-duplication (ops/mating.py:62-65): the reference keeps one
+// of (i,m),(m,i); drop (i,m) iff (m,i) is also present and m < i.
+__global__ void k_pair_dedup(int64_t N, const int32_t* mate, const int32_t* flag, int sexed,
+                             int32_t* flag2) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int f = flag[i];
+  if (f && !sexed) {
+    int m = mate[i];
+    if (flag[m] && mate[m] == (int32_t)i && m < (int32_t)i) f = 0;
+  }
+  flag2[i] = f;
+}
+
+__global__ void k_pair_compact(int64_t N, const int32_t* focal, const int32_t* mate,
+                               const int32_t* flag2, const int32_t* scan, const float* x,
+                               const float* y, int32_t* pairs, float* mid_x, float* mid_y) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  if (flag2[i]) {
+    int p = scan[i];
+    int m = mate[i];
+    int fo = focal ? focal[i] : (int)i;
+    pairs[2 * p] = fo;
+    pairs[2 * p + 1] = m;
+    // pair midpoints for the n_pairs density (ops/demography.py:69-70)
+    mid_x[p] = (x[fo] + x[m]) / 2.0f;
+    mid_y[p] = (y[fo] + y[m]) / 2.0f;
+  }
+}
+
+// panmixia (structs/species.py:2178-2194): n ~ Binomial(N, b) pairs, both
+// members drawn uniformly with replacement, selfing pairs dropped, no
+// de-duplication (ops/mating.py:59-65).  Slot i stands for the i-th Bernoulli
+// trial of the binomial (kept w.p. b by k_pair_flags) and carries two draws.
+__global__ void k_panmixia(int64_t N, const int64_t* id, long long step, unsigned long long seed,
+                           int32_t* focal, int32_t* mate) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  uint4 r = gnx_rand4(seed, (unsigned long long)id[i], step, OP_PAIR_KEEP, 1);
+  int f = (int)(((unsigned long long)r.x * (unsigned long long)N) >> 32);
+  int m = (int)(((unsigned long long)r.y * (unsigned long long)N) >> 32);
+  focal[i] = f;
+  mate[i] = (m == f) ? -1 : m;
+}
+
+int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out) {
+  int64_t N = h->N;
+  *n_pairs_out = 0;
+  h->n_pairs = 0;
+  if (N == 0) return 0;
+  const gnx_species_params& sp = h->sp;
+  GnxSoA s = h->soa[h->cur];
+  unsigned long long pseed = gnx_pair_seed(h->cfg.seed, h->step);
+  int sexed = sp.sexed;
+  const int32_t* focal = nullptr;
+  gnx_time_begin(h);
+  if (sp.mating_radius < 0) {
+    focal = h->off_pair;   // scratch, free until births are expanded
+    hipLaunchKernelGGL(k_panmixia, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, s.id,
+                       h->step, h->cfg.seed, h->off_pair, h->mate);
+  } else {
+    float r = (float)sp.mating_radius;
+    float r2 = r * r;
+    dim3 grid(gnx_grid(N, 256)), blk(256);
+    if (sp.mate_mode == GNX_MATE_NEAREST)
+      hipLaunchKernelGGL(k_find_mates<GNX_MATE_NEAREST>, grid, blk, 0, h->stream, N, s.x, s.y, s.id,
+                         h->key[1], h->cell_start, h->ncx, h->ncy, r, r2, pseed, h->mate);
+    else if (sp.mate_mode == GNX_MATE_INVERSE)
+      hipLaunchKernelGGL(k_find_mates<GNX_MATE_INVERSE>, grid, blk, 0, h->stream, N, s.x, s.y, s.id,
+                         h->key[1], h->cell_start, h->ncx, h->ncy, r, r2, pseed, h->mate);
+    else
+      hipLaunchKernelGGL(k_find_mates<GNX_MATE_UNIFORM>, grid, blk, 0, h->stream, N, s.x, s.y, s.id,
+                         h->key[1], h->cell_start, h->ncx, h->ncy, r, r2, pseed, h->mate);
+  }
+  gnx_time_end(h, GNX_K_FIND_MATES, (double)N * 16.0);
+  gnx_time_begin(h);
+  int sexed_dedup = sexed || (sp.mating_radius < 0);   // no dedup for sexed / panmictic
+  hipLaunchKernelGGL(k_pair_flags, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, focal, h->mate,
+                     d_keep, s, (float)sp.b, sexed, sp.repro_age[0], sp.repro_age[1], h->step,
+                     h->cfg.seed, h->flag);
+  hipLaunchKernelGGL(k_pair_dedup, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, h->mate,
+                     h->flag, sexed_dedup, h->flag2);
+  // scan over N+1 so that scan[N] = number of pairs
+  HIPCHK(hipMemsetAsync(h->flag2 + N, 0, sizeof(int32_t), h->stream));
+  GNXCHK(gnx_prim_scan(h->scan_tmp, h->scan_tmp_bytes, h->flag2, h->scan, (size_t)N + 1,
+                       h->stream));
+  hipLaunchKernelGGL(k_pair_compact, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, focal,
+                     h->mate, h->flag2, h->scan, s.x, s.y, h->pairs, h->mid_x, h->mid_y);
+  HIPCHK(hipMemcpyAsync(h->h_pin, h->scan + N, sizeof(int32_t), hipMemcpyDeviceToHost,
+                        h->stream));
+  gnx_time_end(h, GNX_K_PAIRS, (double)N * 40.0);
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->n_pairs = *(int32_t*)h->h_pin;
+  *n_pairs_out = h->n_pairs;
+  return 0;
+}
+
+// ---------------------------------------------------------------- births / offspring
+// Poisson by multiplication of uniforms (oracle: poisson_knuth), clipped to >= 1
+// (ops/mating.py:124-125); keyed by the focal parent's id.
+__global__ void k_births(int64_t P, const int32_t* pairs, const int64_t* id, float thr,
+                         long long step, unsigned long long seed, int32_t* nb) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  GnxStream st(seed, (unsigned long long)id[pairs[2 * p]], step, OP_BIRTHS);
+  int k = 0;
+  float prod = 1.0f;
+  for (int j = 0; j < 64; ++j) {
+    prod = prod * gnx_u01(st.next());
+    if (!(prod > thr)) break;
+    k++;
+  }
+  nb[p] = max(k, 1);
+}
+
+__global__ void k_expand_births(int64_t P, const int32_t* nb, const int32_t* boff,
+                                int32_t* off_pair) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  int o = boff[p];
+  for (int q = 0; q < nb[p]; ++q) off_pair[o + q] = (int32_t)p;
+}
+
+struct OffP {
+  int64_t N, B, cap;
+  int W, H, n_layers;
+  float xmax, ymax, rrx, rry;
+  int distr;
+  float p1, p2;
+  int surf, surf_layer;
+  float surf_kappa;
+  int sexed;
+  float p_male;
+  int fixed_nb;          // > 0: every pair has this many births
+  int genomes;           // allocate genome rows + draw keys
+  int inject_keys;       // keys/start homologues already in off_keys/off_start
+  int n_paths;
+  int64_t max_id, n_free;
+  long long step;
+  unsigned long long seed;
+};
+
+// one dispersal attempt (ops/movement.py:98-141): returns true when accepted
+__device__ __forceinline__ bool disperse_once(float mx, float my, float theta, float dist,
+                                              float rrx, float rry, float xmax, float ymax,
+                                              float& ox, float& oy) {
+  float dx = cosf(theta) * dist;
+  float dy = sinf(theta) * dist;
+  if (rrx != 1.0f) dx *= rrx;
+  if (rry != 1.0f) dy *= rry;
+  ox = fminf(fmaxf(mx + dx, 0.0f), xmax);
+  oy = fminf(fmaxf(my + dy, 0.0f), ymax);
+  // after clipping the only way to fail 0 < x < dim is x == 0
+  return ox > 0.0f && oy > 0.0f;
+}
+
+// Offspring records (structs/species.py:613-688): ids max_id+1.. in (pair,
+// birth) order, parents' midpoint, dispersal, age 0, sex, environment, genome
+// row, recombination keys and start homologues.
+__global__ void __launch_bounds__(256)
+k_offspring(OffP P, GnxSoA s, const float* rast, const int32_t* pairs, const int32_t* off_pair,
+            const int32_t* free_rows, int32_t* off_parent, int32_t* off_keys, uint8_t* off_start) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= P.B) return;
+  int64_t p = P.fixed_nb > 0 ? k / P.fixed_nb : off_pair[k];
+  int i = pairs[2 * p], m = pairs[2 * p + 1];
+  int64_t slot = P.N + k;
+  unsigned long long oid = (unsigned long long)(P.max_id + 1 + k);
+  float mx = (s.x[i] + s.x[m]) / 2.0f;
+  float my = (s.y[i] + s.y[m]) / 2.0f;
+  float ox = mx, oy = my;
+  for (int a = 0; a < GNX_DISP_ATTEMPTS; ++a) {
+    float theta = 0.f;
+    if (P.surf != GNX_SURF_NONE) {
+      GnxStream st(P.seed, oid, P.step, OP_DISP_SURF, a * 8);
+      theta = surf_direction(rast + (int64_t)P.surf_layer * P.H * P.W, P.W, P.H, (int)mx, (int)my,
+                             P.surf, P.surf_kappa, st);
+    }
+    uint4 r = gnx_rand4(P.seed, oid, P.step, OP_DISPERSAL, a);
+    if (P.surf == GNX_SURF_NONE) theta = GNX_PI_F * (2.0f * gnx_u01(r.w) - 1.0f);
+    float dist = gnx_distance(P.distr, P.p1, P.p2, r);
+    if (disperse_once(mx, my, theta, dist, P.rrx, P.rry, P.xmax, P.ymax, ox, oy)) break;
+  }
+  uint4 r = gnx_rand4(P.seed, oid, P.step, OP_OFFSPRING, 0);
+  // sex (structs/species.py:659-662 then structs/individual.py:110-115): a
+  // drawn 0 is falsy in `if sex:` and is replaced by a Bernoulli(0.5) draw -
+  // kept as is; unsexed species carry a Bernoulli(0.5) sex.
+  uint8_t sx;
+  uint4 r2 = gnx_rand4(P.seed, oid, P.step, OP_OFFSPRING, 1);
+  if (P.sexed && gnx_u01(r2.x) < P.p_male)
+    sx = 1;
+  else
+    sx = gnx_u01(r2.y) < 0.5f ? 1 : 0;
+  s.x[slot] = ox;
+  s.y[slot] = oy;
+  s.age[slot] = 0;
+  s.sex[slot] = sx;
+  s.id[slot] = (int64_t)oid;
+  s.fit[slot] = 1.0f;
+  int cx = (int)ox, cy = (int)oy;
+  for (int l = 0; l < P.n_layers; ++l)
+    s.e[(int64_t)l * P.cap + slot] = rast[((int64_t)l * P.H + cy) * P.W + cx];
+  off_parent[2 * k] = i;
+  off_parent[2 * k + 1] = m;
+  if (P.genomes) {
+    s.grow[slot] = free_rows[P.n_free - 1 - k];
+    if (!P.inject_keys) {
+      // start homologues ~ Bernoulli(.5) x2 (ops/mating.py:133); keys ~
+      // randint(0, n_paths) x2 (structs/species.py:625)
+      off_start[2 * k] = (uint8_t)(r.x & 1u);
+      off_start[2 * k + 1] = (uint8_t)((r.x >> 1) & 1u);
+      off_keys[2 * k] = (int32_t)(((unsigned long long)r.y * (unsigned long long)P.n_paths) >> 32);
+      off_keys[2 * k + 1] = (int32_t)(((unsigned long long)r.z * (unsigned long long)P.n_paths) >> 32);
+    }
+  } else {
+    s.grow[slot] = -1;
+  }
+}
+
+// appends B offspring of the pairs in h->pairs; inject: parents/keys/starts were
+// uploaded to off_parent/off_keys/off_start and no positions are drawn
+__global__ void k_offspring_inject(int64_t N, int64_t B, int64_t cap, GnxSoA s, const float* rast,
+                                   int n_layers, int W, int H, const int32_t* off_parent,
+                                   const int32_t* free_rows, int64_t n_free, int64_t max_id) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= B) return;
+  int i = off_parent[2 * k], m = off_parent[2 * k + 1];
+  int64_t slot = N + k;
+  float ox = (s.x[i] + s.x[m]) / 2.0f, oy = (s.y[i] + s.y[m]) / 2.0f;
+  s.x[slot] = ox;
+  s.y[slot] = oy;
+  s.age[slot] = 0;
+  s.sex[slot] = 0;
+  s.id[slot] = max_id + 1 + k;
+  s.fit[slot] = 1.0f;
+  s.grow[slot] = free_rows[n_free - 1 - k];
+  int cx = (int)ox, cy = (int)oy;
+  for (int l = 0; l < n_layers; ++l)
+    s.e[(int64_t)l * cap + slot] = rast[((int64_t)l * H + cy) * W + cx];
+}
+
+int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* births_out) {
+  const gnx_config& c = h->cfg;
+  const gnx_species_params& sp = h->sp;
+  GnxSoA s = h->soa[h->cur];
+  *births_out = 0;
+  int64_t B = 0;
+  bool genomes = !burn && c.L > 0 && h->genomes_assigned;
+  if (inject) {
+    B = B_inject;
+    if (B == 0) return 0;
+    if (h->N + B > c.cap_inds || B > h->n_free) {
+      gnx_set_error("capacity exceeded: N=%lld + B=%lld > cap_inds=%lld or free rows %lld",
+                    (long long)h->N, (long long)B, (long long)c.cap_inds, (long long)h->n_free);
+      return 2;
+    }
+    hipLaunchKernelGGL(k_offspring_inject, dim3(gnx_grid(B, 256)), dim3(256), 0, h->stream, h->N,
+                       B, c.cap_inds, s, h->rast, c.n_layers, c.W, c.H, h->off_parent,
+                       h->free_rows, h->n_free, h->max_id);
+  } else {
+    int64_t P = h->n_pairs;
+    if (P == 0) return 0;
+    int fixed_nb = 0;
+    if (sp.n_births_fixed) {
+      fixed_nb = (int)sp.n_births_lambda;
+      B = P * fixed_nb;
+    } else {
+      float thr = (float)exp(-sp.n_births_lambda);
+      hipLaunchKernelGGL(k_births, dim3(gnx_grid(P, 256)), dim3(256), 0, h->stream, P, h->pairs,
+                         s.id, thr, h->step, c.seed, h->nbirths);
+      HIPCHK(hipMemsetAsync(h->nbirths + P, 0, sizeof(int32_t), h->stream));
+      GNXCHK(gnx_prim_scan(h->scan_tmp, h->scan_tmp_bytes, h->nbirths, h->boff, (size_t)P + 1,
+                           h->stream));
+      HIPCHK(hipMemcpyAsync(h->h_pin, h->boff + P, sizeof(int32_t), hipMemcpyDeviceToHost,
+                            h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      B = *(int32_t*)h->h_pin;
+      if (B > c.cap_inds) {
+        gnx_set_error("capacity exceeded: births %lld > cap_inds %lld", (long long)B,
+                      (long long)c.cap_inds);
+        return 2;
+      }
+      hipLaunchKernelGGL(k_expand_births, dim3(gnx_grid(P, 256)), dim3(256), 0, h->stream, P,
+                         h->nbirths, h->boff, h->off_pair);
+    }
+    if (B == 0) return 0;
+    if (h->N + B > c.cap_inds || (genomes && B > h->n_free)) {
+      gnx_set_error("capacity exceeded: N=%lld + births=%lld > cap_inds=%lld (free rows %lld)",
+                    (long long)h->N, (long long)B, (long long)c.cap_inds, (long long)h->n_free);
+      return 2;
+    }
+    OffP Q;
+    Q.N = h->N;
+    Q.B = B;
+    Q.cap = c.cap_inds;
+    Q.W = c.W;
+    Q.H = c.H;
+    Q.n_layers = c.n_layers;
+    Q.xmax = (float)(c.W - 0.001);
+    Q.ymax = (float)(c.H - 0.001);
+    Q.rrx = (float)sp.res_ratio[0];
+    Q.rry = (float)sp.res_ratio[1];
+    Q.distr = sp.disp_distr;
+    Q.p1 = (float)sp.disp_p1;
+    Q.p2 = (float)sp.disp_p2;
+    Q.surf = sp.disp_surf;
+    Q.surf_layer = sp.disp_surf_layer;
+    Q.surf_kappa = (float)sp.disp_surf_kappa;
+    Q.sexed = sp.sexed;
+    Q.p_male = (float)sp.p_male;
+    Q.fixed_nb = fixed_nb;
+    Q.genomes = genomes ? 1 : 0;
+    Q.inject_keys = 0;
+    Q.n_paths = h->n_paths;
+    Q.max_id = h->max_id;
+    Q.n_free = h->n_free;
+    Q.step = h->step;
+    Q.seed = c.seed;
+    gnx_time_begin(h);
+    hipLaunchKernelGGL(k_offspring, dim3(gnx_grid(B, 256)), dim3(256), 0, h->stream, Q, s, h->rast,
+                       h->pairs, h->off_pair, h->free_rows, h->off_parent, h->off_keys,
+                       h->off_start);
+    gnx_time_end(h, GNX_K_OFFSPRING, (double)B * (60.0 + 8.0 * c.n_layers));
+  }
+  HIPCHK(hipGetLastError());
+  if (genomes || inject) {
+    GNXCHK(gnx_l_crossover(h, h->N, B));
+    h->n_free -= B;
+    if (c.n_traits > 0) GNXCHK(gnx_l_phenotype(h, h->N, B));
+  }
+  h->N += B;
+  h->max_id += B;
+  *births_out = B;
+  return 0;
+}
+
+// ops/movement.py:98-141 with injected attempts (parity tests)
+__global__ void k_dispersal_inject(int64_t B, int A, const float* mx, const float* my,
+                                   const float* theta, const float* dist, float rrx, float rry,
+                                   float xmax, float ymax, float* ox, float* oy, int32_t* used) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= B) return;
+  float x = 0.f, y = 0.f;
+  int u = A - 1;
+  for (int a = 0; a < A; ++a) {
+    if (disperse_once(mx[k], my[k], theta[(int64_t)a * B + k], dist[(int64_t)a * B + k], rrx, rry,
+                      xmax, ymax, x, y)) {
+      u = a;
+      break;
+    }
+  }
+  ox[k] = x;
+  oy[k] = y;
+  used[k] = u;
+}
+
+int gnx_l_dispersal_inject(gnx_state* h, int64_t B, int A, const float* d_mx, const float* d_my,
+                           const float* d_theta, const float* d_dist, float* d_ox, float* d_oy,
+                           int32_t* d_used) {
+  const gnx_config& c = h->cfg;
+  hipLaunchKernelGGL(k_dispersal_inject, dim3(gnx_grid(B, 256)), dim3(256), 0, h->stream, B, A,
+                     d_mx, d_my, d_theta, d_dist, (float)h->sp.res_ratio[0],
+                     (float)h->sp.res_ratio[1], (float)(c.W - 0.001), (float)(c.H - 0.001), d_ox,
+                     d_oy, d_used);
+  HIPCHK(hipGetLastError());
+  return 0;
+}

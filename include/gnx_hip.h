@@ -1,0 +1,235 @@
+/*
+ * gnx_hip.h - C-ABI of libgnxhip.so: the MI355X (gfx950) implementation of
+ * Geonomics' per-generation simulation loop.
+ *
+ * The reference (erthward/geonomics 1.4.9) is pure Python and has no FFI; the
+ * boundary it offers is the Python object API.  Each entry point below names
+ * the reference method whose work it replaces (paths relative to
+ * geonomics/ in the reference).  The Python host layer in geonomics_amd/
+ * binds these with ctypes (geonomics_amd/_native.py); INTEGRATION.md shows the
+ * stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every call returns 0 on success, non-zero on failure;
+ *     gnx_last_error() then returns a message.
+ *   - the library owns all device memory behind the opaque handle; host
+ *     buffers passed in are copied; downloads write to caller-allocated buffers.
+ *   - one host thread per handle; calls are ordered on the handle's HIP stream
+ *     and synchronous at download / count calls.
+ *   - rasters are float32 [H][W] (row = y, col = x), the reference's
+ *     Layer.rast[y, x] order (structs/landscape.py Layer; dim = (x, y)).
+ *   - genotypes are bit-packed: per individual 2 homologues x W64 u64 words,
+ *     bit l of homologue h == Individual.g[l, h] (structs/individual.py:103).
+ *     W64 = gnx_words_per_hom(L).
+ *   - extinction is not an error: N == 0 after a step (structs/species.py:841).
+ */
+#ifndef GNX_HIP_H
+#define GNX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gnx_state gnx_state;
+
+/* ---- enums -------------------------------------------------------------- */
+enum { GNX_DIST_LOGNORMAL = 0, GNX_DIST_WALD = 1, GNX_DIST_LEVY = 2 };
+enum { GNX_MATE_UNIFORM = 0, GNX_MATE_NEAREST = 1, GNX_MATE_INVERSE = 2 };
+enum { GNX_SURF_NONE = 0, GNX_SURF_MIXTURE = 1, GNX_SURF_UNIMODAL = 2 };
+
+/* fields for gnx_download() */
+enum {
+  GNX_F_X = 0, GNX_F_Y = 1, GNX_F_AGE = 2, GNX_F_SEX = 3, GNX_F_ID = 4,
+  GNX_F_E = 5,      /* float [n_layers][N]   */
+  GNX_F_Z = 6,      /* float [n_traits][N]   */
+  GNX_F_FIT = 7, GNX_F_GROW = 8,
+  GNX_F_GENO = 9    /* uint64 [N][2][W64], in slot order */
+};
+/* rasters for gnx_download_raster(): double [H][W] */
+enum { GNX_R_N = 0, GNX_R_NPAIRS = 1, GNX_R_K = 2, GNX_R_D = 3, GNX_R_COUNTS = 4 };
+
+/* kernels for gnx_kernel_time() */
+enum {
+  GNX_K_MOVE = 0, GNX_K_SORT = 1, GNX_K_PERMUTE = 2, GNX_K_FIND_MATES = 3,
+  GNX_K_PAIRS = 4, GNX_K_OFFSPRING = 5, GNX_K_CROSSOVER = 6,
+  GNX_K_PHENOTYPE = 7, GNX_K_DENSITY = 8, GNX_K_DEATH = 9, GNX_K_COMPACT = 10,
+  GNX_K_COUNT = 11
+};
+
+/* ---- configuration ------------------------------------------------------ */
+typedef struct {
+  int32_t W, H;            /* landscape dim (x, y): Landscape.dim            */
+  int32_t n_layers;
+  int32_t L;               /* loci; 0 = species without gen_arch             */
+  int32_t n_traits;
+  int64_t cap_inds;        /* individual-slot capacity                       */
+  int64_t cap_rows;        /* genome-row capacity (0 if L == 0)              */
+  uint64_t seed;           /* params.model.seed.num (sim/model.py:98-99)     */
+  int32_t device;          /* HIP device ordinal                             */
+  int32_t reserved;
+} gnx_config;
+
+/* Species life-history parameters: the 'mating', 'mortality' and 'movement'
+ * sections of the parameters file (sim/params.py SPP_PARAMS), hoisted to
+ * Species attributes at structs/species.py:409-425.                          */
+typedef struct {
+  /* mating */
+  double  b;                       /* P(pair mates)                          */
+  double  R;                       /* intrinsic growth rate                  */
+  double  n_births_lambda;
+  int32_t n_births_fixed;
+  int32_t sexed;                   /* mating.sex                             */
+  double  p_male;                  /* sex_ratio/(sex_ratio+1) (species.py:416) */
+  double  mating_radius;           /* < 0 => None (panmixia)                 */
+  int32_t mate_mode;               /* GNX_MATE_*                             */
+  int32_t repro_age[2];            /* [female, male]; both equal if unsexed  */
+  /* mortality */
+  int32_t max_age;                 /* < 0 => None                            */
+  double  d_min, d_max;
+  double  window_width;            /* density_grid_window_width; <=0 => None */
+  /* movement */
+  int32_t move;
+  double  dir_mu, dir_kappa;
+  int32_t move_distr;              /* GNX_DIST_*                             */
+  double  move_p1, move_p2;
+  int32_t disp_distr;
+  double  disp_p1, disp_p2;
+  int32_t move_surf;               /* GNX_SURF_*                             */
+  int32_t move_surf_layer;
+  double  move_surf_kappa;
+  int32_t disp_surf;
+  int32_t disp_surf_layer;
+  double  disp_surf_kappa;
+  double  res_ratio[2];            /* Landscape._res_ratio                   */
+  /* carrying capacity: K = rast[K_layer] * K_factor (species.py:546)        */
+  int32_t K_layer;
+  int32_t pad0;
+  double  K_factor;
+} gnx_species_params;
+
+/* ---- lifecycle ---------------------------------------------------------- */
+int  gnx_create(const gnx_config* cfg, gnx_state** out);
+void gnx_destroy(gnx_state* h);
+const char* gnx_last_error(void);
+int  gnx_words_per_hom(int32_t L);
+/* use an externally created hipStream_t (e.g. torch's current stream)       */
+int  gnx_set_stream(gnx_state* h, void* hip_stream);
+int  gnx_synchronize(gnx_state* h);
+
+/* ---- landscape / species setup ----------------------------------------- */
+/* Landscape layers: lyr.rast for every Layer (structs/landscape.py:34-120)  */
+int gnx_upload_rasters(gnx_state* h, const float* rasts /*[n_layers][H][W]*/);
+int gnx_upload_layer(gnx_state* h, int32_t layer, const float* rast);
+int gnx_set_species_params(gnx_state* h, const gnx_species_params* p);
+
+/* Population: _make_species / _make_individual (structs/species.py:3300-3320,
+ * structs/individual.py:188-228).  ids must be ascending.                   */
+int gnx_upload_population(gnx_state* h, int64_t N, const float* x,
+                          const float* y, const int32_t* age,
+                          const uint8_t* sex, const int64_t* id);
+/* N individuals at uniform random positions, ids 0..N-1, age 0              */
+int gnx_init_population(gnx_state* h, int64_t N);
+
+/* ---- genomic architecture ----------------------------------------------- */
+/* Recombinations._subsetters (structs/genome.py:188-230) as path bits:
+ * paths[k][w] bit l = homologue the k-th cached path is on at locus l.      */
+int gnx_set_recomb_paths(gnx_state* h, int32_t n, const uint64_t* paths);
+/* Trait (structs/genome.py:284-438): loci ascending, alpha per locus.
+ * phi_rast == NULL => scalar phi.                                           */
+int gnx_set_trait(gnx_state* h, int32_t t, int32_t n_loci, const int32_t* loci,
+                  const double* alpha, int32_t layer, double phi,
+                  const float* phi_rast, double gamma, int32_t univ_adv);
+/* GenomicArchitecture.dom (structs/genome.py:552-555); NULL => codominant   */
+int gnx_set_dominance(gnx_state* h, const uint8_t* dom /*[L]*/);
+/* delet_loci / delet_loci_s (structs/genome.py:589-591)                     */
+int gnx_set_deleterious(gnx_state* h, int32_t n, const int32_t* loci,
+                        const double* s);
+/* Individuals' genomes, in current slot order (inject / restore)            */
+int gnx_upload_genomes(gnx_state* h, const uint64_t* geno /*[N][2][W64]*/);
+/* Species._set_genomes_and_tables + _make_starting_mutations
+ * (structs/species.py:956-967,1087; structs/genome.py:1108-1157):
+ * exactly n_per_site[l] of the 2N homologues carry a 1 at site l.           */
+int gnx_assign_genomes(gnx_state* h, const int32_t* n_per_site /*[L]*/);
+/* recompute all phenotypes (Species._set_z, structs/species.py:925)         */
+int gnx_set_z(gnx_state* h);
+
+/* ---- one time step ------------------------------------------------------- */
+/* Species._set_age_stage (structs/species.py:567)                           */
+int gnx_age(gnx_state* h);
+/* Species._do_movement (structs/species.py:582-585; ops/movement.py:34-95)  */
+int gnx_move(gnx_state* h);
+/* Species._do_pop_dynamics (structs/species.py:822; ops/demography.py:183):
+ * pairs -> n_pairs density -> mating (births, dispersal, crossover,
+ * phenotype) -> N density -> d -> death probabilities -> mortality.
+ * burn != 0: no genomes/selection (burn-in).  Appends to Nt/births/deaths
+ * counters readable with gnx_counts().                                      */
+int gnx_pop_dynamics(gnx_state* h, int32_t burn, int32_t with_selection);
+/* whole fn-queue entry for one step: age, move (if params.move), pop dynamics
+ * (sim/model.py:603-667)                                                    */
+int gnx_step(gnx_state* h, int32_t burn, int32_t with_selection);
+int gnx_counts(gnx_state* h, int64_t* N, int64_t* births, int64_t* deaths);
+int64_t gnx_step_index(gnx_state* h);
+int gnx_set_step_index(gnx_state* h, int64_t step);
+
+/* mutation (ops/mutation.py:62-131): set bit (locus, hom) of listed slots   */
+int gnx_mutate(gnx_state* h, int32_t n, const int64_t* slot,
+               const int32_t* locus, const uint8_t* hom);
+
+/* ---- read-back ------------------------------------------------------------ */
+/* slot order == ascending id order is NOT guaranteed; download GNX_F_ID and
+ * sort on the host (geonomics_amd does).                                    */
+int gnx_download(gnx_state* h, int32_t field, void* dst, int64_t dst_bytes);
+/* genotypes of selected slots: uint64 [n][2][W64]                           */
+int gnx_download_genomes(gnx_state* h, int64_t n, const int64_t* slots,
+                         uint64_t* dst);
+/* double [H][W]: N (Species.N), n_pairs, K, d as of the last pop_dynamics;
+ * GNX_R_COUNTS = individuals per cell (sim/burnin.py:44-59)                 */
+int gnx_download_raster(gnx_state* h, int32_t which, double* dst);
+/* burn-in spatial tester (sim/burnin.py:44-59): updates the per-cell count
+ * raster and returns mean and std of (counts_now - counts_prev)             */
+int gnx_spatial_diff_stats(gnx_state* h, double* mean, double* std);
+
+/* ---- operator-level entry points (parity tests; explicit random inputs) -- */
+/* ops/movement.py:74-92 with injected direction/distance draws              */
+int gnx_op_move(gnx_state* h, const float* theta, const float* dist);
+/* draws only: what gnx_move would draw for the current population           */
+int gnx_op_move_draws(gnx_state* h, float* theta, float* dist);
+/* structs/species.py:2157-2215 + ops/mating.py:24-117.  Outputs mate slot
+ * per individual (-1 none) and the final pair list; keep == NULL => draw
+ * Bernoulli(b) from the device stream.                                      */
+int gnx_op_find_pairs(gnx_state* h, const uint8_t* keep, int32_t* mate,
+                      int32_t* pairs /*[cap][2]*/, int64_t* n_pairs);
+/* ops/mating.py:130-214: B offspring from parent slots, path keys and start
+ * homologues; children are appended to the population (rows allocated).     */
+int gnx_op_crossover(gnx_state* h, int64_t B, const int32_t* parent_slots,
+                     const int32_t* keys, const uint8_t* start_homs);
+/* ops/movement.py:98-141: offspring positions from A attempts of draws      */
+int gnx_op_dispersal(gnx_state* h, int64_t B, int32_t A, const float* mid_x,
+                     const float* mid_y, const float* theta,
+                     const float* dist, float* out_x, float* out_y,
+                     int32_t* attempt_used);
+/* utils/spatial.py:73-146: density raster of arbitrary points               */
+int gnx_op_density(gnx_state* h, int64_t n, const float* x, const float* y,
+                   double* node_vals /*[Jy][Jx] or NULL*/, double* raster);
+int gnx_density_lattice_dims(gnx_state* h, int32_t* Jx, int32_t* Jy);
+/* ops/demography.py:253-321 + ops/selection.py:119-125: death probabilities
+ * of the current population given node densities for N and n_pairs          */
+int gnx_op_death_probs(gnx_state* h, int32_t with_selection,
+                       const double* nodes_N, const double* nodes_pairs,
+                       double* p_death, double* d_at_cell);
+/* ops/demography.py:175-180 with an injected death mask                     */
+int gnx_op_mortality(gnx_state* h, const uint8_t* dead);
+
+/* ---- measurement ------------------------------------------------------------ */
+int gnx_profiling(gnx_state* h, int32_t on);
+/* accumulated HIP-event time (ms) and launch count of one kernel family,
+ * measured on the handle's stream; resets the accumulator                   */
+int gnx_kernel_time(gnx_state* h, int32_t kernel, double* ms, int64_t* launches,
+                    double* algorithmic_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNX_HIP_H */

@@ -11,9 +11,9 @@ that is consumed in data-dependent order; that cannot be reproduced on a GPU.
 The build's stream layout is instead:
 
     subsequence = individual id   (or offspring id / focal id, see each op)
-    block index = ((step * 32 + op) * 8 + blk)          [= rocRAND offset / 4]
+    block index = ((step * 32 + op) * 64 + blk)         [= rocRAND offset / 4]
 
-so every (individual, step, op) owns 8 blocks of 4 x u32, independent of slot
+so every (individual, step, op) owns 64 blocks of 4 x u32, independent of slot
 order, launch geometry and GPU count.
 """
 import numpy as np
@@ -38,7 +38,7 @@ OP_DISP_SURF = 9      # blk = attempt number
 
 
 def block_index(step, op, blk=0):
-    return (np.uint64(step) * np.uint64(32) + np.uint64(op)) * np.uint64(8) \
+    return (np.uint64(step) * np.uint64(32) + np.uint64(op)) * np.uint64(64) \
         + np.uint64(blk)
 
 
