@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""bench.py - individual-timesteps/s of the Geonomics hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+One "step" = one pass of the per-generation loop (age, movement, mate search,
+mating with bitmask crossover, density, selection, mortality) over the whole
+resident population.  Metric = sum_t N_t / wall time over K timed steps
+(SURVEY 8d), inputs resident in HBM before the timed region.
+
+Workload `c4_metric` (default) is the configuration BASELINE.json's metric is
+quoted on: 2048x2048 two-layer landscape, 10^6 individuals, 10^5-locus genomes,
+4 traits x 10 loci selected on the second layer, ConductanceSurface movement,
+mating_radius 10, b 0.2, one birth per pair, recombination rate 1/L.
+
+For --gpus N > 1 the driver launches one rank per GPU with torch.distributed
+(RCCL); each rank owns one 2048x2048 tile of an N-tile landscape ("weak"
+scaling: per-GPU work fixed).  See DESIGN.md (multi-GPU) for what is and is not
+exchanged between tiles in this round.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (W, H, N, L, n_traits, loci_per_trait, move_surf, n_paths)
+    'c4_metric': dict(W=2048, H=2048, N=1_000_000, L=100_000, n_traits=4,
+                      loci_per_trait=10, move_surf=True, n_paths=10_000),
+    'c3': dict(W=1024, H=1024, N=100_000, L=100_000, n_traits=4,
+               loci_per_trait=10, move_surf=False, n_paths=10_000),
+    'c2': dict(W=1024, H=1024, N=100_000, L=10_000, n_traits=0,
+               loci_per_trait=0, move_surf=False, n_paths=10_000),
+    'small': dict(W=256, H=256, N=20_000, L=10_000, n_traits=4,
+                  loci_per_trait=10, move_surf=True, n_paths=1_000),
+}
+
+
+def smooth_field(W, H, seed):
+    """Seeded smooth random field in [0,1] (conductance / selection layer)."""
+    rng = np.random.RandomState(seed)
+    k = 16
+    coarse = rng.rand(H // k + 3, W // k + 3)
+    from scipy.ndimage import zoom
+    f = zoom(coarse, k, order=3)[:H, :W]
+    f = (f - f.min()) / (f.max() - f.min())
+    return f.astype(np.float32)
+
+
+def _set_bit_range(row, lo, hi):
+    """set bits [lo, hi) of a little-endian u64 word array"""
+    if hi <= lo:
+        return
+    w0, w1 = lo >> 6, (hi - 1) >> 6
+    full = np.uint64(0xFFFFFFFFFFFFFFFF)
+    m0 = full << np.uint64(lo & 63)
+    m1 = full >> np.uint64(63 - ((hi - 1) & 63))
+    if w0 == w1:
+        row[w0] |= m0 & m1
+    else:
+        row[w0] |= m0
+        row[w0 + 1:w1] = full
+        row[w1] |= m1
+
+
+def sparse_paths(n, L, seed, W64):
+    """n recombination paths for per-locus rate 1/L (r_0 = 0): the path switches
+    homologue at Binomial(L-1, 1/L) distinct loci (structs/genome.py:173-221);
+    bit l = homologue the path is on at locus l."""
+    rng = np.random.RandomState(seed)
+    out = np.zeros((n, W64), dtype=np.uint64)
+    ks = rng.binomial(L - 1, 1.0 / L, n)
+    for i in range(n):
+        if ks[i]:
+            bp = np.unique(rng.randint(1, L, ks[i])).tolist() + [L]
+            for j in range(0, len(bp) - 1, 2):
+                _set_bit_range(out[i], bp[j], bp[j + 1])
+    return out
+
+
+def build_device(cfg, seed, device):
+    from geonomics_amd import _native as nat
+    W, H, N, L = cfg['W'], cfg['H'], cfg['N'], cfg['L']
+    lyr0 = smooth_field(W, H, 1) * 0.5 + 0.5          # K / conductance layer
+    lyr1 = np.tile(np.linspace(0, 1, W, dtype=np.float32), (H, 1))
+    rasts = np.stack([lyr0, lyr1])
+    K_factor = N / float(lyr0.sum())                  # sum(K) = N
+    cap = int(N * 1.6) + 1024
+    dev = nat.Device(W, H, 2, L=L, n_traits=cfg['n_traits'], cap_inds=cap,
+                     cap_rows=cap, seed=seed, device=device)
+    dev.upload_rasters(rasts)
+    sp = nat.default_species_params(
+        mating_radius=10.0, K_layer=0, K_factor=K_factor,
+        move_surf=nat.SURF_MIXTURE if cfg['move_surf'] else nat.SURF_NONE,
+        move_surf_layer=0, move_surf_kappa=12.0)
+    dev.set_species_params(sp)
+    rng = np.random.RandomState(seed)
+    if cfg['n_traits']:
+        loci = np.sort(rng.choice(L, cfg['n_traits'] * cfg['loci_per_trait'],
+                                  replace=False)).reshape(cfg['n_traits'], -1)
+        for t in range(cfg['n_traits']):
+            n = cfg['loci_per_trait']
+            alpha = 0.1 * np.array([1 - (i % 2) * 2 for i in range(n)], float)
+            dev.set_trait(t, np.sort(loci[t]), alpha, 1, 0.05, 1.0, False)
+    dev.init_population(N)
+    return dev, rasts, K_factor
+
+
+def setup_genomes(dev, cfg, seed):
+    L = cfg['L']
+    dev.set_recomb_paths(sparse_paths(cfg['n_paths'], L, seed + 1, dev.W64))
+    # start_p_fixed = 0.5: n_l = round(2N * 0.5) = N ones per site
+    dev.assign_genomes(np.full(L, dev.N, dtype=np.int32))
+
+
+def cpu_baseline(budget_s=20.0):
+    """Oracle ("port": numpy, 1 thread) on a bounded sample of the workload:
+    same densities and genome length, smaller landscape."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import gnx_step as S
+    import gnx_oracle as O
+    W = H = 256
+    L = 100_000
+    N = int(1_000_000 * (W * H) / (2048 * 2048))
+    rng = np.random.RandomState(3)
+    lyr0 = smooth_field(W, H, 1) * 0.5 + 0.5
+    lyr1 = np.tile(np.linspace(0, 1, W, dtype=np.float32), (H, 1))
+    loci = np.sort(rng.choice(L, 40, replace=False)).reshape(4, 10)
+    traits = [dict(loci=loci[t], alpha=0.1 * np.array([1 - (i % 2) * 2 for i in range(10)], float),
+                   layer=1, phi=0.05, gamma=1.0, univ_adv=False) for t in range(4)]
+    W64 = O.words_per_hom(L)
+    paths = sparse_paths(256, L, 5, W64)
+    st = S.State(np.stack([lyr0, lyr1]),
+                 S.Params(mating_radius=10.0, K_factor=N / float(lyr0.sum())),
+                 7, L=L, traits=traits, paths_packed=paths)
+    st.init_population(N)
+    S.step(st, burn=True)
+    st.set_genomes(rng.randint(0, 2 ** 63, (st.N, 2, W64)).astype(np.uint64))
+    S.step(st, burn=False)                      # warm-up
+    t0 = time.time()
+    done = 0
+    steps = 0
+    while time.time() - t0 < budget_s and steps < 50:
+        done += st.N
+        S.step(st, burn=False)
+        steps += 1
+    dt = time.time() - t0
+    return dict(value=done / dt, unit='individual-timesteps/s', cores=1, kind='port',
+                sample='%d steps of a %dx%d tile, N~%d, L=%d, numpy oracle (oracle/gnx_step.py), '
+                       '1 thread of %d host cores' % (steps, W, H, N, L, os.cpu_count()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', default='c4_metric', choices=sorted(WORKLOADS))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: no HIP device is visible '
+                         '(the product has no CPU path)')
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    cfg = WORKLOADS[args.workload]
+    t_setup = time.time()
+    dev, rasts, K_factor = build_device(cfg, seed=42 + rank, device=local_rank)
+    # a short burn-in brings the uniform initial population to its density-
+    # regulated spatial distribution before genomes are assigned
+    for _ in range(3):
+        dev.step(True, False)
+    setup_genomes(dev, cfg, seed=42 + rank)
+    dev.synchronize()
+    t_setup = time.time() - t_setup
+
+    for _ in range(args.warmup):
+        dev.step(False, True)
+
+    def barrier():
+        torch.cuda.synchronize()
+        dev.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    dev.profiling(True)
+    barrier()
+    t0 = time.perf_counter()
+    ind_steps = 0
+    births = 0
+    for _ in range(args.steps):
+        ind_steps += dev.N
+        dev.step(False, True)
+        births += dev.counts()[1]
+    dev.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    kt = dev.kernel_times()
+    dev.profiling(False)
+
+    tot = torch.tensor([float(ind_steps)], device='cuda')
+    mx = torch.tensor([elapsed], device='cuda')
+    if dist is not None:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    total_ind_steps = float(tot.item())
+    max_elapsed = float(mx.item())
+
+    if rank == 0:
+        xo = kt['crossover']
+        ach = (xo['bytes'] / (xo['ms'] * 1e-3)) / 1e9 if xo['ms'] > 0 else 0.0
+        peak = 8000.0
+        traffic = None
+        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_crossover.json')
+        if os.path.exists(pmc):
+            try:
+                j = json.load(open(pmc))
+                if j.get('workload') == args.workload:
+                    traffic = j.get('hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+        out = {
+            'metric': 'individual-timesteps/sec', 'value': total_ind_steps / max_elapsed,
+            'unit': 'individual-timesteps/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * max_elapsed / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'u64', 'data': 'synthetic',
+            'config': {
+                'workload': '%s: %dx%d 2-layer landscape, N0=%d per GPU, L=%d, %d traits x %d loci, '
+                            'move_surf=%s, mating_radius=10, b=0.2, lambda=1 fixed, r=1/L, '
+                            'n_recomb_sims=%d' % (
+                                args.workload, cfg['W'], cfg['H'], cfg['N'], cfg['L'],
+                                cfg['n_traits'], cfg['loci_per_trait'], cfg['move_surf'],
+                                cfg['n_paths']),
+                'parallelism': 'tiles%d' % world,
+                'mean_N': ind_steps / args.steps, 'births_per_step': births / args.steps,
+                'setup_s': round(t_setup, 2),
+            },
+            'roofline': {
+                'bound': 'hbm', 'kernel': 'k_crossover', 'achieved': ach, 'peak': peak,
+                'unit': 'GB/s', 'frac': ach / peak, 'traffic': traffic,
+                'launches': xo['launches'],
+                'avg_launch_ms': xo['ms'] / max(xo['launches'], 1),
+                'algorithmic_bytes_per_launch': xo['bytes'] / max(xo['launches'], 1),
+            },
+            'kernel_ms_per_step': {k: v['ms'] / args.steps for k, v in kt.items()},
+        }
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out))
+    dev.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

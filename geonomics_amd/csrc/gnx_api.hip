@@ -24,19 +24,45 @@ extern "C" int gnx_words_per_hom(int32_t L) {
 }
 
 // ---------------------------------------------------------------- timers
+// HIP events on the handle's stream around each kernel family.  Events are
+// recorded without any host synchronisation inside the step (so the timed
+// region is not perturbed) and resolved when gnx_kernel_time() is called.
+static hipEvent_t timer_event(gnx_state* h) {
+  if (!h->ev_free.empty()) {
+    hipEvent_t e = h->ev_free.back();
+    h->ev_free.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
 void gnx_time_begin(gnx_state* h) {
-  if (h->profiling) (void)hipEventRecord(h->ev0, h->stream);
+  if (!h->profiling) return;
+  h->ev_open = timer_event(h);
+  (void)hipEventRecord(h->ev_open, h->stream);
 }
 
 void gnx_time_end(gnx_state* h, int kernel, double bytes) {
-  if (!h->profiling) return;
-  (void)hipEventRecord(h->ev1, h->stream);
-  (void)hipEventSynchronize(h->ev1);
-  float ms = 0.f;
-  (void)hipEventElapsedTime(&ms, h->ev0, h->ev1);
-  h->timers[kernel].ms += ms;
+  if (!h->profiling || !h->ev_open) return;
+  hipEvent_t e1 = timer_event(h);
+  (void)hipEventRecord(e1, h->stream);
+  h->ev_pending[kernel].push_back({h->ev_open, e1});
+  h->ev_open = nullptr;
   h->timers[kernel].launches += 1;
   h->timers[kernel].bytes += bytes;
+}
+
+static void timers_resolve(gnx_state* h, int kernel) {
+  (void)hipStreamSynchronize(h->stream);
+  for (auto& pr : h->ev_pending[kernel]) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) h->timers[kernel].ms += ms;
+    h->ev_free.push_back(pr.first);
+    h->ev_free.push_back(pr.second);
+  }
+  h->ev_pending[kernel].clear();
 }
 
 GnxTraitTab gnx_trait_tab(const gnx_state* h) {
@@ -113,8 +139,6 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
   const int64_t cap = cfg->cap_inds;
   HIPCHK(hipStreamCreate(&h->stream));
   h->own_stream = true;
-  HIPCHK(hipEventCreate(&h->ev0));
-  HIPCHK(hipEventCreate(&h->ev1));
   for (int k = 0; k < 2; ++k) GNXCHK(alloc_soa(&h->soa[k], cap, cfg->n_layers, cfg->n_traits));
   GNXCHK(dalloc(&h->rast, (size_t)cfg->n_layers * cfg->W * cfg->H));
   if (cfg->L > 0) {
@@ -177,8 +201,8 @@ extern "C" void gnx_destroy(gnx_state* h) {
     (void)hipFree(h->traits[t].phi_rast);
   }
   (void)hipHostFree(h->h_pin);
-  (void)hipEventDestroy(h->ev0);
-  (void)hipEventDestroy(h->ev1);
+  for (int k = 0; k < GNX_K_COUNT; ++k) timers_resolve(h, k);
+  for (hipEvent_t e : h->ev_free) (void)hipEventDestroy(e);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -389,14 +413,20 @@ extern "C" int gnx_set_recomb_paths(gnx_state* h, int32_t n, const uint64_t* pat
   int max_bp = 0;
   for (int k = 0; k < n; ++k) {
     const uint64_t* p = paths + (size_t)k * W64;
-    int prev = 0, cnt = 0;
-    for (int l = 0; l < L; ++l) {
-      int b = (int)((p[l >> 6] >> (l & 63)) & 1ull);
-      if (b != prev) {
-        loci.push_back(l);
+    uint64_t carry = 0;      // path bit of locus -1 := 0
+    int cnt = 0;
+    for (int w = 0; w * 64 < L; ++w) {
+      uint64_t v = p[w];
+      if (L - w * 64 < 64) v &= (1ull << (L - w * 64)) - 1ull;
+      uint64_t t = v ^ ((v << 1) | carry);          // bit l set <=> path switches at l
+      if (L - w * 64 < 64) t &= (1ull << (L - w * 64)) - 1ull;
+      carry = v >> 63;
+      while (t) {
+        int bpos = __builtin_ctzll(t);
+        loci.push_back(w * 64 + bpos);
         cnt++;
+        t &= t - 1;
       }
-      prev = b;
     }
     off[k + 1] = (int32_t)loci.size();
     max_bp = std::max(max_bp, cnt);
@@ -914,8 +944,11 @@ extern "C" int gnx_op_mortality(gnx_state* h, const uint8_t* dead) {
 
 // ---------------------------------------------------------------- measurement
 extern "C" int gnx_profiling(gnx_state* h, int32_t on) {
+  for (int k = 0; k < GNX_K_COUNT; ++k) {
+    timers_resolve(h, k);
+    h->timers[k] = GnxKernelTimer();
+  }
   h->profiling = on != 0;
-  for (int k = 0; k < GNX_K_COUNT; ++k) h->timers[k] = GnxKernelTimer();
   return 0;
 }
 
@@ -925,6 +958,7 @@ extern "C" int gnx_kernel_time(gnx_state* h, int32_t kernel, double* ms, int64_t
     gnx_set_error("gnx_kernel_time: bad kernel id");
     return 1;
   }
+  timers_resolve(h, kernel);
   if (ms) *ms = h->timers[kernel].ms;
   if (launches) *launches = h->timers[kernel].launches;
   if (algorithmic_bytes) *algorithmic_bytes = h->timers[kernel].bytes;

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <string>
 #include <vector>
+#include <utility>
 #include <hip/hip_runtime.h>
 #include "../../include/gnx_hip.h"
 
@@ -178,7 +179,9 @@ struct gnx_state {
   // profiling
   bool profiling = false;
   GnxKernelTimer timers[GNX_K_COUNT];
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev_open = nullptr;
+  std::vector<hipEvent_t> ev_free;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending[GNX_K_COUNT];
 };
 
 GnxTraitTab gnx_trait_tab(const gnx_state* h);

@@ -107,9 +107,14 @@ int gnx_l_crossover(gnx_state* h, int64_t first_slot, int64_t B) {
     hipLaunchKernelGGL(k_crossover<false>, dim3(grid), dim3(256), 0, h->stream, B, W16,
                        (const u64x2*)h->G, (u64x2*)h->G, s.grow, first_slot, h->off_parent,
                        h->off_keys, h->off_start, (const u64x2*)h->paths, h->bp_off, h->bp_loci);
-  // algorithmic bytes per birth: 4 parental homologues + 2 masks
-  // read, 2 homologues written = 8 * L/8 = L bytes (padded row width used here)
-  gnx_time_end(h, GNX_K_CROSSOVER, (double)B * 8.0 * (double)h->W64 * 8.0);
+  // algorithmic bytes per birth.  Dense masks: 4 parental
+  // homologues + 2 masks read, 2 homologues written = 8 * L/8 = L bytes.
+  // Sparse paths: each gamete chunk copies ONE parental homologue (the other
+  // is never needed, the mask comes from a handful of breakpoints), so the
+  // kernel must move 2 reads + 2 writes = 4 * L/8 = L/2 bytes per birth.
+  // (padded row width W64*8 is what actually moves)
+  gnx_time_end(h, GNX_K_CROSSOVER,
+               (double)B * (h->sparse_paths ? 4.0 : 8.0) * (double)h->W64 * 8.0);
   HIPCHK(hipGetLastError());
   return 0;
 }

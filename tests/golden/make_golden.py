@@ -554,7 +554,7 @@ def g10_envelopes():
         assert mod.comm.burned
         spp = mod.comm[0]
         nburn = len(spp.Nt)
-        mod.walk(T=60, mode='main', verbose=False)
+        mod.walk(T=100, mode='main', verbose=False)
         out['s%i_Nt' % s] = np.array(spp.Nt)
         out['s%i_births' % s] = np.array(spp.n_births)
         out['s%i_deaths' % s] = np.array(spp.n_deaths)
@@ -563,6 +563,11 @@ def g10_envelopes():
         out['s%i_freq' % s] = g.mean(axis=(0, 2))
         out['s%i_mean_fit' % s] = np.array([np.mean(spp._get_fit())])
         out['s%i_K_sum' % s] = np.array([spp.K.sum()])
+        for t, trt in spp.gen_arch.traits.items():
+            out['s%i_t%i_loci' % (s, t)] = np.asarray(trt.loci, dtype=np.int64)
+            out['s%i_t%i_alpha' % (s, t)] = np.asarray(trt.alpha, dtype=float)
+            out['s%i_t%i_par' % (s, t)] = np.array(
+                [trt.lyr_num, trt.phi, trt.gamma, float(trt.univ_adv)])
     save('g10_envelopes', **out)
 
 
