@@ -27,7 +27,8 @@ EXPORTS = [
     'gnx_init_population', 'gnx_set_recomb_paths', 'gnx_set_trait',
     'gnx_set_dominance', 'gnx_set_deleterious', 'gnx_upload_genomes',
     'gnx_assign_genomes', 'gnx_set_z', 'gnx_age', 'gnx_move',
-    'gnx_pop_dynamics', 'gnx_step', 'gnx_counts', 'gnx_step_index',
+    'gnx_pop_dynamics', 'gnx_pop_dynamics_mate', 'gnx_pop_dynamics_die',
+    'gnx_set_z_range', 'gnx_step', 'gnx_counts', 'gnx_step_index',
     'gnx_set_step_index', 'gnx_mutate', 'gnx_download', 'gnx_download_genomes',
     'gnx_download_raster', 'gnx_spatial_diff_stats', 'gnx_op_move',
     'gnx_op_move_draws', 'gnx_op_find_pairs', 'gnx_op_crossover',
@@ -219,6 +220,16 @@ class Device:
     def pop_dynamics(self, burn, with_selection):
         self._chk(self.lib.gnx_pop_dynamics(self.h, int(bool(burn)),
                                             int(bool(with_selection))))
+
+    def pop_dynamics_mate(self, burn):
+        self._chk(self.lib.gnx_pop_dynamics_mate(self.h, int(bool(burn))))
+
+    def pop_dynamics_die(self, burn, with_selection):
+        self._chk(self.lib.gnx_pop_dynamics_die(self.h, int(bool(burn)),
+                                                int(bool(with_selection))))
+
+    def set_z_range(self, first, n):
+        self._chk(self.lib.gnx_set_z_range(self.h, C.c_int64(first), C.c_int64(n)))
 
     def step(self, burn, with_selection):
         self._chk(self.lib.gnx_step(self.h, int(bool(burn)),

@@ -566,6 +566,17 @@ extern "C" int gnx_set_z(gnx_state* h) {
   return 0;
 }
 
+extern "C" int gnx_set_z_range(gnx_state* h, int64_t first, int64_t n) {
+  GNXCHK(need_genome(h));
+  if (!h->genomes_assigned || first < 0 || n < 0 || first + n > h->N) {
+    gnx_set_error("gnx_set_z_range: genomes not assigned or range out of bounds");
+    return 1;
+  }
+  GNXCHK(gnx_l_phenotype(h, first, n));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
 // ---------------------------------------------------------------- step
 extern "C" int gnx_age(gnx_state* h) { return gnx_l_age(h); }
 
@@ -587,10 +598,10 @@ static int check_recomb_ready(gnx_state* h, bool burn) {
   return 0;
 }
 
-extern "C" int gnx_pop_dynamics(gnx_state* h, int32_t burn, int32_t with_selection) {
+extern "C" int gnx_pop_dynamics_mate(gnx_state* h, int32_t burn) {
   GNXCHK(need_params(h));
   GNXCHK(check_recomb_ready(h, burn != 0));
-  int64_t P = 0, B = 0, D = 0;
+  int64_t P = 0, B = 0;
   // 1. mating pairs (cell-sorted population)
   GNXCHK(gnx_l_sort_by_cell(h));
   GNXCHK(gnx_l_find_pairs(h, nullptr, &P));
@@ -601,6 +612,13 @@ extern "C" int gnx_pop_dynamics(gnx_state* h, int32_t burn, int32_t with_selecti
     h->spl_P.valid = false;
   // 3. births: dispersal, crossover, phenotype
   GNXCHK(gnx_l_mate(h, burn != 0, false, 0, &B));
+  h->last_births = B;
+  return 0;
+}
+
+extern "C" int gnx_pop_dynamics_die(gnx_state* h, int32_t burn, int32_t with_selection) {
+  GNXCHK(need_params(h));
+  int64_t D = 0;
   // 4. N density of everyone incl. offspring (structs/species.py:845-882)
   GnxSoA s = h->soa[h->cur];
   GNXCHK(gnx_l_density(h, h->N, s.x, s.y, &h->spl_N, nullptr));
@@ -608,9 +626,13 @@ extern "C" int gnx_pop_dynamics(gnx_state* h, int32_t burn, int32_t with_selecti
   GNXCHK(gnx_l_death_probs(h, with_selection != 0 && !burn));
   // 7. mortality
   GNXCHK(gnx_l_mortality(h, nullptr, &D));
-  h->last_births = B;
   h->last_deaths = D;
   return 0;
+}
+
+extern "C" int gnx_pop_dynamics(gnx_state* h, int32_t burn, int32_t with_selection) {
+  GNXCHK(gnx_pop_dynamics_mate(h, burn));
+  return gnx_pop_dynamics_die(h, burn, with_selection);
 }
 
 extern "C" int gnx_step(gnx_state* h, int32_t burn, int32_t with_selection) {

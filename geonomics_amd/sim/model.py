@@ -1,0 +1,407 @@
+"""Model: the driver API kept from the reference (geonomics/sim/model.py:47-1182
+and the accessors at :2787-3147).  It builds the Landscape and Community, the
+burn-in and main function queues, and runs them; the queue entries call the
+device-backed Species methods (geonomics_amd/structs/species.py), which call
+libgnxhip.so.
+
+Kept: make_model -> Model.walk(T, mode) / Model.run() / Model.burn(); attributes
+t, burn_t, it, T, burn_T, comm, land, its; the queue order _set_t, _set_comm_t,
+_set_spp_t, _set_age_stage, _do_movement, _do_pop_dynamics, _set_Nt
+(sim/model.py:603-667); ValueError when walking 'main' before burn-in (:1087);
+exceptions inside run() are caught per iteration (:938-953).
+Fixed: queue lambdas bind their own species; both
+params.model.seed.num and params.model.num seed the model.
+Out of scope here: plotting, data/stats collectors, change events.
+"""
+import copy
+import os
+import random
+import sys
+import traceback
+
+import numpy as np
+
+from ..structs.landscape import _make_landscape
+from ..structs.community import _make_community
+from ..structs import genome as _genome
+
+
+class Model:
+    def __init__(self, name, params, verbose=False, device=None):
+        self.params = copy.deepcopy(params)
+        m_params = self.params.model
+        self.name = 'unnamed_model' if name is None else name
+        self._pid = os.getpid()
+        self._verbose = verbose
+        self.__term_width__ = 80
+        self.__tab_len__ = len('\t'.expandtabs())
+        if verbose:
+            print('\nMAKING MODEL...\n', flush=True)
+        # seeds: params.model.seed.num (code) or params.model.num (documented)
+        self.seed = None
+        if 'seed' in [*m_params] and m_params.seed is not None:
+            sd = m_params.seed
+            self.seed = sd.num if hasattr(sd, 'keys') else sd
+        if self.seed is None and m_params.get('num', None) is not None:
+            self.seed = m_params.num
+        self._set_seeds()
+        self.burn_T = m_params.burn_T
+        self.burn_t = -1
+        self.T = m_params.T
+        self.t = -1
+        self.n_its = m_params.its.n_its
+        self.its = [*range(self.n_its)][::-1]
+        self.it = -1
+        if device is None:
+            device = int(os.environ.get('LOCAL_RANK', '0'))
+        self._device = device
+        self.land = self._make_landscape(self._verbose)
+        self.comm = self._make_community(self._verbose)
+        self._never_been_run = True
+        self._data_collector = None
+        self._stats_collector = None
+        for key in ('data', 'stats'):
+            if key in [*m_params]:
+                import warnings
+                warnings.warn("params.model.%s is ignored: data/stats collectors are "
+                              "outside the GPU hot path (SURVEY 8f)." % key)
+        self.reassign_genomes = None
+        self.rand_genarch = m_params.its.rand_genarch
+        self.rand_landscape = m_params.its.rand_landscape
+        self.rand_comm = m_params.its.rand_comm
+        self.repeat_burn = m_params.its.repeat_burn
+        # snapshots replace the reference's deepcopy(comm); only taken when a
+        # later iteration can need them
+        self.orig_land = None if self.rand_landscape else self.land
+        self._orig_comm_snap = None
+        if not self.rand_comm and self.n_its > 1:
+            self._orig_comm_snap = self._snapshot_comm()
+        self.burn_fn_queue = None
+        self.main_fn_queue = None
+
+    def __str__(self):
+        return ('%s\nModel name: %s\nLayers: %s\nSpecies: %s\nNumber of iterations: %i\n'
+                'Number of burn-in timesteps (minimum): %i\nNumber of main timesteps: %i'
+                % (str(type(self)), self.name,
+                   ', '.join("%i: '%s'" % (i, l.name) for i, l in self.land.items()),
+                   ', '.join("%i: '%s'" % (i, s.name) for i, s in self.comm.items()),
+                   self.n_its, self.burn_T, self.T))
+
+    __repr__ = __str__
+
+    # -- helpers --------------------------------------------------------------
+    def _get_lyr_num(self, lyr_id):
+        return self.land._get_lyr_num(lyr_id)
+
+    def _get_spp_num(self, spp_id):
+        if isinstance(spp_id, int):
+            assert spp_id in self.comm.keys(), (
+                'A Species with numeric spp_id %s does not exist.' % str(spp_id))
+            return spp_id
+        if isinstance(spp_id, str):
+            nums = [k for k, spp in self.comm.items() if spp.name == spp_id]
+            assert len(nums) == 1, ("Expected to find a single Species with a name "
+                                    "matching the name provided (%s). Instead found %i."
+                                    % (spp_id, len(nums)))
+            return nums[0]
+        raise ValueError("The Species identifier must be either a str or an int. "
+                         "Instead, a %s was provided." % str(type(spp_id)))
+
+    def _get_trt_num(self, spp, trt_id):
+        if isinstance(trt_id, int) or trt_id is None:
+            return trt_id
+        nums = [k for k, trt in spp.gen_arch.traits.items() if trt.name == trt_id]
+        assert len(nums) == 1
+        return nums[0]
+
+    def _set_seeds(self):
+        """reference sim/model.py:364-366; the device streams are keyed by the
+        same seed (one 64-bit Philox key)."""
+        self._rng = np.random.RandomState(self.seed if self.seed is not None else None)
+        if self.seed is not None:
+            random.seed(self.seed)
+            np.random.seed(self.seed)
+            self._dev_seed = int(self.seed)
+        else:
+            self._dev_seed = int(np.random.randint(0, 2 ** 31 - 1))
+
+    def _set_it(self):
+        self.it = self.its.pop()
+
+    def _set_t(self):
+        self.t += 1
+
+    def _reset_t(self):
+        self.t = -1
+
+    def _set_burn_t(self):
+        self.burn_t += 1
+
+    def _reset_burn_t(self):
+        self.burn_t = -1
+
+    def _set_reassign_genomes(self):
+        self.reassign_genomes = bool(np.any([spp.gen_arch is not None
+                                             for spp in self.comm.values()]))
+
+    def _make_landscape(self, verbose=False):
+        return _make_landscape(mod=self, params=self.params, verbose=verbose)
+
+    def _make_community(self, verbose=False):
+        comm = _make_community(self.land, self.params, burn=True, verbose=verbose,
+                               seed=self._dev_seed, device=self._device, rng=self._rng)
+        return comm
+
+    def _snapshot_comm(self):
+        return {k: spp._snapshot() for k, spp in self.comm.items()}
+
+    def _restore_comm(self, snap):
+        for k, spp in self.comm.items():
+            spp._restore(snap[k])
+        self.comm.burned = bool(np.all([spp.burned for spp in self.comm.values()]))
+
+    def _reset_community(self, rand_comm=True):
+        """reference sim/model.py:457-512"""
+        if not rand_comm and self._orig_comm_snap is not None:
+            if self._verbose:
+                print('Copying the original community for iteration %i...\n\n' % self.it,
+                      flush=True)
+            self._restore_comm(self._orig_comm_snap)
+            if self.rand_genarch:
+                for spp in self.comm.values():
+                    if spp.gen_arch is not None:
+                        spp.gen_arch = _genome._make_genomic_architecture(
+                            spp_params=self.params['comm']['species'][spp.name],
+                            land=self.land, rng=self._rng)
+                        spp._upload_gen_arch()
+                        if not self.repeat_burn and spp.burned:
+                            spp._set_genomes_and_tables(self.burn_T, self.T)
+        else:
+            if self._verbose:
+                print('Creating new community for iteration %i...\n\n' % self.it,
+                      flush=True)
+            for spp in self.comm.values():
+                spp._dev.close()
+            self.comm = self._make_community(self._verbose)
+
+    def _reset(self, rand_landscape=None, rand_comm=None, rand_genarch=None,
+               repeat_burn=None):
+        """reference sim/model.py:540-593"""
+        rand_landscape = self.rand_landscape if rand_landscape is None else rand_landscape
+        rand_comm = self.rand_comm if rand_comm is None else rand_comm
+        repeat_burn = self.repeat_burn if repeat_burn is None else repeat_burn
+        if not self._never_been_run:
+            if rand_landscape:
+                self.land = self._make_landscape()
+            self._reset_community(rand_comm)
+        else:
+            self._never_been_run = False
+        self._reset_t()
+        if repeat_burn:
+            self._reset_burn_t()
+        self.comm._reset_t()
+        for spp in self.comm.values():
+            spp._reset_t()
+        self._set_reassign_genomes()
+        if repeat_burn or self.it <= 0:
+            self.burn_fn_queue = self._make_fn_queue(burn=True)
+        self.main_fn_queue = self._make_fn_queue(burn=False)
+
+    # -- function queue (reference sim/model.py:603-667) ----------------------------
+    def _make_fn_queue(self, burn=False):
+        queue = []
+        if burn:
+            queue.append(self._set_burn_t)
+        else:
+            queue.append(self._set_t)
+            queue.append(self.comm._set_t)
+            for spp in self.comm.values():
+                queue.append(spp._set_t)
+        for spp in self.comm.values():
+            queue.append(spp._set_age_stage)
+        for spp in self.comm.values():
+            if spp._move:
+                queue.append(lambda spp=spp: spp._do_movement(self.land))
+        for spp in self.comm.values():
+            queue.append(lambda spp=spp: spp._do_pop_dynamics(self.land))
+        for spp in self.comm.values():
+            queue.append(spp._set_Nt)
+        if burn:
+            queue.append(self._check_comm_burned)
+        return queue
+
+    def _check_comm_burned(self):
+        self.comm._check_burned(burn_T=self.burn_T, params=self.params)
+
+    def _print_timestep_info(self, mode):
+        msg = '%s:\tit=%i:\tt=%i\n' % (mode, self.it,
+                                       self.burn_t if mode == 'burn' else self.t)
+        for spp in self.comm.values():
+            Nt = spp.Nt[-1] if spp.Nt else np.nan
+            nb = spp.n_births[-1] if spp.n_births else np.nan
+            nd = spp.n_deaths[-1] if spp.n_deaths else np.nan
+            msg += '\tspecies: %s%sN=%s\t(births=%s\tdeaths=%s)\n' % (
+                spp.name, ' ' * (30 - len(spp.name)), Nt, nb, nd)
+        print(msg)
+        print('\t' + '.' * (self.__term_width__ - self.__tab_len__), flush=True)
+
+    def _do_timestep(self, mode):
+        """reference sim/model.py:699-787"""
+        queue = self.burn_fn_queue if mode == 'burn' else self.main_fn_queue
+        for fn in queue:
+            if True not in [spp.extinct for spp in self.comm.values()]:
+                fn()
+            else:
+                break
+        if self._verbose:
+            self._print_timestep_info(mode)
+        if mode == 'burn' and np.all([spp.burned for spp in self.comm.values()]):
+            if self.reassign_genomes:
+                for spp in self.comm.values():
+                    if spp.gen_arch is not None:
+                        if self._verbose:
+                            print('\nAssigning genomes for species "%s"...\n\n' % spp.name,
+                                  flush=True)
+                        spp._set_genomes_and_tables(self.burn_T, self.T)
+                self.reassign_genomes = False
+            self.comm.burned = True
+            if self._verbose:
+                print('Burn-in complete.\n\n', flush=True)
+        extinct = bool(np.any([spp.extinct for spp in self.comm.values()]))
+        if extinct and self._verbose:
+            print('XXXX     Species %s went extinct. Iteration %i aborting.\n\n' % (
+                ' & '.join('"' + spp.name + '"' for spp in self.comm.values()
+                           if spp.extinct), self.it), flush=True)
+        return extinct
+
+    def _set_next_iteration(self):
+        self._set_it()
+        if self._verbose:
+            print('~' * self.__term_width__ + '\n\n')
+            print('Setting up iteration %i...\n\n' % self.it, flush=True)
+        self._reset(rand_landscape=self.rand_landscape, rand_comm=self.rand_comm,
+                    rand_genarch=self.rand_genarch, repeat_burn=self.repeat_burn)
+
+    def _do_next_iteration(self):
+        """reference sim/model.py:808-858"""
+        self._set_next_iteration()
+        if self.rand_comm or (not self.rand_comm and self.repeat_burn) or self.it == 0:
+            if self._verbose:
+                print('Running burn-in, iteration %i...\n\n' % self.it, flush=True)
+            while not np.all([spp.burned for spp in self.comm.values()]):
+                if self._do_timestep(mode='burn'):
+                    break
+            if not self.rand_comm and not self.repeat_burn and self.n_its > 1:
+                self._orig_comm_snap = self._snapshot_comm()
+        if self._verbose:
+            print('Running main model, iteration %i...\n\n' % self.it, flush=True)
+        if np.any([spp.extinct for spp in self.comm.values()]):
+            if self._verbose:
+                print("WARNING: At least one Species went extinct during the burn-in. "
+                      "Cannot run main phase for iteration %i.\n\n" % self.it, flush=True)
+            return
+        for _ in range(self.T):
+            if self._do_timestep('main'):
+                break
+
+    # -- public API ---------------------------------------------------------------------
+    def run(self, verbose=False):
+        """Run all iterations: burn-in then T main timesteps each
+        (reference sim/model.py:866-961)."""
+        self._verbose = verbose
+        if self._verbose:
+            print('\n\n' + '#' * self.__term_width__ + '\n\n')
+            print('Running model "%s"...\n\n' % self.name, flush=True)
+        while len(self.its) > 0:
+            try:
+                self._do_next_iteration()
+            except Exception as e:
+                msg = ('XXXX\tAn error occurred during iteration %i, timestep %i.\n'
+                       % (self.it, self.t if self.comm.burned else self.burn_t))
+                print(msg)
+                print('Error message:\n\t%s\n\n' % e)
+                traceback.print_exc(file=sys.stdout)
+        if self._verbose:
+            print('\n\nModel "%s" is complete.\n' % self.name, flush=True)
+        self._verbose = False
+
+    def walk(self, T=1, mode='main', verbose=True, animate=False):
+        """Run T timesteps in 'burn' or 'main' mode
+        (reference sim/model.py:966-1161)."""
+        assert isinstance(T, (int, float)), "'T' must be a numeric data type."
+        T = int(T)
+        if mode not in ('burn', 'main'):
+            raise ValueError("mode must be 'burn' or 'main'")
+        if mode == 'main' and not self.comm.burned:
+            raise ValueError("The Model.walk method cannot be run in 'main' mode if the "
+                             "Model's Community has not yet been burned in (i.e. if "
+                             "Model.comm.burned is False).")
+        if animate not in (False, None):
+            raise NotImplementedError('plotting is outside the GPU hot path (SURVEY 2)')
+        old_verbose = self._verbose
+        self._verbose = verbose
+        if self._verbose:
+            print('\n')
+        for _ in range(T):
+            if mode == 'burn' and self.comm.burned:
+                break
+            if self.burn_fn_queue is None:
+                if self._verbose:
+                    print('No mod.burn_fn_queue was found. Running mod.reset()...\n\n',
+                          flush=True)
+                self._reset()
+            if self._do_timestep(mode=mode):
+                break
+        self._verbose = old_verbose
+
+    def burn(self):
+        """reference sim/model.py:1166-1181"""
+        if self.comm.burned:
+            print('\nModel has already been burned in.\n')
+        else:
+            while not self.comm.burned:
+                self.walk(10, 'burn')
+                if np.any([spp.extinct for spp in self.comm.values()]):
+                    break
+            print('\nModel has now been burned in.\n')
+
+    # -- accessors (reference sim/model.py:2787-3147): rows sorted by individual id -----
+    def get_coords(self, spp=0, individs=None):
+        spp = self.comm[self._get_spp_num(spp)]
+        return spp._get_coords(individs=None if individs is None else np.sort(individs))
+
+    def get_x(self, spp=0, individs=None):
+        spp = self.comm[self._get_spp_num(spp)]
+        return spp._get_x(individs=None if individs is None else np.sort(individs))
+
+    def get_y(self, spp=0, individs=None):
+        spp = self.comm[self._get_spp_num(spp)]
+        return spp._get_y(individs=None if individs is None else np.sort(individs))
+
+    def get_cells(self, spp=0, individs=None):
+        spp = self.comm[self._get_spp_num(spp)]
+        return spp._get_cells(individs=None if individs is None else np.sort(individs))
+
+    def get_random_individs(self, n, spp=0):
+        spp = self.comm[self._get_spp_num(spp)]
+        ids = np.array([*spp])
+        return self._rng.choice(ids, n, replace=False)
+
+    def get_e(self, spp=0, lyr_num=None, individs=None):
+        spp = self.comm[self._get_spp_num(spp)]
+        return spp._get_e(lyr_num=lyr_num,
+                          individs=None if individs is None else np.sort(individs))
+
+    def get_z(self, spp=0, trt=None, individs=None):
+        spp = self.comm[self._get_spp_num(spp)]
+        trt = self._get_trt_num(spp, trt)
+        return spp._get_z(trait_num=trt,
+                          individs=None if individs is None else np.sort(individs))
+
+    def get_fitness(self, spp=0, trt=None, individs=None):
+        spp = self.comm[self._get_spp_num(spp)]
+        return spp._get_fit(individs=None if individs is None else np.sort(individs))
+
+    def get_genotypes(self, spp=0, loci=None, individs=None, biallelic=False):
+        spp = self.comm[self._get_spp_num(spp)]
+        return spp._get_genotypes(loci=loci, individs=individs, biallelic=biallelic)

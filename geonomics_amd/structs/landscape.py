@@ -1,0 +1,175 @@
+"""Landscape containers (reference: geonomics/structs/landscape.py Layer:34,
+Landscape:245, _make_landscape:522).
+
+The hot path only reads `lyr.rast`; the rasters are mirrored to the GPU as
+float32 [n_layers][H][W] by the Species' device state.  Layer construction is
+one-off host work: 'defined' and 'random' layers are built here; 'file' and
+'nlmpy' layers need rasterio / nlmpy, which are file-I/O and third-party
+generators outside the hot path - pass such rasters in as
+'defined' layers instead.
+"""
+import numpy as np
+
+
+class Layer:
+    """One environmental raster in [0, 1]; rast is indexed [y, x], dim = (x, y)."""
+
+    def __init__(self, rast, lyr_type, name, dim, res=(1, 1), ulc=(0, 0),
+                 prj=None, coord_prec=0, units='', scale_min=0, scale_max=1):
+        self.idx = None
+        self.type = lyr_type
+        self.name = str(name)
+        assert type(dim) in [tuple, list], 'dim must be expressed as a tuple or a list'
+        self.dim = tuple(dim)
+        self.res = res
+        self.ulc = ulc
+        self.prj = prj
+        self.coord_prec = coord_prec
+        self.units = units
+        assert isinstance(rast, np.ndarray), 'rast should be a numpy.ndarray'
+        self.rast = rast
+        self._scale_min = scale_min
+        self._scale_max = scale_max
+        self._is_K = []
+
+    def __str__(self):
+        return "<Layer '%s' (%s), dim %s>" % (self.name, self.type, str(self.dim))
+
+    __repr__ = __str__
+
+
+class Landscape(dict):
+    """Serial-integer-keyed dict of Layers (reference structs/landscape.py:245)."""
+
+    def __init__(self, lyrs, res=(1, 1), ulc=(0, 0), prj=None, mod=None):
+        assert all(lyr.__class__.__name__ == 'Layer' for lyr in lyrs.values()), (
+            'All layers supplied in lyrs must be of type landscape.Layer.')
+        self.update(lyrs)
+        self.n_lyrs = len(self)
+        for k, v in self.items():
+            v.idx = k
+        assert len(set([lyr.dim for lyr in self.values()])) == 1, (
+            'Dimensions of all layers must be equal.')
+        self.dim = list(self.values())[0].dim
+        self._dim_om = max([len(str(d)) for d in self.dim])
+        self.res = res
+        self._res_ratio = tuple(np.abs([val / max(self.res) for val in self.res]))
+        self.ulc = ulc
+        self.prj = prj
+        self._x_cell_bds, self._y_cell_bds = [
+            np.linspace(self.ulc[i], self.ulc[i] + (self.res[i] * self.dim[i]),
+                        self.dim[i] + 1) for i in range(2)]
+        for lyr in lyrs.values():
+            assert lyr.rast.shape == (self.dim[1], self.dim[0]), (
+                "Layer '%s' has raster shape %s; expected (y, x) = %s" % (
+                    lyr.name, str(lyr.rast.shape), str((self.dim[1], self.dim[0]))))
+            assert np.all(0 <= lyr.rast), "Layer '%s' contains values less than 0." % lyr.name
+            assert np.all(lyr.rast <= 1), "Layer '%s' contains values greater than 1." % lyr.name
+        self._changer = None
+
+    def _get_lyr_num(self, lyr_id):
+        if isinstance(lyr_id, int) or lyr_id is None:
+            return lyr_id
+        nums = [k for k, lyr in self.items() if lyr.name == lyr_id]
+        assert len(nums) == 1, ("Expected to find a single Layer with a name "
+                                "matching the name provided (%s). Instead found "
+                                "%i.") % (lyr_id, len(nums))
+        return nums[0]
+
+    def _stack(self):
+        """float32 [n_layers][H][W] for the device."""
+        return np.stack([np.asarray(self[k].rast, dtype=np.float32)
+                         for k in sorted(self.keys())])
+
+    def __str__(self):
+        return '%s\n%i Layer%s: %s' % (str(type(self)), self.n_lyrs,
+                                       's' * (len(self) > 1),
+                                       ', '.join("'%s'" % l.name for l in self.values()))
+
+    __repr__ = __str__
+
+
+def _make_random_lyr(dim, n_pts, interp_method='cubic', num_hab_types=2, rng=None):
+    """Random layer by interpolating beta(0.05, 0.05) seed points placed well
+    beyond the landscape (reference structs/landscape.py:417-467)."""
+    from scipy import interpolate
+    rng = np.random if rng is None else rng
+    max_dim = max(dim)
+    vals = rng.beta(0.05, 0.05, n_pts)
+    if interp_method == 'nearest':
+        vals = vals * (num_hab_types - 1)
+    pts = rng.normal(max_dim / 2, max_dim * 2, [n_pts, 2])
+    grid_x, grid_y = np.mgrid[1:max_dim:complex('%ij' % max_dim),
+                              1:max_dim:complex('%ij' % max_dim)]
+    img = interpolate.griddata(pts, vals, (grid_x, grid_y), method=interp_method)
+    if interp_method == 'nearest':
+        img = img.round().astype(float)
+    if interp_method == 'cubic':
+        img = img + abs(img.min()) + (0.01 * rng.rand())
+        img = img / (img.max() + (0.01 * rng.rand()))
+    if dim[0] != dim[1]:
+        img = img[:dim[1], :dim[0]]
+    return np.clip(np.nan_to_num(img, nan=0.0), 0, 1)
+
+
+def _make_defined_lyr(dim, rast=None, pts=None, vals=None, interp_method='cubic',
+                      num_hab_types=2, rng=None):
+    """reference structs/landscape.py:470-519"""
+    if rast is not None:
+        return np.asarray(rast, dtype=np.float64)
+    from scipy import interpolate
+    rng = np.random if rng is None else rng
+    vals = np.asarray(vals, dtype=float)
+    if interp_method == 'nearest':
+        vals = vals * (num_hab_types - 1)
+    max_dim = max(dim)
+    grid_x, grid_y = np.mgrid[1:max_dim:complex('%ij' % max_dim),
+                              1:max_dim:complex('%ij' % max_dim)]
+    img = interpolate.griddata(pts, vals, (grid_x, grid_y), method=interp_method)
+    if interp_method == 'nearest':
+        img = img.round().astype(float)
+    if interp_method == 'cubic':
+        img = img + abs(img.min()) + (0.01 * rng.rand())
+        img = img / (img.max() + (0.01 * rng.rand()))
+    if dim[0] != dim[1]:
+        img = img[:dim[1], :dim[0]]
+    return img
+
+
+def _make_landscape(mod, params, num_hab_types=2, verbose=False):
+    """reference structs/landscape.py:522-700 (layer types 'random' and
+    'defined'; change events are outside the hot path)."""
+    if verbose:
+        print('\tMAKING LANDSCAPE...\n')
+    main = params.landscape.main
+    dim = tuple(main.dim)
+    res = main.res if main.get('res', None) is not None else (1, 1)
+    ulc = main.ulc if main.get('ulc', None) is not None else (0, 0)
+    prj = main.get('prj', None)
+    lyrs = {}
+    for n, (lyr_name, lyr_params) in enumerate(params.landscape.layers.items()):
+        init = dict(lyr_params['init'])
+        keys = [*init]
+        if len(keys) > 1:
+            raise ValueError(("The %ith layer ('%s') appears to have parameters for "
+                              "more than one layer type.") % (n, str(lyr_name)))
+        kind = keys[0]
+        if kind == 'random':
+            rast = _make_random_lyr(dim, num_hab_types=num_hab_types, **dict(init[kind]))
+        elif kind == 'defined':
+            rast = _make_defined_lyr(dim, num_hab_types=num_hab_types, **dict(init[kind]))
+        elif kind in ('file', 'nlmpy'):
+            raise NotImplementedError(
+                "Layer type '%s' needs %s, which is outside the GPU hot path; read "
+                "the raster yourself and pass it as a 'defined' layer ('rast')." % (
+                    kind, 'rasterio/GDAL' if kind == 'file' else 'nlmpy'))
+        else:
+            raise ValueError("invalid layer type '%s' (valid: 'random', 'defined', "
+                             "'file', 'nlmpy')" % kind)
+        lyrs[n] = Layer(np.asarray(rast, dtype=np.float64), lyr_type=kind, name=lyr_name,
+                        dim=dim, res=res, ulc=ulc, prj=prj)
+        if 'change' in lyr_params:
+            raise NotImplementedError(
+                'Landscape change events (ops/change.py) are outside the hot path '
+                'built so far (SURVEY 8f rank 2).')
+    return Landscape(lyrs, res=res, ulc=ulc, prj=prj, mod=mod)

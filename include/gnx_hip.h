@@ -154,6 +154,8 @@ int gnx_upload_genomes(gnx_state* h, const uint64_t* geno /*[N][2][W64]*/);
 int gnx_assign_genomes(gnx_state* h, const int32_t* n_per_site /*[L]*/);
 /* recompute all phenotypes (Species._set_z, structs/species.py:925)         */
 int gnx_set_z(gnx_state* h);
+/* phenotypes of slots [first, first+n) only (Species._set_z_individ, :929)   */
+int gnx_set_z_range(gnx_state* h, int64_t first, int64_t n);
 
 /* ---- one time step ------------------------------------------------------- */
 /* Species._set_age_stage (structs/species.py:567)                           */
@@ -166,6 +168,13 @@ int gnx_move(gnx_state* h);
  * burn != 0: no genomes/selection (burn-in).  Appends to Nt/births/deaths
  * counters readable with gnx_counts().                                      */
 int gnx_pop_dynamics(gnx_state* h, int32_t burn, int32_t with_selection);
+/* the same in two halves, so that the host can apply this step's mutations to
+ * the new offspring in between, where the reference does
+ * (structs/species.py:807-809): _mate = pairs, n_pairs density, births;
+ * _die = N density, d, death probabilities, mortality.  After _mate the
+ * offspring occupy slots [N_before, N_before + births).                     */
+int gnx_pop_dynamics_mate(gnx_state* h, int32_t burn);
+int gnx_pop_dynamics_die(gnx_state* h, int32_t burn, int32_t with_selection);
 /* whole fn-queue entry for one step: age, move (if params.move), pop dynamics
  * (sim/model.py:603-667)                                                    */
 int gnx_step(gnx_state* h, int32_t burn, int32_t with_selection);

@@ -544,9 +544,10 @@ def g11_conductance():
 # ---------------------------------------------------------------- G10
 def g10_envelopes():
     """Whole-model envelopes from the reference: neutral 2-layer model, real
-    burn-in (ADF stubbed to pass; paired t-tests active), 60 main steps."""
+    burn-in (ADF stubbed to pass; paired t-tests active), 100 main steps,
+    8 seeds (each with its own randomly drawn trait architecture)."""
     out = {}
-    for s in (1, 2, 3):
+    for s in range(1, 9):
         mod = make_ref_model(dim=(30, 30), N=300, L=60, traits=True,
                              K_factor=0.5, r_alpha=0.5, n_recomb=60, seed=s,
                              mating_radius=4)

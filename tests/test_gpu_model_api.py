@@ -1,0 +1,136 @@
+"""The Geonomics API (make_model / walk / run / accessors) on the HIP path."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def small_params(seed=3, traits=True, L=64, n_its=1, T=12, sex=False, dim=(30, 30)):
+    import geonomics_amd as gnx
+    from geonomics_amd.sim import params as P
+    sp = {'genomes': True}
+    if traits:
+        sp['n_traits'] = 2
+    d = P.default_params_dict(layers=[{'type': 'defined'}, {'type': 'defined'}],
+                              species=[sp])
+    W, H = dim
+    d['landscape']['main']['dim'] = dim
+    d['landscape']['layers']['lyr_0']['init']['defined']['rast'] = np.ones((H, W))
+    d['landscape']['layers']['lyr_1']['init']['defined']['rast'] = \
+        np.tile(np.linspace(0, 1, W), (H, 1))
+    s = d['comm']['species']['spp_0']
+    s['init'].update({'N': 300, 'K_factor': 0.5})
+    s['mating'].update({'mating_radius': 4, 'sex': sex})
+    s['gen_arch'].update({'L': L, 'n_recomb_sims': 200, 'use_tskit': False})
+    if traits:
+        s['gen_arch']['traits']['trait_0'].update({'layer': 'lyr_1', 'n_loci': 4})
+        s['gen_arch']['traits']['trait_1'].update({'layer': 'lyr_0', 'n_loci': 1,
+                                                   'univ_adv': True, 'gamma': 2})
+    d['model'].update({'T': T, 'burn_T': 30, 'seed': {'num': seed}})
+    d['model']['its']['n_its'] = n_its
+    return gnx.make_params_dict(d, 'api_test')
+
+
+def test_make_model_burn_walk_accessors():
+    import geonomics_amd as gnx
+    mod = gnx.make_model(small_params())
+    spp = mod.comm[0]
+    assert len(spp) == 300 and mod.t == -1 and not mod.comm.burned
+    with pytest.raises(ValueError):
+        mod.walk(1, 'main', verbose=False)
+    mod.walk(10000, 'burn', verbose=False)
+    assert mod.comm.burned and spp.burned
+    nburn = len(spp.Nt)
+    assert 30 <= nburn < 400            # reference burn-ins end at ~58-65 steps here
+    assert mod.burn_t == nburn - 1
+    # burn-in equilibrium of this configuration in the reference: N ~ 317-322
+    assert 280 < np.mean(spp.Nt[10:]) < 360
+    mod.walk(12, 'main', verbose=False)
+    assert mod.t == 11 and spp.t == 11 and len(spp.Nt) == nburn + 12
+    n = len(spp)
+    assert n == spp.Nt[-1] > 0
+    ids = np.array([*spp])
+    assert (np.diff(ids) > 0).all() and len(ids) == n
+    xy = mod.get_coords()
+    assert xy.shape == (n, 2) and (xy >= 0).all() and (xy < 30).all()
+    np.testing.assert_array_equal(mod.get_cells(), np.int32(np.floor(xy)))
+    e = mod.get_e()
+    rast1 = np.tile(np.linspace(0, 1, 30), (30, 1)).astype(np.float32)
+    cells = mod.get_cells()
+    np.testing.assert_allclose(e[:, 1], rast1[cells[:, 1], cells[:, 0]], atol=1e-7)
+    np.testing.assert_array_equal(e[:, 0], 1.0)
+    G = mod.get_genotypes(biallelic=True)
+    assert G.shape == (n, 64, 2) and set(np.unique(G)) <= {0, 1}
+    z = mod.get_z()
+    ga = spp.gen_arch
+    for t, trt in ga.traits.items():
+        gt = G[:, trt.loci, :].mean(axis=2)
+        zz = 0.5 + (gt * trt.alpha).sum(1) if trt.n_loci > 1 else gt[:, 0]
+        np.testing.assert_allclose(z[:, t], zz, atol=2e-7)
+    fit = mod.get_fitness()
+    assert fit.shape == (n,) and (fit > 0).all() and (fit <= 1).all()
+    # subset accessors are sorted by id regardless of input order
+    sub = ids[[5, 2, 9]]
+    np.testing.assert_array_equal(mod.get_x(individs=sub), mod.get_x()[[2, 5, 9]])
+    ind = spp[int(ids[0])]
+    assert ind.idx == ids[0] and ind.g.shape == (64, 2)
+    assert spp.N.shape == (30, 30) and spp.K.shape == (30, 30)
+    assert abs(spp.N.sum() - n) / n < 0.2
+
+
+def test_run_iterations_and_reproducibility():
+    import geonomics_amd as gnx
+
+    def run(seed):
+        mod = gnx.make_model(small_params(seed=seed, n_its=2, T=6))
+        mod.run(verbose=False)
+        spp = mod.comm[0]
+        return list(spp.Nt), mod.get_genotypes(biallelic=True), mod.it, mod.t
+
+    a = run(5)
+    b = run(5)
+    c = run(6)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1])
+    assert a[2] == 1 and a[3] == 5          # second iteration, 6 main steps
+    assert a[0] != c[0]
+
+
+def test_sexed_species_and_panmixia():
+    import geonomics_amd as gnx
+    p = small_params(sex=True, traits=False)
+    mod = gnx.make_model(p)
+    mod.walk(10000, 'burn', verbose=False)
+    mod.walk(5, 'main', verbose=False)
+    assert len(mod.comm[0]) > 50
+    p = small_params(traits=False)
+    p.comm.species.spp_0.mating.mating_radius = None
+    mod = gnx.make_model(p)
+    mod.walk(10000, 'burn', verbose=False)
+    mod.walk(5, 'main', verbose=False)
+    assert len(mod.comm[0]) > 50
+
+
+def test_parameters_file_round_trip(tmp_path):
+    import geonomics_amd as gnx
+    f = str(tmp_path / 'GNX_params_rt.py')
+    gnx.make_parameters_file(f, layers=[{'type': 'defined'}],
+                             species=[{'genomes': True, 'n_traits': 1}])
+    txt = open(f).read().replace("'use_tskit':                                " +
+                                 "True", "'use_tskit': False")
+    open(f, 'w').write(txt)
+    mod = gnx.make_model(f)
+    assert mod.name == 'GNX_params_rt' and len(mod.comm[0]) == 250
+    mod.walk(10000, 'burn', verbose=False)
+    mod.walk(3, 'main', verbose=False)
+    assert mod.t == 2
+
+
+def test_extinction_is_not_an_error():
+    import geonomics_amd as gnx
+    p = small_params(traits=False)
+    p.comm.species.spp_0.mortality.d_min = 1.0     # everyone dies
+    mod = gnx.make_model(p)
+    mod.walk(5, 'burn', verbose=False)
+    assert mod.comm[0].extinct and len(mod.comm[0]) == 0

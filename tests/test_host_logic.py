@@ -1,0 +1,147 @@
+"""Host-side logic of the drop-in layer (no GPU): parameters-file format,
+landscape construction, genomic architecture, burn-in statistics."""
+import numpy as np
+import pytest
+
+import gnx_oracle as O
+
+
+def test_params_template_and_reader(tmp_path):
+    import geonomics_amd as gnx
+    from geonomics_amd.sim import params as P
+    f = str(tmp_path / 'GNX_params_x.py')
+    gnx.make_parameters_file(f, layers=2, species=[{'genomes': True, 'n_traits': 2,
+                                                    'movement_surface': True}],
+                             data=True, stats=True)
+    p = gnx.read_parameters_file(f)
+    assert p.model.name == 'GNX_params_x'
+    assert p.landscape.main.dim == (20, 20)
+    s = p.comm.species.spp_0
+    assert s.mating.b == 0.2 and s.mating.mating_radius == 10
+    assert s.movement.move_surf.vm_distr_kappa == 12
+    assert s.gen_arch.n_recomb_sims == 10000 and s.gen_arch.r_distr_alpha == 0.5
+    assert [*s.gen_arch.traits] == ['trait_0', 'trait_1']
+    assert p.model.its.n_its == 1 and p.model.T == 100 and p.model.burn_T == 30
+    # dot access and item access agree; deepcopy keeps the type
+    import copy
+    q = copy.deepcopy(p)
+    q.model.T = 5
+    assert p['model']['T'] == 100 and type(q) is P.ParametersDict
+    with pytest.raises(ValueError):
+        P.ParametersDict({'model': {'keys': 1}})
+    # duplicate names are rejected (reference main.py:336-396)
+    txt = open(f).read().replace("'lyr_1'", "'lyr_0'")
+    open(f, 'w').write(txt)
+    with pytest.raises(ValueError):
+        gnx.read_parameters_file(f)
+
+
+def test_defined_layer_needs_np_in_namespace(tmp_path):
+    import geonomics_amd as gnx
+    f = str(tmp_path / 'GNX_params_np.py')
+    gnx.make_parameters_file(f, layers=[{'type': 'defined'}])
+    p = gnx.read_parameters_file(f)
+    assert p.landscape.layers.lyr_0.init.defined.rast.shape == (20, 20)
+
+
+def test_landscape_construction():
+    from geonomics_amd.sim import params as P
+    from geonomics_amd.structs.landscape import _make_landscape
+    d = P.default_params_dict(layers=[{'type': 'defined'}, {'type': 'random'}])
+    d['landscape']['main']['dim'] = (12, 9)
+    d['landscape']['layers']['lyr_0']['init']['defined']['rast'] = np.full((9, 12), 0.5)
+    p = P.ParametersDict(d)
+    np.random.seed(0)
+    land = _make_landscape(None, p)
+    assert land.dim == (12, 9) and land.n_lyrs == 2
+    assert land[1].rast.shape == (9, 12)
+    assert land[1].rast.min() >= 0 and land[1].rast.max() <= 1
+    assert land._stack().shape == (2, 9, 12) and land._stack().dtype == np.float32
+    assert land._get_lyr_num('lyr_1') == 1
+    d['landscape']['layers']['lyr_0']['init']['defined']['rast'] = np.full((9, 12), 1.5)
+    with pytest.raises(AssertionError):
+        _make_landscape(None, P.ParametersDict(d))
+
+
+def _spp_params(L=300, alpha=0.01, beta=None, n=40, traits=True):
+    from geonomics_amd.sim import params as P
+    d = P.default_params_dict(layers=[{'type': 'defined'}, {'type': 'defined'}],
+                              species=[{'genomes': True, 'n_traits': 2 if traits else 0}])
+    s = d['comm']['species']['spp_0']
+    s['gen_arch'].update({'L': L, 'r_distr_alpha': alpha, 'r_distr_beta': beta,
+                          'n_recomb_sims': n, 'use_tskit': False})
+    if traits:
+        s['gen_arch']['traits']['trait_0'].update({'n_loci': 5, 'layer': 'lyr_1'})
+    return P.ParametersDict(d)
+
+
+@pytest.mark.parametrize('alpha,beta', [(0.01, None), (0.5, None), (None, None),
+                                        (2.0, 30.0)])
+def test_recombination_paths(alpha, beta):
+    from geonomics_amd.structs.genome import _make_genomic_architecture
+    from geonomics_amd.structs.landscape import _make_landscape
+    p = _spp_params(alpha=alpha, beta=beta, n=400)
+    land = _make_landscape(None, p)
+    rng = np.random.RandomState(1)
+    ga = _make_genomic_architecture(p.comm.species.spp_0, land, rng=rng)
+    rec = ga.recombinations
+    assert rec._rates[0] == 0 and (rec._rates <= 0.5).all()
+    paths = O.unpack_bits(rec._paths, ga.L)
+    assert paths.shape == (400, ga.L)
+    assert (paths[:, 0] == 0).all()               # r_0 = 0: every path starts on hom 0
+    sw = (paths[:, 1:] != paths[:, :-1])
+    # breakpoint density ~ per-locus rate (reference tests/validation/recomb)
+    exp = rec._rates[1:].sum()
+    got = sw.sum(axis=1).mean()
+    assert abs(got - exp) < 5 * np.sqrt(max(exp, 0.5) / 400) + 0.02 * exp
+    # padding bits are zero
+    assert (O.unpack_bits(rec._paths, rec._paths.shape[1] * 64)[:, ga.L:] == 0).all()
+    # traits: loci sorted, distinct across traits (no pleiotropy), monogenic alpha 0.5
+    t0, t1 = ga.traits[0], ga.traits[1]
+    assert (np.diff(t0.loci) > 0).all() and t0.n_loci == 5 and t1.n_loci == 1
+    assert not set(t0.loci) & set(t1.loci)
+    np.testing.assert_allclose(t0.alpha, [0.1, -0.1, 0.1, -0.1, 0.1])
+    np.testing.assert_allclose(t1.alpha, [0.5])
+    assert len(ga.neut_loci) == ga.L - 6 and (ga.p == 0.5).all()
+
+
+def test_starting_counts_match_oracle():
+    from geonomics_amd.structs.genome import _starting_mutation_counts
+    rng = np.random.RandomState(2)
+    p = rng.rand(200)
+    p[:4] = [0, 1, 1e-9, 1 - 1e-9]
+    np.testing.assert_array_equal(_starting_mutation_counts(77, p),
+                                  O.starting_mutation_counts(77, p))
+
+
+def test_adfuller_behaviour():
+    from geonomics_amd.sim.burnin import adfuller, mackinnonp
+    rng = np.random.RandomState(0)
+    # MacKinnon (1994) asymptotic critical values for 'c', N=1: -2.86 (5%), -3.43 (1%)
+    assert abs(mackinnonp(-2.86) - 0.05) < 0.003
+    assert abs(mackinnonp(-3.43) - 0.01) < 0.002
+    assert abs(mackinnonp(-2.57) - 0.10) < 0.005
+    assert mackinnonp(3.0) == 1.0 and mackinnonp(-20) == 0.0
+    rej_stat = rej_rw = 0
+    for k in range(40):
+        e = rng.randn(120)
+        x = np.zeros(120)
+        for t in range(1, 120):
+            x[t] = 0.3 * x[t - 1] + e[t]
+        rej_stat += adfuller(x + 300)[1] < 0.05
+        rej_rw += adfuller(np.cumsum(e) + 300)[1] < 0.05
+    assert rej_stat >= 36          # stationary AR(1): unit root rejected
+    assert rej_rw <= 8             # random walk: ~5 % false rejections
+    with pytest.raises(ValueError):
+        adfuller(np.ones(30))
+    with pytest.raises(ValueError):
+        adfuller(np.arange(3.0))
+
+
+def test_spatial_test_needs_enough_samples():
+    from geonomics_amd.sim.burnin import spatial_test
+    rng = np.random.RandomState(1)
+    short = {'mean': [0.0, 0.1], 'std': [1.0, 1.1]}
+    assert spatial_test(short, 30) is False
+    ok = {'mean': list(rng.randn(60) * 0.01), 'std': list(1 + rng.randn(60) * 0.01)}
+    assert spatial_test(ok, 30) in (True, False)
