@@ -150,6 +150,8 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
     GNXCHK(dalloc(&h->perm[k], cap));
   }
   GNXCHK(dalloc(&h->mate, cap));
+  GNXCHK(dalloc(&h->tag, cap));
+  HIPCHK(hipMalloc(&h->cand, (size_t)cap * 16));
   GNXCHK(dalloc(&h->flag, cap + 1));
   GNXCHK(dalloc(&h->flag2, cap + 1));
   GNXCHK(dalloc(&h->scan, cap + 1));
@@ -189,11 +191,11 @@ extern "C" void gnx_destroy(gnx_state* h) {
     (void)hipFree(h->counts_rast[k]);
   }
   void* ptrs[] = {h->rast, h->G, h->free_rows, h->paths, h->bp_off, h->bp_loci, h->dom,
-                  h->delet_loci, h->delet_s, h->cell_start, h->sort_tmp, h->scan_tmp, h->mate,
+                  h->delet_loci, h->delet_s, h->cell_start, h->tag, h->cand, h->sort_tmp, h->scan_tmp, h->mate,
                   h->flag, h->flag2, h->scan, h->pairs, h->nbirths, h->boff, h->off_pair,
                   h->off_parent, h->off_keys, h->off_start, h->keep_in, h->inj_a, h->inj_b,
                   h->mid_x, h->mid_y, h->p_death, h->d_cell, h->dead_in, h->nmax_bits, h->red,
-                  h->lat.areas, h->lat.cprime, h->spl_N.c, h->spl_P.c, h->bin_partials, h->nodes};
+                  h->tl_loci, h->tbits, h->lat.areas, h->lat.cprime, h->spl_N.c, h->spl_P.c, h->bin_partials, h->nodes};
   for (void* p : ptrs) (void)hipFree(p);
   for (int t = 0; t < GNX_MAX_TRAITS; ++t) {
     (void)hipFree(h->traits[t].loci);
@@ -292,8 +294,7 @@ static int setup_lattice(gnx_state* h) {
   GNXCHK(dalloc(&h->spl_P.c, 4 * nn));
   GNXCHK(dalloc(&h->nodes, nn));
   size_t nb = (size_t)L.nbx * L.nby;
-  size_t parts = nb * sizeof(int32_t) <= 48 * 1024 ? 512 : 1;
-  GNXCHK(dalloc(&h->bin_partials, nb * parts));
+  GNXCHK(dalloc(&h->bin_partials, nb));
   HIPCHK(hipMemcpy(L.areas, areas.data(), nn * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(L.cprime, cp.data(), (Jm + 1) * sizeof(double), hipMemcpyHostToDevice));
   h->spl_N.valid = h->spl_P.valid = false;
@@ -480,6 +481,19 @@ extern "C" int gnx_set_trait(gnx_state* h, int32_t t, int32_t n_loci, const int3
   r.phi = phi;
   r.gamma = gamma;
   r.univ_adv = univ_adv;
+  // rebuild the concatenated trait-locus table used by the crossover epilogue
+  h->h_trait_loci[t].assign(loci, loci + n_loci);
+  std::vector<int32_t> all;
+  for (int q = 0; q < h->cfg.n_traits; ++q)
+    all.insert(all.end(), h->h_trait_loci[q].begin(), h->h_trait_loci[q].end());
+  (void)hipFree(h->tl_loci);
+  (void)hipFree(h->tbits);
+  h->tl_loci = nullptr;
+  h->tbits = nullptr;
+  h->n_tl = (int)all.size();
+  GNXCHK(dalloc(&h->tl_loci, all.size()));
+  GNXCHK(dalloc(&h->tbits, (size_t)2 * h->cfg.cap_inds * all.size()));
+  HIPCHK(hipMemcpy(h->tl_loci, all.data(), all.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   return 0;
 }
 

@@ -3,6 +3,7 @@
 #include <cstring>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 #include <utility>
@@ -123,6 +124,12 @@ struct gnx_state {
 
   // traits etc
   GnxTrait traits[GNX_MAX_TRAITS];
+  // all trait loci concatenated trait-major (the crossover epilogue extracts
+  // the new gametes' alleles at these loci into tbits[gamete][n_tl])
+  std::vector<int32_t> h_trait_loci[GNX_MAX_TRAITS];
+  int n_tl = 0;
+  int32_t* tl_loci = nullptr;
+  uint8_t* tbits = nullptr;      // [2 * cap][n_tl]
   uint8_t* dom = nullptr;
   int n_delet = 0;
   int32_t* delet_loci = nullptr;
@@ -134,6 +141,8 @@ struct gnx_state {
   uint32_t* key[2]{};
   int32_t* perm[2]{};
   int32_t* cell_start = nullptr;
+  void* cand = nullptr;          // uint4 {x, y, tag, id_lo} per individual, sorted order
+  uint32_t* tag = nullptr;       // per-individual mate-choice tag of this step (sorted order)
   void* sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
   void* scan_tmp = nullptr;
@@ -204,6 +213,7 @@ int gnx_l_dispersal_inject(gnx_state* h, int64_t B, int A, const float* d_mx, co
                            int32_t* d_used);
 int gnx_l_crossover(gnx_state* h, int64_t first_slot, int64_t B);
 int gnx_l_phenotype(gnx_state* h, int64_t first_slot, int64_t n);
+int gnx_l_phenotype_births(gnx_state* h, int64_t first_slot, int64_t n);
 int gnx_l_assign_genomes(gnx_state* h, const int32_t* d_n_per_site);
 int gnx_l_mutate(gnx_state* h, int n, const int64_t* d_slot, const int32_t* d_locus,
                  const uint8_t* d_hom);

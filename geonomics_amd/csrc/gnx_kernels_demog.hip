@@ -30,8 +30,12 @@ k_bins(int64_t n, const float* x, const float* y, double inv_hww, int nbx, int n
     atomicAdd(&lds_hist[hy * nbx + hx], 1);
   }
   __syncthreads();
-  int32_t* out = partials + (int64_t)blockIdx.x * nb;
-  for (int k = threadIdx.x; k < nb; k += blockDim.x) out[k] = lds_hist[k];
+  // flush: one integer atomic per non-empty bin per block (counts are exact and
+  // order-independent, so the result is deterministic)
+  for (int k = threadIdx.x; k < nb; k += blockDim.x) {
+    int v = lds_hist[k];
+    if (v) atomicAdd(&partials[k], v);
+  }
 }
 
 // variant for lattices too large for LDS: global atomics into partials[0]
@@ -150,13 +154,11 @@ int gnx_l_density(gnx_state* h, int64_t n, const float* d_x, const float* d_y, G
     int n_part;
     if ((size_t)nb * sizeof(int32_t) <= 48 * 1024) {
       n_part = (int)std::min<int64_t>(BIN_BLOCKS, std::max<int64_t>(1, (n + 255) / 256));
-      if (n == 0) {
-        n_part = 1;
-        HIPCHK(hipMemsetAsync(h->bin_partials, 0, (size_t)nb * sizeof(int32_t), h->stream));
-      } else {
+      HIPCHK(hipMemsetAsync(h->bin_partials, 0, (size_t)nb * sizeof(int32_t), h->stream));
+      if (n > 0)
         hipLaunchKernelGGL(k_bins, dim3(n_part), dim3(256), (size_t)nb * sizeof(int32_t), h->stream,
                            n, d_x, d_y, 1.0 / L.hww, L.nbx, L.nby, h->bin_partials);
-      }
+      n_part = 1;
     } else {
       n_part = 1;
       HIPCHK(hipMemsetAsync(h->bin_partials, 0, (size_t)nb * sizeof(int32_t), h->stream));

@@ -19,94 +19,145 @@ struct alignas(16) u64x2 {
 // ops/mating.py:130-214.  For gamete p in {0,1} of an offspring:
 //   gamete[l] = parent_p.g[l, path_{k_p}[l] XOR s_p]
 // i.e. with m = path ^ (-s):  gamete = (hom0 & ~m) | (hom1 & m), 128 bits per
-// lane per iteration.  child hom 0 <- parent pair[0], hom 1 <- pair[1] (:169).
+// lane per access.  child hom 0 <- parent pair[0], hom 1 <- pair[1] (:169).
 //
-// One work item = one 16-byte chunk of one gamete; a thread owns UNROLL chunks
-// spaced one block apart so 3*UNROLL independent 16-byte loads are in flight.
+// One WAVEFRONT owns one gamete at a time (grid-stride over the 2B gametes):
+// parent row, child row, path key and start homologue are wave-uniform (scalar
+// registers, no per-chunk metadata chain), and the 64 lanes stream the
+// homologue in 16-byte chunks, 1 KiB per wave-instruction, four independent
+// chunks in flight per lane.
 //
 // DENSE : masks are read from the bit-packed path table (any recombination map).
 // SPARSE: masks are rebuilt from the path's short breakpoint list (<= 24
 //         switches); a chunk whose mask is all 0 / all 1 loads only the one
 //         homologue it copies, which halves the read traffic when crossovers
 //         are rare (r = 1/L).
+//
+// Epilogue (fused phenotype input): lane e re-derives the gamete's allele at
+// trait locus e from the just-read (L2-hot) parental chunk and stores it in the
+// compact table tbits[gamete][e], so phenotypes never gather from the fresh
+// 25-KB child rows.
+#define XO_UNROLL 4
+
+template <bool SPARSE>
+__device__ __forceinline__ u64x2 xo_mask(int c, u64 s, const u64x2* __restrict__ path_row,
+                                         const int32_t* __restrict__ bp, int nbp) {
+  u64x2 m;
+  if (SPARSE) {
+    // mask bits of loci [128c, 128c+128): parity of switches at or before l
+    const int lo = c * 128;
+    u64 par = 0;
+    m.a = 0;
+    m.b = 0;
+    for (int q = 0; q < nbp; ++q) {
+      const int bpl = bp[q];
+      if (bpl < lo) {
+        par ^= ~0ull;
+      } else if (bpl < lo + 64) {
+        m.a ^= ~0ull << (bpl - lo);
+        m.b ^= ~0ull;
+      } else if (bpl < lo + 128) {
+        m.b ^= ~0ull << (bpl - lo - 64);
+      }
+    }
+    m.a ^= par ^ s;
+    m.b ^= par ^ s;
+  } else {
+    m = path_row[c];
+    m.a ^= s;
+    m.b ^= s;
+  }
+  return m;
+}
+
+template <bool SPARSE>
+__device__ __forceinline__ u64x2 xo_chunk(int c, u64x2 m, const u64x2* __restrict__ h0,
+                                          const u64x2* __restrict__ h1) {
+  u64x2 out;
+  if (SPARSE && (m.a | m.b) == 0ull) {
+    out = h0[c];
+  } else if (SPARSE && (m.a & m.b) == ~0ull) {
+    out = h1[c];
+  } else {
+    const u64x2 a = h0[c];
+    const u64x2 b = h1[c];
+    out.a = (a.a & ~m.a) | (b.a & m.a);
+    out.b = (a.b & ~m.b) | (b.b & m.b);
+  }
+  return out;
+}
+
 template <bool SPARSE>
 __global__ void __launch_bounds__(256)
 k_crossover(int64_t B, int W16, const u64x2* __restrict__ G, u64x2* __restrict__ Gout,
             const int32_t* __restrict__ grow, int64_t first_slot,
             const int32_t* __restrict__ off_parent, const int32_t* __restrict__ off_keys,
             const uint8_t* __restrict__ off_start, const u64x2* __restrict__ paths,
-            const int32_t* __restrict__ bp_off, const int32_t* __restrict__ bp_loci) {
-  const int64_t total = B * 2 * (int64_t)W16;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
-    const int64_t gam = g / W16;
-    const int c = (int)(g - gam * W16);
+            const int32_t* __restrict__ bp_off, const int32_t* __restrict__ bp_loci, int n_tl,
+            const int32_t* __restrict__ tl_loci, uint8_t* __restrict__ tbits) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t gam = wave0; gam < 2 * B; gam += n_waves) {
     const int64_t k = gam >> 1;
     const int p = (int)(gam & 1);
-    const int prow = grow[off_parent[2 * k + p]];
-    const int key = off_keys[2 * k + p];
-    const u64 s = off_start[2 * k + p] ? ~0ull : 0ull;
-    const int crow = grow[first_slot + k];
+    // wave-uniform metadata
+    const int prow = __builtin_amdgcn_readfirstlane(grow[off_parent[2 * k + p]]);
+    const int key = __builtin_amdgcn_readfirstlane(off_keys[2 * k + p]);
+    const u64 s = __builtin_amdgcn_readfirstlane((int)off_start[2 * k + p]) ? ~0ull : 0ull;
+    const int crow = __builtin_amdgcn_readfirstlane(grow[first_slot + k]);
     const u64x2* h0 = G + ((int64_t)prow * 2 + 0) * W16;
     const u64x2* h1 = G + ((int64_t)prow * 2 + 1) * W16;
-    u64x2 m;
+    u64x2* dst = Gout + ((int64_t)crow * 2 + p) * W16;
+    const u64x2* prow_mask = paths + (int64_t)key * W16;
+    int bp0 = 0, nbp = 0;
     if (SPARSE) {
-      // mask bits of loci [128c, 128c+128): parity of switches at or before l
-      const int lo = c * 128;
-      u64 par = 0;
-      m.a = 0;
-      m.b = 0;
-      for (int q = bp_off[key]; q < bp_off[key + 1]; ++q) {
-        const int bpl = bp_loci[q];
-        if (bpl < lo) {
-          par ^= ~0ull;
-        } else if (bpl < lo + 64) {
-          m.a ^= ~0ull << (bpl - lo);
-          m.b ^= ~0ull;
-        } else if (bpl < lo + 128) {
-          m.b ^= ~0ull << (bpl - lo - 64);
-        } else {
-          break;     // loci ascending
-        }
+      bp0 = __builtin_amdgcn_readfirstlane(bp_off[key]);
+      nbp = __builtin_amdgcn_readfirstlane(bp_off[key + 1]) - bp0;
+    }
+    const int32_t* bp = bp_loci + bp0;
+    for (int c0 = lane; c0 < W16; c0 += 64 * XO_UNROLL) {
+      u64x2 out[XO_UNROLL];
+#pragma unroll
+      for (int u = 0; u < XO_UNROLL; ++u) {
+        const int c = c0 + u * 64;
+        if (c < W16) out[u] = xo_chunk<SPARSE>(c, xo_mask<SPARSE>(c, s, prow_mask, bp, nbp), h0, h1);
       }
-      m.a ^= par ^ s;
-      m.b ^= par ^ s;
-    } else {
-      m = paths[(int64_t)key * W16 + c];
-      m.a ^= s;
-      m.b ^= s;
+#pragma unroll
+      for (int u = 0; u < XO_UNROLL; ++u) {
+        const int c = c0 + u * 64;
+        if (c < W16) dst[c] = out[u];
+      }
     }
-    u64x2 out;
-    if (SPARSE && (m.a | m.b) == 0ull) {
-      out = h0[c];
-    } else if (SPARSE && (m.a & m.b) == ~0ull) {
-      out = h1[c];
-    } else {
-      const u64x2 a = h0[c];
-      const u64x2 b = h1[c];
-      out.a = (a.a & ~m.a) | (b.a & m.a);
-      out.b = (a.b & ~m.b) | (b.b & m.b);
+    // alleles at the trait loci -> compact table for the phenotype kernel
+    for (int e = lane; e < n_tl; e += 64) {
+      const int l = tl_loci[e];
+      const int c = l >> 7;
+      const u64x2 v = xo_chunk<SPARSE>(c, xo_mask<SPARSE>(c, s, prow_mask, bp, nbp), h0, h1);
+      const int bit = l & 127;
+      tbits[gam * n_tl + e] = (uint8_t)(((bit < 64 ? v.a >> bit : v.b >> (bit - 64))) & 1ull);
     }
-    Gout[((int64_t)crow * 2 + p) * W16 + c] = out;
   }
 }
 
 int gnx_l_crossover(gnx_state* h, int64_t first_slot, int64_t B) {
   if (B == 0) return 0;
   const int W16 = h->W64 / 2;
-  const int64_t total = B * 2 * (int64_t)W16;
-  // enough blocks to fill 256 CUs x 8 waves/SIMD, grid-stride beyond that
-  int grid = gnx_grid(total, 256, 256 * 64);
+  // one wave per gamete, 4 waves per block; cap the grid and stride beyond
+  int grid = gnx_grid(2 * B, 4, 256 * 32);
   GnxSoA s = h->soa[h->cur];
+  const int n_tl = h->n_tl;
   gnx_time_begin(h);
   if (h->sparse_paths)
     hipLaunchKernelGGL(k_crossover<true>, dim3(grid), dim3(256), 0, h->stream, B, W16,
                        (const u64x2*)h->G, (u64x2*)h->G, s.grow, first_slot, h->off_parent,
-                       h->off_keys, h->off_start, (const u64x2*)h->paths, h->bp_off, h->bp_loci);
+                       h->off_keys, h->off_start, (const u64x2*)h->paths, h->bp_off, h->bp_loci,
+                       n_tl, h->tl_loci, h->tbits);
   else
     hipLaunchKernelGGL(k_crossover<false>, dim3(grid), dim3(256), 0, h->stream, B, W16,
                        (const u64x2*)h->G, (u64x2*)h->G, s.grow, first_slot, h->off_parent,
-                       h->off_keys, h->off_start, (const u64x2*)h->paths, h->bp_off, h->bp_loci);
+                       h->off_keys, h->off_start, (const u64x2*)h->paths, h->bp_off, h->bp_loci,
+                       n_tl, h->tl_loci, h->tbits);
   // algorithmic bytes per birth.  Dense masks: 4 parental
   // homologues + 2 masks read, 2 homologues written = 8 * L/8 = L bytes.
   // Sparse paths: each gamete chunk copies ONE parental homologue (the other
@@ -115,6 +166,40 @@ int gnx_l_crossover(gnx_state* h, int64_t first_slot, int64_t B) {
   // (padded row width W64*8 is what actually moves)
   gnx_time_end(h, GNX_K_CROSSOVER,
                (double)B * (h->sparse_paths ? 4.0 : 8.0) * (double)h->W64 * 8.0);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// phenotypes of newly born offspring from the compact allele table written by
+// k_crossover (same arithmetic as k_phenotype)
+__global__ void k_phenotype_tbits(int64_t first, int64_t n, int64_t cap, int n_tl,
+                                  const uint8_t* tbits, GnxTraitTab T, const uint8_t* dom,
+                                  float* z) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const uint8_t* t0 = tbits + (2 * k) * n_tl;
+  const uint8_t* t1 = tbits + (2 * k + 1) * n_tl;
+  int e = 0;
+  for (int t = 0; t < T.n_traits; ++t) {
+    const int nl = T.n_loci[t];
+    double acc = 0.0, g0 = 0.0;
+    for (int j = 0; j < nl; ++j, ++e) {
+      double gt = 0.5 * (double)((int)t0[e] + (int)t1[e]);
+      if (dom) gt = fmin(gt * (1.0 + (double)dom[T.loci[t][j]]), 1.0);
+      if (j == 0) g0 = gt;
+      acc = acc + gt * T.alpha[t][j];
+    }
+    z[(int64_t)t * cap + first + k] = (float)(nl > 1 ? 0.5 + acc : g0);
+  }
+}
+
+int gnx_l_phenotype_births(gnx_state* h, int64_t first_slot, int64_t n) {
+  if (n == 0 || h->cfg.n_traits == 0) return 0;
+  gnx_time_begin(h);
+  hipLaunchKernelGGL(k_phenotype_tbits, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream,
+                     first_slot, n, h->cfg.cap_inds, h->n_tl, h->tbits, gnx_trait_tab(h), h->dom,
+                     h->soa[h->cur].z);
+  gnx_time_end(h, GNX_K_PHENOTYPE, (double)n * (2.0 * h->n_tl + 4.0 * h->cfg.n_traits));
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -255,7 +255,8 @@ __global__ void k_keys(int64_t N, const float* x, const float* y, double inv_cs,
 }
 
 __global__ void k_permute(int64_t N, int64_t cap, const int32_t* perm, GnxSoA a, GnxSoA b,
-                          int n_layers, int n_traits) {
+                          int n_layers, int n_traits, unsigned long long pair_seed,
+                          uint32_t* tag, uint4* cand) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   int64_t j = perm[i];
@@ -263,7 +264,12 @@ __global__ void k_permute(int64_t N, int64_t cap, const int32_t* perm, GnxSoA a,
   b.y[i] = a.y[j];
   b.age[i] = a.age[j];
   b.sex[i] = a.sex[j];
-  b.id[i] = a.id[j];
+  const int64_t idv = a.id[j];
+  b.id[i] = idv;
+  const uint32_t tg = gnx_ind_tag(pair_seed, (unsigned long long)idv);
+  tag[i] = tg;
+  // packed candidate record for the mate search: one 16-byte load per candidate
+  cand[i] = make_uint4(__float_as_uint(a.x[j]), __float_as_uint(a.y[j]), tg, (uint32_t)idv);
   b.fit[i] = a.fit[j];
   b.grow[i] = a.grow[j];
   for (int l = 0; l < n_layers; ++l) b.e[(int64_t)l * cap + i] = a.e[(int64_t)l * cap + j];
@@ -297,7 +303,8 @@ int gnx_l_sort_by_cell(gnx_state* h) {
   gnx_time_end(h, GNX_K_SORT, (double)N * 40.0);
   gnx_time_begin(h);
   hipLaunchKernelGGL(k_permute, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, c.cap_inds,
-                     h->perm[1], a, b, c.n_layers, c.n_traits);
+                     h->perm[1], a, b, c.n_layers, c.n_traits, gnx_pair_seed(c.seed, h->step),
+                     h->tag, (uint4*)h->cand);
   hipLaunchKernelGGL(k_cell_bounds, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, h->key[1],
                      h->cell_start, h->ncx * h->ncy);
   gnx_time_end(h, GNX_K_PERMUTE,
@@ -326,21 +333,21 @@ int gnx_l_sort_by_cell(gnx_state* h) {
 // smallest -ln(u)/(r-d).  Ties break on the smaller id.
 template <int MODE>
 __global__ void __launch_bounds__(256)
-k_find_mates(int64_t N, const float* __restrict__ x, const float* __restrict__ y,
-             const int64_t* __restrict__ id, const uint32_t* __restrict__ key,
-             const int32_t* __restrict__ cell_start, int ncx, int ncy, float r, float r2,
-             unsigned long long pair_seed, int32_t* __restrict__ mate) {
+k_find_mates_wave(int64_t N, const float* __restrict__ x, const float* __restrict__ y,
+             const int64_t* __restrict__ id, const uint32_t* __restrict__ tag,
+             const uint32_t* __restrict__ key, const int32_t* __restrict__ cell_start, int ncx,
+             int ncy, float r, float r2, int32_t* __restrict__ mate) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t i = wave * 64 + lane;
   const bool act = i < N;
   float fx = 0.f, fy = 0.f;
-  long long fid = 0;
+  unsigned int ftag = 0;
   int cx = 0, cy = 0;
   if (act) {
     fx = x[i];
     fy = y[i];
-    fid = id[i];
+    ftag = tag[i] * 0x9E3779B1u;
     int k = (int)key[i];
     cy = k / ncx;
     cx = k - cy * ncx;
@@ -349,14 +356,17 @@ k_find_mates(int64_t N, const float* __restrict__ x, const float* __restrict__ y
   int cymax = __builtin_amdgcn_readfirstlane(wave_max_i(act ? cy : -0x7fffffff));
   if (cymin > cymax) return;     // wave has no active lane (uniform)
 
-  unsigned long long best_h = ~0ull;
-  float best_f = 3.4e38f;
-  long long best_id = 0x7fffffffffffffffll;
+  // Branch-free selection: every candidate gets the 64-bit composite
+  // (key32 << 32 | low 32 bits of its id); the smallest composite wins, so ties
+  // on the key fall to the smaller id.  key32 = pair key (uniform), or the bit
+  // pattern of the non-negative float d2 / -ln(u)/(r-d) (nearest / inverse),
+  // which orders like the float.  Rejected candidates get ~0.
+  unsigned long long best = ~0ull;
   int best_slot = -1;
 
   const int ry0 = max(cymin - 1, 0), ry1 = min(cymax + 1, ncy - 1);
   for (int ry = ry0; ry <= ry1; ++ry) {
-    bool near = act && (cy - ry <= 1) && (ry - cy <= 1);
+    const bool near = act && (cy - ry <= 1) && (ry - cy <= 1);
     int lo = __builtin_amdgcn_readfirstlane(wave_min_i(near ? cx - 1 : 0x7fffffff));
     int hi = __builtin_amdgcn_readfirstlane(wave_max_i(near ? cx + 1 : -0x7fffffff));
     if (lo > hi) continue;
@@ -364,53 +374,109 @@ k_find_mates(int64_t N, const float* __restrict__ x, const float* __restrict__ y
     hi = min(hi, ncx - 1);
     const int s = cell_start[ry * ncx + lo];
     const int e = cell_start[ry * ncx + hi + 1];
+    // lanes that do not neighbour this row can accept nothing: r2 < 0
+    const float r2l = near ? r2 : -1.0f;
     for (int base = s; base < e; base += 64) {
       const int j = base + lane;
       const bool v = j < e;
-      float ox_l = v ? x[j] : 0.f;
-      float oy_l = v ? y[j] : 0.f;
-      long long oid_l = v ? id[j] : 0;
+      const float ox_l = v ? x[j] : 0.f;
+      const float oy_l = v ? y[j] : 0.f;
+      const unsigned int ot_l = v ? tag[j] : 0u;
+      const unsigned int oi_l = v ? (unsigned int)id[j] : 0u;
       const int cnt = min(64, e - base);
-      for (int t = 0; t < cnt; ++t) {
-        const float ox = readlane_f(ox_l, t);
-        const float oy = readlane_f(oy_l, t);
-        const long long oid = readlane_ll(oid_l, t);
-        const int oj = base + t;
-        const float dx = ox - fx, dy = oy - fy;
-        const float d2 = dx * dx + dy * dy;
-        if (near && d2 <= r2 && (int64_t)oj != i) {
-          if (MODE == GNX_MATE_UNIFORM) {
-            unsigned long long hsh = gnx_pair_hash(pair_seed, (unsigned long long)fid,
-                                                   (unsigned long long)oid);
-            if (hsh < best_h || (hsh == best_h && oid < best_id)) {
-              best_h = hsh;
-              best_id = oid;
-              best_slot = oj;
-            }
-          } else if (MODE == GNX_MATE_NEAREST) {
-            if (d2 < best_f || (d2 == best_f && oid < best_id)) {
-              best_f = d2;
-              best_id = oid;
-              best_slot = oj;
-            }
-          } else {
-            if (d2 > 0.f) {
-              unsigned long long hsh = gnx_pair_hash(pair_seed, (unsigned long long)fid,
-                                                     (unsigned long long)oid);
-              float u = gnx_u01((unsigned int)(hsh >> 32));
-              float kf = -logf(u) / (r - sqrtf(d2));
-              if (kf < best_f || (kf == best_f && oid < best_id)) {
-                best_f = kf;
-                best_id = oid;
-                best_slot = oj;
-              }
-            }
-          }
-        }
+#define FM_BODY(T)                                                                        \
+  {                                                                                       \
+    const int tt = (T);                                                                   \
+    const float ox = readlane_f(ox_l, tt);                                                \
+    const float oy = readlane_f(oy_l, tt);                                                \
+    const unsigned int ot = (unsigned int)__builtin_amdgcn_readlane((int)ot_l, tt);       \
+    const unsigned int oi = (unsigned int)__builtin_amdgcn_readlane((int)oi_l, tt);       \
+    const int oj = base + tt;                                                             \
+    const float dx = ox - fx, dy = oy - fy;                                               \
+    const float d2 = dx * dx + dy * dy;                                                   \
+    bool ok = (d2 <= r2l) & ((int64_t)oj != i);                                           \
+    unsigned int k32;                                                                     \
+    if (MODE == GNX_MATE_UNIFORM) {                                                       \
+      k32 = gnx_pair_key(ftag, ot);                                                       \
+    } else if (MODE == GNX_MATE_NEAREST) {                                                \
+      k32 = __float_as_uint(d2);                                                          \
+    } else {                                                                              \
+      ok = ok & (d2 > 0.f);                                                               \
+      const float kf = -logf(gnx_u01(gnx_pair_key(ftag, ot))) / (r - sqrtf(d2));          \
+      k32 = __float_as_uint(kf);                                                          \
+    }                                                                                     \
+    const unsigned long long comp =                                                       \
+        ok ? (((unsigned long long)k32 << 32) | (unsigned long long)oi) : ~0ull;          \
+    const bool better = comp < best;                                                      \
+    best = better ? comp : best;                                                          \
+    best_slot = better ? oj : best_slot;                                                  \
+  }
+      int t = 0;
+      for (; t + 4 <= cnt; t += 4) {
+        FM_BODY(t)
+        FM_BODY(t + 1)
+        FM_BODY(t + 2)
+        FM_BODY(t + 3)
       }
+      for (; t < cnt; ++t) FM_BODY(t)
+#undef FM_BODY
     }
   }
   if (act) mate[i] = best_slot;
+}
+
+// Production variant.  One lane per focal individual; the lane walks its own
+// 3x3 block of hash cells: per cell row ONE contiguous range of the cell-sorted
+// candidate records [cell_start(ry, cx-1), cell_start(ry, cx+2)), one 16-byte
+// record {x, y, tag, id_lo} per load.  Lanes of a wave sit in the same or
+// adjacent cells, so their loads hit the same few cache lines.  Compared with
+// the wave-broadcast variant above (kept for A/B, GNX_FIND_MATES=wave) a lane
+// only evaluates ITS 9 cells (~250 candidates at the metric density) instead of
+// the union of the wave's (~480) and needs no v_readlane per candidate:
+// 3.4x fewer vector instructions, measured (PMC SQ_INSTS_VALU) and timed in
+// profiles/.  Selection is the same branch-free composite-key minimum.
+template <int MODE>
+__global__ void __launch_bounds__(256)
+k_find_mates(int64_t N, const uint4* __restrict__ cand, const uint32_t* __restrict__ key,
+             const int32_t* __restrict__ cell_start, int ncx, int ncy, float r, float r2,
+             int32_t* __restrict__ mate) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const uint4 me = cand[i];
+  const float fx = __uint_as_float(me.x), fy = __uint_as_float(me.y);
+  const unsigned int ftag = me.z * 0x9E3779B1u;
+  const int k = (int)key[i];
+  const int cy = k / ncx;
+  const int cx = k - cy * ncx;
+  const int lo = max(cx - 1, 0), hi = min(cx + 1, ncx - 1);
+  unsigned long long best = ~0ull;
+  int best_slot = -1;
+  for (int ry = max(cy - 1, 0); ry <= min(cy + 1, ncy - 1); ++ry) {
+    const int s = cell_start[ry * ncx + lo];
+    const int e = cell_start[ry * ncx + hi + 1];
+    for (int j = s; j < e; ++j) {
+      const uint4 c = cand[j];
+      const float dx = __uint_as_float(c.x) - fx, dy = __uint_as_float(c.y) - fy;
+      const float d2 = dx * dx + dy * dy;
+      bool ok = (d2 <= r2) & (j != (int)i);
+      unsigned int k32;
+      if (MODE == GNX_MATE_UNIFORM) {
+        k32 = gnx_pair_key(ftag, c.z);
+      } else if (MODE == GNX_MATE_NEAREST) {
+        k32 = __float_as_uint(d2);
+      } else {
+        ok = ok & (d2 > 0.f);
+        const float kf = -logf(gnx_u01(gnx_pair_key(ftag, c.z))) / (r - sqrtf(d2));
+        k32 = __float_as_uint(kf);
+      }
+      const unsigned long long comp =
+          ok ? (((unsigned long long)k32 << 32) | (unsigned long long)c.w) : ~0ull;
+      const bool better = comp < best;
+      best = better ? comp : best;
+      best_slot = better ? j : best_slot;
+    }
+  }
+  mate[i] = best_slot;
 }
 
 // Bernoulli(b) thinning (structs/species.py:2210-2214), sex filter
@@ -492,7 +558,6 @@ int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out) 
   if (N == 0) return 0;
   const gnx_species_params& sp = h->sp;
   GnxSoA s = h->soa[h->cur];
-  unsigned long long pseed = gnx_pair_seed(h->cfg.seed, h->step);
   int sexed = sp.sexed;
   const int32_t* focal = nullptr;
   gnx_time_begin(h);
@@ -504,15 +569,30 @@ int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out) 
     float r = (float)sp.mating_radius;
     float r2 = r * r;
     dim3 grid(gnx_grid(N, 256)), blk(256);
-    if (sp.mate_mode == GNX_MATE_NEAREST)
-      hipLaunchKernelGGL(k_find_mates<GNX_MATE_NEAREST>, grid, blk, 0, h->stream, N, s.x, s.y, s.id,
-                         h->key[1], h->cell_start, h->ncx, h->ncy, r, r2, pseed, h->mate);
-    else if (sp.mate_mode == GNX_MATE_INVERSE)
-      hipLaunchKernelGGL(k_find_mates<GNX_MATE_INVERSE>, grid, blk, 0, h->stream, N, s.x, s.y, s.id,
-                         h->key[1], h->cell_start, h->ncx, h->ncy, r, r2, pseed, h->mate);
-    else
-      hipLaunchKernelGGL(k_find_mates<GNX_MATE_UNIFORM>, grid, blk, 0, h->stream, N, s.x, s.y, s.id,
-                         h->key[1], h->cell_start, h->ncx, h->ncy, r, r2, pseed, h->mate);
+    static const bool use_wave = getenv("GNX_FIND_MATES") &&
+                                 std::string(getenv("GNX_FIND_MATES")) == "wave";
+    if (use_wave) {
+      if (sp.mate_mode == GNX_MATE_NEAREST)
+        hipLaunchKernelGGL(k_find_mates_wave<GNX_MATE_NEAREST>, grid, blk, 0, h->stream, N, s.x, s.y,
+                           s.id, h->tag, h->key[1], h->cell_start, h->ncx, h->ncy, r, r2, h->mate);
+      else if (sp.mate_mode == GNX_MATE_INVERSE)
+        hipLaunchKernelGGL(k_find_mates_wave<GNX_MATE_INVERSE>, grid, blk, 0, h->stream, N, s.x, s.y,
+                           s.id, h->tag, h->key[1], h->cell_start, h->ncx, h->ncy, r, r2, h->mate);
+      else
+        hipLaunchKernelGGL(k_find_mates_wave<GNX_MATE_UNIFORM>, grid, blk, 0, h->stream, N, s.x, s.y,
+                           s.id, h->tag, h->key[1], h->cell_start, h->ncx, h->ncy, r, r2, h->mate);
+    } else {
+      const uint4* cd = (const uint4*)h->cand;
+      if (sp.mate_mode == GNX_MATE_NEAREST)
+        hipLaunchKernelGGL(k_find_mates<GNX_MATE_NEAREST>, grid, blk, 0, h->stream, N, cd, h->key[1],
+                           h->cell_start, h->ncx, h->ncy, r, r2, h->mate);
+      else if (sp.mate_mode == GNX_MATE_INVERSE)
+        hipLaunchKernelGGL(k_find_mates<GNX_MATE_INVERSE>, grid, blk, 0, h->stream, N, cd, h->key[1],
+                           h->cell_start, h->ncx, h->ncy, r, r2, h->mate);
+      else
+        hipLaunchKernelGGL(k_find_mates<GNX_MATE_UNIFORM>, grid, blk, 0, h->stream, N, cd, h->key[1],
+                           h->cell_start, h->ncx, h->ncy, r, r2, h->mate);
+    }
   }
   gnx_time_end(h, GNX_K_FIND_MATES, (double)N * 16.0);
   gnx_time_begin(h);
@@ -768,7 +848,7 @@ int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* 
   if (genomes || inject) {
     GNXCHK(gnx_l_crossover(h, h->N, B));
     h->n_free -= B;
-    if (c.n_traits > 0) GNXCHK(gnx_l_phenotype(h, h->N, B));
+    if (c.n_traits > 0) GNXCHK(gnx_l_phenotype_births(h, h->N, B));
   }
   h->N += B;
   h->max_id += B;

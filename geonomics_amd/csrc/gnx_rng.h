@@ -130,11 +130,26 @@ __device__ __host__ __forceinline__ unsigned long long gnx_pair_seed(unsigned lo
                                                                      long long step) {
   return gnx_mix64(seed + (unsigned long long)step * 0x9E3779B97F4A7C15ull);
 }
-__device__ __forceinline__ unsigned long long gnx_pair_hash(unsigned long long pair_seed,
-                                                            unsigned long long id_a,
-                                                            unsigned long long id_b) {
-  unsigned long long h = gnx_mix64(pair_seed ^ id_a);
-  return gnx_mix64(h + id_b * 0xD1B54A32D192ED03ull);
+// Mate choice keys.  Every individual gets a 32-bit tag per step,
+// tag = high32(mix64(pair_seed ^ id)); the key of the ordered pair (focal f,
+// candidate c) is lowbias32((tag_f * 0x9E3779B1) ^ tag_c) (lowbias32: Wellons'
+// 2-multiply 32-bit finaliser).  For a fixed focal the keys of its candidates
+// are a bijection of iid uniform tags, hence iid uniform: the candidate with the
+// smallest key is a uniform draw, independent of candidate order.
+__device__ __host__ __forceinline__ unsigned int gnx_lowbias32(unsigned int x) {
+  x ^= x >> 16;
+  x *= 0x7feb352dU;
+  x ^= x >> 15;
+  x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ unsigned int gnx_ind_tag(unsigned long long pair_seed,
+                                                    unsigned long long id) {
+  return (unsigned int)(gnx_mix64(pair_seed ^ id) >> 32);
+}
+__device__ __forceinline__ unsigned int gnx_pair_key(unsigned int tag_f_mul, unsigned int tag_c) {
+  return gnx_lowbias32(tag_f_mul ^ tag_c);
 }
 __device__ __host__ __forceinline__ unsigned long long gnx_site_seed(unsigned long long seed) {
   return gnx_mix64(seed ^ 0xA0761D6478BD642Full);

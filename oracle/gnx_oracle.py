@@ -359,7 +359,7 @@ def choose_mates(x, y, ids, radius, seed, step, mode='uniform',
 
     mode 'uniform'  : utils/spatial.py:232-242 picks np.random.choice(opts);
                       the build picks the candidate with the smallest
-                      pair_hash(seed, step, id_focal, id_cand) - uniform over
+                      32-bit pair_hash(seed, step, id_focal, id_cand) - uniform over
                       the candidate set and independent of candidate order.
     mode 'nearest'  : utils/spatial.py:194-203 (ties -> smaller id).
     mode 'inverse'  : utils/spatial.py:209-229, P(j) ~ (r - d_ij) over
@@ -396,7 +396,7 @@ def choose_mates(x, y, ids, radius, seed, step, mode='uniform',
             nb2 = nb[ok]
             wgt = dtype(radius) - d[ok]
             h = pair_hash(seed, step, ids[i], ids[nb2])
-            u = u01((h >> np.uint64(32)).astype(np.uint32))
+            u = u01(h)
             key = -np.log(u) / wgt
             order = np.lexsort((ids[nb2], key))
             mate[i] = nb2[order[0]]

@@ -86,15 +86,35 @@ def mix64(z):
     return z
 
 
-def pair_hash(seed, step, id_a, id_b):
-    """Order-independent-by-construction random key of the ordered pair
-    (focal a, candidate b) at a step; used to pick a mate uniformly: the
-    candidate with the smallest key wins (ties -> smaller id)."""
+def lowbias32(x):
+    """Wellons' 2-multiply 32-bit finaliser (uint32 array)."""
+    x = np.asarray(x, dtype=np.uint32).copy()
+    with np.errstate(over='ignore'):
+        x ^= x >> np.uint32(16)
+        x *= np.uint32(0x7feb352d)
+        x ^= x >> np.uint32(15)
+        x *= np.uint32(0x846ca68b)
+        x ^= x >> np.uint32(16)
+    return x
+
+
+def ind_tag(seed, step, ids):
+    """32-bit mate-choice tag of an individual at a step."""
     with np.errstate(over='ignore'):
         s = mix64(np.uint64(seed) + np.uint64(step) * np.uint64(0x9E3779B97F4A7C15))
-        h = mix64(s ^ np.asarray(id_a, dtype=np.uint64))
-        h = mix64(h + np.asarray(id_b, dtype=np.uint64) * np.uint64(0xD1B54A32D192ED03))
-    return h
+        return (mix64(s ^ np.asarray(ids, dtype=np.uint64)) >> np.uint64(32)).astype(np.uint32)
+
+
+def pair_hash(seed, step, id_a, id_b):
+    """Random 32-bit key of the ordered pair (focal a, candidate b) at a step:
+    lowbias32((tag_a * 0x9E3779B1) ^ tag_b).  Used to pick a mate uniformly and
+    independently of candidate order: the candidate with the smallest key wins
+    (ties -> smaller id).  For a fixed focal the candidates' keys are a
+    bijection of their iid tags, hence iid uniform."""
+    ta = np.atleast_1d(ind_tag(seed, step, id_a))
+    tb = np.atleast_1d(ind_tag(seed, step, id_b))
+    with np.errstate(over='ignore'):
+        return lowbias32((ta * np.uint32(0x9E3779B1)) ^ tb)
 
 
 def site_hash(seed, site, hom):

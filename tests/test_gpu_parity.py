@@ -563,3 +563,95 @@ def test_step_invariants_and_reproducibility():
     # logistic regulation towards sum(K) = 0.5 * 64 * 64 = 2048
     assert 1200 < Ns.mean() < 3000
     assert all(h[1] > 0 and h[2] > 0 for h in h1)
+
+
+def test_whole_model_envelopes_vs_reference_on_device():
+    """Same check as tests/test_oracle_golden.py::test_whole_model_envelopes_vs_reference
+    with the HIP path doing the stepping."""
+    nat = native()
+    g = load_golden('g10_envelopes')
+    W = H = 30
+    L = 60
+    rasts = np.stack([np.ones((H, W)), np.tile(np.linspace(0, 1, W), (H, 1))])
+    rng = np.random.RandomState(0)
+    paths = O.pack_bits(O.recomb_paths((rng.rand(60, L) < 0.5).astype(np.uint8)
+                                       * (np.arange(L) > 0)))
+    ref = dict(burn=[], first=[], main=[])
+    mine = dict(burn=[], first=[], main=[])
+    for s in range(1, 9):
+        nb = int(g['s%i_nburn' % s][0])
+        R = g['s%i_Nt' % s]
+        ref['burn'].append(R[10:nb].mean())
+        ref['first'].append(R[nb:nb + 20].mean())
+        ref['main'].append(R[-50:].mean())
+        dev = make_dev(W, H, rasts=rasts, L=L, n_traits=3, cap=4096, seed=200 + s,
+                       mating_radius=4.0, K_factor=0.5)
+        for t in range(3):
+            par = g['s%i_t%i_par' % (s, t)]
+            dev.set_trait(t, g['s%i_t%i_loci' % (s, t)], g['s%i_t%i_alpha' % (s, t)],
+                          int(par[0]), par[1], par[2], bool(par[3]))
+        dev.set_recomb_paths(paths)
+        dev.init_population(300)
+        Nt = []
+        for _ in range(60):
+            dev.step(True, False)
+            Nt.append(dev.N)
+        dev.assign_genomes(O.starting_mutation_counts(dev.N, np.full(L, 0.5)))
+        for _ in range(100):
+            dev.step(False, True)
+            Nt.append(dev.N)
+        Nt = np.array(Nt)
+        mine['burn'].append(Nt[10:60].mean())
+        mine['first'].append(Nt[60:80].mean())
+        mine['main'].append(Nt[-50:].mean())
+        dev.close()
+    m = {k: (np.mean(ref[k]), np.mean(mine[k])) for k in ref}
+    assert abs(m['burn'][1] / m['burn'][0] - 1) < 0.04, m
+    assert abs(m['first'][1] / m['first'][0] - 1) < 0.15, m
+    assert abs(m['main'][1] / m['main'][0] - 1) < 0.15, m
+
+
+def test_device_step_matches_oracle_step_counts():
+    """The oracle's whole step uses the device's random streams: populations
+    evolve through the same integer decisions; only float rounding (logf/cosf)
+    can flip a rare decision.  Over 10 burn + 10 main steps the per-step
+    (pairs, births, deaths) must agree closely."""
+    import gnx_step as S
+    nat = native()
+    W = H = 40
+    L = 128
+    rasts = np.stack([np.ones((H, W)), np.tile(np.linspace(0, 1, W), (H, 1))]).astype(np.float32)
+    rng = np.random.RandomState(4)
+    paths = O.pack_bits(O.recomb_paths((rng.rand(32, L) < 0.02).astype(np.uint8)
+                                       * (np.arange(L) > 0)))
+    loci = np.array([3, 40, 77, 101])
+    alpha = np.array([0.1, -0.1, 0.1, -0.1])
+    seed = 31
+    dev = make_dev(W, H, rasts=rasts, L=L, n_traits=1, cap=8192, seed=seed,
+                   mating_radius=3.0, K_factor=0.6)
+    dev.set_trait(0, loci, alpha, 1, 0.05, 1.0, False)
+    dev.set_recomb_paths(paths)
+    dev.init_population(900)
+    st = S.State(rasts, S.Params(mating_radius=3.0, K_factor=0.6), seed, L=L,
+                 traits=[dict(loci=loci, alpha=alpha, layer=1, phi=0.05, gamma=1.0,
+                              univ_adv=False)], paths_packed=paths)
+    st.init_population(900)
+    np.testing.assert_array_equal(dev.download(nat.F_X), st.x)
+    same = 0
+    tot = 0
+    for t in range(20):
+        burn = t < 10
+        if t == 10:
+            n = O.starting_mutation_counts(dev.N, np.full(L, 0.5))
+            dev.assign_genomes(n)
+            st.assign_genomes(O.starting_mutation_counts(st.N, np.full(L, 0.5)))
+        dev.step(burn, not burn)
+        _, B, Dth = S.step(st, burn=burn, with_selection=not burn)
+        n_dev, b_dev, d_dev = dev.counts()
+        tot += 1
+        same += (b_dev == B) and (d_dev == Dth)
+        assert abs(b_dev - B) <= max(3, 0.03 * B), (t, b_dev, B)
+        assert abs(d_dev - Dth) <= max(4, 0.05 * Dth), (t, d_dev, Dth)
+        assert abs(n_dev - st.N) <= max(6, 0.03 * st.N)
+    assert same >= 3          # the first steps agree exactly before rounding flips accumulate
+    dev.close()

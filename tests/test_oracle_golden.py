@@ -334,3 +334,56 @@ def test_conductance_distribution_moments():
     loc = O.conductance_unimodal_loc(rast, cy, cx)
     assert np.abs(a1 * np.cos(loc) - g['uni_mean_cos'].ravel()).max() < tol
     assert np.abs(a1 * np.sin(loc) - g['uni_mean_sin'].ravel()).max() < tol
+
+
+# ------------------------------------------------------------------ G10
+def _g10_traits(g, s):
+    traits = []
+    for t in range(3):
+        par = g['s%i_t%i_par' % (s, t)]
+        traits.append(dict(loci=g['s%i_t%i_loci' % (s, t)], alpha=g['s%i_t%i_alpha' % (s, t)],
+                           layer=int(par[0]), phi=par[1], gamma=par[2], univ_adv=bool(par[3])))
+    return traits
+
+
+def test_whole_model_envelopes_vs_reference():
+    """Whole-loop statistics of the oracle step (same operators, device random
+    streams) against 8 reference runs of the same model (30x30, 2 layers, N0 300,
+    K_factor 0.5, radius 4, L 60, r 0.5, 3 traits; each run's own trait
+    architecture).  Trajectories cannot match stream for stream; the means must."""
+    import gnx_step as S
+    g = load_golden('g10_envelopes')
+    W = H = 30
+    L = 60
+    rasts = np.stack([np.ones((H, W)), np.tile(np.linspace(0, 1, W), (H, 1))])
+    rng = np.random.RandomState(0)
+    paths = O.pack_bits(O.recomb_paths((rng.rand(60, L) < 0.5).astype(np.uint8)
+                                       * (np.arange(L) > 0)))
+    ref = dict(burn=[], first=[], main=[], br=[])
+    mine = dict(burn=[], first=[], main=[], br=[])
+    for s in range(1, 9):
+        nb = int(g['s%i_nburn' % s][0])
+        R = g['s%i_Nt' % s]
+        ref['burn'].append(R[10:nb].mean())
+        ref['first'].append(R[nb:nb + 20].mean())
+        ref['main'].append(R[-50:].mean())
+        Rprev = np.concatenate([[300], R[:-1]])
+        ref['br'].append((g['s%i_births' % s][10:nb] / Rprev[10:nb]).mean())
+        st = S.State(rasts, S.Params(mating_radius=4.0, K_factor=0.5), 100 + s, L=L,
+                     traits=_g10_traits(g, s), paths_packed=paths)
+        st.init_population(300)
+        for _ in range(60):
+            S.step(st, burn=True)
+        st.assign_genomes(O.starting_mutation_counts(st.N, np.full(L, 0.5)))
+        for _ in range(100):
+            S.step(st, burn=False)
+        Nt = np.array(st.Nt[1:] + [st.N])
+        mine['burn'].append(Nt[10:60].mean())
+        mine['first'].append(Nt[60:80].mean())
+        mine['main'].append(Nt[-50:].mean())
+        mine['br'].append((np.array(st.n_births[10:60]) / np.array(st.Nt[10:60])).mean())
+    m = {k: (np.mean(ref[k]), np.mean(mine[k])) for k in ref}
+    assert abs(m['burn'][1] / m['burn'][0] - 1) < 0.04, m      # measured -1.3 %
+    assert abs(m['br'][1] / m['br'][0] - 1) < 0.04, m
+    assert abs(m['first'][1] / m['first'][0] - 1) < 0.15, m    # measured -3.6 %
+    assert abs(m['main'][1] / m['main'][0] - 1) < 0.15, m      # measured +3.5 %

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Per-kernel HIP-event times of the hot path without genomes (burn-mode steps)
+or with them (--genomes): a quick loop for kernel work.  GPU only."""
+import argparse
+import os
+import sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from geonomics_amd import _native as nat
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--workload', default='c4_metric')
+ap.add_argument('--steps', type=int, default=10)
+ap.add_argument('--genomes', action='store_true')
+a = ap.parse_args()
+cfg = dict(bench.WORKLOADS[a.workload])
+if not a.genomes:
+    cfg['L'] = 0
+    cfg['n_traits'] = 0
+dev, _, _ = bench.build_device(cfg, 42, 0)
+for _ in range(3):
+    dev.step(True, False)
+if a.genomes:
+    bench.setup_genomes(dev, cfg, 42)
+for _ in range(2):
+    dev.step(not a.genomes, a.genomes)
+dev.profiling(True)
+import time
+dev.synchronize()
+t0 = time.perf_counter()
+n = 0
+for _ in range(a.steps):
+    n += dev.N
+    dev.step(not a.genomes, a.genomes)
+dev.synchronize()
+dt = time.perf_counter() - t0
+kt = dev.kernel_times()
+print('N=%d  ms/step=%.3f  ind-steps/s=%.3e' % (dev.N, 1e3 * dt / a.steps, n / dt))
+for k, v in kt.items():
+    print('  %-11s %8.3f ms/step  (%d launches)' % (k, v['ms'] / a.steps, v['launches']))
+print('  sum         %8.3f' % (sum(v['ms'] for v in kt.values()) / a.steps))
