@@ -37,7 +37,6 @@ struct alignas(16) u64x2 {
 // trait locus e from the just-read (L2-hot) parental chunk and stores it in the
 // compact table tbits[gamete][e], so phenotypes never gather from the fresh
 // 25-KB child rows.
-#define XO_UNROLL 4
 
 template <bool SPARSE>
 __device__ __forceinline__ u64x2 xo_mask(int c, u64 s, const u64x2* __restrict__ path_row,
@@ -87,7 +86,7 @@ __device__ __forceinline__ u64x2 xo_chunk(int c, u64x2 m, const u64x2* __restric
   return out;
 }
 
-template <bool SPARSE>
+template <bool SPARSE, int XO_UNROLL>
 __global__ void __launch_bounds__(256)
 k_crossover(int64_t B, int W16, const u64x2* __restrict__ G, u64x2* __restrict__ Gout,
             const int32_t* __restrict__ grow, int64_t first_slot,
@@ -126,7 +125,11 @@ k_crossover(int64_t B, int W16, const u64x2* __restrict__ G, u64x2* __restrict__
 #pragma unroll
       for (int u = 0; u < XO_UNROLL; ++u) {
         const int c = c0 + u * 64;
-        if (c < W16) dst[c] = out[u];
+        // the child row is not read again this step: keep it out of L2 / MALL
+        if (c < W16) {
+          __builtin_nontemporal_store(out[u].a, &dst[c].a);
+          __builtin_nontemporal_store(out[u].b, &dst[c].b);
+        }
       }
     }
     // alleles at the trait loci -> compact table for the phenotype kernel
@@ -140,24 +143,32 @@ k_crossover(int64_t B, int W16, const u64x2* __restrict__ G, u64x2* __restrict__
   }
 }
 
+template <bool SPARSE, int U>
+static void xo_launch(gnx_state* h, int grid, int64_t first_slot, int64_t B) {
+  const int W16 = h->W64 / 2;
+  GnxSoA s = h->soa[h->cur];
+  hipLaunchKernelGGL((k_crossover<SPARSE, U>), dim3(grid), dim3(256), 0, h->stream, B, W16,
+                     (const u64x2*)h->G, (u64x2*)h->G, s.grow, first_slot, h->off_parent,
+                     h->off_keys, h->off_start, (const u64x2*)h->paths, h->bp_off, h->bp_loci,
+                     h->n_tl, h->tl_loci, h->tbits);
+}
+
 int gnx_l_crossover(gnx_state* h, int64_t first_slot, int64_t B) {
   if (B == 0) return 0;
-  const int W16 = h->W64 / 2;
   // one wave per gamete, 4 waves per block; cap the grid and stride beyond
-  int grid = gnx_grid(2 * B, 4, 256 * 32);
-  GnxSoA s = h->soa[h->cur];
-  const int n_tl = h->n_tl;
+  static const int blocks_per_cu = getenv("GNX_XO_BPC") ? atoi(getenv("GNX_XO_BPC")) : 32;
+  static const int unroll = getenv("GNX_XO_UNROLL") ? atoi(getenv("GNX_XO_UNROLL")) : 4;
+  int grid = gnx_grid(2 * B, 4, 256 * blocks_per_cu);
   gnx_time_begin(h);
-  if (h->sparse_paths)
-    hipLaunchKernelGGL(k_crossover<true>, dim3(grid), dim3(256), 0, h->stream, B, W16,
-                       (const u64x2*)h->G, (u64x2*)h->G, s.grow, first_slot, h->off_parent,
-                       h->off_keys, h->off_start, (const u64x2*)h->paths, h->bp_off, h->bp_loci,
-                       n_tl, h->tl_loci, h->tbits);
-  else
-    hipLaunchKernelGGL(k_crossover<false>, dim3(grid), dim3(256), 0, h->stream, B, W16,
-                       (const u64x2*)h->G, (u64x2*)h->G, s.grow, first_slot, h->off_parent,
-                       h->off_keys, h->off_start, (const u64x2*)h->paths, h->bp_off, h->bp_loci,
-                       n_tl, h->tl_loci, h->tbits);
+  if (h->sparse_paths) {
+    if (unroll == 2) xo_launch<true, 2>(h, grid, first_slot, B);
+    else if (unroll == 8) xo_launch<true, 8>(h, grid, first_slot, B);
+    else xo_launch<true, 4>(h, grid, first_slot, B);
+  } else {
+    if (unroll == 2) xo_launch<false, 2>(h, grid, first_slot, B);
+    else if (unroll == 8) xo_launch<false, 8>(h, grid, first_slot, B);
+    else xo_launch<false, 4>(h, grid, first_slot, B);
+  }
   // algorithmic bytes per birth.  Dense masks: 4 parental
   // homologues + 2 masks read, 2 homologues written = 8 * L/8 = L bytes.
   // Sparse paths: each gamete chunk copies ONE parental homologue (the other
