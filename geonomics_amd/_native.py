@@ -34,7 +34,13 @@ EXPORTS = [
     'gnx_op_move_draws', 'gnx_op_find_pairs', 'gnx_op_crossover',
     'gnx_op_dispersal', 'gnx_op_density', 'gnx_density_lattice_dims',
     'gnx_op_death_probs', 'gnx_op_mortality', 'gnx_profiling',
-    'gnx_kernel_time',
+    'gnx_kernel_time', 'gnx_tile_set', 'gnx_tile_export_migrants',
+    'gnx_tile_export_halo', 'gnx_tile_get_staged', 'gnx_tile_import',
+    'gnx_tile_import_ghosts', 'gnx_tile_pairs', 'gnx_tile_pair_info',
+    'gnx_density_bin_count', 'gnx_get_bins', 'gnx_set_bins',
+    'gnx_tile_offspring', 'gnx_tile_get_requests', 'gnx_tile_serve_gametes',
+    'gnx_tile_put_gametes', 'gnx_tile_finish_births', 'gnx_tile_die',
+    'gnx_set_max_id',
 ]
 
 
@@ -64,6 +70,12 @@ class SpeciesParams(C.Structure):
         ('res_ratio', C.c_double * 2), ('K_layer', C.c_int32),
         ('pad0', C.c_int32), ('K_factor', C.c_double)]
 
+
+# gnx_ind_rec (include/gnx_hip.h) as a numpy record dtype (32 bytes)
+IND_REC = np.dtype([('x', np.float32), ('y', np.float32), ('age', np.int32),
+                    ('sex', np.int32), ('id', np.int64), ('fit', np.float32),
+                    ('nbr_mask', np.int32)], align=True)
+assert IND_REC.itemsize == 32
 
 _lib = None
 
@@ -394,6 +406,120 @@ class Device:
         d = _arr(dead, np.uint8)
         assert d.size == self.N
         self._chk(self.lib.gnx_op_mortality(self.h, _ptr(d, C.c_uint8)))
+
+    # -- spatial tiling (geonomics_amd/parallel.py) ---------------------------------
+    def tile_set(self, R, C, r, c):
+        self._chk(self.lib.gnx_tile_set(self.h, int(R), int(C), int(r), int(c)))
+
+    def _get_staged(self, n, with_z, with_geno):
+        rec = np.zeros(n, dtype=IND_REC)
+        z = np.zeros((n, self.n_traits), np.float32) if (with_z and self.n_traits) else None
+        geno = np.zeros((n, 2, self.W64), np.uint64) if with_geno else None
+        if n:
+            self._chk(self.lib.gnx_tile_get_staged(
+                self.h, rec.ctypes.data_as(C.c_void_p), _ptr(z, C.c_float),
+                _ptr(geno, C.c_uint64)))
+        return rec, z, geno
+
+    def tile_export_migrants(self, with_geno):
+        n = C.c_int64()
+        self._chk(self.lib.gnx_tile_export_migrants(self.h, C.byref(n)))
+        return self._get_staged(n.value, True, with_geno and self.L > 0)
+
+    def tile_export_halo(self, width):
+        n = C.c_int64()
+        self._chk(self.lib.gnx_tile_export_halo(self.h, C.c_double(width), C.byref(n)))
+        return self._get_staged(n.value, False, False)[0]
+
+    def tile_import(self, rec, z=None, geno=None):
+        rec = np.ascontiguousarray(rec, dtype=IND_REC)
+        z = None if z is None else _arr(z, np.float32)
+        geno = None if geno is None else _arr(geno, np.uint64)
+        self._chk(self.lib.gnx_tile_import(self.h, C.c_int64(rec.size),
+                                           rec.ctypes.data_as(C.c_void_p),
+                                           _ptr(z, C.c_float), _ptr(geno, C.c_uint64)))
+
+    def tile_import_ghosts(self, rec):
+        rec = np.ascontiguousarray(rec, dtype=IND_REC)
+        self._chk(self.lib.gnx_tile_import_ghosts(self.h, C.c_int64(rec.size),
+                                                  rec.ctypes.data_as(C.c_void_p)))
+
+    def tile_pairs(self, burn):
+        p, b = C.c_int64(), C.c_int64()
+        self._chk(self.lib.gnx_tile_pairs(self.h, int(bool(burn)), C.byref(p), C.byref(b)))
+        self._n_pairs = p.value
+        return p.value, b.value
+
+    def tile_pair_info(self):
+        P = self._n_pairs
+        ids = np.zeros(P, np.int64)
+        nb = np.zeros(P, np.int32)
+        if P:
+            self._chk(self.lib.gnx_tile_pair_info(self.h, _ptr(ids, C.c_int64),
+                                                  _ptr(nb, C.c_int32)))
+        return ids, nb
+
+    def get_bins(self, which):
+        out = np.zeros(self.lib.gnx_density_bin_count(self.h), np.int32)
+        self._chk(self.lib.gnx_get_bins(self.h, int(which), _ptr(out, C.c_int32)))
+        return out
+
+    def set_bins(self, which, bins):
+        b = _arr(bins, np.int32)
+        assert b.size == self.lib.gnx_density_bin_count(self.h)
+        self._chk(self.lib.gnx_set_bins(self.h, int(which), _ptr(b, C.c_int32)))
+
+    def tile_offspring(self, burn, id_base, pair_goff):
+        g = _arr(pair_goff, np.int64)
+        assert g.size == self._n_pairs
+        n = C.c_int64()
+        self._chk(self.lib.gnx_tile_offspring(self.h, int(bool(burn)), C.c_int64(int(id_base)),
+                                              _ptr(g, C.c_int64), C.byref(n)))
+        self._n_req = n.value
+        return n.value
+
+    def tile_get_requests(self):
+        n = self._n_req
+        pid = np.zeros(n, np.int64)
+        ck = np.zeros(n, np.int32)
+        key = np.zeros(n, np.int32)
+        st = np.zeros(n, np.uint8)
+        px = np.zeros(n, np.float32)
+        py = np.zeros(n, np.float32)
+        if n:
+            self._chk(self.lib.gnx_tile_get_requests(
+                self.h, _ptr(pid, C.c_int64), _ptr(ck, C.c_int32), _ptr(key, C.c_int32),
+                _ptr(st, C.c_uint8), _ptr(px, C.c_float), _ptr(py, C.c_float)))
+        return pid, ck, key, st, px, py
+
+    def tile_serve_gametes(self, pids, keys, starts):
+        pids = _arr(pids, np.int64)
+        keys = _arr(keys, np.int32)
+        starts = _arr(starts, np.uint8)
+        out = np.zeros((pids.size, self.W64), np.uint64)
+        if pids.size:
+            self._chk(self.lib.gnx_tile_serve_gametes(
+                self.h, C.c_int64(pids.size), _ptr(pids, C.c_int64), _ptr(keys, C.c_int32),
+                _ptr(starts, C.c_uint8), _ptr(out, C.c_uint64)))
+        return out
+
+    def tile_put_gametes(self, child_k, data):
+        ck = _arr(child_k, np.int32)
+        d = _arr(data, np.uint64)
+        if ck.size:
+            assert d.shape == (ck.size, self.W64)
+            self._chk(self.lib.gnx_tile_put_gametes(self.h, C.c_int64(ck.size),
+                                                    _ptr(ck, C.c_int32), _ptr(d, C.c_uint64)))
+
+    def tile_finish_births(self, burn):
+        self._chk(self.lib.gnx_tile_finish_births(self.h, int(bool(burn))))
+
+    def tile_die(self, burn, with_selection, have_pairs):
+        self._chk(self.lib.gnx_tile_die(self.h, int(bool(burn)), int(bool(with_selection)),
+                                        int(bool(have_pairs))))
+
+    def set_max_id(self, v):
+        self._chk(self.lib.gnx_set_max_id(self.h, C.c_int64(int(v))))
 
     # -- measurement ---------------------------------------------------------
     def profiling(self, on):

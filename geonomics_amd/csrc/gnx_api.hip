@@ -102,6 +102,8 @@ static int alloc_soa(GnxSoA* s, int64_t cap, int n_layers, int n_traits) {
   GNXCHK(dalloc(&s->z, cap * std::max(n_traits, 1)));
   GNXCHK(dalloc(&s->fit, cap));
   GNXCHK(dalloc(&s->grow, cap));
+  GNXCHK(dalloc(&s->ghost, cap));
+  HIPCHK(hipMemset(s->ghost, 0, cap));
   return 0;
 }
 
@@ -115,6 +117,7 @@ static void free_soa(GnxSoA* s) {
   (void)hipFree(s->z);
   (void)hipFree(s->fit);
   (void)hipFree(s->grow);
+  (void)hipFree(s->ghost);
 }
 
 // ---------------------------------------------------------------- lifecycle
@@ -176,6 +179,19 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
   HIPCHK(hipMalloc(&h->sort_tmp, std::max<size_t>(h->sort_tmp_bytes, 16)));
   GNXCHK(gnx_prim_scan_bytes((size_t)cap + 1, &h->scan_tmp_bytes));
   HIPCHK(hipMalloc(&h->scan_tmp, std::max<size_t>(h->scan_tmp_bytes, 16)));
+  GNXCHK(gnx_prim_sort64_bytes((size_t)cap, &h->sort64_tmp_bytes));
+  HIPCHK(hipMalloc(&h->sort64_tmp, std::max<size_t>(h->sort64_tmp_bytes, 16)));
+  GNXCHK(dalloc(&h->key64[0], cap));
+  GNXCHK(dalloc(&h->key64[1], cap));
+  GNXCHK(dalloc(&h->pairs2, cap * 2));
+  GNXCHK(dalloc(&h->pair_goff, cap));
+  GNXCHK(dalloc(&h->req_pid, cap));
+  GNXCHK(dalloc(&h->req_k, cap));
+  GNXCHK(dalloc(&h->req_key, cap));
+  GNXCHK(dalloc(&h->req_start, cap));
+  GNXCHK(dalloc(&h->req_px, cap));
+  GNXCHK(dalloc(&h->req_py, cap));
+  GNXCHK(dalloc(&h->req_count, 1));
   HIPCHK(hipHostMalloc((void**)&h->h_pin, 16 * sizeof(int64_t)));
   *out = h;
   return 0;
@@ -191,11 +207,13 @@ extern "C" void gnx_destroy(gnx_state* h) {
     (void)hipFree(h->counts_rast[k]);
   }
   void* ptrs[] = {h->rast, h->G, h->free_rows, h->paths, h->bp_off, h->bp_loci, h->dom,
-                  h->delet_loci, h->delet_s, h->cell_start, h->tag, h->cand, h->sort_tmp, h->scan_tmp, h->mate,
+                  h->delet_loci, h->delet_s, h->cell_start, h->tag, h->cand, h->sort64_tmp, h->key64[0], h->key64[1], h->pairs2,
+                  h->pair_goff, h->st_rec, h->st_z, h->st_geno, h->st_slots, h->req_pid, h->req_k, h->req_key, h->req_start, h->req_px, h->req_py,
+                  h->req_count, h->sort_tmp, h->scan_tmp, h->mate,
                   h->flag, h->flag2, h->scan, h->pairs, h->nbirths, h->boff, h->off_pair,
                   h->off_parent, h->off_keys, h->off_start, h->keep_in, h->inj_a, h->inj_b,
                   h->mid_x, h->mid_y, h->p_death, h->d_cell, h->dead_in, h->nmax_bits, h->red,
-                  h->tl_loci, h->tbits, h->lat.areas, h->lat.cprime, h->spl_N.c, h->spl_P.c, h->bin_partials, h->nodes};
+                  h->tl_loci, h->tbits, h->lat.areas, h->lat.cprime, h->spl_N.c, h->spl_P.c, h->bin_partials, h->bins_P, h->nodes};
   for (void* p : ptrs) (void)hipFree(p);
   for (int t = 0; t < GNX_MAX_TRAITS; ++t) {
     (void)hipFree(h->traits[t].loci);
@@ -267,6 +285,7 @@ static int setup_lattice(gnx_state* h) {
   (void)hipFree(h->spl_N.c);
   (void)hipFree(h->spl_P.c);
   (void)hipFree(h->bin_partials);
+  (void)hipFree(h->bins_P);
   (void)hipFree(h->nodes);
   L.hww = ww / 2.0;
   L.Jx = lattice_nodes(c.W, ww);
@@ -295,6 +314,7 @@ static int setup_lattice(gnx_state* h) {
   GNXCHK(dalloc(&h->nodes, nn));
   size_t nb = (size_t)L.nbx * L.nby;
   GNXCHK(dalloc(&h->bin_partials, nb));
+  GNXCHK(dalloc(&h->bins_P, nb));
   HIPCHK(hipMemcpy(L.areas, areas.data(), nn * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(L.cprime, cp.data(), (Jm + 1) * sizeof(double), hipMemcpyHostToDevice));
   h->spl_N.valid = h->spl_P.valid = false;
@@ -374,6 +394,8 @@ extern "C" int gnx_upload_population(gnx_state* h, int64_t N, const float* x, co
   HIPCHK(hipMemcpyAsync(s.id, id, N * sizeof(int64_t), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemsetAsync(s.grow, 0xff, N * sizeof(int32_t), st));
   HIPCHK(hipMemsetAsync(s.fit, 0, N * sizeof(float), st));
+  HIPCHK(hipMemsetAsync(s.ghost, 0, N, st));
+  h->n_ghost = 0;
   HIPCHK(hipStreamSynchronize(st));
   h->N = N;
   int64_t mx = -1;
@@ -661,7 +683,7 @@ extern "C" int gnx_step(gnx_state* h, int32_t burn, int32_t with_selection) {
 }
 
 extern "C" int gnx_counts(gnx_state* h, int64_t* N, int64_t* births, int64_t* deaths) {
-  if (N) *N = h->N;
+  if (N) *N = h->N - h->n_ghost;
   if (births) *births = h->last_births;
   if (deaths) *deaths = h->last_deaths;
   return 0;

@@ -68,6 +68,7 @@ struct GnxSoA {
   float* z;        // [n_traits][cap]
   float* fit;
   int32_t* grow;   // genome row, -1 before genomes are assigned
+  uint8_t* ghost;  // 1 = halo copy of a neighbour tile's individual (tiled runs)
 };
 
 // Density lattice (utils/spatial.py _DensityGridStack restated)
@@ -102,6 +103,7 @@ struct gnx_state {
   int64_t max_id = -1;
   int64_t step = 0;            // global step counter (RNG addressing)
   int64_t last_births = 0, last_deaths = 0;
+  int64_t n_ghost = 0;         // ghosts currently resident (counted in N)
 
   GnxSoA soa[2]{};
   int cur = 0;
@@ -147,6 +149,30 @@ struct gnx_state {
   size_t sort_tmp_bytes = 0;
   void* scan_tmp = nullptr;
   size_t scan_tmp_bytes = 0;
+  void* sort64_tmp = nullptr;
+  size_t sort64_tmp_bytes = 0;
+  uint64_t* key64[2]{};          // 64-bit sort keys (focal ids of pairs; id -> slot lookups)
+  int32_t* pairs2 = nullptr;     // pairs in ascending focal-id order
+  int64_t* pair_goff = nullptr;  // tiled runs: global offspring offset of each local pair
+  int64_t n_births_pending = 0;  // births of the current pair list
+  // gamete requests (tiled runs)
+  int64_t* req_pid = nullptr;
+  int32_t* req_k = nullptr;
+  int32_t* req_key = nullptr;
+  uint8_t* req_start = nullptr;
+  float* req_px = nullptr;
+  float* req_py = nullptr;
+  int32_t* req_count = nullptr;
+  // tiling: uniform R x C grid of tiles over the landscape, this handle owns (r, c)
+  bool tiled = false;
+  int tile_R = 1, tile_C = 1, tile_r = 0, tile_c = 0;
+  gnx_ind_rec* st_rec = nullptr;   // staged selection (migrants / halo)
+  float* st_z = nullptr;
+  uint64_t* st_geno = nullptr;
+  int64_t* st_slots = nullptr;
+  int64_t st_n = 0;
+  int64_t birth_first_slot = 0;
+  int64_t n_req = 0;
 
   // pairing / mating scratch (capacity cap_inds)
   int32_t* mate = nullptr;
@@ -170,7 +196,8 @@ struct gnx_state {
   // density
   GnxLattice lat;
   GnxSpline spl_N, spl_P;
-  int32_t* bin_partials = nullptr;   // [n_blocks][nby*nbx]
+  int32_t* bin_partials = nullptr;   // half-window bin counts of individuals [nby*nbx]
+  int32_t* bins_P = nullptr;         // ... of pair midpoints
   int n_bin_blocks = 0;
   double* nodes = nullptr;           // [Jy][Jx] scratch node values
   unsigned long long* nmax_bits = nullptr;
@@ -207,7 +234,9 @@ int gnx_l_move(gnx_state* h, bool inc_age, const float* inj_theta, const float* 
                float* out_theta, float* out_dist, bool apply);
 int gnx_l_sort_by_cell(gnx_state* h);
 int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out);
-int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* births_out);
+int gnx_l_births(gnx_state* h, int64_t* births_out);
+int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* births_out,
+               int64_t id_base = -1, bool tiled = false);
 int gnx_l_dispersal_inject(gnx_state* h, int64_t B, int A, const float* d_mx, const float* d_my,
                            const float* d_theta, const float* d_dist, float* d_ox, float* d_oy,
                            int32_t* d_used);
@@ -219,6 +248,10 @@ int gnx_l_mutate(gnx_state* h, int n, const int64_t* d_slot, const int32_t* d_lo
                  const uint8_t* d_hom);
 int gnx_l_density(gnx_state* h, int64_t n, const float* d_x, const float* d_y, GnxSpline* spl,
                   const double* d_nodes_override);
+int gnx_l_bins(gnx_state* h, int64_t n, const float* d_x, const float* d_y, const uint8_t* d_ghost,
+               int32_t* d_bins);
+int gnx_l_spline(gnx_state* h, const int32_t* d_bins, GnxSpline* spl,
+                 const double* d_nodes_override);
 int gnx_l_raster(gnx_state* h, int which, double* d_out);
 int gnx_l_death_probs(gnx_state* h, bool with_selection);
 int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_out);
@@ -229,6 +262,9 @@ int gnx_l_gather_genomes(gnx_state* h, int64_t n, const int64_t* d_slots, uint64
 int gnx_prim_sort_bytes(size_t n, int bits, size_t* bytes);
 int gnx_prim_sort(void* tmp, size_t bytes, const uint32_t* kin, uint32_t* kout, const int32_t* vin,
                   int32_t* vout, size_t n, int bits, hipStream_t s);
+int gnx_prim_sort64_bytes(size_t n, size_t* bytes);
+int gnx_prim_sort64(void* tmp, size_t bytes, const uint64_t* kin, uint64_t* kout,
+                    const int32_t* vin, int32_t* vout, size_t n, hipStream_t s);
 int gnx_prim_scan_bytes(size_t n, size_t* bytes);
 int gnx_prim_scan(void* tmp, size_t bytes, const int32_t* in, int32_t* out, size_t n,
                   hipStream_t s);

@@ -17,14 +17,15 @@
 
 // ---------------------------------------------------------------- bins
 __global__ void __launch_bounds__(256)
-k_bins(int64_t n, const float* x, const float* y, double inv_hww, int nbx, int nby,
-       int32_t* partials) {
+k_bins(int64_t n, const float* x, const float* y, const uint8_t* ghost, double inv_hww, int nbx,
+       int nby, int32_t* partials) {
   extern __shared__ int32_t lds_hist[];
   const int nb = nbx * nby;
   for (int k = threadIdx.x; k < nb; k += blockDim.x) lds_hist[k] = 0;
   __syncthreads();
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (ghost && ghost[i]) continue;
     int hx = min(nbx - 1, (int)floor((double)x[i] * inv_hww));
     int hy = min(nby - 1, (int)floor((double)y[i] * inv_hww));
     atomicAdd(&lds_hist[hy * nbx + hx], 1);
@@ -39,10 +40,11 @@ k_bins(int64_t n, const float* x, const float* y, double inv_hww, int nbx, int n
 }
 
 // variant for lattices too large for LDS: global atomics into partials[0]
-__global__ void k_bins_global(int64_t n, const float* x, const float* y, double inv_hww, int nbx,
-                              int nby, int32_t* hist) {
+__global__ void k_bins_global(int64_t n, const float* x, const float* y, const uint8_t* ghost,
+                              double inv_hww, int nbx, int nby, int32_t* hist) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (ghost && ghost[i]) return;
   int hx = min(nbx - 1, (int)floor((double)x[i] * inv_hww));
   int hy = min(nby - 1, (int)floor((double)y[i] * inv_hww));
   atomicAdd(&hist[hy * nbx + hx], 1);
@@ -139,36 +141,38 @@ static SplineC make_splinec(const gnx_state* h, const GnxSpline& s) {
   return c;
 }
 
-// counts n points into bins, builds node densities and the spline coefficients
-int gnx_l_density(gnx_state* h, int64_t n, const float* d_x, const float* d_y, GnxSpline* spl,
-                  const double* d_nodes_override) {
+// counts n points (ghosts skipped) into the half-window bins d_bins [nby*nbx]
+int gnx_l_bins(gnx_state* h, int64_t n, const float* d_x, const float* d_y, const uint8_t* d_ghost,
+               int32_t* d_bins) {
   const GnxLattice& L = h->lat;
   const int nb = L.nbx * L.nby;
+  HIPCHK(hipMemsetAsync(d_bins, 0, (size_t)nb * sizeof(int32_t), h->stream));
+  if (n > 0) {
+    if ((size_t)nb * sizeof(int32_t) <= 48 * 1024) {
+      int blocks = (int)std::min<int64_t>(BIN_BLOCKS, std::max<int64_t>(1, (n + 255) / 256));
+      hipLaunchKernelGGL(k_bins, dim3(blocks), dim3(256), (size_t)nb * sizeof(int32_t), h->stream,
+                         n, d_x, d_y, d_ghost, 1.0 / L.hww, L.nbx, L.nby, d_bins);
+    } else {
+      hipLaunchKernelGGL(k_bins_global, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, n, d_x,
+                         d_y, d_ghost, 1.0 / L.hww, L.nbx, L.nby, d_bins);
+    }
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// node densities (from bins, or given directly) and the spline coefficients
+int gnx_l_spline(gnx_state* h, const int32_t* d_bins, GnxSpline* spl,
+                 const double* d_nodes_override) {
+  const GnxLattice& L = h->lat;
   const int64_t nn = (int64_t)L.Jx * L.Jy;
   double* V = spl->c;
-  gnx_time_begin(h);
-  if (d_nodes_override) {
+  if (d_nodes_override)
     HIPCHK(hipMemcpyAsync(V, d_nodes_override, nn * sizeof(double), hipMemcpyDeviceToDevice,
                           h->stream));
-  } else {
-    int n_part;
-    if ((size_t)nb * sizeof(int32_t) <= 48 * 1024) {
-      n_part = (int)std::min<int64_t>(BIN_BLOCKS, std::max<int64_t>(1, (n + 255) / 256));
-      HIPCHK(hipMemsetAsync(h->bin_partials, 0, (size_t)nb * sizeof(int32_t), h->stream));
-      if (n > 0)
-        hipLaunchKernelGGL(k_bins, dim3(n_part), dim3(256), (size_t)nb * sizeof(int32_t), h->stream,
-                           n, d_x, d_y, 1.0 / L.hww, L.nbx, L.nby, h->bin_partials);
-      n_part = 1;
-    } else {
-      n_part = 1;
-      HIPCHK(hipMemsetAsync(h->bin_partials, 0, (size_t)nb * sizeof(int32_t), h->stream));
-      if (n > 0)
-        hipLaunchKernelGGL(k_bins_global, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, n, d_x,
-                           d_y, 1.0 / L.hww, L.nbx, L.nby, h->bin_partials);
-    }
+  else
     hipLaunchKernelGGL(k_nodes, dim3(gnx_grid(nn, 128)), dim3(128), 0, h->stream, L.Jx, L.Jy, L.nbx,
-                       n_part, h->bin_partials, L.areas, V);
-  }
+                       1, d_bins, L.areas, V);
   double* Mx = V + nn;
   double* My = V + 2 * nn;
   double* Mxy = V + 3 * nn;
@@ -178,9 +182,18 @@ int gnx_l_density(gnx_state* h, int64_t n, const float* d_x, const float* d_y, G
                      L.hww, L.cprime, V, My);
   hipLaunchKernelGGL(k_spline_m, dim3(gnx_grid(L.Jy, 64)), dim3(64), 0, h->stream, L.Jx, L.Jy, 1,
                      L.hww, L.cprime, My, Mxy);
-  gnx_time_end(h, GNX_K_DENSITY, (double)n * 8.0);
   HIPCHK(hipGetLastError());
   spl->valid = true;
+  return 0;
+}
+
+int gnx_l_density(gnx_state* h, int64_t n, const float* d_x, const float* d_y, GnxSpline* spl,
+                  const double* d_nodes_override) {
+  gnx_time_begin(h);
+  int32_t* bins = (spl == &h->spl_P) ? h->bins_P : h->bin_partials;
+  if (!d_nodes_override) GNXCHK(gnx_l_bins(h, n, d_x, d_y, nullptr, bins));
+  GNXCHK(gnx_l_spline(h, bins, spl, d_nodes_override));
+  gnx_time_end(h, GNX_K_DENSITY, (double)n * 8.0);
   return 0;
 }
 
@@ -366,31 +379,37 @@ int gnx_l_death_probs(gnx_state* h, bool with_selection) {
 }
 
 // ---------------------------------------------------------------- mortality + compaction
-// _do_mortality (ops/demography.py:175-180): dead ~ Bernoulli(p_death).
+// _do_mortality (ops/demography.py:175-180): dead ~ Bernoulli(p_death).  Ghosts
+// (halo copies, tiled runs) are dropped here without counting as deaths.
 __global__ void k_alive(int64_t N, const double* p_death, const uint8_t* dead_in,
-                        const int64_t* id, long long step, unsigned long long seed,
-                        int32_t* alive) {
+                        const int64_t* id, const uint8_t* ghost, long long step,
+                        unsigned long long seed, int32_t* alive, int32_t* dead_owned) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   bool dead;
-  if (dead_in) {
+  const bool g = ghost[i] != 0;
+  if (g) {
+    dead = true;
+  } else if (dead_in) {
     dead = dead_in[i] != 0;
   } else {
     uint4 r = gnx_rand4(seed, (unsigned long long)id[i], step, OP_DEATH, 0);
     dead = (double)gnx_u01(r.x) < p_death[i];
   }
   alive[i] = dead ? 0 : 1;
+  dead_owned[i] = (dead && !g) ? 1 : 0;
 }
 
 // Stable compaction of the SoA (survivors keep their relative order); genome
 // rows are NOT moved: the dead's rows are pushed on the free stack.
 __global__ void k_compact(int64_t N, int64_t cap, const int32_t* alive, const int32_t* scan,
-                          GnxSoA a, GnxSoA b, int n_layers, int n_traits, int32_t* free_rows,
-                          int64_t n_free, int has_rows) {
+                          const int32_t* dead_owned, const int32_t* dscan, GnxSoA a, GnxSoA b,
+                          int n_layers, int n_traits, int32_t* free_rows, int64_t n_free,
+                          int has_rows) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  int64_t k = scan[i];              // survivors before i
   if (alive[i]) {
+    int64_t k = scan[i];              // survivors before i
     b.x[k] = a.x[i];
     b.y[k] = a.y[i];
     b.age[k] = a.age[i];
@@ -398,11 +417,11 @@ __global__ void k_compact(int64_t N, int64_t cap, const int32_t* alive, const in
     b.id[k] = a.id[i];
     b.fit[k] = a.fit[i];
     b.grow[k] = a.grow[i];
+    b.ghost[k] = 0;
     for (int l = 0; l < n_layers; ++l) b.e[(int64_t)l * cap + k] = a.e[(int64_t)l * cap + i];
     for (int t = 0; t < n_traits; ++t) b.z[(int64_t)t * cap + k] = a.z[(int64_t)t * cap + i];
-  } else if (has_rows) {
-    int64_t dead_rank = i - k;
-    free_rows[n_free + dead_rank] = a.grow[i];
+  } else if (has_rows && dead_owned[i]) {
+    free_rows[n_free + dscan[i]] = a.grow[i];
   }
 }
 
@@ -414,23 +433,29 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
   GnxSoA a = h->soa[h->cur], b = h->soa[h->cur ^ 1];
   gnx_time_begin(h);
   hipLaunchKernelGGL(k_alive, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, h->p_death,
-                     d_dead_inject, a.id, h->step, c.seed, h->flag);
+                     d_dead_inject, a.id, a.ghost, h->step, c.seed, h->flag, h->flag2);
   HIPCHK(hipMemsetAsync(h->flag + N, 0, sizeof(int32_t), h->stream));
+  HIPCHK(hipMemsetAsync(h->flag2 + N, 0, sizeof(int32_t), h->stream));
   GNXCHK(gnx_prim_scan(h->scan_tmp, h->scan_tmp_bytes, h->flag, h->scan, (size_t)N + 1,
+                       h->stream));
+  GNXCHK(gnx_prim_scan(h->scan_tmp, h->scan_tmp_bytes, h->flag2, h->boff, (size_t)N + 1,
                        h->stream));
   int has_rows = (h->genomes_assigned && c.L > 0) ? 1 : 0;
   hipLaunchKernelGGL(k_compact, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, c.cap_inds,
-                     h->flag, h->scan, a, b, c.n_layers, c.n_traits, h->free_rows, h->n_free,
-                     has_rows);
+                     h->flag, h->scan, h->flag2, h->boff, a, b, c.n_layers, c.n_traits,
+                     h->free_rows, h->n_free, has_rows);
   HIPCHK(hipMemcpyAsync(h->h_pin, h->scan + N, sizeof(int32_t), hipMemcpyDeviceToHost,
                         h->stream));
-  gnx_time_end(h, GNX_K_COMPACT, (double)N * (16.0 + 2.0 * (33.0 + 4.0 * c.n_layers +
+  HIPCHK(hipMemcpyAsync(h->h_pin + 1, h->boff + N, sizeof(int32_t), hipMemcpyDeviceToHost,
+                        h->stream));
+  gnx_time_end(h, GNX_K_COMPACT, (double)N * (24.0 + 2.0 * (34.0 + 4.0 * c.n_layers +
                                                              4.0 * c.n_traits)));
   HIPCHK(hipStreamSynchronize(h->stream));
   int64_t survivors = *(int32_t*)h->h_pin;
-  int64_t deaths = N - survivors;
+  int64_t deaths = *(int32_t*)(h->h_pin + 1);
   if (has_rows) h->n_free += deaths;
   h->N = survivors;
+  h->n_ghost = 0;
   h->cur ^= 1;
   *deaths_out = deaths;
   return 0;

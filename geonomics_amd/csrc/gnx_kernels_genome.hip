@@ -102,6 +102,7 @@ k_crossover(int64_t B, int W16, const u64x2* __restrict__ G, u64x2* __restrict__
     const int p = (int)(gam & 1);
     // wave-uniform metadata
     const int prow = __builtin_amdgcn_readfirstlane(grow[off_parent[2 * k + p]]);
+    if (prow < 0) continue;      // ghost parent (tiled run): gamete arrives from its tile
     const int key = __builtin_amdgcn_readfirstlane(off_keys[2 * k + p]);
     const u64 s = __builtin_amdgcn_readfirstlane((int)off_start[2 * k + p]) ? ~0ull : 0ull;
     const int crow = __builtin_amdgcn_readfirstlane(grow[first_slot + k]);

@@ -41,6 +41,7 @@ __global__ void k_init_population(int64_t N, GnxSoA s, int cap, float Wf, float 
   s.id[i] = i;
   s.fit[i] = 1.0f;
   s.grow[i] = -1;
+  s.ghost[i] = 0;
 }
 
 __global__ void k_gather_e(int64_t first, int64_t n, GnxSoA s, int64_t cap, const float* rast,
@@ -272,6 +273,7 @@ __global__ void k_permute(int64_t N, int64_t cap, const int32_t* perm, GnxSoA a,
   cand[i] = make_uint4(__float_as_uint(a.x[j]), __float_as_uint(a.y[j]), tg, (uint32_t)idv);
   b.fit[i] = a.fit[j];
   b.grow[i] = a.grow[j];
+  b.ghost[i] = a.ghost[j];
   for (int l = 0; l < n_layers; ++l) b.e[(int64_t)l * cap + i] = a.e[(int64_t)l * cap + j];
   for (int t = 0; t < n_traits; ++t) b.z[(int64_t)t * cap + i] = a.z[(int64_t)t * cap + j];
 }
@@ -506,16 +508,20 @@ __global__ void k_pair_flags(int64_t N, const int32_t* focal, const int32_t* mat
 }
 
 // unordered-pair de-duplication (ops/mating.py:62-65): the reference keeps one
-// of (i,m),(m,i); drop (i,m) iff (m,i) is also present and m < i.
+// of (i,m),(m,i); drop (i,m) iff (m,i) is also present and id_m < id_i (ids, not
+// slots, so every tile of a tiled run takes the same decision).  A pair belongs
+// to the tile that owns its focal individual: ghost focals only serve the
+// reciprocity test.
 __global__ void k_pair_dedup(int64_t N, const int32_t* mate, const int32_t* flag, int sexed,
-                             int32_t* flag2) {
+                             const int64_t* id, const uint8_t* ghost, int32_t* flag2) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   int f = flag[i];
   if (f && !sexed) {
     int m = mate[i];
-    if (flag[m] && mate[m] == (int32_t)i && m < (int32_t)i) f = 0;
+    if (flag[m] && mate[m] == (int32_t)i && id[m] < id[i]) f = 0;
   }
+  if (ghost[i]) f = 0;
   flag2[i] = f;
 }
 
@@ -534,6 +540,23 @@ __global__ void k_pair_compact(int64_t N, const int32_t* focal, const int32_t* m
     mid_x[p] = (x[fo] + x[m]) / 2.0f;
     mid_y[p] = (y[fo] + y[m]) / 2.0f;
   }
+}
+
+__global__ void k_pair_keys(int64_t P, const int32_t* pairs, const int64_t* id, uint64_t* key,
+                            int32_t* idx) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  key[p] = (uint64_t)id[pairs[2 * p]];
+  idx[p] = (int32_t)p;
+}
+
+__global__ void k_pair_reorder(int64_t P, const int32_t* perm, const int32_t* pairs,
+                               int32_t* pairs2) {
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= P) return;
+  int p = perm[q];
+  pairs2[2 * q] = pairs[2 * p];
+  pairs2[2 * q + 1] = pairs[2 * p + 1];
 }
 
 // panmixia (structs/species.py:2178-2194): n ~ Binomial(N, b) pairs, both
@@ -601,7 +624,7 @@ int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out) 
                      d_keep, s, (float)sp.b, sexed, sp.repro_age[0], sp.repro_age[1], h->step,
                      h->cfg.seed, h->flag);
   hipLaunchKernelGGL(k_pair_dedup, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, h->mate,
-                     h->flag, sexed_dedup, h->flag2);
+                     h->flag, sexed_dedup, s.id, s.ghost, h->flag2);
   // scan over N+1 so that scan[N] = number of pairs
   HIPCHK(hipMemsetAsync(h->flag2 + N, 0, sizeof(int32_t), h->stream));
   GNXCHK(gnx_prim_scan(h->scan_tmp, h->scan_tmp_bytes, h->flag2, h->scan, (size_t)N + 1,
@@ -614,6 +637,21 @@ int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out) 
   HIPCHK(hipStreamSynchronize(h->stream));
   h->n_pairs = *(int32_t*)h->h_pin;
   *n_pairs_out = h->n_pairs;
+  // Order the pairs by the id of their focal individual: offspring ids are then
+  // handed out in an order that does not depend on slot order or on how the
+  // landscape is tiled over GPUs (the reference's own order is that of a Python
+  // set, i.e. unspecified: ops/mating.py:63).
+  const int64_t P = h->n_pairs;
+  if (P > 1) {
+    hipLaunchKernelGGL(k_pair_keys, dim3(gnx_grid(P, 256)), dim3(256), 0, h->stream, P, h->pairs,
+                       s.id, h->key64[0], h->perm[0]);
+    GNXCHK(gnx_prim_sort64(h->sort64_tmp, h->sort64_tmp_bytes, h->key64[0], h->key64[1],
+                           h->perm[0], h->perm[1], (size_t)P, h->stream));
+    hipLaunchKernelGGL(k_pair_reorder, dim3(gnx_grid(P, 256)), dim3(256), 0, h->stream, P,
+                       h->perm[1], h->pairs, h->pairs2);
+    std::swap(h->pairs, h->pairs2);
+    HIPCHK(hipGetLastError());
+  }
   return 0;
 }
 
@@ -655,11 +693,22 @@ struct OffP {
   float p_male;
   int fixed_nb;          // > 0: every pair has this many births
   int genomes;           // allocate genome rows + draw keys
-  int inject_keys;       // keys/start homologues already in off_keys/off_start
   int n_paths;
-  int64_t max_id, n_free;
+  int64_t id_base, n_free;
   long long step;
   unsigned long long seed;
+};
+
+// gamete requests of a tiled run: the mate is a ghost (it lives on a neighbour
+// tile), so its gamete is computed there and shipped back
+struct GnxReq {
+  int64_t* pid;      // parent (ghost) id
+  int32_t* k;        // local offspring index
+  int32_t* key;      // recombination path
+  uint8_t* start;    // start homologue
+  float* px;         // ghost position (-> owner tile)
+  float* py;
+  int32_t* count;
 };
 
 // one dispersal attempt (ops/movement.py:98-141): returns true when accepted
@@ -676,18 +725,28 @@ __device__ __forceinline__ bool disperse_once(float mx, float my, float theta, f
   return ox > 0.0f && oy > 0.0f;
 }
 
-// Offspring records (structs/species.py:613-688): ids max_id+1.. in (pair,
-// birth) order, parents' midpoint, dispersal, age 0, sex, environment, genome
-// row, recombination keys and start homologues.
+// Offspring records (structs/species.py:613-688): ids id_base.. in (pair,
+// birth) order with pairs ordered by focal id, parents' midpoint, dispersal,
+// age 0, sex, environment, genome row, recombination keys, start homologues.
 __global__ void __launch_bounds__(256)
 k_offspring(OffP P, GnxSoA s, const float* rast, const int32_t* pairs, const int32_t* off_pair,
-            const int32_t* free_rows, int32_t* off_parent, int32_t* off_keys, uint8_t* off_start) {
+            const int32_t* boff, const int64_t* goff, const int32_t* free_rows,
+            int32_t* off_parent, int32_t* off_keys, uint8_t* off_start, GnxReq rq) {
   int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= P.B) return;
-  int64_t p = P.fixed_nb > 0 ? k / P.fixed_nb : off_pair[k];
+  int64_t p, ord;
+  if (P.fixed_nb > 0) {
+    p = k / P.fixed_nb;
+    ord = k - p * P.fixed_nb;
+  } else {
+    p = off_pair[k];
+    ord = k - boff[p];
+  }
+  // global offspring index: local k on one GPU, the pair's global offset on tiles
+  const int64_t gk = goff ? goff[p] + ord : k;
   int i = pairs[2 * p], m = pairs[2 * p + 1];
   int64_t slot = P.N + k;
-  unsigned long long oid = (unsigned long long)(P.max_id + 1 + k);
+  unsigned long long oid = (unsigned long long)(P.id_base + gk);
   float mx = (s.x[i] + s.x[m]) / 2.0f;
   float my = (s.y[i] + s.y[m]) / 2.0f;
   float ox = mx, oy = my;
@@ -719,6 +778,7 @@ k_offspring(OffP P, GnxSoA s, const float* rast, const int32_t* pairs, const int
   s.sex[slot] = sx;
   s.id[slot] = (int64_t)oid;
   s.fit[slot] = 1.0f;
+  s.ghost[slot] = 0;
   int cx = (int)ox, cy = (int)oy;
   for (int l = 0; l < P.n_layers; ++l)
     s.e[(int64_t)l * P.cap + slot] = rast[((int64_t)l * P.H + cy) * P.W + cx];
@@ -726,21 +786,31 @@ k_offspring(OffP P, GnxSoA s, const float* rast, const int32_t* pairs, const int
   off_parent[2 * k + 1] = m;
   if (P.genomes) {
     s.grow[slot] = free_rows[P.n_free - 1 - k];
-    if (!P.inject_keys) {
-      // start homologues ~ Bernoulli(.5) x2 (ops/mating.py:133); keys ~
-      // randint(0, n_paths) x2 (structs/species.py:625)
-      off_start[2 * k] = (uint8_t)(r.x & 1u);
-      off_start[2 * k + 1] = (uint8_t)((r.x >> 1) & 1u);
-      off_keys[2 * k] = (int32_t)(((unsigned long long)r.y * (unsigned long long)P.n_paths) >> 32);
-      off_keys[2 * k + 1] = (int32_t)(((unsigned long long)r.z * (unsigned long long)P.n_paths) >> 32);
+    // start homologues ~ Bernoulli(.5) x2 (ops/mating.py:133); keys ~
+    // randint(0, n_paths) x2 (structs/species.py:625)
+    const uint8_t st0 = (uint8_t)(r.x & 1u), st1 = (uint8_t)((r.x >> 1) & 1u);
+    const int32_t k0 = (int32_t)(((unsigned long long)r.y * (unsigned long long)P.n_paths) >> 32);
+    const int32_t k1 = (int32_t)(((unsigned long long)r.z * (unsigned long long)P.n_paths) >> 32);
+    off_start[2 * k] = st0;
+    off_start[2 * k + 1] = st1;
+    off_keys[2 * k] = k0;
+    off_keys[2 * k + 1] = k1;
+    if (s.ghost[m] && rq.count) {
+      int q = atomicAdd(rq.count, 1);
+      rq.pid[q] = s.id[m];
+      rq.k[q] = (int32_t)k;
+      rq.key[q] = k1;
+      rq.start[q] = st1;
+      rq.px[q] = s.x[m];
+      rq.py[q] = s.y[m];
     }
   } else {
     s.grow[slot] = -1;
   }
 }
 
-// appends B offspring of the pairs in h->pairs; inject: parents/keys/starts were
-// uploaded to off_parent/off_keys/off_start and no positions are drawn
+// appends B offspring whose parents/keys/starts were uploaded to
+// off_parent/off_keys/off_start (operator-level test entry); no positions drawn
 __global__ void k_offspring_inject(int64_t N, int64_t B, int64_t cap, GnxSoA s, const float* rast,
                                    int n_layers, int W, int H, const int32_t* off_parent,
                                    const int32_t* free_rows, int64_t n_free, int64_t max_id) {
@@ -755,13 +825,53 @@ __global__ void k_offspring_inject(int64_t N, int64_t B, int64_t cap, GnxSoA s, 
   s.sex[slot] = 0;
   s.id[slot] = max_id + 1 + k;
   s.fit[slot] = 1.0f;
+  s.ghost[slot] = 0;
   s.grow[slot] = free_rows[n_free - 1 - k];
   int cx = (int)ox, cy = (int)oy;
   for (int l = 0; l < n_layers; ++l)
     s.e[(int64_t)l * cap + slot] = rast[((int64_t)l * H + cy) * W + cx];
 }
 
-int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* births_out) {
+// number of births of the current pair list (fixed lambda or max(Poisson, 1))
+int gnx_l_births(gnx_state* h, int64_t* births_out) {
+  const gnx_species_params& sp = h->sp;
+  GnxSoA s = h->soa[h->cur];
+  int64_t P = h->n_pairs, B = 0;
+  if (P > 0) {
+    if (sp.n_births_fixed) {
+      B = P * (int64_t)sp.n_births_lambda;
+    } else {
+      float thr = (float)exp(-sp.n_births_lambda);
+      hipLaunchKernelGGL(k_births, dim3(gnx_grid(P, 256)), dim3(256), 0, h->stream, P, h->pairs,
+                         s.id, thr, h->step, h->cfg.seed, h->nbirths);
+      HIPCHK(hipMemsetAsync(h->nbirths + P, 0, sizeof(int32_t), h->stream));
+      GNXCHK(gnx_prim_scan(h->scan_tmp, h->scan_tmp_bytes, h->nbirths, h->boff, (size_t)P + 1,
+                           h->stream));
+      HIPCHK(hipMemcpyAsync(h->h_pin, h->boff + P, sizeof(int32_t), hipMemcpyDeviceToHost,
+                            h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      B = *(int32_t*)h->h_pin;
+      if (B > h->cfg.cap_inds) {
+        gnx_set_error("capacity exceeded: births %lld > cap_inds %lld", (long long)B,
+                      (long long)h->cfg.cap_inds);
+        return 2;
+      }
+      hipLaunchKernelGGL(k_expand_births, dim3(gnx_grid(P, 256)), dim3(256), 0, h->stream, P,
+                         h->nbirths, h->boff, h->off_pair);
+      HIPCHK(hipGetLastError());
+    }
+  }
+  h->n_births_pending = B;
+  *births_out = B;
+  return 0;
+}
+
+// Appends the offspring of the current pair list (or, inject: of the uploaded
+// parent list).  tiled: births were counted by gnx_l_births, offspring ids are
+// id_base + pair_goff[pair] + ordinal, gametes of ghost mates are requested,
+// and phenotypes are left to the caller (they need the remote gametes).
+int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* births_out,
+               int64_t id_base, bool tiled) {
   const gnx_config& c = h->cfg;
   const gnx_species_params& sp = h->sp;
   GnxSoA s = h->soa[h->cur];
@@ -780,31 +890,8 @@ int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* 
                        B, c.cap_inds, s, h->rast, c.n_layers, c.W, c.H, h->off_parent,
                        h->free_rows, h->n_free, h->max_id);
   } else {
-    int64_t P = h->n_pairs;
-    if (P == 0) return 0;
-    int fixed_nb = 0;
-    if (sp.n_births_fixed) {
-      fixed_nb = (int)sp.n_births_lambda;
-      B = P * fixed_nb;
-    } else {
-      float thr = (float)exp(-sp.n_births_lambda);
-      hipLaunchKernelGGL(k_births, dim3(gnx_grid(P, 256)), dim3(256), 0, h->stream, P, h->pairs,
-                         s.id, thr, h->step, c.seed, h->nbirths);
-      HIPCHK(hipMemsetAsync(h->nbirths + P, 0, sizeof(int32_t), h->stream));
-      GNXCHK(gnx_prim_scan(h->scan_tmp, h->scan_tmp_bytes, h->nbirths, h->boff, (size_t)P + 1,
-                           h->stream));
-      HIPCHK(hipMemcpyAsync(h->h_pin, h->boff + P, sizeof(int32_t), hipMemcpyDeviceToHost,
-                            h->stream));
-      HIPCHK(hipStreamSynchronize(h->stream));
-      B = *(int32_t*)h->h_pin;
-      if (B > c.cap_inds) {
-        gnx_set_error("capacity exceeded: births %lld > cap_inds %lld", (long long)B,
-                      (long long)c.cap_inds);
-        return 2;
-      }
-      hipLaunchKernelGGL(k_expand_births, dim3(gnx_grid(P, 256)), dim3(256), 0, h->stream, P,
-                         h->nbirths, h->boff, h->off_pair);
-    }
+    if (!tiled) GNXCHK(gnx_l_births(h, &B));
+    B = h->n_births_pending;
     if (B == 0) return 0;
     if (h->N + B > c.cap_inds || (genomes && B > h->n_free)) {
       gnx_set_error("capacity exceeded: N=%lld + births=%lld > cap_inds=%lld (free rows %lld)",
@@ -830,28 +917,38 @@ int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* 
     Q.surf_kappa = (float)sp.disp_surf_kappa;
     Q.sexed = sp.sexed;
     Q.p_male = (float)sp.p_male;
-    Q.fixed_nb = fixed_nb;
+    Q.fixed_nb = sp.n_births_fixed ? (int)sp.n_births_lambda : 0;
     Q.genomes = genomes ? 1 : 0;
-    Q.inject_keys = 0;
     Q.n_paths = h->n_paths;
-    Q.max_id = h->max_id;
+    Q.id_base = id_base >= 0 ? id_base : h->max_id + 1;
     Q.n_free = h->n_free;
     Q.step = h->step;
     Q.seed = c.seed;
+    GnxReq rq{};
+    if (tiled && genomes) {
+      rq.pid = h->req_pid;
+      rq.k = h->req_k;
+      rq.key = h->req_key;
+      rq.start = h->req_start;
+      rq.px = h->req_px;
+      rq.py = h->req_py;
+      rq.count = h->req_count;
+      HIPCHK(hipMemsetAsync(h->req_count, 0, sizeof(int32_t), h->stream));
+    }
     gnx_time_begin(h);
     hipLaunchKernelGGL(k_offspring, dim3(gnx_grid(B, 256)), dim3(256), 0, h->stream, Q, s, h->rast,
-                       h->pairs, h->off_pair, h->free_rows, h->off_parent, h->off_keys,
-                       h->off_start);
+                       h->pairs, h->off_pair, h->boff, tiled ? h->pair_goff : nullptr,
+                       h->free_rows, h->off_parent, h->off_keys, h->off_start, rq);
     gnx_time_end(h, GNX_K_OFFSPRING, (double)B * (60.0 + 8.0 * c.n_layers));
   }
   HIPCHK(hipGetLastError());
   if (genomes || inject) {
     GNXCHK(gnx_l_crossover(h, h->N, B));
     h->n_free -= B;
-    if (c.n_traits > 0) GNXCHK(gnx_l_phenotype_births(h, h->N, B));
+    if (c.n_traits > 0 && !tiled) GNXCHK(gnx_l_phenotype_births(h, h->N, B));
   }
   h->N += B;
-  h->max_id += B;
+  if (!tiled) h->max_id += B;
   *births_out = B;
   return 0;
 }

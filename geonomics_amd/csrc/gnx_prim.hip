@@ -31,3 +31,17 @@ int gnx_prim_scan(void* tmp, size_t bytes, const int32_t* in, int32_t* out, size
   HIPCHK(rocprim::exclusive_scan(tmp, bytes, in, out, 0, n, rocprim::plus<int32_t>(), s));
   return 0;
 }
+
+int gnx_prim_sort64_bytes(size_t n, size_t* bytes) {
+  *bytes = 0;
+  HIPCHK(rocprim::radix_sort_pairs(nullptr, *bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr,
+                                   (const int32_t*)nullptr, (int32_t*)nullptr, n, 0, 64,
+                                   (hipStream_t)0));
+  return 0;
+}
+
+int gnx_prim_sort64(void* tmp, size_t bytes, const uint64_t* kin, uint64_t* kout,
+                    const int32_t* vin, int32_t* vout, size_t n, hipStream_t s) {
+  HIPCHK(rocprim::radix_sort_pairs(tmp, bytes, kin, kout, vin, vout, n, 0, 64, s));
+  return 0;
+}

@@ -1,0 +1,564 @@
+// Spatial tiling of one species over several GPUs.
+//
+// The landscape is cut into a uniform R x C grid of tiles; one process/GPU owns
+// one tile and every individual whose (x, y) lies in it.  Every rank keeps the
+// whole (small) rasters and works in global coordinates.  Per time step the
+// host layer (geonomics_amd/parallel.py, torch.distributed over RCCL) moves:
+//   1. migrants   - individuals that left their tile, with their genomes;
+//   2. halo       - light copies (x, y, age, sex, id) of individuals within
+//                   2 x mating_radius of a tile border ("ghosts"): candidates
+//                   for the mate search AND focal individuals whose own choice
+//                   is recomputed locally, so that the reciprocal-pair rule
+//                   gives the same answer on both sides of a border;
+//   3. pair lists - focal ids + birth counts, all-gathered, so that offspring
+//                   ids are the same as on one GPU (pairs ordered by focal id);
+//   4. gametes    - the gamete of a ghost mate is cut from its genome on the
+//                   tile that owns it and shipped back (L/8 bytes);
+//   5. density    - the integer half-window bin counts, all-reduced (sum).
+// All random draws are keyed by individual id, all choices are order-
+// independent, so a tiled run reproduces the single-GPU run bit for bit.
+#include <algorithm>
+#include "gnx_internal.h"
+#include "gnx_rng.h"
+
+typedef unsigned long long u64;
+struct alignas(16) u64x2 {
+  u64 a, b;
+};
+
+struct TileBox {
+  float x0, y0, x1, y1;   // own tile [x0,x1) x [y0,y1)
+  int r, c, R, C;
+};
+
+static TileBox tile_box(const gnx_state* h) {
+  TileBox t;
+  float tw = (float)h->cfg.W / h->tile_C, th = (float)h->cfg.H / h->tile_R;
+  t.x0 = h->tile_c * tw;
+  t.x1 = (h->tile_c + 1) * tw;
+  t.y0 = h->tile_r * th;
+  t.y1 = (h->tile_r + 1) * th;
+  t.r = h->tile_r;
+  t.c = h->tile_c;
+  t.R = h->tile_R;
+  t.C = h->tile_C;
+  return t;
+}
+
+extern "C" int gnx_tile_set(gnx_state* h, int32_t R, int32_t C, int32_t r, int32_t c) {
+  if (R < 1 || C < 1 || r < 0 || r >= R || c < 0 || c >= C || h->cfg.W % C || h->cfg.H % R) {
+    gnx_set_error("gnx_tile_set: bad tile grid %dx%d (%d,%d) for a %dx%d landscape", R, C, r, c,
+                  h->cfg.W, h->cfg.H);
+    return 1;
+  }
+  h->tile_R = R;
+  h->tile_C = C;
+  h->tile_r = r;
+  h->tile_c = c;
+  h->tiled = R * C > 1;
+  return 0;
+}
+
+// ---------------------------------------------------------------- pack / unpack
+__global__ void k_mark_out(int64_t N, const float* x, const float* y, TileBox t, int32_t* flag,
+                           uint8_t* dead) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  bool out = x[i] < t.x0 || x[i] >= t.x1 || y[i] < t.y0 || y[i] >= t.y1;
+  flag[i] = out ? 1 : 0;
+  dead[i] = out ? 1 : 0;
+}
+
+// neighbour bit k = (dy+1)*3 + (dx+1), dy,dx in {-1,0,1} (bit 4 unused)
+__global__ void k_mark_halo(int64_t N, const float* x, const float* y, const uint8_t* ghost,
+                            TileBox t, float width, int32_t* flag, int32_t* mask) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int m = 0;
+  if (!ghost[i]) {
+    const bool L = t.c > 0 && x[i] - t.x0 < width;
+    const bool Rr = t.c < t.C - 1 && t.x1 - x[i] <= width;
+    const bool U = t.r > 0 && y[i] - t.y0 < width;
+    const bool D = t.r < t.R - 1 && t.y1 - y[i] <= width;
+    if (L) m |= 1 << 3;
+    if (Rr) m |= 1 << 5;
+    if (U) m |= 1 << 1;
+    if (D) m |= 1 << 7;
+    if (L && U) m |= 1 << 0;
+    if (Rr && U) m |= 1 << 2;
+    if (L && D) m |= 1 << 6;
+    if (Rr && D) m |= 1 << 8;
+  }
+  mask[i] = m;
+  flag[i] = m ? 1 : 0;
+}
+
+__global__ void k_pack(int64_t N, int64_t cap, const int32_t* flag, const int32_t* scan,
+                       const int32_t* mask, GnxSoA s, int n_traits, gnx_ind_rec* rec, float* zrec,
+                       int64_t* slots) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N || !flag[i]) return;
+  int64_t q = scan[i];
+  gnx_ind_rec r;
+  r.x = s.x[i];
+  r.y = s.y[i];
+  r.age = s.age[i];
+  r.sex = s.sex[i];
+  r.id = s.id[i];
+  r.fit = s.fit[i];
+  r.nbr_mask = mask ? mask[i] : 0;
+  rec[q] = r;
+  if (zrec)
+    for (int t = 0; t < n_traits; ++t) zrec[q * n_traits + t] = s.z[(int64_t)t * cap + i];
+  if (slots) slots[q] = i;
+}
+
+__global__ void k_unpack(int64_t N, int64_t n, int64_t cap, GnxSoA s, const gnx_ind_rec* rec,
+                         const float* zrec, int n_traits, int n_layers, const float* rast, int W,
+                         int H, const int32_t* free_rows, int64_t n_free, int has_rows, int ghost) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  int64_t slot = N + k;
+  gnx_ind_rec r = rec[k];
+  s.x[slot] = r.x;
+  s.y[slot] = r.y;
+  s.age[slot] = r.age;
+  s.sex[slot] = (uint8_t)r.sex;
+  s.id[slot] = r.id;
+  s.fit[slot] = r.fit;
+  s.ghost[slot] = (uint8_t)ghost;
+  s.grow[slot] = (has_rows && !ghost) ? free_rows[n_free - 1 - k] : -1;
+  for (int t = 0; t < n_traits; ++t)
+    s.z[(int64_t)t * cap + slot] = zrec ? zrec[k * n_traits + t] : 0.f;
+  int cx = (int)r.x, cy = (int)r.y;
+  for (int l = 0; l < n_layers; ++l)
+    s.e[(int64_t)l * cap + slot] = rast[((int64_t)l * H + cy) * W + cx];
+}
+
+__global__ void k_scatter_genomes(int64_t n, int W16, const u64x2* in, u64x2* G,
+                                  const int32_t* grow, int64_t first_slot) {
+  const int64_t total = n * 2 * (int64_t)W16;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+    int64_t k = g / (2 * W16);
+    int64_t c = g - k * 2 * W16;
+    G[(int64_t)grow[first_slot + k] * 2 * W16 + c] = in[g];
+  }
+}
+
+template <typename T>
+static int dalloc_t(T** p, size_t n) {
+  *p = nullptr;
+  HIPCHK(hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T)));
+  return 0;
+}
+
+static bool has_rows(const gnx_state* h) { return h->genomes_assigned && h->cfg.L > 0; }
+
+static int stage_selection(gnx_state* h, const int32_t* d_mask, bool with_z, bool with_geno,
+                           int64_t* n_out) {
+  // flag[] is set; pack the flagged individuals into the staging buffers
+  int64_t N = h->N;
+  GnxSoA s = h->soa[h->cur];
+  HIPCHK(hipMemsetAsync(h->flag + N, 0, sizeof(int32_t), h->stream));
+  GNXCHK(gnx_prim_scan(h->scan_tmp, h->scan_tmp_bytes, h->flag, h->scan, (size_t)N + 1,
+                       h->stream));
+  HIPCHK(hipMemcpyAsync(h->h_pin, h->scan + N, sizeof(int32_t), hipMemcpyDeviceToHost,
+                        h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  int64_t n = *(int32_t*)h->h_pin;
+  *n_out = n;
+  (void)hipFree(h->st_rec);
+  (void)hipFree(h->st_z);
+  (void)hipFree(h->st_geno);
+  (void)hipFree(h->st_slots);
+  h->st_rec = nullptr;
+  h->st_z = nullptr;
+  h->st_geno = nullptr;
+  h->st_slots = nullptr;
+  h->st_n = n;
+  if (n == 0) return 0;
+  GNXCHK(dalloc_t(&h->st_rec, (size_t)n));
+  if (with_z && h->cfg.n_traits) GNXCHK(dalloc_t(&h->st_z, (size_t)n * h->cfg.n_traits));
+  GNXCHK(dalloc_t(&h->st_slots, (size_t)n));
+  hipLaunchKernelGGL(k_pack, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, h->cfg.cap_inds,
+                     h->flag, h->scan, d_mask, s, h->cfg.n_traits, h->st_rec, h->st_z, h->st_slots);
+  if (with_geno && has_rows(h)) {
+    GNXCHK(dalloc_t(&h->st_geno, (size_t)n * 2 * h->W64));
+    GNXCHK(gnx_l_gather_genomes(h, n, h->st_slots, h->st_geno));
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// individuals that left the tile: pack them (records, phenotypes, genomes) and
+// remove them from this tile (their genome rows are freed)
+extern "C" int gnx_tile_export_migrants(gnx_state* h, int64_t* n_out) {
+  *n_out = 0;
+  if (h->n_ghost) {
+    gnx_set_error("gnx_tile_export_migrants: ghosts are resident");
+    return 1;
+  }
+  int64_t N = h->N;
+  if (N == 0) return 0;
+  GnxSoA s = h->soa[h->cur];
+  hipLaunchKernelGGL(k_mark_out, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, s.x, s.y,
+                     tile_box(h), h->flag, h->dead_in);
+  GNXCHK(stage_selection(h, nullptr, true, true, n_out));
+  if (*n_out > 0) {
+    int64_t D = 0;
+    GNXCHK(gnx_l_mortality(h, h->dead_in, &D));
+  }
+  return 0;
+}
+
+extern "C" int gnx_tile_export_halo(gnx_state* h, double width, int64_t* n_out) {
+  *n_out = 0;
+  int64_t N = h->N;
+  if (N == 0) return 0;
+  GnxSoA s = h->soa[h->cur];
+  hipLaunchKernelGGL(k_mark_halo, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, s.x, s.y,
+                     s.ghost, tile_box(h), (float)width, h->flag, h->mate);
+  return stage_selection(h, h->mate, false, false, n_out);
+}
+
+// read the staged selection (after export_migrants / export_halo)
+extern "C" int gnx_tile_get_staged(gnx_state* h, gnx_ind_rec* rec, float* z, uint64_t* geno) {
+  int64_t n = h->st_n;
+  if (n == 0) return 0;
+  if (rec) HIPCHK(hipMemcpy(rec, h->st_rec, n * sizeof(gnx_ind_rec), hipMemcpyDeviceToHost));
+  if (z && h->st_z)
+    HIPCHK(hipMemcpy(z, h->st_z, n * h->cfg.n_traits * sizeof(float), hipMemcpyDeviceToHost));
+  if (geno && h->st_geno)
+    HIPCHK(hipMemcpy(geno, h->st_geno, (size_t)n * 2 * h->W64 * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+static int import_common(gnx_state* h, int64_t n, const gnx_ind_rec* rec, const float* z,
+                         const uint64_t* geno, int ghost) {
+  if (n == 0) return 0;
+  const gnx_config& c = h->cfg;
+  const bool rows = has_rows(h) && !ghost;
+  if (h->N + n > c.cap_inds || (rows && n > h->n_free)) {
+    gnx_set_error("capacity exceeded importing %lld individuals (N=%lld cap=%lld free rows %lld)",
+                  (long long)n, (long long)h->N, (long long)c.cap_inds, (long long)h->n_free);
+    return 2;
+  }
+  for (int64_t k = 0; k < n; ++k)
+    if (!(rec[k].x >= 0 && rec[k].x < c.W && rec[k].y >= 0 && rec[k].y < c.H)) {
+      gnx_set_error("import: record %lld is off the landscape", (long long)k);
+      return 1;
+    }
+  gnx_ind_rec* d_rec = nullptr;
+  float* d_z = nullptr;
+  u64* d_g = nullptr;
+  GNXCHK(dalloc_t(&d_rec, (size_t)n));
+  HIPCHK(hipMemcpy(d_rec, rec, n * sizeof(gnx_ind_rec), hipMemcpyHostToDevice));
+  if (z && c.n_traits) {
+    GNXCHK(dalloc_t(&d_z, (size_t)n * c.n_traits));
+    HIPCHK(hipMemcpy(d_z, z, n * c.n_traits * sizeof(float), hipMemcpyHostToDevice));
+  }
+  GnxSoA s = h->soa[h->cur];
+  hipLaunchKernelGGL(k_unpack, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, h->N, n,
+                     c.cap_inds, s, d_rec, d_z, c.n_traits, c.n_layers, h->rast, c.W, c.H,
+                     h->free_rows, h->n_free, rows ? 1 : 0, ghost);
+  if (rows) {
+    if (!geno) {
+      gnx_set_error("import: genomes are assigned on this tile but none were sent");
+      return 1;
+    }
+    GNXCHK(dalloc_t(&d_g, (size_t)n * 2 * h->W64));
+    HIPCHK(hipMemcpy(d_g, geno, (size_t)n * 2 * h->W64 * 8, hipMemcpyHostToDevice));
+    const int W16 = h->W64 / 2;
+    hipLaunchKernelGGL(k_scatter_genomes, dim3(gnx_grid(n * 2 * W16, 256, 256 * 32)), dim3(256), 0,
+                       h->stream, n, W16, (const u64x2*)d_g, (u64x2*)h->G, s.grow, h->N);
+    h->n_free -= n;
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  (void)hipFree(d_rec);
+  (void)hipFree(d_z);
+  (void)hipFree(d_g);
+  h->N += n;
+  if (ghost) h->n_ghost += n;
+  for (int64_t k = 0; k < n; ++k) h->max_id = std::max<int64_t>(h->max_id, rec[k].id);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int gnx_tile_import(gnx_state* h, int64_t n, const gnx_ind_rec* rec, const float* z,
+                               const uint64_t* geno) {
+  return import_common(h, n, rec, z, geno, 0);
+}
+
+extern "C" int gnx_tile_import_ghosts(gnx_state* h, int64_t n, const gnx_ind_rec* rec) {
+  return import_common(h, n, rec, nullptr, nullptr, 1);
+}
+
+// ---------------------------------------------------------------- step phases
+extern "C" int gnx_tile_pairs(gnx_state* h, int32_t burn, int64_t* n_pairs, int64_t* n_births) {
+  if (!h->have_sp) {
+    gnx_set_error("species parameters not set");
+    return 1;
+  }
+  if (h->sp.mating_radius < 0) {
+    gnx_set_error("panmixia (mating_radius None) is not supported on a tiled landscape");
+    return 1;
+  }
+  int64_t P = 0, B = 0;
+  GNXCHK(gnx_l_sort_by_cell(h));
+  GNXCHK(gnx_l_find_pairs(h, nullptr, &P));
+  GNXCHK(gnx_l_bins(h, P, h->mid_x, h->mid_y, nullptr, h->bins_P));
+  GNXCHK(gnx_l_births(h, &B));
+  *n_pairs = P;
+  *n_births = B;
+  return 0;
+}
+
+// focal ids (ascending) and birth counts of the local pair list
+extern "C" int gnx_tile_pair_info(gnx_state* h, int64_t* focal_ids, int32_t* n_births) {
+  int64_t P = h->n_pairs;
+  if (P == 0) return 0;
+  GnxSoA s = h->soa[h->cur];
+  std::vector<int32_t> pr(2 * P);
+  std::vector<int64_t> ids(h->N);
+  HIPCHK(hipMemcpy(pr.data(), h->pairs, 2 * P * sizeof(int32_t), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(ids.data(), s.id, h->N * sizeof(int64_t), hipMemcpyDeviceToHost));
+  for (int64_t p = 0; p < P; ++p) focal_ids[p] = ids[pr[2 * p]];
+  if (h->sp.n_births_fixed)
+    for (int64_t p = 0; p < P; ++p) n_births[p] = (int32_t)h->sp.n_births_lambda;
+  else
+    HIPCHK(hipMemcpy(n_births, h->nbirths, P * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int gnx_get_bins(gnx_state* h, int32_t which, int32_t* out) {
+  size_t nb = (size_t)h->lat.nbx * h->lat.nby;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(out, which ? h->bins_P : h->bin_partials, nb * sizeof(int32_t),
+                   hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int gnx_set_bins(gnx_state* h, int32_t which, const int32_t* in) {
+  size_t nb = (size_t)h->lat.nbx * h->lat.nby;
+  HIPCHK(hipMemcpy(which ? h->bins_P : h->bin_partials, in, nb * sizeof(int32_t),
+                   hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int gnx_density_bin_count(gnx_state* h) { return h->lat.nbx * h->lat.nby; }
+
+extern "C" int gnx_tile_offspring(gnx_state* h, int32_t burn, int64_t id_base,
+                                  const int64_t* pair_goff, int64_t* n_requests) {
+  *n_requests = 0;
+  int64_t P = h->n_pairs, B = 0;
+  h->birth_first_slot = h->N;
+  if (P > 0)
+    HIPCHK(hipMemcpy(h->pair_goff, pair_goff, P * sizeof(int64_t), hipMemcpyHostToDevice));
+  GNXCHK(gnx_l_mate(h, burn != 0, false, 0, &B, id_base, true));
+  h->last_births = B;
+  if (B > 0 && !burn && has_rows(h)) {
+    HIPCHK(hipMemcpyAsync(h->h_pin, h->req_count, sizeof(int32_t), hipMemcpyDeviceToHost,
+                          h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *n_requests = *(int32_t*)h->h_pin;
+  }
+  h->n_req = *n_requests;
+  return 0;
+}
+
+extern "C" int gnx_tile_get_requests(gnx_state* h, int64_t* pid, int32_t* child_k, int32_t* key,
+                                     uint8_t* start, float* px, float* py) {
+  int64_t n = h->n_req;
+  if (n == 0) return 0;
+  HIPCHK(hipMemcpy(pid, h->req_pid, n * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(child_k, h->req_k, n * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(key, h->req_key, n * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(start, h->req_start, n, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(px, h->req_px, n * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(py, h->req_py, n * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ---------------------------------------------------------------- gamete service
+__global__ void k_id_keys(int64_t N, const int64_t* id, uint64_t* key, int32_t* slot) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  key[i] = (uint64_t)id[i];
+  slot[i] = (int32_t)i;
+}
+
+__global__ void k_lookup(int64_t n, const int64_t* want, int64_t N, const uint64_t* sorted_ids,
+                         const int32_t* sorted_slots, int32_t* out_slot, int32_t* n_missing) {
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  uint64_t w = (uint64_t)want[q];
+  int64_t lo = 0, hi = N;
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if (sorted_ids[mid] < w) lo = mid + 1; else hi = mid;
+  }
+  if (lo < N && sorted_ids[lo] == w) {
+    out_slot[q] = sorted_slots[lo];
+  } else {
+    out_slot[q] = -1;
+    atomicAdd(n_missing, 1);
+  }
+}
+
+// gamete of parent slot[q] along path key[q] from start homologue start[q]
+// (ops/mating.py:165-168), one wave per gamete, written to out[q][W16]
+__global__ void __launch_bounds__(256)
+k_make_gametes(int64_t n, int W16, const u64x2* __restrict__ G, const int32_t* __restrict__ grow,
+               const int32_t* __restrict__ slot, const int32_t* __restrict__ keys,
+               const uint8_t* __restrict__ starts, const u64x2* __restrict__ paths,
+               u64x2* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (q >= n) return;
+  const int prow = grow[slot[q]];
+  const u64 s = starts[q] ? ~0ull : 0ull;
+  const u64x2* h0 = G + ((int64_t)prow * 2 + 0) * W16;
+  const u64x2* h1 = G + ((int64_t)prow * 2 + 1) * W16;
+  const u64x2* pm = paths + (int64_t)keys[q] * W16;
+  for (int c = lane; c < W16; c += 64) {
+    u64x2 m = pm[c];
+    m.a ^= s;
+    m.b ^= s;
+    const u64x2 a = h0[c], b = h1[c];
+    u64x2 o;
+    o.a = (a.a & ~m.a) | (b.a & m.a);
+    o.b = (a.b & ~m.b) | (b.b & m.b);
+    out[q * W16 + c] = o;
+  }
+}
+
+extern "C" int gnx_tile_serve_gametes(gnx_state* h, int64_t n, const int64_t* parent_ids,
+                                      const int32_t* keys, const uint8_t* starts,
+                                      uint64_t* out) {
+  if (n == 0) return 0;
+  if (!has_rows(h) || h->n_paths == 0) {
+    gnx_set_error("gnx_tile_serve_gametes: genomes / paths not set");
+    return 1;
+  }
+  for (int64_t q = 0; q < n; ++q)
+    if (keys[q] < 0 || keys[q] >= h->n_paths || starts[q] > 1) {
+      gnx_set_error("gnx_tile_serve_gametes: request %lld out of range", (long long)q);
+      return 1;
+    }
+  int64_t N = h->N;
+  GnxSoA s = h->soa[h->cur];
+  hipLaunchKernelGGL(k_id_keys, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, s.id,
+                     h->key64[0], h->perm[0]);
+  GNXCHK(gnx_prim_sort64(h->sort64_tmp, h->sort64_tmp_bytes, h->key64[0], h->key64[1], h->perm[0],
+                         h->perm[1], (size_t)N, h->stream));
+  int64_t* d_ids = nullptr;
+  int32_t *d_keys = nullptr, *d_slot = nullptr, *d_miss = nullptr;
+  uint8_t* d_st = nullptr;
+  u64* d_out = nullptr;
+  GNXCHK(dalloc_t(&d_ids, (size_t)n));
+  GNXCHK(dalloc_t(&d_keys, (size_t)n));
+  GNXCHK(dalloc_t(&d_slot, (size_t)n));
+  GNXCHK(dalloc_t(&d_miss, 1));
+  GNXCHK(dalloc_t(&d_st, (size_t)n));
+  GNXCHK(dalloc_t(&d_out, (size_t)n * h->W64));
+  HIPCHK(hipMemcpy(d_ids, parent_ids, n * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_keys, keys, n * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_st, starts, n, hipMemcpyHostToDevice));
+  HIPCHK(hipMemsetAsync(d_miss, 0, 4, h->stream));
+  hipLaunchKernelGGL(k_lookup, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, n, d_ids, N,
+                     h->key64[1], h->perm[1], d_slot, d_miss);
+  int miss = 0;
+  HIPCHK(hipMemcpyAsync(&miss, d_miss, 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  int rc = 0;
+  if (miss) {
+    gnx_set_error("gnx_tile_serve_gametes: %d requested parents do not live on this tile", miss);
+    rc = 1;
+  } else {
+    const int W16 = h->W64 / 2;
+    hipLaunchKernelGGL(k_make_gametes, dim3(gnx_grid(n * 64, 256)), dim3(256), 0, h->stream, n, W16,
+                       (const u64x2*)h->G, s.grow, d_slot, d_keys, d_st, (const u64x2*)h->paths,
+                       (u64x2*)d_out);
+    hipError_t e = hipMemcpyAsync(out, d_out, (size_t)n * h->W64 * 8, hipMemcpyDeviceToHost,
+                                  h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) {
+      gnx_set_error("gnx_tile_serve_gametes: %s", hipGetErrorString(e));
+      rc = 1;
+    }
+  }
+  for (void* p : {(void*)d_ids, (void*)d_keys, (void*)d_slot, (void*)d_miss, (void*)d_st,
+                  (void*)d_out})
+    (void)hipFree(p);
+  return rc;
+}
+
+__global__ void k_put_gametes(int64_t n, int W16, const u64x2* in, u64x2* G, const int32_t* grow,
+                              int64_t first_slot, const int32_t* child_k) {
+  const int64_t total = n * (int64_t)W16;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+    int64_t q = g / W16;
+    int64_t c = g - q * W16;
+    // the mate is pair[1] -> the child's homologue 1 (ops/mating.py:169)
+    G[((int64_t)grow[first_slot + child_k[q]] * 2 + 1) * W16 + c] = in[g];
+  }
+}
+
+extern "C" int gnx_tile_put_gametes(gnx_state* h, int64_t n, const int32_t* child_k,
+                                    const uint64_t* data) {
+  if (n == 0) return 0;
+  for (int64_t q = 0; q < n; ++q)
+    if (child_k[q] < 0 || child_k[q] >= h->last_births) {
+      gnx_set_error("gnx_tile_put_gametes: child index out of range");
+      return 1;
+    }
+  int32_t* d_k = nullptr;
+  u64* d_in = nullptr;
+  GNXCHK(dalloc_t(&d_k, (size_t)n));
+  GNXCHK(dalloc_t(&d_in, (size_t)n * h->W64));
+  HIPCHK(hipMemcpy(d_k, child_k, n * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_in, data, (size_t)n * h->W64 * 8, hipMemcpyHostToDevice));
+  const int W16 = h->W64 / 2;
+  hipLaunchKernelGGL(k_put_gametes, dim3(gnx_grid(n * W16, 256, 256 * 32)), dim3(256), 0, h->stream,
+                     n, W16, (const u64x2*)d_in, (u64x2*)h->G, h->soa[h->cur].grow,
+                     h->birth_first_slot, d_k);
+  HIPCHK(hipStreamSynchronize(h->stream));
+  (void)hipFree(d_k);
+  (void)hipFree(d_in);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// phenotypes of this step's offspring (all gametes are in place) and the bins
+// of the tile's own individuals (ghosts skipped) for the N density
+extern "C" int gnx_tile_finish_births(gnx_state* h, int32_t burn) {
+  int64_t B = h->last_births;
+  if (B > 0 && !burn && has_rows(h) && h->cfg.n_traits > 0)
+    GNXCHK(gnx_l_phenotype(h, h->birth_first_slot, B));
+  GnxSoA s = h->soa[h->cur];
+  GNXCHK(gnx_l_bins(h, h->N, s.x, s.y, s.ghost, h->bin_partials));
+  return 0;
+}
+
+// N and n_pairs splines from the (all-reduced) bins, death probabilities,
+// mortality; ghosts are dropped
+extern "C" int gnx_tile_die(gnx_state* h, int32_t burn, int32_t with_selection,
+                            int32_t have_pairs) {
+  if (have_pairs)
+    GNXCHK(gnx_l_spline(h, h->bins_P, &h->spl_P, nullptr));
+  else
+    h->spl_P.valid = false;
+  GNXCHK(gnx_l_spline(h, h->bin_partials, &h->spl_N, nullptr));
+  GNXCHK(gnx_l_death_probs(h, with_selection != 0 && !burn));
+  int64_t D = 0;
+  GNXCHK(gnx_l_mortality(h, nullptr, &D));
+  h->last_deaths = D;
+  return 0;
+}
+
+extern "C" int gnx_set_max_id(gnx_state* h, int64_t max_id) {
+  h->max_id = max_id;
+  return 0;
+}

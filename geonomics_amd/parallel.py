@@ -1,0 +1,346 @@
+"""Spatial tiling of one species over the GPUs of a node.
+
+One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on the
+MI355X node, "gloo" in CPU rehearsals).  The landscape is cut into a uniform
+R x C grid of tiles; rank = r * C + c owns tile (r, c) and the individuals in
+it.  `TiledStepper.step` runs one time step of the reference's function queue
+(age, movement, pop dynamics) with the exchanges listed in
+csrc/gnx_tile.hip: migrants, halo, pair lists, gametes and the density bins.
+
+The only collectives are tiny (pair lists, integer density bins, counters);
+the byte movers are neighbour point-to-point messages (migrants with their
+genomes, gametes), which is what xGMI's point-to-point links are good at.
+
+The stepper talks to a *shard*: `DeviceShard` (the HIP library) in production;
+the CPU rehearsals in tests/ drive the same stepper with the numpy oracle
+(oracle/gnx_shard.py) as the shard.  Because every random draw is keyed by
+individual id and every choice is order-independent, a tiled run reproduces the
+single-tile run bit for bit (tests/test_tiling_cpu.py, tests/test_gpu_tiling.py).
+"""
+import numpy as np
+
+from . import _native as nat
+
+
+def tile_grid(world):
+    """R x C with R <= C, both powers of two where possible (8 -> 2 x 4)."""
+    r = int(np.floor(np.sqrt(world)))
+    while world % r:
+        r -= 1
+    return r, world // r
+
+
+class DeviceShard:
+    """The shard interface on top of a _native.Device."""
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.n_traits = dev.n_traits
+        self.W64 = dev.W64
+        self.has_genomes = False
+
+    def tile_set(self, R, C, r, c):
+        self.dev.tile_set(R, C, r, c)
+
+    def age_and_move(self, move):
+        if move:
+            self.dev.age()
+            self.dev.move()
+        else:
+            self.dev.age()
+
+    def export_migrants(self):
+        return self.dev.tile_export_migrants(self.has_genomes)
+
+    def import_individuals(self, rec, z, geno):
+        if rec.size:
+            self.dev.tile_import(rec, z, geno if self.has_genomes else None)
+
+    def export_halo(self, width):
+        return self.dev.tile_export_halo(width)
+
+    def import_ghosts(self, rec):
+        if rec.size:
+            self.dev.tile_import_ghosts(rec)
+
+    def pairs(self, burn):
+        return self.dev.tile_pairs(burn)
+
+    def pair_info(self):
+        return self.dev.tile_pair_info()
+
+    def get_bins(self, which):
+        return self.dev.get_bins(which)
+
+    def set_bins(self, which, b):
+        self.dev.set_bins(which, b)
+
+    def offspring(self, burn, id_base, goff):
+        return self.dev.tile_offspring(burn, id_base, goff)
+
+    def get_requests(self):
+        return self.dev.tile_get_requests()
+
+    def serve_gametes(self, pids, keys, starts):
+        return self.dev.tile_serve_gametes(pids, keys, starts)
+
+    def put_gametes(self, child_k, data):
+        self.dev.tile_put_gametes(child_k, data)
+
+    def finish_births(self, burn):
+        self.dev.tile_finish_births(burn)
+
+    def die(self, burn, with_selection, have_pairs):
+        self.dev.tile_die(burn, with_selection, have_pairs)
+
+    def counts(self):
+        return self.dev.counts()
+
+    def set_max_id(self, v):
+        self.dev.set_max_id(v)
+
+    def advance_step(self):
+        self.dev.step_index = self.dev.step_index + 1
+
+
+class Comm:
+    """Thin layer over torch.distributed: variable-size all-to-all of byte
+    buffers by point-to-point messages, all-gather-v and sum all-reduce."""
+
+    def __init__(self, dist=None):
+        self.dist = dist
+        if dist is None or not dist.is_initialized():
+            self.rank, self.world, self.device = 0, 1, 'cpu'
+            self.dist = None
+        else:
+            self.rank = dist.get_rank()
+            self.world = dist.get_world_size()
+            self.device = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+
+    def _t(self, a):
+        import torch
+        return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+    def allreduce_sum(self, a):
+        if self.dist is None:
+            return a
+        t = self._t(a)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
+    def allgather_i64(self, a):
+        """All ranks' 1-d int64 arrays (variable length) -> list per rank."""
+        a = np.ascontiguousarray(a, dtype=np.int64)
+        if self.dist is None:
+            return [a]
+        import torch
+        n = torch.tensor([a.size], dtype=torch.int64, device=self.device)
+        ns = [torch.zeros_like(n) for _ in range(self.world)]
+        self.dist.all_gather(ns, n)
+        ns = [int(v.item()) for v in ns]
+        m = max(max(ns), 1)
+        buf = torch.zeros(m, dtype=torch.int64, device=self.device)
+        buf[:a.size] = self._t(a)
+        out = [torch.zeros_like(buf) for _ in range(self.world)]
+        self.dist.all_gather(out, buf)
+        return [o[:k].cpu().numpy() for o, k in zip(out, ns)]
+
+    def alltoallv(self, send):
+        """send: list (len world) of uint8 arrays -> list of received arrays."""
+        if self.dist is None:
+            return [send[0]]
+        import torch
+        counts = np.array([s.size for s in send], dtype=np.int64)
+        mat = np.stack(self.allgather_i64(counts))          # mat[src][dst]
+        recv = [None] * self.world
+        ops = []
+        keep = []
+        for peer in range(self.world):
+            if peer == self.rank:
+                recv[peer] = send[peer]
+                continue
+            if mat[self.rank, peer] > 0:
+                t = self._t(send[peer].view(np.uint8))
+                keep.append(t)
+                ops.append(self.dist.P2POp(self.dist.isend, t, peer))
+            if mat[peer, self.rank] > 0:
+                r = torch.empty(int(mat[peer, self.rank]), dtype=torch.uint8, device=self.device)
+                recv[peer] = r
+                ops.append(self.dist.P2POp(self.dist.irecv, r, peer))
+            else:
+                recv[peer] = np.zeros(0, np.uint8)
+        if ops:
+            for req in self.dist.batch_isend_irecv(ops):
+                req.wait()
+        return [r.cpu().numpy() if hasattr(r, 'cpu') else r for r in recv]
+
+
+def _cat(chunks, dtype, shape_tail=()):
+    chunks = [c for c in chunks if c is not None and c.size]
+    if not chunks:
+        return np.zeros((0,) + tuple(shape_tail), dtype=dtype)
+    return np.concatenate(chunks)
+
+
+class TiledStepper:
+    def __init__(self, shard, comm, W, H, mating_radius, move=True, max_id=-1,
+                 grid=None):
+        self.shard = shard
+        self.comm = comm
+        self.W, self.H = W, H
+        self.R, self.C = grid if grid is not None else tile_grid(comm.world)
+        assert self.R * self.C == comm.world
+        assert W % self.C == 0 and H % self.R == 0, 'tiles must divide the landscape'
+        self.tw, self.th = W // self.C, H // self.R
+        self.r, self.c = divmod(comm.rank, self.C)
+        self.radius = float(mating_radius)
+        if comm.world > 1:
+            assert 2 * self.radius <= min(self.tw, self.th), (
+                'tiles must be at least 2 x mating_radius wide')
+        self.move = move
+        self.max_id = int(max_id)            # global maximum id handed out
+        shard.tile_set(self.R, self.C, self.r, self.c)
+        self.bytes_sent = 0
+
+    def rank_of(self, x, y):
+        c = np.minimum(self.C - 1, (np.asarray(x) // self.tw).astype(np.int64))
+        r = np.minimum(self.R - 1, (np.asarray(y) // self.th).astype(np.int64))
+        return r * self.C + c
+
+    # -- exchanges -------------------------------------------------------------------
+    def _exchange_records(self, dest, rec, z, geno):
+        w = self.comm.world
+        nt, W64 = self.shard.n_traits, self.shard.W64
+        send = []
+        for p in range(w):
+            sel = dest == p
+            parts = [rec[sel].view(np.uint8).ravel()]
+            if nt:
+                parts.append(np.ascontiguousarray(z[sel]).view(np.uint8).ravel())
+            if geno is not None:
+                parts.append(np.ascontiguousarray(geno[sel]).view(np.uint8).ravel())
+            send.append(np.concatenate(parts) if sel.any() else np.zeros(0, np.uint8))
+        self.bytes_sent += sum(s.size for i, s in enumerate(send) if i != self.comm.rank)
+        recv = self.comm.alltoallv(send)
+        per = nat.IND_REC.itemsize + 4 * nt + (16 * W64 if geno is not None else 0)
+        recs, zs, gs = [], [], []
+        for p, buf in enumerate(recv):
+            if p == self.comm.rank or buf.size == 0:
+                continue
+            n = buf.size // per
+            o = 0
+            recs.append(buf[o:o + n * nat.IND_REC.itemsize].view(nat.IND_REC))
+            o += n * nat.IND_REC.itemsize
+            if nt:
+                zs.append(buf[o:o + 4 * nt * n].view(np.float32).reshape(n, nt))
+                o += 4 * nt * n
+            if geno is not None:
+                gs.append(buf[o:o + 16 * W64 * n].view(np.uint64).reshape(n, 2, W64))
+        return (_cat(recs, nat.IND_REC),
+                _cat(zs, np.float32, (nt,)) if nt else None,
+                _cat(gs, np.uint64, (2, W64)) if geno is not None else None)
+
+    def _migrate(self):
+        rec, z, geno = self.shard.export_migrants()
+        dest = self.rank_of(rec['x'], rec['y']) if rec.size else np.zeros(0, np.int64)
+        if self.comm.world == 1:
+            assert rec.size == 0
+            return
+        if geno is None and self.shard.has_genomes:
+            geno = np.zeros((0, 2, self.shard.W64), np.uint64)
+        rec2, z2, g2 = self._exchange_records(dest, rec, z, geno)
+        self.shard.import_individuals(rec2, z2, g2)
+
+    def _halo(self):
+        if self.comm.world == 1:
+            return
+        rec = self.shard.export_halo(2.0 * self.radius)
+        w = self.comm.world
+        send = [np.zeros(0, np.uint8)] * w
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                if dx == 0 and dy == 0:
+                    continue
+                rr, cc = self.r + dy, self.c + dx
+                if not (0 <= rr < self.R and 0 <= cc < self.C):
+                    continue
+                bit = 1 << ((dy + 1) * 3 + (dx + 1))
+                sel = (rec['nbr_mask'] & bit) != 0
+                peer = rr * self.C + cc
+                if sel.any():
+                    send[peer] = np.concatenate([send[peer], rec[sel].view(np.uint8).ravel()])
+        self.bytes_sent += sum(s.size for s in send)
+        recv = self.comm.alltoallv(send)
+        ghosts = _cat([b.view(nat.IND_REC) for p, b in enumerate(recv)
+                       if p != self.comm.rank and b.size], nat.IND_REC)
+        # a corner individual reaches a tile through one message only, but make the
+        # ghost list unique by id anyway
+        if ghosts.size:
+            _, first = np.unique(ghosts['id'], return_index=True)
+            ghosts = ghosts[np.sort(first)]
+        self.shard.import_ghosts(ghosts)
+
+    def _pair_offsets(self):
+        ids, nb = self.shard.pair_info()
+        all_ids = self.comm.allgather_i64(ids)
+        all_nb = self.comm.allgather_i64(nb.astype(np.int64))
+        gi = np.concatenate(all_ids)
+        gn = np.concatenate(all_nb)
+        order = np.argsort(gi, kind='stable')
+        start = np.zeros(gi.size, np.int64)
+        start[order] = np.concatenate([[0], np.cumsum(gn[order])[:-1]]) if gi.size else []
+        lo = sum(a.size for a in all_ids[:self.comm.rank])
+        return start[lo:lo + ids.size], int(gn.sum()), gi.size
+
+    def _gametes(self, n_req):
+        w = self.comm.world
+        if w == 1:
+            return
+        pid, ck, key, st, px, py = self.shard.get_requests()
+        owner = self.rank_of(px, py) if n_req else np.zeros(0, np.int64)
+        req_dt = np.dtype([('pid', np.int64), ('key', np.int32), ('start', np.int32)])
+        send, order = [], []
+        for p in range(w):
+            sel = np.nonzero(owner == p)[0]
+            order.append(sel)
+            q = np.zeros(sel.size, req_dt)
+            q['pid'], q['key'], q['start'] = pid[sel], key[sel], st[sel]
+            send.append(q.view(np.uint8).ravel())
+        recv = self.comm.alltoallv(send)
+        back = []
+        for p, buf in enumerate(recv):
+            if p == self.comm.rank or buf.size == 0:
+                back.append(np.zeros(0, np.uint8))
+                continue
+            q = buf.view(req_dt)
+            data = self.shard.serve_gametes(q['pid'], q['key'], q['start'].astype(np.uint8))
+            back.append(np.ascontiguousarray(data).view(np.uint8).ravel())
+        self.bytes_sent += sum(b.size for b in back)
+        got = self.comm.alltoallv(back)
+        W64 = self.shard.W64
+        for p, buf in enumerate(got):
+            if p == self.comm.rank or buf.size == 0:
+                continue
+            self.shard.put_gametes(ck[order[p]], buf.view(np.uint64).reshape(-1, W64))
+
+    # -- one time step -------------------------------------------------------------------
+    def step(self, burn, with_selection):
+        sh = self.shard
+        sh.age_and_move(self.move)
+        self._migrate()
+        self._halo()
+        P, B = sh.pairs(burn)
+        goff, total_births, total_pairs = self._pair_offsets()
+        sh.set_bins(1, self.comm.allreduce_sum(sh.get_bins(1)))
+        n_req = sh.offspring(burn, self.max_id + 1, goff)
+        self.max_id += total_births
+        sh.set_max_id(self.max_id)
+        if not burn and sh.has_genomes:
+            self._gametes(n_req)
+        sh.finish_births(burn)
+        sh.set_bins(0, self.comm.allreduce_sum(sh.get_bins(0)))
+        sh.die(burn, with_selection, total_pairs > 0)
+        sh.advance_step()
+        n, b, d = sh.counts()
+        tot = self.comm.allreduce_sum(np.array([n, b, d], dtype=np.int64))
+        return int(tot[0]), int(tot[1]), int(tot[2])

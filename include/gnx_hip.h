@@ -231,6 +231,51 @@ int gnx_op_death_probs(gnx_state* h, int32_t with_selection,
 /* ops/demography.py:175-180 with an injected death mask                     */
 int gnx_op_mortality(gnx_state* h, const uint8_t* dead);
 
+/* ---- spatial tiling over several GPUs ---------------------------
+ * The reference has no distributed mode; these entry points are new.  One
+ * process/GPU owns one tile of a uniform R x C grid and the individuals inside
+ * it; the host layer (geonomics_amd/parallel.py) moves the staged buffers with
+ * torch.distributed (RCCL).  Step order on a tiled landscape:
+ *   gnx_age / gnx_move -> export_migrants + import -> export_halo +
+ *   import_ghosts -> tile_pairs -> [all-gather pair_info, all-reduce bins 1] ->
+ *   tile_offspring -> [requests -> serve_gametes -> put_gametes] ->
+ *   tile_finish_births -> [all-reduce bins 0] -> tile_die.                      */
+typedef struct {
+  float x, y;
+  int32_t age, sex;
+  int64_t id;
+  float fit;
+  int32_t nbr_mask;   /* halo: bit (dy+1)*3+(dx+1) = neighbour tile that needs it */
+} gnx_ind_rec;
+
+int gnx_tile_set(gnx_state* h, int32_t R, int32_t C, int32_t r, int32_t c);
+int gnx_tile_export_migrants(gnx_state* h, int64_t* n_out);
+int gnx_tile_export_halo(gnx_state* h, double width, int64_t* n_out);
+int gnx_tile_get_staged(gnx_state* h, gnx_ind_rec* rec, float* z /*[n][n_traits]*/,
+                        uint64_t* geno /*[n][2][W64]*/);
+int gnx_tile_import(gnx_state* h, int64_t n, const gnx_ind_rec* rec, const float* z,
+                    const uint64_t* geno);
+int gnx_tile_import_ghosts(gnx_state* h, int64_t n, const gnx_ind_rec* rec);
+int gnx_tile_pairs(gnx_state* h, int32_t burn, int64_t* n_pairs, int64_t* n_births);
+int gnx_tile_pair_info(gnx_state* h, int64_t* focal_ids /*[P] ascending*/,
+                       int32_t* n_births /*[P]*/);
+int gnx_density_bin_count(gnx_state* h);
+/* which: 0 = individuals, 1 = pair midpoints; int32 [bin_count]             */
+int gnx_get_bins(gnx_state* h, int32_t which, int32_t* out);
+int gnx_set_bins(gnx_state* h, int32_t which, const int32_t* in);
+int gnx_tile_offspring(gnx_state* h, int32_t burn, int64_t id_base,
+                       const int64_t* pair_goff /*[P]*/, int64_t* n_requests);
+int gnx_tile_get_requests(gnx_state* h, int64_t* parent_id, int32_t* child_k, int32_t* key,
+                          uint8_t* start, float* px, float* py);
+int gnx_tile_serve_gametes(gnx_state* h, int64_t n, const int64_t* parent_ids,
+                           const int32_t* keys, const uint8_t* starts,
+                           uint64_t* out /*[n][W64]*/);
+int gnx_tile_put_gametes(gnx_state* h, int64_t n, const int32_t* child_k,
+                         const uint64_t* data /*[n][W64]*/);
+int gnx_tile_finish_births(gnx_state* h, int32_t burn);
+int gnx_tile_die(gnx_state* h, int32_t burn, int32_t with_selection, int32_t have_pairs);
+int gnx_set_max_id(gnx_state* h, int64_t max_id);
+
 /* ---- measurement ------------------------------------------------------------ */
 int gnx_profiling(gnx_state* h, int32_t on);
 /* accumulated HIP-event time (ms) and launch count of one kernel family,

@@ -403,7 +403,7 @@ def choose_mates(x, y, ids, radius, seed, step, mode='uniform',
     return mate
 
 
-def pairs_from_mates(mate, keep):
+def pairs_from_mates(mate, keep, ids=None):
     """structs/species.py:2210-2214 then ops/mating.py:62-65.
 
     mate: chosen mate per focal (-1 none); keep: Bernoulli(b) per focal.
@@ -416,7 +416,11 @@ def pairs_from_mates(mate, keep):
     has = (mate >= 0) & keep
     i = np.nonzero(has)[0]
     m = mate[i]
-    recip = has[m] & (mate[m] == i) & (m < i)
+    if ids is None:
+        recip = has[m] & (mate[m] == i) & (m < i)
+    else:       # the build's rule: by id, so that every tile decides alike
+        ids = np.asarray(ids)
+        recip = has[m] & (mate[m] == i) & (ids[m] < ids[i])
     return np.stack([i[~recip], m[~recip]], axis=1)
 
 
@@ -510,6 +514,22 @@ class DensityLattice:
         edge = np.arange(0, d + ww, ww)                 # :282
         inner = np.arange(0 + hww, d + hww, ww)         # :283
         return int(round(max(edge.max(), inner.max()) / hww)) + 1
+
+    def bins(self, x, y):
+        """Half-window bin counts [Jy, Jx] (bin b covers [b*hww, (b+1)*hww))."""
+        hx = np.floor(np.asarray(x, dtype=np.float64) / self.hww).astype(np.int64)
+        hy = np.floor(np.asarray(y, dtype=np.float64) / self.hww).astype(np.int64)
+        hist = np.zeros((self.J[1], self.J[0]), dtype=np.int64)
+        np.add.at(hist, (np.minimum(hy, self.J[1] - 1), np.minimum(hx, self.J[0] - 1)), 1)
+        return hist
+
+    def nodes_from_bins(self, hist):
+        """node density = (sum of the 2x2 bins around the node) / area"""
+        h = np.asarray(hist, dtype=np.int64).reshape(self.J[1], self.J[0])
+        p = np.zeros((self.J[1] + 1, self.J[0] + 1), dtype=np.int64)
+        p[1:, 1:] = h
+        c = p[1:, 1:] + p[:-1, 1:] + p[1:, :-1] + p[:-1, :-1]
+        return c / self.areas
 
     def counts(self, x, y):
         """Window counts at every lattice node, [Jy, Jx]."""

@@ -1,0 +1,242 @@
+"""TEST INFRASTRUCTURE ONLY.  The shard interface of geonomics_amd/parallel.py on
+top of the numpy oracle, so that the tiling protocol (migrants, halo ghosts,
+global pair order, gamete requests, density-bin all-reduce) can be rehearsed on
+CPU with the gloo backend, and so that the device's tile entry points
+(csrc/gnx_tile.hip) have a reference to be compared with."""
+import numpy as np
+
+import gnx_oracle as O
+import gnx_draws as D
+import gnx_step as S
+
+F = np.float32
+
+IND_REC = np.dtype([('x', np.float32), ('y', np.float32), ('age', np.int32),
+                    ('sex', np.int32), ('id', np.int64), ('fit', np.float32),
+                    ('nbr_mask', np.int32)], align=True)
+
+
+class OracleShard:
+    def __init__(self, state):
+        self.s = state
+        self.n_traits = len(state.traits)
+        self.W64 = O.words_per_hom(state.L) if state.L else 0
+        self.ghost = np.zeros(state.N, bool)
+        self.R = self.C = 1
+        self.r = self.c = 0
+        self.bins = [None, None]
+        self.n_births = 0
+        self.n_deaths = 0
+
+    @property
+    def has_genomes(self):
+        return self.s.geno is not None
+
+    # -- helpers ---------------------------------------------------------------------
+    def _box(self):
+        tw, th = self.s.W / self.C, self.s.H / self.R
+        return F(self.c * tw), F(self.r * th), F((self.c + 1) * tw), F((self.r + 1) * th)
+
+    def _take(self, keep):
+        idx = np.nonzero(keep)[0]
+        S._permute(self.s, idx)
+        self.ghost = self.ghost[idx]
+
+    def _records(self, sel, mask=None):
+        s = self.s
+        rec = np.zeros(int(sel.sum()), IND_REC)
+        rec['x'], rec['y'] = s.x[sel], s.y[sel]
+        rec['age'], rec['sex'], rec['id'] = s.age[sel], s.sex[sel], s.id[sel]
+        rec['fit'] = s.fit[sel]
+        if mask is not None:
+            rec['nbr_mask'] = mask[sel]
+        return rec
+
+    def _append(self, rec, z, geno, ghost):
+        s = self.s
+        n = rec.size
+        if n == 0:
+            return
+        s.x = np.concatenate([s.x, rec['x']])
+        s.y = np.concatenate([s.y, rec['y']])
+        s.age = np.concatenate([s.age, rec['age']])
+        s.sex = np.concatenate([s.sex, rec['sex'].astype(np.uint8)])
+        s.id = np.concatenate([s.id, rec['id']])
+        s.fit = np.concatenate([s.fit, rec['fit']])
+        s.e = np.concatenate([s.e, O.gather_e(list(s.rasts), rec['x'], rec['y']).astype(F)])
+        zz = z if (z is not None and self.n_traits) else np.zeros((n, self.n_traits), F)
+        s.z = np.concatenate([s.z, zz.astype(F)])
+        if s.geno is not None:
+            g = geno if geno is not None else np.zeros((n, 2, self.W64), np.uint64)
+            s.geno = np.concatenate([s.geno, g])
+        self.ghost = np.concatenate([self.ghost, np.full(n, ghost)])
+
+    # -- shard interface ---------------------------------------------------------------
+    def tile_set(self, R, C, r, c):
+        self.R, self.C, self.r, self.c = R, C, r, c
+
+    def age_and_move(self, move):
+        old = self.s.p.move
+        self.s.p.move = bool(move)
+        S.move(self.s, inc_age=True)
+        self.s.p.move = old
+
+    def export_migrants(self):
+        s = self.s
+        x0, y0, x1, y1 = self._box()
+        out = (s.x < x0) | (s.x >= x1) | (s.y < y0) | (s.y >= y1)
+        rec = self._records(out)
+        z = s.z[out].copy() if self.n_traits else None
+        geno = s.geno[out].copy() if s.geno is not None else None
+        self._take(~out)
+        return rec, z, geno
+
+    def import_individuals(self, rec, z, geno):
+        self._append(rec, z, geno, False)
+        if rec.size:
+            self.s.max_id = max(self.s.max_id, int(rec['id'].max()))
+
+    def export_halo(self, width):
+        s = self.s
+        x0, y0, x1, y1 = self._box()
+        w = F(width)
+        own = ~self.ghost
+        Lf = (self.c > 0) & (s.x - x0 < w)
+        Rt = (self.c < self.C - 1) & (x1 - s.x <= w)
+        Up = (self.r > 0) & (s.y - y0 < w)
+        Dn = (self.r < self.R - 1) & (y1 - s.y <= w)
+        m = (Lf * (1 << 3) + Rt * (1 << 5) + Up * (1 << 1) + Dn * (1 << 7)
+             + (Lf & Up) * (1 << 0) + (Rt & Up) * (1 << 2) + (Lf & Dn) * (1 << 6)
+             + (Rt & Dn) * (1 << 8)).astype(np.int32)
+        m = np.where(own, m, 0)
+        return self._records(m != 0, m)
+
+    def import_ghosts(self, rec):
+        self._append(rec, None, None, True)
+
+    def pairs(self, burn):
+        s, p = self.s, self.s.p
+        n = s.N
+        keep = D.keep_draws(s.seed, s.id, s.step, p.b)
+        mate = S.choose_mates_fast(s) if p.mate_mode == 'uniform' else O.choose_mates(
+            s.x, s.y, s.id, p.mating_radius, s.seed, s.step, mode=p.mate_mode)
+        m0 = np.maximum(mate, 0)
+        has = (mate >= 0) & keep
+        has &= (s.age >= p.repro_age[0]) & (s.age[m0] >= p.repro_age[1])
+        if p.sexed:
+            has &= (s.sex == 0) & (s.sex[m0] == 1)
+            f2 = has.copy()
+        else:
+            recip = has[m0] & (mate[m0] == np.arange(n)) & (s.id[m0] < s.id)
+            f2 = has & ~recip
+        f2 &= ~self.ghost
+        i = np.nonzero(f2)[0]
+        pr = np.stack([i, mate[i]], 1) if i.size else np.zeros((0, 2), np.int64)
+        pr = pr[np.argsort(s.id[pr[:, 0]], kind='stable')]
+        self.pairs_ = pr
+        if p.n_births_fixed:
+            self.nb = np.full(len(pr), int(p.n_births_lambda), np.int64)
+        else:
+            self.nb = D.births_draws(s.seed, s.id[pr[:, 0]], s.step,
+                                     p.n_births_lambda).astype(np.int64)
+        mx = (s.x[pr[:, 0]] + s.x[pr[:, 1]]) / F(2.0)
+        my = (s.y[pr[:, 0]] + s.y[pr[:, 1]]) / F(2.0)
+        self.bins[1] = s.lat.bins(mx, my).ravel().astype(np.int32)
+        return len(pr), int(self.nb.sum())
+
+    def pair_info(self):
+        return self.s.id[self.pairs_[:, 0]].astype(np.int64), self.nb.astype(np.int32)
+
+    def get_bins(self, which):
+        return self.bins[which]
+
+    def set_bins(self, which, b):
+        self.bins[which] = np.asarray(b)
+
+    def offspring(self, burn, id_base, goff):
+        s, p = self.s, self.s.p
+        pr, nb = self.pairs_, self.nb
+        B = int(nb.sum())
+        self.n_births = B
+        self.req = None
+        self.first = s.N
+        if B == 0:
+            return 0
+        par = np.repeat(pr, nb, axis=0)
+        local_start = np.concatenate([[0], np.cumsum(nb)[:-1]])
+        ordn = np.arange(B) - np.repeat(local_start, nb)
+        oid = int(id_base) + np.repeat(np.asarray(goff, np.int64), nb) + ordn
+        mx = (s.x[par[:, 0]] + s.x[par[:, 1]]) / F(2.0)
+        my = (s.y[par[:, 0]] + s.y[par[:, 1]]) / F(2.0)
+        th, ds = D.dispersal_draws(s.seed, oid, s.step, p.disp_distr, p.disp_p1, p.disp_p2)
+        ox, oy, _ = O.dispersal(mx, my, th, ds, (s.W, s.H), dtype=F)
+        genomes = (not burn) and s.geno is not None
+        n_paths = s.paths.shape[0] if s.paths is not None else 1
+        start, keys, sex = D.offspring_draws(s.seed, oid, s.step, n_paths, p.sexed, p.p_male)
+        rec = np.zeros(B, IND_REC)
+        rec['x'], rec['y'], rec['id'], rec['sex'], rec['fit'] = ox, oy, oid, sex, 1.0
+        child = None
+        n_req = 0
+        if genomes:
+            gm = self.ghost[par[:, 1]]
+            child = np.zeros((B, 2, self.W64), np.uint64)
+            loc = np.nonzero(~gm)[0]
+            full = O.crossover(s.geno, s.paths, par[loc], keys[loc], start[loc])
+            child[loc] = full
+            rem = np.nonzero(gm)[0]
+            if rem.size:
+                # hom 0 (focal parent) is local
+                c0 = O.crossover(s.geno, s.paths, np.stack([par[rem, 0], par[rem, 0]], 1),
+                                 keys[rem], start[rem])
+                child[rem, 0] = c0[:, 0]
+                self.req = (s.id[par[rem, 1]].copy(), rem.astype(np.int32), keys[rem, 1].copy(),
+                            start[rem, 1].copy(), s.x[par[rem, 1]].copy(),
+                            s.y[par[rem, 1]].copy())
+                n_req = rem.size
+        self._append(rec, None, child, False)
+        return n_req
+
+    def get_requests(self):
+        if self.req is None:
+            z = np.zeros(0)
+            return (z.astype(np.int64), z.astype(np.int32), z.astype(np.int32),
+                    z.astype(np.uint8), z.astype(F), z.astype(F))
+        return self.req
+
+    def serve_gametes(self, pids, keys, starts):
+        s = self.s
+        pos = {int(i): k for k, i in enumerate(s.id)}
+        rows = np.array([pos[int(i)] for i in pids], dtype=np.int64)
+        par = np.stack([rows, rows], 1)
+        kk = np.stack([keys, keys], 1)
+        ss = np.stack([starts, starts], 1)
+        return O.crossover(s.geno, s.paths, par, kk, ss)[:, 0]
+
+    def put_gametes(self, child_k, data):
+        self.s.geno[self.first + np.asarray(child_k), 1] = data
+
+    def finish_births(self, burn):
+        s = self.s
+        B = self.n_births
+        if B and not burn and s.geno is not None and self.n_traits:
+            s._set_z(np.arange(self.first, self.first + B))
+        own = ~self.ghost
+        self.bins[0] = s.lat.bins(s.x[own], s.y[own]).ravel().astype(np.int32)
+
+    def die(self, burn, with_selection, have_pairs):
+        s = self.s
+        VN = s.lat.nodes_from_bins(self.bins[0])
+        VP = s.lat.nodes_from_bins(self.bins[1]) if have_pairs else None
+        pd_, _ = S.death_probs(s, with_selection and not burn, VN, VP)
+        dead = D.death_draws(s.seed, s.id, s.step).astype(np.float64) < pd_
+        self.n_deaths = int((dead & ~self.ghost).sum())
+        self._take(~dead & ~self.ghost)
+
+    def counts(self):
+        return int((~self.ghost).sum()), self.n_births, self.n_deaths
+
+    def set_max_id(self, v):
+        self.s.max_id = int(v)
+
+    def advance_step(self):
+        self.s.step += 1

@@ -185,7 +185,7 @@ def find_pairs(s):
         has &= (s.sex == 0) & (s.sex[m0] == 1)
         i = np.nonzero(has)[0]
         return np.stack([i, mate[i]], 1)
-    return O.pairs_from_mates(np.where(has, mate, -1), has)
+    return O.pairs_from_mates(np.where(has, mate, -1), has, s.id)
 
 
 def mate(s, pairs, burn):
@@ -266,6 +266,9 @@ def death_probs(s, with_selection, VN, VP):
 def pop_dynamics(s, burn=False, with_selection=True):
     sort_by_cell(s)
     pairs = find_pairs(s)
+    # offspring ids follow the pairs' focal ids (tiling-independent order)
+    if len(pairs):
+        pairs = pairs[np.argsort(s.id[pairs[:, 0]], kind='stable')]
     VP = None
     if len(pairs):
         mx = (s.x[pairs[:, 0]] + s.x[pairs[:, 1]]) / F(2.0)
