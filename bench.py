@@ -14,9 +14,11 @@ quoted on: 2048x2048 two-layer landscape, 10^6 individuals, 10^5-locus genomes,
 mating_radius 10, b 0.2, one birth per pair, recombination rate 1/L.
 
 For --gpus N > 1 the driver launches one rank per GPU with torch.distributed
-(RCCL); each rank owns one 2048x2048 tile of an N-tile landscape ("weak"
-scaling: per-GPU work fixed).  See DESIGN.md (multi-GPU) for what is and is not
-exchanged between tiles in this round.
+(RCCL); the landscape grows to an R x C grid of 2048x2048 tiles (8 GPUs: 2 x 4 =
+8192x4096, 8x10^6 individuals), one tile per rank ("weak" scaling: per-GPU work
+fixed), stepped by geonomics_amd.parallel.TiledStepper: migrants (with genomes),
+halo ghosts, pair lists, gametes of cross-border mates and the density bins are
+exchanged every step (csrc/gnx_tile.hip).
 """
 import argparse
 import json
@@ -84,16 +86,20 @@ def sparse_paths(n, L, seed, W64):
     return out
 
 
-def build_device(cfg, seed, device):
+def build_device(cfg, seed, device, grid=(1, 1)):
     from geonomics_amd import _native as nat
-    W, H, N, L = cfg['W'], cfg['H'], cfg['N'], cfg['L']
+    R, C = grid
+    W, H, L = cfg['W'] * C, cfg['H'] * R, cfg['L']
+    N = cfg['N'] * R * C
     lyr0 = smooth_field(W, H, 1) * 0.5 + 0.5          # K / conductance layer
     lyr1 = np.tile(np.linspace(0, 1, W, dtype=np.float32), (H, 1))
     rasts = np.stack([lyr0, lyr1])
     K_factor = N / float(lyr0.sum())                  # sum(K) = N
-    cap = int(N * 1.6) + 1024
+    cap_rows = int(cfg['N'] * 1.6) + 1024
+    # tiled: every rank first creates the whole initial population, then keeps its tile
+    cap = cap_rows if R * C == 1 else max(cap_rows, int(N * 1.02) + 1024)
     dev = nat.Device(W, H, 2, L=L, n_traits=cfg['n_traits'], cap_inds=cap,
-                     cap_rows=cap, seed=seed, device=device)
+                     cap_rows=cap_rows, seed=seed, device=device)
     dev.upload_rasters(rasts)
     sp = nat.default_species_params(
         mating_radius=10.0, K_layer=0, K_factor=K_factor,
@@ -166,31 +172,65 @@ def main():
     args = ap.parse_args()
 
     import torch
+    torch.set_num_threads(1)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: no HIP device is visible '
                          '(the product has no CPU path)')
+    # rehearsal on a 1-GPU box: GNX_BENCH_BACKEND=gloo GNX_BENCH_SINGLE_DEVICE=1
+    backend = os.environ.get('GNX_BENCH_BACKEND', 'nccl')
+    if os.environ.get('GNX_BENCH_SINGLE_DEVICE'):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
 
     cfg = WORKLOADS[args.workload]
     t_setup = time.time()
-    dev, rasts, K_factor = build_device(cfg, seed=42 + rank, device=local_rank)
+    stepper = None
+    grid = (1, 1)
+    force_stepper = bool(os.environ.get('GNX_BENCH_FORCE_STEPPER'))   # overhead study at N=1
+    if world > 1 or force_stepper:
+        from geonomics_amd.parallel import Comm, DeviceShard, TiledStepper, tile_grid
+        grid = tile_grid(world)
+    dev, rasts, K_factor = build_device(cfg, seed=42, device=local_rank, grid=grid)
+    if world > 1 or force_stepper:
+        shard = DeviceShard(dev)
+        stepper = TiledStepper(shard, Comm(dist), cfg['W'] * grid[1], cfg['H'] * grid[0], 10.0,
+                               move=True, max_id=cfg['N'] * world - 1, grid=grid,
+                               fixed_births=1)
+        shard.export_migrants()            # keep this rank's tile of the common population
+
+    def do_step(burn):
+        if stepper is None:
+            n0 = dev.N
+            dev.step(burn, not burn)
+            return n0, dev.counts()[1]
+        n, b, _ = stepper.step(burn, not burn)
+        return n, b
+
     # a short burn-in brings the uniform initial population to its density-
     # regulated spatial distribution before genomes are assigned
     for _ in range(3):
-        dev.step(True, False)
+        do_step(True)
     setup_genomes(dev, cfg, seed=42 + rank)
+    if stepper is not None:
+        stepper.shard.has_genomes = True
     dev.synchronize()
     t_setup = time.time() - t_setup
 
+    n_glob = None
     for _ in range(args.warmup):
-        dev.step(False, True)
+        n_glob, _ = do_step(False)
+    if stepper is not None and n_glob is None:
+        n_glob = int(stepper.comm.allreduce_sum(np.array([dev.N], np.int64))[0])
 
     def barrier():
         torch.cuda.synchronize()
@@ -198,15 +238,20 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    dev.profiling(True)
+    # inside the timed region only the dominant kernel is bracketed with HIP events
+    dev.profiling(2 if os.environ.get('GNX_BENCH_PROFILE_ALL') is None else 1)
     barrier()
     t0 = time.perf_counter()
     ind_steps = 0
     births = 0
     for _ in range(args.steps):
-        ind_steps += dev.N
-        dev.step(False, True)
-        births += dev.counts()[1]
+        if stepper is None:
+            n0, b = do_step(False)          # population at the start of the step
+            ind_steps += n0
+        else:
+            ind_steps += n_glob             # global population at the start of the step
+            n_glob, b = do_step(False)
+        births += b
     dev.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -214,12 +259,10 @@ def main():
     kt = dev.kernel_times()
     dev.profiling(False)
 
-    tot = torch.tensor([float(ind_steps)], device='cuda')
     mx = torch.tensor([elapsed], device='cuda')
     if dist is not None:
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-    total_ind_steps = float(tot.item())
+    total_ind_steps = float(ind_steps)      # tiled: already the global count
     max_elapsed = float(mx.item())
 
     if rank == 0:
@@ -248,8 +291,10 @@ def main():
                                 args.workload, cfg['W'], cfg['H'], cfg['N'], cfg['L'],
                                 cfg['n_traits'], cfg['loci_per_trait'], cfg['move_surf'],
                                 cfg['n_paths']),
-                'parallelism': 'tiles%d' % world,
-                'mean_N': ind_steps / args.steps, 'births_per_step': births / args.steps,
+                'parallelism': ('1 tile' if world == 1 else 'tiles %dx%d: migrants+halo+gametes p2p, '
+                                'pair lists / density bins collectives (RCCL)' % grid),
+                'landscape': '%dx%d' % (cfg['W'] * grid[1], cfg['H'] * grid[0]),
+                'mean_N_global': ind_steps / args.steps, 'births_per_step_global': births / args.steps,
                 'setup_s': round(t_setup, 2),
             },
             'roofline': {
@@ -261,6 +306,9 @@ def main():
             },
             'kernel_ms_per_step': {k: v['ms'] / args.steps for k, v in kt.items()},
         }
+        if stepper is not None and stepper.profile:
+            out['tile_phase_ms_per_step'] = {k: 1e3 * v / (args.steps + args.warmup + 3)
+                                             for k, v in stepper.phase_s.items()}
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))

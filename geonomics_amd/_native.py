@@ -523,7 +523,8 @@ class Device:
 
     # -- measurement ---------------------------------------------------------
     def profiling(self, on):
-        self._chk(self.lib.gnx_profiling(self.h, int(bool(on))))
+        """0 off, 1 all kernel families, 2 only the dominant kernel (crossover)"""
+        self._chk(self.lib.gnx_profiling(self.h, int(on)))
 
     def kernel_times(self):
         out = {}

@@ -46,6 +46,11 @@ void gnx_time_begin(gnx_state* h) {
 
 void gnx_time_end(gnx_state* h, int kernel, double bytes) {
   if (!h->profiling || !h->ev_open) return;
+  if (h->profile_only >= 0 && kernel != h->profile_only) {   // time one kernel family only
+    h->ev_free.push_back(h->ev_open);
+    h->ev_open = nullptr;
+    return;
+  }
   hipEvent_t e1 = timer_event(h);
   (void)hipEventRecord(e1, h->stream);
   h->ev_pending[kernel].push_back({h->ev_open, e1});
@@ -63,6 +68,43 @@ static void timers_resolve(gnx_state* h, int kernel) {
     h->ev_free.push_back(pr.second);
   }
   h->ev_pending[kernel].clear();
+}
+
+static int stage_reserve(gnx_state* h, size_t bytes) {
+  if (bytes <= h->h_stage_bytes) return 0;
+  if (h->h_stage) (void)hipHostFree(h->h_stage);
+  h->h_stage = nullptr;
+  h->h_stage_bytes = 0;
+  size_t want = std::max<size_t>(bytes + bytes / 4, 1 << 20);
+  HIPCHK(hipHostMalloc(&h->h_stage, want));
+  h->h_stage_bytes = want;
+  return 0;
+}
+
+int gnx_h2d(gnx_state* h, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return 0;
+  const size_t chunk = 64u << 20;
+  GNXCHK(stage_reserve(h, std::min(bytes, chunk)));
+  for (size_t o = 0; o < bytes; o += chunk) {
+    size_t n = std::min(chunk, bytes - o);
+    memcpy(h->h_stage, (const char*)src + o, n);
+    HIPCHK(hipMemcpyAsync((char*)dst + o, h->h_stage, n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  return 0;
+}
+
+int gnx_d2h(gnx_state* h, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return 0;
+  const size_t chunk = 64u << 20;
+  GNXCHK(stage_reserve(h, std::min(bytes, chunk)));
+  for (size_t o = 0; o < bytes; o += chunk) {
+    size_t n = std::min(chunk, bytes - o);
+    HIPCHK(hipMemcpyAsync(h->h_stage, (const char*)src + o, n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    memcpy((char*)dst + o, h->h_stage, n);
+  }
+  return 0;
 }
 
 GnxTraitTab gnx_trait_tab(const gnx_state* h) {
@@ -221,6 +263,7 @@ extern "C" void gnx_destroy(gnx_state* h) {
     (void)hipFree(h->traits[t].phi_rast);
   }
   (void)hipHostFree(h->h_pin);
+  if (h->h_stage) (void)hipHostFree(h->h_stage);
   for (int k = 0; k < GNX_K_COUNT; ++k) timers_resolve(h, k);
   for (hipEvent_t e : h->ev_free) (void)hipEventDestroy(e);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -769,9 +812,7 @@ extern "C" int gnx_download(gnx_state* h, int32_t field, void* dst, int64_t dst_
     return 1;
   }
   for (int64_t p = 0; p < planes; ++p)
-    HIPCHK(hipMemcpyAsync((char*)dst + p * N * elt, (const char*)src + p * cap * elt, N * elt,
-                          hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+    GNXCHK(gnx_d2h(h, (char*)dst + p * N * elt, (const char*)src + p * cap * elt, N * elt));
   return 0;
 }
 
@@ -1007,6 +1048,9 @@ extern "C" int gnx_profiling(gnx_state* h, int32_t on) {
     h->timers[k] = GnxKernelTimer();
   }
   h->profiling = on != 0;
+  // on == 2: only the dominant kernel (crossover) is timed, so that very few
+  // events are in flight (used by bench.py inside the timed region)
+  h->profile_only = (on == 2) ? GNX_K_CROSSOVER : -1;
   return 0;
 }
 

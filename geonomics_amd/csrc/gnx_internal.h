@@ -170,7 +170,8 @@ struct gnx_state {
   float* st_z = nullptr;
   uint64_t* st_geno = nullptr;
   int64_t* st_slots = nullptr;
-  int64_t st_n = 0;
+  int64_t st_n = 0, st_cap = 0, st_geno_cap = 0;
+  bool st_has_geno = false;
   int64_t birth_first_slot = 0;
   int64_t n_req = 0;
 
@@ -211,9 +212,12 @@ struct gnx_state {
 
   // pinned host scratch for read-backs
   int64_t* h_pin = nullptr;          // [16]
+  void* h_stage = nullptr;           // pinned host staging buffer for per-step transfers
+  size_t h_stage_bytes = 0;
 
   // profiling
   bool profiling = false;
+  int profile_only = -1;
   GnxKernelTimer timers[GNX_K_COUNT];
   hipEvent_t ev_open = nullptr;
   std::vector<hipEvent_t> ev_free;
@@ -225,6 +229,11 @@ GnxTraitTab gnx_trait_tab(const gnx_state* h);
 // RAII-less scoped timer helpers (events on h->stream)
 void gnx_time_begin(gnx_state* h);
 void gnx_time_end(gnx_state* h, int kernel, double bytes);
+
+// host <-> device copies through the pinned staging buffer (pageable hipMemcpy
+// pins the user buffer on every call, which costs milliseconds per step)
+int gnx_h2d(gnx_state* h, void* dst, const void* src, size_t bytes);
+int gnx_d2h(gnx_state* h, void* dst, const void* src, size_t bytes);
 
 // ---- launchers (gnx_kernels_*.hip) ---------------------------------------
 int gnx_l_init_population(gnx_state* h, int64_t N);
@@ -243,6 +252,7 @@ int gnx_l_dispersal_inject(gnx_state* h, int64_t B, int A, const float* d_mx, co
 int gnx_l_crossover(gnx_state* h, int64_t first_slot, int64_t B);
 int gnx_l_phenotype(gnx_state* h, int64_t first_slot, int64_t n);
 int gnx_l_phenotype_births(gnx_state* h, int64_t first_slot, int64_t n);
+int gnx_l_phenotype_list(gnx_state* h, int64_t first_slot, int64_t n, const int32_t* d_list);
 int gnx_l_assign_genomes(gnx_state* h, const int32_t* d_n_per_site);
 int gnx_l_mutate(gnx_state* h, int n, const int64_t* d_slot, const int32_t* d_locus,
                  const uint8_t* d_hom);

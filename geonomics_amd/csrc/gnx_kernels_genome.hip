@@ -243,6 +243,42 @@ __global__ void k_phenotype(int64_t first, int64_t n, int64_t cap, int W64, cons
   }
 }
 
+// phenotype of listed offspring (slot = first + list[q]) by gathering the trait
+// loci from their genome rows (used for offspring that received a remote gamete)
+__global__ void k_phenotype_list(int64_t first, int64_t n, const int32_t* list, int64_t cap,
+                                 int W64, const u64* G, const int32_t* grow, GnxTraitTab T,
+                                 const uint8_t* dom, float* z) {
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  int64_t slot = first + list[q];
+  const u64* r0 = G + (int64_t)grow[slot] * 2 * W64;
+  const u64* r1 = r0 + W64;
+  for (int t = 0; t < T.n_traits; ++t) {
+    const int nl = T.n_loci[t];
+    double acc = 0.0, g0 = 0.0;
+    for (int j = 0; j < nl; ++j) {
+      int l = T.loci[t][j];
+      int a = (int)((r0[l >> 6] >> (l & 63)) & 1ull);
+      int b = (int)((r1[l >> 6] >> (l & 63)) & 1ull);
+      double gt = 0.5 * (double)(a + b);
+      if (dom) gt = fmin(gt * (1.0 + (double)dom[l]), 1.0);
+      if (j == 0) g0 = gt;
+      acc = acc + gt * T.alpha[t][j];
+    }
+    z[(int64_t)t * cap + slot] = (float)(nl > 1 ? 0.5 + acc : g0);
+  }
+}
+
+int gnx_l_phenotype_list(gnx_state* h, int64_t first_slot, int64_t n, const int32_t* d_list) {
+  if (n == 0 || h->cfg.n_traits == 0) return 0;
+  GnxSoA s = h->soa[h->cur];
+  hipLaunchKernelGGL(k_phenotype_list, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, first_slot,
+                     n, d_list, h->cfg.cap_inds, h->W64, (const u64*)h->G, s.grow,
+                     gnx_trait_tab(h), h->dom, s.z);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 int gnx_l_phenotype(gnx_state* h, int64_t first_slot, int64_t n) {
   if (n == 0 || h->cfg.n_traits == 0) return 0;
   GnxSoA s = h->soa[h->cur];

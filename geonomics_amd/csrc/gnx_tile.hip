@@ -18,6 +18,7 @@
 // All random draws are keyed by individual id, all choices are order-
 // independent, so a tiled run reproduces the single-GPU run bit for bit.
 #include <algorithm>
+#include <chrono>
 #include "gnx_internal.h"
 #include "gnx_rng.h"
 
@@ -168,24 +169,30 @@ static int stage_selection(gnx_state* h, const int32_t* d_mask, bool with_z, boo
   HIPCHK(hipStreamSynchronize(h->stream));
   int64_t n = *(int32_t*)h->h_pin;
   *n_out = n;
-  (void)hipFree(h->st_rec);
-  (void)hipFree(h->st_z);
-  (void)hipFree(h->st_geno);
-  (void)hipFree(h->st_slots);
-  h->st_rec = nullptr;
-  h->st_z = nullptr;
-  h->st_geno = nullptr;
-  h->st_slots = nullptr;
   h->st_n = n;
+  h->st_has_geno = false;
   if (n == 0) return 0;
-  GNXCHK(dalloc_t(&h->st_rec, (size_t)n));
-  if (with_z && h->cfg.n_traits) GNXCHK(dalloc_t(&h->st_z, (size_t)n * h->cfg.n_traits));
-  GNXCHK(dalloc_t(&h->st_slots, (size_t)n));
+  // grow-only staging buffers (no hipMalloc/hipFree on the per-step path)
+  if (n > h->st_cap) {
+    (void)hipFree(h->st_rec);
+    (void)hipFree(h->st_z);
+    (void)hipFree(h->st_slots);
+    h->st_cap = n + n / 4 + 1024;
+    GNXCHK(dalloc_t(&h->st_rec, (size_t)h->st_cap));
+    GNXCHK(dalloc_t(&h->st_z, (size_t)h->st_cap * std::max(h->cfg.n_traits, 1)));
+    GNXCHK(dalloc_t(&h->st_slots, (size_t)h->st_cap));
+  }
   hipLaunchKernelGGL(k_pack, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, h->cfg.cap_inds,
-                     h->flag, h->scan, d_mask, s, h->cfg.n_traits, h->st_rec, h->st_z, h->st_slots);
+                     h->flag, h->scan, d_mask, s, h->cfg.n_traits, h->st_rec,
+                     (with_z && h->cfg.n_traits) ? h->st_z : nullptr, h->st_slots);
   if (with_geno && has_rows(h)) {
-    GNXCHK(dalloc_t(&h->st_geno, (size_t)n * 2 * h->W64));
+    if (n > h->st_geno_cap) {
+      (void)hipFree(h->st_geno);
+      h->st_geno_cap = n + n / 4 + 64;
+      GNXCHK(dalloc_t(&h->st_geno, (size_t)h->st_geno_cap * 2 * h->W64));
+    }
     GNXCHK(gnx_l_gather_genomes(h, n, h->st_slots, h->st_geno));
+    h->st_has_geno = true;
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -226,11 +233,11 @@ extern "C" int gnx_tile_export_halo(gnx_state* h, double width, int64_t* n_out) 
 extern "C" int gnx_tile_get_staged(gnx_state* h, gnx_ind_rec* rec, float* z, uint64_t* geno) {
   int64_t n = h->st_n;
   if (n == 0) return 0;
-  if (rec) HIPCHK(hipMemcpy(rec, h->st_rec, n * sizeof(gnx_ind_rec), hipMemcpyDeviceToHost));
-  if (z && h->st_z)
-    HIPCHK(hipMemcpy(z, h->st_z, n * h->cfg.n_traits * sizeof(float), hipMemcpyDeviceToHost));
-  if (geno && h->st_geno)
-    HIPCHK(hipMemcpy(geno, h->st_geno, (size_t)n * 2 * h->W64 * 8, hipMemcpyDeviceToHost));
+  if (rec) GNXCHK(gnx_d2h(h, rec, h->st_rec, n * sizeof(gnx_ind_rec)));
+  if (z && h->st_z && h->cfg.n_traits)
+    GNXCHK(gnx_d2h(h, z, h->st_z, n * h->cfg.n_traits * sizeof(float)));
+  if (geno && h->st_has_geno)
+    GNXCHK(gnx_d2h(h, geno, h->st_geno, (size_t)n * 2 * h->W64 * 8));
   return 0;
 }
 
@@ -253,10 +260,10 @@ static int import_common(gnx_state* h, int64_t n, const gnx_ind_rec* rec, const 
   float* d_z = nullptr;
   u64* d_g = nullptr;
   GNXCHK(dalloc_t(&d_rec, (size_t)n));
-  HIPCHK(hipMemcpy(d_rec, rec, n * sizeof(gnx_ind_rec), hipMemcpyHostToDevice));
+  GNXCHK(gnx_h2d(h, d_rec, rec, n * sizeof(gnx_ind_rec)));
   if (z && c.n_traits) {
     GNXCHK(dalloc_t(&d_z, (size_t)n * c.n_traits));
-    HIPCHK(hipMemcpy(d_z, z, n * c.n_traits * sizeof(float), hipMemcpyHostToDevice));
+    GNXCHK(gnx_h2d(h, d_z, z, n * c.n_traits * sizeof(float)));
   }
   GnxSoA s = h->soa[h->cur];
   hipLaunchKernelGGL(k_unpack, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, h->N, n,
@@ -268,7 +275,7 @@ static int import_common(gnx_state* h, int64_t n, const gnx_ind_rec* rec, const 
       return 1;
     }
     GNXCHK(dalloc_t(&d_g, (size_t)n * 2 * h->W64));
-    HIPCHK(hipMemcpy(d_g, geno, (size_t)n * 2 * h->W64 * 8, hipMemcpyHostToDevice));
+    GNXCHK(gnx_h2d(h, d_g, geno, (size_t)n * 2 * h->W64 * 8));
     const int W16 = h->W64 / 2;
     hipLaunchKernelGGL(k_scatter_genomes, dim3(gnx_grid(n * 2 * W16, 256, 256 * 32)), dim3(256), 0,
                        h->stream, n, W16, (const u64x2*)d_g, (u64x2*)h->G, s.grow, h->N);
@@ -319,30 +326,31 @@ extern "C" int gnx_tile_pair_info(gnx_state* h, int64_t* focal_ids, int32_t* n_b
   int64_t P = h->n_pairs;
   if (P == 0) return 0;
   GnxSoA s = h->soa[h->cur];
-  std::vector<int32_t> pr(2 * P);
-  std::vector<int64_t> ids(h->N);
-  HIPCHK(hipMemcpy(pr.data(), h->pairs, 2 * P * sizeof(int32_t), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(ids.data(), s.id, h->N * sizeof(int64_t), hipMemcpyDeviceToHost));
-  for (int64_t p = 0; p < P; ++p) focal_ids[p] = ids[pr[2 * p]];
+  // gnx_l_find_pairs left the sorted focal ids in key64[1] when it sorted (P > 1)
+  if (P > 1) {
+    GNXCHK(gnx_d2h(h, focal_ids, h->key64[1], P * sizeof(int64_t)));
+  } else {
+    int32_t slot = 0;
+    GNXCHK(gnx_d2h(h, &slot, h->pairs, sizeof(int32_t)));
+    GNXCHK(gnx_d2h(h, focal_ids, s.id + slot, sizeof(int64_t)));
+  }
   if (h->sp.n_births_fixed)
     for (int64_t p = 0; p < P; ++p) n_births[p] = (int32_t)h->sp.n_births_lambda;
   else
-    HIPCHK(hipMemcpy(n_births, h->nbirths, P * sizeof(int32_t), hipMemcpyDeviceToHost));
+    GNXCHK(gnx_d2h(h, n_births, h->nbirths, P * sizeof(int32_t)));
   return 0;
 }
 
 extern "C" int gnx_get_bins(gnx_state* h, int32_t which, int32_t* out) {
   size_t nb = (size_t)h->lat.nbx * h->lat.nby;
   HIPCHK(hipStreamSynchronize(h->stream));
-  HIPCHK(hipMemcpy(out, which ? h->bins_P : h->bin_partials, nb * sizeof(int32_t),
-                   hipMemcpyDeviceToHost));
+  GNXCHK(gnx_d2h(h, out, which ? h->bins_P : h->bin_partials, nb * sizeof(int32_t)));
   return 0;
 }
 
 extern "C" int gnx_set_bins(gnx_state* h, int32_t which, const int32_t* in) {
   size_t nb = (size_t)h->lat.nbx * h->lat.nby;
-  HIPCHK(hipMemcpy(which ? h->bins_P : h->bin_partials, in, nb * sizeof(int32_t),
-                   hipMemcpyHostToDevice));
+  GNXCHK(gnx_h2d(h, which ? h->bins_P : h->bin_partials, in, nb * sizeof(int32_t)));
   return 0;
 }
 
@@ -353,9 +361,21 @@ extern "C" int gnx_tile_offspring(gnx_state* h, int32_t burn, int64_t id_base,
   *n_requests = 0;
   int64_t P = h->n_pairs, B = 0;
   h->birth_first_slot = h->N;
+  static const bool dbg = getenv("GNX_DEBUG_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(
+                      std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t0 = now();
+  if (dbg) (void)hipStreamSynchronize(h->stream);
+  double t1 = now();
   if (P > 0)
-    HIPCHK(hipMemcpy(h->pair_goff, pair_goff, P * sizeof(int64_t), hipMemcpyHostToDevice));
+    GNXCHK(gnx_h2d(h, h->pair_goff, pair_goff, P * sizeof(int64_t)));
+  double t2 = now();
   GNXCHK(gnx_l_mate(h, burn != 0, false, 0, &B, id_base, true));
+  if (dbg) {
+    (void)hipStreamSynchronize(h->stream);
+    fprintf(stderr, "[tile_offspring] wait-prev %.3f  h2d %.3f  mate %.3f ms (P=%lld B=%lld)\n",
+            t1 - t0, t2 - t1, now() - t2, (long long)P, (long long)B);
+  }
   h->last_births = B;
   if (B > 0 && !burn && has_rows(h)) {
     HIPCHK(hipMemcpyAsync(h->h_pin, h->req_count, sizeof(int32_t), hipMemcpyDeviceToHost,
@@ -371,12 +391,12 @@ extern "C" int gnx_tile_get_requests(gnx_state* h, int64_t* pid, int32_t* child_
                                      uint8_t* start, float* px, float* py) {
   int64_t n = h->n_req;
   if (n == 0) return 0;
-  HIPCHK(hipMemcpy(pid, h->req_pid, n * 8, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(child_k, h->req_k, n * 4, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(key, h->req_key, n * 4, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(start, h->req_start, n, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(px, h->req_px, n * 4, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(py, h->req_py, n * 4, hipMemcpyDeviceToHost));
+  GNXCHK(gnx_d2h(h, pid, h->req_pid, n * 8));
+  GNXCHK(gnx_d2h(h, child_k, h->req_k, n * 4));
+  GNXCHK(gnx_d2h(h, key, h->req_key, n * 4));
+  GNXCHK(gnx_d2h(h, start, h->req_start, n));
+  GNXCHK(gnx_d2h(h, px, h->req_px, n * 4));
+  GNXCHK(gnx_d2h(h, py, h->req_py, n * 4));
   return 0;
 }
 
@@ -462,15 +482,14 @@ extern "C" int gnx_tile_serve_gametes(gnx_state* h, int64_t n, const int64_t* pa
   GNXCHK(dalloc_t(&d_miss, 1));
   GNXCHK(dalloc_t(&d_st, (size_t)n));
   GNXCHK(dalloc_t(&d_out, (size_t)n * h->W64));
-  HIPCHK(hipMemcpy(d_ids, parent_ids, n * 8, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(d_keys, keys, n * 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(d_st, starts, n, hipMemcpyHostToDevice));
+  GNXCHK(gnx_h2d(h, d_ids, parent_ids, n * 8));
+  GNXCHK(gnx_h2d(h, d_keys, keys, n * 4));
+  GNXCHK(gnx_h2d(h, d_st, starts, n));
   HIPCHK(hipMemsetAsync(d_miss, 0, 4, h->stream));
   hipLaunchKernelGGL(k_lookup, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, n, d_ids, N,
                      h->key64[1], h->perm[1], d_slot, d_miss);
   int miss = 0;
-  HIPCHK(hipMemcpyAsync(&miss, d_miss, 4, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  GNXCHK(gnx_d2h(h, &miss, d_miss, 4));
   int rc = 0;
   if (miss) {
     gnx_set_error("gnx_tile_serve_gametes: %d requested parents do not live on this tile", miss);
@@ -480,13 +499,7 @@ extern "C" int gnx_tile_serve_gametes(gnx_state* h, int64_t n, const int64_t* pa
     hipLaunchKernelGGL(k_make_gametes, dim3(gnx_grid(n * 64, 256)), dim3(256), 0, h->stream, n, W16,
                        (const u64x2*)h->G, s.grow, d_slot, d_keys, d_st, (const u64x2*)h->paths,
                        (u64x2*)d_out);
-    hipError_t e = hipMemcpyAsync(out, d_out, (size_t)n * h->W64 * 8, hipMemcpyDeviceToHost,
-                                  h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    if (e != hipSuccess) {
-      gnx_set_error("gnx_tile_serve_gametes: %s", hipGetErrorString(e));
-      rc = 1;
-    }
+    rc = gnx_d2h(h, out, d_out, (size_t)n * h->W64 * 8);
   }
   for (void* p : {(void*)d_ids, (void*)d_keys, (void*)d_slot, (void*)d_miss, (void*)d_st,
                   (void*)d_out})
@@ -518,8 +531,8 @@ extern "C" int gnx_tile_put_gametes(gnx_state* h, int64_t n, const int32_t* chil
   u64* d_in = nullptr;
   GNXCHK(dalloc_t(&d_k, (size_t)n));
   GNXCHK(dalloc_t(&d_in, (size_t)n * h->W64));
-  HIPCHK(hipMemcpy(d_k, child_k, n * 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(d_in, data, (size_t)n * h->W64 * 8, hipMemcpyHostToDevice));
+  GNXCHK(gnx_h2d(h, d_k, child_k, n * 4));
+  GNXCHK(gnx_h2d(h, d_in, data, (size_t)n * h->W64 * 8));
   const int W16 = h->W64 / 2;
   hipLaunchKernelGGL(k_put_gametes, dim3(gnx_grid(n * W16, 256, 256 * 32)), dim3(256), 0, h->stream,
                      n, W16, (const u64x2*)d_in, (u64x2*)h->G, h->soa[h->cur].grow,
@@ -535,8 +548,12 @@ extern "C" int gnx_tile_put_gametes(gnx_state* h, int64_t n, const int32_t* chil
 // of the tile's own individuals (ghosts skipped) for the N density
 extern "C" int gnx_tile_finish_births(gnx_state* h, int32_t burn) {
   int64_t B = h->last_births;
-  if (B > 0 && !burn && has_rows(h) && h->cfg.n_traits > 0)
-    GNXCHK(gnx_l_phenotype(h, h->birth_first_slot, B));
+  if (B > 0 && !burn && has_rows(h) && h->cfg.n_traits > 0) {
+    // local gametes left their trait alleles in tbits (crossover epilogue); only
+    // offspring that received a remote gamete re-read their trait loci
+    GNXCHK(gnx_l_phenotype_births(h, h->birth_first_slot, B));
+    GNXCHK(gnx_l_phenotype_list(h, h->birth_first_slot, h->n_req, h->req_k));
+  }
   GnxSoA s = h->soa[h->cur];
   GNXCHK(gnx_l_bins(h, h->N, s.x, s.y, s.ghost, h->bin_partials));
   return 0;

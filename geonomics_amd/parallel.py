@@ -109,6 +109,14 @@ class Comm:
 
     def __init__(self, dist=None):
         self.dist = dist
+        # the host side of a step is a few tiny tensor ops; torch's intra-op thread
+        # pool (one spinning thread per core) only burns the box's CPU quota and
+        # stalls the launching thread
+        try:
+            import torch
+            torch.set_num_threads(1)
+        except Exception:
+            pass
         if dist is None or not dist.is_initialized():
             self.rank, self.world, self.device = 0, 1, 'cpu'
             self.dist = None
@@ -127,6 +135,23 @@ class Comm:
         t = self._t(a)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return t.cpu().numpy()
+
+    def allgather_var(self, t):
+        """All ranks' 1-d int64 tensors (variable length) -> list of tensors that
+        stay on the communication device."""
+        import torch
+        if self.dist is None:
+            return [t]
+        n = torch.tensor([t.numel()], dtype=torch.int64, device=self.device)
+        ns = [torch.zeros_like(n) for _ in range(self.world)]
+        self.dist.all_gather(ns, n)
+        ns = [int(v.item()) for v in ns]
+        m = max(max(ns), 1)
+        buf = torch.zeros(m, dtype=torch.int64, device=self.device)
+        buf[:t.numel()] = t
+        out = [torch.zeros_like(buf) for _ in range(self.world)]
+        self.dist.all_gather(out, buf)
+        return [o[:k] for o, k in zip(out, ns)]
 
     def allgather_i64(self, a):
         """All ranks' 1-d int64 arrays (variable length) -> list per rank."""
@@ -184,7 +209,7 @@ def _cat(chunks, dtype, shape_tail=()):
 
 class TiledStepper:
     def __init__(self, shard, comm, W, H, mating_radius, move=True, max_id=-1,
-                 grid=None):
+                 grid=None, fixed_births=0):
         self.shard = shard
         self.comm = comm
         self.W, self.H = W, H
@@ -198,9 +223,14 @@ class TiledStepper:
             assert 2 * self.radius <= min(self.tw, self.th), (
                 'tiles must be at least 2 x mating_radius wide')
         self.move = move
+        self.fixed_births = int(fixed_births)   # > 0: every pair has this many births
         self.max_id = int(max_id)            # global maximum id handed out
         shard.tile_set(self.R, self.C, self.r, self.c)
         self.bytes_sent = 0
+        import os
+        self.profile = bool(os.environ.get('GNX_TILE_PROFILE'))
+        self.phase_s = {}
+        self._t0 = 0.0
 
     def rank_of(self, x, y):
         c = np.minimum(self.C - 1, (np.asarray(x) // self.tw).astype(np.int64))
@@ -281,16 +311,40 @@ class TiledStepper:
         self.shard.import_ghosts(ghosts)
 
     def _pair_offsets(self):
+        """Global offspring offset of every local pair: pairs are ordered by
+        focal id over ALL tiles (each tile's list is already sorted), births are
+        numbered in that order.  offset(v) = sum over tiles of the births of that
+        tile's pairs with focal id < v (searchsorted on the comm device)."""
+        import torch
         ids, nb = self.shard.pair_info()
-        all_ids = self.comm.allgather_i64(ids)
-        all_nb = self.comm.allgather_i64(nb.astype(np.int64))
-        gi = np.concatenate(all_ids)
-        gn = np.concatenate(all_nb)
-        order = np.argsort(gi, kind='stable')
-        start = np.zeros(gi.size, np.int64)
-        start[order] = np.concatenate([[0], np.cumsum(gn[order])[:-1]]) if gi.size else []
-        lo = sum(a.size for a in all_ids[:self.comm.rank])
-        return start[lo:lo + ids.size], int(gn.sum()), gi.size
+        if self.comm.world == 1:        # one tile: the local order is the global order
+            nb64 = nb.astype(np.int64)
+            goff = np.concatenate([[0], np.cumsum(nb64)[:-1]]) if ids.size else nb64
+            return goff.astype(np.int64), int(nb64.sum()), ids.size
+        dev = self.comm.device
+        mine = torch.from_numpy(ids).to(dev)
+        all_ids = self.comm.allgather_var(mine)
+        fixed = self.fixed_births
+        all_nb = None if fixed else self.comm.allgather_var(
+            torch.from_numpy(nb.astype(np.int64)).to(dev))
+        goff = torch.zeros(ids.size, dtype=torch.int64, device=dev)
+        total_births = 0
+        total_pairs = 0
+        for r in range(self.comm.world):
+            li = all_ids[r]
+            if fixed:
+                if ids.size:
+                    goff += torch.searchsorted(li, mine) * int(fixed)
+                total_births += int(fixed) * li.numel()
+            else:
+                cum = torch.zeros(li.numel() + 1, dtype=torch.int64, device=dev)
+                if li.numel():
+                    cum[1:] = torch.cumsum(all_nb[r], 0)
+                if ids.size:
+                    goff += cum[torch.searchsorted(li, mine)]
+                total_births += int(cum[-1].item())
+            total_pairs += li.numel()
+        return goff.cpu().numpy(), total_births, total_pairs
 
     def _gametes(self, n_req):
         w = self.comm.world
@@ -324,23 +378,50 @@ class TiledStepper:
             self.shard.put_gametes(ck[order[p]], buf.view(np.uint64).reshape(-1, W64))
 
     # -- one time step -------------------------------------------------------------------
+    def _tick(self, name):
+        """host wall time per phase (GNX_TILE_PROFILE=1); the device is
+        synchronised at each mark so the figures include kernel time"""
+        if not self.profile:
+            return
+        import time
+        sync = getattr(getattr(self.shard, 'dev', None), 'synchronize', None)
+        if sync:
+            sync()
+        now = time.perf_counter()
+        if name is not None:
+            self.phase_s[name] = self.phase_s.get(name, 0.0) + now - self._t0
+        self._t0 = now
+
     def step(self, burn, with_selection):
         sh = self.shard
+        self._tick(None)
         sh.age_and_move(self.move)
+        self._tick('age+move')
         self._migrate()
+        self._tick('migrants')
         self._halo()
+        self._tick('halo')
         P, B = sh.pairs(burn)
+        self._tick('pairs')
         goff, total_births, total_pairs = self._pair_offsets()
-        sh.set_bins(1, self.comm.allreduce_sum(sh.get_bins(1)))
+        self._tick('pair order')
         n_req = sh.offspring(burn, self.max_id + 1, goff)
         self.max_id += total_births
         sh.set_max_id(self.max_id)
+        self._tick('offspring+crossover')
         if not burn and sh.has_genomes:
             self._gametes(n_req)
+        self._tick('gametes')
         sh.finish_births(burn)
-        sh.set_bins(0, self.comm.allreduce_sum(sh.get_bins(0)))
+        # one all-reduce for both density fields (individuals, pair midpoints)
+        b0, b1 = sh.get_bins(0), sh.get_bins(1)
+        both = self.comm.allreduce_sum(np.concatenate([b0, b1]))
+        sh.set_bins(0, both[:b0.size])
+        sh.set_bins(1, both[b0.size:])
+        self._tick('phenotype + bins')
         sh.die(burn, with_selection, total_pairs > 0)
         sh.advance_step()
         n, b, d = sh.counts()
         tot = self.comm.allreduce_sum(np.array([n, b, d], dtype=np.int64))
+        self._tick('die + counts')
         return int(tot[0]), int(tot[1]), int(tot[2])
