@@ -118,17 +118,22 @@ __constant__ int c_queen_dx[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
 // neighbours on the zero-embedded raster, weights = value / sum (1/8 each if the
 // sum is 0); mixture: pick a bearing ~ weights then von Mises(kappa) about it;
 // unimodal: von Mises about the arithmetic mean of the arg-max bearings.
-__device__ __forceinline__ float surf_direction(const float* rast, int W, int H, int cx, int cy,
-                                                int mode, float kappa, GnxStream& s) {
-  float n[8];
-  float sum = 0.f, mx = -1.f;
+__device__ __forceinline__ void surf_neighbours(const float* rast, int W, int H, int cx, int cy,
+                                                float n[8]) {
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     int yy = cy + c_queen_dy[k], xx = cx + c_queen_dx[k];
-    float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? rast[(int64_t)yy * W + xx] : 0.f;
-    n[k] = v;
-    sum += v;
-    mx = fmaxf(mx, v);
+    n[k] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? rast[(int64_t)yy * W + xx] : 0.f;
+  }
+}
+
+__device__ __forceinline__ float surf_sample(const float n[8], int mode, float kappa,
+                                             GnxStream& s) {
+  float sum = 0.f, mx = -1.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    sum += n[k];
+    mx = fmaxf(mx, n[k]);
   }
   float loc;
   if (mode == GNX_SURF_MIXTURE) {
@@ -163,14 +168,77 @@ __device__ __forceinline__ float surf_direction(const float* rast, int W, int H,
   return loc + gnx_vonmises(s, 0.0f, kappa);
 }
 
+__device__ __forceinline__ float surf_direction(const float* rast, int W, int H, int cx, int cy,
+                                                int mode, float kappa, GnxStream& s) {
+  float n[8];
+  surf_neighbours(rast, W, H, cx, cy, n);
+  return surf_sample(n, mode, kappa, s);
+}
+
+// LDS-tiled 3x3 gather for a workgroup of (cell-sorted) individuals: the block
+// takes the bounding box of its individuals' cells, widened by one cell, stages
+// that window of the conductance raster in LDS with coalesced row reads (zeros
+// outside the landscape = the reference's zero-embedding) and every lane reads
+// its 8 neighbours from LDS.  A block whose box does not fit (e.g. the unsorted
+// tail of newborns) falls back to global gathers.  Returns false on fallback.
+#define SURF_TILE_FLOATS 8192
+__device__ __forceinline__ bool surf_neighbours_lds(const float* rast, int W, int H, bool act,
+                                                    int cx, int cy, float* tile, int* box,
+                                                    float n[8]) {
+  // box = {xmin, xmax, ymin, ymax} in LDS
+  if (threadIdx.x == 0) {
+    box[0] = 0x7fffffff;
+    box[1] = -1;
+    box[2] = 0x7fffffff;
+    box[3] = -1;
+  }
+  __syncthreads();
+  if (act) {
+    atomicMin(&box[0], cx);
+    atomicMax(&box[1], cx);
+    atomicMin(&box[2], cy);
+    atomicMax(&box[3], cy);
+  }
+  __syncthreads();
+  const int x0 = box[0] - 1, x1 = box[1] + 1, y0 = box[2] - 1, y1 = box[3] + 1;
+  const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
+  if (box[1] < 0 || (int64_t)bw * bh > SURF_TILE_FLOATS) return false;   // block-uniform
+  for (int t = threadIdx.x; t < bw * bh; t += blockDim.x) {
+    int ty = t / bw, tx = t - ty * bw;
+    int yy = y0 + ty, xx = x0 + tx;
+    tile[t] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? rast[(int64_t)yy * W + xx] : 0.f;
+  }
+  __syncthreads();
+  if (act) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      n[k] = tile[(cy + c_queen_dy[k] - y0) * bw + (cx + c_queen_dx[k] - x0)];
+  }
+  return true;
+}
+
 // ops/movement.py:34-95 + Species._set_e (structs/species.py:913-922).
 // Optionally increments age first (Species._set_age_stage, :567-569).
 __global__ void __launch_bounds__(256)
 k_move(MoveP P, GnxSoA s, const float* rast, const float* inj_theta, const float* inj_dist,
        float* out_theta, float* out_dist) {
+  __shared__ float surf_tile[SURF_TILE_FLOATS];
+  __shared__ int surf_box[4];
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P.N) return;
-  float x = s.x[i], y = s.y[i];
+  const bool act = i < P.N;
+  float x = 0.f, y = 0.f;
+  if (act) {
+    x = s.x[i];
+    y = s.y[i];
+  }
+  float nb[8];
+  bool have_nb = false;
+  if (P.surf != GNX_SURF_NONE && !inj_theta) {     // block-uniform condition
+    const float* cond = rast + (int64_t)P.surf_layer * P.H * P.W;
+    have_nb = surf_neighbours_lds(cond, P.W, P.H, act, (int)x, (int)y, surf_tile, surf_box, nb);
+    if (!have_nb && act) surf_neighbours(cond, P.W, P.H, (int)x, (int)y, nb);
+  }
+  if (!act) return;
   unsigned long long id = (unsigned long long)s.id[i];
   float theta, dist;
   if (inj_theta) {
@@ -179,8 +247,7 @@ k_move(MoveP P, GnxSoA s, const float* rast, const float* inj_theta, const float
   } else {
     if (P.surf != GNX_SURF_NONE) {
       GnxStream st(P.seed, id, P.step, OP_MOVE_SURF);
-      theta = surf_direction(rast + (int64_t)P.surf_layer * P.H * P.W, P.W, P.H, (int)x, (int)y,
-                             P.surf, P.surf_kappa, st);
+      theta = surf_sample(nb, P.surf, P.surf_kappa, st);
     } else {
       GnxStream st(P.seed, id, P.step, OP_MOVE_DIR);
       theta = gnx_vonmises(st, P.mu, P.kappa);

@@ -40,7 +40,8 @@ def vonmises(seed, ids, step, op, mu, kappa, first_word=0):
     first_word; returns f32 angles."""
     ids = np.asarray(ids, dtype=np.uint64)
     n = ids.size
-    words = np.concatenate([_u(seed, ids, step, op, b) for b in range(9)], axis=1)
+    nblk = 9 + (first_word // 4)
+    words = np.concatenate([_u(seed, ids, step, op, b) for b in range(nblk)], axis=1)
     w = first_word
     mu, kappa = F(mu), F(kappa)
     if kappa < 1e-8:
@@ -133,3 +134,53 @@ def init_positions(seed, n, W, H):
     y = np.minimum(P.u01(r[:, 1]) * F(H), F(H - 0.001))
     sex = (P.u01(r[:, 2]) < F(0.5)).astype(np.uint8)
     return x.astype(F), y.astype(F), sex
+
+
+QUEEN_DIRS_F = np.array([-2.35619449019234492885, -1.57079632679489661923,
+                         -0.78539816339744830962, 3.14159265358979323846, 0.0,
+                         2.35619449019234492885, 1.57079632679489661923,
+                         0.78539816339744830962], dtype=F)
+QUEEN_OFFS = [(-1, -1), (-1, 0), (-1, 1), (0, -1), (0, 1), (1, -1), (1, 0), (1, 1)]
+
+
+def surf_directions(seed, ids, step, op, rast, x, y, mixture, kappa, first_blk=0):
+    """surf_sample (csrc/gnx_kernels_pop.hip): the on-the-fly restatement of the
+    reference's conductance-surface LUT (utils/spatial.py:365-461)."""
+    rast = np.asarray(rast, dtype=F)
+    H, W = rast.shape
+    cx = np.asarray(x).astype(np.int64)
+    cy = np.asarray(y).astype(np.int64)
+    n = np.zeros((cx.size, 8), dtype=F)
+    for k, (dy, dx) in enumerate(QUEEN_OFFS):
+        yy, xx = cy + dy, cx + dx
+        ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W)
+        n[ok, k] = rast[yy[ok], xx[ok]]
+    ssum = np.zeros(cx.size, dtype=F)
+    for k in range(8):
+        ssum = (ssum + n[:, k]).astype(F)
+    words = _u(seed, ids, step, op, first_blk)
+    if mixture:
+        u = P.u01(words[:, 0])
+        t = (u * ssum).astype(F)
+        pick = np.full(cx.size, -1)
+        c = np.zeros(cx.size, dtype=F)
+        last = np.zeros(cx.size, dtype=np.int64)
+        for k in range(8):
+            c = (c + n[:, k]).astype(F)
+            last = np.where(n[:, k] > 0, k, last)
+            pick = np.where((pick < 0) & (t < c), k, pick)
+        pick = np.where(pick < 0, last, pick)
+        uni = np.minimum(7, (u * F(8.0)).astype(np.int64))
+        pick = np.where(ssum > 0, pick, uni)
+        loc = QUEEN_DIRS_F[pick]
+        first_word = 1
+    else:
+        mx = n.max(axis=1)
+        ismax = n == mx[:, None]
+        acc = np.zeros(cx.size, dtype=F)
+        for k in range(8):
+            acc = np.where(ismax[:, k], (acc + QUEEN_DIRS_F[k]).astype(F), acc)
+        loc = (acc / ismax.sum(axis=1).astype(F)).astype(F)
+        first_word = 0
+    vm = vonmises(seed, ids, step, op, 0.0, kappa, first_word=first_word + 4 * first_blk)
+    return (loc + vm).astype(F)

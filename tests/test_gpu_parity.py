@@ -657,3 +657,64 @@ def test_device_step_matches_oracle_step_counts():
         assert abs(n_dev - st.N) <= max(6, 0.03 * st.N)
     assert same >= 3          # the first steps agree exactly before rounding flips accumulate
     dev.close()
+
+
+# ------------------------------------------------------------------ A3 on device
+@pytest.mark.parametrize('mixture', [True, False])
+def test_conductance_directions_vs_reference_and_oracle(mixture):
+    """Directions drawn from a conductance surface: (i) the device draws equal
+    the oracle's restatement of the same stream (LDS-tiled and fallback gather
+    paths), (ii) their circular moments per cell match the reference's LUT."""
+    nat = native()
+    g = load_golden('g11_conductance')
+    rast = g['rast'].astype(np.float32)
+    H, W = rast.shape
+    per = 1500
+    cy, cx = np.mgrid[0:H, 0:W]
+    x = (np.repeat(cx.ravel(), per) + 0.5).astype(np.float32)
+    y = (np.repeat(cy.ravel(), per) + 0.5).astype(np.float32)
+    n = x.size
+    ids = np.arange(n) + 7
+    dev = make_dev(W, H, rasts=rast[None], cap=n + 64, seed=5,
+                   move_surf=nat.SURF_MIXTURE if mixture else nat.SURF_UNIMODAL,
+                   move_surf_layer=0, move_surf_kappa=12.0)
+    upload_simple(dev, x, y, ids=ids)
+    dev.step_index = 3
+    th, _ = dev.op_move_draws()
+    tho = D.surf_directions(5, ids, 3, P.OP_MOVE_SURF, rast, x, y, mixture, 12.0)
+    d = np.abs(th - tho)
+    d = np.minimum(d, 2 * np.pi - d)
+    assert (d < 2e-3).mean() > 0.9995       # same picks; acosf/logf ulps only
+    tag = 'mix' if mixture else 'uni'
+    tol = 4.5 / np.sqrt(g['approx_len'][0]) + 4.5 / np.sqrt(per)
+    mc = np.cos(th).reshape(H * W, per).mean(1)
+    ms = np.sin(th).reshape(H * W, per).mean(1)
+    assert np.abs(mc - g[tag + '_mean_cos'].ravel()).max() < tol
+    assert np.abs(ms - g[tag + '_mean_sin'].ravel()).max() < tol
+    dev.close()
+
+
+def test_conductance_gather_lds_and_fallback_agree():
+    """A block whose individuals are spread over a box larger than the LDS tile
+    takes the global-gather fallback; both must give the oracle's draws."""
+    nat = native()
+    rng = np.random.RandomState(3)
+    W = H = 160
+    rast = rng.rand(H, W).astype(np.float32)
+    n = 4096
+    for spread in (False, True):
+        if spread:
+            x = (rng.rand(n) * W).astype(np.float32)      # box = whole landscape > tile
+            y = (rng.rand(n) * H).astype(np.float32)
+        else:
+            x = (20 + rng.rand(n) * 30).astype(np.float32)  # box ~ 32 x 32 cells
+            y = (40 + rng.rand(n) * 30).astype(np.float32)
+        dev = make_dev(W, H, rasts=rast[None], cap=n + 8, seed=9, move_surf=nat.SURF_MIXTURE,
+                       move_surf_layer=0, move_surf_kappa=6.0)
+        upload_simple(dev, x, y)
+        th, _ = dev.op_move_draws()
+        tho = D.surf_directions(9, np.arange(n), 0, P.OP_MOVE_SURF, rast, x, y, True, 6.0)
+        d = np.abs(th - tho)
+        d = np.minimum(d, 2 * np.pi - d)
+        assert (d < 2e-3).mean() > 0.9995, spread
+        dev.close()
