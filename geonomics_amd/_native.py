@@ -40,7 +40,7 @@ EXPORTS = [
     'gnx_density_bin_count', 'gnx_get_bins', 'gnx_set_bins',
     'gnx_tile_offspring', 'gnx_tile_get_requests', 'gnx_tile_serve_gametes',
     'gnx_tile_put_gametes', 'gnx_tile_finish_births', 'gnx_tile_die',
-    'gnx_set_max_id',
+    'gnx_set_max_id', 'gnx_stats_locus_counts', 'gnx_stats_ld',
 ]
 
 
@@ -520,6 +520,21 @@ class Device:
 
     def set_max_id(self, v):
         self._chk(self.lib.gnx_set_max_id(self.h, C.c_int64(int(v))))
+
+    # -- statistics ------------------------------------------------------------------
+    def stats_locus_counts(self):
+        c1 = np.zeros(self.L, np.int32)
+        ch = np.zeros(self.L, np.int32)
+        self._chk(self.lib.gnx_stats_locus_counts(self.h, _ptr(c1, C.c_int32),
+                                                  _ptr(ch, C.c_int32)))
+        return c1, ch
+
+    def stats_ld(self, loci):
+        loci = _arr(loci, np.int32)
+        out = np.zeros((loci.size, loci.size), np.float64)
+        self._chk(self.lib.gnx_stats_ld(self.h, int(loci.size), _ptr(loci, C.c_int32),
+                                        _ptr(out, C.c_double)))
+        return out
 
     # -- measurement ---------------------------------------------------------
     def profiling(self, on):

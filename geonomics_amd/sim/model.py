@@ -11,7 +11,8 @@ _set_spp_t, _set_age_stage, _do_movement, _do_pop_dynamics, _set_Nt
 exceptions inside run() are caught per iteration (:938-953).
 Fixed: queue lambdas bind their own species; both
 params.model.seed.num and params.model.num seed the model.
-Out of scope here: plotting, data/stats collectors, change events.
+Statistics (params.model.stats) are collected by sim/stats.py from the device.
+Out of scope here: plotting, the data collector, change events.
 """
 import copy
 import os
@@ -24,6 +25,7 @@ import numpy as np
 from ..structs.landscape import _make_landscape
 from ..structs.community import _make_community
 from ..structs import genome as _genome
+from .stats import _StatsCollector
 
 
 class Model:
@@ -60,11 +62,12 @@ class Model:
         self._never_been_run = True
         self._data_collector = None
         self._stats_collector = None
-        for key in ('data', 'stats'):
-            if key in [*m_params]:
-                import warnings
-                warnings.warn("params.model.%s is ignored: data/stats collectors are "
-                              "outside the GPU hot path (SURVEY 8f)." % key)
+        if 'stats' in [*m_params]:
+            self._stats_collector = self._make_stats_collector()
+        if 'data' in [*m_params]:
+            import warnings
+            warnings.warn("params.model.data is ignored: the data collector is "
+                          "outside the GPU hot path (SURVEY 8f).")
         self.reassign_genomes = None
         self.rand_genarch = m_params.its.rand_genarch
         self.rand_landscape = m_params.its.rand_landscape
@@ -152,6 +155,14 @@ class Model:
                                seed=self._dev_seed, device=self._device, rng=self._rng)
         return comm
 
+    def _make_stats_collector(self):
+        """reference sim/model.py:527-535"""
+        return _StatsCollector(self.name, self.params)
+
+    def calc_stats(self):
+        """reference sim/model.py:1190-1191"""
+        self._stats_collector._calc_stats(self.comm, self.t, self.it)
+
     def _snapshot_comm(self):
         return {k: spp._snapshot() for k, spp in self.comm.items()}
 
@@ -197,6 +208,8 @@ class Model:
         else:
             self._never_been_run = False
         self._reset_t()
+        if self._stats_collector is not None:
+            self._stats_collector = self._make_stats_collector()
         if repeat_burn:
             self._reset_burn_t()
         self.comm._reset_t()
@@ -226,6 +239,8 @@ class Model:
             queue.append(lambda spp=spp: spp._do_pop_dynamics(self.land))
         for spp in self.comm.values():
             queue.append(spp._set_Nt)
+        if not burn and self._stats_collector is not None:
+            queue.append(self.calc_stats)
         if burn:
             queue.append(self._check_comm_burned)
         return queue

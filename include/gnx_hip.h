@@ -276,6 +276,13 @@ int gnx_tile_finish_births(gnx_state* h, int32_t burn);
 int gnx_tile_die(gnx_state* h, int32_t burn, int32_t with_selection, int32_t have_pairs);
 int gnx_set_max_id(gnx_state* h, int64_t max_id);
 
+/* ---- statistics (reference sim/stats.py:359-435) ---------- */
+/* per-locus count of 1-alleles over the 2N chromosomes and of heterozygous
+ * individuals: het = cnt_het / N (_calc_het), f1 = cnt1 / 2N (_calc_maf)     */
+int gnx_stats_locus_counts(gnx_state* h, int32_t* cnt1 /*[L]*/, int32_t* cnt_het /*[L]*/);
+/* r^2 between the listed loci (_calc_ld); double [n][n], NaN on the diagonal */
+int gnx_stats_ld(gnx_state* h, int32_t n_loci, const int32_t* loci, double* r2);
+
 /* ---- measurement ------------------------------------------------------------ */
 int gnx_profiling(gnx_state* h, int32_t on);
 /* accumulated HIP-event time (ms) and launch count of one kernel family,

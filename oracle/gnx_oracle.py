@@ -683,3 +683,34 @@ def starting_genomes(N, L, n_per_site, seed, align_words=16):
         g[q // 2, :, q % 2] = take
         sel += take
     return pack_genomes(g, align_words)
+
+
+# ---------------------------------------------------------------------------
+# statistics (reference sim/stats.py:359-421), g = int [N, L, 2]
+# ---------------------------------------------------------------------------
+def stats_het(g):
+    """fraction of heterozygotes per locus (sim/stats.py:394-405)"""
+    g = np.asarray(g)
+    return (g[:, :, 0] != g[:, :, 1]).sum(axis=0) / g.shape[0]
+
+
+def stats_maf(g):
+    """minor-allele frequency per locus (sim/stats.py:408-421)"""
+    g = np.asarray(g)
+    f1 = g.sum(axis=(0, 2)) / (2 * g.shape[0])
+    return np.where(f1 > 0.5, 1 - f1, f1)
+
+
+def stats_ld(g):
+    """r^2 over the 2N chromosomes, NaN diagonal (sim/stats.py:359-390)"""
+    g = np.asarray(g)
+    N, L, _ = g.shape
+    chrom = np.concatenate([g[:, :, 0], g[:, :, 1]], axis=0).astype(np.float64)  # [2N, L]
+    two_N = 2.0 * N
+    f = chrom.sum(axis=0) / two_N
+    f11 = (chrom.T @ chrom) / two_N
+    D = f11 - (f[:, None] * f[None, :])
+    with np.errstate(divide='ignore', invalid='ignore'):
+        r2 = (D * D) / ((f * (1 - f))[:, None] * (f * (1 - f))[None, :])
+    r2[np.arange(L), np.arange(L)] = np.nan
+    return r2

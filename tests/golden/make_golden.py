@@ -572,13 +572,55 @@ def g10_envelopes():
     save('g10_envelopes', **out)
 
 
+def g12_stats():
+    """sim/stats.py calculators on a reference species + the text the
+    reference's writers (utils/io.py:126-168) produce for given values."""
+    import tempfile
+    from geonomics.sim import stats as ref_stats
+    from geonomics.utils import io as ref_io
+    out = {}
+    mod = make_ref_model(L=48, N=90, traits=True)
+    spp = assign_genomes(mod)
+    # some drift so that frequencies differ from the 0.5 start and LD exists
+    rng = np.random.RandomState(5)
+    for ind in spp.values():
+        flip = rng.rand(*ind.g.shape) < 0.25
+        ind.g = np.where(flip, 0, ind.g).astype(ind.g.dtype)
+    out['g'] = stack_g(spp)
+    out['het'] = ref_stats._calc_het(spp)
+    out['het_mean'] = np.array(ref_stats._calc_het(spp, mean=True))
+    out['maf'] = ref_stats._calc_maf(spp)
+    with np.errstate(all='ignore'):
+        out['ld'] = ref_stats._calc_ld(spp)
+    d = tempfile.mkdtemp()
+    vals_a = np.array([0.25, 0.5, 1 / 3.0, 0.0])
+    p1 = os.path.join(d, 'a.csv')
+    ref_io._append_row_to_csv(p1, vals_a, 0)
+    ref_io._append_row_to_csv(p1, vals_a[::-1], 5)
+    ref_io._append_row_to_csv(p1, 0.125, 10)
+    out['row_in'] = vals_a
+    out['row_txt'] = np.array(open(p1).read())
+    p2 = os.path.join(d, 'b.txt')
+    m = out['ld'][:4, :4]
+    ref_io._append_array2d_to_array_stack(p2, m)
+    ref_io._append_array2d_to_array_stack(p2, m * 2)
+    out['stack_txt'] = np.array(open(p2).read())
+    p3 = os.path.join(d, 'c.csv')
+    ref_io._write_dict_to_csv(p3, {'Nt': [100, np.nan, 104, 99],
+                                   'mean_fit': [0.9912345, np.nan, np.nan, 1.0]})
+    out['other_float_txt'] = np.array(open(p3).read())
+    ref_io._write_dict_to_csv(p3, {'Nt': [100, 101, 104, 99]})
+    out['other_int_txt'] = np.array(open(p3).read())
+    save('g12_stats', **out)
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g7', 'g8', 'g9',
-                             'g10', 'g11']
+                             'g10', 'g11', 'g12']
     fns = {'g1': g1_crossover, 'g2': g2_recomb_paths,
            'g3': g3_phenotype_fitness, 'g4': g4_density,
            'g5': g5_demography, 'g7': g7_movement, 'g8': g8_pairing,
            'g9': g9_starting_genomes, 'g10': g10_envelopes,
-           'g11': g11_conductance}
+           'g11': g11_conductance, 'g12': g12_stats}
     for w in which:
         fns[w]()

@@ -134,3 +134,48 @@ def test_extinction_is_not_an_error():
     mod = gnx.make_model(p)
     mod.walk(5, 'burn', verbose=False)
     assert mod.comm[0].extinct and len(mod.comm[0]) == 0
+
+
+def test_model_stats_collection(tmp_path, monkeypatch):
+    """params.model.stats drives the device-side statistics
+    (reference sim/stats.py; files as utils/io.py:126-168 writes them)"""
+    import csv
+    import geonomics_amd as gnx
+    monkeypatch.chdir(tmp_path)
+    p = small_params(T=6, L=40)
+    from geonomics_amd.sim.params import ParametersDict
+    p['model']['stats'] = ParametersDict(
+        {'Nt': {'calc': True, 'freq': 1}, 'het': {'calc': True, 'freq': 2, 'mean': False},
+         'maf': {'calc': True, 'freq': 3}, 'mean_fit': {'calc': True, 'freq': 1},
+         'ld': {'calc': True, 'freq': 0}})
+    mod = gnx.make_model(p)
+    mod.run()
+    spp = mod.comm[0]
+    base = tmp_path / 'GNX_mod-api_test' / 'it-0' / 'spp-spp_0'
+    pre = 'mod-api_test_it-0_spp-spp_0_'
+    rows = list(csv.DictReader(open(base / (pre + 'OTHER_STATS.csv'))))
+    assert [int(r['t']) for r in rows] == list(range(6))
+    assert [int(r['Nt']) for r in rows] == spp.Nt[-6:]
+    assert all(0 < float(r['mean_fit']) <= 1 for r in rows)
+    het = list(csv.reader(open(base / (pre + 'HET.csv'))))
+    assert het[0] == ['t'] + [str(i) for i in range(40)]
+    assert [int(r[0]) for r in het[1:]] == [0, 2, 4]
+    maf = list(csv.reader(open(base / (pre + 'MAF.csv'))))
+    assert [int(r[0]) for r in maf[1:]] == [0, 3]
+    ld = np.loadtxt(base / (pre + 'LD.txt'))
+    assert ld.shape == (80, 40)                      # t = 0 and t = 5 stacked
+    # the last in-memory samples are those of the final timestep: compare with
+    # the oracle on the downloaded genotypes
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
+    import gnx_oracle as O
+    g = mod.comm[0]._get_genotypes()
+    st = mod._stats_collector.stats['spp_0']
+    np.testing.assert_array_equal(st['het']['vals'][5], O.stats_het(g))
+    np.testing.assert_array_equal(st['maf']['vals'][5], O.stats_maf(g))
+    exp = O.stats_ld(g)
+    got = st['ld']['vals'][5]
+    fin = np.isfinite(exp)
+    np.testing.assert_allclose(got[fin], exp[fin], rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(ld[40:][fin], exp[fin], atol=5.1e-6)
+    assert st['mean_fit']['vals'][5] == pytest.approx(np.mean(spp._get_fit()))

@@ -718,3 +718,61 @@ def test_conductance_gather_lds_and_fallback_agree():
         d = np.minimum(d, 2 * np.pi - d)
         assert (d < 2e-3).mean() > 0.9995, spread
         dev.close()
+
+
+# ------------------------------------------------------------------ statistics
+def test_stats_vs_reference_golden():
+    """het / maf / ld of the reference (sim/stats.py:359-421) on its genotypes"""
+    d = load_golden('g12_stats')
+    g = d['g']
+    N, L, _ = g.shape
+    dev = make_dev(16, 16, L=L, cap=128)
+    rng = np.random.RandomState(0)
+    upload_simple(dev, rng.rand(N) * 16, rng.rand(N) * 16)
+    dev.upload_genomes(O.pack_genomes(g, dev.W64))
+    c1, ch = dev.stats_locus_counts()
+    np.testing.assert_array_equal(ch / N, d['het'])
+    f1 = c1 / (2 * N)
+    np.testing.assert_array_equal(np.where(f1 > 0.5, 1 - f1, f1), d['maf'])
+    np.testing.assert_allclose(dev.stats_ld(np.arange(L)), d['ld'], rtol=1e-10, atol=1e-14,
+                               equal_nan=True)
+    dev.close()
+
+
+def test_stats_vs_oracle_after_births_and_deaths():
+    """counts follow the genome-row indirection: run real steps (rows recycled,
+    slots permuted), then compare with the oracle on the downloaded genotypes;
+    L not a multiple of 64 and a monomorphic locus (r2 not finite, as numpy's)."""
+    nat = native()
+    rng = np.random.RandomState(3)
+    W = H = 48
+    L = 777
+    dev = make_dev(W, H, L=L, cap=8192, seed=5, mating_radius=3.0, K_factor=0.5)
+    dev.init_population(1500)
+    for _ in range(6):
+        dev.step(True, False)
+    n0 = dev.N
+    n1 = rng.randint(0, 2 * n0 + 1, L)
+    n1[5] = 0
+    dev.assign_genomes(n1)
+    paths = O.recomb_paths((rng.rand(50, L) < 0.01).astype(np.uint8) * (np.arange(L) > 0))
+    dev.set_recomb_paths(O.pack_bits(paths))
+    for _ in range(5):
+        dev.step(False, False)
+    Nn = dev.N
+    assert Nn > 0
+    g = O.unpack_genomes(dev.download(nat.F_GENO), L)
+    assert g.shape[0] == Nn
+    c1, ch = dev.stats_locus_counts()
+    np.testing.assert_array_equal(ch / Nn, O.stats_het(g))
+    f1 = c1 / (2 * Nn)
+    np.testing.assert_array_equal(np.where(f1 > 0.5, 1 - f1, f1), O.stats_maf(g))
+    loci = np.sort(rng.choice(L, 200, replace=False))
+    loci[0] = 5
+    r2 = dev.stats_ld(loci)
+    exp = O.stats_ld(g[:, loci, :])
+    fin = np.isfinite(exp)
+    assert not fin[0, 1]
+    np.testing.assert_array_equal(np.isfinite(r2), fin)
+    np.testing.assert_allclose(r2[fin], exp[fin], rtol=1e-9, atol=1e-13)
+    dev.close()

@@ -145,3 +145,85 @@ def test_spatial_test_needs_enough_samples():
     assert spatial_test(short, 30) is False
     ok = {'mean': list(rng.randn(60) * 0.01), 'std': list(1 + rng.randn(60) * 0.01)}
     assert spatial_test(ok, 30) in (True, False)
+
+
+# ---- statistics collector: file formats against the reference's writers ---------------
+def test_stats_writers_match_reference_text(tmp_path):
+    from conftest import load_golden
+    from geonomics_amd.sim.stats import _StatsCollector
+    d = load_golden('g12_stats')
+    row = d['row_in']
+    p1 = str(tmp_path / 'a.csv')
+    _StatsCollector._write_row_to_csv(p1, row, 0)
+    _StatsCollector._write_row_to_csv(p1, row[::-1], 5)
+    _StatsCollector._write_row_to_csv(p1, 0.125, 10)
+    assert open(p1).read() == str(d['row_txt'])
+    p2 = str(tmp_path / 'b.txt')
+    m = d['ld'][:4, :4]
+    _StatsCollector._write_array_to_stack(p2, m, 0)
+    _StatsCollector._write_array_to_stack(p2, m * 2, 1)
+    assert open(p2).read() == str(d['stack_txt'])
+
+
+def _collector(T, stats, genome=True):
+    import geonomics_amd as gnx
+    from geonomics_amd.sim.params import default_params_dict
+    from geonomics_amd.sim.stats import _StatsCollector
+    pd = default_params_dict(1, 1, stats=True)
+    pd['model']['T'] = T
+    pd['model']['stats'] = stats
+    if not genome:
+        del pd['comm']['species']['spp_0']['gen_arch']
+    return _StatsCollector('m', gnx.make_params_dict(pd, 'm'))
+
+
+def test_stats_collector_schedule_and_other_stats(tmp_path, monkeypatch):
+    from conftest import load_golden
+    from geonomics_amd.sim import stats as S
+    d = load_golden('g12_stats')
+    monkeypatch.chdir(tmp_path)
+    sc = _collector(4, {'Nt': {'calc': True, 'freq': 1},
+                        'mean_fit': {'calc': True, 'freq': 0},
+                        'het': {'calc': True, 'freq': 2, 'mean': False},
+                        'ld': {'calc': False, 'freq': 1}})
+    assert [*sc.stats['spp_0']] == ['Nt', 'mean_fit', 'het']
+    assert sc.stats['spp_0']['mean_fit']['freq'] == 3      # freq 0 -> first and last
+    Nts = [100, 101, 104, 99]
+    fits = [0.9912345, None, None, 1.0]
+    calls = []
+
+    class Spp:
+        name = 'spp_0'
+        Nt = []
+    spp = Spp()
+    monkeypatch.setitem(sc.calc_fn_dict, 'mean_fit', lambda s: fits[len(s.Nt) - 1])
+    monkeypatch.setitem(sc.calc_fn_dict, 'het',
+                        lambda s, mean=False: calls.append(len(s.Nt) - 1) or np.array([0.5, 0.25]))
+    for t in range(4):
+        spp.Nt.append(Nts[t])
+        sc._calc_stats({0: spp}, t, 0)
+    assert calls == [0, 2, 3]                  # every 2nd step + forced at T-1
+    base = tmp_path / 'GNX_mod-m' / 'it-0' / 'spp-spp_0'
+    other = (base / 'mod-m_it-0_spp-spp_0_OTHER_STATS.csv').read_text()
+    # mean_fit sampled at t=0 and t=3 only; Nt complete -> integer column
+    assert other == 't,Nt,mean_fit\n0,100,0.99123\n1,101,\n2,104,\n3,99,1.00000\n'
+    het = (base / 'mod-m_it-0_spp-spp_0_HET.csv').read_text()
+    assert het == 't,0,1\n0,0.5,0.25\n2,0.5,0.25\n'      # t=3 collected, not written (ref)
+    # the reference's float/int column rendering, from its own writer
+    sc2 = _collector(4, {'Nt': {'calc': True, 'freq': 1}, 'mean_fit': {'calc': True, 'freq': 1}})
+    sc2._set_filepaths(1)
+    sc2.stats['spp_0']['Nt']['vals'] = [100, np.nan, 104, 99]
+    sc2.stats['spp_0']['mean_fit']['vals'] = [0.9912345, np.nan, np.nan, 1.0]
+    sc2._write_other_stats()
+    path = sc2.stats['spp_0']['Nt']['filepath']
+    assert open(path).read() == str(d['other_float_txt'])
+    sc2.stats['spp_0'].pop('mean_fit')
+    sc2.stats['spp_0']['Nt']['vals'] = [100, 101, 104, 99]
+    sc2._write_other_stats()
+    assert open(path).read() == str(d['other_int_txt'])
+
+
+def test_stats_collector_species_without_genome():
+    sc = _collector(5, {'Nt': {'calc': True, 'freq': 1}, 'het': {'calc': True, 'freq': 1},
+                        'maf': {'calc': True, 'freq': 1}}, genome=False)
+    assert [*sc.stats['spp_0']] == ['Nt']

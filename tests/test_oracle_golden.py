@@ -387,3 +387,13 @@ def test_whole_model_envelopes_vs_reference():
     assert abs(m['br'][1] / m['br'][0] - 1) < 0.04, m
     assert abs(m['first'][1] / m['first'][0] - 1) < 0.15, m    # measured -3.6 %
     assert abs(m['main'][1] / m['main'][0] - 1) < 0.15, m      # measured +3.5 %
+
+
+# ---- g12: statistics (reference sim/stats.py) ---------------------------------------
+def test_stats_oracle_vs_reference():
+    d = load_golden("g12_stats")
+    g = d['g']
+    np.testing.assert_array_equal(O.stats_het(g), d['het'])
+    assert float(np.mean(O.stats_het(g))) == float(d['het_mean'])
+    np.testing.assert_array_equal(O.stats_maf(g), d['maf'])
+    np.testing.assert_allclose(O.stats_ld(g), d['ld'], rtol=1e-10, atol=1e-14, equal_nan=True)
