@@ -41,6 +41,10 @@ EXPORTS = [
     'gnx_tile_offspring', 'gnx_tile_get_requests', 'gnx_tile_serve_gametes',
     'gnx_tile_put_gametes', 'gnx_tile_finish_births', 'gnx_tile_die',
     'gnx_set_max_id', 'gnx_stats_locus_counts', 'gnx_stats_ld',
+    'gnx_tile_export_migrants_dev', 'gnx_tile_export_halo_dev', 'gnx_tile_staged_ptrs',
+    'gnx_tile_import_dev', 'gnx_tile_import_ghosts_dev', 'gnx_tile_pair_ptrs',
+    'gnx_tile_offspring_dev', 'gnx_tile_group_requests', 'gnx_tile_serve_gametes_dev',
+    'gnx_tile_put_gametes_dev', 'gnx_tile_bins_ptr',
 ]
 
 
@@ -410,6 +414,7 @@ class Device:
     # -- spatial tiling (geonomics_amd/parallel.py) ---------------------------------
     def tile_set(self, R, C, r, c):
         self._chk(self.lib.gnx_tile_set(self.h, int(R), int(C), int(r), int(c)))
+        self._n_tiles = int(R) * int(C)
 
     def _get_staged(self, n, with_z, with_geno):
         rec = np.zeros(n, dtype=IND_REC)
@@ -520,6 +525,70 @@ class Device:
 
     def set_max_id(self, v):
         self._chk(self.lib.gnx_set_max_id(self.h, C.c_int64(int(v))))
+
+    # -- device-resident transport: addresses are plain ints (device memory) -----------
+    def _tile_counts(self):
+        return np.zeros(max(getattr(self, '_n_tiles', 1), 1), np.int64)
+
+    def tile_export_migrants_dev(self):
+        """-> counts[R*C], (rec, z, geno) device addresses (0 when absent)"""
+        cnt = self._tile_counts()
+        self._chk(self.lib.gnx_tile_export_migrants_dev(self.h, _ptr(cnt, C.c_int64)))
+        return cnt, self._staged_ptrs()
+
+    def tile_export_halo_dev(self, width):
+        cnt = self._tile_counts()
+        self._chk(self.lib.gnx_tile_export_halo_dev(self.h, C.c_double(width),
+                                                    _ptr(cnt, C.c_int64)))
+        return cnt, self._staged_ptrs()[0]
+
+    def _staged_ptrs(self):
+        r, z, g = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._chk(self.lib.gnx_tile_staged_ptrs(self.h, C.byref(r), C.byref(z), C.byref(g)))
+        return r.value or 0, z.value or 0, g.value or 0
+
+    def tile_import_dev(self, n, rec, z=0, geno=0):
+        self._chk(self.lib.gnx_tile_import_dev(self.h, C.c_int64(int(n)), C.c_void_p(rec),
+                                               C.c_void_p(z or None), C.c_void_p(geno or None)))
+
+    def tile_import_ghosts_dev(self, n, rec):
+        self._chk(self.lib.gnx_tile_import_ghosts_dev(self.h, C.c_int64(int(n)),
+                                                      C.c_void_p(rec)))
+
+    def tile_pair_ptrs(self):
+        """-> P, focal ids address (int64[P]), n_births address (int32[P]) or 0"""
+        n, a, b = C.c_int64(), C.c_void_p(), C.c_void_p()
+        self._chk(self.lib.gnx_tile_pair_ptrs(self.h, C.byref(n), C.byref(a), C.byref(b)))
+        return n.value, a.value or 0, b.value or 0
+
+    def tile_offspring_dev(self, burn, id_base, goff_ptr):
+        n = C.c_int64()
+        self._chk(self.lib.gnx_tile_offspring_dev(self.h, int(bool(burn)),
+                                                  C.c_int64(int(id_base)),
+                                                  C.c_void_p(goff_ptr or None), C.byref(n)))
+        self._n_req = n.value
+        return n.value
+
+    def tile_group_requests(self):
+        cnt = self._tile_counts()
+        a = C.c_void_p()
+        self._chk(self.lib.gnx_tile_group_requests(self.h, _ptr(cnt, C.c_int64), C.byref(a)))
+        return cnt, a.value or 0
+
+    def tile_serve_gametes_dev(self, n, req_ptr):
+        a = C.c_void_p()
+        self._chk(self.lib.gnx_tile_serve_gametes_dev(self.h, C.c_int64(int(n)),
+                                                      C.c_void_p(req_ptr or None), C.byref(a)))
+        return a.value or 0
+
+    def tile_put_gametes_dev(self, n, data_ptr):
+        self._chk(self.lib.gnx_tile_put_gametes_dev(self.h, C.c_int64(int(n)),
+                                                    C.c_void_p(data_ptr or None)))
+
+    def tile_bins_ptr(self):
+        a, n = C.c_void_p(), C.c_int64()
+        self._chk(self.lib.gnx_tile_bins_ptr(self.h, C.byref(a), C.byref(n)))
+        return a.value, n.value
 
     # -- statistics ------------------------------------------------------------------
     def stats_locus_counts(self):

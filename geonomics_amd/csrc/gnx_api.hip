@@ -255,7 +255,8 @@ extern "C" void gnx_destroy(gnx_state* h) {
                   h->flag, h->flag2, h->scan, h->pairs, h->nbirths, h->boff, h->off_pair,
                   h->off_parent, h->off_keys, h->off_start, h->keep_in, h->inj_a, h->inj_b,
                   h->mid_x, h->mid_y, h->p_death, h->d_cell, h->dead_in, h->nmax_bits, h->red,
-                  h->tl_loci, h->tbits, h->lat.areas, h->lat.cprime, h->spl_N.c, h->spl_P.c, h->bin_partials, h->bins_P, h->nodes};
+                  h->tl_loci, h->tbits, h->lat.areas, h->lat.cprime, h->spl_N.c, h->spl_P.c, h->bin_partials, h->nodes,
+                  h->gp_rec, h->gp_z, h->gp_slots, h->tile_counts, h->rq_sorted, h->rq_k, h->gam_out, h->gam_slot, h->chk};
   for (void* p : ptrs) (void)hipFree(p);
   for (int t = 0; t < GNX_MAX_TRAITS; ++t) {
     (void)hipFree(h->traits[t].loci);
@@ -327,8 +328,7 @@ static int setup_lattice(gnx_state* h) {
   (void)hipFree(L.cprime);
   (void)hipFree(h->spl_N.c);
   (void)hipFree(h->spl_P.c);
-  (void)hipFree(h->bin_partials);
-  (void)hipFree(h->bins_P);
+  (void)hipFree(h->bin_partials);   // bins_P lives in the same allocation
   (void)hipFree(h->nodes);
   L.hww = ww / 2.0;
   L.Jx = lattice_nodes(c.W, ww);
@@ -356,8 +356,9 @@ static int setup_lattice(gnx_state* h) {
   GNXCHK(dalloc(&h->spl_P.c, 4 * nn));
   GNXCHK(dalloc(&h->nodes, nn));
   size_t nb = (size_t)L.nbx * L.nby;
-  GNXCHK(dalloc(&h->bin_partials, nb));
-  GNXCHK(dalloc(&h->bins_P, nb));
+  // one allocation, so that a tiled run all-reduces both fields in one call
+  GNXCHK(dalloc(&h->bin_partials, 2 * nb));
+  h->bins_P = h->bin_partials + nb;
   HIPCHK(hipMemcpy(L.areas, areas.data(), nn * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(L.cprime, cp.data(), (Jm + 1) * sizeof(double), hipMemcpyHostToDevice));
   h->spl_N.valid = h->spl_P.valid = false;

@@ -92,6 +92,7 @@ struct GnxKernelTimer {
   double bytes = 0;
 };
 
+#define GNX_MAX_TILES 4096
 struct gnx_state {
   gnx_config cfg{};
   gnx_species_params sp{};
@@ -174,6 +175,19 @@ struct gnx_state {
   bool st_has_geno = false;
   int64_t birth_first_slot = 0;
   int64_t n_req = 0;
+  // device-resident transport: the staged selection grouped by destination rank
+  gnx_ind_rec* gp_rec = nullptr;
+  float* gp_z = nullptr;
+  int64_t* gp_slots = nullptr;
+  int64_t gp_n = 0, gp_cap = 0;
+  int32_t* tile_counts = nullptr;    // [GNX_MAX_TILES] per-destination counts
+  void* rq_sorted = nullptr;         // gnx_gamete_req [n_req] grouped by owner rank
+  int32_t* rq_k = nullptr;           // child index of each grouped request
+  int64_t rq_cap = 0;
+  uint64_t* gam_out = nullptr;       // gametes cut for other tiles
+  int32_t* gam_slot = nullptr;
+  int64_t gam_cap = 0;
+  int64_t* chk = nullptr;            // [2] device-side record check: bad count, max id
 
   // pairing / mating scratch (capacity cap_inds)
   int32_t* mate = nullptr;

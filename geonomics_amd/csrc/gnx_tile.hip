@@ -579,3 +579,465 @@ extern "C" int gnx_set_max_id(gnx_state* h, int64_t max_id) {
   h->max_id = max_id;
   return 0;
 }
+
+// =====================================================================================
+// Device-resident transport.  RCCL moves GPU memory, so the payloads of a step
+// never visit the host: the staged selection is grouped by destination rank on
+// the device, the host layer wraps the device addresses returned here in
+// tensors and hands them to isend/irecv, and the receiving side imports
+// straight from the buffers RCCL filled.  Only the per-destination counts
+// (R*C integers) cross PCIe.
+// =====================================================================================
+__device__ __forceinline__ int tile_index(float v, int tw, int n) {
+  int c = (int)(v / (float)tw);
+  c = max(0, min(n - 1, c));
+  while (c + 1 < n && (float)((c + 1) * tw) <= v) ++c;     // exact: boundaries are integers
+  while (c > 0 && (float)(c * tw) > v) --c;
+  return c;
+}
+
+__global__ void k_dest_owner(int64_t n, const gnx_ind_rec* rec, int tw, int th, int R, int C,
+                             uint32_t* key, int32_t* idx) {
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  key[q] = (uint32_t)(tile_index(rec[q].y, th, R) * C + tile_index(rec[q].x, tw, C));
+  idx[q] = (int32_t)q;
+}
+
+__global__ void k_halo_count(int64_t n, const gnx_ind_rec* rec, int32_t* cnt) {
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q > n) return;
+  cnt[q] = q < n ? __popc(rec[q].nbr_mask & 0x1ef) : 0;
+}
+
+__global__ void k_halo_emit(int64_t n, const gnx_ind_rec* rec, const int32_t* off, int r, int c,
+                            int C, uint32_t* key, int32_t* idx) {
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  int m = rec[q].nbr_mask & 0x1ef, o = off[q];
+  while (m) {
+    int k = __ffs(m) - 1;
+    m &= m - 1;
+    key[o] = (uint32_t)((r + k / 3 - 1) * C + (c + k % 3 - 1));
+    idx[o] = (int32_t)q;
+    ++o;
+  }
+}
+
+__global__ void k_req_owner(int64_t n, const float* px, const float* py, int tw, int th, int R,
+                            int C, uint32_t* key, int32_t* idx) {
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  key[q] = (uint32_t)(tile_index(py[q], th, R) * C + tile_index(px[q], tw, C));
+  idx[q] = (int32_t)q;
+}
+
+__global__ void k_count_keys(int64_t m, const uint32_t* key, int32_t* counts) {
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= m) return;
+  // sorted keys: one atomic per run boundary would do, but m is a few 10^4
+  atomicAdd(&counts[key[q]], 1);
+}
+
+__global__ void k_gather_staged(int64_t m, const int32_t* idx, const gnx_ind_rec* rec,
+                                const float* z, const int64_t* slots, int n_traits,
+                                gnx_ind_rec* rec_o, float* z_o, int64_t* slots_o) {
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= m) return;
+  int i = idx[q];
+  rec_o[q] = rec[i];
+  slots_o[q] = slots[i];
+  if (z)
+    for (int t = 0; t < n_traits; ++t) z_o[q * n_traits + t] = z[(int64_t)i * n_traits + t];
+}
+
+static int n_tiles(const gnx_state* h) { return h->tile_R * h->tile_C; }
+
+// sort (key, idx)[m] by key (stable), count per destination -> host counts[R*C]
+static int group_by_key(gnx_state* h, int64_t m, int64_t* counts) {
+  const int nt = n_tiles(h);
+  if (!h->tile_counts) GNXCHK(dalloc_t(&h->tile_counts, (size_t)GNX_MAX_TILES));
+  HIPCHK(hipMemsetAsync(h->tile_counts, 0, nt * sizeof(int32_t), h->stream));
+  if (m > 0) {
+    int bits = 1;
+    while ((1 << bits) < nt) ++bits;
+    GNXCHK(gnx_prim_sort(h->sort_tmp, h->sort_tmp_bytes, h->key[0], h->key[1], h->perm[0],
+                         h->perm[1], (size_t)m, bits, h->stream));
+    hipLaunchKernelGGL(k_count_keys, dim3(gnx_grid(m, 256)), dim3(256), 0, h->stream, m,
+                       h->key[1], h->tile_counts);
+  }
+  std::vector<int32_t> c(nt);
+  GNXCHK(gnx_d2h(h, c.data(), h->tile_counts, nt * sizeof(int32_t)));
+  for (int p = 0; p < nt; ++p) counts[p] = c[p];
+  return 0;
+}
+
+static int grouped_gather(gnx_state* h, int64_t m, bool with_z) {
+  h->gp_n = m;
+  if (m == 0) return 0;
+  if (m > h->gp_cap) {
+    (void)hipFree(h->gp_rec);
+    (void)hipFree(h->gp_z);
+    (void)hipFree(h->gp_slots);
+    h->gp_cap = m + m / 4 + 1024;
+    GNXCHK(dalloc_t(&h->gp_rec, (size_t)h->gp_cap));
+    GNXCHK(dalloc_t(&h->gp_z, (size_t)h->gp_cap * std::max(h->cfg.n_traits, 1)));
+    GNXCHK(dalloc_t(&h->gp_slots, (size_t)h->gp_cap));
+  }
+  hipLaunchKernelGGL(k_gather_staged, dim3(gnx_grid(m, 256)), dim3(256), 0, h->stream, m,
+                     h->perm[1], h->st_rec, (with_z && h->cfg.n_traits) ? h->st_z : nullptr,
+                     h->st_slots, h->cfg.n_traits, h->gp_rec, h->gp_z, h->gp_slots);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int check_tiles(gnx_state* h, const char* who) {
+  if (n_tiles(h) > GNX_MAX_TILES) {
+    gnx_set_error("%s: more than %d tiles", who, GNX_MAX_TILES);
+    return 1;
+  }
+  return 0;
+}
+
+// migrants grouped by the rank that owns their new position; they leave this tile
+extern "C" int gnx_tile_export_migrants_dev(gnx_state* h, int64_t* counts /*[R*C]*/) {
+  GNXCHK(check_tiles(h, "gnx_tile_export_migrants_dev"));
+  for (int p = 0; p < n_tiles(h); ++p) counts[p] = 0;
+  h->gp_n = 0;
+  h->st_has_geno = false;
+  if (h->n_ghost) {
+    gnx_set_error("gnx_tile_export_migrants_dev: ghosts are resident");
+    return 1;
+  }
+  int64_t N = h->N, n = 0;
+  if (N == 0) return 0;
+  GnxSoA s = h->soa[h->cur];
+  hipLaunchKernelGGL(k_mark_out, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, s.x, s.y,
+                     tile_box(h), h->flag, h->dead_in);
+  GNXCHK(stage_selection(h, nullptr, true, false, &n));
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_dest_owner, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, n, h->st_rec,
+                     h->cfg.W / h->tile_C, h->cfg.H / h->tile_R, h->tile_R, h->tile_C, h->key[0],
+                     h->perm[0]);
+  GNXCHK(group_by_key(h, n, counts));
+  GNXCHK(grouped_gather(h, n, true));
+  if (has_rows(h)) {
+    if (n > h->st_geno_cap) {
+      (void)hipFree(h->st_geno);
+      h->st_geno_cap = n + n / 4 + 64;
+      GNXCHK(dalloc_t(&h->st_geno, (size_t)h->st_geno_cap * 2 * h->W64));
+    }
+    GNXCHK(gnx_l_gather_genomes(h, n, h->gp_slots, h->st_geno));
+    h->st_has_geno = true;
+  }
+  int64_t D = 0;
+  GNXCHK(gnx_l_mortality(h, h->dead_in, &D));
+  return 0;
+}
+
+// halo records, one copy per neighbour tile that needs them, grouped by rank
+extern "C" int gnx_tile_export_halo_dev(gnx_state* h, double width, int64_t* counts) {
+  GNXCHK(check_tiles(h, "gnx_tile_export_halo_dev"));
+  for (int p = 0; p < n_tiles(h); ++p) counts[p] = 0;
+  h->gp_n = 0;
+  h->st_has_geno = false;
+  int64_t N = h->N, n = 0;
+  if (N == 0) return 0;
+  GnxSoA s = h->soa[h->cur];
+  hipLaunchKernelGGL(k_mark_halo, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, s.x, s.y,
+                     s.ghost, tile_box(h), (float)width, h->flag, h->mate);
+  GNXCHK(stage_selection(h, h->mate, false, false, &n));
+  if (n == 0) return 0;
+  if (n + 1 > h->cfg.cap_inds) {
+    gnx_set_error("gnx_tile_export_halo_dev: halo larger than the capacity");
+    return 2;
+  }
+  hipLaunchKernelGGL(k_halo_count, dim3(gnx_grid(n + 1, 256)), dim3(256), 0, h->stream, n,
+                     h->st_rec, h->flag);
+  GNXCHK(gnx_prim_scan(h->scan_tmp, h->scan_tmp_bytes, h->flag, h->scan, (size_t)n + 1,
+                       h->stream));
+  int32_t m32 = 0;
+  GNXCHK(gnx_d2h(h, &m32, h->scan + n, sizeof(int32_t)));
+  const int64_t m = m32;
+  if (m > h->cfg.cap_inds) {
+    gnx_set_error("gnx_tile_export_halo_dev: %lld halo copies exceed the capacity %lld",
+                  (long long)m, (long long)h->cfg.cap_inds);
+    return 2;
+  }
+  hipLaunchKernelGGL(k_halo_emit, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, n, h->st_rec,
+                     h->scan, h->tile_r, h->tile_c, h->tile_C, h->key[0], h->perm[0]);
+  GNXCHK(group_by_key(h, m, counts));
+  GNXCHK(grouped_gather(h, m, false));
+  return 0;
+}
+
+// device addresses of the grouped selection: rec [n], z [n][n_traits] (migrants),
+// geno [n][2][W64] (migrants of a species with genomes); null when absent
+extern "C" int gnx_tile_staged_ptrs(gnx_state* h, void** rec, void** z, void** geno) {
+  HIPCHK(hipStreamSynchronize(h->stream));
+  *rec = h->gp_n ? (void*)h->gp_rec : nullptr;
+  *z = (h->gp_n && h->cfg.n_traits) ? (void*)h->gp_z : nullptr;
+  *geno = (h->gp_n && h->st_has_geno) ? (void*)h->st_geno : nullptr;
+  return 0;
+}
+
+__global__ void k_check_rec(int64_t n, const gnx_ind_rec* rec, int W, int H, int64_t* chk) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  gnx_ind_rec r = rec[k];
+  if (!(r.x >= 0 && r.x < W && r.y >= 0 && r.y < H)) atomicAdd((unsigned long long*)&chk[0], 1ull);
+  atomicMax((long long*)&chk[1], (long long)r.id);
+}
+
+static int import_device(gnx_state* h, int64_t n, const gnx_ind_rec* d_rec, const float* d_z,
+                         const uint64_t* d_g, int ghost) {
+  if (n == 0) return 0;
+  const gnx_config& c = h->cfg;
+  const bool rows = has_rows(h) && !ghost;
+  if (h->N + n > c.cap_inds || (rows && n > h->n_free)) {
+    gnx_set_error("capacity exceeded importing %lld individuals (N=%lld cap=%lld free rows %lld)",
+                  (long long)n, (long long)h->N, (long long)c.cap_inds, (long long)h->n_free);
+    return 2;
+  }
+  if (rows && !d_g) {
+    gnx_set_error("import: genomes are assigned on this tile but none were sent");
+    return 1;
+  }
+  if (!h->chk) GNXCHK(dalloc_t(&h->chk, 2));
+  int64_t init[2] = {0, h->max_id};
+  GNXCHK(gnx_h2d(h, h->chk, init, sizeof(init)));
+  hipLaunchKernelGGL(k_check_rec, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, n, d_rec, c.W,
+                     c.H, h->chk);
+  int64_t res[2];
+  GNXCHK(gnx_d2h(h, res, h->chk, sizeof(res)));
+  if (res[0]) {
+    gnx_set_error("import: %lld records are off the landscape", (long long)res[0]);
+    return 1;
+  }
+  GnxSoA s = h->soa[h->cur];
+  hipLaunchKernelGGL(k_unpack, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, h->N, n,
+                     c.cap_inds, s, d_rec, (d_z && c.n_traits) ? d_z : nullptr, c.n_traits,
+                     c.n_layers, h->rast, c.W, c.H, h->free_rows, h->n_free, rows ? 1 : 0, ghost);
+  if (rows) {
+    const int W16 = h->W64 / 2;
+    hipLaunchKernelGGL(k_scatter_genomes, dim3(gnx_grid(n * 2 * W16, 256, 256 * 32)), dim3(256), 0,
+                       h->stream, n, W16, (const u64x2*)d_g, (u64x2*)h->G, s.grow, h->N);
+    h->n_free -= n;
+  }
+  // the source buffers belong to the caller: finish reading them before returning
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->N += n;
+  if (ghost) h->n_ghost += n;
+  h->max_id = std::max(h->max_id, res[1]);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int gnx_tile_import_dev(gnx_state* h, int64_t n, const void* rec, const void* z,
+                                   const void* geno) {
+  return import_device(h, n, (const gnx_ind_rec*)rec, (const float*)z, (const uint64_t*)geno, 0);
+}
+
+extern "C" int gnx_tile_import_ghosts_dev(gnx_state* h, int64_t n, const void* rec) {
+  return import_device(h, n, (const gnx_ind_rec*)rec, nullptr, nullptr, 1);
+}
+
+// focal ids (ascending, int64 [P]) and birth counts (int32 [P]; null when every
+// pair has the fixed n_births) of the local pair list, on the device
+__global__ void k_one_focal(const int32_t* pairs, const int64_t* id, uint64_t* out) {
+  out[0] = (uint64_t)id[pairs[0]];
+}
+
+extern "C" int gnx_tile_pair_ptrs(gnx_state* h, int64_t* n_pairs, void** focal_ids,
+                                  void** n_births) {
+  const int64_t P = h->n_pairs;
+  *n_pairs = P;
+  *focal_ids = nullptr;
+  *n_births = nullptr;
+  if (P == 0) return 0;
+  if (P == 1)     // gnx_l_find_pairs sorts (and fills key64[1]) only when P > 1
+    hipLaunchKernelGGL(k_one_focal, dim3(1), dim3(1), 0, h->stream, h->pairs,
+                       h->soa[h->cur].id, h->key64[1]);
+  HIPCHK(hipStreamSynchronize(h->stream));
+  *focal_ids = h->key64[1];
+  if (!h->sp.n_births_fixed) *n_births = h->nbirths;
+  return 0;
+}
+
+extern "C" int gnx_tile_offspring_dev(gnx_state* h, int32_t burn, int64_t id_base,
+                                      const void* pair_goff_dev, int64_t* n_requests) {
+  *n_requests = 0;
+  int64_t P = h->n_pairs, B = 0;
+  h->birth_first_slot = h->N;
+  if (P > 0)
+    HIPCHK(hipMemcpyAsync(h->pair_goff, pair_goff_dev, P * sizeof(int64_t),
+                          hipMemcpyDeviceToDevice, h->stream));
+  GNXCHK(gnx_l_mate(h, burn != 0, false, 0, &B, id_base, true));
+  h->last_births = B;
+  if (B > 0 && !burn && has_rows(h)) {
+    HIPCHK(hipMemcpyAsync(h->h_pin, h->req_count, sizeof(int32_t), hipMemcpyDeviceToHost,
+                          h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *n_requests = *(int32_t*)h->h_pin;
+  }
+  h->n_req = *n_requests;
+  return 0;
+}
+
+// ---- gametes of ghost mates, device to device
+__global__ void k_pack_requests(int64_t n, const int32_t* idx, const int64_t* pid,
+                                const int32_t* key, const uint8_t* start, const int32_t* child_k,
+                                gnx_gamete_req* out, int32_t* k_out) {
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  int i = idx[q];
+  gnx_gamete_req r;
+  r.parent_id = pid[i];
+  r.key = key[i];
+  r.start = start[i];
+  out[q] = r;
+  k_out[q] = child_k[i];
+}
+
+// requests of this step grouped by the rank that owns the ghost mate
+extern "C" int gnx_tile_group_requests(gnx_state* h, int64_t* counts, void** req_dev) {
+  GNXCHK(check_tiles(h, "gnx_tile_group_requests"));
+  for (int p = 0; p < n_tiles(h); ++p) counts[p] = 0;
+  *req_dev = nullptr;
+  const int64_t n = h->n_req;
+  if (n == 0) return 0;
+  if (n > h->rq_cap) {
+    (void)hipFree(h->rq_sorted);
+    (void)hipFree(h->rq_k);
+    h->rq_cap = n + n / 4 + 1024;
+    gnx_gamete_req* p = nullptr;
+    GNXCHK(dalloc_t(&p, (size_t)h->rq_cap));
+    h->rq_sorted = p;
+    GNXCHK(dalloc_t(&h->rq_k, (size_t)h->rq_cap));
+  }
+  hipLaunchKernelGGL(k_req_owner, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, n, h->req_px,
+                     h->req_py, h->cfg.W / h->tile_C, h->cfg.H / h->tile_R, h->tile_R, h->tile_C,
+                     h->key[0], h->perm[0]);
+  GNXCHK(group_by_key(h, n, counts));
+  hipLaunchKernelGGL(k_pack_requests, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, n,
+                     h->perm[1], h->req_pid, h->req_key, h->req_start, h->req_k,
+                     (gnx_gamete_req*)h->rq_sorted, h->rq_k);
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipGetLastError());
+  *req_dev = h->rq_sorted;
+  return 0;
+}
+
+__global__ void k_lookup_req(int64_t n, const gnx_gamete_req* req, int64_t N, int n_paths,
+                             const uint64_t* sorted_ids, const int32_t* sorted_slots,
+                             int32_t* out_slot, int32_t* n_bad) {
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const gnx_gamete_req r = req[q];
+  uint64_t w = (uint64_t)r.parent_id;
+  int64_t lo = 0, hi = N;
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if (sorted_ids[mid] < w) lo = mid + 1; else hi = mid;
+  }
+  const bool ok = lo < N && sorted_ids[lo] == w && r.key >= 0 && r.key < n_paths &&
+                  (r.start == 0 || r.start == 1);
+  out_slot[q] = ok ? sorted_slots[lo] : -1;
+  if (!ok) atomicAdd(n_bad, 1);
+}
+
+__global__ void __launch_bounds__(256)
+k_make_gametes_req(int64_t n, int W16, const u64x2* __restrict__ G,
+                   const int32_t* __restrict__ grow, const int32_t* __restrict__ slot,
+                   const gnx_gamete_req* __restrict__ req, const u64x2* __restrict__ paths,
+                   u64x2* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (q >= n) return;
+  const int prow = grow[slot[q]];
+  const gnx_gamete_req r = req[q];
+  const u64 s = r.start ? ~0ull : 0ull;
+  const u64x2* h0 = G + ((int64_t)prow * 2 + 0) * W16;
+  const u64x2* h1 = G + ((int64_t)prow * 2 + 1) * W16;
+  const u64x2* pm = paths + (int64_t)r.key * W16;
+  for (int c = lane; c < W16; c += 64) {
+    u64x2 m = pm[c];
+    m.a ^= s;
+    m.b ^= s;
+    const u64x2 a = h0[c], b = h1[c];
+    u64x2 o;
+    o.a = (a.a & ~m.a) | (b.a & m.a);
+    o.b = (a.b & ~m.b) | (b.b & m.b);
+    out[q * W16 + c] = o;
+  }
+}
+
+// cut the requested gametes (requests in device memory, as received) into a
+// device buffer owned by the handle; *out_dev stays valid until the next call
+extern "C" int gnx_tile_serve_gametes_dev(gnx_state* h, int64_t n, const void* req_dev,
+                                          void** out_dev) {
+  *out_dev = nullptr;
+  if (n == 0) return 0;
+  if (!has_rows(h) || h->n_paths == 0) {
+    gnx_set_error("gnx_tile_serve_gametes_dev: genomes / paths not set");
+    return 1;
+  }
+  if (n > h->gam_cap) {
+    (void)hipFree(h->gam_out);
+    (void)hipFree(h->gam_slot);
+    h->gam_cap = n + n / 4 + 256;
+    GNXCHK(dalloc_t(&h->gam_out, (size_t)h->gam_cap * h->W64));
+    GNXCHK(dalloc_t(&h->gam_slot, (size_t)h->gam_cap + 1));
+  }
+  const int64_t N = h->N;
+  GnxSoA s = h->soa[h->cur];
+  hipLaunchKernelGGL(k_id_keys, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, s.id,
+                     h->key64[0], h->perm[0]);
+  GNXCHK(gnx_prim_sort64(h->sort64_tmp, h->sort64_tmp_bytes, h->key64[0], h->key64[1], h->perm[0],
+                         h->perm[1], (size_t)N, h->stream));
+  int32_t* d_bad = h->gam_slot + h->gam_cap;
+  HIPCHK(hipMemsetAsync(d_bad, 0, 4, h->stream));
+  hipLaunchKernelGGL(k_lookup_req, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, n,
+                     (const gnx_gamete_req*)req_dev, N, h->n_paths, h->key64[1], h->perm[1],
+                     h->gam_slot, d_bad);
+  int bad = 0;
+  GNXCHK(gnx_d2h(h, &bad, d_bad, 4));
+  if (bad) {
+    gnx_set_error("gnx_tile_serve_gametes_dev: %d requests name a parent that does not live on "
+                  "this tile, or a path / start out of range", bad);
+    return 1;
+  }
+  const int W16 = h->W64 / 2;
+  hipLaunchKernelGGL(k_make_gametes_req, dim3(gnx_grid(n * 64, 256)), dim3(256), 0, h->stream, n,
+                     W16, (const u64x2*)h->G, s.grow, h->gam_slot, (const gnx_gamete_req*)req_dev,
+                     (const u64x2*)h->paths, (u64x2*)h->gam_out);
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipGetLastError());
+  *out_dev = h->gam_out;
+  return 0;
+}
+
+// the gametes answering this tile's grouped requests, in the grouped order
+extern "C" int gnx_tile_put_gametes_dev(gnx_state* h, int64_t n, const void* data_dev) {
+  if (n == 0) return 0;
+  if (n != h->n_req) {
+    gnx_set_error("gnx_tile_put_gametes_dev: %lld gametes for %lld requests", (long long)n,
+                  (long long)h->n_req);
+    return 1;
+  }
+  const int W16 = h->W64 / 2;
+  hipLaunchKernelGGL(k_put_gametes, dim3(gnx_grid(n * W16, 256, 256 * 32)), dim3(256), 0, h->stream,
+                     n, W16, (const u64x2*)data_dev, (u64x2*)h->G, h->soa[h->cur].grow,
+                     h->birth_first_slot, h->rq_k);
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// both density bin fields, contiguous int32 [2][bin_count]: individuals, pair midpoints
+extern "C" int gnx_tile_bins_ptr(gnx_state* h, void** bins, int64_t* n_total) {
+  HIPCHK(hipStreamSynchronize(h->stream));
+  *bins = h->bin_partials;
+  *n_total = 2 * (int64_t)h->lat.nbx * h->lat.nby;
+  return 0;
+}

@@ -102,6 +102,9 @@ class DeviceShard:
     def advance_step(self):
         self.dev.step_index = self.dev.step_index + 1
 
+    def synchronize(self):
+        self.dev.synchronize()
+
 
 class Comm:
     """Thin layer over torch.distributed: variable-size all-to-all of byte
@@ -170,6 +173,52 @@ class Comm:
         self.dist.all_gather(out, buf)
         return [o[:k].cpu().numpy() for o, k in zip(out, ns)]
 
+    # -- device-resident transport (backend nccl = RCCL) -----------------------------
+    def count_matrix(self, counts):
+        """every rank's per-destination counts -> int64 [src][dst] on the host"""
+        import torch
+        c = torch.from_numpy(np.ascontiguousarray(counts, dtype=np.int64)).to(self.device)
+        out = [torch.zeros_like(c) for _ in range(self.world)]
+        self.dist.all_gather(out, c)
+        return torch.stack(out).cpu().numpy()
+
+    def exchange_dev(self, parts, mat):
+        """parts: [(uint8 device tensor grouped by destination rank, bytes per
+        element)]; mat[src][dst] = element counts.  One batch of isend/irecv for
+        all parts; returns the received tensors, grouped by source rank."""
+        import torch
+        me = self.rank
+        soff = np.concatenate([[0], np.cumsum(mat[me])])
+        roff = np.concatenate([[0], np.cumsum(mat[:, me])])
+        ops, recv = [], []
+        for t, unit in parts:
+            r = torch.empty(int(roff[-1]) * unit, dtype=torch.uint8, device=t.device)
+            recv.append(r)
+            for peer in range(self.world):
+                if peer == me:
+                    if mat[me, me]:
+                        r[roff[me] * unit:roff[me + 1] * unit] = \
+                            t[soff[me] * unit:soff[me + 1] * unit]
+                    continue
+                if mat[me, peer]:
+                    ops.append(self.dist.P2POp(
+                        self.dist.isend, t[soff[peer] * unit:soff[peer + 1] * unit], peer))
+                if mat[peer, me]:
+                    ops.append(self.dist.P2POp(
+                        self.dist.irecv, r[roff[peer] * unit:roff[peer + 1] * unit], peer))
+        if ops:
+            for req in self.dist.batch_isend_irecv(ops):
+                req.wait()
+        # the library reads these buffers from its own stream
+        torch.cuda.current_stream().synchronize()
+        return recv
+
+    def allreduce_dev_(self, t):
+        import torch
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        torch.cuda.current_stream().synchronize()
+        return t
+
     def alltoallv(self, send):
         """send: list (len world) of uint8 arrays -> list of received arrays."""
         if self.dist is None:
@@ -200,6 +249,23 @@ class Comm:
         return [r.cpu().numpy() if hasattr(r, 'cpu') else r for r in recv]
 
 
+class _DevMem:
+    """Device memory owned by libgnxhip.so, exposed through the CUDA array
+    interface so that torch can wrap it without a copy."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {'shape': (int(nbytes),), 'typestr': '|u1',
+                                         'data': (int(ptr), False), 'version': 2}
+
+
+def dev_bytes(ptr, nbytes):
+    """uint8 tensor over [ptr, ptr + nbytes) of the current device (no copy)."""
+    import torch
+    if not nbytes:
+        return torch.empty(0, dtype=torch.uint8, device='cuda')
+    return torch.as_tensor(_DevMem(ptr, nbytes), device='cuda')
+
+
 def _cat(chunks, dtype, shape_tail=()):
     chunks = [c for c in chunks if c is not None and c.size]
     if not chunks:
@@ -228,6 +294,17 @@ class TiledStepper:
         shard.tile_set(self.R, self.C, self.r, self.c)
         self.bytes_sent = 0
         import os
+        # payloads stay in GPU memory when the transport can move it (RCCL);
+        # gloo rehearsals stage through the host
+        want = os.environ.get('GNX_TILE_TRANSPORT')
+        self.dev_transport = (comm.world > 1 and hasattr(shard, 'dev') and
+                              getattr(comm, 'device', 'cpu') == 'cuda')
+        if want == 'host':
+            self.dev_transport = False
+        elif want == 'device':
+            assert hasattr(shard, 'dev') and getattr(comm, 'device', 'cpu') == 'cuda', (
+                'GNX_TILE_TRANSPORT=device needs the HIP shard and a device-capable backend')
+            self.dev_transport = comm.world > 1
         self.profile = bool(os.environ.get('GNX_TILE_PROFILE'))
         self.phase_s = {}
         self._t0 = 0.0
@@ -270,7 +347,93 @@ class TiledStepper:
                 _cat(zs, np.float32, (nt,)) if nt else None,
                 _cat(gs, np.uint64, (2, W64)) if geno is not None else None)
 
+    # -- device-resident exchanges (see csrc/gnx_tile.hip, "Device-resident transport")
+    def _migrate_dev(self):
+        dev = self.shard.dev
+        geno = self.shard.has_genomes
+        nt, W64 = self.shard.n_traits, self.shard.W64
+        counts, (p_rec, p_z, p_g) = dev.tile_export_migrants_dev()
+        assert counts[self.comm.rank] == 0
+        mat = self.comm.count_matrix(counts)
+        n = int(counts.sum())
+        parts = [(dev_bytes(p_rec, n * 32), 32)]
+        if nt:
+            parts.append((dev_bytes(p_z, n * 4 * nt), 4 * nt))
+        if geno:
+            parts.append((dev_bytes(p_g, n * 16 * W64), 16 * W64))
+        self.bytes_sent += sum(t.numel() for t, _ in parts)
+        got = self.comm.exchange_dev(parts, mat)
+        m = int(mat[:, self.comm.rank].sum())
+        if m:
+            dev.tile_import_dev(m, got[0].data_ptr(), got[1].data_ptr() if nt else 0,
+                                got[-1].data_ptr() if geno else 0)
+
+    def _halo_dev(self):
+        dev = self.shard.dev
+        counts, p_rec = dev.tile_export_halo_dev(2.0 * self.radius)
+        mat = self.comm.count_matrix(counts)
+        n = int(counts.sum())
+        self.bytes_sent += n * 32
+        got = self.comm.exchange_dev([(dev_bytes(p_rec, n * 32), 32)], mat)
+        m = int(mat[:, self.comm.rank].sum())
+        if m:
+            dev.tile_import_ghosts_dev(m, got[0].data_ptr())
+
+    def _offspring_dev(self, burn):
+        """pair order on the device: all-gather the focal ids, searchsorted, and
+        hand the offsets to the library without leaving GPU memory"""
+        import torch
+        dev = self.shard.dev
+        P, p_ids, p_nb = dev.tile_pair_ptrs()
+        mine = dev_bytes(p_ids, P * 8).view(torch.int64)
+        all_ids = self.comm.allgather_var(mine)
+        fixed = self.fixed_births
+        all_nb = None
+        if not fixed:
+            nb = dev_bytes(p_nb, P * 4).view(torch.int32).to(torch.int64) if P else mine
+            all_nb = self.comm.allgather_var(nb)
+        goff = torch.zeros(P, dtype=torch.int64, device=mine.device)
+        total_births = total_pairs = 0
+        for r in range(self.comm.world):
+            li = all_ids[r]
+            if fixed:
+                if P:
+                    goff += torch.searchsorted(li, mine) * int(fixed)
+                total_births += int(fixed) * li.numel()
+            else:
+                cum = torch.zeros(li.numel() + 1, dtype=torch.int64, device=mine.device)
+                if li.numel():
+                    cum[1:] = torch.cumsum(all_nb[r], 0)
+                if P:
+                    goff += cum[torch.searchsorted(li, mine)]
+                total_births += int(cum[-1].item())
+            total_pairs += li.numel()
+        torch.cuda.current_stream().synchronize()
+        n_req = dev.tile_offspring_dev(burn, self.max_id + 1, goff.data_ptr() if P else 0)
+        return n_req, total_births, total_pairs
+
+    def _gametes_dev(self):
+        dev = self.shard.dev
+        W64 = self.shard.W64
+        counts, p_req = dev.tile_group_requests()
+        mat = self.comm.count_matrix(counts)
+        n = int(counts.sum())
+        got = self.comm.exchange_dev([(dev_bytes(p_req, n * 16), 16)], mat)
+        m = int(mat[:, self.comm.rank].sum())
+        p_out = dev.tile_serve_gametes_dev(m, got[0].data_ptr() if m else 0)
+        self.bytes_sent += m * 8 * W64
+        back = self.comm.exchange_dev([(dev_bytes(p_out, m * 8 * W64), 8 * W64)], mat.T.copy())
+        if n:
+            dev.tile_put_gametes_dev(n, back[0].data_ptr())
+
+    def _bins_dev(self):
+        import torch
+        ptr, n = self.shard.dev.tile_bins_ptr()
+        self.comm.allreduce_dev_(dev_bytes(ptr, n * 4).view(torch.int32))
+
     def _migrate(self):
+        if self.dev_transport:
+            return self._migrate_dev()
         rec, z, geno = self.shard.export_migrants()
         dest = self.rank_of(rec['x'], rec['y']) if rec.size else np.zeros(0, np.int64)
         if self.comm.world == 1:
@@ -284,6 +447,8 @@ class TiledStepper:
     def _halo(self):
         if self.comm.world == 1:
             return
+        if self.dev_transport:
+            return self._halo_dev()
         rec = self.shard.export_halo(2.0 * self.radius)
         w = self.comm.world
         send = [np.zeros(0, np.uint8)] * w
@@ -403,21 +568,30 @@ class TiledStepper:
         self._tick('halo')
         P, B = sh.pairs(burn)
         self._tick('pairs')
-        goff, total_births, total_pairs = self._pair_offsets()
-        self._tick('pair order')
-        n_req = sh.offspring(burn, self.max_id + 1, goff)
+        if self.dev_transport:
+            n_req, total_births, total_pairs = self._offspring_dev(burn)
+        else:
+            goff, total_births, total_pairs = self._pair_offsets()
+            self._tick('pair order')
+            n_req = sh.offspring(burn, self.max_id + 1, goff)
         self.max_id += total_births
         sh.set_max_id(self.max_id)
         self._tick('offspring+crossover')
         if not burn and sh.has_genomes:
-            self._gametes(n_req)
+            if self.dev_transport:
+                self._gametes_dev()
+            else:
+                self._gametes(n_req)
         self._tick('gametes')
         sh.finish_births(burn)
         # one all-reduce for both density fields (individuals, pair midpoints)
-        b0, b1 = sh.get_bins(0), sh.get_bins(1)
-        both = self.comm.allreduce_sum(np.concatenate([b0, b1]))
-        sh.set_bins(0, both[:b0.size])
-        sh.set_bins(1, both[b0.size:])
+        if self.dev_transport:
+            self._bins_dev()
+        else:
+            b0, b1 = sh.get_bins(0), sh.get_bins(1)
+            both = self.comm.allreduce_sum(np.concatenate([b0, b1]))
+            sh.set_bins(0, both[:b0.size])
+            sh.set_bins(1, both[b0.size:])
         self._tick('phenotype + bins')
         sh.die(burn, with_selection, total_pairs > 0)
         sh.advance_step()

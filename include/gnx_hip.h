@@ -276,6 +276,39 @@ int gnx_tile_finish_births(gnx_state* h, int32_t burn);
 int gnx_tile_die(gnx_state* h, int32_t burn, int32_t with_selection, int32_t have_pairs);
 int gnx_set_max_id(gnx_state* h, int64_t max_id);
 
+/* Device-resident transport: RCCL moves GPU memory, so under the "nccl" backend
+ * the payloads never visit the host.  The *_dev entry points group the staged
+ * selection by destination rank ON the device, return per-rank counts
+ * (counts[R*C], the only thing that crosses PCIe) and DEVICE addresses that the
+ * host layer wraps in tensors for isend/irecv; imports read the buffers RCCL
+ * filled.  Returned addresses belong to the handle and stay valid until the
+ * next tile call; every call returns with the handle's stream idle.          */
+typedef struct {
+  int64_t parent_id;
+  int32_t key;      /* recombination path */
+  int32_t start;    /* starting homologue, 0 / 1 */
+} gnx_gamete_req;
+
+int gnx_tile_export_migrants_dev(gnx_state* h, int64_t* counts /*[R*C]*/);
+int gnx_tile_export_halo_dev(gnx_state* h, double width, int64_t* counts /*[R*C]*/);
+/* grouped selection: rec gnx_ind_rec[n], z float[n][n_traits], geno u64[n][2][W64] */
+int gnx_tile_staged_ptrs(gnx_state* h, void** rec, void** z, void** geno);
+int gnx_tile_import_dev(gnx_state* h, int64_t n, const void* rec, const void* z,
+                        const void* geno);
+int gnx_tile_import_ghosts_dev(gnx_state* h, int64_t n, const void* rec);
+/* focal ids int64[P] ascending; n_births int32[P] or NULL when fixed          */
+int gnx_tile_pair_ptrs(gnx_state* h, int64_t* n_pairs, void** focal_ids, void** n_births);
+int gnx_tile_offspring_dev(gnx_state* h, int32_t burn, int64_t id_base,
+                           const void* pair_goff_dev /*int64[P]*/, int64_t* n_requests);
+/* this step's gamete requests grouped by owner rank: gnx_gamete_req[n_requests] */
+int gnx_tile_group_requests(gnx_state* h, int64_t* counts /*[R*C]*/, void** req_dev);
+int gnx_tile_serve_gametes_dev(gnx_state* h, int64_t n, const void* req_dev,
+                               void** out_dev /*u64[n][W64]*/);
+/* answers in the grouped request order                                         */
+int gnx_tile_put_gametes_dev(gnx_state* h, int64_t n, const void* data_dev);
+/* int32 [2][bin_count]: individuals, pair midpoints (all-reduce in place)     */
+int gnx_tile_bins_ptr(gnx_state* h, void** bins, int64_t* n_total);
+
 /* ---- statistics (reference sim/stats.py:359-435) ---------- */
 /* per-locus count of 1-alleles over the 2N chromosomes and of heterozygous
  * individuals: het = cnt_het / N (_calc_het), f1 = cnt1 / 2N (_calc_maf)     */

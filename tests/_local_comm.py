@@ -1,0 +1,83 @@
+"""In-process stand-in for torch.distributed: the ranks are THREADS of one
+process, each with its own libgnxhip handle on the one GPU, and `LocalComm`
+moves device tensors between them with plain device copies.  It implements the
+interface TiledStepper uses for the device-resident transport (the one RCCL
+serves on a multi-GPU node), so the whole device path - grouping by
+destination, device-address imports, on-device pair order, gamete service -
+runs on a 1-GPU box; only the RCCL calls themselves are replaced."""
+import threading
+
+import numpy as np
+
+
+class Hub:
+    def __init__(self, world):
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+
+
+class LocalComm:
+    device = 'cuda'
+
+    def __init__(self, hub, rank):
+        self.hub, self.rank, self.world = hub, rank, hub.world
+        self.dist = None
+
+    def _swap(self, obj):
+        self.hub.slots[self.rank] = obj
+        self.hub.barrier.wait()
+        out = list(self.hub.slots)
+        self.hub.barrier.wait()
+        return out
+
+    def _done(self):
+        """nobody reuses a posted buffer before every rank has copied from it"""
+        import torch
+        torch.cuda.synchronize()
+        self.hub.barrier.wait()
+
+    # host-side small collectives
+    def allreduce_sum(self, a):
+        return np.sum(np.stack(self._swap(np.asarray(a).copy())), axis=0)
+
+    def allgather_i64(self, a):
+        return [x.copy() for x in self._swap(np.ascontiguousarray(a, dtype=np.int64))]
+
+    def count_matrix(self, counts):
+        return np.stack(self._swap(np.asarray(counts, dtype=np.int64).copy()))
+
+    # device-side
+    def allgather_var(self, t):
+        out = [x.clone() for x in self._swap(t)]
+        self._done()
+        return out
+
+    def allreduce_dev_(self, t):
+        import torch
+        posted = self._swap(t)
+        total = torch.stack([p.clone() for p in posted]).sum(0).to(t.dtype)
+        self._done()
+        t.copy_(total)
+        torch.cuda.synchronize()
+        return t
+
+    def exchange_dev(self, parts, mat):
+        import torch
+        me = self.rank
+        posted = self._swap([t for t, _ in parts])
+        recv = []
+        for k, (t, unit) in enumerate(parts):
+            chunks = []
+            for peer in range(self.world):
+                off = int(mat[peer, :me].sum())
+                n = int(mat[peer, me])
+                chunks.append(posted[peer][k][off * unit:(off + n) * unit])
+            recv.append(torch.cat(chunks).clone() if chunks else
+                        torch.empty(0, dtype=torch.uint8, device='cuda'))
+        self._done()
+        return recv
+
+    def alltoallv(self, send):
+        got = self._swap([np.asarray(s).copy() for s in send])
+        return [got[p][self.rank] for p in range(self.world)]

@@ -69,3 +69,120 @@ def test_single_tile_stepper_equals_gnx_step():
     ga = dev_a.download(nat.F_GENO)[np.argsort(dev_a.download(nat.F_ID))]
     gb = dev_b.download(nat.F_GENO)[np.argsort(dev_b.download(nat.F_ID))]
     np.testing.assert_array_equal(ga, gb)
+
+
+# ---- device-resident transport (what RCCL carries on a multi-GPU node) -----------------
+def _run_threads(world, steps, fixed):
+    """`world` tiles as threads of this process, LocalComm between them; the
+    same schedule as _tiling_worker.run; returns the gathered final population."""
+    import threading
+    import torch
+    from _local_comm import Hub, LocalComm
+    from _tiling_worker import config, make_device_shard
+    from geonomics_amd import _native as nat
+    from geonomics_amd.parallel import Comm, TiledStepper
+    import gnx_oracle as O
+    cfg = config()
+    hub = Hub(world)
+    res, errs = [None] * world, []
+
+    def body(rank):
+        try:
+            torch.cuda.set_device(0)
+            comm = LocalComm(hub, rank) if world > 1 else Comm(None)
+            shard, dev = make_device_shard(cfg, fixed)
+            stepper = TiledStepper(shard, comm, cfg['W'], cfg['H'], cfg['radius'], move=True,
+                                   max_id=cfg['N0'] - 1, fixed_births=1 if fixed else 0)
+            assert stepper.dev_transport == (world > 1)
+            shard.export_migrants()
+            hist = []
+            for t in range(steps):
+                burn = t < cfg['n_burn']
+                if t == cfg['n_burn']:
+                    n_tot = comm.allreduce_sum(np.array([shard.counts()[0]], np.int64))[0]
+                    ids = dev.download(nat.F_ID)
+                    all_ids = np.sort(np.concatenate(comm.allgather_i64(ids)))
+                    n_site = O.starting_mutation_counts(int(n_tot), np.full(cfg['L'], 0.5))
+                    G = O.starting_genomes(int(n_tot), cfg['L'], n_site, cfg['seed'])
+                    dev.upload_genomes(G[np.searchsorted(all_ids, ids)])
+                    shard.has_genomes = True
+                hist.append(stepper.step(burn, not burn))
+            res[rank] = dict(ids=dev.download(nat.F_ID), x=dev.download(nat.F_X),
+                             y=dev.download(nat.F_Y), age=dev.download(nat.F_AGE),
+                             z=dev.download(nat.F_Z)[0], geno=dev.download(nat.F_GENO),
+                             hist=hist, bytes_sent=stepper.bytes_sent)
+            dev.close()
+        except BaseException as e:       # noqa: BLE001 - re-raised in the main thread
+            errs.append(e)
+            hub.barrier.abort()
+
+    ths = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=300)
+    if errs:
+        raise errs[0]
+    ids = np.concatenate([r['ids'] for r in res])
+    order = np.argsort(ids)
+    out = {k: np.concatenate([r[k] for r in res])[order]
+           for k in ('ids', 'x', 'y', 'age', 'z', 'geno')}
+    out['hist'] = np.array(res[0]['hist'])
+    out['bytes_sent'] = sum(r['bytes_sent'] for r in res)
+    return out
+
+
+@pytest.mark.parametrize('world,fixed', [(2, True), (4, False)])
+def test_device_resident_transport_is_bit_identical(world, fixed):
+    steps = 8
+    one = _run_threads(1, steps, fixed)
+    many = _run_threads(world, steps, fixed)
+    assert one['hist'].tolist() == many['hist'].tolist()
+    for k in ('ids', 'x', 'y', 'age', 'z', 'geno'):
+        np.testing.assert_array_equal(one[k], many[k], err_msg=k)
+    assert many['bytes_sent'] > 0 and len(one['ids']) > 500
+
+
+def test_device_transport_equals_host_transport(tmp_path):
+    """the same tiled run through host-staged payloads (gloo processes)"""
+    host = launch('gloo', 'device', 2, 8, str(tmp_path / 'h.npz'), 'fixed')
+    devt = _run_threads(2, 8, True)
+    assert host['hist'].tolist() == devt['hist'].tolist()
+    for k in ('ids', 'x', 'y', 'age', 'z', 'geno'):
+        np.testing.assert_array_equal(host[k], devt[k], err_msg=k)
+
+
+def test_nccl_backend_world1_wraps_library_memory():
+    """RCCL refuses two ranks on one GPU, so the multi-rank RCCL path cannot run
+    on this box; a 1-rank group still checks what is specific to it: tensors
+    over library-owned device memory handed to RCCL collectives."""
+    import torch
+    import torch.distributed as dist
+    from _tiling_worker import config, make_device_shard
+    from geonomics_amd.parallel import Comm, dev_bytes
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        comm = Comm(dist)
+        assert comm.device == 'cuda'
+        sh, dev = make_device_shard(config())
+        dev.tile_set(1, 1, 0, 0)
+        dev.tile_pairs(True)
+        sh.finish_births(True)
+        ptr, n = dev.tile_bins_ptr()
+        before = np.concatenate([dev.get_bins(0), dev.get_bins(1)])
+        t = dev_bytes(ptr, n * 4).view(torch.int32)
+        np.testing.assert_array_equal(t.cpu().numpy(), before)
+        comm.allreduce_dev_(t)                       # sum over 1 rank: unchanged, in place
+        np.testing.assert_array_equal(np.concatenate([dev.get_bins(0), dev.get_bins(1)]), before)
+        assert before[:n // 2].sum() == dev.N
+        mat = comm.count_matrix(np.array([0]))
+        assert mat.tolist() == [[0]]
+        P, p_ids, _ = dev.tile_pair_ptrs()
+        ids = comm.allgather_var(dev_bytes(p_ids, P * 8).view(torch.int64))[0]
+        np.testing.assert_array_equal(ids.cpu().numpy(), dev.tile_pair_info()[0])
+        dev.close()
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Device-resident tile transport at the metric workload on ONE GPU: `world`
+tiles as threads of one process (tests/_local_comm.py instead of RCCL), phase
+times per step.  Kernels of the tiles share the GPU, so the compute phases are
+about `world` times slower than on a real node; the exchange phases show the
+host-side cost of the device path (grouping, counts, address hand-over)."""
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+os.environ['GNX_TILE_PROFILE'] = '1'
+import torch                                         # noqa: E402
+import bench                                         # noqa: E402
+from _local_comm import Hub, LocalComm               # noqa: E402
+from geonomics_amd.parallel import DeviceShard, TiledStepper, tile_grid   # noqa: E402
+
+world = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+workload = sys.argv[3] if len(sys.argv) > 3 else 'c4_metric'
+cfg = bench.WORKLOADS[workload]
+grid = tile_grid(world)
+hub = Hub(world)
+out = [None] * world
+
+
+def body(rank):
+    try:
+        torch.cuda.set_device(0)
+        dev, _, _ = bench.build_device(cfg, seed=42, device=0, grid=grid)
+        shard = DeviceShard(dev)
+        st = TiledStepper(shard, LocalComm(hub, rank), cfg['W'] * grid[1], cfg['H'] * grid[0],
+                          10.0, move=True, max_id=cfg['N'] * world - 1, grid=grid, fixed_births=1)
+        shard.export_migrants()
+        for _ in range(3):
+            st.step(True, False)
+        bench.setup_genomes(dev, cfg, 42 + rank)
+        shard.has_genomes = True
+        for _ in range(2):
+            st.step(False, True)
+        st.phase_s.clear()
+        st.bytes_sent = 0
+        dev.synchronize()
+        hub.barrier.wait()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            n = st.step(False, True)
+        dev.synchronize()
+        dt = time.perf_counter() - t0
+        out[rank] = (dt / steps * 1e3, {k: v / steps * 1e3 for k, v in st.phase_s.items()},
+                     st.bytes_sent / steps, n)
+        dev.close()
+    except BaseException:
+        hub.barrier.abort()
+        raise
+
+
+ths = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+[t.start() for t in ths]
+[t.join() for t in ths]
+for r, o in enumerate(out):
+    if o:
+        print('rank %d: %.2f ms/step, %.1f MB sent/step, (N, births, deaths) = %s' % (
+            r, o[0], o[2] / 1e6, o[3]))
+        print('   ' + '  '.join('%s %.2f' % kv for kv in o[1].items()))
