@@ -291,8 +291,11 @@ def main():
                                 args.workload, cfg['W'], cfg['H'], cfg['N'], cfg['L'],
                                 cfg['n_traits'], cfg['loci_per_trait'], cfg['move_surf'],
                                 cfg['n_paths']),
-                'parallelism': ('1 tile' if world == 1 else 'tiles %dx%d: migrants+halo+gametes p2p, '
-                                'pair lists / density bins collectives (RCCL)' % grid),
+                'parallelism': ('1 tile' if world == 1 else
+                                'tiles %dx%d: migrants+halo+gametes p2p, pair lists / density '
+                                'bins collectives (RCCL), payloads %s' % (
+                                    grid + ('device-resident' if stepper.dev_transport
+                                            else 'staged through the host',))),
                 'landscape': '%dx%d' % (cfg['W'] * grid[1], cfg['H'] * grid[0]),
                 'mean_N_global': ind_steps / args.steps, 'births_per_step_global': births / args.steps,
                 'setup_s': round(t_setup, 2),

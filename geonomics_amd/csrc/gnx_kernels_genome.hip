@@ -24,75 +24,41 @@ struct alignas(16) u64x2 {
 // One WAVEFRONT owns one gamete at a time (grid-stride over the 2B gametes):
 // parent row, child row, path key and start homologue are wave-uniform (scalar
 // registers, no per-chunk metadata chain), and the 64 lanes stream the
-// homologue in 16-byte chunks, 1 KiB per wave-instruction, four independent
+// homologue in 16-byte chunks, 1 KiB per wave-instruction, U independent
 // chunks in flight per lane.
 //
-// DENSE : masks are read from the bit-packed path table (any recombination map).
-// SPARSE: masks are rebuilt from the path's short breakpoint list (<= 24
-//         switches); a chunk whose mask is all 0 / all 1 loads only the one
-//         homologue it copies, which halves the read traffic when crossovers
-//         are rare (r = 1/L).
+// k_crossover        (dense) : masks are read from the bit-packed path table (any
+//                    recombination map): 2 homologues + 1 mask read per gamete.
+// k_crossover_stream (sparse): masks are rebuilt from the path's short breakpoint
+//                    list (<= 24 switches) and each chunk loads only the one
+//                    homologue it copies, which halves the read traffic when
+//                    crossovers are rare (r = 1/L).
 //
 // Epilogue (fused phenotype input): lane e re-derives the gamete's allele at
 // trait locus e from the just-read (L2-hot) parental chunk and stores it in the
 // compact table tbits[gamete][e], so phenotypes never gather from the fresh
 // 25-KB child rows.
 
-template <bool SPARSE>
-__device__ __forceinline__ u64x2 xo_mask(int c, u64 s, const u64x2* __restrict__ path_row,
-                                         const int32_t* __restrict__ bp, int nbp) {
-  u64x2 m;
-  if (SPARSE) {
-    // mask bits of loci [128c, 128c+128): parity of switches at or before l
-    const int lo = c * 128;
-    u64 par = 0;
-    m.a = 0;
-    m.b = 0;
-    for (int q = 0; q < nbp; ++q) {
-      const int bpl = bp[q];
-      if (bpl < lo) {
-        par ^= ~0ull;
-      } else if (bpl < lo + 64) {
-        m.a ^= ~0ull << (bpl - lo);
-        m.b ^= ~0ull;
-      } else if (bpl < lo + 128) {
-        m.b ^= ~0ull << (bpl - lo - 64);
-      }
-    }
-    m.a ^= par ^ s;
-    m.b ^= par ^ s;
-  } else {
-    m = path_row[c];
-    m.a ^= s;
-    m.b ^= s;
-  }
-  return m;
-}
-
-template <bool SPARSE>
-__device__ __forceinline__ u64x2 xo_chunk(int c, u64x2 m, const u64x2* __restrict__ h0,
-                                          const u64x2* __restrict__ h1) {
+__device__ __forceinline__ u64x2 xo_dense_chunk(int c, u64 s, const u64x2* __restrict__ path_row,
+                                                const u64x2* __restrict__ h0,
+                                                const u64x2* __restrict__ h1) {
+  u64x2 m = path_row[c];
+  m.a ^= s;
+  m.b ^= s;
+  const u64x2 a = h0[c];
+  const u64x2 b = h1[c];
   u64x2 out;
-  if (SPARSE && (m.a | m.b) == 0ull) {
-    out = h0[c];
-  } else if (SPARSE && (m.a & m.b) == ~0ull) {
-    out = h1[c];
-  } else {
-    const u64x2 a = h0[c];
-    const u64x2 b = h1[c];
-    out.a = (a.a & ~m.a) | (b.a & m.a);
-    out.b = (a.b & ~m.b) | (b.b & m.b);
-  }
+  out.a = (a.a & ~m.a) | (b.a & m.a);
+  out.b = (a.b & ~m.b) | (b.b & m.b);
   return out;
 }
 
-template <bool SPARSE, int XO_UNROLL>
+template <int XO_UNROLL>
 __global__ void __launch_bounds__(256)
 k_crossover(int64_t B, int W16, const u64x2* __restrict__ G, u64x2* __restrict__ Gout,
             const int32_t* __restrict__ grow, int64_t first_slot,
             const int32_t* __restrict__ off_parent, const int32_t* __restrict__ off_keys,
-            const uint8_t* __restrict__ off_start, const u64x2* __restrict__ paths,
-            const int32_t* __restrict__ bp_off, const int32_t* __restrict__ bp_loci, int n_tl,
+            const uint8_t* __restrict__ off_start, const u64x2* __restrict__ paths, int n_tl,
             const int32_t* __restrict__ tl_loci, uint8_t* __restrict__ tbits) {
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -110,18 +76,12 @@ k_crossover(int64_t B, int W16, const u64x2* __restrict__ G, u64x2* __restrict__
     const u64x2* h1 = G + ((int64_t)prow * 2 + 1) * W16;
     u64x2* dst = Gout + ((int64_t)crow * 2 + p) * W16;
     const u64x2* prow_mask = paths + (int64_t)key * W16;
-    int bp0 = 0, nbp = 0;
-    if (SPARSE) {
-      bp0 = __builtin_amdgcn_readfirstlane(bp_off[key]);
-      nbp = __builtin_amdgcn_readfirstlane(bp_off[key + 1]) - bp0;
-    }
-    const int32_t* bp = bp_loci + bp0;
     for (int c0 = lane; c0 < W16; c0 += 64 * XO_UNROLL) {
       u64x2 out[XO_UNROLL];
 #pragma unroll
       for (int u = 0; u < XO_UNROLL; ++u) {
         const int c = c0 + u * 64;
-        if (c < W16) out[u] = xo_chunk<SPARSE>(c, xo_mask<SPARSE>(c, s, prow_mask, bp, nbp), h0, h1);
+        if (c < W16) out[u] = xo_dense_chunk(c, s, prow_mask, h0, h1);
       }
 #pragma unroll
       for (int u = 0; u < XO_UNROLL; ++u) {
@@ -136,39 +96,144 @@ k_crossover(int64_t B, int W16, const u64x2* __restrict__ G, u64x2* __restrict__
     // alleles at the trait loci -> compact table for the phenotype kernel
     for (int e = lane; e < n_tl; e += 64) {
       const int l = tl_loci[e];
-      const int c = l >> 7;
-      const u64x2 v = xo_chunk<SPARSE>(c, xo_mask<SPARSE>(c, s, prow_mask, bp, nbp), h0, h1);
+      const u64x2 v = xo_dense_chunk(l >> 7, s, prow_mask, h0, h1);
       const int bit = l & 127;
       tbits[gam * n_tl + e] = (uint8_t)(((bit < 64 ? v.a >> bit : v.b >> (bit - 64))) & 1ull);
     }
   }
 }
 
-template <bool SPARSE, int U>
-static void xo_launch(gnx_state* h, int grid, int64_t first_slot, int64_t B) {
+// Sparse paths.  The streaming part is branch-free: every chunk issues exactly
+// one load, from the homologue selected by a v_cndmask on the address, U loads
+// back to back (classifying chunks with divergent copy-h0 / copy-h1 / blend
+// branches makes the compiler drain vmcnt before every arm that reuses a
+// destination register, i.e. one load in flight per lane); the few chunks that
+// contain a switch point (<= 24 per gamete) are patched in a rare wave-level
+// branch afterwards.  Breakpoints live in a VGPR (lane q holds switch q) and
+// are broadcast with v_readlane, so building the mask touches no memory.
+__device__ __forceinline__ u64x2 xo_mask_lanes(int c, u64 s, int mybp, int nbp) {
+  const int lo = c * 128;
+  u64 par = s;
+  u64x2 m;
+  m.a = 0;
+  m.b = 0;
+  for (int q = 0; q < nbp; ++q) {
+    const int bpl = __builtin_amdgcn_readlane(mybp, q);
+    const int d = bpl - lo;
+    par ^= d < 0 ? ~0ull : 0ull;
+    const u64 fa = ~0ull << (d & 63);
+    m.a ^= (d >= 0 && d < 64) ? fa : 0ull;
+    m.b ^= (d >= 0 && d < 64) ? ~0ull : ((d >= 64 && d < 128) ? fa : 0ull);
+  }
+  m.a ^= par;
+  m.b ^= par;
+  return m;
+}
+
+template <int XO_UNROLL>
+__global__ void __launch_bounds__(256)
+k_crossover_stream(int64_t B, int W16, const u64x2* __restrict__ G, u64x2* __restrict__ Gout,
+                   const int32_t* __restrict__ grow, int64_t first_slot,
+                   const int32_t* __restrict__ off_parent, const int32_t* __restrict__ off_keys,
+                   const uint8_t* __restrict__ off_start, const int32_t* __restrict__ bp_off,
+                   const int32_t* __restrict__ bp_loci, int n_tl,
+                   const int32_t* __restrict__ tl_loci, uint8_t* __restrict__ tbits) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t gam = wave0; gam < 2 * B; gam += n_waves) {
+    const int64_t k = gam >> 1;
+    const int p = (int)(gam & 1);
+    const int prow = __builtin_amdgcn_readfirstlane(grow[off_parent[2 * k + p]]);
+    if (prow < 0) continue;      // ghost parent (tiled run): gamete arrives from its tile
+    const int key = __builtin_amdgcn_readfirstlane(off_keys[2 * k + p]);
+    const u64 s = __builtin_amdgcn_readfirstlane((int)off_start[2 * k + p]) ? ~0ull : 0ull;
+    const int crow = __builtin_amdgcn_readfirstlane(grow[first_slot + k]);
+    const u64x2* h0 = G + ((int64_t)prow * 2 + 0) * W16;
+    const u64x2* h1 = G + ((int64_t)prow * 2 + 1) * W16;
+    u64x2* dst = Gout + ((int64_t)crow * 2 + p) * W16;
+    const int bp0 = __builtin_amdgcn_readfirstlane(bp_off[key]);
+    const int nbp = __builtin_amdgcn_readfirstlane(bp_off[key + 1]) - bp0;
+    const int mybp = lane < nbp ? bp_loci[bp0 + lane] : 0x7fffffff;
+    for (int c0 = lane; c0 < W16; c0 += 64 * XO_UNROLL) {
+      u64x2 m[XO_UNROLL], v[XO_UNROLL];
+      bool mixed = false;
+#pragma unroll
+      for (int u = 0; u < XO_UNROLL; ++u) {
+        const int c = min(c0 + u * 64, W16 - 1);     // tail lanes re-read the last chunk
+        m[u] = xo_mask_lanes(c, s, mybp, nbp);
+        const bool one = (m[u].a & m[u].b) == ~0ull;
+        mixed |= !one && (m[u].a | m[u].b) != 0ull;
+        v[u] = (one ? h1 : h0)[c];
+      }
+      if (__builtin_expect(mixed, 0)) {
+#pragma unroll
+        for (int u = 0; u < XO_UNROLL; ++u) {
+          const int c = min(c0 + u * 64, W16 - 1);
+          if ((m[u].a & m[u].b) != ~0ull && (m[u].a | m[u].b) != 0ull) {
+            const u64x2 b = h1[c];
+            v[u].a = (v[u].a & ~m[u].a) | (b.a & m[u].a);
+            v[u].b = (v[u].b & ~m[u].b) | (b.b & m[u].b);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < XO_UNROLL; ++u) {
+        const int c = c0 + u * 64;
+        if (c < W16) {
+          __builtin_nontemporal_store(v[u].a, &dst[c].a);
+          __builtin_nontemporal_store(v[u].b, &dst[c].b);
+        }
+      }
+    }
+    for (int e = lane; e < n_tl; e += 64) {
+      const int l = tl_loci[e];
+      const int c = l >> 7;
+      const u64x2 mm = xo_mask_lanes(c, s, mybp, nbp);
+      const int bit = l & 127;
+      // bit of the mask at l selects the homologue the allele comes from
+      const u64 sel = ((bit < 64 ? mm.a >> bit : mm.b >> (bit - 64))) & 1ull;
+      const u64x2 w = (sel ? h1 : h0)[c];
+      tbits[gam * n_tl + e] = (uint8_t)(((bit < 64 ? w.a >> bit : w.b >> (bit - 64))) & 1ull);
+    }
+  }
+}
+
+template <int U>
+static void xo_launch_stream(gnx_state* h, int grid, int64_t first_slot, int64_t B) {
   const int W16 = h->W64 / 2;
   GnxSoA s = h->soa[h->cur];
-  hipLaunchKernelGGL((k_crossover<SPARSE, U>), dim3(grid), dim3(256), 0, h->stream, B, W16,
+  hipLaunchKernelGGL((k_crossover_stream<U>), dim3(grid), dim3(256), 0, h->stream, B, W16,
                      (const u64x2*)h->G, (u64x2*)h->G, s.grow, first_slot, h->off_parent,
-                     h->off_keys, h->off_start, (const u64x2*)h->paths, h->bp_off, h->bp_loci,
-                     h->n_tl, h->tl_loci, h->tbits);
+                     h->off_keys, h->off_start, h->bp_off, h->bp_loci, h->n_tl, h->tl_loci,
+                     h->tbits);
+}
+
+template <int U>
+static void xo_launch_dense(gnx_state* h, int grid, int64_t first_slot, int64_t B) {
+  const int W16 = h->W64 / 2;
+  GnxSoA s = h->soa[h->cur];
+  hipLaunchKernelGGL((k_crossover<U>), dim3(grid), dim3(256), 0, h->stream, B, W16,
+                     (const u64x2*)h->G, (u64x2*)h->G, s.grow, first_slot, h->off_parent,
+                     h->off_keys, h->off_start, (const u64x2*)h->paths, h->n_tl, h->tl_loci,
+                     h->tbits);
 }
 
 int gnx_l_crossover(gnx_state* h, int64_t first_slot, int64_t B) {
   if (B == 0) return 0;
   // one wave per gamete, 4 waves per block; cap the grid and stride beyond
   static const int blocks_per_cu = getenv("GNX_XO_BPC") ? atoi(getenv("GNX_XO_BPC")) : 32;
-  static const int unroll = getenv("GNX_XO_UNROLL") ? atoi(getenv("GNX_XO_UNROLL")) : 4;
+  static const int unroll = getenv("GNX_XO_UNROLL") ? atoi(getenv("GNX_XO_UNROLL")) : 0;
   int grid = gnx_grid(2 * B, 4, 256 * blocks_per_cu);
   gnx_time_begin(h);
-  if (h->sparse_paths) {
-    if (unroll == 2) xo_launch<true, 2>(h, grid, first_slot, B);
-    else if (unroll == 8) xo_launch<true, 8>(h, grid, first_slot, B);
-    else xo_launch<true, 4>(h, grid, first_slot, B);
+  if (h->sparse_paths) {          // measured: 8 chunks in flight per lane is best (A/B in profiles/)
+    if (unroll == 2) xo_launch_stream<2>(h, grid, first_slot, B);
+    else if (unroll == 4) xo_launch_stream<4>(h, grid, first_slot, B);
+    else xo_launch_stream<8>(h, grid, first_slot, B);
   } else {
-    if (unroll == 2) xo_launch<false, 2>(h, grid, first_slot, B);
-    else if (unroll == 8) xo_launch<false, 8>(h, grid, first_slot, B);
-    else xo_launch<false, 4>(h, grid, first_slot, B);
+    if (unroll == 2) xo_launch_dense<2>(h, grid, first_slot, B);
+    else if (unroll == 8) xo_launch_dense<8>(h, grid, first_slot, B);
+    else xo_launch_dense<4>(h, grid, first_slot, B);
   }
   // algorithmic bytes per birth.  Dense masks: 4 parental
   // homologues + 2 masks read, 2 homologues written = 8 * L/8 = L bytes.

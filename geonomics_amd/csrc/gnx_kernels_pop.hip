@@ -387,165 +387,129 @@ int gnx_l_sort_by_cell(gnx_state* h) {
 // Species._get_mating_pairs / _KDTree._get_mating_pairs (structs/species.py:
 // 2157-2215; utils/spatial.py:191-245) on a cell list instead of a KD-tree.
 //
-// One wavefront owns 64 consecutive cell-sorted focal individuals.  For every
-// cell row that any of its lanes neighbours, the candidates of cells
-// [min cx - 1, max cx + 1] form ONE contiguous range of the sorted arrays; the
-// wave loads it 64 candidates at a time (coalesced) and broadcasts each
-// candidate with v_readlane, so every lane tests the same candidate against its
-// own focal individual with no divergence.  Cells are >= mating_radius wide, so
+// Who needs a mate at all?  A pair (i, mate_i) survives only if i's own
+// Bernoulli(b) draw keeps it (structs/species.py:2210-2214) and i passes the
+// focal side of the sex / reproductive-age filters (ops/mating.py:41-104);
+// the reciprocity test of the de-duplication only looks at mates of kept
+// individuals.  The draw is keyed by i's id, not by the mate, so the kernel
+// evaluates it FIRST and the search runs for the kept ~b*N individuals only
+// (b = 0.2 -> five times less work); everybody else gets mate = -1.  The
+// compaction is block-local (each block lists the kept ones among its 1024
+// consecutive individuals in LDS, in order): no global atomics, no extra pass.
+//
+// k_find_mates: one lane per listed focal individual; the lane walks its own
+// 3x3 block of hash cells: per cell row ONE contiguous range of the cell-sorted
+// candidate records [cell_start(ry, cx-1), cell_start(ry, cx+2)), one 16-byte
+// record {x, y, tag, id_lo} per load.  The list keeps the cell-sorted order
+// within a wave, so the lanes of a wave sit in the same or adjacent cells and
+// their loads hit the same few cache lines.  Cells are >= mating_radius wide, so
 // every neighbour within the radius lies in the scanned ranges; extra
 // candidates simply fail the distance test (dx*dx + dy*dy <= r*r in f32, the
-// same expression the oracle evaluates).
+// same expression the oracle evaluates).  (A wave-broadcast variant - the wave
+// loads the union of its lanes' ranges and v_readlane's each candidate - was
+// 5x slower: 3.4x more vector instructions, PMC SQ_INSTS_VALU, round-1 profiles.)
 //
 // Mate choice is independent of candidate order: uniform = smallest
 // pair_hash(focal id, candidate id); nearest = smallest d2; inverse-distance =
-// smallest -ln(u)/(r-d).  Ties break on the smaller id.
+// smallest -ln(u)/(r-d).  Ties break on the smaller id; selection is a
+// branch-free composite-key minimum.
+#define FM_PER_BLOCK 1024      // individuals per 256-thread block (~b * 1024 are searched)
+#define FM_LANES 4             // lanes that share one focal individual's candidate ranges
+
+struct FocalP {
+  int64_t N;
+  const uint8_t* keep_in;
+  float b;
+  int sexed, ra_f;
+  long long step;
+  unsigned long long seed;
+};
+
 template <int MODE>
 __global__ void __launch_bounds__(256)
-k_find_mates_wave(int64_t N, const float* __restrict__ x, const float* __restrict__ y,
-             const int64_t* __restrict__ id, const uint32_t* __restrict__ tag,
+k_find_mates(FocalP fp, GnxSoA s, const uint4* __restrict__ cand,
              const uint32_t* __restrict__ key, const int32_t* __restrict__ cell_start, int ncx,
              int ncy, float r, float r2, int32_t* __restrict__ mate) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t i = wave * 64 + lane;
-  const bool act = i < N;
-  float fx = 0.f, fy = 0.f;
-  unsigned int ftag = 0;
-  int cx = 0, cy = 0;
-  if (act) {
-    fx = x[i];
-    fy = y[i];
-    ftag = tag[i] * 0x9E3779B1u;
-    int k = (int)key[i];
-    cy = k / ncx;
-    cx = k - cy * ncx;
-  }
-  int cymin = __builtin_amdgcn_readfirstlane(wave_min_i(act ? cy : 0x7fffffff));
-  int cymax = __builtin_amdgcn_readfirstlane(wave_max_i(act ? cy : -0x7fffffff));
-  if (cymin > cymax) return;     // wave has no active lane (uniform)
-
-  // Branch-free selection: every candidate gets the 64-bit composite
-  // (key32 << 32 | low 32 bits of its id); the smallest composite wins, so ties
-  // on the key fall to the smaller id.  key32 = pair key (uniform), or the bit
-  // pattern of the non-negative float d2 / -ln(u)/(r-d) (nearest / inverse),
-  // which orders like the float.  Rejected candidates get ~0.
-  unsigned long long best = ~0ull;
-  int best_slot = -1;
-
-  const int ry0 = max(cymin - 1, 0), ry1 = min(cymax + 1, ncy - 1);
-  for (int ry = ry0; ry <= ry1; ++ry) {
-    const bool near = act && (cy - ry <= 1) && (ry - cy <= 1);
-    int lo = __builtin_amdgcn_readfirstlane(wave_min_i(near ? cx - 1 : 0x7fffffff));
-    int hi = __builtin_amdgcn_readfirstlane(wave_max_i(near ? cx + 1 : -0x7fffffff));
-    if (lo > hi) continue;
-    lo = max(lo, 0);
-    hi = min(hi, ncx - 1);
-    const int s = cell_start[ry * ncx + lo];
-    const int e = cell_start[ry * ncx + hi + 1];
-    // lanes that do not neighbour this row can accept nothing: r2 < 0
-    const float r2l = near ? r2 : -1.0f;
-    for (int base = s; base < e; base += 64) {
-      const int j = base + lane;
-      const bool v = j < e;
-      const float ox_l = v ? x[j] : 0.f;
-      const float oy_l = v ? y[j] : 0.f;
-      const unsigned int ot_l = v ? tag[j] : 0u;
-      const unsigned int oi_l = v ? (unsigned int)id[j] : 0u;
-      const int cnt = min(64, e - base);
-#define FM_BODY(T)                                                                        \
-  {                                                                                       \
-    const int tt = (T);                                                                   \
-    const float ox = readlane_f(ox_l, tt);                                                \
-    const float oy = readlane_f(oy_l, tt);                                                \
-    const unsigned int ot = (unsigned int)__builtin_amdgcn_readlane((int)ot_l, tt);       \
-    const unsigned int oi = (unsigned int)__builtin_amdgcn_readlane((int)oi_l, tt);       \
-    const int oj = base + tt;                                                             \
-    const float dx = ox - fx, dy = oy - fy;                                               \
-    const float d2 = dx * dx + dy * dy;                                                   \
-    bool ok = (d2 <= r2l) & ((int64_t)oj != i);                                           \
-    unsigned int k32;                                                                     \
-    if (MODE == GNX_MATE_UNIFORM) {                                                       \
-      k32 = gnx_pair_key(ftag, ot);                                                       \
-    } else if (MODE == GNX_MATE_NEAREST) {                                                \
-      k32 = __float_as_uint(d2);                                                          \
-    } else {                                                                              \
-      ok = ok & (d2 > 0.f);                                                               \
-      const float kf = -logf(gnx_u01(gnx_pair_key(ftag, ot))) / (r - sqrtf(d2));          \
-      k32 = __float_as_uint(kf);                                                          \
-    }                                                                                     \
-    const unsigned long long comp =                                                       \
-        ok ? (((unsigned long long)k32 << 32) | (unsigned long long)oi) : ~0ull;          \
-    const bool better = comp < best;                                                      \
-    best = better ? comp : best;                                                          \
-    best_slot = better ? oj : best_slot;                                                  \
-  }
-      int t = 0;
-      for (; t + 4 <= cnt; t += 4) {
-        FM_BODY(t)
-        FM_BODY(t + 1)
-        FM_BODY(t + 2)
-        FM_BODY(t + 3)
-      }
-      for (; t < cnt; ++t) FM_BODY(t)
-#undef FM_BODY
-    }
-  }
-  if (act) mate[i] = best_slot;
-}
-
-// Production variant.  One lane per focal individual; the lane walks its own
-// 3x3 block of hash cells: per cell row ONE contiguous range of the cell-sorted
-// candidate records [cell_start(ry, cx-1), cell_start(ry, cx+2)), one 16-byte
-// record {x, y, tag, id_lo} per load.  Lanes of a wave sit in the same or
-// adjacent cells, so their loads hit the same few cache lines.  Compared with
-// the wave-broadcast variant above (kept for A/B, GNX_FIND_MATES=wave) a lane
-// only evaluates ITS 9 cells (~250 candidates at the metric density) instead of
-// the union of the wave's (~480) and needs no v_readlane per candidate:
-// 3.4x fewer vector instructions, measured (PMC SQ_INSTS_VALU) and timed in
-// profiles/.  Selection is the same branch-free composite-key minimum.
-template <int MODE>
-__global__ void __launch_bounds__(256)
-k_find_mates(int64_t N, const uint4* __restrict__ cand, const uint32_t* __restrict__ key,
-             const int32_t* __restrict__ cell_start, int ncx, int ncy, float r, float r2,
-             int32_t* __restrict__ mate) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  const uint4 me = cand[i];
-  const float fx = __uint_as_float(me.x), fy = __uint_as_float(me.y);
-  const unsigned int ftag = me.z * 0x9E3779B1u;
-  const int k = (int)key[i];
-  const int cy = k / ncx;
-  const int cx = k - cy * ncx;
-  const int lo = max(cx - 1, 0), hi = min(cx + 1, ncx - 1);
-  unsigned long long best = ~0ull;
-  int best_slot = -1;
-  for (int ry = max(cy - 1, 0); ry <= min(cy + 1, ncy - 1); ++ry) {
-    const int s = cell_start[ry * ncx + lo];
-    const int e = cell_start[ry * ncx + hi + 1];
-    for (int j = s; j < e; ++j) {
-      const uint4 c = cand[j];
-      const float dx = __uint_as_float(c.x) - fx, dy = __uint_as_float(c.y) - fy;
-      const float d2 = dx * dx + dy * dy;
-      bool ok = (d2 <= r2) & (j != (int)i);
-      unsigned int k32;
-      if (MODE == GNX_MATE_UNIFORM) {
-        k32 = gnx_pair_key(ftag, c.z);
-      } else if (MODE == GNX_MATE_NEAREST) {
-        k32 = __float_as_uint(d2);
+  __shared__ int32_t list[FM_PER_BLOCK];
+  __shared__ int32_t wcnt[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t base = (int64_t)blockIdx.x * FM_PER_BLOCK;
+  // phase 1: block-local, order-preserving list of the individuals that need a mate
+  int n_list = 0;
+  for (int round = 0; round < FM_PER_BLOCK / 256; ++round) {
+    const int64_t i = base + round * 256 + tid;
+    bool ok = false;
+    if (i < fp.N) {
+      if (fp.keep_in) {
+        ok = fp.keep_in[i] != 0;
       } else {
-        ok = ok & (d2 > 0.f);
-        const float kf = -logf(gnx_u01(gnx_pair_key(ftag, c.z))) / (r - sqrtf(d2));
-        k32 = __float_as_uint(kf);
+        uint4 rr = gnx_rand4(fp.seed, (unsigned long long)s.id[i], fp.step, OP_PAIR_KEEP, 0);
+        ok = gnx_u01(rr.x) < fp.b;
       }
-      const unsigned long long comp =
-          ok ? (((unsigned long long)k32 << 32) | (unsigned long long)c.w) : ~0ull;
-      const bool better = comp < best;
-      best = better ? comp : best;
-      best_slot = better ? j : best_slot;
+      if (fp.sexed) ok = ok && s.sex[i] == 0;
+      ok = ok && s.age[i] >= fp.ra_f;
+      if (!ok) mate[i] = -1;
     }
+    const unsigned long long bal = __ballot(ok);
+    if (lane == 0) wcnt[wave] = __popcll(bal);
+    __syncthreads();
+    int off = n_list;
+    for (int w = 0; w < wave; ++w) off += wcnt[w];
+    if (ok) list[off + __popcll(bal & ((1ull << lane) - 1ull))] = (int32_t)i;
+    n_list += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    __syncthreads();
   }
-  mate[i] = best_slot;
+  // phase 2: FM_LANES adjacent lanes per listed focal individual; they stride the
+  // candidate ranges together (64 contiguous bytes per group and step) and
+  // combine their minima with two DPP shuffles
+  for (int t = tid; t < n_list * FM_LANES; t += 256) {
+    const int i = list[t / FM_LANES];
+    const int sub = t % FM_LANES;
+    const uint4 me = cand[i];
+    const float fx = __uint_as_float(me.x), fy = __uint_as_float(me.y);
+    const unsigned int ftag = me.z * 0x9E3779B1u;
+    const int k = (int)key[i];
+    const int cy = k / ncx;
+    const int cx = k - cy * ncx;
+    const int lo = max(cx - 1, 0), hi = min(cx + 1, ncx - 1);
+    unsigned long long best = ~0ull;
+    int best_slot = -1;
+    for (int ry = max(cy - 1, 0); ry <= min(cy + 1, ncy - 1); ++ry) {
+      const int st = cell_start[ry * ncx + lo];
+      const int e = cell_start[ry * ncx + hi + 1];
+      for (int j = st + sub; j < e; j += FM_LANES) {
+        const uint4 c = cand[j];
+        const float dx = __uint_as_float(c.x) - fx, dy = __uint_as_float(c.y) - fy;
+        const float d2 = dx * dx + dy * dy;
+        bool ok = (d2 <= r2) & (j != i);
+        unsigned int k32;
+        if (MODE == GNX_MATE_UNIFORM) {
+          k32 = gnx_pair_key(ftag, c.z);
+        } else if (MODE == GNX_MATE_NEAREST) {
+          k32 = __float_as_uint(d2);
+        } else {
+          ok = ok & (d2 > 0.f);
+          const float kf = -logf(gnx_u01(gnx_pair_key(ftag, c.z))) / (r - sqrtf(d2));
+          k32 = __float_as_uint(kf);
+        }
+        const unsigned long long comp =
+            ok ? (((unsigned long long)k32 << 32) | (unsigned long long)c.w) : ~0ull;
+        const bool better = comp < best;
+        best = better ? comp : best;
+        best_slot = better ? j : best_slot;
+      }
+    }
+#pragma unroll
+    for (int m = 1; m < FM_LANES; m <<= 1) {
+      const unsigned long long ob = __shfl_xor(best, m);
+      const int os = __shfl_xor(best_slot, m);
+      // composite keys of distinct candidates differ unless both are "none"
+      const bool take = ob < best;
+      best = take ? ob : best;
+      best_slot = take ? os : best_slot;
+    }
+    if (sub == 0) mate[i] = best_slot;
+  }
 }
 
 // Bernoulli(b) thinning (structs/species.py:2210-2214), sex filter
@@ -658,31 +622,18 @@ int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out) 
   } else {
     float r = (float)sp.mating_radius;
     float r2 = r * r;
-    dim3 grid(gnx_grid(N, 256)), blk(256);
-    static const bool use_wave = getenv("GNX_FIND_MATES") &&
-                                 std::string(getenv("GNX_FIND_MATES")) == "wave";
-    if (use_wave) {
-      if (sp.mate_mode == GNX_MATE_NEAREST)
-        hipLaunchKernelGGL(k_find_mates_wave<GNX_MATE_NEAREST>, grid, blk, 0, h->stream, N, s.x, s.y,
-                           s.id, h->tag, h->key[1], h->cell_start, h->ncx, h->ncy, r, r2, h->mate);
-      else if (sp.mate_mode == GNX_MATE_INVERSE)
-        hipLaunchKernelGGL(k_find_mates_wave<GNX_MATE_INVERSE>, grid, blk, 0, h->stream, N, s.x, s.y,
-                           s.id, h->tag, h->key[1], h->cell_start, h->ncx, h->ncy, r, r2, h->mate);
-      else
-        hipLaunchKernelGGL(k_find_mates_wave<GNX_MATE_UNIFORM>, grid, blk, 0, h->stream, N, s.x, s.y,
-                           s.id, h->tag, h->key[1], h->cell_start, h->ncx, h->ncy, r, r2, h->mate);
-    } else {
-      const uint4* cd = (const uint4*)h->cand;
-      if (sp.mate_mode == GNX_MATE_NEAREST)
-        hipLaunchKernelGGL(k_find_mates<GNX_MATE_NEAREST>, grid, blk, 0, h->stream, N, cd, h->key[1],
-                           h->cell_start, h->ncx, h->ncy, r, r2, h->mate);
-      else if (sp.mate_mode == GNX_MATE_INVERSE)
-        hipLaunchKernelGGL(k_find_mates<GNX_MATE_INVERSE>, grid, blk, 0, h->stream, N, cd, h->key[1],
-                           h->cell_start, h->ncx, h->ncy, r, r2, h->mate);
-      else
-        hipLaunchKernelGGL(k_find_mates<GNX_MATE_UNIFORM>, grid, blk, 0, h->stream, N, cd, h->key[1],
-                           h->cell_start, h->ncx, h->ncy, r, r2, h->mate);
-    }
+    FocalP fp{N, d_keep, (float)sp.b, sexed, sp.repro_age[0], h->step, h->cfg.seed};
+    dim3 grid(gnx_grid(N, FM_PER_BLOCK)), blk(256);
+    const uint4* cd = (const uint4*)h->cand;
+    if (sp.mate_mode == GNX_MATE_NEAREST)
+      hipLaunchKernelGGL(k_find_mates<GNX_MATE_NEAREST>, grid, blk, 0, h->stream, fp, s, cd,
+                         h->key[1], h->cell_start, h->ncx, h->ncy, r, r2, h->mate);
+    else if (sp.mate_mode == GNX_MATE_INVERSE)
+      hipLaunchKernelGGL(k_find_mates<GNX_MATE_INVERSE>, grid, blk, 0, h->stream, fp, s, cd,
+                         h->key[1], h->cell_start, h->ncx, h->ncy, r, r2, h->mate);
+    else
+      hipLaunchKernelGGL(k_find_mates<GNX_MATE_UNIFORM>, grid, blk, 0, h->stream, fp, s, cd,
+                         h->key[1], h->cell_start, h->ncx, h->ncy, r, r2, h->mate);
   }
   gnx_time_end(h, GNX_K_FIND_MATES, (double)N * 16.0);
   gnx_time_begin(h);

@@ -13,10 +13,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--workload', default='c4_metric')
 ap.add_argument('--steps', type=int, default=10)
 ap.add_argument('--genomes', action='store_true')
+ap.add_argument('--no-traits', action='store_true')
 a = ap.parse_args()
 cfg = dict(bench.WORKLOADS[a.workload])
 if not a.genomes:
     cfg['L'] = 0
+    cfg['n_traits'] = 0
+if a.no_traits:
     cfg['n_traits'] = 0
 dev, _, _ = bench.build_device(cfg, 42, 0)
 for _ in range(3):
