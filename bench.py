@@ -162,6 +162,26 @@ def cpu_baseline(budget_s=20.0):
                        '1 thread of %d host cores' % (steps, W, H, N, L, os.cpu_count()))
 
 
+def measured_copy_bandwidth(torch, nbytes=2 << 30, reps=5):
+    """read + write bytes / time of a 2-GiB device-to-device copy (GB/s)"""
+    try:
+        a = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+        b = torch.empty_like(a)
+        b.copy_(a)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        del a, b
+        return 2.0 * nbytes / (ms * 1e-3) / 1e9
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -269,15 +289,19 @@ def main():
         xo = kt['crossover']
         ach = (xo['bytes'] / (xo['ms'] * 1e-3)) / 1e9 if xo['ms'] > 0 else 0.0
         peak = 8000.0
+        # HBM bytes per launch from the PMC passes of the latest committed profile
+        # (tools/profile_round.sh; separate --pmc runs, gfx950 corrections applied there)
         traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_crossover.json')
-        if os.path.exists(pmc):
+        import glob
+        for pmc in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_crossover.json')))[::-1]:
             try:
                 j = json.load(open(pmc))
                 if j.get('workload') == args.workload:
                     traffic = j.get('hbm_bytes_per_launch')
+                    break
             except Exception:
-                traffic = None
+                continue
+        copy_gbps = measured_copy_bandwidth(torch)
         out = {
             'metric': 'individual-timesteps/sec', 'value': total_ind_steps / max_elapsed,
             'unit': 'individual-timesteps/s', 'n_gpus': world, 'steps': args.steps,
@@ -306,6 +330,9 @@ def main():
                 'launches': xo['launches'],
                 'avg_launch_ms': xo['ms'] / max(xo['launches'], 1),
                 'algorithmic_bytes_per_launch': xo['bytes'] / max(xo['launches'], 1),
+                # also quote a device-to-device copy measured on this box
+                'measured_copy_GBps': copy_gbps,
+                'frac_of_measured_copy': (ach / copy_gbps) if copy_gbps else None,
             },
             'kernel_ms_per_step': {k: v['ms'] / args.steps for k, v in kt.items()},
         }

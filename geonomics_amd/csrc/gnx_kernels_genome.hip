@@ -130,6 +130,22 @@ __device__ __forceinline__ u64x2 xo_mask_lanes(int c, u64 s, int mybp, int nbp) 
   return m;
 }
 
+// the parental chunk that holds the gamete's allele at locus l (the mask bit at l
+// selects the homologue), and the allele itself
+__device__ __forceinline__ u64x2 xo_trait_chunk(int l, u64 s, int mybp, int nbp,
+                                                const u64x2* __restrict__ h0,
+                                                const u64x2* __restrict__ h1) {
+  const int c = l >> 7, bit = l & 127;
+  const u64x2 mm = xo_mask_lanes(c, s, mybp, nbp);
+  const u64 sel = ((bit < 64 ? mm.a >> bit : mm.b >> (bit - 64))) & 1ull;
+  return (sel ? h1 : h0)[c];
+}
+
+__device__ __forceinline__ uint8_t xo_bit(u64x2 w, int l) {
+  const int bit = l & 127;
+  return (uint8_t)(((bit < 64 ? w.a >> bit : w.b >> (bit - 64))) & 1ull);
+}
+
 template <int XO_UNROLL>
 __global__ void __launch_bounds__(256)
 k_crossover_stream(int64_t B, int W16, const u64x2* __restrict__ G, u64x2* __restrict__ Gout,
@@ -155,6 +171,15 @@ k_crossover_stream(int64_t B, int W16, const u64x2* __restrict__ G, u64x2* __res
     const int bp0 = __builtin_amdgcn_readfirstlane(bp_off[key]);
     const int nbp = __builtin_amdgcn_readfirstlane(bp_off[key + 1]) - bp0;
     const int mybp = lane < nbp ? bp_loci[bp0 + lane] : 0x7fffffff;
+    // trait alleles (fused phenotype input): lane e fetches the chunk of trait
+    // locus e NOW, so that the 64-byte sectors it pulls in are the ones the stream
+    // below reads microseconds later (L2 hits); fetched after the stream they
+    // had been evicted again and cost ~10 % extra HBM reads (PMC, profiles/)
+    const int tl = lane < n_tl ? tl_loci[lane] : 0;
+    u64x2 tw;
+    tw.a = 0;
+    tw.b = 0;
+    if (lane < n_tl) tw = xo_trait_chunk(tl, s, mybp, nbp, h0, h1);
     for (int c0 = lane; c0 < W16; c0 += 64 * XO_UNROLL) {
       u64x2 m[XO_UNROLL], v[XO_UNROLL];
       bool mixed = false;
@@ -186,15 +211,10 @@ k_crossover_stream(int64_t B, int W16, const u64x2* __restrict__ G, u64x2* __res
         }
       }
     }
-    for (int e = lane; e < n_tl; e += 64) {
+    if (lane < n_tl) tbits[gam * n_tl + lane] = xo_bit(tw, tl);
+    for (int e = lane + 64; e < n_tl; e += 64) {      // more than 64 trait loci: the rest
       const int l = tl_loci[e];
-      const int c = l >> 7;
-      const u64x2 mm = xo_mask_lanes(c, s, mybp, nbp);
-      const int bit = l & 127;
-      // bit of the mask at l selects the homologue the allele comes from
-      const u64 sel = ((bit < 64 ? mm.a >> bit : mm.b >> (bit - 64))) & 1ull;
-      const u64x2 w = (sel ? h1 : h0)[c];
-      tbits[gam * n_tl + e] = (uint8_t)(((bit < 64 ? w.a >> bit : w.b >> (bit - 64))) & 1ull);
+      tbits[gam * n_tl + e] = xo_bit(xo_trait_chunk(l, s, mybp, nbp, h0, h1), l);
     }
   }
 }
