@@ -256,7 +256,7 @@ extern "C" void gnx_destroy(gnx_state* h) {
                   h->off_parent, h->off_keys, h->off_start, h->keep_in, h->inj_a, h->inj_b,
                   h->mid_x, h->mid_y, h->p_death, h->d_cell, h->dead_in, h->nmax_bits, h->red,
                   h->tl_loci, h->tbits, h->lat.areas, h->lat.cprime, h->spl_N.c, h->spl_P.c, h->bin_partials, h->nodes,
-                  h->gp_rec, h->gp_z, h->gp_slots, h->tile_counts, h->rq_sorted, h->rq_k, h->gam_out, h->gam_slot, h->chk};
+                  h->K_over, h->gp_rec, h->gp_z, h->gp_slots, h->tile_counts, h->rq_sorted, h->rq_k, h->gam_out, h->gam_slot, h->chk};
   for (void* p : ptrs) (void)hipFree(p);
   for (int t = 0; t < GNX_MAX_TRAITS; ++t) {
     (void)hipFree(h->traits[t].loci);
@@ -301,6 +301,21 @@ extern "C" int gnx_upload_layer(gnx_state* h, int32_t layer, const float* rast) 
   HIPCHK(hipMemcpyAsync(h->rast + layer * n, rast, n * sizeof(float), hipMemcpyHostToDevice,
                         h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// explicit carrying-capacity raster (Species.K after a demographic change event,
+// ops/change.py:633-651); NULL returns to rast[K_layer] * K_factor
+extern "C" int gnx_set_K_raster(gnx_state* h, const double* K) {
+  size_t n = (size_t)h->cfg.W * h->cfg.H;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (!K) {
+    (void)hipFree(h->K_over);
+    h->K_over = nullptr;
+    return 0;
+  }
+  if (!h->K_over) HIPCHK(hipMalloc((void**)&h->K_over, n * sizeof(double)));
+  GNXCHK(gnx_h2d(h, h->K_over, K, n * sizeof(double)));
   return 0;
 }
 

@@ -215,6 +215,7 @@ struct gnx_state {
   int32_t* bins_P = nullptr;         // ... of pair midpoints
   int n_bin_blocks = 0;
   double* nodes = nullptr;           // [Jy][Jx] scratch node values
+  double* K_over = nullptr;          // explicit K raster [H][W] (null: rast[K_layer] * K_factor)
   unsigned long long* nmax_bits = nullptr;
   double* p_death = nullptr;         // [cap]
   double* d_cell = nullptr;          // [cap]

@@ -222,9 +222,18 @@ k_nmax(SplineC S, int W, int H, unsigned long long* out_bits) {
 
 struct DemP {
   double R, b, lam, d_min, d_max, K_factor;
+  const double* K_over;    // explicit K raster (demographic change events) or null
   int K_layer, W, H;
   int have_pairs;
 };
+
+// carrying capacity of cell (cx, cy): the explicit raster if one was set
+// (Species.K after a demographic change, ops/change.py:633-651), else
+// rast[K_layer] * K_factor (structs/species.py:546)
+__device__ __forceinline__ double k_at_cell(const DemP& P, const float* rast, int cx, int cy) {
+  if (P.K_over) return P.K_over[(int64_t)cy * P.W + cx];
+  return (double)rast[((int64_t)P.K_layer * P.H + cy) * P.W + cx] * P.K_factor;
+}
 
 // d at one cell (ops/demography.py:95-172, in the reference's order of
 // operations): dNdt = R(1-N/K)N clipped to >= -Nmax, NaN/inf -> -Nmax;
@@ -252,7 +261,7 @@ __global__ void k_raster(int which, SplineC SN, SplineC SP, DemP P, const float*
   if (c >= (int64_t)P.W * P.H) return;
   int cy = (int)(c / P.W), cx = (int)(c - (int64_t)cy * P.W);
   double px = cx + 0.5, py = cy + 0.5;
-  double K = (double)rast[((int64_t)P.K_layer * P.H + cy) * P.W + cx] * P.K_factor;
+  double K = k_at_cell(P, rast, cx, cy);
   if (which == GNX_R_K) {
     out[c] = K;
     return;
@@ -279,6 +288,7 @@ static DemP make_demp(const gnx_state* h) {
   P.d_min = h->sp.d_min;
   P.d_max = h->sp.d_max;
   P.K_factor = h->sp.K_factor;
+  P.K_over = h->K_over;
   P.K_layer = h->sp.K_layer;
   P.W = h->cfg.W;
   P.H = h->cfg.H;
@@ -317,7 +327,7 @@ k_death_probs(DeathP Q, DemP P, SplineC SN, SplineC SP, GnxSoA s, const float* r
   if (i >= Q.N) return;
   int cx = (int)s.x[i], cy = (int)s.y[i];
   double px = cx + 0.5, py = cy + 0.5;
-  double K = (double)rast[((int64_t)P.K_layer * P.H + cy) * P.W + cx] * P.K_factor;
+  double K = k_at_cell(P, rast, cx, cy);
   double N = fmax(spline_eval(SN, px, py), 0.0);
   double np_ = P.have_pairs ? fmax(spline_eval(SP, px, py), 0.0) : 0.0;
   double nmax = __longlong_as_double((long long)*nmax_bits);

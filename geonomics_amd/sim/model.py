@@ -76,6 +76,10 @@ class Model:
         # snapshots replace the reference's deepcopy(comm); only taken when a
         # later iteration can need them
         self.orig_land = None if self.rand_landscape else self.land
+        # a changing landscape is restored from a copy at every new iteration
+        self._orig_land_copy = (copy.deepcopy(self.land)
+                                if (self.land._changer is not None and not self.rand_landscape)
+                                else None)
         self._orig_comm_snap = None
         if not self.rand_comm and self.n_its > 1:
             self._orig_comm_snap = self._snapshot_comm()
@@ -155,6 +159,17 @@ class Model:
                                seed=self._dev_seed, device=self._device, rng=self._rng)
         return comm
 
+    def _make_land_change(self):
+        """reference sim/model.py:397-398, plus the device mirrors of the changed layers"""
+        self.land._make_change(t=self.t, verbose=self._verbose)
+        self._sync_changed_layers()
+
+    def _sync_changed_layers(self):
+        for lyr_num in sorted(self.land._changed_lyrs):
+            for spp in self.comm.values():
+                spp._dev.upload_layer(lyr_num, self.land[lyr_num].rast)
+        self.land._changed_lyrs.clear()
+
     def _make_stats_collector(self):
         """reference sim/model.py:527-535"""
         return _StatsCollector(self.name, self.params)
@@ -204,6 +219,12 @@ class Model:
         if not self._never_been_run:
             if rand_landscape:
                 self.land = self._make_landscape()
+            elif self._orig_land_copy is not None:
+                self.land = copy.deepcopy(self._orig_land_copy)
+                for spp in self.comm.values():
+                    spp._land_ref = self.land
+                    spp._dev.upload_rasters(self.land._stack())
+                    spp._set_K(self.land)
             self._reset_community(rand_comm)
         else:
             self._never_been_run = False
@@ -239,8 +260,17 @@ class Model:
             queue.append(lambda spp=spp: spp._do_pop_dynamics(self.land))
         for spp in self.comm.values():
             queue.append(spp._set_Nt)
-        if not burn and self._stats_collector is not None:
-            queue.append(self.calc_stats)
+        if not burn:
+            # change events, then statistics (reference sim/model.py:644-662)
+            if self.land._changer is not None:
+                queue.append(self._make_land_change)
+                for spp in self.comm.values():
+                    queue.append(lambda spp=spp: spp._set_K(self.land))
+            for spp in self.comm.values():
+                if spp._changer is not None:
+                    queue.append(lambda spp=spp: spp._make_change(verbose=self._verbose))
+            if self._stats_collector is not None:
+                queue.append(self.calc_stats)
         if burn:
             queue.append(self._check_comm_burned)
         return queue

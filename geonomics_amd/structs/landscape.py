@@ -66,6 +66,17 @@ class Landscape(dict):
             assert np.all(0 <= lyr.rast), "Layer '%s' contains values less than 0." % lyr.name
             assert np.all(lyr.rast <= 1), "Layer '%s' contains values greater than 1." % lyr.name
         self._changer = None
+        self._changed_lyrs = set()     # layers whose raster changed since the last device sync
+
+    def _set_raster(self, lyr_num, rast):
+        """reference structs/landscape.py:353-354; the Model mirrors the layer to the
+        species' devices right after the change (sim/model.py _make_land_change)"""
+        self[lyr_num].rast = rast
+        self._changed_lyrs.add(lyr_num)
+
+    def _make_change(self, t, verbose=False):
+        """reference structs/landscape.py:363-365"""
+        self._changer._make_change(t=t, additional_args={'land': self}, verbose=verbose)
 
     def _get_lyr_num(self, lyr_id):
         if isinstance(lyr_id, int) or lyr_id is None:
@@ -138,7 +149,7 @@ def _make_defined_lyr(dim, rast=None, pts=None, vals=None, interp_method='cubic'
 
 def _make_landscape(mod, params, num_hab_types=2, verbose=False):
     """reference structs/landscape.py:522-700 (layer types 'random' and
-    'defined'; change events are outside the hot path)."""
+    'defined'; change events: ops/change.py)."""
     if verbose:
         print('\tMAKING LANDSCAPE...\n')
     main = params.landscape.main
@@ -168,8 +179,11 @@ def _make_landscape(mod, params, num_hab_types=2, verbose=False):
                              "'file', 'nlmpy')" % kind)
         lyrs[n] = Layer(np.asarray(rast, dtype=np.float64), lyr_type=kind, name=lyr_name,
                         dim=dim, res=res, ulc=ulc, prj=prj)
-        if 'change' in lyr_params:
-            raise NotImplementedError(
-                'Landscape change events (ops/change.py) are outside the hot path '
-                'built so far (SURVEY 8f rank 2).')
-    return Landscape(lyrs, res=res, ulc=ulc, prj=prj, mod=mod)
+    land = Landscape(lyrs, res=res, ulc=ulc, prj=prj, mod=mod)
+    # change events (reference structs/landscape.py:655-672)
+    change_params = {land._get_lyr_num(k): v.change for k, v in params.landscape.layers.items()
+                     if 'change' in v.keys()}
+    if len(change_params) > 0:
+        from ..ops.change import _LandscapeChanger
+        land._changer = _LandscapeChanger(land, change_params, mod=mod)
+    return land

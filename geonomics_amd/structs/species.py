@@ -67,7 +67,7 @@ class Species:
         self.Nt = []
         self.n_births = []
         self.n_deaths = []
-        self.K = None
+        self._K = None
         self.K_layer = None
         self.K_factor = None
         self._move = False
@@ -104,6 +104,36 @@ class Species:
         self._burnin_spat_stats = {'mean': [], 'std': []}
         self.start_N = None
         self.max_ind_idx = None
+
+    # -- carrying capacity ------------------------------------------------------------
+    @property
+    def K(self):
+        return self._K
+
+    @K.setter
+    def K(self, val):
+        """Assigning Species.K (demographic change events do, ops/change.py:633-651)
+        makes the raster the device's explicit K."""
+        self._K = val
+        if self.__dict__.get('_dev', None) is not None and val is not None:
+            self._dev.set_K_raster(np.asarray(val, dtype=np.float64))
+
+    def __setattr__(self, attr, val):
+        """life-history parameters live in the hoisted params block; changing one
+        (ops/change.py:744-752 does setattr(spp, parameter, val)) refreshes the
+        device's parameter block"""
+        pv = self.__dict__.get('_pv', None)
+        if pv is not None and attr in pv.__dict__ and attr != 'spp_name':
+            setattr(pv, attr, val)
+            if self.__dict__.get('_dev', None) is not None and \
+                    self.__dict__.get('_land_ref', None) is not None:
+                self._dev.set_species_params(self._species_params_struct(self._land_ref))
+            return
+        object.__setattr__(self, attr, val)
+
+    def _make_change(self, verbose=False):
+        """reference structs/species.py:836-838"""
+        self._changer._make_change(t=self.t, additional_args={'spp': self}, verbose=verbose)
 
     # -- attribute fall-through to the hoisted params (species.py:529-534) ----
     def __getattr__(self, attr):
@@ -177,6 +207,7 @@ class Species:
                          device=self._device_ordinal)
         dev.upload_rasters(land._stack())
         dev.set_species_params(self._species_params_struct(land))
+        self._land_ref = land
         self._dev = dev
         self._upload_gen_arch()
         return dev
@@ -244,9 +275,12 @@ class Species:
 
     # -- small setters used by the Model's function queue -------------------------
     def _set_K(self, land):
-        self.K = land[self.K_layer].rast * self.K_factor
+        """reference structs/species.py:545-546: K = K-layer raster * K_factor (this
+        also drops whatever a demographic change had scaled K to, as there)"""
+        self._K = land[self.K_layer].rast * self.K_factor
         if self._dev is not None:
             self._dev.upload_layer(self.K_layer, land[self.K_layer].rast)
+            self._dev.set_K_raster(None)
 
     def _set_N(self, N):
         self._N_cache = N
@@ -469,7 +503,9 @@ class Species:
                     step=d.step_index, Nt=list(self.Nt), n_births=list(self.n_births),
                     n_deaths=list(self.n_deaths), burned=self.burned, t=self.t,
                     max_ind_idx=self.max_ind_idx, extinct=self.extinct,
-                    spat=copy.deepcopy(self._burnin_spat_stats), geno=None)
+                    spat=copy.deepcopy(self._burnin_spat_stats), geno=None,
+                    K=None if self._K is None else np.array(self._K, copy=True),
+                    pv=copy.deepcopy(self._pv.__dict__))
         if self.gen_arch is not None and self.burned and d.L > 0:
             snap['geno'] = d.download(nat.F_GENO)
         return snap
@@ -488,6 +524,10 @@ class Species:
         self.max_ind_idx = snap['max_ind_idx']
         self.extinct = snap['extinct']
         self._burnin_spat_stats = copy.deepcopy(snap['spat'])
+        if self._changer is not None:        # events start over with the iteration
+            self._changer = copy.deepcopy(self._changer_orig)
+            self._pv.__dict__.update(copy.deepcopy(snap['pv']))
+            self._dev.set_species_params(self._species_params_struct(self._land_ref))
 
 
 def _make_K(spp, land, K_layer, K_factor):
@@ -517,9 +557,6 @@ def _make_species(land, name, idx, spp_params, burn=False, verbose=False, seed=0
     if 'msprime' in init_params:
         raise NotImplementedError('msprime-seeded populations are outside the hot path '
                                   '(SURVEY section 2).')
-    if 'change' in spp_params.keys():
-        raise NotImplementedError('Species change events (ops/change.py) are outside the '
-                                  'hot path built so far (SURVEY 8f rank 2).')
     N = init_params.pop('N')
     spp = Species(name=name, idx=idx, land=land, spp_params=spp_params,
                   genomic_architecture=gen_arch, seed=seed, device=device, rng=rng)
@@ -533,4 +570,11 @@ def _make_species(land, name, idx, spp_params, burn=False, verbose=False, seed=0
     # the burn-in spatial tester takes its first count at creation
     # (reference sim/burnin.py:36-37)
     spp._spatial_update()
+    # change events (reference structs/species.py:3376-3395); movement / dispersal
+    # surfaces follow their Layer on the device, so only parameterised changes
+    # need a changer
+    if 'change' in spp_params.keys():
+        from ..ops.change import _SpeciesChanger
+        spp._changer = _SpeciesChanger(spp, spp_params.change, land=land, rng=rng)
+        spp._changer_orig = copy.deepcopy(spp._changer)
     return spp

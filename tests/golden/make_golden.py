@@ -614,13 +614,109 @@ def g12_stats():
     save('g12_stats', **out)
 
 
+def g13_change():
+    """ops/change.py: layer series, demographic size series, and the K / layer
+    trajectory of a whole reference model with landscape + demographic +
+    life-history change events."""
+    from geonomics.ops import change as ref_change
+    out = {}
+    rng = np.random.RandomState(11)
+
+    class Lyr:
+        pass
+    lyr = Lyr()
+    lyr.rast = rng.rand(5, 6)
+    lyr.dim = (6, 5)
+    lyr._scale_min, lyr._scale_max = 0, 1
+    lyr.ulc, lyr.res, lyr.prj, lyr.idx = (0, 0), (1, 1), None, 0
+    end = rng.rand(5, 6)
+    series = ref_change._make_lyr_series(lyr, end, start_t=3, end_t=11, n_steps=4)[0]
+    out['lyr_start'], out['lyr_end'] = lyr.rast, end
+    out['lyr_t'] = np.array([t for t, _ in series])
+    out['lyr_rasts'] = np.stack([r for _, r in series])
+
+    class Spp:
+        pass
+
+    class Ch:
+        base_K = None
+
+        def _set_base_K(self, spp):
+            self.base_K = spp.K
+
+    def run(T, **kw):
+        spp, ch = Spp(), Ch()
+        spp.K = np.full((2, 2), 2.0)
+        fns = list(ref_change._get_dem_change_fns(spp, **kw))
+        Ks, ts = [], [t for t, _ in fns]
+        for t in range(T):
+            spp.t = t
+            for tt, fn in fns:
+                if tt == t:
+                    fn(ch, spp)
+            Ks.append(spp.K[0, 0])
+        return np.array(Ks), np.array(ts)
+
+    out['mono_K'], out['mono_t'] = run(20, kind='monotonic', start_t=5, end_t=12, rate=0.98)
+    out['cyc_K'], out['cyc_t'] = run(60, kind='cyclical', start_t=5, end_t=45, n_cycles=4,
+                                     size_range=(0.5, 1.5))
+    out['cyc2_K'], out['cyc2_t'] = run(40, kind='cyclical', start_t=2, end_t=30, n_cycles=3,
+                                       min_size=0.25, max_size=2.0, increase_first=False)
+    out['cust_K'], out['cust_t'] = run(30, kind='custom', timesteps=[4, 9, 20],
+                                       sizes=[2, 5, 0.5])
+    np.random.seed(3)
+    out['stoch_u_K'], out['stoch_u_t'] = run(30, kind='stochastic', start_t=3, end_t=23,
+                                             interval=4, size_range=(0.5, 1.5),
+                                             distr='uniform')
+    np.random.seed(3)
+    out['stoch_n_K'], out['stoch_n_t'] = run(30, kind='stochastic', start_t=3, end_t=23,
+                                             interval=None, size_range=(0.5, 1.5),
+                                             distr='normal')
+    # whole model
+    p = base_params(dim=(20, 20), N=120, L=40, traits=True, seed=5)
+    lyrs = p['landscape']['layers']
+    k0 = [*lyrs][0]
+    end_rast = np.linspace(0.2, 1.0, 400).reshape(20, 20)
+    lyrs[k0]['change'] = {0: {'change_rast': end_rast, 'start_t': 4, 'end_t': 12,
+                              'n_steps': 3}}
+    sp = p['comm']['species'][[*p['comm']['species']][0]]
+    sp['change'] = {'dem': {0: {'kind': 'monotonic', 'start_t': 2, 'end_t': 6, 'rate': 0.9,
+                                'interval': None, 'distr': None, 'n_cycles': None,
+                                'size_range': None, 'timesteps': None, 'sizes': None},
+                            1: {'kind': 'custom', 'start_t': None, 'end_t': None,
+                                'rate': None, 'interval': None, 'distr': None,
+                                'n_cycles': None, 'size_range': None,
+                                'timesteps': [14, 16], 'sizes': [0.5, 1.5]}},
+                    'life_hist': {'b': {'timesteps': [3, 10], 'vals': [0.5, 0.1]}}}
+    p['model']['T'] = 20
+    mod = gnx.make_model(gnx.make_params_dict(p, 'golden'))
+    spp = mod.comm[0]
+    mod.walk(T=400, mode='burn', verbose=False)
+    assert mod.comm.burned
+    Ksum, Lsum, bs = [], [], []
+    for t in range(20):
+        mod.walk(1, 'main', verbose=False)
+        Ksum.append(spp.K.sum())
+        Lsum.append(mod.land[spp.K_layer].rast.sum())
+        bs.append(spp.b)
+    out['model_K_layer'] = np.array([spp.K_layer])
+    out['model_start_rast'] = p['landscape']['layers'][k0]['init']['defined']['rast']
+    out['model_end_rast'] = end_rast
+    out['model_K_factor'] = np.array([spp.K_factor])
+    out['model_Ksum'] = np.array(Ksum)
+    out['model_Lsum'] = np.array(Lsum)
+    out['model_b'] = np.array(bs)
+    out['model_K_final'] = spp.K
+    save('g13_change', **out)
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g7', 'g8', 'g9',
-                             'g10', 'g11', 'g12']
+                             'g10', 'g11', 'g12', 'g13']
     fns = {'g1': g1_crossover, 'g2': g2_recomb_paths,
            'g3': g3_phenotype_fitness, 'g4': g4_density,
            'g5': g5_demography, 'g7': g7_movement, 'g8': g8_pairing,
            'g9': g9_starting_genomes, 'g10': g10_envelopes,
-           'g11': g11_conductance, 'g12': g12_stats}
+           'g11': g11_conductance, 'g12': g12_stats, 'g13': g13_change}
     for w in which:
         fns[w]()

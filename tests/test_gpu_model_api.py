@@ -179,3 +179,71 @@ def test_model_stats_collection(tmp_path, monkeypatch):
     np.testing.assert_allclose(got[fin], exp[fin], rtol=1e-9, atol=1e-13)
     np.testing.assert_allclose(ld[40:][fin], exp[fin], atol=5.1e-6)
     assert st['mean_fit']['vals'][5] == pytest.approx(np.mean(spp._get_fit()))
+
+
+def test_model_change_events_follow_reference_K_trajectory():
+    """landscape + demographic + life-history change events (reference ops/change.py):
+    the same parameters as the reference run behind tests/golden/g13_change.npz give the
+    same K / layer / b trajectory, and the device uses that K."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from conftest import load_golden
+    import geonomics_amd as gnx
+    from geonomics_amd import _native as nat
+    d = load_golden('g13_change')
+    p = small_params(seed=5, traits=True, L=40, T=20, dim=(20, 20))
+    lyr0 = p['landscape']['layers']['lyr_0']
+    lyr0['init']['defined']['rast'] = d['model_start_rast']
+    from geonomics_amd.sim.params import ParametersDict
+    lyr0['change'] = ParametersDict({0: {'change_rast': d['model_end_rast'], 'start_t': 4,
+                                         'end_t': 12, 'n_steps': 3}})
+    sp = p['comm']['species']['spp_0']
+    sp['init'].update({'N': 120, 'K_factor': float(d['model_K_factor'][0])})
+    none = dict(rate=None, interval=None, distr=None, n_cycles=None, size_range=None,
+                timesteps=None, sizes=None, start_t=None, end_t=None)
+    sp['change'] = ParametersDict({
+        'dem': {0: dict(none, kind='monotonic', start_t=2, end_t=6, rate=0.9),
+                1: dict(none, kind='custom', timesteps=[14, 16], sizes=[0.5, 1.5])},
+        'life_hist': {'b': {'timesteps': [3, 10], 'vals': [0.5, 0.1]}}})
+    mod = gnx.make_model(p)
+    spp = mod.comm[0]
+    assert mod.land._changer is not None and spp._changer is not None
+    mod.walk(10000, 'burn', verbose=False)
+    Ksum, Lsum, bs, births = [], [], [], []
+    for t in range(20):
+        mod.walk(1, 'main', verbose=False)
+        Ksum.append(spp.K.sum())
+        Lsum.append(mod.land[spp.K_layer].rast.sum())
+        bs.append(spp.b)
+        # the device's K is the host's (f32 layer * K_factor when no event scaled it)
+        np.testing.assert_allclose(spp._dev.download_raster(nat.R_K), spp.K, rtol=1e-6)
+        assert spp._dev.sp.b == pytest.approx(spp.b)
+    np.testing.assert_allclose(Ksum, d['model_Ksum'], rtol=1e-12)
+    np.testing.assert_allclose(Lsum, d['model_Lsum'], rtol=1e-12)
+    assert bs == d['model_b'].tolist()
+    np.testing.assert_allclose(spp.K, d['model_K_final'], rtol=1e-12)
+    # a second iteration starts from the original landscape and events again
+    p2 = gnx.make_params_dict(p, 'api_test')
+    p2['model']['its']['n_its'] = 2
+    mod2 = gnx.make_model(p2)
+    mod2.run()
+    assert mod2.land[0].rast.sum() == pytest.approx(d['model_Lsum'][-1])
+    assert mod2.comm[0].K.sum() == pytest.approx(d['model_Ksum'][-1])
+
+
+def test_demographic_change_moves_population_size():
+    """a custom bottleneck (K x 0.6) and recovery is followed by N.  The reference
+    with these parameters (3 seeds, run in the build container): N = 319-329 before,
+    118-122 during (steps 25-35), 302-320 after."""
+    import geonomics_amd as gnx
+    from geonomics_amd.sim.params import ParametersDict
+    p = small_params(seed=9, traits=False, L=32, T=60)
+    none = dict(rate=None, interval=None, distr=None, n_cycles=None, size_range=None,
+                start_t=None, end_t=None)
+    p['comm']['species']['spp_0']['change'] = ParametersDict(
+        {'dem': {0: dict(none, kind='custom', timesteps=[5, 35], sizes=[0.6, 1.0])}})
+    mod = gnx.make_model(p)
+    mod.run()
+    Nt = np.array(mod.comm[0].Nt[-60:])
+    before, low, after = Nt[:5].mean(), Nt[25:35].mean(), Nt[52:].mean()
+    assert 290 < before < 350 and 95 < low < 145 and after > 0.85 * before

@@ -227,3 +227,80 @@ def test_stats_collector_species_without_genome():
     sc = _collector(5, {'Nt': {'calc': True, 'freq': 1}, 'het': {'calc': True, 'freq': 1},
                         'maf': {'calc': True, 'freq': 1}}, genome=False)
     assert [*sc.stats['spp_0']] == ['Nt']
+
+
+# ---- change events (reference ops/change.py) -------------------------------------------
+def test_layer_change_series_matches_reference():
+    from conftest import load_golden
+    from geonomics_amd.ops import change as CH
+    d = load_golden('g13_change')
+
+    class Lyr:
+        rast = d['lyr_start']
+        coord_prec = 0
+    series = CH._make_lyr_series(Lyr(), d['lyr_end'], start_t=3, end_t=11, n_steps=4)
+    assert [t for t, _ in series] == d['lyr_t'].tolist()
+    np.testing.assert_array_equal(np.stack([r for _, r in series]), d['lyr_rasts'])
+    np.testing.assert_array_equal(series[-1][1], d['lyr_end'])
+
+
+def _run_dem(T, rng=None, **kw):
+    from geonomics_amd.ops import change as CH
+
+    class Spp:
+        pass
+
+    class Ch:
+        base_K = None
+
+        def _set_base_K(self, spp):
+            self.base_K = spp.K
+    spp, ch = Spp(), Ch()
+    spp.K = np.full((2, 2), 2.0)
+    fns = CH._get_dem_change_fns(spp, rng=rng, **kw)
+    Ks = []
+    for t in range(T):
+        spp.t = t
+        for tt, fn in fns:
+            if tt == t:
+                fn(ch, spp)
+        Ks.append(spp.K[0, 0])
+    return np.array(Ks), np.array([t for t, _ in fns])
+
+
+def test_demographic_change_sizes_match_reference():
+    from conftest import load_golden
+    d = load_golden('g13_change')
+    cases = {
+        'mono': (20, dict(kind='monotonic', start_t=5, end_t=12, rate=0.98), None),
+        'cyc': (60, dict(kind='cyclical', start_t=5, end_t=45, n_cycles=4,
+                         size_range=(0.5, 1.5)), None),
+        'cyc2': (40, dict(kind='cyclical', start_t=2, end_t=30, n_cycles=3, min_size=0.25,
+                          max_size=2.0, increase_first=False), None),
+        'cust': (30, dict(kind='custom', timesteps=[4, 9, 20], sizes=[2, 5, 0.5]), None),
+        'stoch_u': (30, dict(kind='stochastic', start_t=3, end_t=23, interval=4,
+                             size_range=(0.5, 1.5), distr='uniform'), 3),
+        'stoch_n': (30, dict(kind='stochastic', start_t=3, end_t=23, interval=None,
+                             size_range=(0.5, 1.5), distr='normal'), 3),
+    }
+    for tag, (T, kw, seed) in cases.items():
+        rng = np.random.RandomState(seed) if seed is not None else None
+        K, ts = _run_dem(T, rng=rng, **kw)
+        np.testing.assert_array_equal(ts, d[tag + '_t'], err_msg=tag)
+        np.testing.assert_array_equal(K, d[tag + '_K'], err_msg=tag)
+
+
+def test_changer_fires_on_equal_timestep_only():
+    from geonomics_amd.ops.change import _Changer
+    ch = _Changer({})
+    log = []
+    ch._set_changes_list([(2, lambda changer: log.append('a')),
+                          (2, lambda changer: log.append('b')),
+                          (5, lambda changer: log.append('c'))])
+    for t in range(4):
+        ch._make_change(t, {})
+    assert log == ['a', 'b'] and ch.next_change[0] == 5
+    ch._add_change((4, lambda changer: log.append('x')))
+    ch._make_change(4, {})
+    ch._make_change(6, {})            # 5 was skipped: it blocks (reference :56-86)
+    assert log == ['a', 'b', 'x'] and ch.next_change[0] == 5
