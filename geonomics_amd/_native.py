@@ -44,7 +44,7 @@ EXPORTS = [
     'gnx_tile_export_migrants_dev', 'gnx_tile_export_halo_dev', 'gnx_tile_staged_ptrs',
     'gnx_tile_import_dev', 'gnx_tile_import_ghosts_dev', 'gnx_tile_pair_ptrs',
     'gnx_tile_offspring_dev', 'gnx_tile_group_requests', 'gnx_tile_serve_gametes_dev',
-    'gnx_tile_put_gametes_dev', 'gnx_tile_bins_ptr', 'gnx_set_K_raster',
+    'gnx_tile_put_gametes_dev', 'gnx_tile_bins_ptr', 'gnx_set_k_raster',
 ]
 
 
@@ -163,11 +163,11 @@ class Device:
     def set_K_raster(self, K):
         """explicit K raster (float64 [H][W]) or None for rast[K_layer] * K_factor"""
         if K is None:
-            self._chk(self.lib.gnx_set_K_raster(self.h, None))
+            self._chk(self.lib.gnx_set_k_raster(self.h, None))
             return
         k = _arr(K, np.float64)
         assert k.shape == (self.H, self.W), k.shape
-        self._chk(self.lib.gnx_set_K_raster(self.h, _ptr(k, C.c_double)))
+        self._chk(self.lib.gnx_set_k_raster(self.h, _ptr(k, C.c_double)))
 
     def set_species_params(self, sp):
         self.sp = sp

@@ -306,7 +306,7 @@ extern "C" int gnx_upload_layer(gnx_state* h, int32_t layer, const float* rast) 
 
 // explicit carrying-capacity raster (Species.K after a demographic change event,
 // ops/change.py:633-651); NULL returns to rast[K_layer] * K_factor
-extern "C" int gnx_set_K_raster(gnx_state* h, const double* K) {
+extern "C" int gnx_set_k_raster(gnx_state* h, const double* K) {
   size_t n = (size_t)h->cfg.W * h->cfg.H;
   HIPCHK(hipStreamSynchronize(h->stream));
   if (!K) {

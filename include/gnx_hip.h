@@ -124,7 +124,7 @@ int gnx_upload_rasters(gnx_state* h, const float* rasts /*[n_layers][H][W]*/);
 int gnx_upload_layer(gnx_state* h, int32_t layer, const float* rast);
 /* Species.K given explicitly, double [H][W] (demographic change events scale it:
  * ops/change.py:633-651); NULL returns to rast[K_layer] * K_factor            */
-int gnx_set_K_raster(gnx_state* h, const double* K);
+int gnx_set_k_raster(gnx_state* h, const double* K);
 int gnx_set_species_params(gnx_state* h, const gnx_species_params* p);
 
 /* Population: _make_species / _make_individual (structs/species.py:3300-3320,
