@@ -11,8 +11,9 @@ _set_spp_t, _set_age_stage, _do_movement, _do_pop_dynamics, _set_Nt
 exceptions inside run() are caught per iteration (:938-953).
 Fixed: queue lambdas bind their own species; both
 params.model.seed.num and params.model.num seed the model.
-Statistics (params.model.stats) are collected by sim/stats.py from the device.
-Out of scope here: plotting, the data collector, change events.
+Statistics (params.model.stats), data sampling / writers (params.model.data) and
+change events run from the main queue after the hot path (sim/stats.py,
+sim/data.py, ops/change.py).  Out of scope here: plotting.
 """
 import copy
 import os
@@ -26,6 +27,8 @@ from ..structs.landscape import _make_landscape
 from ..structs.community import _make_community
 from ..structs import genome as _genome
 from .stats import _StatsCollector
+from .data import (_DataCollector, _get_adhoc_sample, _format_vcf, _format_fasta, _write_csv,
+                   _write_file)
 
 
 class Model:
@@ -65,9 +68,7 @@ class Model:
         if 'stats' in [*m_params]:
             self._stats_collector = self._make_stats_collector()
         if 'data' in [*m_params]:
-            import warnings
-            warnings.warn("params.model.data is ignored: the data collector is "
-                          "outside the GPU hot path (SURVEY 8f).")
+            self._data_collector = self._make_data_collector()
         self.reassign_genomes = None
         self.rand_genarch = m_params.its.rand_genarch
         self.rand_landscape = m_params.its.rand_landscape
@@ -170,6 +171,42 @@ class Model:
                 spp._dev.upload_layer(lyr_num, self.land[lyr_num].rast)
         self.land._changed_lyrs.clear()
 
+    def _make_data_collector(self):
+        """reference sim/model.py:515-523"""
+        return _DataCollector(self.name, self.params, rng=self._rng)
+
+    def _write_data(self):
+        """reference sim/model.py:1185-1186"""
+        self._data_collector._write_data(self.comm, self.land, self.it)
+
+    def write_gendata(self, filepath, spp=0, n=None, include_fixed_sites=True):
+        """VCF / FASTA (by extension) of all or n random individuals
+        (reference sim/model.py:3342-3396)"""
+        extension = filepath.split('.')[-1].lower()
+        assert extension in ['vcf', 'fasta'], ('Must provide valid file extension. Valid '
+                                               'extensions include ".vcf" and ".fasta".')
+        spp = self.comm[self._get_spp_num(spp)]
+        sample = _get_adhoc_sample(spp, n, rng=self._rng)
+        gts = spp._get_genotypes(individs=[*sample], as_dict=True)
+        if extension == 'vcf':
+            text = _format_vcf(sample, gts, spp.gen_arch,
+                               include_fixed_sites=include_fixed_sites)
+        else:
+            text = _format_fasta(sample, gts)
+        _write_file(filepath, text)
+
+    def write_geodata(self, filepath, spp=0, n=None):
+        """CSV of all or n random individuals (reference sim/model.py:3399-3446;
+        shapefile / GeoJSON need geopandas and are not written by this build)"""
+        extension = filepath.split('.')[-1].lower()
+        assert extension in ['csv', 'shp', 'json'], (
+            'Must provide valid file extension. Valid extensions include ".csv", ".shp", '
+            'and ".json".')
+        if extension != 'csv':
+            raise NotImplementedError('shapefile / GeoJSON output needs geopandas')
+        spp = self.comm[self._get_spp_num(spp)]
+        _write_csv(filepath, _get_adhoc_sample(spp, n, rng=self._rng))
+
     def _make_stats_collector(self):
         """reference sim/model.py:527-535"""
         return _StatsCollector(self.name, self.params)
@@ -231,6 +268,8 @@ class Model:
         self._reset_t()
         if self._stats_collector is not None:
             self._stats_collector = self._make_stats_collector()
+        if self._data_collector is not None:
+            self._data_collector = self._make_data_collector()
         if repeat_burn:
             self._reset_burn_t()
         self.comm._reset_t()
@@ -269,6 +308,8 @@ class Model:
             for spp in self.comm.values():
                 if spp._changer is not None:
                     queue.append(lambda spp=spp: spp._make_change(verbose=self._verbose))
+            if self._data_collector is not None:
+                queue.append(self._write_data)
             if self._stats_collector is not None:
                 queue.append(self.calc_stats)
         if burn:

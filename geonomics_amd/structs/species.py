@@ -267,6 +267,27 @@ class Species:
                           int(d.download(nat.F_SEX)[s]), e, z,
                           float(d.download(nat.F_FIT)[s]), g)
 
+    def _get_individs(self, ids):
+        """{id: Individual} for the listed ids (ascending), one download per field;
+        genomes are left out (the writers fetch the sample's genotypes separately)"""
+        ids = np.asarray(ids, dtype=np.int64)
+        d = self._dev
+        all_ids, order = self._ids_sorted()
+        sorted_ids = all_ids[order]
+        pos = np.searchsorted(sorted_ids, ids)
+        assert (pos < len(sorted_ids)).all() and (sorted_ids[pos] == ids).all(), (
+            'some requested individuals are not alive')
+        slots = order[pos]
+        x, y = d.download(nat.F_X)[slots], d.download(nat.F_Y)[slots]
+        age, sex = d.download(nat.F_AGE)[slots], d.download(nat.F_SEX)[slots]
+        fit = d.download(nat.F_FIT)[slots]
+        e = d.download(nat.F_E)[:, slots].astype(np.float64).T
+        z = (d.download(nat.F_Z)[:, slots].astype(np.float64).T if d.n_traits
+             else np.zeros((len(ids), 0)))
+        return {int(i): Individual(int(i), float(x[k]), float(y[k]), int(age[k]), int(sex[k]),
+                                   e[k].tolist(), z[k].tolist(), float(fit[k]), None)
+                for k, i in enumerate(ids)}
+
     def __str__(self):
         return "%s\n%i Individuals (on MI355X, slots %i)\n" % (str(type(self)), len(self),
                                                                self._cap)

@@ -710,13 +710,61 @@ def g13_change():
     save('g13_change', **out)
 
 
+def g14_data():
+    """sim/data.py formatters on a reference sample: VCF and FASTA text, the
+    attribute strings the CSV writer emits, and the sampling schedule."""
+    import re
+    from geonomics.sim import data as ref_data
+    out = {}
+    mod = make_ref_model(L=24, N=60, traits=True, dim=(12, 12))
+    spp = assign_genomes(mod)
+    rng = np.random.RandomState(2)
+    for ind in spp.values():          # drift + a few fixed sites (0 and 1)
+        flip = rng.rand(*ind.g.shape) < 0.3
+        g = np.where(flip, 0, ind.g).astype(ind.g.dtype)
+        g[3, :] = 0
+        g[7, :] = 1
+        ind.g = g
+    ids = sorted([*spp])[:7]
+    sample = {i: spp[i] for i in ids}
+    genotypes = {i: np.int8(spp[i].g) for i in ids}
+    out['ids'] = np.array(ids)
+    out['g'] = np.stack([genotypes[i] for i in ids])
+    for att in ('x', 'y', 'age', 'sex'):
+        out[att] = np.array([getattr(sample[i], att) for i in ids], dtype=float)
+    out['z'] = np.array([np.asarray(sample[i].z, dtype=float) for i in ids])
+    out['e'] = np.array([np.asarray(sample[i].e, dtype=float) for i in ids])
+    vcf = ref_data._format_vcf(sample, genotypes, spp.gen_arch, include_fixed_sites=False)
+    vcf_all = ref_data._format_vcf(sample, genotypes, spp.gen_arch, include_fixed_sites=True)
+    out['vcf'] = np.array(re.sub(r'##fileDate=\d+', '##fileDate=DATE', vcf))
+    out['vcf_fixed'] = np.array(re.sub(r'##fileDate=\d+', '##fileDate=DATE', vcf_all))
+    out['fasta'] = np.array(ref_data._format_fasta(sample, genotypes))
+    out['csv_str_z'] = np.array([str(sample[i].z) for i in ids])
+    out['csv_str_e'] = np.array([str(sample[i].e) for i in ids])
+    out['transect'] = np.array(ref_data._get_transect_points([(1.5, 2.0), (9.0, 11.0)], 5))
+    # sampling schedules: (T, when) -> list of timesteps
+    for tag, (T, when) in {'w0': (20, 0), 'wNone': (20, None), 'w6': (20, 6),
+                           'wlist': (20, [2, 5, 19]), 'wlist2': (20, [2, 5])}.items():
+        class P(dict):
+            __getattr__ = dict.__getitem__
+        params = P(model=P(T=T, data=P(
+            sampling=P(scheme='all', when=when, include_landscape=False),
+            format=P(gen_format=['vcf', 'fasta'], geo_vect_format='csv',
+                     geo_rast_format='txt', nonneut_loc_format=None))))
+        dc = ref_data._DataCollector('m', params)
+        ts = [dc.next_t] + list(dc.when)
+        out['when_' + tag] = np.array(ts)
+    save('g14_data', **out)
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g7', 'g8', 'g9',
-                             'g10', 'g11', 'g12', 'g13']
+                             'g10', 'g11', 'g12', 'g13', 'g14']
     fns = {'g1': g1_crossover, 'g2': g2_recomb_paths,
            'g3': g3_phenotype_fitness, 'g4': g4_density,
            'g5': g5_demography, 'g7': g7_movement, 'g8': g8_pairing,
            'g9': g9_starting_genomes, 'g10': g10_envelopes,
-           'g11': g11_conductance, 'g12': g12_stats, 'g13': g13_change}
+           'g11': g11_conductance, 'g12': g12_stats, 'g13': g13_change,
+           'g14': g14_data}
     for w in which:
         fns[w]()

@@ -304,3 +304,86 @@ def test_changer_fires_on_equal_timestep_only():
     ch._make_change(4, {})
     ch._make_change(6, {})            # 5 was skipped: it blocks (reference :56-86)
     assert log == ['a', 'b', 'x'] and ch.next_change[0] == 5
+
+
+# ---- data sampling / writers (reference sim/data.py, utils/io.py) ---------------------------
+def _golden_sample():
+    from conftest import load_golden
+    from geonomics_amd.structs.species import Individual
+    d = load_golden('g14_data')
+    ids = d['ids'].tolist()
+    sample = {i: Individual(i, float(d['x'][k]), float(d['y'][k]), int(d['age'][k]),
+                            int(d['sex'][k]), d['e'][k].tolist(), d['z'][k].tolist(), 1.0, None)
+              for k, i in enumerate(ids)}
+    genotypes = {i: d['g'][k] for k, i in enumerate(ids)}
+    return d, sample, genotypes
+
+
+def test_vcf_and_fasta_text_match_reference():
+    import re
+    from geonomics_amd.sim import data as D
+    d, sample, genotypes = _golden_sample()
+
+    class GA:
+        L = d['g'].shape[1]
+    for key, fixed in (('vcf', False), ('vcf_fixed', True)):
+        mine = re.sub(r'##fileDate=\d+', '##fileDate=DATE',
+                      D._format_vcf(sample, genotypes, GA, include_fixed_sites=fixed))
+        assert mine == str(d[key])
+    assert 'FIX' in str(d['vcf_fixed']) and 'FIX' not in str(d['vcf'])
+    # FASTA: sequences exact; headers the same numbers (the reference's text carries numpy's
+    # scalar repr, 'np.float64(0.55)', under the numpy it ran with)
+    ref = re.sub(r'np\.float64\(([^)]*)\)', r'\1', str(d['fasta'])).splitlines()
+    mine = D._format_fasta(sample, genotypes).splitlines()
+    assert len(ref) == len(mine) == 4 * len(sample)
+    for a, b in zip(ref, mine):
+        if a.startswith('>'):
+            assert a.split(';')[0] == b.split(';')[0]            # >idx:hap
+            fa = [float(v) for part in a.split(';')[1:] for v in part.split('|')]
+            fb = [float(v) for part in b.split(';')[1:] for v in part.split('|')]
+            assert fa == fb
+        else:
+            assert a == b
+
+
+def test_data_schedule_transect_and_buffers():
+    from conftest import load_golden
+    import geonomics_amd as gnx
+    from geonomics_amd.sim import data as D
+    from geonomics_amd.sim.params import default_params_dict
+    d = load_golden('g14_data')
+    for tag, when in (('w0', 0), ('wNone', None), ('w6', 6), ('wlist', [2, 5, 19]),
+                      ('wlist2', [2, 5])):
+        pd = default_params_dict(1, 1, data=True)
+        pd['model']['T'] = 20
+        pd['model']['data']['sampling'].update({'scheme': 'all', 'when': when})
+        pd['model']['data']['format'].update({'geo_vect_format': 'csv',
+                                              'geo_rast_format': 'txt'})
+        dc = D._DataCollector('m', gnx.make_params_dict(pd, 'm'))
+        assert [dc.next_t] + list(dc.when) == d['when_' + tag].tolist(), tag
+    np.testing.assert_array_equal(
+        np.array(D._get_transect_points([(1.5, 2.0), (9.0, 11.0)], 5)), d['transect'])
+    # the buffer is shapely's 64-gon: vertices on the circle at multiples of 2*pi/64
+    R, w = 2.0, 2 * np.pi / 64
+    apo = R * np.cos(w / 2)
+    at = lambda r, ang: (5 + r * np.cos(ang), 7 + r * np.sin(ang))     # noqa: E731
+    assert D._in_buffer(*at(0.999 * R, 3 * w), 5, 7, R)                # towards a vertex
+    assert not D._in_buffer(*at(0.5 * (apo + R), 3.5 * w), 5, 7, R)    # beyond an edge midpoint
+    assert D._in_buffer(*at(0.999 * apo, 3.5 * w), 5, 7, R)
+    assert not D._in_buffer(*at(1.001 * R, 0.0), 5, 7, R)
+
+
+def test_csv_writer_columns(tmp_path):
+    import csv
+    from geonomics_amd.sim import data as D
+    d, sample, _ = _golden_sample()
+    path = str(tmp_path / 'geo')
+    D._write_csv(path, sample)
+    rows = list(csv.DictReader(open(path + '.csv')))
+    assert [*rows[0]] == ['idx', 'z', 'e', 'age', 'sex', 'x', 'y']     # io.py:173-193
+    assert [int(r['idx']) for r in rows] == d['ids'].tolist()
+    for k, r in enumerate(rows):
+        assert eval(r['z']) == d['z'][k].tolist() and eval(r['e']) == d['e'][k].tolist()
+        assert float(r['x']) == d['x'][k] and float(r['y']) == d['y'][k]
+    with pytest.raises(ValueError):
+        D._write_csv(str(tmp_path / 'geo.vcf'), sample)
