@@ -147,6 +147,7 @@ class _DataCollector:
         self.model_name = model_name
         self.T = params.model.T
         self._rng = np.random if rng is None else rng
+        self.writer = True      # several GPUs: every rank samples and formats, rank 0 writes
         sp = params.model.data.sampling
         fp = params.model.data.format
         self.scheme = sp.scheme
@@ -268,23 +269,26 @@ class _DataCollector:
         for spp in community.values():
             subdir = os.path.join(dirname, 'spp-%s' % spp.name)
             if spp.t == self.next_t:
-                os.makedirs(subdir, exist_ok=True)
+                if self.writer:
+                    os.makedirs(subdir, exist_ok=True)
                 gen_files, geo_files = self._make_filenames(iteration, spp.name)
                 sample = self._get_sample(spp)
                 if len(sample) > 0:
                     if spp.gen_arch is not None:
                         for fname, fmt in zip(gen_files, self.gen_formats):
-                            _write_file(os.path.join(subdir, fname),
-                                        self._format_gen_data(fmt, sample, spp))
+                            text = self._format_gen_data(fmt, sample, spp)
+                            if self.writer:
+                                _write_file(os.path.join(subdir, fname), text)
                     for fname in geo_files:
-                        _write_csv(os.path.join(subdir, fname), sample)
-                else:
+                        if self.writer:
+                            _write_csv(os.path.join(subdir, fname), sample)
+                elif self.writer:
                     base = os.path.splitext((gen_files + geo_files)[0])[0]
                     _write_file(os.path.join(subdir, base + '_ZERO_SAMPLE'), '')
-            if self.nonneut_loc_format is not None:
+            if self.nonneut_loc_format is not None and self.writer:
                 os.makedirs(subdir, exist_ok=True)
                 self._write_nonneut_loc_file(spp, subdir, iteration)
-        if self.rast_format is not None:
+        if self.rast_format is not None and self.writer:
             os.makedirs(dirname, exist_ok=True)
             for lyr in land.values():
                 _write_txt_array(os.path.join(dirname, 'mod-%s_it-%i_t-%i_lyr-%s.txt' % (

@@ -60,6 +60,8 @@ class Model:
         if device is None:
             device = int(os.environ.get('LOCAL_RANK', '0'))
         self._device = device
+        self._comm = self._make_comm()
+        self._rank = 0 if self._comm is None else self._comm.rank
         self.land = self._make_landscape(self._verbose)
         self.comm = self._make_community(self._verbose)
         self._never_been_run = True
@@ -152,12 +154,40 @@ class Model:
         self.reassign_genomes = bool(np.any([spp.gen_arch is not None
                                              for spp in self.comm.values()]))
 
+    def _make_comm(self):
+        """Several GPUs: when the script runs under torch.distributed
+        (WORLD_SIZE > 1; `python -m torch.distributed.run --nproc-per-node N script.py`)
+        every rank builds the same Model and each Species is tiled over the ranks
+        (structs/tiled.py).  Backend: RCCL ("nccl") unless GNX_DIST_BACKEND says
+        otherwise (CPU rehearsals use "gloo")."""
+        if int(os.environ.get('WORLD_SIZE', '1')) <= 1:
+            return None
+        import torch
+        import torch.distributed as dist
+        from ..parallel import Comm
+        if not dist.is_initialized():
+            backend = os.environ.get('GNX_DIST_BACKEND', 'nccl')
+            if backend == 'nccl':
+                torch.cuda.set_device(self._device)
+                dist.init_process_group('nccl', device_id=torch.device('cuda', self._device))
+            else:
+                dist.init_process_group(backend)
+        comm = Comm(dist)
+        if self.seed is None:            # one device seed for all ranks
+            self._dev_seed = int(comm.allgather_i64(np.array([self._dev_seed]))[0][0])
+            self._rng = np.random.RandomState(self._dev_seed)
+        # every rank prints nothing but rank 0; files are written by rank 0
+        if comm.rank != 0:
+            self._verbose = False
+        return comm
+
     def _make_landscape(self, verbose=False):
         return _make_landscape(mod=self, params=self.params, verbose=verbose)
 
     def _make_community(self, verbose=False):
         comm = _make_community(self.land, self.params, burn=True, verbose=verbose,
-                               seed=self._dev_seed, device=self._device, rng=self._rng)
+                               seed=self._dev_seed, device=self._device, rng=self._rng,
+                               comm=self._comm)
         return comm
 
     def _make_land_change(self):
@@ -173,7 +203,9 @@ class Model:
 
     def _make_data_collector(self):
         """reference sim/model.py:515-523"""
-        return _DataCollector(self.name, self.params, rng=self._rng)
+        dc = _DataCollector(self.name, self.params, rng=self._rng)
+        dc.writer = self._rank == 0
+        return dc
 
     def _write_data(self):
         """reference sim/model.py:1185-1186"""
@@ -209,7 +241,9 @@ class Model:
 
     def _make_stats_collector(self):
         """reference sim/model.py:527-535"""
-        return _StatsCollector(self.name, self.params)
+        sc = _StatsCollector(self.name, self.params)
+        sc.writer = self._rank == 0
+        return sc
 
     def calc_stats(self):
         """reference sim/model.py:1190-1191"""
@@ -394,7 +428,7 @@ class Model:
     def run(self, verbose=False):
         """Run all iterations: burn-in then T main timesteps each
         (reference sim/model.py:866-961)."""
-        self._verbose = verbose
+        self._verbose = verbose and self._rank == 0
         if self._verbose:
             print('\n\n' + '#' * self.__term_width__ + '\n\n')
             print('Running model "%s"...\n\n' % self.name, flush=True)
@@ -425,7 +459,7 @@ class Model:
         if animate not in (False, None):
             raise NotImplementedError('plotting is outside the GPU hot path (SURVEY 2)')
         old_verbose = self._verbose
-        self._verbose = verbose
+        self._verbose = verbose and self._rank == 0
         if self._verbose:
             print('\n')
         for _ in range(T):

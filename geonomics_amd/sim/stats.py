@@ -26,7 +26,7 @@ def _calc_Nt(spp):
 def _calc_het(spp, mean=False):
     """fraction of heterozygous individuals per locus (sim/stats.py:394-405)"""
     N = len(spp)
-    _, cnt_het = spp._dev.stats_locus_counts()
+    _, cnt_het = spp._locus_counts()
     with np.errstate(divide='ignore', invalid='ignore'):
         het = cnt_het / N
     if mean:
@@ -37,7 +37,7 @@ def _calc_het(spp, mean=False):
 def _calc_maf(spp):
     """minor-allele frequency per locus (sim/stats.py:408-421)"""
     two_N = 2 * len(spp)
-    cnt1, _ = spp._dev.stats_locus_counts()
+    cnt1, _ = spp._locus_counts()
     with np.errstate(divide='ignore', invalid='ignore'):
         f1 = cnt1 / two_N
     return np.where(f1 > 0.5, 1 - f1, f1)
@@ -49,6 +49,8 @@ def _calc_ld(spp, plot=False, loci=None):
     per call by the C-ABI)."""
     if loci is None:
         loci = np.arange(spp.gen_arch.L)
+    if getattr(spp, '_comm', None) is not None:
+        raise NotImplementedError('linkage statistics on a tiled landscape')
     return spp._dev.stats_ld(np.asarray(loci, dtype=np.int32))
 
 
@@ -81,6 +83,7 @@ class _StatsCollector:
     def __init__(self, model_name, params):
         self.model_name = model_name
         self.T = params.model.T
+        self.writer = True      # several GPUs: every rank calculates, rank 0 writes
         stats_params = params.model.stats
         self.stats = {}
         for spp_name, spp_params in params.comm.species.items():
@@ -122,7 +125,8 @@ class _StatsCollector:
         dirname = os.path.join('GNX_mod-%s' % self.model_name, 'it-%i' % iteration)
         for spp_name, sub in self.stats.items():
             subdir = os.path.join(dirname, 'spp-%s' % spp_name)
-            os.makedirs(subdir, exist_ok=True)
+            if self.writer:
+                os.makedirs(subdir, exist_ok=True)
             for stat in sub:
                 sub[stat]['filepath'] = os.path.join(
                     subdir, 'mod-%s_it-%i_spp-%s_%s' % (self.model_name, iteration, spp_name,
@@ -144,6 +148,8 @@ class _StatsCollector:
             np.savetxt(f, arr, fmt='%0.5f')
 
     def _write_other_stats(self):
+        if not self.writer:
+            return
         for sub in self.stats.values():
             cols = {k: v['vals'] for k, v in sub.items() if _OTHER in v['filepath']}
             if not cols:
@@ -176,7 +182,8 @@ class _StatsCollector:
                     continue
                 writer = (self._write_array_to_stack if stat == 'ld'
                           else self._write_row_to_csv)
-                writer(sd['filepath'], vals[t], t)
+                if self.writer:
+                    writer(sd['filepath'], vals[t], t)
                 # keep only the latest sample in memory (sim/stats.py:214-222)
                 for k in range(len(vals)):
                     if k != t and vals[k] is not None and vals[k] is not np.nan:

@@ -42,11 +42,13 @@ class Community(dict):
             spp.burned = status
 
 
-def _make_community(land, params, burn=False, verbose=False, seed=0, device=0, rng=None):
+def _make_community(land, params, burn=False, verbose=False, seed=0, device=0, rng=None,
+                    comm=None):
     if verbose:
         print('\tMAKING COMMUNITY...\n')
     spps = {n: _make_species(land=land, name=name, idx=n,
                              spp_params=params.comm.species[name], burn=burn,
-                             verbose=verbose, seed=seed + 7919 * n, device=device, rng=rng)
+                             verbose=verbose, seed=seed + 7919 * n, device=device, rng=rng,
+                             comm=comm)
             for n, name in enumerate(params.comm.species.keys())}
     return Community(land, spps)

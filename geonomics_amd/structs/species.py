@@ -229,8 +229,20 @@ class Species:
     def __len__(self):
         return int(self._dev.N) if self._dev is not None else 0
 
+    def _field(self, field):
+        """one per-individual array of the device state (a tiled species gathers the
+        tiles' arrays: structs/tiled.py)"""
+        return self._dev.download(field)
+
+    def _locus_counts(self):
+        """per-locus counts of 1-alleles and of heterozygotes (sim/stats.py)"""
+        return self._dev.stats_locus_counts()
+
+    def _after_init_population(self, N):
+        """hook between init_population and the first spatial snapshot"""
+
     def _ids_sorted(self):
-        ids = self._dev.download(nat.F_ID)
+        ids = self._field(nat.F_ID)
         order = np.argsort(ids, kind='stable')
         return ids, order
 
@@ -251,7 +263,7 @@ class Species:
         return [(i, self[i]) for i in self.keys()]
 
     def __getitem__(self, idx):
-        ids = self._dev.download(nat.F_ID)
+        ids = self._field(nat.F_ID)
         w = np.nonzero(ids == idx)[0]
         if w.size == 0:
             raise KeyError(idx)
@@ -260,12 +272,12 @@ class Species:
         g = None
         if self.gen_arch is not None and self.burned and d.L > 0:
             g = self._unpack(d.download_genomes([s]))[0]
-        e = d.download(nat.F_E)[:, s].astype(np.float64).tolist()
-        z = d.download(nat.F_Z)[:, s].astype(np.float64).tolist() if d.n_traits else []
-        return Individual(int(idx), float(d.download(nat.F_X)[s]),
-                          float(d.download(nat.F_Y)[s]), int(d.download(nat.F_AGE)[s]),
-                          int(d.download(nat.F_SEX)[s]), e, z,
-                          float(d.download(nat.F_FIT)[s]), g)
+        e = self._field(nat.F_E)[:, s].astype(np.float64).tolist()
+        z = self._field(nat.F_Z)[:, s].astype(np.float64).tolist() if d.n_traits else []
+        return Individual(int(idx), float(self._field(nat.F_X)[s]),
+                          float(self._field(nat.F_Y)[s]), int(self._field(nat.F_AGE)[s]),
+                          int(self._field(nat.F_SEX)[s]), e, z,
+                          float(self._field(nat.F_FIT)[s]), g)
 
     def _get_individs(self, ids):
         """{id: Individual} for the listed ids (ascending), one download per field;
@@ -278,11 +290,11 @@ class Species:
         assert (pos < len(sorted_ids)).all() and (sorted_ids[pos] == ids).all(), (
             'some requested individuals are not alive')
         slots = order[pos]
-        x, y = d.download(nat.F_X)[slots], d.download(nat.F_Y)[slots]
-        age, sex = d.download(nat.F_AGE)[slots], d.download(nat.F_SEX)[slots]
-        fit = d.download(nat.F_FIT)[slots]
-        e = d.download(nat.F_E)[:, slots].astype(np.float64).T
-        z = (d.download(nat.F_Z)[:, slots].astype(np.float64).T if d.n_traits
+        x, y = self._field(nat.F_X)[slots], self._field(nat.F_Y)[slots]
+        age, sex = self._field(nat.F_AGE)[slots], self._field(nat.F_SEX)[slots]
+        fit = self._field(nat.F_FIT)[slots]
+        e = self._field(nat.F_E)[:, slots].astype(np.float64).T
+        z = (self._field(nat.F_Z)[:, slots].astype(np.float64).T if d.n_traits
              else np.zeros((len(ids), 0)))
         return {int(i): Individual(int(i), float(x[k]), float(y[k]), int(age[k]), int(sex[k]),
                                    e[k].tolist(), z[k].tolist(), float(fit[k]), None)
@@ -420,7 +432,7 @@ class Species:
 
     # -- accessors (reference structs/species.py:1347-1543) ---------------------------
     def _sorted(self, field):
-        arr = self._dev.download(field)
+        arr = self._field(field)
         ids, order = self._ids_sorted()
         return ids, order, arr
 
@@ -432,8 +444,8 @@ class Species:
 
     def _get_coords(self, individs=None, as_float=True):
         ids, order = self._ids_sorted()
-        x = self._dev.download(nat.F_X)[order].astype(np.float64)
-        y = self._dev.download(nat.F_Y)[order].astype(np.float64)
+        x = self._field(nat.F_X)[order].astype(np.float64)
+        y = self._field(nat.F_Y)[order].astype(np.float64)
         coords = self._select(np.stack([x, y], axis=1), ids[order], individs)
         if not as_float:
             coords = np.int32(np.floor(coords))
@@ -450,28 +462,28 @@ class Species:
 
     def _get_e(self, lyr_num=None, individs=None):
         ids, order = self._ids_sorted()
-        e = self._dev.download(nat.F_E)[:, order].T.astype(np.float64)
+        e = self._field(nat.F_E)[:, order].T.astype(np.float64)
         e = self._select(e, ids[order], individs)
         return e if lyr_num is None else e[:, lyr_num]
 
     def _get_z(self, trait_num=None, individs=None):
         ids, order = self._ids_sorted()
-        z = self._dev.download(nat.F_Z)[:, order].T.astype(np.float64)
+        z = self._field(nat.F_Z)[:, order].T.astype(np.float64)
         z = self._select(z, ids[order], individs)
         return z if trait_num is None else np.atleast_2d(z)[:, trait_num]
 
     def _get_fit(self, individs=None):
         ids, order = self._ids_sorted()
-        return self._select(self._dev.download(nat.F_FIT)[order].astype(np.float64),
+        return self._select(self._field(nat.F_FIT)[order].astype(np.float64),
                             ids[order], individs)
 
     def _get_age(self, individs=None):
         ids, order = self._ids_sorted()
-        return self._select(self._dev.download(nat.F_AGE)[order], ids[order], individs)
+        return self._select(self._field(nat.F_AGE)[order], ids[order], individs)
 
     def _get_sex(self, individs=None):
         ids, order = self._ids_sorted()
-        return self._select(self._dev.download(nat.F_SEX)[order], ids[order], individs)
+        return self._select(self._field(nat.F_SEX)[order], ids[order], individs)
 
     def _unpack(self, packed):
         L = self.gen_arch.L
@@ -479,19 +491,22 @@ class Species:
         bits = np.unpackbits(by, axis=2, bitorder='little')[:, :, :L]
         return np.transpose(bits, (0, 2, 1)).astype(np.int8)
 
+    def _packed_genomes(self, ids):
+        """bit-packed genomes [n][2][W64] of the listed (ascending, living) ids"""
+        all_ids = self._dev.download(nat.F_ID)
+        order = np.argsort(all_ids, kind='stable')
+        pos = np.searchsorted(all_ids[order], ids)
+        return self._dev.download_genomes(order[pos])
+
     def _get_genotypes(self, loci=None, individs=None, biallelic=True, as_dict=False):
         """N x L x 2 int8 (or N x L means if biallelic=False), sorted by id
         (reference structs/species.py:1364-1448)."""
-        ids, order = self._ids_sorted()
         if individs is None:
-            slots = order
+            ids, order = self._ids_sorted()
             out_ids = ids[order]
         else:
-            individs = np.sort(np.asarray(individs))
-            pos = {int(i): k for k, i in enumerate(ids)}
-            slots = np.array([pos[int(i)] for i in individs], dtype=np.int64)
-            out_ids = individs
-        gts = self._unpack(self._dev.download_genomes(slots))
+            out_ids = np.sort(np.asarray(individs, dtype=np.int64))
+        gts = self._unpack(self._packed_genomes(out_ids))
         if loci is not None:
             gts = gts[:, np.asarray(loci), :]
         if not biallelic:
@@ -507,8 +522,8 @@ class Species:
 
     def _calc_density(self, normalize=False, as_layer=False, set_N=False):
         """reference structs/species.py:845-882"""
-        x = self._dev.download(nat.F_X)
-        y = self._dev.download(nat.F_Y)
+        x = self._field(nat.F_X)
+        y = self._field(nat.F_Y)
         _, dens = self._dev.op_density(x, y)
         if normalize:
             dens = (dens - dens.min()) / (dens.max() - dens.min())
@@ -563,7 +578,7 @@ def _make_K(spp, land, K_layer, K_factor):
 
 
 def _make_species(land, name, idx, spp_params, burn=False, verbose=False, seed=0,
-                  device=0, rng=None):
+                  device=0, rng=None, comm=None):
     """reference structs/species.py:3276-3397"""
     rng = np.random if rng is None else rng
     init_params = copy.deepcopy(dict(spp_params.init))
@@ -579,8 +594,12 @@ def _make_species(land, name, idx, spp_params, burn=False, verbose=False, seed=0
         raise NotImplementedError('msprime-seeded populations are outside the hot path '
                                   '(SURVEY section 2).')
     N = init_params.pop('N')
-    spp = Species(name=name, idx=idx, land=land, spp_params=spp_params,
-                  genomic_architecture=gen_arch, seed=seed, device=device, rng=rng)
+    cls, extra = Species, {}
+    if comm is not None and comm.world > 1:
+        from .tiled import TiledSpecies
+        cls, extra = TiledSpecies, {'comm': comm}
+    spp = cls(name=name, idx=idx, land=land, spp_params=spp_params,
+              genomic_architecture=gen_arch, seed=seed, device=device, rng=rng, **extra)
     _make_K(spp, land, **init_params)
     if verbose:
         print('\t\t\tmaking individuals...\n', flush=True)
@@ -588,6 +607,7 @@ def _make_species(land, name, idx, spp_params, burn=False, verbose=False, seed=0
     spp._dev.init_population(N)
     spp.start_N = N
     spp.max_ind_idx = N - 1
+    spp._after_init_population(N)
     # the burn-in spatial tester takes its first count at creation
     # (reference sim/burnin.py:36-37)
     spp._spatial_update()

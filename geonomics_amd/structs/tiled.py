@@ -1,0 +1,178 @@
+"""A Species spread over the GPUs of a node: the same object API as
+structs/species.py, one process per GPU (launch the unchanged model script with
+`python -m torch.distributed.run --nproc-per-node N script.py`), every rank runs
+the same host code and owns one spatial tile of the individuals.
+
+What changes with respect to the single-GPU Species:
+  * the hot path of a step (age, movement, pop dynamics) is ONE call of
+    geonomics_amd.parallel.TiledStepper.step, issued from `_do_pop_dynamics`;
+    `_set_age_stage` / `_do_movement` are the stepper's first phase and do nothing
+    when the queue calls them;
+  * counters (`Nt`, `n_births`, `n_deaths`, `len(spp)`) are global;
+  * the burn-in spatial test combines the tiles' sums (the count rasters of
+    disjoint tiles add);
+  * starting genomes: the exact global count of 1-alleles per site
+    (structs/genome.py:1124-1130) is split over the tiles by a multivariate
+    hypergeometric draw from a generator seeded alike on every rank, and each tile
+    places its share (the union is a uniform choice of n of the 2N homologues);
+  * accessors and statistics return the GLOBAL population on every rank (tiles
+    gathered); files are written by rank 0.
+Not supported on several GPUs: mutation (its draws come from the host's
+sequential generator), panmixia, linkage statistics.
+"""
+import numpy as np
+
+from .. import _native as nat
+from ..parallel import DeviceShard, TiledStepper
+from .species import Species
+from . import genome as _genome
+from ..sim import burnin as _burnin
+
+
+class TiledSpecies(Species):
+    def __init__(self, *args, comm=None, **kw):
+        super().__init__(*args, **kw)
+        self._comm = comm
+        self._stepper = None
+        self._glob_N = 0
+
+    # -- construction -----------------------------------------------------------------
+    def _after_init_population(self, N):
+        if self.mutate:
+            raise NotImplementedError('mutation is not supported on a tiled landscape')
+        if self.mating_radius is None:
+            raise NotImplementedError('panmixia is not supported on a tiled landscape')
+        W, H = self._land_dim
+        self._shard = DeviceShard(self._dev)
+        self._stepper = TiledStepper(
+            self._shard, self._comm, W, H, float(self.mating_radius), move=self._move,
+            max_id=N - 1,
+            fixed_births=int(self.n_births_distr_lambda) if self.n_births_fixed else 0)
+        self._shard.export_migrants()       # every rank drew all N; keep this tile's
+        self._glob_N = int(N)
+
+    # -- counters -----------------------------------------------------------------------
+    def __len__(self):
+        return int(self._glob_N)
+
+    def _check_extinct(self):
+        return self._glob_N == 0
+
+    # -- the hot path -------------------------------------------------------------------
+    def _set_age_stage(self):
+        pass
+
+    def _do_movement(self, land=None):
+        pass
+
+    def _do_pop_dynamics(self, land=None):
+        burn = not self.burned
+        n, births, deaths = self._stepper.step(burn, self.selection and self.burned)
+        self._glob_N = int(n)
+        self.n_births.append(int(births))
+        self.n_deaths.append(int(deaths))
+        self.max_ind_idx = self._stepper.max_id
+        if self._check_extinct():
+            self.extinct = True
+
+    # -- burn-in ---------------------------------------------------------------------------
+    def _spatial_update(self):
+        m, s = self._dev.spatial_diff_stats()
+        cells = float(self._land_dim[0] * self._land_dim[1])
+        tot = self._comm.allreduce_sum(np.array([m * cells, (s * s + m * m) * cells]))
+        mean = tot[0] / cells
+        var = tot[1] / cells - mean * mean
+        self._burnin_spat_stats['mean'].append(float(mean))
+        self._burnin_spat_stats['std'].append(float(np.sqrt(var)) if var > 0 else 0.0)
+
+    def _set_genomes_and_tables(self, burn_T, T):
+        ga = self.gen_arch
+        n_births_tail = self.n_births[-int(burn_T):] if self.n_births else [0]
+        est_tot_muts = float(np.mean(n_births_tail)) * ga.L * (ga._mu_tot or 0) * T
+        _genome._check_mutation_rates(ga, est_tot_muts, burn_T, T)
+        n_glob = _genome._starting_mutation_counts(len(self), ga.p).astype(np.int64)
+        # homologues per tile, known to everybody
+        mine = np.zeros(self._comm.world, np.int64)
+        mine[self._comm.rank] = 2 * int(self._dev.N)
+        homs = self._comm.allreduce_sum(mine)
+        # sequential hypergeometric splits = one multivariate hypergeometric draw per
+        # site; the generator is seeded alike on every rank
+        gen = np.random.default_rng([self._seed & 0x7fffffff, 0x67656e6f])
+        left_n, left_h = n_glob.copy(), int(homs.sum())
+        share = None
+        for r in range(self._comm.world):
+            h_r = int(homs[r])
+            if r == self._comm.world - 1 or left_h - h_r == 0:
+                k = left_n.copy()
+            elif h_r == 0:
+                k = np.zeros_like(left_n)
+            else:
+                k = gen.hypergeometric(h_r, left_h - h_r, left_n)
+            if r == self._comm.rank:
+                share = k
+            left_n = left_n - k
+            left_h -= h_r
+        self._dev.assign_genomes(share.astype(np.int32))
+        self._shard.has_genomes = True
+
+    # -- iterations (Model snapshots) ---------------------------------------------------
+    def _snapshot(self):
+        snap = super()._snapshot()
+        snap['glob_N'] = self._glob_N
+        snap['stepper_max_id'] = self._stepper.max_id
+        snap['has_genomes'] = self._shard.has_genomes
+        return snap
+
+    def _restore(self, snap):
+        super()._restore(snap)
+        self._glob_N = snap['glob_N']
+        self._stepper.max_id = snap['stepper_max_id']
+        self._shard.set_max_id(self._stepper.max_id)
+        self._shard.has_genomes = snap['has_genomes']
+
+    # -- global views --------------------------------------------------------------------
+    def _field(self, field):
+        arr = np.ascontiguousarray(self._dev.download(field))
+        parts = self._gather_bytes(arr)
+        tail_first = arr.ndim == 2          # e / z planes: [k][N]
+        out = []
+        for b in parts:
+            a = b.view(arr.dtype)
+            out.append(a.reshape(arr.shape[0], -1) if tail_first else a)
+        return np.concatenate(out, axis=1 if tail_first else 0)
+
+    def _gather_bytes(self, arr):
+        """every rank's array (as bytes) on every rank"""
+        raw = np.ascontiguousarray(arr).view(np.uint8).ravel()
+        pad = (-raw.size) % 8
+        buf = np.concatenate([raw, np.zeros(pad, np.uint8)]).view(np.int64)
+        sizes = self._comm.allgather_i64(np.array([raw.size], np.int64))
+        parts = self._comm.allgather_i64(buf)
+        return [p.view(np.uint8)[:int(n[0])] for p, n in zip(parts, sizes)]
+
+    def _locus_counts(self):
+        c1, ch = self._dev.stats_locus_counts()
+        tot = self._comm.allreduce_sum(np.concatenate([c1, ch]).astype(np.int64))
+        return tot[:c1.size], tot[c1.size:]
+
+    def _packed_genomes(self, ids):
+        ids = np.asarray(ids, dtype=np.int64)
+        own = self._dev.download(nat.F_ID)
+        order = np.argsort(own, kind='stable')
+        pos = np.searchsorted(own[order], ids)
+        pos = np.minimum(pos, max(own.size - 1, 0))
+        have = (own[order][pos] == ids) if own.size else np.zeros(ids.size, bool)
+        g = self._dev.download_genomes(order[pos[have]]) if have.any() else \
+            np.zeros((0, 2, self._dev.W64), np.uint64)
+        id_parts = self._comm.allgather_i64(ids[have])
+        g_parts = self._gather_bytes(g)
+        W64 = self._dev.W64
+        all_ids = np.concatenate(id_parts)
+        all_g = np.concatenate([b.view(np.uint64).reshape(-1, 2, W64) for b in g_parts])
+        o = np.argsort(all_ids, kind='stable')
+        assert all_ids.size == ids.size and (all_ids[o] == ids).all(), (
+            'some requested individuals are not alive')
+        return all_g[o]
+
+    def _calc_density(self, normalize=False, as_layer=False, set_N=False):
+        raise NotImplementedError('Species._calc_density on a tiled landscape: use Species.N')

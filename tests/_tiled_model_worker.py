@@ -1,0 +1,54 @@
+"""One rank of a Model run over several ranks (tests/test_gpu_tiling.py).  The script is
+what a user's model script would be: it builds the params and calls make_model / run;
+the tiling comes from the torch.distributed environment alone.
+
+    python tests/_tiled_model_worker.py <out.npz> <traits 0|1> <workdir>
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+out, traits, workdir = sys.argv[1], bool(int(sys.argv[2])), sys.argv[3]
+os.chdir(workdir)
+import geonomics_amd as gnx                                # noqa: E402
+from geonomics_amd.sim.params import ParametersDict        # noqa: E402
+from test_gpu_model_api import small_params               # noqa: E402
+
+p = small_params(seed=4, traits=traits, L=48, T=15, dim=(32, 32))
+p['model']['stats'] = ParametersDict({'Nt': {'calc': True, 'freq': 1},
+                                      'het': {'calc': True, 'freq': 5, 'mean': False},
+                                      'maf': {'calc': True, 'freq': 5},
+                                      'mean_fit': {'calc': True, 'freq': 5}})
+p['model']['data'] = ParametersDict({
+    'sampling': {'scheme': 'random', 'n': 20, 'points': None, 'transect_endpoints': None,
+                 'n_transect_points': None, 'radius': None, 'when': None,
+                 'include_landscape': False, 'include_fixed_sites': True},
+    'format': {'gen_format': 'vcf', 'geo_vect_format': 'csv', 'geo_rast_format': 'txt',
+               'nonneut_loc_format': None}})
+mod = gnx.make_model(p)
+spp = mod.comm[0]
+mod.walk(10000, 'burn', verbose=False)
+nburn = len(spp.Nt)
+n_at_assign = spp.Nt[-1]
+g0 = spp._get_genotypes()                 # right after the genome assignment
+mod.walk(15, 'main', verbose=False)
+ids = np.array([*spp])
+xy = mod.get_coords()
+g = spp._get_genotypes()
+z = mod.get_z() if traits else np.zeros((len(ids), 0))
+het = mod._stats_collector.stats['spp_0']['het']['vals'][14]
+rank = int(os.environ.get('RANK', '0'))
+if rank == 0:
+    np.savez(out, Nt=np.array(spp.Nt), births=np.array(spp.n_births),
+             deaths=np.array(spp.n_deaths), nburn=nburn, n_at_assign=n_at_assign,
+             site_counts0=g0.sum(axis=(0, 2)), n0=g0.shape[0], ids=ids, xy=xy, g=g, z=z,
+             het=np.asarray(het), K=spp.K, N_rast=spp.N, world=int(os.environ.get('WORLD_SIZE', 1)))
+import torch.distributed as dist                           # noqa: E402
+if dist.is_initialized():
+    dist.barrier()
+    dist.destroy_process_group()

@@ -186,3 +186,69 @@ def test_nccl_backend_world1_wraps_library_memory():
         dev.close()
     finally:
         dist.destroy_process_group()
+
+
+# ---- the Model API over several ranks (structs/tiled.py) -----------------------------------
+def _run_model(tmp_path, world, traits, tag):
+    import subprocess
+    from test_tiling_cpu import free_port
+    out = str(tmp_path / ('%s.npz' % tag))
+    wd = tmp_path / ('wd_' + tag)
+    wd.mkdir()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_tiled_model_worker.py')
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ)
+        if world > 1:
+            env.update({'WORLD_SIZE': str(world), 'RANK': str(r), 'LOCAL_RANK': '0',
+                        'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port),
+                        'GNX_DIST_BACKEND': 'gloo'})
+        else:
+            for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+                env.pop(k, None)
+        procs.append(subprocess.Popen([sys.executable, worker, out, str(int(traits)), str(wd)],
+                                      env=env))
+    assert [p.wait(timeout=600) for p in procs] == [0] * world
+    return np.load(out), wd
+
+
+def test_model_over_two_ranks_equals_single_process_when_neutral(tmp_path):
+    """the unchanged model script under torch.distributed: a neutral species' demography
+    and positions do not depend on genotypes, so the whole trajectory equals the
+    single-GPU run; genomes differ only by which homologues got the starting 1-alleles"""
+    one, _ = _run_model(tmp_path, 1, False, 'one')
+    two, wd = _run_model(tmp_path, 2, False, 'two')
+    assert int(two['world']) == 2
+    for k in ('Nt', 'births', 'deaths', 'nburn', 'ids'):
+        np.testing.assert_array_equal(one[k], two[k], err_msg=k)
+    np.testing.assert_array_equal(one['xy'], two['xy'])
+    np.testing.assert_allclose(one['N_rast'], two['N_rast'], rtol=1e-12, atol=1e-12)
+    # exact global starting counts: round(2 N p) ones per site (structs/genome.py:1124-1130)
+    for r in (one, two):
+        assert int(r['n0']) == int(r['n_at_assign'])
+        np.testing.assert_array_equal(r['site_counts0'], np.full(48, int(r['n0'])))
+    assert two['g'].shape == one['g'].shape and 0.3 < two['g'].mean() < 0.7
+    assert two['het'].shape == (48,) and 0.3 < two['het'].mean() < 0.7
+    # rank 0 wrote the files, once (Model.walk leaves mod.it at -1, as the reference does)
+    base = wd / 'GNX_mod-api_test' / 'it--1' / 'spp-spp_0'
+    names = sorted(os.listdir(base))
+    assert 'mod-api_test_it--1_spp-spp_0_HET.csv' in names
+    assert 'mod-api_test_it--1_t-14_spp-spp_0.vcf' in names
+    vcf = open(base / 'mod-api_test_it--1_t-14_spp-spp_0.vcf').read().splitlines()
+    ids = [int(v) for v in vcf[3].split('\t')[9:]]
+    assert len(ids) == 20 and set(ids) <= set(two['ids'].tolist())
+    col = {i: k for k, i in enumerate(two['ids'].tolist())}
+    got = np.array([[[int(c) for c in cell.split('|')] for cell in l.split('\t')[9:]]
+                    for l in vcf[4:]])
+    np.testing.assert_array_equal(got, np.transpose(two['g'][[col[i] for i in ids]], (1, 0, 2)))
+
+
+def test_model_over_two_ranks_with_selection(tmp_path):
+    one, _ = _run_model(tmp_path, 1, True, 'one')
+    two, _ = _run_model(tmp_path, 2, True, 'two')
+    np.testing.assert_array_equal(one['Nt'][:int(one['nburn'])], two['Nt'][:int(two['nburn'])])
+    assert abs(one['Nt'][-10:].mean() - two['Nt'][-10:].mean()) < 0.15 * one['Nt'][-10:].mean()
+    assert two['z'].shape == (len(two['ids']), 2)
+    # phenotypes follow the gathered genotypes (z = 0.5 + sum(gt * alpha), monogenic z = gt)
+    assert np.isfinite(two['z']).all() and 0 <= two['z'][:, 1].min() and two['z'][:, 1].max() <= 1
