@@ -1,0 +1,114 @@
+"""Full-size checks (BASELINE configs[1]: 2048 x 2048, N = 10^6, L = 10^5) through
+properties that need no oracle at that size: exact allele-count checksums of the
+crossover's routing, integer conservation laws of a step, uniqueness of ids and genome
+rows, determinism."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+import gnx_oracle as O                                   # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+NBITS = 20          # 2^20 > 10^6 ids
+TAG0 = 31000        # loci that carry the id tag
+
+
+def _build(cfg_name='c4_metric'):
+    import bench
+    from geonomics_amd import _native as nat
+    cfg = dict(bench.WORKLOADS[cfg_name])
+    dev, _, _ = bench.build_device(cfg, seed=42, device=0)
+    return bench, nat, cfg, dev
+
+
+def test_crossover_routing_checksum_at_metric_size():
+    """Every individual carries its id, bit by bit, on BOTH homologues at loci
+    [31000, 31020) of an otherwise empty genome, so whatever path and start homologue a
+    gamete uses it must carry its parent's tag: child homologue 0 = tag(parent A),
+    homologue 1 = tag(parent B), all other bits 0.  Checked exactly for all 2 x 10^5
+    offspring through the per-locus allele counts (a checksum over 10^6 + 2 x 10^5
+    genomes) and bit for bit on a sample of rows."""
+    bench, nat, cfg, dev = _build()
+    N, L = dev.N, cfg['L']
+    assert N == 1_000_000 and L == 100_000
+    dev.set_recomb_paths(bench.sparse_paths(cfg['n_paths'], L, 43, dev.W64))
+    dev.assign_genomes(np.zeros(L, np.int32))
+    ids = dev.download(nat.F_ID)
+    slots = np.arange(N, dtype=np.int64)
+    bit = (ids[:, None] >> np.arange(NBITS)[None, :]) & 1            # [N, NBITS]
+    who, which = np.nonzero(bit)
+    for hom in (0, 1):
+        dev.mutate(slots[who], (TAG0 + which).astype(np.int32),
+                   np.full(who.size, hom, np.uint8))
+    c1, ch = dev.stats_locus_counts()
+    np.testing.assert_array_equal(c1[TAG0:TAG0 + NBITS], 2 * bit.sum(axis=0))
+    assert c1.sum() == 2 * bit.sum() and ch.sum() == 0
+    rng = np.random.RandomState(5)
+    B = 200_000
+    parents = rng.randint(0, N, (B, 2)).astype(np.int32)
+    keys = rng.randint(0, cfg['n_paths'], (B, 2)).astype(np.int32)
+    starts = rng.randint(0, 2, (B, 2)).astype(np.uint8)
+    dev.op_crossover(parents, keys, starts)
+    assert dev.N == N + B
+    # checksum over all N + B genomes
+    exp = 2 * bit.sum(axis=0) + bit[parents[:, 0]].sum(axis=0) + bit[parents[:, 1]].sum(axis=0)
+    c1b, chb = dev.stats_locus_counts()
+    np.testing.assert_array_equal(c1b[TAG0:TAG0 + NBITS], exp)
+    assert c1b.sum() == exp.sum()                       # nothing anywhere else
+    # heterozygous at tag locus k: exactly the offspring whose parents differ at bit k
+    np.testing.assert_array_equal(
+        chb[TAG0:TAG0 + NBITS], (bit[parents[:, 0]] != bit[parents[:, 1]]).sum(axis=0))
+    # bit for bit on 3000 offspring rows (75 MB)
+    pick = np.sort(rng.choice(B, 3000, replace=False))
+    rows = O.unpack_genomes(dev.download_genomes(N + pick), L)        # [n, L, 2]
+    np.testing.assert_array_equal(rows[:, TAG0:TAG0 + NBITS, 0], bit[parents[pick, 0]])
+    np.testing.assert_array_equal(rows[:, TAG0:TAG0 + NBITS, 1], bit[parents[pick, 1]])
+    assert rows.sum() == bit[parents[pick]].sum()
+    dev.close()
+
+
+def test_step_invariants_at_metric_size():
+    """six main steps of the metric workload: N' = N + births - deaths, ids unique and
+    ascending offspring ids, genome rows unique, positions on the landscape, cell
+    order sorted, density bins sum to N, and the run is reproducible."""
+    def run():
+        bench, nat, cfg, dev = _build()
+        for _ in range(3):
+            dev.step(True, False)
+        bench.setup_genomes(dev, cfg, 42)
+        hist = []
+        max_id = int(dev.download(nat.F_ID).max())
+        for _ in range(6):
+            n0 = dev.N
+            dev.step(False, True)
+            n1, b, d = dev.counts()
+            assert n1 == n0 + b - d and b > 0 and d > 0
+            ids = dev.download(nat.F_ID)
+            assert ids.size == n1 and np.unique(ids).size == n1
+            new = ids[ids > max_id]
+            assert 0 < new.size <= b and new.max() <= max_id + b
+            max_id += b
+            hist.append((n1, b, d))
+            # integer conservation of the density counts (taken before the mortality)
+            assert dev.get_bins(0).sum() == n0 + b
+        x, y = dev.download(nat.F_X), dev.download(nat.F_Y)
+        assert (x >= 0).all() and (x <= np.float32(cfg['W'] - 0.001)).all()
+        assert (y >= 0).all() and (y <= np.float32(cfg['H'] - 0.001)).all()
+        rows = dev.download(nat.F_GROW)
+        assert np.unique(rows).size == rows.size and rows.min() >= 0
+        c1, ch = dev.stats_locus_counts()
+        f = c1 / (2.0 * dev.N)
+        # start_p = 0.5 at N = 10^6: six generations of drift move no site far
+        assert 0.49 < f.mean() < 0.51 and f.min() > 0.45 and f.max() < 0.55
+        assert abs(ch.mean() / dev.N - 0.5) < 0.01
+        sig = (hist, int(ids.sum()), int(np.bitwise_xor.reduce(ids)), float(x.sum()),
+               c1[:64].tolist())
+        dev.close()
+        return sig
+    assert run() == run()
