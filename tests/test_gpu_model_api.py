@@ -332,3 +332,23 @@ def test_point_sampling_on_device_population(tmp_path, monkeypatch):
     for r in rows:
         x, y = float(r['x']), float(r['y'])
         assert any(_in_buffer(x, y, c, c, 4.0) for c in (5.0, 15.0, 25.0))
+
+
+@pytest.mark.parametrize('selection', [False, True])
+def test_run_default_model(tmp_path, monkeypatch, capsys, selection):
+    """BASELINE configs[0]: gnx.run_default_model() (reference main.py:608-676): template
+    parameters file -> model -> burn-in -> 50 main steps"""
+    import geonomics_amd as gnx
+    monkeypatch.chdir(tmp_path)
+    mod = gnx.run_default_model(selection=selection)
+    spp = mod.comm[0]
+    assert mod.comm.burned and mod.t == 49 and len(spp) > 0
+    assert len(spp.Nt) == mod.burn_t + 1 + 50
+    assert not [f for f in os.listdir(tmp_path) if f.endswith('.py')]   # params file removed
+    out = capsys.readouterr().out
+    assert 'main:\tit=-1:\tt=49' in out and 'Burn-in complete' in out
+    if selection:
+        assert spp.gen_arch.traits[0].n_loci == 4 and mod.get_z().shape == (len(spp), 1)
+        z = mod.get_z()[:, 0]
+        assert np.isfinite(z).all() and 0.0 <= z.min() and z.max() <= 1.5
+        assert (mod.get_fitness() <= 1).all() and (mod.get_fitness() > 0.9).all()
