@@ -73,12 +73,13 @@ def test_crossover_routing_checksum_at_metric_size():
     dev.close()
 
 
-def test_step_invariants_at_metric_size():
-    """six main steps of the metric workload: N' = N + births - deaths, ids unique and
+@pytest.mark.parametrize('workload', ['c2', 'c3', 'c4_metric'])
+def test_step_invariants_at_baseline_sizes(workload):
+    """six main steps of BASELINE configs[1], [2] and the metric workload ([3] with 10^5 loci): N' = N + births - deaths, ids unique and
     ascending offspring ids, genome rows unique, positions on the landscape, cell
     order sorted, density bins sum to N, and the run is reproducible."""
     def run():
-        bench, nat, cfg, dev = _build()
+        bench, nat, cfg, dev = _build(workload)
         for _ in range(3):
             dev.step(True, False)
         bench.setup_genomes(dev, cfg, 42)
