@@ -440,9 +440,9 @@ class Device:
         self._chk(self.lib.gnx_tile_export_migrants(self.h, C.byref(n)))
         return self._get_staged(n.value, True, with_geno and self.L > 0)
 
-    def tile_export_halo(self, width):
+    def tile_export_halo(self):
         n = C.c_int64()
-        self._chk(self.lib.gnx_tile_export_halo(self.h, C.c_double(width), C.byref(n)))
+        self._chk(self.lib.gnx_tile_export_halo(self.h, C.byref(n)))
         return self._get_staged(n.value, False, False)[0]
 
     def tile_import(self, rec, z=None, geno=None):
@@ -545,10 +545,9 @@ class Device:
         self._chk(self.lib.gnx_tile_export_migrants_dev(self.h, _ptr(cnt, C.c_int64)))
         return cnt, self._staged_ptrs()
 
-    def tile_export_halo_dev(self, width):
+    def tile_export_halo_dev(self):
         cnt = self._tile_counts()
-        self._chk(self.lib.gnx_tile_export_halo_dev(self.h, C.c_double(width),
-                                                    _ptr(cnt, C.c_int64)))
+        self._chk(self.lib.gnx_tile_export_halo_dev(self.h, _ptr(cnt, C.c_int64)))
         return cnt, self._staged_ptrs()[0]
 
     def _staged_ptrs(self):

@@ -312,13 +312,22 @@ int gnx_l_move(gnx_state* h, bool inc_age, const float* inj_theta, const float* 
 }
 
 // ---------------------------------------------------------------- spatial sort
-__global__ void k_keys(int64_t N, const float* x, const float* y, double inv_cs, int ncx, int ncy,
-                       uint32_t* key, int32_t* idx) {
+__device__ __forceinline__ int gnx_cell_of(float x, float y, double inv_cs, int ncx, int ncy) {
+  int cx = min(ncx - 1, (int)((double)x * inv_cs));
+  int cy = min(ncy - 1, (int)((double)y * inv_cs));
+  return cy * ncx + cx;
+}
+
+// sort key: hash cell, then individual id - the order of the sorted arrays is
+// CANONICAL (it does not depend on the order the individuals were stored in, nor
+// on how the landscape is tiled), which is what lets the mate search address
+// candidates by index
+__global__ void k_keys(int64_t N, const float* x, const float* y, const int64_t* id,
+                       double inv_cs, int ncx, int ncy, uint64_t* key, int32_t* idx) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  int cx = min(ncx - 1, (int)((double)x[i] * inv_cs));
-  int cy = min(ncy - 1, (int)((double)y[i] * inv_cs));
-  key[i] = (uint32_t)(cy * ncx + cx);
+  key[i] = ((uint64_t)gnx_cell_of(x[i], y[i], inv_cs, ncx, ncy) << 32) |
+           (uint64_t)(uint32_t)id[i];
   idx[i] = (int32_t)i;
 }
 
@@ -346,36 +355,34 @@ __global__ void k_permute(int64_t N, int64_t cap, const int32_t* perm, GnxSoA a,
 }
 
 // cell_start[c] = first sorted slot whose key >= c; cell_start[ncells] = N
-__global__ void k_cell_bounds(int64_t N, const uint32_t* key, int32_t* cell_start, int ncells) {
+__global__ void k_cell_bounds(int64_t N, const uint64_t* key, int32_t* cell_start, int ncells) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  int k = (int)key[i];
-  int prev = (i == 0) ? -1 : (int)key[i - 1];
+  int k = (int)(key[i] >> 32);
+  int prev = (i == 0) ? -1 : (int)(key[i - 1] >> 32);
   for (int c = prev + 1; c <= k; ++c) cell_start[c] = (int32_t)i;
   if (i == N - 1)
     for (int c = k + 1; c <= ncells; ++c) cell_start[c] = (int32_t)N;
 }
 
-// Stable sort of the whole SoA by hash cell (cell size >= mating radius).
-// Stability + deterministic inputs make slot order, hence offspring ids,
-// reproducible run to run.
+// Sort of the whole SoA by (hash cell, id); cell size >= mating radius.
 int gnx_l_sort_by_cell(gnx_state* h) {
   int64_t N = h->N;
   if (N == 0) return 0;
   const gnx_config& c = h->cfg;
   GnxSoA a = h->soa[h->cur], b = h->soa[h->cur ^ 1];
   gnx_time_begin(h);
-  hipLaunchKernelGGL(k_keys, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, a.x, a.y,
-                     h->inv_cs, h->ncx, h->ncy, h->key[0], h->perm[0]);
-  GNXCHK(gnx_prim_sort(h->sort_tmp, h->sort_tmp_bytes, h->key[0], h->key[1], h->perm[0],
-                       h->perm[1], (size_t)N, h->key_bits, h->stream));
+  hipLaunchKernelGGL(k_keys, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, a.x, a.y, a.id,
+                     h->inv_cs, h->ncx, h->ncy, h->key64[0], h->perm[0]);
+  GNXCHK(gnx_prim_sort64_bits(h->sort64_tmp, h->sort64_tmp_bytes, h->key64[0], h->key64[1],
+                              h->perm[0], h->perm[1], (size_t)N, 32 + h->key_bits, h->stream));
   gnx_time_end(h, GNX_K_SORT, (double)N * 40.0);
   gnx_time_begin(h);
   hipLaunchKernelGGL(k_permute, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, c.cap_inds,
                      h->perm[1], a, b, c.n_layers, c.n_traits, gnx_pair_seed(c.seed, h->step),
                      h->tag, (uint4*)h->cand);
-  hipLaunchKernelGGL(k_cell_bounds, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, h->key[1],
-                     h->cell_start, h->ncx * h->ncy);
+  hipLaunchKernelGGL(k_cell_bounds, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N,
+                     h->key64[1], h->cell_start, h->ncx * h->ncy);
   gnx_time_end(h, GNX_K_PERMUTE,
                (double)N * 2.0 * (33.0 + 4.0 * c.n_layers + 4.0 * c.n_traits));
   HIPCHK(hipGetLastError());
@@ -397,24 +404,37 @@ int gnx_l_sort_by_cell(gnx_state* h) {
 // compaction is block-local (each block lists the kept ones among its 1024
 // consecutive individuals in LDS, in order): no global atomics, no extra pass.
 //
-// k_find_mates: one lane per listed focal individual; the lane walks its own
-// 3x3 block of hash cells: per cell row ONE contiguous range of the cell-sorted
-// candidate records [cell_start(ry, cx-1), cell_start(ry, cx+2)), one 16-byte
-// record {x, y, tag, id_lo} per load.  The list keeps the cell-sorted order
-// within a wave, so the lanes of a wave sit in the same or adjacent cells and
-// their loads hit the same few cache lines.  Cells are >= mating_radius wide, so
-// every neighbour within the radius lies in the scanned ranges; extra
-// candidates simply fail the distance test (dx*dx + dy*dy <= r*r in f32, the
-// same expression the oracle evaluates).  (A wave-broadcast variant - the wave
-// loads the union of its lanes' ranges and v_readlane's each candidate - was
-// 5x slower: 3.4x more vector instructions, PMC SQ_INSTS_VALU, round-1 profiles.)
+// Candidates of a focal individual: the 3x3 block of hash cells around its own, i.e.
+// per cell row ONE contiguous range [cell_start(ry, cx-1), cell_start(ry, cx+2)) of the
+// sorted arrays, one 16-byte record {x, y, tag, id_lo} per candidate.  Cells are >=
+// mating_radius wide, so every neighbour within the radius lies in the three ranges;
+// the distance test is dx*dx + dy*dy <= r*r in f32, the expression the oracle evaluates.
 //
-// Mate choice is independent of candidate order: uniform = smallest
-// pair_hash(focal id, candidate id); nearest = smallest d2; inverse-distance =
-// smallest -ln(u)/(r-d).  Ties break on the smaller id; selection is a
-// branch-free composite-key minimum.
+// UNIFORM choice (the reference's default: np.random.choice over the neighbours within
+// the radius, utils/spatial.py:236-241) by REJECTION SAMPLING IN INDEX SPACE: the three
+// ranges are one canonical list of M candidates (cells in grid order, ids ascending
+// inside a cell); the focal draws indices from its own Philox stream
+// (seed, id, step, OP_MATE_PICK) until the candidate drawn is within the radius (and is
+// not itself) - a uniform pick from the in-radius set in ~M/m expected draws, whatever M
+// is.  That matters: conductance-surface movement piles individuals onto ridges (the
+// metric model at equilibrium holds up to 6,700 individuals in one cell, a mean of
+// 4,600 candidates per focal against 270 for a uniform spread) and a scan of all
+// candidates per focal then costs as much as the crossover.  After about M/2 rejected
+// draws (32 .. 8192, a multiple of 4 fixed by M) the lane falls back to an exact scan:
+// count the m in-radius candidates, take the (u*m)-th.  The result depends on ids, positions and the seed only: slot order and
+// tiling do not matter (tiles import whole cells, csrc/gnx_tile.hip).
+//
+// NEAREST and INVERSE-DISTANCE choices need every candidate: FM_LANES adjacent lanes
+// share one focal's ranges (64 contiguous bytes per group and step) and combine
+// their branch-free composite-key minima with DPP shuffles; nearest = smallest d2,
+// inverse-distance = smallest -ln(u)/(r-d) (Efraimidis-Spirakis), ties on the smaller id.
+// (A wave-broadcast variant - the wave loads the union of its lanes' ranges and
+// v_readlane's each candidate - was 5x slower: 3.4x more vector instructions, PMC
+// SQ_INSTS_VALU, round-1 profiles.)
 #define FM_PER_BLOCK 1024      // individuals per 256-thread block (~b * 1024 are searched)
 #define FM_LANES 4             // lanes that share one focal individual's candidate ranges
+#define FM_MIN_BLOCKS 8         // index draws before the exact fallback scan: 4 per Philox
+#define FM_MAX_BLOCKS 2048      // block, between 32 and 8192, about half the candidate count
 
 struct FocalP {
   int64_t N;
@@ -427,9 +447,9 @@ struct FocalP {
 
 template <int MODE>
 __global__ void __launch_bounds__(256)
-k_find_mates(FocalP fp, GnxSoA s, const uint4* __restrict__ cand,
-             const uint32_t* __restrict__ key, const int32_t* __restrict__ cell_start, int ncx,
-             int ncy, float r, float r2, int32_t* __restrict__ mate) {
+k_find_mates(FocalP fp, GnxSoA s, const uint4* __restrict__ cand, double inv_cs,
+             const int32_t* __restrict__ cell_start, int ncx, int ncy, float r, float r2,
+             int32_t* __restrict__ mate) {
   __shared__ int32_t list[FM_PER_BLOCK];
   __shared__ int32_t wcnt[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -459,16 +479,80 @@ k_find_mates(FocalP fp, GnxSoA s, const uint4* __restrict__ cand,
     n_list += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
     __syncthreads();
   }
-  // phase 2: FM_LANES adjacent lanes per listed focal individual; they stride the
-  // candidate ranges together (64 contiguous bytes per group and step) and
-  // combine their minima with two DPP shuffles
+  // phase 2
+  if (MODE == GNX_MATE_UNIFORM) {
+    for (int t = tid; t < n_list; t += 256) {
+      const int i = list[t];
+      const uint4 me = cand[i];
+      const float fx = __uint_as_float(me.x), fy = __uint_as_float(me.y);
+      const int k = gnx_cell_of(fx, fy, inv_cs, ncx, ncy);
+      const int cy = k / ncx;
+      const int cx = k - cy * ncx;
+      const int lo = max(cx - 1, 0), hi = min(cx + 1, ncx - 1);
+      // the three row ranges (an absent row has length 0)
+      int st[3], len[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int ry = cy - 1 + q;
+        const bool in = ry >= 0 && ry < ncy;
+        st[q] = in ? cell_start[ry * ncx + lo] : 0;
+        len[q] = in ? cell_start[ry * ncx + hi + 1] - st[q] : 0;
+      }
+      const unsigned int M = (unsigned int)(len[0] + len[1] + len[2]);
+      GnxStream rs(fp.seed, (unsigned long long)s.id[i], fp.step, OP_MATE_PICK);
+      int found = -1;
+      // draws before the exact scan: about M/2 (a scan costs 2M loads), 32 .. 8192
+      const int tries = 4 * min(max((int)(M >> 3), FM_MIN_BLOCKS), FM_MAX_BLOCKS);
+      if (M > 1) {
+        for (int tr = 0; tr < tries && found < 0; ++tr) {
+          int j = (int)__umulhi(rs.next(), M);
+          const int slot = j < len[0] ? st[0] + j
+                           : (j < len[0] + len[1] ? st[1] + (j - len[0])
+                                                  : st[2] + (j - len[0] - len[1]));
+          const uint4 c = cand[slot];
+          const float dx = __uint_as_float(c.x) - fx, dy = __uint_as_float(c.y) - fy;
+          if (slot != i && dx * dx + dy * dy <= r2) found = slot;
+        }
+        if (found < 0) {
+          // exact fallback: the (u * m)-th of the m in-radius candidates, canonical order
+          GnxStream fb(fp.seed, (unsigned long long)s.id[i], fp.step, OP_MATE_PICK,
+                       tries / 4);
+          unsigned int m = 0;
+          for (int q = 0; q < 3; ++q)
+            for (int slot = st[q]; slot < st[q] + len[q]; ++slot) {
+              const uint4 c = cand[slot];
+              const float dx = __uint_as_float(c.x) - fx, dy = __uint_as_float(c.y) - fy;
+              m += (slot != i && dx * dx + dy * dy <= r2) ? 1u : 0u;
+            }
+          if (m > 0) {
+            unsigned int want = __umulhi(fb.next(), m);
+            for (int q = 0; q < 3 && found < 0; ++q)
+              for (int slot = st[q]; slot < st[q] + len[q]; ++slot) {
+                const uint4 c = cand[slot];
+                const float dx = __uint_as_float(c.x) - fx, dy = __uint_as_float(c.y) - fy;
+                if (slot != i && dx * dx + dy * dy <= r2) {
+                  if (want == 0) {
+                    found = slot;
+                    break;
+                  }
+                  --want;
+                }
+              }
+          }
+        }
+      }
+      mate[i] = found;
+    }
+    return;
+  }
+  // NEAREST / INVERSE: FM_LANES adjacent lanes per listed focal individual
   for (int t = tid; t < n_list * FM_LANES; t += 256) {
     const int i = list[t / FM_LANES];
     const int sub = t % FM_LANES;
     const uint4 me = cand[i];
     const float fx = __uint_as_float(me.x), fy = __uint_as_float(me.y);
     const unsigned int ftag = me.z * 0x9E3779B1u;
-    const int k = (int)key[i];
+    const int k = gnx_cell_of(fx, fy, inv_cs, ncx, ncy);
     const int cy = k / ncx;
     const int cx = k - cy * ncx;
     const int lo = max(cx - 1, 0), hi = min(cx + 1, ncx - 1);
@@ -483,9 +567,7 @@ k_find_mates(FocalP fp, GnxSoA s, const uint4* __restrict__ cand,
         const float d2 = dx * dx + dy * dy;
         bool ok = (d2 <= r2) & (j != i);
         unsigned int k32;
-        if (MODE == GNX_MATE_UNIFORM) {
-          k32 = gnx_pair_key(ftag, c.z);
-        } else if (MODE == GNX_MATE_NEAREST) {
+        if (MODE == GNX_MATE_NEAREST) {
           k32 = __float_as_uint(d2);
         } else {
           ok = ok & (d2 > 0.f);
@@ -627,13 +709,13 @@ int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out) 
     const uint4* cd = (const uint4*)h->cand;
     if (sp.mate_mode == GNX_MATE_NEAREST)
       hipLaunchKernelGGL(k_find_mates<GNX_MATE_NEAREST>, grid, blk, 0, h->stream, fp, s, cd,
-                         h->key[1], h->cell_start, h->ncx, h->ncy, r, r2, h->mate);
+                         h->inv_cs, h->cell_start, h->ncx, h->ncy, r, r2, h->mate);
     else if (sp.mate_mode == GNX_MATE_INVERSE)
       hipLaunchKernelGGL(k_find_mates<GNX_MATE_INVERSE>, grid, blk, 0, h->stream, fp, s, cd,
-                         h->key[1], h->cell_start, h->ncx, h->ncy, r, r2, h->mate);
+                         h->inv_cs, h->cell_start, h->ncx, h->ncy, r, r2, h->mate);
     else
       hipLaunchKernelGGL(k_find_mates<GNX_MATE_UNIFORM>, grid, blk, 0, h->stream, fp, s, cd,
-                         h->key[1], h->cell_start, h->ncx, h->ncy, r, r2, h->mate);
+                         h->inv_cs, h->cell_start, h->ncx, h->ncy, r, r2, h->mate);
   }
   gnx_time_end(h, GNX_K_FIND_MATES, (double)N * 16.0);
   gnx_time_begin(h);

@@ -45,3 +45,11 @@ int gnx_prim_sort64(void* tmp, size_t bytes, const uint64_t* kin, uint64_t* kout
   HIPCHK(rocprim::radix_sort_pairs(tmp, bytes, kin, kout, vin, vout, n, 0, 64, s));
   return 0;
 }
+
+// only the low `end_bit` bits of the keys are significant (fewer radix passes)
+int gnx_prim_sort64_bits(void* tmp, size_t bytes, const uint64_t* kin, uint64_t* kout,
+                         const int32_t* vin, int32_t* vout, size_t n, int end_bit,
+                         hipStream_t s) {
+  HIPCHK(rocprim::radix_sort_pairs(tmp, bytes, kin, kout, vin, vout, n, 0, end_bit, s));
+  return 0;
+}

@@ -16,7 +16,7 @@
 enum {
   OP_MOVE_DIR = 0, OP_MOVE_DIST = 1, OP_PAIR_KEEP = 2, OP_BIRTHS = 3,
   OP_DISPERSAL = 4, OP_OFFSPRING = 5, OP_DEATH = 6, OP_INIT = 7,
-  OP_MOVE_SURF = 8, OP_DISP_SURF = 9
+  OP_MOVE_SURF = 8, OP_DISP_SURF = 9, OP_MATE_PICK = 10
 };
 
 #define GNX_PI_F 3.14159274101257324f

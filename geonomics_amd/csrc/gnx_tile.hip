@@ -5,8 +5,8 @@
 // whole (small) rasters and works in global coordinates.  Per time step the
 // host layer (geonomics_amd/parallel.py, torch.distributed over RCCL) moves:
 //   1. migrants   - individuals that left their tile, with their genomes;
-//   2. halo       - light copies (x, y, age, sex, id) of individuals within
-//                   2 x mating_radius of a tile border ("ghosts"): candidates
+//   2. halo       - light copies (x, y, age, sex, id) of the individuals in the hash
+//                   cells within 2 cells of a neighbour tile ("ghosts"): candidates
 //                   for the mate search AND focal individuals whose own choice
 //                   is recomputed locally, so that the reciprocal-pair rule
 //                   gives the same answer on both sides of a border;
@@ -70,28 +70,53 @@ __global__ void k_mark_out(int64_t N, const float* x, const float* y, TileBox t,
   dead[i] = out ? 1 : 0;
 }
 
+// Halo: whole hash cells.  A neighbour tile needs every individual whose cell lies
+// within 2 cells of the tile's own cell range: ring 1 completes the 3x3 candidate
+// blocks of the neighbour's own focal individuals, ring 2 those of the ghosts they can
+// choose (a ghost's own choice decides the reciprocal-pair rule), so that the index
+// sampling of the mate search sees the same candidate lists on every tile.
 // neighbour bit k = (dy+1)*3 + (dx+1), dy,dx in {-1,0,1} (bit 4 unused)
+struct HaloSpans {
+  int cx0[3], cx1[3], cy0[3], cy1[3];   // cell spans (+/- 2 rings) of tile columns c-1..c+1, rows r-1..r+1
+  int okx[3], oky[3];                   // that column / row exists
+};
+
 __global__ void k_mark_halo(int64_t N, const float* x, const float* y, const uint8_t* ghost,
-                            TileBox t, float width, int32_t* flag, int32_t* mask) {
+                            HaloSpans sp, double inv_cs, int ncx, int ncy, int32_t* flag,
+                            int32_t* mask) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   int m = 0;
   if (!ghost[i]) {
-    const bool L = t.c > 0 && x[i] - t.x0 < width;
-    const bool Rr = t.c < t.C - 1 && t.x1 - x[i] <= width;
-    const bool U = t.r > 0 && y[i] - t.y0 < width;
-    const bool D = t.r < t.R - 1 && t.y1 - y[i] <= width;
-    if (L) m |= 1 << 3;
-    if (Rr) m |= 1 << 5;
-    if (U) m |= 1 << 1;
-    if (D) m |= 1 << 7;
-    if (L && U) m |= 1 << 0;
-    if (Rr && U) m |= 1 << 2;
-    if (L && D) m |= 1 << 6;
-    if (Rr && D) m |= 1 << 8;
+    const int cx = min(ncx - 1, (int)((double)x[i] * inv_cs));
+    const int cy = min(ncy - 1, (int)((double)y[i] * inv_cs));
+    for (int dy = 0; dy < 3; ++dy)
+      for (int dx = 0; dx < 3; ++dx) {
+        if (dx == 1 && dy == 1) continue;
+        if (sp.okx[dx] && sp.oky[dy] && cx >= sp.cx0[dx] && cx <= sp.cx1[dx] &&
+            cy >= sp.cy0[dy] && cy <= sp.cy1[dy])
+          m |= 1 << (dy * 3 + dx);
+      }
   }
   mask[i] = m;
   flag[i] = m ? 1 : 0;
+}
+
+static HaloSpans halo_spans(const gnx_state* h) {
+  HaloSpans sp;
+  const int tw = h->cfg.W / h->tile_C, th = h->cfg.H / h->tile_R;
+  for (int d = 0; d < 3; ++d) {
+    const int cc = h->tile_c + d - 1, rr = h->tile_r + d - 1;
+    sp.okx[d] = cc >= 0 && cc < h->tile_C;
+    sp.oky[d] = rr >= 0 && rr < h->tile_R;
+    const float x0 = (float)(cc * tw), x1 = nextafterf((float)((cc + 1) * tw), 0.f);
+    const float y0 = (float)(rr * th), y1 = nextafterf((float)((rr + 1) * th), 0.f);
+    sp.cx0[d] = std::min(h->ncx - 1, (int)((double)x0 * h->inv_cs)) - 2;
+    sp.cx1[d] = std::min(h->ncx - 1, (int)((double)x1 * h->inv_cs)) + 2;
+    sp.cy0[d] = std::min(h->ncy - 1, (int)((double)y0 * h->inv_cs)) - 2;
+    sp.cy1[d] = std::min(h->ncy - 1, (int)((double)y1 * h->inv_cs)) + 2;
+  }
+  return sp;
 }
 
 __global__ void k_pack(int64_t N, int64_t cap, const int32_t* flag, const int32_t* scan,
@@ -219,13 +244,13 @@ extern "C" int gnx_tile_export_migrants(gnx_state* h, int64_t* n_out) {
   return 0;
 }
 
-extern "C" int gnx_tile_export_halo(gnx_state* h, double width, int64_t* n_out) {
+extern "C" int gnx_tile_export_halo(gnx_state* h, int64_t* n_out) {
   *n_out = 0;
   int64_t N = h->N;
   if (N == 0) return 0;
   GnxSoA s = h->soa[h->cur];
   hipLaunchKernelGGL(k_mark_halo, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, s.x, s.y,
-                     s.ghost, tile_box(h), (float)width, h->flag, h->mate);
+                     s.ghost, halo_spans(h), h->inv_cs, h->ncx, h->ncy, h->flag, h->mate);
   return stage_selection(h, h->mate, false, false, n_out);
 }
 
@@ -736,7 +761,7 @@ extern "C" int gnx_tile_export_migrants_dev(gnx_state* h, int64_t* counts /*[R*C
 }
 
 // halo records, one copy per neighbour tile that needs them, grouped by rank
-extern "C" int gnx_tile_export_halo_dev(gnx_state* h, double width, int64_t* counts) {
+extern "C" int gnx_tile_export_halo_dev(gnx_state* h, int64_t* counts) {
   GNXCHK(check_tiles(h, "gnx_tile_export_halo_dev"));
   for (int p = 0; p < n_tiles(h); ++p) counts[p] = 0;
   h->gp_n = 0;
@@ -745,7 +770,7 @@ extern "C" int gnx_tile_export_halo_dev(gnx_state* h, double width, int64_t* cou
   if (N == 0) return 0;
   GnxSoA s = h->soa[h->cur];
   hipLaunchKernelGGL(k_mark_halo, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, s.x, s.y,
-                     s.ghost, tile_box(h), (float)width, h->flag, h->mate);
+                     s.ghost, halo_spans(h), h->inv_cs, h->ncx, h->ncy, h->flag, h->mate);
   GNXCHK(stage_selection(h, h->mate, false, false, &n));
   if (n == 0) return 0;
   if (n + 1 > h->cfg.cap_inds) {

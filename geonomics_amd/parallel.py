@@ -56,8 +56,8 @@ class DeviceShard:
         if rec.size:
             self.dev.tile_import(rec, z, geno if self.has_genomes else None)
 
-    def export_halo(self, width):
-        return self.dev.tile_export_halo(width)
+    def export_halo(self):
+        return self.dev.tile_export_halo()
 
     def import_ghosts(self, rec):
         if rec.size:
@@ -286,8 +286,11 @@ class TiledStepper:
         self.r, self.c = divmod(comm.rank, self.C)
         self.radius = float(mating_radius)
         if comm.world > 1:
-            assert 2 * self.radius <= min(self.tw, self.th), (
-                'tiles must be at least 2 x mating_radius wide')
+            # the halo is made of whole hash cells (2 rings); it must come from the
+            # adjacent tiles only
+            cs = max(self.radius * (1.0 + 1e-9), max(W, H) / 2048.0)
+            assert 3 * cs <= min(self.tw, self.th), (
+                'tiles must be at least 3 hash cells (3 x mating_radius) wide')
         self.move = move
         self.fixed_births = int(fixed_births)   # > 0: every pair has this many births
         self.max_id = int(max_id)            # global maximum id handed out
@@ -370,7 +373,7 @@ class TiledStepper:
 
     def _halo_dev(self):
         dev = self.shard.dev
-        counts, p_rec = dev.tile_export_halo_dev(2.0 * self.radius)
+        counts, p_rec = dev.tile_export_halo_dev()
         mat = self.comm.count_matrix(counts)
         n = int(counts.sum())
         self.bytes_sent += n * 32
@@ -449,7 +452,7 @@ class TiledStepper:
             return
         if self.dev_transport:
             return self._halo_dev()
-        rec = self.shard.export_halo(2.0 * self.radius)
+        rec = self.shard.export_halo()
         w = self.comm.world
         send = [np.zeros(0, np.uint8)] * w
         for dy in (-1, 0, 1):

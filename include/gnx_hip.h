@@ -253,7 +253,10 @@ typedef struct {
 
 int gnx_tile_set(gnx_state* h, int32_t R, int32_t C, int32_t r, int32_t c);
 int gnx_tile_export_migrants(gnx_state* h, int64_t* n_out);
-int gnx_tile_export_halo(gnx_state* h, double width, int64_t* n_out);
+/* halo = whole hash cells: every individual whose cell lies within 2 cells of a
+ * neighbour tile's cell range (complete candidate lists for the neighbour's own
+ * focal individuals and for the ghosts they can choose)                        */
+int gnx_tile_export_halo(gnx_state* h, int64_t* n_out);
 int gnx_tile_get_staged(gnx_state* h, gnx_ind_rec* rec, float* z /*[n][n_traits]*/,
                         uint64_t* geno /*[n][2][W64]*/);
 int gnx_tile_import(gnx_state* h, int64_t n, const gnx_ind_rec* rec, const float* z,
@@ -293,7 +296,7 @@ typedef struct {
 } gnx_gamete_req;
 
 int gnx_tile_export_migrants_dev(gnx_state* h, int64_t* counts /*[R*C]*/);
-int gnx_tile_export_halo_dev(gnx_state* h, double width, int64_t* counts /*[R*C]*/);
+int gnx_tile_export_halo_dev(gnx_state* h, int64_t* counts /*[R*C]*/);
 /* grouped selection: rec gnx_ind_rec[n], z float[n][n_traits], geno u64[n][2][W64] */
 int gnx_tile_staged_ptrs(gnx_state* h, void** rec, void** z, void** geno);
 int gnx_tile_import_dev(gnx_state* h, int64_t n, const void* rec, const void* z,

@@ -353,14 +353,119 @@ def neighbour_lists(x, y, radius, dtype=np.float32):
     return out
 
 
+def hash_grid(dim, radius):
+    """geometry of the device's hash grid (csrc/gnx_api.hip: setup_hash_grid):
+    cell size >= mating radius, at most 2048 cells per axis"""
+    W, H = dim
+    cs = float(radius) * (1.0 + 1e-9) if radius > 0 else 8.0
+    cs = max(cs, max(W, H) / 2048.0)
+    inv_cs = 1.0 / cs
+    return inv_cs, max(1, int(np.ceil(W / cs))), max(1, int(np.ceil(H / cs)))
+
+
+def cell_of(x, y, inv_cs, ncx, ncy):
+    """gnx_cell_of: (int)((double)x * inv_cs), clamped to the last cell"""
+    cx = np.minimum(ncx - 1, (np.asarray(x, dtype=np.float32).astype(np.float64)
+                              * inv_cs).astype(np.int64))
+    cy = np.minimum(ncy - 1, (np.asarray(y, dtype=np.float32).astype(np.float64)
+                              * inv_cs).astype(np.int64))
+    return cy * ncx + cx, cx, cy
+
+
+def mate_tries(M):
+    """index draws before the exact scan: 4 * clamp(M // 8, 8, 2048)"""
+    return 4 * np.clip(np.asarray(M, dtype=np.int64) >> 3, 8, 2048)
+
+
+def choose_mates_uniform(x, y, ids, radius, seed, step, dim, focal=None):
+    """The build's uniform mate choice (utils/spatial.py:232-242 picks
+    np.random.choice among the neighbours within the radius): rejection sampling in
+    index space.  Candidates of a focal individual = the individuals in the 3x3 block
+    of hash cells around its own, in CANONICAL order (cell rows ascending, cells
+    ascending inside a row, ids ascending inside a cell); the focal draws indices
+    (w * M) >> 32 from its Philox stream (seed, id, step, OP_MATE_PICK) until the
+    candidate drawn lies within the radius and is not itself; after T = mate_tries(M)
+    rejections it takes the ((w_T * m) >> 32)-th of the m in-radius candidates in
+    canonical order (w_T = the first word of Philox block T/4).
+    focal: optional mask of the individuals that need a mate (others get -1)."""
+    import philox as P
+    F = np.float32
+    x = np.asarray(x, dtype=F)
+    y = np.asarray(y, dtype=F)
+    ids = np.asarray(ids, dtype=np.int64)
+    n = x.size
+    mate = np.full(n, -1, dtype=np.int64)
+    if n < 2:
+        return mate
+    inv_cs, ncx, ncy = hash_grid(dim, radius)
+    cell, cx, cy = cell_of(x, y, inv_cs, ncx, ncy)
+    order = np.lexsort((ids & 0xffffffff, cell))            # canonical order of the slots
+    cell_sorted = cell[order]
+    cell_start = np.searchsorted(cell_sorted, np.arange(ncx * ncy + 1))
+    foc = np.arange(n) if focal is None else np.nonzero(np.asarray(focal, dtype=bool))[0]
+    if foc.size == 0:
+        return mate
+    lo, hi = np.maximum(cx[foc] - 1, 0), np.minimum(cx[foc] + 1, ncx - 1)
+    st = np.zeros((foc.size, 3), np.int64)
+    ln = np.zeros((foc.size, 3), np.int64)
+    for q in range(3):
+        ry = cy[foc] - 1 + q
+        ok = (ry >= 0) & (ry < ncy)
+        ryc = np.clip(ry, 0, ncy - 1)
+        s0 = cell_start[ryc * ncx + lo]
+        s1 = cell_start[ryc * ncx + hi + 1]
+        st[:, q] = np.where(ok, s0, 0)
+        ln[:, q] = np.where(ok, s1 - s0, 0)
+    M = ln.sum(axis=1)
+    r2 = F(radius) * F(radius)
+    found = np.full(foc.size, -1, dtype=np.int64)
+    tries = mate_tries(M)
+    fid = ids[foc].astype(np.uint64)
+    active = M > 1
+    blk = 0
+    while active.any():
+        a = np.nonzero(active & (tries > 4 * blk))[0]
+        if a.size == 0:
+            break
+        w4 = P.philox4x32(seed, fid[a], P.block_index(step, P.OP_MATE_PICK, blk)).astype(
+            np.uint64)
+        for t in range(4):
+            live = active[a]
+            if not live.any():
+                break
+            aa = a[live]
+            j = ((w4[live, t] * M[aa].astype(np.uint64)) >> np.uint64(32)).astype(np.int64)
+            slot = np.where(j < ln[aa, 0], st[aa, 0] + j,
+                            np.where(j < ln[aa, 0] + ln[aa, 1], st[aa, 1] + (j - ln[aa, 0]),
+                                     st[aa, 2] + (j - ln[aa, 0] - ln[aa, 1])))
+            c = order[slot]
+            dx = x[c] - x[foc[aa]]
+            dy = y[c] - y[foc[aa]]
+            ok = (c != foc[aa]) & ((dx * dx + dy * dy) <= r2)
+            found[aa[ok]] = c[ok]
+            active[aa[ok]] = False
+        blk += 1
+    for k in np.nonzero(active)[0]:                 # exact fallback
+        i = foc[k]
+        c = np.concatenate([order[st[k, q]:st[k, q] + ln[k, q]] for q in range(3)])
+        dx = x[c] - x[i]
+        dy = y[c] - y[i]
+        inr = c[(c != i) & ((dx * dx + dy * dy) <= r2)]
+        if inr.size:
+            w = int(P.philox4x32(seed, fid[k:k + 1],
+                                 P.block_index(step, P.OP_MATE_PICK, int(tries[k]) // 4))[0, 0])
+            found[k] = inr[(w * inr.size) >> 32]
+    mate[foc] = found
+    return mate
+
+
 def choose_mates(x, y, ids, radius, seed, step, mode='uniform',
-                 dtype=np.float32):
+                 dtype=np.float32, dim=None, focal=None):
     """For each individual with >= 1 other within radius pick one mate.
 
     mode 'uniform'  : utils/spatial.py:232-242 picks np.random.choice(opts);
-                      the build picks the candidate with the smallest
-                      32-bit pair_hash(seed, step, id_focal, id_cand) - uniform over
-                      the candidate set and independent of candidate order.
+                      the build samples indices of a canonical candidate list until
+                      one lies within the radius (choose_mates_uniform; needs dim).
     mode 'nearest'  : utils/spatial.py:194-203 (ties -> smaller id).
     mode 'inverse'  : utils/spatial.py:209-229, P(j) ~ (r - d_ij) over
                       candidates with d > 0; the build picks
@@ -368,6 +473,9 @@ def choose_mates(x, y, ids, radius, seed, step, mode='uniform',
                       (Efraimidis-Spirakis weighted choice).
     Returns mate index per individual (-1 = none)."""
     from philox import pair_hash, u01
+    if mode == 'uniform':
+        assert dim is not None, "uniform mate choice needs the landscape dim (W, H)"
+        return choose_mates_uniform(x, y, ids, radius, seed, step, dim, focal=focal)
     x = np.asarray(x, dtype=dtype)
     y = np.asarray(y, dtype=dtype)
     ids = np.asarray(ids, dtype=np.uint64)
@@ -376,11 +484,7 @@ def choose_mates(x, y, ids, radius, seed, step, mode='uniform',
     for i, nb in enumerate(nbs):
         if nb.size == 0:
             continue
-        if mode == 'uniform':
-            h = pair_hash(seed, step, ids[i], ids[nb])
-            order = np.lexsort((ids[nb], h))
-            mate[i] = nb[order[0]]
-        elif mode == 'nearest':
+        if mode == 'nearest':
             dx = x[nb] - x[i]
             dy = y[nb] - y[i]
             d2 = dx * dx + dy * dy

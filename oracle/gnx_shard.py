@@ -96,18 +96,36 @@ class OracleShard:
         if rec.size:
             self.s.max_id = max(self.s.max_id, int(rec['id'].max()))
 
-    def export_halo(self, width):
+    def export_halo(self):
+        """Whole hash cells: a neighbour tile needs every individual whose cell lies
+        within 2 cells of the tile's own cell range (csrc/gnx_tile.hip, k_mark_halo):
+        1 ring for the candidates of its own focal individuals, 1 more so that the
+        ghosts its individuals can choose have complete candidate lists themselves."""
         s = self.s
-        x0, y0, x1, y1 = self._box()
-        w = F(width)
+        inv_cs, ncx, ncy = O.hash_grid((s.W, s.H), s.p.mating_radius)
+        _, cxi, cyi = O.cell_of(s.x, s.y, inv_cs, ncx, ncy)
+        tw, th = s.W // self.C, s.H // self.R
+
+        def span(k, size, n, ncell):
+            if k < 0 or k >= n:
+                return None
+            lo = F(k * size)
+            hi = np.nextafter(F((k + 1) * size), F(0))
+            c0 = min(ncell - 1, int(np.float64(lo) * inv_cs))
+            c1 = min(ncell - 1, int(np.float64(hi) * inv_cs))
+            return c0 - 2, c1 + 2
         own = ~self.ghost
-        Lf = (self.c > 0) & (s.x - x0 < w)
-        Rt = (self.c < self.C - 1) & (x1 - s.x <= w)
-        Up = (self.r > 0) & (s.y - y0 < w)
-        Dn = (self.r < self.R - 1) & (y1 - s.y <= w)
-        m = (Lf * (1 << 3) + Rt * (1 << 5) + Up * (1 << 1) + Dn * (1 << 7)
-             + (Lf & Up) * (1 << 0) + (Rt & Up) * (1 << 2) + (Lf & Dn) * (1 << 6)
-             + (Rt & Dn) * (1 << 8)).astype(np.int32)
+        m = np.zeros(s.N, np.int32)
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                if dx == 0 and dy == 0:
+                    continue
+                sx = span(self.c + dx, tw, self.C, ncx)
+                sy = span(self.r + dy, th, self.R, ncy)
+                if sx is None or sy is None:
+                    continue
+                need = (cxi >= sx[0]) & (cxi <= sx[1]) & (cyi >= sy[0]) & (cyi <= sy[1])
+                m |= (need.astype(np.int32) << ((dy + 1) * 3 + (dx + 1)))
         m = np.where(own, m, 0)
         return self._records(m != 0, m)
 

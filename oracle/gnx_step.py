@@ -133,31 +133,11 @@ def sort_by_cell(s):
     _permute(s, order)
 
 
-def choose_mates_fast(s):
-    """choose_mates(mode='uniform') with a KD-tree for the neighbour lists
-    (the reference's own data structure, utils/spatial.py:187-189)."""
-    n = s.N
-    mate = np.full(n, -1, dtype=np.int64)
-    if n < 2:
-        return mate
-    pts = np.stack([s.x, s.y], 1).astype(np.float64)
-    pr = cKDTree(pts).query_pairs(float(F(s.p.mating_radius)), output_type='ndarray')
-    if len(pr) == 0:
-        return mate
-    # exact f32 distance test, as the device evaluates it
-    dx = s.x[pr[:, 1]] - s.x[pr[:, 0]]
-    dy = s.y[pr[:, 1]] - s.y[pr[:, 0]]
-    r = F(s.p.mating_radius)
-    pr = pr[(dx * dx + dy * dy) <= r * r]
-    foc = np.concatenate([pr[:, 0], pr[:, 1]])
-    cand = np.concatenate([pr[:, 1], pr[:, 0]])
-    ids = s.id.astype(np.uint64)
-    h = P.pair_hash(s.seed, s.step, ids[foc], ids[cand])
-    order = np.lexsort((ids[cand], h, foc))
-    foc_s, cand_s = foc[order], cand[order]
-    first = np.concatenate([[True], foc_s[1:] != foc_s[:-1]])
-    mate[foc_s[first]] = cand_s[first]
-    return mate
+def choose_mates_fast(s, focal=None):
+    """the build's uniform mate choice (index sampling over the canonical candidate
+    list, oracle/gnx_oracle.py: choose_mates_uniform)"""
+    return O.choose_mates_uniform(s.x, s.y, s.id, s.p.mating_radius, s.seed, s.step,
+                                  (s.W, s.H), focal=focal)
 
 
 def find_pairs(s):

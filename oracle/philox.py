@@ -35,6 +35,7 @@ OP_DEATH = 6
 OP_INIT = 7           # initial positions / sex
 OP_MOVE_SURF = 8
 OP_DISP_SURF = 9      # blk = attempt number
+OP_MATE_PICK = 10     # index draws of the uniform mate choice (32 words + 1 fallback word)
 
 
 def block_index(step, op, blk=0):

@@ -73,7 +73,7 @@ def test_everyone_in_one_cell():
     mate, pairs = dev.op_find_pairs(keep)
     from test_gpu_parity import _slot_maps
     o = _slot_maps(dev, ids)
-    exp = O.choose_mates(x, y, ids, r, 4, 0)
+    exp = O.choose_mates(x, y, ids, r, 4, 0, dim=(64, 64))
     got = np.full(n, -2)
     got[o] = np.where(mate >= 0, o[np.maximum(mate, 0)], -1)
     np.testing.assert_array_equal(got[keep], exp[keep])

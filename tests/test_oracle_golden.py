@@ -240,7 +240,7 @@ def test_nearest_mate_matches_kdtree():
 
 
 def test_uniform_mate_choice_is_uniform():
-    # chi-square of the hash-ranked choice over candidate positions
+    # chi-square of the index-sampled choice over candidate positions
     rng = np.random.RandomState(2)
     n = 600
     x = rng.rand(n) * 20
@@ -248,7 +248,7 @@ def test_uniform_mate_choice_is_uniform():
     counts = np.zeros(4)
     tot = 0
     for step in range(30):
-        mate = O.choose_mates(x, y, np.arange(n) + 1000, 1.2, 77, step)
+        mate = O.choose_mates(x, y, np.arange(n) + 1000, 1.2, 77, step, dim=(20, 20))
         nbs = O.neighbour_lists(x, y, 1.2)
         for i in range(n):
             if len(nbs[i]) == 4:
@@ -397,3 +397,35 @@ def test_stats_oracle_vs_reference():
     assert float(np.mean(O.stats_het(g))) == float(d['het_mean'])
     np.testing.assert_array_equal(O.stats_maf(g), d['maf'])
     np.testing.assert_allclose(O.stats_ld(g), d['ld'], rtol=1e-10, atol=1e-14, equal_nan=True)
+
+
+def test_uniform_mate_choice_properties():
+    """index sampling: a mate iff a neighbour exists, always within the radius, the same
+    (by id) however the individuals are ordered, and the exact fallback when almost all
+    candidates of the 3x3 cells are out of reach"""
+    rng = np.random.RandomState(8)
+    n, W, H, r = 1500, 40, 30, 1.7
+    x = (rng.rand(n) * W).astype(np.float32)
+    y = (rng.rand(n) * H).astype(np.float32)
+    # a dense clump next to a loner whose only neighbour is 1 of ~400 candidates
+    x[:400] = 20.0 + rng.rand(400) * 0.8
+    y[:400] = 12.0 + rng.rand(400) * 0.8
+    x[400], y[400] = 18.35, 13.9
+    x[401], y[401] = 18.40, 13.95
+    ids = rng.permutation(10**5)[:n]
+    mate = O.choose_mates(x, y, ids, r, 5, 3, dim=(W, H))
+    nbs = O.neighbour_lists(x, y, r)
+    has = np.array([len(v) > 0 for v in nbs])
+    np.testing.assert_array_equal(mate >= 0, has)
+    for i in np.nonzero(has)[0]:
+        assert mate[i] in nbs[i]
+    perm = rng.permutation(n)
+    mate_p = O.choose_mates(x[perm], y[perm], ids[perm], r, 5, 3, dim=(W, H))
+    np.testing.assert_array_equal(np.where(mate_p >= 0, ids[perm][np.maximum(mate_p, 0)], -1),
+                                  np.where(mate >= 0, ids[np.maximum(mate, 0)], -1)[perm])
+    focal = rng.rand(n) < 0.3
+    mate_f = O.choose_mates(x, y, ids, r, 5, 3, dim=(W, H), focal=focal)
+    np.testing.assert_array_equal(mate_f[focal], mate[focal])
+    assert (mate_f[~focal] == -1).all()
+    # different steps give different picks
+    assert (O.choose_mates(x, y, ids, r, 5, 4, dim=(W, H)) != mate).mean() > 0.3

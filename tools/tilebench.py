@@ -21,7 +21,7 @@ import torch
 for it in range(6):
     tm('age', dev.age); tm('move', dev.move)
     tm('export_migrants', lambda: dev.tile_export_migrants(True))
-    tm('export_halo', lambda: dev.tile_export_halo(20.0))
+    tm('export_halo', lambda: dev.tile_export_halo())
     P, B = tm('tile_pairs', lambda: dev.tile_pairs(False))
     ids, nb = tm('pair_info', dev.tile_pair_info)
     goff = tm('searchsorted_cpu', lambda: (torch.searchsorted(torch.from_numpy(ids), torch.from_numpy(ids))).numpy().astype(np.int64))
