@@ -162,6 +162,67 @@ def cpu_baseline(budget_s=20.0):
                        '1 thread of %d host cores' % (steps, W, H, N, L, os.cpu_count()))
 
 
+def model_api_params(cfg, name, T):
+    """the workload as a Geonomics parameters dict (what a user's script would hold)"""
+    import geonomics_amd as gnx
+    from geonomics_amd.sim import params as P
+    W, H, L, N = cfg['W'], cfg['H'], cfg['L'], cfg['N']
+    sp = {'genomes': True, 'n_traits': cfg['n_traits'],
+          'movement_surface': bool(cfg['move_surf'])}
+    d = P.default_params_dict(layers=[{'type': 'defined'}, {'type': 'defined'}], species=[sp])
+    lyr0 = smooth_field(W, H, 1) * 0.5 + 0.5
+    lyr1 = np.tile(np.linspace(0, 1, W), (H, 1))
+    d['landscape']['main']['dim'] = (W, H)
+    d['landscape']['layers']['lyr_0']['init']['defined']['rast'] = lyr0.astype(np.float64)
+    d['landscape']['layers']['lyr_1']['init']['defined']['rast'] = lyr1
+    s = d['comm']['species']['spp_0']
+    s['init'].update({'N': N, 'K_layer': 'lyr_0', 'K_factor': N / float(lyr0.sum())})
+    s['mating'].update({'mating_radius': 10, 'b': 0.2, 'n_births_fixed': True,
+                        'n_births_distr_lambda': 1})
+    if cfg['move_surf']:
+        s['movement']['move_surf'].update({'layer': 'lyr_0', 'mixture': True,
+                                           'vm_distr_kappa': 12})
+    s['gen_arch'].update({'L': L, 'r_distr_alpha': None, 'r_distr_beta': None,
+                          'n_recomb_sims': cfg['n_paths'], 'use_tskit': False, 'mu_neut': 0,
+                          'mu_delet': 0})
+    for t in range(cfg['n_traits']):
+        s['gen_arch']['traits']['trait_%i' % t].update(
+            {'layer': 'lyr_1', 'n_loci': cfg['loci_per_trait'], 'alpha_distr_sigma': 0})
+    d['model'].update({'T': T, 'burn_T': 30, 'seed': {'num': 42}})
+    return gnx.make_params_dict(d, name)
+
+
+def model_api_measure(cfg, name, steps, warmup=5):
+    """SURVEY 8(d)'s definition of the metric, literally: sum of N_t over the wall time of
+    Model.walk(T, 'main') after make_model and the burn-in, i.e. at the model's
+    equilibrium and through the Geonomics API (structs/species.py on the C-ABI)."""
+    import geonomics_amd as gnx
+    os.environ.setdefault('GNX_CAP_FACTOR', '2.0')
+    t0 = time.time()
+    mod = gnx.make_model(model_api_params(cfg, name, steps))
+    mod.walk(10000, 'burn', verbose=False)
+    spp = mod.comm[0]
+    n_burn = len(spp.Nt)
+    mod.walk(warmup, 'main', verbose=False)
+    spp._dev.synchronize()
+    setup = time.time() - t0
+    n0 = len(spp.Nt)
+    t1 = time.perf_counter()
+    mod.walk(steps, 'main', verbose=False)
+    spp._dev.synchronize()
+    dt = time.perf_counter() - t1
+    ind_steps = float(sum(spp.Nt[n0 - 1:n0 - 1 + steps]))
+    out = {'value': ind_steps / dt, 'unit': 'individual-timesteps/s',
+           'ms_per_step': 1e3 * dt / steps, 'steps': steps,
+           'state': 'equilibrium: make_model, %d burn-in steps, %d main steps, then timed '
+                    'Model.walk' % (n_burn, warmup),
+           'mean_N': ind_steps / steps, 'births_per_step': float(np.mean(spp.n_births[-steps:])),
+           'setup_s': round(setup, 1)}
+    for s_ in mod.comm.values():
+        s_._dev.close()
+    return out, mod
+
+
 def measured_copy_bandwidth(torch, nbytes=2 << 30, reps=5):
     """read + write bytes / time of a 2-GiB device-to-device copy (GB/s)"""
     try:
@@ -189,6 +250,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='c4_metric', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-model-api', action='store_true',
+                    help='skip the second measurement through Model.walk (N = 1 only)')
     args = ap.parse_args()
 
     import torch
@@ -341,8 +404,17 @@ def main():
                                              for k, v in stepper.phase_s.items()}
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
+        if world == 1 and not args.no_model_api:
+            # the same workload through the drop-in API, at the model's own equilibrium
+            dev.close()
+            dev = None
+            try:
+                out['model_api'], _ = model_api_measure(cfg, args.workload, args.steps)
+            except Exception as e:      # the contract line must still be printed
+                out['model_api'] = {'error': '%s: %s' % (type(e).__name__, e)}
         print(json.dumps(out))
-    dev.close()
+    if dev is not None:
+        dev.close()
     if dist is not None:
         dist.destroy_process_group()
 

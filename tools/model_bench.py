@@ -17,31 +17,11 @@ from geonomics_amd.sim import params as P              # noqa: E402
 name = sys.argv[1] if len(sys.argv) > 1 else 'c4_metric'
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 cfg = bench.WORKLOADS[name]
-W, H, L, N = cfg['W'], cfg['H'], cfg['L'], cfg['N']
-sp = {'genomes': True, 'n_traits': cfg['n_traits'], 'movement_surface': bool(cfg['move_surf'])}
-d = P.default_params_dict(layers=[{'type': 'defined'}, {'type': 'defined'}], species=[sp])
-lyr0 = bench.smooth_field(W, H, 1) * 0.5 + 0.5
-lyr1 = np.tile(np.linspace(0, 1, W), (H, 1))
-d['landscape']['main']['dim'] = (W, H)
-d['landscape']['layers']['lyr_0']['init']['defined']['rast'] = lyr0.astype(np.float64)
-d['landscape']['layers']['lyr_1']['init']['defined']['rast'] = lyr1
-s = d['comm']['species']['spp_0']
-s['init'].update({'N': N, 'K_layer': 'lyr_0', 'K_factor': N / float(lyr0.sum())})
-s['mating'].update({'mating_radius': 10, 'b': 0.2, 'n_births_fixed': True,
-                    'n_births_distr_lambda': 1})
-if cfg['move_surf']:
-    s['movement']['move_surf'].update({'layer': 'lyr_0', 'mixture': True, 'vm_distr_kappa': 12})
-s['gen_arch'].update({'L': L, 'r_distr_alpha': None, 'r_distr_beta': None,
-                      'n_recomb_sims': cfg['n_paths'], 'use_tskit': False, 'mu_neut': 0,
-                      'mu_delet': 0})
-for t in range(cfg['n_traits']):
-    s['gen_arch']['traits']['trait_%i' % t].update({'layer': 'lyr_1',
-                                                    'n_loci': cfg['loci_per_trait'],
-                                                    'alpha_distr_sigma': 0})
-d['model'].update({'T': T, 'burn_T': 30, 'seed': {'num': 42}})
+W, H = cfg['W'], cfg['H']
+d = bench.model_api_params(cfg, name, T)
 os.environ.setdefault('GNX_CAP_FACTOR', '2.0')
 t0 = time.time()
-mod = gnx.make_model(gnx.make_params_dict(d, name))
+mod = gnx.make_model(d)
 t1 = time.time()
 mod.walk(10000, 'burn', verbose=False)
 spp = mod.comm[0]
