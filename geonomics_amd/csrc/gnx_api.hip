@@ -183,6 +183,7 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
   h->W64 = cfg->L > 0 ? gnx_words_per_hom(cfg->L) : 0;
   const int64_t cap = cfg->cap_inds;
   HIPCHK(hipStreamCreate(&h->stream));
+  HIPCHK(hipStreamCreate(&h->stream2));
   h->own_stream = true;
   for (int k = 0; k < 2; ++k) GNXCHK(alloc_soa(&h->soa[k], cap, cfg->n_layers, cfg->n_traits));
   GNXCHK(dalloc(&h->rast, (size_t)cfg->n_layers * cfg->W * cfg->H));
@@ -268,12 +269,16 @@ extern "C" void gnx_destroy(gnx_state* h) {
   for (int k = 0; k < GNX_K_COUNT; ++k) timers_resolve(h, k);
   for (hipEvent_t e : h->ev_free) (void)hipEventDestroy(e);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
+  if (h->stream2) (void)hipStreamDestroy(h->stream2);
+  h->stream2 = nullptr;
   delete h;
 }
 
 extern "C" int gnx_set_stream(gnx_state* h, void* hip_stream) {
   HIPCHK(hipStreamSynchronize(h->stream));
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
+  if (h->stream2) (void)hipStreamDestroy(h->stream2);
+  h->stream2 = nullptr;
   h->stream = (hipStream_t)hip_stream;
   h->own_stream = false;
   return 0;

@@ -98,6 +98,10 @@ struct gnx_state {
   gnx_species_params sp{};
   bool have_sp = false;
   hipStream_t stream = nullptr;
+  // tiled runs: while this step's crossover is in flight on `stream`, the gamete service
+  // for the neighbour tiles (requests, lookups, cuts, puts) runs on `stream2`
+  hipStream_t stream2 = nullptr;
+  bool xo_pending = false;
   bool own_stream = false;
   int W64 = 0;                 // u64 words per homologue
   int64_t N = 0;

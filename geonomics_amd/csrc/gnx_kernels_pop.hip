@@ -1040,6 +1040,14 @@ int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* 
                        h->pairs, h->off_pair, h->boff, tiled ? h->pair_goff : nullptr,
                        h->free_rows, h->off_parent, h->off_keys, h->off_start, rq);
     gnx_time_end(h, GNX_K_OFFSPRING, (double)B * (60.0 + 8.0 * c.n_layers));
+    if (tiled && genomes) {
+      // the number of gamete requests is known before the crossover is launched: the host
+      // layer serves the neighbour tiles while the crossover runs
+      HIPCHK(hipMemcpyAsync(h->h_pin, h->req_count, sizeof(int32_t), hipMemcpyDeviceToHost,
+                            h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      h->n_req = *(int32_t*)h->h_pin;
+    }
   }
   HIPCHK(hipGetLastError());
   if (genomes || inject) {

@@ -18,7 +18,6 @@
 // All random draws are keyed by individual id, all choices are order-
 // independent, so a tiled run reproduces the single-GPU run bit for bit.
 #include <algorithm>
-#include <chrono>
 #include "gnx_internal.h"
 #include "gnx_rng.h"
 
@@ -381,39 +380,38 @@ extern "C" int gnx_set_bins(gnx_state* h, int32_t which, const int32_t* in) {
 
 extern "C" int gnx_density_bin_count(gnx_state* h) { return h->lat.nbx * h->lat.nby; }
 
+// While the crossover launched by gnx_tile_offspring(_dev) is in flight on the handle's
+// stream, the entry points of the gamete service run on a second stream (they touch
+// parent rows and the ghost-mate halves of child rows only, which the crossover leaves
+// alone); gnx_tile_finish_births joins the two.
+struct SideStream {
+  gnx_state* h;
+  hipStream_t saved;
+  explicit SideStream(gnx_state* hh) : h(hh), saved(hh->stream) {
+    if (h->xo_pending && h->stream2) h->stream = h->stream2;
+  }
+  ~SideStream() { h->stream = saved; }
+};
+
 extern "C" int gnx_tile_offspring(gnx_state* h, int32_t burn, int64_t id_base,
                                   const int64_t* pair_goff, int64_t* n_requests) {
   *n_requests = 0;
   int64_t P = h->n_pairs, B = 0;
   h->birth_first_slot = h->N;
-  static const bool dbg = getenv("GNX_DEBUG_TIMING") != nullptr;
-  auto now = [] { return std::chrono::duration<double, std::milli>(
-                      std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  double t0 = now();
-  if (dbg) (void)hipStreamSynchronize(h->stream);
-  double t1 = now();
+  h->n_req = 0;
   if (P > 0)
     GNXCHK(gnx_h2d(h, h->pair_goff, pair_goff, P * sizeof(int64_t)));
-  double t2 = now();
   GNXCHK(gnx_l_mate(h, burn != 0, false, 0, &B, id_base, true));
-  if (dbg) {
-    (void)hipStreamSynchronize(h->stream);
-    fprintf(stderr, "[tile_offspring] wait-prev %.3f  h2d %.3f  mate %.3f ms (P=%lld B=%lld)\n",
-            t1 - t0, t2 - t1, now() - t2, (long long)P, (long long)B);
-  }
   h->last_births = B;
-  if (B > 0 && !burn && has_rows(h)) {
-    HIPCHK(hipMemcpyAsync(h->h_pin, h->req_count, sizeof(int32_t), hipMemcpyDeviceToHost,
-                          h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    *n_requests = *(int32_t*)h->h_pin;
-  }
-  h->n_req = *n_requests;
+  if (B == 0) h->n_req = 0;
+  *n_requests = h->n_req;
+  h->xo_pending = B > 0 && !burn && has_rows(h);
   return 0;
 }
 
 extern "C" int gnx_tile_get_requests(gnx_state* h, int64_t* pid, int32_t* child_k, int32_t* key,
                                      uint8_t* start, float* px, float* py) {
+  SideStream side(h);
   int64_t n = h->n_req;
   if (n == 0) return 0;
   GNXCHK(gnx_d2h(h, pid, h->req_pid, n * 8));
@@ -481,6 +479,7 @@ k_make_gametes(int64_t n, int W16, const u64x2* __restrict__ G, const int32_t* _
 extern "C" int gnx_tile_serve_gametes(gnx_state* h, int64_t n, const int64_t* parent_ids,
                                       const int32_t* keys, const uint8_t* starts,
                                       uint64_t* out) {
+  SideStream side(h);
   if (n == 0) return 0;
   if (!has_rows(h) || h->n_paths == 0) {
     gnx_set_error("gnx_tile_serve_gametes: genomes / paths not set");
@@ -546,6 +545,7 @@ __global__ void k_put_gametes(int64_t n, int W16, const u64x2* in, u64x2* G, con
 
 extern "C" int gnx_tile_put_gametes(gnx_state* h, int64_t n, const int32_t* child_k,
                                     const uint64_t* data) {
+  SideStream side(h);
   if (n == 0) return 0;
   for (int64_t q = 0; q < n; ++q)
     if (child_k[q] < 0 || child_k[q] >= h->last_births) {
@@ -572,6 +572,9 @@ extern "C" int gnx_tile_put_gametes(gnx_state* h, int64_t n, const int32_t* chil
 // phenotypes of this step's offspring (all gametes are in place) and the bins
 // of the tile's own individuals (ghosts skipped) for the N density
 extern "C" int gnx_tile_finish_births(gnx_state* h, int32_t burn) {
+  // the service entry points return with stream2 idle; what follows is ordered behind
+  // the crossover on the main stream
+  h->xo_pending = false;
   int64_t B = h->last_births;
   if (B > 0 && !burn && has_rows(h) && h->cfg.n_traits > 0) {
     // local gametes left their trait alleles in tbits (crossover epilogue); only
@@ -894,18 +897,15 @@ extern "C" int gnx_tile_offspring_dev(gnx_state* h, int32_t burn, int64_t id_bas
   *n_requests = 0;
   int64_t P = h->n_pairs, B = 0;
   h->birth_first_slot = h->N;
+  h->n_req = 0;
   if (P > 0)
     HIPCHK(hipMemcpyAsync(h->pair_goff, pair_goff_dev, P * sizeof(int64_t),
                           hipMemcpyDeviceToDevice, h->stream));
   GNXCHK(gnx_l_mate(h, burn != 0, false, 0, &B, id_base, true));
   h->last_births = B;
-  if (B > 0 && !burn && has_rows(h)) {
-    HIPCHK(hipMemcpyAsync(h->h_pin, h->req_count, sizeof(int32_t), hipMemcpyDeviceToHost,
-                          h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    *n_requests = *(int32_t*)h->h_pin;
-  }
-  h->n_req = *n_requests;
+  if (B == 0) h->n_req = 0;
+  *n_requests = h->n_req;
+  h->xo_pending = B > 0 && !burn && has_rows(h);     // the crossover is still running
   return 0;
 }
 
@@ -926,6 +926,7 @@ __global__ void k_pack_requests(int64_t n, const int32_t* idx, const int64_t* pi
 
 // requests of this step grouped by the rank that owns the ghost mate
 extern "C" int gnx_tile_group_requests(gnx_state* h, int64_t* counts, void** req_dev) {
+  SideStream side(h);
   GNXCHK(check_tiles(h, "gnx_tile_group_requests"));
   for (int p = 0; p < n_tiles(h); ++p) counts[p] = 0;
   *req_dev = nullptr;
@@ -1001,6 +1002,7 @@ k_make_gametes_req(int64_t n, int W16, const u64x2* __restrict__ G,
 // device buffer owned by the handle; *out_dev stays valid until the next call
 extern "C" int gnx_tile_serve_gametes_dev(gnx_state* h, int64_t n, const void* req_dev,
                                           void** out_dev) {
+  SideStream side(h);
   *out_dev = nullptr;
   if (n == 0) return 0;
   if (!has_rows(h) || h->n_paths == 0) {
@@ -1044,6 +1046,7 @@ extern "C" int gnx_tile_serve_gametes_dev(gnx_state* h, int64_t n, const void* r
 
 // the gametes answering this tile's grouped requests, in the grouped order
 extern "C" int gnx_tile_put_gametes_dev(gnx_state* h, int64_t n, const void* data_dev) {
+  SideStream side(h);
   if (n == 0) return 0;
   if (n != h->n_req) {
     gnx_set_error("gnx_tile_put_gametes_dev: %lld gametes for %lld requests", (long long)n,

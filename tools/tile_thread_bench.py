@@ -14,7 +14,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
-os.environ['GNX_TILE_PROFILE'] = '1'
+os.environ.setdefault('GNX_TILE_PROFILE', '1')
 import torch                                         # noqa: E402
 import bench                                         # noqa: E402
 from _local_comm import Hub, LocalComm               # noqa: E402
