@@ -211,6 +211,13 @@ class Model:
         """reference sim/model.py:1185-1186"""
         self._data_collector._write_data(self.comm, self.land, self.it)
 
+    def remove_individuals(self, spp=0, n=None, n_left=None, individs=None):
+        """remove n random individuals, all but n_left, or the listed ids
+        (reference sim/model.py:3179-3225)"""
+        spp = self.comm[self._get_spp_num(spp)]
+        spp._remove_individuals(individs=individs, n=n, n_left=n_left,
+                                verbose=self._rank == 0)
+
     def write_gendata(self, filepath, spp=0, n=None, include_fixed_sites=True):
         """VCF / FASTA (by extension) of all or n random individuals
         (reference sim/model.py:3342-3396)"""

@@ -420,6 +420,36 @@ class Species:
     def _set_z(self):
         self._dev.set_z()
 
+    def _remove_individuals(self, individs=None, n=None, n_left=None, keep_sites_tab=False,
+                            check_extinct=False, verbose=False):
+        """remove listed or randomly drawn individuals (reference
+        structs/species.py:1559-1640); their genome rows go back on the free stack"""
+        given = [p is not None for p in (individs, n, n_left)]
+        assert sum(given) == 1, ("One of 'individs', 'n', and 'n_left' must be provided, the "
+                                 "other two must be None.")
+        ids = self._dev.download(nat.F_ID)
+        if individs is None:
+            if n_left is not None:
+                assert 0 <= n_left <= len(self), (
+                    "'n_left' must be a number between 0 and the current size of the "
+                    "population (%i)." % len(self))
+                n = len(self) - n_left
+            assert isinstance(n, (int, np.integer)) and n >= 0, (
+                "'n' must either be a non-negative int or None.")
+            assert n <= len(self), ("Cannot remove more Individuals than currently exist "
+                                    "(current population size is %i)." % len(self))
+            individs = self._rng.choice(np.sort(ids), n, replace=False)
+        individs = np.asarray(individs, dtype=np.int64)
+        dead = np.isin(ids, individs)
+        assert dead.sum() == individs.size, 'some of the listed Individuals do not exist'
+        n_b4 = len(self)
+        self._dev.op_mortality(dead.astype(np.uint8))
+        assert n_b4 - len(self) == individs.size
+        if verbose:
+            print('\n%i Individuals successfully removed.\n' % individs.size)
+        if check_extinct and self._check_extinct():
+            self.extinct = True
+
     # -- burn-in spatial test (reference sim/burnin.py:21-91) -------------------------
     def _spatial_update(self):
         m, s = self._dev.spatial_diff_stats()

@@ -353,3 +353,29 @@ def test_run_default_model(tmp_path, monkeypatch, capsys, selection):
         z = mod.get_z()[:, 0]
         assert np.isfinite(z).all() and 0.0 <= z.min() and z.max() <= 1.5
         assert (mod.get_fitness() <= 1).all() and (mod.get_fitness() > 0.9).all()
+
+
+def test_remove_individuals(capsys):
+    """reference sim/model.py:3179-3225 / structs/species.py:1559-1640"""
+    import geonomics_amd as gnx
+    mod = gnx.make_model(small_params(T=5, L=32))
+    mod.walk(10000, 'burn', verbose=False)
+    spp = mod.comm[0]
+    ids = np.array([*spp])
+    g = spp._get_genotypes()
+    gone = ids[[3, 10, 50]]
+    mod.remove_individuals(individs=gone)
+    assert len(spp) == len(ids) - 3 and not set(gone) & set(spp)
+    keep = ~np.isin(ids, gone)
+    np.testing.assert_array_equal(np.array([*spp]), ids[keep])
+    np.testing.assert_array_equal(spp._get_genotypes(), g[keep])      # rows stay attached
+    mod.remove_individuals(n=20)
+    assert len(spp) == len(ids) - 23
+    mod.remove_individuals(n_left=100)
+    assert len(spp) == 100
+    with pytest.raises(AssertionError):
+        mod.remove_individuals(n=5, n_left=3)
+    with pytest.raises(AssertionError):
+        mod.remove_individuals(individs=[10**9])
+    mod.walk(5, 'main', verbose=False)       # the freed genome rows are reused
+    assert len(spp) > 100 and len(set(spp)) == len(spp)
