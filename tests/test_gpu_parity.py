@@ -584,6 +584,7 @@ def test_whole_model_envelopes_vs_reference_on_device():
                                        * (np.arange(L) > 0)))
     ref = dict(burn=[], first=[], main=[])
     mine = dict(burn=[], first=[], main=[])
+    drift_ref, drift_mine = [], []
     for s in range(1, 9):
         nb = int(g['s%i_nburn' % s][0])
         R = g['s%i_Nt' % s]
@@ -610,7 +611,19 @@ def test_whole_model_envelopes_vs_reference_on_device():
         mine['burn'].append(Nt[10:60].mean())
         mine['first'].append(Nt[60:80].mean())
         mine['main'].append(Nt[-50:].mean())
+        # genetic drift: allele frequencies of the neutral loci after 100 generations
+        # (start 0.5; the spread measures 1/(2 Ne), i.e. mate choice, birth and death
+        # variances and recombination all at once)
+        sel = np.concatenate([g['s%i_t%i_loci' % (s, t)] for t in range(3)])
+        neutral = np.setdiff1d(np.arange(L), sel)
+        c1, _ = dev.stats_locus_counts()
+        drift_mine.append((c1 / (2.0 * dev.N))[neutral] - 0.5)
+        drift_ref.append(g['s%i_freq' % s][neutral] - 0.5)
         dev.close()
+    v_ref = np.mean(np.concatenate(drift_ref) ** 2)
+    v_mine = np.mean(np.concatenate(drift_mine) ** 2)
+    # ~380 independent loci each: the two variance estimates carry ~7 % sampling error
+    assert 0.7 < v_mine / v_ref < 1.4, (v_mine, v_ref)
     m = {k: (np.mean(ref[k]), np.mean(mine[k])) for k in ref}
     assert abs(m['burn'][1] / m['burn'][0] - 1) < 0.04, m
     assert abs(m['first'][1] / m['first'][0] - 1) < 0.15, m
