@@ -402,7 +402,7 @@ def main():
         if stepper is not None and stepper.profile:
             out['tile_phase_ms_per_step'] = {k: 1e3 * v / (args.steps + args.warmup + 3)
                                              for k, v in stepper.phase_s.items()}
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:     # rank 0 at N = 1 only
             out['cpu_baseline'] = cpu_baseline()
         if world == 1 and not args.no_model_api:
             # the same workload through the drop-in API, at the model's own equilibrium
