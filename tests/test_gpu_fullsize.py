@@ -115,3 +115,90 @@ def test_step_invariants_at_baseline_sizes(workload):
         dev.close()
         return sig
     assert run() == run()
+
+
+def test_two_tiles_equal_one_device_at_metric_size():
+    """BASELINE configs[4] in small: a 4096 x 2048 landscape with 2 x 10^6 individuals and
+    10^5 loci, once on one device and once as two 2048^2 tiles (threads of this process,
+    tests/_local_comm.py in place of RCCL, device-resident transport).  Genomes carry each
+    founder's id (both homologues, an otherwise empty genome), so the two runs start from
+    the same genomes; after burn-in and main steps with selection the two populations must
+    be identical: ids, positions, ages, phenotypes, per-locus allele counts."""
+    import threading
+    import torch
+    import bench
+    from geonomics_amd import _native as nat
+    from geonomics_amd.parallel import Comm, DeviceShard, TiledStepper
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from _local_comm import Hub, LocalComm
+    cfg = dict(bench.WORKLOADS['c4_metric'])
+    L, grid = cfg['L'], (1, 2)
+    n_burn, n_main = 2, 3
+
+    def tag_genomes(dev):
+        dev.set_recomb_paths(bench.sparse_paths(2000, L, 43, dev.W64))
+        dev.assign_genomes(np.zeros(L, np.int32))
+        ids = dev.download(nat.F_ID)
+        bit = (ids[:, None] >> np.arange(21)[None, :]) & 1
+        who, which = np.nonzero(bit)
+        for hom in (0, 1):
+            dev.mutate(who.astype(np.int64), (TAG0 + which).astype(np.int32),
+                       np.full(who.size, hom, np.uint8))
+        dev.set_z()
+
+    def summary(dev):
+        ids = dev.download(nat.F_ID)
+        o = np.argsort(ids)
+        c1, ch = dev.stats_locus_counts()
+        return dict(ids=ids[o], x=dev.download(nat.F_X)[o], y=dev.download(nat.F_Y)[o],
+                    age=dev.download(nat.F_AGE)[o], z=dev.download(nat.F_Z)[:, o],
+                    c1=c1.astype(np.int64), ch=ch.astype(np.int64))
+
+    def run(world):
+        hub = Hub(world)
+        res, errs = [None] * world, []
+
+        def body(rank):
+            try:
+                torch.cuda.set_device(0)
+                if world > 1:
+                    dev, _, _ = bench.build_device(cfg, seed=42, device=0, grid=grid)
+                else:       # the same landscape and population on one device
+                    whole = dict(cfg, W=cfg['W'] * 2, N=cfg['N'] * 2)
+                    dev, _, _ = bench.build_device(whole, seed=42, device=0)
+                comm = LocalComm(hub, rank) if world > 1 else Comm(None)
+                shard = DeviceShard(dev)
+                # world 1: one tile that spans the whole landscape
+                st = TiledStepper(shard, comm, cfg['W'] * 2, cfg['H'], 10.0, move=True,
+                                  max_id=2 * cfg['N'] - 1, grid=grid if world > 1 else (1, 1),
+                                  fixed_births=1)
+                shard.export_migrants()
+                hist = [st.step(True, False) for _ in range(n_burn)]
+                tag_genomes(dev)
+                shard.has_genomes = True
+                hist += [st.step(False, True) for _ in range(n_main)]
+                res[rank] = (summary(dev), hist)
+                dev.close()
+            except BaseException as e:       # noqa: BLE001
+                errs.append(e)
+                hub.barrier.abort()
+        ths = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+        [t.start() for t in ths]
+        [t.join(timeout=600) for t in ths]
+        if errs:
+            raise errs[0]
+        return res
+
+    one = run(1)[0]
+    two = run(2)
+    assert one[1] == two[0][1] == two[1][1]               # global (N, births, deaths) per step
+    ids = np.concatenate([r[0]['ids'] for r in two])
+    o = np.argsort(ids)
+    np.testing.assert_array_equal(ids[o], one[0]['ids'])
+    for k in ('x', 'y', 'age'):
+        np.testing.assert_array_equal(np.concatenate([r[0][k] for r in two])[o], one[0][k], k)
+    np.testing.assert_array_equal(np.concatenate([r[0]['z'] for r in two], axis=1)[:, o],
+                                  one[0]['z'])
+    for k in ('c1', 'ch'):
+        np.testing.assert_array_equal(two[0][0][k] + two[1][0][k], one[0][k], k)
+    assert one[0]['c1'][TAG0:TAG0 + 21].sum() > 10**6 and len(ids) > 1.9e6
