@@ -379,3 +379,45 @@ def test_remove_individuals(capsys):
         mod.remove_individuals(individs=[10**9])
     mod.walk(5, 'main', verbose=False)       # the freed genome rows are reused
     assert len(spp) > 100 and len(set(spp)) == len(spp)
+
+
+def test_two_species_nonsquare_landscape():
+    """two species with their own device state on a non-square landscape; the second has
+    a reproductive age and Poisson births (the queue binds each species' methods: the
+    reference's late-binding lambdas would act on the last species only,
+    sim/model.py:612-656).  (Sexed species are covered at operator level: with the
+    reference's sex assignment, structs/individual.py:110-115, three quarters of the
+    offspring are male and small sexed populations drift to a single sex.)"""
+    import geonomics_amd as gnx
+    from geonomics_amd.sim import params as P
+    W, H = 40, 24
+    d = P.default_params_dict(layers=[{'type': 'defined'}, {'type': 'defined'}],
+                              species=[{'genomes': True, 'n_traits': 1}, {'genomes': True}])
+    d['landscape']['main']['dim'] = (W, H)
+    d['landscape']['layers']['lyr_0']['init']['defined']['rast'] = np.ones((H, W))
+    d['landscape']['layers']['lyr_1']['init']['defined']['rast'] = np.tile(
+        np.linspace(0, 1, W), (H, 1))
+    a, b = d['comm']['species']['spp_0'], d['comm']['species']['spp_1']
+    a['init'].update({'N': 300, 'K_factor': 0.4})
+    a['mating'].update({'mating_radius': 3})
+    a['gen_arch'].update({'L': 32, 'n_recomb_sims': 100, 'use_tskit': False})
+    a['gen_arch']['traits']['trait_0'].update({'layer': 'lyr_1', 'n_loci': 3})
+    b['init'].update({'N': 200, 'K_factor': 0.3})
+    b['mating'].update({'mating_radius': 4, 'repro_age': 1,
+                        'n_births_fixed': False, 'n_births_distr_lambda': 2})
+    b['gen_arch'].update({'L': 20, 'n_recomb_sims': 100, 'use_tskit': False})
+    d['model'].update({'T': 25, 'burn_T': 30, 'seed': {'num': 2}})
+    mod = gnx.make_model(gnx.make_params_dict(d, 'two_spp'))
+    mod.run()
+    s0, s1 = mod.comm[0], mod.comm[1]
+    assert mod.t == 24 and s0.burned and s1.burned and not (s0.extinct or s1.extinct)
+    assert len(s0.Nt) == len(s1.Nt) and s0.Nt != s1.Nt
+    assert 0.5 * 0.4 * W * H < np.mean(s0.Nt[-20:]) < 1.1 * 0.4 * W * H
+    assert 0.4 * 0.3 * W * H < np.mean(s1.Nt[-20:]) < 1.2 * 0.3 * W * H
+    for k, spp in mod.comm.items():
+        xy = mod.get_coords(spp=k)
+        assert (xy[:, 0] < W).all() and (xy[:, 1] < H).all() and (xy >= 0).all()
+        assert mod.get_genotypes(spp=k).shape == (len(spp), spp.gen_arch.L)
+    assert (mod.comm[1]._get_age() >= 0).all()
+    assert mod.get_z(spp=0).shape == (len(s0), 1)
+    assert mod.comm[1].N.shape == (H, W) and mod.comm[0].K.shape == (H, W)
