@@ -44,7 +44,7 @@ EXPORTS = [
     'gnx_tile_export_migrants_dev', 'gnx_tile_export_halo_dev', 'gnx_tile_staged_ptrs',
     'gnx_tile_import_dev', 'gnx_tile_import_ghosts_dev', 'gnx_tile_pair_ptrs',
     'gnx_tile_offspring_dev', 'gnx_tile_group_requests', 'gnx_tile_serve_gametes_dev',
-    'gnx_tile_put_gametes_dev', 'gnx_tile_bins_ptr', 'gnx_set_k_raster',
+    'gnx_tile_put_gametes_dev', 'gnx_tile_bins_ptr', 'gnx_set_k_raster', 'gnx_last_births',
 ]
 
 
@@ -597,6 +597,22 @@ class Device:
         a, n = C.c_void_p(), C.c_int64()
         self._chk(self.lib.gnx_tile_bins_ptr(self.h, C.byref(a), C.byref(n)))
         return a.value, n.value
+
+    def last_births(self, with_gametes=True):
+        """offspring of the last pop_dynamics_mate (call before pop_dynamics_die):
+        child ids [B], parent ids [B,2], path keys [B,2], start homologues [B,2], xy [B,2]"""
+        B = self.counts()[1]
+        child = np.zeros(B, np.int64)
+        par = np.zeros((B, 2), np.int64)
+        keys = np.zeros((B, 2), np.int32)
+        starts = np.zeros((B, 2), np.uint8)
+        xy = np.zeros((B, 2), np.float32)
+        if B:
+            self._chk(self.lib.gnx_last_births(
+                self.h, _ptr(child, C.c_int64), _ptr(par, C.c_int64),
+                _ptr(keys, C.c_int32) if with_gametes else None,
+                _ptr(starts, C.c_uint8) if with_gametes else None, _ptr(xy, C.c_float)))
+        return child, par, keys, starts, xy
 
     # -- statistics ------------------------------------------------------------------
     def stats_locus_counts(self):

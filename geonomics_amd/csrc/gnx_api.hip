@@ -746,6 +746,46 @@ extern "C" int gnx_step(gnx_state* h, int32_t burn, int32_t with_selection) {
   return 0;
 }
 
+// ---- pedigree of the last births (tree-sequence recording on the host; reference
+// structs/species.py:692-736 adds these rows to its tskit tables one offspring at a time)
+__global__ void k_gather_births(int64_t B, int64_t first, GnxSoA s, const int32_t* off_parent,
+                                int64_t* child_id, int64_t* parent_id, float* xy) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= B) return;
+  child_id[k] = s.id[first + k];
+  parent_id[2 * k] = s.id[off_parent[2 * k]];
+  parent_id[2 * k + 1] = s.id[off_parent[2 * k + 1]];
+  xy[2 * k] = s.x[first + k];
+  xy[2 * k + 1] = s.y[first + k];
+}
+
+extern "C" int gnx_last_births(gnx_state* h, int64_t* child_id, int64_t* parent_id, int32_t* keys,
+                               uint8_t* starts, float* xy) {
+  const int64_t B = h->last_births;
+  if (B <= 0) return 0;
+  if (B > h->N) {
+    gnx_set_error("gnx_last_births: call it between gnx_pop_dynamics_mate and _die");
+    return 1;
+  }
+  int64_t *d_c = nullptr, *d_p = nullptr;
+  float* d_xy = nullptr;
+  GNXCHK(dalloc(&d_c, B));
+  GNXCHK(dalloc(&d_p, 2 * B));
+  GNXCHK(dalloc(&d_xy, 2 * B));
+  hipLaunchKernelGGL(k_gather_births, dim3(gnx_grid(B, 256)), dim3(256), 0, h->stream, B,
+                     h->N - B, h->soa[h->cur], h->off_parent, d_c, d_p, d_xy);
+  int rc = gnx_d2h(h, child_id, d_c, B * 8);
+  if (!rc) rc = gnx_d2h(h, parent_id, d_p, 2 * B * 8);
+  if (!rc) rc = gnx_d2h(h, xy, d_xy, 2 * B * 4);
+  if (!rc && keys) rc = gnx_d2h(h, keys, h->off_keys, 2 * B * 4);
+  if (!rc && starts) rc = gnx_d2h(h, starts, h->off_start, 2 * B);
+  (void)hipFree(d_c);
+  (void)hipFree(d_p);
+  (void)hipFree(d_xy);
+  HIPCHK(hipGetLastError());
+  return rc;
+}
+
 extern "C" int gnx_counts(gnx_state* h, int64_t* N, int64_t* births, int64_t* deaths) {
   if (N) *N = h->N - h->n_ghost;
   if (births) *births = h->last_births;

@@ -218,6 +218,35 @@ class Model:
         spp._remove_individuals(individs=individs, n=n, n_left=n_left,
                                 verbose=self._rank == 0)
 
+    def write_tskit_table_collection(self, file_basename, spp=0, sep=','):
+        """the spatial pedigree as <basename>_{NODES,EDGES,SITES,MUTATIONS,INDIVIDUALS}.csv
+        (reference sim/model.py:3449-3486) and, beside them, tskit's text format
+        (<basename>.nodes.txt ..., readable with tskit.load_text)"""
+        spp = self.comm[self._get_spp_num(spp)]
+        if spp._tt is None:
+            raise ValueError("no pedigree was recorded for this Species ('use_tskit' False, "
+                             "not yet burned in, or the model is too large)")
+        spp._tt.write_csv(file_basename, sep=sep)
+        spp._tt.write_text(file_basename)
+
+    def get_tree_sequence(self, spp=0):
+        """tskit.TreeSequence of the recorded pedigree (needs tskit on this machine;
+        reference sim/model.py get_tree_sequence)"""
+        import io
+        import tempfile
+        try:
+            import tskit
+        except ImportError:
+            raise ImportError('get_tree_sequence needs the tskit package; '
+                              'write_tskit_table_collection writes the tables without it')
+        spp = self.comm[self._get_spp_num(spp)]
+        with tempfile.TemporaryDirectory() as d:
+            base = os.path.join(d, 'ts')
+            spp._tt.write_text(base)
+            args = {k: io.StringIO(open('%s.%s.txt' % (base, k)).read())
+                    for k in ('nodes', 'edges', 'sites', 'mutations', 'individuals')}
+            return tskit.load_text(sequence_length=spp.gen_arch.L, strict=False, **args)
+
     def write_gendata(self, filepath, spp=0, n=None, include_fixed_sites=True):
         """VCF / FASTA (by extension) of all or n random individuals
         (reference sim/model.py:3342-3396)"""

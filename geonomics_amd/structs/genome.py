@@ -5,8 +5,9 @@ _make_genomic_architecture:870).
 Everything here is one-off setup; the per-generation work (crossover,
 phenotype, fitness) runs on the GPU from the tables this module uploads:
 bit-packed recombination paths, trait loci / effect sizes, dominance,
-deleterious loci.  Genotypes are tracked in full (the reference's
-`use_tskit=False` mode); tree-sequence recording is out of scope.
+deleterious loci.  Genotypes are tracked in full on the device (the
+reference's `use_tskit=False` mode); with `use_tskit=True` the pedigree is
+also recorded as tree-sequence tables on the host (structs/pedigree.py).
 """
 import bisect
 import warnings
@@ -105,6 +106,15 @@ class Recombinations:
                 out[a:a + m] = np.packbits(bits, axis=1, bitorder='little').view('<u8')
         self._paths = out
 
+    def _breakpoints(self):
+        """CSR list of the loci where each cached path switches homologue
+        (path[l] != path[l-1]; a path starts on homologue 0)"""
+        bits = np.unpackbits(self._paths.view(np.uint8), axis=1, bitorder='little')[:, :self._L]
+        prev = np.concatenate([np.zeros((bits.shape[0], 1), np.uint8), bits[:, :-1]], axis=1)
+        sw = bits != prev
+        off = np.concatenate([[0], np.cumsum(sw.sum(axis=1))]).astype(np.int64)
+        return off, np.nonzero(sw)[1].astype(np.int64)
+
     def _get_path_bits(self, key):
         by = self._paths[key].view(np.uint8)
         return np.unpackbits(by, bitorder='little')[:self._L]
@@ -160,7 +170,9 @@ class GenomicArchitecture:
         self.dom = np.asarray(dom)
         self._use_dom = bool(np.any(self.dom))
         self.sex = g_params.sex
-        self.use_tskit = False
+        # genotypes are tracked in full on the device either way; True additionally
+        # records the spatial pedigree as tree-sequence tables (structs/pedigree.py)
+        self.use_tskit = bool(g_params.get('use_tskit', False))
         self.tskit_simp_interval = g_params.get('tskit_simp_interval', None)
         self.mu_neut = g_params.mu_neut or 0
         self.neut_loci = np.arange(self.L)
@@ -299,10 +311,6 @@ def _make_genomic_architecture(spp_params, land, rng=None):
         assert len(gen_arch_file) == g_params.L, (
             "The length of the custom genomic architecture file must match the "
             "genome length 'L' in the parameters file.")
-    if g_params.get('use_tskit', False):
-        warnings.warn("'use_tskit': True requested; tree-sequence recording is outside "
-                      "the GPU hot path - genotypes are tracked in full on the device "
-                      "(the reference's use_tskit=False mode).")
     g_params['sex'] = spp_params.mating.sex
     recomb_rates = recomb_positions = None
     if gen_arch_file is not None:

@@ -97,6 +97,12 @@ class Species:
                        and self.gen_arch._mu_tot > 0)
         self.mut_log = spp_params.gen_arch.get('mut_log', None) if 'gen_arch' in [
             *spp_params] else None
+        # spatial pedigree (reference use_tskit=True): genotypes are tracked in full on
+        # the device either way; the tree-sequence tables are an observer kept on the
+        # host (structs/pedigree.py) for models small enough to hold them
+        self._tt = None
+        self._record_pedigree = bool(self.gen_arch is not None and
+                                     getattr(self.gen_arch, 'use_tskit', False))
         self._seed = int(seed)
         self._device_ordinal = device
         self._dev = None
@@ -359,6 +365,9 @@ class Species:
         self.n_births.append(int(births))
         if births:
             self.max_ind_idx += int(births)
+        if self._tt is not None and not burn and births > 0:
+            child, par, keys, starts, xy = dev.last_births()
+            self._tt.add_births(self.t, child, par, keys, starts, xy)
         if self.mutate and not burn and births > 0:
             self._do_mutation(n_before, int(births))
         dev.pop_dynamics_die(burn, with_selection)
@@ -397,6 +406,8 @@ class Species:
         if dirty:
             self._upload_gen_arch()
         self._dev.mutate(slots, loci, homs)
+        if self._tt is not None:
+            self._tt.add_mutations(self._dev.download(nat.F_ID)[slots], loci, homs)
         if dirty and ga.traits is not None:
             for s in set(int(v) for v, k in zip(slots, kinds) if k != 'neut'):
                 self._dev.set_z_range(s, 1)
@@ -416,6 +427,29 @@ class Species:
         _genome._check_mutation_rates(ga, est_tot_muts, burn_T, T)
         n = _genome._starting_mutation_counts(len(self), ga.p)
         self._dev.assign_genomes(n)
+        self._start_pedigree()
+
+    # founders of the tree-sequence tables: the population at genome assignment
+    _PEDIGREE_MAX_BITS = 2e8
+
+    def _start_pedigree(self):
+        self._tt = None
+        if not self._record_pedigree:
+            return
+        ga = self.gen_arch
+        if len(self) * ga.L * 2 > self._PEDIGREE_MAX_BITS or getattr(self, '_comm', None):
+            import warnings
+            warnings.warn("'use_tskit': True - the spatial pedigree is recorded as plain "
+                          "tree-sequence tables on the host for models up to %.0e genotype "
+                          "bits on one GPU; this one is larger (or tiled): not recorded. "
+                          "Genotypes are tracked in full on the device either way."
+                          % self._PEDIGREE_MAX_BITS)
+            return
+        from .pedigree import TreeTables
+        off, loci = ga.recombinations._breakpoints()
+        self._tt = TreeTables(ga.L, off, loci)
+        ids, order = self._ids_sorted()
+        self._tt.add_founders(ids[order], self._get_coords(), self._get_genotypes())
 
     def _set_z(self):
         self._dev.set_z()

@@ -315,6 +315,13 @@ int gnx_tile_put_gametes_dev(gnx_state* h, int64_t n, const void* data_dev);
 /* int32 [2][bin_count]: individuals, pair midpoints (all-reduce in place)     */
 int gnx_tile_bins_ptr(gnx_state* h, void** bins, int64_t* n_total);
 
+/* ---- pedigree (reference structs/species.py:692-736: rows of the tskit tables) --
+ * the offspring of the last gnx_pop_dynamics_mate, in birth order; call it before
+ * gnx_pop_dynamics_die.  keys / starts: recombination path and start homologue of
+ * the gamete from parent 0 and from parent 1 (NULL to skip; burn-in has none)   */
+int gnx_last_births(gnx_state* h, int64_t* child_id /*[B]*/, int64_t* parent_id /*[B][2]*/,
+                    int32_t* keys /*[B][2]*/, uint8_t* starts /*[B][2]*/, float* xy /*[B][2]*/);
+
 /* ---- statistics (reference sim/stats.py:359-435) ---------- */
 /* per-locus count of 1-alleles over the 2N chromosomes and of heterozygous
  * individuals: het = cnt_het / N (_calc_het), f1 = cnt1 / 2N (_calc_maf)     */

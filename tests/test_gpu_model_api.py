@@ -421,3 +421,37 @@ def test_two_species_nonsquare_landscape():
     assert (mod.comm[1]._get_age() >= 0).all()
     assert mod.get_z(spp=0).shape == (len(s0), 1)
     assert mod.comm[1].N.shape == (H, W) and mod.comm[0].K.shape == (H, W)
+
+
+def test_pedigree_tables_reproduce_device_genotypes(tmp_path):
+    """'use_tskit': True records the spatial pedigree (reference structs/species.py:692-736)
+    from the device's birth records; the genotypes read back through the recorded edges
+    to the founders equal the genotypes the device holds, for every living individual -
+    with mutations on"""
+    import geonomics_amd as gnx
+    p = small_params(seed=8, traits=True, L=56, T=15)
+    ga = p['comm']['species']['spp_0']['gen_arch']
+    ga['use_tskit'] = True
+    ga['mu_neut'] = 2e-4
+    mod = gnx.make_model(p)
+    spp = mod.comm[0]
+    mod.walk(10000, 'burn', verbose=False)
+    assert spp._tt is not None and spp._tt.n_founders == len(spp)
+    mod.walk(15, 'main', verbose=False)
+    ids = np.array([*spp])
+    g_dev = spp._get_genotypes()
+    g_ped = spp._tt.genotypes_of(ids)
+    np.testing.assert_array_equal(g_ped, g_dev)
+    tab = spp._tt.tables()
+    assert tab['individuals']['gnx_id'].size == spp._tt.n_founders + sum(spp.n_births[-15:])
+    assert tab['nodes']['time'].min() == -14 and tab['nodes']['time'].max() == 1
+    n_mut = len(spp._tt._new_muts)
+    assert n_mut > 0 and tab['mutations']['site'].size >= n_mut
+    mod.write_tskit_table_collection(str(tmp_path / 'ped'))
+    for suffix in ('NODES', 'EDGES', 'SITES', 'MUTATIONS', 'INDIVIDUALS'):
+        assert os.path.getsize(tmp_path / ('ped_%s.csv' % suffix)) > 0
+    # a species without 'use_tskit' records nothing and says so
+    mod2 = gnx.make_model(small_params(T=3, L=16))
+    mod2.run()
+    with pytest.raises(ValueError):
+        mod2.write_tskit_table_collection(str(tmp_path / 'none'))

@@ -387,3 +387,61 @@ def test_csv_writer_columns(tmp_path):
         assert float(r['x']) == d['x'][k] and float(r['y']) == d['y'][k]
     with pytest.raises(ValueError):
         D._write_csv(str(tmp_path / 'geo.vcf'), sample)
+
+
+# ---- spatial pedigree as tree-sequence tables -------------------------------------------------
+def test_tree_tables_segments_and_genotypes(tmp_path):
+    """edges per path segment with the reference's half-locus breakpoints
+    (structs/genome.py:234-281), parent homologues alternating from the start homologue;
+    genotypes read back through the edges equal direct bit selection (the oracle's
+    crossover)"""
+    from geonomics_amd.structs.pedigree import TreeTables
+    rng = np.random.RandomState(3)
+    L, F, n_paths = 37, 6, 9
+    cross = (rng.rand(n_paths, L) < 0.15).astype(np.uint8)
+    cross[:, 0] = 0
+    paths = O.recomb_paths(cross)
+    off, loci = O.breakpoints_from_paths(paths)
+    g = rng.randint(0, 2, (F, L, 2)).astype(np.int8)
+    tt = TreeTables(L, off, loci)
+    ids = np.array([3, 4, 8, 11, 12, 20])
+    tt.add_founders(ids, rng.rand(F, 2), g)
+    geno = {int(i): g[k] for k, i in enumerate(ids)}
+    next_id = 21
+    for t in range(4):
+        alive = np.array(sorted(geno))
+        B = 5
+        par = alive[rng.randint(0, alive.size, (B, 2))]
+        keys = rng.randint(0, n_paths, (B, 2))
+        starts = rng.randint(0, 2, (B, 2))
+        child = np.arange(next_id, next_id + B)
+        next_id += B
+        # hand the births over in scrambled order, as the device might
+        o = rng.permutation(B)
+        tt.add_births(t, child[o], par[o], keys[o], starts[o], rng.rand(B, 2))
+        for k in range(B):
+            kid = np.zeros((L, 2), np.int8)
+            for h in range(2):
+                sel = paths[keys[k, h]] ^ starts[k, h]
+                kid[:, h] = geno[int(par[k, h])][np.arange(L), sel]
+            geno[int(child[k])] = kid
+    tt.add_mutations([int(child[0])], [5], [1])
+    geno[int(child[0])][5, 1] = 1
+    all_ids = np.array(sorted(geno))
+    np.testing.assert_array_equal(tt.genotypes_of(all_ids), np.stack([geno[int(i)] for i in all_ids]))
+    tab = tt.tables()
+    e, n = tab['edges'], tab['nodes']
+    assert (n['time'][e['parent']] > n['time'][e['child']]).all()      # tskit's requirement
+    # every non-founder node is covered exactly once over [0, L)
+    for node in range(2 * F, n['time'].size):
+        seg = sorted(zip(e['left'][e['child'] == node], e['right'][e['child'] == node]))
+        assert seg[0][0] == 0 and seg[-1][1] == L
+        assert all(a[1] == b[0] for a, b in zip(seg, seg[1:]))
+        assert all(l == 0 or l % 1 == 0.5 for l, _ in seg)
+    tt.write_csv(str(tmp_path / 'ped'))
+    tt.write_text(str(tmp_path / 'ped'))
+    head = open(tmp_path / 'ped_EDGES.csv').readline().strip()
+    assert head == 'left,right,parent,child'
+    assert open(tmp_path / 'ped.nodes.txt').readline().split() == [
+        'is_sample', 'time', 'population', 'individual']
+    assert len(open(tmp_path / 'ped.edges.txt').read().splitlines()) == 1 + e['left'].size
