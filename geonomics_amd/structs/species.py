@@ -616,6 +616,7 @@ class Species:
         if snap['geno'] is not None:
             d.upload_genomes(snap['geno'])
         d.step_index = snap['step']
+        self._tt = None
         self.Nt = list(snap['Nt'])
         self.n_births = list(snap['n_births'])
         self.n_deaths = list(snap['n_deaths'])
@@ -624,6 +625,8 @@ class Species:
         self.max_ind_idx = snap['max_ind_idx']
         self.extinct = snap['extinct']
         self._burnin_spat_stats = copy.deepcopy(snap['spat'])
+        if snap['geno'] is not None:         # a new iteration starts a new pedigree
+            self._start_pedigree()
         if self._changer is not None:        # events start over with the iteration
             self._changer = copy.deepcopy(self._changer_orig)
             self._pv.__dict__.update(copy.deepcopy(snap['pv']))
