@@ -898,9 +898,12 @@ extern "C" int gnx_tile_offspring_dev(gnx_state* h, int32_t burn, int64_t id_bas
   int64_t P = h->n_pairs, B = 0;
   h->birth_first_slot = h->N;
   h->n_req = 0;
-  if (P > 0)
+  if (P > 0) {
     HIPCHK(hipMemcpyAsync(h->pair_goff, pair_goff_dev, P * sizeof(int64_t),
                           hipMemcpyDeviceToDevice, h->stream));
+    // the source belongs to the caller (a tensor it may release on return)
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
   GNXCHK(gnx_l_mate(h, burn != 0, false, 0, &B, id_base, true));
   h->last_births = B;
   if (B == 0) h->n_req = 0;
