@@ -123,6 +123,7 @@ class Species:
         self._K = val
         if self.__dict__.get('_dev', None) is not None and val is not None:
             self._dev.set_K_raster(np.asarray(val, dtype=np.float64))
+            self._K_explicit = True
 
     def __setattr__(self, attr, val):
         """life-history parameters live in the hoisted params block; changing one
@@ -320,6 +321,7 @@ class Species:
         if self._dev is not None:
             self._dev.upload_layer(self.K_layer, land[self.K_layer].rast)
             self._dev.set_K_raster(None)
+            self._K_explicit = False
 
     def _set_N(self, N):
         self._N_cache = N
@@ -360,7 +362,19 @@ class Species:
         burn = not self.burned
         dev = self._dev
         n_before = dev.N
-        dev.pop_dynamics_mate(burn)
+        for attempt in range(6):
+            try:
+                dev.pop_dynamics_mate(burn)
+                break
+            except nat.GnxError as e:
+                # the reference's population is a dict that simply grows; here the slots
+                # are preallocated, so make room and repeat the call (it failed before any
+                # offspring was written and every draw is keyed by id and step: the
+                # repeated call takes the same decisions)
+                if 'capacity exceeded' not in str(e) or attempt == 5 or \
+                        getattr(self, '_comm', None) is not None:
+                    raise
+                dev = self._grow_device()
         n_after, births, _ = dev.counts()
         self.n_births.append(int(births))
         if births:
@@ -376,6 +390,27 @@ class Species:
         dev.step_index = dev.step_index + 1
         if self._check_extinct():
             self.extinct = True
+
+    def _grow_device(self, factor=2.0):
+        """a larger device state with the same population (capacity is an implementation
+        detail of the build: GNX_CAP_FACTOR sets the initial headroom)"""
+        d = self._dev
+        has_geno = bool(d.L > 0 and self.gen_arch is not None and self.burned and
+                        self.__dict__.get('_genomes_assigned', False))
+        keep = dict(x=d.download(nat.F_X), y=d.download(nat.F_Y), age=d.download(nat.F_AGE),
+                    sex=d.download(nat.F_SEX), id=d.download(nat.F_ID), step=d.step_index,
+                    geno=d.download(nat.F_GENO) if has_geno else None)
+        d.close()
+        self._make_device(self._land_ref, len(keep['x']), cap=int(self._cap * factor) + 1024)
+        nd = self._dev
+        nd.upload_population(keep['x'], keep['y'], keep['age'], keep['sex'], keep['id'])
+        if keep['geno'] is not None:
+            nd.upload_genomes(keep['geno'])
+        nd.step_index = keep['step']
+        nd.set_max_id(self.max_ind_idx)
+        if self.__dict__.get('_K_explicit', False):
+            nd.set_K_raster(np.asarray(self._K, dtype=np.float64))
+        return nd
 
     def _do_mutation(self, first_slot, n_offspring):
         """ops/mutation.py:169-206 on the new offspring (slots
@@ -427,6 +462,7 @@ class Species:
         _genome._check_mutation_rates(ga, est_tot_muts, burn_T, T)
         n = _genome._starting_mutation_counts(len(self), ga.p)
         self._dev.assign_genomes(n)
+        self._genomes_assigned = True
         self._start_pedigree()
 
     # founders of the tree-sequence tables: the population at genome assignment
@@ -615,6 +651,7 @@ class Species:
         d.upload_population(snap['x'], snap['y'], snap['age'], snap['sex'], snap['id'])
         if snap['geno'] is not None:
             d.upload_genomes(snap['geno'])
+        self._genomes_assigned = snap['geno'] is not None
         d.step_index = snap['step']
         self._tt = None
         self.Nt = list(snap['Nt'])

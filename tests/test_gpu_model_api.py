@@ -455,3 +455,34 @@ def test_pedigree_tables_reproduce_device_genotypes(tmp_path):
     mod2.run()
     with pytest.raises(ValueError):
         mod2.write_tskit_table_collection(str(tmp_path / 'none'))
+
+
+def test_capacity_grows_transparently(monkeypatch):
+    """the reference's population is a dict that simply grows; the build's preallocated
+    device state is enlarged on demand, and the run is the one a roomy allocation gives"""
+    import geonomics_amd as gnx
+    from geonomics_amd.sim.params import ParametersDict
+
+    def run(cap_factor):
+        monkeypatch.setenv('GNX_CAP_FACTOR', cap_factor)
+        p = small_params(seed=6, traits=True, L=48, T=40)
+        none = dict(rate=None, interval=None, distr=None, n_cycles=None, size_range=None,
+                    start_t=None, end_t=None)
+        # a 3-fold demographic expansion half way through
+        p['comm']['species']['spp_0']['change'] = ParametersDict(
+            {'dem': {0: dict(none, kind='custom', timesteps=[10], sizes=[3.0])}})
+        mod = gnx.make_model(p)
+        spp = mod.comm[0]
+        mod.walk(10000, 'burn', verbose=False)
+        nburn = len(spp.Nt)
+        mod.walk(40, 'main', verbose=False)
+        return spp, nburn
+    a, nb_a = run('6.0')
+    b, nb_b = run('1.05')
+    assert b._cap > 1.05 * 450 + 1024 and a._cap == int(6.0 * 450) + 1024      # b grew
+    assert nb_a == nb_b                 # the headroom lasts through the burn-in
+    assert a.Nt == b.Nt and a.n_births == b.n_births and a.n_deaths == b.n_deaths
+    np.testing.assert_array_equal(np.array([*a]), np.array([*b]))
+    np.testing.assert_array_equal(a._get_genotypes(), b._get_genotypes())
+    np.testing.assert_array_equal(a._get_coords(), b._get_coords())
+    assert max(b.Nt) > 2 * 450 * 0.6
