@@ -132,7 +132,7 @@ def _run_threads(world, steps, fixed):
     return out
 
 
-@pytest.mark.parametrize('world,fixed', [(2, True), (4, False)])
+@pytest.mark.parametrize('world,fixed', [(2, True), (4, False), (8, True)])
 def test_device_resident_transport_is_bit_identical(world, fixed):
     steps = 8
     one = _run_threads(1, steps, fixed)
