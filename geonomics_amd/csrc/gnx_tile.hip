@@ -632,26 +632,6 @@ __global__ void k_dest_owner(int64_t n, const gnx_ind_rec* rec, int tw, int th, 
   idx[q] = (int32_t)q;
 }
 
-__global__ void k_halo_count(int64_t n, const gnx_ind_rec* rec, int32_t* cnt) {
-  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q > n) return;
-  cnt[q] = q < n ? __popc(rec[q].nbr_mask & 0x1ef) : 0;
-}
-
-__global__ void k_halo_emit(int64_t n, const gnx_ind_rec* rec, const int32_t* off, int r, int c,
-                            int C, uint32_t* key, int32_t* idx) {
-  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= n) return;
-  int m = rec[q].nbr_mask & 0x1ef, o = off[q];
-  while (m) {
-    int k = __ffs(m) - 1;
-    m &= m - 1;
-    key[o] = (uint32_t)((r + k / 3 - 1) * C + (c + k % 3 - 1));
-    idx[o] = (int32_t)q;
-    ++o;
-  }
-}
-
 __global__ void k_req_owner(int64_t n, const float* px, const float* py, int tw, int th, int R,
                             int C, uint32_t* key, int32_t* idx) {
   int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -684,7 +664,7 @@ static int n_tiles(const gnx_state* h) { return h->tile_R * h->tile_C; }
 // sort (key, idx)[m] by key (stable), count per destination -> host counts[R*C]
 static int group_by_key(gnx_state* h, int64_t m, int64_t* counts) {
   const int nt = n_tiles(h);
-  if (!h->tile_counts) GNXCHK(dalloc_t(&h->tile_counts, (size_t)GNX_MAX_TILES));
+  if (!h->tile_counts) GNXCHK(dalloc_t(&h->tile_counts, (size_t)GNX_MAX_TILES * 2));
   HIPCHK(hipMemsetAsync(h->tile_counts, 0, nt * sizeof(int32_t), h->stream));
   if (m > 0) {
     int bits = 1;
@@ -763,39 +743,101 @@ extern "C" int gnx_tile_export_migrants_dev(gnx_state* h, int64_t* counts /*[R*C
   return 0;
 }
 
-// halo records, one copy per neighbour tile that needs them, grouped by rank
+// halo records, one copy per neighbour tile that needs them, grouped by rank.  Two
+// passes over the individuals with wave-aggregated atomics (count per destination, then
+// append behind the destination's offset): the order inside a group is whatever the
+// atomics give, which nobody depends on - the receiver sorts by (cell, id).
+__device__ __forceinline__ int halo_mask_of(float x, float y, const HaloSpans& sp, double inv_cs,
+                                            int ncx, int ncy) {
+  const int cx = min(ncx - 1, (int)((double)x * inv_cs));
+  const int cy = min(ncy - 1, (int)((double)y * inv_cs));
+  int m = 0;
+  for (int dy = 0; dy < 3; ++dy)
+    for (int dx = 0; dx < 3; ++dx) {
+      if (dx == 1 && dy == 1) continue;
+      if (sp.okx[dx] && sp.oky[dy] && cx >= sp.cx0[dx] && cx <= sp.cx1[dx] &&
+          cy >= sp.cy0[dy] && cy <= sp.cy1[dy])
+        m |= 1 << (dy * 3 + dx);
+    }
+  return m;
+}
+
+template <bool WRITE>
+__global__ void __launch_bounds__(256)
+k_halo_direct(int64_t N, GnxSoA s, HaloSpans sp, double inv_cs, int ncx, int ncy, int tr, int tc,
+              int C, int32_t* __restrict__ counts, const int32_t* __restrict__ offs,
+              gnx_ind_rec* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  int m = 0;
+  if (i < N && !s.ghost[i]) m = halo_mask_of(s.x[i], s.y[i], sp, inv_cs, ncx, ncy);
+  if (__ballot(m != 0) == 0ull) return;          // wave-uniform: nobody near a border
+  for (int k = 0; k < 9; ++k) {
+    if (k == 4) continue;
+    const unsigned long long b = __ballot((m >> k) & 1);
+    if (b == 0ull) continue;
+    const int rank = (tr + k / 3 - 1) * C + (tc + k % 3 - 1);
+    int base = 0;
+    if (lane == __ffsll((long long)b) - 1) base = atomicAdd(&counts[rank], __popcll(b));
+    if (WRITE) {
+      base = __shfl(base, __ffsll((long long)b) - 1);
+      if ((m >> k) & 1) {
+        gnx_ind_rec r;
+        r.x = s.x[i];
+        r.y = s.y[i];
+        r.age = s.age[i];
+        r.sex = s.sex[i];
+        r.id = s.id[i];
+        r.fit = s.fit[i];
+        r.nbr_mask = m;
+        out[offs[rank] + base + __popcll(b & ((1ull << lane) - 1ull))] = r;
+      }
+    }
+  }
+}
+
 extern "C" int gnx_tile_export_halo_dev(gnx_state* h, int64_t* counts) {
   GNXCHK(check_tiles(h, "gnx_tile_export_halo_dev"));
-  for (int p = 0; p < n_tiles(h); ++p) counts[p] = 0;
+  const int nt = n_tiles(h);
+  for (int p = 0; p < nt; ++p) counts[p] = 0;
   h->gp_n = 0;
   h->st_has_geno = false;
-  int64_t N = h->N, n = 0;
+  const int64_t N = h->N;
   if (N == 0) return 0;
+  if (!h->tile_counts) GNXCHK(dalloc_t(&h->tile_counts, (size_t)GNX_MAX_TILES * 2));
   GnxSoA s = h->soa[h->cur];
-  hipLaunchKernelGGL(k_mark_halo, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, s.x, s.y,
-                     s.ghost, halo_spans(h), h->inv_cs, h->ncx, h->ncy, h->flag, h->mate);
-  GNXCHK(stage_selection(h, h->mate, false, false, &n));
-  if (n == 0) return 0;
-  if (n + 1 > h->cfg.cap_inds) {
-    gnx_set_error("gnx_tile_export_halo_dev: halo larger than the capacity");
-    return 2;
+  const HaloSpans sp = halo_spans(h);
+  int32_t* cnt = h->tile_counts;
+  int32_t* off = h->tile_counts + GNX_MAX_TILES;
+  HIPCHK(hipMemsetAsync(cnt, 0, nt * sizeof(int32_t), h->stream));
+  hipLaunchKernelGGL(k_halo_direct<false>, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, s,
+                     sp, h->inv_cs, h->ncx, h->ncy, h->tile_r, h->tile_c, h->tile_C, cnt, nullptr,
+                     nullptr);
+  std::vector<int32_t> c(nt), o(nt);
+  GNXCHK(gnx_d2h(h, c.data(), cnt, nt * sizeof(int32_t)));
+  int64_t m = 0;
+  for (int p = 0; p < nt; ++p) {
+    o[p] = (int32_t)m;
+    counts[p] = c[p];
+    m += c[p];
   }
-  hipLaunchKernelGGL(k_halo_count, dim3(gnx_grid(n + 1, 256)), dim3(256), 0, h->stream, n,
-                     h->st_rec, h->flag);
-  GNXCHK(gnx_prim_scan(h->scan_tmp, h->scan_tmp_bytes, h->flag, h->scan, (size_t)n + 1,
-                       h->stream));
-  int32_t m32 = 0;
-  GNXCHK(gnx_d2h(h, &m32, h->scan + n, sizeof(int32_t)));
-  const int64_t m = m32;
-  if (m > h->cfg.cap_inds) {
-    gnx_set_error("gnx_tile_export_halo_dev: %lld halo copies exceed the capacity %lld",
-                  (long long)m, (long long)h->cfg.cap_inds);
-    return 2;
+  if (m == 0) return 0;
+  if (m > h->gp_cap) {
+    (void)hipFree(h->gp_rec);
+    (void)hipFree(h->gp_z);
+    (void)hipFree(h->gp_slots);
+    h->gp_cap = m + m / 4 + 1024;
+    GNXCHK(dalloc_t(&h->gp_rec, (size_t)h->gp_cap));
+    GNXCHK(dalloc_t(&h->gp_z, (size_t)h->gp_cap * std::max(h->cfg.n_traits, 1)));
+    GNXCHK(dalloc_t(&h->gp_slots, (size_t)h->gp_cap));
   }
-  hipLaunchKernelGGL(k_halo_emit, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, n, h->st_rec,
-                     h->scan, h->tile_r, h->tile_c, h->tile_C, h->key[0], h->perm[0]);
-  GNXCHK(group_by_key(h, m, counts));
-  GNXCHK(grouped_gather(h, m, false));
+  GNXCHK(gnx_h2d(h, off, o.data(), nt * sizeof(int32_t)));
+  HIPCHK(hipMemsetAsync(cnt, 0, nt * sizeof(int32_t), h->stream));
+  hipLaunchKernelGGL(k_halo_direct<true>, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, s,
+                     sp, h->inv_cs, h->ncx, h->ncy, h->tile_r, h->tile_c, h->tile_C, cnt, off,
+                     h->gp_rec);
+  HIPCHK(hipGetLastError());
+  h->gp_n = m;
   return 0;
 }
 

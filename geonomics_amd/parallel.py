@@ -356,8 +356,10 @@ class TiledStepper:
         geno = self.shard.has_genomes
         nt, W64 = self.shard.n_traits, self.shard.W64
         counts, (p_rec, p_z, p_g) = dev.tile_export_migrants_dev()
+        self._tick('  mig export')
         assert counts[self.comm.rank] == 0
         mat = self.comm.count_matrix(counts)
+        self._tick('  mig counts')
         n = int(counts.sum())
         parts = [(dev_bytes(p_rec, n * 32), 32)]
         if nt:
@@ -366,21 +368,26 @@ class TiledStepper:
             parts.append((dev_bytes(p_g, n * 16 * W64), 16 * W64))
         self.bytes_sent += sum(t.numel() for t, _ in parts)
         got = self.comm.exchange_dev(parts, mat)
+        self._tick('  mig exchange')
         m = int(mat[:, self.comm.rank].sum())
         if m:
             dev.tile_import_dev(m, got[0].data_ptr(), got[1].data_ptr() if nt else 0,
                                 got[-1].data_ptr() if geno else 0)
+        self._tick('  mig import')
 
     def _halo_dev(self):
         dev = self.shard.dev
         counts, p_rec = dev.tile_export_halo_dev()
+        self._tick('  halo export')
         mat = self.comm.count_matrix(counts)
         n = int(counts.sum())
         self.bytes_sent += n * 32
         got = self.comm.exchange_dev([(dev_bytes(p_rec, n * 32), 32)], mat)
+        self._tick('  halo exchange')
         m = int(mat[:, self.comm.rank].sum())
         if m:
             dev.tile_import_ghosts_dev(m, got[0].data_ptr())
+        self._tick('  halo import')
 
     def _offspring_dev(self, burn):
         """pair order on the device: all-gather the focal ids, searchsorted, and
