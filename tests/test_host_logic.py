@@ -1,5 +1,7 @@
 """Host-side logic of the drop-in layer (no GPU): parameters-file format,
 landscape construction, genomic architecture, burn-in statistics."""
+import os
+
 import numpy as np
 import pytest
 
@@ -445,3 +447,46 @@ def test_tree_tables_segments_and_genotypes(tmp_path):
     assert open(tmp_path / 'ped.nodes.txt').readline().split() == [
         'is_sample', 'time', 'population', 'individual']
     assert len(open(tmp_path / 'ped.edges.txt').read().splitlines()) == 1 + e['left'].size
+
+
+# ---- the reference's own parameter files (read in place; this container only) ------------------
+REF = '/root/reference'
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='the reference is mounted in the build container only')
+@pytest.mark.parametrize('rel', ['tests/runtime/runtime_params.py',
+                                 'tests/runtime/runtime_params_selection.py',
+                                 'tests/validation/bottleneck/bottleneck_params.py',
+                                 'tests/validation/wf/wf_params.py'])
+def test_reference_parameter_files_load_unchanged(rel):
+    """drop-in for the parameters-file format: the files the reference's own runtime and
+    validation tests use are read as they are, and the host-side structures they describe
+    (landscape, genomic architecture, change events, data / stats schedules) build"""
+    import geonomics_amd as gnx
+    from geonomics_amd.structs.landscape import _make_landscape
+    from geonomics_amd.structs import genome as G
+    from geonomics_amd.sim.stats import _StatsCollector
+    from geonomics_amd.sim.data import _DataCollector
+    from geonomics_amd.ops.change import _SpeciesChanger
+    p = gnx.read_parameters_file(os.path.join(REF, rel))
+    land = _make_landscape(None, p)
+    assert tuple(land.dim) == tuple(p.landscape.main.dim) and len(land) == len(p.landscape.layers)
+    for name, sp in p.comm.species.items():
+        assert {'init', 'mating', 'mortality', 'movement'} <= set(sp.keys())
+        if 'gen_arch' in sp:
+            ga = G._make_genomic_architecture(sp, land, rng=np.random.RandomState(1))
+            assert ga.L == sp.gen_arch.L
+            assert ga.recombinations._rates[0] == 0
+            n_traits = len(sp.gen_arch.traits) if 'traits' in sp.gen_arch else 0
+            assert (ga.traits is None and n_traits == 0) or len(ga.traits) == n_traits
+        if 'change' in sp:
+            class Spp:
+                K = np.ones((land.dim[1], land.dim[0]))
+                t = 0
+            ch = _SpeciesChanger(Spp(), sp.change, land=land, rng=np.random.RandomState(1))
+            assert len(ch._list) > 0 and ch.next_change is not None
+    if 'data' in p.model:
+        dc = _DataCollector('m', p)
+        assert dc._when[-1] == p.model.T - 1
+    if 'stats' in p.model:
+        assert _StatsCollector('m', p).stats
