@@ -44,7 +44,7 @@ EXPORTS = [
     'gnx_tile_export_migrants_dev', 'gnx_tile_export_halo_dev', 'gnx_tile_staged_ptrs',
     'gnx_tile_import_dev', 'gnx_tile_import_ghosts_dev', 'gnx_tile_pair_ptrs',
     'gnx_tile_offspring_dev', 'gnx_tile_group_requests', 'gnx_tile_serve_gametes_dev',
-    'gnx_tile_put_gametes_dev', 'gnx_tile_bins_ptr', 'gnx_set_k_raster', 'gnx_last_births',
+    'gnx_tile_put_gametes_dev', 'gnx_tile_bins_ptr', 'gnx_set_k_raster', 'gnx_last_births', 'gnx_set_positions',
 ]
 
 
@@ -184,6 +184,11 @@ class Device:
         self._chk(self.lib.gnx_upload_population(
             self.h, C.c_int64(n), _ptr(x, C.c_float), _ptr(y, C.c_float),
             _ptr(age, C.c_int32), _ptr(sex, C.c_uint8), _ptr(ids, C.c_int64)))
+
+    def set_positions(self, x, y):
+        x, y = _arr(x, np.float32), _arr(y, np.float32)
+        assert x.size == self.N and y.size == self.N
+        self._chk(self.lib.gnx_set_positions(self.h, _ptr(x, C.c_float), _ptr(y, C.c_float)))
 
     def init_population(self, n):
         self._chk(self.lib.gnx_init_population(self.h, C.c_int64(n)))

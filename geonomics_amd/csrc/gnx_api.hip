@@ -877,6 +877,29 @@ extern "C" int gnx_download(gnx_state* h, int32_t field, void* dst, int64_t dst_
   return 0;
 }
 
+// new coordinates for every individual, in slot order (the reference lets a script
+// assign Individual.x / .y and then calls Species._set_coords_and_cells,
+// structs/species.py:937-939; tests/validation/wf does so every step); the environment
+// values follow as in _set_e (:913-922)
+extern "C" int gnx_set_positions(gnx_state* h, const float* x, const float* y) {
+  GNXCHK(need_params(h));
+  const int64_t N = h->N;
+  if (N == 0) return 0;
+  const float xmax = (float)(h->cfg.W - 0.001), ymax = (float)(h->cfg.H - 0.001);
+  for (int64_t i = 0; i < N; ++i)
+    if (!(x[i] >= 0 && x[i] <= xmax && y[i] >= 0 && y[i] <= ymax)) {
+      gnx_set_error("gnx_set_positions: individual %lld at (%g, %g) is off the landscape "
+                    "[0, dim - 0.001]", (long long)i, x[i], y[i]);
+      return 1;
+    }
+  GnxSoA s = h->soa[h->cur];
+  GNXCHK(gnx_h2d(h, s.x, x, N * sizeof(float)));
+  GNXCHK(gnx_h2d(h, s.y, y, N * sizeof(float)));
+  GNXCHK(gnx_l_gather_e(h, 0, N));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
 extern "C" int gnx_download_genomes(gnx_state* h, int64_t n, const int64_t* slots,
                                     uint64_t* dst) {
   GNXCHK(need_genome(h));

@@ -22,18 +22,29 @@ from ..sim import burnin as _burnin
 
 
 class Individual:
-    """Read-only snapshot of one individual (reference structs/individual.py:100)."""
+    """Snapshot of one individual (reference structs/individual.py:100).  Assigning
+    `x` or `y` is remembered by the Species and written to the device by
+    `Species._set_coords_and_cells()` (the reference's scripts move individuals that way:
+    tests/validation/wf/wf_test.py:69-76); everything else is read-only."""
 
-    def __init__(self, idx, x, y, age, sex, e, z, fit, g):
-        self.idx = idx
-        self.x = x
-        self.y = y
-        self.age = age
-        self.sex = sex
-        self.e = e
-        self.z = z
-        self.fit = fit
-        self.g = g
+    def __init__(self, idx, x, y, age, sex, e, z, fit, g, spp=None):
+        d = self.__dict__
+        d['_spp'] = spp
+        d['idx'] = idx
+        d['x'] = x
+        d['y'] = y
+        d['age'] = age
+        d['sex'] = sex
+        d['e'] = e
+        d['z'] = z
+        d['fit'] = fit
+        d['g'] = g
+
+    def __setattr__(self, name, val):
+        self.__dict__[name] = val
+        if name in ('x', 'y') and self.__dict__.get('_spp') is not None:
+            self._spp._pending_xy.setdefault(int(self.idx), [None, None])[
+                0 if name == 'x' else 1] = float(val)
 
     def __repr__(self):
         return '<Individual %i at (%.3f, %.3f), age %i>' % (self.idx, self.x, self.y,
@@ -100,6 +111,7 @@ class Species:
         # spatial pedigree (reference use_tskit=True): genotypes are tracked in full on
         # the device either way; the tree-sequence tables are an observer kept on the
         # host (structs/pedigree.py) for models small enough to hold them
+        self._pending_xy = {}       # id -> [x, y] assigned through Individual objects
         self._tt = None
         self._record_pedigree = bool(self.gen_arch is not None and
                                      getattr(self.gen_arch, 'use_tskit', False))
@@ -264,10 +276,28 @@ class Species:
         return idx in set(self.keys())
 
     def values(self):
-        return [self[i] for i in self.keys()]
+        return [*self._get_individs(np.array(self.keys(), dtype=np.int64)).values()]
 
     def items(self):
-        return [(i, self[i]) for i in self.keys()]
+        return [*self._get_individs(np.array(self.keys(), dtype=np.int64)).items()]
+
+    def _set_coords_and_cells(self):
+        """write the coordinates assigned through Individual objects to the device and
+        refresh e (reference structs/species.py:937-939 caches coords and cells)"""
+        if not self._pending_xy:
+            return
+        ids = self._dev.download(nat.F_ID)
+        x = self._dev.download(nat.F_X).copy()
+        y = self._dev.download(nat.F_Y).copy()
+        pos = {int(i): k for k, i in enumerate(ids)}
+        for i, (nx, ny) in self._pending_xy.items():
+            if i in pos:
+                if nx is not None:
+                    x[pos[i]] = nx
+                if ny is not None:
+                    y[pos[i]] = ny
+        self._pending_xy = {}
+        self._dev.set_positions(x, y)
 
     def __getitem__(self, idx):
         ids = self._field(nat.F_ID)
@@ -284,7 +314,7 @@ class Species:
         return Individual(int(idx), float(self._field(nat.F_X)[s]),
                           float(self._field(nat.F_Y)[s]), int(self._field(nat.F_AGE)[s]),
                           int(self._field(nat.F_SEX)[s]), e, z,
-                          float(self._field(nat.F_FIT)[s]), g)
+                          float(self._field(nat.F_FIT)[s]), g, spp=self)
 
     def _get_individs(self, ids):
         """{id: Individual} for the listed ids (ascending), one download per field;
@@ -304,7 +334,7 @@ class Species:
         z = (self._field(nat.F_Z)[:, slots].astype(np.float64).T if d.n_traits
              else np.zeros((len(ids), 0)))
         return {int(i): Individual(int(i), float(x[k]), float(y[k]), int(age[k]), int(sex[k]),
-                                   e[k].tolist(), z[k].tolist(), float(fit[k]), None)
+                                   e[k].tolist(), z[k].tolist(), float(fit[k]), None, spp=self)
                 for k, i in enumerate(ids)}
 
     def __str__(self):

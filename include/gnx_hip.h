@@ -194,6 +194,9 @@ int gnx_mutate(gnx_state* h, int32_t n, const int64_t* slot,
  * sort on the host (geonomics_amd does).                                    */
 int gnx_download(gnx_state* h, int32_t field, void* dst, int64_t dst_bytes);
 /* genotypes of selected slots: uint64 [n][2][W64]                           */
+/* new coordinates of all N individuals, slot order (Individual.x / .y assigned by a
+ * script + Species._set_coords_and_cells, structs/species.py:937-939); e follows */
+int gnx_set_positions(gnx_state* h, const float* x /*[N]*/, const float* y /*[N]*/);
 int gnx_download_genomes(gnx_state* h, int64_t n, const int64_t* slots,
                          uint64_t* dst);
 /* double [H][W]: N (Species.N), n_pairs, K, d as of the last pop_dynamics;

@@ -486,3 +486,34 @@ def test_capacity_grows_transparently(monkeypatch):
     np.testing.assert_array_equal(a._get_genotypes(), b._get_genotypes())
     np.testing.assert_array_equal(a._get_coords(), b._get_coords())
     assert max(b.Nt) > 2 * 450 * 0.6
+
+
+def test_scripts_can_move_individuals():
+    """the reference's validation scripts assign Individual.x / .y and call
+    Species._set_coords_and_cells() between steps (tests/validation/wf/wf_test.py:69-76)"""
+    import geonomics_amd as gnx
+    mod = gnx.make_model(small_params(T=50, L=32, traits=True))
+    mod.walk(10000, 'burn', verbose=False)
+    spp = mod.comm[0]
+    rng = np.random.RandomState(0)
+    for _ in range(5):
+        n = len(spp)
+        new_x = rng.uniform(0, mod.land.dim[0] - 0.01, n)
+        new_y = rng.uniform(0, mod.land.dim[1] - 0.01, n)
+        for k, ind in enumerate(spp.values()):
+            ind.x = new_x[k]
+            ind.y = new_y[k]
+        spp._set_coords_and_cells()
+        xy = mod.get_coords()
+        np.testing.assert_allclose(xy[:, 0], new_x.astype(np.float32))
+        np.testing.assert_allclose(xy[:, 1], new_y.astype(np.float32))
+        # e follows the new cells (reference _set_e, structs/species.py:913-922)
+        rast1 = mod.land[1].rast.astype(np.float32)
+        np.testing.assert_array_equal(mod.get_e()[:, 1],
+                                      rast1[xy[:, 1].astype(int), xy[:, 0].astype(int)])
+        mod.walk(1, 'main', verbose=False)
+    assert len(spp) > 0
+    ind = spp[[*spp][0]]
+    ind.x = 1e9
+    with pytest.raises(Exception):
+        spp._set_coords_and_cells()
