@@ -757,14 +757,53 @@ def g14_data():
     save('g14_data', **out)
 
 
+def g15_wf():
+    """The reference's Wright-Fisher validation (tests/validation/wf/wf_test.py) in small:
+    positions re-drawn uniformly every step, walk one main step, until every locus is
+    fixed; persistence times of the loci and the harmonic-mean population size."""
+    out = {}
+    for s in range(1, 5):
+        mod = make_ref_model(dim=(10, 10), N=100, L=60, traits=False, K_factor=1.0,
+                             r_alpha=0.5, n_recomb=80, seed=s, mating_radius=20)
+        mod.walk(T=400, mode='burn', verbose=False)
+        assert mod.comm.burned
+        spp = mod.comm[0]
+        t0 = len(spp.Nt)
+        freqs = []
+        for t in range(2500):
+            g = stack_g(spp)
+            f = g.mean(axis=(0, 2))
+            freqs.append(f)
+            if ((f == 0) | (f == 1)).all():
+                break
+            n = len(spp)
+            new_x = np.random.uniform(0, 10, n)
+            new_y = np.random.uniform(0, 10, n)
+            for k, ind in enumerate(spp.values()):
+                ind.x = new_x[k]
+                ind.y = new_y[k]
+            spp._set_coords_and_cells()
+            mod.walk(1, 'main', verbose=False)
+        F = np.array(freqs)
+        fixed = (F == 0) | (F == 1)
+        persist = np.where(fixed.any(axis=0), fixed.argmax(axis=0), len(F))
+        Nt = np.array(spp.Nt[t0:], dtype=float)
+        out['s%i_persist' % s] = persist
+        out['s%i_Nharm' % s] = np.array([1.0 / np.mean(1.0 / Nt)])
+        out['s%i_steps' % s] = np.array([len(F)])
+        print('seed', s, 'steps', len(F), 'mean persistence', persist.mean(),
+              'N_harm', out['s%i_Nharm' % s][0], flush=True)
+    save('g15_wf', **out)
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g7', 'g8', 'g9',
-                             'g10', 'g11', 'g12', 'g13', 'g14']
+                             'g10', 'g11', 'g12', 'g13', 'g14', 'g15']
     fns = {'g1': g1_crossover, 'g2': g2_recomb_paths,
            'g3': g3_phenotype_fitness, 'g4': g4_density,
            'g5': g5_demography, 'g7': g7_movement, 'g8': g8_pairing,
            'g9': g9_starting_genomes, 'g10': g10_envelopes,
            'g11': g11_conductance, 'g12': g12_stats, 'g13': g13_change,
-           'g14': g14_data}
+           'g14': g14_data, 'g15': g15_wf}
     for w in which:
         fns[w]()
