@@ -555,8 +555,15 @@ class Model:
                           individs=None if individs is None else np.sort(individs))
 
     def get_fitness(self, spp=0, trt=None, individs=None):
+        """overall fitness, or that of one trait (reference sim/model.py get_fitness)"""
         spp = self.comm[self._get_spp_num(spp)]
-        return spp._get_fit(individs=None if individs is None else np.sort(individs))
+        if trt is None:
+            return spp._get_fit(individs=None if individs is None else np.sort(individs))
+        w = spp._calc_fitness(trait_num=self._get_trt_num(spp, trt))
+        if individs is None:
+            return w
+        ids = np.array([*spp])
+        return w[np.searchsorted(ids, np.sort(individs))]
 
     def get_genotypes(self, spp=0, loci=None, individs=None, biallelic=False):
         spp = self.comm[self._get_spp_num(spp)]

@@ -646,9 +646,19 @@ class Species:
         return gts
 
     def _calc_fitness(self, trait_num=None, set_fit=True):
-        """Fitness as last set by _do_pop_dynamics (ops/selection.py:99-112 is
-        evaluated on the device inside the death-probability kernel)."""
-        return self._get_fit()
+        """reference ops/selection.py:51-112.  Overall fitness (trait_num None) is what
+        the death-probability kernel of the last _do_pop_dynamics stored; the fitness of
+        one trait is recomputed here from the downloaded e and z with the same formula,
+        w = max(1 - phi |e^(not univ_adv) - z|^gamma, 0.001)."""
+        if trait_num is None or self.gen_arch is None or self.gen_arch.traits is None:
+            return self._get_fit()
+        trt = self.gen_arch.traits[trait_num]
+        e = self._get_e()[:, trt.lyr_num]
+        z = self._get_z()[:, trt.idx]
+        phi = trt.phi if np.isscalar(trt.phi) else np.asarray(trt.phi)[
+            tuple(self._get_cells()[:, ::-1].T)]
+        w = 1 - phi * np.abs((e ** (not trt.univ_adv)) - z) ** trt.gamma
+        return np.clip(w, a_min=0.001, a_max=None)
 
     def _calc_density(self, normalize=False, as_layer=False, set_N=False):
         """reference structs/species.py:845-882"""

@@ -69,8 +69,14 @@ def test_make_model_burn_walk_accessors():
         gt = G[:, trt.loci, :].mean(axis=2)
         zz = 0.5 + (gt * trt.alpha).sum(1) if trt.n_loci > 1 else gt[:, 0]
         np.testing.assert_allclose(z[:, t], zz, atol=2e-7)
+    sub_ids = np.array([*spp])[[5, 2, 9]]
     fit = mod.get_fitness()
     assert fit.shape == (n,) and (fit > 0).all() and (fit <= 1).all()
+    # per-trait fitness (ops/selection.py:51-75); their product is the overall fitness of
+    # the survivors as the last death-probability pass left it
+    w0, w1 = mod.get_fitness(trt=0), mod.get_fitness(trt='trait_1')
+    np.testing.assert_allclose(np.clip(w0 * w1, 0.001, None), fit, rtol=2e-5)
+    np.testing.assert_array_equal(mod.get_fitness(trt=0, individs=sub_ids), w0[[2, 5, 9]])
     # subset accessors are sorted by id regardless of input order
     sub = ids[[5, 2, 9]]
     np.testing.assert_array_equal(mod.get_x(individs=sub), mod.get_x()[[2, 5, 9]])
