@@ -397,7 +397,10 @@ def main():
                 'measured_copy_GBps': copy_gbps,
                 'frac_of_measured_copy': (ach / copy_gbps) if copy_gbps else None,
             },
-            'kernel_ms_per_step': {k: v['ms'] / args.steps for k, v in kt.items()},
+            # only the dominant kernel is bracketed with events inside the timed region
+            # (GNX_BENCH_PROFILE_ALL=1 times every kernel family, with more event overhead)
+            'kernel_ms_per_step': {k: v['ms'] / args.steps for k, v in kt.items()
+                                   if v['launches'] > 0},
         }
         if stepper is not None and stepper.profile:
             out['tile_phase_ms_per_step'] = {k: 1e3 * v / (args.steps + args.warmup + 3)
