@@ -354,13 +354,22 @@ def main():
         peak = 8000.0
         # HBM bytes per launch from the PMC passes of the latest committed profile
         # (tools/profile_round.sh; separate --pmc runs, gfx950 corrections applied there)
-        traffic = None
+        # The PMC runs are shorter (fewer births per launch than here), so the measured
+        # bytes are scaled by the launches' algorithmic bytes: traffic = this run's
+        # algorithmic bytes x (PMC bytes / algorithmic bytes of the PMC run).
+        traffic = traffic_src = None
         import glob
         for pmc in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_crossover.json')))[::-1]:
             try:
                 j = json.load(open(pmc))
-                if j.get('workload') == args.workload:
-                    traffic = j.get('hbm_bytes_per_launch')
+                if j.get('workload') == args.workload and j.get('algorithmic_bytes_per_launch'):
+                    ratio = j['hbm_bytes_per_launch'] / j['algorithmic_bytes_per_launch']
+                    traffic = ratio * xo['bytes'] / max(xo['launches'], 1)
+                    traffic_src = {'file': 'profiles/' + os.path.basename(pmc),
+                                   'hbm_bytes_per_launch': j['hbm_bytes_per_launch'],
+                                   'algorithmic_bytes_per_launch':
+                                       j['algorithmic_bytes_per_launch'],
+                                   'ratio': ratio}
                     break
             except Exception:
                 continue
@@ -390,6 +399,7 @@ def main():
             'roofline': {
                 'bound': 'hbm', 'kernel': 'k_crossover', 'achieved': ach, 'peak': peak,
                 'unit': 'GB/s', 'frac': ach / peak, 'traffic': traffic,
+                'traffic_pmc': traffic_src,
                 'launches': xo['launches'],
                 'avg_launch_ms': xo['ms'] / max(xo['launches'], 1),
                 'algorithmic_bytes_per_launch': xo['bytes'] / max(xo['launches'], 1),
