@@ -221,8 +221,9 @@ class Species:
             factor = float(os.environ.get('GNX_CAP_FACTOR', '2.5'))
             cap = int(factor * max(N0, _sum_K(land, self.K_layer, self.K_factor))) + 1024
         self._cap = cap
+        cap_inds, cap_rows = self._capacities(cap, N0)
         dev = nat.Device(land.dim[0], land.dim[1], land.n_lyrs, L=L, n_traits=n_traits,
-                         cap_inds=cap, cap_rows=cap, seed=self._seed,
+                         cap_inds=cap_inds, cap_rows=cap_rows, seed=self._seed,
                          device=self._device_ordinal)
         dev.upload_rasters(land._stack())
         dev.set_species_params(self._species_params_struct(land))
@@ -230,6 +231,10 @@ class Species:
         self._dev = dev
         self._upload_gen_arch()
         return dev
+
+    def _capacities(self, cap, N0):
+        """(individual slots, genome rows) of the device state"""
+        return cap, cap
 
     def _upload_gen_arch(self):
         ga = self.gen_arch

@@ -37,6 +37,17 @@ class TiledSpecies(Species):
         self._glob_N = 0
 
     # -- construction -----------------------------------------------------------------
+    def _capacities(self, cap, N0):
+        """Every rank draws the whole initial population before keeping its tile, so the
+        individual slots are sized for the global N0; genome rows (the big table) only
+        for this tile's share, with a margin for uneven tiles (GNX_TILE_ROW_MARGIN,
+        default 2: clumped populations do not spread evenly over tiles)."""
+        import os
+        margin = float(os.environ.get('GNX_TILE_ROW_MARGIN', '2.0'))
+        rows = int(cap / self._comm.world * margin) + 1024
+        return max(int(N0 * 1.02) + 1024, rows), rows
+
+
     def _after_init_population(self, N):
         if self.mutate:
             raise NotImplementedError('mutation is not supported on a tiled landscape')
