@@ -44,7 +44,7 @@ EXPORTS = [
     'gnx_tile_export_migrants_dev', 'gnx_tile_export_halo_dev', 'gnx_tile_staged_ptrs',
     'gnx_tile_import_dev', 'gnx_tile_import_ghosts_dev', 'gnx_tile_pair_ptrs',
     'gnx_tile_offspring_dev', 'gnx_tile_group_requests', 'gnx_tile_serve_gametes_dev',
-    'gnx_tile_put_gametes_dev', 'gnx_tile_bins_ptr', 'gnx_set_k_raster', 'gnx_last_births', 'gnx_set_positions',
+    'gnx_tile_put_gametes_dev', 'gnx_tile_bins_ptr', 'gnx_set_k_raster', 'gnx_last_births', 'gnx_set_positions', 'gnx_n_slots',
 ]
 
 
@@ -97,6 +97,7 @@ def load():
     lib = C.CDLL(LIB_PATH)
     lib.gnx_last_error.restype = C.c_char_p
     lib.gnx_step_index.restype = C.c_int64
+    lib.gnx_n_slots.restype = C.c_int64
     lib.gnx_destroy.restype = None
     _lib = lib
     return lib
@@ -303,7 +304,7 @@ class Device:
                  F_GROW: np.int32}
 
     def download(self, field):
-        n = self.N
+        n = int(self.lib.gnx_n_slots(self.h))     # = N, plus the ghosts while a tiled step runs
         if field == F_E:
             out = np.empty((self.n_layers, n), dtype=np.float32)
         elif field == F_Z:

@@ -793,6 +793,8 @@ extern "C" int gnx_counts(gnx_state* h, int64_t* N, int64_t* births, int64_t* de
   return 0;
 }
 
+// occupied slots, ghosts of a tiled step included (gnx_counts reports the tile's own)
+extern "C" int64_t gnx_n_slots(gnx_state* h) { return h->N; }
 extern "C" int64_t gnx_step_index(gnx_state* h) { return h->step; }
 extern "C" int gnx_set_step_index(gnx_state* h, int64_t step) {
   h->step = step;

@@ -567,7 +567,9 @@ class TiledStepper:
             self.phase_s[name] = self.phase_s.get(name, 0.0) + now - self._t0
         self._t0 = now
 
-    def step(self, burn, with_selection):
+    def step(self, burn, with_selection, after_births=None):
+        """one time step; `after_births(first_id, total_births)` runs once every
+        offspring of the step has its genome and phenotype (mutations go there)"""
         sh = self.shard
         self._tick(None)
         sh.age_and_move(self.move)
@@ -594,6 +596,8 @@ class TiledStepper:
                 self._gametes(n_req)
         self._tick('gametes')
         sh.finish_births(burn)
+        if after_births is not None and total_births > 0:
+            after_births(self.max_id - total_births + 1, total_births)
         # one all-reduce for both density fields (individuals, pair midpoints)
         if self.dev_transport:
             self._bins_dev()

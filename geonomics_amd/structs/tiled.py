@@ -17,8 +17,9 @@ What changes with respect to the single-GPU Species:
     places its share (the union is a uniform choice of n of the 2N homologues);
   * accessors and statistics return the GLOBAL population on every rank (tiles
     gathered); files are written by rank 0.
-Not supported on several GPUs: mutation (its draws come from the host's
-sequential generator), panmixia, linkage statistics.
+Mutations: every rank draws the same list from the host generator and applies those
+whose offspring it owns (_mutate_tiled).  Not supported on several GPUs: panmixia,
+linkage statistics, the pedigree tables.
 """
 import numpy as np
 
@@ -49,8 +50,6 @@ class TiledSpecies(Species):
 
 
     def _after_init_population(self, N):
-        if self.mutate:
-            raise NotImplementedError('mutation is not supported on a tiled landscape')
         if self.mating_radius is None:
             raise NotImplementedError('panmixia is not supported on a tiled landscape')
         W, H = self._land_dim
@@ -78,13 +77,55 @@ class TiledSpecies(Species):
 
     def _do_pop_dynamics(self, land=None):
         burn = not self.burned
-        n, births, deaths = self._stepper.step(burn, self.selection and self.burned)
+        hook = self._mutate_tiled if (self.mutate and not burn) else None
+        n, births, deaths = self._stepper.step(burn, self.selection and self.burned,
+                                               after_births=hook)
         self._glob_N = int(n)
         self.n_births.append(int(births))
         self.n_deaths.append(int(deaths))
         self.max_ind_idx = self._stepper.max_id
         if self._check_extinct():
             self.extinct = True
+
+    def _mutate_tiled(self, first_id, n_offspring):
+        """ops/mutation.py:169-206 over the step's offspring of ALL tiles: every rank
+        draws the same mutations from the host generator (same seed, same call
+        sequence) - how many, their kinds, the offspring by its position in the step's
+        id order, the homologue, the never-mutated locus - and applies those whose
+        offspring it owns.  A single-GPU run draws the same list (structs/species.py
+        _do_mutation: slot k of the newborn block has id first_id + k)."""
+        ga = self.gen_arch
+        rng = self._rng
+        n_muts = rng.binomial(n=n_offspring * ga.L, p=ga._mu_tot)
+        if n_muts == 0 or not ga._mutables:
+            return
+        n_muts = min(n_muts, len(ga._mutables))
+        kinds = ga._draw_mut_types(n_muts)
+        who = first_id + rng.randint(0, n_offspring, n_muts)
+        homs = rng.binomial(1, 0.5, n_muts)
+        loci = [ga._mutables.pop() for _ in range(n_muts)]
+        dirty = False
+        for kind, locus in zip(kinds, loci):
+            if kind == 'neut':
+                continue
+            if kind == 'delet':
+                ga._add_nonneut_locus(locus, delet_s=ga._draw_delet_s())
+            else:
+                ga._add_nonneut_locus(locus, trait_nums=[int(kind[1:])])
+            dirty = True
+        if dirty:
+            self._upload_gen_arch()
+        ids = self._dev.download(nat.F_ID)
+        order = np.argsort(ids, kind='stable')
+        pos = np.minimum(np.searchsorted(ids[order], who), max(ids.size - 1, 0))
+        mine = (ids[order][pos] == who) if ids.size else np.zeros(n_muts, bool)
+        slots = order[pos[mine]]
+        if slots.size:
+            self._dev.mutate(slots, np.asarray(loci)[mine], homs[mine])
+            if dirty and ga.traits is not None:
+                for s_, k in zip(slots, np.asarray(kinds, dtype=object)[mine]):
+                    if k != 'neut':
+                        self._dev.set_z_range(int(s_), 1)
 
     # -- burn-in ---------------------------------------------------------------------------
     def _spatial_update(self):

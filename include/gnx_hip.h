@@ -197,6 +197,9 @@ int gnx_download(gnx_state* h, int32_t field, void* dst, int64_t dst_bytes);
 /* new coordinates of all N individuals, slot order (Individual.x / .y assigned by a
  * script + Species._set_coords_and_cells, structs/species.py:937-939); e follows */
 int gnx_set_positions(gnx_state* h, const float* x /*[N]*/, const float* y /*[N]*/);
+/* slots in use = rows of a gnx_download (the tile's ghosts included while they are
+ * resident, i.e. between gnx_tile_import_ghosts and gnx_tile_die)              */
+int64_t gnx_n_slots(gnx_state* h);
 int gnx_download_genomes(gnx_state* h, int64_t n, const int64_t* slots,
                          uint64_t* dst);
 /* double [H][W]: N (Species.N), n_pairs, K, d as of the last pop_dynamics;

@@ -14,12 +14,16 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 out, traits, workdir = sys.argv[1], bool(int(sys.argv[2])), sys.argv[3]
+mutate = len(sys.argv) > 4 and sys.argv[4] == 'mutate'   # all-zero start + neutral mutations
 os.chdir(workdir)
 import geonomics_amd as gnx                                # noqa: E402
 from geonomics_amd.sim.params import ParametersDict        # noqa: E402
 from test_gpu_model_api import small_params               # noqa: E402
 
 p = small_params(seed=4, traits=traits, L=48, T=15, dim=(32, 32))
+if mutate:
+    p['comm']['species']['spp_0']['gen_arch'].update({'start_neut_zero': True,
+                                                      'mu_neut': 5e-4})
 p['model']['stats'] = ParametersDict({'Nt': {'calc': True, 'freq': 1},
                                       'het': {'calc': True, 'freq': 5, 'mean': False},
                                       'maf': {'calc': True, 'freq': 5},

@@ -189,7 +189,7 @@ def test_nccl_backend_world1_wraps_library_memory():
 
 
 # ---- the Model API over several ranks (structs/tiled.py) -----------------------------------
-def _run_model(tmp_path, world, traits, tag):
+def _run_model(tmp_path, world, traits, tag, extra=()):
     import subprocess
     from test_tiling_cpu import free_port
     out = str(tmp_path / ('%s.npz' % tag))
@@ -207,8 +207,8 @@ def _run_model(tmp_path, world, traits, tag):
         else:
             for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
                 env.pop(k, None)
-        procs.append(subprocess.Popen([sys.executable, worker, out, str(int(traits)), str(wd)],
-                                      env=env))
+        procs.append(subprocess.Popen([sys.executable, worker, out, str(int(traits)), str(wd),
+                                       *extra], env=env))
     assert [p.wait(timeout=600) for p in procs] == [0] * world
     return np.load(out), wd
 
@@ -252,3 +252,17 @@ def test_model_over_two_ranks_with_selection(tmp_path):
     assert two['z'].shape == (len(two['ids']), 2)
     # phenotypes follow the gathered genotypes (z = 0.5 + sum(gt * alpha), monogenic z = gt)
     assert np.isfinite(two['z']).all() and 0 <= two['z'][:, 1].min() and two['z'][:, 1].max() <= 1
+
+
+def test_model_over_two_ranks_with_mutation(tmp_path):
+    """neutral loci start at 0 and mutate (mu_neut > 0): every 1-allele in the population
+    is a mutation drawn during the run, and the two-rank run must place exactly the
+    mutations of the single-GPU run - every rank draws the same list from the host
+    generator and applies those whose offspring it owns (structs/tiled.py)"""
+    one, _ = _run_model(tmp_path, 1, False, 'one', extra=('mutate',))
+    two, _ = _run_model(tmp_path, 2, False, 'two', extra=('mutate',))
+    for k in ('Nt', 'births', 'deaths', 'ids'):
+        np.testing.assert_array_equal(one[k], two[k], err_msg=k)
+    assert one['site_counts0'].sum() == 0 and two['site_counts0'].sum() == 0
+    assert one['g'].sum() > 0                       # mutations happened and were inherited
+    np.testing.assert_array_equal(one['g'], two['g'])
