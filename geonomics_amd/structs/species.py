@@ -508,11 +508,11 @@ class Species:
         if not self._record_pedigree:
             return
         ga = self.gen_arch
-        if len(self) * ga.L * 2 > self._PEDIGREE_MAX_BITS or getattr(self, '_comm', None):
+        if len(self) * ga.L * 2 > self._PEDIGREE_MAX_BITS:
             import warnings
             warnings.warn("'use_tskit': True - the spatial pedigree is recorded as plain "
                           "tree-sequence tables on the host for models up to %.0e genotype "
-                          "bits on one GPU; this one is larger (or tiled): not recorded. "
+                          "bits; this one is larger: not recorded. "
                           "Genotypes are tracked in full on the device either way."
                           % self._PEDIGREE_MAX_BITS)
             return

@@ -18,8 +18,9 @@ What changes with respect to the single-GPU Species:
   * accessors and statistics return the GLOBAL population on every rank (tiles
     gathered); files are written by rank 0.
 Mutations: every rank draws the same list from the host generator and applies those
-whose offspring it owns (_mutate_tiled).  Not supported on several GPUs: panmixia,
-linkage statistics, the pedigree tables.
+whose offspring it owns (_mutate_tiled); the pedigree tables are kept whole on every
+rank (birth records gathered each step).  Not supported on several GPUs: panmixia,
+linkage statistics.
 """
 import numpy as np
 
@@ -77,7 +78,8 @@ class TiledSpecies(Species):
 
     def _do_pop_dynamics(self, land=None):
         burn = not self.burned
-        hook = self._mutate_tiled if (self.mutate and not burn) else None
+        hook = self._after_births if (not burn and (self.mutate or self._tt is not None)) \
+            else None
         n, births, deaths = self._stepper.step(burn, self.selection and self.burned,
                                                after_births=hook)
         self._glob_N = int(n)
@@ -86,6 +88,16 @@ class TiledSpecies(Species):
         self.max_ind_idx = self._stepper.max_id
         if self._check_extinct():
             self.extinct = True
+
+    def _after_births(self, first_id, n_offspring):
+        if self._tt is not None:
+            # every rank keeps the whole pedigree: gather the tiles' birth records
+            rec = self._dev.last_births()
+            parts = [np.concatenate([b.view(a.dtype).reshape((-1,) + a.shape[1:])
+                                     for b in self._gather_bytes(a)]) for a in rec]
+            self._tt.add_births(self.t, *parts)
+        if self.mutate:
+            self._mutate_tiled(first_id, n_offspring)
 
     def _mutate_tiled(self, first_id, n_offspring):
         """ops/mutation.py:169-206 over the step's offspring of ALL tiles: every rank
@@ -115,6 +127,8 @@ class TiledSpecies(Species):
             dirty = True
         if dirty:
             self._upload_gen_arch()
+        if self._tt is not None:
+            self._tt.add_mutations(who, loci, homs)
         ids = self._dev.download(nat.F_ID)
         order = np.argsort(ids, kind='stable')
         pos = np.minimum(np.searchsorted(ids[order], who), max(ids.size - 1, 0))
@@ -166,6 +180,8 @@ class TiledSpecies(Species):
             left_h -= h_r
         self._dev.assign_genomes(share.astype(np.int32))
         self._shard.has_genomes = True
+        self._genomes_assigned = True
+        self._start_pedigree()
 
     # -- iterations (Model snapshots) ---------------------------------------------------
     def _snapshot(self):

@@ -23,7 +23,7 @@ from test_gpu_model_api import small_params               # noqa: E402
 p = small_params(seed=4, traits=traits, L=48, T=15, dim=(32, 32))
 if mutate:
     p['comm']['species']['spp_0']['gen_arch'].update({'start_neut_zero': True,
-                                                      'mu_neut': 5e-4})
+                                                      'mu_neut': 5e-4, 'use_tskit': True})
 p['model']['stats'] = ParametersDict({'Nt': {'calc': True, 'freq': 1},
                                       'het': {'calc': True, 'freq': 5, 'mean': False},
                                       'maf': {'calc': True, 'freq': 5},
@@ -46,12 +46,15 @@ xy = mod.get_coords()
 g = spp._get_genotypes()
 z = mod.get_z() if traits else np.zeros((len(ids), 0))
 het = mod._stats_collector.stats['spp_0']['het']['vals'][14]
+ped_ok = -1
+if spp._tt is not None:        # genotypes read back through the recorded pedigree
+    ped_ok = int((spp._tt.genotypes_of(ids) == g).all())
 rank = int(os.environ.get('RANK', '0'))
 if rank == 0:
     np.savez(out, Nt=np.array(spp.Nt), births=np.array(spp.n_births),
              deaths=np.array(spp.n_deaths), nburn=nburn, n_at_assign=n_at_assign,
              site_counts0=g0.sum(axis=(0, 2)), n0=g0.shape[0], ids=ids, xy=xy, g=g, z=z,
-             het=np.asarray(het), K=spp.K, N_rast=spp.N, world=int(os.environ.get('WORLD_SIZE', 1)))
+             het=np.asarray(het), K=spp.K, ped_ok=ped_ok, N_rast=spp.N, world=int(os.environ.get('WORLD_SIZE', 1)))
 import torch.distributed as dist                           # noqa: E402
 if dist.is_initialized():
     dist.barrier()

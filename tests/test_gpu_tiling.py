@@ -266,3 +266,6 @@ def test_model_over_two_ranks_with_mutation(tmp_path):
     assert one['site_counts0'].sum() == 0 and two['site_counts0'].sum() == 0
     assert one['g'].sum() > 0                       # mutations happened and were inherited
     np.testing.assert_array_equal(one['g'], two['g'])
+    # 'use_tskit': the pedigree recorded on one GPU and over two ranks reproduces the
+    # device genotypes (edges + mutation rows, structs/pedigree.py)
+    assert int(one['ped_ok']) == 1 and int(two['ped_ok']) == 1
