@@ -44,7 +44,7 @@ EXPORTS = [
     'gnx_tile_export_migrants_dev', 'gnx_tile_export_halo_dev', 'gnx_tile_staged_ptrs',
     'gnx_tile_import_dev', 'gnx_tile_import_ghosts_dev', 'gnx_tile_pair_ptrs',
     'gnx_tile_offspring_dev', 'gnx_tile_group_requests', 'gnx_tile_serve_gametes_dev',
-    'gnx_tile_put_gametes_dev', 'gnx_tile_bins_ptr', 'gnx_set_k_raster', 'gnx_last_births', 'gnx_set_positions', 'gnx_n_slots',
+    'gnx_tile_put_gametes_dev', 'gnx_tile_bins_ptr', 'gnx_set_k_raster', 'gnx_last_births', 'gnx_set_positions', 'gnx_n_slots', 'gnx_stats_ld_counts',
 ]
 
 
@@ -634,6 +634,14 @@ class Device:
         self._chk(self.lib.gnx_stats_ld(self.h, int(loci.size), _ptr(loci, C.c_int32),
                                         _ptr(out, C.c_double)))
         return out
+
+    def stats_ld_counts(self, loci):
+        loci = _arr(loci, np.int32)
+        c = np.zeros(loci.size, np.int64)
+        cc = np.zeros((loci.size, loci.size), np.int64)
+        self._chk(self.lib.gnx_stats_ld_counts(self.h, int(loci.size), _ptr(loci, C.c_int32),
+                                               _ptr(c, C.c_int64), _ptr(cc, C.c_int64)))
+        return c, cc
 
     # -- measurement ---------------------------------------------------------
     def profiling(self, on):

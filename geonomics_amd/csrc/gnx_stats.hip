@@ -106,6 +106,62 @@ __global__ void k_ld_pairs(int n_loci, int64_t n_hwords, double two_N, const u64
   r2[(int64_t)j * n_loci + i] = v;
 }
 
+// the counts behind r^2 (they add over tiles): c[i] = 1-alleles at locus i over the 2N
+// chromosomes, cc[i][j] = chromosomes carrying 1 at both
+__global__ void k_ld_counts(int n_loci, int64_t n_hwords, const u64* __restrict__ T,
+                            long long* __restrict__ c, long long* __restrict__ cc) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y;
+  if (j >= n_loci || j < i) return;
+  const u64* a = T + (int64_t)i * n_hwords;
+  const u64* b = T + (int64_t)j * n_hwords;
+  long long cij = 0;
+  for (int64_t q = 0; q < n_hwords; ++q) cij += __popcll(a[q] & b[q]);
+  cc[(int64_t)i * n_loci + j] = cij;
+  cc[(int64_t)j * n_loci + i] = cij;
+  if (i == j) c[i] = cij;
+}
+
+extern "C" int gnx_stats_ld_counts(gnx_state* h, int32_t n_loci, const int32_t* loci,
+                                   int64_t* c, int64_t* cc) {
+  if (h->cfg.L == 0 || !h->genomes_assigned) {
+    gnx_set_error("gnx_stats_ld_counts: genomes not assigned");
+    return 1;
+  }
+  if (n_loci <= 0 || n_loci > 8192) {
+    gnx_set_error("gnx_stats_ld_counts: 1..8192 loci per call (the matrix is n x n)");
+    return 1;
+  }
+  for (int j = 0; j < n_loci; ++j)
+    if (loci[j] < 0 || loci[j] >= h->cfg.L) {
+      gnx_set_error("gnx_stats_ld_counts: locus out of range");
+      return 1;
+    }
+  const int64_t N = h->N;
+  const int64_t n_hwords = std::max<int64_t>(1, (2 * N + 63) / 64);
+  int32_t* d_loci = nullptr;
+  u64* T = nullptr;
+  long long *d_c = nullptr, *d_cc = nullptr;
+  HIPCHK(hipMalloc((void**)&d_loci, n_loci * sizeof(int32_t)));
+  HIPCHK(hipMalloc((void**)&T, (size_t)n_loci * n_hwords * 8));
+  HIPCHK(hipMalloc((void**)&d_c, (size_t)n_loci * 8));
+  HIPCHK(hipMalloc((void**)&d_cc, (size_t)n_loci * n_loci * 8));
+  GNXCHK(gnx_h2d(h, d_loci, loci, n_loci * sizeof(int32_t)));
+  hipLaunchKernelGGL(k_ld_transpose, dim3(gnx_grid(n_hwords, 128), n_loci), dim3(128), 0,
+                     h->stream, n_loci, n_hwords, N, h->W64, d_loci, (const u64*)h->G,
+                     h->soa[h->cur].grow, T);
+  hipLaunchKernelGGL(k_ld_counts, dim3(gnx_grid(n_loci, 128), n_loci), dim3(128), 0, h->stream,
+                     n_loci, n_hwords, T, d_c, d_cc);
+  int rc = gnx_d2h(h, c, d_c, (size_t)n_loci * 8);
+  if (!rc) rc = gnx_d2h(h, cc, d_cc, (size_t)n_loci * n_loci * 8);
+  (void)hipFree(d_loci);
+  (void)hipFree(T);
+  (void)hipFree(d_c);
+  (void)hipFree(d_cc);
+  HIPCHK(hipGetLastError());
+  return rc;
+}
+
 extern "C" int gnx_stats_ld(gnx_state* h, int32_t n_loci, const int32_t* loci, double* r2) {
   if (h->cfg.L == 0 || !h->genomes_assigned) {
     gnx_set_error("gnx_stats_ld: genomes not assigned");

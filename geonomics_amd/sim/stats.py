@@ -49,9 +49,21 @@ def _calc_ld(spp, plot=False, loci=None):
     per call by the C-ABI)."""
     if loci is None:
         loci = np.arange(spp.gen_arch.L)
-    if getattr(spp, '_comm', None) is not None:
-        raise NotImplementedError('linkage statistics on a tiled landscape')
-    return spp._dev.stats_ld(np.asarray(loci, dtype=np.int32))
+    loci = np.asarray(loci, dtype=np.int32)
+    comm = getattr(spp, '_comm', None)
+    if comm is None:
+        return spp._dev.stats_ld(loci)
+    # tiles: the chromosome counts add; r^2 from the global counts, as the kernel does
+    c, cc = spp._dev.stats_ld_counts(loci)
+    tot = comm.allreduce_sum(np.concatenate([c, cc.ravel()]))
+    c, cc = tot[:c.size].astype(np.float64), tot[c.size:].reshape(cc.shape).astype(np.float64)
+    two_n = 2.0 * len(spp)
+    f = c / two_n
+    D = cc / two_n - (f[:, None] * f[None, :])
+    with np.errstate(divide='ignore', invalid='ignore'):
+        r2 = (D * D) / ((f * (1 - f))[:, None] * (f * (1 - f))[None, :])
+    r2[np.arange(loci.size), np.arange(loci.size)] = np.nan
+    return r2
 
 
 def _calc_mean_fitness(spp):

@@ -19,8 +19,8 @@ What changes with respect to the single-GPU Species:
     gathered); files are written by rank 0.
 Mutations: every rank draws the same list from the host generator and applies those
 whose offspring it owns (_mutate_tiled); the pedigree tables are kept whole on every
-rank (birth records gathered each step).  Not supported on several GPUs: panmixia,
-linkage statistics.
+rank (birth records gathered each step); linkage r^2 from counts summed over the tiles
+(sim/stats.py).  Not supported on several GPUs: panmixia.
 """
 import numpy as np
 

@@ -334,6 +334,10 @@ int gnx_last_births(gnx_state* h, int64_t* child_id /*[B]*/, int64_t* parent_id 
 int gnx_stats_locus_counts(gnx_state* h, int32_t* cnt1 /*[L]*/, int32_t* cnt_het /*[L]*/);
 /* r^2 between the listed loci (_calc_ld); double [n][n], NaN on the diagonal */
 int gnx_stats_ld(gnx_state* h, int32_t n_loci, const int32_t* loci, double* r2);
+/* the counts behind r^2, which add over tiles: c[i] 1-alleles at locus i, cc[i][j]
+ * chromosomes carrying 1 at both i and j                                        */
+int gnx_stats_ld_counts(gnx_state* h, int32_t n_loci, const int32_t* loci, int64_t* c /*[n]*/,
+                        int64_t* cc /*[n][n]*/);
 
 /* ---- measurement ------------------------------------------------------------ */
 int gnx_profiling(gnx_state* h, int32_t on);

@@ -46,6 +46,8 @@ xy = mod.get_coords()
 g = spp._get_genotypes()
 z = mod.get_z() if traits else np.zeros((len(ids), 0))
 het = mod._stats_collector.stats['spp_0']['het']['vals'][14]
+from geonomics_amd.sim.stats import _calc_ld          # noqa: E402
+ld = _calc_ld(spp, loci=np.arange(0, 48, 3))
 ped_ok = -1
 if spp._tt is not None:        # genotypes read back through the recorded pedigree
     ped_ok = int((spp._tt.genotypes_of(ids) == g).all())
@@ -54,7 +56,7 @@ if rank == 0:
     np.savez(out, Nt=np.array(spp.Nt), births=np.array(spp.n_births),
              deaths=np.array(spp.n_deaths), nburn=nburn, n_at_assign=n_at_assign,
              site_counts0=g0.sum(axis=(0, 2)), n0=g0.shape[0], ids=ids, xy=xy, g=g, z=z,
-             het=np.asarray(het), K=spp.K, ped_ok=ped_ok, N_rast=spp.N, world=int(os.environ.get('WORLD_SIZE', 1)))
+             het=np.asarray(het), K=spp.K, ped_ok=ped_ok, ld=ld, N_rast=spp.N, world=int(os.environ.get('WORLD_SIZE', 1)))
 import torch.distributed as dist                           # noqa: E402
 if dist.is_initialized():
     dist.barrier()

@@ -229,6 +229,11 @@ def test_model_over_two_ranks_equals_single_process_when_neutral(tmp_path):
         assert int(r['n0']) == int(r['n_at_assign'])
         np.testing.assert_array_equal(r['site_counts0'], np.full(48, int(r['n0'])))
     assert two['g'].shape == one['g'].shape and 0.3 < two['g'].mean() < 0.7
+    # linkage statistics over the tiles: global chromosome counts, the oracle's r^2
+    import gnx_oracle as O
+    exp = O.stats_ld(two['g'][:, ::3, :])
+    fin = np.isfinite(exp)
+    np.testing.assert_allclose(two['ld'][fin], exp[fin], rtol=1e-9, atol=1e-13)
     assert two['het'].shape == (48,) and 0.3 < two['het'].mean() < 0.7
     # rank 0 wrote the files, once (Model.walk leaves mod.it at -1, as the reference does)
     base = wd / 'GNX_mod-api_test' / 'it--1' / 'spp-spp_0'
