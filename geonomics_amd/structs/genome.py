@@ -88,14 +88,32 @@ class Recombinations:
         expected = rates.sum()
         uniform = np.allclose(rates[1:], rates[1]) if L > 1 else True
         if uniform and expected <= 32 and L > 1:
-            # equal small rates: #switches ~ Binomial(L-1, r) at distinct loci
+            # equal small rates: #switches ~ Binomial(L-1, r) at distinct loci; the path
+            # words are the prefix parity of the switch bits (word-parallel)
             ks = self._rng.binomial(L - 1, rates[1], n)
-            for i in range(n):
-                if ks[i]:
-                    bp = np.sort(self._rng.choice(L - 1, ks[i], replace=False) + 1)
-                    bp = bp.tolist() + [L]
-                    for j in range(0, len(bp) - 1, 2):
-                        _set_bit_range(out[i], bp[j], bp[j + 1])
+            rows = np.repeat(np.arange(n), ks)
+            bps = self._rng.randint(1, L, rows.size)
+            while True:                      # redraw the (rare) repeats inside a path
+                key = rows * L + bps
+                _, first = np.unique(key, return_index=True)
+                dup = np.ones(key.size, bool)
+                dup[first] = False
+                if not dup.any():
+                    break
+                bps[dup] = self._rng.randint(1, L, int(dup.sum()))
+            T = np.zeros((n, W64), dtype=np.uint64)
+            np.bitwise_xor.at(T, (rows, bps >> 6), np.uint64(1) << (bps & 63).astype(np.uint64))
+            out = T.copy()
+            for sh in (1, 2, 4, 8, 16, 32):
+                out ^= out << np.uint64(sh)
+            par = (np.bitwise_count(T) & 1).astype(np.int64)
+            carry = (np.cumsum(par, axis=1) - par) & 1
+            out ^= np.where(carry == 1, np.uint64(0xFFFFFFFFFFFFFFFF), np.uint64(0))
+            # bits beyond L stay clear
+            last = L >> 6
+            if last < W64:
+                out[:, last] &= (np.uint64(1) << np.uint64(L & 63)) - np.uint64(1)
+                out[:, last + 1:] = 0
         else:
             chunk = max(1, int(2e7 // max(L, 1)))
             for a in range(0, n, chunk):
@@ -109,11 +127,25 @@ class Recombinations:
     def _breakpoints(self):
         """CSR list of the loci where each cached path switches homologue
         (path[l] != path[l-1]; a path starts on homologue 0)"""
-        bits = np.unpackbits(self._paths.view(np.uint8), axis=1, bitorder='little')[:, :self._L]
-        prev = np.concatenate([np.zeros((bits.shape[0], 1), np.uint8), bits[:, :-1]], axis=1)
-        sw = bits != prev
-        off = np.concatenate([[0], np.cumsum(sw.sum(axis=1))]).astype(np.int64)
-        return off, np.nonzero(sw)[1].astype(np.int64)
+        x = self._paths
+        prev_top = np.concatenate([np.zeros((x.shape[0], 1), np.uint64),
+                                   x[:, :-1] >> np.uint64(63)], axis=1)
+        sw = x ^ ((x << np.uint64(1)) | prev_top)          # bit l set: path[l] != path[l-1]
+        last = self._L >> 6
+        if last < sw.shape[1]:
+            sw[:, last] &= (np.uint64(1) << np.uint64(self._L & 63)) - np.uint64(1)
+            sw[:, last + 1:] = 0
+        r, w = np.nonzero(sw)
+        rows, loci = [], []
+        for b in range(64):                # at most a few set bits per non-zero word
+            hit = (sw[r, w] >> np.uint64(b)) & np.uint64(1) == 1
+            rows.append(r[hit])
+            loci.append(w[hit] * 64 + b)
+        rows, loci = np.concatenate(rows), np.concatenate(loci)
+        o = np.lexsort((loci, rows))
+        counts = np.bincount(rows, minlength=x.shape[0])
+        off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        return off, loci[o].astype(np.int64)
 
     def _get_path_bits(self, key):
         by = self._paths[key].view(np.uint8)
