@@ -126,7 +126,11 @@ class Comm:
         else:
             self.rank = dist.get_rank()
             self.world = dist.get_world_size()
-            self.device = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+            import os
+            # tensors of the collectives live where the backend can move them; rehearsals
+            # can force device tensors over another backend (GNX_COMM_DEVICE=cuda)
+            self.device = os.environ.get('GNX_COMM_DEVICE') or (
+                'cuda' if dist.get_backend() == 'nccl' else 'cpu')
 
     def _t(self, a):
         import torch

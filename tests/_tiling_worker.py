@@ -128,7 +128,7 @@ def run(backend, shard_kind, world, rank, port, steps, out, fixed=True):
         np.savez(out, ids=I[order], x=np.concatenate(X)[order], y=np.concatenate(Y)[order],
                  age=np.concatenate(A)[order], z=np.concatenate(Z)[order],
                  geno=np.concatenate(Gs)[order], hist=np.array(hist),
-                 bytes_sent=stepper.bytes_sent)
+                 bytes_sent=stepper.bytes_sent, dev_transport=int(stepper.dev_transport))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

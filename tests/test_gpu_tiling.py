@@ -274,3 +274,17 @@ def test_model_over_two_ranks_with_mutation(tmp_path):
     # 'use_tskit': the pedigree recorded on one GPU and over two ranks reproduces the
     # device genotypes (edges + mutation rows, structs/pedigree.py)
     assert int(one['ped_ok']) == 1 and int(two['ped_ok']) == 1
+
+
+def test_device_transport_across_processes(tmp_path, monkeypatch):
+    """the device-resident exchanges between separate PROCESSES (separate address spaces,
+    torch.distributed point-to-point and collectives on device tensors that wrap the
+    library's memory), carried by gloo on the 1-GPU box - what RCCL carries on a node"""
+    one = launch('gloo', 'device', 1, 8, str(tmp_path / 'one.npz'), 'poisson')
+    monkeypatch.setenv('GNX_COMM_DEVICE', 'cuda')
+    many = launch('gloo', 'device', 4, 8, str(tmp_path / 'many.npz'), 'poisson')
+    assert int(many['dev_transport']) == 1 and int(one['dev_transport']) == 0
+    assert one['hist'].tolist() == many['hist'].tolist()
+    for k in ('ids', 'x', 'y', 'age', 'z', 'geno'):
+        np.testing.assert_array_equal(one[k], many[k], err_msg=k)
+    assert many['bytes_sent'] > 0
