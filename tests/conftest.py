@@ -13,6 +13,10 @@ for p in (ROOT, os.path.join(ROOT, 'oracle')):
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (HIP device)')
+    # no test may hang the run (multi-process / multi-thread tiling tests): with the
+    # pytest-timeout plugin present, every test gets a ceiling
+    if config.pluginmanager.hasplugin('timeout') and not getattr(config.option, 'timeout', None):
+        config.option.timeout = 900
 
 
 def load_golden(name):
