@@ -13,10 +13,6 @@ for p in (ROOT, os.path.join(ROOT, 'oracle')):
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (HIP device)')
-    # no test may hang the run (multi-process / multi-thread tiling tests): with the
-    # pytest-timeout plugin present, every test gets a ceiling
-    if config.pluginmanager.hasplugin('timeout') and not getattr(config.option, 'timeout', None):
-        config.option.timeout = 900
 
 
 def load_golden(name):
@@ -40,6 +36,12 @@ HAVE_GPU = None
 
 
 def pytest_collection_modifyitems(config, items):
+    # no test may hang the run (multi-process / multi-thread tiling tests): with the
+    # pytest-timeout plugin present, every test gets a ceiling
+    if config.pluginmanager.hasplugin('timeout'):
+        for item in items:
+            if item.get_closest_marker('timeout') is None:
+                item.add_marker(pytest.mark.timeout(900))
     # gpu-marked tests are selected with -m gpu on the GPU box; when collected
     # without a device (plain `pytest tests/`), skip them instead of failing.
     global HAVE_GPU
