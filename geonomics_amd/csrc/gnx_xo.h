@@ -1,0 +1,196 @@
+// Bitmask crossover kernels (ops/mating.py:130-214) - shared by libgnxhip.so
+// (gnx_kernels_genome.hip) and the kernel lab (tools/xo_lab.hip), so that what the lab
+// times is the product kernel.
+//
+// For gamete p in {0,1} of an offspring:  gamete[l] = parent_p.g[l, path_k[l] XOR s]
+// i.e. with m = path ^ (-s):  gamete = (hom0 & ~m) | (hom1 & m), 128 bits per lane per
+// access.  Child homologue 0 <- pair[0]'s gamete, homologue 1 <- pair[1]'s (:169).
+//
+// Work arrives as a JOB LIST, one 16-byte record per gamete (GnxXoJob), built on the
+// device after the step's death draws: only offspring that SURVIVE their first
+// mortality round get a genome row and a job (the others' 25-KB rows would be written
+// and never read).  One WAVEFRONT owns one job at a time: the record is a scalar load,
+// parent row / child row / path / start homologue live in SGPRs, and the 64 lanes stream
+// the homologue in 16-byte chunks (1 KiB per wave-instruction, U chunks in flight per
+// lane).  The grid is fixed (persistent-style, job-strided) and reads the job count from
+// device memory, so the host never needs the count to launch.
+//
+// k_xo_sparse: masks rebuilt from the path's short breakpoint list (<= GNX_SPARSE_MAX_BP
+//   switches, held in a VGPR and broadcast with v_readlane); a chunk loads only the ONE
+//   homologue it copies (the rare chunks holding a switch are patched afterwards), which
+//   halves the read traffic when crossovers are rare (r = 1/L): L/2 bytes per birth.
+// k_xo_dense: masks read from the bit-packed path table (any recombination map): two
+//   homologues + mask read, one written per gamete: L bytes per birth.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned long long u64;
+
+struct alignas(16) u64x2 {
+  u64 a, b;
+};
+
+struct alignas(16) GnxXoJob {
+  int32_t prow;    // parent's genome row
+  int32_t dst;     // destination half-row: child_row * 2 + p
+  int32_t key;     // recombination path
+  int32_t start;   // start homologue (0 / 1)
+};
+
+template <bool NT>
+__device__ __forceinline__ u64x2 xo_load(const u64x2* __restrict__ p) {
+  if (NT) {
+    u64x2 v;
+    v.a = __builtin_nontemporal_load(&p->a);
+    v.b = __builtin_nontemporal_load(&p->b);
+    return v;
+  }
+  return *p;
+}
+
+// the child row is not read again this step: keep it out of L2 / MALL
+__device__ __forceinline__ void xo_store(u64x2* __restrict__ p, u64x2 v) {
+  __builtin_nontemporal_store(v.a, &p->a);
+  __builtin_nontemporal_store(v.b, &p->b);
+}
+
+// mask of chunk c (loci [128c, 128c+128)) from the breakpoint list: lane q of `mybp`
+// holds switch point q (ascending), broadcast with v_readlane - no memory touched
+__device__ __forceinline__ u64x2 xo_mask_lanes(int c, u64 s, int mybp, int nbp) {
+  const int lo = c * 128;
+  u64 par = s;
+  u64x2 m;
+  m.a = 0;
+  m.b = 0;
+  for (int q = 0; q < nbp; ++q) {
+    const int bpl = __builtin_amdgcn_readlane(mybp, q);
+    const int d = bpl - lo;
+    par ^= d < 0 ? ~0ull : 0ull;
+    const u64 fa = ~0ull << (d & 63);
+    m.a ^= (d >= 0 && d < 64) ? fa : 0ull;
+    m.b ^= (d >= 0 && d < 64) ? ~0ull : ((d >= 64 && d < 128) ? fa : 0ull);
+  }
+  m.a ^= par;
+  m.b ^= par;
+  return m;
+}
+
+// homologue (0/1) the gamete copies at locus l
+__device__ __forceinline__ int xo_sel_sparse(int l, int start, int mybp, int nbp) {
+  int sel = start;
+  for (int q = 0; q < nbp; ++q) sel ^= (__builtin_amdgcn_readlane(mybp, q) <= l) ? 1 : 0;
+  return sel;
+}
+
+// The streaming part is branch-free: every chunk issues exactly one load, from the
+// homologue selected by a v_cndmask on the address, U loads back to back (divergent
+// copy-h0 / copy-h1 / blend arms make the compiler drain vmcnt before each arm).
+template <int U, bool NT_LD>
+__global__ void __launch_bounds__(256)
+k_xo_sparse(const int32_t* __restrict__ n_jobs_p, int W16, const u64x2* __restrict__ G,
+            u64x2* __restrict__ Gout, const GnxXoJob* __restrict__ jobs,
+            const int32_t* __restrict__ bp_off, const int32_t* __restrict__ bp_loci) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int n_jobs = *n_jobs_p;
+  const int n_waves = (int)gridDim.x * 4;
+  for (int j = (int)blockIdx.x * 4 + wv; j < n_jobs; j += n_waves) {
+    const GnxXoJob jb = jobs[j];
+    const int prow = __builtin_amdgcn_readfirstlane(jb.prow);
+    const int dsth = __builtin_amdgcn_readfirstlane(jb.dst);
+    const int key = __builtin_amdgcn_readfirstlane(jb.key);
+    const u64 s = __builtin_amdgcn_readfirstlane(jb.start) ? ~0ull : 0ull;
+    const u64x2* h0 = G + ((int64_t)prow * 2 + 0) * W16;
+    const u64x2* h1 = h0 + W16;
+    u64x2* dst = Gout + (int64_t)dsth * W16;
+    const int bp0 = __builtin_amdgcn_readfirstlane(bp_off[key]);
+    const int nbp = __builtin_amdgcn_readfirstlane(bp_off[key + 1]) - bp0;
+    const int mybp = lane < nbp ? bp_loci[bp0 + lane] : 0x7fffffff;
+    for (int c0 = lane; c0 < W16; c0 += 64 * U) {
+      u64x2 m[U], v[U];
+      bool mixed = false;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = min(c0 + u * 64, W16 - 1);     // tail lanes re-read the last chunk
+        m[u] = xo_mask_lanes(c, s, mybp, nbp);
+        const bool one = (m[u].a & m[u].b) == ~0ull;
+        mixed |= !one && (m[u].a | m[u].b) != 0ull;
+        v[u] = xo_load<NT_LD>((one ? h1 : h0) + c);
+      }
+      if (__builtin_expect(mixed, 0)) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int c = min(c0 + u * 64, W16 - 1);
+          if ((m[u].a & m[u].b) != ~0ull && (m[u].a | m[u].b) != 0ull) {
+            const u64x2 b = h1[c];
+            v[u].a = (v[u].a & ~m[u].a) | (b.a & m[u].a);
+            v[u].b = (v[u].b & ~m[u].b) | (b.b & m[u].b);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = c0 + u * 64;
+        if (c < W16) xo_store(dst + c, v[u]);
+      }
+    }
+  }
+}
+
+template <int U, bool NT_LD>
+__global__ void __launch_bounds__(256)
+k_xo_dense(const int32_t* __restrict__ n_jobs_p, int W16, const u64x2* __restrict__ G,
+           u64x2* __restrict__ Gout, const GnxXoJob* __restrict__ jobs,
+           const u64x2* __restrict__ paths) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int n_jobs = *n_jobs_p;
+  const int n_waves = (int)gridDim.x * 4;
+  for (int j = (int)blockIdx.x * 4 + wv; j < n_jobs; j += n_waves) {
+    const GnxXoJob jb = jobs[j];
+    const int prow = __builtin_amdgcn_readfirstlane(jb.prow);
+    const int dsth = __builtin_amdgcn_readfirstlane(jb.dst);
+    const int key = __builtin_amdgcn_readfirstlane(jb.key);
+    const u64 s = __builtin_amdgcn_readfirstlane(jb.start) ? ~0ull : 0ull;
+    const u64x2* h0 = G + ((int64_t)prow * 2 + 0) * W16;
+    const u64x2* h1 = h0 + W16;
+    u64x2* dst = Gout + (int64_t)dsth * W16;
+    // the path table (n_recomb_sims x L/8 bytes) is re-read by every gamete that drew
+    // the key: default cache policy, so it can stay in L2 / the Infinity Cache
+    const u64x2* pm = paths + (int64_t)key * W16;
+    for (int c0 = lane; c0 < W16; c0 += 64 * U) {
+      u64x2 m[U], a[U], b[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = min(c0 + u * 64, W16 - 1);
+        m[u] = pm[c];
+        a[u] = xo_load<NT_LD>(h0 + c);
+        b[u] = xo_load<NT_LD>(h1 + c);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = c0 + u * 64;
+        const u64 ma = m[u].a ^ s, mb = m[u].b ^ s;
+        u64x2 o;
+        o.a = (a[u].a & ~ma) | (b[u].a & ma);
+        o.b = (a[u].b & ~mb) | (b[u].b & mb);
+        if (c < W16) xo_store(dst + c, o);
+      }
+    }
+  }
+}
+
+// unroll that wastes the fewest wave-loads for a homologue of W16 chunks
+static inline int gnx_xo_pick_unroll(int W16) {
+  const int T = (W16 + 63) / 64;
+  int best = 8, waste = 1 << 30;
+  for (int U = 8; U >= 4; --U) {
+    const int w = ((T + U - 1) / U) * U - T;
+    if (w < waste) {
+      waste = w;
+      best = U;
+    }
+  }
+  return best;
+}

@@ -818,3 +818,21 @@ def stats_ld(g):
         r2 = (D * D) / ((f * (1 - f))[:, None] * (f * (1 - f))[None, :])
     r2[np.arange(L), np.arange(L)] = np.nan
     return r2
+
+
+# --------------------------------------------------------------------------
+# f4  burn-in spatial tester (sim/burnin.py:44-59)
+# --------------------------------------------------------------------------
+
+def spatial_diff_stats(prev_counts, x, y, dim):
+    """SpatialTester.update: per-cell counts of individuals (cell = int(x), int(y);
+    counts[i, j] holds cell (x=j, y=i)), their difference to the previous counts,
+    and np.mean / np.std (population) of the difference raster.
+    Returns counts, mean, std."""
+    W, H = dim
+    cx = np.asarray(x).astype(np.int64)
+    cy = np.asarray(y).astype(np.int64)
+    counts = np.bincount(cy * W + cx, minlength=W * H).reshape(H, W).astype(np.float64)
+    diff = counts - np.asarray(prev_counts, dtype=np.float64)
+    return counts, float(np.mean(diff)), float(np.std(diff))
+

@@ -796,14 +796,41 @@ def g15_wf():
     save('g15_wf', **out)
 
 
+def g16_spatial_tester():
+    """SpatialTester.update (sim/burnin.py:44-59) over the burn-in steps of a reference
+    model: positions handed to it at every update, and the mean / std of the per-cell
+    count differences it records (the burn-in stationarity tests run on these series)."""
+    from geonomics.sim import burnin as ref_burnin
+    out = {}
+    for s, dim in ((1, (24, 24)), (2, (17, 17))):
+        mod = make_ref_model(dim=dim, N=200, L=16, traits=False, seed=s)
+        spp = mod.comm[0]
+        tester = ref_burnin.SpatialTester(spp)
+        xs = [np.array(spp._get_x())]
+        ys = [np.array(spp._get_y())]
+        for t in range(7):
+            mod.walk(1, 'burn', verbose=False)
+            xs.append(np.array(spp._get_x()))
+            ys.append(np.array(spp._get_y()))
+            tester.update(spp)
+        out['s%i_dim' % s] = np.array(dim)
+        out['s%i_n' % s] = np.array([len(a) for a in xs])
+        out['s%i_x' % s] = np.concatenate(xs)
+        out['s%i_y' % s] = np.concatenate(ys)
+        out['s%i_mean' % s] = np.array(tester.stats[np.mean], dtype=float)
+        out['s%i_std' % s] = np.array(tester.stats[np.std], dtype=float)
+        out['s%i_counts' % s] = np.array(tester.counts)
+    save('g16_spatial_tester', **out)
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g7', 'g8', 'g9',
-                             'g10', 'g11', 'g12', 'g13', 'g14', 'g15']
+                             'g10', 'g11', 'g12', 'g13', 'g14', 'g15', 'g16']
     fns = {'g1': g1_crossover, 'g2': g2_recomb_paths,
            'g3': g3_phenotype_fitness, 'g4': g4_density,
            'g5': g5_demography, 'g7': g7_movement, 'g8': g8_pairing,
            'g9': g9_starting_genomes, 'g10': g10_envelopes,
            'g11': g11_conductance, 'g12': g12_stats, 'g13': g13_change,
-           'g14': g14_data, 'g15': g15_wf}
+           'g14': g14_data, 'g15': g15_wf, 'g16': g16_spatial_tester}
     for w in which:
         fns[w]()

@@ -429,3 +429,20 @@ def test_uniform_mate_choice_properties():
     assert (mate_f[~focal] == -1).all()
     # different steps give different picks
     assert (O.choose_mates(x, y, ids, r, 5, 4, dim=(W, H)) != mate).mean() > 0.3
+
+
+def test_spatial_tester_vs_reference():
+    """G16: the reference's SpatialTester.update series (sim/burnin.py:44-59) over the
+    first burn-in steps of two reference models"""
+    g = load_golden('g16_spatial_tester')
+    for s in (1, 2):
+        dim = tuple(int(v) for v in g['s%i_dim' % s])
+        off = np.concatenate([[0], np.cumsum(g['s%i_n' % s])])
+        counts = np.zeros((dim[1], dim[0]))
+        for t in range(len(off) - 1):
+            x = g['s%i_x' % s][off[t]:off[t + 1]]
+            y = g['s%i_y' % s][off[t]:off[t + 1]]
+            counts, m, sd = O.spatial_diff_stats(counts, x, y, dim)
+            assert abs(m - g['s%i_mean' % s][t]) < 1e-12
+            assert abs(sd - g['s%i_std' % s][t]) < 1e-12
+        np.testing.assert_array_equal(counts, g['s%i_counts' % s])
