@@ -45,6 +45,7 @@ EXPORTS = [
     'gnx_tile_import_dev', 'gnx_tile_import_ghosts_dev', 'gnx_tile_pair_ptrs',
     'gnx_tile_offspring_dev', 'gnx_tile_group_requests', 'gnx_tile_serve_gametes_dev',
     'gnx_tile_put_gametes_dev', 'gnx_tile_bins_ptr', 'gnx_set_k_raster', 'gnx_last_births', 'gnx_set_positions', 'gnx_n_slots', 'gnx_stats_ld_counts',
+    'gnx_set_defer_crossover', 'gnx_last_crossover_births',
 ]
 
 
@@ -98,6 +99,7 @@ def load():
     lib.gnx_last_error.restype = C.c_char_p
     lib.gnx_step_index.restype = C.c_int64
     lib.gnx_n_slots.restype = C.c_int64
+    lib.gnx_last_crossover_births.restype = C.c_int64
     lib.gnx_destroy.restype = None
     _lib = lib
     return lib
@@ -285,6 +287,14 @@ class Device:
 
     def synchronize(self):
         self._chk(self.lib.gnx_synchronize(self.h))
+
+    def set_defer_crossover(self, on):
+        """cut the offspring's genomes after the death draws, survivors only (default)"""
+        self._chk(self.lib.gnx_set_defer_crossover(self.h, int(bool(on))))
+
+    @property
+    def last_crossover_births(self):
+        return self.lib.gnx_last_crossover_births(self.h)
 
     def set_stream(self, stream_ptr):
         self._chk(self.lib.gnx_set_stream(self.h, C.c_void_p(stream_ptr)))

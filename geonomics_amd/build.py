@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libgnxhip.so')
 SOURCES = ['gnx_api.hip', 'gnx_kernels_pop.hip', 'gnx_kernels_genome.hip',
            'gnx_kernels_demog.hip', 'gnx_tile.hip', 'gnx_stats.hip', 'gnx_prim.hip']
-HEADERS = ['gnx_internal.h', 'gnx_rng.h', os.path.join('..', '..', 'include', 'gnx_hip.h')]
+HEADERS = ['gnx_internal.h', 'gnx_rng.h', 'gnx_xo.h', os.path.join('..', '..', 'include', 'gnx_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
          # IEEE-exact f32/f64 arithmetic (no fma contraction): the parity tests
          # compare against numpy evaluating the same expressions

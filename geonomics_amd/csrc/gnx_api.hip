@@ -61,6 +61,7 @@ void gnx_time_end(gnx_state* h, int kernel, double bytes) {
 
 static void timers_resolve(gnx_state* h, int kernel) {
   (void)hipStreamSynchronize(h->stream);
+  if (h->stream2) (void)hipStreamSynchronize(h->stream2);
   for (auto& pr : h->ev_pending[kernel]) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) h->timers[kernel].ms += ms;
@@ -146,6 +147,7 @@ static int alloc_soa(GnxSoA* s, int64_t cap, int n_layers, int n_traits) {
   GNXCHK(dalloc(&s->grow, cap));
   GNXCHK(dalloc(&s->ghost, cap));
   HIPCHK(hipMemset(s->ghost, 0, cap));
+  s->tb = nullptr;           // sized by gnx_l_rebuild_sel once the selected loci are known
   return 0;
 }
 
@@ -160,6 +162,7 @@ static void free_soa(GnxSoA* s) {
   (void)hipFree(s->fit);
   (void)hipFree(s->grow);
   (void)hipFree(s->ghost);
+  (void)hipFree(s->tb);
 }
 
 // ---------------------------------------------------------------- lifecycle
@@ -236,6 +239,15 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
   GNXCHK(dalloc(&h->req_py, cap));
   GNXCHK(dalloc(&h->req_count, 1));
   HIPCHK(hipHostMalloc((void**)&h->h_pin, 16 * sizeof(int64_t)));
+  if (cfg->L > 0) {
+    for (int k = 0; k < 2; ++k) {
+      HIPCHK(hipMalloc(&h->jobs[k], (size_t)cap * 2 * 16));
+      GNXCHK(dalloc(&h->n_jobs_dev[k], 1));
+      HIPCHK(hipEventCreateWithFlags(&h->ev_xo_done[k], hipEventDisableTiming));
+    }
+    HIPCHK(hipEventCreateWithFlags(&h->ev_jobs, hipEventDisableTiming));
+  }
+  h->defer_xo = !(getenv("GNX_DEFER_XO") && atoi(getenv("GNX_DEFER_XO")) == 0);
   *out = h;
   return 0;
 }
@@ -243,6 +255,13 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
 extern "C" void gnx_destroy(gnx_state* h) {
   if (!h) return;
   (void)hipStreamSynchronize(h->stream);
+  if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+  for (int k = 0; k < 2; ++k) {
+    (void)hipFree(h->jobs[k]);
+    (void)hipFree(h->n_jobs_dev[k]);
+    if (h->ev_xo_done[k]) (void)hipEventDestroy(h->ev_xo_done[k]);
+  }
+  if (h->ev_jobs) (void)hipEventDestroy(h->ev_jobs);
   for (int k = 0; k < 2; ++k) {
     free_soa(&h->soa[k]);
     (void)hipFree(h->key[k]);
@@ -256,7 +275,7 @@ extern "C" void gnx_destroy(gnx_state* h) {
                   h->flag, h->flag2, h->scan, h->pairs, h->nbirths, h->boff, h->off_pair,
                   h->off_parent, h->off_keys, h->off_start, h->keep_in, h->inj_a, h->inj_b,
                   h->mid_x, h->mid_y, h->p_death, h->d_cell, h->dead_in, h->nmax_bits, h->red,
-                  h->tl_loci, h->tbits, h->lat.areas, h->lat.cprime, h->spl_N.c, h->spl_P.c, h->bin_partials, h->nodes,
+                  h->sel_loci, h->path_sel, h->lat.areas, h->lat.cprime, h->spl_N.c, h->spl_P.c, h->bin_partials, h->nodes,
                   h->K_over, h->gp_rec, h->gp_z, h->gp_slots, h->tile_counts, h->rq_sorted, h->rq_k, h->gam_out, h->gam_slot, h->chk};
   for (void* p : ptrs) (void)hipFree(p);
   for (int t = 0; t < GNX_MAX_TRAITS; ++t) {
@@ -275,10 +294,12 @@ extern "C" void gnx_destroy(gnx_state* h) {
 }
 
 extern "C" int gnx_set_stream(gnx_state* h, void* hip_stream) {
+  GNXCHK(gnx_xo_join(h));
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->stream2) HIPCHK(hipStreamSynchronize(h->stream2));
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   if (h->stream2) (void)hipStreamDestroy(h->stream2);
-  h->stream2 = nullptr;
+  h->stream2 = nullptr;          // no side stream next to a foreign stream: nothing is deferred
   h->stream = (hipStream_t)hip_stream;
   h->own_stream = false;
   return 0;
@@ -286,6 +307,7 @@ extern "C" int gnx_set_stream(gnx_state* h, void* hip_stream) {
 
 extern "C" int gnx_synchronize(gnx_state* h) {
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->stream2) HIPCHK(hipStreamSynchronize(h->stream2));
   return 0;
 }
 
@@ -449,6 +471,7 @@ extern "C" int gnx_upload_population(gnx_state* h, int64_t N, const float* x, co
       return 1;
     }
   }
+  GNXCHK(gnx_xo_join(h));
   GnxSoA s = h->soa[h->cur];
   hipStream_t st = h->stream;
   HIPCHK(hipMemcpyAsync(s.x, x, N * sizeof(float), hipMemcpyHostToDevice, st));
@@ -477,6 +500,7 @@ extern "C" int gnx_init_population(gnx_state* h, int64_t N) {
     gnx_set_error("gnx_init_population: N > cap_inds");
     return 1;
   }
+  GNXCHK(gnx_xo_join(h));
   h->genomes_assigned = false;
   GNXCHK(gnx_l_init_population(h, N));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -490,6 +514,8 @@ extern "C" int gnx_set_recomb_paths(gnx_state* h, int32_t n, const uint64_t* pat
     return 1;
   }
   const int W64 = h->W64, L = h->cfg.L;
+  GNXCHK(gnx_xo_join(h));
+  HIPCHK(hipStreamSynchronize(h->stream));
   (void)hipFree(h->paths);
   (void)hipFree(h->bp_off);
   (void)hipFree(h->bp_loci);
@@ -532,6 +558,8 @@ extern "C" int gnx_set_recomb_paths(gnx_state* h, int32_t n, const uint64_t* pat
   if (!loci.empty())
     HIPCHK(hipMemcpy(h->bp_loci, loci.data(), loci.size() * sizeof(int32_t),
                      hipMemcpyHostToDevice));
+  GNXCHK(gnx_l_path_sel(h));
+  HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
 
@@ -567,19 +595,44 @@ extern "C" int gnx_set_trait(gnx_state* h, int32_t t, int32_t n_loci, const int3
   r.phi = phi;
   r.gamma = gamma;
   r.univ_adv = univ_adv;
-  // rebuild the concatenated trait-locus table used by the crossover epilogue
   h->h_trait_loci[t].assign(loci, loci + n_loci);
+  return gnx_l_rebuild_sel(h);
+}
+
+// The selected loci (all trait loci trait-major, then the deleterious loci), the homologue
+// every cached path is on at them (path_sel) and every individual's alleles there
+// (GnxSoA.tb): rebuilt whenever a trait or the deleterious loci change (also after
+// non-neutral mutations, structs/genome.py:753-788).
+int gnx_l_rebuild_sel(gnx_state* h) {
   std::vector<int32_t> all;
   for (int q = 0; q < h->cfg.n_traits; ++q)
     all.insert(all.end(), h->h_trait_loci[q].begin(), h->h_trait_loci[q].end());
-  (void)hipFree(h->tl_loci);
-  (void)hipFree(h->tbits);
-  h->tl_loci = nullptr;
-  h->tbits = nullptr;
   h->n_tl = (int)all.size();
-  GNXCHK(dalloc(&h->tl_loci, all.size()));
-  GNXCHK(dalloc(&h->tbits, (size_t)2 * h->cfg.cap_inds * all.size()));
-  HIPCHK(hipMemcpy(h->tl_loci, all.data(), all.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  all.insert(all.end(), h->h_delet_loci.begin(), h->h_delet_loci.end());
+  GNXCHK(gnx_xo_join(h));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  (void)hipFree(h->sel_loci);
+  h->sel_loci = nullptr;
+  h->n_sel = (int)all.size();
+  const int TW = (h->n_sel + 63) / 64;
+  if (TW != h->TW) {
+    for (int k = 0; k < 2; ++k) {
+      (void)hipFree(h->soa[k].tb);
+      h->soa[k].tb = nullptr;
+      if (TW > 0) {
+        GNXCHK(dalloc(&h->soa[k].tb, (size_t)h->cfg.cap_inds * 2 * TW));
+        HIPCHK(hipMemset(h->soa[k].tb, 0, (size_t)h->cfg.cap_inds * 2 * TW * 8));
+      }
+    }
+    h->TW = TW;
+  }
+  if (h->n_sel > 0) {
+    GNXCHK(dalloc(&h->sel_loci, all.size()));
+    HIPCHK(hipMemcpy(h->sel_loci, all.data(), all.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+  GNXCHK(gnx_l_path_sel(h));
+  if (h->genomes_assigned) GNXCHK(gnx_l_tb_from_rows(h, 0, h->N, nullptr, nullptr));
+  HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
 
@@ -604,7 +657,8 @@ extern "C" int gnx_set_deleterious(gnx_state* h, int32_t n, const int32_t* loci,
   h->delet_loci = nullptr;
   h->delet_s = nullptr;
   h->n_delet = 0;
-  if (n <= 0) return 0;
+  h->h_delet_loci.clear();
+  if (n <= 0) return gnx_l_rebuild_sel(h);
   for (int j = 0; j < n; ++j)
     if (loci[j] < 0 || loci[j] >= h->cfg.L) {
       gnx_set_error("gnx_set_deleterious: locus out of range");
@@ -615,7 +669,8 @@ extern "C" int gnx_set_deleterious(gnx_state* h, int32_t n, const int32_t* loci,
   HIPCHK(hipMemcpy(h->delet_loci, loci, n * sizeof(int32_t), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(h->delet_s, s, n * sizeof(double), hipMemcpyHostToDevice));
   h->n_delet = n;
-  return 0;
+  h->h_delet_loci.assign(loci, loci + n);
+  return gnx_l_rebuild_sel(h);
 }
 
 static int need_genome(gnx_state* h) {
@@ -638,6 +693,7 @@ extern "C" int gnx_upload_genomes(gnx_state* h, const uint64_t* geno) {
   HIPCHK(hipMemcpyAsync(h->G, tmp.data(), (size_t)h->N * rowb, hipMemcpyHostToDevice,
                         h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  GNXCHK(gnx_l_tb_from_rows(h, 0, h->N, nullptr, nullptr));
   if (h->cfg.n_traits > 0) GNXCHK(gnx_l_phenotype(h, 0, h->N));
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
@@ -649,6 +705,7 @@ extern "C" int gnx_assign_genomes(gnx_state* h, const int32_t* n_per_site) {
   GNXCHK(dalloc(&d, h->cfg.L));
   HIPCHK(hipMemcpy(d, n_per_site, h->cfg.L * sizeof(int32_t), hipMemcpyHostToDevice));
   int r = gnx_l_assign_genomes(h, d);
+  if (!r) r = gnx_l_tb_from_rows(h, 0, h->N, nullptr, nullptr);
   if (!r && h->cfg.n_traits > 0) r = gnx_l_phenotype(h, 0, h->N);
   (void)hipStreamSynchronize(h->stream);
   (void)hipFree(d);
@@ -661,6 +718,7 @@ extern "C" int gnx_set_z(gnx_state* h) {
     gnx_set_error("gnx_set_z: genomes not assigned");
     return 1;
   }
+  GNXCHK(gnx_l_tb_from_rows(h, 0, h->N, nullptr, nullptr));
   GNXCHK(gnx_l_phenotype(h, 0, h->N));
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
@@ -672,6 +730,7 @@ extern "C" int gnx_set_z_range(gnx_state* h, int64_t first, int64_t n) {
     gnx_set_error("gnx_set_z_range: genomes not assigned or range out of bounds");
     return 1;
   }
+  GNXCHK(gnx_l_tb_from_rows(h, first, n, nullptr, nullptr));
   GNXCHK(gnx_l_phenotype(h, first, n));
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
@@ -793,6 +852,14 @@ extern "C" int gnx_counts(gnx_state* h, int64_t* N, int64_t* births, int64_t* de
   return 0;
 }
 
+extern "C" int gnx_set_defer_crossover(gnx_state* h, int32_t on) {
+  GNXCHK(gnx_xo_join(h));
+  h->defer_xo = on != 0;
+  return 0;
+}
+
+extern "C" int64_t gnx_last_crossover_births(gnx_state* h) { return h->last_xo_births; }
+
 // occupied slots, ghosts of a tiled step included (gnx_counts reports the tile's own)
 extern "C" int64_t gnx_n_slots(gnx_state* h) { return h->N; }
 extern "C" int64_t gnx_step_index(gnx_state* h) { return h->step; }
@@ -820,6 +887,7 @@ extern "C" int gnx_mutate(gnx_state* h, int32_t n, const int64_t* slot, const in
   HIPCHK(hipMemcpy(dl, locus, n * sizeof(int32_t), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dh, hom, n, hipMemcpyHostToDevice));
   int r = gnx_l_mutate(h, n, ds, dl, dh);
+  if (!r) r = gnx_l_tb_from_rows(h, 0, n, nullptr, ds);
   (void)hipStreamSynchronize(h->stream);
   (void)hipFree(ds);
   (void)hipFree(dl);

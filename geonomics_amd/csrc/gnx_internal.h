@@ -69,6 +69,10 @@ struct GnxSoA {
   float* fit;
   int32_t* grow;   // genome row, -1 before genomes are assigned
   uint8_t* ghost;  // 1 = halo copy of a neighbour tile's individual (tiled runs)
+  // alleles at the SELECTED loci (trait loci trait-major, then deleterious loci), bit e of
+  // tb[(i*2 + hom)*TW + e/64]: phenotype, fitness and the newborns' alleles at these loci
+  // never touch the 25-KB genome rows
+  uint64_t* tb;
 };
 
 // Density lattice (utils/spatial.py _DensityGridStack restated)
@@ -131,16 +135,33 @@ struct gnx_state {
 
   // traits etc
   GnxTrait traits[GNX_MAX_TRAITS];
-  // all trait loci concatenated trait-major (the crossover epilogue extracts
-  // the new gametes' alleles at these loci into tbits[gamete][n_tl])
+  // selected loci: all trait loci concatenated trait-major (n_tl of them), then the
+  // deleterious loci; GnxSoA.tb holds every individual's alleles there and
+  // path_sel[key] the homologue each cached recombination path is on there
   std::vector<int32_t> h_trait_loci[GNX_MAX_TRAITS];
+  std::vector<int32_t> h_delet_loci;
   int n_tl = 0;
-  int32_t* tl_loci = nullptr;
-  uint8_t* tbits = nullptr;      // [2 * cap][n_tl]
+  int n_sel = 0, TW = 0;         // selected loci, u64 words per homologue of GnxSoA.tb
+  int32_t* sel_loci = nullptr;   // device [n_sel]
+  uint64_t* path_sel = nullptr;  // device [n_paths][TW]
   uint8_t* dom = nullptr;
   int n_delet = 0;
   int32_t* delet_loci = nullptr;
   double* delet_s = nullptr;
+
+  // crossover jobs (csrc/gnx_xo.h).  Deferred mode (one GPU): the offspring of a step get
+  // their genome rows and their crossover only after the step's death draws, survivors
+  // only, on stream2 - under the next step's latency-bound kernels on `stream`.
+  bool defer_xo = true;          // GNX_DEFER_XO=0: crossover of every birth at once
+  bool xo_deferred = false;      // births of this step still wait for their crossover
+  int64_t xo_first = 0, xo_B = 0;
+  void* jobs[2]{};               // GnxXoJob [2 * cap] each, double-buffered
+  int32_t* n_jobs_dev[2]{};
+  int jobs_cur = 0;
+  hipEvent_t ev_jobs = nullptr, ev_xo_done[2]{};
+  bool xo_inflight[2]{};         // ev_xo_done[k] recorded and not yet joined
+  bool xo_running = false;       // a crossover may still be running on stream2
+  int64_t last_xo_births = 0;    // births that went through the last crossover
 
   // hash grid for neighbour search
   double cs = 1, inv_cs = 1;
@@ -268,10 +289,27 @@ int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* 
 int gnx_l_dispersal_inject(gnx_state* h, int64_t B, int A, const float* d_mx, const float* d_my,
                            const float* d_theta, const float* d_dist, float* d_ox, float* d_oy,
                            int32_t* d_used);
-int gnx_l_crossover(gnx_state* h, int64_t first_slot, int64_t B);
+// crossover of every birth of the current step at once (rows for all of them)
+int gnx_l_crossover_all(gnx_state* h, int64_t first_slot, int64_t B);
+// crossover of the surviving offspring only (after k_alive + scan; gnx_l_mortality)
+int gnx_l_crossover_survivors(gnx_state* h, int64_t first_slot, int64_t B, const int32_t* d_alive,
+                              const int32_t* d_scan);
+// every reader / writer of genome rows on `stream` goes through this first: a pending
+// deferred crossover is carried out (for all pending offspring) and `stream` waits for
+// the crossover in flight on stream2
+int gnx_xo_join(gnx_state* h);
+double gnx_xo_bytes_per_birth(const gnx_state* h);
+// selected-locus tables: rebuild sel_loci / path_sel / GnxSoA.tb after a change of the
+// traits, the deleterious loci or the recombination paths
+int gnx_l_rebuild_sel(gnx_state* h);
+int gnx_l_path_sel(gnx_state* h);
+// tb of slots [first, first+n) (or of first + list[q]) re-read from their genome rows
+int gnx_l_tb_from_rows(gnx_state* h, int64_t first, int64_t n, const int32_t* d_list,
+                       const int64_t* d_slots);
+// tb of this step's offspring from their parents' tb and the paths' path_sel
+int gnx_l_newborn_tb(gnx_state* h, int64_t first_slot, int64_t B);
+// phenotypes of slots [first, first+n) from tb
 int gnx_l_phenotype(gnx_state* h, int64_t first_slot, int64_t n);
-int gnx_l_phenotype_births(gnx_state* h, int64_t first_slot, int64_t n);
-int gnx_l_phenotype_list(gnx_state* h, int64_t first_slot, int64_t n, const int32_t* d_list);
 int gnx_l_assign_genomes(gnx_state* h, const int32_t* d_n_per_site);
 int gnx_l_mutate(gnx_state* h, int n, const int64_t* d_slot, const int32_t* d_locus,
                  const uint8_t* d_hom);

@@ -312,7 +312,7 @@ int gnx_l_raster(gnx_state* h, int which, double* d_out) {
 // ---------------------------------------------------------------- death probabilities
 struct DeathP {
   int64_t N, cap;
-  int n_layers, with_selection, max_age, n_delet, W64;
+  int n_layers, with_selection, max_age, n_delet, n_tl, TW;
 };
 
 // ops/demography.py:305-321 + ops/selection.py:51-125: d at the individual's
@@ -320,9 +320,8 @@ struct DeathP {
 // x prod_del (1 - s_l (g_l0 + g_l1)); p = 1 - (1 - d) w; age > max_age => 1.
 __global__ void __launch_bounds__(256)
 k_death_probs(DeathP Q, DemP P, SplineC SN, SplineC SP, GnxSoA s, const float* rast,
-              GnxTraitTab T, const int32_t* delet_loci, const double* delet_s,
-              const unsigned long long* G, const unsigned long long* nmax_bits, double* p_death,
-              double* d_cell) {
+              GnxTraitTab T, const double* delet_s, const unsigned long long* nmax_bits,
+              double* p_death, double* d_cell) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Q.N) return;
   int cx = (int)s.x[i], cy = (int)s.y[i];
@@ -347,11 +346,12 @@ k_death_probs(DeathP Q, DemP P, SplineC SN, SplineC SP, GnxSoA s, const float* r
       w = fmax(w, 0.001);
     }
     if (Q.n_delet > 0) {
-      const unsigned long long* r0 = G + (int64_t)s.grow[i] * 2 * Q.W64;
-      const unsigned long long* r1 = r0 + Q.W64;
+      // deleterious loci follow the trait loci in the compact allele table
+      const uint64_t* t0 = s.tb + (i * 2 + 0) * Q.TW;
+      const uint64_t* t1 = t0 + Q.TW;
       for (int k = 0; k < Q.n_delet; ++k) {
-        int l = delet_loci[k];
-        int cnt = (int)((r0[l >> 6] >> (l & 63)) & 1ull) + (int)((r1[l >> 6] >> (l & 63)) & 1ull);
+        const int e = Q.n_tl + k;
+        int cnt = (int)((t0[e >> 6] >> (e & 63)) & 1ull) + (int)((t1[e >> 6] >> (e & 63)) & 1ull);
         w *= 1.0 - (double)cnt * delet_s[k];
       }
     }
@@ -377,12 +377,12 @@ int gnx_l_death_probs(gnx_state* h, bool with_selection) {
   Q.n_layers = h->cfg.n_layers;
   Q.with_selection = with_selection ? 1 : 0;
   Q.max_age = h->sp.max_age;
-  Q.n_delet = with_selection ? h->n_delet : 0;
-  Q.W64 = h->W64;
+  Q.n_delet = (with_selection && h->genomes_assigned) ? h->n_delet : 0;
+  Q.n_tl = h->n_tl;
+  Q.TW = h->TW;
   hipLaunchKernelGGL(k_death_probs, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, Q,
                      make_demp(h), SN, SP, h->soa[h->cur], h->rast, gnx_trait_tab(h),
-                     h->delet_loci, h->delet_s, (const unsigned long long*)h->G, h->nmax_bits,
-                     h->p_death, h->d_cell);
+                     h->delet_s, h->nmax_bits, h->p_death, h->d_cell);
   gnx_time_end(h, GNX_K_DEATH, (double)N * (28.0 + 8.0 * h->cfg.n_traits));
   HIPCHK(hipGetLastError());
   return 0;
@@ -392,8 +392,9 @@ int gnx_l_death_probs(gnx_state* h, bool with_selection) {
 // _do_mortality (ops/demography.py:175-180): dead ~ Bernoulli(p_death).  Ghosts
 // (halo copies, tiled runs) are dropped here without counting as deaths.
 __global__ void k_alive(int64_t N, const double* p_death, const uint8_t* dead_in,
-                        const int64_t* id, const uint8_t* ghost, long long step,
-                        unsigned long long seed, int32_t* alive, int32_t* dead_owned) {
+                        const int64_t* id, const uint8_t* ghost, const int32_t* grow,
+                        long long step, unsigned long long seed, int32_t* alive,
+                        int32_t* dead_row) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   bool dead;
@@ -407,17 +408,22 @@ __global__ void k_alive(int64_t N, const double* p_death, const uint8_t* dead_in
     dead = (double)gnx_u01(r.x) < p_death[i];
   }
   alive[i] = dead ? 0 : 1;
-  dead_owned[i] = (dead && !g) ? 1 : 0;
+  // rows to return to the free stack (offspring that die before their deferred
+  // crossover never had one; ghosts own none)
+  dead_row[i] = (dead && !g && grow[i] >= 0) ? 1 : 0;
 }
 
 // Stable compaction of the SoA (survivors keep their relative order); genome
 // rows are NOT moved: the dead's rows are pushed on the free stack.
 __global__ void k_compact(int64_t N, int64_t cap, const int32_t* alive, const int32_t* scan,
-                          const int32_t* dead_owned, const int32_t* dscan, GnxSoA a, GnxSoA b,
-                          int n_layers, int n_traits, int32_t* free_rows, int64_t n_free,
-                          int has_rows) {
+                          const int32_t* dead_row, const int32_t* dscan, GnxSoA a, GnxSoA b,
+                          int n_layers, int n_traits, int tbw, int32_t* free_rows, int64_t n_free,
+                          int has_rows, int64_t xo_first, int64_t xo_B) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
+  // deferred crossover: the surviving offspring [xo_first, xo_first + xo_B) have just
+  // popped one row each from the top of the free stack (k_xo_jobs_surv)
+  if (xo_B > 0) n_free -= scan[xo_first + xo_B] - scan[xo_first];
   if (alive[i]) {
     int64_t k = scan[i];              // survivors before i
     b.x[k] = a.x[i];
@@ -430,7 +436,8 @@ __global__ void k_compact(int64_t N, int64_t cap, const int32_t* alive, const in
     b.ghost[k] = 0;
     for (int l = 0; l < n_layers; ++l) b.e[(int64_t)l * cap + k] = a.e[(int64_t)l * cap + i];
     for (int t = 0; t < n_traits; ++t) b.z[(int64_t)t * cap + k] = a.z[(int64_t)t * cap + i];
-  } else if (has_rows && dead_owned[i]) {
+    for (int w = 0; w < tbw; ++w) b.tb[k * tbw + w] = a.tb[i * tbw + w];
+  } else if (has_rows && dead_row[i]) {
     free_rows[n_free + dscan[i]] = a.grow[i];
   }
 }
@@ -443,31 +450,52 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
   GnxSoA a = h->soa[h->cur], b = h->soa[h->cur ^ 1];
   gnx_time_begin(h);
   hipLaunchKernelGGL(k_alive, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, h->p_death,
-                     d_dead_inject, a.id, a.ghost, h->step, c.seed, h->flag, h->flag2);
+                     d_dead_inject, a.id, a.ghost, a.grow, h->step, c.seed, h->flag, h->flag2);
   HIPCHK(hipMemsetAsync(h->flag + N, 0, sizeof(int32_t), h->stream));
   HIPCHK(hipMemsetAsync(h->flag2 + N, 0, sizeof(int32_t), h->stream));
   GNXCHK(gnx_prim_scan(h->scan_tmp, h->scan_tmp_bytes, h->flag, h->scan, (size_t)N + 1,
                        h->stream));
   GNXCHK(gnx_prim_scan(h->scan_tmp, h->scan_tmp_bytes, h->flag2, h->boff, (size_t)N + 1,
                        h->stream));
+  gnx_time_end(h, GNX_K_COMPACT, 0.0);
   int has_rows = (h->genomes_assigned && c.L > 0) ? 1 : 0;
+  // deferred crossover of this step's births: rows and jobs for the survivors, the kernel
+  // itself on stream2 (it runs on under the compaction and the next step's small kernels)
+  const bool xo = h->xo_deferred;
+  const int64_t xo_first = h->xo_first, xo_B = xo ? h->xo_B : 0;
+  if (xo) {
+    h->xo_deferred = false;
+    GNXCHK(gnx_l_crossover_survivors(h, xo_first, xo_B, h->flag, h->scan));
+    // survivors among the offspring, read back with the other counts below
+    HIPCHK(hipMemcpyAsync(h->h_pin + 2, h->scan + xo_first, sizeof(int32_t),
+                          hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->h_pin + 3, h->scan + xo_first + xo_B, sizeof(int32_t),
+                          hipMemcpyDeviceToHost, h->stream));
+  }
+  gnx_time_begin(h);
   hipLaunchKernelGGL(k_compact, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, c.cap_inds,
                      h->flag, h->scan, h->flag2, h->boff, a, b, c.n_layers, c.n_traits,
-                     h->free_rows, h->n_free, has_rows);
+                     a.tb ? 2 * h->TW : 0, h->free_rows, h->n_free, has_rows, xo_first, xo_B);
   HIPCHK(hipMemcpyAsync(h->h_pin, h->scan + N, sizeof(int32_t), hipMemcpyDeviceToHost,
                         h->stream));
   HIPCHK(hipMemcpyAsync(h->h_pin + 1, h->boff + N, sizeof(int32_t), hipMemcpyDeviceToHost,
                         h->stream));
   gnx_time_end(h, GNX_K_COMPACT, (double)N * (24.0 + 2.0 * (34.0 + 4.0 * c.n_layers +
-                                                             4.0 * c.n_traits)));
+                                                             4.0 * c.n_traits + 16.0 * h->TW)));
   HIPCHK(hipStreamSynchronize(h->stream));
-  int64_t survivors = *(int32_t*)h->h_pin;
-  int64_t deaths = *(int32_t*)(h->h_pin + 1);
-  if (has_rows) h->n_free += deaths;
+  const int64_t survivors = *(int32_t*)h->h_pin;
+  const int64_t rows_freed = *(int32_t*)(h->h_pin + 1);
+  if (xo) {
+    const int64_t S = *(int32_t*)(h->h_pin + 3) - *(int32_t*)(h->h_pin + 2);
+    h->n_free -= S;
+    h->last_xo_births = S;
+    if (h->profiling) h->timers[GNX_K_CROSSOVER].bytes += (double)S * gnx_xo_bytes_per_birth(h);
+  }
+  if (has_rows) h->n_free += rows_freed;
+  *deaths_out = N - h->n_ghost - survivors;       // ghosts are dropped, not counted
   h->N = survivors;
   h->n_ghost = 0;
   h->cur ^= 1;
-  *deaths_out = deaths;
   return 0;
 }
 

@@ -1,5 +1,6 @@
-// Genome kernels: bitmask crossover (the dominant byte mover of the step),
-// phenotype at birth, starting genomes, point mutations, genome gathers.
+// Genome kernels: bitmask crossover (the dominant byte mover of the step; kernels in
+// gnx_xo.h), the compact table of alleles at the selected loci, phenotypes,
+// starting genomes, point mutations, genome gathers.
 //
 // Genome layout in HBM: G[row][hom][W64] u64, little-endian bits, bit l of
 // homologue h == Individual.g[l, h] (structs/individual.py:103-104).  W64 is
@@ -8,295 +9,279 @@
 // GnxSoA.grow; survivors' rows are never moved.
 #include "gnx_internal.h"
 #include "gnx_rng.h"
+#include "gnx_xo.h"
 
-typedef unsigned long long u64;
-
-struct alignas(16) u64x2 {
-  u64 a, b;
-};
-
-// ---------------------------------------------------------------- crossover
-// ops/mating.py:130-214.  For gamete p in {0,1} of an offspring:
-//   gamete[l] = parent_p.g[l, path_{k_p}[l] XOR s_p]
-// i.e. with m = path ^ (-s):  gamete = (hom0 & ~m) | (hom1 & m), 128 bits per
-// lane per access.  child hom 0 <- parent pair[0], hom 1 <- pair[1] (:169).
-//
-// One WAVEFRONT owns one gamete at a time (grid-stride over the 2B gametes):
-// parent row, child row, path key and start homologue are wave-uniform (scalar
-// registers, no per-chunk metadata chain), and the 64 lanes stream the
-// homologue in 16-byte chunks, 1 KiB per wave-instruction, U independent
-// chunks in flight per lane.
-//
-// k_crossover        (dense) : masks are read from the bit-packed path table (any
-//                    recombination map): 2 homologues + 1 mask read per gamete.
-// k_crossover_stream (sparse): masks are rebuilt from the path's short breakpoint
-//                    list (<= 24 switches) and each chunk loads only the one
-//                    homologue it copies, which halves the read traffic when
-//                    crossovers are rare (r = 1/L).
-//
-// Epilogue (fused phenotype input): lane e re-derives the gamete's allele at
-// trait locus e from the just-read (L2-hot) parental chunk and stores it in the
-// compact table tbits[gamete][e], so phenotypes never gather from the fresh
-// 25-KB child rows.
-
-__device__ __forceinline__ u64x2 xo_dense_chunk(int c, u64 s, const u64x2* __restrict__ path_row,
-                                                const u64x2* __restrict__ h0,
-                                                const u64x2* __restrict__ h1) {
-  u64x2 m = path_row[c];
-  m.a ^= s;
-  m.b ^= s;
-  const u64x2 a = h0[c];
-  const u64x2 b = h1[c];
-  u64x2 out;
-  out.a = (a.a & ~m.a) | (b.a & m.a);
-  out.b = (a.b & ~m.b) | (b.b & m.b);
-  return out;
-}
-
-template <int XO_UNROLL>
-__global__ void __launch_bounds__(256)
-k_crossover(int64_t B, int W16, const u64x2* __restrict__ G, u64x2* __restrict__ Gout,
-            const int32_t* __restrict__ grow, int64_t first_slot,
-            const int32_t* __restrict__ off_parent, const int32_t* __restrict__ off_keys,
-            const uint8_t* __restrict__ off_start, const u64x2* __restrict__ paths, int n_tl,
-            const int32_t* __restrict__ tl_loci, uint8_t* __restrict__ tbits) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t gam = wave0; gam < 2 * B; gam += n_waves) {
-    const int64_t k = gam >> 1;
-    const int p = (int)(gam & 1);
-    // wave-uniform metadata
-    const int prow = __builtin_amdgcn_readfirstlane(grow[off_parent[2 * k + p]]);
-    if (prow < 0) continue;      // ghost parent (tiled run): gamete arrives from its tile
-    const int key = __builtin_amdgcn_readfirstlane(off_keys[2 * k + p]);
-    const u64 s = __builtin_amdgcn_readfirstlane((int)off_start[2 * k + p]) ? ~0ull : 0ull;
-    const int crow = __builtin_amdgcn_readfirstlane(grow[first_slot + k]);
-    const u64x2* h0 = G + ((int64_t)prow * 2 + 0) * W16;
-    const u64x2* h1 = G + ((int64_t)prow * 2 + 1) * W16;
-    u64x2* dst = Gout + ((int64_t)crow * 2 + p) * W16;
-    const u64x2* prow_mask = paths + (int64_t)key * W16;
-    for (int c0 = lane; c0 < W16; c0 += 64 * XO_UNROLL) {
-      u64x2 out[XO_UNROLL];
+// ---------------------------------------------------------------- crossover jobs
+// Every birth of the step at once: child k takes the k-th row from the top of the free
+// stack; a gamete whose parent is a ghost (tiled run: the mate lives on a neighbour
+// tile, its gamete arrives from there) gets prow = -1 and is skipped by the kernel.
+__global__ void k_xo_jobs_all(int64_t B, int64_t first, int32_t* __restrict__ grow,
+                              const int32_t* __restrict__ off_parent,
+                              const int32_t* __restrict__ off_keys,
+                              const uint8_t* __restrict__ off_start,
+                              const int32_t* __restrict__ free_rows, int64_t n_free,
+                              GnxXoJob* __restrict__ jobs, int32_t* __restrict__ n_jobs) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k == 0) *n_jobs = (int32_t)(2 * B);
+  if (k >= B) return;
+  const int32_t row = free_rows[n_free - 1 - k];
+  grow[first + k] = row;
 #pragma unroll
-      for (int u = 0; u < XO_UNROLL; ++u) {
-        const int c = c0 + u * 64;
-        if (c < W16) out[u] = xo_dense_chunk(c, s, prow_mask, h0, h1);
-      }
-#pragma unroll
-      for (int u = 0; u < XO_UNROLL; ++u) {
-        const int c = c0 + u * 64;
-        // the child row is not read again this step: keep it out of L2 / MALL
-        if (c < W16) {
-          __builtin_nontemporal_store(out[u].a, &dst[c].a);
-          __builtin_nontemporal_store(out[u].b, &dst[c].b);
-        }
-      }
-    }
-    // alleles at the trait loci -> compact table for the phenotype kernel
-    for (int e = lane; e < n_tl; e += 64) {
-      const int l = tl_loci[e];
-      const u64x2 v = xo_dense_chunk(l >> 7, s, prow_mask, h0, h1);
-      const int bit = l & 127;
-      tbits[gam * n_tl + e] = (uint8_t)(((bit < 64 ? v.a >> bit : v.b >> (bit - 64))) & 1ull);
-    }
+  for (int p = 0; p < 2; ++p) {
+    GnxXoJob j;
+    j.prow = grow[off_parent[2 * k + p]];
+    j.dst = row * 2 + p;
+    j.key = off_keys[2 * k + p];
+    j.start = off_start[2 * k + p];
+    jobs[2 * k + p] = j;
   }
 }
 
-// Sparse paths.  The streaming part is branch-free: every chunk issues exactly
-// one load, from the homologue selected by a v_cndmask on the address, U loads
-// back to back (classifying chunks with divergent copy-h0 / copy-h1 / blend
-// branches makes the compiler drain vmcnt before every arm that reuses a
-// destination register, i.e. one load in flight per lane); the few chunks that
-// contain a switch point (<= 24 per gamete) are patched in a rare wave-level
-// branch afterwards.  Breakpoints live in a VGPR (lane q holds switch q) and
-// are broadcast with v_readlane, so building the mask touches no memory.
-__device__ __forceinline__ u64x2 xo_mask_lanes(int c, u64 s, int mybp, int nbp) {
-  const int lo = c * 128;
-  u64 par = s;
-  u64x2 m;
-  m.a = 0;
-  m.b = 0;
-  for (int q = 0; q < nbp; ++q) {
-    const int bpl = __builtin_amdgcn_readlane(mybp, q);
-    const int d = bpl - lo;
-    par ^= d < 0 ? ~0ull : 0ull;
-    const u64 fa = ~0ull << (d & 63);
-    m.a ^= (d >= 0 && d < 64) ? fa : 0ull;
-    m.b ^= (d >= 0 && d < 64) ? ~0ull : ((d >= 64 && d < 128) ? fa : 0ull);
-  }
-  m.a ^= par;
-  m.b ^= par;
-  return m;
-}
-
-// the parental chunk that holds the gamete's allele at locus l (the mask bit at l
-// selects the homologue), and the allele itself
-__device__ __forceinline__ u64x2 xo_trait_chunk(int l, u64 s, int mybp, int nbp,
-                                                const u64x2* __restrict__ h0,
-                                                const u64x2* __restrict__ h1) {
-  const int c = l >> 7, bit = l & 127;
-  const u64x2 mm = xo_mask_lanes(c, s, mybp, nbp);
-  const u64 sel = ((bit < 64 ? mm.a >> bit : mm.b >> (bit - 64))) & 1ull;
-  return (sel ? h1 : h0)[c];
-}
-
-__device__ __forceinline__ uint8_t xo_bit(u64x2 w, int l) {
-  const int bit = l & 127;
-  return (uint8_t)(((bit < 64 ? w.a >> bit : w.b >> (bit - 64))) & 1ull);
-}
-
-template <int XO_UNROLL>
-__global__ void __launch_bounds__(256)
-k_crossover_stream(int64_t B, int W16, const u64x2* __restrict__ G, u64x2* __restrict__ Gout,
-                   const int32_t* __restrict__ grow, int64_t first_slot,
-                   const int32_t* __restrict__ off_parent, const int32_t* __restrict__ off_keys,
-                   const uint8_t* __restrict__ off_start, const int32_t* __restrict__ bp_off,
-                   const int32_t* __restrict__ bp_loci, int n_tl,
-                   const int32_t* __restrict__ tl_loci, uint8_t* __restrict__ tbits) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t gam = wave0; gam < 2 * B; gam += n_waves) {
-    const int64_t k = gam >> 1;
-    const int p = (int)(gam & 1);
-    const int prow = __builtin_amdgcn_readfirstlane(grow[off_parent[2 * k + p]]);
-    if (prow < 0) continue;      // ghost parent (tiled run): gamete arrives from its tile
-    const int key = __builtin_amdgcn_readfirstlane(off_keys[2 * k + p]);
-    const u64 s = __builtin_amdgcn_readfirstlane((int)off_start[2 * k + p]) ? ~0ull : 0ull;
-    const int crow = __builtin_amdgcn_readfirstlane(grow[first_slot + k]);
-    const u64x2* h0 = G + ((int64_t)prow * 2 + 0) * W16;
-    const u64x2* h1 = G + ((int64_t)prow * 2 + 1) * W16;
-    u64x2* dst = Gout + ((int64_t)crow * 2 + p) * W16;
-    const int bp0 = __builtin_amdgcn_readfirstlane(bp_off[key]);
-    const int nbp = __builtin_amdgcn_readfirstlane(bp_off[key + 1]) - bp0;
-    const int mybp = lane < nbp ? bp_loci[bp0 + lane] : 0x7fffffff;
-    // trait alleles (fused phenotype input): lane e fetches the chunk of trait
-    // locus e NOW, so that the 64-byte sectors it pulls in are the ones the stream
-    // below reads microseconds later (L2 hits); fetched after the stream they
-    // had been evicted again and cost ~10 % extra HBM reads (PMC, profiles/)
-    const int tl = lane < n_tl ? tl_loci[lane] : 0;
-    u64x2 tw;
-    tw.a = 0;
-    tw.b = 0;
-    if (lane < n_tl) tw = xo_trait_chunk(tl, s, mybp, nbp, h0, h1);
-    for (int c0 = lane; c0 < W16; c0 += 64 * XO_UNROLL) {
-      u64x2 m[XO_UNROLL], v[XO_UNROLL];
-      bool mixed = false;
+// Survivors only (deferred mode): offspring k is alive iff alive[first + k]; its rank
+// among the surviving offspring (scan = exclusive scan of alive) picks its row from the
+// top of the free stack.  Offspring that died at age 0 never get a row.
+__global__ void k_xo_jobs_surv(int64_t B, int64_t first, int32_t* __restrict__ grow,
+                               const int32_t* __restrict__ alive,
+                               const int32_t* __restrict__ scan,
+                               const int32_t* __restrict__ off_parent,
+                               const int32_t* __restrict__ off_keys,
+                               const uint8_t* __restrict__ off_start,
+                               const int32_t* __restrict__ free_rows, int64_t n_free,
+                               GnxXoJob* __restrict__ jobs, int32_t* __restrict__ n_jobs) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int32_t s0 = scan[first];
+  if (k == 0) *n_jobs = 2 * (scan[first + B] - s0);
+  if (k >= B || !alive[first + k]) return;
+  const int32_t j = scan[first + k] - s0;
+  const int32_t row = free_rows[n_free - 1 - j];
+  grow[first + k] = row;
 #pragma unroll
-      for (int u = 0; u < XO_UNROLL; ++u) {
-        const int c = min(c0 + u * 64, W16 - 1);     // tail lanes re-read the last chunk
-        m[u] = xo_mask_lanes(c, s, mybp, nbp);
-        const bool one = (m[u].a & m[u].b) == ~0ull;
-        mixed |= !one && (m[u].a | m[u].b) != 0ull;
-        v[u] = (one ? h1 : h0)[c];
-      }
-      if (__builtin_expect(mixed, 0)) {
-#pragma unroll
-        for (int u = 0; u < XO_UNROLL; ++u) {
-          const int c = min(c0 + u * 64, W16 - 1);
-          if ((m[u].a & m[u].b) != ~0ull && (m[u].a | m[u].b) != 0ull) {
-            const u64x2 b = h1[c];
-            v[u].a = (v[u].a & ~m[u].a) | (b.a & m[u].a);
-            v[u].b = (v[u].b & ~m[u].b) | (b.b & m[u].b);
-          }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < XO_UNROLL; ++u) {
-        const int c = c0 + u * 64;
-        if (c < W16) {
-          __builtin_nontemporal_store(v[u].a, &dst[c].a);
-          __builtin_nontemporal_store(v[u].b, &dst[c].b);
-        }
-      }
-    }
-    if (lane < n_tl) tbits[gam * n_tl + lane] = xo_bit(tw, tl);
-    for (int e = lane + 64; e < n_tl; e += 64) {      // more than 64 trait loci: the rest
-      const int l = tl_loci[e];
-      tbits[gam * n_tl + e] = xo_bit(xo_trait_chunk(l, s, mybp, nbp, h0, h1), l);
-    }
+  for (int p = 0; p < 2; ++p) {
+    GnxXoJob jb;
+    jb.prow = grow[off_parent[2 * k + p]];      // parents are older: slots < first
+    jb.dst = row * 2 + p;
+    jb.key = off_keys[2 * k + p];
+    jb.start = off_start[2 * k + p];
+    jobs[2 * j + p] = jb;
   }
 }
 
 template <int U>
-static void xo_launch_stream(gnx_state* h, int grid, int64_t first_slot, int64_t B) {
+static void xo_launch_sparse(gnx_state* h, hipStream_t st, int grid, int buf, bool nt) {
   const int W16 = h->W64 / 2;
-  GnxSoA s = h->soa[h->cur];
-  hipLaunchKernelGGL((k_crossover_stream<U>), dim3(grid), dim3(256), 0, h->stream, B, W16,
-                     (const u64x2*)h->G, (u64x2*)h->G, s.grow, first_slot, h->off_parent,
-                     h->off_keys, h->off_start, h->bp_off, h->bp_loci, h->n_tl, h->tl_loci,
-                     h->tbits);
+  if (nt)
+    hipLaunchKernelGGL((k_xo_sparse<U, true>), dim3(grid), dim3(256), 0, st, h->n_jobs_dev[buf],
+                       W16, (const u64x2*)h->G, (u64x2*)h->G, (const GnxXoJob*)h->jobs[buf],
+                       h->bp_off, h->bp_loci);
+  else
+    hipLaunchKernelGGL((k_xo_sparse<U, false>), dim3(grid), dim3(256), 0, st, h->n_jobs_dev[buf],
+                       W16, (const u64x2*)h->G, (u64x2*)h->G, (const GnxXoJob*)h->jobs[buf],
+                       h->bp_off, h->bp_loci);
 }
 
-template <int U>
-static void xo_launch_dense(gnx_state* h, int grid, int64_t first_slot, int64_t B) {
+// the crossover of job buffer `buf` on stream `st`; max_jobs bounds the grid
+static int xo_launch(gnx_state* h, hipStream_t st, int buf, int64_t max_jobs) {
+  // one wave per gamete, 4 waves per block, job-strided beyond 32 blocks per CU
+  // (measured: profiles/r02b_xo_lab_*.txt - time is flat in the grid size from 16 to 64
+  // blocks per CU and in the unroll from 4 to 8; non-temporal loads +2 %)
+  static const int bpc = getenv("GNX_XO_BPC") ? atoi(getenv("GNX_XO_BPC")) : 32;
+  static const int unroll_env = getenv("GNX_XO_UNROLL") ? atoi(getenv("GNX_XO_UNROLL")) : 0;
+  static const int nt = getenv("GNX_XO_NT") ? atoi(getenv("GNX_XO_NT")) : 1;
   const int W16 = h->W64 / 2;
-  GnxSoA s = h->soa[h->cur];
-  hipLaunchKernelGGL((k_crossover<U>), dim3(grid), dim3(256), 0, h->stream, B, W16,
-                     (const u64x2*)h->G, (u64x2*)h->G, s.grow, first_slot, h->off_parent,
-                     h->off_keys, h->off_start, (const u64x2*)h->paths, h->n_tl, h->tl_loci,
-                     h->tbits);
-}
-
-int gnx_l_crossover(gnx_state* h, int64_t first_slot, int64_t B) {
-  if (B == 0) return 0;
-  // one wave per gamete, 4 waves per block; cap the grid and stride beyond
-  static const int blocks_per_cu = getenv("GNX_XO_BPC") ? atoi(getenv("GNX_XO_BPC")) : 32;
-  static const int unroll = getenv("GNX_XO_UNROLL") ? atoi(getenv("GNX_XO_UNROLL")) : 0;
-  int grid = gnx_grid(2 * B, 4, 256 * blocks_per_cu);
-  gnx_time_begin(h);
-  if (h->sparse_paths) {          // measured: 8 chunks in flight per lane is best (A/B in profiles/)
-    if (unroll == 2) xo_launch_stream<2>(h, grid, first_slot, B);
-    else if (unroll == 4) xo_launch_stream<4>(h, grid, first_slot, B);
-    else xo_launch_stream<8>(h, grid, first_slot, B);
+  const int grid = gnx_grid(max_jobs, 4, 256 * bpc);
+  if (h->sparse_paths) {
+    const int U = unroll_env ? unroll_env : gnx_xo_pick_unroll(W16);
+    switch (U) {
+      case 4: xo_launch_sparse<4>(h, st, grid, buf, nt); break;
+      case 5: xo_launch_sparse<5>(h, st, grid, buf, nt); break;
+      case 6: xo_launch_sparse<6>(h, st, grid, buf, nt); break;
+      case 7: xo_launch_sparse<7>(h, st, grid, buf, nt); break;
+      default: xo_launch_sparse<8>(h, st, grid, buf, nt); break;
+    }
   } else {
-    if (unroll == 2) xo_launch_dense<2>(h, grid, first_slot, B);
-    else if (unroll == 8) xo_launch_dense<8>(h, grid, first_slot, B);
-    else xo_launch_dense<4>(h, grid, first_slot, B);
+    // dense masks: genome chunks stream past once (non-temporal), the path table is
+    // re-read by every gamete that drew the key and stays in L2 / the Infinity Cache
+    if (nt)
+      hipLaunchKernelGGL((k_xo_dense<4, true>), dim3(grid), dim3(256), 0, st, h->n_jobs_dev[buf],
+                         W16, (const u64x2*)h->G, (u64x2*)h->G, (const GnxXoJob*)h->jobs[buf],
+                         (const u64x2*)h->paths);
+    else
+      hipLaunchKernelGGL((k_xo_dense<4, false>), dim3(grid), dim3(256), 0, st, h->n_jobs_dev[buf],
+                         W16, (const u64x2*)h->G, (u64x2*)h->G, (const GnxXoJob*)h->jobs[buf],
+                         (const u64x2*)h->paths);
   }
-  // algorithmic bytes per birth.  Dense masks: 4 parental
-  // homologues + 2 masks read, 2 homologues written = 8 * L/8 = L bytes.
-  // Sparse paths: each gamete chunk copies ONE parental homologue (the other
-  // is never needed, the mask comes from a handful of breakpoints), so the
-  // kernel must move 2 reads + 2 writes = 4 * L/8 = L/2 bytes per birth.
-  // (padded row width W64*8 is what actually moves)
-  gnx_time_end(h, GNX_K_CROSSOVER,
-               (double)B * (h->sparse_paths ? 4.0 : 8.0) * (double)h->W64 * 8.0);
   HIPCHK(hipGetLastError());
   return 0;
 }
 
-// phenotypes of newly born offspring from the compact allele table written by
-// k_crossover (same arithmetic as k_phenotype)
-__global__ void k_phenotype_tbits(int64_t first, int64_t n, int64_t cap, int n_tl,
-                                  const uint8_t* tbits, GnxTraitTab T, const uint8_t* dom,
-                                  float* z) {
-  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n) return;
-  const uint8_t* t0 = tbits + (2 * k) * n_tl;
-  const uint8_t* t1 = tbits + (2 * k + 1) * n_tl;
-  int e = 0;
-  for (int t = 0; t < T.n_traits; ++t) {
-    const int nl = T.n_loci[t];
-    double acc = 0.0, g0 = 0.0;
-    for (int j = 0; j < nl; ++j, ++e) {
-      double gt = 0.5 * (double)((int)t0[e] + (int)t1[e]);
-      if (dom) gt = fmin(gt * (1.0 + (double)dom[T.loci[t][j]]), 1.0);
-      if (j == 0) g0 = gt;
-      acc = acc + gt * T.alpha[t][j];
+// algorithmic bytes per birth.  Dense masks: 4 parental homologues + 2 masks
+// read, 2 homologues written = 8 * L/8 = L bytes.  Sparse paths: each gamete chunk copies
+// ONE parental homologue (the other is never needed, the mask comes from a handful of
+// breakpoints): 2 reads + 2 writes = 4 * L/8 = L/2 bytes per birth (padded row width
+// W64*8 is what actually moves).
+double gnx_xo_bytes_per_birth(const gnx_state* h) {
+  return (h->sparse_paths ? 4.0 : 8.0) * (double)h->W64 * 8.0;
+}
+
+// stream `st` waits until no crossover reads or writes job buffer `buf` any more
+static int xo_wait_buf(gnx_state* h, hipStream_t st, int buf) {
+  if (h->xo_inflight[buf]) {
+    HIPCHK(hipStreamWaitEvent(st, h->ev_xo_done[buf], 0));
+    h->xo_inflight[buf] = false;
+  }
+  return 0;
+}
+
+int gnx_l_crossover_all(gnx_state* h, int64_t first_slot, int64_t B) {
+  if (B == 0) return 0;
+  // rows written here may be parents' rows of a crossover still running on stream2
+  GNXCHK(xo_wait_buf(h, h->stream, 0));
+  GNXCHK(xo_wait_buf(h, h->stream, 1));
+  const int buf = h->jobs_cur;
+  GnxSoA s = h->soa[h->cur];
+  hipLaunchKernelGGL(k_xo_jobs_all, dim3(gnx_grid(B, 256)), dim3(256), 0, h->stream, B, first_slot,
+                     s.grow, h->off_parent, h->off_keys, h->off_start, h->free_rows, h->n_free,
+                     (GnxXoJob*)h->jobs[buf], h->n_jobs_dev[buf]);
+  if (h->stream2) {
+    // tiled runs serve the neighbours' gamete requests on stream2 meanwhile: the rows
+    // handed out above must be visible there
+    HIPCHK(hipEventRecord(h->ev_jobs, h->stream));
+    HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_jobs, 0));
+  }
+  gnx_time_begin(h);
+  GNXCHK(xo_launch(h, h->stream, buf, 2 * B));
+  gnx_time_end(h, GNX_K_CROSSOVER, (double)B * gnx_xo_bytes_per_birth(h));
+  h->n_free -= B;
+  h->last_xo_births = B;
+  return 0;
+}
+
+int gnx_l_crossover_survivors(gnx_state* h, int64_t first_slot, int64_t B, const int32_t* d_alive,
+                              const int32_t* d_scan) {
+  if (B == 0) return 0;
+  const int buf = h->jobs_cur;
+  GNXCHK(xo_wait_buf(h, h->stream, buf));       // the crossover two steps back read this buffer
+  GnxSoA s = h->soa[h->cur];
+  hipLaunchKernelGGL(k_xo_jobs_surv, dim3(gnx_grid(B, 256)), dim3(256), 0, h->stream, B, first_slot,
+                     s.grow, d_alive, d_scan, h->off_parent, h->off_keys, h->off_start,
+                     h->free_rows, h->n_free, (GnxXoJob*)h->jobs[buf], h->n_jobs_dev[buf]);
+  HIPCHK(hipEventRecord(h->ev_jobs, h->stream));
+  HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_jobs, 0));
+  hipStream_t main = h->stream;
+  h->stream = h->stream2;                        // the timer events go where the kernel goes
+  gnx_time_begin(h);
+  int rc = xo_launch(h, h->stream2, buf, 2 * B);
+  gnx_time_end(h, GNX_K_CROSSOVER, 0.0);         // bytes are added once the survivors are counted
+  h->stream = main;
+  GNXCHK(rc);
+  HIPCHK(hipEventRecord(h->ev_xo_done[buf], h->stream2));
+  h->xo_inflight[buf] = true;
+  h->xo_running = true;
+  h->jobs_cur ^= 1;
+  return 0;
+}
+
+int gnx_xo_join(gnx_state* h) {
+  if (h->xo_deferred) {
+    // somebody needs this step's genomes before its death draws: every pending offspring
+    // gets its row and its crossover now (same genomes as the deferred path would give
+    // the survivors; the dead's rows return to the free stack with the other deaths)
+    h->xo_deferred = false;
+    GNXCHK(gnx_l_crossover_all(h, h->xo_first, h->xo_B));
+  }
+  GNXCHK(xo_wait_buf(h, h->stream, 0));
+  GNXCHK(xo_wait_buf(h, h->stream, 1));
+  return 0;
+}
+
+// ---------------------------------------------------------------- selected-locus table
+// path_sel[k] bit e = homologue path k is on at selected locus e
+__global__ void k_path_sel(int n_paths, int TW, int n_sel, int W64, const int32_t* sel_loci,
+                           const u64* paths, u64* out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_paths * TW) return;
+  const int k = idx / TW, w = idx - k * TW;
+  u64 v = 0;
+  for (int e = w * 64; e < min(n_sel, w * 64 + 64); ++e) {
+    const int l = sel_loci[e];
+    v |= ((paths[(int64_t)k * W64 + (l >> 6)] >> (l & 63)) & 1ull) << (e & 63);
+  }
+  out[idx] = v;
+}
+
+int gnx_l_path_sel(gnx_state* h) {
+  (void)hipFree(h->path_sel);
+  h->path_sel = nullptr;
+  if (h->n_paths == 0 || h->TW == 0) return 0;
+  HIPCHK(hipMalloc((void**)&h->path_sel, (size_t)h->n_paths * h->TW * 8));
+  const int n = h->n_paths * h->TW;
+  hipLaunchKernelGGL(k_path_sel, dim3(gnx_grid(n, 128)), dim3(128), 0, h->stream, h->n_paths, h->TW,
+                     h->n_sel, h->W64, h->sel_loci, (const u64*)h->paths, (u64*)h->path_sel);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// tb of a slot from its genome row: one thread per (slot, homologue)
+__global__ void k_tb_from_rows(int64_t first, int64_t n, const int32_t* list, const int64_t* slots,
+                               int TW, int n_sel, int W64, const int32_t* sel_loci, const u64* G,
+                               const int32_t* grow, u64* tb) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * n) return;
+  const int64_t q = t >> 1;
+  const int hom = (int)(t & 1);
+  const int64_t slot = slots ? slots[q] : first + (list ? list[q] : q);
+  const int32_t row = grow[slot];
+  if (row < 0) return;
+  const u64* r = G + ((int64_t)row * 2 + hom) * W64;
+  for (int w = 0; w < TW; ++w) {
+    u64 v = 0;
+    for (int e = w * 64; e < min(n_sel, w * 64 + 64); ++e) {
+      const int l = sel_loci[e];
+      v |= ((r[l >> 6] >> (l & 63)) & 1ull) << (e & 63);
     }
-    z[(int64_t)t * cap + first + k] = (float)(nl > 1 ? 0.5 + acc : g0);
+    tb[(slot * 2 + hom) * TW + w] = v;
   }
 }
 
-int gnx_l_phenotype_births(gnx_state* h, int64_t first_slot, int64_t n) {
-  if (n == 0 || h->cfg.n_traits == 0) return 0;
-  gnx_time_begin(h);
-  hipLaunchKernelGGL(k_phenotype_tbits, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream,
-                     first_slot, n, h->cfg.cap_inds, h->n_tl, h->tbits, gnx_trait_tab(h), h->dom,
-                     h->soa[h->cur].z);
-  gnx_time_end(h, GNX_K_PHENOTYPE, (double)n * (2.0 * h->n_tl + 4.0 * h->cfg.n_traits));
+int gnx_l_tb_from_rows(gnx_state* h, int64_t first, int64_t n, const int32_t* d_list,
+                       const int64_t* d_slots) {
+  if (n == 0 || h->TW == 0 || !h->genomes_assigned) return 0;
+  GNXCHK(gnx_xo_join(h));
+  GnxSoA s = h->soa[h->cur];
+  hipLaunchKernelGGL(k_tb_from_rows, dim3(gnx_grid(2 * n, 256)), dim3(256), 0, h->stream, first, n,
+                     d_list, d_slots, h->TW, h->n_sel, h->W64, h->sel_loci, (const u64*)h->G,
+                     s.grow, (u64*)s.tb);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// tb of offspring k, homologue p = the gamete of parent p: at selected locus e the gamete
+// copies the parent's homologue path_sel[key][e] XOR start (ops/mating.py:165-168 at these
+// loci only).  A ghost parent's gamete (tiled run) is filled in once it has arrived.
+__global__ void k_newborn_tb(int64_t B, int64_t first, int TW, const int32_t* off_parent,
+                             const int32_t* off_keys, const uint8_t* off_start,
+                             const uint8_t* ghost, const u64* path_sel, u64* tb) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * B) return;
+  const int64_t ps = off_parent[t];
+  if (ghost[ps]) return;
+  const int64_t k = t >> 1;
+  const int p = (int)(t & 1);
+  const u64 s = off_start[t] ? ~0ull : 0ull;
+  const u64* m = path_sel + (int64_t)off_keys[t] * TW;
+  for (int w = 0; w < TW; ++w) {
+    const u64 mm = m[w] ^ s;
+    const u64 a = tb[(ps * 2 + 0) * TW + w], b = tb[(ps * 2 + 1) * TW + w];
+    tb[((first + k) * 2 + p) * TW + w] = (a & ~mm) | (b & mm);
+  }
+}
+
+int gnx_l_newborn_tb(gnx_state* h, int64_t first_slot, int64_t B) {
+  if (B == 0 || h->TW == 0) return 0;
+  GnxSoA s = h->soa[h->cur];
+  hipLaunchKernelGGL(k_newborn_tb, dim3(gnx_grid(2 * B, 256)), dim3(256), 0, h->stream, B,
+                     first_slot, h->TW, h->off_parent, h->off_keys, h->off_start, s.ghost,
+                     (const u64*)h->path_sel, (u64*)s.tb);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -304,64 +289,30 @@ int gnx_l_phenotype_births(gnx_state* h, int64_t first_slot, int64_t n) {
 // ---------------------------------------------------------------- phenotype
 // ops/selection.py:22-48: gt_l = (g[l,0] + g[l,1]) / 2 at the trait's loci
 // (x (1 + dom_l), capped at 1, if any dominance); z = 0.5 + sum gt_l alpha_l for
-// polygenic traits, z = gt_0 for monogenic ones.  f64 accumulate, f32 store.
-__global__ void k_phenotype(int64_t first, int64_t n, int64_t cap, int W64, const u64* G,
-                            const int32_t* grow, GnxTraitTab T, const uint8_t* dom, float* z) {
-  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// polygenic traits, z = gt_0 for monogenic ones.  f64 accumulate, f32 store.  The
+// alleles come from the compact table (trait loci are its first n_tl entries,
+// trait-major).
+__global__ void k_phenotype(int64_t first, int64_t n, int64_t cap, int TW, const u64* tb,
+                            GnxTraitTab T, const uint8_t* dom, float* z) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
-  int64_t slot = first + k;
-  const u64* r0 = G + (int64_t)grow[slot] * 2 * W64;
-  const u64* r1 = r0 + W64;
+  const int64_t slot = first + k;
+  const u64* t0 = tb + (slot * 2 + 0) * TW;
+  const u64* t1 = t0 + TW;
+  int e = 0;
   for (int t = 0; t < T.n_traits; ++t) {
     const int nl = T.n_loci[t];
     double acc = 0.0, g0 = 0.0;
-    for (int j = 0; j < nl; ++j) {
-      int l = T.loci[t][j];
-      int a = (int)((r0[l >> 6] >> (l & 63)) & 1ull);
-      int b = (int)((r1[l >> 6] >> (l & 63)) & 1ull);
+    for (int j = 0; j < nl; ++j, ++e) {
+      const int a = (int)((t0[e >> 6] >> (e & 63)) & 1ull);
+      const int b = (int)((t1[e >> 6] >> (e & 63)) & 1ull);
       double gt = 0.5 * (double)(a + b);
-      if (dom) gt = fmin(gt * (1.0 + (double)dom[l]), 1.0);
+      if (dom) gt = fmin(gt * (1.0 + (double)dom[T.loci[t][j]]), 1.0);
       if (j == 0) g0 = gt;
       acc = acc + gt * T.alpha[t][j];
     }
     z[(int64_t)t * cap + slot] = (float)(nl > 1 ? 0.5 + acc : g0);
   }
-}
-
-// phenotype of listed offspring (slot = first + list[q]) by gathering the trait
-// loci from their genome rows (used for offspring that received a remote gamete)
-__global__ void k_phenotype_list(int64_t first, int64_t n, const int32_t* list, int64_t cap,
-                                 int W64, const u64* G, const int32_t* grow, GnxTraitTab T,
-                                 const uint8_t* dom, float* z) {
-  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= n) return;
-  int64_t slot = first + list[q];
-  const u64* r0 = G + (int64_t)grow[slot] * 2 * W64;
-  const u64* r1 = r0 + W64;
-  for (int t = 0; t < T.n_traits; ++t) {
-    const int nl = T.n_loci[t];
-    double acc = 0.0, g0 = 0.0;
-    for (int j = 0; j < nl; ++j) {
-      int l = T.loci[t][j];
-      int a = (int)((r0[l >> 6] >> (l & 63)) & 1ull);
-      int b = (int)((r1[l >> 6] >> (l & 63)) & 1ull);
-      double gt = 0.5 * (double)(a + b);
-      if (dom) gt = fmin(gt * (1.0 + (double)dom[l]), 1.0);
-      if (j == 0) g0 = gt;
-      acc = acc + gt * T.alpha[t][j];
-    }
-    z[(int64_t)t * cap + slot] = (float)(nl > 1 ? 0.5 + acc : g0);
-  }
-}
-
-int gnx_l_phenotype_list(gnx_state* h, int64_t first_slot, int64_t n, const int32_t* d_list) {
-  if (n == 0 || h->cfg.n_traits == 0) return 0;
-  GnxSoA s = h->soa[h->cur];
-  hipLaunchKernelGGL(k_phenotype_list, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, first_slot,
-                     n, d_list, h->cfg.cap_inds, h->W64, (const u64*)h->G, s.grow,
-                     gnx_trait_tab(h), h->dom, s.z);
-  HIPCHK(hipGetLastError());
-  return 0;
 }
 
 int gnx_l_phenotype(gnx_state* h, int64_t first_slot, int64_t n) {
@@ -369,9 +320,8 @@ int gnx_l_phenotype(gnx_state* h, int64_t first_slot, int64_t n) {
   GnxSoA s = h->soa[h->cur];
   gnx_time_begin(h);
   hipLaunchKernelGGL(k_phenotype, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, first_slot, n,
-                     h->cfg.cap_inds, h->W64, (const u64*)h->G, s.grow, gnx_trait_tab(h), h->dom,
-                     s.z);
-  gnx_time_end(h, GNX_K_PHENOTYPE, (double)n * 4.0 * h->cfg.n_traits);
+                     h->cfg.cap_inds, h->TW, (const u64*)s.tb, gnx_trait_tab(h), h->dom, s.z);
+  gnx_time_end(h, GNX_K_PHENOTYPE, (double)n * (16.0 * h->TW + 4.0 * h->cfg.n_traits));
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -418,6 +368,7 @@ int gnx_l_assign_genomes(gnx_state* h, const int32_t* d_n_per_site) {
     gnx_set_error("cap_rows %lld < N %lld", (long long)c.cap_rows, (long long)N);
     return 2;
   }
+  GNXCHK(gnx_xo_join(h));
   GnxSoA s = h->soa[h->cur];
   int64_t m = N > c.cap_rows - N ? N : c.cap_rows - N;
   hipLaunchKernelGGL(k_assign_rows, dim3(gnx_grid(m, 256)), dim3(256), 0, h->stream, N, c.cap_rows,
@@ -448,6 +399,7 @@ __global__ void k_mutate(int n, int W64, u64* G, const int32_t* grow, const int6
 int gnx_l_mutate(gnx_state* h, int n, const int64_t* d_slot, const int32_t* d_locus,
                  const uint8_t* d_hom) {
   if (n == 0) return 0;
+  GNXCHK(gnx_xo_join(h));
   hipLaunchKernelGGL(k_mutate, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, n, h->W64,
                      (u64*)h->G, h->soa[h->cur].grow, d_slot, d_locus, d_hom);
   HIPCHK(hipGetLastError());
@@ -469,6 +421,7 @@ __global__ void k_gather_genomes(int64_t n, int W16, const u64x2* G, const int32
 
 int gnx_l_gather_genomes(gnx_state* h, int64_t n, const int64_t* d_slots, uint64_t* d_out) {
   if (n == 0) return 0;
+  GNXCHK(gnx_xo_join(h));
   const int W16 = h->W64 / 2;
   hipLaunchKernelGGL(k_gather_genomes, dim3(gnx_grid(n * 2 * W16, 256, 256 * 32)), dim3(256), 0,
                      h->stream, n, W16, (const u64x2*)h->G, h->soa[h->cur].grow, d_slots,

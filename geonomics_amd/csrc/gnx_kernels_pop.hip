@@ -332,7 +332,7 @@ __global__ void k_keys(int64_t N, const float* x, const float* y, const int64_t*
 }
 
 __global__ void k_permute(int64_t N, int64_t cap, const int32_t* perm, GnxSoA a, GnxSoA b,
-                          int n_layers, int n_traits, unsigned long long pair_seed,
+                          int n_layers, int n_traits, int tbw, unsigned long long pair_seed,
                           uint32_t* tag, uint4* cand) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
@@ -352,6 +352,7 @@ __global__ void k_permute(int64_t N, int64_t cap, const int32_t* perm, GnxSoA a,
   b.ghost[i] = a.ghost[j];
   for (int l = 0; l < n_layers; ++l) b.e[(int64_t)l * cap + i] = a.e[(int64_t)l * cap + j];
   for (int t = 0; t < n_traits; ++t) b.z[(int64_t)t * cap + i] = a.z[(int64_t)t * cap + j];
+  for (int w = 0; w < tbw; ++w) b.tb[i * tbw + w] = a.tb[j * tbw + w];     // tbw = 2 * TW
 }
 
 // cell_start[c] = first sorted slot whose key >= c; cell_start[ncells] = N
@@ -369,6 +370,7 @@ __global__ void k_cell_bounds(int64_t N, const uint64_t* key, int32_t* cell_star
 int gnx_l_sort_by_cell(gnx_state* h) {
   int64_t N = h->N;
   if (N == 0) return 0;
+  GNXCHK(gnx_xo_join(h));      // slots move: offspring still waiting for their crossover get it now
   const gnx_config& c = h->cfg;
   GnxSoA a = h->soa[h->cur], b = h->soa[h->cur ^ 1];
   gnx_time_begin(h);
@@ -379,12 +381,12 @@ int gnx_l_sort_by_cell(gnx_state* h) {
   gnx_time_end(h, GNX_K_SORT, (double)N * 40.0);
   gnx_time_begin(h);
   hipLaunchKernelGGL(k_permute, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, c.cap_inds,
-                     h->perm[1], a, b, c.n_layers, c.n_traits, gnx_pair_seed(c.seed, h->step),
-                     h->tag, (uint4*)h->cand);
+                     h->perm[1], a, b, c.n_layers, c.n_traits, a.tb ? 2 * h->TW : 0,
+                     gnx_pair_seed(c.seed, h->step), h->tag, (uint4*)h->cand);
   hipLaunchKernelGGL(k_cell_bounds, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N,
                      h->key64[1], h->cell_start, h->ncx * h->ncy);
   gnx_time_end(h, GNX_K_PERMUTE,
-               (double)N * 2.0 * (33.0 + 4.0 * c.n_layers + 4.0 * c.n_traits));
+               (double)N * 2.0 * (33.0 + 4.0 * c.n_layers + 4.0 * c.n_traits + 16.0 * h->TW));
   HIPCHK(hipGetLastError());
   h->cur ^= 1;
   return 0;
@@ -792,7 +794,7 @@ struct OffP {
   int sexed;
   float p_male;
   int fixed_nb;          // > 0: every pair has this many births
-  int genomes;           // allocate genome rows + draw keys
+  int genomes;           // draw recombination keys and start homologues
   int n_paths;
   int64_t id_base, n_free;
   long long step;
@@ -830,7 +832,7 @@ __device__ __forceinline__ bool disperse_once(float mx, float my, float theta, f
 // age 0, sex, environment, genome row, recombination keys, start homologues.
 __global__ void __launch_bounds__(256)
 k_offspring(OffP P, GnxSoA s, const float* rast, const int32_t* pairs, const int32_t* off_pair,
-            const int32_t* boff, const int64_t* goff, const int32_t* free_rows,
+            const int32_t* boff, const int64_t* goff,
             int32_t* off_parent, int32_t* off_keys, uint8_t* off_start, GnxReq rq) {
   int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= P.B) return;
@@ -884,8 +886,10 @@ k_offspring(OffP P, GnxSoA s, const float* rast, const int32_t* pairs, const int
     s.e[(int64_t)l * P.cap + slot] = rast[((int64_t)l * P.H + cy) * P.W + cx];
   off_parent[2 * k] = i;
   off_parent[2 * k + 1] = m;
+  // the genome row comes with the crossover (k_xo_jobs_*): at once for every birth, or
+  // after the death draws for the survivors only
+  s.grow[slot] = -1;
   if (P.genomes) {
-    s.grow[slot] = free_rows[P.n_free - 1 - k];
     // start homologues ~ Bernoulli(.5) x2 (ops/mating.py:133); keys ~
     // randint(0, n_paths) x2 (structs/species.py:625)
     const uint8_t st0 = (uint8_t)(r.x & 1u), st1 = (uint8_t)((r.x >> 1) & 1u);
@@ -904,8 +908,6 @@ k_offspring(OffP P, GnxSoA s, const float* rast, const int32_t* pairs, const int
       rq.px[q] = s.x[m];
       rq.py[q] = s.y[m];
     }
-  } else {
-    s.grow[slot] = -1;
   }
 }
 
@@ -913,7 +915,7 @@ k_offspring(OffP P, GnxSoA s, const float* rast, const int32_t* pairs, const int
 // off_parent/off_keys/off_start (operator-level test entry); no positions drawn
 __global__ void k_offspring_inject(int64_t N, int64_t B, int64_t cap, GnxSoA s, const float* rast,
                                    int n_layers, int W, int H, const int32_t* off_parent,
-                                   const int32_t* free_rows, int64_t n_free, int64_t max_id) {
+                                   int64_t max_id) {
   int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= B) return;
   int i = off_parent[2 * k], m = off_parent[2 * k + 1];
@@ -926,7 +928,7 @@ __global__ void k_offspring_inject(int64_t N, int64_t B, int64_t cap, GnxSoA s, 
   s.id[slot] = max_id + 1 + k;
   s.fit[slot] = 1.0f;
   s.ghost[slot] = 0;
-  s.grow[slot] = free_rows[n_free - 1 - k];
+  s.grow[slot] = -1;
   int cx = (int)ox, cy = (int)oy;
   for (int l = 0; l < n_layers; ++l)
     s.e[(int64_t)l * cap + slot] = rast[((int64_t)l * H + cy) * W + cx];
@@ -977,6 +979,7 @@ int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* 
   GnxSoA s = h->soa[h->cur];
   *births_out = 0;
   int64_t B = 0;
+  if (h->xo_deferred) GNXCHK(gnx_xo_join(h));
   bool genomes = !burn && c.L > 0 && h->genomes_assigned;
   if (inject) {
     B = B_inject;
@@ -987,8 +990,7 @@ int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* 
       return 2;
     }
     hipLaunchKernelGGL(k_offspring_inject, dim3(gnx_grid(B, 256)), dim3(256), 0, h->stream, h->N,
-                       B, c.cap_inds, s, h->rast, c.n_layers, c.W, c.H, h->off_parent,
-                       h->free_rows, h->n_free, h->max_id);
+                       B, c.cap_inds, s, h->rast, c.n_layers, c.W, c.H, h->off_parent, h->max_id);
   } else {
     if (!tiled) GNXCHK(gnx_l_births(h, &B));
     B = h->n_births_pending;
@@ -1038,7 +1040,7 @@ int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* 
     gnx_time_begin(h);
     hipLaunchKernelGGL(k_offspring, dim3(gnx_grid(B, 256)), dim3(256), 0, h->stream, Q, s, h->rast,
                        h->pairs, h->off_pair, h->boff, tiled ? h->pair_goff : nullptr,
-                       h->free_rows, h->off_parent, h->off_keys, h->off_start, rq);
+                       h->off_parent, h->off_keys, h->off_start, rq);
     gnx_time_end(h, GNX_K_OFFSPRING, (double)B * (60.0 + 8.0 * c.n_layers));
     if (tiled && genomes) {
       // the number of gamete requests is known before the crossover is launched: the host
@@ -1051,9 +1053,20 @@ int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* 
   }
   HIPCHK(hipGetLastError());
   if (genomes || inject) {
-    GNXCHK(gnx_l_crossover(h, h->N, B));
-    h->n_free -= B;
-    if (c.n_traits > 0 && !tiled) GNXCHK(gnx_l_phenotype_births(h, h->N, B));
+    // alleles at the selected loci and the phenotype come from the parents' compact
+    // tables; the 25-KB rows are only needed by the NEXT generation's crossover, so on one
+    // GPU they are cut after this step's death draws, for the survivors only
+    // (gnx_l_mortality), unless somebody asks for them earlier (gnx_xo_join)
+    GNXCHK(gnx_l_newborn_tb(h, h->N, B));
+    const bool defer = h->defer_xo && !tiled && !inject && h->stream2 != nullptr;
+    if (defer) {
+      h->xo_deferred = true;
+      h->xo_first = h->N;
+      h->xo_B = B;
+    } else {
+      GNXCHK(gnx_l_crossover_all(h, h->N, B));
+    }
+    if (c.n_traits > 0 && !tiled) GNXCHK(gnx_l_phenotype(h, h->N, B));
   }
   h->N += B;
   if (!tiled) h->max_id += B;

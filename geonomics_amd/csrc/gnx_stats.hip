@@ -38,6 +38,7 @@ extern "C" int gnx_stats_locus_counts(gnx_state* h, int32_t* cnt1, int32_t* cnt_
     gnx_set_error("gnx_stats_locus_counts: genomes not assigned");
     return 1;
   }
+  GNXCHK(gnx_xo_join(h));
   const int L = h->cfg.L;
   int32_t *d1 = nullptr, *d2 = nullptr;
   HIPCHK(hipMalloc((void**)&d1, L * sizeof(int32_t)));
@@ -137,6 +138,7 @@ extern "C" int gnx_stats_ld_counts(gnx_state* h, int32_t n_loci, const int32_t* 
       gnx_set_error("gnx_stats_ld_counts: locus out of range");
       return 1;
     }
+  GNXCHK(gnx_xo_join(h));
   const int64_t N = h->N;
   const int64_t n_hwords = std::max<int64_t>(1, (2 * N + 63) / 64);
   int32_t* d_loci = nullptr;
@@ -176,6 +178,7 @@ extern "C" int gnx_stats_ld(gnx_state* h, int32_t n_loci, const int32_t* loci, d
       gnx_set_error("gnx_stats_ld: locus out of range");
       return 1;
     }
+  GNXCHK(gnx_xo_join(h));
   const int64_t N = h->N;
   const int64_t n_hwords = std::max<int64_t>(1, (2 * N + 63) / 64);
   int32_t* d_loci = nullptr;

@@ -21,10 +21,7 @@
 #include "gnx_internal.h"
 #include "gnx_rng.h"
 
-typedef unsigned long long u64;
-struct alignas(16) u64x2 {
-  u64 a, b;
-};
+#include "gnx_xo.h"
 
 struct TileBox {
   float x0, y0, x1, y1;   // own tile [x0,x1) x [y0,y1)
@@ -300,10 +297,12 @@ static int import_common(gnx_state* h, int64_t n, const gnx_ind_rec* rec, const 
     }
     GNXCHK(dalloc_t(&d_g, (size_t)n * 2 * h->W64));
     GNXCHK(gnx_h2d(h, d_g, geno, (size_t)n * 2 * h->W64 * 8));
+    GNXCHK(gnx_xo_join(h));
     const int W16 = h->W64 / 2;
     hipLaunchKernelGGL(k_scatter_genomes, dim3(gnx_grid(n * 2 * W16, 256, 256 * 32)), dim3(256), 0,
                        h->stream, n, W16, (const u64x2*)d_g, (u64x2*)h->G, s.grow, h->N);
     h->n_free -= n;
+    GNXCHK(gnx_l_tb_from_rows(h, h->N, n, nullptr, nullptr));
   }
   HIPCHK(hipStreamSynchronize(h->stream));
   (void)hipFree(d_rec);
@@ -576,11 +575,12 @@ extern "C" int gnx_tile_finish_births(gnx_state* h, int32_t burn) {
   // the crossover on the main stream
   h->xo_pending = false;
   int64_t B = h->last_births;
-  if (B > 0 && !burn && has_rows(h) && h->cfg.n_traits > 0) {
-    // local gametes left their trait alleles in tbits (crossover epilogue); only
-    // offspring that received a remote gamete re-read their trait loci
-    GNXCHK(gnx_l_phenotype_births(h, h->birth_first_slot, B));
-    GNXCHK(gnx_l_phenotype_list(h, h->birth_first_slot, h->n_req, h->req_k));
+  if (B > 0 && !burn && has_rows(h)) {
+    // local gametes took their alleles at the selected loci from the parents' compact
+    // tables (k_newborn_tb); offspring that received a remote gamete re-read theirs from
+    // the row the gamete was put in
+    GNXCHK(gnx_l_tb_from_rows(h, h->birth_first_slot, h->n_req, h->req_k, nullptr));
+    GNXCHK(gnx_l_phenotype(h, h->birth_first_slot, B));
   }
   GnxSoA s = h->soa[h->cur];
   GNXCHK(gnx_l_bins(h, h->N, s.x, s.y, s.ghost, h->bin_partials));
@@ -889,10 +889,12 @@ static int import_device(gnx_state* h, int64_t n, const gnx_ind_rec* d_rec, cons
                      c.cap_inds, s, d_rec, (d_z && c.n_traits) ? d_z : nullptr, c.n_traits,
                      c.n_layers, h->rast, c.W, c.H, h->free_rows, h->n_free, rows ? 1 : 0, ghost);
   if (rows) {
+    GNXCHK(gnx_xo_join(h));
     const int W16 = h->W64 / 2;
     hipLaunchKernelGGL(k_scatter_genomes, dim3(gnx_grid(n * 2 * W16, 256, 256 * 32)), dim3(256), 0,
                        h->stream, n, W16, (const u64x2*)d_g, (u64x2*)h->G, s.grow, h->N);
     h->n_free -= n;
+    GNXCHK(gnx_l_tb_from_rows(h, h->N, n, nullptr, nullptr));
   }
   // the source buffers belong to the caller: finish reading them before returning
   HIPCHK(hipStreamSynchronize(h->stream));

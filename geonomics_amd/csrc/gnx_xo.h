@@ -98,6 +98,7 @@ k_xo_sparse(const int32_t* __restrict__ n_jobs_p, int W16, const u64x2* __restri
   for (int j = (int)blockIdx.x * 4 + wv; j < n_jobs; j += n_waves) {
     const GnxXoJob jb = jobs[j];
     const int prow = __builtin_amdgcn_readfirstlane(jb.prow);
+    if (prow < 0) continue;      // ghost parent (tiled run): the gamete arrives from its tile
     const int dsth = __builtin_amdgcn_readfirstlane(jb.dst);
     const int key = __builtin_amdgcn_readfirstlane(jb.key);
     const u64 s = __builtin_amdgcn_readfirstlane(jb.start) ? ~0ull : 0ull;
@@ -150,6 +151,7 @@ k_xo_dense(const int32_t* __restrict__ n_jobs_p, int W16, const u64x2* __restric
   for (int j = (int)blockIdx.x * 4 + wv; j < n_jobs; j += n_waves) {
     const GnxXoJob jb = jobs[j];
     const int prow = __builtin_amdgcn_readfirstlane(jb.prow);
+    if (prow < 0) continue;      // ghost parent (tiled run): the gamete arrives from its tile
     const int dsth = __builtin_amdgcn_readfirstlane(jb.dst);
     const int key = __builtin_amdgcn_readfirstlane(jb.key);
     const u64 s = __builtin_amdgcn_readfirstlane(jb.start) ? ~0ull : 0ull;

@@ -182,6 +182,15 @@ int gnx_pop_dynamics_die(gnx_state* h, int32_t burn, int32_t with_selection);
  * (sim/model.py:603-667)                                                    */
 int gnx_step(gnx_state* h, int32_t burn, int32_t with_selection);
 int gnx_counts(gnx_state* h, int64_t* N, int64_t* births, int64_t* deaths);
+/* Where the new offspring's genomes are cut (ops/mating.py:130-214, the crossover).
+ * on (default, one GPU): after the step's death draws, for the offspring that survive
+ * them only, on a second HIP stream under the next step's kernels - offspring that die at
+ * age 0 (structs/species.py:822-833 kills them in the same _do_pop_dynamics call) never
+ * get a genome.  off: for every birth, inside gnx_pop_dynamics_mate.  Same results either
+ * way (draws are keyed by id); any genome access in between triggers the off path.      */
+int gnx_set_defer_crossover(gnx_state* h, int32_t on);
+/* births whose genomes the last crossover wrote (== births when not deferred)          */
+int64_t gnx_last_crossover_births(gnx_state* h);
 int64_t gnx_step_index(gnx_state* h);
 int gnx_set_step_index(gnx_state* h, int64_t step);
 

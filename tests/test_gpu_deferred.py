@@ -1,0 +1,97 @@
+"""The crossover of a step's offspring is deferred behind the death draws (survivors only,
+on a second stream) - gnx_set_defer_crossover.  Draws are keyed by id, so the deferred and
+the immediate order of operations must give the same population bit for bit; any access to
+genomes between the two halves of the step falls back to the immediate path.  Needs an
+MI355X."""
+import numpy as np
+import pytest
+
+import gnx_oracle as O
+from test_gpu_parity import make_dev, native
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(defer, L=900, seed=17, dense=False):
+    nat = native()
+    W = H = 40
+    rasts = np.stack([np.ones((H, W)), np.tile(np.linspace(0, 1, W), (H, 1))]).astype(np.float32)
+    dev = make_dev(W, H, rasts=rasts, L=L, n_traits=2, cap=16384, seed=seed,
+                   mating_radius=3.0, K_factor=1.2, max_age=6)
+    dev.set_defer_crossover(defer)
+    rng = np.random.RandomState(3)
+    loci = np.sort(rng.choice(L, 80, replace=False))
+    dev.set_trait(0, loci[:70], 0.05 * np.where(np.arange(70) % 2, -1.0, 1.0), 1, 0.3, 1.0, False)
+    dev.set_trait(1, loci[70:71], np.array([0.25]), 1, 0.1, 2.0, True)
+    dev.set_deleterious(loci[71:], np.full(9, 0.02))
+    rate = 0.3 if dense else 0.003
+    dev.set_recomb_paths(O.pack_bits(O.recomb_paths(
+        (rng.rand(64, L) < rate).astype(np.uint8) * (np.arange(L) > 0))))
+    dev.init_population(1800)
+    for _ in range(4):
+        dev.step(True, False)
+    dev.assign_genomes(O.starting_mutation_counts(dev.N, np.full(L, 0.5)))
+    return dev, nat
+
+
+def _state(dev, nat):
+    ids = dev.download(nat.F_ID)
+    o = np.argsort(ids)
+    return dict(ids=ids[o], x=dev.download(nat.F_X)[o], y=dev.download(nat.F_Y)[o],
+                age=dev.download(nat.F_AGE)[o], z=dev.download(nat.F_Z)[:, o],
+                fit=dev.download(nat.F_FIT)[o], g=dev.download(nat.F_GENO)[o])
+
+
+@pytest.mark.parametrize('dense', [False, True])
+def test_deferred_crossover_equals_immediate(dense):
+    a, nat = _model(True, dense=dense)
+    b, _ = _model(False, dense=dense)
+    skipped = 0
+    for t in range(12):
+        a.step(False, True)
+        b.step(False, True)
+        assert a.counts() == b.counts(), t
+        births = a.counts()[1]
+        assert b.last_crossover_births == births
+        assert a.last_crossover_births <= births
+        skipped += births - a.last_crossover_births
+    assert skipped > 50                  # offspring that died at age 0 never got a genome
+    sa, sb = _state(a, nat), _state(b, nat)
+    for k in sa:
+        np.testing.assert_array_equal(sa[k], sb[k], err_msg=k)
+    # rows in use are distinct and the free stack holds the rest (no leak, no double use)
+    for dev in (a, b):
+        rows = dev.download(nat.F_GROW)
+        assert rows.min() >= 0 and np.unique(rows).size == rows.size
+    a.close()
+    b.close()
+
+
+def test_genome_access_between_mate_and_die_materialises():
+    """reading the offspring's genomes between gnx_pop_dynamics_mate and _die (the
+    pedigree recorder, mutation, statistics do) cuts them at once, for every birth"""
+    a, nat = _model(True, seed=5)
+    b, _ = _model(False, seed=5)
+    for t in range(5):
+        for dev in (a, b):
+            n0 = dev.N
+            dev.pop_dynamics_mate(False)
+        B = a.counts()[1]
+        assert B == b.counts()[1] and B > 0
+        if t % 2 == 0:
+            slots = np.arange(n0, n0 + B)
+            np.testing.assert_array_equal(a.download_genomes(slots), b.download_genomes(slots))
+        else:
+            c1a, cha = a.stats_locus_counts()
+            c1b, chb = b.stats_locus_counts()
+            np.testing.assert_array_equal(c1a, c1b)
+        for dev in (a, b):
+            dev.pop_dynamics_die(False, True)
+            dev.step_index = dev.step_index + 1
+        assert a.counts() == b.counts()
+        assert a.last_crossover_births == B          # fell back to every birth
+    sa, sb = _state(a, nat), _state(b, nat)
+    for k in sa:
+        np.testing.assert_array_equal(sa[k], sb[k], err_msg=k)
+    a.close()
+    b.close()
