@@ -14,11 +14,15 @@ quoted on: 2048x2048 two-layer landscape, 10^6 individuals, 10^5-locus genomes,
 mating_radius 10, b 0.2, one birth per pair, recombination rate 1/L.
 
 For --gpus N > 1 the driver launches one rank per GPU with torch.distributed
-(RCCL); the landscape grows to an R x C grid of 2048x2048 tiles (8 GPUs: 2 x 4 =
-8192x4096, 8x10^6 individuals), one tile per rank ("weak" scaling: per-GPU work
-fixed), stepped by geonomics_amd.parallel.TiledStepper: migrants (with genomes),
-halo ghosts, pair lists, gametes of cross-border mates and the density bins are
-exchanged every step (csrc/gnx_tile.hip).
+(RCCL), one landscape tile per rank, stepped by geonomics_amd.parallel.TiledStepper:
+migrants (with genomes), halo ghosts, pair lists, gametes of cross-border mates and the
+density bins are exchanged every step (csrc/gnx_tile.hip).  `--gpus 8` is BASELINE.json's
+configs[4] (C5) exactly: a 4096x4096 landscape tiled 2 x 4 (tiles 1024 wide, 2048 tall),
+10^7 individuals, L = 10^5 (31 GB of genomes per GPU); `--gpus 4` / `--gpus 2` are the
+2 x 2 / 1 x 2 sub-grids of the same tiles (2048x4096 with 5x10^6, 2048x2048 with
+2.5x10^6 individuals), so per-GPU work is fixed ("weak").  `--scaling weak2048` instead
+grows the landscape by one 2048x2048 tile of the metric workload per GPU.
+`python bench.py --gpus N` without a launcher starts the N ranks itself.
 """
 import argparse
 import json
@@ -35,6 +39,14 @@ WORKLOADS = {
     # name: (W, H, N, L, n_traits, loci_per_trait, move_surf, n_paths)
     'c4_metric': dict(W=2048, H=2048, N=1_000_000, L=100_000, n_traits=4,
                       loci_per_trait=10, move_surf=True, n_paths=10_000),
+    # the same with the parameters-file template's recombination default
+    # (r_distr_alpha = 0.5, sim/params.py:445: free recombination): dense masks, the
+    # crossover reads both parental homologues and the 125-MB path table
+    'c4_dense': dict(W=2048, H=2048, N=1_000_000, L=100_000, n_traits=4,
+                     loci_per_trait=10, move_surf=True, n_paths=10_000, paths='dense'),
+    # one tile of BASELINE.json's configs[4] (C5: 4096x4096 tiled 2 x 4, 10^7 individuals)
+    'c5_tile': dict(W=1024, H=2048, N=1_250_000, L=100_000, n_traits=4,
+                    loci_per_trait=10, move_surf=True, n_paths=10_000),
     'c3': dict(W=1024, H=1024, N=100_000, L=100_000, n_traits=4,
                loci_per_trait=10, move_surf=False, n_paths=10_000),
     'c2': dict(W=1024, H=1024, N=100_000, L=10_000, n_traits=0,
@@ -86,7 +98,17 @@ def sparse_paths(n, L, seed, W64):
     return out
 
 
-def build_device(cfg, seed, device, grid=(1, 1)):
+def dense_paths(n, L, seed, W64):
+    """n recombination paths for per-locus rate 0.5 (free recombination): every locus
+    switches homologue with probability 1/2, i.e. the path bits are fair coins"""
+    rng = np.random.RandomState(seed)
+    out = rng.randint(0, 2 ** 63, (n, W64), dtype=np.int64).astype(np.uint64) << np.uint64(1)
+    out |= rng.randint(0, 2, (n, W64)).astype(np.uint64)
+    out[:, 0] &= ~np.uint64(1)                       # r_0 = 0 (structs/genome.py:183)
+    return out
+
+
+def build_device(cfg, seed, device, grid=(1, 1), rank=0, host_init=None, cap_factor=1.6):
     from geonomics_amd import _native as nat
     R, C = grid
     W, H, L = cfg['W'] * C, cfg['H'] * R, cfg['L']
@@ -95,9 +117,9 @@ def build_device(cfg, seed, device, grid=(1, 1)):
     lyr1 = np.tile(np.linspace(0, 1, W, dtype=np.float32), (H, 1))
     rasts = np.stack([lyr0, lyr1])
     K_factor = N / float(lyr0.sum())                  # sum(K) = N
-    cap_rows = int(cfg['N'] * 1.6) + 1024
-    # tiled: every rank first creates the whole initial population, then keeps its tile
-    cap = cap_rows if R * C == 1 else max(cap_rows, int(N * 1.02) + 1024)
+    n_own = N if host_init and R * C == 1 else cfg['N']
+    cap_rows = int(n_own * cap_factor) + 1024
+    cap = cap_rows
     dev = nat.Device(W, H, 2, L=L, n_traits=cfg['n_traits'], cap_inds=cap,
                      cap_rows=cap_rows, seed=seed, device=device)
     dev.upload_rasters(rasts)
@@ -114,13 +136,29 @@ def build_device(cfg, seed, device, grid=(1, 1)):
             n = cfg['loci_per_trait']
             alpha = 0.1 * np.array([1 - (i % 2) * 2 for i in range(n)], float)
             dev.set_trait(t, np.sort(loci[t]), alpha, 1, 0.05, 1.0, False)
-    dev.init_population(N)
+    if host_init is None:
+        host_init = R * C > 1
+    if not host_init:
+        dev.init_population(N)
+    else:
+        # the same uniform initial population on every rank (same generator), of which
+        # each rank keeps the individuals of its own tile; ids = index in the common list
+        prng = np.random.RandomState(seed + 12345)
+        x = np.minimum(prng.rand(N) * W, W - 0.001).astype(np.float32)
+        y = np.minimum(prng.rand(N) * H, H - 0.001).astype(np.float32)
+        sex = (prng.rand(N) < 0.5).astype(np.uint8)
+        r, c = divmod(rank, C)
+        mine = np.nonzero((x // (W // C) == c) & (y // (H // R) == r))[0]
+        dev.upload_population(x[mine], y[mine], np.zeros(mine.size, np.int32), sex[mine],
+                              mine.astype(np.int64))
+        dev.set_max_id(N - 1)
     return dev, rasts, K_factor
 
 
 def setup_genomes(dev, cfg, seed):
     L = cfg['L']
-    dev.set_recomb_paths(sparse_paths(cfg['n_paths'], L, seed + 1, dev.W64))
+    mk = dense_paths if cfg.get('paths') == 'dense' else sparse_paths
+    dev.set_recomb_paths(mk(cfg['n_paths'], L, seed + 1, dev.W64))
     # start_p_fixed = 0.5: n_l = round(2N * 0.5) = N ones per site
     dev.assign_genomes(np.full(L, dev.N, dtype=np.int32))
 
@@ -243,28 +281,89 @@ def measured_copy_bandwidth(torch, nbytes=2 << 30, reps=5):
         return None
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child
+    processes (before this process touches the GPU), relay rank 0's line and the first
+    non-zero exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=env, stdout=subprocess.PIPE if r == 0 else None))
+    rc = 0
+    try:
+        out0 = procs[0].communicate()[0]
+        pending = list(procs)
+        while pending:
+            for p_ in list(pending):
+                code = p_.poll()
+                if code is None:
+                    continue
+                pending.remove(p_)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:          # a dead rank leaves its peers in a collective
+                        q.kill()
+            time.sleep(0.2)
+        if rc == 0:
+            sys.stdout.write(out0.decode())
+    finally:
+        for p_ in procs:
+            if p_.poll() is None:
+                p_.kill()
+                p_.wait()
+    raise SystemExit(rc)
+
+
+def ref_cpu_number():
+    """the reference itself, timed in the build container by tools/ref_cpu_baseline.py
+    (it never travels to the GPU box): quoted next to the same-run port number"""
+    try:
+        return json.load(open(os.path.join(ROOT, 'profiles', 'ref_cpu_baseline.json')))
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--workload', default='c4_metric', choices=sorted(WORKLOADS))
+    ap.add_argument('--gpus', type=int, default=None)
+    ap.add_argument('--steps', type=int, default=100)       # SURVEY 8(d): T >= 100
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--workload', default=None, choices=sorted(WORKLOADS))
+    ap.add_argument('--scaling', default='c5', choices=['c5', 'weak2048'],
+                    help='N > 1: tiles of BASELINE C5 (default) or 2048x2048 metric tiles')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-model-api', action='store_true',
                     help='skip the second measurement through Model.walk (N = 1 only)')
     args = ap.parse_args()
 
-    import torch
-    torch.set_num_threads(1)
-    world = int(os.environ.get('WORLD_SIZE', '1'))
+    env_world = os.environ.get('WORLD_SIZE')
+    if args.gpus is None:
+        args.gpus = int(env_world) if env_world else 1
+    if env_world is None and args.gpus > 1:
+        spawn_ranks(args)                                   # does not return
+    world = int(env_world or '1')
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+
+    import torch
+    torch.set_num_threads(1)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: no HIP device is visible '
                          '(the product has no CPU path)')
     # rehearsal on a 1-GPU box: GNX_BENCH_BACKEND=gloo GNX_BENCH_SINGLE_DEVICE=1
     backend = os.environ.get('GNX_BENCH_BACKEND', 'nccl')
-    if os.environ.get('GNX_BENCH_SINGLE_DEVICE'):
+    single_dev = bool(os.environ.get('GNX_BENCH_SINGLE_DEVICE'))
+    if single_dev:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
@@ -274,7 +373,20 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         else:
             dist.init_process_group(backend)
+        # every rank on its own GPU (a launcher that put two ranks on one device would
+        # give a number that is not an N-GPU number)
+        mine = torch.tensor([local_rank], dtype=torch.int64,
+                            device='cuda' if backend == 'nccl' else 'cpu')
+        seen = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(seen, mine)
+        devs = [int(v.item()) for v in seen]
+        assert dist.get_world_size() == world
+        if not single_dev:
+            assert len(set(devs)) == world and max(devs) < torch.cuda.device_count(), (
+                'ranks do not sit on distinct GPUs: %s' % devs)
 
+    if args.workload is None:
+        args.workload = 'c4_metric' if world == 1 or args.scaling == 'weak2048' else 'c5_tile'
     cfg = WORKLOADS[args.workload]
     t_setup = time.time()
     stepper = None
@@ -283,13 +395,13 @@ def main():
     if world > 1 or force_stepper:
         from geonomics_amd.parallel import Comm, DeviceShard, TiledStepper, tile_grid
         grid = tile_grid(world)
-    dev, rasts, K_factor = build_device(cfg, seed=42, device=local_rank, grid=grid)
+    dev, rasts, K_factor = build_device(cfg, seed=42, device=local_rank, grid=grid, rank=rank)
     if world > 1 or force_stepper:
         shard = DeviceShard(dev)
         stepper = TiledStepper(shard, Comm(dist), cfg['W'] * grid[1], cfg['H'] * grid[0], 10.0,
                                move=True, max_id=cfg['N'] * world - 1, grid=grid,
                                fixed_births=1)
-        shard.export_migrants()            # keep this rank's tile of the common population
+        stepper.profile = False
 
     def do_step(burn):
         if stepper is None:
@@ -303,7 +415,7 @@ def main():
     # regulated spatial distribution before genomes are assigned
     for _ in range(3):
         do_step(True)
-    setup_genomes(dev, cfg, seed=42 + rank)
+    setup_genomes(dev, cfg, seed=42)
     if stepper is not None:
         stepper.shard.has_genomes = True
     dev.synchronize()
@@ -327,6 +439,7 @@ def main():
     t0 = time.perf_counter()
     ind_steps = 0
     births = 0
+    xo_births = 0
     for _ in range(args.steps):
         if stepper is None:
             n0, b = do_step(False)          # population at the start of the step
@@ -335,6 +448,7 @@ def main():
             ind_steps += n_glob             # global population at the start of the step
             n_glob, b = do_step(False)
         births += b
+        xo_births += dev.last_crossover_births
     dev.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -347,6 +461,18 @@ def main():
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     total_ind_steps = float(ind_steps)      # tiled: already the global count
     max_elapsed = float(mx.item())
+
+    phases = None
+    if stepper is not None:
+        # per-phase host wall time of the tile protocol, from a few extra steps with a
+        # device synchronisation at every phase mark (outside the timed region)
+        stepper.profile = True
+        stepper.phase_s = {}
+        n_prof = 5
+        for _ in range(n_prof):
+            do_step(False)
+        phases = {k: 1e3 * v / n_prof for k, v in stepper.phase_s.items()}
+        stepper.profile = False
 
     if rank == 0:
         xo = kt['crossover']
@@ -374,6 +500,7 @@ def main():
             except Exception:
                 continue
         copy_gbps = measured_copy_bandwidth(torch)
+        dense = cfg.get('paths') == 'dense'
         out = {
             'metric': 'individual-timesteps/sec', 'value': total_ind_steps / max_elapsed,
             'unit': 'individual-timesteps/s', 'n_gpus': world, 'steps': args.steps,
@@ -381,11 +508,12 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'u64', 'data': 'synthetic',
             'config': {
-                'workload': '%s: %dx%d 2-layer landscape, N0=%d per GPU, L=%d, %d traits x %d loci, '
-                            'move_surf=%s, mating_radius=10, b=0.2, lambda=1 fixed, r=1/L, '
-                            'n_recomb_sims=%d' % (
+                'workload': '%s: %dx%d 2-layer landscape per GPU, N0=%d per GPU, L=%d, '
+                            '%d traits x %d loci, move_surf=%s, mating_radius=10, b=0.2, '
+                            'lambda=1 fixed, %s, n_recomb_sims=%d' % (
                                 args.workload, cfg['W'], cfg['H'], cfg['N'], cfg['L'],
                                 cfg['n_traits'], cfg['loci_per_trait'], cfg['move_surf'],
+                                'r=0.5 (free recombination, dense masks)' if dense else 'r=1/L',
                                 cfg['n_paths']),
                 'parallelism': ('1 tile' if world == 1 else
                                 'tiles %dx%d: migrants+halo+gametes p2p, pair lists / density '
@@ -393,15 +521,19 @@ def main():
                                     grid + ('device-resident' if stepper.dev_transport
                                             else 'staged through the host',))),
                 'landscape': '%dx%d' % (cfg['W'] * grid[1], cfg['H'] * grid[0]),
+                'N0_global': cfg['N'] * world,
                 'mean_N_global': ind_steps / args.steps, 'births_per_step_global': births / args.steps,
+                'births_with_genome_per_step_rank0': xo_births / args.steps,
                 'setup_s': round(t_setup, 2),
             },
             'roofline': {
-                'bound': 'hbm', 'kernel': 'k_crossover', 'achieved': ach, 'peak': peak,
+                'bound': 'hbm', 'kernel': 'k_xo_dense<4>' if dense else 'k_xo_sparse',
+                'achieved': ach, 'peak': peak,
                 'unit': 'GB/s', 'frac': ach / peak, 'traffic': traffic,
                 'traffic_pmc': traffic_src,
                 'launches': xo['launches'],
                 'avg_launch_ms': xo['ms'] / max(xo['launches'], 1),
+                # offspring that survive their first death draw x (L bytes dense, L/2 sparse)
                 'algorithmic_bytes_per_launch': xo['bytes'] / max(xo['launches'], 1),
                 # also quote a device-to-device copy measured on this box
                 'measured_copy_GBps': copy_gbps,
@@ -412,17 +544,19 @@ def main():
             'kernel_ms_per_step': {k: v['ms'] / args.steps for k, v in kt.items()
                                    if v['launches'] > 0},
         }
-        if stepper is not None and stepper.profile:
-            out['tile_phase_ms_per_step'] = {k: 1e3 * v / (args.steps + args.warmup + 3)
-                                             for k, v in stepper.phase_s.items()}
+        if phases is not None:
+            out['tile_phase_ms_per_step'] = phases
         if world == 1 and not args.no_cpu_baseline:     # rank 0 at N = 1 only
             out['cpu_baseline'] = cpu_baseline()
+            ref = ref_cpu_number()
+            if ref is not None:
+                out['cpu_baseline']['reference'] = ref
         if world == 1 and not args.no_model_api:
             # the same workload through the drop-in API, at the model's own equilibrium
             dev.close()
             dev = None
             try:
-                out['model_api'], _ = model_api_measure(cfg, args.workload, args.steps)
+                out['model_api'], _ = model_api_measure(cfg, args.workload, min(args.steps, 40))
             except Exception as e:      # the contract line must still be printed
                 out['model_api'] = {'error': '%s: %s' % (type(e).__name__, e)}
         print(json.dumps(out))

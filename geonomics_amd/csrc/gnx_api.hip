@@ -60,6 +60,7 @@ void gnx_time_end(gnx_state* h, int kernel, double bytes) {
 }
 
 static void timers_resolve(gnx_state* h, int kernel) {
+  (void)gnx_xo_launch_pending(h);
   (void)hipStreamSynchronize(h->stream);
   if (h->stream2) (void)hipStreamSynchronize(h->stream2);
   for (auto& pr : h->ev_pending[kernel]) {
@@ -105,6 +106,21 @@ int gnx_d2h(gnx_state* h, void* dst, const void* src, size_t bytes) {
     HIPCHK(hipStreamSynchronize(h->stream));
     memcpy((char*)dst + o, h->h_stage, n);
   }
+  return 0;
+}
+
+__global__ void k_publish(const int32_t* a, const int32_t* b, const int32_t* c, const int32_t* d,
+                          int64_t* host) {
+  if (a) host[0] = *a;
+  if (b) host[1] = *b;
+  if (c) host[2] = *c;
+  if (d) host[3] = *d;
+}
+
+int gnx_publish(gnx_state* h, int slot, const int32_t* a, const int32_t* b, const int32_t* c,
+                const int32_t* d) {
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, h->stream, a, b, c, d, h->h_pin_dev + slot);
+  HIPCHK(hipGetLastError());
   return 0;
 }
 
@@ -185,8 +201,34 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
   if (cfg->L == 0) h->cfg.cap_rows = 0;
   h->W64 = cfg->L > 0 ? gnx_words_per_hom(cfg->L) : 0;
   const int64_t cap = cfg->cap_inds;
-  HIPCHK(hipStreamCreate(&h->stream));
-  HIPCHK(hipStreamCreate(&h->stream2));
+  // `stream` carries the step's many small latency-bound kernels, `stream2` the deferred
+  // crossover (one long bandwidth-bound kernel per step, under the NEXT step's small
+  // kernels): the small kernels get the higher dispatch priority so that they are not
+  // queued behind the crossover's workgroups, and the crossover can be kept off a few
+  // CUs of every XCD (GNX_XO_DROP=d: d of every 8 CUs; it is HBM-bound, not CU-bound)
+  {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    const bool prio = !(getenv("GNX_XO_PRIO") && atoi(getenv("GNX_XO_PRIO")) == 0);
+    const int drop = getenv("GNX_XO_DROP") ? atoi(getenv("GNX_XO_DROP")) : 0;
+    if (prio) HIPCHK(hipStreamCreateWithPriority(&h->stream, hipStreamDefault, hi));
+    else HIPCHK(hipStreamCreate(&h->stream));
+    if (drop > 0 && drop < 8) {
+      hipDeviceProp_t prop;
+      HIPCHK(hipGetDeviceProperties(&prop, cfg->device));
+      const int ncu = prop.multiProcessorCount;
+      std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+      // rotate the dropped CUs so that every XCD loses the same number whichever way the
+      // mask bits map to XCDs (striped or blocked)
+      for (int i = 0; i < ncu; ++i)
+        if ((i + i / 8) % 8 >= drop) mask[i / 32] |= 1u << (i % 32);
+      HIPCHK(hipExtStreamCreateWithCUMask(&h->stream2, (uint32_t)mask.size(), mask.data()));
+    } else if (prio) {
+      HIPCHK(hipStreamCreateWithPriority(&h->stream2, hipStreamDefault, lo));
+    } else {
+      HIPCHK(hipStreamCreate(&h->stream2));
+    }
+  }
   h->own_stream = true;
   for (int k = 0; k < 2; ++k) GNXCHK(alloc_soa(&h->soa[k], cap, cfg->n_layers, cfg->n_traits));
   GNXCHK(dalloc(&h->rast, (size_t)cfg->n_layers * cfg->W * cfg->H));
@@ -239,6 +281,7 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
   GNXCHK(dalloc(&h->req_py, cap));
   GNXCHK(dalloc(&h->req_count, 1));
   HIPCHK(hipHostMalloc((void**)&h->h_pin, 16 * sizeof(int64_t)));
+  HIPCHK(hipHostGetDevicePointer((void**)&h->h_pin_dev, h->h_pin, 0));
   if (cfg->L > 0) {
     for (int k = 0; k < 2; ++k) {
       HIPCHK(hipMalloc(&h->jobs[k], (size_t)cap * 2 * 16));
@@ -248,12 +291,15 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
     HIPCHK(hipEventCreateWithFlags(&h->ev_jobs, hipEventDisableTiming));
   }
   h->defer_xo = !(getenv("GNX_DEFER_XO") && atoi(getenv("GNX_DEFER_XO")) == 0);
+  if (getenv("GNX_XO_LAUNCH")) h->xo_launch_policy = atoi(getenv("GNX_XO_LAUNCH"));
+  if (getenv("GNX_XO_SORT_WAIT")) h->xo_sort_waits = atoi(getenv("GNX_XO_SORT_WAIT")) != 0;
   *out = h;
   return 0;
 }
 
 extern "C" void gnx_destroy(gnx_state* h) {
   if (!h) return;
+  (void)gnx_xo_launch_pending(h);
   (void)hipStreamSynchronize(h->stream);
   if (h->stream2) (void)hipStreamSynchronize(h->stream2);
   for (int k = 0; k < 2; ++k) {
@@ -306,6 +352,7 @@ extern "C" int gnx_set_stream(gnx_state* h, void* hip_stream) {
 }
 
 extern "C" int gnx_synchronize(gnx_state* h) {
+  GNXCHK(gnx_xo_launch_pending(h));
   HIPCHK(hipStreamSynchronize(h->stream));
   if (h->stream2) HIPCHK(hipStreamSynchronize(h->stream2));
   return 0;
@@ -887,7 +934,17 @@ extern "C" int gnx_mutate(gnx_state* h, int32_t n, const int64_t* slot, const in
   HIPCHK(hipMemcpy(dl, locus, n * sizeof(int32_t), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dh, hom, n, hipMemcpyHostToDevice));
   int r = gnx_l_mutate(h, n, ds, dl, dh);
-  if (!r) r = gnx_l_tb_from_rows(h, 0, n, nullptr, ds);
+  // the compact allele table follows only where a selected locus was hit
+  bool hit = false;
+  if (h->n_sel > 0) {
+    std::vector<int32_t> sel;
+    for (int q = 0; q < h->cfg.n_traits; ++q)
+      sel.insert(sel.end(), h->h_trait_loci[q].begin(), h->h_trait_loci[q].end());
+    sel.insert(sel.end(), h->h_delet_loci.begin(), h->h_delet_loci.end());
+    std::sort(sel.begin(), sel.end());
+    for (int i = 0; i < n && !hit; ++i) hit = std::binary_search(sel.begin(), sel.end(), locus[i]);
+  }
+  if (!r && hit) r = gnx_l_tb_from_rows(h, 0, n, nullptr, ds);
   (void)hipStreamSynchronize(h->stream);
   (void)hipFree(ds);
   (void)hipFree(dl);

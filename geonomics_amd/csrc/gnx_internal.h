@@ -161,6 +161,20 @@ struct gnx_state {
   hipEvent_t ev_jobs = nullptr, ev_xo_done[2]{};
   bool xo_inflight[2]{};         // ev_xo_done[k] recorded and not yet joined
   bool xo_running = false;       // a crossover may still be running on stream2
+  // How the deferred crossover shares the chip with the next step's small kernels
+  // (measured: profiles/r02_xo_overlap_*.txt).  They are latency-bound chains (index
+  // sampling, look-back sort and scans, spline gathers) and crawl 3-12x while a
+  // bandwidth-bound kernel saturates HBM, and the crossover loses a third of its rate to
+  // them.  Default: the crossover is launched as soon as its jobs are built, at full
+  // width, and runs under the compaction, the next step's movement and sort keys; `stream`
+  // then WAITS for it before the cell sort (xo_sort_waits).  GNX_XO_SORT_WAIT=0 lets the
+  // whole next step run beside a narrow crossover (2 workgroups per CU): ~10 % more
+  // individual-timesteps/s, but the crossover then stretches over the whole step.
+  // xo_launch_policy 1 / 2 launch it after the next step's cell sort / pair sort instead.
+  int xo_launch_policy = 0;
+  bool xo_sort_waits = true;
+  int xo_ready_buf = -1;         // jobs built, kernel not launched yet
+  int64_t xo_ready_jobs = 0;
   int64_t last_xo_births = 0;    // births that went through the last crossover
 
   // hash grid for neighbour search
@@ -252,6 +266,7 @@ struct gnx_state {
 
   // pinned host scratch for read-backs
   int64_t* h_pin = nullptr;          // [16]
+  int64_t* h_pin_dev = nullptr;      // the same memory as the device sees it
   void* h_stage = nullptr;           // pinned host staging buffer for per-step transfers
   size_t h_stage_bytes = 0;
 
@@ -265,6 +280,12 @@ struct gnx_state {
 };
 
 GnxTraitTab gnx_trait_tab(const gnx_state* h);
+
+// read-back of up to four device int32 counters: one tiny kernel writes them straight into
+// pinned host memory h->h_pin[slot..] (an async D2H copy of 4 bytes is a blit kernel or an
+// SDMA job of its own and queues behind whatever else runs, 50-900 us under load)
+int gnx_publish(gnx_state* h, int slot, const int32_t* a, const int32_t* b = nullptr,
+                const int32_t* c = nullptr, const int32_t* d = nullptr);
 
 // RAII-less scoped timer helpers (events on h->stream)
 void gnx_time_begin(gnx_state* h);
@@ -298,6 +319,13 @@ int gnx_l_crossover_survivors(gnx_state* h, int64_t first_slot, int64_t B, const
 // deferred crossover is carried out (for all pending offspring) and `stream` waits for
 // the crossover in flight on stream2
 int gnx_xo_join(gnx_state* h);
+// only the first half: offspring still waiting for their crossover get it now (their slots
+// are about to move); a crossover already in flight on stream2 is left alone
+int gnx_xo_flush_deferred(gnx_state* h);
+// launch the crossover whose jobs are ready (policy 1 / 2 hooks; no-op otherwise)
+int gnx_xo_launch_pending(gnx_state* h);
+// `stream` waits for the crossover in flight (not for one that is not launched yet)
+int gnx_xo_wait_inflight(gnx_state* h);
 double gnx_xo_bytes_per_birth(const gnx_state* h);
 // selected-locus tables: rebuild sel_loci / path_sel / GnxSoA.tb after a change of the
 // traits, the deleterious loci or the recombination paths

@@ -466,27 +466,21 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
   if (xo) {
     h->xo_deferred = false;
     GNXCHK(gnx_l_crossover_survivors(h, xo_first, xo_B, h->flag, h->scan));
-    // survivors among the offspring, read back with the other counts below
-    HIPCHK(hipMemcpyAsync(h->h_pin + 2, h->scan + xo_first, sizeof(int32_t),
-                          hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(h->h_pin + 3, h->scan + xo_first + xo_B, sizeof(int32_t),
-                          hipMemcpyDeviceToHost, h->stream));
   }
   gnx_time_begin(h);
   hipLaunchKernelGGL(k_compact, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, c.cap_inds,
                      h->flag, h->scan, h->flag2, h->boff, a, b, c.n_layers, c.n_traits,
                      a.tb ? 2 * h->TW : 0, h->free_rows, h->n_free, has_rows, xo_first, xo_B);
-  HIPCHK(hipMemcpyAsync(h->h_pin, h->scan + N, sizeof(int32_t), hipMemcpyDeviceToHost,
-                        h->stream));
-  HIPCHK(hipMemcpyAsync(h->h_pin + 1, h->boff + N, sizeof(int32_t), hipMemcpyDeviceToHost,
-                        h->stream));
+  // survivors, rows freed and (deferred crossover) the survivors among the offspring
+  GNXCHK(gnx_publish(h, 0, h->scan + N, h->boff + N, xo ? h->scan + xo_first : nullptr,
+                     xo ? h->scan + xo_first + xo_B : nullptr));
   gnx_time_end(h, GNX_K_COMPACT, (double)N * (24.0 + 2.0 * (34.0 + 4.0 * c.n_layers +
                                                              4.0 * c.n_traits + 16.0 * h->TW)));
   HIPCHK(hipStreamSynchronize(h->stream));
-  const int64_t survivors = *(int32_t*)h->h_pin;
-  const int64_t rows_freed = *(int32_t*)(h->h_pin + 1);
+  const int64_t survivors = h->h_pin[0];
+  const int64_t rows_freed = h->h_pin[1];
   if (xo) {
-    const int64_t S = *(int32_t*)(h->h_pin + 3) - *(int32_t*)(h->h_pin + 2);
+    const int64_t S = h->h_pin[3] - h->h_pin[2];
     h->n_free -= S;
     h->last_xo_births = S;
     if (h->profiling) h->timers[GNX_K_CROSSOVER].bytes += (double)S * gnx_xo_bytes_per_birth(h);

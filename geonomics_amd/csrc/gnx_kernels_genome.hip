@@ -80,17 +80,20 @@ static void xo_launch_sparse(gnx_state* h, hipStream_t st, int grid, int buf, bo
 }
 
 // the crossover of job buffer `buf` on stream `st`; max_jobs bounds the grid
-static int xo_launch(gnx_state* h, hipStream_t st, int buf, int64_t max_jobs) {
+static int xo_launch(gnx_state* h, hipStream_t st, int buf, int64_t max_jobs, bool deferred) {
   // one wave per gamete, 4 waves per block, job-strided beyond 32 blocks per CU
   // (measured: profiles/r02b_xo_lab_*.txt - time is flat in the grid size from 16 to 64
-  // blocks per CU and in the unroll from 4 to 8; non-temporal loads +2 %)
-  static const int bpc = getenv("GNX_XO_BPC") ? atoi(getenv("GNX_XO_BPC")) : 32;
+  // blocks per CU and in the unroll from 4 to 8; non-temporal loads +2 %); beside a whole
+  // step of small kernels (GNX_XO_SORT_WAIT=0) 2 blocks per CU, 6 chunks in flight
+  static const int bpc_env = getenv("GNX_XO_BPC") ? atoi(getenv("GNX_XO_BPC")) : 0;
   static const int unroll_env = getenv("GNX_XO_UNROLL") ? atoi(getenv("GNX_XO_UNROLL")) : 0;
   static const int nt = getenv("GNX_XO_NT") ? atoi(getenv("GNX_XO_NT")) : 1;
+  const bool narrow = deferred && !h->xo_sort_waits;
+  const int bpc = bpc_env ? bpc_env : (narrow ? 2 : 32);
   const int W16 = h->W64 / 2;
   const int grid = gnx_grid(max_jobs, 4, 256 * bpc);
   if (h->sparse_paths) {
-    const int U = unroll_env ? unroll_env : gnx_xo_pick_unroll(W16);
+    const int U = unroll_env ? unroll_env : (narrow ? 6 : gnx_xo_pick_unroll(W16));
     switch (U) {
       case 4: xo_launch_sparse<4>(h, st, grid, buf, nt); break;
       case 5: xo_launch_sparse<5>(h, st, grid, buf, nt); break;
@@ -134,6 +137,7 @@ static int xo_wait_buf(gnx_state* h, hipStream_t st, int buf) {
 
 int gnx_l_crossover_all(gnx_state* h, int64_t first_slot, int64_t B) {
   if (B == 0) return 0;
+  GNXCHK(gnx_xo_launch_pending(h));
   // rows written here may be parents' rows of a crossover still running on stream2
   GNXCHK(xo_wait_buf(h, h->stream, 0));
   GNXCHK(xo_wait_buf(h, h->stream, 1));
@@ -149,16 +153,44 @@ int gnx_l_crossover_all(gnx_state* h, int64_t first_slot, int64_t B) {
     HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_jobs, 0));
   }
   gnx_time_begin(h);
-  GNXCHK(xo_launch(h, h->stream, buf, 2 * B));
+  GNXCHK(xo_launch(h, h->stream, buf, 2 * B, false));
   gnx_time_end(h, GNX_K_CROSSOVER, (double)B * gnx_xo_bytes_per_birth(h));
   h->n_free -= B;
   h->last_xo_births = B;
   return 0;
 }
 
+int gnx_xo_launch_pending(gnx_state* h) {
+  const int buf = h->xo_ready_buf;
+  if (buf < 0) return 0;
+  h->xo_ready_buf = -1;
+  // behind everything `stream` has been given so far (the jobs, and with launch policy
+  // 1 / 2 the sort that is meant to run alone)
+  HIPCHK(hipEventRecord(h->ev_jobs, h->stream));
+  HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_jobs, 0));
+  hipStream_t main = h->stream;
+  h->stream = h->stream2;                        // the timer events go where the kernel goes
+  gnx_time_begin(h);
+  int rc = xo_launch(h, h->stream2, buf, h->xo_ready_jobs, true);
+  gnx_time_end(h, GNX_K_CROSSOVER, 0.0);         // bytes are added once the survivors are counted
+  h->stream = main;
+  GNXCHK(rc);
+  HIPCHK(hipEventRecord(h->ev_xo_done[buf], h->stream2));
+  h->xo_inflight[buf] = true;
+  h->xo_running = true;
+  return 0;
+}
+
+int gnx_xo_wait_inflight(gnx_state* h) {
+  GNXCHK(xo_wait_buf(h, h->stream, 0));
+  GNXCHK(xo_wait_buf(h, h->stream, 1));
+  return 0;
+}
+
 int gnx_l_crossover_survivors(gnx_state* h, int64_t first_slot, int64_t B, const int32_t* d_alive,
                               const int32_t* d_scan) {
   if (B == 0) return 0;
+  GNXCHK(gnx_xo_launch_pending(h));              // at most one set of jobs waits
   const int buf = h->jobs_cur;
   GNXCHK(xo_wait_buf(h, h->stream, buf));       // the crossover two steps back read this buffer
   GnxSoA s = h->soa[h->cur];
@@ -166,29 +198,28 @@ int gnx_l_crossover_survivors(gnx_state* h, int64_t first_slot, int64_t B, const
                      s.grow, d_alive, d_scan, h->off_parent, h->off_keys, h->off_start,
                      h->free_rows, h->n_free, (GnxXoJob*)h->jobs[buf], h->n_jobs_dev[buf]);
   HIPCHK(hipEventRecord(h->ev_jobs, h->stream));
-  HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_jobs, 0));
-  hipStream_t main = h->stream;
-  h->stream = h->stream2;                        // the timer events go where the kernel goes
-  gnx_time_begin(h);
-  int rc = xo_launch(h, h->stream2, buf, 2 * B);
-  gnx_time_end(h, GNX_K_CROSSOVER, 0.0);         // bytes are added once the survivors are counted
-  h->stream = main;
-  GNXCHK(rc);
-  HIPCHK(hipEventRecord(h->ev_xo_done[buf], h->stream2));
-  h->xo_inflight[buf] = true;
-  h->xo_running = true;
+  h->xo_ready_buf = buf;
+  h->xo_ready_jobs = 2 * B;
   h->jobs_cur ^= 1;
+  if (h->xo_launch_policy == 0) GNXCHK(gnx_xo_launch_pending(h));
   return 0;
 }
 
-int gnx_xo_join(gnx_state* h) {
+int gnx_xo_flush_deferred(gnx_state* h) {
   if (h->xo_deferred) {
+    GNXCHK(gnx_xo_launch_pending(h));
     // somebody needs this step's genomes before its death draws: every pending offspring
     // gets its row and its crossover now (same genomes as the deferred path would give
     // the survivors; the dead's rows return to the free stack with the other deaths)
     h->xo_deferred = false;
     GNXCHK(gnx_l_crossover_all(h, h->xo_first, h->xo_B));
   }
+  return 0;
+}
+
+int gnx_xo_join(gnx_state* h) {
+  GNXCHK(gnx_xo_flush_deferred(h));
+  GNXCHK(gnx_xo_launch_pending(h));
   GNXCHK(xo_wait_buf(h, h->stream, 0));
   GNXCHK(xo_wait_buf(h, h->stream, 1));
   return 0;

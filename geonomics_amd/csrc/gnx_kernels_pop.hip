@@ -370,7 +370,8 @@ __global__ void k_cell_bounds(int64_t N, const uint64_t* key, int32_t* cell_star
 int gnx_l_sort_by_cell(gnx_state* h) {
   int64_t N = h->N;
   if (N == 0) return 0;
-  GNXCHK(gnx_xo_join(h));      // slots move: offspring still waiting for their crossover get it now
+  GNXCHK(gnx_xo_flush_deferred(h));   // slots move: offspring still waiting for their crossover get it now
+  if (h->xo_sort_waits) GNXCHK(gnx_xo_wait_inflight(h));   // the radix sort runs alone
   const gnx_config& c = h->cfg;
   GnxSoA a = h->soa[h->cur], b = h->soa[h->cur ^ 1];
   gnx_time_begin(h);
@@ -389,6 +390,7 @@ int gnx_l_sort_by_cell(gnx_state* h) {
                (double)N * 2.0 * (33.0 + 4.0 * c.n_layers + 4.0 * c.n_traits + 16.0 * h->TW));
   HIPCHK(hipGetLastError());
   h->cur ^= 1;
+  if (h->xo_launch_policy == 1) GNXCHK(gnx_xo_launch_pending(h));
   return 0;
 }
 
@@ -733,11 +735,10 @@ int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out) 
                        h->stream));
   hipLaunchKernelGGL(k_pair_compact, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, focal,
                      h->mate, h->flag2, h->scan, s.x, s.y, h->pairs, h->mid_x, h->mid_y);
-  HIPCHK(hipMemcpyAsync(h->h_pin, h->scan + N, sizeof(int32_t), hipMemcpyDeviceToHost,
-                        h->stream));
+  GNXCHK(gnx_publish(h, 0, h->scan + N));
   gnx_time_end(h, GNX_K_PAIRS, (double)N * 40.0);
   HIPCHK(hipStreamSynchronize(h->stream));
-  h->n_pairs = *(int32_t*)h->h_pin;
+  h->n_pairs = h->h_pin[0];
   *n_pairs_out = h->n_pairs;
   // Order the pairs by the id of their focal individual: offspring ids are then
   // handed out in an order that does not depend on slot order or on how the
@@ -754,6 +755,7 @@ int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out) 
     std::swap(h->pairs, h->pairs2);
     HIPCHK(hipGetLastError());
   }
+  if (h->xo_launch_policy == 2) GNXCHK(gnx_xo_launch_pending(h));
   return 0;
 }
 
@@ -949,10 +951,9 @@ int gnx_l_births(gnx_state* h, int64_t* births_out) {
       HIPCHK(hipMemsetAsync(h->nbirths + P, 0, sizeof(int32_t), h->stream));
       GNXCHK(gnx_prim_scan(h->scan_tmp, h->scan_tmp_bytes, h->nbirths, h->boff, (size_t)P + 1,
                            h->stream));
-      HIPCHK(hipMemcpyAsync(h->h_pin, h->boff + P, sizeof(int32_t), hipMemcpyDeviceToHost,
-                            h->stream));
+      GNXCHK(gnx_publish(h, 0, h->boff + P));
       HIPCHK(hipStreamSynchronize(h->stream));
-      B = *(int32_t*)h->h_pin;
+      B = h->h_pin[0];
       if (B > h->cfg.cap_inds) {
         gnx_set_error("capacity exceeded: births %lld > cap_inds %lld", (long long)B,
                       (long long)h->cfg.cap_inds);
@@ -979,7 +980,7 @@ int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* 
   GnxSoA s = h->soa[h->cur];
   *births_out = 0;
   int64_t B = 0;
-  if (h->xo_deferred) GNXCHK(gnx_xo_join(h));
+  GNXCHK(gnx_xo_flush_deferred(h));
   bool genomes = !burn && c.L > 0 && h->genomes_assigned;
   if (inject) {
     B = B_inject;
@@ -1045,10 +1046,9 @@ int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* 
     if (tiled && genomes) {
       // the number of gamete requests is known before the crossover is launched: the host
       // layer serves the neighbour tiles while the crossover runs
-      HIPCHK(hipMemcpyAsync(h->h_pin, h->req_count, sizeof(int32_t), hipMemcpyDeviceToHost,
-                            h->stream));
+      GNXCHK(gnx_publish(h, 0, h->req_count));
       HIPCHK(hipStreamSynchronize(h->stream));
-      h->n_req = *(int32_t*)h->h_pin;
+      h->n_req = h->h_pin[0];
     }
   }
   HIPCHK(hipGetLastError());

@@ -185,10 +185,9 @@ static int stage_selection(gnx_state* h, const int32_t* d_mask, bool with_z, boo
   HIPCHK(hipMemsetAsync(h->flag + N, 0, sizeof(int32_t), h->stream));
   GNXCHK(gnx_prim_scan(h->scan_tmp, h->scan_tmp_bytes, h->flag, h->scan, (size_t)N + 1,
                        h->stream));
-  HIPCHK(hipMemcpyAsync(h->h_pin, h->scan + N, sizeof(int32_t), hipMemcpyDeviceToHost,
-                        h->stream));
+  GNXCHK(gnx_publish(h, 0, h->scan + N));
   HIPCHK(hipStreamSynchronize(h->stream));
-  int64_t n = *(int32_t*)h->h_pin;
+  int64_t n = h->h_pin[0];
   *n_out = n;
   h->st_n = n;
   h->st_has_geno = false;

@@ -109,24 +109,28 @@ k_xo_sparse(const int32_t* __restrict__ n_jobs_p, int W16, const u64x2* __restri
     const int nbp = __builtin_amdgcn_readfirstlane(bp_off[key + 1]) - bp0;
     const int mybp = lane < nbp ? bp_loci[bp0 + lane] : 0x7fffffff;
     for (int c0 = lane; c0 < W16; c0 += 64 * U) {
-      u64x2 m[U], v[U];
+      // masks are not kept: the rare batch that holds a switch point rebuilds them (the
+      // kernel's register footprint decides how many of the step's small kernels fit on
+      // the CUs beside it)
+      u64x2 v[U];
       bool mixed = false;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int c = min(c0 + u * 64, W16 - 1);     // tail lanes re-read the last chunk
-        m[u] = xo_mask_lanes(c, s, mybp, nbp);
-        const bool one = (m[u].a & m[u].b) == ~0ull;
-        mixed |= !one && (m[u].a | m[u].b) != 0ull;
+        const u64x2 m = xo_mask_lanes(c, s, mybp, nbp);
+        const bool one = (m.a & m.b) == ~0ull;
+        mixed |= !one && (m.a | m.b) != 0ull;
         v[u] = xo_load<NT_LD>((one ? h1 : h0) + c);
       }
-      if (__builtin_expect(mixed, 0)) {
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(mixed) != 0ull, 0)) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int c = min(c0 + u * 64, W16 - 1);
-          if ((m[u].a & m[u].b) != ~0ull && (m[u].a | m[u].b) != 0ull) {
+          const u64x2 m = xo_mask_lanes(c, s, mybp, nbp);
+          if ((m.a & m.b) != ~0ull && (m.a | m.b) != 0ull) {
             const u64x2 b = h1[c];
-            v[u].a = (v[u].a & ~m[u].a) | (b.a & m[u].a);
-            v[u].b = (v[u].b & ~m[u].b) | (b.b & m[u].b);
+            v[u].a = (v[u].a & ~m.a) | (b.a & m.a);
+            v[u].b = (v[u].b & ~m.b) | (b.b & m.b);
           }
         }
       }

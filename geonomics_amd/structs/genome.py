@@ -106,7 +106,9 @@ class Recombinations:
             out = T.copy()
             for sh in (1, 2, 4, 8, 16, 32):
                 out ^= out << np.uint64(sh)
-            par = (np.bitwise_count(T) & 1).astype(np.int64)
+            # parity of each word's switch count = top bit of its prefix XOR (no
+            # np.bitwise_count: that needs NumPy >= 2.0)
+            par = (out >> np.uint64(63)).astype(np.int64)
             carry = (np.cumsum(par, axis=1) - par) & 1
             out ^= np.where(carry == 1, np.uint64(0xFFFFFFFFFFFFFFFF), np.uint64(0))
             # bits beyond L stay clear

@@ -100,51 +100,51 @@ class Landscape(dict):
     __repr__ = __str__
 
 
-def _make_random_lyr(dim, n_pts, interp_method='cubic', num_hab_types=2, rng=None):
-    """Random layer by interpolating beta(0.05, 0.05) seed points placed well
-    beyond the landscape (reference structs/landscape.py:417-467)."""
-    from scipy import interpolate
+def _scattered_to_raster(pts, vals, dim, method, n_classes, rng):
+    """Raster of a layer given by scattered points: the values are interpolated
+    (scipy griddata) at the nodes of a square max(dim) x max(dim) lattice running from 1 to
+    max(dim) along both axes, first axis = first coordinate of `pts`, and the landscape's
+    own extent is cut out of it afterwards.  'nearest' makes patches of n_classes integer
+    habitat classes (the values are proportions, scaled to 0 .. n_classes - 1 and rounded);
+    'cubic' surfaces are shifted and scaled into (0, 1), with a small random margin that
+    keeps them off exactly 0 and 1.  Both 'random' and 'defined' layers are built this way
+    (reference structs/landscape.py:417-519)."""
+    from scipy.interpolate import griddata
+    side = max(dim)
+    axis = np.linspace(1, side, side)
+    nodes = tuple(np.meshgrid(axis, axis, indexing='ij'))
+    vals = np.asarray(vals, dtype=float)
+    patches = method == 'nearest'
+    surface = griddata(np.asarray(pts, dtype=float), vals * (n_classes - 1) if patches else vals,
+                       nodes, method=method)
+    if patches:
+        surface = np.rint(surface).astype(float)
+    elif method == 'cubic':
+        lift = abs(surface.min()) + 0.01 * rng.rand()
+        surface = (surface + lift) / ((surface + lift).max() + 0.01 * rng.rand())
+    W, H = dim
+    return surface if W == H else surface[:H, :W]
+
+
+def _make_random_lyr(dim, n_pts, interp_method='cubic', num_hab_types=2, dist='beta',
+                     alpha=0.05, beta=0.05, rng=None):
+    """'random' layer: n_pts seed values (beta(alpha, beta) or uniform) at points drawn
+    well beyond the landscape, N(max_dim / 2, 2 max_dim) per coordinate, so that the
+    interpolation spans the whole extent; cells the hull still misses are 0"""
     rng = np.random if rng is None else rng
-    max_dim = max(dim)
-    vals = rng.beta(0.05, 0.05, n_pts)
-    if interp_method == 'nearest':
-        vals = vals * (num_hab_types - 1)
-    pts = rng.normal(max_dim / 2, max_dim * 2, [n_pts, 2])
-    grid_x, grid_y = np.mgrid[1:max_dim:complex('%ij' % max_dim),
-                              1:max_dim:complex('%ij' % max_dim)]
-    img = interpolate.griddata(pts, vals, (grid_x, grid_y), method=interp_method)
-    if interp_method == 'nearest':
-        img = img.round().astype(float)
-    if interp_method == 'cubic':
-        img = img + abs(img.min()) + (0.01 * rng.rand())
-        img = img / (img.max() + (0.01 * rng.rand()))
-    if dim[0] != dim[1]:
-        img = img[:dim[1], :dim[0]]
-    return np.clip(np.nan_to_num(img, nan=0.0), 0, 1)
+    seeds = rng.rand(n_pts) if dist == 'unif' else rng.beta(alpha, beta, n_pts)
+    where = rng.normal(max(dim) / 2, max(dim) * 2, [n_pts, 2])
+    rast = _scattered_to_raster(where, seeds, dim, interp_method, num_hab_types, rng)
+    return np.clip(np.nan_to_num(rast, nan=0.0), 0, 1)
 
 
 def _make_defined_lyr(dim, rast=None, pts=None, vals=None, interp_method='cubic',
                       num_hab_types=2, rng=None):
-    """reference structs/landscape.py:470-519"""
+    """'defined' layer: the raster itself, or scattered (pts, vals) to interpolate"""
     if rast is not None:
         return np.asarray(rast, dtype=np.float64)
-    from scipy import interpolate
-    rng = np.random if rng is None else rng
-    vals = np.asarray(vals, dtype=float)
-    if interp_method == 'nearest':
-        vals = vals * (num_hab_types - 1)
-    max_dim = max(dim)
-    grid_x, grid_y = np.mgrid[1:max_dim:complex('%ij' % max_dim),
-                              1:max_dim:complex('%ij' % max_dim)]
-    img = interpolate.griddata(pts, vals, (grid_x, grid_y), method=interp_method)
-    if interp_method == 'nearest':
-        img = img.round().astype(float)
-    if interp_method == 'cubic':
-        img = img + abs(img.min()) + (0.01 * rng.rand())
-        img = img / (img.max() + (0.01 * rng.rand()))
-    if dim[0] != dim[1]:
-        img = img[:dim[1], :dim[0]]
-    return img
+    return _scattered_to_raster(pts, vals, dim, interp_method, num_hab_types,
+                                np.random if rng is None else rng)
 
 
 def _make_landscape(mod, params, num_hab_types=2, verbose=False):

@@ -686,13 +686,32 @@ class Species:
                     max_ind_idx=self.max_ind_idx, extinct=self.extinct,
                     spat=copy.deepcopy(self._burnin_spat_stats), geno=None,
                     K=None if self._K is None else np.array(self._K, copy=True),
+                    K_explicit=bool(self.__dict__.get('_K_explicit', False)),
+                    # only mutation changes the genomic architecture within an iteration
+                    gen_arch=(copy.deepcopy(self.gen_arch)
+                              if self.gen_arch is not None and getattr(self, 'mutate', False)
+                              else None),
                     pv=copy.deepcopy(self._pv.__dict__))
         if self.gen_arch is not None and self.burned and d.L > 0:
             snap['geno'] = d.download(nat.F_GENO)
         return snap
 
     def _restore(self, snap):
+        """back to the snapshot in everything an iteration can change (the reference
+        deep-copies the whole community, sim/model.py:386-399): population, genomes, the
+        carrying capacity a demographic change has scaled (ops/change.py:633-651), the
+        genomic architecture mutation has extended (structs/genome.py:753-788), the
+        life-history parameters and the event schedules"""
         d = self._dev
+        if snap.get('gen_arch') is not None:
+            self.gen_arch = copy.deepcopy(snap['gen_arch'])
+            self._upload_gen_arch()
+        if snap['K_explicit'] and snap['K'] is not None:
+            self.K = np.array(snap['K'], copy=True)
+        else:
+            self._K = None if snap['K'] is None else np.array(snap['K'], copy=True)
+            d.set_K_raster(None)
+            self._K_explicit = False
         d.upload_population(snap['x'], snap['y'], snap['age'], snap['sex'], snap['id'])
         if snap['geno'] is not None:
             d.upload_genomes(snap['geno'])

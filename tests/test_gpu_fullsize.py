@@ -117,13 +117,13 @@ def test_step_invariants_at_baseline_sizes(workload):
     assert run() == run()
 
 
-def test_two_tiles_equal_one_device_at_metric_size():
-    """BASELINE configs[4] in small: a 4096 x 2048 landscape with 2 x 10^6 individuals and
-    10^5 loci, once on one device and once as two 2048^2 tiles (threads of this process,
-    tests/_local_comm.py in place of RCCL, device-resident transport).  Genomes carry each
-    founder's id (both homologues, an otherwise empty genome), so the two runs start from
-    the same genomes; after burn-in and main steps with selection the two populations must
-    be identical: ids, positions, ages, phenotypes, per-locus allele counts."""
+def _tiles_equal_one_device(cfg, grid, n_paths, n_burn, n_main, nbits):
+    """A landscape of grid[0] x grid[1] tiles of `cfg`, once on one device and once as
+    tiles (threads of this process, tests/_local_comm.py in place of RCCL, device-resident
+    transport).  Genomes carry each founder's id (both homologues, an otherwise empty
+    genome), so the two runs start from the same genomes; after burn-in and main steps
+    with selection the two populations must be identical: ids, positions, ages,
+    phenotypes, per-locus allele counts."""
     import threading
     import torch
     import bench
@@ -131,18 +131,19 @@ def test_two_tiles_equal_one_device_at_metric_size():
     from geonomics_amd.parallel import Comm, DeviceShard, TiledStepper
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from _local_comm import Hub, LocalComm
-    cfg = dict(bench.WORKLOADS['c4_metric'])
-    L, grid = cfg['L'], (1, 2)
-    n_burn, n_main = 2, 3
+    L = cfg['L']
+    R, C = grid
+    n_tiles = R * C
+    tag0 = min(TAG0, L - 64)
 
     def tag_genomes(dev):
-        dev.set_recomb_paths(bench.sparse_paths(2000, L, 43, dev.W64))
+        dev.set_recomb_paths(bench.sparse_paths(n_paths, L, 43, dev.W64))
         dev.assign_genomes(np.zeros(L, np.int32))
         ids = dev.download(nat.F_ID)
-        bit = (ids[:, None] >> np.arange(21)[None, :]) & 1
+        bit = (ids[:, None] >> np.arange(nbits)[None, :]) & 1
         who, which = np.nonzero(bit)
         for hom in (0, 1):
-            dev.mutate(who.astype(np.int64), (TAG0 + which).astype(np.int32),
+            dev.mutate(who.astype(np.int64), (tag0 + which).astype(np.int32),
                        np.full(who.size, hom, np.uint8))
         dev.set_z()
 
@@ -162,17 +163,17 @@ def test_two_tiles_equal_one_device_at_metric_size():
             try:
                 torch.cuda.set_device(0)
                 if world > 1:
-                    dev, _, _ = bench.build_device(cfg, seed=42, device=0, grid=grid)
-                else:       # the same landscape and population on one device
-                    whole = dict(cfg, W=cfg['W'] * 2, N=cfg['N'] * 2)
-                    dev, _, _ = bench.build_device(whole, seed=42, device=0)
+                    dev, _, _ = bench.build_device(cfg, seed=42, device=0, grid=grid, rank=rank,
+                                                   cap_factor=1.7)
+                else:       # the same landscape and the same initial population on one device
+                    whole = dict(cfg, W=cfg['W'] * C, H=cfg['H'] * R, N=cfg['N'] * n_tiles)
+                    dev, _, _ = bench.build_device(whole, seed=42, device=0, host_init=True)
                 comm = LocalComm(hub, rank) if world > 1 else Comm(None)
                 shard = DeviceShard(dev)
                 # world 1: one tile that spans the whole landscape
-                st = TiledStepper(shard, comm, cfg['W'] * 2, cfg['H'], 10.0, move=True,
-                                  max_id=2 * cfg['N'] - 1, grid=grid if world > 1 else (1, 1),
-                                  fixed_births=1)
-                shard.export_migrants()
+                st = TiledStepper(shard, comm, cfg['W'] * C, cfg['H'] * R, 10.0, move=True,
+                                  max_id=n_tiles * cfg['N'] - 1,
+                                  grid=grid if world > 1 else (1, 1), fixed_births=1)
                 hist = [st.step(True, False) for _ in range(n_burn)]
                 tag_genomes(dev)
                 shard.has_genomes = True
@@ -184,21 +185,49 @@ def test_two_tiles_equal_one_device_at_metric_size():
                 hub.barrier.abort()
         ths = [threading.Thread(target=body, args=(r,)) for r in range(world)]
         [t.start() for t in ths]
-        [t.join(timeout=600) for t in ths]
+        [t.join(timeout=800) for t in ths]
         if errs:
             raise errs[0]
         return res
 
     one = run(1)[0]
-    two = run(2)
-    assert one[1] == two[0][1] == two[1][1]               # global (N, births, deaths) per step
-    ids = np.concatenate([r[0]['ids'] for r in two])
+    many = run(n_tiles)
+    for r in many:
+        assert r[1] == one[1]                             # global (N, births, deaths) per step
+    ids = np.concatenate([r[0]['ids'] for r in many])
     o = np.argsort(ids)
     np.testing.assert_array_equal(ids[o], one[0]['ids'])
     for k in ('x', 'y', 'age'):
-        np.testing.assert_array_equal(np.concatenate([r[0][k] for r in two])[o], one[0][k], k)
-    np.testing.assert_array_equal(np.concatenate([r[0]['z'] for r in two], axis=1)[:, o],
+        np.testing.assert_array_equal(np.concatenate([r[0][k] for r in many])[o], one[0][k], k)
+    np.testing.assert_array_equal(np.concatenate([r[0]['z'] for r in many], axis=1)[:, o],
                                   one[0]['z'])
     for k in ('c1', 'ch'):
-        np.testing.assert_array_equal(two[0][0][k] + two[1][0][k], one[0][k], k)
-    assert one[0]['c1'][TAG0:TAG0 + 21].sum() > 10**6 and len(ids) > 1.9e6
+        np.testing.assert_array_equal(sum(r[0][k] for r in many), one[0][k], k)
+    assert one[0]['c1'][tag0:tag0 + nbits].sum() > cfg['N'] * n_tiles // 2
+    assert len(ids) > 0.9 * cfg['N'] * n_tiles
+    return one, many
+
+
+def test_two_tiles_equal_one_device_at_metric_size():
+    """a 4096 x 2048 landscape with 2 x 10^6 individuals and 10^5 loci: two 2048^2 tiles of
+    the metric workload equal the one-device run"""
+    import bench
+    _tiles_equal_one_device(dict(bench.WORKLOADS['c4_metric']), (1, 2), n_paths=2000,
+                            n_burn=2, n_main=3, nbits=21)
+
+
+@pytest.mark.timeout(1500)
+def test_c5_eight_tiles_equal_one_device_at_size():
+    """BASELINE.json configs[4] (C5) AT SIZE: a 4096 x 4096 landscape tiled 2 x 4 (tiles
+    1024 wide, 2048 tall), 10^7 individuals, conductance-surface movement, 4 selected
+    traits; L = 10^4 so that the one-device run and the eight tiles fit one MI355X
+    (SURVEY 8d allows it).  The eight in-process tiles exchange migrants with genomes,
+    halos, pair lists, gametes and density bins exactly as eight ranks would, with plain
+    device copies in place of RCCL; the result equals the one-device run bit for bit."""
+    import bench
+    cfg = dict(bench.WORKLOADS['c5_tile'], L=10_000, n_paths=2000)
+    one, many = _tiles_equal_one_device(cfg, (2, 4), n_paths=2000, n_burn=2, n_main=2,
+                                        nbits=24)
+    assert len(one[0]['ids']) > 9_000_000
+    sizes = [len(r[0]['ids']) for r in many]
+    assert min(sizes) > 500_000                           # every tile carries its share

@@ -14,6 +14,7 @@ ap.add_argument('--workload', default='c4_metric')
 ap.add_argument('--steps', type=int, default=10)
 ap.add_argument('--genomes', action='store_true')
 ap.add_argument('--no-traits', action='store_true')
+ap.add_argument('--no-profile', action='store_true')
 a = ap.parse_args()
 cfg = dict(bench.WORKLOADS[a.workload])
 if not a.genomes:
@@ -28,7 +29,7 @@ if a.genomes:
     bench.setup_genomes(dev, cfg, 42)
 for _ in range(2):
     dev.step(not a.genomes, a.genomes)
-dev.profiling(True)
+dev.profiling(not a.no_profile)
 import time
 dev.synchronize()
 t0 = time.perf_counter()

@@ -12,6 +12,8 @@ import shutil
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+workload = sys.argv[2] if len(sys.argv) > 2 else 'c4_metric'
+wl = workload.split('_')[0] if workload == 'c4_metric' else workload
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, 'gpurun_out')
 prof = os.path.join(root, 'profiles')
@@ -33,7 +35,8 @@ def counter_rows(d, counter, dst):
         wr = csv.DictWriter(g, rd.fieldnames)
         wr.writeheader()
         for r in rd:
-            if 'k_crossover' in r['Kernel_Name'] and r['Counter_Name'] == counter:
+            if ('k_xo_sparse' in r['Kernel_Name'] or 'k_xo_dense' in r['Kernel_Name']) \
+                    and r['Counter_Name'] == counter:
                 wr.writerow(r)
                 vals.append(float(r['Counter_Value']))
                 dur.append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-6)
@@ -42,7 +45,7 @@ def counter_rows(d, counter, dst):
 
 ks = find('prof_' + tag, 'kernel_stats.csv')
 if ks:
-    shutil.copy(ks, os.path.join(prof, '%s_c4_kernel_stats.csv' % tag))
+    shutil.copy(ks, os.path.join(prof, '%s_%s_kernel_stats.csv' % (tag, wl)))
 fv, _ = counter_rows('pmc_fetch_' + tag, 'FETCH_SIZE',
                      os.path.join(prof, '%s_pmc_fetch_crossover.csv' % tag))
 wv, _ = counter_rows('pmc_write_' + tag, 'WRITE_SIZE',
@@ -56,11 +59,11 @@ try:
     alg = b['roofline']['algorithmic_bytes_per_launch']
     kernel = b['roofline']['kernel']
 except Exception:
-    kernel = 'k_crossover'
+    kernel = 'k_xo'
 if fv and wv:
     rd = 2.0 * 1024.0 * sum(fv) / len(fv)
     wrb = 1024.0 * sum(wv) / len(wv)
-    js = {'workload': 'c4_metric', 'kernel': kernel,
+    js = {'workload': workload, 'kernel': kernel,
           'FETCH_SIZE_KB_mean': sum(fv) / len(fv), 'WRITE_SIZE_KB_mean': sum(wv) / len(wv),
           'correction': 'gfx950: FETCH_SIZE reports 1/2 of a 16-B-per-lane coalesced stream '
                         '(MI355X_MICROARCH.md, HBM) -> x2; WRITE_SIZE exact; separate --pmc passes',
@@ -75,4 +78,4 @@ for name in ('prof_%s_bench.json' % tag,):
     if os.path.exists(src):
         line = [l for l in open(src) if l.startswith('{"metric"')]
         if line:
-            open(os.path.join(prof, '%s_c4_bench_under_rocprof.json' % tag), 'w').write(line[-1])
+            open(os.path.join(prof, '%s_%s_bench_under_rocprof.json' % (tag, wl)), 'w').write(line[-1])
