@@ -45,7 +45,7 @@ EXPORTS = [
     'gnx_tile_import_dev', 'gnx_tile_import_ghosts_dev', 'gnx_tile_pair_ptrs',
     'gnx_tile_offspring_dev', 'gnx_tile_group_requests', 'gnx_tile_serve_gametes_dev',
     'gnx_tile_put_gametes_dev', 'gnx_tile_bins_ptr', 'gnx_set_k_raster', 'gnx_last_births', 'gnx_set_positions', 'gnx_n_slots', 'gnx_stats_ld_counts',
-    'gnx_set_defer_crossover', 'gnx_last_crossover_births',
+    'gnx_set_defer_crossover', 'gnx_last_crossover_births', 'gnx_set_crossover_overlap',
 ]
 
 
@@ -291,6 +291,11 @@ class Device:
     def set_defer_crossover(self, on):
         """cut the offspring's genomes after the death draws, survivors only (default)"""
         self._chk(self.lib.gnx_set_defer_crossover(self.h, int(bool(on))))
+
+    def set_crossover_overlap(self, whole_step):
+        """False (default): the crossover keeps the chip, the next cell sort waits for it;
+        True: a narrow crossover runs beside the whole next step"""
+        self._chk(self.lib.gnx_set_crossover_overlap(self.h, int(bool(whole_step))))
 
     @property
     def last_crossover_births(self):

@@ -280,6 +280,10 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
   GNXCHK(dalloc(&h->req_px, cap));
   GNXCHK(dalloc(&h->req_py, cap));
   GNXCHK(dalloc(&h->req_count, 1));
+  h->blk_stride = (int)((cap + 1023) / 1024) + 2;
+  GNXCHK(dalloc(&h->blk_cnt, (size_t)2 * h->blk_stride));
+  GNXCHK(dalloc(&h->blk_off, (size_t)2 * h->blk_stride));
+  GNXCHK(dalloc(&h->cnt_dev, 4));
   HIPCHK(hipHostMalloc((void**)&h->h_pin, 16 * sizeof(int64_t)));
   HIPCHK(hipHostGetDevicePointer((void**)&h->h_pin_dev, h->h_pin, 0));
   if (cfg->L > 0) {
@@ -290,6 +294,7 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
     }
     HIPCHK(hipEventCreateWithFlags(&h->ev_jobs, hipEventDisableTiming));
   }
+  HIPCHK(hipEventCreateWithFlags(&h->ev_counts, hipEventDisableTiming));
   h->defer_xo = !(getenv("GNX_DEFER_XO") && atoi(getenv("GNX_DEFER_XO")) == 0);
   if (getenv("GNX_XO_LAUNCH")) h->xo_launch_policy = atoi(getenv("GNX_XO_LAUNCH"));
   if (getenv("GNX_XO_SORT_WAIT")) h->xo_sort_waits = atoi(getenv("GNX_XO_SORT_WAIT")) != 0;
@@ -308,6 +313,7 @@ extern "C" void gnx_destroy(gnx_state* h) {
     if (h->ev_xo_done[k]) (void)hipEventDestroy(h->ev_xo_done[k]);
   }
   if (h->ev_jobs) (void)hipEventDestroy(h->ev_jobs);
+  if (h->ev_counts) (void)hipEventDestroy(h->ev_counts);
   for (int k = 0; k < 2; ++k) {
     free_soa(&h->soa[k]);
     (void)hipFree(h->key[k]);
@@ -322,7 +328,7 @@ extern "C" void gnx_destroy(gnx_state* h) {
                   h->off_parent, h->off_keys, h->off_start, h->keep_in, h->inj_a, h->inj_b,
                   h->mid_x, h->mid_y, h->p_death, h->d_cell, h->dead_in, h->nmax_bits, h->red,
                   h->sel_loci, h->path_sel, h->lat.areas, h->lat.cprime, h->spl_N.c, h->spl_P.c, h->bin_partials, h->nodes,
-                  h->K_over, h->gp_rec, h->gp_z, h->gp_slots, h->tile_counts, h->rq_sorted, h->rq_k, h->gam_out, h->gam_slot, h->chk};
+                  h->K_over, h->blk_cnt, h->blk_off, h->cnt_dev, h->gp_rec, h->gp_z, h->gp_slots, h->tile_counts, h->rq_sorted, h->rq_k, h->gam_out, h->gam_slot, h->chk};
   for (void* p : ptrs) (void)hipFree(p);
   for (int t = 0; t < GNX_MAX_TRAITS; ++t) {
     (void)hipFree(h->traits[t].loci);
@@ -906,6 +912,12 @@ extern "C" int gnx_set_defer_crossover(gnx_state* h, int32_t on) {
 }
 
 extern "C" int64_t gnx_last_crossover_births(gnx_state* h) { return h->last_xo_births; }
+
+extern "C" int gnx_set_crossover_overlap(gnx_state* h, int32_t whole_step) {
+  GNXCHK(gnx_xo_join(h));
+  h->xo_sort_waits = whole_step == 0;
+  return 0;
+}
 
 // occupied slots, ghosts of a tiled step included (gnx_counts reports the tile's own)
 extern "C" int64_t gnx_n_slots(gnx_state* h) { return h->N; }

@@ -159,6 +159,7 @@ struct gnx_state {
   int32_t* n_jobs_dev[2]{};
   int jobs_cur = 0;
   hipEvent_t ev_jobs = nullptr, ev_xo_done[2]{};
+  hipEvent_t ev_counts = nullptr;   // the step's counts have reached pinned host memory
   bool xo_inflight[2]{};         // ev_xo_done[k] recorded and not yet joined
   bool xo_running = false;       // a crossover may still be running on stream2
   // How the deferred crossover shares the chip with the next step's small kernels
@@ -264,6 +265,14 @@ struct gnx_state {
   bool counts_init = false;
   double* red = nullptr;             // small reduction scratch [8]
 
+  // block counts / offsets of the compactions (2 arrays of blk_stride entries each) and
+  // their totals: cnt_dev[0] survivors, [1] rows freed, [2] survivors older than this
+  // step's offspring
+  int32_t* blk_cnt = nullptr;
+  int32_t* blk_off = nullptr;
+  int blk_stride = 0;
+  int32_t* cnt_dev = nullptr;        // [4]
+
   // pinned host scratch for read-backs
   int64_t* h_pin = nullptr;          // [16]
   int64_t* h_pin_dev = nullptr;      // the same memory as the device sees it
@@ -352,6 +361,12 @@ int gnx_l_death_probs(gnx_state* h, bool with_selection);
 int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_out);
 int gnx_l_spatial_diff(gnx_state* h, double* mean, double* sd);
 int gnx_l_gather_genomes(gnx_state* h, int64_t n, const int64_t* d_slots, uint64_t* d_out);
+
+// look-back-free compaction (gnx_compact.h): block counts cnt[k * blk_stride + b] ->
+// exclusive block offsets off[...], totals (and the flagged items below `mark`) to
+// out[0..2] on the device and to pinned host memory
+int gnx_block_scan(gnx_state* h, int K, int64_t n_items, const int32_t* cnt, int32_t* off,
+                   int64_t mark, const int32_t* flags0, int32_t* out, int64_t* host);
 
 // rocPRIM wrappers (gnx_prim.hip)
 int gnx_prim_sort_bytes(size_t n, int bits, size_t* bytes);

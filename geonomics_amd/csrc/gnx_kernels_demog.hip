@@ -12,6 +12,8 @@
 // All density arithmetic is f64 so it matches the numpy oracle to ~1e-12.
 #include "gnx_internal.h"
 #include "gnx_rng.h"
+#include "gnx_compact.h"
+#include "gnx_xo.h"
 
 #define BIN_BLOCKS 512
 
@@ -161,6 +163,59 @@ int gnx_l_bins(gnx_state* h, int64_t n, const float* d_x, const float* d_y, cons
   return 0;
 }
 
+// One workgroup does the whole lattice of one density field: node values from the bins,
+// then the three families of natural-spline second derivatives (rows of V, columns of V,
+// rows of My), with workgroup barriers in between - four launches of a few microseconds
+// of work each otherwise (the lattice is ~(2 dim / ww)^2 = 41^2 nodes by default).
+__device__ __forceinline__ void spline_line(int J, int64_t base, int64_t stride, double h,
+                                            const double* cp, const double* V, double* M) {
+  M[base] = 0.0;
+  M[base + (int64_t)(J - 1) * stride] = 0.0;
+  if (J <= 2) return;
+  const double s = 6.0 / (h * h);
+  double dprev = 0.0;
+  for (int k = 1; k <= J - 2; ++k) {
+    double d = s * (V[base + (k - 1) * stride] - 2.0 * V[base + k * stride] +
+                    V[base + (k + 1) * stride]);
+    double denom = (k == 1) ? 4.0 : 4.0 - cp[k - 1];
+    double dp = (k == 1) ? d / denom : (d - dprev) / denom;
+    M[base + k * stride] = dp;
+    dprev = dp;
+  }
+  for (int k = J - 3; k >= 1; --k)
+    M[base + k * stride] -= cp[k] * M[base + (k + 1) * stride];
+}
+
+__global__ void __launch_bounds__(256)
+k_lattice(int Jx, int Jy, int nbx, const int32_t* bins, const double* areas, double hww,
+          const double* cp, double* C) {
+  const int nn = Jx * Jy;
+  double* V = C;
+  double* Mx = C + nn;
+  double* My = C + 2 * (int64_t)nn;
+  double* Mxy = C + 3 * (int64_t)nn;
+  if (bins) {
+    for (int idx = threadIdx.x; idx < nn; idx += blockDim.x) {
+      const int i = idx / Jx, j = idx - i * Jx;
+      long long cnt = 0;
+      for (int di = -1; di <= 0; ++di)
+        for (int dj = -1; dj <= 0; ++dj) {
+          const int ii = i + di, jj = j + dj;
+          if (ii >= 0 && jj >= 0) cnt += bins[ii * nbx + jj];
+        }
+      V[idx] = (double)cnt / areas[idx];
+    }
+  }
+  __syncthreads();
+  for (int line = threadIdx.x; line < Jy; line += blockDim.x)
+    spline_line(Jx, (int64_t)line * Jx, 1, hww, cp, V, Mx);
+  for (int line = threadIdx.x; line < Jx; line += blockDim.x)
+    spline_line(Jy, line, Jx, hww, cp, V, My);
+  __syncthreads();
+  for (int line = threadIdx.x; line < Jy; line += blockDim.x)
+    spline_line(Jx, (int64_t)line * Jx, 1, hww, cp, My, Mxy);
+}
+
 // node densities (from bins, or given directly) and the spline coefficients
 int gnx_l_spline(gnx_state* h, const int32_t* d_bins, GnxSpline* spl,
                  const double* d_nodes_override) {
@@ -170,7 +225,15 @@ int gnx_l_spline(gnx_state* h, const int32_t* d_bins, GnxSpline* spl,
   if (d_nodes_override)
     HIPCHK(hipMemcpyAsync(V, d_nodes_override, nn * sizeof(double), hipMemcpyDeviceToDevice,
                           h->stream));
-  else
+  if (nn <= 65536) {
+    hipLaunchKernelGGL(k_lattice, dim3(1), dim3(256), 0, h->stream, L.Jx, L.Jy, L.nbx,
+                       d_nodes_override ? nullptr : d_bins, L.areas, L.hww, L.cprime, V);
+    HIPCHK(hipGetLastError());
+    spl->valid = true;
+    return 0;
+  }
+  // very fine lattices (tiny density_grid_window_width): one launch per stage
+  if (!d_nodes_override)
     hipLaunchKernelGGL(k_nodes, dim3(gnx_grid(nn, 128)), dim3(128), 0, h->stream, L.Jx, L.Jy, L.nbx,
                        1, d_bins, L.areas, V);
   double* Mx = V + nn;
@@ -391,55 +454,146 @@ int gnx_l_death_probs(gnx_state* h, bool with_selection) {
 // ---------------------------------------------------------------- mortality + compaction
 // _do_mortality (ops/demography.py:175-180): dead ~ Bernoulli(p_death).  Ghosts
 // (halo copies, tiled runs) are dropped here without counting as deaths.
-__global__ void k_alive(int64_t N, const double* p_death, const uint8_t* dead_in,
-                        const int64_t* id, const uint8_t* ghost, const int32_t* grow,
-                        long long step, unsigned long long seed, int32_t* alive,
-                        int32_t* dead_row) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  bool dead;
-  const bool g = ghost[i] != 0;
-  if (g) {
-    dead = true;
-  } else if (dead_in) {
-    dead = dead_in[i] != 0;
-  } else {
-    uint4 r = gnx_rand4(seed, (unsigned long long)id[i], step, OP_DEATH, 0);
-    dead = (double)gnx_u01(r.x) < p_death[i];
+// Compaction without look-back scans (gnx_compact.h): k_alive decides and counts per
+// block, one workgroup scans the block counts, k_xo_jobs_surv / k_compact recompute
+// the in-block ranks from the stored flags.
+__global__ void __launch_bounds__(256)
+k_alive(int64_t N, const double* p_death, const uint8_t* dead_in, const int64_t* id,
+        const uint8_t* ghost, const int32_t* grow, long long step, unsigned long long seed,
+        int32_t* alive, int32_t* dead_row, int32_t* cnt, int stride) {
+  __shared__ int lds[16];
+  const int64_t base = (int64_t)blockIdx.x * GNX_CB;
+  bool fa[4], fd[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    fa[r] = fd[r] = false;
+    if (i < N) {
+      bool dead;
+      const bool g = ghost[i] != 0;
+      if (g) {
+        dead = true;
+      } else if (dead_in) {
+        dead = dead_in[i] != 0;
+      } else {
+        uint4 rr = gnx_rand4(seed, (unsigned long long)id[i], step, OP_DEATH, 0);
+        dead = (double)gnx_u01(rr.x) < p_death[i];
+      }
+      fa[r] = !dead;
+      // rows to return to the free stack (offspring that die before their deferred
+      // crossover never had one; ghosts own none)
+      fd[r] = dead && !g && grow[i] >= 0;
+      alive[i] = fa[r] ? 1 : 0;
+      dead_row[i] = fd[r] ? 1 : 0;
+    }
   }
-  alive[i] = dead ? 0 : 1;
-  // rows to return to the free stack (offspring that die before their deferred
-  // crossover never had one; ghosts own none)
-  dead_row[i] = (dead && !g && grow[i] >= 0) ? 1 : 0;
+  int rank[4], ta, td;
+  gnx_block_ranks(fa, rank, ta, lds);
+  gnx_block_ranks(fd, rank, td, lds);
+  if (threadIdx.x == 0) {
+    cnt[blockIdx.x] = ta;
+    cnt[stride + blockIdx.x] = td;
+  }
+}
+
+// Crossover jobs of the surviving offspring (deferred mode): offspring k = slot first + k
+// is alive iff alive[first + k]; its rank among the surviving offspring picks its row from
+// the top of the free stack.  Offspring that died at age 0 never get a row.
+// cnts[0] = survivors in all, cnts[2] = survivors older than this step's offspring.
+__global__ void __launch_bounds__(256)
+k_xo_jobs_surv(int64_t N, int64_t first, int32_t* __restrict__ grow,
+               const int32_t* __restrict__ alive, const int32_t* __restrict__ blk_off,
+               const int32_t* __restrict__ cnts, const int32_t* __restrict__ off_parent,
+               const int32_t* __restrict__ off_keys, const uint8_t* __restrict__ off_start,
+               const int32_t* __restrict__ free_rows, int64_t n_free,
+               GnxXoJob* __restrict__ jobs, int32_t* __restrict__ n_jobs) {
+  __shared__ int lds[16];
+  const int64_t b = first / GNX_CB + blockIdx.x;
+  const int64_t base = b * GNX_CB;
+  const int32_t s0 = cnts[2];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *n_jobs = 2 * (cnts[0] - s0);
+  bool fa[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    fa[r] = i < N && alive[i] != 0;
+  }
+  int rank[4], tot;
+  gnx_block_ranks(fa, rank, tot, lds);
+  const int32_t boff = blk_off[b];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    if (!fa[r] || i < first) continue;
+    const int64_t k = i - first;
+    const int32_t j = boff + rank[r] - s0;
+    const int32_t row = free_rows[n_free - 1 - j];
+    grow[i] = row;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      GnxXoJob jb;
+      jb.prow = grow[off_parent[2 * k + p]];      // parents are older: slots < first
+      jb.dst = row * 2 + p;
+      jb.key = off_keys[2 * k + p];
+      jb.start = off_start[2 * k + p];
+      jobs[2 * j + p] = jb;
+    }
+  }
 }
 
 // Stable compaction of the SoA (survivors keep their relative order); genome
 // rows are NOT moved: the dead's rows are pushed on the free stack.
-__global__ void k_compact(int64_t N, int64_t cap, const int32_t* alive, const int32_t* scan,
-                          const int32_t* dead_row, const int32_t* dscan, GnxSoA a, GnxSoA b,
-                          int n_layers, int n_traits, int tbw, int32_t* free_rows, int64_t n_free,
-                          int has_rows, int64_t xo_first, int64_t xo_B) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  // deferred crossover: the surviving offspring [xo_first, xo_first + xo_B) have just
-  // popped one row each from the top of the free stack (k_xo_jobs_surv)
-  if (xo_B > 0) n_free -= scan[xo_first + xo_B] - scan[xo_first];
-  if (alive[i]) {
-    int64_t k = scan[i];              // survivors before i
-    b.x[k] = a.x[i];
-    b.y[k] = a.y[i];
-    b.age[k] = a.age[i];
-    b.sex[k] = a.sex[i];
-    b.id[k] = a.id[i];
-    b.fit[k] = a.fit[i];
-    b.grow[k] = a.grow[i];
-    b.ghost[k] = 0;
-    for (int l = 0; l < n_layers; ++l) b.e[(int64_t)l * cap + k] = a.e[(int64_t)l * cap + i];
-    for (int t = 0; t < n_traits; ++t) b.z[(int64_t)t * cap + k] = a.z[(int64_t)t * cap + i];
-    for (int w = 0; w < tbw; ++w) b.tb[k * tbw + w] = a.tb[i * tbw + w];
-  } else if (has_rows && dead_row[i]) {
-    free_rows[n_free + dscan[i]] = a.grow[i];
+__global__ void __launch_bounds__(256)
+k_compact(int64_t N, int64_t cap, const int32_t* alive, const int32_t* dead_row,
+          const int32_t* blk_off, int stride, const int32_t* cnts, GnxSoA a, GnxSoA b,
+          int n_layers, int n_traits, int tbw, int32_t* free_rows, int64_t n_free, int has_rows,
+          int xo) {
+  __shared__ int lds[16];
+  const int64_t base = (int64_t)blockIdx.x * GNX_CB;
+  bool fa[4], fd[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    fa[r] = i < N && alive[i] != 0;
+    fd[r] = i < N && dead_row[i] != 0;
   }
+  int ra[4], rd[4], ta, td;
+  gnx_block_ranks(fa, ra, ta, lds);
+  gnx_block_ranks(fd, rd, td, lds);
+  // deferred crossover: the surviving offspring have just popped one row each from the
+  // top of the free stack (k_xo_jobs_surv)
+  if (xo) n_free -= cnts[0] - cnts[2];
+  const int32_t oa = blk_off[blockIdx.x], od = blk_off[stride + blockIdx.x];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    if (fa[r]) {
+      const int64_t k = oa + ra[r];            // survivors before i
+      b.x[k] = a.x[i];
+      b.y[k] = a.y[i];
+      b.age[k] = a.age[i];
+      b.sex[k] = a.sex[i];
+      b.id[k] = a.id[i];
+      b.fit[k] = a.fit[i];
+      b.grow[k] = a.grow[i];
+      b.ghost[k] = 0;
+      for (int l = 0; l < n_layers; ++l) b.e[(int64_t)l * cap + k] = a.e[(int64_t)l * cap + i];
+      for (int t = 0; t < n_traits; ++t) b.z[(int64_t)t * cap + k] = a.z[(int64_t)t * cap + i];
+      for (int w = 0; w < tbw; ++w) b.tb[k * tbw + w] = a.tb[i * tbw + w];
+    } else if (has_rows && fd[r]) {
+      free_rows[n_free + od + rd[r]] = a.grow[i];
+    }
+  }
+}
+
+void gnx_launch_xo_jobs_surv(gnx_state* h, int64_t first_slot, const int32_t* d_alive,
+                             const int32_t* d_blk_off, int buf) {
+  const int64_t N = h->N;
+  const int nbj = (int)((N - 1) / GNX_CB - first_slot / GNX_CB + 1);
+  hipLaunchKernelGGL(k_xo_jobs_surv, dim3(nbj), dim3(256), 0, h->stream, N, first_slot,
+                     h->soa[h->cur].grow, d_alive, d_blk_off, h->cnt_dev, h->off_parent,
+                     h->off_keys, h->off_start, h->free_rows, h->n_free, (GnxXoJob*)h->jobs[buf],
+                     h->n_jobs_dev[buf]);
 }
 
 int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_out) {
@@ -448,39 +602,40 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
   if (N == 0) return 0;
   const gnx_config& c = h->cfg;
   GnxSoA a = h->soa[h->cur], b = h->soa[h->cur ^ 1];
-  gnx_time_begin(h);
-  hipLaunchKernelGGL(k_alive, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, h->p_death,
-                     d_dead_inject, a.id, a.ghost, a.grow, h->step, c.seed, h->flag, h->flag2);
-  HIPCHK(hipMemsetAsync(h->flag + N, 0, sizeof(int32_t), h->stream));
-  HIPCHK(hipMemsetAsync(h->flag2 + N, 0, sizeof(int32_t), h->stream));
-  GNXCHK(gnx_prim_scan(h->scan_tmp, h->scan_tmp_bytes, h->flag, h->scan, (size_t)N + 1,
-                       h->stream));
-  GNXCHK(gnx_prim_scan(h->scan_tmp, h->scan_tmp_bytes, h->flag2, h->boff, (size_t)N + 1,
-                       h->stream));
-  gnx_time_end(h, GNX_K_COMPACT, 0.0);
-  int has_rows = (h->genomes_assigned && c.L > 0) ? 1 : 0;
-  // deferred crossover of this step's births: rows and jobs for the survivors, the kernel
-  // itself on stream2 (it runs on under the compaction and the next step's small kernels)
+  const int nb = (int)((N + GNX_CB - 1) / GNX_CB);
   const bool xo = h->xo_deferred;
   const int64_t xo_first = h->xo_first, xo_B = xo ? h->xo_B : 0;
+  gnx_time_begin(h);
+  hipLaunchKernelGGL(k_alive, dim3(nb), dim3(256), 0, h->stream, N, h->p_death, d_dead_inject,
+                     a.id, a.ghost, a.grow, h->step, c.seed, h->flag, h->flag2, h->blk_cnt,
+                     h->blk_stride);
+  // survivors, rows freed and (deferred crossover) the survivors older than this step's
+  // offspring: block offsets on the device, totals also straight into pinned host memory
+  GNXCHK(gnx_block_scan(h, 2, N, h->blk_cnt, h->blk_off, xo ? xo_first : -1, h->flag, h->cnt_dev,
+                        h->h_pin_dev));
+  gnx_time_end(h, GNX_K_COMPACT, 0.0);
+  // the host only needs the counts: it waits for the scan, not for the compaction, and
+  // enqueues the next step's first kernels while the compaction still runs
+  HIPCHK(hipEventRecord(h->ev_counts, h->stream));
+  int has_rows = (h->genomes_assigned && c.L > 0) ? 1 : 0;
+  // deferred crossover of this step's births: rows and jobs for the survivors, the kernel
+  // itself on stream2 (it runs on under the compaction and the next step's movement)
   if (xo) {
     h->xo_deferred = false;
-    GNXCHK(gnx_l_crossover_survivors(h, xo_first, xo_B, h->flag, h->scan));
+    GNXCHK(gnx_l_crossover_survivors(h, xo_first, xo_B, h->flag, h->blk_off));
   }
   gnx_time_begin(h);
-  hipLaunchKernelGGL(k_compact, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, c.cap_inds,
-                     h->flag, h->scan, h->flag2, h->boff, a, b, c.n_layers, c.n_traits,
-                     a.tb ? 2 * h->TW : 0, h->free_rows, h->n_free, has_rows, xo_first, xo_B);
-  // survivors, rows freed and (deferred crossover) the survivors among the offspring
-  GNXCHK(gnx_publish(h, 0, h->scan + N, h->boff + N, xo ? h->scan + xo_first : nullptr,
-                     xo ? h->scan + xo_first + xo_B : nullptr));
+  hipLaunchKernelGGL(k_compact, dim3(nb), dim3(256), 0, h->stream, N, c.cap_inds, h->flag,
+                     h->flag2, h->blk_off, h->blk_stride, h->cnt_dev, a, b, c.n_layers, c.n_traits,
+                     a.tb ? 2 * h->TW : 0, h->free_rows, h->n_free, has_rows, xo ? 1 : 0);
   gnx_time_end(h, GNX_K_COMPACT, (double)N * (24.0 + 2.0 * (34.0 + 4.0 * c.n_layers +
                                                              4.0 * c.n_traits + 16.0 * h->TW)));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventSynchronize(h->ev_counts));
   const int64_t survivors = h->h_pin[0];
   const int64_t rows_freed = h->h_pin[1];
   if (xo) {
-    const int64_t S = h->h_pin[3] - h->h_pin[2];
+    const int64_t S = survivors - h->h_pin[2];
     h->n_free -= S;
     h->last_xo_births = S;
     if (h->profiling) h->timers[GNX_K_CROSSOVER].bytes += (double)S * gnx_xo_bytes_per_birth(h);

@@ -10,6 +10,7 @@
 #include "gnx_internal.h"
 #include "gnx_rng.h"
 #include "gnx_xo.h"
+#include "gnx_tb.h"
 
 // ---------------------------------------------------------------- crossover jobs
 // Every birth of the step at once: child k takes the k-th row from the top of the free
@@ -37,34 +38,10 @@ __global__ void k_xo_jobs_all(int64_t B, int64_t first, int32_t* __restrict__ gr
   }
 }
 
-// Survivors only (deferred mode): offspring k is alive iff alive[first + k]; its rank
-// among the surviving offspring (scan = exclusive scan of alive) picks its row from the
-// top of the free stack.  Offspring that died at age 0 never get a row.
-__global__ void k_xo_jobs_surv(int64_t B, int64_t first, int32_t* __restrict__ grow,
-                               const int32_t* __restrict__ alive,
-                               const int32_t* __restrict__ scan,
-                               const int32_t* __restrict__ off_parent,
-                               const int32_t* __restrict__ off_keys,
-                               const uint8_t* __restrict__ off_start,
-                               const int32_t* __restrict__ free_rows, int64_t n_free,
-                               GnxXoJob* __restrict__ jobs, int32_t* __restrict__ n_jobs) {
-  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int32_t s0 = scan[first];
-  if (k == 0) *n_jobs = 2 * (scan[first + B] - s0);
-  if (k >= B || !alive[first + k]) return;
-  const int32_t j = scan[first + k] - s0;
-  const int32_t row = free_rows[n_free - 1 - j];
-  grow[first + k] = row;
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    GnxXoJob jb;
-    jb.prow = grow[off_parent[2 * k + p]];      // parents are older: slots < first
-    jb.dst = row * 2 + p;
-    jb.key = off_keys[2 * k + p];
-    jb.start = off_start[2 * k + p];
-    jobs[2 * j + p] = jb;
-  }
-}
+// (the job builder of the deferred mode, k_xo_jobs_surv, sits with the mortality kernels in
+// gnx_kernels_demog.hip: it shares their block-rank compaction)
+void gnx_launch_xo_jobs_surv(gnx_state* h, int64_t first_slot, const int32_t* d_alive,
+                             const int32_t* d_blk_off, int buf);
 
 template <int U>
 static void xo_launch_sparse(gnx_state* h, hipStream_t st, int grid, int buf, bool nt) {
@@ -193,10 +170,8 @@ int gnx_l_crossover_survivors(gnx_state* h, int64_t first_slot, int64_t B, const
   GNXCHK(gnx_xo_launch_pending(h));              // at most one set of jobs waits
   const int buf = h->jobs_cur;
   GNXCHK(xo_wait_buf(h, h->stream, buf));       // the crossover two steps back read this buffer
-  GnxSoA s = h->soa[h->cur];
-  hipLaunchKernelGGL(k_xo_jobs_surv, dim3(gnx_grid(B, 256)), dim3(256), 0, h->stream, B, first_slot,
-                     s.grow, d_alive, d_scan, h->off_parent, h->off_keys, h->off_start,
-                     h->free_rows, h->n_free, (GnxXoJob*)h->jobs[buf], h->n_jobs_dev[buf]);
+  gnx_launch_xo_jobs_surv(h, first_slot, d_alive, d_scan, buf);
+  HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(h->ev_jobs, h->stream));
   h->xo_ready_buf = buf;
   h->xo_ready_jobs = 2 * B;
@@ -286,9 +261,8 @@ int gnx_l_tb_from_rows(gnx_state* h, int64_t first, int64_t n, const int32_t* d_
   return 0;
 }
 
-// tb of offspring k, homologue p = the gamete of parent p: at selected locus e the gamete
-// copies the parent's homologue path_sel[key][e] XOR start (ops/mating.py:165-168 at these
-// loci only).  A ghost parent's gamete (tiled run) is filled in once it has arrived.
+// tb of offspring k, homologue p = the gamete of parent p (gnx_gamete_tb).  A ghost
+// parent's gamete (tiled run) is filled in once it has arrived.
 __global__ void k_newborn_tb(int64_t B, int64_t first, int TW, const int32_t* off_parent,
                              const int32_t* off_keys, const uint8_t* off_start,
                              const uint8_t* ghost, const u64* path_sel, u64* tb) {
@@ -298,13 +272,9 @@ __global__ void k_newborn_tb(int64_t B, int64_t first, int TW, const int32_t* of
   if (ghost[ps]) return;
   const int64_t k = t >> 1;
   const int p = (int)(t & 1);
-  const u64 s = off_start[t] ? ~0ull : 0ull;
-  const u64* m = path_sel + (int64_t)off_keys[t] * TW;
-  for (int w = 0; w < TW; ++w) {
-    const u64 mm = m[w] ^ s;
-    const u64 a = tb[(ps * 2 + 0) * TW + w], b = tb[(ps * 2 + 1) * TW + w];
-    tb[((first + k) * 2 + p) * TW + w] = (a & ~mm) | (b & mm);
-  }
+  gnx_gamete_tb(TW, (const uint64_t*)tb + ps * 2 * TW,
+                (const uint64_t*)path_sel + (int64_t)off_keys[t] * TW, off_start[t] != 0,
+                (uint64_t*)tb + ((first + k) * 2 + p) * TW);
 }
 
 int gnx_l_newborn_tb(gnx_state* h, int64_t first_slot, int64_t B) {
@@ -318,32 +288,14 @@ int gnx_l_newborn_tb(gnx_state* h, int64_t first_slot, int64_t B) {
 }
 
 // ---------------------------------------------------------------- phenotype
-// ops/selection.py:22-48: gt_l = (g[l,0] + g[l,1]) / 2 at the trait's loci
-// (x (1 + dom_l), capped at 1, if any dominance); z = 0.5 + sum gt_l alpha_l for
-// polygenic traits, z = gt_0 for monogenic ones.  f64 accumulate, f32 store.  The
-// alleles come from the compact table (trait loci are its first n_tl entries,
-// trait-major).
+// (gnx_phenotype_tb) of slots [first, first + n)
 __global__ void k_phenotype(int64_t first, int64_t n, int64_t cap, int TW, const u64* tb,
                             GnxTraitTab T, const uint8_t* dom, float* z) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const int64_t slot = first + k;
-  const u64* t0 = tb + (slot * 2 + 0) * TW;
-  const u64* t1 = t0 + TW;
-  int e = 0;
-  for (int t = 0; t < T.n_traits; ++t) {
-    const int nl = T.n_loci[t];
-    double acc = 0.0, g0 = 0.0;
-    for (int j = 0; j < nl; ++j, ++e) {
-      const int a = (int)((t0[e >> 6] >> (e & 63)) & 1ull);
-      const int b = (int)((t1[e >> 6] >> (e & 63)) & 1ull);
-      double gt = 0.5 * (double)(a + b);
-      if (dom) gt = fmin(gt * (1.0 + (double)dom[T.loci[t][j]]), 1.0);
-      if (j == 0) g0 = gt;
-      acc = acc + gt * T.alpha[t][j];
-    }
-    z[(int64_t)t * cap + slot] = (float)(nl > 1 ? 0.5 + acc : g0);
-  }
+  const uint64_t* t0 = (const uint64_t*)tb + (slot * 2 + 0) * TW;
+  gnx_phenotype_tb(t0, t0 + TW, T, dom, cap, slot, z);
 }
 
 int gnx_l_phenotype(gnx_state* h, int64_t first_slot, int64_t n) {

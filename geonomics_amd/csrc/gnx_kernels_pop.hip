@@ -3,6 +3,8 @@
 // offspring records.  gfx950 only (64-wide wavefronts are assumed).
 #include "gnx_internal.h"
 #include "gnx_rng.h"
+#include "gnx_compact.h"
+#include "gnx_tb.h"
 
 // ---------------------------------------------------------------- helpers
 __device__ __forceinline__ int wave_min_i(int v) {
@@ -322,12 +324,13 @@ __device__ __forceinline__ int gnx_cell_of(float x, float y, double inv_cs, int 
 // CANONICAL (it does not depend on the order the individuals were stored in, nor
 // on how the landscape is tiled), which is what lets the mate search address
 // candidates by index
+// (the id takes the low idbits bits - every resident id is <= max_id < 2^idbits - and the
+// cell the bits above, so that the radix sort passes over idbits + cell bits only)
 __global__ void k_keys(int64_t N, const float* x, const float* y, const int64_t* id,
-                       double inv_cs, int ncx, int ncy, uint64_t* key, int32_t* idx) {
+                       double inv_cs, int ncx, int ncy, int idbits, uint64_t* key, int32_t* idx) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  key[i] = ((uint64_t)gnx_cell_of(x[i], y[i], inv_cs, ncx, ncy) << 32) |
-           (uint64_t)(uint32_t)id[i];
+  key[i] = ((uint64_t)gnx_cell_of(x[i], y[i], inv_cs, ncx, ncy) << idbits) | (uint64_t)id[i];
   idx[i] = (int32_t)i;
 }
 
@@ -356,14 +359,22 @@ __global__ void k_permute(int64_t N, int64_t cap, const int32_t* perm, GnxSoA a,
 }
 
 // cell_start[c] = first sorted slot whose key >= c; cell_start[ncells] = N
-__global__ void k_cell_bounds(int64_t N, const uint64_t* key, int32_t* cell_start, int ncells) {
+__global__ void k_cell_bounds(int64_t N, const uint64_t* key, int idbits, int32_t* cell_start,
+                              int ncells) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  int k = (int)(key[i] >> 32);
-  int prev = (i == 0) ? -1 : (int)(key[i - 1] >> 32);
+  int k = (int)(key[i] >> idbits);
+  int prev = (i == 0) ? -1 : (int)(key[i - 1] >> idbits);
   for (int c = prev + 1; c <= k; ++c) cell_start[c] = (int32_t)i;
   if (i == N - 1)
     for (int c = k + 1; c <= ncells; ++c) cell_start[c] = (int32_t)N;
+}
+
+// bits that hold every resident id (ids are handed out upwards from max_id)
+static int gnx_id_bits(const gnx_state* h) {
+  int b = 1;
+  while (b < 40 && (h->max_id >> b) != 0) ++b;
+  return b;
 }
 
 // Sort of the whole SoA by (hash cell, id); cell size >= mating radius.
@@ -374,18 +385,20 @@ int gnx_l_sort_by_cell(gnx_state* h) {
   if (h->xo_sort_waits) GNXCHK(gnx_xo_wait_inflight(h));   // the radix sort runs alone
   const gnx_config& c = h->cfg;
   GnxSoA a = h->soa[h->cur], b = h->soa[h->cur ^ 1];
+  const int idbits = gnx_id_bits(h);
   gnx_time_begin(h);
   hipLaunchKernelGGL(k_keys, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, a.x, a.y, a.id,
-                     h->inv_cs, h->ncx, h->ncy, h->key64[0], h->perm[0]);
+                     h->inv_cs, h->ncx, h->ncy, idbits, h->key64[0], h->perm[0]);
   GNXCHK(gnx_prim_sort64_bits(h->sort64_tmp, h->sort64_tmp_bytes, h->key64[0], h->key64[1],
-                              h->perm[0], h->perm[1], (size_t)N, 32 + h->key_bits, h->stream));
+                              h->perm[0], h->perm[1], (size_t)N, idbits + h->key_bits,
+                              h->stream));
   gnx_time_end(h, GNX_K_SORT, (double)N * 40.0);
   gnx_time_begin(h);
   hipLaunchKernelGGL(k_permute, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, c.cap_inds,
                      h->perm[1], a, b, c.n_layers, c.n_traits, a.tb ? 2 * h->TW : 0,
                      gnx_pair_seed(c.seed, h->step), h->tag, (uint4*)h->cand);
   hipLaunchKernelGGL(k_cell_bounds, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N,
-                     h->key64[1], h->cell_start, h->ncx * h->ncy);
+                     h->key64[1], idbits, h->cell_start, h->ncx * h->ncy);
   gnx_time_end(h, GNX_K_PERMUTE,
                (double)N * 2.0 * (33.0 + 4.0 * c.n_layers + 4.0 * c.n_traits + 16.0 * h->TW));
   HIPCHK(hipGetLastError());
@@ -550,6 +563,7 @@ k_find_mates(FocalP fp, GnxSoA s, const uint4* __restrict__ cand, double inv_cs,
     return;
   }
   // NEAREST / INVERSE: FM_LANES adjacent lanes per listed focal individual
+  const double cs = 1.0 / inv_cs;
   for (int t = tid; t < n_list * FM_LANES; t += 256) {
     const int i = list[t / FM_LANES];
     const int sub = t % FM_LANES;
@@ -562,6 +576,50 @@ k_find_mates(FocalP fp, GnxSoA s, const uint4* __restrict__ cand, double inv_cs,
     const int lo = max(cx - 1, 0), hi = min(cx + 1, ncx - 1);
     unsigned long long best = ~0ull;
     int best_slot = -1;
+    if (MODE == GNX_MATE_NEAREST) {
+      // own cell first, then a neighbour cell only if its rectangle comes closer than the
+      // best candidate so far (a clumped population holds thousands of candidates in the
+      // 3 x 3 block, nearly all of them farther than the nearest one of the own cell)
+      for (int q = 0; q < 9; ++q) {
+        const int ccx = q == 0 ? cx : (cx - 1 + (q - 1 + (q > 4 ? 1 : 0)) % 3);
+        const int ccy = q == 0 ? cy : (cy - 1 + (q - 1 + (q > 4 ? 1 : 0)) / 3);
+        if (ccx < 0 || ccx >= ncx || ccy < 0 || ccy >= ncy) continue;
+        if (q > 0) {
+          // distance from the focal individual to the cell's rectangle, shrunk a little so
+          // that rounding can never hide a candidate at equal distance
+          const double gx = fmax(fmax(ccx * cs - (double)fx, (double)fx - (ccx + 1) * cs), 0.0);
+          const double gy = fmax(fmax(ccy * cs - (double)fy, (double)fy - (ccy + 1) * cs), 0.0);
+          const float dmin2 = (float)((gx * gx + gy * gy) * 0.99999);
+          const float lim = best_slot >= 0 ? __uint_as_float((unsigned int)(best >> 32)) : r2;
+          if (dmin2 > lim) continue;                       // uniform over the FM_LANES lanes
+        }
+        const int st = cell_start[ccy * ncx + ccx];
+        const int e = cell_start[ccy * ncx + ccx + 1];
+        for (int j = st + sub; j < e; j += FM_LANES) {
+          const uint4 c = cand[j];
+          const float dx = __uint_as_float(c.x) - fx, dy = __uint_as_float(c.y) - fy;
+          const float d2 = dx * dx + dy * dy;
+          const bool ok = (d2 <= r2) & (j != i);
+          const unsigned long long comp =
+              ok ? (((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)c.w)
+                 : ~0ull;
+          const bool better = comp < best;
+          best = better ? comp : best;
+          best_slot = better ? j : best_slot;
+        }
+        // the lanes of the group agree on the best so far before the next cell's test
+#pragma unroll
+        for (int m = 1; m < FM_LANES; m <<= 1) {
+          const unsigned long long ob = __shfl_xor(best, m);
+          const int os = __shfl_xor(best_slot, m);
+          const bool take = ob < best;
+          best = take ? ob : best;
+          best_slot = take ? os : best_slot;
+        }
+      }
+      if (sub == 0) mate[i] = best_slot;
+      continue;
+    }
     for (int ry = max(cy - 1, 0); ry <= min(cy + 1, ncy - 1); ++ry) {
       const int st = cell_start[ry * ncx + lo];
       const int e = cell_start[ry * ncx + hi + 1];
@@ -569,15 +627,9 @@ k_find_mates(FocalP fp, GnxSoA s, const uint4* __restrict__ cand, double inv_cs,
         const uint4 c = cand[j];
         const float dx = __uint_as_float(c.x) - fx, dy = __uint_as_float(c.y) - fy;
         const float d2 = dx * dx + dy * dy;
-        bool ok = (d2 <= r2) & (j != i);
-        unsigned int k32;
-        if (MODE == GNX_MATE_NEAREST) {
-          k32 = __float_as_uint(d2);
-        } else {
-          ok = ok & (d2 > 0.f);
-          const float kf = -logf(gnx_u01(gnx_pair_key(ftag, c.z))) / (r - sqrtf(d2));
-          k32 = __float_as_uint(kf);
-        }
+        bool ok = (d2 <= r2) & (j != i) & (d2 > 0.f);
+        const float kf = -logf(gnx_u01(gnx_pair_key(ftag, c.z))) / (r - sqrtf(d2));
+        const unsigned int k32 = __float_as_uint(kf);
         const unsigned long long comp =
             ok ? (((unsigned long long)k32 << 32) | (unsigned long long)c.w) : ~0ull;
         const bool better = comp < best;
@@ -599,72 +651,95 @@ k_find_mates(FocalP fp, GnxSoA s, const uint4* __restrict__ cand, double inv_cs,
 }
 
 // Bernoulli(b) thinning (structs/species.py:2210-2214), sex filter
-// (ops/mating.py:41-55), reproductive-age filter (:79-104).
-__global__ void k_pair_flags(int64_t N, const int32_t* focal, const int32_t* mate,
-                             const uint8_t* keep_in, GnxSoA s, float b, int sexed, int ra_f,
-                             int ra_m, long long step, unsigned long long seed, int32_t* flag) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  int m = mate[i];
-  int f = 0;
-  if (m >= 0) {
-    const int fo = focal ? focal[i] : (int)i;
-    bool keep;
-    if (keep_in) {
-      keep = keep_in[i] != 0;
-    } else {
-      uint4 r = gnx_rand4(seed, (unsigned long long)s.id[i], step, OP_PAIR_KEEP, 0);
-      keep = gnx_u01(r.x) < b;
+// (ops/mating.py:41-55), reproductive-age filter (:79-104) of the pair (i, mate[i]).
+struct PairP {
+  int64_t N;
+  const int32_t* focal;
+  const int32_t* mate;
+  const uint8_t* keep_in;
+  float b;
+  int sexed, ra_f, ra_m, dedup;
+  long long step;
+  unsigned long long seed;
+};
+
+__device__ __forceinline__ bool pair_ok(const PairP& P, const GnxSoA& s, int64_t i) {
+  const int m = P.mate[i];
+  if (m < 0) return false;
+  const int fo = P.focal ? P.focal[i] : (int)i;
+  bool keep;
+  if (P.keep_in) {
+    keep = P.keep_in[i] != 0;
+  } else {
+    uint4 r = gnx_rand4(P.seed, (unsigned long long)s.id[i], P.step, OP_PAIR_KEEP, 0);
+    keep = gnx_u01(r.x) < P.b;
+  }
+  bool ok = keep;
+  if (P.sexed) ok = ok && (s.sex[fo] == 0) && (s.sex[m] == 1);
+  return ok && (s.age[fo] >= P.ra_f) && (s.age[m] >= P.ra_m);
+}
+
+// + unordered-pair de-duplication (ops/mating.py:62-65): the reference keeps one of
+// (i,m),(m,i); drop (i,m) iff (m,i) is also present and id_m < id_i (ids, not slots, so
+// every tile of a tiled run takes the same decision).  A pair belongs to the tile that
+// owns its focal individual: ghost focals only serve the reciprocity test.  Flags and
+// their per-block counts (gnx_compact.h).
+__global__ void __launch_bounds__(256)
+k_pair_flags(PairP P, GnxSoA s, int32_t* flag2, int32_t* cnt) {
+  __shared__ int lds[16];
+  const int64_t base = (int64_t)blockIdx.x * GNX_CB;
+  bool f[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    f[r] = false;
+    if (i < P.N) {
+      bool ok = pair_ok(P, s, i);
+      if (ok && P.dedup) {
+        const int m = P.mate[i];
+        if (P.mate[m] == (int32_t)i && s.id[m] < s.id[i] && pair_ok(P, s, m)) ok = false;
+      }
+      if (s.ghost[i]) ok = false;
+      f[r] = ok;
+      flag2[i] = ok ? 1 : 0;
     }
-    bool ok = keep;
-    if (sexed) ok = ok && (s.sex[fo] == 0) && (s.sex[m] == 1);
-    ok = ok && (s.age[fo] >= ra_f) && (s.age[m] >= ra_m);
-    f = ok ? 1 : 0;
   }
-  flag[i] = f;
+  int rank[4], tot;
+  gnx_block_ranks(f, rank, tot, lds);
+  if (threadIdx.x == 0) cnt[blockIdx.x] = tot;
 }
 
-// unordered-pair de-duplication (ops/mating.py:62-65): the reference keeps one
-// of (i,m),(m,i); drop (i,m) iff (m,i) is also present and id_m < id_i (ids, not
-// slots, so every tile of a tiled run takes the same decision).  A pair belongs
-// to the tile that owns its focal individual: ghost focals only serve the
-// reciprocity test.
-__global__ void k_pair_dedup(int64_t N, const int32_t* mate, const int32_t* flag, int sexed,
-                             const int64_t* id, const uint8_t* ghost, int32_t* flag2) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  int f = flag[i];
-  if (f && !sexed) {
-    int m = mate[i];
-    if (flag[m] && mate[m] == (int32_t)i && id[m] < id[i]) f = 0;
+// pairs in slot order, their midpoints (n_pairs density, ops/demography.py:69-70) and the
+// sort keys (focal id) that put them in the order offspring ids are handed out in
+__global__ void __launch_bounds__(256)
+k_pair_compact(int64_t N, const int32_t* focal, const int32_t* mate, const int32_t* flag2,
+               const int32_t* blk_off, const float* x, const float* y, const int64_t* id,
+               int32_t* pairs, float* mid_x, float* mid_y, uint64_t* key, int32_t* idx) {
+  __shared__ int lds[16];
+  const int64_t base = (int64_t)blockIdx.x * GNX_CB;
+  bool f[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    f[r] = i < N && flag2[i] != 0;
   }
-  if (ghost[i]) f = 0;
-  flag2[i] = f;
-}
-
-__global__ void k_pair_compact(int64_t N, const int32_t* focal, const int32_t* mate,
-                               const int32_t* flag2, const int32_t* scan, const float* x,
-                               const float* y, int32_t* pairs, float* mid_x, float* mid_y) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  if (flag2[i]) {
-    int p = scan[i];
-    int m = mate[i];
-    int fo = focal ? focal[i] : (int)i;
+  int rank[4], tot;
+  gnx_block_ranks(f, rank, tot, lds);
+  const int32_t bo = blk_off[blockIdx.x];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    if (!f[r]) continue;
+    const int p = bo + rank[r];
+    const int m = mate[i];
+    const int fo = focal ? focal[i] : (int)i;
     pairs[2 * p] = fo;
     pairs[2 * p + 1] = m;
-    // pair midpoints for the n_pairs density (ops/demography.py:69-70)
     mid_x[p] = (x[fo] + x[m]) / 2.0f;
     mid_y[p] = (y[fo] + y[m]) / 2.0f;
+    key[p] = (uint64_t)id[fo];
+    idx[p] = p;
   }
-}
-
-__global__ void k_pair_keys(int64_t P, const int32_t* pairs, const int64_t* id, uint64_t* key,
-                            int32_t* idx) {
-  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P) return;
-  key[p] = (uint64_t)id[pairs[2 * p]];
-  idx[p] = (int32_t)p;
 }
 
 __global__ void k_pair_reorder(int64_t P, const int32_t* perm, const int32_t* pairs,
@@ -723,22 +798,18 @@ int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out) 
   }
   gnx_time_end(h, GNX_K_FIND_MATES, (double)N * 16.0);
   gnx_time_begin(h);
-  int sexed_dedup = sexed || (sp.mating_radius < 0);   // no dedup for sexed / panmictic
-  hipLaunchKernelGGL(k_pair_flags, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, focal, h->mate,
-                     d_keep, s, (float)sp.b, sexed, sp.repro_age[0], sp.repro_age[1], h->step,
-                     h->cfg.seed, h->flag);
-  hipLaunchKernelGGL(k_pair_dedup, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, h->mate,
-                     h->flag, sexed_dedup, s.id, s.ghost, h->flag2);
-  // scan over N+1 so that scan[N] = number of pairs
-  HIPCHK(hipMemsetAsync(h->flag2 + N, 0, sizeof(int32_t), h->stream));
-  GNXCHK(gnx_prim_scan(h->scan_tmp, h->scan_tmp_bytes, h->flag2, h->scan, (size_t)N + 1,
-                       h->stream));
-  hipLaunchKernelGGL(k_pair_compact, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, focal,
-                     h->mate, h->flag2, h->scan, s.x, s.y, h->pairs, h->mid_x, h->mid_y);
-  GNXCHK(gnx_publish(h, 0, h->scan + N));
+  const int nb = (int)((N + GNX_CB - 1) / GNX_CB);
+  PairP pp{N, focal, h->mate, d_keep, (float)sp.b, sexed, sp.repro_age[0], sp.repro_age[1],
+           (sexed || sp.mating_radius < 0) ? 0 : 1,      // no dedup for sexed / panmictic
+           h->step, h->cfg.seed};
+  hipLaunchKernelGGL(k_pair_flags, dim3(nb), dim3(256), 0, h->stream, pp, s, h->flag2, h->blk_cnt);
+  GNXCHK(gnx_block_scan(h, 1, N, h->blk_cnt, h->blk_off, -1, nullptr, nullptr, h->h_pin_dev + 4));
+  hipLaunchKernelGGL(k_pair_compact, dim3(nb), dim3(256), 0, h->stream, N, focal, h->mate,
+                     h->flag2, h->blk_off, s.x, s.y, s.id, h->pairs, h->mid_x, h->mid_y,
+                     h->key64[0], h->perm[0]);
   gnx_time_end(h, GNX_K_PAIRS, (double)N * 40.0);
   HIPCHK(hipStreamSynchronize(h->stream));
-  h->n_pairs = h->h_pin[0];
+  h->n_pairs = h->h_pin[4];
   *n_pairs_out = h->n_pairs;
   // Order the pairs by the id of their focal individual: offspring ids are then
   // handed out in an order that does not depend on slot order or on how the
@@ -746,10 +817,8 @@ int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out) 
   // set, i.e. unspecified: ops/mating.py:63).
   const int64_t P = h->n_pairs;
   if (P > 1) {
-    hipLaunchKernelGGL(k_pair_keys, dim3(gnx_grid(P, 256)), dim3(256), 0, h->stream, P, h->pairs,
-                       s.id, h->key64[0], h->perm[0]);
-    GNXCHK(gnx_prim_sort64(h->sort64_tmp, h->sort64_tmp_bytes, h->key64[0], h->key64[1],
-                           h->perm[0], h->perm[1], (size_t)P, h->stream));
+    GNXCHK(gnx_prim_sort64_bits(h->sort64_tmp, h->sort64_tmp_bytes, h->key64[0], h->key64[1],
+                                h->perm[0], h->perm[1], (size_t)P, gnx_id_bits(h), h->stream));
     hipLaunchKernelGGL(k_pair_reorder, dim3(gnx_grid(P, 256)), dim3(256), 0, h->stream, P,
                        h->perm[1], h->pairs, h->pairs2);
     std::swap(h->pairs, h->pairs2);
@@ -801,6 +870,11 @@ struct OffP {
   int64_t id_base, n_free;
   long long step;
   unsigned long long seed;
+  // one GPU: the offspring's alleles at the selected loci and its phenotype in the same
+  // kernel (tiles wait for the gametes of ghost mates first)
+  int fuse_tb, TW;
+  const uint64_t* path_sel;
+  const uint8_t* dom;
 };
 
 // gamete requests of a tiled run: the mate is a ghost (it lives on a neighbour
@@ -835,7 +909,7 @@ __device__ __forceinline__ bool disperse_once(float mx, float my, float theta, f
 __global__ void __launch_bounds__(256)
 k_offspring(OffP P, GnxSoA s, const float* rast, const int32_t* pairs, const int32_t* off_pair,
             const int32_t* boff, const int64_t* goff,
-            int32_t* off_parent, int32_t* off_keys, uint8_t* off_start, GnxReq rq) {
+            int32_t* off_parent, int32_t* off_keys, uint8_t* off_start, GnxReq rq, GnxTraitTab T) {
   int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= P.B) return;
   int64_t p, ord;
@@ -909,6 +983,16 @@ k_offspring(OffP P, GnxSoA s, const float* rast, const int32_t* pairs, const int
       rq.start[q] = st1;
       rq.px[q] = s.x[m];
       rq.py[q] = s.y[m];
+    }
+    if (P.fuse_tb) {
+      uint64_t* t0 = s.tb + slot * 2 * P.TW;
+      if (P.TW > 0) {
+        gnx_gamete_tb(P.TW, s.tb + (int64_t)i * 2 * P.TW, P.path_sel + (int64_t)k0 * P.TW, st0 != 0,
+                      t0);
+        gnx_gamete_tb(P.TW, s.tb + (int64_t)m * 2 * P.TW, P.path_sel + (int64_t)k1 * P.TW, st1 != 0,
+                      t0 + P.TW);
+      }
+      if (T.n_traits > 0) gnx_phenotype_tb(t0, t0 + P.TW, T, P.dom, P.cap, slot, s.z);
     }
   }
 }
@@ -1027,6 +1111,10 @@ int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* 
     Q.n_free = h->n_free;
     Q.step = h->step;
     Q.seed = c.seed;
+    Q.fuse_tb = (genomes && !tiled) ? 1 : 0;
+    Q.TW = h->TW;
+    Q.path_sel = h->path_sel;
+    Q.dom = h->dom;
     GnxReq rq{};
     if (tiled && genomes) {
       rq.pid = h->req_pid;
@@ -1041,8 +1129,9 @@ int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* 
     gnx_time_begin(h);
     hipLaunchKernelGGL(k_offspring, dim3(gnx_grid(B, 256)), dim3(256), 0, h->stream, Q, s, h->rast,
                        h->pairs, h->off_pair, h->boff, tiled ? h->pair_goff : nullptr,
-                       h->off_parent, h->off_keys, h->off_start, rq);
-    gnx_time_end(h, GNX_K_OFFSPRING, (double)B * (60.0 + 8.0 * c.n_layers));
+                       h->off_parent, h->off_keys, h->off_start, rq, gnx_trait_tab(h));
+    gnx_time_end(h, GNX_K_OFFSPRING, (double)B * (60.0 + 8.0 * c.n_layers + 48.0 * h->TW +
+                                                  4.0 * c.n_traits));
     if (tiled && genomes) {
       // the number of gamete requests is known before the crossover is launched: the host
       // layer serves the neighbour tiles while the crossover runs
@@ -1057,7 +1146,8 @@ int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* 
     // tables; the 25-KB rows are only needed by the NEXT generation's crossover, so on one
     // GPU they are cut after this step's death draws, for the survivors only
     // (gnx_l_mortality), unless somebody asks for them earlier (gnx_xo_join)
-    GNXCHK(gnx_l_newborn_tb(h, h->N, B));
+    const bool fused = !inject && !tiled;        // k_offspring did both already
+    if (!fused) GNXCHK(gnx_l_newborn_tb(h, h->N, B));
     const bool defer = h->defer_xo && !tiled && !inject && h->stream2 != nullptr;
     if (defer) {
       h->xo_deferred = true;
@@ -1066,7 +1156,7 @@ int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* 
     } else {
       GNXCHK(gnx_l_crossover_all(h, h->N, B));
     }
-    if (c.n_traits > 0 && !tiled) GNXCHK(gnx_l_phenotype(h, h->N, B));
+    if (c.n_traits > 0 && !tiled && !fused) GNXCHK(gnx_l_phenotype(h, h->N, B));
   }
   h->N += B;
   if (!tiled) h->max_id += B;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 #include "gnx_internal.h"
+#include "gnx_compact.h"
 
 int gnx_prim_sort_bytes(size_t n, int bits, size_t* bytes) {
   *bytes = 0;
@@ -51,5 +52,80 @@ int gnx_prim_sort64_bits(void* tmp, size_t bytes, const uint64_t* kin, uint64_t*
                          const int32_t* vin, int32_t* vout, size_t n, int end_bit,
                          hipStream_t s) {
   HIPCHK(rocprim::radix_sort_pairs(tmp, bytes, kin, kout, vin, vout, n, 0, end_bit, s));
+  return 0;
+}
+
+// ---------------------------------------------------------------- block-count scan
+// Exclusive scan of K count arrays (cnt[k * stride + b], b < nb) into off[k * stride + b],
+// off[k * stride + nb] = total.  One workgroup of 1024 threads.  Optionally (mark >= 0,
+// array 0 only) the number of flagged items below item `mark`, from the stored flags
+// (mark's block is only partly below it): out[2].  out[0], out[1] = totals of arrays 0, 1.
+// `host` (pinned, device-visible) receives the same four numbers.
+__global__ void __launch_bounds__(1024)
+k_block_scan(int K, int nb, int stride, const int32_t* __restrict__ cnt, int32_t* __restrict__ off,
+             int64_t mark, const int32_t* __restrict__ flags0, int32_t* __restrict__ out,
+             int64_t* __restrict__ host) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int totals[2] = {0, 0};
+  for (int k = 0; k < K; ++k) {
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nb; b0 += 1024) {
+      const int b = b0 + tid;
+      const int v = b < nb ? cnt[k * stride + b] : 0;
+      int x = v;                                  // inclusive scan inside the wave
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+      }
+      if (lane == 63) wsum[wave] = x;
+      __syncthreads();
+      int woff = 0;
+      for (int w = 0; w < wave; ++w) woff += wsum[w];
+      const int carry = carry_s;
+      if (b < nb) off[k * stride + b] = carry + woff + x - v;
+      __syncthreads();
+      if (tid == 1023) carry_s = carry + woff + x;
+      __syncthreads();
+    }
+    totals[k] = carry_s;
+    if (tid == 0) off[k * stride + nb] = carry_s;
+    __syncthreads();
+  }
+  int below = 0;
+  if (mark >= 0) {
+    const int64_t blk = mark / GNX_CB;
+    const int64_t i = blk * GNX_CB + tid;
+    int c = (i < mark && flags0[i]) ? 1 : 0;
+    unsigned long long bal = __ballot(c);
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int part = 0;
+    for (int w = 0; w < 16; ++w) part += wsum[w];
+    below = (blk < nb ? off[blk] : totals[0]) + part;
+  }
+  if (tid == 0) {
+    if (out) {
+      out[0] = totals[0];
+      out[1] = totals[1];
+      out[2] = below;
+    }
+    if (host) {
+      host[0] = totals[0];
+      host[1] = totals[1];
+      host[2] = below;
+    }
+  }
+}
+
+int gnx_block_scan(gnx_state* h, int K, int64_t n_items, const int32_t* cnt, int32_t* off,
+                   int64_t mark, const int32_t* flags0, int32_t* out, int64_t* host) {
+  const int nb = (int)((n_items + GNX_CB - 1) / GNX_CB);
+  hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, h->stream, K, nb, h->blk_stride, cnt, off,
+                     mark, flags0, out, host);
+  HIPCHK(hipGetLastError());
   return 0;
 }

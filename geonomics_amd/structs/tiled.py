@@ -242,5 +242,40 @@ class TiledSpecies(Species):
             'some requested individuals are not alive')
         return all_g[o]
 
+    def _remove_individuals(self, individs=None, n=None, n_left=None, keep_sites_tab=False,
+                            check_extinct=False, verbose=False):
+        """reference structs/species.py:1559-1640 over the tiles: the same individuals are
+        drawn on every rank (shared generator, gathered ids), each tile removes the ones it
+        owns, the counts are global"""
+        given = [p is not None for p in (individs, n, n_left)]
+        assert sum(given) == 1, ("One of 'individs', 'n', and 'n_left' must be provided, the "
+                                 "other two must be None.")
+        all_ids = np.sort(self._field(nat.F_ID))
+        n_glob = all_ids.size
+        if individs is None:
+            if n_left is not None:
+                assert 0 <= n_left <= n_glob, (
+                    "'n_left' must be a number between 0 and the current size of the "
+                    "population (%i)." % n_glob)
+                n = n_glob - n_left
+            assert isinstance(n, (int, np.integer)) and 0 <= n <= n_glob, (
+                "'n' must be a non-negative int no larger than the population (%i)." % n_glob)
+            individs = self._rng.choice(all_ids, n, replace=False)
+        individs = np.asarray(individs, dtype=np.int64)
+        assert np.isin(individs, all_ids).all(), 'some of the listed Individuals do not exist'
+        mine = self._dev.download(nat.F_ID)
+        dead = np.isin(mine, individs)
+        self._dev.op_mortality(dead.astype(np.uint8))
+        removed = int(self._comm_sum(np.array([dead.sum()], np.int64))[0])
+        assert removed == individs.size
+        self._glob_N = n_glob - removed
+        if verbose:
+            print('\n%i Individuals successfully removed.\n' % individs.size)
+        if check_extinct and self._check_extinct():
+            self.extinct = True
+
+    def _comm_sum(self, a):
+        return self._stepper.comm.allreduce_sum(a)
+
     def _calc_density(self, normalize=False, as_layer=False, set_N=False):
         raise NotImplementedError('Species._calc_density on a tiled landscape: use Species.N')

@@ -189,6 +189,11 @@ int gnx_counts(gnx_state* h, int64_t* N, int64_t* births, int64_t* deaths);
  * get a genome.  off: for every birth, inside gnx_pop_dynamics_mate.  Same results either
  * way (draws are keyed by id); any genome access in between triggers the off path.      */
 int gnx_set_defer_crossover(gnx_state* h, int32_t on);
+/* How the deferred crossover shares the GPU with the next step's kernels.  0 (default):
+ * it runs at full width under the compaction and the next movement only, the next cell
+ * sort waits for it - the crossover keeps its full rate.  1: a narrow crossover runs
+ * beside the WHOLE next step - more individual-timesteps/s, a slower crossover.        */
+int gnx_set_crossover_overlap(gnx_state* h, int32_t whole_step);
 /* births whose genomes the last crossover wrote (== births when not deferred)          */
 int64_t gnx_last_crossover_births(gnx_state* h);
 int64_t gnx_step_index(gnx_state* h);

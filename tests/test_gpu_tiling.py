@@ -209,7 +209,8 @@ def _run_model(tmp_path, world, traits, tag, extra=()):
                 env.pop(k, None)
         procs.append(subprocess.Popen([sys.executable, worker, out, str(int(traits)), str(wd),
                                        *extra], env=env))
-    assert [p.wait(timeout=600) for p in procs] == [0] * world
+    from _procs import wait_all
+    assert wait_all(procs) == [0] * world
     return np.load(out), wd
 
 

@@ -25,7 +25,8 @@ def launch(backend, shard, world, steps, out, mode='fixed'):
     port = free_port()
     procs = [subprocess.Popen([sys.executable, WORKER, backend, shard, str(world), str(r),
                                str(port), str(steps), out, mode]) for r in range(world)]
-    rcs = [p.wait(timeout=600) for p in procs]
+    from _procs import wait_all
+    rcs = wait_all(procs)
     assert rcs == [0] * world, rcs
     return np.load(out)
 
