@@ -298,6 +298,7 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
   h->defer_xo = !(getenv("GNX_DEFER_XO") && atoi(getenv("GNX_DEFER_XO")) == 0);
   if (getenv("GNX_XO_LAUNCH")) h->xo_launch_policy = atoi(getenv("GNX_XO_LAUNCH"));
   if (getenv("GNX_XO_SORT_WAIT")) h->xo_sort_waits = atoi(getenv("GNX_XO_SORT_WAIT")) != 0;
+  if (getenv("GNX_XO_WAIT")) h->xo_wait_at = atoi(getenv("GNX_XO_WAIT"));
   *out = h;
   return 0;
 }

@@ -174,6 +174,9 @@ struct gnx_state {
   // xo_launch_policy 1 / 2 launch it after the next step's cell sort / pair sort instead.
   int xo_launch_policy = 0;
   bool xo_sort_waits = true;
+  // where `stream` waits for the full-width crossover (GNX_XO_WAIT): 1 before the next cell
+  // sort, 2 right after launching it (strictly serial), 3 after the compaction
+  int xo_wait_at = 1;
   int xo_ready_buf = -1;         // jobs built, kernel not launched yet
   int64_t xo_ready_jobs = 0;
   int64_t last_xo_births = 0;    // births that went through the last crossover

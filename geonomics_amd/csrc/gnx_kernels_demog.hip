@@ -623,6 +623,7 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
   if (xo) {
     h->xo_deferred = false;
     GNXCHK(gnx_l_crossover_survivors(h, xo_first, xo_B, h->flag, h->blk_off));
+    if (h->xo_sort_waits && h->xo_wait_at == 2) GNXCHK(gnx_xo_wait_inflight(h));
   }
   gnx_time_begin(h);
   hipLaunchKernelGGL(k_compact, dim3(nb), dim3(256), 0, h->stream, N, c.cap_inds, h->flag,
@@ -631,6 +632,7 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
   gnx_time_end(h, GNX_K_COMPACT, (double)N * (24.0 + 2.0 * (34.0 + 4.0 * c.n_layers +
                                                              4.0 * c.n_traits + 16.0 * h->TW)));
   HIPCHK(hipGetLastError());
+  if (xo && h->xo_sort_waits && h->xo_wait_at == 3) GNXCHK(gnx_xo_wait_inflight(h));
   HIPCHK(hipEventSynchronize(h->ev_counts));
   const int64_t survivors = h->h_pin[0];
   const int64_t rows_freed = h->h_pin[1];

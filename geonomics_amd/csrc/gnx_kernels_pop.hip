@@ -441,10 +441,14 @@ int gnx_l_sort_by_cell(gnx_state* h) {
 // count the m in-radius candidates, take the (u*m)-th.  The result depends on ids, positions and the seed only: slot order and
 // tiling do not matter (tiles import whole cells, csrc/gnx_tile.hip).
 //
-// NEAREST and INVERSE-DISTANCE choices need every candidate: FM_LANES adjacent lanes
-// share one focal's ranges (64 contiguous bytes per group and step) and combine
-// their branch-free composite-key minima with DPP shuffles; nearest = smallest d2,
-// inverse-distance = smallest -ln(u)/(r-d) (Efraimidis-Spirakis), ties on the smaller id.
+// INVERSE-DISTANCE choice (P(j) ~ r - d_ij over the neighbours with d > 0,
+// utils/spatial.py:209-229) is the same index sampling with an acceptance draw: a
+// candidate drawn is taken iff u * r < r - d (two stream words per try); the exact
+// fallback walks the candidates once for the total weight and once for the pick.
+// NEAREST: FM_LANES adjacent lanes share one focal's cells (64 contiguous bytes per group
+// and step) and combine their branch-free composite-key minima (d2, id) with DPP
+// shuffles, own cell first; a neighbour cell is read only if its rectangle comes closer
+// than the best candidate so far.
 // (A wave-broadcast variant - the wave loads the union of its lanes' ranges and
 // v_readlane's each candidate - was 5x slower: 3.4x more vector instructions, PMC
 // SQ_INSTS_VALU, round-1 profiles.)
@@ -497,7 +501,11 @@ k_find_mates(FocalP fp, GnxSoA s, const uint4* __restrict__ cand, double inv_cs,
     __syncthreads();
   }
   // phase 2
-  if (MODE == GNX_MATE_UNIFORM) {
+  if (MODE != GNX_MATE_NEAREST) {
+    // UNIFORM: one stream word per try (the index).  INVERSE-DISTANCE (P(j) ~ r - d_ij
+    // over the neighbours with d > 0, utils/spatial.py:209-229): two words per try, the
+    // index and an acceptance draw u: the candidate is taken iff u * r < r - d.
+    constexpr bool WT = MODE == GNX_MATE_INVERSE;
     for (int t = tid; t < n_list; t += 256) {
       const int i = list[t];
       const uint4 me = cand[i];
@@ -516,45 +524,85 @@ k_find_mates(FocalP fp, GnxSoA s, const uint4* __restrict__ cand, double inv_cs,
         len[q] = in ? cell_start[ry * ncx + hi + 1] - st[q] : 0;
       }
       const unsigned int M = (unsigned int)(len[0] + len[1] + len[2]);
-      GnxStream rs(fp.seed, (unsigned long long)s.id[i], fp.step, OP_MATE_PICK);
+      const unsigned long long fid = (unsigned long long)s.id[i];
       int found = -1;
-      // draws before the exact scan: about M/2 (a scan costs 2M loads), 32 .. 8192
-      const int tries = 4 * min(max((int)(M >> 3), FM_MIN_BLOCKS), FM_MAX_BLOCKS);
+      // Philox blocks before the exact scan (a scan costs 2M loads): about M/8 blocks of
+      // 4 index draws (32 .. 8192 draws), or M/4 blocks of 2 weighted tries (32 .. 8192)
+      const int blocks = WT ? min(max((int)(M >> 2), 2 * FM_MIN_BLOCKS), 2 * FM_MAX_BLOCKS)
+                            : min(max((int)(M >> 3), FM_MIN_BLOCKS), FM_MAX_BLOCKS);
       if (M > 1) {
-        for (int tr = 0; tr < tries && found < 0; ++tr) {
-          int j = (int)__umulhi(rs.next(), M);
-          const int slot = j < len[0] ? st[0] + j
-                           : (j < len[0] + len[1] ? st[1] + (j - len[0])
-                                                  : st[2] + (j - len[0] - len[1]));
-          const uint4 c = cand[slot];
-          const float dx = __uint_as_float(c.x) - fx, dy = __uint_as_float(c.y) - fy;
-          if (slot != i && dx * dx + dy * dy <= r2) found = slot;
+        // one Philox block per round: its tries' candidates are fetched TOGETHER (the
+        // loads are independent, the round trip to L2 / HBM is what a try costs) and
+        // examined in stream order, so the first accepted try is the one a sequential
+        // walk of the stream would take
+        for (int blk = 0; blk < blocks && found < 0; ++blk) {
+          const uint4 w = gnx_rand4(fp.seed, fid, fp.step, OP_MATE_PICK, blk);
+          const unsigned int wi[4] = {w.x, WT ? w.z : w.y, w.z, w.w};
+          const unsigned int wa[2] = {w.y, w.w};
+          constexpr int NT = WT ? 2 : 4;
+          int slot[NT];
+          uint4 c[NT];
+#pragma unroll
+          for (int q = 0; q < NT; ++q) {
+            const int j = (int)__umulhi(wi[q], M);
+            slot[q] = j < len[0] ? st[0] + j
+                      : (j < len[0] + len[1] ? st[1] + (j - len[0])
+                                             : st[2] + (j - len[0] - len[1]));
+            c[q] = cand[slot[q]];
+          }
+#pragma unroll
+          for (int q = 0; q < NT; ++q) {
+            const float dx = __uint_as_float(c[q].x) - fx, dy = __uint_as_float(c[q].y) - fy;
+            const float d2 = dx * dx + dy * dy;
+            bool ok = slot[q] != i && d2 <= r2;
+            if (WT) ok = ok && d2 > 0.f && gnx_u01(wa[q]) * r < r - sqrtf(d2);
+            if (ok && found < 0) found = slot[q];
+          }
         }
         if (found < 0) {
-          // exact fallback: the (u * m)-th of the m in-radius candidates, canonical order
-          GnxStream fb(fp.seed, (unsigned long long)s.id[i], fp.step, OP_MATE_PICK,
-                       tries / 4);
+          // exact fallback in canonical order: the (u * m)-th of the m in-radius
+          // candidates, or the first whose running weight passes u * (total weight)
+          GnxStream fb(fp.seed, (unsigned long long)s.id[i], fp.step, OP_MATE_PICK, blocks);
           unsigned int m = 0;
+          float wsum = 0.f;
           for (int q = 0; q < 3; ++q)
             for (int slot = st[q]; slot < st[q] + len[q]; ++slot) {
               const uint4 c = cand[slot];
               const float dx = __uint_as_float(c.x) - fx, dy = __uint_as_float(c.y) - fy;
-              m += (slot != i && dx * dx + dy * dy <= r2) ? 1u : 0u;
+              const float d2 = dx * dx + dy * dy;
+              const bool in = slot != i && d2 <= r2 && (!WT || d2 > 0.f);
+              m += in ? 1u : 0u;
+              if (WT && in) wsum = wsum + (r - sqrtf(d2));
             }
           if (m > 0) {
-            unsigned int want = __umulhi(fb.next(), m);
+            const unsigned int w0 = fb.next();
+            unsigned int want = __umulhi(w0, m);
+            const float target = gnx_u01(w0) * wsum;
+            float run = 0.f;
+            int last = -1;
             for (int q = 0; q < 3 && found < 0; ++q)
               for (int slot = st[q]; slot < st[q] + len[q]; ++slot) {
                 const uint4 c = cand[slot];
                 const float dx = __uint_as_float(c.x) - fx, dy = __uint_as_float(c.y) - fy;
-                if (slot != i && dx * dx + dy * dy <= r2) {
-                  if (want == 0) {
-                    found = slot;
-                    break;
+                const float d2 = dx * dx + dy * dy;
+                if (slot != i && d2 <= r2 && (!WT || d2 > 0.f)) {
+                  if (WT) {
+                    run = run + (r - sqrtf(d2));
+                    last = slot;
+                    if (run > target) {
+                      found = slot;
+                      break;
+                    }
+                  } else {
+                    if (want == 0) {
+                      found = slot;
+                      break;
+                    }
+                    --want;
                   }
-                  --want;
                 }
               }
+            if (WT && found < 0) found = last;
           }
         }
       }
@@ -562,21 +610,19 @@ k_find_mates(FocalP fp, GnxSoA s, const uint4* __restrict__ cand, double inv_cs,
     }
     return;
   }
-  // NEAREST / INVERSE: FM_LANES adjacent lanes per listed focal individual
+  // NEAREST: FM_LANES adjacent lanes per listed focal individual
   const double cs = 1.0 / inv_cs;
   for (int t = tid; t < n_list * FM_LANES; t += 256) {
     const int i = list[t / FM_LANES];
     const int sub = t % FM_LANES;
     const uint4 me = cand[i];
     const float fx = __uint_as_float(me.x), fy = __uint_as_float(me.y);
-    const unsigned int ftag = me.z * 0x9E3779B1u;
     const int k = gnx_cell_of(fx, fy, inv_cs, ncx, ncy);
     const int cy = k / ncx;
     const int cx = k - cy * ncx;
-    const int lo = max(cx - 1, 0), hi = min(cx + 1, ncx - 1);
     unsigned long long best = ~0ull;
     int best_slot = -1;
-    if (MODE == GNX_MATE_NEAREST) {
+    {
       // own cell first, then a neighbour cell only if its rectangle comes closer than the
       // best candidate so far (a clumped population holds thousands of candidates in the
       // 3 x 3 block, nearly all of them farther than the nearest one of the own cell)
@@ -618,35 +664,7 @@ k_find_mates(FocalP fp, GnxSoA s, const uint4* __restrict__ cand, double inv_cs,
         }
       }
       if (sub == 0) mate[i] = best_slot;
-      continue;
     }
-    for (int ry = max(cy - 1, 0); ry <= min(cy + 1, ncy - 1); ++ry) {
-      const int st = cell_start[ry * ncx + lo];
-      const int e = cell_start[ry * ncx + hi + 1];
-      for (int j = st + sub; j < e; j += FM_LANES) {
-        const uint4 c = cand[j];
-        const float dx = __uint_as_float(c.x) - fx, dy = __uint_as_float(c.y) - fy;
-        const float d2 = dx * dx + dy * dy;
-        bool ok = (d2 <= r2) & (j != i) & (d2 > 0.f);
-        const float kf = -logf(gnx_u01(gnx_pair_key(ftag, c.z))) / (r - sqrtf(d2));
-        const unsigned int k32 = __float_as_uint(kf);
-        const unsigned long long comp =
-            ok ? (((unsigned long long)k32 << 32) | (unsigned long long)c.w) : ~0ull;
-        const bool better = comp < best;
-        best = better ? comp : best;
-        best_slot = better ? j : best_slot;
-      }
-    }
-#pragma unroll
-    for (int m = 1; m < FM_LANES; m <<= 1) {
-      const unsigned long long ob = __shfl_xor(best, m);
-      const int os = __shfl_xor(best_slot, m);
-      // composite keys of distinct candidates differ unless both are "none"
-      const bool take = ob < best;
-      best = take ? ob : best;
-      best_slot = take ? os : best_slot;
-    }
-    if (sub == 0) mate[i] = best_slot;
   }
 }
 

@@ -377,7 +377,12 @@ def mate_tries(M):
     return 4 * np.clip(np.asarray(M, dtype=np.int64) >> 3, 8, 2048)
 
 
-def choose_mates_uniform(x, y, ids, radius, seed, step, dim, focal=None):
+def mate_blocks_weighted(M):
+    """Philox blocks (2 weighted tries each) before the exact scan: clamp(M // 4, 16, 4096)"""
+    return np.clip(np.asarray(M, dtype=np.int64) >> 2, 16, 4096)
+
+
+def choose_mates_uniform(x, y, ids, radius, seed, step, dim, focal=None, weighted=False):
     """The build's uniform mate choice (utils/spatial.py:232-242 picks
     np.random.choice among the neighbours within the radius): rejection sampling in
     index space.  Candidates of a focal individual = the individuals in the 3x3 block
@@ -387,6 +392,11 @@ def choose_mates_uniform(x, y, ids, radius, seed, step, dim, focal=None):
     candidate drawn lies within the radius and is not itself; after T = mate_tries(M)
     rejections it takes the ((w_T * m) >> 32)-th of the m in-radius candidates in
     canonical order (w_T = the first word of Philox block T/4).
+    weighted=True is the inverse-distance choice (utils/spatial.py:209-229: P(j) ~ r - d_ij
+    over the neighbours with d > 0): two stream words per try, the index and an acceptance
+    draw u - the candidate drawn is taken iff u * r < r - d (f32); after
+    mate_blocks_weighted(M) blocks the exact pick: total weight W summed in canonical order
+    (f32), then the first candidate whose running weight passes u01(w) * W.
     focal: optional mask of the individuals that need a mate (others get -1)."""
     import philox as P
     F = np.float32
@@ -419,29 +429,36 @@ def choose_mates_uniform(x, y, ids, radius, seed, step, dim, focal=None):
     M = ln.sum(axis=1)
     r2 = F(radius) * F(radius)
     found = np.full(foc.size, -1, dtype=np.int64)
-    tries = mate_tries(M)
+    rF = F(radius)
+    per_blk = 2 if weighted else 4
+    blocks = mate_blocks_weighted(M) if weighted else mate_tries(M) // 4
     fid = ids[foc].astype(np.uint64)
     active = M > 1
     blk = 0
     while active.any():
-        a = np.nonzero(active & (tries > 4 * blk))[0]
+        a = np.nonzero(active & (blocks > blk))[0]
         if a.size == 0:
             break
         w4 = P.philox4x32(seed, fid[a], P.block_index(step, P.OP_MATE_PICK, blk)).astype(
             np.uint64)
-        for t in range(4):
+        for t in range(per_blk):
             live = active[a]
             if not live.any():
                 break
             aa = a[live]
-            j = ((w4[live, t] * M[aa].astype(np.uint64)) >> np.uint64(32)).astype(np.int64)
+            wi = w4[live, 2 * t if weighted else t]
+            j = ((wi * M[aa].astype(np.uint64)) >> np.uint64(32)).astype(np.int64)
             slot = np.where(j < ln[aa, 0], st[aa, 0] + j,
                             np.where(j < ln[aa, 0] + ln[aa, 1], st[aa, 1] + (j - ln[aa, 0]),
                                      st[aa, 2] + (j - ln[aa, 0] - ln[aa, 1])))
             c = order[slot]
             dx = x[c] - x[foc[aa]]
             dy = y[c] - y[foc[aa]]
-            ok = (c != foc[aa]) & ((dx * dx + dy * dy) <= r2)
+            d2 = dx * dx + dy * dy
+            ok = (c != foc[aa]) & (d2 <= r2)
+            if weighted:
+                u = P.u01(w4[live, 2 * t + 1].astype(np.uint32))
+                ok = ok & (d2 > 0) & ((u * rF).astype(F) < (rF - np.sqrt(d2)).astype(F))
             found[aa[ok]] = c[ok]
             active[aa[ok]] = False
         blk += 1
@@ -450,11 +467,30 @@ def choose_mates_uniform(x, y, ids, radius, seed, step, dim, focal=None):
         c = np.concatenate([order[st[k, q]:st[k, q] + ln[k, q]] for q in range(3)])
         dx = x[c] - x[i]
         dy = y[c] - y[i]
-        inr = c[(c != i) & ((dx * dx + dy * dy) <= r2)]
+        d2 = dx * dx + dy * dy
+        sel = (c != i) & (d2 <= r2)
+        if weighted:
+            sel = sel & (d2 > 0)
+        inr = c[sel]
         if inr.size:
             w = int(P.philox4x32(seed, fid[k:k + 1],
-                                 P.block_index(step, P.OP_MATE_PICK, int(tries[k]) // 4))[0, 0])
-            found[k] = inr[(w * inr.size) >> 32]
+                                 P.block_index(step, P.OP_MATE_PICK, int(blocks[k])))[0, 0])
+            if not weighted:
+                found[k] = inr[(w * inr.size) >> 32]
+            else:
+                wt = (rF - np.sqrt(d2[sel])).astype(F)
+                run = F(0)
+                for v in wt:
+                    run = F(run + v)
+                target = F(P.u01(np.array([w], np.uint32))[0] * run)
+                acc = F(0)
+                pick = inr[-1]
+                for cc, v in zip(inr, wt):
+                    acc = F(acc + v)
+                    if acc > target:
+                        pick = cc
+                        break
+                found[k] = pick
     mate[foc] = found
     return mate
 
@@ -468,14 +504,15 @@ def choose_mates(x, y, ids, radius, seed, step, mode='uniform',
                       one lies within the radius (choose_mates_uniform; needs dim).
     mode 'nearest'  : utils/spatial.py:194-203 (ties -> smaller id).
     mode 'inverse'  : utils/spatial.py:209-229, P(j) ~ (r - d_ij) over
-                      candidates with d > 0; the build picks
-                      argmin(-ln(u_ij) / (r - d_ij)), u from pair_hash
-                      (Efraimidis-Spirakis weighted choice).
+                      candidates with d > 0; the build samples candidate indices like
+                      'uniform' and accepts with probability (r - d) / r
+                      (choose_mates_uniform(weighted=True); needs dim).
     Returns mate index per individual (-1 = none)."""
     from philox import pair_hash, u01
-    if mode == 'uniform':
-        assert dim is not None, "uniform mate choice needs the landscape dim (W, H)"
-        return choose_mates_uniform(x, y, ids, radius, seed, step, dim, focal=focal)
+    if mode in ('uniform', 'inverse'):
+        assert dim is not None, "index-sampled mate choice needs the landscape dim (W, H)"
+        return choose_mates_uniform(x, y, ids, radius, seed, step, dim, focal=focal,
+                                    weighted=mode == 'inverse')
     x = np.asarray(x, dtype=dtype)
     y = np.asarray(y, dtype=dtype)
     ids = np.asarray(ids, dtype=np.uint64)

@@ -446,3 +446,37 @@ def test_spatial_tester_vs_reference():
             assert abs(m - g['s%i_mean' % s][t]) < 1e-12
             assert abs(sd - g['s%i_std' % s][t]) < 1e-12
         np.testing.assert_array_equal(counts, g['s%i_counts' % s])
+
+
+def test_inverse_distance_choice_follows_the_weights():
+    """the build's inverse-distance mate choice (index sampling + acceptance u * r < r - d,
+    exact weighted fallback) draws neighbour j of a focal individual with probability
+    (r - d_j) / sum_k (r - d_k) (utils/spatial.py:222-227), never a coincident one"""
+    rng = np.random.RandomState(2)
+    r = 3.0
+    # one focal individual (id 0) in the middle of a fixed ring of neighbours
+    ang = np.linspace(0, 2 * np.pi, 13)[:-1]
+    dist = np.array([0.3, 0.6, 0.9, 1.2, 1.5, 1.8, 2.1, 2.4, 2.7, 2.95, 3.2, 0.0])
+    x = np.concatenate([[10.0], 10.0 + dist * np.cos(ang)]).astype(np.float32)
+    y = np.concatenate([[10.0], 10.0 + dist * np.sin(ang)]).astype(np.float32)
+    ids = np.arange(x.size)
+    counts = np.zeros(x.size)
+    T = 6000
+    for step in range(T):
+        m = O.choose_mates(x, y, ids, r, 11, step, mode='inverse', dim=(20, 20),
+                           focal=np.arange(x.size) == 0)
+        counts[m[0]] += 1
+    dx, dy = x - x[0], y - y[0]
+    d = np.sqrt(dx * dx + dy * dy)
+    w = np.where((d > 0) & (d <= r), r - d, 0.0)
+    w[0] = 0
+    p = w / w.sum()
+    assert counts[w == 0].sum() == 0                     # out of range / coincident: never
+    assert np.abs(counts / T - p).max() < 4.5 * np.sqrt(p.max() / T)
+    # the fallback path (few blocks, many rejections) agrees with the weights too
+    xs = np.concatenate([[10.0], 10.0 + rng.rand(400) * 0.02 + 2.93]).astype(np.float32)
+    ys = np.full(401, 10.0, np.float32)
+    got = np.array([O.choose_mates(xs, ys, np.arange(401), r, 3, s_, mode='inverse',
+                                   dim=(20, 20), focal=np.arange(401) == 0)[0]
+                    for s_ in range(300)])
+    assert (got > 0).all()
