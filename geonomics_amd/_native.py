@@ -45,7 +45,7 @@ EXPORTS = [
     'gnx_tile_import_dev', 'gnx_tile_import_ghosts_dev', 'gnx_tile_pair_ptrs',
     'gnx_tile_offspring_dev', 'gnx_tile_group_requests', 'gnx_tile_serve_gametes_dev',
     'gnx_tile_put_gametes_dev', 'gnx_tile_bins_ptr', 'gnx_set_k_raster', 'gnx_last_births', 'gnx_set_positions', 'gnx_n_slots', 'gnx_stats_ld_counts',
-    'gnx_set_defer_crossover', 'gnx_last_crossover_births', 'gnx_set_crossover_overlap',
+    'gnx_set_defer_crossover', 'gnx_last_crossover_births', 'gnx_set_crossover_overlap', 'gnx_spatial_diff_sums',
 ]
 
 
@@ -353,6 +353,11 @@ class Device:
         self._chk(self.lib.gnx_spatial_diff_stats(self.h, C.byref(m), C.byref(s)))
         return m.value, s.value
 
+    def spatial_diff_sums(self):
+        a, b = C.c_double(), C.c_double()
+        self._chk(self.lib.gnx_spatial_diff_sums(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     # -- operator-level (tests) ----------------------------------------------
     def op_move(self, theta, dist):
         t = _arr(theta, np.float32)
@@ -585,7 +590,7 @@ class Device:
                                                       C.c_void_p(rec)))
 
     def tile_pair_ptrs(self):
-        """-> P, focal ids address (int64[P]), n_births address (int32[P]) or 0"""
+        """-> P, order keys address (int64[P], ascending), n_births address (int32[P]) or 0"""
         n, a, b = C.c_int64(), C.c_void_p(), C.c_void_p()
         self._chk(self.lib.gnx_tile_pair_ptrs(self.h, C.byref(n), C.byref(a), C.byref(b)))
         return n.value, a.value or 0, b.value or 0

@@ -458,6 +458,8 @@ static int setup_lattice(gnx_state* h) {
   HIPCHK(hipMemcpy(L.areas, areas.data(), nn * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(L.cprime, cp.data(), (Jm + 1) * sizeof(double), hipMemcpyHostToDevice));
   h->spl_N.valid = h->spl_P.valid = false;
+  h->bins_zeroed[0] = h->bins_zeroed[1] = false;
+  h->nmax_zeroed = false;
   return 0;
 }
 
@@ -850,10 +852,14 @@ extern "C" int gnx_pop_dynamics(gnx_state* h, int32_t burn, int32_t with_selecti
 
 extern "C" int gnx_step(gnx_state* h, int32_t burn, int32_t with_selection) {
   GNXCHK(need_params(h));
-  if (h->sp.move)
-    GNXCHK(gnx_l_move(h, true, nullptr, nullptr, nullptr, nullptr, true));
-  else
+  if (h->sp.move) {
+    h->move_writes_keys = h->sp.mating_radius >= 0;     // the cell sort follows at once
+    int rc = gnx_l_move(h, true, nullptr, nullptr, nullptr, nullptr, true);
+    h->move_writes_keys = false;
+    GNXCHK(rc);
+  } else {
     GNXCHK(gnx_l_age(h));
+  }
   GNXCHK(gnx_pop_dynamics(h, burn, with_selection));
   h->step += 1;
   return 0;
@@ -1100,6 +1106,15 @@ extern "C" int gnx_download_raster(gnx_state* h, int32_t which, double* dst) {
 extern "C" int gnx_spatial_diff_stats(gnx_state* h, double* mean, double* sd) {
   GNXCHK(need_params(h));
   return gnx_l_spatial_diff(h, mean, sd);
+}
+
+extern "C" int gnx_spatial_diff_sums(gnx_state* h, double* sum, double* sum_sq) {
+  GNXCHK(need_params(h));
+  double r[2] = {0, 0};
+  GNXCHK(gnx_l_spatial_diff(h, nullptr, nullptr, r));
+  *sum = r[0];
+  *sum_sq = r[1];
+  return 0;
 }
 
 // ---------------------------------------------------------------- operator-level entry points

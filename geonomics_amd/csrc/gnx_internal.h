@@ -256,6 +256,10 @@ struct gnx_state {
   GnxSpline spl_N, spl_P;
   int32_t* bin_partials = nullptr;   // half-window bin counts of individuals [nby*nbx]
   int32_t* bins_P = nullptr;         // ... of pair midpoints
+  bool bins_zeroed[2]{};             // [0] individuals, [1] pairs: already cleared by k_lattice
+  bool nmax_zeroed = false;          // nmax_bits already cleared by k_lattice
+  bool keys_fresh = false;
+  bool move_writes_keys = false;     // set around the movement of gnx_step           // k_move has written this step's sort keys
   int n_bin_blocks = 0;
   double* nodes = nullptr;           // [Jy][Jx] scratch node values
   double* K_over = nullptr;          // explicit K raster [H][W] (null: rast[K_layer] * K_factor)
@@ -359,10 +363,12 @@ int gnx_l_bins(gnx_state* h, int64_t n, const float* d_x, const float* d_y, cons
                int32_t* d_bins);
 int gnx_l_spline(gnx_state* h, const int32_t* d_bins, GnxSpline* spl,
                  const double* d_nodes_override);
+int gnx_l_spline_z(gnx_state* h, const int32_t* d_bins, GnxSpline* spl,
+                   const double* d_nodes_override, bool housekeeping);
 int gnx_l_raster(gnx_state* h, int which, double* d_out);
 int gnx_l_death_probs(gnx_state* h, bool with_selection);
 int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_out);
-int gnx_l_spatial_diff(gnx_state* h, double* mean, double* sd);
+int gnx_l_spatial_diff(gnx_state* h, double* mean, double* sd, double* sums = nullptr);
 int gnx_l_gather_genomes(gnx_state* h, int64_t n, const int64_t* d_slots, uint64_t* d_out);
 
 // look-back-free compaction (gnx_compact.h): block counts cnt[k * blk_stride + b] ->

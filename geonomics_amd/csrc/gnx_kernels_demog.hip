@@ -148,7 +148,10 @@ int gnx_l_bins(gnx_state* h, int64_t n, const float* d_x, const float* d_y, cons
                int32_t* d_bins) {
   const GnxLattice& L = h->lat;
   const int nb = L.nbx * L.nby;
-  HIPCHK(hipMemsetAsync(d_bins, 0, (size_t)nb * sizeof(int32_t), h->stream));
+  const int field = (d_bins == h->bins_P) ? 1 : 0;
+  if (!h->bins_zeroed[field])
+    HIPCHK(hipMemsetAsync(d_bins, 0, (size_t)nb * sizeof(int32_t), h->stream));
+  h->bins_zeroed[field] = false;
   if (n > 0) {
     if ((size_t)nb * sizeof(int32_t) <= 48 * 1024) {
       int blocks = (int)std::min<int64_t>(BIN_BLOCKS, std::max<int64_t>(1, (n + 255) / 256));
@@ -188,8 +191,13 @@ __device__ __forceinline__ void spline_line(int J, int64_t base, int64_t stride,
 
 __global__ void __launch_bounds__(256)
 k_lattice(int Jx, int Jy, int nbx, const int32_t* bins, const double* areas, double hww,
-          const double* cp, double* C) {
+          const double* cp, double* C, int32_t* zero_bins, int n_zero,
+          unsigned long long* zero_word) {
   const int nn = Jx * Jy;
+  // housekeeping that would otherwise be launches of their own: clear the OTHER density
+  // field's bins for their next use, and the N.max() accumulator
+  for (int k = threadIdx.x; k < n_zero; k += blockDim.x) zero_bins[k] = 0;
+  if (zero_word && threadIdx.x == 0) *zero_word = 0ull;
   double* V = C;
   double* Mx = C + nn;
   double* My = C + 2 * (int64_t)nn;
@@ -219,6 +227,11 @@ k_lattice(int Jx, int Jy, int nbx, const int32_t* bins, const double* areas, dou
 // node densities (from bins, or given directly) and the spline coefficients
 int gnx_l_spline(gnx_state* h, const int32_t* d_bins, GnxSpline* spl,
                  const double* d_nodes_override) {
+  return gnx_l_spline_z(h, d_bins, spl, d_nodes_override, false);
+}
+
+int gnx_l_spline_z(gnx_state* h, const int32_t* d_bins, GnxSpline* spl,
+                   const double* d_nodes_override, bool housekeeping) {
   const GnxLattice& L = h->lat;
   const int64_t nn = (int64_t)L.Jx * L.Jy;
   double* V = spl->c;
@@ -226,8 +239,19 @@ int gnx_l_spline(gnx_state* h, const int32_t* d_bins, GnxSpline* spl,
     HIPCHK(hipMemcpyAsync(V, d_nodes_override, nn * sizeof(double), hipMemcpyDeviceToDevice,
                           h->stream));
   if (nn <= 65536) {
+    // single-GPU step: the lattice kernel of one field clears the other field's bins
+    int32_t* zb = nullptr;
+    int other = -1;
+    if (housekeeping && !d_nodes_override) {
+      other = (d_bins == h->bins_P) ? 0 : 1;
+      zb = other ? h->bins_P : h->bin_partials;
+    }
     hipLaunchKernelGGL(k_lattice, dim3(1), dim3(256), 0, h->stream, L.Jx, L.Jy, L.nbx,
-                       d_nodes_override ? nullptr : d_bins, L.areas, L.hww, L.cprime, V);
+                       d_nodes_override ? nullptr : d_bins, L.areas, L.hww, L.cprime, V, zb,
+                       zb ? L.nbx * L.nby : 0,
+                       (housekeeping && spl == &h->spl_N) ? h->nmax_bits : nullptr);
+    if (zb) h->bins_zeroed[other] = true;
+    if (housekeeping && spl == &h->spl_N) h->nmax_zeroed = true;
     HIPCHK(hipGetLastError());
     spl->valid = true;
     return 0;
@@ -255,7 +279,7 @@ int gnx_l_density(gnx_state* h, int64_t n, const float* d_x, const float* d_y, G
   gnx_time_begin(h);
   int32_t* bins = (spl == &h->spl_P) ? h->bins_P : h->bin_partials;
   if (!d_nodes_override) GNXCHK(gnx_l_bins(h, n, d_x, d_y, nullptr, bins));
-  GNXCHK(gnx_l_spline(h, bins, spl, d_nodes_override));
+  GNXCHK(gnx_l_spline_z(h, bins, spl, d_nodes_override, !d_nodes_override));
   gnx_time_end(h, GNX_K_DENSITY, (double)n * 8.0);
   return 0;
 }
@@ -431,7 +455,9 @@ int gnx_l_death_probs(gnx_state* h, bool with_selection) {
   SplineC SN = make_splinec(h, h->spl_N), SP = make_splinec(h, h->spl_P);
   int64_t cells = (int64_t)h->cfg.W * h->cfg.H;
   gnx_time_begin(h);
-  HIPCHK(hipMemsetAsync(h->nmax_bits, 0, sizeof(unsigned long long), h->stream));
+  if (!h->nmax_zeroed)
+    HIPCHK(hipMemsetAsync(h->nmax_bits, 0, sizeof(unsigned long long), h->stream));
+  h->nmax_zeroed = false;
   hipLaunchKernelGGL(k_nmax, dim3(gnx_grid(cells, 256, 2048)), dim3(256), 0, h->stream, SN,
                      h->cfg.W, h->cfg.H, h->nmax_bits);
   DeathP Q;
@@ -685,7 +711,7 @@ k_diff_stats(int64_t cells, const int32_t* now, const int32_t* prev, double* red
   }
 }
 
-int gnx_l_spatial_diff(gnx_state* h, double* mean, double* sd) {
+int gnx_l_spatial_diff(gnx_state* h, double* mean, double* sd, double* sums) {
   int64_t cells = (int64_t)h->cfg.W * h->cfg.H;
   int nowi = h->counts_cur ^ 1, prev = h->counts_cur;
   if (!h->counts_init) {
@@ -704,8 +730,12 @@ int gnx_l_spatial_diff(gnx_state* h, double* mean, double* sd) {
   HIPCHK(hipStreamSynchronize(h->stream));
   double m = r[0] / (double)cells;
   double var = r[1] / (double)cells - m * m;
-  *mean = m;
-  *sd = var > 0 ? sqrt(var) : 0.0;
+  if (mean) *mean = m;
+  if (sd) *sd = var > 0 ? sqrt(var) : 0.0;
+  if (sums) {                 // integers (sums of count differences and of their squares)
+    sums[0] = r[0];
+    sums[1] = r[1];
+  }
   h->counts_cur = nowi;
   return 0;
 }

@@ -7,6 +7,13 @@
 #include "gnx_tb.h"
 
 // ---------------------------------------------------------------- helpers
+// bits that hold every resident id (ids are handed out upwards from max_id)
+static int gnx_id_bits(const gnx_state* h) {
+  int b = 1;
+  while (b < 40 && (h->max_id >> b) != 0) ++b;
+  return b;
+}
+
 __device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m));
@@ -106,6 +113,11 @@ struct MoveP {
   int inc_age, apply;
   long long step;
   unsigned long long seed;
+  // sort keys of the step's cell sort (gnx_step: the sort follows the movement at once)
+  uint64_t* key;
+  int32_t* idx;
+  double inv_cs;
+  int ncx, ncy, idbits;
 };
 
 __constant__ float c_queen_dirs[8] = {-2.35619449019234492885f, -1.57079632679489661923f,
@@ -273,6 +285,12 @@ k_move(MoveP P, GnxSoA s, const float* rast, const float* inj_theta, const float
   int cx = (int)nx, cy = (int)ny;
   for (int l = 0; l < P.n_layers; ++l)
     s.e[(int64_t)l * P.cap + i] = rast[((int64_t)l * P.H + cy) * P.W + cx];
+  if (P.key) {
+    const int hx = min(P.ncx - 1, (int)((double)nx * P.inv_cs));
+    const int hy = min(P.ncy - 1, (int)((double)ny * P.inv_cs));
+    P.key[i] = ((uint64_t)(hy * P.ncx + hx) << P.idbits) | (uint64_t)id;
+    P.idx[i] = (int32_t)i;
+  }
 }
 
 int gnx_l_move(gnx_state* h, bool inc_age, const float* inj_theta, const float* inj_dist,
@@ -302,6 +320,15 @@ int gnx_l_move(gnx_state* h, bool inc_age, const float* inj_theta, const float* 
   P.apply = apply ? 1 : 0;
   P.step = h->step;
   P.seed = c.seed;
+  // inside gnx_step the cell sort comes next: write its keys here (k_keys otherwise)
+  const bool with_keys = h->move_writes_keys && apply && !inj_theta;
+  P.key = with_keys ? h->key64[0] : nullptr;
+  P.idx = h->perm[0];
+  P.inv_cs = h->inv_cs;
+  P.ncx = h->ncx;
+  P.ncy = h->ncy;
+  P.idbits = gnx_id_bits(h);
+  h->keys_fresh = with_keys;
   gnx_time_begin(h);
   hipLaunchKernelGGL(k_move, dim3(gnx_grid(h->N, 256)), dim3(256), 0, h->stream, P,
                      h->soa[h->cur], h->rast, inj_theta, inj_dist, out_theta, out_dist);
@@ -336,9 +363,18 @@ __global__ void k_keys(int64_t N, const float* x, const float* y, const int64_t*
 
 __global__ void k_permute(int64_t N, int64_t cap, const int32_t* perm, GnxSoA a, GnxSoA b,
                           int n_layers, int n_traits, int tbw, unsigned long long pair_seed,
-                          uint32_t* tag, uint4* cand) {
+                          uint32_t* tag, uint4* cand, const uint64_t* key, int idbits,
+                          int32_t* cell_start, int ncells) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
+  {
+    // cell_start[c] = first sorted slot whose cell >= c; cell_start[ncells] = N
+    const int k = (int)(key[i] >> idbits);
+    const int prev = (i == 0) ? -1 : (int)(key[i - 1] >> idbits);
+    for (int c = prev + 1; c <= k; ++c) cell_start[c] = (int32_t)i;
+    if (i == N - 1)
+      for (int c = k + 1; c <= ncells; ++c) cell_start[c] = (int32_t)N;
+  }
   int64_t j = perm[i];
   b.x[i] = a.x[j];
   b.y[i] = a.y[j];
@@ -358,25 +394,6 @@ __global__ void k_permute(int64_t N, int64_t cap, const int32_t* perm, GnxSoA a,
   for (int w = 0; w < tbw; ++w) b.tb[i * tbw + w] = a.tb[j * tbw + w];     // tbw = 2 * TW
 }
 
-// cell_start[c] = first sorted slot whose key >= c; cell_start[ncells] = N
-__global__ void k_cell_bounds(int64_t N, const uint64_t* key, int idbits, int32_t* cell_start,
-                              int ncells) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  int k = (int)(key[i] >> idbits);
-  int prev = (i == 0) ? -1 : (int)(key[i - 1] >> idbits);
-  for (int c = prev + 1; c <= k; ++c) cell_start[c] = (int32_t)i;
-  if (i == N - 1)
-    for (int c = k + 1; c <= ncells; ++c) cell_start[c] = (int32_t)N;
-}
-
-// bits that hold every resident id (ids are handed out upwards from max_id)
-static int gnx_id_bits(const gnx_state* h) {
-  int b = 1;
-  while (b < 40 && (h->max_id >> b) != 0) ++b;
-  return b;
-}
-
 // Sort of the whole SoA by (hash cell, id); cell size >= mating radius.
 int gnx_l_sort_by_cell(gnx_state* h) {
   int64_t N = h->N;
@@ -387,8 +404,10 @@ int gnx_l_sort_by_cell(gnx_state* h) {
   GnxSoA a = h->soa[h->cur], b = h->soa[h->cur ^ 1];
   const int idbits = gnx_id_bits(h);
   gnx_time_begin(h);
-  hipLaunchKernelGGL(k_keys, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, a.x, a.y, a.id,
-                     h->inv_cs, h->ncx, h->ncy, idbits, h->key64[0], h->perm[0]);
+  if (!h->keys_fresh)
+    hipLaunchKernelGGL(k_keys, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, a.x, a.y, a.id,
+                       h->inv_cs, h->ncx, h->ncy, idbits, h->key64[0], h->perm[0]);
+  h->keys_fresh = false;
   GNXCHK(gnx_prim_sort64_bits(h->sort64_tmp, h->sort64_tmp_bytes, h->key64[0], h->key64[1],
                               h->perm[0], h->perm[1], (size_t)N, idbits + h->key_bits,
                               h->stream));
@@ -396,9 +415,8 @@ int gnx_l_sort_by_cell(gnx_state* h) {
   gnx_time_begin(h);
   hipLaunchKernelGGL(k_permute, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, c.cap_inds,
                      h->perm[1], a, b, c.n_layers, c.n_traits, a.tb ? 2 * h->TW : 0,
-                     gnx_pair_seed(c.seed, h->step), h->tag, (uint4*)h->cand);
-  hipLaunchKernelGGL(k_cell_bounds, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N,
-                     h->key64[1], idbits, h->cell_start, h->ncx * h->ncy);
+                     gnx_pair_seed(c.seed, h->step), h->tag, (uint4*)h->cand, h->key64[1], idbits,
+                     h->cell_start, h->ncx * h->ncy);
   gnx_time_end(h, GNX_K_PERMUTE,
                (double)N * 2.0 * (33.0 + 4.0 * c.n_layers + 4.0 * c.n_traits + 16.0 * h->TW));
   HIPCHK(hipGetLastError());
@@ -727,12 +745,16 @@ k_pair_flags(PairP P, GnxSoA s, int32_t* flag2, int32_t* cnt) {
   if (threadIdx.x == 0) cnt[blockIdx.x] = tot;
 }
 
-// pairs in slot order, their midpoints (n_pairs density, ops/demography.py:69-70) and the
-// sort keys (focal id) that put them in the order offspring ids are handed out in
+// Pairs in slot order, i.e. in the CANONICAL (hash cell, id) order of their focal individual
+// - the order offspring ids are handed out in: it depends on positions and ids only, not
+// on storage order or on how the landscape is tiled (the reference's own order is that of
+// a Python set, i.e. unspecified: ops/mating.py:63).  Also their midpoints (n_pairs
+// density, ops/demography.py:69-70) and, for the tiles' merge of their pair lists, the
+// order key (cell << 40 | id) of every pair.
 __global__ void __launch_bounds__(256)
 k_pair_compact(int64_t N, const int32_t* focal, const int32_t* mate, const int32_t* flag2,
-               const int32_t* blk_off, const float* x, const float* y, const int64_t* id,
-               int32_t* pairs, float* mid_x, float* mid_y, uint64_t* key, int32_t* idx) {
+               const int32_t* blk_off, const float* x, const float* y, const uint64_t* popkey,
+               int idbits, int32_t* pairs, float* mid_x, float* mid_y, uint64_t* key) {
   __shared__ int lds[16];
   const int64_t base = (int64_t)blockIdx.x * GNX_CB;
   bool f[4];
@@ -755,18 +777,9 @@ k_pair_compact(int64_t N, const int32_t* focal, const int32_t* mate, const int32
     pairs[2 * p + 1] = m;
     mid_x[p] = (x[fo] + x[m]) / 2.0f;
     mid_y[p] = (y[fo] + y[m]) / 2.0f;
-    key[p] = (uint64_t)id[fo];
-    idx[p] = p;
+    const uint64_t k = popkey[i];
+    key[p] = ((k >> idbits) << 40) | (k & ((1ull << idbits) - 1ull));
   }
-}
-
-__global__ void k_pair_reorder(int64_t P, const int32_t* perm, const int32_t* pairs,
-                               int32_t* pairs2) {
-  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= P) return;
-  int p = perm[q];
-  pairs2[2 * q] = pairs[2 * p];
-  pairs2[2 * q + 1] = pairs[2 * p + 1];
 }
 
 // panmixia (structs/species.py:2178-2194): n ~ Binomial(N, b) pairs, both
@@ -822,26 +835,15 @@ int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out) 
            h->step, h->cfg.seed};
   hipLaunchKernelGGL(k_pair_flags, dim3(nb), dim3(256), 0, h->stream, pp, s, h->flag2, h->blk_cnt);
   GNXCHK(gnx_block_scan(h, 1, N, h->blk_cnt, h->blk_off, -1, nullptr, nullptr, h->h_pin_dev + 4));
+  // (the population was sorted by gnx_l_sort_by_cell with this idbits: max_id has not moved)
   hipLaunchKernelGGL(k_pair_compact, dim3(nb), dim3(256), 0, h->stream, N, focal, h->mate,
-                     h->flag2, h->blk_off, s.x, s.y, s.id, h->pairs, h->mid_x, h->mid_y,
-                     h->key64[0], h->perm[0]);
+                     h->flag2, h->blk_off, s.x, s.y, h->key64[1], gnx_id_bits(h), h->pairs,
+                     h->mid_x, h->mid_y, h->key64[0]);
   gnx_time_end(h, GNX_K_PAIRS, (double)N * 40.0);
+  HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
   h->n_pairs = h->h_pin[4];
   *n_pairs_out = h->n_pairs;
-  // Order the pairs by the id of their focal individual: offspring ids are then
-  // handed out in an order that does not depend on slot order or on how the
-  // landscape is tiled over GPUs (the reference's own order is that of a Python
-  // set, i.e. unspecified: ops/mating.py:63).
-  const int64_t P = h->n_pairs;
-  if (P > 1) {
-    GNXCHK(gnx_prim_sort64_bits(h->sort64_tmp, h->sort64_tmp_bytes, h->key64[0], h->key64[1],
-                                h->perm[0], h->perm[1], (size_t)P, gnx_id_bits(h), h->stream));
-    hipLaunchKernelGGL(k_pair_reorder, dim3(gnx_grid(P, 256)), dim3(256), 0, h->stream, P,
-                       h->perm[1], h->pairs, h->pairs2);
-    std::swap(h->pairs, h->pairs2);
-    HIPCHK(hipGetLastError());
-  }
   if (h->xo_launch_policy == 2) GNXCHK(gnx_xo_launch_pending(h));
   return 0;
 }

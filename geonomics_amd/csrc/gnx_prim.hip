@@ -6,9 +6,15 @@
 #include "gnx_internal.h"
 #include "gnx_compact.h"
 
+// rocPRIM's radix_sort switches to a merge sort below 2^20 items: ~22 launches of a few
+// microseconds for the 2 x 10^5 pairs of a step, where Onesweep over the ~24 significant
+// id bits takes 5.  Merge sort only for inputs that fit a few blocks.
+using gnx_sort_config = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                   rocprim::default_config, 8192>;
+
 int gnx_prim_sort_bytes(size_t n, int bits, size_t* bytes) {
   *bytes = 0;
-  HIPCHK(rocprim::radix_sort_pairs(nullptr, *bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+  HIPCHK(rocprim::radix_sort_pairs<gnx_sort_config>(nullptr, *bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
                                    (const int32_t*)nullptr, (int32_t*)nullptr, n, 0, bits,
                                    (hipStream_t)0));
   return 0;
@@ -16,7 +22,7 @@ int gnx_prim_sort_bytes(size_t n, int bits, size_t* bytes) {
 
 int gnx_prim_sort(void* tmp, size_t bytes, const uint32_t* kin, uint32_t* kout, const int32_t* vin,
                   int32_t* vout, size_t n, int bits, hipStream_t s) {
-  HIPCHK(rocprim::radix_sort_pairs(tmp, bytes, kin, kout, vin, vout, n, 0, bits, s));
+  HIPCHK(rocprim::radix_sort_pairs<gnx_sort_config>(tmp, bytes, kin, kout, vin, vout, n, 0, bits, s));
   return 0;
 }
 
@@ -35,7 +41,7 @@ int gnx_prim_scan(void* tmp, size_t bytes, const int32_t* in, int32_t* out, size
 
 int gnx_prim_sort64_bytes(size_t n, size_t* bytes) {
   *bytes = 0;
-  HIPCHK(rocprim::radix_sort_pairs(nullptr, *bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr,
+  HIPCHK(rocprim::radix_sort_pairs<gnx_sort_config>(nullptr, *bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr,
                                    (const int32_t*)nullptr, (int32_t*)nullptr, n, 0, 64,
                                    (hipStream_t)0));
   return 0;
@@ -43,7 +49,7 @@ int gnx_prim_sort64_bytes(size_t n, size_t* bytes) {
 
 int gnx_prim_sort64(void* tmp, size_t bytes, const uint64_t* kin, uint64_t* kout,
                     const int32_t* vin, int32_t* vout, size_t n, hipStream_t s) {
-  HIPCHK(rocprim::radix_sort_pairs(tmp, bytes, kin, kout, vin, vout, n, 0, 64, s));
+  HIPCHK(rocprim::radix_sort_pairs<gnx_sort_config>(tmp, bytes, kin, kout, vin, vout, n, 0, 64, s));
   return 0;
 }
 
@@ -51,7 +57,7 @@ int gnx_prim_sort64(void* tmp, size_t bytes, const uint64_t* kin, uint64_t* kout
 int gnx_prim_sort64_bits(void* tmp, size_t bytes, const uint64_t* kin, uint64_t* kout,
                          const int32_t* vin, int32_t* vout, size_t n, int end_bit,
                          hipStream_t s) {
-  HIPCHK(rocprim::radix_sort_pairs(tmp, bytes, kin, kout, vin, vout, n, 0, end_bit, s));
+  HIPCHK(rocprim::radix_sort_pairs<gnx_sort_config>(tmp, bytes, kin, kout, vin, vout, n, 0, end_bit, s));
   return 0;
 }
 

@@ -343,19 +343,13 @@ extern "C" int gnx_tile_pairs(gnx_state* h, int32_t burn, int64_t* n_pairs, int6
   return 0;
 }
 
-// focal ids (ascending) and birth counts of the local pair list
+// order keys (ascending: hash cell << 40 | id of the focal individual) and birth counts of
+// the local pair list
 extern "C" int gnx_tile_pair_info(gnx_state* h, int64_t* focal_ids, int32_t* n_births) {
   int64_t P = h->n_pairs;
   if (P == 0) return 0;
-  GnxSoA s = h->soa[h->cur];
-  // gnx_l_find_pairs left the sorted focal ids in key64[1] when it sorted (P > 1)
-  if (P > 1) {
-    GNXCHK(gnx_d2h(h, focal_ids, h->key64[1], P * sizeof(int64_t)));
-  } else {
-    int32_t slot = 0;
-    GNXCHK(gnx_d2h(h, &slot, h->pairs, sizeof(int32_t)));
-    GNXCHK(gnx_d2h(h, focal_ids, s.id + slot, sizeof(int64_t)));
-  }
+  // gnx_l_find_pairs left the pairs' order keys in key64[0]
+  GNXCHK(gnx_d2h(h, focal_ids, h->key64[0], P * sizeof(int64_t)));
   if (h->sp.n_births_fixed)
     for (int64_t p = 0; p < P; ++p) n_births[p] = (int32_t)h->sp.n_births_lambda;
   else
@@ -373,6 +367,7 @@ extern "C" int gnx_get_bins(gnx_state* h, int32_t which, int32_t* out) {
 extern "C" int gnx_set_bins(gnx_state* h, int32_t which, const int32_t* in) {
   size_t nb = (size_t)h->lat.nbx * h->lat.nby;
   GNXCHK(gnx_h2d(h, which ? h->bins_P : h->bin_partials, in, nb * sizeof(int32_t)));
+  h->bins_zeroed[which ? 1 : 0] = false;
   return 0;
 }
 
@@ -913,12 +908,8 @@ extern "C" int gnx_tile_import_ghosts_dev(gnx_state* h, int64_t n, const void* r
   return import_device(h, n, (const gnx_ind_rec*)rec, nullptr, nullptr, 1);
 }
 
-// focal ids (ascending, int64 [P]) and birth counts (int32 [P]; null when every
+// order keys (ascending, int64 [P]) and birth counts (int32 [P]; null when every
 // pair has the fixed n_births) of the local pair list, on the device
-__global__ void k_one_focal(const int32_t* pairs, const int64_t* id, uint64_t* out) {
-  out[0] = (uint64_t)id[pairs[0]];
-}
-
 extern "C" int gnx_tile_pair_ptrs(gnx_state* h, int64_t* n_pairs, void** focal_ids,
                                   void** n_births) {
   const int64_t P = h->n_pairs;
@@ -926,11 +917,8 @@ extern "C" int gnx_tile_pair_ptrs(gnx_state* h, int64_t* n_pairs, void** focal_i
   *focal_ids = nullptr;
   *n_births = nullptr;
   if (P == 0) return 0;
-  if (P == 1)     // gnx_l_find_pairs sorts (and fills key64[1]) only when P > 1
-    hipLaunchKernelGGL(k_one_focal, dim3(1), dim3(1), 0, h->stream, h->pairs,
-                       h->soa[h->cur].id, h->key64[1]);
   HIPCHK(hipStreamSynchronize(h->stream));
-  *focal_ids = h->key64[1];
+  *focal_ids = h->key64[0];
   if (!h->sp.n_births_fixed) *n_births = h->nbirths;
   return 0;
 }

@@ -394,8 +394,9 @@ class TiledStepper:
         self._tick('  halo import')
 
     def _offspring_dev(self, burn):
-        """pair order on the device: all-gather the focal ids, searchsorted, and
-        hand the offsets to the library without leaving GPU memory"""
+        """pair order on the device: all-gather the pairs' order keys (hash cell << 40 |
+        focal id, ascending on every tile), searchsorted, and hand the offsets to the
+        library without leaving GPU memory"""
         import torch
         dev = self.shard.dev
         P, p_ids, p_nb = dev.tile_pair_ptrs()
@@ -490,10 +491,11 @@ class TiledStepper:
         self.shard.import_ghosts(ghosts)
 
     def _pair_offsets(self):
-        """Global offspring offset of every local pair: pairs are ordered by
-        focal id over ALL tiles (each tile's list is already sorted), births are
-        numbered in that order.  offset(v) = sum over tiles of the births of that
-        tile's pairs with focal id < v (searchsorted on the comm device)."""
+        """Global offspring offset of every local pair: pairs are ordered by their key
+        (hash cell << 40 | focal id: the canonical order of the cell-sorted population)
+        over ALL tiles (each tile's list is already sorted), births are numbered in that
+        order.  offset(v) = sum over tiles of the births of that tile's pairs with
+        key < v (searchsorted on the comm device)."""
         import torch
         ids, nb = self.shard.pair_info()
         if self.comm.world == 1:        # one tile: the local order is the global order

@@ -143,9 +143,15 @@ class TiledSpecies(Species):
 
     # -- burn-in ---------------------------------------------------------------------------
     def _spatial_update(self):
-        m, s = self._dev.spatial_diff_stats()
+        # offspring may have dispersed across a tile border since the step's migration: hand
+        # them over first, so that a tile's count raster is non-zero inside its own region
+        # only; the integer sums then add exactly over the tiles and mean and std are the
+        # single-GPU run's to the last bit (the burn-in tests compare p-values with
+        # thresholds: a last-bit difference can end the burn-in a step earlier or later)
+        self._stepper._migrate()
+        a, b = self._dev.spatial_diff_sums()
         cells = float(self._land_dim[0] * self._land_dim[1])
-        tot = self._comm.allreduce_sum(np.array([m * cells, (s * s + m * m) * cells]))
+        tot = self._comm.allreduce_sum(np.array([a, b]))
         mean = tot[0] / cells
         var = tot[1] / cells - mean * mean
         self._burnin_spat_stats['mean'].append(float(mean))

@@ -222,6 +222,9 @@ int gnx_download_raster(gnx_state* h, int32_t which, double* dst);
 /* burn-in spatial tester (sim/burnin.py:44-59): updates the per-cell count
  * raster and returns mean and std of (counts_now - counts_prev)             */
 int gnx_spatial_diff_stats(gnx_state* h, double* mean, double* std);
+/* the same update, returning the sums behind them (integers: sum of the per-cell count
+ * differences and of their squares), which add exactly over the tiles of a tiled run  */
+int gnx_spatial_diff_sums(gnx_state* h, double* sum, double* sum_sq);
 
 /* ---- operator-level entry points (parity tests; explicit random inputs) -- */
 /* ops/movement.py:74-92 with injected direction/distance draws              */
@@ -283,7 +286,7 @@ int gnx_tile_import(gnx_state* h, int64_t n, const gnx_ind_rec* rec, const float
                     const uint64_t* geno);
 int gnx_tile_import_ghosts(gnx_state* h, int64_t n, const gnx_ind_rec* rec);
 int gnx_tile_pairs(gnx_state* h, int32_t burn, int64_t* n_pairs, int64_t* n_births);
-int gnx_tile_pair_info(gnx_state* h, int64_t* focal_ids /*[P] ascending*/,
+int gnx_tile_pair_info(gnx_state* h, int64_t* focal_ids /*[P] order keys (cell << 40 | id), ascending*/,
                        int32_t* n_births /*[P]*/);
 int gnx_density_bin_count(gnx_state* h);
 /* which: 0 = individuals, 1 = pair midpoints; int32 [bin_count]             */
@@ -322,7 +325,7 @@ int gnx_tile_staged_ptrs(gnx_state* h, void** rec, void** z, void** geno);
 int gnx_tile_import_dev(gnx_state* h, int64_t n, const void* rec, const void* z,
                         const void* geno);
 int gnx_tile_import_ghosts_dev(gnx_state* h, int64_t n, const void* rec);
-/* focal ids int64[P] ascending; n_births int32[P] or NULL when fixed          */
+/* order keys (cell << 40 | focal id) int64[P] ascending; n_births int32[P] or NULL    */
 int gnx_tile_pair_ptrs(gnx_state* h, int64_t* n_pairs, void** focal_ids, void** n_births);
 int gnx_tile_offspring_dev(gnx_state* h, int32_t burn, int64_t id_base,
                            const void* pair_goff_dev /*int64[P]*/, int64_t* n_requests);

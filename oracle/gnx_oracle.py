@@ -372,6 +372,15 @@ def cell_of(x, y, inv_cs, ncx, ncy):
     return cy * ncx + cx, cx, cy
 
 
+def pair_order_keys(x, y, ids, dim, radius):
+    """Order key of an individual as the focal one of a pair: (hash cell << 40) | id.  Pairs
+    are taken in ascending key order (the device's cell-sorted slot order), which fixes the
+    order offspring ids are handed out in - independent of storage order and of tiling."""
+    inv_cs, ncx, ncy = hash_grid(dim, radius if radius is not None else -1.0)
+    cell, _, _ = cell_of(x, y, inv_cs, ncx, ncy)
+    return (cell.astype(np.int64) << 40) | np.asarray(ids, dtype=np.int64)
+
+
 def mate_tries(M):
     """index draws before the exact scan: 4 * clamp(M // 8, 8, 2048)"""
     return 4 * np.clip(np.asarray(M, dtype=np.int64) >> 3, 8, 2048)

@@ -150,7 +150,10 @@ class OracleShard:
         f2 &= ~self.ghost
         i = np.nonzero(f2)[0]
         pr = np.stack([i, mate[i]], 1) if i.size else np.zeros((0, 2), np.int64)
-        pr = pr[np.argsort(s.id[pr[:, 0]], kind='stable')]
+        self.pair_keys = O.pair_order_keys(s.x[pr[:, 0]], s.y[pr[:, 0]], s.id[pr[:, 0]],
+                                           (s.W, s.H), p.mating_radius)
+        o = np.argsort(self.pair_keys, kind='stable')
+        pr, self.pair_keys = pr[o], self.pair_keys[o]
         self.pairs_ = pr
         if p.n_births_fixed:
             self.nb = np.full(len(pr), int(p.n_births_lambda), np.int64)
@@ -163,7 +166,7 @@ class OracleShard:
         return len(pr), int(self.nb.sum())
 
     def pair_info(self):
-        return self.s.id[self.pairs_[:, 0]].astype(np.int64), self.nb.astype(np.int32)
+        return self.pair_keys.astype(np.int64), self.nb.astype(np.int32)
 
     def get_bins(self, which):
         return self.bins[which]

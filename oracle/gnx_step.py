@@ -152,6 +152,7 @@ def find_pairs(s):
         ok &= (s.age[f] >= p.repro_age[0]) & (s.age[m] >= p.repro_age[1])
         if p.sexed:
             ok &= (s.sex[f] == 0) & (s.sex[m] == 1)
+        s.pair_trial = np.nonzero(ok)[0]          # the trial's slot orders the pair
         return np.stack([f[ok], m[ok]], 1)
     if p.mate_mode == 'uniform':
         mate = choose_mates_fast(s)
@@ -245,10 +246,14 @@ def death_probs(s, with_selection, VN, VP):
 
 def pop_dynamics(s, burn=False, with_selection=True):
     sort_by_cell(s)
+    s.pair_trial = None
     pairs = find_pairs(s)
-    # offspring ids follow the pairs' focal ids (tiling-independent order)
+    # offspring ids follow the canonical (hash cell, id) order of the pairs' focal
+    # individuals (of the trial's slot under panmixia): tiling-independent
     if len(pairs):
-        pairs = pairs[np.argsort(s.id[pairs[:, 0]], kind='stable')]
+        who = pairs[:, 0] if s.pair_trial is None else s.pair_trial
+        k = O.pair_order_keys(s.x[who], s.y[who], s.id[who], (s.W, s.H), s.p.mating_radius)
+        pairs = pairs[np.argsort(k, kind='stable')]
     VP = None
     if len(pairs):
         mx = (s.x[pairs[:, 0]] + s.x[pairs[:, 1]]) / F(2.0)

@@ -29,7 +29,8 @@ def _population(rng, n, W, H, id0=1000):
 def test_poisson_births_match_oracle(lam):
     """k_births: max(Poisson(lambda), 1) per pair from the focal parent's stream equals
     O.poisson_knuth on the same uniforms, pair by pair; offspring ids ascend in
-    (pair by focal id, birth) order (structs/species.py:614-648)"""
+    (pair, birth) order (structs/species.py:614-648), pairs in the canonical
+    (hash cell, id) order of their focal individual"""
     rng = np.random.RandomState(int(lam * 10))
     W = H = 48
     seed, step = 77, 9
@@ -44,7 +45,10 @@ def test_poisson_births_match_oracle(lam):
     B = child.size
     assert B > 300
     focal = par[:, 0]
-    assert (np.diff(focal) >= 0).all()                       # pairs ordered by focal id
+    pos = {int(i): k for k, i in enumerate(ids)}
+    who = np.array([pos[int(f)] for f in focal])
+    key = O.pair_order_keys(x[who], y[who], focal, (W, H), 3.0)
+    assert (np.diff(key) >= 0).all()                         # canonical pair order
     np.testing.assert_array_equal(child, ids.max() + 1 + np.arange(B))
     uf, counts = np.unique(focal, return_counts=True)
     exp = D.births_draws(seed, uf, step, lam)

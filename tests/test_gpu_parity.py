@@ -450,8 +450,8 @@ def test_panmixia_pairs():
     keep = D.keep_draws(21, ids_now, 2, 0.3)
     sel = keep & (f != m)
     exp = np.stack([f[sel], m[sel]], 1)
-    # the pair list is ordered by the focal individual's id (offspring-id order)
-    exp = exp[np.argsort(ids_now[exp[:, 0]], kind='stable')]
+    # the pair list is in trial order = the canonical (hash cell, id) slot order of the
+    # sorted population (the order offspring ids are handed out in)
     np.testing.assert_array_equal(pairs, exp)
     assert abs(len(pairs) - 0.3 * n) < 5 * np.sqrt(n * 0.3 * 0.7)
     dev.close()

@@ -8,6 +8,8 @@ TAG=${1:-r02}
 WL=${2:-c4_metric}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
+# only the contract's timed region: no second measurement in the other overlap mode
+export GNX_BENCH_NO_ALT=1
 OUT=$ROOT/gpurun_out
 cd "$ROOT"
 rm -rf $OUT/prof_$TAG $OUT/pmc_fetch_$TAG $OUT/pmc_write_$TAG
