@@ -45,7 +45,7 @@ EXPORTS = [
     'gnx_tile_import_dev', 'gnx_tile_import_ghosts_dev', 'gnx_tile_pair_ptrs',
     'gnx_tile_offspring_dev', 'gnx_tile_group_requests', 'gnx_tile_serve_gametes_dev',
     'gnx_tile_put_gametes_dev', 'gnx_tile_bins_ptr', 'gnx_set_k_raster', 'gnx_last_births', 'gnx_set_positions', 'gnx_n_slots', 'gnx_stats_ld_counts',
-    'gnx_set_defer_crossover', 'gnx_last_crossover_births', 'gnx_set_crossover_overlap', 'gnx_spatial_diff_sums',
+    'gnx_set_defer_crossover', 'gnx_last_crossover_births', 'gnx_set_crossover_overlap', 'gnx_spatial_diff_sums', 'gnx_last_crossover_jobs',
 ]
 
 
@@ -296,6 +296,16 @@ class Device:
         """False (default): the crossover keeps the chip, the next cell sort waits for it;
         True: a narrow crossover runs beside the whole next step"""
         self._chk(self.lib.gnx_set_crossover_overlap(self.h, int(bool(whole_step))))
+
+    def last_crossover_jobs(self):
+        """int32 [n, 4]: parent row, child half-row, path key, start homologue"""
+        n = C.c_int64()
+        self._chk(self.lib.gnx_last_crossover_jobs(self.h, None, 0, C.byref(n)))
+        out = np.zeros((n.value, 4), np.int32)
+        if n.value:
+            self._chk(self.lib.gnx_last_crossover_jobs(self.h, _ptr(out, C.c_int32), n.value,
+                                                       C.byref(n)))
+        return out
 
     @property
     def last_crossover_births(self):

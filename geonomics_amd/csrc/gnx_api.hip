@@ -233,7 +233,20 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
   for (int k = 0; k < 2; ++k) GNXCHK(alloc_soa(&h->soa[k], cap, cfg->n_layers, cfg->n_traits));
   GNXCHK(dalloc(&h->rast, (size_t)cfg->n_layers * cfg->W * cfg->H));
   if (cfg->L > 0) {
-    GNXCHK(dalloc(&h->G, (size_t)h->cfg.cap_rows * 2 * h->W64));
+    // spread the table over twice its size when the device has the room (GNX_ROW_SPREAD
+    // overrides: 1 = compact)
+    {
+      const size_t need = (size_t)h->cfg.cap_rows * 2 * h->W64 * 8;
+      size_t free_b = 0, total_b = 0;
+      (void)hipMemGetInfo(&free_b, &total_b);
+      int want = getenv("GNX_ROW_SPREAD") ? atoi(getenv("GNX_ROW_SPREAD")) : 2;
+      want = std::max(1, std::min(want, 8));
+      while (want > 1 && ((double)need * want > 0.6 * (double)free_b ||
+                          (double)h->cfg.cap_rows * want > 1.0e9))
+        --want;
+      h->row_spread = want;
+    }
+    GNXCHK(dalloc(&h->G, (size_t)h->cfg.cap_rows * h->row_spread * 2 * h->W64));
     GNXCHK(dalloc(&h->free_rows, (size_t)h->cfg.cap_rows));
   }
   for (int k = 0; k < 2; ++k) {
@@ -746,9 +759,13 @@ extern "C" int gnx_upload_genomes(gnx_state* h, const uint64_t* geno) {
   for (int64_t r = 0; r < h->N * 2; ++r)
     for (int l = h->cfg.L; l < h->W64 * 64; ++l)
       tmp[(size_t)r * h->W64 + (l >> 6)] &= ~(1ull << (l & 63));
-  HIPCHK(hipMemcpyAsync(h->G, tmp.data(), (size_t)h->N * rowb, hipMemcpyHostToDevice,
-                        h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  uint64_t* d_tmp = nullptr;
+  GNXCHK(dalloc(&d_tmp, (size_t)h->N * 2 * h->W64));
+  int rc = gnx_h2d(h, d_tmp, tmp.data(), (size_t)h->N * rowb);
+  if (!rc) rc = gnx_l_scatter_genomes(h, h->N, d_tmp, 0);
+  (void)hipStreamSynchronize(h->stream);
+  (void)hipFree(d_tmp);
+  GNXCHK(rc);
   GNXCHK(gnx_l_tb_from_rows(h, 0, h->N, nullptr, nullptr));
   if (h->cfg.n_traits > 0) GNXCHK(gnx_l_phenotype(h, 0, h->N));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -919,6 +936,20 @@ extern "C" int gnx_set_defer_crossover(gnx_state* h, int32_t on) {
 }
 
 extern "C" int64_t gnx_last_crossover_births(gnx_state* h) { return h->last_xo_births; }
+
+// the job list of the last crossover (kernel lab: tools/xo_lab.hip replays it)
+extern "C" int gnx_last_crossover_jobs(gnx_state* h, void* dst, int64_t max_jobs, int64_t* n_jobs) {
+  GNXCHK(gnx_xo_join(h));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const int buf = h->jobs_cur ^ 1;
+  int32_t n = 0;
+  HIPCHK(hipMemcpy(&n, h->n_jobs_dev[buf], sizeof(n), hipMemcpyDeviceToHost));
+  *n_jobs = n;
+  if (dst && n > 0)
+    HIPCHK(hipMemcpy(dst, h->jobs[buf], (size_t)std::min<int64_t>(n, max_jobs) * 16,
+                     hipMemcpyDeviceToHost));
+  return 0;
+}
 
 extern "C" int gnx_set_crossover_overlap(gnx_state* h, int32_t whole_step) {
   GNXCHK(gnx_xo_join(h));

@@ -118,7 +118,13 @@ struct gnx_state {
   int cur = 0;
 
   // genomes
-  uint64_t* G = nullptr;       // [cap_rows][2][W64]
+  // [cap_rows * row_spread][2][W64]: logical row r lives at physical row r * row_spread.
+  // The crossover's achieved bandwidth depends on how much of the HBM address space its
+  // rows cover (profiles/r02_xo_lab_footprint.txt: 5.6 TB/s on a 41-GB table, 6.1 TB/s on the
+  // same rows spread over 82 GB), so the table is spread when memory allows; `grow`, the
+  // free stack and the crossover jobs hold PHYSICAL row numbers.
+  uint64_t* G = nullptr;
+  int row_spread = 1;
   int32_t* free_rows = nullptr;
   int64_t n_free = 0;
   bool genomes_assigned = false;
@@ -370,6 +376,8 @@ int gnx_l_death_probs(gnx_state* h, bool with_selection);
 int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_out);
 int gnx_l_spatial_diff(gnx_state* h, double* mean, double* sd, double* sums = nullptr);
 int gnx_l_gather_genomes(gnx_state* h, int64_t n, const int64_t* d_slots, uint64_t* d_out);
+// genomes d_in [n][2][W64] -> the rows of slots [first_slot, first_slot + n)
+int gnx_l_scatter_genomes(gnx_state* h, int64_t n, const uint64_t* d_in, int64_t first_slot);
 
 // look-back-free compaction (gnx_compact.h): block counts cnt[k * blk_stride + b] ->
 // exclusive block offsets off[...], totals (and the flagged items below `mark`) to

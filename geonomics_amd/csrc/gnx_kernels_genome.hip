@@ -337,11 +337,12 @@ k_assign_genomes(int64_t N, int L, int W64, u64* G, const int32_t* grow,
   }
 }
 
-__global__ void k_assign_rows(int64_t N, int64_t cap_rows, int32_t* grow, int32_t* free_rows) {
+__global__ void k_assign_rows(int64_t N, int64_t cap_rows, int spread, int32_t* grow,
+                              int32_t* free_rows) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < N) grow[i] = (int32_t)i;
-  // free stack: rows N..cap_rows-1, popped from the top (highest index first)
-  if (i < cap_rows - N) free_rows[i] = (int32_t)(cap_rows - 1 - i);
+  if (i < N) grow[i] = (int32_t)(i * spread);
+  // free stack: rows N..cap_rows-1 (physical: x spread), popped from the top (highest first)
+  if (i < cap_rows - N) free_rows[i] = (int32_t)((cap_rows - 1 - i) * spread);
 }
 
 int gnx_l_assign_genomes(gnx_state* h, const int32_t* d_n_per_site) {
@@ -355,7 +356,7 @@ int gnx_l_assign_genomes(gnx_state* h, const int32_t* d_n_per_site) {
   GnxSoA s = h->soa[h->cur];
   int64_t m = N > c.cap_rows - N ? N : c.cap_rows - N;
   hipLaunchKernelGGL(k_assign_rows, dim3(gnx_grid(m, 256)), dim3(256), 0, h->stream, N, c.cap_rows,
-                     s.grow, h->free_rows);
+                     h->row_spread, s.grow, h->free_rows);
   h->n_free = c.cap_rows - N;
   if (N > 0 && d_n_per_site) {
     int64_t threads = (int64_t)h->W64 * 64;
@@ -400,6 +401,28 @@ __global__ void k_gather_genomes(int64_t n, int W16, const u64x2* G, const int32
     int64_t slot = slots ? slots[k] : k;
     out[g] = G[(int64_t)grow[slot] * 2 * W16 + c];
   }
+}
+
+__global__ void k_scatter_genomes(int64_t n, int W16, const u64x2* in, u64x2* G,
+                                  const int32_t* grow, int64_t first_slot) {
+  const int64_t total = n * 2 * (int64_t)W16;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+    int64_t k = g / (2 * W16);
+    int64_t c = g - k * 2 * W16;
+    G[(int64_t)grow[first_slot + k] * 2 * W16 + c] = in[g];
+  }
+}
+
+int gnx_l_scatter_genomes(gnx_state* h, int64_t n, const uint64_t* d_in, int64_t first_slot) {
+  if (n == 0) return 0;
+  GNXCHK(gnx_xo_join(h));
+  const int W16 = h->W64 / 2;
+  hipLaunchKernelGGL(k_scatter_genomes, dim3(gnx_grid(n * 2 * W16, 256, 256 * 32)), dim3(256), 0,
+                     h->stream, n, W16, (const u64x2*)d_in, (u64x2*)h->G, h->soa[h->cur].grow,
+                     first_slot);
+  HIPCHK(hipGetLastError());
+  return 0;
 }
 
 int gnx_l_gather_genomes(gnx_state* h, int64_t n, const int64_t* d_slots, uint64_t* d_out) {

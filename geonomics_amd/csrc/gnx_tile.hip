@@ -157,17 +157,6 @@ __global__ void k_unpack(int64_t N, int64_t n, int64_t cap, GnxSoA s, const gnx_
     s.e[(int64_t)l * cap + slot] = rast[((int64_t)l * H + cy) * W + cx];
 }
 
-__global__ void k_scatter_genomes(int64_t n, int W16, const u64x2* in, u64x2* G,
-                                  const int32_t* grow, int64_t first_slot) {
-  const int64_t total = n * 2 * (int64_t)W16;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
-    int64_t k = g / (2 * W16);
-    int64_t c = g - k * 2 * W16;
-    G[(int64_t)grow[first_slot + k] * 2 * W16 + c] = in[g];
-  }
-}
-
 template <typename T>
 static int dalloc_t(T** p, size_t n) {
   *p = nullptr;
@@ -296,10 +285,7 @@ static int import_common(gnx_state* h, int64_t n, const gnx_ind_rec* rec, const 
     }
     GNXCHK(dalloc_t(&d_g, (size_t)n * 2 * h->W64));
     GNXCHK(gnx_h2d(h, d_g, geno, (size_t)n * 2 * h->W64 * 8));
-    GNXCHK(gnx_xo_join(h));
-    const int W16 = h->W64 / 2;
-    hipLaunchKernelGGL(k_scatter_genomes, dim3(gnx_grid(n * 2 * W16, 256, 256 * 32)), dim3(256), 0,
-                       h->stream, n, W16, (const u64x2*)d_g, (u64x2*)h->G, s.grow, h->N);
+    GNXCHK(gnx_l_scatter_genomes(h, n, (const uint64_t*)d_g, h->N));
     h->n_free -= n;
     GNXCHK(gnx_l_tb_from_rows(h, h->N, n, nullptr, nullptr));
   }
@@ -883,10 +869,7 @@ static int import_device(gnx_state* h, int64_t n, const gnx_ind_rec* d_rec, cons
                      c.cap_inds, s, d_rec, (d_z && c.n_traits) ? d_z : nullptr, c.n_traits,
                      c.n_layers, h->rast, c.W, c.H, h->free_rows, h->n_free, rows ? 1 : 0, ghost);
   if (rows) {
-    GNXCHK(gnx_xo_join(h));
-    const int W16 = h->W64 / 2;
-    hipLaunchKernelGGL(k_scatter_genomes, dim3(gnx_grid(n * 2 * W16, 256, 256 * 32)), dim3(256), 0,
-                       h->stream, n, W16, (const u64x2*)d_g, (u64x2*)h->G, s.grow, h->N);
+    GNXCHK(gnx_l_scatter_genomes(h, n, (const uint64_t*)d_g, h->N));
     h->n_free -= n;
     GNXCHK(gnx_l_tb_from_rows(h, h->N, n, nullptr, nullptr));
   }

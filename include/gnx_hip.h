@@ -194,6 +194,9 @@ int gnx_set_defer_crossover(gnx_state* h, int32_t on);
  * sort waits for it - the crossover keeps its full rate.  1: a narrow crossover runs
  * beside the WHOLE next step - more individual-timesteps/s, a slower crossover.        */
 int gnx_set_crossover_overlap(gnx_state* h, int32_t whole_step);
+/* measurement: the job list of the last crossover, 16 bytes per gamete {parent row,
+ * child half-row, path, start homologue} (csrc/gnx_xo.h); tools/xo_lab.hip replays it   */
+int gnx_last_crossover_jobs(gnx_state* h, void* dst, int64_t max_jobs, int64_t* n_jobs);
 /* births whose genomes the last crossover wrote (== births when not deferred)          */
 int64_t gnx_last_crossover_births(gnx_state* h);
 int64_t gnx_step_index(gnx_state* h);

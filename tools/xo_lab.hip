@@ -152,25 +152,35 @@ int main(int argc, char** argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 30;
   const int B = argc > 2 ? atoi(argv[2]) : 218405;
   const std::string set = argc > 3 ? argv[3] : "all";
+  // optional: a job list dumped from a product run (tools/xo_trend.py <steps> <file>)
+  // replaces job kind 0 ("nat/rnd-dst"); kinds 1..3 are derived from it
+  const char* jobs_file = argc > 4 ? argv[4] : nullptr;
   const int L = 100000;
   const int W64 = ((L + 63) / 64 + 15) / 16 * 16, W16 = W64 / 2;       // 1568, 784
-  const int64_t rows = 1600000, live = 1200000;
+  const int64_t rows = 1601024 + 1024, live = 1200000;
   const int n_paths = 10000;
   const int n_jobs = 2 * B;
   printf("xo_lab: L=%d W16=%d rows=%lld births=%d jobs=%d reps=%d set=%s\n", L, W16,
          (long long)rows, B, n_jobs, reps, set.c_str());
+  // XO_LAB_SPREAD=k: logical row r lives at physical row r * k of a k times larger table
+  // (is the achieved bandwidth a matter of WHERE in HBM the rows sit?)
+  const int spread = getenv("XO_LAB_SPREAD") ? atoi(getenv("XO_LAB_SPREAD")) : 1;
   u64x2* G;
-  CHK(hipMalloc((void**)&G, (size_t)rows * 2 * W16 * 16));
-  hipLaunchKernelGGL(k_fill, dim3(256 * 16), dim3(256), 0, 0, rows * 2 * (int64_t)W64, (u64*)G, W64, L);
+  CHK(hipMalloc((void**)&G, (size_t)rows * spread * 2 * W16 * 16));
+  hipLaunchKernelGGL(k_fill, dim3(256 * 16), dim3(256), 0, 0, rows * spread * 2 * (int64_t)W64, (u64*)G, W64, L);
   CHK(hipDeviceSynchronize());
 
   std::mt19937_64 rng(12345);
   // which rows are live parents / free: a random subset, as after many generations
-  std::vector<int32_t> perm(rows);
-  for (int64_t i = 0; i < rows; ++i) perm[i] = (int32_t)i;
+  // XO_LAB_LO / XO_LAB_HI restrict the rows the synthetic jobs use to [lo, hi)
+  const int64_t lo_row = getenv("XO_LAB_LO") ? atoll(getenv("XO_LAB_LO")) : 0;
+  const int64_t hi_row = getenv("XO_LAB_HI") ? atoll(getenv("XO_LAB_HI")) : rows;
+  std::vector<int32_t> perm;
+  for (int64_t i = lo_row; i < hi_row; ++i) perm.push_back((int32_t)i);
   std::shuffle(perm.begin(), perm.end(), rng);
-  std::vector<int32_t> live_rows(perm.begin(), perm.begin() + live);
-  std::vector<int32_t> free_rows(perm.begin() + live, perm.end());      // random order
+  const int64_t n_live = (int64_t)perm.size() * 3 / 4;
+  std::vector<int32_t> live_rows(perm.begin(), perm.begin() + n_live);
+  std::vector<int32_t> free_rows(perm.begin() + n_live, perm.end());      // random order
   if ((int64_t)free_rows.size() < B) { printf("too many births\n"); return 1; }
   // recombination paths, rate 1/L
   std::vector<int32_t> bp_off(n_paths + 1, 0), bp_loci;
@@ -197,7 +207,7 @@ int main(int argc, char** argv) {
   std::vector<int32_t> par(2 * (size_t)B), key(2 * (size_t)B);
   std::vector<uint8_t> st(2 * (size_t)B);
   for (int64_t q = 0; q < 2 * (int64_t)B; ++q) {
-    par[q] = live_rows[rng() % live];
+    par[q] = live_rows[rng() % live_rows.size()];
     key[q] = (int32_t)(rng() % n_paths);
     st[q] = (uint8_t)(rng() & 1);
   }
@@ -223,8 +233,65 @@ int main(int argc, char** argv) {
   };
   const int NK = 4;
   GnxXoJob* d_jobs[NK];
+  std::vector<GnxXoJob> file_jobs;
+  if (jobs_file) {
+    FILE* f = fopen(jobs_file, "rb");
+    if (!f) { printf("cannot open %s\n", jobs_file); return 1; }
+    file_jobs.resize(n_jobs);
+    size_t got = fread(file_jobs.data(), sizeof(GnxXoJob), n_jobs, f);
+    fclose(f);
+    if ((int)got != n_jobs) { printf("job file holds %zu jobs, births*2 = %d\n", got, n_jobs); return 1; }
+    for (auto& j : file_jobs)
+      if (j.prow < 0 || j.prow >= rows || j.dst < 0 || j.dst >= 2 * rows || j.key < 0 ||
+          j.key >= n_paths) { printf("job out of range\n"); return 1; }
+    printf("replaying %d product jobs from %s\n", n_jobs, jobs_file);
+  }
   for (int kind = 0; kind < NK; ++kind) {
     auto jobs = make_jobs(kind);
+    if (jobs_file) {
+      // replay: [0] as dumped; [1] the product's parents, synthetic child rows; [2] synthetic
+      // parents, the product's child rows; [3] as dumped, shuffled
+      jobs = file_jobs;
+      std::vector<char> used(rows, 0);
+      for (auto& j : file_jobs) { used[j.prow] = 1; used[j.dst >> 1] = 1; }
+      std::vector<int32_t> unused;
+      for (int64_t r = 0; r < rows; ++r) if (!used[r]) unused.push_back((int32_t)r);
+      std::shuffle(unused.begin(), unused.end(), rng);
+      if (kind == 1)
+        for (size_t q = 0; q + 1 < jobs.size(); q += 2) {
+          const int32_t r = unused[(q / 2) % unused.size()];
+          jobs[q].dst = r * 2;
+          jobs[q + 1].dst = r * 2 + 1;
+        }
+      const char* alt = getenv("XO_LAB_ALT");
+      if (kind == 2 && !alt)
+        for (size_t q = 0; q < jobs.size(); ++q) jobs[q].prow = unused[(unused.size() - 1 - q % unused.size())];
+      if (kind == 3 && !alt) std::shuffle(jobs.begin(), jobs.end(), rng);
+      if (alt && kind == 2) {
+        // synthetic children drawn only from unused rows BELOW the product's highest row
+        std::vector<int32_t> low;
+        for (int32_t r : unused) if (r < 1400000) low.push_back(r);
+        for (size_t q = 0; q + 1 < jobs.size(); q += 2) {
+          const int32_t r = low[(q / 2) % low.size()];
+          jobs[q].dst = r * 2;
+          jobs[q + 1].dst = r * 2 + 1;
+        }
+      }
+      if (alt && kind == 3) {
+        // the product's children moved to the nearest unused row above them
+        std::vector<char> taken(rows, 0);
+        for (auto& j : file_jobs) taken[j.prow] = 1;
+        for (size_t q = 0; q + 1 < jobs.size(); q += 2) {
+          int64_t r = (jobs[q].dst >> 1) + 1;
+          while (r < rows && (used[r] || taken[r])) ++r;
+          if (r >= rows) r = jobs[q].dst >> 1;
+          taken[r] = 1;
+          jobs[q].dst = (int32_t)r * 2;
+          jobs[q + 1].dst = (int32_t)r * 2 + 1;
+        }
+      }
+    }
+    for (auto& j : jobs) { j.prow *= spread; j.dst = ((j.dst >> 1) * spread) * 2 + (j.dst & 1); }
     CHK(hipMalloc((void**)&d_jobs[kind], (size_t)n_jobs * sizeof(GnxXoJob)));
     CHK(hipMemcpy(d_jobs[kind], jobs.data(), (size_t)n_jobs * sizeof(GnxXoJob), hipMemcpyHostToDevice));
   }
@@ -234,8 +301,8 @@ int main(int argc, char** argv) {
   u64 *d_paths, *d_sum;
   {
     std::vector<int32_t> grow(rows + B);
-    for (int64_t i = 0; i < rows; ++i) grow[i] = (int32_t)i;
-    for (int k = 0; k < B; ++k) grow[rows + k] = free_rows[k];
+    for (int64_t i = 0; i < rows; ++i) grow[i] = (int32_t)(i * spread);
+    for (int k = 0; k < B; ++k) grow[rows + k] = free_rows[k] * spread;
     CHK(hipMalloc((void**)&d_grow, grow.size() * 4));
     CHK(hipMemcpy(d_grow, grow.data(), grow.size() * 4, hipMemcpyHostToDevice));
   }

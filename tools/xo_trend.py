@@ -23,6 +23,10 @@ for t in range(steps):
     if t % 10 == 0 or t < 5:
         print('%4d %8d %7d %9d  %6.3f  %5.2f' % (t, n0, b, dev.last_crossover_births, kt['ms'],
                                                  kt['bytes'] / max(kt['ms'], 1e-9) / 1e9), flush=True)
+jobs = dev.last_crossover_jobs()
+if len(sys.argv) > 2:
+    jobs.tofile(sys.argv[2])
+    print('wrote %d jobs to %s' % (len(jobs), sys.argv[2]))
 rows = dev.download(5 + 3)     # F_GROW
 print('rows: min %d max %d; mean |row[i+1]-row[i]| in slot order %.0f' % (
     rows.min(), rows.max(), np.abs(np.diff(rows.astype(np.int64))).mean()))
