@@ -261,8 +261,10 @@ def model_api_measure(cfg, name, steps, warmup=5):
     return out, mod
 
 
-def measured_copy_bandwidth(torch, nbytes=2 << 30, reps=5):
-    """read + write bytes / time of a 2-GiB device-to-device copy (GB/s)"""
+def measured_copy_bandwidth(torch, nbytes=16 << 30, reps=5):
+    """read + write bytes / time of a 16-GiB device-to-device copy (GB/s); the buffers are
+    large on purpose: on this part the rate of a streaming kernel grows with the span of
+    HBM it touches (profiles/r02_xo_lab_footprint.txt)"""
     try:
         a = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
         b = torch.empty_like(a)
