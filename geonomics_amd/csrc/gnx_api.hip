@@ -233,15 +233,17 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
   for (int k = 0; k < 2; ++k) GNXCHK(alloc_soa(&h->soa[k], cap, cfg->n_layers, cfg->n_traits));
   GNXCHK(dalloc(&h->rast, (size_t)cfg->n_layers * cfg->W * cfg->H));
   if (cfg->L > 0) {
-    // spread the table over twice its size when the device has the room (GNX_ROW_SPREAD
-    // overrides: 1 = compact)
+    // spread the table over up to four times its size when the device has the room
+    // (GNX_ROW_SPREAD overrides: 1 = compact).  2x is not enough to be safe: the rate then
+    // depends on where the driver happens to place the allocation (4.9 or 5.95 TB/s from one
+    // process to the next, profiles/r02_xo_lab_footprint.txt); 3x and 4x are steady.
     {
       const size_t need = (size_t)h->cfg.cap_rows * 2 * h->W64 * 8;
       size_t free_b = 0, total_b = 0;
       (void)hipMemGetInfo(&free_b, &total_b);
-      int want = getenv("GNX_ROW_SPREAD") ? atoi(getenv("GNX_ROW_SPREAD")) : 2;
+      int want = getenv("GNX_ROW_SPREAD") ? atoi(getenv("GNX_ROW_SPREAD")) : 4;
       want = std::max(1, std::min(want, 8));
-      while (want > 1 && ((double)need * want > 0.6 * (double)free_b ||
+      while (want > 1 && ((double)need * want > 0.75 * (double)free_b ||
                           (double)h->cfg.cap_rows * want > 1.0e9))
         --want;
       h->row_spread = want;

@@ -19,6 +19,11 @@ T = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 cfg = bench.WORKLOADS[name]
 W, H = cfg['W'], cfg['H']
 d = bench.model_api_params(cfg, name, T)
+# GNX_MODEL_BENCH_MATE=nearest|inverse: the non-default mate choices at the clumped equilibrium
+mode = os.environ.get('GNX_MODEL_BENCH_MATE', 'uniform')
+mating = d['comm']['species']['spp_0']['mating']
+mating['choose_nearest_mate'] = mode == 'nearest'
+mating['inverse_dist_mating'] = mode == 'inverse'
 os.environ.setdefault('GNX_CAP_FACTOR', '2.0')
 t0 = time.time()
 mod = gnx.make_model(d)
