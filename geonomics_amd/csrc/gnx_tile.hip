@@ -224,6 +224,7 @@ extern "C" int gnx_tile_export_migrants(gnx_state* h, int64_t* n_out) {
   if (*n_out > 0) {
     int64_t D = 0;
     GNXCHK(gnx_l_mortality(h, h->dead_in, &D));
+    HIPCHK(hipStreamSynchronize(h->stream));     // tile calls return with the stream idle
   }
   return 0;
 }
@@ -579,6 +580,7 @@ extern "C" int gnx_tile_die(gnx_state* h, int32_t burn, int32_t with_selection,
   GNXCHK(gnx_l_death_probs(h, with_selection != 0 && !burn));
   int64_t D = 0;
   GNXCHK(gnx_l_mortality(h, nullptr, &D));
+  HIPCHK(hipStreamSynchronize(h->stream));       // tile calls return with the stream idle
   h->last_deaths = D;
   return 0;
 }
@@ -720,6 +722,7 @@ extern "C" int gnx_tile_export_migrants_dev(gnx_state* h, int64_t* counts /*[R*C
   }
   int64_t D = 0;
   GNXCHK(gnx_l_mortality(h, h->dead_in, &D));
+  HIPCHK(hipStreamSynchronize(h->stream));       // tile calls return with the stream idle
   return 0;
 }
 

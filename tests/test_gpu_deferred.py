@@ -95,3 +95,30 @@ def test_genome_access_between_mate_and_die_materialises():
         np.testing.assert_array_equal(sa[k], sb[k], err_msg=k)
     a.close()
     b.close()
+
+
+def test_overlap_mode_and_table_spread_do_not_change_results(monkeypatch):
+    """how the crossover shares the GPU with the next step (gnx_set_crossover_overlap) and
+    where the genome rows sit in HBM (GNX_ROW_SPREAD) are scheduling / placement choices:
+    the population after 10 steps is the same bit for bit"""
+    ref, nat = _model(True, seed=23)
+    alt, _ = _model(True, seed=23)
+    alt.set_crossover_overlap(True)
+    monkeypatch.setenv('GNX_ROW_SPREAD', '1')
+    compact, _ = _model(True, seed=23)
+    monkeypatch.delenv('GNX_ROW_SPREAD')
+    for t in range(10):
+        for dev in (ref, alt, compact):
+            dev.step(False, True)
+        assert ref.counts() == alt.counts() == compact.counts(), t
+    s0 = _state(ref, nat)
+    for dev in (alt, compact):
+        s1 = _state(dev, nat)
+        for k in s0:
+            np.testing.assert_array_equal(s0[k], s1[k], err_msg=k)
+    # the spread table really is spread: rows are multiples of the stride
+    r_ref, r_cmp = ref.download(nat.F_GROW), compact.download(nat.F_GROW)
+    stride = np.gcd.reduce(r_ref[r_ref > 0])
+    assert stride >= 2 and np.gcd.reduce(r_cmp[r_cmp > 0]) == 1
+    for dev in (ref, alt, compact):
+        dev.close()
