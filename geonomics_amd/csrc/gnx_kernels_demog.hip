@@ -189,19 +189,33 @@ __device__ __forceinline__ void spline_line(int J, int64_t base, int64_t stride,
     M[base + k * stride] -= cp[k] * M[base + (k + 1) * stride];
 }
 
+// use_lds: the four coefficient planes and the Thomas factors live in LDS while the
+// (dependent, one line per thread) sweeps run - a global round trip per element of a
+// 43-long chain is what the kernel's time was - and are written out once at the end.
 __global__ void __launch_bounds__(256)
 k_lattice(int Jx, int Jy, int nbx, const int32_t* bins, const double* areas, double hww,
-          const double* cp, double* C, int32_t* zero_bins, int n_zero,
-          unsigned long long* zero_word) {
+          const double* cp_g, double* C, int32_t* zero_bins, int n_zero,
+          unsigned long long* zero_word, int use_lds) {
+  extern __shared__ double lat_lds[];
   const int nn = Jx * Jy;
   // housekeeping that would otherwise be launches of their own: clear the OTHER density
   // field's bins for their next use, and the N.max() accumulator
   for (int k = threadIdx.x; k < n_zero; k += blockDim.x) zero_bins[k] = 0;
   if (zero_word && threadIdx.x == 0) *zero_word = 0ull;
-  double* V = C;
-  double* Mx = C + nn;
-  double* My = C + 2 * (int64_t)nn;
-  double* Mxy = C + 3 * (int64_t)nn;
+  double* W = use_lds ? lat_lds : C;
+  double* V = W;
+  double* Mx = W + nn;
+  double* My = W + 2 * (int64_t)nn;
+  double* Mxy = W + 3 * (int64_t)nn;
+  const double* cp = cp_g;
+  if (use_lds) {
+    double* cpl = lat_lds + 4 * (int64_t)nn;
+    const int Jm = max(Jx, Jy);
+    for (int k = threadIdx.x; k <= Jm; k += blockDim.x) cpl[k] = cp_g[k];
+    cp = cpl;
+    if (!bins)
+      for (int idx = threadIdx.x; idx < nn; idx += blockDim.x) V[idx] = C[idx];
+  }
   if (bins) {
     for (int idx = threadIdx.x; idx < nn; idx += blockDim.x) {
       const int i = idx / Jx, j = idx - i * Jx;
@@ -222,6 +236,10 @@ k_lattice(int Jx, int Jy, int nbx, const int32_t* bins, const double* areas, dou
   __syncthreads();
   for (int line = threadIdx.x; line < Jy; line += blockDim.x)
     spline_line(Jx, (int64_t)line * Jx, 1, hww, cp, My, Mxy);
+  if (use_lds) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 4 * nn; idx += blockDim.x) C[idx] = lat_lds[idx];
+  }
 }
 
 // node densities (from bins, or given directly) and the spline coefficients
@@ -246,10 +264,12 @@ int gnx_l_spline_z(gnx_state* h, const int32_t* d_bins, GnxSpline* spl,
       other = (d_bins == h->bins_P) ? 0 : 1;
       zb = other ? h->bins_P : h->bin_partials;
     }
-    hipLaunchKernelGGL(k_lattice, dim3(1), dim3(256), 0, h->stream, L.Jx, L.Jy, L.nbx,
-                       d_nodes_override ? nullptr : d_bins, L.areas, L.hww, L.cprime, V, zb,
-                       zb ? L.nbx * L.nby : 0,
-                       (housekeeping && spl == &h->spl_N) ? h->nmax_bits : nullptr);
+    const size_t lds_bytes = ((size_t)4 * nn + std::max(L.Jx, L.Jy) + 1) * sizeof(double);
+    const int use_lds = lds_bytes <= 60 * 1024 ? 1 : 0;
+    hipLaunchKernelGGL(k_lattice, dim3(1), dim3(256), use_lds ? lds_bytes : 0, h->stream, L.Jx,
+                       L.Jy, L.nbx, d_nodes_override ? nullptr : d_bins, L.areas, L.hww, L.cprime,
+                       V, zb, zb ? L.nbx * L.nby : 0,
+                       (housekeeping && spl == &h->spl_N) ? h->nmax_bits : nullptr, use_lds);
     if (zb) h->bins_zeroed[other] = true;
     if (housekeeping && spl == &h->spl_N) h->nmax_zeroed = true;
     HIPCHK(hipGetLastError());
