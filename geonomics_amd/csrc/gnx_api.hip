@@ -838,12 +838,12 @@ extern "C" int gnx_pop_dynamics_mate(gnx_state* h, int32_t burn) {
   int64_t P = 0, B = 0;
   // 1. mating pairs (cell-sorted population)
   GNXCHK(gnx_l_sort_by_cell(h));
-  GNXCHK(gnx_l_find_pairs(h, nullptr, &P));
-  // 2. n_pairs density of pair midpoints (ops/demography.py:60-91)
-  if (P > 0)
+  // 2. n_pairs density of the pair midpoints (ops/demography.py:60-91), launched inside
+  //    find_pairs while the pair count travels to the host
+  static const bool early = !(getenv("GNX_EARLY_DENSITY") && atoi(getenv("GNX_EARLY_DENSITY")) == 0);
+  GNXCHK(gnx_l_find_pairs(h, nullptr, &P, early));
+  if (P > 0 && !h->spl_P.valid)
     GNXCHK(gnx_l_density(h, P, h->mid_x, h->mid_y, &h->spl_P, nullptr));
-  else
-    h->spl_P.valid = false;
   // 3. births: dispersal, crossover, phenotype
   GNXCHK(gnx_l_mate(h, burn != 0, false, 0, &B));
   h->last_births = B;

@@ -325,7 +325,10 @@ int gnx_l_age(gnx_state* h);
 int gnx_l_move(gnx_state* h, bool inc_age, const float* inj_theta, const float* inj_dist,
                float* out_theta, float* out_dist, bool apply);
 int gnx_l_sort_by_cell(gnx_state* h);
-int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out);
+// with_density: the n_pairs density (ops/demography.py:60-91) is launched before the host
+// has read the pair count back, so the GPU works through the round trip
+int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out,
+                     bool with_density = false);
 int gnx_l_births(gnx_state* h, int64_t* births_out);
 int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* births_out,
                int64_t id_base = -1, bool tiled = false);
@@ -363,10 +366,11 @@ int gnx_l_phenotype(gnx_state* h, int64_t first_slot, int64_t n);
 int gnx_l_assign_genomes(gnx_state* h, const int32_t* d_n_per_site);
 int gnx_l_mutate(gnx_state* h, int n, const int64_t* d_slot, const int32_t* d_locus,
                  const uint8_t* d_hom);
+// n_dev != null: n is an upper bound (grid size), the count itself is read on the device
 int gnx_l_density(gnx_state* h, int64_t n, const float* d_x, const float* d_y, GnxSpline* spl,
-                  const double* d_nodes_override);
+                  const double* d_nodes_override, const int32_t* n_dev = nullptr);
 int gnx_l_bins(gnx_state* h, int64_t n, const float* d_x, const float* d_y, const uint8_t* d_ghost,
-               int32_t* d_bins);
+               int32_t* d_bins, const int32_t* n_dev = nullptr);
 int gnx_l_spline(gnx_state* h, const int32_t* d_bins, GnxSpline* spl,
                  const double* d_nodes_override);
 int gnx_l_spline_z(gnx_state* h, const int32_t* d_bins, GnxSpline* spl,

@@ -19,9 +19,12 @@
 
 // ---------------------------------------------------------------- bins
 __global__ void __launch_bounds__(256)
-k_bins(int64_t n, const float* x, const float* y, const uint8_t* ghost, double inv_hww, int nbx,
-       int nby, int32_t* partials) {
+k_bins(int64_t n, const int32_t* n_dev, const float* x, const float* y, const uint8_t* ghost,
+       double inv_hww, int nbx, int nby, int32_t* partials) {
   extern __shared__ int32_t lds_hist[];
+  // n_dev: the count is still on its way to the host (the compaction's scan kernel left it
+  // in device memory too); the grid was sized for an upper bound
+  if (n_dev) n = *n_dev;
   const int nb = nbx * nby;
   for (int k = threadIdx.x; k < nb; k += blockDim.x) lds_hist[k] = 0;
   __syncthreads();
@@ -145,7 +148,7 @@ static SplineC make_splinec(const gnx_state* h, const GnxSpline& s) {
 
 // counts n points (ghosts skipped) into the half-window bins d_bins [nby*nbx]
 int gnx_l_bins(gnx_state* h, int64_t n, const float* d_x, const float* d_y, const uint8_t* d_ghost,
-               int32_t* d_bins) {
+               int32_t* d_bins, const int32_t* n_dev) {
   const GnxLattice& L = h->lat;
   const int nb = L.nbx * L.nby;
   const int field = (d_bins == h->bins_P) ? 1 : 0;
@@ -156,7 +159,7 @@ int gnx_l_bins(gnx_state* h, int64_t n, const float* d_x, const float* d_y, cons
     if ((size_t)nb * sizeof(int32_t) <= 48 * 1024) {
       int blocks = (int)std::min<int64_t>(BIN_BLOCKS, std::max<int64_t>(1, (n + 255) / 256));
       hipLaunchKernelGGL(k_bins, dim3(blocks), dim3(256), (size_t)nb * sizeof(int32_t), h->stream,
-                         n, d_x, d_y, d_ghost, 1.0 / L.hww, L.nbx, L.nby, d_bins);
+                         n, n_dev, d_x, d_y, d_ghost, 1.0 / L.hww, L.nbx, L.nby, d_bins);
     } else {
       hipLaunchKernelGGL(k_bins_global, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, n, d_x,
                          d_y, d_ghost, 1.0 / L.hww, L.nbx, L.nby, d_bins);
@@ -295,10 +298,10 @@ int gnx_l_spline_z(gnx_state* h, const int32_t* d_bins, GnxSpline* spl,
 }
 
 int gnx_l_density(gnx_state* h, int64_t n, const float* d_x, const float* d_y, GnxSpline* spl,
-                  const double* d_nodes_override) {
+                  const double* d_nodes_override, const int32_t* n_dev) {
   gnx_time_begin(h);
   int32_t* bins = (spl == &h->spl_P) ? h->bins_P : h->bin_partials;
-  if (!d_nodes_override) GNXCHK(gnx_l_bins(h, n, d_x, d_y, nullptr, bins));
+  if (!d_nodes_override) GNXCHK(gnx_l_bins(h, n, d_x, d_y, nullptr, bins, n_dev));
   GNXCHK(gnx_l_spline_z(h, bins, spl, d_nodes_override, !d_nodes_override));
   gnx_time_end(h, GNX_K_DENSITY, (double)n * 8.0);
   return 0;

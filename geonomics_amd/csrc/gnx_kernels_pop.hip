@@ -797,7 +797,7 @@ __global__ void k_panmixia(int64_t N, const int64_t* id, long long step, unsigne
   mate[i] = (m == f) ? -1 : m;
 }
 
-int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out) {
+int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out, bool with_density) {
   int64_t N = h->N;
   *n_pairs_out = 0;
   h->n_pairs = 0;
@@ -834,16 +834,27 @@ int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out) 
            (sexed || sp.mating_radius < 0) ? 0 : 1,      // no dedup for sexed / panmictic
            h->step, h->cfg.seed};
   hipLaunchKernelGGL(k_pair_flags, dim3(nb), dim3(256), 0, h->stream, pp, s, h->flag2, h->blk_cnt);
-  GNXCHK(gnx_block_scan(h, 1, N, h->blk_cnt, h->blk_off, -1, nullptr, nullptr, h->h_pin_dev + 4));
+  GNXCHK(gnx_block_scan(h, 1, N, h->blk_cnt, h->blk_off, -1, nullptr, h->cnt_dev, h->h_pin_dev + 4));
   // (the population was sorted by gnx_l_sort_by_cell with this idbits: max_id has not moved)
   hipLaunchKernelGGL(k_pair_compact, dim3(nb), dim3(256), 0, h->stream, N, focal, h->mate,
                      h->flag2, h->blk_off, s.x, s.y, h->key64[1], gnx_id_bits(h), h->pairs,
                      h->mid_x, h->mid_y, h->key64[0]);
   gnx_time_end(h, GNX_K_PAIRS, (double)N * 40.0);
   HIPCHK(hipGetLastError());
+  if (with_density) {
+    // the density of the pair midpoints reads the pair count on the device (at most N
+    // pairs: the grid's bound) while the host waits for its copy in pinned memory
+    const bool lds_bins = (size_t)h->lat.nbx * h->lat.nby * sizeof(int32_t) <= 48 * 1024;
+    if (lds_bins)
+      GNXCHK(gnx_l_density(h, N, h->mid_x, h->mid_y, &h->spl_P, nullptr, h->cnt_dev));
+    else
+      with_density = false;
+  }
   HIPCHK(hipStreamSynchronize(h->stream));
   h->n_pairs = h->h_pin[4];
   *n_pairs_out = h->n_pairs;
+  if (!with_density) h->spl_P.valid = false;
+  else if (h->n_pairs == 0) h->spl_P.valid = false;
   if (h->xo_launch_policy == 2) GNXCHK(gnx_xo_launch_pending(h));
   return 0;
 }
