@@ -482,8 +482,13 @@ static int setup_hash_grid(gnx_state* h) {
   const gnx_config& c = h->cfg;
   double r = h->sp.mating_radius;
   double cs = r > 0 ? r * (1.0 + 1e-9) : 8.0;
+  // nearest-mate choice walks outwards ring by ring over FINE cells (an eighth of the
+  // radius): in a clumped population the 3 x 3 block of radius-sized cells holds thousands
+  // of candidates, the nearest one sits a fraction of a cell away
+  if (r > 0 && h->sp.mate_mode == GNX_MATE_NEAREST) cs /= 8.0;
   // bound the number of cells (<= 2048 per axis)
   cs = std::max(cs, std::max(c.W, c.H) / 2048.0);
+  h->cell_ref = r > 0 ? std::max(1, (int)ceil(r * (1.0 + 1e-9) / cs - 1e-12)) : 1;
   h->cs = cs;
   h->inv_cs = 1.0 / cs;
   h->ncx = std::max(1, (int)ceil(c.W / cs));

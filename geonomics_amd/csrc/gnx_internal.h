@@ -190,6 +190,9 @@ struct gnx_state {
   // hash grid for neighbour search
   double cs = 1, inv_cs = 1;
   int ncx = 1, ncy = 1, key_bits = 1;
+  // cells that cover the mating radius: 1 (cell >= radius: uniform / inverse-distance index
+  // sampling over the 3 x 3 block) or up to 8 (nearest-mate search: fine cells, ring by ring)
+  int cell_ref = 1;
   uint32_t* key[2]{};
   int32_t* perm[2]{};
   int32_t* cell_start = nullptr;

@@ -487,7 +487,7 @@ struct FocalP {
 template <int MODE>
 __global__ void __launch_bounds__(256)
 k_find_mates(FocalP fp, GnxSoA s, const uint4* __restrict__ cand, double inv_cs,
-             const int32_t* __restrict__ cell_start, int ncx, int ncy, float r, float r2,
+             const int32_t* __restrict__ cell_start, int ncx, int ncy, int ref, float r, float r2,
              int32_t* __restrict__ mate) {
   __shared__ int32_t list[FM_PER_BLOCK];
   __shared__ int32_t wcnt[4];
@@ -628,61 +628,73 @@ k_find_mates(FocalP fp, GnxSoA s, const uint4* __restrict__ cand, double inv_cs,
     }
     return;
   }
-  // NEAREST: FM_LANES adjacent lanes per listed focal individual
+  // NEAREST: FM_LANES adjacent lanes per listed focal individual; cells are `ref` to a
+  // mating radius (fine cells), searched ring by ring around the focal's own cell: ring k
+  // is the square frame at Chebyshev distance k - its top and bottom rows are one
+  // contiguous range of the sorted records each, its sides two single cells per row.  A
+  // ring whose nearest point is farther than the best candidate so far ends the search; a
+  // row or cell of the ring whose rectangle is farther is skipped.
   const double cs = 1.0 / inv_cs;
   for (int t = tid; t < n_list * FM_LANES; t += 256) {
     const int i = list[t / FM_LANES];
     const int sub = t % FM_LANES;
     const uint4 me = cand[i];
     const float fx = __uint_as_float(me.x), fy = __uint_as_float(me.y);
-    const int k = gnx_cell_of(fx, fy, inv_cs, ncx, ncy);
-    const int cy = k / ncx;
-    const int cx = k - cy * ncx;
+    const int k0 = gnx_cell_of(fx, fy, inv_cs, ncx, ncy);
+    const int cy = k0 / ncx;
+    const int cx = k0 - cy * ncx;
     unsigned long long best = ~0ull;
     int best_slot = -1;
-    {
-      // own cell first, then a neighbour cell only if its rectangle comes closer than the
-      // best candidate so far (a clumped population holds thousands of candidates in the
-      // 3 x 3 block, nearly all of them farther than the nearest one of the own cell)
-      for (int q = 0; q < 9; ++q) {
-        const int ccx = q == 0 ? cx : (cx - 1 + (q - 1 + (q > 4 ? 1 : 0)) % 3);
-        const int ccy = q == 0 ? cy : (cy - 1 + (q - 1 + (q > 4 ? 1 : 0)) / 3);
-        if (ccx < 0 || ccx >= ncx || ccy < 0 || ccy >= ncy) continue;
-        if (q > 0) {
-          // distance from the focal individual to the cell's rectangle, shrunk a little so
-          // that rounding can never hide a candidate at equal distance
-          const double gx = fmax(fmax(ccx * cs - (double)fx, (double)fx - (ccx + 1) * cs), 0.0);
-          const double gy = fmax(fmax(ccy * cs - (double)fy, (double)fy - (ccy + 1) * cs), 0.0);
-          const float dmin2 = (float)((gx * gx + gy * gy) * 0.99999);
-          const float lim = best_slot >= 0 ? __uint_as_float((unsigned int)(best >> 32)) : r2;
-          if (dmin2 > lim) continue;                       // uniform over the FM_LANES lanes
-        }
-        const int st = cell_start[ccy * ncx + ccx];
-        const int e = cell_start[ccy * ncx + ccx + 1];
-        for (int j = st + sub; j < e; j += FM_LANES) {
-          const uint4 c = cand[j];
-          const float dx = __uint_as_float(c.x) - fx, dy = __uint_as_float(c.y) - fy;
-          const float d2 = dx * dx + dy * dy;
-          const bool ok = (d2 <= r2) & (j != i);
-          const unsigned long long comp =
-              ok ? (((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)c.w)
-                 : ~0ull;
-          const bool better = comp < best;
-          best = better ? comp : best;
-          best_slot = better ? j : best_slot;
-        }
-        // the lanes of the group agree on the best so far before the next cell's test
+    for (int k = 0; k <= ref; ++k) {
+      float lim = best_slot >= 0 ? __uint_as_float((unsigned int)(best >> 32)) : r2;
+      if (k >= 2) {
+        // every cell of ring k is at least (k - 1) cells away (shrunk a little so that
+        // rounding can never hide a candidate at equal distance)
+        const double g = (k - 1) * cs;
+        if ((float)(g * g * 0.99999) > lim) break;
+      }
+      for (int dy = -k; dy <= k; ++dy) {
+        const int ry = cy + dy;
+        if (ry < 0 || ry >= ncy) continue;
+        const double gy = fmax(fmax(ry * cs - (double)fy, (double)fy - (ry + 1) * cs), 0.0);
+        const bool full_row = dy == -k || dy == k;
+        // full rows: one range [cx - k, cx + k]; side rows: the two cells cx - k and cx + k
+        for (int part = 0; part < (full_row || k == 0 ? 1 : 2); ++part) {
+          int x0 = full_row ? cx - k : (part == 0 ? cx - k : cx + k);
+          int x1 = full_row ? cx + k : x0;
+          x0 = max(x0, 0);
+          x1 = min(x1, ncx - 1);
+          if (x0 > x1) continue;
+          const double gx = fmax(fmax(x0 * cs - (double)fx, (double)fx - (x1 + 1) * cs), 0.0);
+          if ((float)((gx * gx + gy * gy) * 0.99999) > lim) continue;   // uniform over the lanes
+          const int st = cell_start[ry * ncx + x0];
+          const int e = cell_start[ry * ncx + x1 + 1];
+          for (int j = st + sub; j < e; j += FM_LANES) {
+            const uint4 c = cand[j];
+            const float dx = __uint_as_float(c.x) - fx, dyy = __uint_as_float(c.y) - fy;
+            const float d2 = dx * dx + dyy * dyy;
+            const bool ok = (d2 <= r2) & (j != i);
+            const unsigned long long comp =
+                ok ? (((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)c.w)
+                   : ~0ull;
+            const bool better = comp < best;
+            best = better ? comp : best;
+            best_slot = better ? j : best_slot;
+          }
+          // the lanes of the group agree on the best so far before the next bound test
 #pragma unroll
-        for (int m = 1; m < FM_LANES; m <<= 1) {
-          const unsigned long long ob = __shfl_xor(best, m);
-          const int os = __shfl_xor(best_slot, m);
-          const bool take = ob < best;
-          best = take ? ob : best;
-          best_slot = take ? os : best_slot;
+          for (int m = 1; m < FM_LANES; m <<= 1) {
+            const unsigned long long ob = __shfl_xor(best, m);
+            const int os = __shfl_xor(best_slot, m);
+            const bool take = ob < best;
+            best = take ? ob : best;
+            best_slot = take ? os : best_slot;
+          }
+          lim = best_slot >= 0 ? __uint_as_float((unsigned int)(best >> 32)) : r2;
         }
       }
-      if (sub == 0) mate[i] = best_slot;
     }
+    if (sub == 0) mate[i] = best_slot;
   }
 }
 
@@ -819,13 +831,13 @@ int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out, 
     const uint4* cd = (const uint4*)h->cand;
     if (sp.mate_mode == GNX_MATE_NEAREST)
       hipLaunchKernelGGL(k_find_mates<GNX_MATE_NEAREST>, grid, blk, 0, h->stream, fp, s, cd,
-                         h->inv_cs, h->cell_start, h->ncx, h->ncy, r, r2, h->mate);
+                         h->inv_cs, h->cell_start, h->ncx, h->ncy, h->cell_ref, r, r2, h->mate);
     else if (sp.mate_mode == GNX_MATE_INVERSE)
       hipLaunchKernelGGL(k_find_mates<GNX_MATE_INVERSE>, grid, blk, 0, h->stream, fp, s, cd,
-                         h->inv_cs, h->cell_start, h->ncx, h->ncy, r, r2, h->mate);
+                         h->inv_cs, h->cell_start, h->ncx, h->ncy, h->cell_ref, r, r2, h->mate);
     else
       hipLaunchKernelGGL(k_find_mates<GNX_MATE_UNIFORM>, grid, blk, 0, h->stream, fp, s, cd,
-                         h->inv_cs, h->cell_start, h->ncx, h->ncy, r, r2, h->mate);
+                         h->inv_cs, h->cell_start, h->ncx, h->ncy, h->cell_ref, r, r2, h->mate);
   }
   gnx_time_end(h, GNX_K_FIND_MATES, (double)N * 16.0);
   gnx_time_begin(h);

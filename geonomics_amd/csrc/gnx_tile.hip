@@ -107,10 +107,11 @@ static HaloSpans halo_spans(const gnx_state* h) {
     sp.oky[d] = rr >= 0 && rr < h->tile_R;
     const float x0 = (float)(cc * tw), x1 = nextafterf((float)((cc + 1) * tw), 0.f);
     const float y0 = (float)(rr * th), y1 = nextafterf((float)((rr + 1) * th), 0.f);
-    sp.cx0[d] = std::min(h->ncx - 1, (int)((double)x0 * h->inv_cs)) - 2;
-    sp.cx1[d] = std::min(h->ncx - 1, (int)((double)x1 * h->inv_cs)) + 2;
-    sp.cy0[d] = std::min(h->ncy - 1, (int)((double)y0 * h->inv_cs)) - 2;
-    sp.cy1[d] = std::min(h->ncy - 1, (int)((double)y1 * h->inv_cs)) + 2;
+    const int ring = 2 * h->cell_ref;       // two mating radii, in cells
+    sp.cx0[d] = std::min(h->ncx - 1, (int)((double)x0 * h->inv_cs)) - ring;
+    sp.cx1[d] = std::min(h->ncx - 1, (int)((double)x1 * h->inv_cs)) + ring;
+    sp.cy0[d] = std::min(h->ncy - 1, (int)((double)y0 * h->inv_cs)) - ring;
+    sp.cy1[d] = std::min(h->ncy - 1, (int)((double)y1 * h->inv_cs)) + ring;
   }
   return sp;
 }

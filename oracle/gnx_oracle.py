@@ -353,11 +353,14 @@ def neighbour_lists(x, y, radius, dtype=np.float32):
     return out
 
 
-def hash_grid(dim, radius):
+def hash_grid(dim, radius, fine=False):
     """geometry of the device's hash grid (csrc/gnx_api.hip: setup_hash_grid):
-    cell size >= mating radius, at most 2048 cells per axis"""
+    cell size >= mating radius (an eighth of it for the nearest-mate search, fine=True),
+    at most 2048 cells per axis"""
     W, H = dim
     cs = float(radius) * (1.0 + 1e-9) if radius > 0 else 8.0
+    if fine and radius > 0:
+        cs /= 8.0
     cs = max(cs, max(W, H) / 2048.0)
     inv_cs = 1.0 / cs
     return inv_cs, max(1, int(np.ceil(W / cs))), max(1, int(np.ceil(H / cs)))
@@ -372,11 +375,12 @@ def cell_of(x, y, inv_cs, ncx, ncy):
     return cy * ncx + cx, cx, cy
 
 
-def pair_order_keys(x, y, ids, dim, radius):
+def pair_order_keys(x, y, ids, dim, radius, mate_mode='uniform'):
     """Order key of an individual as the focal one of a pair: (hash cell << 40) | id.  Pairs
     are taken in ascending key order (the device's cell-sorted slot order), which fixes the
     order offspring ids are handed out in - independent of storage order and of tiling."""
-    inv_cs, ncx, ncy = hash_grid(dim, radius if radius is not None else -1.0)
+    inv_cs, ncx, ncy = hash_grid(dim, radius if radius is not None else -1.0,
+                                 fine=mate_mode == 'nearest')
     cell, _, _ = cell_of(x, y, inv_cs, ncx, ncy)
     return (cell.astype(np.int64) << 40) | np.asarray(ids, dtype=np.int64)
 

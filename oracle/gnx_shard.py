@@ -151,7 +151,7 @@ class OracleShard:
         i = np.nonzero(f2)[0]
         pr = np.stack([i, mate[i]], 1) if i.size else np.zeros((0, 2), np.int64)
         self.pair_keys = O.pair_order_keys(s.x[pr[:, 0]], s.y[pr[:, 0]], s.id[pr[:, 0]],
-                                           (s.W, s.H), p.mating_radius)
+                                           (s.W, s.H), p.mating_radius, p.mate_mode)
         o = np.argsort(self.pair_keys, kind='stable')
         pr, self.pair_keys = pr[o], self.pair_keys[o]
         self.pairs_ = pr

@@ -252,7 +252,8 @@ def pop_dynamics(s, burn=False, with_selection=True):
     # individuals (of the trial's slot under panmixia): tiling-independent
     if len(pairs):
         who = pairs[:, 0] if s.pair_trial is None else s.pair_trial
-        k = O.pair_order_keys(s.x[who], s.y[who], s.id[who], (s.W, s.H), s.p.mating_radius)
+        k = O.pair_order_keys(s.x[who], s.y[who], s.id[who], (s.W, s.H), s.p.mating_radius,
+                              s.p.mate_mode)
         pairs = pairs[np.argsort(k, kind='stable')]
     VP = None
     if len(pairs):
