@@ -553,15 +553,19 @@ k_find_mates(FocalP fp, GnxSoA s, const uint4* __restrict__ cand, double inv_cs,
         // loads are independent, the round trip to L2 / HBM is what a try costs) and
         // examined in stream order, so the first accepted try is the one a sequential
         // walk of the stream would take
-        for (int blk = 0; blk < blocks && found < 0; ++blk) {
+        for (int blk = 0; blk < blocks && found < 0; blk += WT ? 2 : 1) {
+          // four tries per round: one Philox block of index words, or two blocks of
+          // (index, acceptance) words
           const uint4 w = gnx_rand4(fp.seed, fid, fp.step, OP_MATE_PICK, blk);
-          const unsigned int wi[4] = {w.x, WT ? w.z : w.y, w.z, w.w};
-          const unsigned int wa[2] = {w.y, w.w};
-          constexpr int NT = WT ? 2 : 4;
-          int slot[NT];
-          uint4 c[NT];
+          const bool two = WT && blk + 1 < blocks;
+          const uint4 w2 = two ? gnx_rand4(fp.seed, fid, fp.step, OP_MATE_PICK, blk + 1) : w;
+          const unsigned int wi[4] = {w.x, WT ? w.z : w.y, WT ? w2.x : w.z, WT ? w2.z : w.w};
+          const unsigned int wa[4] = {w.y, w.w, w2.y, w2.w};
+          const int nt = WT ? (two ? 4 : 2) : 4;
+          int slot[4];
+          uint4 c[4];
 #pragma unroll
-          for (int q = 0; q < NT; ++q) {
+          for (int q = 0; q < 4; ++q) {
             const int j = (int)__umulhi(wi[q], M);
             slot[q] = j < len[0] ? st[0] + j
                       : (j < len[0] + len[1] ? st[1] + (j - len[0])
@@ -569,10 +573,10 @@ k_find_mates(FocalP fp, GnxSoA s, const uint4* __restrict__ cand, double inv_cs,
             c[q] = cand[slot[q]];
           }
 #pragma unroll
-          for (int q = 0; q < NT; ++q) {
+          for (int q = 0; q < 4; ++q) {
             const float dx = __uint_as_float(c[q].x) - fx, dy = __uint_as_float(c[q].y) - fy;
             const float d2 = dx * dx + dy * dy;
-            bool ok = slot[q] != i && d2 <= r2;
+            bool ok = q < nt && slot[q] != i && d2 <= r2;
             if (WT) ok = ok && d2 > 0.f && gnx_u01(wa[q]) * r < r - sqrtf(d2);
             if (ok && found < 0) found = slot[q];
           }
