@@ -296,8 +296,8 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
   GNXCHK(dalloc(&h->req_py, cap));
   GNXCHK(dalloc(&h->req_count, 1));
   h->blk_stride = (int)((cap + 1023) / 1024) + 2;
-  GNXCHK(dalloc(&h->blk_cnt, (size_t)2 * h->blk_stride));
-  GNXCHK(dalloc(&h->blk_off, (size_t)2 * h->blk_stride));
+  GNXCHK(dalloc(&h->blk_cnt, (size_t)3 * h->blk_stride));
+  GNXCHK(dalloc(&h->blk_off, (size_t)3 * h->blk_stride));
   GNXCHK(dalloc(&h->cnt_dev, 4));
   HIPCHK(hipHostMalloc((void**)&h->h_pin, 16 * sizeof(int64_t)));
   HIPCHK(hipHostGetDevicePointer((void**)&h->h_pin_dev, h->h_pin, 0));

@@ -281,9 +281,9 @@ struct gnx_state {
   bool counts_init = false;
   double* red = nullptr;             // small reduction scratch [8]
 
-  // block counts / offsets of the compactions (2 arrays of blk_stride entries each) and
-  // their totals: cnt_dev[0] survivors, [1] rows freed, [2] survivors older than this
-  // step's offspring
+  // block counts / offsets of the compactions (3 arrays of blk_stride entries each) and
+  // their totals: cnt_dev[0] survivors, [1] rows freed, [2] surviving offspring that still
+  // wait for their genome row and crossover
   int32_t* blk_cnt = nullptr;
   int32_t* blk_off = nullptr;
   int blk_stride = 0;
@@ -386,11 +386,11 @@ int gnx_l_gather_genomes(gnx_state* h, int64_t n, const int64_t* d_slots, uint64
 // genomes d_in [n][2][W64] -> the rows of slots [first_slot, first_slot + n)
 int gnx_l_scatter_genomes(gnx_state* h, int64_t n, const uint64_t* d_in, int64_t first_slot);
 
-// look-back-free compaction (gnx_compact.h): block counts cnt[k * blk_stride + b] ->
-// exclusive block offsets off[...], totals (and the flagged items below `mark`) to
-// out[0..2] on the device and to pinned host memory
+// look-back-free compaction (gnx_compact.h): block counts cnt[k * blk_stride + b], k < K
+// <= 3, -> exclusive block offsets off[...], totals to out[0..2] on the device and to
+// pinned host memory
 int gnx_block_scan(gnx_state* h, int K, int64_t n_items, const int32_t* cnt, int32_t* off,
-                   int64_t mark, const int32_t* flags0, int32_t* out, int64_t* host);
+                   int32_t* out, int64_t* host);
 
 // rocPRIM wrappers (gnx_prim.hip)
 int gnx_prim_sort_bytes(size_t n, int bits, size_t* bytes);

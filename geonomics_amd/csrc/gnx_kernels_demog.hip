@@ -509,14 +509,14 @@ int gnx_l_death_probs(gnx_state* h, bool with_selection) {
 __global__ void __launch_bounds__(256)
 k_alive(int64_t N, const double* p_death, const uint8_t* dead_in, const int64_t* id,
         const uint8_t* ghost, const int32_t* grow, long long step, unsigned long long seed,
-        int32_t* alive, int32_t* dead_row, int32_t* cnt, int stride) {
+        int32_t* alive, int32_t* dead_row, int32_t* cnt, int stride, int64_t xo_first) {
   __shared__ int lds[16];
   const int64_t base = (int64_t)blockIdx.x * GNX_CB;
-  bool fa[4], fd[4];
+  bool fa[4], fd[4], fx[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t i = base + r * 256 + threadIdx.x;
-    fa[r] = fd[r] = false;
+    fa[r] = fd[r] = fx[r] = false;
     if (i < N) {
       bool dead;
       const bool g = ghost[i] != 0;
@@ -532,26 +532,31 @@ k_alive(int64_t N, const double* p_death, const uint8_t* dead_in, const int64_t*
       // rows to return to the free stack (offspring that die before their deferred
       // crossover never had one; ghosts own none)
       fd[r] = dead && !g && grow[i] >= 0;
-      alive[i] = fa[r] ? 1 : 0;
+      // surviving offspring of this step whose crossover was deferred: it gets its genome
+      // row and its crossover now (xo_first < 0: nothing deferred).  alive[] bit 1 marks it.
+      fx[r] = !dead && xo_first >= 0 && i >= xo_first && grow[i] < 0;
+      alive[i] = (fa[r] ? 1 : 0) | (fx[r] ? 2 : 0);
       dead_row[i] = fd[r] ? 1 : 0;
     }
   }
-  int rank[4], ta, td;
+  int rank[4], ta, td, tx;
   gnx_block_ranks(fa, rank, ta, lds);
   gnx_block_ranks(fd, rank, td, lds);
+  gnx_block_ranks(fx, rank, tx, lds);
   if (threadIdx.x == 0) {
     cnt[blockIdx.x] = ta;
     cnt[stride + blockIdx.x] = td;
+    cnt[2 * stride + blockIdx.x] = tx;
   }
 }
 
-// Crossover jobs of the surviving offspring (deferred mode): offspring k = slot first + k
-// is alive iff alive[first + k]; its rank among the surviving offspring picks its row from
-// the top of the free stack.  Offspring that died at age 0 never get a row.
-// cnts[0] = survivors in all, cnts[2] = survivors older than this step's offspring.
+// Crossover jobs of the surviving offspring whose crossover was deferred (alive[] bit 1):
+// the rank among them picks the row from the top of the free stack.  Offspring that died
+// at age 0 never get a row; offspring that already have one (their mate was a ghost: the
+// tile cut their genome at once, csrc/gnx_tile.hip) are left alone.  cnts[2] = how many.
 __global__ void __launch_bounds__(256)
 k_xo_jobs_surv(int64_t N, int64_t first, int32_t* __restrict__ grow,
-               const int32_t* __restrict__ alive, const int32_t* __restrict__ blk_off,
+               const int32_t* __restrict__ alive, const int32_t* __restrict__ blk_off3,
                const int32_t* __restrict__ cnts, const int32_t* __restrict__ off_parent,
                const int32_t* __restrict__ off_keys, const uint8_t* __restrict__ off_start,
                const int32_t* __restrict__ free_rows, int64_t n_free,
@@ -559,23 +564,22 @@ k_xo_jobs_surv(int64_t N, int64_t first, int32_t* __restrict__ grow,
   __shared__ int lds[16];
   const int64_t b = first / GNX_CB + blockIdx.x;
   const int64_t base = b * GNX_CB;
-  const int32_t s0 = cnts[2];
-  if (blockIdx.x == 0 && threadIdx.x == 0) *n_jobs = 2 * (cnts[0] - s0);
-  bool fa[4];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *n_jobs = 2 * cnts[2];
+  bool fx[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t i = base + r * 256 + threadIdx.x;
-    fa[r] = i < N && alive[i] != 0;
+    fx[r] = i < N && (alive[i] & 2) != 0;
   }
   int rank[4], tot;
-  gnx_block_ranks(fa, rank, tot, lds);
-  const int32_t boff = blk_off[b];
+  gnx_block_ranks(fx, rank, tot, lds);
+  const int32_t boff = blk_off3[b];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t i = base + r * 256 + threadIdx.x;
-    if (!fa[r] || i < first) continue;
+    if (!fx[r]) continue;
     const int64_t k = i - first;
-    const int32_t j = boff + rank[r] - s0;
+    const int32_t j = boff + rank[r];
     const int32_t row = free_rows[n_free - 1 - j];
     grow[i] = row;
 #pragma unroll
@@ -603,7 +607,7 @@ k_compact(int64_t N, int64_t cap, const int32_t* alive, const int32_t* dead_row,
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t i = base + r * 256 + threadIdx.x;
-    fa[r] = i < N && alive[i] != 0;
+    fa[r] = i < N && (alive[i] & 1) != 0;
     fd[r] = i < N && dead_row[i] != 0;
   }
   int ra[4], rd[4], ta, td;
@@ -611,7 +615,7 @@ k_compact(int64_t N, int64_t cap, const int32_t* alive, const int32_t* dead_row,
   gnx_block_ranks(fd, rd, td, lds);
   // deferred crossover: the surviving offspring have just popped one row each from the
   // top of the free stack (k_xo_jobs_surv)
-  if (xo) n_free -= cnts[0] - cnts[2];
+  if (xo) n_free -= cnts[2];
   const int32_t oa = blk_off[blockIdx.x], od = blk_off[stride + blockIdx.x];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -640,7 +644,8 @@ void gnx_launch_xo_jobs_surv(gnx_state* h, int64_t first_slot, const int32_t* d_
   const int64_t N = h->N;
   const int nbj = (int)((N - 1) / GNX_CB - first_slot / GNX_CB + 1);
   hipLaunchKernelGGL(k_xo_jobs_surv, dim3(nbj), dim3(256), 0, h->stream, N, first_slot,
-                     h->soa[h->cur].grow, d_alive, d_blk_off, h->cnt_dev, h->off_parent,
+                     h->soa[h->cur].grow, d_alive, d_blk_off + 2 * h->blk_stride, h->cnt_dev,
+                     h->off_parent,
                      h->off_keys, h->off_start, h->free_rows, h->n_free, (GnxXoJob*)h->jobs[buf],
                      h->n_jobs_dev[buf]);
 }
@@ -657,11 +662,10 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
   gnx_time_begin(h);
   hipLaunchKernelGGL(k_alive, dim3(nb), dim3(256), 0, h->stream, N, h->p_death, d_dead_inject,
                      a.id, a.ghost, a.grow, h->step, c.seed, h->flag, h->flag2, h->blk_cnt,
-                     h->blk_stride);
-  // survivors, rows freed and (deferred crossover) the survivors older than this step's
-  // offspring: block offsets on the device, totals also straight into pinned host memory
-  GNXCHK(gnx_block_scan(h, 2, N, h->blk_cnt, h->blk_off, xo ? xo_first : -1, h->flag, h->cnt_dev,
-                        h->h_pin_dev));
+                     h->blk_stride, xo ? xo_first : (int64_t)-1);
+  // survivors, rows freed and (deferred crossover) the surviving offspring that need a
+  // row: block offsets on the device, totals also straight into pinned host memory
+  GNXCHK(gnx_block_scan(h, 3, N, h->blk_cnt, h->blk_off, h->cnt_dev, h->h_pin_dev));
   gnx_time_end(h, GNX_K_COMPACT, 0.0);
   // the host only needs the counts: it waits for the scan, not for the compaction, and
   // enqueues the next step's first kernels while the compaction still runs
@@ -686,7 +690,7 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
   const int64_t survivors = h->h_pin[0];
   const int64_t rows_freed = h->h_pin[1];
   if (xo) {
-    const int64_t S = survivors - h->h_pin[2];
+    const int64_t S = h->h_pin[2];
     h->n_free -= S;
     h->last_xo_births = S;
     if (h->profiling) h->timers[GNX_K_CROSSOVER].bytes += (double)S * gnx_xo_bytes_per_birth(h);

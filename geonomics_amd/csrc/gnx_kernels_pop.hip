@@ -850,7 +850,7 @@ int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out, 
            (sexed || sp.mating_radius < 0) ? 0 : 1,      // no dedup for sexed / panmictic
            h->step, h->cfg.seed};
   hipLaunchKernelGGL(k_pair_flags, dim3(nb), dim3(256), 0, h->stream, pp, s, h->flag2, h->blk_cnt);
-  GNXCHK(gnx_block_scan(h, 1, N, h->blk_cnt, h->blk_off, -1, nullptr, h->cnt_dev, h->h_pin_dev + 4));
+  GNXCHK(gnx_block_scan(h, 1, N, h->blk_cnt, h->blk_off, h->cnt_dev, h->h_pin_dev + 4));
   // (the population was sorted by gnx_l_sort_by_cell with this idbits: max_id has not moved)
   hipLaunchKernelGGL(k_pair_compact, dim3(nb), dim3(256), 0, h->stream, N, focal, h->mate,
                      h->flag2, h->blk_off, s.x, s.y, h->key64[1], gnx_id_bits(h), h->pairs,

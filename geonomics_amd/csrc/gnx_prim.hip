@@ -62,19 +62,16 @@ int gnx_prim_sort64_bits(void* tmp, size_t bytes, const uint64_t* kin, uint64_t*
 }
 
 // ---------------------------------------------------------------- block-count scan
-// Exclusive scan of K count arrays (cnt[k * stride + b], b < nb) into off[k * stride + b],
-// off[k * stride + nb] = total.  One workgroup of 1024 threads.  Optionally (mark >= 0,
-// array 0 only) the number of flagged items below item `mark`, from the stored flags
-// (mark's block is only partly below it): out[2].  out[0], out[1] = totals of arrays 0, 1.
-// `host` (pinned, device-visible) receives the same four numbers.
+// Exclusive scan of K (<= 3) count arrays (cnt[k * stride + b], b < nb) into
+// off[k * stride + b], off[k * stride + nb] = total.  One workgroup of 1024 threads.
+// out[k] = total of array k; `host` (pinned, device-visible) receives the same numbers.
 __global__ void __launch_bounds__(1024)
 k_block_scan(int K, int nb, int stride, const int32_t* __restrict__ cnt, int32_t* __restrict__ off,
-             int64_t mark, const int32_t* __restrict__ flags0, int32_t* __restrict__ out,
-             int64_t* __restrict__ host) {
+             int32_t* __restrict__ out, int64_t* __restrict__ host) {
   __shared__ int wsum[16];
   __shared__ int carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int totals[2] = {0, 0};
+  int totals[3] = {0, 0, 0};
   for (int k = 0; k < K; ++k) {
     if (tid == 0) carry_s = 0;
     __syncthreads();
@@ -101,37 +98,19 @@ k_block_scan(int K, int nb, int stride, const int32_t* __restrict__ cnt, int32_t
     if (tid == 0) off[k * stride + nb] = carry_s;
     __syncthreads();
   }
-  int below = 0;
-  if (mark >= 0) {
-    const int64_t blk = mark / GNX_CB;
-    const int64_t i = blk * GNX_CB + tid;
-    int c = (i < mark && flags0[i]) ? 1 : 0;
-    unsigned long long bal = __ballot(c);
-    if (lane == 0) wsum[wave] = __popcll(bal);
-    __syncthreads();
-    int part = 0;
-    for (int w = 0; w < 16; ++w) part += wsum[w];
-    below = (blk < nb ? off[blk] : totals[0]) + part;
-  }
   if (tid == 0) {
-    if (out) {
-      out[0] = totals[0];
-      out[1] = totals[1];
-      out[2] = below;
-    }
-    if (host) {
-      host[0] = totals[0];
-      host[1] = totals[1];
-      host[2] = below;
+    for (int k = 0; k < 3; ++k) {
+      if (out) out[k] = totals[k];
+      if (host) host[k] = totals[k];
     }
   }
 }
 
 int gnx_block_scan(gnx_state* h, int K, int64_t n_items, const int32_t* cnt, int32_t* off,
-                   int64_t mark, const int32_t* flags0, int32_t* out, int64_t* host) {
+                   int32_t* out, int64_t* host) {
   const int nb = (int)((n_items + GNX_CB - 1) / GNX_CB);
   hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, h->stream, K, nb, h->blk_stride, cnt, off,
-                     mark, flags0, out, host);
+                     out, host);
   HIPCHK(hipGetLastError());
   return 0;
 }
