@@ -246,9 +246,21 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
       while (want > 1 && ((double)need * want > 0.75 * (double)free_b ||
                           (double)h->cfg.cap_rows * want > 1.0e9))
         --want;
+      // several handles may be created at once on one GPU (tiles as threads or processes
+      // in rehearsals): what looked free a moment ago may be gone - fall back to less
+      for (; want >= 1; --want) {
+        h->G = nullptr;
+        const hipError_t e = hipMalloc((void**)&h->G, need * (size_t)want);
+        if (e == hipSuccess) break;
+        (void)hipGetLastError();
+        if (want == 1) {
+          gnx_set_error("hipMalloc of the genome table (%zu bytes) failed: %s", need,
+                        hipGetErrorString(e));
+          return 1;
+        }
+      }
       h->row_spread = want;
     }
-    GNXCHK(dalloc(&h->G, (size_t)h->cfg.cap_rows * h->row_spread * 2 * h->W64));
     GNXCHK(dalloc(&h->free_rows, (size_t)h->cfg.cap_rows));
   }
   for (int k = 0; k < 2; ++k) {
@@ -298,7 +310,7 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
   h->blk_stride = (int)((cap + 1023) / 1024) + 2;
   GNXCHK(dalloc(&h->blk_cnt, (size_t)3 * h->blk_stride));
   GNXCHK(dalloc(&h->blk_off, (size_t)3 * h->blk_stride));
-  GNXCHK(dalloc(&h->cnt_dev, 4));
+  GNXCHK(dalloc(&h->cnt_dev, 8));
   HIPCHK(hipHostMalloc((void**)&h->h_pin, 16 * sizeof(int64_t)));
   HIPCHK(hipHostGetDevicePointer((void**)&h->h_pin_dev, h->h_pin, 0));
   if (cfg->L > 0) {

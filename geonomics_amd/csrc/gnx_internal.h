@@ -340,6 +340,10 @@ int gnx_l_dispersal_inject(gnx_state* h, int64_t B, int A, const float* d_mx, co
                            int32_t* d_used);
 // crossover of every birth of the current step at once (rows for all of them)
 int gnx_l_crossover_all(gnx_state* h, int64_t first_slot, int64_t B);
+// tiled runs: row + local gamete, at once, of the n_req offspring whose mate is a ghost
+int gnx_l_crossover_requests(gnx_state* h, int64_t first_slot, int64_t n_req);
+// rows + crossover, now, of the offspring [first_slot, first_slot + B) that have no row yet
+int gnx_l_crossover_pending(gnx_state* h, int64_t first_slot, int64_t B);
 // crossover of the surviving offspring only (after k_alive + scan; gnx_l_mortality)
 int gnx_l_crossover_survivors(gnx_state* h, int64_t first_slot, int64_t B, const int32_t* d_alive,
                               const int32_t* d_scan);
@@ -361,7 +365,7 @@ int gnx_l_rebuild_sel(gnx_state* h);
 int gnx_l_path_sel(gnx_state* h);
 // tb of slots [first, first+n) (or of first + list[q]) re-read from their genome rows
 int gnx_l_tb_from_rows(gnx_state* h, int64_t first, int64_t n, const int32_t* d_list,
-                       const int64_t* d_slots);
+                       const int64_t* d_slots, bool join = true);
 // tb of this step's offspring from their parents' tb and the paths' path_sel
 int gnx_l_newborn_tb(gnx_state* h, int64_t first_slot, int64_t B);
 // phenotypes of slots [first, first+n) from tb

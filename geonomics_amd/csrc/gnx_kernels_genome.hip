@@ -11,6 +11,7 @@
 #include "gnx_rng.h"
 #include "gnx_xo.h"
 #include "gnx_tb.h"
+#include "gnx_compact.h"
 
 // ---------------------------------------------------------------- crossover jobs
 // Every birth of the step at once: child k takes the k-th row from the top of the free
@@ -137,6 +138,95 @@ int gnx_l_crossover_all(gnx_state* h, int64_t first_slot, int64_t B) {
   return 0;
 }
 
+// Tiled runs: the offspring whose mate is a ghost (one gamete request each, req_k) get
+// their row and the crossover of their LOCAL gamete at once - the remote gamete is put
+// next to it and their alleles at the selected loci are read from the finished row -
+// while every other offspring of the step waits for the death draws like on one GPU.
+__global__ void k_xo_jobs_req(int n_req, int64_t first, int32_t* __restrict__ grow,
+                              const int32_t* __restrict__ req_k,
+                              const int32_t* __restrict__ off_parent,
+                              const int32_t* __restrict__ off_keys,
+                              const uint8_t* __restrict__ off_start,
+                              const int32_t* __restrict__ free_rows, int64_t n_free,
+                              GnxXoJob* __restrict__ jobs, int32_t* __restrict__ n_jobs) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q == 0) *n_jobs = n_req;
+  if (q >= n_req) return;
+  const int64_t k = req_k[q];
+  const int32_t row = free_rows[n_free - 1 - q];
+  grow[first + k] = row;
+  GnxXoJob j;
+  j.prow = grow[off_parent[2 * k]];
+  j.dst = row * 2;
+  j.key = off_keys[2 * k];
+  j.start = off_start[2 * k];
+  jobs[q] = j;
+}
+
+int gnx_l_crossover_requests(gnx_state* h, int64_t first_slot, int64_t n_req) {
+  if (n_req == 0) return 0;
+  GNXCHK(gnx_xo_launch_pending(h));
+  GNXCHK(xo_wait_buf(h, h->stream, 0));
+  GNXCHK(xo_wait_buf(h, h->stream, 1));
+  const int buf = h->jobs_cur;
+  hipLaunchKernelGGL(k_xo_jobs_req, dim3(gnx_grid(n_req, 256)), dim3(256), 0, h->stream, (int)n_req,
+                     first_slot, h->soa[h->cur].grow, h->req_k, h->off_parent, h->off_keys,
+                     h->off_start, h->free_rows, h->n_free, (GnxXoJob*)h->jobs[buf],
+                     h->n_jobs_dev[buf]);
+  if (h->stream2) {      // the rows handed out above must be visible to the gamete puts
+    HIPCHK(hipEventRecord(h->ev_jobs, h->stream));
+    HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_jobs, 0));
+  }
+  gnx_time_begin(h);
+  GNXCHK(xo_launch(h, h->stream, buf, n_req, false));
+  gnx_time_end(h, GNX_K_CROSSOVER, (double)n_req * 0.5 * gnx_xo_bytes_per_birth(h));
+  h->n_free -= n_req;
+  return 0;
+}
+
+// Offspring [first, first + B) that have no genome row yet get one, and their crossover,
+// now, on `stream` (somebody needs the genomes before the step's death draws).
+__global__ void k_pending_flags(int64_t N, int64_t first, const int32_t* grow, int32_t* alive,
+                                int32_t* cnt3) {
+  __shared__ int lds[16];
+  const int64_t base = (int64_t)blockIdx.x * GNX_CB;
+  bool fx[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    fx[r] = i < N && i >= first && grow[i] < 0;
+    if (i < N) alive[i] = fx[r] ? 2 : 0;
+  }
+  int rank[4], tot;
+  gnx_block_ranks(fx, rank, tot, lds);
+  if (threadIdx.x == 0) cnt3[blockIdx.x] = tot;
+}
+
+int gnx_l_crossover_pending(gnx_state* h, int64_t first_slot, int64_t B) {
+  if (B == 0) return 0;
+  GNXCHK(gnx_xo_launch_pending(h));
+  GNXCHK(xo_wait_buf(h, h->stream, 0));
+  GNXCHK(xo_wait_buf(h, h->stream, 1));
+  const int64_t N = h->N;
+  const int nb = (int)((N + GNX_CB - 1) / GNX_CB);
+  const int buf = h->jobs_cur;
+  int32_t* cnt3 = h->blk_cnt + 2 * h->blk_stride;
+  int32_t* off3 = h->blk_off + 2 * h->blk_stride;
+  hipLaunchKernelGGL(k_pending_flags, dim3(nb), dim3(256), 0, h->stream, N, first_slot,
+                     h->soa[h->cur].grow, h->flag, cnt3);
+  // totals land in cnt_dev[2] (what k_xo_jobs_surv reads) and in pinned memory
+  GNXCHK(gnx_block_scan(h, 1, N, cnt3, off3, h->cnt_dev + 2, h->h_pin_dev + 8));
+  gnx_launch_xo_jobs_surv(h, first_slot, h->flag, h->blk_off, buf);
+  gnx_time_begin(h);
+  GNXCHK(xo_launch(h, h->stream, buf, 2 * B, false));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const int64_t S = h->h_pin[8];
+  gnx_time_end(h, GNX_K_CROSSOVER, (double)S * gnx_xo_bytes_per_birth(h));
+  h->n_free -= S;
+  h->last_xo_births = S;
+  return 0;
+}
+
 int gnx_xo_launch_pending(gnx_state* h) {
   const int buf = h->xo_ready_buf;
   if (buf < 0) return 0;
@@ -187,7 +277,7 @@ int gnx_xo_flush_deferred(gnx_state* h) {
     // gets its row and its crossover now (same genomes as the deferred path would give
     // the survivors; the dead's rows return to the free stack with the other deaths)
     h->xo_deferred = false;
-    GNXCHK(gnx_l_crossover_all(h, h->xo_first, h->xo_B));
+    GNXCHK(gnx_l_crossover_pending(h, h->xo_first, h->xo_B));
   }
   return 0;
 }
@@ -250,9 +340,9 @@ __global__ void k_tb_from_rows(int64_t first, int64_t n, const int32_t* list, co
 }
 
 int gnx_l_tb_from_rows(gnx_state* h, int64_t first, int64_t n, const int32_t* d_list,
-                       const int64_t* d_slots) {
+                       const int64_t* d_slots, bool join) {
   if (n == 0 || h->TW == 0 || !h->genomes_assigned) return 0;
-  GNXCHK(gnx_xo_join(h));
+  if (join) GNXCHK(gnx_xo_join(h));
   GnxSoA s = h->soa[h->cur];
   hipLaunchKernelGGL(k_tb_from_rows, dim3(gnx_grid(2 * n, 256)), dim3(256), 0, h->stream, first, n,
                      d_list, d_slots, h->TW, h->n_sel, h->W64, h->sel_loci, (const u64*)h->G,

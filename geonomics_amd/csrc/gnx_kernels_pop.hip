@@ -1195,8 +1195,11 @@ int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* 
     // (gnx_l_mortality), unless somebody asks for them earlier (gnx_xo_join)
     const bool fused = !inject && !tiled;        // k_offspring did both already
     if (!fused) GNXCHK(gnx_l_newborn_tb(h, h->N, B));
-    const bool defer = h->defer_xo && !tiled && !inject && h->stream2 != nullptr;
+    const bool defer = h->defer_xo && !inject && h->stream2 != nullptr;
     if (defer) {
+      // tiles: the few offspring whose mate is a ghost cannot wait (their alleles at the
+      // selected loci need the remote gamete): row and local gamete now
+      if (tiled) GNXCHK(gnx_l_crossover_requests(h, h->N, h->n_req));
       h->xo_deferred = true;
       h->xo_first = h->N;
       h->xo_B = B;

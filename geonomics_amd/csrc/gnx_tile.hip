@@ -561,7 +561,9 @@ extern "C" int gnx_tile_finish_births(gnx_state* h, int32_t burn) {
     // local gametes took their alleles at the selected loci from the parents' compact
     // tables (k_newborn_tb); offspring that received a remote gamete re-read theirs from
     // the row the gamete was put in
-    GNXCHK(gnx_l_tb_from_rows(h, h->birth_first_slot, h->n_req, h->req_k, nullptr));
+    // (their rows are complete: the local gametes were cut on this stream, the puts were
+    // waited for; no join, the other offspring's crossover stays deferred)
+    GNXCHK(gnx_l_tb_from_rows(h, h->birth_first_slot, h->n_req, h->req_k, nullptr, false));
     GNXCHK(gnx_l_phenotype(h, h->birth_first_slot, B));
   }
   GnxSoA s = h->soa[h->cur];

@@ -32,14 +32,13 @@ out = [None] * world
 def body(rank):
     try:
         torch.cuda.set_device(0)
-        dev, _, _ = bench.build_device(cfg, seed=42, device=0, grid=grid)
+        dev, _, _ = bench.build_device(cfg, seed=42, device=0, grid=grid, rank=rank)
         shard = DeviceShard(dev)
         st = TiledStepper(shard, LocalComm(hub, rank), cfg['W'] * grid[1], cfg['H'] * grid[0],
                           10.0, move=True, max_id=cfg['N'] * world - 1, grid=grid, fixed_births=1)
-        shard.export_migrants()
         for _ in range(3):
             st.step(True, False)
-        bench.setup_genomes(dev, cfg, 42 + rank)
+        bench.setup_genomes(dev, cfg, 42)
         shard.has_genomes = True
         for _ in range(2):
             st.step(False, True)
