@@ -484,18 +484,61 @@ struct FocalP {
   unsigned long long seed;
 };
 
+// the three row ranges of a focal individual's 3x3 block of cells (an absent row has
+// length 0) and the slot of index j of their concatenation
+struct FmRanges {
+  int st[3], len[3];
+  unsigned int M;
+  __device__ __forceinline__ int slot(int j) const {
+    return j < len[0] ? st[0] + j
+                      : (j < len[0] + len[1] ? st[1] + (j - len[0]) : st[2] + (j - len[0] - len[1]));
+  }
+};
+
+__device__ __forceinline__ FmRanges fm_ranges(float fx, float fy, double inv_cs, int ncx, int ncy,
+                                              const int32_t* __restrict__ cell_start) {
+  FmRanges R;
+  const int k = gnx_cell_of(fx, fy, inv_cs, ncx, ncy);
+  const int cy = k / ncx;
+  const int cx = k - cy * ncx;
+  const int lo = max(cx - 1, 0), hi = min(cx + 1, ncx - 1);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int ry = cy - 1 + q;
+    const bool in = ry >= 0 && ry < ncy;
+    R.st[q] = in ? cell_start[ry * ncx + lo] : 0;
+    R.len[q] = in ? cell_start[ry * ncx + hi + 1] - R.st[q] : 0;
+  }
+  R.M = (unsigned int)(R.len[0] + R.len[1] + R.len[2]);
+  return R;
+}
+
+// Philox blocks before the exact scan (a scan costs 2M loads): about M/8 blocks of 4 index
+// draws (32 .. 8192 draws), or M/4 blocks of 2 weighted tries (32 .. 8192)
+template <bool WT>
+__device__ __forceinline__ int fm_blocks(unsigned int M) {
+  return WT ? min(max((int)(M >> 2), 2 * FM_MIN_BLOCKS), 2 * FM_MAX_BLOCKS)
+            : min(max((int)(M >> 3), FM_MIN_BLOCKS), FM_MAX_BLOCKS);
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(256)
 k_find_mates(FocalP fp, GnxSoA s, const uint4* __restrict__ cand, double inv_cs,
              const int32_t* __restrict__ cell_start, int ncx, int ncy, int ref, float r, float r2,
-             int32_t* __restrict__ mate) {
+             int easy_rounds, int32_t* __restrict__ mate) {
   __shared__ int32_t list[FM_PER_BLOCK];
-  __shared__ int32_t wcnt[4];
+  __shared__ int32_t hard[FM_PER_BLOCK];
+  __shared__ int32_t wcnt[FM_PER_BLOCK / 256][4];
+  __shared__ int32_t n_hard_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t base = (int64_t)blockIdx.x * FM_PER_BLOCK;
   // phase 1: block-local, order-preserving list of the individuals that need a mate
-  int n_list = 0;
-  for (int round = 0; round < FM_PER_BLOCK / 256; ++round) {
+  // (all four rounds' loads and draws first, then one exchange of the wave counts)
+  constexpr int ROUNDS = FM_PER_BLOCK / 256;
+  bool okr[ROUNDS];
+  unsigned long long balr[ROUNDS];
+#pragma unroll
+  for (int round = 0; round < ROUNDS; ++round) {
     const int64_t i = base + round * 256 + tid;
     bool ok = false;
     if (i < fp.N) {
@@ -509,126 +552,207 @@ k_find_mates(FocalP fp, GnxSoA s, const uint4* __restrict__ cand, double inv_cs,
       ok = ok && s.age[i] >= fp.ra_f;
       if (!ok) mate[i] = -1;
     }
-    const unsigned long long bal = __ballot(ok);
-    if (lane == 0) wcnt[wave] = __popcll(bal);
-    __syncthreads();
-    int off = n_list;
-    for (int w = 0; w < wave; ++w) off += wcnt[w];
-    if (ok) list[off + __popcll(bal & ((1ull << lane) - 1ull))] = (int32_t)i;
-    n_list += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-    __syncthreads();
+    okr[round] = ok;
+    balr[round] = __ballot(ok);
+    if (lane == 0) wcnt[round][wave] = __popcll(balr[round]);
   }
+  if (tid == 0) n_hard_s = 0;
+  __syncthreads();
+  int n_list = 0;
+#pragma unroll
+  for (int round = 0; round < ROUNDS; ++round) {
+    int off = n_list;
+    for (int w = 0; w < wave; ++w) off += wcnt[round][w];
+    if (okr[round])
+      list[off + __popcll(balr[round] & ((1ull << lane) - 1ull))] =
+          (int32_t)(base + round * 256 + tid);
+    n_list += wcnt[round][0] + wcnt[round][1] + wcnt[round][2] + wcnt[round][3];
+  }
+  __syncthreads();
   // phase 2
   if (MODE != GNX_MATE_NEAREST) {
     // UNIFORM: one stream word per try (the index).  INVERSE-DISTANCE (P(j) ~ r - d_ij
     // over the neighbours with d > 0, utils/spatial.py:209-229): two words per try, the
     // index and an acceptance draw u: the candidate is taken iff u * r < r - d.
+    // The tries are examined in stream order, so the first accepted try is the one a
+    // sequential walk of the stream would take.  Most focal individuals are served by
+    // their first few tries (2a: one lane each, a round's candidates fetched TOGETHER -
+    // the loads are independent, the round trip to L2 / HBM is what a try costs); whoever
+    // is not (the edge of a clump: one in-radius neighbour among hundreds of candidates)
+    // would hold its whole wave for tens of rounds, so the rest go on a list that the
+    // block's waves work off one focal individual at a time (2b), a Philox block per lane:
+    // 256 (128 weighted) tries in flight per round.
     constexpr bool WT = MODE == GNX_MATE_INVERSE;
+    constexpr int STEP = WT ? 2 : 1;
     for (int t = tid; t < n_list; t += 256) {
       const int i = list[t];
       const uint4 me = cand[i];
       const float fx = __uint_as_float(me.x), fy = __uint_as_float(me.y);
-      const int k = gnx_cell_of(fx, fy, inv_cs, ncx, ncy);
-      const int cy = k / ncx;
-      const int cx = k - cy * ncx;
-      const int lo = max(cx - 1, 0), hi = min(cx + 1, ncx - 1);
-      // the three row ranges (an absent row has length 0)
-      int st[3], len[3];
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const int ry = cy - 1 + q;
-        const bool in = ry >= 0 && ry < ncy;
-        st[q] = in ? cell_start[ry * ncx + lo] : 0;
-        len[q] = in ? cell_start[ry * ncx + hi + 1] - st[q] : 0;
-      }
-      const unsigned int M = (unsigned int)(len[0] + len[1] + len[2]);
+      const FmRanges R = fm_ranges(fx, fy, inv_cs, ncx, ncy, cell_start);
+      const unsigned int M = R.M;
       const unsigned long long fid = (unsigned long long)s.id[i];
       int found = -1;
-      // Philox blocks before the exact scan (a scan costs 2M loads): about M/8 blocks of
-      // 4 index draws (32 .. 8192 draws), or M/4 blocks of 2 weighted tries (32 .. 8192)
-      const int blocks = WT ? min(max((int)(M >> 2), 2 * FM_MIN_BLOCKS), 2 * FM_MAX_BLOCKS)
-                            : min(max((int)(M >> 3), FM_MIN_BLOCKS), FM_MAX_BLOCKS);
+      bool open = false;
       if (M > 1) {
-        // one Philox block per round: its tries' candidates are fetched TOGETHER (the
-        // loads are independent, the round trip to L2 / HBM is what a try costs) and
-        // examined in stream order, so the first accepted try is the one a sequential
-        // walk of the stream would take
-        for (int blk = 0; blk < blocks && found < 0; blk += WT ? 2 : 1) {
+        const int early = min(fm_blocks<WT>(M), easy_rounds * STEP);
+        for (int blk = 0; blk < early && found < 0; blk += STEP) {
           // four tries per round: one Philox block of index words, or two blocks of
           // (index, acceptance) words
           const uint4 w = gnx_rand4(fp.seed, fid, fp.step, OP_MATE_PICK, blk);
-          const bool two = WT && blk + 1 < blocks;
-          const uint4 w2 = two ? gnx_rand4(fp.seed, fid, fp.step, OP_MATE_PICK, blk + 1) : w;
+          const uint4 w2 = WT ? gnx_rand4(fp.seed, fid, fp.step, OP_MATE_PICK, blk + 1) : w;
           const unsigned int wi[4] = {w.x, WT ? w.z : w.y, WT ? w2.x : w.z, WT ? w2.z : w.w};
           const unsigned int wa[4] = {w.y, w.w, w2.y, w2.w};
-          const int nt = WT ? (two ? 4 : 2) : 4;
           int slot[4];
           uint4 c[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const int j = (int)__umulhi(wi[q], M);
-            slot[q] = j < len[0] ? st[0] + j
-                      : (j < len[0] + len[1] ? st[1] + (j - len[0])
-                                             : st[2] + (j - len[0] - len[1]));
+            slot[q] = R.slot((int)__umulhi(wi[q], M));
             c[q] = cand[slot[q]];
           }
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const float dx = __uint_as_float(c[q].x) - fx, dy = __uint_as_float(c[q].y) - fy;
             const float d2 = dx * dx + dy * dy;
-            bool ok = q < nt && slot[q] != i && d2 <= r2;
+            bool ok = slot[q] != i && d2 <= r2;
             if (WT) ok = ok && d2 > 0.f && gnx_u01(wa[q]) * r < r - sqrtf(d2);
             if (ok && found < 0) found = slot[q];
           }
         }
-        if (found < 0) {
-          // exact fallback in canonical order: the (u * m)-th of the m in-radius
-          // candidates, or the first whose running weight passes u * (total weight)
-          GnxStream fb(fp.seed, (unsigned long long)s.id[i], fp.step, OP_MATE_PICK, blocks);
-          unsigned int m = 0;
-          float wsum = 0.f;
-          for (int q = 0; q < 3; ++q)
-            for (int slot = st[q]; slot < st[q] + len[q]; ++slot) {
-              const uint4 c = cand[slot];
-              const float dx = __uint_as_float(c.x) - fx, dy = __uint_as_float(c.y) - fy;
+        open = found < 0;
+      }
+      if (open)
+        hard[atomicAdd(&n_hard_s, 1)] = i;
+      else
+        mate[i] = found;
+    }
+    __syncthreads();
+    const int n_hard = n_hard_s;
+    for (int hh = wave; hh < n_hard; hh += 4) {
+      const int i = __builtin_amdgcn_readfirstlane(hard[hh]);
+      const uint4 me = cand[i];
+      const float fx = __uint_as_float(me.x), fy = __uint_as_float(me.y);
+      const FmRanges R = fm_ranges(fx, fy, inv_cs, ncx, ncy, cell_start);
+      const unsigned int M = R.M;
+      const unsigned long long fid = (unsigned long long)s.id[i];
+      const int blocks = fm_blocks<WT>(M);
+      int found = -1;
+      for (int b0 = easy_rounds * STEP; b0 < blocks && found < 0; b0 += 64) {
+        const int blk = b0 + lane;
+        const uint4 w = gnx_rand4(fp.seed, fid, fp.step, OP_MATE_PICK, blk);
+        constexpr int NT = WT ? 2 : 4;
+        const unsigned int wi[4] = {w.x, WT ? w.z : w.y, w.z, w.w};
+        const unsigned int wa[2] = {w.y, w.w};
+        int slot[NT];
+        uint4 c[NT];
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+          slot[q] = R.slot((int)__umulhi(wi[q], M));
+          c[q] = cand[slot[q]];
+        }
+        int mine = -1;
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+          const float dx = __uint_as_float(c[q].x) - fx, dy = __uint_as_float(c[q].y) - fy;
+          const float d2 = dx * dx + dy * dy;
+          bool ok = slot[q] != i && d2 <= r2;
+          if (WT) ok = ok && d2 > 0.f && gnx_u01(wa[q]) * r < r - sqrtf(d2);
+          if (ok && mine < 0) mine = slot[q];
+        }
+        // lanes hold ascending blocks: the lowest lane with an accepted try has the first
+        const unsigned long long bal = __ballot(blk < blocks && mine >= 0);
+        if (bal)
+          found = __builtin_amdgcn_readlane(
+              mine, __builtin_amdgcn_readfirstlane(__ffsll((long long)bal) - 1));
+      }
+      if (found < 0) {
+        // exact fallback in canonical order, 256 candidates per step (four independent
+        // loads per lane): the (u * m)-th of the m in-radius candidates, or the first whose
+        // running weight passes u * (total weight).  The f32 weights are added one by one in
+        // canonical order (v_readlane of the in-radius lanes only: skipping a zero changes
+        // nothing), so the sums are the sequential ones the oracle forms.
+        unsigned int m = 0;
+        float wsum = 0.f;
+        for (unsigned int j0 = 0; j0 < M; j0 += 256) {
+          uint4 c[4];
+          int sl[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const unsigned int j = j0 + q * 64 + lane;
+            sl[q] = j < M ? R.slot((int)j) : -1;
+            if (sl[q] >= 0) c[q] = cand[sl[q]];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float wj = 0.f;
+            bool in = false;
+            if (sl[q] >= 0) {
+              const float dx = __uint_as_float(c[q].x) - fx, dy = __uint_as_float(c[q].y) - fy;
               const float d2 = dx * dx + dy * dy;
-              const bool in = slot != i && d2 <= r2 && (!WT || d2 > 0.f);
-              m += in ? 1u : 0u;
-              if (WT && in) wsum = wsum + (r - sqrtf(d2));
+              in = sl[q] != i && d2 <= r2 && (!WT || d2 > 0.f);
+              if (WT && in) wj = r - sqrtf(d2);
             }
-          if (m > 0) {
-            const unsigned int w0 = fb.next();
-            unsigned int want = __umulhi(w0, m);
-            const float target = gnx_u01(w0) * wsum;
-            float run = 0.f;
-            int last = -1;
-            for (int q = 0; q < 3 && found < 0; ++q)
-              for (int slot = st[q]; slot < st[q] + len[q]; ++slot) {
-                const uint4 c = cand[slot];
-                const float dx = __uint_as_float(c.x) - fx, dy = __uint_as_float(c.y) - fy;
-                const float d2 = dx * dx + dy * dy;
-                if (slot != i && d2 <= r2 && (!WT || d2 > 0.f)) {
-                  if (WT) {
-                    run = run + (r - sqrtf(d2));
-                    last = slot;
-                    if (run > target) {
-                      found = slot;
-                      break;
-                    }
-                  } else {
-                    if (want == 0) {
-                      found = slot;
-                      break;
-                    }
-                    --want;
-                  }
-                }
+            unsigned long long bal = __ballot(in);
+            m += (unsigned int)__popcll(bal);
+            if (WT)
+              while (bal) {
+                const int k = __ffsll((long long)bal) - 1;
+                bal &= bal - 1;
+                wsum = wsum + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(wj), k));
               }
-            if (WT && found < 0) found = last;
           }
         }
+        if (m > 0) {
+          const uint4 w0 = gnx_rand4(fp.seed, fid, fp.step, OP_MATE_PICK, blocks);
+          unsigned int want = __umulhi(w0.x, m);
+          const float target = gnx_u01(w0.x) * wsum;
+          float run = 0.f;
+          int last = -1;
+          for (unsigned int j0 = 0; j0 < M && found < 0; j0 += 256) {
+            uint4 c[4];
+            int sl[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const unsigned int j = j0 + q * 64 + lane;
+              sl[q] = j < M ? R.slot((int)j) : -1;
+              if (sl[q] >= 0) c[q] = cand[sl[q]];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              float wj = 0.f;
+              bool in = false;
+              if (sl[q] >= 0) {
+                const float dx = __uint_as_float(c[q].x) - fx, dy = __uint_as_float(c[q].y) - fy;
+                const float d2 = dx * dx + dy * dy;
+                in = sl[q] != i && d2 <= r2 && (!WT || d2 > 0.f);
+                if (WT && in) wj = r - sqrtf(d2);
+              }
+              unsigned long long bal = __ballot(in);
+              if (found >= 0) continue;
+              if (WT) {
+                while (bal && found < 0) {
+                  const int k = __ffsll((long long)bal) - 1;
+                  bal &= bal - 1;
+                  run = run + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(wj), k));
+                  last = __builtin_amdgcn_readlane(sl[q], k);
+                  if (run > target) found = last;
+                }
+              } else {
+                const unsigned int n_in = (unsigned int)__popcll(bal);
+                if (want < n_in) {
+                  const unsigned long long pick = __ballot(
+                      in && (unsigned int)__popcll(bal & ((1ull << lane) - 1ull)) == want);
+                  found = __builtin_amdgcn_readlane(
+                      sl[q], __builtin_amdgcn_readfirstlane(__ffsll((long long)pick) - 1));
+                } else {
+                  want -= n_in;
+                }
+              }
+            }
+          }
+          if (WT && found < 0) found = last;
+        }
       }
-      mate[i] = found;
+      if (lane == 0) mate[i] = found;
     }
     return;
   }
@@ -833,15 +957,16 @@ int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out, 
     FocalP fp{N, d_keep, (float)sp.b, sexed, sp.repro_age[0], h->step, h->cfg.seed};
     dim3 grid(gnx_grid(N, FM_PER_BLOCK)), blk(256);
     const uint4* cd = (const uint4*)h->cand;
+    static const int easy = getenv("GNX_FM_EASY") ? std::max(1, atoi(getenv("GNX_FM_EASY"))) : 2;
     if (sp.mate_mode == GNX_MATE_NEAREST)
       hipLaunchKernelGGL(k_find_mates<GNX_MATE_NEAREST>, grid, blk, 0, h->stream, fp, s, cd,
-                         h->inv_cs, h->cell_start, h->ncx, h->ncy, h->cell_ref, r, r2, h->mate);
+                         h->inv_cs, h->cell_start, h->ncx, h->ncy, h->cell_ref, r, r2, easy, h->mate);
     else if (sp.mate_mode == GNX_MATE_INVERSE)
       hipLaunchKernelGGL(k_find_mates<GNX_MATE_INVERSE>, grid, blk, 0, h->stream, fp, s, cd,
-                         h->inv_cs, h->cell_start, h->ncx, h->ncy, h->cell_ref, r, r2, h->mate);
+                         h->inv_cs, h->cell_start, h->ncx, h->ncy, h->cell_ref, r, r2, easy, h->mate);
     else
       hipLaunchKernelGGL(k_find_mates<GNX_MATE_UNIFORM>, grid, blk, 0, h->stream, fp, s, cd,
-                         h->inv_cs, h->cell_start, h->ncx, h->ncy, h->cell_ref, r, r2, h->mate);
+                         h->inv_cs, h->cell_start, h->ncx, h->ncy, h->cell_ref, r, r2, easy, h->mate);
   }
   gnx_time_end(h, GNX_K_FIND_MATES, (double)N * 16.0);
   gnx_time_begin(h);

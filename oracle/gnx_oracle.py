@@ -395,7 +395,8 @@ def mate_blocks_weighted(M):
     return np.clip(np.asarray(M, dtype=np.int64) >> 2, 16, 4096)
 
 
-def choose_mates_uniform(x, y, ids, radius, seed, step, dim, focal=None, weighted=False):
+def choose_mates_uniform(x, y, ids, radius, seed, step, dim, focal=None, weighted=False,
+                         fallback_out=None):
     """The build's uniform mate choice (utils/spatial.py:232-242 picks
     np.random.choice among the neighbours within the radius): rejection sampling in
     index space.  Candidates of a focal individual = the individuals in the 3x3 block
@@ -410,7 +411,8 @@ def choose_mates_uniform(x, y, ids, radius, seed, step, dim, focal=None, weighte
     draw u - the candidate drawn is taken iff u * r < r - d (f32); after
     mate_blocks_weighted(M) blocks the exact pick: total weight W summed in canonical order
     (f32), then the first candidate whose running weight passes u01(w) * W.
-    focal: optional mask of the individuals that need a mate (others get -1)."""
+    focal: optional mask of the individuals that need a mate (others get -1);
+    fallback_out: optional bool array, set where the exact pick decided."""
     import philox as P
     F = np.float32
     x = np.asarray(x, dtype=F)
@@ -486,6 +488,8 @@ def choose_mates_uniform(x, y, ids, radius, seed, step, dim, focal=None, weighte
             sel = sel & (d2 > 0)
         inr = c[sel]
         if inr.size:
+            if fallback_out is not None:
+                fallback_out[i] = True
             w = int(P.philox4x32(seed, fid[k:k + 1],
                                  P.block_index(step, P.OP_MATE_PICK, int(blocks[k])))[0, 0])
             if not weighted:
@@ -506,6 +510,14 @@ def choose_mates_uniform(x, y, ids, radius, seed, step, dim, focal=None, weighte
                 found[k] = pick
     mate[foc] = found
     return mate
+
+
+def mate_fallbacks(x, y, ids, radius, seed, step, mode='uniform', dim=None, focal=None):
+    """Who ran out of index tries and took the exact pick (test instrumentation)."""
+    out = np.zeros(np.asarray(x).size, dtype=bool)
+    choose_mates_uniform(x, y, ids, radius, seed, step, dim, focal=focal,
+                         weighted=mode == 'inverse', fallback_out=out)
+    return out
 
 
 def choose_mates(x, y, ids, radius, seed, step, mode='uniform',

@@ -376,6 +376,52 @@ def test_find_pairs_vs_oracle(mode):
     dev.close()
 
 
+@pytest.mark.parametrize('mode', ['uniform', 'nearest', 'inverse'])
+def test_find_pairs_at_the_edge_of_a_clump(mode):
+    """The hard case of the index sampling: a focal individual with two in-radius
+    neighbours among ~400 candidates (a dense blob in the next hash cell, out of reach).
+    Most of its tries are rejected, so the block's waves take it over (a Philox block per
+    lane) and many end in the exact scan; every one must still equal the oracle's walk of
+    the same stream (utils/spatial.py:209-241)."""
+    nat = native()
+    rng = np.random.RandomState(31)
+    W, H, r = 80, 60, 2.5
+    xs, ys = [], []
+    centres = [(11.25, 11.25), (41.25, 31.25), (61.25, 13.75), (23.75, 46.25), (68.75, 48.75)]
+    for cx, cy in centres:
+        xs.append(cx + 0.15 * rng.randn(400))
+        ys.append(cy + 0.15 * rng.randn(400))
+        th = np.arange(12) * (2 * np.pi / 12) + rng.rand() * 0.3
+        xs.append(cx + 3.3 * np.cos(th))
+        ys.append(cy + 3.3 * np.sin(th))
+    xs.append(rng.rand(300) * W)
+    ys.append(rng.rand(300) * H)
+    x = np.concatenate(xs).astype(np.float32)
+    y = np.concatenate(ys).astype(np.float32)
+    n = x.size
+    ids = np.sort(rng.choice(10**5, n, replace=False))
+    mm = {'uniform': nat.MATE_UNIFORM, 'nearest': nat.MATE_NEAREST,
+          'inverse': nat.MATE_INVERSE}[mode]
+    dev = make_dev(W, H, cap=4096, seed=123, mating_radius=r, mate_mode=mm, b=1.0)
+    upload_simple(dev, x, y, ids=ids)
+    dev.step_index = 2
+    keep = np.ones(n, bool)
+    mate, _ = dev.op_find_pairs(keep)
+    o = _slot_maps(dev, ids)
+    got = np.full(n, -2)
+    got[o] = np.where(mate >= 0, o[np.maximum(mate, 0)], -1)
+    exp = O.choose_mates(x, y, ids, r, 123, 2, mode=mode, dim=(W, H))
+    np.testing.assert_array_equal(got, exp)
+    ring = np.concatenate([np.arange(400, 412) + 412 * k for k in range(len(centres))])
+    assert (exp[ring] >= 0).all()
+    if mode != 'nearest':
+        # the case is what it claims to be: a good share of the ring's individuals run out
+        # of tries (about M/2 of them) and take the exact scan
+        n_fb = O.mate_fallbacks(x, y, ids, r, 123, 2, mode=mode, dim=(W, H))[ring].sum()
+        assert n_fb >= 8, n_fb
+    dev.close()
+
+
 def test_nearest_pairs_vs_reference_kdtree():
     nat = native()
     g = load_golden('g8_pairing')
