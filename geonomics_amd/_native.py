@@ -18,7 +18,7 @@ SURF_NONE, SURF_MIXTURE, SURF_UNIMODAL = 0, 1, 2
 (F_X, F_Y, F_AGE, F_SEX, F_ID, F_E, F_Z, F_FIT, F_GROW, F_GENO) = range(10)
 (R_N, R_NPAIRS, R_K, R_D, R_COUNTS) = range(5)
 KERNELS = ['move', 'sort', 'permute', 'find_mates', 'pairs', 'offspring',
-           'crossover', 'phenotype', 'density', 'death', 'compact']
+           'crossover', 'phenotype', 'density', 'death', 'compact', 'crossover_tail']
 
 EXPORTS = [
     'gnx_create', 'gnx_destroy', 'gnx_last_error', 'gnx_words_per_hom',
@@ -45,7 +45,7 @@ EXPORTS = [
     'gnx_tile_import_dev', 'gnx_tile_import_ghosts_dev', 'gnx_tile_pair_ptrs',
     'gnx_tile_offspring_dev', 'gnx_tile_group_requests', 'gnx_tile_serve_gametes_dev',
     'gnx_tile_put_gametes_dev', 'gnx_tile_bins_ptr', 'gnx_set_k_raster', 'gnx_last_births', 'gnx_set_positions', 'gnx_n_slots', 'gnx_stats_ld_counts',
-    'gnx_set_defer_crossover', 'gnx_last_crossover_births', 'gnx_set_crossover_overlap', 'gnx_spatial_diff_sums', 'gnx_last_crossover_jobs',
+    'gnx_set_defer_crossover', 'gnx_last_crossover_births', 'gnx_set_crossover_overlap', 'gnx_set_crossover_split', 'gnx_spatial_diff_sums', 'gnx_last_crossover_jobs',
 ]
 
 
@@ -296,6 +296,11 @@ class Device:
         """False (default): the crossover keeps the chip, the next cell sort waits for it;
         True: a narrow crossover runs beside the whole next step"""
         self._chk(self.lib.gnx_set_crossover_overlap(self.h, int(bool(whole_step))))
+
+    def set_crossover_split(self, wide_per_1024):
+        """share (/1024) of a deferred crossover's jobs that runs at full width before the next
+        cell sort; the rest runs narrow beside the sort and the kernels after it"""
+        self._chk(self.lib.gnx_set_crossover_split(self.h, int(wide_per_1024)))
 
     def last_crossover_jobs(self):
         """int32 [n, 4]: parent row, child half-row, path key, start homologue"""

@@ -3,6 +3,8 @@
 #include <cmath>
 #include <cstdarg>
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include "gnx_internal.h"
 #include "gnx_rng.h"
 
@@ -36,6 +38,26 @@ static hipEvent_t timer_event(gnx_state* h) {
   hipEvent_t e = nullptr;
   (void)hipEventCreate(&e);
   return e;
+}
+
+int gnx_wait_published(gnx_state* h, int slot, int64_t seq) {
+  volatile int64_t* word = h->h_pin + slot + 3;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int spin = 0; *word != seq; ++spin) {
+    if ((spin & 1023) == 1023 &&
+        std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
+      // something is slow or has gone wrong: let the runtime wait and report
+      HIPCHK(hipStreamSynchronize(h->stream));
+      if (*word != seq) {
+        gnx_set_error("read-back of device counters never arrived");
+        return 1;
+      }
+      break;
+    }
+    __builtin_ia32_pause();
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return 0;
 }
 
 void gnx_time_begin(gnx_state* h) {
@@ -311,13 +333,17 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
   GNXCHK(dalloc(&h->blk_cnt, (size_t)3 * h->blk_stride));
   GNXCHK(dalloc(&h->blk_off, (size_t)3 * h->blk_stride));
   GNXCHK(dalloc(&h->cnt_dev, 8));
-  HIPCHK(hipHostMalloc((void**)&h->h_pin, 16 * sizeof(int64_t)));
+  // fine-grained: the host polls words that kernels write (gnx_wait_published)
+  HIPCHK(hipHostMalloc((void**)&h->h_pin, 16 * sizeof(int64_t),
+                       hipHostMallocCoherent | hipHostMallocMapped));
+  memset(h->h_pin, 0, 16 * sizeof(int64_t));
   HIPCHK(hipHostGetDevicePointer((void**)&h->h_pin_dev, h->h_pin, 0));
   if (cfg->L > 0) {
     for (int k = 0; k < 2; ++k) {
       HIPCHK(hipMalloc(&h->jobs[k], (size_t)cap * 2 * 16));
       GNXCHK(dalloc(&h->n_jobs_dev[k], 1));
       HIPCHK(hipEventCreateWithFlags(&h->ev_xo_done[k], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&h->ev_xo_wide[k], hipEventDisableTiming));
     }
     HIPCHK(hipEventCreateWithFlags(&h->ev_jobs, hipEventDisableTiming));
   }
@@ -326,6 +352,7 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
   if (getenv("GNX_XO_LAUNCH")) h->xo_launch_policy = atoi(getenv("GNX_XO_LAUNCH"));
   if (getenv("GNX_XO_SORT_WAIT")) h->xo_sort_waits = atoi(getenv("GNX_XO_SORT_WAIT")) != 0;
   if (getenv("GNX_XO_WAIT")) h->xo_wait_at = atoi(getenv("GNX_XO_WAIT"));
+  if (getenv("GNX_XO_SPLIT")) h->xo_split = std::min(1024, std::max(0, atoi(getenv("GNX_XO_SPLIT"))));
   *out = h;
   return 0;
 }
@@ -339,6 +366,7 @@ extern "C" void gnx_destroy(gnx_state* h) {
     (void)hipFree(h->jobs[k]);
     (void)hipFree(h->n_jobs_dev[k]);
     if (h->ev_xo_done[k]) (void)hipEventDestroy(h->ev_xo_done[k]);
+    if (h->ev_xo_wide[k]) (void)hipEventDestroy(h->ev_xo_wide[k]);
   }
   if (h->ev_jobs) (void)hipEventDestroy(h->ev_jobs);
   if (h->ev_counts) (void)hipEventDestroy(h->ev_counts);
@@ -973,6 +1001,14 @@ extern "C" int gnx_last_crossover_jobs(gnx_state* h, void* dst, int64_t max_jobs
 extern "C" int gnx_set_crossover_overlap(gnx_state* h, int32_t whole_step) {
   GNXCHK(gnx_xo_join(h));
   h->xo_sort_waits = whole_step == 0;
+  return 0;
+}
+
+// wide_per_1024 of every deferred crossover's jobs run at full width before the next cell
+// sort, the rest narrow beside the sort and what follows it (0 or 1024: one launch)
+extern "C" int gnx_set_crossover_split(gnx_state* h, int32_t wide_per_1024) {
+  GNXCHK(gnx_xo_join(h));
+  h->xo_split = std::min(1024, std::max(0, (int)wide_per_1024));
   return 0;
 }
 

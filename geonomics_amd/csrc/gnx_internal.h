@@ -167,6 +167,10 @@ struct gnx_state {
   hipEvent_t ev_jobs = nullptr, ev_xo_done[2]{};
   hipEvent_t ev_counts = nullptr;   // the step's counts have reached pinned host memory
   bool xo_inflight[2]{};         // ev_xo_done[k] recorded and not yet joined
+  hipEvent_t ev_xo_wide[2]{};    // end of the full-width share of a split launch
+  bool xo_wide_inflight[2]{};
+  int xo_split = 0;              // /1024 of the jobs that run at full width (0 = no split)
+  int xo_last_split = 0;         // the split of the latest deferred launch
   bool xo_running = false;       // a crossover may still be running on stream2
   // How the deferred crossover shares the chip with the next step's small kernels
   // (measured: profiles/r02_xo_overlap_*.txt).  They are latency-bound chains (index
@@ -292,6 +296,7 @@ struct gnx_state {
   // pinned host scratch for read-backs
   int64_t* h_pin = nullptr;          // [16]
   int64_t* h_pin_dev = nullptr;      // the same memory as the device sees it
+  int64_t pin_seq = 0;               // sequence numbers of the polled read-backs
   void* h_stage = nullptr;           // pinned host staging buffer for per-step transfers
   size_t h_stage_bytes = 0;
 
@@ -358,6 +363,7 @@ int gnx_xo_flush_deferred(gnx_state* h);
 int gnx_xo_launch_pending(gnx_state* h);
 // `stream` waits for the crossover in flight (not for one that is not launched yet)
 int gnx_xo_wait_inflight(gnx_state* h);
+int gnx_xo_wait_wide(gnx_state* h);
 double gnx_xo_bytes_per_birth(const gnx_state* h);
 // selected-locus tables: rebuild sel_loci / path_sel / GnxSoA.tb after a change of the
 // traits, the deleterious loci or the recombination paths
@@ -394,7 +400,11 @@ int gnx_l_scatter_genomes(gnx_state* h, int64_t n, const uint64_t* d_in, int64_t
 // <= 3, -> exclusive block offsets off[...], totals to out[0..2] on the device and to
 // pinned host memory
 int gnx_block_scan(gnx_state* h, int K, int64_t n_items, const int32_t* cnt, int32_t* off,
-                   int32_t* out, int64_t* host);
+                   int32_t* out, int64_t* host, int64_t seq = 0);
+// the host spins on pinned word h_pin[slot + 3] until the scan kernel given `seq` has
+// published its totals there (falls back to a stream sync after a while): no wait for the
+// kernels queued behind the scan, no driver wake-up latency
+int gnx_wait_published(gnx_state* h, int slot, int64_t seq);
 
 // rocPRIM wrappers (gnx_prim.hip)
 int gnx_prim_sort_bytes(size_t n, int bits, size_t* bytes);

@@ -693,7 +693,13 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
     const int64_t S = h->h_pin[2];
     h->n_free -= S;
     h->last_xo_births = S;
-    if (h->profiling) h->timers[GNX_K_CROSSOVER].bytes += (double)S * gnx_xo_bytes_per_birth(h);
+    if (h->profiling) {
+      // a split launch: the first (2S * split) >> 10 gametes ran at full width
+      const double per_job = 0.5 * gnx_xo_bytes_per_birth(h);
+      const int64_t wide = h->xo_last_split ? ((2 * S * h->xo_last_split) >> 10) : 2 * S;
+      h->timers[GNX_K_CROSSOVER].bytes += (double)wide * per_job;
+      h->timers[GNX_K_CROSSOVER_TAIL].bytes += (double)(2 * S - wide) * per_job;
+    }
   }
   if (has_rows) h->n_free += rows_freed;
   *deaths_out = N - h->n_ghost - survivors;       // ghosts are dropped, not counted

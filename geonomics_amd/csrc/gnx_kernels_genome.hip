@@ -45,20 +45,24 @@ void gnx_launch_xo_jobs_surv(gnx_state* h, int64_t first_slot, const int32_t* d_
                              const int32_t* d_blk_off, int buf);
 
 template <int U>
-static void xo_launch_sparse(gnx_state* h, hipStream_t st, int grid, int buf, bool nt) {
+static void xo_launch_sparse(gnx_state* h, hipStream_t st, int grid, int buf, bool nt, int lo,
+                             int hi) {
   const int W16 = h->W64 / 2;
   if (nt)
     hipLaunchKernelGGL((k_xo_sparse<U, true>), dim3(grid), dim3(256), 0, st, h->n_jobs_dev[buf],
                        W16, (const u64x2*)h->G, (u64x2*)h->G, (const GnxXoJob*)h->jobs[buf],
-                       h->bp_off, h->bp_loci);
+                       h->bp_off, h->bp_loci, lo, hi);
   else
     hipLaunchKernelGGL((k_xo_sparse<U, false>), dim3(grid), dim3(256), 0, st, h->n_jobs_dev[buf],
                        W16, (const u64x2*)h->G, (u64x2*)h->G, (const GnxXoJob*)h->jobs[buf],
-                       h->bp_off, h->bp_loci);
+                       h->bp_off, h->bp_loci, lo, hi);
 }
 
-// the crossover of job buffer `buf` on stream `st`; max_jobs bounds the grid
-static int xo_launch(gnx_state* h, hipStream_t st, int buf, int64_t max_jobs, bool deferred) {
+// the crossover of job buffer `buf` on stream `st` (the share [lo, hi) / 1024 of its jobs);
+// max_jobs bounds the grid.  narrow: few workgroups per CU, for a launch that shares the
+// chip with the step's small kernels.
+static int xo_launch(gnx_state* h, hipStream_t st, int buf, int64_t max_jobs, bool narrow,
+                     int lo = 0, int hi = 1024) {
   // one wave per gamete, 4 waves per block, job-strided beyond 32 blocks per CU
   // (measured: profiles/r02b_xo_lab_*.txt - time is flat in the grid size from 16 to 64
   // blocks per CU and in the unroll from 4 to 8; non-temporal loads +2 %); beside a whole
@@ -66,18 +70,19 @@ static int xo_launch(gnx_state* h, hipStream_t st, int buf, int64_t max_jobs, bo
   static const int bpc_env = getenv("GNX_XO_BPC") ? atoi(getenv("GNX_XO_BPC")) : 0;
   static const int unroll_env = getenv("GNX_XO_UNROLL") ? atoi(getenv("GNX_XO_UNROLL")) : 0;
   static const int nt = getenv("GNX_XO_NT") ? atoi(getenv("GNX_XO_NT")) : 1;
-  const bool narrow = deferred && !h->xo_sort_waits;
-  const int bpc = bpc_env ? bpc_env : (narrow ? 2 : 32);
+  static const int tail_bpc = getenv("GNX_XO_TAIL_BPC") ? atoi(getenv("GNX_XO_TAIL_BPC")) : 2;
+  static const int tail_unroll = getenv("GNX_XO_TAIL_UNROLL") ? atoi(getenv("GNX_XO_TAIL_UNROLL")) : 6;
+  const int bpc = narrow ? tail_bpc : (bpc_env ? bpc_env : 32);
   const int W16 = h->W64 / 2;
   const int grid = gnx_grid(max_jobs, 4, 256 * bpc);
   if (h->sparse_paths) {
-    const int U = unroll_env ? unroll_env : (narrow ? 6 : gnx_xo_pick_unroll(W16));
+    const int U = narrow ? tail_unroll : (unroll_env ? unroll_env : gnx_xo_pick_unroll(W16));
     switch (U) {
-      case 4: xo_launch_sparse<4>(h, st, grid, buf, nt); break;
-      case 5: xo_launch_sparse<5>(h, st, grid, buf, nt); break;
-      case 6: xo_launch_sparse<6>(h, st, grid, buf, nt); break;
-      case 7: xo_launch_sparse<7>(h, st, grid, buf, nt); break;
-      default: xo_launch_sparse<8>(h, st, grid, buf, nt); break;
+      case 4: xo_launch_sparse<4>(h, st, grid, buf, nt, lo, hi); break;
+      case 5: xo_launch_sparse<5>(h, st, grid, buf, nt, lo, hi); break;
+      case 6: xo_launch_sparse<6>(h, st, grid, buf, nt, lo, hi); break;
+      case 7: xo_launch_sparse<7>(h, st, grid, buf, nt, lo, hi); break;
+      default: xo_launch_sparse<8>(h, st, grid, buf, nt, lo, hi); break;
     }
   } else {
     // dense masks: genome chunks stream past once (non-temporal), the path table is
@@ -85,11 +90,11 @@ static int xo_launch(gnx_state* h, hipStream_t st, int buf, int64_t max_jobs, bo
     if (nt)
       hipLaunchKernelGGL((k_xo_dense<4, true>), dim3(grid), dim3(256), 0, st, h->n_jobs_dev[buf],
                          W16, (const u64x2*)h->G, (u64x2*)h->G, (const GnxXoJob*)h->jobs[buf],
-                         (const u64x2*)h->paths);
+                         (const u64x2*)h->paths, lo, hi);
     else
       hipLaunchKernelGGL((k_xo_dense<4, false>), dim3(grid), dim3(256), 0, st, h->n_jobs_dev[buf],
                          W16, (const u64x2*)h->G, (u64x2*)h->G, (const GnxXoJob*)h->jobs[buf],
-                         (const u64x2*)h->paths);
+                         (const u64x2*)h->paths, lo, hi);
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -109,6 +114,7 @@ static int xo_wait_buf(gnx_state* h, hipStream_t st, int buf) {
   if (h->xo_inflight[buf]) {
     HIPCHK(hipStreamWaitEvent(st, h->ev_xo_done[buf], 0));
     h->xo_inflight[buf] = false;
+    h->xo_wide_inflight[buf] = false;
   }
   return 0;
 }
@@ -237,9 +243,23 @@ int gnx_xo_launch_pending(gnx_state* h) {
   HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_jobs, 0));
   hipStream_t main = h->stream;
   h->stream = h->stream2;                        // the timer events go where the kernel goes
+  // Split launch (xo_split / 1024 of the jobs): the first share at full width, alone on the
+  // chip but for the compaction and the next step's movement - the cell sort waits for it;
+  // the rest narrow, beside the sort, the mate search, the density and the death draws,
+  // which are latency-bound chains and leave the memory system idle.
+  const int split = (h->xo_sort_waits && h->xo_split > 0 && h->xo_split < 1024) ? h->xo_split : 0;
+  h->xo_last_split = split;
   gnx_time_begin(h);
-  int rc = xo_launch(h, h->stream2, buf, h->xo_ready_jobs, true);
+  int rc = xo_launch(h, h->stream2, buf, h->xo_ready_jobs, !h->xo_sort_waits, 0,
+                     split ? split : 1024);
   gnx_time_end(h, GNX_K_CROSSOVER, 0.0);         // bytes are added once the survivors are counted
+  if (split && !rc) {
+    HIPCHK(hipEventRecord(h->ev_xo_wide[buf], h->stream2));
+    h->xo_wide_inflight[buf] = true;
+    gnx_time_begin(h);
+    rc = xo_launch(h, h->stream2, buf, h->xo_ready_jobs, true, split, 1024);
+    gnx_time_end(h, GNX_K_CROSSOVER_TAIL, 0.0);
+  }
   h->stream = main;
   GNXCHK(rc);
   HIPCHK(hipEventRecord(h->ev_xo_done[buf], h->stream2));
@@ -251,6 +271,20 @@ int gnx_xo_launch_pending(gnx_state* h) {
 int gnx_xo_wait_inflight(gnx_state* h) {
   GNXCHK(xo_wait_buf(h, h->stream, 0));
   GNXCHK(xo_wait_buf(h, h->stream, 1));
+  return 0;
+}
+
+// what the cell sort waits for: the full-width share of a split launch (its narrow share
+// runs on beside the sort), or the whole crossover
+int gnx_xo_wait_wide(gnx_state* h) {
+  for (int buf = 0; buf < 2; ++buf) {
+    if (h->xo_wide_inflight[buf]) {
+      HIPCHK(hipStreamWaitEvent(h->stream, h->ev_xo_wide[buf], 0));
+      h->xo_wide_inflight[buf] = false;
+    } else if (!h->xo_last_split) {
+      GNXCHK(xo_wait_buf(h, h->stream, buf));
+    }
+  }
   return 0;
 }
 

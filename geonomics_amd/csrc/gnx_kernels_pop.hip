@@ -399,7 +399,7 @@ int gnx_l_sort_by_cell(gnx_state* h) {
   int64_t N = h->N;
   if (N == 0) return 0;
   GNXCHK(gnx_xo_flush_deferred(h));   // slots move: offspring still waiting for their crossover get it now
-  if (h->xo_sort_waits) GNXCHK(gnx_xo_wait_inflight(h));   // the radix sort runs alone
+  if (h->xo_sort_waits) GNXCHK(gnx_xo_wait_wide(h));   // the radix sort runs alone, or beside a narrow tail
   const gnx_config& c = h->cfg;
   GnxSoA a = h->soa[h->cur], b = h->soa[h->cur ^ 1];
   const int idbits = gnx_id_bits(h);
@@ -975,7 +975,8 @@ int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out, 
            (sexed || sp.mating_radius < 0) ? 0 : 1,      // no dedup for sexed / panmictic
            h->step, h->cfg.seed};
   hipLaunchKernelGGL(k_pair_flags, dim3(nb), dim3(256), 0, h->stream, pp, s, h->flag2, h->blk_cnt);
-  GNXCHK(gnx_block_scan(h, 1, N, h->blk_cnt, h->blk_off, h->cnt_dev, h->h_pin_dev + 4));
+  const int64_t seq = ++h->pin_seq;
+  GNXCHK(gnx_block_scan(h, 1, N, h->blk_cnt, h->blk_off, h->cnt_dev, h->h_pin_dev + 4, seq));
   // (the population was sorted by gnx_l_sort_by_cell with this idbits: max_id has not moved)
   hipLaunchKernelGGL(k_pair_compact, dim3(nb), dim3(256), 0, h->stream, N, focal, h->mate,
                      h->flag2, h->blk_off, s.x, s.y, h->key64[1], gnx_id_bits(h), h->pairs,
@@ -991,7 +992,9 @@ int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out, 
     else
       with_density = false;
   }
-  HIPCHK(hipStreamSynchronize(h->stream));
+  // the pair count comes from the scan kernel through pinned memory; the kernels queued
+  // behind it (pair list, midpoint density) keep the GPU busy while the host goes on
+  GNXCHK(gnx_wait_published(h, 4, seq));
   h->n_pairs = h->h_pin[4];
   *n_pairs_out = h->n_pairs;
   if (!with_density) h->spl_P.valid = false;

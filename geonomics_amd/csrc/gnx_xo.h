@@ -90,12 +90,16 @@ template <int U, bool NT_LD>
 __global__ void __launch_bounds__(256)
 k_xo_sparse(const int32_t* __restrict__ n_jobs_p, int W16, const u64x2* __restrict__ G,
             u64x2* __restrict__ Gout, const GnxXoJob* __restrict__ jobs,
-            const int32_t* __restrict__ bp_off, const int32_t* __restrict__ bp_loci) {
+            const int32_t* __restrict__ bp_off, const int32_t* __restrict__ bp_loci,
+            int part_lo, int part_hi) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int n_jobs = *n_jobs_p;
+  // this launch's share of the job list, in 1/1024ths of the (device-resident) count
+  const int n_all = *n_jobs_p;
+  const int j_lo = (int)(((long long)n_all * part_lo) >> 10);
+  const int n_jobs = (int)(((long long)n_all * part_hi) >> 10);
   const int n_waves = (int)gridDim.x * 4;
-  for (int j = (int)blockIdx.x * 4 + wv; j < n_jobs; j += n_waves) {
+  for (int j = j_lo + (int)blockIdx.x * 4 + wv; j < n_jobs; j += n_waves) {
     const GnxXoJob jb = jobs[j];
     const int prow = __builtin_amdgcn_readfirstlane(jb.prow);
     if (prow < 0) continue;      // ghost parent (tiled run): the gamete arrives from its tile
@@ -147,12 +151,14 @@ template <int U, bool NT_LD>
 __global__ void __launch_bounds__(256)
 k_xo_dense(const int32_t* __restrict__ n_jobs_p, int W16, const u64x2* __restrict__ G,
            u64x2* __restrict__ Gout, const GnxXoJob* __restrict__ jobs,
-           const u64x2* __restrict__ paths) {
+           const u64x2* __restrict__ paths, int part_lo, int part_hi) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int n_jobs = *n_jobs_p;
+  const int n_all = *n_jobs_p;
+  const int j_lo = (int)(((long long)n_all * part_lo) >> 10);
+  const int n_jobs = (int)(((long long)n_all * part_hi) >> 10);
   const int n_waves = (int)gridDim.x * 4;
-  for (int j = (int)blockIdx.x * 4 + wv; j < n_jobs; j += n_waves) {
+  for (int j = j_lo + (int)blockIdx.x * 4 + wv; j < n_jobs; j += n_waves) {
     const GnxXoJob jb = jobs[j];
     const int prow = __builtin_amdgcn_readfirstlane(jb.prow);
     if (prow < 0) continue;      // ghost parent (tiled run): the gamete arrives from its tile

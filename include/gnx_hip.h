@@ -55,7 +55,8 @@ enum {
   GNX_K_MOVE = 0, GNX_K_SORT = 1, GNX_K_PERMUTE = 2, GNX_K_FIND_MATES = 3,
   GNX_K_PAIRS = 4, GNX_K_OFFSPRING = 5, GNX_K_CROSSOVER = 6,
   GNX_K_PHENOTYPE = 7, GNX_K_DENSITY = 8, GNX_K_DEATH = 9, GNX_K_COMPACT = 10,
-  GNX_K_COUNT = 11
+  GNX_K_CROSSOVER_TAIL = 11,   /* the narrow share of a split crossover launch */
+  GNX_K_COUNT = 12
 };
 
 /* ---- configuration ------------------------------------------------------ */
@@ -194,6 +195,11 @@ int gnx_set_defer_crossover(gnx_state* h, int32_t on);
  * sort waits for it - the crossover keeps its full rate.  1: a narrow crossover runs
  * beside the WHOLE next step - more individual-timesteps/s, a slower crossover.        */
 int gnx_set_crossover_overlap(gnx_state* h, int32_t whole_step);
+/* Split every deferred crossover launch: wide_per_1024 / 1024 of its jobs at full width
+ * (the next cell sort waits for them), the rest as a narrow launch that shares the chip
+ * with the sort and the kernels after it.  0 or 1024 = one launch.  Results do not depend
+ * on it. */
+int gnx_set_crossover_split(gnx_state* h, int32_t wide_per_1024);
 /* measurement: the job list of the last crossover, 16 bytes per gamete {parent row,
  * child half-row, path, start homologue} (csrc/gnx_xo.h); tools/xo_lab.hip replays it   */
 int gnx_last_crossover_jobs(gnx_state* h, void* dst, int64_t max_jobs, int64_t* n_jobs);
