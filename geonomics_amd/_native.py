@@ -45,7 +45,7 @@ EXPORTS = [
     'gnx_tile_import_dev', 'gnx_tile_import_ghosts_dev', 'gnx_tile_pair_ptrs',
     'gnx_tile_offspring_dev', 'gnx_tile_group_requests', 'gnx_tile_serve_gametes_dev',
     'gnx_tile_put_gametes_dev', 'gnx_tile_bins_ptr', 'gnx_set_k_raster', 'gnx_last_births', 'gnx_set_positions', 'gnx_n_slots', 'gnx_stats_ld_counts',
-    'gnx_set_defer_crossover', 'gnx_last_crossover_births', 'gnx_set_crossover_overlap', 'gnx_set_crossover_split', 'gnx_spatial_diff_sums', 'gnx_last_crossover_jobs',
+    'gnx_set_defer_crossover', 'gnx_last_crossover_births', 'gnx_set_crossover_overlap', 'gnx_set_crossover_split', 'gnx_debug_halves', 'gnx_spatial_diff_sums', 'gnx_last_crossover_jobs',
 ]
 
 
@@ -296,6 +296,13 @@ class Device:
         """False (default): the crossover keeps the chip, the next cell sort waits for it;
         True: a narrow crossover runs beside the whole next step"""
         self._chk(self.lib.gnx_set_crossover_overlap(self.h, int(bool(whole_step))))
+
+    def debug_halves(self):
+        """(rows in use, broken references, sum of reference counts, half-rows in use, free
+        half-rows, half-rows in all) of the shared genome half-rows"""
+        out = np.zeros(6, np.int64)
+        self._chk(self.lib.gnx_debug_halves(self.h, _ptr(out, C.c_int64)))
+        return out
 
     def set_crossover_split(self, wide_per_1024):
         """share (/1024) of a deferred crossover's jobs that runs at full width before the next

@@ -42,6 +42,11 @@ static hipEvent_t timer_event(gnx_state* h) {
 
 int gnx_wait_published(gnx_state* h, int slot, int64_t seq) {
   volatile int64_t* word = h->h_pin + slot + 3;
+  static const bool poll = !(getenv("GNX_POLL") && atoi(getenv("GNX_POLL")) == 0);
+  if (!poll) {
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+  }
   const auto t0 = std::chrono::steady_clock::now();
   for (int spin = 0; *word != seq; ++spin) {
     if ((spin & 1023) == 1023 &&
@@ -68,7 +73,8 @@ void gnx_time_begin(gnx_state* h) {
 
 void gnx_time_end(gnx_state* h, int kernel, double bytes) {
   if (!h->profiling || !h->ev_open) return;
-  if (h->profile_only >= 0 && kernel != h->profile_only) {   // time one kernel family only
+  if (h->profile_only >= 0 && kernel != h->profile_only &&
+      !(h->profile_only == GNX_K_CROSSOVER && kernel == GNX_K_CROSSOVER_TAIL)) {   // one family only
     h->ev_free.push_back(h->ev_open);
     h->ev_open = nullptr;
     return;
@@ -284,6 +290,21 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
       h->row_spread = want;
     }
     GNXCHK(dalloc(&h->free_rows, (size_t)h->cfg.cap_rows));
+    const size_t halves = (size_t)h->cfg.cap_rows * h->row_spread * 2;
+    GNXCHK(dalloc(&h->hmap, halves));
+    GNXCHK(dalloc(&h->half_rc, halves));
+    GNXCHK(dalloc(&h->half_free, (size_t)h->cfg.cap_rows * 2));
+    GNXCHK(dalloc(&h->half_top, 1));
+    GNXCHK(dalloc(&h->rel_cnt, 2));
+    HIPCHK(hipStreamCreate(&h->stream3));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_compact, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_release, hipEventDisableTiming));
+    HIPCHK(hipMalloc((void**)&h->xo_jobs_acc, 2 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(h->xo_jobs_acc, 0, 2 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(h->hmap, 0xff, halves * sizeof(int32_t)));
+    HIPCHK(hipMemset(h->half_rc, 0, halves * sizeof(int32_t)));
+    HIPCHK(hipMemset(h->half_top, 0, sizeof(int32_t)));
+    if (getenv("GNX_XO_ALIAS")) h->alias_xo = atoi(getenv("GNX_XO_ALIAS")) != 0;
   }
   for (int k = 0; k < 2; ++k) {
     GNXCHK(dalloc(&h->key[k], cap));
@@ -376,7 +397,7 @@ extern "C" void gnx_destroy(gnx_state* h) {
     (void)hipFree(h->perm[k]);
     (void)hipFree(h->counts_rast[k]);
   }
-  void* ptrs[] = {h->rast, h->G, h->free_rows, h->paths, h->bp_off, h->bp_loci, h->dom,
+  void* ptrs[] = {h->rel_cnt, h->hmap, h->half_rc, h->half_free, h->half_top, h->xo_jobs_acc, h->rast, h->G, h->free_rows, h->paths, h->bp_off, h->bp_loci, h->dom,
                   h->delet_loci, h->delet_s, h->cell_start, h->tag, h->cand, h->sort64_tmp, h->key64[0], h->key64[1], h->pairs2,
                   h->pair_goff, h->st_rec, h->st_z, h->st_geno, h->st_slots, h->req_pid, h->req_k, h->req_key, h->req_start, h->req_px, h->req_py,
                   h->req_count, h->sort_tmp, h->scan_tmp, h->mate,
@@ -398,6 +419,12 @@ extern "C" void gnx_destroy(gnx_state* h) {
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   if (h->stream2) (void)hipStreamDestroy(h->stream2);
   h->stream2 = nullptr;
+  if (h->stream3) {
+    (void)hipStreamSynchronize(h->stream3);
+    (void)hipStreamDestroy(h->stream3);
+  }
+  if (h->ev_compact) (void)hipEventDestroy(h->ev_compact);
+  if (h->ev_release) (void)hipEventDestroy(h->ev_release);
   delete h;
 }
 
@@ -415,6 +442,7 @@ extern "C" int gnx_set_stream(gnx_state* h, void* hip_stream) {
 
 extern "C" int gnx_synchronize(gnx_state* h) {
   GNXCHK(gnx_xo_launch_pending(h));
+  if (h->stream3) HIPCHK(hipStreamSynchronize(h->stream3));
   HIPCHK(hipStreamSynchronize(h->stream));
   if (h->stream2) HIPCHK(hipStreamSynchronize(h->stream2));
   return 0;
@@ -1372,6 +1400,7 @@ extern "C" int gnx_profiling(gnx_state* h, int32_t on) {
     timers_resolve(h, k);
     h->timers[k] = GnxKernelTimer();
   }
+  if (h->xo_jobs_acc) HIPCHK(hipMemset(h->xo_jobs_acc, 0, 2 * sizeof(unsigned long long)));
   h->profiling = on != 0;
   // on == 2: only the dominant kernel (crossover) is timed, so that very few
   // events are in flight (used by bench.py inside the timed region)
@@ -1386,6 +1415,15 @@ extern "C" int gnx_kernel_time(gnx_state* h, int32_t kernel, double* ms, int64_t
     return 1;
   }
   timers_resolve(h, kernel);
+  if ((kernel == GNX_K_CROSSOVER || kernel == GNX_K_CROSSOVER_TAIL) && h->xo_jobs_acc) {
+    // the crossover kernels count the gametes they copy (those without a switch point are
+    // not copied and the host never learns how many there were)
+    const int slot = kernel == GNX_K_CROSSOVER_TAIL ? 1 : 0;
+    unsigned long long n = 0;
+    HIPCHK(hipMemcpy(&n, h->xo_jobs_acc + slot, sizeof(n), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(h->xo_jobs_acc + slot, 0, sizeof(n)));
+    h->timers[kernel].bytes = (double)n * 0.5 * gnx_xo_bytes_per_birth(h);
+  }
   if (ms) *ms = h->timers[kernel].ms;
   if (launches) *launches = h->timers[kernel].launches;
   if (algorithmic_bytes) *algorithmic_bytes = h->timers[kernel].bytes;

@@ -9,6 +9,7 @@
 #include <utility>
 #include <hip/hip_runtime.h>
 #include "../../include/gnx_hip.h"
+#include "gnx_half.h"
 
 #define GNX_MAX_TRAITS 16
 #define GNX_MAX_LAYERS 16
@@ -127,6 +128,18 @@ struct gnx_state {
   int row_spread = 1;
   int32_t* free_rows = nullptr;
   int64_t n_free = 0;
+  // physical half-rows (gnx_half.h): hmap / half_rc over 2 * cap_rows * row_spread halves,
+  // the stack of free ones and its height on the device
+  int32_t* hmap = nullptr;
+  int32_t* half_rc = nullptr;
+  int32_t* half_free = nullptr;
+  int32_t* half_top = nullptr;
+  hipStream_t stream3 = nullptr;       // releases of the dead's half-rows
+  hipEvent_t ev_compact = nullptr, ev_release = nullptr;
+  bool release_inflight = false;
+  int32_t* rel_cnt = nullptr;          // [2] rows freed / rows popped by the last compaction
+  bool alias_xo = true;          // gametes without a switch point share the parent's half-row
+  unsigned long long* xo_jobs_acc = nullptr;   // [2] gametes copied by the (wide, tail) launches
   bool genomes_assigned = false;
 
   // landscape
@@ -311,6 +324,27 @@ struct gnx_state {
 
 GnxTraitTab gnx_trait_tab(const gnx_state* h);
 
+static inline GnxHalves gnx_halves(const gnx_state* h) {
+  return GnxHalves{h->hmap, h->half_rc, h->half_free, h->half_top};
+}
+// before anything that pops half-rows: the last release of the dead's half-rows has
+// finished (it runs on a stream of its own)
+static inline int gnx_halves_ready(gnx_state* h) {
+  if (h->release_inflight) {
+    if (hipStreamWaitEvent(h->stream, h->ev_release, 0) != hipSuccess) {
+      gnx_set_error("hipStreamWaitEvent(ev_release) failed");
+      return 1;
+    }
+    h->release_inflight = false;
+  }
+  return 0;
+}
+// breakpoint offsets when gametes without a switch point may share the parent's half-row
+// (sparse paths only: the dense path table is not scanned for all-zero masks), else null
+static inline const int32_t* gnx_alias_bp(const gnx_state* h) {
+  return (h->alias_xo && h->sparse_paths) ? h->bp_off : nullptr;
+}
+
 // read-back of up to four device int32 counters: one tiny kernel writes them straight into
 // pinned host memory h->h_pin[slot..] (an async D2H copy of 4 bytes is a blit kernel or an
 // SDMA job of its own and queues behind whatever else runs, 50-900 us under load)
@@ -363,6 +397,7 @@ int gnx_xo_flush_deferred(gnx_state* h);
 int gnx_xo_launch_pending(gnx_state* h);
 // `stream` waits for the crossover in flight (not for one that is not launched yet)
 int gnx_xo_wait_inflight(gnx_state* h);
+int gnx_xo_prepare_jobs(gnx_state* h, int32_t** zero);
 int gnx_xo_wait_wide(gnx_state* h);
 double gnx_xo_bytes_per_birth(const gnx_state* h);
 // selected-locus tables: rebuild sel_loci / path_sel / GnxSoA.tb after a change of the

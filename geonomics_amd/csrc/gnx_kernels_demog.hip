@@ -13,6 +13,7 @@
 #include "gnx_internal.h"
 #include "gnx_rng.h"
 #include "gnx_compact.h"
+#include "gnx_half.h"
 #include "gnx_xo.h"
 
 #define BIN_BLOCKS 512
@@ -509,9 +510,12 @@ int gnx_l_death_probs(gnx_state* h, bool with_selection) {
 __global__ void __launch_bounds__(256)
 k_alive(int64_t N, const double* p_death, const uint8_t* dead_in, const int64_t* id,
         const uint8_t* ghost, const int32_t* grow, long long step, unsigned long long seed,
-        int32_t* alive, int32_t* dead_row, int32_t* cnt, int stride, int64_t xo_first) {
+        int32_t* alive, int32_t* dead_row, int32_t* cnt, int stride, int64_t xo_first,
+        int32_t* zero_jobs) {
   __shared__ int lds[16];
   const int64_t base = (int64_t)blockIdx.x * GNX_CB;
+  // the job list of the deferred crossover is appended to (k_xo_jobs_surv): empty it
+  if (zero_jobs && blockIdx.x == 0 && threadIdx.x == 0) *zero_jobs = 0;
   bool fa[4], fd[4], fx[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -557,14 +561,13 @@ k_alive(int64_t N, const double* p_death, const uint8_t* dead_in, const int64_t*
 __global__ void __launch_bounds__(256)
 k_xo_jobs_surv(int64_t N, int64_t first, int32_t* __restrict__ grow,
                const int32_t* __restrict__ alive, const int32_t* __restrict__ blk_off3,
-               const int32_t* __restrict__ cnts, const int32_t* __restrict__ off_parent,
-               const int32_t* __restrict__ off_keys, const uint8_t* __restrict__ off_start,
-               const int32_t* __restrict__ free_rows, int64_t n_free,
+               const int32_t* __restrict__ off_parent, const int32_t* __restrict__ off_keys,
+               const uint8_t* __restrict__ off_start, const int32_t* __restrict__ free_rows,
+               int64_t n_free, GnxHalves H, const int32_t* __restrict__ bp_off,
                GnxXoJob* __restrict__ jobs, int32_t* __restrict__ n_jobs) {
   __shared__ int lds[16];
   const int64_t b = first / GNX_CB + blockIdx.x;
   const int64_t base = b * GNX_CB;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *n_jobs = 2 * cnts[2];
   bool fx[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -577,20 +580,20 @@ k_xo_jobs_surv(int64_t N, int64_t first, int32_t* __restrict__ grow,
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t i = base + r * 256 + threadIdx.x;
-    if (!fx[r]) continue;
+    const bool act = fx[r];
     const int64_t k = i - first;
-    const int32_t j = boff + rank[r];
-    const int32_t row = free_rows[n_free - 1 - j];
-    grow[i] = row;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      GnxXoJob jb;
-      jb.prow = grow[off_parent[2 * k + p]];      // parents are older: slots < first
-      jb.dst = row * 2 + p;
-      jb.key = off_keys[2 * k + p];
-      jb.start = off_start[2 * k + p];
-      jobs[2 * j + p] = jb;
+    int32_t row = -1;
+    if (act) {
+      row = free_rows[n_free - 1 - (boff + rank[r])];
+      grow[i] = row;
     }
+    // a gamete without a switch point refers to the parent's half-row, the others get a
+    // half-row of their own and a job (gnx_half.h); parents are older: slots < first
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+      gnx_xo_gamete(H, act, row, p, act ? grow[off_parent[2 * k + p]] : -1,
+                    act ? off_keys[2 * k + p] : 0, act ? off_start[2 * k + p] : 0, bp_off, jobs,
+                    n_jobs);
   }
 }
 
@@ -600,8 +603,13 @@ __global__ void __launch_bounds__(256)
 k_compact(int64_t N, int64_t cap, const int32_t* alive, const int32_t* dead_row,
           const int32_t* blk_off, int stride, const int32_t* cnts, GnxSoA a, GnxSoA b,
           int n_layers, int n_traits, int tbw, int32_t* free_rows, int64_t n_free, int has_rows,
-          int xo) {
+          int xo, int32_t* rel_cnt) {
   __shared__ int lds[16];
+  // k_release_halves reads its counts here (cnts is reused by the next step's scans)
+  if (rel_cnt && blockIdx.x == 0 && threadIdx.x == 0) {
+    rel_cnt[0] = cnts[1];
+    rel_cnt[1] = cnts[2];
+  }
   const int64_t base = (int64_t)blockIdx.x * GNX_CB;
   bool fa[4], fd[4];
 #pragma unroll
@@ -639,15 +647,43 @@ k_compact(int64_t N, int64_t cap, const int32_t* alive, const int32_t* dead_row,
   }
 }
 
+// The rows k_compact has just pushed on the free-row stack (free_rows[base, base + n)):
+// their two half-rows lose a referrer each, the last one frees the half-row.  Nothing
+// needs the result before the next kernel that pops half-rows, so this runs on a stream
+// of its own beside the crossover and the next step (gnx_halves_ready joins it).
+__global__ void __launch_bounds__(256)
+k_release_halves(const int32_t* __restrict__ free_rows, int64_t n_free, int xo,
+                 const int32_t* __restrict__ rel_cnt, GnxHalves H) {
+  const int64_t base = n_free - (xo ? rel_cnt[1] : 0);
+  const int64_t n = rel_cnt[0];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  // whole waves stay in the loop together (the pushes are wave-aggregated)
+  const int64_t n_up = (n + 63) / 64 * 64;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_up; j += stride) {
+    const int32_t row = j < n ? free_rows[base + j] : -1;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      bool last = false;
+      int32_t phys = -1;
+      if (row >= 0) {
+        phys = H.hmap[(int64_t)row * 2 + hh];
+        last = atomicSub(&H.rc[phys], 1) == 1;
+      }
+      const int32_t idx = gnx_wave_append(H.top, last);
+      if (last) H.stack[idx] = phys;
+    }
+  }
+}
+
 void gnx_launch_xo_jobs_surv(gnx_state* h, int64_t first_slot, const int32_t* d_alive,
                              const int32_t* d_blk_off, int buf) {
+  (void)gnx_halves_ready(h);
   const int64_t N = h->N;
   const int nbj = (int)((N - 1) / GNX_CB - first_slot / GNX_CB + 1);
   hipLaunchKernelGGL(k_xo_jobs_surv, dim3(nbj), dim3(256), 0, h->stream, N, first_slot,
-                     h->soa[h->cur].grow, d_alive, d_blk_off + 2 * h->blk_stride, h->cnt_dev,
-                     h->off_parent,
-                     h->off_keys, h->off_start, h->free_rows, h->n_free, (GnxXoJob*)h->jobs[buf],
-                     h->n_jobs_dev[buf]);
+                     h->soa[h->cur].grow, d_alive, d_blk_off + 2 * h->blk_stride, h->off_parent,
+                     h->off_keys, h->off_start, h->free_rows, h->n_free, gnx_halves(h),
+                     gnx_alias_bp(h), (GnxXoJob*)h->jobs[buf], h->n_jobs_dev[buf]);
 }
 
 int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_out) {
@@ -659,10 +695,14 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
   const int nb = (int)((N + GNX_CB - 1) / GNX_CB);
   const bool xo = h->xo_deferred;
   const int64_t xo_first = h->xo_first, xo_B = xo ? h->xo_B : 0;
+  // the job buffer the deferred crossover is about to fill: nobody reads it any more,
+  // and its counter starts at zero
+  int32_t* zero_jobs = nullptr;
+  if (xo) GNXCHK(gnx_xo_prepare_jobs(h, &zero_jobs));
   gnx_time_begin(h);
   hipLaunchKernelGGL(k_alive, dim3(nb), dim3(256), 0, h->stream, N, h->p_death, d_dead_inject,
                      a.id, a.ghost, a.grow, h->step, c.seed, h->flag, h->flag2, h->blk_cnt,
-                     h->blk_stride, xo ? xo_first : (int64_t)-1);
+                     h->blk_stride, xo ? xo_first : (int64_t)-1, zero_jobs);
   // survivors, rows freed and (deferred crossover) the surviving offspring that need a
   // row: block offsets on the device, totals also straight into pinned host memory
   GNXCHK(gnx_block_scan(h, 3, N, h->blk_cnt, h->blk_off, h->cnt_dev, h->h_pin_dev));
@@ -681,9 +721,24 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
   gnx_time_begin(h);
   hipLaunchKernelGGL(k_compact, dim3(nb), dim3(256), 0, h->stream, N, c.cap_inds, h->flag,
                      h->flag2, h->blk_off, h->blk_stride, h->cnt_dev, a, b, c.n_layers, c.n_traits,
-                     a.tb ? 2 * h->TW : 0, h->free_rows, h->n_free, has_rows, xo ? 1 : 0);
+                     a.tb ? 2 * h->TW : 0, h->free_rows, h->n_free, has_rows, xo ? 1 : 0,
+                     h->rel_cnt);
   gnx_time_end(h, GNX_K_COMPACT, (double)N * (24.0 + 2.0 * (34.0 + 4.0 * c.n_layers +
                                                              4.0 * c.n_traits + 16.0 * h->TW)));
+  if (has_rows) {
+    // the dead's half-rows are released off the critical path
+    hipStream_t st = h->stream3 ? h->stream3 : h->stream;
+    if (h->stream3) {
+      HIPCHK(hipEventRecord(h->ev_compact, h->stream));
+      HIPCHK(hipStreamWaitEvent(h->stream3, h->ev_compact, 0));
+    }
+    hipLaunchKernelGGL(k_release_halves, dim3(256), dim3(256), 0, st, h->free_rows, h->n_free,
+                       xo ? 1 : 0, h->rel_cnt, gnx_halves(h));
+    if (h->stream3) {
+      HIPCHK(hipEventRecord(h->ev_release, h->stream3));
+      h->release_inflight = true;
+    }
+  }
   HIPCHK(hipGetLastError());
   if (xo && h->xo_sort_waits && h->xo_wait_at == 3) GNXCHK(gnx_xo_wait_inflight(h));
   HIPCHK(hipEventSynchronize(h->ev_counts));
@@ -693,13 +748,6 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
     const int64_t S = h->h_pin[2];
     h->n_free -= S;
     h->last_xo_births = S;
-    if (h->profiling) {
-      // a split launch: the first (2S * split) >> 10 gametes ran at full width
-      const double per_job = 0.5 * gnx_xo_bytes_per_birth(h);
-      const int64_t wide = h->xo_last_split ? ((2 * S * h->xo_last_split) >> 10) : 2 * S;
-      h->timers[GNX_K_CROSSOVER].bytes += (double)wide * per_job;
-      h->timers[GNX_K_CROSSOVER_TAIL].bytes += (double)(2 * S - wide) * per_job;
-    }
   }
   if (has_rows) h->n_free += rows_freed;
   *deaths_out = N - h->n_ghost - survivors;       // ghosts are dropped, not counted

@@ -5,11 +5,14 @@
 // Genome layout in HBM: G[row][hom][W64] u64, little-endian bits, bit l of
 // homologue h == Individual.g[l, h] (structs/individual.py:103-104).  W64 is
 // padded to a multiple of 16 words so every homologue starts on a 128-byte line
-// and splits into whole 16-byte chunks.  Individuals reference rows through
-// GnxSoA.grow; survivors' rows are never moved.
+// and splits into whole 16-byte chunks.  Individuals reference LOGICAL rows through
+// GnxSoA.grow; where a row's two homologues live is the second indirection of
+// gnx_half.h (hmap: logical half -> physical half-row, shared between a parent and the
+// children that inherit the homologue unrecombined).  Half-rows are never moved.
 #include "gnx_internal.h"
 #include "gnx_rng.h"
 #include "gnx_xo.h"
+#include "gnx_half.h"
 #include "gnx_tb.h"
 #include "gnx_compact.h"
 
@@ -17,25 +20,24 @@
 // Every birth of the step at once: child k takes the k-th row from the top of the free
 // stack; a gamete whose parent is a ghost (tiled run: the mate lives on a neighbour
 // tile, its gamete arrives from there) gets prow = -1 and is skipped by the kernel.
-__global__ void k_xo_jobs_all(int64_t B, int64_t first, int32_t* __restrict__ grow,
-                              const int32_t* __restrict__ off_parent,
-                              const int32_t* __restrict__ off_keys,
-                              const uint8_t* __restrict__ off_start,
-                              const int32_t* __restrict__ free_rows, int64_t n_free,
-                              GnxXoJob* __restrict__ jobs, int32_t* __restrict__ n_jobs) {
+__global__ void __launch_bounds__(256)
+k_xo_jobs_all(int64_t B, int64_t first, int32_t* __restrict__ grow,
+              const int32_t* __restrict__ off_parent, const int32_t* __restrict__ off_keys,
+              const uint8_t* __restrict__ off_start, const int32_t* __restrict__ free_rows,
+              int64_t n_free, GnxHalves H, const int32_t* __restrict__ bp_off,
+              GnxXoJob* __restrict__ jobs, int32_t* __restrict__ n_jobs) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k == 0) *n_jobs = (int32_t)(2 * B);
-  if (k >= B) return;
-  const int32_t row = free_rows[n_free - 1 - k];
-  grow[first + k] = row;
+  const bool act = k < B;
+  int32_t row = -1;
+  if (act) {
+    row = free_rows[n_free - 1 - k];
+    grow[first + k] = row;
+  }
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
-    GnxXoJob j;
-    j.prow = grow[off_parent[2 * k + p]];
-    j.dst = row * 2 + p;
-    j.key = off_keys[2 * k + p];
-    j.start = off_start[2 * k + p];
-    jobs[2 * k + p] = j;
+    const int32_t prow = act ? grow[off_parent[2 * k + p]] : -1;
+    gnx_xo_gamete(H, act, row, p, prow, act ? off_keys[2 * k + p] : 0,
+                  act ? off_start[2 * k + p] : 0, bp_off, jobs, n_jobs);
   }
 }
 
@@ -46,16 +48,16 @@ void gnx_launch_xo_jobs_surv(gnx_state* h, int64_t first_slot, const int32_t* d_
 
 template <int U>
 static void xo_launch_sparse(gnx_state* h, hipStream_t st, int grid, int buf, bool nt, int lo,
-                             int hi) {
+                             int hi, unsigned long long* acc) {
   const int W16 = h->W64 / 2;
   if (nt)
     hipLaunchKernelGGL((k_xo_sparse<U, true>), dim3(grid), dim3(256), 0, st, h->n_jobs_dev[buf],
                        W16, (const u64x2*)h->G, (u64x2*)h->G, (const GnxXoJob*)h->jobs[buf],
-                       h->bp_off, h->bp_loci, lo, hi);
+                       h->bp_off, h->bp_loci, lo, hi, acc);
   else
     hipLaunchKernelGGL((k_xo_sparse<U, false>), dim3(grid), dim3(256), 0, st, h->n_jobs_dev[buf],
                        W16, (const u64x2*)h->G, (u64x2*)h->G, (const GnxXoJob*)h->jobs[buf],
-                       h->bp_off, h->bp_loci, lo, hi);
+                       h->bp_off, h->bp_loci, lo, hi, acc);
 }
 
 // the crossover of job buffer `buf` on stream `st` (the share [lo, hi) / 1024 of its jobs);
@@ -73,16 +75,18 @@ static int xo_launch(gnx_state* h, hipStream_t st, int buf, int64_t max_jobs, bo
   static const int tail_bpc = getenv("GNX_XO_TAIL_BPC") ? atoi(getenv("GNX_XO_TAIL_BPC")) : 2;
   static const int tail_unroll = getenv("GNX_XO_TAIL_UNROLL") ? atoi(getenv("GNX_XO_TAIL_UNROLL")) : 6;
   const int bpc = narrow ? tail_bpc : (bpc_env ? bpc_env : 32);
+  // the narrow share of a split launch is accounted for on its own
+  unsigned long long* acc = h->xo_jobs_acc ? h->xo_jobs_acc + ((narrow && lo > 0) ? 1 : 0) : nullptr;
   const int W16 = h->W64 / 2;
   const int grid = gnx_grid(max_jobs, 4, 256 * bpc);
   if (h->sparse_paths) {
     const int U = narrow ? tail_unroll : (unroll_env ? unroll_env : gnx_xo_pick_unroll(W16));
     switch (U) {
-      case 4: xo_launch_sparse<4>(h, st, grid, buf, nt, lo, hi); break;
-      case 5: xo_launch_sparse<5>(h, st, grid, buf, nt, lo, hi); break;
-      case 6: xo_launch_sparse<6>(h, st, grid, buf, nt, lo, hi); break;
-      case 7: xo_launch_sparse<7>(h, st, grid, buf, nt, lo, hi); break;
-      default: xo_launch_sparse<8>(h, st, grid, buf, nt, lo, hi); break;
+      case 4: xo_launch_sparse<4>(h, st, grid, buf, nt, lo, hi, acc); break;
+      case 5: xo_launch_sparse<5>(h, st, grid, buf, nt, lo, hi, acc); break;
+      case 6: xo_launch_sparse<6>(h, st, grid, buf, nt, lo, hi, acc); break;
+      case 7: xo_launch_sparse<7>(h, st, grid, buf, nt, lo, hi, acc); break;
+      default: xo_launch_sparse<8>(h, st, grid, buf, nt, lo, hi, acc); break;
     }
   } else {
     // dense masks: genome chunks stream past once (non-temporal), the path table is
@@ -90,21 +94,22 @@ static int xo_launch(gnx_state* h, hipStream_t st, int buf, int64_t max_jobs, bo
     if (nt)
       hipLaunchKernelGGL((k_xo_dense<4, true>), dim3(grid), dim3(256), 0, st, h->n_jobs_dev[buf],
                          W16, (const u64x2*)h->G, (u64x2*)h->G, (const GnxXoJob*)h->jobs[buf],
-                         (const u64x2*)h->paths, lo, hi);
+                         (const u64x2*)h->paths, lo, hi, acc);
     else
       hipLaunchKernelGGL((k_xo_dense<4, false>), dim3(grid), dim3(256), 0, st, h->n_jobs_dev[buf],
                          W16, (const u64x2*)h->G, (u64x2*)h->G, (const GnxXoJob*)h->jobs[buf],
-                         (const u64x2*)h->paths, lo, hi);
+                         (const u64x2*)h->paths, lo, hi, acc);
   }
   HIPCHK(hipGetLastError());
   return 0;
 }
 
-// algorithmic bytes per birth.  Dense masks: 4 parental homologues + 2 masks
-// read, 2 homologues written = 8 * L/8 = L bytes.  Sparse paths: each gamete chunk copies
-// ONE parental homologue (the other is never needed, the mask comes from a handful of
-// breakpoints): 2 reads + 2 writes = 4 * L/8 = L/2 bytes per birth (padded row width
-// W64*8 is what actually moves).
+// algorithmic bytes per birth whose two gametes are both copied.  Dense masks:
+// 4 parental homologues + 2 masks read, 2 homologues written = 8 * L/8 = L bytes.  Sparse
+// paths: each gamete chunk copies ONE parental homologue (the other is never needed, the
+// mask comes from a handful of breakpoints): 2 reads + 2 writes = 4 * L/8 = L/2 bytes per
+// birth (padded row width W64*8 is what actually moves).  A gamete without a switch point
+// moves nothing (gnx_half.h); the kernels count the gametes they copy (xo_jobs_acc).
 double gnx_xo_bytes_per_birth(const gnx_state* h) {
   return (h->sparse_paths ? 4.0 : 8.0) * (double)h->W64 * 8.0;
 }
@@ -127,9 +132,11 @@ int gnx_l_crossover_all(gnx_state* h, int64_t first_slot, int64_t B) {
   GNXCHK(xo_wait_buf(h, h->stream, 1));
   const int buf = h->jobs_cur;
   GnxSoA s = h->soa[h->cur];
+  GNXCHK(gnx_halves_ready(h));
+  HIPCHK(hipMemsetAsync(h->n_jobs_dev[buf], 0, sizeof(int32_t), h->stream));
   hipLaunchKernelGGL(k_xo_jobs_all, dim3(gnx_grid(B, 256)), dim3(256), 0, h->stream, B, first_slot,
                      s.grow, h->off_parent, h->off_keys, h->off_start, h->free_rows, h->n_free,
-                     (GnxXoJob*)h->jobs[buf], h->n_jobs_dev[buf]);
+                     gnx_halves(h), gnx_alias_bp(h), (GnxXoJob*)h->jobs[buf], h->n_jobs_dev[buf]);
   if (h->stream2) {
     // tiled runs serve the neighbours' gamete requests on stream2 meanwhile: the rows
     // handed out above must be visible there
@@ -138,7 +145,7 @@ int gnx_l_crossover_all(gnx_state* h, int64_t first_slot, int64_t B) {
   }
   gnx_time_begin(h);
   GNXCHK(xo_launch(h, h->stream, buf, 2 * B, false));
-  gnx_time_end(h, GNX_K_CROSSOVER, (double)B * gnx_xo_bytes_per_birth(h));
+  gnx_time_end(h, GNX_K_CROSSOVER, 0.0);   // bytes: the kernels count the gametes they copy
   h->n_free -= B;
   h->last_xo_births = B;
   return 0;
@@ -148,25 +155,26 @@ int gnx_l_crossover_all(gnx_state* h, int64_t first_slot, int64_t B) {
 // their row and the crossover of their LOCAL gamete at once - the remote gamete is put
 // next to it and their alleles at the selected loci are read from the finished row -
 // while every other offspring of the step waits for the death draws like on one GPU.
-__global__ void k_xo_jobs_req(int n_req, int64_t first, int32_t* __restrict__ grow,
-                              const int32_t* __restrict__ req_k,
-                              const int32_t* __restrict__ off_parent,
-                              const int32_t* __restrict__ off_keys,
-                              const uint8_t* __restrict__ off_start,
-                              const int32_t* __restrict__ free_rows, int64_t n_free,
-                              GnxXoJob* __restrict__ jobs, int32_t* __restrict__ n_jobs) {
+__global__ void __launch_bounds__(256)
+k_xo_jobs_req(int n_req, int64_t first, int32_t* __restrict__ grow,
+              const int32_t* __restrict__ req_k, const int32_t* __restrict__ off_parent,
+              const int32_t* __restrict__ off_keys, const uint8_t* __restrict__ off_start,
+              const int32_t* __restrict__ free_rows, int64_t n_free, GnxHalves H,
+              const int32_t* __restrict__ bp_off, GnxXoJob* __restrict__ jobs,
+              int32_t* __restrict__ n_jobs) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q == 0) *n_jobs = n_req;
-  if (q >= n_req) return;
-  const int64_t k = req_k[q];
-  const int32_t row = free_rows[n_free - 1 - q];
-  grow[first + k] = row;
-  GnxXoJob j;
-  j.prow = grow[off_parent[2 * k]];
-  j.dst = row * 2;
-  j.key = off_keys[2 * k];
-  j.start = off_start[2 * k];
-  jobs[q] = j;
+  const bool act = q < n_req;
+  const int64_t k = act ? req_k[q] : 0;
+  int32_t row = -1;
+  if (act) {
+    row = free_rows[n_free - 1 - q];
+    grow[first + k] = row;
+  }
+  // the local parent's gamete (homologue 0), and an empty half-row for the one that
+  // arrives from the neighbour tile
+  gnx_xo_gamete(H, act, row, 0, act ? grow[off_parent[2 * k]] : -1, act ? off_keys[2 * k] : 0,
+                act ? off_start[2 * k] : 0, bp_off, jobs, n_jobs);
+  gnx_half_new(H, (int64_t)row * 2 + 1, act);
 }
 
 int gnx_l_crossover_requests(gnx_state* h, int64_t first_slot, int64_t n_req) {
@@ -175,17 +183,19 @@ int gnx_l_crossover_requests(gnx_state* h, int64_t first_slot, int64_t n_req) {
   GNXCHK(xo_wait_buf(h, h->stream, 0));
   GNXCHK(xo_wait_buf(h, h->stream, 1));
   const int buf = h->jobs_cur;
+  GNXCHK(gnx_halves_ready(h));
+  HIPCHK(hipMemsetAsync(h->n_jobs_dev[buf], 0, sizeof(int32_t), h->stream));
   hipLaunchKernelGGL(k_xo_jobs_req, dim3(gnx_grid(n_req, 256)), dim3(256), 0, h->stream, (int)n_req,
                      first_slot, h->soa[h->cur].grow, h->req_k, h->off_parent, h->off_keys,
-                     h->off_start, h->free_rows, h->n_free, (GnxXoJob*)h->jobs[buf],
-                     h->n_jobs_dev[buf]);
+                     h->off_start, h->free_rows, h->n_free, gnx_halves(h), gnx_alias_bp(h),
+                     (GnxXoJob*)h->jobs[buf], h->n_jobs_dev[buf]);
   if (h->stream2) {      // the rows handed out above must be visible to the gamete puts
     HIPCHK(hipEventRecord(h->ev_jobs, h->stream));
     HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_jobs, 0));
   }
   gnx_time_begin(h);
   GNXCHK(xo_launch(h, h->stream, buf, n_req, false));
-  gnx_time_end(h, GNX_K_CROSSOVER, (double)n_req * 0.5 * gnx_xo_bytes_per_birth(h));
+  gnx_time_end(h, GNX_K_CROSSOVER, 0.0);
   h->n_free -= n_req;
   return 0;
 }
@@ -222,12 +232,13 @@ int gnx_l_crossover_pending(gnx_state* h, int64_t first_slot, int64_t B) {
                      h->soa[h->cur].grow, h->flag, cnt3);
   // totals land in cnt_dev[2] (what k_xo_jobs_surv reads) and in pinned memory
   GNXCHK(gnx_block_scan(h, 1, N, cnt3, off3, h->cnt_dev + 2, h->h_pin_dev + 8));
+  HIPCHK(hipMemsetAsync(h->n_jobs_dev[buf], 0, sizeof(int32_t), h->stream));
   gnx_launch_xo_jobs_surv(h, first_slot, h->flag, h->blk_off, buf);
   gnx_time_begin(h);
   GNXCHK(xo_launch(h, h->stream, buf, 2 * B, false));
   HIPCHK(hipStreamSynchronize(h->stream));
   const int64_t S = h->h_pin[8];
-  gnx_time_end(h, GNX_K_CROSSOVER, (double)S * gnx_xo_bytes_per_birth(h));
+  gnx_time_end(h, GNX_K_CROSSOVER, 0.0);
   h->n_free -= S;
   h->last_xo_births = S;
   return 0;
@@ -252,7 +263,7 @@ int gnx_xo_launch_pending(gnx_state* h) {
   gnx_time_begin(h);
   int rc = xo_launch(h, h->stream2, buf, h->xo_ready_jobs, !h->xo_sort_waits, 0,
                      split ? split : 1024);
-  gnx_time_end(h, GNX_K_CROSSOVER, 0.0);         // bytes are added once the survivors are counted
+  gnx_time_end(h, GNX_K_CROSSOVER, 0.0);
   if (split && !rc) {
     HIPCHK(hipEventRecord(h->ev_xo_wide[buf], h->stream2));
     h->xo_wide_inflight[buf] = true;
@@ -288,12 +299,20 @@ int gnx_xo_wait_wide(gnx_state* h) {
   return 0;
 }
 
-int gnx_l_crossover_survivors(gnx_state* h, int64_t first_slot, int64_t B, const int32_t* d_alive,
-                              const int32_t* d_scan) {
-  if (B == 0) return 0;
+// before the death draws of a step with a deferred crossover: the job buffer that
+// gnx_l_crossover_survivors will fill is free, *zero = its counter (k_alive clears it)
+int gnx_xo_prepare_jobs(gnx_state* h, int32_t** zero) {
   GNXCHK(gnx_xo_launch_pending(h));              // at most one set of jobs waits
   const int buf = h->jobs_cur;
   GNXCHK(xo_wait_buf(h, h->stream, buf));       // the crossover two steps back read this buffer
+  *zero = h->n_jobs_dev[buf];
+  return 0;
+}
+
+int gnx_l_crossover_survivors(gnx_state* h, int64_t first_slot, int64_t B, const int32_t* d_alive,
+                              const int32_t* d_scan) {
+  if (B == 0) return 0;
+  const int buf = h->jobs_cur;                   // prepared by gnx_xo_prepare_jobs
   gnx_launch_xo_jobs_surv(h, first_slot, d_alive, d_scan, buf);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(h->ev_jobs, h->stream));
@@ -354,7 +373,7 @@ int gnx_l_path_sel(gnx_state* h) {
 // tb of a slot from its genome row: one thread per (slot, homologue)
 __global__ void k_tb_from_rows(int64_t first, int64_t n, const int32_t* list, const int64_t* slots,
                                int TW, int n_sel, int W64, const int32_t* sel_loci, const u64* G,
-                               const int32_t* grow, u64* tb) {
+                               const int32_t* grow, const int32_t* hmap, u64* tb) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= 2 * n) return;
   const int64_t q = t >> 1;
@@ -362,7 +381,7 @@ __global__ void k_tb_from_rows(int64_t first, int64_t n, const int32_t* list, co
   const int64_t slot = slots ? slots[q] : first + (list ? list[q] : q);
   const int32_t row = grow[slot];
   if (row < 0) return;
-  const u64* r = G + ((int64_t)row * 2 + hom) * W64;
+  const u64* r = G + (int64_t)hmap[(int64_t)row * 2 + hom] * W64;
   for (int w = 0; w < TW; ++w) {
     u64 v = 0;
     for (int e = w * 64; e < min(n_sel, w * 64 + 64); ++e) {
@@ -380,7 +399,7 @@ int gnx_l_tb_from_rows(gnx_state* h, int64_t first, int64_t n, const int32_t* d_
   GnxSoA s = h->soa[h->cur];
   hipLaunchKernelGGL(k_tb_from_rows, dim3(gnx_grid(2 * n, 256)), dim3(256), 0, h->stream, first, n,
                      d_list, d_slots, h->TW, h->n_sel, h->W64, h->sel_loci, (const u64*)h->G,
-                     s.grow, (u64*)s.tb);
+                     s.grow, h->hmap, (u64*)s.tb);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -440,7 +459,7 @@ int gnx_l_phenotype(gnx_state* h, int64_t first_slot, int64_t n) {
 // One lane per site, one wavefront per 64-site word: __ballot of the 64 lanes'
 // decisions IS the u64 genome word (row of individual q/2, homologue q%2).
 __global__ void __launch_bounds__(256)
-k_assign_genomes(int64_t N, int L, int W64, u64* G, const int32_t* grow,
+k_assign_genomes(int64_t N, int L, int W64, u64* G, const int32_t* grow, const int32_t* hmap,
                  const int32_t* n_per_site, unsigned long long site_seed) {
   const int lane = threadIdx.x & 63;
   const int64_t word = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -457,16 +476,31 @@ k_assign_genomes(int64_t N, int L, int W64, u64* G, const int32_t* grow,
     }
     remaining -= take ? 1 : 0;
     u64 w = __ballot(take);
-    if (lane == 0) G[((int64_t)grow[q >> 1] * 2 + (q & 1)) * W64 + word] = w;
+    if (lane == 0) G[(int64_t)hmap[(int64_t)grow[q >> 1] * 2 + (q & 1)] * W64 + word] = w;
   }
 }
 
 __global__ void k_assign_rows(int64_t N, int64_t cap_rows, int spread, int32_t* grow,
-                              int32_t* free_rows) {
+                              int32_t* free_rows, GnxHalves H) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < N) grow[i] = (int32_t)(i * spread);
-  // free stack: rows N..cap_rows-1 (physical: x spread), popped from the top (highest first)
-  if (i < cap_rows - N) free_rows[i] = (int32_t)((cap_rows - 1 - i) * spread);
+  if (i < N) {
+    const int32_t row = (int32_t)(i * spread);
+    grow[i] = row;
+    // every individual starts with its own two half-rows, at its logical row's address
+    for (int hh = 0; hh < 2; ++hh) {
+      H.hmap[(int64_t)row * 2 + hh] = row * 2 + hh;
+      H.rc[(int64_t)row * 2 + hh] = 1;
+    }
+  }
+  // free stacks: rows N..cap_rows-1 (row numbers are physical: x spread) and their halves,
+  // popped from the top (highest first)
+  if (i < cap_rows - N) {
+    const int32_t row = (int32_t)((cap_rows - 1 - i) * spread);
+    free_rows[i] = row;
+    H.stack[2 * i] = row * 2 + 1;
+    H.stack[2 * i + 1] = row * 2;
+  }
+  if (i == 0) *H.top = (int32_t)(2 * (cap_rows - N));
 }
 
 int gnx_l_assign_genomes(gnx_state* h, const int32_t* d_n_per_site) {
@@ -477,15 +511,19 @@ int gnx_l_assign_genomes(gnx_state* h, const int32_t* d_n_per_site) {
     return 2;
   }
   GNXCHK(gnx_xo_join(h));
+  GNXCHK(gnx_halves_ready(h));
   GnxSoA s = h->soa[h->cur];
   int64_t m = N > c.cap_rows - N ? N : c.cap_rows - N;
+  HIPCHK(hipMemsetAsync(h->half_rc, 0, (size_t)c.cap_rows * h->row_spread * 2 * sizeof(int32_t),
+                        h->stream));
   hipLaunchKernelGGL(k_assign_rows, dim3(gnx_grid(m, 256)), dim3(256), 0, h->stream, N, c.cap_rows,
-                     h->row_spread, s.grow, h->free_rows);
+                     h->row_spread, s.grow, h->free_rows, gnx_halves(h));
   h->n_free = c.cap_rows - N;
   if (N > 0 && d_n_per_site) {
     int64_t threads = (int64_t)h->W64 * 64;
     hipLaunchKernelGGL(k_assign_genomes, dim3(gnx_grid(threads, 256)), dim3(256), 0, h->stream, N,
-                       c.L, h->W64, (u64*)h->G, s.grow, d_n_per_site, gnx_site_seed(c.seed));
+                       c.L, h->W64, (u64*)h->G, s.grow, h->hmap, d_n_per_site,
+                       gnx_site_seed(c.seed));
   }
   HIPCHK(hipGetLastError());
   h->genomes_assigned = true;
@@ -495,46 +533,102 @@ int gnx_l_assign_genomes(gnx_state* h, const int32_t* d_n_per_site) {
 // ---------------------------------------------------------------- mutation
 // ops/mutation.py:62-131: set allele 1 at (locus, homologue) of the chosen
 // offspring.
-__global__ void k_mutate(int n, int W64, u64* G, const int32_t* grow, const int64_t* slot,
-                         const int32_t* locus, const uint8_t* hom) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  int l = locus[i];
-  u64* w = G + ((int64_t)grow[slot[i]] * 2 + hom[i]) * W64 + (l >> 6);
-  atomicOr(w, 1ull << (l & 63));
+// A half-row that only the mutated individual refers to takes the bit in place; one that
+// somebody else refers to as well (an unrecombined homologue shared with a parent or a
+// sibling) goes on a list, and one workgroup walks that list in order, copying first.
+__global__ void k_mutate(int n, int W64, u64* G, const int32_t* grow, GnxHalves H,
+                         const int64_t* slot, const int32_t* locus, const uint8_t* hom,
+                         int32_t* list, int32_t* n_list) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool shared = false;
+  if (i < n) {
+    const int32_t p = H.hmap[(int64_t)grow[slot[i]] * 2 + hom[i]];
+    shared = H.rc[p] > 1;
+    if (!shared) {
+      const int l = locus[i];
+      atomicOr(G + (int64_t)p * W64 + (l >> 6), 1ull << (l & 63));
+    }
+  }
+  const int32_t idx = gnx_wave_append(n_list, shared);
+  if (shared) list[idx] = i;
+}
+
+__global__ void __launch_bounds__(256)
+k_mutate_shared(const int32_t* list, const int32_t* n_list, int W64, u64* G, const int32_t* grow,
+                GnxHalves H, const int64_t* slot, const int32_t* locus, const uint8_t* hom) {
+  __shared__ int32_t s_old, s_new;
+  const int n = *n_list;
+  for (int t = 0; t < n; ++t) {
+    const int i = list[t];
+    if (threadIdx.x == 0) {
+      const int64_t lh = (int64_t)grow[slot[i]] * 2 + hom[i];
+      const int32_t p = H.hmap[lh];
+      s_old = s_new = p;
+      if (H.rc[p] > 1) {
+        const int32_t q = H.stack[atomicSub(H.top, 1) - 1];
+        H.rc[q] = 1;
+        atomicSub(&H.rc[p], 1);
+        H.hmap[lh] = q;
+        s_new = q;
+      }
+    }
+    __syncthreads();
+    const int32_t po = s_old, pn = s_new;
+    if (pn != po)
+      for (int w = threadIdx.x; w < W64; w += 256) G[(int64_t)pn * W64 + w] = G[(int64_t)po * W64 + w];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int l = locus[i];
+      G[(int64_t)pn * W64 + (l >> 6)] |= 1ull << (l & 63);
+    }
+    __syncthreads();
+  }
 }
 
 int gnx_l_mutate(gnx_state* h, int n, const int64_t* d_slot, const int32_t* d_locus,
                  const uint8_t* d_hom) {
   if (n == 0) return 0;
   GNXCHK(gnx_xo_join(h));
+  GNXCHK(gnx_halves_ready(h));
+  int32_t* list = nullptr;
+  HIPCHK(hipMalloc((void**)&list, ((size_t)n + 1) * sizeof(int32_t)));
+  int32_t* n_list = list + n;
+  HIPCHK(hipMemsetAsync(n_list, 0, sizeof(int32_t), h->stream));
   hipLaunchKernelGGL(k_mutate, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, n, h->W64,
-                     (u64*)h->G, h->soa[h->cur].grow, d_slot, d_locus, d_hom);
+                     (u64*)h->G, h->soa[h->cur].grow, gnx_halves(h), d_slot, d_locus, d_hom, list,
+                     n_list);
+  hipLaunchKernelGGL(k_mutate_shared, dim3(1), dim3(256), 0, h->stream, (const int32_t*)list,
+                     (const int32_t*)n_list, h->W64, (u64*)h->G, h->soa[h->cur].grow,
+                     gnx_halves(h), d_slot, d_locus, d_hom);
+  HIPCHK(hipStreamSynchronize(h->stream));
+  (void)hipFree(list);
   HIPCHK(hipGetLastError());
   return 0;
 }
 
 // ---------------------------------------------------------------- genome gather
 __global__ void k_gather_genomes(int64_t n, int W16, const u64x2* G, const int32_t* grow,
-                                 const int64_t* slots, u64x2* out) {
+                                 const int32_t* hmap, const int64_t* slots, u64x2* out) {
   const int64_t total = n * 2 * (int64_t)W16;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
     int64_t k = g / (2 * W16);
     int64_t c = g - k * 2 * W16;
     int64_t slot = slots ? slots[k] : k;
-    out[g] = G[(int64_t)grow[slot] * 2 * W16 + c];
+    const int hh = c >= W16 ? 1 : 0;
+    out[g] = G[(int64_t)hmap[(int64_t)grow[slot] * 2 + hh] * W16 + (c - hh * W16)];
   }
 }
 
 __global__ void k_scatter_genomes(int64_t n, int W16, const u64x2* in, u64x2* G,
-                                  const int32_t* grow, int64_t first_slot) {
+                                  const int32_t* grow, const int32_t* hmap, int64_t first_slot) {
   const int64_t total = n * 2 * (int64_t)W16;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
     int64_t k = g / (2 * W16);
     int64_t c = g - k * 2 * W16;
-    G[(int64_t)grow[first_slot + k] * 2 * W16 + c] = in[g];
+    const int hh = c >= W16 ? 1 : 0;
+    G[(int64_t)hmap[(int64_t)grow[first_slot + k] * 2 + hh] * W16 + (c - hh * W16)] = in[g];
   }
 }
 
@@ -544,7 +638,7 @@ int gnx_l_scatter_genomes(gnx_state* h, int64_t n, const uint64_t* d_in, int64_t
   const int W16 = h->W64 / 2;
   hipLaunchKernelGGL(k_scatter_genomes, dim3(gnx_grid(n * 2 * W16, 256, 256 * 32)), dim3(256), 0,
                      h->stream, n, W16, (const u64x2*)d_in, (u64x2*)h->G, h->soa[h->cur].grow,
-                     first_slot);
+                     h->hmap, first_slot);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -554,8 +648,60 @@ int gnx_l_gather_genomes(gnx_state* h, int64_t n, const int64_t* d_slots, uint64
   GNXCHK(gnx_xo_join(h));
   const int W16 = h->W64 / 2;
   hipLaunchKernelGGL(k_gather_genomes, dim3(gnx_grid(n * 2 * W16, 256, 256 * 32)), dim3(256), 0,
-                     h->stream, n, W16, (const u64x2*)h->G, h->soa[h->cur].grow, d_slots,
+                     h->stream, n, W16, (const u64x2*)h->G, h->soa[h->cur].grow, h->hmap, d_slots,
                      (u64x2*)d_out);
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- half-row bookkeeping check
+// out[0] individuals with a logical row, out[1] broken references (no physical half, or
+// one nobody counts), out[2] sum of the reference counts, out[3] half-rows in use,
+// out[4] height of the free stack.  Consistent iff out[1] == 0, out[2] == 2 * out[0] and
+// out[3] + out[4] == 2 * cap_rows.
+__global__ void k_half_check(int64_t N, const int32_t* grow, GnxHalves H, int64_t n_halves,
+                             unsigned long long* out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t i = t0; i < N; i += stride) {
+    const int32_t row = grow[i];
+    if (row < 0) continue;
+    atomicAdd(&out[0], 1ull);
+    for (int hh = 0; hh < 2; ++hh) {
+      const int32_t p = H.hmap[(int64_t)row * 2 + hh];
+      if (p < 0 || p >= n_halves || H.rc[p] <= 0) atomicAdd(&out[1], 1ull);
+    }
+  }
+  for (int64_t q = t0; q < n_halves; q += stride) {
+    const int32_t r = H.rc[q];
+    if (r > 0) {
+      atomicAdd(&out[2], (unsigned long long)r);
+      atomicAdd(&out[3], 1ull);
+    } else if (r < 0) {
+      atomicAdd(&out[1], 1ull);
+    }
+  }
+  if (t0 == 0) out[4] = (unsigned long long)*H.top;
+}
+
+extern "C" int gnx_debug_halves(gnx_state* h, int64_t* out) {
+  if (h->cfg.L == 0 || !h->genomes_assigned) {
+    gnx_set_error("gnx_debug_halves: genomes not assigned");
+    return 1;
+  }
+  GNXCHK(gnx_xo_join(h));
+  GNXCHK(gnx_halves_ready(h));
+  unsigned long long* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, 5 * sizeof(unsigned long long)));
+  HIPCHK(hipMemsetAsync(d, 0, 5 * sizeof(unsigned long long), h->stream));
+  const int64_t n_halves = (int64_t)h->cfg.cap_rows * h->row_spread * 2;
+  hipLaunchKernelGGL(k_half_check, dim3(1024), dim3(256), 0, h->stream, h->N, h->soa[h->cur].grow,
+                     gnx_halves(h), n_halves, d);
+  unsigned long long host[5];
+  int rc = gnx_d2h(h, host, d, sizeof(host));
+  (void)hipFree(d);
+  GNXCHK(rc);
+  for (int k = 0; k < 5; ++k) out[k] = (int64_t)host[k];
+  out[5] = 2 * h->cfg.cap_rows;
   return 0;
 }

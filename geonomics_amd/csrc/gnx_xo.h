@@ -8,8 +8,9 @@
 //
 // Work arrives as a JOB LIST, one 16-byte record per gamete (GnxXoJob), built on the
 // device after the step's death draws: only offspring that SURVIVE their first
-// mortality round get a genome row and a job (the others' 25-KB rows would be written
-// and never read).  One WAVEFRONT owns one job at a time: the record is a scalar load,
+// mortality round get a genome row (the others' 25-KB rows would be written and never
+// read), and only gametes that carry a switch point get a job: the others alias the
+// parent's half-row (gnx_half.h).  One WAVEFRONT owns one job at a time: the record is a scalar load,
 // parent row / child row / path / start homologue live in SGPRs, and the 64 lanes stream
 // the homologue in 16-byte chunks (1 KiB per wave-instruction, U chunks in flight per
 // lane).  The grid is fixed (persistent-style, job-strided) and reads the job count from
@@ -24,6 +25,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "gnx_half.h"
 
 typedef unsigned long long u64;
 
@@ -32,11 +34,40 @@ struct alignas(16) u64x2 {
 };
 
 struct alignas(16) GnxXoJob {
-  int32_t prow;    // parent's genome row
-  int32_t dst;     // destination half-row: child_row * 2 + p
-  int32_t key;     // recombination path
-  int32_t start;   // start homologue (0 / 1)
+  int32_t ph0, ph1;   // the parent's two physical half-rows (gnx_half.h)
+  int32_t dst;        // physical half-row the gamete is written to
+  int32_t ks;         // recombination path * 2 + start homologue
 };
+
+// One gamete of a child that has logical row `row`: alias the parent's half-row when the
+// path has no switch point, else a fresh half-row and a crossover job.  A ghost parent
+// (prow < 0, tiled run: the gamete arrives from the tile that owns it) gets the fresh
+// half-row and no job.  Called by all lanes of a wave (act = this lane has a gamete).
+__device__ __forceinline__ void gnx_xo_gamete(const GnxHalves& H, bool act, int32_t row, int p,
+                                              int32_t prow, int key, int st,
+                                              const int32_t* __restrict__ bp_off,
+                                              GnxXoJob* __restrict__ jobs,
+                                              int32_t* __restrict__ n_jobs) {
+  const bool pure = act && prow >= 0 && bp_off && bp_off[key + 1] == bp_off[key];
+  const bool fresh = act && !pure;
+  const int64_t lh = (int64_t)row * 2 + p;
+  const int32_t dst = gnx_half_new(H, lh, fresh);
+  if (pure) {
+    const int32_t src = H.hmap[(int64_t)prow * 2 + st];
+    H.hmap[lh] = src;
+    atomicAdd(&H.rc[src], 1);
+  }
+  const bool job = fresh && prow >= 0;
+  const int32_t idx = gnx_wave_append(n_jobs, job);
+  if (job) {
+    GnxXoJob j;
+    j.ph0 = H.hmap[(int64_t)prow * 2];
+    j.ph1 = H.hmap[(int64_t)prow * 2 + 1];
+    j.dst = dst;
+    j.ks = key * 2 + st;
+    jobs[idx] = j;
+  }
+}
 
 template <bool NT>
 __device__ __forceinline__ u64x2 xo_load(const u64x2* __restrict__ p) {
@@ -91,7 +122,7 @@ __global__ void __launch_bounds__(256)
 k_xo_sparse(const int32_t* __restrict__ n_jobs_p, int W16, const u64x2* __restrict__ G,
             u64x2* __restrict__ Gout, const GnxXoJob* __restrict__ jobs,
             const int32_t* __restrict__ bp_off, const int32_t* __restrict__ bp_loci,
-            int part_lo, int part_hi) {
+            int part_lo, int part_hi, unsigned long long* __restrict__ acc) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   // this launch's share of the job list, in 1/1024ths of the (device-resident) count
@@ -99,15 +130,19 @@ k_xo_sparse(const int32_t* __restrict__ n_jobs_p, int W16, const u64x2* __restri
   const int j_lo = (int)(((long long)n_all * part_lo) >> 10);
   const int n_jobs = (int)(((long long)n_all * part_hi) >> 10);
   const int n_waves = (int)gridDim.x * 4;
+  // gametes copied by the launches so far (the host prices them when it reads the timers)
+  if (acc && blockIdx.x == 0 && threadIdx.x == 0 && n_jobs > j_lo)
+    atomicAdd(acc, (unsigned long long)(n_jobs - j_lo));
   for (int j = j_lo + (int)blockIdx.x * 4 + wv; j < n_jobs; j += n_waves) {
     const GnxXoJob jb = jobs[j];
-    const int prow = __builtin_amdgcn_readfirstlane(jb.prow);
-    if (prow < 0) continue;      // ghost parent (tiled run): the gamete arrives from its tile
+    const int ph0 = __builtin_amdgcn_readfirstlane(jb.ph0);
+    const int ph1 = __builtin_amdgcn_readfirstlane(jb.ph1);
     const int dsth = __builtin_amdgcn_readfirstlane(jb.dst);
-    const int key = __builtin_amdgcn_readfirstlane(jb.key);
-    const u64 s = __builtin_amdgcn_readfirstlane(jb.start) ? ~0ull : 0ull;
-    const u64x2* h0 = G + ((int64_t)prow * 2 + 0) * W16;
-    const u64x2* h1 = h0 + W16;
+    const int ks = __builtin_amdgcn_readfirstlane(jb.ks);
+    const int key = ks >> 1;
+    const u64 s = (ks & 1) ? ~0ull : 0ull;
+    const u64x2* h0 = G + (int64_t)ph0 * W16;
+    const u64x2* h1 = G + (int64_t)ph1 * W16;
     u64x2* dst = Gout + (int64_t)dsth * W16;
     const int bp0 = __builtin_amdgcn_readfirstlane(bp_off[key]);
     const int nbp = __builtin_amdgcn_readfirstlane(bp_off[key + 1]) - bp0;
@@ -151,22 +186,27 @@ template <int U, bool NT_LD>
 __global__ void __launch_bounds__(256)
 k_xo_dense(const int32_t* __restrict__ n_jobs_p, int W16, const u64x2* __restrict__ G,
            u64x2* __restrict__ Gout, const GnxXoJob* __restrict__ jobs,
-           const u64x2* __restrict__ paths, int part_lo, int part_hi) {
+           const u64x2* __restrict__ paths, int part_lo, int part_hi,
+           unsigned long long* __restrict__ acc) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int n_all = *n_jobs_p;
   const int j_lo = (int)(((long long)n_all * part_lo) >> 10);
   const int n_jobs = (int)(((long long)n_all * part_hi) >> 10);
   const int n_waves = (int)gridDim.x * 4;
+  // gametes copied by the launches so far (the host prices them when it reads the timers)
+  if (acc && blockIdx.x == 0 && threadIdx.x == 0 && n_jobs > j_lo)
+    atomicAdd(acc, (unsigned long long)(n_jobs - j_lo));
   for (int j = j_lo + (int)blockIdx.x * 4 + wv; j < n_jobs; j += n_waves) {
     const GnxXoJob jb = jobs[j];
-    const int prow = __builtin_amdgcn_readfirstlane(jb.prow);
-    if (prow < 0) continue;      // ghost parent (tiled run): the gamete arrives from its tile
+    const int ph0 = __builtin_amdgcn_readfirstlane(jb.ph0);
+    const int ph1 = __builtin_amdgcn_readfirstlane(jb.ph1);
     const int dsth = __builtin_amdgcn_readfirstlane(jb.dst);
-    const int key = __builtin_amdgcn_readfirstlane(jb.key);
-    const u64 s = __builtin_amdgcn_readfirstlane(jb.start) ? ~0ull : 0ull;
-    const u64x2* h0 = G + ((int64_t)prow * 2 + 0) * W16;
-    const u64x2* h1 = h0 + W16;
+    const int ks = __builtin_amdgcn_readfirstlane(jb.ks);
+    const int key = ks >> 1;
+    const u64 s = (ks & 1) ? ~0ull : 0ull;
+    const u64x2* h0 = G + (int64_t)ph0 * W16;
+    const u64x2* h1 = G + (int64_t)ph1 * W16;
     u64x2* dst = Gout + (int64_t)dsth * W16;
     // the path table (n_recomb_sims x L/8 bytes) is re-read by every gamete that drew
     // the key: default cache policy, so it can stay in L2 / the Infinity Cache

@@ -42,5 +42,7 @@ dt = time.perf_counter() - t0
 kt = dev.kernel_times()
 print('N=%d  ms/step=%.3f  ind-steps/s=%.3e' % (dev.N, 1e3 * dt / a.steps, n / dt))
 for k, v in kt.items():
-    print('  %-11s %8.3f ms/step  (%d launches)' % (k, v['ms'] / a.steps, v['launches']))
+    gbs = v['bytes'] / (v['ms'] * 1e-3) / 1e9 if v['ms'] > 0 else 0.0
+    print('  %-14s %8.3f ms/step  (%d launches)  %8.1f MB/launch  %7.0f GB/s' % (
+        k, v['ms'] / a.steps, v['launches'], v['bytes'] / max(v['launches'], 1) / 1e6, gbs))
 print('  sum         %8.3f' % (sum(v['ms'] for v in kt.values()) / a.steps))
