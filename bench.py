@@ -530,6 +530,7 @@ def main():
                 continue
         copy_gbps = measured_copy_bandwidth(torch)
         dense = cfg.get('paths') == 'dense'
+        per_gamete = (4.0 if dense else 2.0) * dev.W64 * 8.0
         out = {
             'metric': 'individual-timesteps/sec', 'value': total_ind_steps / max_elapsed,
             'unit': 'individual-timesteps/s', 'n_gpus': world, 'steps': args.steps,
@@ -562,8 +563,14 @@ def main():
                 'traffic_pmc': traffic_src,
                 'launches': xo['launches'],
                 'avg_launch_ms': xo['ms'] / max(xo['launches'], 1),
-                # offspring that survive their first death draw x (L bytes dense, L/2 sparse)
+                # gametes the kernel copied (counted on the device) x (L/2 bytes dense masks,
+                # L/4 sparse): the two gametes of every offspring that survives its first
+                # death draw, minus the gametes whose path has no switch point - those
+                # refer to the parent's half-row and move nothing (csrc/gnx_half.h)
                 'algorithmic_bytes_per_launch': xo['bytes'] / max(xo['launches'], 1),
+                'gametes_copied_per_launch': xo['bytes'] / max(xo['launches'], 1) / per_gamete,
+                'gametes_sharing_the_parents_half_row':
+                    1.0 - (xo['bytes'] / per_gamete) / max(2.0 * xo_births, 1.0),
                 # also quote a device-to-device copy measured on this box
                 'measured_copy_GBps': copy_gbps,
                 'frac_of_measured_copy': (ach / copy_gbps) if copy_gbps else None,

@@ -566,6 +566,7 @@ k_xo_jobs_surv(int64_t N, int64_t first, int32_t* __restrict__ grow,
                int64_t n_free, GnxHalves H, const int32_t* __restrict__ bp_off,
                GnxXoJob* __restrict__ jobs, int32_t* __restrict__ n_jobs) {
   __shared__ int lds[16];
+  __shared__ int s_pop, s_job;
   const int64_t b = first / GNX_CB + blockIdx.x;
   const int64_t base = b * GNX_CB;
   bool fx[4];
@@ -577,23 +578,67 @@ k_xo_jobs_surv(int64_t N, int64_t first, int32_t* __restrict__ grow,
   int rank[4], tot;
   gnx_block_ranks(fx, rank, tot, lds);
   const int32_t boff = blk_off3[b];
+  // a gamete without a switch point refers to the parent's half-row, the others get a
+  // half-row of their own and a job (gnx_half.h; parents are older: slots < first).  The
+  // block takes its half-rows and its stretch of the job list with ONE atomic each: the
+  // stack height and the list length are single words, and a thousand waves taking turns
+  // on them cost more than everything else in this kernel.
+  int32_t row[4], prow[4][2], ks[4][2];
+  bool pure[2][4], fresh[2][4], job[2][4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t i = base + r * 256 + threadIdx.x;
-    const bool act = fx[r];
     const int64_t k = i - first;
-    int32_t row = -1;
-    if (act) {
-      row = free_rows[n_free - 1 - (boff + rank[r])];
-      grow[i] = row;
+    row[r] = -1;
+    if (fx[r]) {
+      row[r] = free_rows[n_free - 1 - (boff + rank[r])];
+      grow[i] = row[r];
     }
-    // a gamete without a switch point refers to the parent's half-row, the others get a
-    // half-row of their own and a job (gnx_half.h); parents are older: slots < first
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
-      gnx_xo_gamete(H, act, row, p, act ? grow[off_parent[2 * k + p]] : -1,
-                    act ? off_keys[2 * k + p] : 0, act ? off_start[2 * k + p] : 0, bp_off, jobs,
-                    n_jobs);
+    for (int p = 0; p < 2; ++p) {
+      prow[r][p] = fx[r] ? grow[off_parent[2 * k + p]] : -1;
+      const int key = fx[r] ? off_keys[2 * k + p] : 0;
+      ks[r][p] = key * 2 + (fx[r] ? off_start[2 * k + p] : 0);
+      pure[p][r] = fx[r] && prow[r][p] >= 0 && bp_off && bp_off[key + 1] == bp_off[key];
+      fresh[p][r] = fx[r] && !pure[p][r];
+      job[p][r] = fresh[p][r] && prow[r][p] >= 0;
+    }
+  }
+  int rf[2][4], rj[2][4], tf[2], tj[2];
+  gnx_block_ranks(fresh[0], rf[0], tf[0], lds);
+  gnx_block_ranks(fresh[1], rf[1], tf[1], lds);
+  gnx_block_ranks(job[0], rj[0], tj[0], lds);
+  gnx_block_ranks(job[1], rj[1], tj[1], lds);
+  if (threadIdx.x == 0) {
+    s_pop = (tf[0] + tf[1]) ? atomicSub(H.top, tf[0] + tf[1]) : 0;
+    s_job = (tj[0] + tj[1]) ? atomicAdd(n_jobs, tj[0] + tj[1]) : 0;
+  }
+  __syncthreads();
+  const int pop0 = s_pop, job0 = s_job;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int64_t lh = (int64_t)row[r] * 2 + p;
+      int32_t dst = -1;
+      if (fresh[p][r]) {
+        dst = H.stack[pop0 - 1 - (p * tf[0] + rf[p][r])];
+        H.rc[dst] = 1;
+        H.hmap[lh] = dst;
+      } else if (pure[p][r]) {
+        const int32_t src = H.hmap[(int64_t)prow[r][p] * 2 + (ks[r][p] & 1)];
+        H.hmap[lh] = src;
+        atomicAdd(&H.rc[src], 1);
+      }
+      if (job[p][r]) {
+        GnxXoJob j;
+        j.ph0 = H.hmap[(int64_t)prow[r][p] * 2];
+        j.ph1 = H.hmap[(int64_t)prow[r][p] * 2 + 1];
+        j.dst = dst;
+        j.ks = ks[r][p];
+        jobs[job0 + p * tj[0] + rj[p][r]] = j;
+      }
+    }
   }
 }
 

@@ -19,6 +19,16 @@
 #include <functional>
 #include "../geonomics_amd/csrc/gnx_xo.h"
 
+// how the lab describes a gamete (and the format of a replay file dumped by an earlier
+// build): logical parent row, child half-row, path, start homologue; converted to the
+// product's GnxXoJob (physical half-rows, csrc/gnx_half.h) on upload
+struct LabJob {
+  int32_t prow, dst, key, start;
+};
+static inline GnxXoJob lab_to_job(const LabJob& j) {
+  return GnxXoJob{j.prow * 2, j.prow * 2 + 1, j.dst, j.key * 2 + j.start};
+}
+
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 
 // ---- the round-1 kernel (k_crossover_stream<8> of round 1), for reference ----------
@@ -87,10 +97,10 @@ k_copy_jobs(const int32_t* __restrict__ n_jobs_p, int W16, const u64x2* __restri
   const int n_waves = (int)gridDim.x * 4;
   for (int j = (int)blockIdx.x * 4 + wv; j < n_jobs; j += n_waves) {
     const GnxXoJob jb = jobs[j];
-    const int prow = __builtin_amdgcn_readfirstlane(jb.prow);
+    const int ks_ = __builtin_amdgcn_readfirstlane(jb.ks);
     const int dsth = __builtin_amdgcn_readfirstlane(jb.dst);
-    const int st = __builtin_amdgcn_readfirstlane(jb.start);
-    const u64x2* src = G + ((int64_t)prow * 2 + st) * W16;
+    const int ph = __builtin_amdgcn_readfirstlane((ks_ & 1) ? jb.ph1 : jb.ph0);
+    const u64x2* src = G + (int64_t)ph * W16;
     u64x2* dst = Gout + (int64_t)dsth * W16;
     for (int c0 = lane; c0 < W16; c0 += 64 * U) {
       u64x2 v[U];
@@ -221,24 +231,24 @@ int main(int argc, char** argv) {
     if (kind >= 1) std::sort(crow.begin(), crow.end());
     if (kind == 2)
       std::sort(order.begin(), order.end(), [&](int a, int b) { return par[2 * a] < par[2 * b]; });
-    std::vector<GnxXoJob> jobs(n_jobs);
+    std::vector<LabJob> jobs(n_jobs);
     for (int q = 0; q < B; ++q) {
       const int k = order[q];
       for (int p = 0; p < 2; ++p)
-        jobs[2 * q + p] = GnxXoJob{par[2 * k + p], crow[q] * 2 + p, key[2 * k + p], st[2 * k + p]};
+        jobs[2 * q + p] = LabJob{par[2 * k + p], crow[q] * 2 + p, key[2 * k + p], st[2 * k + p]};
     }
     if (kind == 3)
-      std::sort(jobs.begin(), jobs.end(), [](const GnxXoJob& a, const GnxXoJob& b) { return a.prow < b.prow; });
+      std::sort(jobs.begin(), jobs.end(), [](const LabJob& a, const LabJob& b) { return a.prow < b.prow; });
     return jobs;
   };
   const int NK = 4;
   GnxXoJob* d_jobs[NK];
-  std::vector<GnxXoJob> file_jobs;
+  std::vector<LabJob> file_jobs;
   if (jobs_file) {
     FILE* f = fopen(jobs_file, "rb");
     if (!f) { printf("cannot open %s\n", jobs_file); return 1; }
     file_jobs.resize(n_jobs);
-    size_t got = fread(file_jobs.data(), sizeof(GnxXoJob), n_jobs, f);
+    size_t got = fread(file_jobs.data(), sizeof(LabJob), n_jobs, f);
     fclose(f);
     if ((int)got != n_jobs) { printf("job file holds %zu jobs, births*2 = %d\n", got, n_jobs); return 1; }
     for (auto& j : file_jobs)
@@ -292,8 +302,10 @@ int main(int argc, char** argv) {
       }
     }
     for (auto& j : jobs) { j.prow *= spread; j.dst = ((j.dst >> 1) * spread) * 2 + (j.dst & 1); }
+    std::vector<GnxXoJob> up(jobs.size());
+    for (size_t q = 0; q < jobs.size(); ++q) up[q] = lab_to_job(jobs[q]);
     CHK(hipMalloc((void**)&d_jobs[kind], (size_t)n_jobs * sizeof(GnxXoJob)));
-    CHK(hipMemcpy(d_jobs[kind], jobs.data(), (size_t)n_jobs * sizeof(GnxXoJob), hipMemcpyHostToDevice));
+    CHK(hipMemcpy(d_jobs[kind], up.data(), (size_t)n_jobs * sizeof(GnxXoJob), hipMemcpyHostToDevice));
   }
   // round-1 metadata (job kind 0): slots = rows; grow identity
   int32_t *d_grow, *d_offp, *d_offk, *d_bpoff, *d_bploci, *d_njobs;
@@ -337,11 +349,11 @@ int main(int argc, char** argv) {
 #define SPARSE(U, NT, BPC, KIND)                                                                  \
   add(std::string("xo_sparse U=" #U " nt=" #NT " bpc=" #BPC " ") + kn[KIND], [=]() {             \
     hipLaunchKernelGGL((k_xo_sparse<U, NT>), dim3(256 * BPC), dim3(256), 0, 0, d_njobs, W16, G, G, \
-                       d_jobs[KIND], d_bpoff, d_bploci, 0, 1024); }, sparse_bytes)
+                       d_jobs[KIND], d_bpoff, d_bploci, 0, 1024, nullptr); }, sparse_bytes)
 #define DENSE(U, NT, BPC, KIND)                                                                   \
   add(std::string("xo_dense U=" #U " nt=" #NT " bpc=" #BPC " ") + kn[KIND], [=]() {              \
     hipLaunchKernelGGL((k_xo_dense<U, NT>), dim3(256 * BPC), dim3(256), 0, 0, d_njobs, W16, G, G,  \
-                       d_jobs[KIND], (const u64x2*)d_paths, 0, 1024); }, dense_bytes)
+                       d_jobs[KIND], (const u64x2*)d_paths, 0, 1024, nullptr); }, dense_bytes)
 #define COPYJ(U, NT, BPC, KIND)                                                                   \
   add(std::string("copy_jobs U=" #U " nt=" #NT " bpc=" #BPC " ") + kn[KIND], [=]() {             \
     hipLaunchKernelGGL((k_copy_jobs<U, NT>), dim3(256 * BPC), dim3(256), 0, 0, d_njobs, W16, G, G, \
