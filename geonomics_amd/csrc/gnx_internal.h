@@ -450,7 +450,7 @@ int gnx_prim_sort64(void* tmp, size_t bytes, const uint64_t* kin, uint64_t* kout
                     const int32_t* vin, int32_t* vout, size_t n, hipStream_t s);
 int gnx_prim_sort64_bits(void* tmp, size_t bytes, const uint64_t* kin, uint64_t* kout,
                          const int32_t* vin, int32_t* vout, size_t n, int end_bit,
-                         hipStream_t s);
+                         hipStream_t s, bool alone = true);
 int gnx_prim_scan_bytes(size_t n, size_t* bytes);
 int gnx_prim_scan(void* tmp, size_t bytes, const int32_t* in, int32_t* out, size_t n,
                   hipStream_t s);

@@ -776,6 +776,13 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
     if (h->stream3) {
       HIPCHK(hipEventRecord(h->ev_compact, h->stream));
       HIPCHK(hipStreamWaitEvent(h->stream3, h->ev_compact, 0));
+      // GNX_RELEASE_LATE=1: not beside the crossover either.  Measured: the crossover gains
+      // 2 % (5.63 -> 5.76 TB/s), the step loses 2 % (1.652 -> 1.686 ms; the small kernels
+      // after the crossover then share the chip with the release): off.
+      static const bool late = getenv("GNX_RELEASE_LATE") && atoi(getenv("GNX_RELEASE_LATE")) != 0;
+      if (late)
+        for (int k = 0; k < 2; ++k)
+          if (h->xo_inflight[k]) HIPCHK(hipStreamWaitEvent(h->stream3, h->ev_xo_done[k], 0));
     }
     hipLaunchKernelGGL(k_release_halves, dim3(256), dim3(256), 0, st, h->free_rows, h->n_free,
                        xo ? 1 : 0, h->rel_cnt, gnx_halves(h));

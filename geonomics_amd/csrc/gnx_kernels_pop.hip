@@ -410,7 +410,7 @@ int gnx_l_sort_by_cell(gnx_state* h) {
   h->keys_fresh = false;
   GNXCHK(gnx_prim_sort64_bits(h->sort64_tmp, h->sort64_tmp_bytes, h->key64[0], h->key64[1],
                               h->perm[0], h->perm[1], (size_t)N, idbits + h->key_bits,
-                              h->stream));
+                              h->stream, h->xo_sort_waits || !h->xo_running));
   gnx_time_end(h, GNX_K_SORT, (double)N * 40.0);
   gnx_time_begin(h);
   hipLaunchKernelGGL(k_permute, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, c.cap_inds,

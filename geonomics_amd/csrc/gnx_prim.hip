@@ -72,11 +72,14 @@ int gnx_prim_sort64(void* tmp, size_t bytes, const uint64_t* kin, uint64_t* kout
 // only the low `end_bit` bits of the keys are significant (fewer radix passes)
 int gnx_prim_sort64_bits(void* tmp, size_t bytes, const uint64_t* kin, uint64_t* kout,
                          const int32_t* vin, int32_t* vout, size_t n, int end_bit,
-                         hipStream_t s) {
-  // 10-bit digits, 6 keys per thread: 0.138 ms for the 1.25 x 10^6 40-bit keys of the metric
+                         hipStream_t s, bool alone) {
+  // alone on the chip: 10-bit digits, 6 keys per thread: 0.138 ms for the 1.25 x 10^6 40-bit keys of the metric
   // workload (8-bit default config 0.187; 2 / 3 / 4 / 8 / 12 keys per thread 0.191 / 0.166 /
-  // 0.154 / 0.151 / 0.167); GNX_SORT_BITS=8 selects the library's default digits
-  static const int digit = getenv("GNX_SORT_BITS") ? atoi(getenv("GNX_SORT_BITS")) : 10;
+  // 0.154 / 0.151 / 0.167).  Beside a crossover (whole-step overlap) its 1024-thread blocks
+  // wait longer for a CU than the default's and the step loses 5-9 %: default digits there.
+  // GNX_SORT_BITS=8 / 10 forces one or the other.
+  static const int forced = getenv("GNX_SORT_BITS") ? atoi(getenv("GNX_SORT_BITS")) : 0;
+  const int digit = forced ? forced : (alone ? 10 : 8);
   if (digit == 10)
     HIPCHK(rocprim::radix_sort_pairs<gnx_sort_config10>(tmp, bytes, kin, kout, vin, vout, n, 0,
                                                         end_bit, s));
