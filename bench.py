@@ -300,8 +300,11 @@ def spawn_ranks(args):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
                                       env=env, stdout=subprocess.PIPE if r == 0 else None))
     rc = 0
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     try:
-        out0 = procs[0].communicate()[0]
         pending = list(procs)
         while pending:
             for p_ in list(pending):
@@ -314,8 +317,9 @@ def spawn_ranks(args):
                     for q in pending:          # a dead rank leaves its peers in a collective
                         q.kill()
             time.sleep(0.2)
-        if rc == 0:
-            sys.stdout.write(out0.decode())
+        reader.join(timeout=10)
+        if rc == 0 and out0:
+            sys.stdout.write(out0[0].decode())
     finally:
         for p_ in procs:
             if p_.poll() is None:
