@@ -583,23 +583,44 @@ k_xo_jobs_surv(int64_t N, int64_t first, int32_t* __restrict__ grow,
   // block takes its half-rows and its stretch of the job list with ONE atomic each: the
   // stack height and the list length are single words, and a thousand waves taking turns
   // on them cost more than everything else in this kernel.
+  // every load of a stage is issued for all eight gametes of the thread before the first
+  // result is used (unconditional loads from clamped indices: behind `fx ? load : 0` the
+  // compiler waits for each one in turn, 24 round trips instead of 3)
   int32_t row[4], prow[4][2], ks[4][2];
   bool pure[2][4], fresh[2][4], job[2][4];
+  int32_t par[4][2], key[4][2], st[4][2];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t i = base + r * 256 + threadIdx.x;
-    const int64_t k = i - first;
-    row[r] = -1;
-    if (fx[r]) {
-      row[r] = free_rows[n_free - 1 - (boff + rank[r])];
-      grow[i] = row[r];
-    }
+    const int64_t k = fx[r] ? i - first : 0;
+    row[r] = free_rows[n_free - 1 - (fx[r] ? boff + rank[r] : 0)];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      prow[r][p] = fx[r] ? grow[off_parent[2 * k + p]] : -1;
-      const int key = fx[r] ? off_keys[2 * k + p] : 0;
-      ks[r][p] = key * 2 + (fx[r] ? off_start[2 * k + p] : 0);
-      pure[p][r] = fx[r] && prow[r][p] >= 0 && bp_off && bp_off[key + 1] == bp_off[key];
+      par[r][p] = off_parent[2 * k + p];
+      key[r][p] = off_keys[2 * k + p];
+      st[r][p] = off_start[2 * k + p];
+    }
+  }
+  int32_t b0[4][2], b1[4][2];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    if (fx[r]) grow[i] = row[r];
+    else row[r] = -1;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      prow[r][p] = grow[par[r][p]];
+      b0[r][p] = bp_off ? bp_off[key[r][p]] : 0;
+      b1[r][p] = bp_off ? bp_off[key[r][p] + 1] : 1;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      if (!fx[r]) prow[r][p] = -1;
+      ks[r][p] = key[r][p] * 2 + st[r][p];
+      pure[p][r] = fx[r] && prow[r][p] >= 0 && b0[r][p] == b1[r][p];
       fresh[p][r] = fx[r] && !pure[p][r];
       job[p][r] = fresh[p][r] && prow[r][p] >= 0;
     }
@@ -615,25 +636,37 @@ k_xo_jobs_surv(int64_t N, int64_t first, int32_t* __restrict__ grow,
   }
   __syncthreads();
   const int pop0 = s_pop, job0 = s_job;
+  // the parents' physical half-rows, again all loads first (hmap[0..1] for a gamete that
+  // has no local parent: read and dropped)
+  int32_t ph[4][2][2], fresh_dst[4][2];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int64_t pr = prow[r][p] >= 0 ? prow[r][p] : 0;
+      ph[r][p][0] = H.hmap[pr * 2];
+      ph[r][p][1] = H.hmap[pr * 2 + 1];
+      fresh_dst[r][p] = H.stack[max(pop0 - 1 - (fresh[p][r] ? p * tf[0] + rf[p][r] : 0), 0)];
+    }
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int64_t lh = (int64_t)row[r] * 2 + p;
-      int32_t dst = -1;
+      const int32_t dst = fresh_dst[r][p];
       if (fresh[p][r]) {
-        dst = H.stack[pop0 - 1 - (p * tf[0] + rf[p][r])];
         H.rc[dst] = 1;
         H.hmap[lh] = dst;
       } else if (pure[p][r]) {
-        const int32_t src = H.hmap[(int64_t)prow[r][p] * 2 + (ks[r][p] & 1)];
+        const int32_t src = ph[r][p][ks[r][p] & 1];
         H.hmap[lh] = src;
         atomicAdd(&H.rc[src], 1);
       }
       if (job[p][r]) {
         GnxXoJob j;
-        j.ph0 = H.hmap[(int64_t)prow[r][p] * 2];
-        j.ph1 = H.hmap[(int64_t)prow[r][p] * 2 + 1];
+        j.ph0 = ph[r][p][0];
+        j.ph1 = ph[r][p][1];
         j.dst = dst;
         j.ks = ks[r][p];
         jobs[job0 + p * tj[0] + rj[p][r]] = j;
