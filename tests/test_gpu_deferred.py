@@ -98,21 +98,23 @@ def test_genome_access_between_mate_and_die_materialises():
 
 
 def test_overlap_mode_and_table_spread_do_not_change_results(monkeypatch):
-    """how the crossover shares the GPU with the next step (gnx_set_crossover_overlap) and
-    where the genome rows sit in HBM (GNX_ROW_SPREAD) are scheduling / placement choices:
-    the population after 10 steps is the same bit for bit"""
+    """how the crossover shares the GPU with the next step (gnx_set_crossover_overlap,
+    gnx_set_crossover_split) and where the genome rows sit in HBM (GNX_ROW_SPREAD) are
+    scheduling / placement choices: the population after 10 steps is the same bit for bit"""
     ref, nat = _model(True, seed=23)
     alt, _ = _model(True, seed=23)
     alt.set_crossover_overlap(True)
+    split, _ = _model(True, seed=23)
+    split.set_crossover_split(400)
     monkeypatch.setenv('GNX_ROW_SPREAD', '1')
     compact, _ = _model(True, seed=23)
     monkeypatch.delenv('GNX_ROW_SPREAD')
     for t in range(10):
-        for dev in (ref, alt, compact):
+        for dev in (ref, alt, split, compact):
             dev.step(False, True)
-        assert ref.counts() == alt.counts() == compact.counts(), t
+        assert ref.counts() == alt.counts() == split.counts() == compact.counts(), t
     s0 = _state(ref, nat)
-    for dev in (alt, compact):
+    for dev in (alt, split, compact):
         s1 = _state(dev, nat)
         for k in s0:
             np.testing.assert_array_equal(s0[k], s1[k], err_msg=k)
@@ -120,5 +122,5 @@ def test_overlap_mode_and_table_spread_do_not_change_results(monkeypatch):
     r_ref, r_cmp = ref.download(nat.F_GROW), compact.download(nat.F_GROW)
     stride = np.gcd.reduce(r_ref[r_ref > 0])
     assert stride >= 2 and np.gcd.reduce(r_cmp[r_cmp > 0]) == 1
-    for dev in (ref, alt, compact):
+    for dev in (ref, alt, split, compact):
         dev.close()
