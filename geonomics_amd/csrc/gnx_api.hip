@@ -290,11 +290,23 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
       h->row_spread = want;
     }
     GNXCHK(dalloc(&h->free_rows, (size_t)h->cfg.cap_rows));
-    const size_t halves = (size_t)h->cfg.cap_rows * h->row_spread * 2;
+    // blocks per homologue: a divisor of the 128-byte lines per homologue (GNX_HALF_BLOCKS,
+    // default 2: half a homologue per block)
+    {
+      const int lines = h->W64 / 16;
+      int want = getenv("GNX_HALF_BLOCKS") ? atoi(getenv("GNX_HALF_BLOCKS")) : 2;
+      want = std::max(1, std::min(want, GNX_MAX_NB));
+      while (want > 1 && lines % want) --want;
+      h->NB = want;
+    }
+    const size_t halves = (size_t)h->cfg.cap_rows * h->row_spread * 2 * h->NB;
     GNXCHK(dalloc(&h->hmap, halves));
     GNXCHK(dalloc(&h->half_rc, halves));
-    GNXCHK(dalloc(&h->half_free, (size_t)h->cfg.cap_rows * 2));
+    GNXCHK(dalloc(&h->half_free, (size_t)h->cfg.cap_rows * 2 * h->NB));
     GNXCHK(dalloc(&h->half_top, 1));
+    GNXCHK(dalloc(&h->half_share, (size_t)cap * 2 * h->NB));
+    GNXCHK(dalloc(&h->half_n_share, 2));        // count, and the flush kernel's exit counter
+    HIPCHK(hipMemset(h->half_n_share, 0, 2 * sizeof(int32_t)));
     GNXCHK(dalloc(&h->rel_cnt, 2));
     HIPCHK(hipStreamCreate(&h->stream3));
     HIPCHK(hipEventCreateWithFlags(&h->ev_compact, hipEventDisableTiming));
@@ -361,7 +373,7 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
   HIPCHK(hipHostGetDevicePointer((void**)&h->h_pin_dev, h->h_pin, 0));
   if (cfg->L > 0) {
     for (int k = 0; k < 2; ++k) {
-      HIPCHK(hipMalloc(&h->jobs[k], (size_t)cap * 2 * 16));
+      HIPCHK(hipMalloc(&h->jobs[k], (size_t)cap * 2 * h->NB * 16));     // a job per cut block
       GNXCHK(dalloc(&h->n_jobs_dev[k], 1));
       HIPCHK(hipEventCreateWithFlags(&h->ev_xo_done[k], hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&h->ev_xo_wide[k], hipEventDisableTiming));
@@ -397,7 +409,7 @@ extern "C" void gnx_destroy(gnx_state* h) {
     (void)hipFree(h->perm[k]);
     (void)hipFree(h->counts_rast[k]);
   }
-  void* ptrs[] = {h->rel_cnt, h->hmap, h->half_rc, h->half_free, h->half_top, h->xo_jobs_acc, h->rast, h->G, h->free_rows, h->paths, h->bp_off, h->bp_loci, h->dom,
+  void* ptrs[] = {h->half_share, h->half_n_share, h->rel_cnt, h->hmap, h->half_rc, h->half_free, h->half_top, h->xo_jobs_acc, h->rast, h->G, h->free_rows, h->paths, h->bp_off, h->bp_loci, h->dom,
                   h->delet_loci, h->delet_s, h->cell_start, h->tag, h->cand, h->sort64_tmp, h->key64[0], h->key64[1], h->pairs2,
                   h->pair_goff, h->st_rec, h->st_z, h->st_geno, h->st_slots, h->req_pid, h->req_k, h->req_key, h->req_start, h->req_px, h->req_py,
                   h->req_count, h->sort_tmp, h->scan_tmp, h->mate,
@@ -1422,7 +1434,7 @@ extern "C" int gnx_kernel_time(gnx_state* h, int32_t kernel, double* ms, int64_t
     unsigned long long n = 0;
     HIPCHK(hipMemcpy(&n, h->xo_jobs_acc + slot, sizeof(n), hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(h->xo_jobs_acc + slot, 0, sizeof(n)));
-    h->timers[kernel].bytes = (double)n * 0.5 * gnx_xo_bytes_per_birth(h);
+    h->timers[kernel].bytes = (double)n * 0.5 * gnx_xo_bytes_per_birth(h) / h->NB;   // a job = a block
   }
   if (ms) *ms = h->timers[kernel].ms;
   if (launches) *launches = h->timers[kernel].launches;

@@ -134,6 +134,9 @@ struct gnx_state {
   int32_t* half_rc = nullptr;
   int32_t* half_free = nullptr;
   int32_t* half_top = nullptr;
+  int32_t* half_share = nullptr;       // blocks shared by the builders since the last flush
+  int32_t* half_n_share = nullptr;
+  int NB = 1;                          // blocks per homologue (gnx_half.h), BW = W64 / NB words
   hipStream_t stream3 = nullptr;       // releases of the dead's half-rows
   hipEvent_t ev_compact = nullptr, ev_release = nullptr;
   bool release_inflight = false;
@@ -325,8 +328,11 @@ struct gnx_state {
 GnxTraitTab gnx_trait_tab(const gnx_state* h);
 
 static inline GnxHalves gnx_halves(const gnx_state* h) {
-  return GnxHalves{h->hmap, h->half_rc, h->half_free, h->half_top};
+  return GnxHalves{h->hmap,       h->half_rc,       h->half_free, h->half_top,
+                   h->half_share, h->half_n_share,  h->NB,        h->W64 / h->NB};
 }
+// the shared blocks listed by the builders get their counts raised (on `st`), list emptied
+int gnx_share_flush(gnx_state* h, hipStream_t st);
 // before anything that pops half-rows: the last release of the dead's half-rows has
 // finished (it runs on a stream of its own)
 static inline int gnx_halves_ready(gnx_state* h) {
@@ -343,6 +349,9 @@ static inline int gnx_halves_ready(gnx_state* h) {
 // (sparse paths only: the dense path table is not scanned for all-zero masks), else null
 static inline const int32_t* gnx_alias_bp(const gnx_state* h) {
   return (h->alias_xo && h->sparse_paths) ? h->bp_off : nullptr;
+}
+static inline const int32_t* gnx_alias_loci(const gnx_state* h) {
+  return (h->alias_xo && h->sparse_paths) ? h->bp_loci : nullptr;
 }
 
 // read-back of up to four device int32 counters: one tiny kernel writes them straight into

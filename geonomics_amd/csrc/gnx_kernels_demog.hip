@@ -564,9 +564,10 @@ k_xo_jobs_surv(int64_t N, int64_t first, int32_t* __restrict__ grow,
                const int32_t* __restrict__ off_parent, const int32_t* __restrict__ off_keys,
                const uint8_t* __restrict__ off_start, const int32_t* __restrict__ free_rows,
                int64_t n_free, GnxHalves H, const int32_t* __restrict__ bp_off,
-               GnxXoJob* __restrict__ jobs, int32_t* __restrict__ n_jobs) {
+               const int32_t* __restrict__ bp_loci, GnxXoJob* __restrict__ jobs,
+               int32_t* __restrict__ n_jobs) {
   __shared__ int lds[16];
-  __shared__ int s_pop, s_job;
+  __shared__ int s_pop, s_job, s_share;
   const int64_t b = first / GNX_CB + blockIdx.x;
   const int64_t base = b * GNX_CB;
   bool fx[4];
@@ -578,16 +579,17 @@ k_xo_jobs_surv(int64_t N, int64_t first, int32_t* __restrict__ grow,
   int rank[4], tot;
   gnx_block_ranks(fx, rank, tot, lds);
   const int32_t boff = blk_off3[b];
-  // a gamete without a switch point refers to the parent's half-row, the others get a
-  // half-row of their own and a job (gnx_half.h; parents are older: slots < first).  The
-  // block takes its half-rows and its stretch of the job list with ONE atomic each: the
-  // stack height and the list length are single words, and a thousand waves taking turns
-  // on them cost more than everything else in this kernel.
-  // every load of a stage is issued for all eight gametes of the thread before the first
+  // Block by block (gnx_half.h), a gamete refers to the parent's block where its path has no
+  // switch point and gets a block of its own and a job where it has one (parents are older:
+  // slots < first).  The workgroup takes its blocks, its stretch of the job list and its
+  // stretch of the list of shared blocks with ONE atomic each: those are single words, and a
+  // thousand waves taking turns on them cost more than everything else in this kernel.
+  // Every load of a stage is issued for all eight gametes of the thread before the first
   // result is used (unconditional loads from clamped indices: behind `fx ? load : 0` the
-  // compiler waits for each one in turn, 24 round trips instead of 3)
+  // compiler waits for each one in turn).
+  const int NB = H.NB;
+  const unsigned int all = (1u << NB) - 1u;
   int32_t row[4], prow[4][2], ks[4][2];
-  bool pure[2][4], fresh[2][4], job[2][4];
   int32_t par[4][2], key[4][2], st[4][2];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -611,65 +613,69 @@ k_xo_jobs_surv(int64_t N, int64_t first, int32_t* __restrict__ grow,
     for (int p = 0; p < 2; ++p) {
       prow[r][p] = grow[par[r][p]];
       b0[r][p] = bp_off ? bp_off[key[r][p]] : 0;
-      b1[r][p] = bp_off ? bp_off[key[r][p] + 1] : 1;
+      b1[r][p] = bp_off ? bp_off[key[r][p] + 1] : 0;
     }
   }
+  unsigned int mixed[4][2], sel[4][2];
+  int cf[4], cj[4], cs[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
+    cf[r] = cj[r] = cs[r] = 0;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       if (!fx[r]) prow[r][p] = -1;
       ks[r][p] = key[r][p] * 2 + st[r][p];
-      pure[p][r] = fx[r] && prow[r][p] >= 0 && b0[r][p] == b1[r][p];
-      fresh[p][r] = fx[r] && !pure[p][r];
-      job[p][r] = fresh[p][r] && prow[r][p] >= 0;
+      mixed[r][p] = all;                       // dense masks, ghost parent: cut everything
+      sel[r][p] = 0u;
+      if (fx[r] && prow[r][p] >= 0 && bp_off)
+        gnx_block_masks(bp_loci + b0[r][p], b1[r][p] - b0[r][p], st[r][p], NB, H.BW, mixed[r][p],
+                        sel[r][p]);
+      if (fx[r]) {
+        const int nf = __popc(mixed[r][p] & all);
+        cf[r] += nf;
+        cj[r] += prow[r][p] >= 0 ? nf : 0;
+        cs[r] += NB - nf;
+      }
     }
   }
-  int rf[2][4], rj[2][4], tf[2], tj[2];
-  gnx_block_ranks(fresh[0], rf[0], tf[0], lds);
-  gnx_block_ranks(fresh[1], rf[1], tf[1], lds);
-  gnx_block_ranks(job[0], rj[0], tj[0], lds);
-  gnx_block_ranks(job[1], rj[1], tj[1], lds);
+  int of[4], oj[4], os[4], tf, tj, ts;
+  gnx_block_sums(cf, of, tf, lds);
+  gnx_block_sums(cj, oj, tj, lds);
+  gnx_block_sums(cs, os, ts, lds);
   if (threadIdx.x == 0) {
-    s_pop = (tf[0] + tf[1]) ? atomicSub(H.top, tf[0] + tf[1]) : 0;
-    s_job = (tj[0] + tj[1]) ? atomicAdd(n_jobs, tj[0] + tj[1]) : 0;
+    s_pop = tf ? atomicSub(H.top, tf) : 0;
+    s_job = tj ? atomicAdd(n_jobs, tj) : 0;
+    s_share = ts ? atomicAdd(H.n_share, ts) : 0;
   }
   __syncthreads();
-  const int pop0 = s_pop, job0 = s_job;
-  // the parents' physical half-rows, again all loads first (hmap[0..1] for a gamete that
-  // has no local parent: read and dropped)
-  int32_t ph[4][2][2], fresh_dst[4][2];
+  const int pop0 = s_pop, job0 = s_job, share0 = s_share;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
+    if (!fx[r]) continue;
+    int pi = of[r], ji = oj[r], si = os[r];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      const int64_t pr = prow[r][p] >= 0 ? prow[r][p] : 0;
-      ph[r][p][0] = H.hmap[pr * 2];
-      ph[r][p][1] = H.hmap[pr * 2 + 1];
-      fresh_dst[r][p] = H.stack[max(pop0 - 1 - (fresh[p][r] ? p * tf[0] + rf[p][r] : 0), 0)];
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
+      const bool local = prow[r][p] >= 0;
       const int64_t lh = (int64_t)row[r] * 2 + p;
-      const int32_t dst = fresh_dst[r][p];
-      if (fresh[p][r]) {
-        H.rc[dst] = 1;
-        H.hmap[lh] = dst;
-      } else if (pure[p][r]) {
-        const int32_t src = ph[r][p][ks[r][p] & 1];
-        H.hmap[lh] = src;
-        atomicAdd(&H.rc[src], 1);
-      }
-      if (job[p][r]) {
-        GnxXoJob j;
-        j.ph0 = ph[r][p][0];
-        j.ph1 = ph[r][p][1];
-        j.dst = dst;
-        j.ks = ks[r][p];
-        jobs[job0 + p * tj[0] + rj[p][r]] = j;
+      const int64_t ph0 = (int64_t)(local ? prow[r][p] : 0) * 2 * NB;
+      for (int q = 0; q < NB; ++q) {
+        if ((mixed[r][p] >> q) & 1u) {
+          const int32_t dst = H.stack[pop0 - 1 - pi++];
+          H.rc[dst] = 1;
+          H.hmap[lh * NB + q] = dst;
+          if (local) {
+            GnxXoJob j;
+            j.ph0 = H.hmap[ph0 + q];
+            j.ph1 = H.hmap[ph0 + NB + q];
+            j.dst = dst;
+            j.ks = ks[r][p] | (q << 24);
+            jobs[job0 + ji++] = j;
+          }
+        } else {
+          const int32_t src = H.hmap[ph0 + ((sel[r][p] >> q) & 1u) * NB + q];
+          H.hmap[lh * NB + q] = src;
+          H.share[share0 + si++] = src;
+        }
       }
     }
   }
@@ -739,12 +745,11 @@ k_release_halves(const int32_t* __restrict__ free_rows, int64_t n_free, int xo,
   const int64_t n_up = (n + 63) / 64 * 64;
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_up; j += stride) {
     const int32_t row = j < n ? free_rows[base + j] : -1;
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
+    for (int q = 0; q < 2 * H.NB; ++q) {
       bool last = false;
       int32_t phys = -1;
       if (row >= 0) {
-        phys = H.hmap[(int64_t)row * 2 + hh];
+        phys = H.hmap[(int64_t)row * 2 * H.NB + q];
         last = atomicSub(&H.rc[phys], 1) == 1;
       }
       const int32_t idx = gnx_wave_append(H.top, last);
@@ -761,7 +766,8 @@ void gnx_launch_xo_jobs_surv(gnx_state* h, int64_t first_slot, const int32_t* d_
   hipLaunchKernelGGL(k_xo_jobs_surv, dim3(nbj), dim3(256), 0, h->stream, N, first_slot,
                      h->soa[h->cur].grow, d_alive, d_blk_off + 2 * h->blk_stride, h->off_parent,
                      h->off_keys, h->off_start, h->free_rows, h->n_free, gnx_halves(h),
-                     gnx_alias_bp(h), (GnxXoJob*)h->jobs[buf], h->n_jobs_dev[buf]);
+                     gnx_alias_bp(h), gnx_alias_loci(h), (GnxXoJob*)h->jobs[buf],
+                     h->n_jobs_dev[buf]);
 }
 
 int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_out) {
@@ -817,6 +823,8 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
         for (int k = 0; k < 2; ++k)
           if (h->xo_inflight[k]) HIPCHK(hipStreamWaitEvent(h->stream3, h->ev_xo_done[k], 0));
     }
+    // first the counts of the blocks this step's gametes share, then the dead's releases
+    GNXCHK(gnx_share_flush(h, st));
     hipLaunchKernelGGL(k_release_halves, dim3(256), dim3(256), 0, st, h->free_rows, h->n_free,
                        xo ? 1 : 0, h->rel_cnt, gnx_halves(h));
     if (h->stream3) {

@@ -25,7 +25,8 @@ k_xo_jobs_all(int64_t B, int64_t first, int32_t* __restrict__ grow,
               const int32_t* __restrict__ off_parent, const int32_t* __restrict__ off_keys,
               const uint8_t* __restrict__ off_start, const int32_t* __restrict__ free_rows,
               int64_t n_free, GnxHalves H, const int32_t* __restrict__ bp_off,
-              GnxXoJob* __restrict__ jobs, int32_t* __restrict__ n_jobs) {
+              const int32_t* __restrict__ bp_loci, GnxXoJob* __restrict__ jobs,
+              int32_t* __restrict__ n_jobs) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool act = k < B;
   int32_t row = -1;
@@ -37,7 +38,7 @@ k_xo_jobs_all(int64_t B, int64_t first, int32_t* __restrict__ grow,
   for (int p = 0; p < 2; ++p) {
     const int32_t prow = act ? grow[off_parent[2 * k + p]] : -1;
     gnx_xo_gamete(H, act, row, p, prow, act ? off_keys[2 * k + p] : 0,
-                  act ? off_start[2 * k + p] : 0, bp_off, jobs, n_jobs);
+                  act ? off_start[2 * k + p] : 0, bp_off, bp_loci, jobs, n_jobs);
   }
 }
 
@@ -49,7 +50,7 @@ void gnx_launch_xo_jobs_surv(gnx_state* h, int64_t first_slot, const int32_t* d_
 template <int U>
 static void xo_launch_sparse(gnx_state* h, hipStream_t st, int grid, int buf, bool nt, int lo,
                              int hi, unsigned long long* acc) {
-  const int W16 = h->W64 / 2;
+  const int W16 = h->W64 / 2 / h->NB;       // chunks per block
   if (nt)
     hipLaunchKernelGGL((k_xo_sparse<U, true>), dim3(grid), dim3(256), 0, st, h->n_jobs_dev[buf],
                        W16, (const u64x2*)h->G, (u64x2*)h->G, (const GnxXoJob*)h->jobs[buf],
@@ -77,11 +78,16 @@ static int xo_launch(gnx_state* h, hipStream_t st, int buf, int64_t max_jobs, bo
   const int bpc = narrow ? tail_bpc : (bpc_env ? bpc_env : 32);
   // the narrow share of a split launch is accounted for on its own
   unsigned long long* acc = h->xo_jobs_acc ? h->xo_jobs_acc + ((narrow && lo > 0) ? 1 : 0) : nullptr;
-  const int W16 = h->W64 / 2;
-  const int grid = gnx_grid(max_jobs, 4, 256 * bpc);
+  const int W16 = h->W64 / 2 / h->NB;       // chunks per block
+  const int grid = gnx_grid(max_jobs * h->NB, 4, 256 * bpc);
   if (h->sparse_paths) {
-    const int U = narrow ? tail_unroll : (unroll_env ? unroll_env : gnx_xo_pick_unroll(W16));
+    // (blocks shorter than a homologue: as many loads in flight as the block has chunks)
+    const int U = (narrow && h->NB == 1) ? tail_unroll
+                                          : (unroll_env ? unroll_env : gnx_xo_pick_unroll(W16));
     switch (U) {
+      case 1: xo_launch_sparse<1>(h, st, grid, buf, nt, lo, hi, acc); break;
+      case 2: xo_launch_sparse<2>(h, st, grid, buf, nt, lo, hi, acc); break;
+      case 3: xo_launch_sparse<3>(h, st, grid, buf, nt, lo, hi, acc); break;
       case 4: xo_launch_sparse<4>(h, st, grid, buf, nt, lo, hi, acc); break;
       case 5: xo_launch_sparse<5>(h, st, grid, buf, nt, lo, hi, acc); break;
       case 6: xo_launch_sparse<6>(h, st, grid, buf, nt, lo, hi, acc); break;
@@ -94,11 +100,11 @@ static int xo_launch(gnx_state* h, hipStream_t st, int buf, int64_t max_jobs, bo
     if (nt)
       hipLaunchKernelGGL((k_xo_dense<4, true>), dim3(grid), dim3(256), 0, st, h->n_jobs_dev[buf],
                          W16, (const u64x2*)h->G, (u64x2*)h->G, (const GnxXoJob*)h->jobs[buf],
-                         (const u64x2*)h->paths, lo, hi, acc);
+                         (const u64x2*)h->paths, h->W64 / 2, lo, hi, acc);
     else
       hipLaunchKernelGGL((k_xo_dense<4, false>), dim3(grid), dim3(256), 0, st, h->n_jobs_dev[buf],
                          W16, (const u64x2*)h->G, (u64x2*)h->G, (const GnxXoJob*)h->jobs[buf],
-                         (const u64x2*)h->paths, lo, hi, acc);
+                         (const u64x2*)h->paths, h->W64 / 2, lo, hi, acc);
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -136,7 +142,9 @@ int gnx_l_crossover_all(gnx_state* h, int64_t first_slot, int64_t B) {
   HIPCHK(hipMemsetAsync(h->n_jobs_dev[buf], 0, sizeof(int32_t), h->stream));
   hipLaunchKernelGGL(k_xo_jobs_all, dim3(gnx_grid(B, 256)), dim3(256), 0, h->stream, B, first_slot,
                      s.grow, h->off_parent, h->off_keys, h->off_start, h->free_rows, h->n_free,
-                     gnx_halves(h), gnx_alias_bp(h), (GnxXoJob*)h->jobs[buf], h->n_jobs_dev[buf]);
+                     gnx_halves(h), gnx_alias_bp(h), gnx_alias_loci(h), (GnxXoJob*)h->jobs[buf],
+                     h->n_jobs_dev[buf]);
+  GNXCHK(gnx_share_flush(h, h->stream));
   if (h->stream2) {
     // tiled runs serve the neighbours' gamete requests on stream2 meanwhile: the rows
     // handed out above must be visible there
@@ -160,8 +168,8 @@ k_xo_jobs_req(int n_req, int64_t first, int32_t* __restrict__ grow,
               const int32_t* __restrict__ req_k, const int32_t* __restrict__ off_parent,
               const int32_t* __restrict__ off_keys, const uint8_t* __restrict__ off_start,
               const int32_t* __restrict__ free_rows, int64_t n_free, GnxHalves H,
-              const int32_t* __restrict__ bp_off, GnxXoJob* __restrict__ jobs,
-              int32_t* __restrict__ n_jobs) {
+              const int32_t* __restrict__ bp_off, const int32_t* __restrict__ bp_loci,
+              GnxXoJob* __restrict__ jobs, int32_t* __restrict__ n_jobs) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   const bool act = q < n_req;
   const int64_t k = act ? req_k[q] : 0;
@@ -173,8 +181,8 @@ k_xo_jobs_req(int n_req, int64_t first, int32_t* __restrict__ grow,
   // the local parent's gamete (homologue 0), and an empty half-row for the one that
   // arrives from the neighbour tile
   gnx_xo_gamete(H, act, row, 0, act ? grow[off_parent[2 * k]] : -1, act ? off_keys[2 * k] : 0,
-                act ? off_start[2 * k] : 0, bp_off, jobs, n_jobs);
-  gnx_half_new(H, (int64_t)row * 2 + 1, act);
+                act ? off_start[2 * k] : 0, bp_off, bp_loci, jobs, n_jobs);
+  for (int b = 0; b < H.NB; ++b) gnx_half_new(H, ((int64_t)row * 2 + 1) * H.NB + b, act);
 }
 
 int gnx_l_crossover_requests(gnx_state* h, int64_t first_slot, int64_t n_req) {
@@ -188,7 +196,8 @@ int gnx_l_crossover_requests(gnx_state* h, int64_t first_slot, int64_t n_req) {
   hipLaunchKernelGGL(k_xo_jobs_req, dim3(gnx_grid(n_req, 256)), dim3(256), 0, h->stream, (int)n_req,
                      first_slot, h->soa[h->cur].grow, h->req_k, h->off_parent, h->off_keys,
                      h->off_start, h->free_rows, h->n_free, gnx_halves(h), gnx_alias_bp(h),
-                     (GnxXoJob*)h->jobs[buf], h->n_jobs_dev[buf]);
+                     gnx_alias_loci(h), (GnxXoJob*)h->jobs[buf], h->n_jobs_dev[buf]);
+  GNXCHK(gnx_share_flush(h, h->stream));
   if (h->stream2) {      // the rows handed out above must be visible to the gamete puts
     HIPCHK(hipEventRecord(h->ev_jobs, h->stream));
     HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_jobs, 0));
@@ -234,6 +243,7 @@ int gnx_l_crossover_pending(gnx_state* h, int64_t first_slot, int64_t B) {
   GNXCHK(gnx_block_scan(h, 1, N, cnt3, off3, h->cnt_dev + 2, h->h_pin_dev + 8));
   HIPCHK(hipMemsetAsync(h->n_jobs_dev[buf], 0, sizeof(int32_t), h->stream));
   gnx_launch_xo_jobs_surv(h, first_slot, h->flag, h->blk_off, buf);
+  GNXCHK(gnx_share_flush(h, h->stream));
   gnx_time_begin(h);
   GNXCHK(xo_launch(h, h->stream, buf, 2 * B, false));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -373,7 +383,7 @@ int gnx_l_path_sel(gnx_state* h) {
 // tb of a slot from its genome row: one thread per (slot, homologue)
 __global__ void k_tb_from_rows(int64_t first, int64_t n, const int32_t* list, const int64_t* slots,
                                int TW, int n_sel, int W64, const int32_t* sel_loci, const u64* G,
-                               const int32_t* grow, const int32_t* hmap, u64* tb) {
+                               const int32_t* grow, GnxHalves H, u64* tb) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= 2 * n) return;
   const int64_t q = t >> 1;
@@ -381,12 +391,12 @@ __global__ void k_tb_from_rows(int64_t first, int64_t n, const int32_t* list, co
   const int64_t slot = slots ? slots[q] : first + (list ? list[q] : q);
   const int32_t row = grow[slot];
   if (row < 0) return;
-  const u64* r = G + (int64_t)hmap[(int64_t)row * 2 + hom] * W64;
+  const int64_t lh = (int64_t)row * 2 + hom;
   for (int w = 0; w < TW; ++w) {
     u64 v = 0;
     for (int e = w * 64; e < min(n_sel, w * 64 + 64); ++e) {
       const int l = sel_loci[e];
-      v |= ((r[l >> 6] >> (l & 63)) & 1ull) << (e & 63);
+      v |= ((G[gnx_word_at(H, lh, l >> 6)] >> (l & 63)) & 1ull) << (e & 63);
     }
     tb[(slot * 2 + hom) * TW + w] = v;
   }
@@ -399,7 +409,7 @@ int gnx_l_tb_from_rows(gnx_state* h, int64_t first, int64_t n, const int32_t* d_
   GnxSoA s = h->soa[h->cur];
   hipLaunchKernelGGL(k_tb_from_rows, dim3(gnx_grid(2 * n, 256)), dim3(256), 0, h->stream, first, n,
                      d_list, d_slots, h->TW, h->n_sel, h->W64, h->sel_loci, (const u64*)h->G,
-                     s.grow, h->hmap, (u64*)s.tb);
+                     s.grow, gnx_halves(h), (u64*)s.tb);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -459,7 +469,7 @@ int gnx_l_phenotype(gnx_state* h, int64_t first_slot, int64_t n) {
 // One lane per site, one wavefront per 64-site word: __ballot of the 64 lanes'
 // decisions IS the u64 genome word (row of individual q/2, homologue q%2).
 __global__ void __launch_bounds__(256)
-k_assign_genomes(int64_t N, int L, int W64, u64* G, const int32_t* grow, const int32_t* hmap,
+k_assign_genomes(int64_t N, int L, int W64, u64* G, const int32_t* grow, GnxHalves H,
                  const int32_t* n_per_site, unsigned long long site_seed) {
   const int lane = threadIdx.x & 63;
   const int64_t word = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -476,7 +486,7 @@ k_assign_genomes(int64_t N, int L, int W64, u64* G, const int32_t* grow, const i
     }
     remaining -= take ? 1 : 0;
     u64 w = __ballot(take);
-    if (lane == 0) G[(int64_t)hmap[(int64_t)grow[q >> 1] * 2 + (q & 1)] * W64 + word] = w;
+    if (lane == 0) G[gnx_word_at(H, (int64_t)grow[q >> 1] * 2 + (q & 1), (int)word)] = w;
   }
 }
 
@@ -486,21 +496,21 @@ __global__ void k_assign_rows(int64_t N, int64_t cap_rows, int spread, int32_t* 
   if (i < N) {
     const int32_t row = (int32_t)(i * spread);
     grow[i] = row;
-    // every individual starts with its own two half-rows, at its logical row's address
-    for (int hh = 0; hh < 2; ++hh) {
-      H.hmap[(int64_t)row * 2 + hh] = row * 2 + hh;
-      H.rc[(int64_t)row * 2 + hh] = 1;
+    // every individual starts with its own blocks, at its logical row's address
+    for (int q = 0; q < 2 * H.NB; ++q) {
+      H.hmap[(int64_t)row * 2 * H.NB + q] = row * 2 * H.NB + q;
+      H.rc[(int64_t)row * 2 * H.NB + q] = 1;
     }
   }
-  // free stacks: rows N..cap_rows-1 (row numbers are physical: x spread) and their halves,
+  // free stacks: rows N..cap_rows-1 (row numbers are physical: x spread) and their blocks,
   // popped from the top (highest first)
   if (i < cap_rows - N) {
     const int32_t row = (int32_t)((cap_rows - 1 - i) * spread);
     free_rows[i] = row;
-    H.stack[2 * i] = row * 2 + 1;
-    H.stack[2 * i + 1] = row * 2;
+    for (int q = 0; q < 2 * H.NB; ++q)
+      H.stack[2 * H.NB * i + q] = row * 2 * H.NB + (2 * H.NB - 1 - q);
   }
-  if (i == 0) *H.top = (int32_t)(2 * (cap_rows - N));
+  if (i == 0) *H.top = (int32_t)(2 * H.NB * (cap_rows - N));
 }
 
 int gnx_l_assign_genomes(gnx_state* h, const int32_t* d_n_per_site) {
@@ -514,15 +524,17 @@ int gnx_l_assign_genomes(gnx_state* h, const int32_t* d_n_per_site) {
   GNXCHK(gnx_halves_ready(h));
   GnxSoA s = h->soa[h->cur];
   int64_t m = N > c.cap_rows - N ? N : c.cap_rows - N;
-  HIPCHK(hipMemsetAsync(h->half_rc, 0, (size_t)c.cap_rows * h->row_spread * 2 * sizeof(int32_t),
+  HIPCHK(hipMemsetAsync(h->half_rc, 0,
+                        (size_t)c.cap_rows * h->row_spread * 2 * h->NB * sizeof(int32_t),
                         h->stream));
+  HIPCHK(hipMemsetAsync(h->half_n_share, 0, sizeof(int32_t), h->stream));
   hipLaunchKernelGGL(k_assign_rows, dim3(gnx_grid(m, 256)), dim3(256), 0, h->stream, N, c.cap_rows,
                      h->row_spread, s.grow, h->free_rows, gnx_halves(h));
   h->n_free = c.cap_rows - N;
   if (N > 0 && d_n_per_site) {
     int64_t threads = (int64_t)h->W64 * 64;
     hipLaunchKernelGGL(k_assign_genomes, dim3(gnx_grid(threads, 256)), dim3(256), 0, h->stream, N,
-                       c.L, h->W64, (u64*)h->G, s.grow, h->hmap, d_n_per_site,
+                       c.L, h->W64, (u64*)h->G, s.grow, gnx_halves(h), d_n_per_site,
                        gnx_site_seed(c.seed));
   }
   HIPCHK(hipGetLastError());
@@ -533,54 +545,53 @@ int gnx_l_assign_genomes(gnx_state* h, const int32_t* d_n_per_site) {
 // ---------------------------------------------------------------- mutation
 // ops/mutation.py:62-131: set allele 1 at (locus, homologue) of the chosen
 // offspring.
-// A half-row that only the mutated individual refers to takes the bit in place; one that
-// somebody else refers to as well (an unrecombined homologue shared with a parent or a
+// A block that only the mutated individual refers to takes the bit in place; one that
+// somebody else refers to as well (an unrecombined stretch shared with a parent or a
 // sibling) goes on a list, and one workgroup walks that list in order, copying first.
-__global__ void k_mutate(int n, int W64, u64* G, const int32_t* grow, GnxHalves H,
-                         const int64_t* slot, const int32_t* locus, const uint8_t* hom,
-                         int32_t* list, int32_t* n_list) {
+__global__ void k_mutate(int n, u64* G, const int32_t* grow, GnxHalves H, const int64_t* slot,
+                         const int32_t* locus, const uint8_t* hom, int32_t* list,
+                         int32_t* n_list) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   bool shared = false;
   if (i < n) {
-    const int32_t p = H.hmap[(int64_t)grow[slot[i]] * 2 + hom[i]];
+    const int l = locus[i];
+    const int w = l >> 6, b = w / H.BW;
+    const int32_t p = H.hmap[((int64_t)grow[slot[i]] * 2 + hom[i]) * H.NB + b];
     shared = H.rc[p] > 1;
-    if (!shared) {
-      const int l = locus[i];
-      atomicOr(G + (int64_t)p * W64 + (l >> 6), 1ull << (l & 63));
-    }
+    if (!shared) atomicOr(G + (int64_t)p * H.BW + (w - b * H.BW), 1ull << (l & 63));
   }
   const int32_t idx = gnx_wave_append(n_list, shared);
   if (shared) list[idx] = i;
 }
 
 __global__ void __launch_bounds__(256)
-k_mutate_shared(const int32_t* list, const int32_t* n_list, int W64, u64* G, const int32_t* grow,
+k_mutate_shared(const int32_t* list, const int32_t* n_list, u64* G, const int32_t* grow,
                 GnxHalves H, const int64_t* slot, const int32_t* locus, const uint8_t* hom) {
   __shared__ int32_t s_old, s_new;
   const int n = *n_list;
   for (int t = 0; t < n; ++t) {
     const int i = list[t];
+    const int l = locus[i];
+    const int w = l >> 6, b = w / H.BW;
     if (threadIdx.x == 0) {
-      const int64_t lh = (int64_t)grow[slot[i]] * 2 + hom[i];
-      const int32_t p = H.hmap[lh];
+      const int64_t lb = ((int64_t)grow[slot[i]] * 2 + hom[i]) * H.NB + b;
+      const int32_t p = H.hmap[lb];
       s_old = s_new = p;
       if (H.rc[p] > 1) {
         const int32_t q = H.stack[atomicSub(H.top, 1) - 1];
         H.rc[q] = 1;
         atomicSub(&H.rc[p], 1);
-        H.hmap[lh] = q;
+        H.hmap[lb] = q;
         s_new = q;
       }
     }
     __syncthreads();
     const int32_t po = s_old, pn = s_new;
     if (pn != po)
-      for (int w = threadIdx.x; w < W64; w += 256) G[(int64_t)pn * W64 + w] = G[(int64_t)po * W64 + w];
+      for (int x = threadIdx.x; x < H.BW; x += 256)
+        G[(int64_t)pn * H.BW + x] = G[(int64_t)po * H.BW + x];
     __syncthreads();
-    if (threadIdx.x == 0) {
-      const int l = locus[i];
-      G[(int64_t)pn * W64 + (l >> 6)] |= 1ull << (l & 63);
-    }
+    if (threadIdx.x == 0) G[(int64_t)pn * H.BW + (w - b * H.BW)] |= 1ull << (l & 63);
     __syncthreads();
   }
 }
@@ -594,12 +605,11 @@ int gnx_l_mutate(gnx_state* h, int n, const int64_t* d_slot, const int32_t* d_lo
   HIPCHK(hipMalloc((void**)&list, ((size_t)n + 1) * sizeof(int32_t)));
   int32_t* n_list = list + n;
   HIPCHK(hipMemsetAsync(n_list, 0, sizeof(int32_t), h->stream));
-  hipLaunchKernelGGL(k_mutate, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, n, h->W64,
-                     (u64*)h->G, h->soa[h->cur].grow, gnx_halves(h), d_slot, d_locus, d_hom, list,
-                     n_list);
+  hipLaunchKernelGGL(k_mutate, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, n, (u64*)h->G,
+                     h->soa[h->cur].grow, gnx_halves(h), d_slot, d_locus, d_hom, list, n_list);
   hipLaunchKernelGGL(k_mutate_shared, dim3(1), dim3(256), 0, h->stream, (const int32_t*)list,
-                     (const int32_t*)n_list, h->W64, (u64*)h->G, h->soa[h->cur].grow,
-                     gnx_halves(h), d_slot, d_locus, d_hom);
+                     (const int32_t*)n_list, (u64*)h->G, h->soa[h->cur].grow, gnx_halves(h),
+                     d_slot, d_locus, d_hom);
   HIPCHK(hipStreamSynchronize(h->stream));
   (void)hipFree(list);
   HIPCHK(hipGetLastError());
@@ -608,7 +618,7 @@ int gnx_l_mutate(gnx_state* h, int n, const int64_t* d_slot, const int32_t* d_lo
 
 // ---------------------------------------------------------------- genome gather
 __global__ void k_gather_genomes(int64_t n, int W16, const u64x2* G, const int32_t* grow,
-                                 const int32_t* hmap, const int64_t* slots, u64x2* out) {
+                                 GnxHalves H, const int64_t* slots, u64x2* out) {
   const int64_t total = n * 2 * (int64_t)W16;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
@@ -616,19 +626,19 @@ __global__ void k_gather_genomes(int64_t n, int W16, const u64x2* G, const int32
     int64_t c = g - k * 2 * W16;
     int64_t slot = slots ? slots[k] : k;
     const int hh = c >= W16 ? 1 : 0;
-    out[g] = G[(int64_t)hmap[(int64_t)grow[slot] * 2 + hh] * W16 + (c - hh * W16)];
+    out[g] = G[gnx_chunk_at(H, (int64_t)grow[slot] * 2 + hh, (int)(c - hh * W16))];
   }
 }
 
 __global__ void k_scatter_genomes(int64_t n, int W16, const u64x2* in, u64x2* G,
-                                  const int32_t* grow, const int32_t* hmap, int64_t first_slot) {
+                                  const int32_t* grow, GnxHalves H, int64_t first_slot) {
   const int64_t total = n * 2 * (int64_t)W16;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
     int64_t k = g / (2 * W16);
     int64_t c = g - k * 2 * W16;
     const int hh = c >= W16 ? 1 : 0;
-    G[(int64_t)hmap[(int64_t)grow[first_slot + k] * 2 + hh] * W16 + (c - hh * W16)] = in[g];
+    G[gnx_chunk_at(H, (int64_t)grow[first_slot + k] * 2 + hh, (int)(c - hh * W16))] = in[g];
   }
 }
 
@@ -638,7 +648,7 @@ int gnx_l_scatter_genomes(gnx_state* h, int64_t n, const uint64_t* d_in, int64_t
   const int W16 = h->W64 / 2;
   hipLaunchKernelGGL(k_scatter_genomes, dim3(gnx_grid(n * 2 * W16, 256, 256 * 32)), dim3(256), 0,
                      h->stream, n, W16, (const u64x2*)d_in, (u64x2*)h->G, h->soa[h->cur].grow,
-                     h->hmap, first_slot);
+                     gnx_halves(h), first_slot);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -648,17 +658,17 @@ int gnx_l_gather_genomes(gnx_state* h, int64_t n, const int64_t* d_slots, uint64
   GNXCHK(gnx_xo_join(h));
   const int W16 = h->W64 / 2;
   hipLaunchKernelGGL(k_gather_genomes, dim3(gnx_grid(n * 2 * W16, 256, 256 * 32)), dim3(256), 0,
-                     h->stream, n, W16, (const u64x2*)h->G, h->soa[h->cur].grow, h->hmap, d_slots,
-                     (u64x2*)d_out);
+                     h->stream, n, W16, (const u64x2*)h->G, h->soa[h->cur].grow, gnx_halves(h),
+                     d_slots, (u64x2*)d_out);
   HIPCHK(hipGetLastError());
   return 0;
 }
 
 // ---------------------------------------------------------------- half-row bookkeeping check
-// out[0] individuals with a logical row, out[1] broken references (no physical half, or
-// one nobody counts), out[2] sum of the reference counts, out[3] half-rows in use,
-// out[4] height of the free stack.  Consistent iff out[1] == 0, out[2] == 2 * out[0] and
-// out[3] + out[4] == 2 * cap_rows.
+// out[0] individuals with a logical row (x blocks per homologue), out[1] broken references
+// (no physical block, or one nobody counts), out[2] sum of the reference counts, out[3]
+// blocks in use, out[4] height of the free stack.  Consistent iff out[1] == 0,
+// out[2] == 2 * out[0] and out[3] + out[4] == 2 * NB * cap_rows.
 __global__ void k_half_check(int64_t N, const int32_t* grow, GnxHalves H, int64_t n_halves,
                              unsigned long long* out) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -667,8 +677,8 @@ __global__ void k_half_check(int64_t N, const int32_t* grow, GnxHalves H, int64_
     const int32_t row = grow[i];
     if (row < 0) continue;
     atomicAdd(&out[0], 1ull);
-    for (int hh = 0; hh < 2; ++hh) {
-      const int32_t p = H.hmap[(int64_t)row * 2 + hh];
+    for (int q = 0; q < 2 * H.NB; ++q) {
+      const int32_t p = H.hmap[(int64_t)row * 2 * H.NB + q];
       if (p < 0 || p >= n_halves || H.rc[p] <= 0) atomicAdd(&out[1], 1ull);
     }
   }
@@ -694,7 +704,7 @@ extern "C" int gnx_debug_halves(gnx_state* h, int64_t* out) {
   unsigned long long* d = nullptr;
   HIPCHK(hipMalloc((void**)&d, 5 * sizeof(unsigned long long)));
   HIPCHK(hipMemsetAsync(d, 0, 5 * sizeof(unsigned long long), h->stream));
-  const int64_t n_halves = (int64_t)h->cfg.cap_rows * h->row_spread * 2;
+  const int64_t n_halves = (int64_t)h->cfg.cap_rows * h->row_spread * 2 * h->NB;
   hipLaunchKernelGGL(k_half_check, dim3(1024), dim3(256), 0, h->stream, h->N, h->soa[h->cur].grow,
                      gnx_halves(h), n_halves, d);
   unsigned long long host[5];
@@ -702,6 +712,33 @@ extern "C" int gnx_debug_halves(gnx_state* h, int64_t* out) {
   (void)hipFree(d);
   GNXCHK(rc);
   for (int k = 0; k < 5; ++k) out[k] = (int64_t)host[k];
-  out[5] = 2 * h->cfg.cap_rows;
+  out[5] = 2 * h->cfg.cap_rows * h->NB;
+  out[0] *= h->NB;      // in units of blocks, like the other counts
+  return 0;
+}
+
+// ---------------------------------------------------------------- shared blocks
+// the blocks the job builders shared since the last flush get their new referrers counted
+__global__ void k_share_refs(const int32_t* __restrict__ share, int32_t* __restrict__ n_share,
+                             int32_t* __restrict__ rc, int32_t* __restrict__ done) {
+  const int n = *n_share;
+  const int stride = gridDim.x * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) atomicAdd(&rc[share[i]], 1);
+  // the last block out empties the list
+  __shared__ int last;
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(done, 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (last && threadIdx.x == 0) {
+    *n_share = 0;
+    *done = 0;
+  }
+}
+
+int gnx_share_flush(gnx_state* h, hipStream_t st) {
+  if (!h->half_share) return 0;
+  hipLaunchKernelGGL(k_share_refs, dim3(256), dim3(256), 0, st, (const int32_t*)h->half_share,
+                     h->half_n_share, h->half_rc, h->half_n_share + 1);
+  HIPCHK(hipGetLastError());
   return 0;
 }

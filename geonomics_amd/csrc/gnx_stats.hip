@@ -12,7 +12,7 @@ typedef unsigned long long u64;
 // blockIdx.y strides over the individuals.
 __global__ void __launch_bounds__(1024)
 k_locus_counts(int64_t N, int W64, int L, const u64* __restrict__ G,
-               const int32_t* __restrict__ grow, const int32_t* __restrict__ hmap,
+               const int32_t* __restrict__ grow, GnxHalves H,
                int32_t* __restrict__ cnt1, int32_t* __restrict__ cnt_het) {
   const int lane = threadIdx.x & 63;
   const int w = blockIdx.x * 16 + (threadIdx.x >> 6);
@@ -20,8 +20,8 @@ k_locus_counts(int64_t N, int W64, int L, const u64* __restrict__ G,
   int c1 = 0, ch = 0;
   for (int64_t i = blockIdx.y; i < N; i += gridDim.y) {
     const int64_t row = grow[i];
-    const u64 v0 = G[(int64_t)hmap[row * 2 + 0] * W64 + w];
-    const u64 v1 = G[(int64_t)hmap[row * 2 + 1] * W64 + w];
+    const u64 v0 = G[gnx_word_at(H, row * 2 + 0, w)];
+    const u64 v1 = G[gnx_word_at(H, row * 2 + 1, w)];
     const int a = (int)((v0 >> lane) & 1ull), b = (int)((v1 >> lane) & 1ull);
     c1 += a + b;
     ch += a ^ b;
@@ -49,7 +49,7 @@ extern "C" int gnx_stats_locus_counts(gnx_state* h, int32_t* cnt1, int32_t* cnt_
   if (N > 0) {
     int gy = (int)std::min<int64_t>(N, 256);
     hipLaunchKernelGGL(k_locus_counts, dim3((h->W64 + 15) / 16, gy), dim3(1024), 0, h->stream, N,
-                       h->W64, L, (const u64*)h->G, h->soa[h->cur].grow, h->hmap, d1, d2);
+                       h->W64, L, (const u64*)h->G, h->soa[h->cur].grow, gnx_halves(h), d1, d2);
   }
   int rc = gnx_d2h(h, cnt1, d1, L * sizeof(int32_t));
   if (!rc) rc = gnx_d2h(h, cnt_het, d2, L * sizeof(int32_t));
@@ -63,7 +63,7 @@ extern "C" int gnx_stats_locus_counts(gnx_state* h, int32_t* cnt1, int32_t* cnt_
 // (homologue index = 2 * individual + hom)
 __global__ void k_ld_transpose(int n_loci, int64_t n_hwords, int64_t N, int W64,
                                const int32_t* __restrict__ loci, const u64* __restrict__ G,
-                               const int32_t* __restrict__ grow, const int32_t* __restrict__ hmap,
+                               const int32_t* __restrict__ grow, GnxHalves H,
                                u64* __restrict__ T) {
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y;
@@ -74,7 +74,7 @@ __global__ void k_ld_transpose(int n_loci, int64_t n_hwords, int64_t N, int W64,
     const int64_t hidx = q * 64 + b;
     if (hidx >= 2 * N) break;
     const int64_t row = grow[hidx >> 1];
-    const u64 v = G[(int64_t)hmap[row * 2 + (hidx & 1)] * W64 + (l >> 6)];
+    const u64 v = G[gnx_word_at(H, row * 2 + (hidx & 1), l >> 6)];
     out |= ((v >> (l & 63)) & 1ull) << b;
   }
   T[(int64_t)j * n_hwords + q] = out;
@@ -152,7 +152,7 @@ extern "C" int gnx_stats_ld_counts(gnx_state* h, int32_t n_loci, const int32_t* 
   GNXCHK(gnx_h2d(h, d_loci, loci, n_loci * sizeof(int32_t)));
   hipLaunchKernelGGL(k_ld_transpose, dim3(gnx_grid(n_hwords, 128), n_loci), dim3(128), 0,
                      h->stream, n_loci, n_hwords, N, h->W64, d_loci, (const u64*)h->G,
-                     h->soa[h->cur].grow, h->hmap, T);
+                     h->soa[h->cur].grow, gnx_halves(h), T);
   hipLaunchKernelGGL(k_ld_counts, dim3(gnx_grid(n_loci, 128), n_loci), dim3(128), 0, h->stream,
                      n_loci, n_hwords, T, d_c, d_cc);
   int rc = gnx_d2h(h, c, d_c, (size_t)n_loci * 8);
@@ -191,7 +191,7 @@ extern "C" int gnx_stats_ld(gnx_state* h, int32_t n_loci, const int32_t* loci, d
   GNXCHK(gnx_h2d(h, d_loci, loci, n_loci * sizeof(int32_t)));
   hipLaunchKernelGGL(k_ld_transpose, dim3(gnx_grid(n_hwords, 128), n_loci), dim3(128), 0,
                      h->stream, n_loci, n_hwords, N, h->W64, d_loci, (const u64*)h->G,
-                     h->soa[h->cur].grow, h->hmap, T);
+                     h->soa[h->cur].grow, gnx_halves(h), T);
   hipLaunchKernelGGL(k_ld_pairs, dim3(gnx_grid(n_loci, 128), n_loci), dim3(128), 0, h->stream,
                      n_loci, n_hwords, (double)(2 * N), T, d_r2);
   int rc = gnx_d2h(h, r2, d_r2, (size_t)n_loci * n_loci * 8);

@@ -152,10 +152,9 @@ __global__ void k_unpack(int64_t N, int64_t n, int64_t cap, GnxSoA s, const gnx_
   s.fit[slot] = r.fit;
   s.ghost[slot] = (uint8_t)ghost;
   s.grow[slot] = (has_rows && !ghost) ? free_rows[n_free - 1 - k] : -1;
-  if (has_rows && !ghost) {      // (uniform over the launch) two half-rows for the genome
-    gnx_half_new(Hv, (int64_t)s.grow[slot] * 2, true);
-    gnx_half_new(Hv, (int64_t)s.grow[slot] * 2 + 1, true);
-  }
+  if (has_rows && !ghost)        // (uniform over the launch) blocks for the genome
+    for (int q = 0; q < 2 * Hv.NB; ++q)
+      gnx_half_new(Hv, (int64_t)s.grow[slot] * 2 * Hv.NB + q, true);
   for (int t = 0; t < n_traits; ++t)
     s.z[(int64_t)t * cap + slot] = zrec ? zrec[k * n_traits + t] : 0.f;
   int cx = (int)r.x, cy = (int)r.y;
@@ -441,7 +440,7 @@ __global__ void k_lookup(int64_t n, const int64_t* want, int64_t N, const uint64
 // (ops/mating.py:165-168), one wave per gamete, written to out[q][W16]
 __global__ void __launch_bounds__(256)
 k_make_gametes(int64_t n, int W16, const u64x2* __restrict__ G, const int32_t* __restrict__ grow,
-               const int32_t* __restrict__ hmap, const int32_t* __restrict__ slot, const int32_t* __restrict__ keys,
+               GnxHalves H, const int32_t* __restrict__ slot, const int32_t* __restrict__ keys,
                const uint8_t* __restrict__ starts, const u64x2* __restrict__ paths,
                u64x2* __restrict__ out) {
   const int lane = threadIdx.x & 63;
@@ -449,14 +448,13 @@ k_make_gametes(int64_t n, int W16, const u64x2* __restrict__ G, const int32_t* _
   if (q >= n) return;
   const int prow = grow[slot[q]];
   const u64 s = starts[q] ? ~0ull : 0ull;
-  const u64x2* h0 = G + (int64_t)hmap[(int64_t)prow * 2 + 0] * W16;
-  const u64x2* h1 = G + (int64_t)hmap[(int64_t)prow * 2 + 1] * W16;
+  const int64_t lh0 = (int64_t)prow * 2;
   const u64x2* pm = paths + (int64_t)keys[q] * W16;
   for (int c = lane; c < W16; c += 64) {
     u64x2 m = pm[c];
     m.a ^= s;
     m.b ^= s;
-    const u64x2 a = h0[c], b = h1[c];
+    const u64x2 a = G[gnx_chunk_at(H, lh0, c)], b = G[gnx_chunk_at(H, lh0 + 1, c)];
     u64x2 o;
     o.a = (a.a & ~m.a) | (b.a & m.a);
     o.b = (a.b & ~m.b) | (b.b & m.b);
@@ -509,7 +507,7 @@ extern "C" int gnx_tile_serve_gametes(gnx_state* h, int64_t n, const int64_t* pa
   } else {
     const int W16 = h->W64 / 2;
     hipLaunchKernelGGL(k_make_gametes, dim3(gnx_grid(n * 64, 256)), dim3(256), 0, h->stream, n, W16,
-                       (const u64x2*)h->G, s.grow, h->hmap, d_slot, d_keys, d_st, (const u64x2*)h->paths,
+                       (const u64x2*)h->G, s.grow, gnx_halves(h), d_slot, d_keys, d_st, (const u64x2*)h->paths,
                        (u64x2*)d_out);
     rc = gnx_d2h(h, out, d_out, (size_t)n * h->W64 * 8);
   }
@@ -520,14 +518,14 @@ extern "C" int gnx_tile_serve_gametes(gnx_state* h, int64_t n, const int64_t* pa
 }
 
 __global__ void k_put_gametes(int64_t n, int W16, const u64x2* in, u64x2* G, const int32_t* grow,
-                              const int32_t* hmap, int64_t first_slot, const int32_t* child_k) {
+                              GnxHalves H, int64_t first_slot, const int32_t* child_k) {
   const int64_t total = n * (int64_t)W16;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
     int64_t q = g / W16;
     int64_t c = g - q * W16;
     // the mate is pair[1] -> the child's homologue 1 (ops/mating.py:169)
-    G[(int64_t)hmap[(int64_t)grow[first_slot + child_k[q]] * 2 + 1] * W16 + c] = in[g];
+    G[gnx_chunk_at(H, (int64_t)grow[first_slot + child_k[q]] * 2 + 1, (int)c)] = in[g];
   }
 }
 
@@ -549,7 +547,7 @@ extern "C" int gnx_tile_put_gametes(gnx_state* h, int64_t n, const int32_t* chil
   const int W16 = h->W64 / 2;
   hipLaunchKernelGGL(k_put_gametes, dim3(gnx_grid(n * W16, 256, 256 * 32)), dim3(256), 0, h->stream,
                      n, W16, (const u64x2*)d_in, (u64x2*)h->G, h->soa[h->cur].grow,
-                     h->hmap, h->birth_first_slot, d_k);
+                     gnx_halves(h), h->birth_first_slot, d_k);
   HIPCHK(hipStreamSynchronize(h->stream));
   (void)hipFree(d_k);
   (void)hipFree(d_in);
@@ -1006,7 +1004,7 @@ __global__ void k_lookup_req(int64_t n, const gnx_gamete_req* req, int64_t N, in
 
 __global__ void __launch_bounds__(256)
 k_make_gametes_req(int64_t n, int W16, const u64x2* __restrict__ G,
-                   const int32_t* __restrict__ grow, const int32_t* __restrict__ hmap,
+                   const int32_t* __restrict__ grow, GnxHalves H,
                    const int32_t* __restrict__ slot, const gnx_gamete_req* __restrict__ req, const u64x2* __restrict__ paths,
                    u64x2* __restrict__ out) {
   const int lane = threadIdx.x & 63;
@@ -1015,14 +1013,13 @@ k_make_gametes_req(int64_t n, int W16, const u64x2* __restrict__ G,
   const int prow = grow[slot[q]];
   const gnx_gamete_req r = req[q];
   const u64 s = r.start ? ~0ull : 0ull;
-  const u64x2* h0 = G + (int64_t)hmap[(int64_t)prow * 2 + 0] * W16;
-  const u64x2* h1 = G + (int64_t)hmap[(int64_t)prow * 2 + 1] * W16;
+  const int64_t lh0 = (int64_t)prow * 2;
   const u64x2* pm = paths + (int64_t)r.key * W16;
   for (int c = lane; c < W16; c += 64) {
     u64x2 m = pm[c];
     m.a ^= s;
     m.b ^= s;
-    const u64x2 a = h0[c], b = h1[c];
+    const u64x2 a = G[gnx_chunk_at(H, lh0, c)], b = G[gnx_chunk_at(H, lh0 + 1, c)];
     u64x2 o;
     o.a = (a.a & ~m.a) | (b.a & m.a);
     o.b = (a.b & ~m.b) | (b.b & m.b);
@@ -1068,7 +1065,7 @@ extern "C" int gnx_tile_serve_gametes_dev(gnx_state* h, int64_t n, const void* r
   }
   const int W16 = h->W64 / 2;
   hipLaunchKernelGGL(k_make_gametes_req, dim3(gnx_grid(n * 64, 256)), dim3(256), 0, h->stream, n,
-                     W16, (const u64x2*)h->G, s.grow, h->hmap, h->gam_slot,
+                     W16, (const u64x2*)h->G, s.grow, gnx_halves(h), h->gam_slot,
                      (const gnx_gamete_req*)req_dev,
                      (const u64x2*)h->paths, (u64x2*)h->gam_out);
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -1089,7 +1086,7 @@ extern "C" int gnx_tile_put_gametes_dev(gnx_state* h, int64_t n, const void* dat
   const int W16 = h->W64 / 2;
   hipLaunchKernelGGL(k_put_gametes, dim3(gnx_grid(n * W16, 256, 256 * 32)), dim3(256), 0, h->stream,
                      n, W16, (const u64x2*)data_dev, (u64x2*)h->G, h->soa[h->cur].grow,
-                     h->hmap, h->birth_first_slot, h->rq_k);
+                     gnx_halves(h), h->birth_first_slot, h->rq_k);
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipGetLastError());
   return 0;

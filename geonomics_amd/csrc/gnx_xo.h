@@ -34,38 +34,50 @@ struct alignas(16) u64x2 {
 };
 
 struct alignas(16) GnxXoJob {
-  int32_t ph0, ph1;   // the parent's two physical half-rows (gnx_half.h)
-  int32_t dst;        // physical half-row the gamete is written to
-  int32_t ks;         // recombination path * 2 + start homologue
+  int32_t ph0, ph1;   // the parent's two physical blocks at this block index (gnx_half.h)
+  int32_t dst;        // physical block the gamete's block is written to
+  int32_t ks;         // (recombination path * 2 + start homologue) | block index << 24
 };
 
-// One gamete of a child that has logical row `row`: alias the parent's half-row when the
-// path has no switch point, else a fresh half-row and a crossover job.  A ghost parent
-// (prow < 0, tiled run: the gamete arrives from the tile that owns it) gets the fresh
-// half-row and no job.  Called by all lanes of a wave (act = this lane has a gamete).
+// One gamete of a child that has logical row `row`, block by block: a block without a
+// switch point refers to the parent's block (listed in H.share: its count is raised off the
+// critical path), a block with one gets a fresh physical block and a crossover job.  A
+// ghost parent (prow < 0, tiled run: the gamete arrives from the tile that owns it) and
+// dense masks (bp_off == null) get fresh blocks throughout, the former without jobs.
+// Called by all lanes of a wave (act = this lane has a gamete).
 __device__ __forceinline__ void gnx_xo_gamete(const GnxHalves& H, bool act, int32_t row, int p,
                                               int32_t prow, int key, int st,
                                               const int32_t* __restrict__ bp_off,
+                                              const int32_t* __restrict__ bp_loci,
                                               GnxXoJob* __restrict__ jobs,
                                               int32_t* __restrict__ n_jobs) {
-  const bool pure = act && prow >= 0 && bp_off && bp_off[key + 1] == bp_off[key];
-  const bool fresh = act && !pure;
-  const int64_t lh = (int64_t)row * 2 + p;
-  const int32_t dst = gnx_half_new(H, lh, fresh);
-  if (pure) {
-    const int32_t src = H.hmap[(int64_t)prow * 2 + st];
-    H.hmap[lh] = src;
-    atomicAdd(&H.rc[src], 1);
-  }
-  const bool job = fresh && prow >= 0;
-  const int32_t idx = gnx_wave_append(n_jobs, job);
-  if (job) {
-    GnxXoJob j;
-    j.ph0 = H.hmap[(int64_t)prow * 2];
-    j.ph1 = H.hmap[(int64_t)prow * 2 + 1];
-    j.dst = dst;
-    j.ks = key * 2 + st;
-    jobs[idx] = j;
+  const bool local = act && prow >= 0;
+  unsigned int mixed = ~0u, sel = 0u;
+  if (local && bp_off)
+    gnx_block_masks(bp_loci + bp_off[key], bp_off[key + 1] - bp_off[key], st, H.NB, H.BW, mixed,
+                    sel);
+  for (int b = 0; b < H.NB; ++b) {
+    const bool fresh = act && (((mixed >> b) & 1u) != 0u);
+    const bool shared = act && !fresh;
+    const int64_t lb = ((int64_t)row * 2 + p) * H.NB + b;
+    const int32_t dst = gnx_half_new(H, lb, fresh);
+    int32_t src = -1;
+    if (shared) {
+      src = H.hmap[((int64_t)prow * 2 + ((sel >> b) & 1u)) * H.NB + b];
+      H.hmap[lb] = src;
+    }
+    const int32_t si = gnx_wave_append(H.n_share, shared);
+    if (shared) H.share[si] = src;
+    const bool job = fresh && local;
+    const int32_t idx = gnx_wave_append(n_jobs, job);
+    if (job) {
+      GnxXoJob j;
+      j.ph0 = H.hmap[((int64_t)prow * 2) * H.NB + b];
+      j.ph1 = H.hmap[((int64_t)prow * 2 + 1) * H.NB + b];
+      j.dst = dst;
+      j.ks = (key * 2 + st) | (b << 24);
+      jobs[idx] = j;
+    }
   }
 }
 
@@ -139,9 +151,10 @@ k_xo_sparse(const int32_t* __restrict__ n_jobs_p, int W16, const u64x2* __restri
     const int ph1 = __builtin_amdgcn_readfirstlane(jb.ph1);
     const int dsth = __builtin_amdgcn_readfirstlane(jb.dst);
     const int ks = __builtin_amdgcn_readfirstlane(jb.ks);
-    const int key = ks >> 1;
+    const int key = (ks & 0xffffff) >> 1;
     const u64 s = (ks & 1) ? ~0ull : 0ull;
-    const u64x2* h0 = G + (int64_t)ph0 * W16;
+    const int cb = (ks >> 24) * W16;           // first chunk of this block in the homologue
+    const u64x2* h0 = G + (int64_t)ph0 * W16;  // (W16 = chunks per BLOCK)
     const u64x2* h1 = G + (int64_t)ph1 * W16;
     u64x2* dst = Gout + (int64_t)dsth * W16;
     const int bp0 = __builtin_amdgcn_readfirstlane(bp_off[key]);
@@ -156,7 +169,7 @@ k_xo_sparse(const int32_t* __restrict__ n_jobs_p, int W16, const u64x2* __restri
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int c = min(c0 + u * 64, W16 - 1);     // tail lanes re-read the last chunk
-        const u64x2 m = xo_mask_lanes(c, s, mybp, nbp);
+        const u64x2 m = xo_mask_lanes(cb + c, s, mybp, nbp);
         const bool one = (m.a & m.b) == ~0ull;
         mixed |= !one && (m.a | m.b) != 0ull;
         v[u] = xo_load<NT_LD>((one ? h1 : h0) + c);
@@ -165,7 +178,7 @@ k_xo_sparse(const int32_t* __restrict__ n_jobs_p, int W16, const u64x2* __restri
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int c = min(c0 + u * 64, W16 - 1);
-          const u64x2 m = xo_mask_lanes(c, s, mybp, nbp);
+          const u64x2 m = xo_mask_lanes(cb + c, s, mybp, nbp);
           if ((m.a & m.b) != ~0ull && (m.a | m.b) != 0ull) {
             const u64x2 b = h1[c];
             v[u].a = (v[u].a & ~m.a) | (b.a & m.a);
@@ -186,7 +199,7 @@ template <int U, bool NT_LD>
 __global__ void __launch_bounds__(256)
 k_xo_dense(const int32_t* __restrict__ n_jobs_p, int W16, const u64x2* __restrict__ G,
            u64x2* __restrict__ Gout, const GnxXoJob* __restrict__ jobs,
-           const u64x2* __restrict__ paths, int part_lo, int part_hi,
+           const u64x2* __restrict__ paths, int path_w16, int part_lo, int part_hi,
            unsigned long long* __restrict__ acc) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -203,14 +216,15 @@ k_xo_dense(const int32_t* __restrict__ n_jobs_p, int W16, const u64x2* __restric
     const int ph1 = __builtin_amdgcn_readfirstlane(jb.ph1);
     const int dsth = __builtin_amdgcn_readfirstlane(jb.dst);
     const int ks = __builtin_amdgcn_readfirstlane(jb.ks);
-    const int key = ks >> 1;
+    const int key = (ks & 0xffffff) >> 1;
     const u64 s = (ks & 1) ? ~0ull : 0ull;
-    const u64x2* h0 = G + (int64_t)ph0 * W16;
+    const int cb = (ks >> 24) * W16;           // first chunk of this block in the homologue
+    const u64x2* h0 = G + (int64_t)ph0 * W16;  // (W16 = chunks per BLOCK)
     const u64x2* h1 = G + (int64_t)ph1 * W16;
     u64x2* dst = Gout + (int64_t)dsth * W16;
     // the path table (n_recomb_sims x L/8 bytes) is re-read by every gamete that drew
     // the key: default cache policy, so it can stay in L2 / the Infinity Cache
-    const u64x2* pm = paths + (int64_t)key * W16;
+    const u64x2* pm = paths + (int64_t)key * path_w16 + cb;
     for (int c0 = lane; c0 < W16; c0 += 64 * U) {
       u64x2 m[U], a[U], b[U];
 #pragma unroll
@@ -237,6 +251,7 @@ k_xo_dense(const int32_t* __restrict__ n_jobs_p, int W16, const u64x2* __restric
 static inline int gnx_xo_pick_unroll(int W16) {
   const int T = (W16 + 63) / 64;
   int best = 8, waste = 1 << 30;
+  if (T <= 3) return T;                  // short blocks: exactly as many loads as chunks
   for (int U = 8; U >= 4; --U) {
     const int w = ((T + U - 1) / U) * U - T;
     if (w < waste) {

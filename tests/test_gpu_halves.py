@@ -1,9 +1,9 @@
-"""Shared genome half-rows (csrc/gnx_half.h): a gamete whose recombination path has no
-switch point is the parent's homologue bit for bit (ops/mating.py:165-167 with an all-0
-or all-1 subsetter), so the child refers to the parent's half-row instead of copying it.
-Nothing visible may depend on that: same genotypes as with every gamete copied, a
-mutation reaches the mutated individual only, and the reference counts add up.
-Needs an MI355X."""
+"""Shared genome blocks (csrc/gnx_half.h): where a gamete's recombination path has no
+switch point the gamete is the parent's homologue bit for bit (ops/mating.py:165-167: the
+subsetter is constant there), so the child refers to the parent's block instead of copying
+it.  Nothing visible may depend on that: same genotypes as with every gamete copied and
+with any number of blocks per homologue, a mutation reaches the mutated individual only,
+and the reference counts add up.  Needs an MI355X."""
 import numpy as np
 import pytest
 
@@ -12,10 +12,10 @@ from test_gpu_parity import make_dev, native
 
 pytestmark = pytest.mark.gpu
 
-L = 1200
+L = 1200          # 32 words per homologue = 2 lines of 128 bytes: 2 blocks by default
 
 
-def _model(seed=23, defer=True):
+def _model(seed=23, defer=True, L=L):
     nat = native()
     W = H = 40
     rasts = np.stack([np.ones((H, W)), np.tile(np.linspace(0, 1, W), (H, 1))]).astype(np.float32)
@@ -23,7 +23,7 @@ def _model(seed=23, defer=True):
                    mating_radius=3.0, K_factor=1.2, max_age=5)
     dev.set_defer_crossover(defer)
     rng = np.random.RandomState(5)
-    loci = np.sort(rng.choice(L, 30, replace=False))
+    loci = np.sort(rng.choice(min(L, 1200), 30, replace=False))
     dev.set_trait(0, loci, 0.05 * np.where(np.arange(30) % 2, -1.0, 1.0), 1, 0.3, 1.0, False)
     # one expected crossover per gamete: e^-1 of the 256 paths have no switch point
     paths = O.recomb_paths((rng.rand(256, L) < 1.0 / L).astype(np.uint8) * (np.arange(L) > 0))
@@ -104,3 +104,35 @@ def test_mutation_copies_a_shared_half_row_first():
         dev.step(False, True)
         _check(dev)
     dev.close()
+
+
+def test_blocks_per_homologue_do_not_change_genotypes(monkeypatch):
+    """L = 5000: 80 words = 5 lines per homologue: one block or five"""
+    monkeypatch.setenv('GNX_HALF_BLOCKS', '5')
+    a, nat = _model(L=5000)
+    monkeypatch.setenv('GNX_HALF_BLOCKS', '1')
+    b, _ = _model(L=5000)
+    monkeypatch.delenv('GNX_HALF_BLOCKS')
+    for t in range(10):
+        a.step(False, True)
+        b.step(False, True)
+        assert a.counts() == b.counts(), t
+        ra, ua = _check(a)
+        rb, ub = _check(b)
+        assert ra == 5 * rb                       # counted in blocks
+    assert 2 * ra - ua > 5 * (2 * rb - ub)        # finer blocks: more of them shared
+    ia, ga = _genotypes(a, nat)
+    ib, gb = _genotypes(b, nat)
+    np.testing.assert_array_equal(ia, ib)
+    np.testing.assert_array_equal(ga, gb)
+    # a mutation in each of the five blocks of somebody's homologue
+    slots = np.full(5, 7, np.int64)
+    loci = (np.arange(5) * 1024 + 3).astype(np.int32)
+    for dev in (a, b):
+        dev.mutate(slots, loci, np.zeros(5, np.uint8))
+        _check(dev)
+    ia, ga = _genotypes(a, nat)
+    ib, gb = _genotypes(b, nat)
+    np.testing.assert_array_equal(ga, gb)
+    a.close()
+    b.close()

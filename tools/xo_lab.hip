@@ -353,7 +353,7 @@ int main(int argc, char** argv) {
 #define DENSE(U, NT, BPC, KIND)                                                                   \
   add(std::string("xo_dense U=" #U " nt=" #NT " bpc=" #BPC " ") + kn[KIND], [=]() {              \
     hipLaunchKernelGGL((k_xo_dense<U, NT>), dim3(256 * BPC), dim3(256), 0, 0, d_njobs, W16, G, G,  \
-                       d_jobs[KIND], (const u64x2*)d_paths, 0, 1024, nullptr); }, dense_bytes)
+                       d_jobs[KIND], (const u64x2*)d_paths, W16, 0, 1024, nullptr); }, dense_bytes)
 #define COPYJ(U, NT, BPC, KIND)                                                                   \
   add(std::string("copy_jobs U=" #U " nt=" #NT " bpc=" #BPC " ") + kn[KIND], [=]() {             \
     hipLaunchKernelGGL((k_copy_jobs<U, NT>), dim3(256 * BPC), dim3(256), 0, 0, d_njobs, W16, G, G, \
