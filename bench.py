@@ -468,33 +468,37 @@ def main():
     total_ind_steps = float(ind_steps)      # tiled: already the global count
     max_elapsed = float(mx.item())
 
-    # the other way to share the GPU between the deferred crossover and the next step (a
-    # narrow crossover beside the WHOLE next step, gnx_set_crossover_overlap): reported
-    # next to the contract's numbers, measured the same way right after them
+    # the other ways to share the GPU between the deferred crossover and the next step
+    # (gnx_set_crossover_overlap), reported next to the contract's numbers and measured the
+    # same way right after them: 2 = nothing runs beside the crossover (the kernel's own
+    # rate), 1 = a narrow crossover beside the WHOLE next step
     alt = None
+    alone = None
     if stepper is None and not os.environ.get('GNX_BENCH_NO_ALT'):
-        dev.set_crossover_overlap(True)
-        for _ in range(5):
-            do_step(False)
-        dev.profiling(2)
-        dev.synchronize()
-        t1 = time.perf_counter()
-        n_alt = 0
-        k_alt = min(args.steps, 50)
-        for _ in range(k_alt):
-            n0, _b = do_step(False)
-            n_alt += n0
-        dev.synchronize()
-        dt = time.perf_counter() - t1
-        kx = dev.kernel_times()['crossover']
-        dev.profiling(False)
-        dev.set_crossover_overlap(False)
-        a_gbps = (kx['bytes'] / (kx['ms'] * 1e-3)) / 1e9 if kx['ms'] > 0 else 0.0
-        alt = {'mode': 'narrow crossover (2 workgroups per CU) beside the whole next step',
-               'value': n_alt / dt, 'ms_per_step': 1e3 * dt / k_alt, 'steps': k_alt,
-               'crossover_avg_launch_ms': kx['ms'] / max(kx['launches'], 1),
-               'crossover_achieved_GBps': a_gbps, 'crossover_frac': a_gbps / 8000.0}
-
+        def other_mode(mode, label):
+            dev.set_crossover_overlap(mode)
+            for _ in range(5):
+                do_step(False)
+            dev.profiling(2)
+            dev.synchronize()
+            t1 = time.perf_counter()
+            n_alt = 0
+            k_alt = min(args.steps, 50)
+            for _ in range(k_alt):
+                n0, _b = do_step(False)
+                n_alt += n0
+            dev.synchronize()
+            dt = time.perf_counter() - t1
+            kx = dev.kernel_times()['crossover']
+            dev.profiling(False)
+            dev.set_crossover_overlap(0)
+            a_gbps = (kx['bytes'] / (kx['ms'] * 1e-3)) / 1e9 if kx['ms'] > 0 else 0.0
+            return {'mode': label, 'value': n_alt / dt, 'ms_per_step': 1e3 * dt / k_alt,
+                    'steps': k_alt, 'crossover_avg_launch_ms': kx['ms'] / max(kx['launches'], 1),
+                    'crossover_achieved_GBps': a_gbps, 'crossover_frac': a_gbps / 8000.0}
+        alone = other_mode(2, 'nothing runs beside the crossover (compaction, reference counts '
+                              'and the next movement wait for it)')
+        alt = other_mode(1, 'narrow crossover (2 workgroups per CU) beside the whole next step')
     phases = None
     if stepper is not None:
         # per-phase host wall time of the tile protocol, from a few extra steps with a
@@ -567,13 +571,15 @@ def main():
                 'traffic_pmc': traffic_src,
                 'launches': xo['launches'],
                 'avg_launch_ms': xo['ms'] / max(xo['launches'], 1),
-                # gametes the kernel copied (counted on the device) x (L/2 bytes dense masks,
-                # L/4 sparse): the two gametes of every offspring that survives its first
-                # death draw, minus the gametes whose path has no switch point - those
-                # refer to the parent's half-row and move nothing (csrc/gnx_half.h)
+                # blocks the kernel copied (counted on the device) x 2 x block bytes (x 4 with
+                # dense masks): of the two gametes of every offspring that survives its first
+                # death draw, the blocks that hold a switch point - the others refer to the
+                # parent's block and move nothing (csrc/gnx_half.h)
                 'algorithmic_bytes_per_launch': xo['bytes'] / max(xo['launches'], 1),
-                'gametes_copied_per_launch': xo['bytes'] / max(xo['launches'], 1) / per_gamete,
-                'gametes_sharing_the_parents_half_row':
+                # in whole gametes (a gamete = one homologue of L/8 bytes read and written)
+                'gamete_equivalents_copied_per_launch':
+                    xo['bytes'] / max(xo['launches'], 1) / per_gamete,
+                'share_of_the_survivors_gametes_not_copied':
                     1.0 - (xo['bytes'] / per_gamete) / max(2.0 * xo_births, 1.0),
                 # also quote a device-to-device copy measured on this box
                 'measured_copy_GBps': copy_gbps,
@@ -586,6 +592,8 @@ def main():
         }
         if phases is not None:
             out['tile_phase_ms_per_step'] = phases
+        if alone is not None:
+            out['roofline']['kernel_alone'] = alone
         if alt is not None:
             out['whole_step_overlap'] = alt
         if world == 1 and not args.no_cpu_baseline:     # rank 0 at N = 1 only

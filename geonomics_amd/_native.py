@@ -292,10 +292,11 @@ class Device:
         """cut the offspring's genomes after the death draws, survivors only (default)"""
         self._chk(self.lib.gnx_set_defer_crossover(self.h, int(bool(on))))
 
-    def set_crossover_overlap(self, whole_step):
-        """False (default): the crossover keeps the chip, the next cell sort waits for it;
-        True: a narrow crossover runs beside the whole next step"""
-        self._chk(self.lib.gnx_set_crossover_overlap(self.h, int(bool(whole_step))))
+    def set_crossover_overlap(self, mode):
+        """0 / False (default): full-width crossover beside the compaction and the next
+        movement, the next cell sort waits for it; 1 / True: a narrow crossover beside the whole
+        next step; 2: nothing runs beside the crossover"""
+        self._chk(self.lib.gnx_set_crossover_overlap(self.h, int(mode)))
 
     def debug_halves(self):
         """(rows in use, broken references, sum of reference counts, half-rows in use, free

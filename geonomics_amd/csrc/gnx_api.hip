@@ -1038,9 +1038,11 @@ extern "C" int gnx_last_crossover_jobs(gnx_state* h, void* dst, int64_t max_jobs
   return 0;
 }
 
-extern "C" int gnx_set_crossover_overlap(gnx_state* h, int32_t whole_step) {
+extern "C" int gnx_set_crossover_overlap(gnx_state* h, int32_t mode) {
   GNXCHK(gnx_xo_join(h));
-  h->xo_sort_waits = whole_step == 0;
+  static const int wait_env = getenv("GNX_XO_WAIT") ? atoi(getenv("GNX_XO_WAIT")) : 1;
+  h->xo_sort_waits = mode != 1;
+  h->xo_wait_at = mode == 2 ? 2 : wait_env;      // 2: nothing else runs beside the crossover
   return 0;
 }
 

@@ -191,10 +191,11 @@ int gnx_counts(gnx_state* h, int64_t* N, int64_t* births, int64_t* deaths);
  * way (draws are keyed by id); any genome access in between triggers the off path.      */
 int gnx_set_defer_crossover(gnx_state* h, int32_t on);
 /* How the deferred crossover shares the GPU with the next step's kernels.  0 (default):
- * it runs at full width under the compaction and the next movement only, the next cell
- * sort waits for it - the crossover keeps its full rate.  1: a narrow crossover runs
- * beside the WHOLE next step - more individual-timesteps/s, a slower crossover.        */
-int gnx_set_crossover_overlap(gnx_state* h, int32_t whole_step);
+ * it runs at full width beside the compaction, the reference-count updates and the next
+ * movement; the next cell sort waits for it.  1: a narrow crossover runs beside the
+ * WHOLE next step.  2: nothing runs beside it (the kernel's own rate; a slower step).
+ * Results do not depend on the mode.                                                   */
+int gnx_set_crossover_overlap(gnx_state* h, int32_t mode);
 /* Split every deferred crossover launch: wide_per_1024 / 1024 of its jobs at full width
  * (the next cell sort waits for them), the rest as a narrow launch that shares the chip
  * with the sort and the kernels after it.  0 or 1024 = one launch.  Results do not depend
