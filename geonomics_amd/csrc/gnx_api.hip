@@ -7,6 +7,7 @@
 #include <chrono>
 #include "gnx_internal.h"
 #include "gnx_rng.h"
+#include "gnx_compact.h"
 
 // ---------------------------------------------------------------- errors
 static thread_local char g_err[1024] = "";
@@ -308,9 +309,6 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
     GNXCHK(dalloc(&h->half_n_share, 2));        // count, and the flush kernel's exit counter
     HIPCHK(hipMemset(h->half_n_share, 0, 2 * sizeof(int32_t)));
     GNXCHK(dalloc(&h->rel_cnt, 2));
-    HIPCHK(hipStreamCreate(&h->stream3));
-    HIPCHK(hipEventCreateWithFlags(&h->ev_compact, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&h->ev_release, hipEventDisableTiming));
     HIPCHK(hipMalloc((void**)&h->xo_jobs_acc, 2 * sizeof(unsigned long long)));
     HIPCHK(hipMemset(h->xo_jobs_acc, 0, 2 * sizeof(unsigned long long)));
     HIPCHK(hipMemset(h->hmap, 0xff, halves * sizeof(int32_t)));
@@ -323,6 +321,20 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
     GNXCHK(dalloc(&h->perm[k], cap));
   }
   GNXCHK(dalloc(&h->mate, cap));
+  for (int k = 0; k < 2; ++k) {
+    GNXCHK(dalloc(&h->ord[k], cap));
+    GNXCHK(dalloc(&h->keyk[k], cap));
+    GNXCHK(dalloc(&h->valk[k], cap));
+  }
+  GNXCHK(dalloc(&h->newslot, cap));
+  GNXCHK(dalloc(&h->cell32, cap));
+  GNXCHK(dalloc(&h->ord_cnt, cap / GNX_CB + 2));
+  GNXCHK(dalloc(&h->ord_off, cap / GNX_CB + 2));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_ord, hipEventDisableTiming));
+  HIPCHK(hipStreamCreate(&h->stream3));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_compact, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_release, hipEventDisableTiming));
+  if (getenv("GNX_ORD_SORT")) h->ord_mode = atoi(getenv("GNX_ORD_SORT")) != 0;
   GNXCHK(dalloc(&h->tag, cap));
   HIPCHK(hipMalloc(&h->cand, (size_t)cap * 16));
   GNXCHK(dalloc(&h->flag, cap + 1));
@@ -409,7 +421,7 @@ extern "C" void gnx_destroy(gnx_state* h) {
     (void)hipFree(h->perm[k]);
     (void)hipFree(h->counts_rast[k]);
   }
-  void* ptrs[] = {h->half_share, h->half_n_share, h->rel_cnt, h->hmap, h->half_rc, h->half_free, h->half_top, h->xo_jobs_acc, h->rast, h->G, h->free_rows, h->paths, h->bp_off, h->bp_loci, h->dom,
+  void* ptrs[] = {h->ord[0], h->ord[1], h->keyk[0], h->keyk[1], h->valk[0], h->valk[1], h->newslot, h->cell32, h->ord_cnt, h->ord_off, h->half_share, h->half_n_share, h->rel_cnt, h->hmap, h->half_rc, h->half_free, h->half_top, h->xo_jobs_acc, h->rast, h->G, h->free_rows, h->paths, h->bp_off, h->bp_loci, h->dom,
                   h->delet_loci, h->delet_s, h->cell_start, h->tag, h->cand, h->sort64_tmp, h->key64[0], h->key64[1], h->pairs2,
                   h->pair_goff, h->st_rec, h->st_z, h->st_geno, h->st_slots, h->req_pid, h->req_k, h->req_key, h->req_start, h->req_px, h->req_py,
                   h->req_count, h->sort_tmp, h->scan_tmp, h->mate,
@@ -435,6 +447,7 @@ extern "C" void gnx_destroy(gnx_state* h) {
     (void)hipStreamSynchronize(h->stream3);
     (void)hipStreamDestroy(h->stream3);
   }
+  if (h->ev_ord) (void)hipEventDestroy(h->ev_ord);
   if (h->ev_compact) (void)hipEventDestroy(h->ev_compact);
   if (h->ev_release) (void)hipEventDestroy(h->ev_release);
   delete h;
@@ -642,8 +655,16 @@ extern "C" int gnx_upload_population(gnx_state* h, int64_t N, const float* x, co
   HIPCHK(hipStreamSynchronize(st));
   h->N = N;
   int64_t mx = -1;
-  for (int64_t i = 0; i < N; ++i) mx = std::max(mx, id[i]);
+  bool asc = true;
+  for (int64_t i = 0; i < N; ++i) {
+    asc = asc && id[i] > mx;
+    mx = std::max(mx, id[i]);
+  }
   h->max_id = mx;
+  // ids ascending in slot order: the id-ordered index is the identity (ord_n = 0 explicit
+  // entries); otherwise the next cell sort rebuilds it
+  h->ord_valid = asc;
+  h->ord_n = 0;
   h->genomes_assigned = false;
   // environment values (Species._set_e at creation, structs/species.py:3318)
   GNXCHK(gnx_l_gather_e(h, 0, N));

@@ -287,6 +287,27 @@ struct gnx_state {
   int32_t* bins_P = nullptr;         // ... of pair midpoints
   bool bins_zeroed[2]{};             // [0] individuals, [1] pairs: already cleared by k_lattice
   bool nmax_zeroed = false;          // nmax_bits already cleared by k_lattice
+  // An index of the slots in ascending id order (ord[k] = slot of the k-th smallest id, k <
+  // ord_n; slots appended since - this step's offspring - follow in slot order).  With it the
+  // cell sort is a STABLE radix sort of that sequence by cell alone (2 passes instead of 4-5:
+  // the id never enters the keys) while the slots themselves stay in cell order.  Kept up to
+  // date by the permute kernel and by a compaction of its own behind the mortality
+  // compaction; lost by anything else that moves slots (uploads, tile imports) and rebuilt
+  // by one sort of (id, slot).
+  bool ord_mode = true;          // GNX_ORD_SORT=0: always sort by (cell, id)
+  bool ord_valid = false;
+  int64_t ord_n = 0;
+  int ord_cur = 0;
+  int32_t* ord[2]{};
+  int32_t* newslot = nullptr;    // [cap] where the last compaction put each slot (-1: dead)
+  uint32_t* cell32 = nullptr;    // [cap] hash cell of each slot (k_move / k_keys)
+  uint32_t* keyk[2]{};           // cells in id order / sorted
+  int32_t* valk[2]{};            // id ranks in id order / sorted
+  int32_t* ord_cnt = nullptr;    // block counts / offsets of the index's own compaction
+  int32_t* ord_off = nullptr;
+  hipEvent_t ev_ord = nullptr;
+  bool ord_inflight = false;     // the index's compaction runs on stream3
+  bool keys_ordmode = false;     // k_move wrote cell32, not key64
   bool keys_fresh = false;
   bool move_writes_keys = false;     // set around the movement of gnx_step           // k_move has written this step's sort keys
   int n_bin_blocks = 0;
@@ -444,7 +465,10 @@ int gnx_l_scatter_genomes(gnx_state* h, int64_t n, const uint64_t* d_in, int64_t
 // <= 3, -> exclusive block offsets off[...], totals to out[0..2] on the device and to
 // pinned host memory
 int gnx_block_scan(gnx_state* h, int K, int64_t n_items, const int32_t* cnt, int32_t* off,
-                   int32_t* out, int64_t* host, int64_t seq = 0);
+                   int32_t* out, int64_t* host, int64_t seq = 0, hipStream_t st = nullptr);
+int gnx_prim_sort32_bits(void* tmp, size_t bytes, const uint32_t* kin, uint32_t* kout,
+                         const int32_t* vin, int32_t* vout, size_t n, int end_bit,
+                         hipStream_t s, bool alone);
 // the host spins on pinned word h_pin[slot + 3] until the scan kernel given `seq` has
 // published its totals there (falls back to a stream sync after a while): no wait for the
 // kernels queued behind the scan, no driver wake-up latency

@@ -687,7 +687,7 @@ __global__ void __launch_bounds__(256)
 k_compact(int64_t N, int64_t cap, const int32_t* alive, const int32_t* dead_row,
           const int32_t* blk_off, int stride, const int32_t* cnts, GnxSoA a, GnxSoA b,
           int n_layers, int n_traits, int tbw, int32_t* free_rows, int64_t n_free, int has_rows,
-          int xo, int32_t* rel_cnt) {
+          int xo, int32_t* rel_cnt, int32_t* __restrict__ newslot) {
   __shared__ int lds[16];
   // k_release_halves reads its counts here (cnts is reused by the next step's scans)
   if (rel_cnt && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -712,6 +712,7 @@ k_compact(int64_t N, int64_t cap, const int32_t* alive, const int32_t* dead_row,
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t i = base + r * 256 + threadIdx.x;
+    if (newslot && i < N) newslot[i] = fa[r] ? oa + ra[r] : -1;   // for the id-ordered index
     if (fa[r]) {
       const int64_t k = oa + ra[r];            // survivors before i
       b.x[k] = a.x[i];
@@ -770,6 +771,48 @@ void gnx_launch_xo_jobs_surv(gnx_state* h, int64_t first_slot, const int32_t* d_
                      h->n_jobs_dev[buf]);
 }
 
+// The id-ordered index follows the compaction: entry k (slot ord[k], or slot k itself for the
+// entries appended since the last sort) stays iff its slot survived, and then names the
+// slot's new place.  Same three-launch compaction as the population's (gnx_compact.h), on
+// the side stream: nothing needs the index before the next cell sort.
+__global__ void __launch_bounds__(256)
+k_ord_flags(int64_t N, int64_t ord_n, const int32_t* __restrict__ ord,
+            const int32_t* __restrict__ newslot, int32_t* __restrict__ cnt) {
+  __shared__ int lds[16];
+  const int64_t base = (int64_t)blockIdx.x * GNX_CB;
+  bool f[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t k = base + r * 256 + threadIdx.x;
+    f[r] = k < N && newslot[k < ord_n ? ord[k] : k] >= 0;
+  }
+  int rank[4], tot;
+  gnx_block_ranks(f, rank, tot, lds);
+  if (threadIdx.x == 0) cnt[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(256)
+k_ord_write(int64_t N, int64_t ord_n, const int32_t* __restrict__ ord,
+            const int32_t* __restrict__ newslot, const int32_t* __restrict__ off,
+            int32_t* __restrict__ ord_new) {
+  __shared__ int lds[16];
+  const int64_t base = (int64_t)blockIdx.x * GNX_CB;
+  bool f[4];
+  int32_t ns[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t k = base + r * 256 + threadIdx.x;
+    ns[r] = k < N ? newslot[k < ord_n ? ord[k] : k] : -1;
+    f[r] = ns[r] >= 0;
+  }
+  int rank[4], tot;
+  gnx_block_ranks(f, rank, tot, lds);
+  const int32_t o = off[blockIdx.x];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (f[r]) ord_new[o + rank[r]] = ns[r];
+}
+
 int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_out) {
   int64_t N = h->N;
   *deaths_out = 0;
@@ -779,6 +822,7 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
   const int nb = (int)((N + GNX_CB - 1) / GNX_CB);
   const bool xo = h->xo_deferred;
   const int64_t xo_first = h->xo_first, xo_B = xo ? h->xo_B : 0;
+  const bool ord_keep = h->ord_mode && h->ord_valid && !h->tiled;   // the id-ordered index follows
   // the job buffer the deferred crossover is about to fill: nobody reads it any more,
   // and its counter starts at zero
   int32_t* zero_jobs = nullptr;
@@ -806,9 +850,24 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
   hipLaunchKernelGGL(k_compact, dim3(nb), dim3(256), 0, h->stream, N, c.cap_inds, h->flag,
                      h->flag2, h->blk_off, h->blk_stride, h->cnt_dev, a, b, c.n_layers, c.n_traits,
                      a.tb ? 2 * h->TW : 0, h->free_rows, h->n_free, has_rows, xo ? 1 : 0,
-                     h->rel_cnt);
+                     h->rel_cnt, ord_keep ? h->newslot : nullptr);
   gnx_time_end(h, GNX_K_COMPACT, (double)N * (24.0 + 2.0 * (34.0 + 4.0 * c.n_layers +
                                                              4.0 * c.n_traits + 16.0 * h->TW)));
+  if (ord_keep) {
+    HIPCHK(hipEventRecord(h->ev_compact, h->stream));
+    HIPCHK(hipStreamWaitEvent(h->stream3, h->ev_compact, 0));
+    if (h->ord_inflight) h->ord_inflight = false;       // (stream3 runs them in order)
+    hipLaunchKernelGGL(k_ord_flags, dim3(nb), dim3(256), 0, h->stream3, N, h->ord_n,
+                       h->ord[h->ord_cur], h->newslot, h->ord_cnt);
+    GNXCHK(gnx_block_scan(h, 1, N, h->ord_cnt, h->ord_off, nullptr, nullptr, 0, h->stream3));
+    hipLaunchKernelGGL(k_ord_write, dim3(nb), dim3(256), 0, h->stream3, N, h->ord_n,
+                       h->ord[h->ord_cur], h->newslot, h->ord_off, h->ord[h->ord_cur ^ 1]);
+    HIPCHK(hipEventRecord(h->ev_ord, h->stream3));
+    h->ord_inflight = true;
+    h->ord_cur ^= 1;
+  } else {
+    h->ord_valid = false;
+  }
   if (has_rows) {
     // the dead's half-rows are released off the critical path
     hipStream_t st = h->stream3 ? h->stream3 : h->stream;
@@ -847,6 +906,7 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
   h->N = survivors;
   h->n_ghost = 0;
   h->cur ^= 1;
+  if (ord_keep) h->ord_n = survivors;
   return 0;
 }
 

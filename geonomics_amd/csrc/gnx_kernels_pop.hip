@@ -13,6 +13,10 @@ static int gnx_id_bits(const gnx_state* h) {
   while (b < 40 && (h->max_id >> b) != 0) ++b;
   return b;
 }
+// the coming cell sort can run over the id-ordered index with the cell as its only key
+static bool gnx_ord_sort(const gnx_state* h) {
+  return h->ord_mode && h->ord_valid && !h->tiled;
+}
 
 __device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
@@ -83,6 +87,8 @@ int gnx_l_init_population(gnx_state* h, int64_t N) {
   HIPCHK(hipGetLastError());
   h->N = N;
   h->max_id = N - 1;
+  h->ord_valid = true;            // ids 0 .. N-1 in slot order: the index is the identity
+  h->ord_n = 0;
   return 0;
 }
 
@@ -118,6 +124,7 @@ struct MoveP {
   int32_t* idx;
   double inv_cs;
   int ncx, ncy, idbits;
+  uint32_t* cell32;
 };
 
 __constant__ float c_queen_dirs[8] = {-2.35619449019234492885f, -1.57079632679489661923f,
@@ -285,11 +292,15 @@ k_move(MoveP P, GnxSoA s, const float* rast, const float* inj_theta, const float
   int cx = (int)nx, cy = (int)ny;
   for (int l = 0; l < P.n_layers; ++l)
     s.e[(int64_t)l * P.cap + i] = rast[((int64_t)l * P.H + cy) * P.W + cx];
-  if (P.key) {
+  if (P.key || P.cell32) {
     const int hx = min(P.ncx - 1, (int)((double)nx * P.inv_cs));
     const int hy = min(P.ncy - 1, (int)((double)ny * P.inv_cs));
-    P.key[i] = ((uint64_t)(hy * P.ncx + hx) << P.idbits) | (uint64_t)id;
-    P.idx[i] = (int32_t)i;
+    if (P.cell32) {               // the sort runs over the id-ordered index: the cell is all it needs
+      P.cell32[i] = (uint32_t)(hy * P.ncx + hx);
+    } else {
+      P.key[i] = ((uint64_t)(hy * P.ncx + hx) << P.idbits) | (uint64_t)id;
+      P.idx[i] = (int32_t)i;
+    }
   }
 }
 
@@ -322,13 +333,16 @@ int gnx_l_move(gnx_state* h, bool inc_age, const float* inj_theta, const float* 
   P.seed = c.seed;
   // inside gnx_step the cell sort comes next: write its keys here (k_keys otherwise)
   const bool with_keys = h->move_writes_keys && apply && !inj_theta;
-  P.key = with_keys ? h->key64[0] : nullptr;
+  const bool ordm = with_keys && gnx_ord_sort(h);
+  P.key = (with_keys && !ordm) ? h->key64[0] : nullptr;
+  P.cell32 = ordm ? h->cell32 : nullptr;
   P.idx = h->perm[0];
   P.inv_cs = h->inv_cs;
   P.ncx = h->ncx;
   P.ncy = h->ncy;
   P.idbits = gnx_id_bits(h);
   h->keys_fresh = with_keys;
+  if (with_keys) h->keys_ordmode = ordm;
   gnx_time_begin(h);
   hipLaunchKernelGGL(k_move, dim3(gnx_grid(h->N, 256)), dim3(256), 0, h->stream, P,
                      h->soa[h->cur], h->rast, inj_theta, inj_dist, out_theta, out_dist);
@@ -363,25 +377,36 @@ __global__ void k_keys(int64_t N, const float* x, const float* y, const int64_t*
 
 __global__ void k_permute(int64_t N, int64_t cap, const int32_t* perm, GnxSoA a, GnxSoA b,
                           int n_layers, int n_traits, int tbw, unsigned long long pair_seed,
-                          uint32_t* tag, uint4* cand, const uint64_t* key, int idbits,
-                          int32_t* cell_start, int ncells) {
+                          uint32_t* tag, uint4* cand, uint64_t* key, int idbits,
+                          int32_t* cell_start, int ncells, const uint32_t* __restrict__ cellk,
+                          const int32_t* __restrict__ ord, int64_t ord_n,
+                          int32_t* __restrict__ ord_new, int32_t* __restrict__ perm_out) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
+  // sorted (cell << idbits | id) keys with the slots as values, or - the sort ran over the
+  // id-ordered index - sorted cells (cellk) with id ranks as values
   {
     // cell_start[c] = first sorted slot whose cell >= c; cell_start[ncells] = N
-    const int k = (int)(key[i] >> idbits);
-    const int prev = (i == 0) ? -1 : (int)(key[i - 1] >> idbits);
+    const int k = cellk ? (int)cellk[i] : (int)(key[i] >> idbits);
+    const int prev = (i == 0) ? -1 : (cellk ? (int)cellk[i - 1] : (int)(key[i - 1] >> idbits));
     for (int c = prev + 1; c <= k; ++c) cell_start[c] = (int32_t)i;
     if (i == N - 1)
       for (int c = k + 1; c <= ncells; ++c) cell_start[c] = (int32_t)N;
   }
   int64_t j = perm[i];
+  if (cellk) {
+    const int64_t kk = j;                       // id rank
+    j = kk < ord_n ? ord[kk] : kk;              // the slot it was in
+    ord_new[kk] = (int32_t)i;                   // and the slot it is in now
+    perm_out[i] = (int32_t)j;                   // (the sort permutation, as the other path leaves it)
+  }
   b.x[i] = a.x[j];
   b.y[i] = a.y[j];
   b.age[i] = a.age[j];
   b.sex[i] = a.sex[j];
   const int64_t idv = a.id[j];
   b.id[i] = idv;
+  if (cellk) key[i] = ((uint64_t)cellk[i] << idbits) | (uint64_t)idv;   // what the pair list reads
   const uint32_t tg = gnx_ind_tag(pair_seed, (unsigned long long)idv);
   tag[i] = tg;
   // packed candidate record for the mate search: one 16-byte load per candidate
@@ -394,6 +419,29 @@ __global__ void k_permute(int64_t N, int64_t cap, const int32_t* perm, GnxSoA a,
   for (int w = 0; w < tbw; ++w) b.tb[i * tbw + w] = a.tb[j * tbw + w];     // tbw = 2 * TW
 }
 
+__global__ void k_cells(int64_t N, const float* x, const float* y, double inv_cs, int ncx, int ncy,
+                        uint32_t* cell32) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) cell32[i] = (uint32_t)gnx_cell_of(x[i], y[i], inv_cs, ncx, ncy);
+}
+
+// keys of the id-ordered sequence: entry k is slot ord[k] (k < ord_n), or slot k itself
+// (appended since the index was last compacted: offspring, ascending ids)
+__global__ void k_keys_ord(int64_t N, int64_t ord_n, const int32_t* __restrict__ ord,
+                           const uint32_t* __restrict__ cell32, uint32_t* __restrict__ key,
+                           int32_t* __restrict__ val) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= N) return;
+  const int64_t slot = k < ord_n ? ord[k] : k;
+  key[k] = cell32[slot];
+  val[k] = (int32_t)k;
+}
+
+__global__ void k_iota(int64_t N, int32_t* v) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) v[i] = (int32_t)i;
+}
+
 // Sort of the whole SoA by (hash cell, id); cell size >= mating radius.
 int gnx_l_sort_by_cell(gnx_state* h) {
   int64_t N = h->N;
@@ -403,22 +451,60 @@ int gnx_l_sort_by_cell(gnx_state* h) {
   const gnx_config& c = h->cfg;
   GnxSoA a = h->soa[h->cur], b = h->soa[h->cur ^ 1];
   const int idbits = gnx_id_bits(h);
+  const bool alone = h->xo_sort_waits || !h->xo_running;
+  const bool ordm = h->keys_fresh ? h->keys_ordmode : gnx_ord_sort(h);
   gnx_time_begin(h);
-  if (!h->keys_fresh)
-    hipLaunchKernelGGL(k_keys, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, a.x, a.y, a.id,
-                       h->inv_cs, h->ncx, h->ncy, idbits, h->key64[0], h->perm[0]);
+  if (ordm) {
+    // stable sort of the id-ordered index by cell alone (gnx_internal.h)
+    if (!h->keys_fresh)
+      hipLaunchKernelGGL(k_cells, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, a.x, a.y,
+                         h->inv_cs, h->ncx, h->ncy, h->cell32);
+    if (h->ord_inflight) {        // the index's own compaction (stream3) has finished
+      HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ord, 0));
+      h->ord_inflight = false;
+    }
+    hipLaunchKernelGGL(k_keys_ord, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, h->ord_n,
+                       h->ord[h->ord_cur], h->cell32, h->keyk[0], h->valk[0]);
+    GNXCHK(gnx_prim_sort32_bits(h->sort64_tmp, h->sort64_tmp_bytes, h->keyk[0], h->keyk[1],
+                                h->valk[0], h->valk[1], (size_t)N, h->key_bits, h->stream, alone));
+  } else {
+    if (!h->keys_fresh)
+      hipLaunchKernelGGL(k_keys, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, a.x, a.y, a.id,
+                         h->inv_cs, h->ncx, h->ncy, idbits, h->key64[0], h->perm[0]);
+    GNXCHK(gnx_prim_sort64_bits(h->sort64_tmp, h->sort64_tmp_bytes, h->key64[0], h->key64[1],
+                                h->perm[0], h->perm[1], (size_t)N, idbits + h->key_bits,
+                                h->stream, alone));
+  }
   h->keys_fresh = false;
-  GNXCHK(gnx_prim_sort64_bits(h->sort64_tmp, h->sort64_tmp_bytes, h->key64[0], h->key64[1],
-                              h->perm[0], h->perm[1], (size_t)N, idbits + h->key_bits,
-                              h->stream, h->xo_sort_waits || !h->xo_running));
   gnx_time_end(h, GNX_K_SORT, (double)N * 40.0);
   gnx_time_begin(h);
   hipLaunchKernelGGL(k_permute, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, c.cap_inds,
-                     h->perm[1], a, b, c.n_layers, c.n_traits, a.tb ? 2 * h->TW : 0,
-                     gnx_pair_seed(c.seed, h->step), h->tag, (uint4*)h->cand, h->key64[1], idbits,
-                     h->cell_start, h->ncx * h->ncy);
+                     ordm ? h->valk[1] : h->perm[1], a, b, c.n_layers, c.n_traits,
+                     a.tb ? 2 * h->TW : 0, gnx_pair_seed(c.seed, h->step), h->tag, (uint4*)h->cand,
+                     h->key64[1], idbits, h->cell_start, h->ncx * h->ncy,
+                     ordm ? h->keyk[1] : nullptr, h->ord[h->ord_cur], h->ord_n,
+                     h->ord[h->ord_cur ^ 1], h->perm[1]);
   gnx_time_end(h, GNX_K_PERMUTE,
                (double)N * 2.0 * (33.0 + 4.0 * c.n_layers + 4.0 * c.n_traits + 16.0 * h->TW));
+  if (ordm) {
+    h->ord_cur ^= 1;
+    h->ord_n = N;
+  } else if (h->ord_mode && !h->tiled) {
+    // no index (an upload in another order, a tile that became a single device): one sort of
+    // (id, sorted slot) rebuilds it
+    if (h->ord_inflight) {
+      HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ord, 0));
+      h->ord_inflight = false;
+    }
+    hipLaunchKernelGGL(k_iota, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, h->perm[0]);
+    GNXCHK(gnx_prim_sort64_bits(h->sort64_tmp, h->sort64_tmp_bytes, (const uint64_t*)b.id,
+                                h->key64[0], h->perm[0], h->ord[h->ord_cur], (size_t)N, idbits,
+                                h->stream, alone));
+    h->ord_valid = true;
+    h->ord_n = N;
+  } else {
+    h->ord_valid = false;         // the slots moved and nobody followed them
+  }
   HIPCHK(hipGetLastError());
   h->cur ^= 1;
   if (h->xo_launch_policy == 1) GNXCHK(gnx_xo_launch_pending(h));

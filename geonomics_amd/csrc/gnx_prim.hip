@@ -60,6 +60,15 @@ int gnx_prim_sort64_bytes(size_t n, size_t* bytes) {
                                                            (uint64_t*)nullptr, (const int32_t*)nullptr,
                                                            (int32_t*)nullptr, n, 0, 64, (hipStream_t)0));
   if (b10 > *bytes) *bytes = b10;
+  size_t b32 = 0;
+  HIPCHK(rocprim::radix_sort_pairs<gnx_sort_config10>(nullptr, b32, (const uint32_t*)nullptr,
+                                                      (uint32_t*)nullptr, (const int32_t*)nullptr,
+                                                      (int32_t*)nullptr, n, 0, 32, (hipStream_t)0));
+  if (b32 > *bytes) *bytes = b32;
+  HIPCHK(rocprim::radix_sort_pairs<gnx_sort_config>(nullptr, b32, (const uint32_t*)nullptr,
+                                                    (uint32_t*)nullptr, (const int32_t*)nullptr,
+                                                    (int32_t*)nullptr, n, 0, 32, (hipStream_t)0));
+  if (b32 > *bytes) *bytes = b32;
   return 0;
 }
 
@@ -78,6 +87,21 @@ int gnx_prim_sort64_bits(void* tmp, size_t bytes, const uint64_t* kin, uint64_t*
   // 0.154 / 0.151 / 0.167).  Beside a crossover (whole-step overlap) its 1024-thread blocks
   // wait longer for a CU than the default's and the step loses 5-9 %: default digits there.
   // GNX_SORT_BITS=8 / 10 forces one or the other.
+  static const int forced = getenv("GNX_SORT_BITS") ? atoi(getenv("GNX_SORT_BITS")) : 0;
+  const int digit = forced ? forced : (alone ? 10 : 8);
+  if (digit == 10)
+    HIPCHK(rocprim::radix_sort_pairs<gnx_sort_config10>(tmp, bytes, kin, kout, vin, vout, n, 0,
+                                                        end_bit, s));
+  else
+    HIPCHK(rocprim::radix_sort_pairs<gnx_sort_config>(tmp, bytes, kin, kout, vin, vout, n, 0,
+                                                      end_bit, s));
+  return 0;
+}
+
+// 32-bit keys (hash cells of the id-ordered index), same digit choice
+int gnx_prim_sort32_bits(void* tmp, size_t bytes, const uint32_t* kin, uint32_t* kout,
+                         const int32_t* vin, int32_t* vout, size_t n, int end_bit,
+                         hipStream_t s, bool alone) {
   static const int forced = getenv("GNX_SORT_BITS") ? atoi(getenv("GNX_SORT_BITS")) : 0;
   const int digit = forced ? forced : (alone ? 10 : 8);
   if (digit == 10)
@@ -138,9 +162,9 @@ k_block_scan(int K, int nb, int stride, const int32_t* __restrict__ cnt, int32_t
 }
 
 int gnx_block_scan(gnx_state* h, int K, int64_t n_items, const int32_t* cnt, int32_t* off,
-                   int32_t* out, int64_t* host, int64_t seq) {
+                   int32_t* out, int64_t* host, int64_t seq, hipStream_t st) {
   const int nb = (int)((n_items + GNX_CB - 1) / GNX_CB);
-  hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, h->stream, K, nb, h->blk_stride, cnt, off,
+  hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, st ? st : h->stream, K, nb, h->blk_stride, cnt, off,
                      out, host, (long long)seq);
   HIPCHK(hipGetLastError());
   return 0;

@@ -302,6 +302,7 @@ static int import_common(gnx_state* h, int64_t n, const gnx_ind_rec* rec, const 
   (void)hipFree(d_z);
   (void)hipFree(d_g);
   h->N += n;
+  h->ord_valid = false;          // arrivals carry any id: no id-ordered index
   if (ghost) h->n_ghost += n;
   for (int64_t k = 0; k < n; ++k) h->max_id = std::max<int64_t>(h->max_id, rec[k].id);
   HIPCHK(hipGetLastError());
@@ -889,6 +890,7 @@ static int import_device(gnx_state* h, int64_t n, const gnx_ind_rec* d_rec, cons
   // the source buffers belong to the caller: finish reading them before returning
   HIPCHK(hipStreamSynchronize(h->stream));
   h->N += n;
+  h->ord_valid = false;          // arrivals carry any id: no id-ordered index
   if (ghost) h->n_ghost += n;
   h->max_id = std::max(h->max_id, res[1]);
   HIPCHK(hipGetLastError());
