@@ -314,13 +314,9 @@ __global__ void __launch_bounds__(256)
 k_nmax(SplineC S, int W, int H, unsigned long long* out_bits) {
   __shared__ double red[256];
   double m = 0.0;
-  const int64_t total = (int64_t)W * H;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += stride) {
-    int cy = (int)(c / W), cx = (int)(c - (int64_t)cy * W);
-    double v = spline_eval(S, cx + 0.5, cy + 0.5);
-    m = fmax(m, v);
-  }
+  // rows strided over the blocks, columns over the threads: no index division per cell
+  for (int cy = blockIdx.x; cy < H; cy += gridDim.x)
+    for (int cx = threadIdx.x; cx < W; cx += 256) m = fmax(m, spline_eval(S, cx + 0.5, cy + 0.5));
   red[threadIdx.x] = m;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
@@ -452,7 +448,9 @@ k_death_probs(DeathP Q, DemP P, SplineC SN, SplineC SP, GnxSoA s, const float* r
         if (T.univ_adv[t]) e = 1.0;                    // e ** 0
         double z = (double)s.z[(int64_t)t * Q.cap + i];
         double phi = T.phi_rast[t] ? (double)T.phi_rast[t][(int64_t)cy * P.W + cx] : T.phi[t];
-        w *= 1.0 - phi * pow(fabs(e - z), T.gamma[t]);
+        // (gamma = 1, the parameters-file default: x ** 1 is x, without the library call)
+        const double dz = fabs(e - z);
+        w *= 1.0 - phi * (T.gamma[t] == 1.0 ? dz : pow(dz, T.gamma[t]));
       }
       w = fmax(w, 0.001);
     }
@@ -482,7 +480,8 @@ int gnx_l_death_probs(gnx_state* h, bool with_selection) {
   if (!h->nmax_zeroed)
     HIPCHK(hipMemsetAsync(h->nmax_bits, 0, sizeof(unsigned long long), h->stream));
   h->nmax_zeroed = false;
-  hipLaunchKernelGGL(k_nmax, dim3(gnx_grid(cells, 256, 2048)), dim3(256), 0, h->stream, SN,
+  (void)cells;
+  hipLaunchKernelGGL(k_nmax, dim3(std::min(h->cfg.H, 2048)), dim3(256), 0, h->stream, SN,
                      h->cfg.W, h->cfg.H, h->nmax_bits);
   DeathP Q;
   Q.N = N;
