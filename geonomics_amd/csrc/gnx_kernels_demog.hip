@@ -481,7 +481,8 @@ int gnx_l_death_probs(gnx_state* h, bool with_selection) {
     HIPCHK(hipMemsetAsync(h->nmax_bits, 0, sizeof(unsigned long long), h->stream));
   h->nmax_zeroed = false;
   (void)cells;
-  hipLaunchKernelGGL(k_nmax, dim3(std::min(h->cfg.H, 2048)), dim3(256), 0, h->stream, SN,
+  static const int nmax_blocks = getenv("GNX_NMAX_BLOCKS") ? atoi(getenv("GNX_NMAX_BLOCKS")) : 512;
+  hipLaunchKernelGGL(k_nmax, dim3(std::min(h->cfg.H, nmax_blocks)), dim3(256), 0, h->stream, SN,
                      h->cfg.W, h->cfg.H, h->nmax_bits);
   DeathP Q;
   Q.N = N;
