@@ -299,8 +299,8 @@ class Device:
         self._chk(self.lib.gnx_set_crossover_overlap(self.h, int(mode)))
 
     def debug_halves(self):
-        """(rows in use, broken references, sum of reference counts, half-rows in use, free
-        half-rows, half-rows in all) of the shared genome half-rows"""
+        """(logical blocks in use / 2, broken references, sum of reference counts, physical
+        blocks in use, free blocks, blocks in all) of the shared genome blocks"""
         out = np.zeros(6, np.int64)
         self._chk(self.lib.gnx_debug_halves(self.h, _ptr(out, C.c_int64)))
         return out
@@ -311,7 +311,8 @@ class Device:
         self._chk(self.lib.gnx_set_crossover_split(self.h, int(wide_per_1024)))
 
     def last_crossover_jobs(self):
-        """int32 [n, 4]: parent row, child half-row, path key, start homologue"""
+        """int32 [n, 4]: the parent's two physical blocks, the block written,
+        (path * 2 + start homologue) | block index << 24"""
         n = C.c_int64()
         self._chk(self.lib.gnx_last_crossover_jobs(self.h, None, 0, C.byref(n)))
         out = np.zeros((n.value, 4), np.int32)

@@ -128,7 +128,7 @@ struct gnx_state {
   int row_spread = 1;
   int32_t* free_rows = nullptr;
   int64_t n_free = 0;
-  // physical half-rows (gnx_half.h): hmap / half_rc over 2 * cap_rows * row_spread halves,
+  // physical blocks (gnx_half.h): hmap / half_rc over 2 * cap_rows * row_spread * NB blocks,
   // the stack of free ones and its height on the device
   int32_t* hmap = nullptr;
   int32_t* half_rc = nullptr;
@@ -137,11 +137,11 @@ struct gnx_state {
   int32_t* half_share = nullptr;       // blocks shared by the builders since the last flush
   int32_t* half_n_share = nullptr;
   int NB = 1;                          // blocks per homologue (gnx_half.h), BW = W64 / NB words
-  hipStream_t stream3 = nullptr;       // releases of the dead's half-rows
+  hipStream_t stream3 = nullptr;       // reference counts of the genome blocks, the sort index
   hipEvent_t ev_compact = nullptr, ev_release = nullptr;
   bool release_inflight = false;
   int32_t* rel_cnt = nullptr;          // [2] rows freed / rows popped by the last compaction
-  bool alias_xo = true;          // gametes without a switch point share the parent's half-row
+  bool alias_xo = true;          // blocks without a switch point are shared with the parent
   unsigned long long* xo_jobs_acc = nullptr;   // [2] gametes copied by the (wide, tail) launches
   bool genomes_assigned = false;
 
@@ -354,7 +354,7 @@ static inline GnxHalves gnx_halves(const gnx_state* h) {
 }
 // the shared blocks listed by the builders get their counts raised (on `st`), list emptied
 int gnx_share_flush(gnx_state* h, hipStream_t st);
-// before anything that pops half-rows: the last release of the dead's half-rows has
+// before anything that pops blocks: the last release of the dead's blocks has
 // finished (it runs on a stream of its own)
 static inline int gnx_halves_ready(gnx_state* h) {
   if (h->release_inflight) {
@@ -366,7 +366,7 @@ static inline int gnx_halves_ready(gnx_state* h) {
   }
   return 0;
 }
-// breakpoint offsets when gametes without a switch point may share the parent's half-row
+// breakpoint offsets when blocks without a switch point may be shared with the parent
 // (sparse paths only: the dense path table is not scanned for all-zero masks), else null
 static inline const int32_t* gnx_alias_bp(const gnx_state* h) {
   return (h->alias_xo && h->sparse_paths) ? h->bp_off : nullptr;

@@ -733,8 +733,8 @@ k_compact(int64_t N, int64_t cap, const int32_t* alive, const int32_t* dead_row,
 }
 
 // The rows k_compact has just pushed on the free-row stack (free_rows[base, base + n)):
-// their two half-rows lose a referrer each, the last one frees the half-row.  Nothing
-// needs the result before the next kernel that pops half-rows, so this runs on a stream
+// their blocks lose a referrer each, the last one frees the block.  Nothing
+// needs the result before the next kernel that pops blocks, so this runs on a stream
 // of its own beside the crossover and the next step (gnx_halves_ready joins it).
 __global__ void __launch_bounds__(256)
 k_release_halves(const int32_t* __restrict__ free_rows, int64_t n_free, int xo,
@@ -869,7 +869,7 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
     h->ord_valid = false;
   }
   if (has_rows) {
-    // the dead's half-rows are released off the critical path
+    // the dead's blocks are released off the critical path
     hipStream_t st = h->stream3 ? h->stream3 : h->stream;
     if (h->stream3) {
       HIPCHK(hipEventRecord(h->ev_compact, h->stream));

@@ -7,7 +7,7 @@
 // padded to a multiple of 16 words so every homologue starts on a 128-byte line
 // and splits into whole 16-byte chunks.  Individuals reference LOGICAL rows through
 // GnxSoA.grow; where a row's two homologues live is the second indirection of
-// gnx_half.h (hmap: logical half -> physical half-row, shared between a parent and the
+// gnx_half.h (hmap: logical block -> physical block, shared between a parent and the
 // children that inherit the homologue unrecombined).  Half-rows are never moved.
 #include "gnx_internal.h"
 #include "gnx_rng.h"
@@ -178,7 +178,7 @@ k_xo_jobs_req(int n_req, int64_t first, int32_t* __restrict__ grow,
     row = free_rows[n_free - 1 - q];
     grow[first + k] = row;
   }
-  // the local parent's gamete (homologue 0), and an empty half-row for the one that
+  // the local parent's gamete (homologue 0), and empty blocks for the one that
   // arrives from the neighbour tile
   gnx_xo_gamete(H, act, row, 0, act ? grow[off_parent[2 * k]] : -1, act ? off_keys[2 * k] : 0,
                 act ? off_start[2 * k] : 0, bp_off, bp_loci, jobs, n_jobs);
@@ -664,7 +664,7 @@ int gnx_l_gather_genomes(gnx_state* h, int64_t n, const int64_t* d_slots, uint64
   return 0;
 }
 
-// ---------------------------------------------------------------- half-row bookkeeping check
+// ---------------------------------------------------------------- block bookkeeping check
 // out[0] individuals with a logical row (x blocks per homologue), out[1] broken references
 // (no physical block, or one nobody counts), out[2] sum of the reference counts, out[3]
 // blocks in use, out[4] height of the free stack.  Consistent iff out[1] == 0,

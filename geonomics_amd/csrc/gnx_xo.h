@@ -10,7 +10,7 @@
 // device after the step's death draws: only offspring that SURVIVE their first
 // mortality round get a genome row (the others' 25-KB rows would be written and never
 // read), and only gametes that carry a switch point get a job: the others alias the
-// parent's half-row (gnx_half.h).  One WAVEFRONT owns one job at a time: the record is a scalar load,
+// parent's blocks (gnx_half.h).  One WAVEFRONT owns one job at a time: the record is a scalar load,
 // parent row / child row / path / start homologue live in SGPRs, and the 64 lanes stream
 // the homologue in 16-byte chunks (1 KiB per wave-instruction, U chunks in flight per
 // lane).  The grid is fixed (persistent-style, job-strided) and reads the job count from

@@ -201,14 +201,15 @@ int gnx_set_crossover_overlap(gnx_state* h, int32_t mode);
  * with the sort and the kernels after it.  0 or 1024 = one launch.  Results do not depend
  * on it. */
 int gnx_set_crossover_split(gnx_state* h, int32_t wide_per_1024);
-/* Bookkeeping of the shared genome half-rows (a gamete without a switch point refers to
- * the parent's half-row instead of copying it): out[6] = individuals with a genome row,
- * broken references, sum of reference counts, half-rows in use, free half-rows, half-rows
- * in all.  Consistent iff out[1] == 0, out[2] == 2 * out[0], out[3] + out[4] == out[5]. */
+/* Bookkeeping of the shared genome blocks (where a gamete's path has no switch point the
+ * child refers to the parent's block instead of copying it): out[6] = logical blocks of the
+ * individuals that have a genome row / 2, broken references, sum of reference counts,
+ * physical blocks in use, free physical blocks, physical blocks in all.  Consistent iff
+ * out[1] == 0, out[2] == 2 * out[0], out[3] + out[4] == out[5]. */
 int gnx_debug_halves(gnx_state* h, int64_t* out);
-/* measurement: the job list of the last crossover, 16 bytes per copied gamete {the
- * parent's two physical half-rows, the half-row written, path * 2 + start homologue}
- * (csrc/gnx_xo.h); gametes without a switch point are not in it                        */
+/* measurement: the job list of the last crossover, 16 bytes per copied block {the
+ * parent's two physical blocks, the block written, (path * 2 + start homologue) | block
+ * index << 24} (csrc/gnx_xo.h); blocks without a switch point are not in it            */
 int gnx_last_crossover_jobs(gnx_state* h, void* dst, int64_t max_jobs, int64_t* n_jobs);
 /* births whose genomes the last crossover wrote (== births when not deferred)          */
 int64_t gnx_last_crossover_births(gnx_state* h);
