@@ -125,6 +125,7 @@ struct MoveP {
   double inv_cs;
   int ncx, ncy, idbits;
   uint32_t* cell32;
+  int tile_floats;
 };
 
 __constant__ float c_queen_dirs[8] = {-2.35619449019234492885f, -1.57079632679489661923f,
@@ -204,8 +205,8 @@ __device__ __forceinline__ float surf_direction(const float* rast, int W, int H,
 // tail of newborns) falls back to global gathers.  Returns false on fallback.
 #define SURF_TILE_FLOATS 8192
 __device__ __forceinline__ bool surf_neighbours_lds(const float* rast, int W, int H, bool act,
-                                                    int cx, int cy, float* tile, int* box,
-                                                    float n[8]) {
+                                                    int cx, int cy, float* tile, int tile_floats,
+                                                    int* box, float n[8]) {
   // box = {xmin, xmax, ymin, ymax} in LDS
   if (threadIdx.x == 0) {
     box[0] = 0x7fffffff;
@@ -223,7 +224,7 @@ __device__ __forceinline__ bool surf_neighbours_lds(const float* rast, int W, in
   __syncthreads();
   const int x0 = box[0] - 1, x1 = box[1] + 1, y0 = box[2] - 1, y1 = box[3] + 1;
   const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
-  if (box[1] < 0 || (int64_t)bw * bh > SURF_TILE_FLOATS) return false;   // block-uniform
+  if (box[1] < 0 || (int64_t)bw * bh > tile_floats) return false;   // block-uniform
   for (int t = threadIdx.x; t < bw * bh; t += blockDim.x) {
     int ty = t / bw, tx = t - ty * bw;
     int yy = y0 + ty, xx = x0 + tx;
@@ -243,7 +244,7 @@ __device__ __forceinline__ bool surf_neighbours_lds(const float* rast, int W, in
 __global__ void __launch_bounds__(256)
 k_move(MoveP P, GnxSoA s, const float* rast, const float* inj_theta, const float* inj_dist,
        float* out_theta, float* out_dist) {
-  __shared__ float surf_tile[SURF_TILE_FLOATS];
+  extern __shared__ float surf_tile[];       // P.tile_floats floats
   __shared__ int surf_box[4];
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool act = i < P.N;
@@ -256,7 +257,8 @@ k_move(MoveP P, GnxSoA s, const float* rast, const float* inj_theta, const float
   bool have_nb = false;
   if (P.surf != GNX_SURF_NONE && !inj_theta) {     // block-uniform condition
     const float* cond = rast + (int64_t)P.surf_layer * P.H * P.W;
-    have_nb = surf_neighbours_lds(cond, P.W, P.H, act, (int)x, (int)y, surf_tile, surf_box, nb);
+    have_nb = surf_neighbours_lds(cond, P.W, P.H, act, (int)x, (int)y, surf_tile, P.tile_floats,
+                                  surf_box, nb);
     if (!have_nb && act) surf_neighbours(cond, P.W, P.H, (int)x, (int)y, nb);
   }
   if (!act) return;
@@ -343,8 +345,13 @@ int gnx_l_move(gnx_state* h, bool inc_age, const float* inj_theta, const float* 
   P.idbits = gnx_id_bits(h);
   h->keys_fresh = with_keys;
   if (with_keys) h->keys_ordmode = ordm;
+  // LDS window of the conductance raster per workgroup (GNX_MOVE_TILE floats): smaller
+  // windows let more workgroups share a CU while the kernel crawls beside the crossover
+  static const int tile_env = getenv("GNX_MOVE_TILE") ? atoi(getenv("GNX_MOVE_TILE")) : SURF_TILE_FLOATS;
+  P.tile_floats = sp.move_surf != GNX_SURF_NONE ? std::max(256, std::min(tile_env, 12288)) : 0;
   gnx_time_begin(h);
-  hipLaunchKernelGGL(k_move, dim3(gnx_grid(h->N, 256)), dim3(256), 0, h->stream, P,
+  hipLaunchKernelGGL(k_move, dim3(gnx_grid(h->N, 256)), dim3(256),
+                     (size_t)P.tile_floats * sizeof(float), h->stream, P,
                      h->soa[h->cur], h->rast, inj_theta, inj_dist, out_theta, out_dist);
   // per individual: x,y rw 16 + id 8 + age rw 8 + e store 4*n_lyr + raster gathers 4*n_lyr
   // (+36 for the 3x3 conductance neighbourhood)
