@@ -751,7 +751,14 @@ k_release_halves(const int32_t* __restrict__ free_rows, int64_t n_free, int xo,
       int32_t phys = -1;
       if (row >= 0) {
         phys = H.hmap[(int64_t)row * 2 * H.NB + q];
-        last = atomicSub(&H.rc[phys], 1) == 1;
+        // the only referrer needs no atomic (nobody can be adding one: the counts of this
+        // step's shares were raised before this kernel, and only referrers release)
+        if (H.rc[phys] == 1) {
+          H.rc[phys] = 0;
+          last = true;
+        } else {
+          last = atomicSub(&H.rc[phys], 1) == 1;
+        }
       }
       const int32_t idx = gnx_wave_append(H.top, last);
       if (last) H.stack[idx] = phys;
