@@ -498,7 +498,8 @@ def main():
                     'crossover_achieved_GBps': a_gbps, 'crossover_frac': a_gbps / 8000.0}
         alone = other_mode(2, 'nothing runs beside the crossover (compaction, reference counts '
                               'and the next movement wait for it)')
-        alt = other_mode(1, 'narrow crossover (2 workgroups per CU) beside the whole next step')
+        alt = other_mode(1, 'crossover (8 workgroups per CU) beside the whole next step: nothing waits '
+                             'for it but the next crossover')
     phases = None
     if stepper is not None:
         # per-phase host wall time of the tile protocol, from a few extra steps with a
