@@ -75,8 +75,8 @@ static int xo_launch(gnx_state* h, hipStream_t st, int buf, int64_t max_jobs, bo
   static const int nt = getenv("GNX_XO_NT") ? atoi(getenv("GNX_XO_NT")) : 1;
   // beside the whole next step: 2 workgroups per CU while a job was a whole homologue; with
   // half-homologue blocks 4 .. 16 measure alike (1.23-1.25 ms/step) and 2 loses 15 %
-  static const int tail_bpc = getenv("GNX_XO_TAIL_BPC") ? atoi(getenv("GNX_XO_TAIL_BPC"))
-                                                        : (h->NB > 1 ? 8 : 2);
+  static const int tail_bpc_env = getenv("GNX_XO_TAIL_BPC") ? atoi(getenv("GNX_XO_TAIL_BPC")) : 0;
+  const int tail_bpc = tail_bpc_env ? tail_bpc_env : (h->NB > 1 ? 8 : 2);
   static const int tail_unroll = getenv("GNX_XO_TAIL_UNROLL") ? atoi(getenv("GNX_XO_TAIL_UNROLL")) : 6;
   const int bpc = narrow ? tail_bpc : (bpc_env ? bpc_env : 32);
   // the narrow share of a split launch is accounted for on its own
