@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Long run of the metric workload with the bookkeeping checked along the way: the
+reference counts of the shared genome blocks add up (gnx_debug_halves), blocks in use
+level off (no leak), the population stays at its carrying capacity.
+    python tools/soak.py [steps] [check every]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench                                           # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
+every = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+cfg = bench.WORKLOADS[os.environ.get('GNX_SOAK_WORKLOAD', 'c4_metric')]
+dev, _, _ = bench.build_device(cfg, seed=42, device=0)
+for _ in range(3):
+    dev.step(True, False)
+bench.setup_genomes(dev, cfg, 42)
+t0 = time.time()
+for t in range(1, steps + 1):
+    dev.step(False, True)
+    if t % every == 0 or t == steps:
+        rows, broken, refs, used, free, total = (int(v) for v in dev.debug_halves())
+        n, b, d = dev.counts()
+        ok = broken == 0 and refs == 2 * rows and used + free == total
+        print('step %5d  N=%d births=%d deaths=%d  blocks: logical %d  physical in use %d '
+              '(%.1f %% shared)  free %d  %s  %.1f s' % (
+                  t, n, b, d, 2 * rows, used, 100.0 * (1 - used / max(2 * rows, 1)), free,
+                  'ok' if ok else 'INCONSISTENT', time.time() - t0), flush=True)
+        if not ok:
+            sys.exit(1)
+dev.close()
