@@ -108,7 +108,7 @@ def dense_paths(n, L, seed, W64):
     return out
 
 
-def build_device(cfg, seed, device, grid=(1, 1), rank=0, host_init=None, cap_factor=1.6):
+def build_device(cfg, seed, device, grid=(1, 1), rank=0, host_init=None, cap_factor=2.0):
     from geonomics_amd import _native as nat
     R, C = grid
     W, H, L = cfg['W'] * C, cfg['H'] * R, cfg['L']

@@ -32,7 +32,8 @@ out = [None] * world
 def body(rank):
     try:
         torch.cuda.set_device(0)
-        dev, _, _ = bench.build_device(cfg, seed=42, device=0, grid=grid, rank=rank)
+        dev, _, _ = bench.build_device(cfg, seed=42, device=0, grid=grid, rank=rank,
+                                         cap_factor=float(os.environ.get("GNX_TILE_CAP", "1.6")))
         shard = DeviceShard(dev)
         st = TiledStepper(shard, LocalComm(hub, rank), cfg['W'] * grid[1], cfg['H'] * grid[0],
                           10.0, move=True, max_id=cfg['N'] * world - 1, grid=grid, fixed_births=1)
@@ -47,8 +48,16 @@ def body(rank):
         dev.synchronize()
         hub.barrier.wait()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        check = int(os.environ.get('GNX_TILE_CHECK', '0'))      # block bookkeeping every k steps
+        for k in range(steps):
             n = st.step(False, True)
+            if check and (k + 1) % check == 0:
+                rows, broken, refs, used, free, total = (int(v) for v in dev.debug_halves())
+                assert broken == 0 and refs == 2 * rows and used + free == total, (
+                    rank, k, rows, broken, refs, used, free, total)
+                if rank == 0:
+                    print('step %d: N=%s, blocks consistent on every tile (rank 0: %d logical, '
+                          '%d physical)' % (k + 1, n, 2 * rows, used), flush=True)
         dev.synchronize()
         dt = time.perf_counter() - t0
         out[rank] = (dt / steps * 1e3, {k: v / steps * 1e3 for k, v in st.phase_s.items()},
