@@ -299,8 +299,8 @@ class Device:
         self._chk(self.lib.gnx_set_crossover_overlap(self.h, int(mode)))
 
     def debug_halves(self):
-        """(logical blocks in use / 2, broken references, sum of reference counts, physical
-        blocks in use, free blocks, blocks in all) of the shared genome blocks"""
+        """(logical blocks in use / 2, broken references, collections so far, physical blocks
+        in use, free blocks, blocks in all) of the shared genome blocks, after a collection"""
         out = np.zeros(6, np.int64)
         self._chk(self.lib.gnx_debug_halves(self.h, _ptr(out, C.c_int64)))
         return out

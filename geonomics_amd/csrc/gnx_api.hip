@@ -291,28 +291,31 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
       h->row_spread = want;
     }
     GNXCHK(dalloc(&h->free_rows, (size_t)h->cfg.cap_rows));
-    // blocks per homologue: a divisor of the 128-byte lines per homologue (GNX_HALF_BLOCKS,
-    // default 2: half a homologue per block)
+    // blocks per homologue: the largest divisor of the 128-byte lines per homologue that is
+    // not above 8 (L = 10^5: 98 lines, 7 blocks of 1.8 KB; GNX_HALF_BLOCKS asks for another
+    // one), as long as the block numbers fit 31 bits
     {
       const int lines = h->W64 / 16;
-      int want = getenv("GNX_HALF_BLOCKS") ? atoi(getenv("GNX_HALF_BLOCKS")) : 2;
+      int want = getenv("GNX_HALF_BLOCKS") ? atoi(getenv("GNX_HALF_BLOCKS")) : 8;
       want = std::max(1, std::min(want, GNX_MAX_NB));
-      while (want > 1 && lines % want) --want;
+      while (want > 1 && (lines % want ||
+                          (double)h->cfg.cap_rows * h->row_spread * 2.0 * want >= 2.0e9))
+        --want;
       h->NB = want;
     }
     const size_t halves = (size_t)h->cfg.cap_rows * h->row_spread * 2 * h->NB;
     GNXCHK(dalloc(&h->hmap, halves));
-    GNXCHK(dalloc(&h->half_rc, halves));
+    GNXCHK(dalloc(&h->half_own, halves));
+    GNXCHK(dalloc(&h->half_mark, halves));
     GNXCHK(dalloc(&h->half_free, (size_t)h->cfg.cap_rows * 2 * h->NB));
     GNXCHK(dalloc(&h->half_top, 1));
-    GNXCHK(dalloc(&h->half_share, (size_t)cap * 2 * h->NB));
-    GNXCHK(dalloc(&h->half_n_share, 2));        // count, and the flush kernel's exit counter
-    HIPCHK(hipMemset(h->half_n_share, 0, 2 * sizeof(int32_t)));
-    GNXCHK(dalloc(&h->rel_cnt, 2));
+    GNXCHK(dalloc(&h->gc_cnt, (size_t)h->cfg.cap_rows * 2 * h->NB / GNX_CB + 2));
+    GNXCHK(dalloc(&h->gc_off, (size_t)h->cfg.cap_rows * 2 * h->NB / GNX_CB + 2));
+    HIPCHK(hipMemset(h->half_own, 0, halves));
+    HIPCHK(hipMemset(h->half_mark, 0, halves));
     HIPCHK(hipMalloc((void**)&h->xo_jobs_acc, 2 * sizeof(unsigned long long)));
     HIPCHK(hipMemset(h->xo_jobs_acc, 0, 2 * sizeof(unsigned long long)));
     HIPCHK(hipMemset(h->hmap, 0xff, halves * sizeof(int32_t)));
-    HIPCHK(hipMemset(h->half_rc, 0, halves * sizeof(int32_t)));
     HIPCHK(hipMemset(h->half_top, 0, sizeof(int32_t)));
     if (getenv("GNX_XO_ALIAS")) h->alias_xo = atoi(getenv("GNX_XO_ALIAS")) != 0;
   }
@@ -333,7 +336,6 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
   HIPCHK(hipEventCreateWithFlags(&h->ev_ord, hipEventDisableTiming));
   HIPCHK(hipStreamCreate(&h->stream3));
   HIPCHK(hipEventCreateWithFlags(&h->ev_compact, hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&h->ev_release, hipEventDisableTiming));
   if (getenv("GNX_ORD_SORT")) h->ord_mode = atoi(getenv("GNX_ORD_SORT")) != 0;
   GNXCHK(dalloc(&h->tag, cap));
   HIPCHK(hipMalloc(&h->cand, (size_t)cap * 16));
@@ -379,9 +381,9 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
   GNXCHK(dalloc(&h->blk_off, (size_t)3 * h->blk_stride));
   GNXCHK(dalloc(&h->cnt_dev, 8));
   // fine-grained: the host polls words that kernels write (gnx_wait_published)
-  HIPCHK(hipHostMalloc((void**)&h->h_pin, 16 * sizeof(int64_t),
+  HIPCHK(hipHostMalloc((void**)&h->h_pin, 32 * sizeof(int64_t),
                        hipHostMallocCoherent | hipHostMallocMapped));
-  memset(h->h_pin, 0, 16 * sizeof(int64_t));
+  memset(h->h_pin, 0, 32 * sizeof(int64_t));
   HIPCHK(hipHostGetDevicePointer((void**)&h->h_pin_dev, h->h_pin, 0));
   if (cfg->L > 0) {
     for (int k = 0; k < 2; ++k) {
@@ -421,7 +423,7 @@ extern "C" void gnx_destroy(gnx_state* h) {
     (void)hipFree(h->perm[k]);
     (void)hipFree(h->counts_rast[k]);
   }
-  void* ptrs[] = {h->ord[0], h->ord[1], h->keyk[0], h->keyk[1], h->valk[0], h->valk[1], h->newslot, h->cell32, h->ord_cnt, h->ord_off, h->half_share, h->half_n_share, h->rel_cnt, h->hmap, h->half_rc, h->half_free, h->half_top, h->xo_jobs_acc, h->rast, h->G, h->free_rows, h->paths, h->bp_off, h->bp_loci, h->dom,
+  void* ptrs[] = {h->ord[0], h->ord[1], h->keyk[0], h->keyk[1], h->valk[0], h->valk[1], h->newslot, h->cell32, h->ord_cnt, h->ord_off, h->gc_cnt, h->gc_off, h->half_own, h->half_mark, h->hmap, h->half_free, h->half_top, h->xo_jobs_acc, h->rast, h->G, h->free_rows, h->paths, h->bp_off, h->bp_loci, h->dom,
                   h->delet_loci, h->delet_s, h->cell_start, h->tag, h->cand, h->sort64_tmp, h->key64[0], h->key64[1], h->pairs2,
                   h->pair_goff, h->st_rec, h->st_z, h->st_geno, h->st_slots, h->req_pid, h->req_k, h->req_key, h->req_start, h->req_px, h->req_py,
                   h->req_count, h->sort_tmp, h->scan_tmp, h->mate,
@@ -449,7 +451,6 @@ extern "C" void gnx_destroy(gnx_state* h) {
   }
   if (h->ev_ord) (void)hipEventDestroy(h->ev_ord);
   if (h->ev_compact) (void)hipEventDestroy(h->ev_compact);
-  if (h->ev_release) (void)hipEventDestroy(h->ev_release);
   delete h;
 }
 

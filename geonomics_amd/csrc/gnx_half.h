@@ -4,19 +4,22 @@
 // rank from the free-row stack, counted exactly on the host as before).  A homologue
 // (logical half lh = 2 * row + h) is NB blocks of BW words; where block b actually lives
 // is a second table: hmap[lh * NB + b] is the PHYSICAL block (BW words at G + phys * BW).
-// Blocks are immutable once written and reference-counted, so the part of a gamete that
+// Blocks are immutable once written, so the part of a gamete that
 // carries no switch point - the child's block IS the block of one of the parent's
 // homologues, bit for bit (ops/mating.py:165-167: the subsetter is constant there) - is
 // not copied: the child's entry points at the parent's block.  With one expected crossover
 // per gamete (r = 1/L) e^-1 of all gametes carry none at all, and the others switch in one
-// or two blocks.  A block returns to the free stack when its last referrer dies.
+// or two blocks.
 //
-// Every referrer holds exactly one count, so the live blocks never outnumber
-// 2 * NB x (logical rows in use): the stack cannot run dry while logical rows are left, and
-// the host needs no count of it.  Pops happen only in the kernels that hand out rows,
-// pushes only in k_release_halves: never in the same kernel.  The counts of shared blocks
-// are raised off the critical path (k_share_refs, same stream as the releases, before
-// them): the job builders only list the blocks they shared.
+// Nobody counts the references.  A block is live iff some living individual's table points
+// at it; every few steps, when the stack of free blocks runs low, a mark-and-sweep pass
+// (gnx_gc: mark the blocks of the living, put everything else back on the stack) finds the
+// blocks the dead have left behind - about 0.15 ms every dozen steps instead of a million
+// atomic count updates in every step.  The live blocks never outnumber 2 * NB x (logical
+// rows in use), and the host makes sure before every kernel that pops blocks that the stack
+// holds enough (gnx_half_reserve: it collects first if it may not), so the stack cannot
+// run dry while logical rows are left.  own[lb] says that logical block lb was cut for its
+// individual and never shared: only such a block may take a mutation in place.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -25,11 +28,9 @@
 
 struct GnxHalves {
   int32_t* hmap;    // [2 * row span * NB]  logical block -> physical block
-  int32_t* rc;      // [2 * row span * NB]  references to a physical block
+  uint8_t* own;     // [2 * row span * NB]  1: the physical block belongs to this logical block alone
   int32_t* stack;   // free physical blocks
   int32_t* top;     // how many
-  int32_t* share;   // physical blocks shared by the last builder (one entry per new referrer)
-  int32_t* n_share;
   int NB;           // blocks per homologue
   int BW;           // u64 words per block (a multiple of 16: whole 128-byte lines)
 };
@@ -77,7 +78,7 @@ __device__ __forceinline__ int32_t gnx_wave_append(int32_t* counter, bool want) 
 __device__ __forceinline__ int32_t gnx_half_new(const GnxHalves& H, int64_t lb, bool want) {
   const int32_t p = gnx_half_pop(H, want);
   if (want) {
-    H.rc[p] = 1;
+    H.own[lb] = 1;
     H.hmap[lb] = p;
   }
   return p;

@@ -128,19 +128,20 @@ struct gnx_state {
   int row_spread = 1;
   int32_t* free_rows = nullptr;
   int64_t n_free = 0;
-  // physical blocks (gnx_half.h): hmap / half_rc over 2 * cap_rows * row_spread * NB blocks,
+  // physical blocks (gnx_half.h): hmap / half_own / half_mark over 2 * cap_rows * row_spread * NB blocks,
   // the stack of free ones and its height on the device
   int32_t* hmap = nullptr;
-  int32_t* half_rc = nullptr;
+  uint8_t* half_own = nullptr;         // logical block cut for its individual, never shared
+  uint8_t* half_mark = nullptr;        // physical block referred to by somebody alive (gnx_gc)
   int32_t* half_free = nullptr;
   int32_t* half_top = nullptr;
-  int32_t* half_share = nullptr;       // blocks shared by the builders since the last flush
-  int32_t* half_n_share = nullptr;
+  int64_t half_free_est = 0;           // free blocks the host can count on (a lower bound)
+  int64_t gc_runs = 0;
+  int32_t* gc_cnt = nullptr;           // block counts / offsets of the collector's sweep
+  int32_t* gc_off = nullptr;
   int NB = 1;                          // blocks per homologue (gnx_half.h), BW = W64 / NB words
   hipStream_t stream3 = nullptr;       // reference counts of the genome blocks, the sort index
-  hipEvent_t ev_compact = nullptr, ev_release = nullptr;
-  bool release_inflight = false;
-  int32_t* rel_cnt = nullptr;          // [2] rows freed / rows popped by the last compaction
+  hipEvent_t ev_compact = nullptr;
   bool alias_xo = true;          // blocks without a switch point are shared with the parent
   unsigned long long* xo_jobs_acc = nullptr;   // [2] gametes copied by the (wide, tail) launches
   bool genomes_assigned = false;
@@ -349,23 +350,12 @@ struct gnx_state {
 GnxTraitTab gnx_trait_tab(const gnx_state* h);
 
 static inline GnxHalves gnx_halves(const gnx_state* h) {
-  return GnxHalves{h->hmap,       h->half_rc,       h->half_free, h->half_top,
-                   h->half_share, h->half_n_share,  h->NB,        h->W64 / h->NB};
+  return GnxHalves{h->hmap, h->half_own, h->half_free, h->half_top, h->NB, h->W64 / h->NB};
 }
-// the shared blocks listed by the builders get their counts raised (on `st`), list emptied
-int gnx_share_flush(gnx_state* h, hipStream_t st);
-// before anything that pops blocks: the last release of the dead's blocks has
-// finished (it runs on a stream of its own)
-static inline int gnx_halves_ready(gnx_state* h) {
-  if (h->release_inflight) {
-    if (hipStreamWaitEvent(h->stream, h->ev_release, 0) != hipSuccess) {
-      gnx_set_error("hipStreamWaitEvent(ev_release) failed");
-      return 1;
-    }
-    h->release_inflight = false;
-  }
-  return 0;
-}
+// Before a kernel that pops up to `blocks` physical blocks: the free stack holds that many
+// (a mark-and-sweep collection runs first if the host cannot be sure, gnx_gc).
+int gnx_half_reserve(gnx_state* h, int64_t blocks);
+int gnx_gc(gnx_state* h);
 // breakpoint offsets when blocks without a switch point may be shared with the parent
 // (sparse paths only: the dense path table is not scanned for all-zero masks), else null
 static inline const int32_t* gnx_alias_bp(const gnx_state* h) {
@@ -465,7 +455,8 @@ int gnx_l_scatter_genomes(gnx_state* h, int64_t n, const uint64_t* d_in, int64_t
 // <= 3, -> exclusive block offsets off[...], totals to out[0..2] on the device and to
 // pinned host memory
 int gnx_block_scan(gnx_state* h, int K, int64_t n_items, const int32_t* cnt, int32_t* off,
-                   int32_t* out, int64_t* host, int64_t seq = 0, hipStream_t st = nullptr);
+                   int32_t* out, int64_t* host, int64_t seq = 0, hipStream_t st = nullptr,
+                   const int32_t* extra = nullptr);
 int gnx_prim_sort32_bits(void* tmp, size_t bytes, const uint32_t* kin, uint32_t* kout,
                          const int32_t* vin, int32_t* vout, size_t n, int end_bit,
                          hipStream_t s, bool alone);

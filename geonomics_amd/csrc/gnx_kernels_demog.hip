@@ -567,7 +567,7 @@ k_xo_jobs_surv(int64_t N, int64_t first, int32_t* __restrict__ grow,
                const int32_t* __restrict__ bp_loci, GnxXoJob* __restrict__ jobs,
                int32_t* __restrict__ n_jobs) {
   __shared__ int lds[16];
-  __shared__ int s_pop, s_job, s_share;
+  __shared__ int s_pop, s_job;
   const int64_t b = first / GNX_CB + blockIdx.x;
   const int64_t base = b * GNX_CB;
   bool fx[4];
@@ -581,9 +581,9 @@ k_xo_jobs_surv(int64_t N, int64_t first, int32_t* __restrict__ grow,
   const int32_t boff = blk_off3[b];
   // Block by block (gnx_half.h), a gamete refers to the parent's block where its path has no
   // switch point and gets a block of its own and a job where it has one (parents are older:
-  // slots < first).  The workgroup takes its blocks, its stretch of the job list and its
-  // stretch of the list of shared blocks with ONE atomic each: those are single words, and a
-  // thousand waves taking turns on them cost more than everything else in this kernel.
+  // slots < first).  The workgroup takes its blocks and its stretch of the job list with ONE
+  // atomic each: those are single words, and a thousand waves taking turns on them cost more
+  // than everything else in this kernel.
   // Every load of a stage is issued for all eight gametes of the thread before the first
   // result is used (unconditional loads from clamped indices: behind `fx ? load : 0` the
   // compiler waits for each one in turn).
@@ -617,10 +617,10 @@ k_xo_jobs_surv(int64_t N, int64_t first, int32_t* __restrict__ grow,
     }
   }
   unsigned int mixed[4][2], sel[4][2];
-  int cf[4], cj[4], cs[4];
+  int cf[4], cj[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    cf[r] = cj[r] = cs[r] = 0;
+    cf[r] = cj[r] = 0;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       if (!fx[r]) prow[r][p] = -1;
@@ -634,25 +634,22 @@ k_xo_jobs_surv(int64_t N, int64_t first, int32_t* __restrict__ grow,
         const int nf = __popc(mixed[r][p] & all);
         cf[r] += nf;
         cj[r] += prow[r][p] >= 0 ? nf : 0;
-        cs[r] += NB - nf;
       }
     }
   }
-  int of[4], oj[4], os[4], tf, tj, ts;
+  int of[4], oj[4], tf, tj;
   gnx_block_sums(cf, of, tf, lds);
   gnx_block_sums(cj, oj, tj, lds);
-  gnx_block_sums(cs, os, ts, lds);
   if (threadIdx.x == 0) {
     s_pop = tf ? atomicSub(H.top, tf) : 0;
     s_job = tj ? atomicAdd(n_jobs, tj) : 0;
-    s_share = ts ? atomicAdd(H.n_share, ts) : 0;
   }
   __syncthreads();
-  const int pop0 = s_pop, job0 = s_job, share0 = s_share;
+  const int pop0 = s_pop, job0 = s_job;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     if (!fx[r]) continue;
-    int pi = of[r], ji = oj[r], si = os[r];
+    int pi = of[r], ji = oj[r];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const bool local = prow[r][p] >= 0;
@@ -661,7 +658,7 @@ k_xo_jobs_surv(int64_t N, int64_t first, int32_t* __restrict__ grow,
       for (int q = 0; q < NB; ++q) {
         if ((mixed[r][p] >> q) & 1u) {
           const int32_t dst = H.stack[pop0 - 1 - pi++];
-          H.rc[dst] = 1;
+          H.own[lh * NB + q] = 1;
           H.hmap[lh * NB + q] = dst;
           if (local) {
             GnxXoJob j;
@@ -672,9 +669,11 @@ k_xo_jobs_surv(int64_t N, int64_t first, int32_t* __restrict__ grow,
             jobs[job0 + ji++] = j;
           }
         } else {
-          const int32_t src = H.hmap[ph0 + ((sel[r][p] >> q) & 1u) * NB + q];
-          H.hmap[lh * NB + q] = src;
-          H.share[share0 + si++] = src;
+          // shared with the parent: neither may take a mutation in place from now on
+          const int64_t plb = ph0 + ((sel[r][p] >> q) & 1u) * NB + q;
+          H.hmap[lh * NB + q] = H.hmap[plb];
+          H.own[lh * NB + q] = 0;
+          H.own[plb] = 0;
         }
       }
     }
@@ -687,13 +686,8 @@ __global__ void __launch_bounds__(256)
 k_compact(int64_t N, int64_t cap, const int32_t* alive, const int32_t* dead_row,
           const int32_t* blk_off, int stride, const int32_t* cnts, GnxSoA a, GnxSoA b,
           int n_layers, int n_traits, int tbw, int32_t* free_rows, int64_t n_free, int has_rows,
-          int xo, int32_t* rel_cnt, int32_t* __restrict__ newslot) {
+          int xo, int32_t* __restrict__ newslot) {
   __shared__ int lds[16];
-  // k_release_halves reads its counts here (cnts is reused by the next step's scans)
-  if (rel_cnt && blockIdx.x == 0 && threadIdx.x == 0) {
-    rel_cnt[0] = cnts[1];
-    rel_cnt[1] = cnts[2];
-  }
   const int64_t base = (int64_t)blockIdx.x * GNX_CB;
   bool fa[4], fd[4];
 #pragma unroll
@@ -732,43 +726,8 @@ k_compact(int64_t N, int64_t cap, const int32_t* alive, const int32_t* dead_row,
   }
 }
 
-// The rows k_compact has just pushed on the free-row stack (free_rows[base, base + n)):
-// their blocks lose a referrer each, the last one frees the block.  Nothing
-// needs the result before the next kernel that pops blocks, so this runs on a stream
-// of its own beside the crossover and the next step (gnx_halves_ready joins it).
-__global__ void __launch_bounds__(256)
-k_release_halves(const int32_t* __restrict__ free_rows, int64_t n_free, int xo,
-                 const int32_t* __restrict__ rel_cnt, GnxHalves H) {
-  const int64_t base = n_free - (xo ? rel_cnt[1] : 0);
-  const int64_t n = rel_cnt[0];
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  // whole waves stay in the loop together (the pushes are wave-aggregated)
-  const int64_t n_up = (n + 63) / 64 * 64;
-  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_up; j += stride) {
-    const int32_t row = j < n ? free_rows[base + j] : -1;
-    for (int q = 0; q < 2 * H.NB; ++q) {
-      bool last = false;
-      int32_t phys = -1;
-      if (row >= 0) {
-        phys = H.hmap[(int64_t)row * 2 * H.NB + q];
-        // the only referrer needs no atomic (nobody can be adding one: the counts of this
-        // step's shares were raised before this kernel, and only referrers release)
-        if (H.rc[phys] == 1) {
-          H.rc[phys] = 0;
-          last = true;
-        } else {
-          last = atomicSub(&H.rc[phys], 1) == 1;
-        }
-      }
-      const int32_t idx = gnx_wave_append(H.top, last);
-      if (last) H.stack[idx] = phys;
-    }
-  }
-}
-
 void gnx_launch_xo_jobs_surv(gnx_state* h, int64_t first_slot, const int32_t* d_alive,
                              const int32_t* d_blk_off, int buf) {
-  (void)gnx_halves_ready(h);
   const int64_t N = h->N;
   const int nbj = (int)((N - 1) / GNX_CB - first_slot / GNX_CB + 1);
   hipLaunchKernelGGL(k_xo_jobs_surv, dim3(nbj), dim3(256), 0, h->stream, N, first_slot,
@@ -833,7 +792,12 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
   // the job buffer the deferred crossover is about to fill: nobody reads it any more,
   // and its counter starts at zero
   int32_t* zero_jobs = nullptr;
-  if (xo) GNXCHK(gnx_xo_prepare_jobs(h, &zero_jobs));
+  if (xo) {
+    GNXCHK(gnx_xo_prepare_jobs(h, &zero_jobs));
+    // the survivors' gametes will pop at most this many blocks (the dead's blocks come back
+    // through the collector, gnx_gc, when the stack runs low)
+    GNXCHK(gnx_half_reserve(h, 2 * (int64_t)h->NB * xo_B));
+  }
   gnx_time_begin(h);
   hipLaunchKernelGGL(k_alive, dim3(nb), dim3(256), 0, h->stream, N, h->p_death, d_dead_inject,
                      a.id, a.ghost, a.grow, h->step, c.seed, h->flag, h->flag2, h->blk_cnt,
@@ -857,7 +821,7 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
   hipLaunchKernelGGL(k_compact, dim3(nb), dim3(256), 0, h->stream, N, c.cap_inds, h->flag,
                      h->flag2, h->blk_off, h->blk_stride, h->cnt_dev, a, b, c.n_layers, c.n_traits,
                      a.tb ? 2 * h->TW : 0, h->free_rows, h->n_free, has_rows, xo ? 1 : 0,
-                     h->rel_cnt, ord_keep ? h->newslot : nullptr);
+                     ord_keep ? h->newslot : nullptr);
   gnx_time_end(h, GNX_K_COMPACT, (double)N * (24.0 + 2.0 * (34.0 + 4.0 * c.n_layers +
                                                              4.0 * c.n_traits + 16.0 * h->TW)));
   if (ord_keep) {
@@ -874,29 +838,6 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
     h->ord_cur ^= 1;
   } else {
     h->ord_valid = false;
-  }
-  if (has_rows) {
-    // the dead's blocks are released off the critical path
-    hipStream_t st = h->stream3 ? h->stream3 : h->stream;
-    if (h->stream3) {
-      HIPCHK(hipEventRecord(h->ev_compact, h->stream));
-      HIPCHK(hipStreamWaitEvent(h->stream3, h->ev_compact, 0));
-      // GNX_RELEASE_LATE=1: not beside the crossover either.  Measured: the crossover gains
-      // 2 % (5.63 -> 5.76 TB/s), the step loses 2 % (1.652 -> 1.686 ms; the small kernels
-      // after the crossover then share the chip with the release): off.
-      static const bool late = getenv("GNX_RELEASE_LATE") && atoi(getenv("GNX_RELEASE_LATE")) != 0;
-      if (late)
-        for (int k = 0; k < 2; ++k)
-          if (h->xo_inflight[k]) HIPCHK(hipStreamWaitEvent(h->stream3, h->ev_xo_done[k], 0));
-    }
-    // first the counts of the blocks this step's gametes share, then the dead's releases
-    GNXCHK(gnx_share_flush(h, st));
-    hipLaunchKernelGGL(k_release_halves, dim3(256), dim3(256), 0, st, h->free_rows, h->n_free,
-                       xo ? 1 : 0, h->rel_cnt, gnx_halves(h));
-    if (h->stream3) {
-      HIPCHK(hipEventRecord(h->ev_release, h->stream3));
-      h->release_inflight = true;
-    }
   }
   HIPCHK(hipGetLastError());
   if (xo && h->xo_sort_waits && h->xo_wait_at == 3) GNXCHK(gnx_xo_wait_inflight(h));

@@ -141,13 +141,12 @@ int gnx_l_crossover_all(gnx_state* h, int64_t first_slot, int64_t B) {
   GNXCHK(xo_wait_buf(h, h->stream, 1));
   const int buf = h->jobs_cur;
   GnxSoA s = h->soa[h->cur];
-  GNXCHK(gnx_halves_ready(h));
+  GNXCHK(gnx_half_reserve(h, 2 * (int64_t)h->NB * B));
   HIPCHK(hipMemsetAsync(h->n_jobs_dev[buf], 0, sizeof(int32_t), h->stream));
   hipLaunchKernelGGL(k_xo_jobs_all, dim3(gnx_grid(B, 256)), dim3(256), 0, h->stream, B, first_slot,
                      s.grow, h->off_parent, h->off_keys, h->off_start, h->free_rows, h->n_free,
                      gnx_halves(h), gnx_alias_bp(h), gnx_alias_loci(h), (GnxXoJob*)h->jobs[buf],
                      h->n_jobs_dev[buf]);
-  GNXCHK(gnx_share_flush(h, h->stream));
   if (h->stream2) {
     // tiled runs serve the neighbours' gamete requests on stream2 meanwhile: the rows
     // handed out above must be visible there
@@ -194,13 +193,12 @@ int gnx_l_crossover_requests(gnx_state* h, int64_t first_slot, int64_t n_req) {
   GNXCHK(xo_wait_buf(h, h->stream, 0));
   GNXCHK(xo_wait_buf(h, h->stream, 1));
   const int buf = h->jobs_cur;
-  GNXCHK(gnx_halves_ready(h));
+  GNXCHK(gnx_half_reserve(h, 2 * (int64_t)h->NB * n_req));
   HIPCHK(hipMemsetAsync(h->n_jobs_dev[buf], 0, sizeof(int32_t), h->stream));
   hipLaunchKernelGGL(k_xo_jobs_req, dim3(gnx_grid(n_req, 256)), dim3(256), 0, h->stream, (int)n_req,
                      first_slot, h->soa[h->cur].grow, h->req_k, h->off_parent, h->off_keys,
                      h->off_start, h->free_rows, h->n_free, gnx_halves(h), gnx_alias_bp(h),
                      gnx_alias_loci(h), (GnxXoJob*)h->jobs[buf], h->n_jobs_dev[buf]);
-  GNXCHK(gnx_share_flush(h, h->stream));
   if (h->stream2) {      // the rows handed out above must be visible to the gamete puts
     HIPCHK(hipEventRecord(h->ev_jobs, h->stream));
     HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_jobs, 0));
@@ -244,9 +242,9 @@ int gnx_l_crossover_pending(gnx_state* h, int64_t first_slot, int64_t B) {
                      h->soa[h->cur].grow, h->flag, cnt3);
   // totals land in cnt_dev[2] (what k_xo_jobs_surv reads) and in pinned memory
   GNXCHK(gnx_block_scan(h, 1, N, cnt3, off3, h->cnt_dev + 2, h->h_pin_dev + 8));
+  GNXCHK(gnx_half_reserve(h, 2 * (int64_t)h->NB * B));
   HIPCHK(hipMemsetAsync(h->n_jobs_dev[buf], 0, sizeof(int32_t), h->stream));
   gnx_launch_xo_jobs_surv(h, first_slot, h->flag, h->blk_off, buf);
-  GNXCHK(gnx_share_flush(h, h->stream));
   gnx_time_begin(h);
   GNXCHK(xo_launch(h, h->stream, buf, 2 * B, false));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -502,7 +500,7 @@ __global__ void k_assign_rows(int64_t N, int64_t cap_rows, int spread, int32_t* 
     // every individual starts with its own blocks, at its logical row's address
     for (int q = 0; q < 2 * H.NB; ++q) {
       H.hmap[(int64_t)row * 2 * H.NB + q] = row * 2 * H.NB + q;
-      H.rc[(int64_t)row * 2 * H.NB + q] = 1;
+      H.own[(int64_t)row * 2 * H.NB + q] = 1;
     }
   }
   // free stacks: rows N..cap_rows-1 (row numbers are physical: x spread) and their blocks,
@@ -524,16 +522,12 @@ int gnx_l_assign_genomes(gnx_state* h, const int32_t* d_n_per_site) {
     return 2;
   }
   GNXCHK(gnx_xo_join(h));
-  GNXCHK(gnx_halves_ready(h));
   GnxSoA s = h->soa[h->cur];
   int64_t m = N > c.cap_rows - N ? N : c.cap_rows - N;
-  HIPCHK(hipMemsetAsync(h->half_rc, 0,
-                        (size_t)c.cap_rows * h->row_spread * 2 * h->NB * sizeof(int32_t),
-                        h->stream));
-  HIPCHK(hipMemsetAsync(h->half_n_share, 0, sizeof(int32_t), h->stream));
   hipLaunchKernelGGL(k_assign_rows, dim3(gnx_grid(m, 256)), dim3(256), 0, h->stream, N, c.cap_rows,
                      h->row_spread, s.grow, h->free_rows, gnx_halves(h));
   h->n_free = c.cap_rows - N;
+  h->half_free_est = 2 * (int64_t)h->NB * (c.cap_rows - N);
   if (N > 0 && d_n_per_site) {
     int64_t threads = (int64_t)h->W64 * 64;
     hipLaunchKernelGGL(k_assign_genomes, dim3(gnx_grid(threads, 256)), dim3(256), 0, h->stream, N,
@@ -548,9 +542,10 @@ int gnx_l_assign_genomes(gnx_state* h, const int32_t* d_n_per_site) {
 // ---------------------------------------------------------------- mutation
 // ops/mutation.py:62-131: set allele 1 at (locus, homologue) of the chosen
 // offspring.
-// A block that only the mutated individual refers to takes the bit in place; one that
-// somebody else refers to as well (an unrecombined stretch shared with a parent or a
-// sibling) goes on a list, and one workgroup walks that list in order, copying first.
+// A block cut for the mutated individual and never shared takes the bit in place; one that
+// is or was shared (an unrecombined stretch of a parent's, or a block a child refers to)
+// goes on a list, and one workgroup walks that list in order, copying first.  (The copy is
+// the individual's own from then on; what it replaced is the collector's business.)
 __global__ void k_mutate(int n, u64* G, const int32_t* grow, GnxHalves H, const int64_t* slot,
                          const int32_t* locus, const uint8_t* hom, int32_t* list,
                          int32_t* n_list) {
@@ -559,9 +554,10 @@ __global__ void k_mutate(int n, u64* G, const int32_t* grow, GnxHalves H, const 
   if (i < n) {
     const int l = locus[i];
     const int w = l >> 6, b = w / H.BW;
-    const int32_t p = H.hmap[((int64_t)grow[slot[i]] * 2 + hom[i]) * H.NB + b];
-    shared = H.rc[p] > 1;
-    if (!shared) atomicOr(G + (int64_t)p * H.BW + (w - b * H.BW), 1ull << (l & 63));
+    const int64_t lb = ((int64_t)grow[slot[i]] * 2 + hom[i]) * H.NB + b;
+    shared = H.own[lb] == 0;
+    if (!shared)
+      atomicOr(G + (int64_t)H.hmap[lb] * H.BW + (w - b * H.BW), 1ull << (l & 63));
   }
   const int32_t idx = gnx_wave_append(n_list, shared);
   if (shared) list[idx] = i;
@@ -580,10 +576,9 @@ k_mutate_shared(const int32_t* list, const int32_t* n_list, u64* G, const int32_
       const int64_t lb = ((int64_t)grow[slot[i]] * 2 + hom[i]) * H.NB + b;
       const int32_t p = H.hmap[lb];
       s_old = s_new = p;
-      if (H.rc[p] > 1) {
+      if (!H.own[lb]) {            // (an earlier mutation of this list may have copied it already)
         const int32_t q = H.stack[atomicSub(H.top, 1) - 1];
-        H.rc[q] = 1;
-        atomicSub(&H.rc[p], 1);
+        H.own[lb] = 1;
         H.hmap[lb] = q;
         s_new = q;
       }
@@ -603,16 +598,24 @@ int gnx_l_mutate(gnx_state* h, int n, const int64_t* d_slot, const int32_t* d_lo
                  const uint8_t* d_hom) {
   if (n == 0) return 0;
   GNXCHK(gnx_xo_join(h));
-  GNXCHK(gnx_halves_ready(h));
   int32_t* list = nullptr;
   HIPCHK(hipMalloc((void**)&list, ((size_t)n + 1) * sizeof(int32_t)));
   int32_t* n_list = list + n;
   HIPCHK(hipMemsetAsync(n_list, 0, sizeof(int32_t), h->stream));
   hipLaunchKernelGGL(k_mutate, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, n, (u64*)h->G,
                      h->soa[h->cur].grow, gnx_halves(h), d_slot, d_locus, d_hom, list, n_list);
-  hipLaunchKernelGGL(k_mutate_shared, dim3(1), dim3(256), 0, h->stream, (const int32_t*)list,
-                     (const int32_t*)n_list, (u64*)h->G, h->soa[h->cur].grow, gnx_halves(h),
-                     d_slot, d_locus, d_hom);
+  // the mutations that hit a shared block need a copy each at most
+  int32_t n_shared = 0;
+  int rc = gnx_d2h(h, &n_shared, n_list, sizeof(n_shared));
+  if (!rc && n_shared > 0) rc = gnx_half_reserve(h, n_shared);
+  if (rc) {
+    (void)hipFree(list);
+    return rc;
+  }
+  if (n_shared > 0)
+    hipLaunchKernelGGL(k_mutate_shared, dim3(1), dim3(256), 0, h->stream, (const int32_t*)list,
+                       (const int32_t*)n_list, (u64*)h->G, h->soa[h->cur].grow, gnx_halves(h),
+                       d_slot, d_locus, d_hom);
   HIPCHK(hipStreamSynchronize(h->stream));
   (void)hipFree(list);
   HIPCHK(hipGetLastError());
@@ -667,13 +670,113 @@ int gnx_l_gather_genomes(gnx_state* h, int64_t n, const int64_t* d_slots, uint64
   return 0;
 }
 
+// ---------------------------------------------------------------- block collector
+// gnx_gc: the blocks some living individual's table points at are marked, everything else
+// goes (back) on the free stack.  Individuals whose crossover is still to come have no row
+// yet; the dead of earlier steps are gone from the slots; a crossover in flight on stream2
+// writes blocks of the living and reads blocks that, at worst, go on the stack now and are
+// written again by a later crossover behind it on the same stream.
+__global__ void k_gc_mark(int64_t N, const int32_t* __restrict__ grow, GnxHalves H,
+                          uint8_t* __restrict__ mark) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int per = 2 * H.NB;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < N * per; t += stride) {
+    const int64_t i = t / per;
+    const int32_t row = grow[i];
+    if (row >= 0) mark[H.hmap[(int64_t)row * per + (t - i * per)]] = 1;
+  }
+}
+
+// the sweep is an order-preserving compaction of the unmarked block numbers (gnx_compact.h:
+// count per 1024 items, scan of the counts by one workgroup, write) - one atomic per wave
+// on the stack height took 1.4 ms for the 8 x 10^6 blocks of the metric workload
+__device__ __forceinline__ int32_t gc_block_id(int64_t t, int per, int spread) {
+  const int64_t r = t / per;
+  return (int32_t)(r * spread * per + (t - r * per));
+}
+
+__global__ void __launch_bounds__(256)
+k_gc_count(int64_t n, int per, int spread, const uint8_t* __restrict__ mark,
+           int32_t* __restrict__ cnt) {
+  __shared__ int lds[16];
+  const int64_t base = (int64_t)blockIdx.x * GNX_CB;
+  bool f[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t t = base + r * 256 + threadIdx.x;
+    f[r] = t < n && mark[gc_block_id(t, per, spread)] == 0;
+  }
+  int rank[4], tot;
+  gnx_block_ranks(f, rank, tot, lds);
+  if (threadIdx.x == 0) cnt[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(256)
+k_gc_write(int64_t n, int per, int spread, uint8_t* __restrict__ mark,
+           const int32_t* __restrict__ off, int nb, int32_t* __restrict__ stack,
+           int32_t* __restrict__ top) {
+  __shared__ int lds[16];
+  const int64_t base = (int64_t)blockIdx.x * GNX_CB;
+  bool f[4];
+  int32_t id[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t t = base + r * 256 + threadIdx.x;
+    id[r] = t < n ? gc_block_id(t, per, spread) : 0;
+    f[r] = t < n && mark[id[r]] == 0;
+    if (t < n) mark[id[r]] = 0;
+  }
+  int rank[4], tot;
+  gnx_block_ranks(f, rank, tot, lds);
+  const int32_t o = off[blockIdx.x];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (f[r]) stack[o + rank[r]] = id[r];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *top = off[nb];
+}
+
+int gnx_gc(gnx_state* h) {
+  if (h->cfg.L == 0 || !h->genomes_assigned) return 0;
+  const int per = 2 * h->NB;
+  const int64_t n = (int64_t)h->cfg.cap_rows * per;
+  const int nb = (int)((n + GNX_CB - 1) / GNX_CB);
+  if (h->N > 0)
+    hipLaunchKernelGGL(k_gc_mark, dim3(2048), dim3(256), 0, h->stream, h->N, h->soa[h->cur].grow,
+                       gnx_halves(h), h->half_mark);
+  hipLaunchKernelGGL(k_gc_count, dim3(nb), dim3(256), 0, h->stream, n, per, h->row_spread,
+                     (const uint8_t*)h->half_mark, h->gc_cnt);
+  GNXCHK(gnx_block_scan(h, 1, n, h->gc_cnt, h->gc_off, nullptr, nullptr));
+  hipLaunchKernelGGL(k_gc_write, dim3(nb), dim3(256), 0, h->stream, n, per, h->row_spread,
+                     h->half_mark, (const int32_t*)h->gc_off, nb, h->half_free, h->half_top);
+  int32_t top = 0;
+  GNXCHK(gnx_d2h(h, &top, h->half_top, sizeof(top)));
+  h->half_free_est = top;
+  h->gc_runs += 1;
+  return 0;
+}
+
+int gnx_half_reserve(gnx_state* h, int64_t blocks) {
+  if (h->cfg.L == 0 || !h->genomes_assigned || blocks <= 0) return 0;
+  if (h->half_free_est < blocks) {
+    GNXCHK(gnx_gc(h));
+    if (h->half_free_est < blocks) {
+      gnx_set_error("genome blocks exhausted: %lld needed, %lld free after a collection",
+                    (long long)blocks, (long long)h->half_free_est);
+      return 2;
+    }
+  }
+  h->half_free_est -= blocks;       // what the kernel may take at most
+  return 0;
+}
+
 // ---------------------------------------------------------------- block bookkeeping check
-// out[0] individuals with a logical row (x blocks per homologue), out[1] broken references
-// (no physical block, or one nobody counts), out[2] sum of the reference counts, out[3]
-// blocks in use, out[4] height of the free stack.  Consistent iff out[1] == 0,
-// out[2] == 2 * out[0] and out[3] + out[4] == 2 * NB * cap_rows.
+// After a collection: out[0] logical blocks of the individuals that have a genome row / 2,
+// out[1] broken references (no physical block), out[2] 0, out[3] physical blocks in use
+// (= marked by the collector: distinct blocks the living refer to), out[4] free blocks,
+// out[5] blocks in all.  Consistent iff out[1] == 0 and out[3] + out[4] == out[5];
+// 2 * out[0] - out[3] blocks are shared.
 __global__ void k_half_check(int64_t N, const int32_t* grow, GnxHalves H, int64_t n_halves,
-                             unsigned long long* out) {
+                             const uint8_t* mark, unsigned long long* out) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (int64_t i = t0; i < N; i += stride) {
@@ -682,19 +785,11 @@ __global__ void k_half_check(int64_t N, const int32_t* grow, GnxHalves H, int64_
     atomicAdd(&out[0], 1ull);
     for (int q = 0; q < 2 * H.NB; ++q) {
       const int32_t p = H.hmap[(int64_t)row * 2 * H.NB + q];
-      if (p < 0 || p >= n_halves || H.rc[p] <= 0) atomicAdd(&out[1], 1ull);
+      if (p < 0 || p >= n_halves) atomicAdd(&out[1], 1ull);
     }
   }
-  for (int64_t q = t0; q < n_halves; q += stride) {
-    const int32_t r = H.rc[q];
-    if (r > 0) {
-      atomicAdd(&out[2], (unsigned long long)r);
-      atomicAdd(&out[3], 1ull);
-    } else if (r < 0) {
-      atomicAdd(&out[1], 1ull);
-    }
-  }
-  if (t0 == 0) out[4] = (unsigned long long)*H.top;
+  for (int64_t q = t0; q < n_halves; q += stride)
+    if (mark[q]) atomicAdd(&out[3], 1ull);
 }
 
 extern "C" int gnx_debug_halves(gnx_state* h, int64_t* out) {
@@ -703,45 +798,25 @@ extern "C" int gnx_debug_halves(gnx_state* h, int64_t* out) {
     return 1;
   }
   GNXCHK(gnx_xo_join(h));
-  GNXCHK(gnx_halves_ready(h));
   unsigned long long* d = nullptr;
   HIPCHK(hipMalloc((void**)&d, 5 * sizeof(unsigned long long)));
   HIPCHK(hipMemsetAsync(d, 0, 5 * sizeof(unsigned long long), h->stream));
   const int64_t n_halves = (int64_t)h->cfg.cap_rows * h->row_spread * 2 * h->NB;
+  // marks as the collector would set them (its sweep clears them again)
+  if (h->N > 0)
+    hipLaunchKernelGGL(k_gc_mark, dim3(2048), dim3(256), 0, h->stream, h->N, h->soa[h->cur].grow,
+                       gnx_halves(h), h->half_mark);
   hipLaunchKernelGGL(k_half_check, dim3(1024), dim3(256), 0, h->stream, h->N, h->soa[h->cur].grow,
-                     gnx_halves(h), n_halves, d);
+                     gnx_halves(h), n_halves, (const uint8_t*)h->half_mark, d);
   unsigned long long host[5];
   int rc = gnx_d2h(h, host, d, sizeof(host));
   (void)hipFree(d);
   GNXCHK(rc);
+  GNXCHK(gnx_gc(h));                 // collects, clears the marks, counts the free blocks
   for (int k = 0; k < 5; ++k) out[k] = (int64_t)host[k];
+  out[0] *= h->NB;
+  out[2] = h->gc_runs;
+  out[4] = h->half_free_est;
   out[5] = 2 * h->cfg.cap_rows * h->NB;
-  out[0] *= h->NB;      // in units of blocks, like the other counts
-  return 0;
-}
-
-// ---------------------------------------------------------------- shared blocks
-// the blocks the job builders shared since the last flush get their new referrers counted
-__global__ void k_share_refs(const int32_t* __restrict__ share, int32_t* __restrict__ n_share,
-                             int32_t* __restrict__ rc, int32_t* __restrict__ done) {
-  const int n = *n_share;
-  const int stride = gridDim.x * blockDim.x;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) atomicAdd(&rc[share[i]], 1);
-  // the last block out empties the list
-  __shared__ int last;
-  __syncthreads();
-  if (threadIdx.x == 0) last = atomicAdd(done, 1) == (int)gridDim.x - 1;
-  __syncthreads();
-  if (last && threadIdx.x == 0) {
-    *n_share = 0;
-    *done = 0;
-  }
-}
-
-int gnx_share_flush(gnx_state* h, hipStream_t st) {
-  if (!h->half_share) return 0;
-  hipLaunchKernelGGL(k_share_refs, dim3(256), dim3(256), 0, st, (const int32_t*)h->half_share,
-                     h->half_n_share, h->half_rc, h->half_n_share + 1);
-  HIPCHK(hipGetLastError());
   return 0;
 }

@@ -1069,7 +1069,10 @@ int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out, 
            h->step, h->cfg.seed};
   hipLaunchKernelGGL(k_pair_flags, dim3(nb), dim3(256), 0, h->stream, pp, s, h->flag2, h->blk_cnt);
   const int64_t seq = ++h->pin_seq;
-  GNXCHK(gnx_block_scan(h, 1, N, h->blk_cnt, h->blk_off, h->cnt_dev, h->h_pin_dev + 4, seq));
+  // (the height of the free-block stack rides along: the host's count of it is exact again)
+  const bool with_top = h->half_top && h->genomes_assigned;
+  GNXCHK(gnx_block_scan(h, 1, N, h->blk_cnt, h->blk_off, h->cnt_dev, h->h_pin_dev + 4, seq, nullptr,
+                        with_top ? h->half_top : nullptr));
   // (the population was sorted by gnx_l_sort_by_cell with this idbits: max_id has not moved)
   hipLaunchKernelGGL(k_pair_compact, dim3(nb), dim3(256), 0, h->stream, N, focal, h->mate,
                      h->flag2, h->blk_off, s.x, s.y, h->key64[1], gnx_id_bits(h), h->pairs,
@@ -1089,6 +1092,7 @@ int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out, 
   // behind it (pair list, midpoint density) keep the GPU busy while the host goes on
   GNXCHK(gnx_wait_published(h, 4, seq));
   h->n_pairs = h->h_pin[4];
+  if (with_top) h->half_free_est = h->h_pin[16];
   *n_pairs_out = h->n_pairs;
   if (!with_density) h->spl_P.valid = false;
   else if (h->n_pairs == 0) h->spl_P.valid = false;

@@ -119,7 +119,8 @@ int gnx_prim_sort32_bits(void* tmp, size_t bytes, const uint32_t* kin, uint32_t*
 // out[k] = total of array k; `host` (pinned, device-visible) receives the same numbers.
 __global__ void __launch_bounds__(1024)
 k_block_scan(int K, int nb, int stride, const int32_t* __restrict__ cnt, int32_t* __restrict__ off,
-             int32_t* __restrict__ out, int64_t* __restrict__ host, long long seq) {
+             int32_t* __restrict__ out, int64_t* __restrict__ host, long long seq,
+             const int32_t* __restrict__ extra) {
   __shared__ int wsum[16];
   __shared__ int carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -155,6 +156,7 @@ k_block_scan(int K, int nb, int stride, const int32_t* __restrict__ cnt, int32_t
       if (out) out[k] = totals[k];
       if (host) host[k] = totals[k];
     }
+    if (host && extra) host[12] = (int64_t)*extra;    // one more word for the host
     // a host that polls host[3] for `seq` (gnx_wait_published) sees the totals first
     if (host && seq)
       __hip_atomic_store(&host[3], (int64_t)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -162,10 +164,10 @@ k_block_scan(int K, int nb, int stride, const int32_t* __restrict__ cnt, int32_t
 }
 
 int gnx_block_scan(gnx_state* h, int K, int64_t n_items, const int32_t* cnt, int32_t* off,
-                   int32_t* out, int64_t* host, int64_t seq, hipStream_t st) {
+                   int32_t* out, int64_t* host, int64_t seq, hipStream_t st, const int32_t* extra) {
   const int nb = (int)((n_items + GNX_CB - 1) / GNX_CB);
   hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, st ? st : h->stream, K, nb, h->blk_stride, cnt, off,
-                     out, host, (long long)seq);
+                     out, host, (long long)seq, extra);
   HIPCHK(hipGetLastError());
   return 0;
 }

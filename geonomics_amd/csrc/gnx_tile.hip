@@ -281,7 +281,7 @@ static int import_common(gnx_state* h, int64_t n, const gnx_ind_rec* rec, const 
     GNXCHK(gnx_h2d(h, d_z, z, n * c.n_traits * sizeof(float)));
   }
   GnxSoA s = h->soa[h->cur];
-  GNXCHK(gnx_halves_ready(h));
+  if (rows && !ghost) GNXCHK(gnx_half_reserve(h, 2 * (int64_t)h->NB * n));
   hipLaunchKernelGGL(k_unpack, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, h->N, n,
                      c.cap_inds, s, d_rec, d_z, c.n_traits, c.n_layers, h->rast, c.W, c.H,
                      h->free_rows, h->n_free, rows ? 1 : 0, ghost,
@@ -877,7 +877,7 @@ static int import_device(gnx_state* h, int64_t n, const gnx_ind_rec* d_rec, cons
     return 1;
   }
   GnxSoA s = h->soa[h->cur];
-  GNXCHK(gnx_halves_ready(h));
+  if (rows && !ghost) GNXCHK(gnx_half_reserve(h, 2 * (int64_t)h->NB * n));
   hipLaunchKernelGGL(k_unpack, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, h->N, n,
                      c.cap_inds, s, d_rec, (d_z && c.n_traits) ? d_z : nullptr, c.n_traits,
                      c.n_layers, h->rast, c.W, c.H, h->free_rows, h->n_free, rows ? 1 : 0, ghost,

@@ -40,8 +40,8 @@ struct alignas(16) GnxXoJob {
 };
 
 // One gamete of a child that has logical row `row`, block by block: a block without a
-// switch point refers to the parent's block (listed in H.share: its count is raised off the
-// critical path), a block with one gets a fresh physical block and a crossover job.  A
+// switch point refers to the parent's block (neither may take a mutation in place from now
+// on), a block with one gets a fresh physical block and a crossover job.  A
 // ghost parent (prow < 0, tiled run: the gamete arrives from the tile that owns it) and
 // dense masks (bp_off == null) get fresh blocks throughout, the former without jobs.
 // Called by all lanes of a wave (act = this lane has a gamete).
@@ -61,13 +61,12 @@ __device__ __forceinline__ void gnx_xo_gamete(const GnxHalves& H, bool act, int3
     const bool shared = act && !fresh;
     const int64_t lb = ((int64_t)row * 2 + p) * H.NB + b;
     const int32_t dst = gnx_half_new(H, lb, fresh);
-    int32_t src = -1;
     if (shared) {
-      src = H.hmap[((int64_t)prow * 2 + ((sel >> b) & 1u)) * H.NB + b];
-      H.hmap[lb] = src;
+      const int64_t plb = ((int64_t)prow * 2 + ((sel >> b) & 1u)) * H.NB + b;
+      H.hmap[lb] = H.hmap[plb];
+      H.own[lb] = 0;
+      H.own[plb] = 0;
     }
-    const int32_t si = gnx_wave_append(H.n_share, shared);
-    if (shared) H.share[si] = src;
     const bool job = fresh && local;
     const int32_t idx = gnx_wave_append(n_jobs, job);
     if (job) {

@@ -202,10 +202,11 @@ int gnx_set_crossover_overlap(gnx_state* h, int32_t mode);
  * on it. */
 int gnx_set_crossover_split(gnx_state* h, int32_t wide_per_1024);
 /* Bookkeeping of the shared genome blocks (where a gamete's path has no switch point the
- * child refers to the parent's block instead of copying it): out[6] = logical blocks of the
- * individuals that have a genome row / 2, broken references, sum of reference counts,
- * physical blocks in use, free physical blocks, physical blocks in all.  Consistent iff
- * out[1] == 0, out[2] == 2 * out[0], out[3] + out[4] == out[5]. */
+ * child refers to the parent's block instead of copying it; blocks nobody alive refers to
+ * are found by a mark-and-sweep collection when the free stack runs low).  Runs a
+ * collection, then out[6] = logical blocks of the individuals that have a genome row / 2,
+ * broken references, collections so far, physical blocks in use, free physical blocks,
+ * physical blocks in all.  Consistent iff out[1] == 0 and out[3] + out[4] == out[5]. */
 int gnx_debug_halves(gnx_state* h, int64_t* out);
 /* measurement: the job list of the last crossover, 16 bytes per copied block {the
  * parent's two physical blocks, the block written, (path * 2 + start homologue) | block

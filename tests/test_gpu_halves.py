@@ -3,7 +3,7 @@ switch point the gamete is the parent's homologue bit for bit (ops/mating.py:165
 subsetter is constant there), so the child refers to the parent's block instead of copying
 it.  Nothing visible may depend on that: same genotypes as with every gamete copied and
 with any number of blocks per homologue, a mutation reaches the mutated individual only,
-and the reference counts add up.  Needs an MI355X."""
+and after a collection every block is either in use or free.  Needs an MI355X."""
 import numpy as np
 import pytest
 
@@ -38,10 +38,11 @@ def _model(seed=23, defer=True, L=L):
 
 
 def _check(dev):
-    rows, broken, refs, used, free, total = (int(v) for v in dev.debug_halves())
+    # (after a collection: every physical block is either referred to by somebody alive or free)
+    rows, broken, _gc_runs, used, free, total = (int(v) for v in dev.debug_halves())
     assert broken == 0
-    assert refs == 2 * rows
     assert used + free == total
+    assert used <= 2 * rows
     return rows, used
 
 

@@ -24,7 +24,7 @@ for t in range(1, steps + 1):
     if t % every == 0 or t == steps:
         rows, broken, refs, used, free, total = (int(v) for v in dev.debug_halves())
         n, b, d = dev.counts()
-        ok = broken == 0 and refs == 2 * rows and used + free == total
+        ok = broken == 0 and used + free == total and used <= 2 * rows
         print('step %5d  N=%d births=%d deaths=%d  blocks: logical %d  physical in use %d '
               '(%.1f %% shared)  free %d  %s  %.1f s' % (
                   t, n, b, d, 2 * rows, used, 100.0 * (1 - used / max(2 * rows, 1)), free,

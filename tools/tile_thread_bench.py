@@ -53,7 +53,7 @@ def body(rank):
             n = st.step(False, True)
             if check and (k + 1) % check == 0:
                 rows, broken, refs, used, free, total = (int(v) for v in dev.debug_halves())
-                assert broken == 0 and refs == 2 * rows and used + free == total, (
+                assert broken == 0 and used + free == total and used <= 2 * rows, (
                     rank, k, rows, broken, refs, used, free, total)
                 if rank == 0:
                     print('step %d: N=%s, blocks consistent on every tile (rank 0: %d logical, '
