@@ -18,17 +18,20 @@
 // atomic count updates in every step.  The live blocks never outnumber 2 * NB x (logical
 // rows in use), and the host makes sure before every kernel that pops blocks that the stack
 // holds enough (gnx_half_reserve: it collects first if it may not), so the stack cannot
-// run dry while logical rows are left.  own[lb] says that logical block lb was cut for its
-// individual and never shared: only such a block may take a mutation in place.
+// run dry while logical rows are left.  The top bit of a table entry (GNX_OWN) says that the
+// block was cut for this individual and never shared: only such a block may take a mutation
+// in place.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #define GNX_MAX_NB 16
 
+#define GNX_OWN 0x80000000u      // table entry: the block belongs to this logical block alone
+#define GNX_BLK(e) ((int32_t)((uint32_t)(e) & 0x7fffffffu))
+
 struct GnxHalves {
-  int32_t* hmap;    // [2 * row span * NB]  logical block -> physical block
-  uint8_t* own;     // [2 * row span * NB]  1: the physical block belongs to this logical block alone
+  int32_t* hmap;    // [2 * row span * NB]  logical block -> physical block | GNX_OWN
   int32_t* stack;   // free physical blocks
   int32_t* top;     // how many
   int NB;           // blocks per homologue
@@ -38,13 +41,13 @@ struct GnxHalves {
 // word w of logical half lh
 __device__ __forceinline__ int64_t gnx_word_at(const GnxHalves& H, int64_t lh, int w) {
   const int b = w / H.BW;
-  return (int64_t)H.hmap[lh * H.NB + b] * H.BW + (w - b * H.BW);
+  return (int64_t)GNX_BLK(H.hmap[lh * H.NB + b]) * H.BW + (w - b * H.BW);
 }
 // 16-byte chunk c of logical half lh (index into a u64x2 view of the table)
 __device__ __forceinline__ int64_t gnx_chunk_at(const GnxHalves& H, int64_t lh, int c) {
   const int bw16 = H.BW >> 1;
   const int b = c / bw16;
-  return (int64_t)H.hmap[lh * H.NB + b] * bw16 + (c - b * bw16);
+  return (int64_t)GNX_BLK(H.hmap[lh * H.NB + b]) * bw16 + (c - b * bw16);
 }
 
 // wave-aggregated pop: every lane with want == true gets a free physical block
@@ -77,10 +80,7 @@ __device__ __forceinline__ int32_t gnx_wave_append(int32_t* counter, bool want) 
 // a fresh physical block for logical block lb (= lh * NB + b)
 __device__ __forceinline__ int32_t gnx_half_new(const GnxHalves& H, int64_t lb, bool want) {
   const int32_t p = gnx_half_pop(H, want);
-  if (want) {
-    H.own[lb] = 1;
-    H.hmap[lb] = p;
-  }
+  if (want) H.hmap[lb] = (int32_t)((uint32_t)p | GNX_OWN);
   return p;
 }
 

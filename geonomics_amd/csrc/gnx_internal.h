@@ -128,10 +128,9 @@ struct gnx_state {
   int row_spread = 1;
   int32_t* free_rows = nullptr;
   int64_t n_free = 0;
-  // physical blocks (gnx_half.h): hmap / half_own / half_mark over 2 * cap_rows * row_spread * NB blocks,
+  // physical blocks (gnx_half.h): hmap / half_mark over 2 * cap_rows * row_spread * NB blocks,
   // the stack of free ones and its height on the device
   int32_t* hmap = nullptr;
-  uint8_t* half_own = nullptr;         // logical block cut for its individual, never shared
   uint8_t* half_mark = nullptr;        // physical block referred to by somebody alive (gnx_gc)
   int32_t* half_free = nullptr;
   int32_t* half_top = nullptr;
@@ -350,7 +349,7 @@ struct gnx_state {
 GnxTraitTab gnx_trait_tab(const gnx_state* h);
 
 static inline GnxHalves gnx_halves(const gnx_state* h) {
-  return GnxHalves{h->hmap, h->half_own, h->half_free, h->half_top, h->NB, h->W64 / h->NB};
+  return GnxHalves{h->hmap, h->half_free, h->half_top, h->NB, h->W64 / h->NB};
 }
 // Before a kernel that pops up to `blocks` physical blocks: the free stack holds that many
 // (a mark-and-sweep collection runs first if the host cannot be sure, gnx_gc).

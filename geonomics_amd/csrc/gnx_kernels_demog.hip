@@ -658,12 +658,11 @@ k_xo_jobs_surv(int64_t N, int64_t first, int32_t* __restrict__ grow,
       for (int q = 0; q < NB; ++q) {
         if ((mixed[r][p] >> q) & 1u) {
           const int32_t dst = H.stack[pop0 - 1 - pi++];
-          H.own[lh * NB + q] = 1;
-          H.hmap[lh * NB + q] = dst;
+          H.hmap[lh * NB + q] = (int32_t)((uint32_t)dst | GNX_OWN);
           if (local) {
             GnxXoJob j;
-            j.ph0 = H.hmap[ph0 + q];
-            j.ph1 = H.hmap[ph0 + NB + q];
+            j.ph0 = GNX_BLK(H.hmap[ph0 + q]);
+            j.ph1 = GNX_BLK(H.hmap[ph0 + NB + q]);
             j.dst = dst;
             j.ks = ks[r][p] | (q << 24);
             jobs[job0 + ji++] = j;
@@ -671,9 +670,9 @@ k_xo_jobs_surv(int64_t N, int64_t first, int32_t* __restrict__ grow,
         } else {
           // shared with the parent: neither may take a mutation in place from now on
           const int64_t plb = ph0 + ((sel[r][p] >> q) & 1u) * NB + q;
-          H.hmap[lh * NB + q] = H.hmap[plb];
-          H.own[lh * NB + q] = 0;
-          H.own[plb] = 0;
+          const int32_t e = H.hmap[plb];
+          H.hmap[lh * NB + q] = GNX_BLK(e);
+          if (e < 0) H.hmap[plb] = GNX_BLK(e);   // (only the first child to share it writes)
         }
       }
     }

@@ -499,8 +499,7 @@ __global__ void k_assign_rows(int64_t N, int64_t cap_rows, int spread, int32_t* 
     grow[i] = row;
     // every individual starts with its own blocks, at its logical row's address
     for (int q = 0; q < 2 * H.NB; ++q) {
-      H.hmap[(int64_t)row * 2 * H.NB + q] = row * 2 * H.NB + q;
-      H.own[(int64_t)row * 2 * H.NB + q] = 1;
+      H.hmap[(int64_t)row * 2 * H.NB + q] = (int32_t)((uint32_t)(row * 2 * H.NB + q) | GNX_OWN);
     }
   }
   // free stacks: rows N..cap_rows-1 (row numbers are physical: x spread) and their blocks,
@@ -554,10 +553,9 @@ __global__ void k_mutate(int n, u64* G, const int32_t* grow, GnxHalves H, const 
   if (i < n) {
     const int l = locus[i];
     const int w = l >> 6, b = w / H.BW;
-    const int64_t lb = ((int64_t)grow[slot[i]] * 2 + hom[i]) * H.NB + b;
-    shared = H.own[lb] == 0;
-    if (!shared)
-      atomicOr(G + (int64_t)H.hmap[lb] * H.BW + (w - b * H.BW), 1ull << (l & 63));
+    const int32_t e = H.hmap[((int64_t)grow[slot[i]] * 2 + hom[i]) * H.NB + b];
+    shared = e >= 0;
+    if (!shared) atomicOr(G + (int64_t)GNX_BLK(e) * H.BW + (w - b * H.BW), 1ull << (l & 63));
   }
   const int32_t idx = gnx_wave_append(n_list, shared);
   if (shared) list[idx] = i;
@@ -574,12 +572,11 @@ k_mutate_shared(const int32_t* list, const int32_t* n_list, u64* G, const int32_
     const int w = l >> 6, b = w / H.BW;
     if (threadIdx.x == 0) {
       const int64_t lb = ((int64_t)grow[slot[i]] * 2 + hom[i]) * H.NB + b;
-      const int32_t p = H.hmap[lb];
-      s_old = s_new = p;
-      if (!H.own[lb]) {            // (an earlier mutation of this list may have copied it already)
+      const int32_t e = H.hmap[lb];
+      s_old = s_new = GNX_BLK(e);
+      if (e >= 0) {                // (an earlier mutation of this list may have copied it already)
         const int32_t q = H.stack[atomicSub(H.top, 1) - 1];
-        H.own[lb] = 1;
-        H.hmap[lb] = q;
+        H.hmap[lb] = (int32_t)((uint32_t)q | GNX_OWN);
         s_new = q;
       }
     }
@@ -683,7 +680,7 @@ __global__ void k_gc_mark(int64_t N, const int32_t* __restrict__ grow, GnxHalves
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < N * per; t += stride) {
     const int64_t i = t / per;
     const int32_t row = grow[i];
-    if (row >= 0) mark[H.hmap[(int64_t)row * per + (t - i * per)]] = 1;
+    if (row >= 0) mark[GNX_BLK(H.hmap[(int64_t)row * per + (t - i * per)])] = 1;
   }
 }
 
@@ -784,8 +781,8 @@ __global__ void k_half_check(int64_t N, const int32_t* grow, GnxHalves H, int64_
     if (row < 0) continue;
     atomicAdd(&out[0], 1ull);
     for (int q = 0; q < 2 * H.NB; ++q) {
-      const int32_t p = H.hmap[(int64_t)row * 2 * H.NB + q];
-      if (p < 0 || p >= n_halves) atomicAdd(&out[1], 1ull);
+      const int32_t e = H.hmap[(int64_t)row * 2 * H.NB + q];
+      if (e == -1 || GNX_BLK(e) >= n_halves) atomicAdd(&out[1], 1ull);
     }
   }
   for (int64_t q = t0; q < n_halves; q += stride)

@@ -63,16 +63,16 @@ __device__ __forceinline__ void gnx_xo_gamete(const GnxHalves& H, bool act, int3
     const int32_t dst = gnx_half_new(H, lb, fresh);
     if (shared) {
       const int64_t plb = ((int64_t)prow * 2 + ((sel >> b) & 1u)) * H.NB + b;
-      H.hmap[lb] = H.hmap[plb];
-      H.own[lb] = 0;
-      H.own[plb] = 0;
+      const int32_t e = H.hmap[plb];
+      H.hmap[lb] = GNX_BLK(e);
+      if (e < 0) H.hmap[plb] = GNX_BLK(e);        // the parent's block is shared from now on
     }
     const bool job = fresh && local;
     const int32_t idx = gnx_wave_append(n_jobs, job);
     if (job) {
       GnxXoJob j;
-      j.ph0 = H.hmap[((int64_t)prow * 2) * H.NB + b];
-      j.ph1 = H.hmap[((int64_t)prow * 2 + 1) * H.NB + b];
+      j.ph0 = GNX_BLK(H.hmap[((int64_t)prow * 2) * H.NB + b]);
+      j.ph1 = GNX_BLK(H.hmap[((int64_t)prow * 2 + 1) * H.NB + b]);
       j.dst = dst;
       j.ks = (key * 2 + st) | (b << 24);
       jobs[idx] = j;
