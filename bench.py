@@ -496,8 +496,8 @@ def main():
             return {'mode': label, 'value': n_alt / dt, 'ms_per_step': 1e3 * dt / k_alt,
                     'steps': k_alt, 'crossover_avg_launch_ms': kx['ms'] / max(kx['launches'], 1),
                     'crossover_achieved_GBps': a_gbps, 'crossover_frac': a_gbps / 8000.0}
-        alone = other_mode(2, 'nothing runs beside the crossover (compaction, reference counts '
-                              'and the next movement wait for it)')
+        alone = other_mode(2, 'nothing runs beside the crossover (the compactions and the next '
+                              'movement wait for it)')
         alt = other_mode(1, 'crossover (8 workgroups per CU) beside the whole next step: nothing waits '
                              'for it but the next crossover')
     phases = None

@@ -191,7 +191,7 @@ int gnx_counts(gnx_state* h, int64_t* N, int64_t* births, int64_t* deaths);
  * way (draws are keyed by id); any genome access in between triggers the off path.      */
 int gnx_set_defer_crossover(gnx_state* h, int32_t on);
 /* How the deferred crossover shares the GPU with the next step's kernels.  0 (default):
- * it runs at full width beside the compaction, the reference-count updates and the next
+ * it runs at full width beside the compaction, the sort index's compaction and the next
  * movement; the next cell sort waits for it.  1: a narrow crossover runs beside the
  * WHOLE next step.  2: nothing runs beside it (the kernel's own rate; a slower step).
  * Results do not depend on the mode.                                                   */

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Long run of the metric workload with the bookkeeping checked along the way: the
-reference counts of the shared genome blocks add up (gnx_debug_halves), blocks in use
+tables of the shared genome blocks are sound after a collection (gnx_debug_halves), blocks in use
 level off (no leak), the population stays at its carrying capacity.
     python tools/soak.py [steps] [check every]"""
 import os
