@@ -136,6 +136,7 @@ struct gnx_state {
   int32_t* half_top = nullptr;
   int64_t half_free_est = 0;           // free blocks the host can count on (a lower bound)
   int64_t gc_runs = 0;
+  void* xo_plan = nullptr;             // [cap] GnxXoPlan: what the job builder decided per offspring
   int32_t* gc_cnt = nullptr;           // block counts / offsets of the collector's sweep
   int32_t* gc_off = nullptr;
   int NB = 1;                          // blocks per homologue (gnx_half.h), BW = W64 / NB words

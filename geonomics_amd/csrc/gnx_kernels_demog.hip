@@ -554,6 +554,15 @@ k_alive(int64_t N, const double* p_death, const uint8_t* dead_in, const int64_t*
   }
 }
 
+struct GnxXoPlan {
+  int32_t row;          // the offspring's logical row (-1: it gets none)
+  int32_t pop, job;     // stack index of its first fresh block, its first slot in the job list
+  int32_t prow[2];      // the parents' rows (-1: ghost)
+  int32_t mixsel[2];    // blocks with a switch point | homologue at each block's start << 16
+  int32_t ks[2];        // path * 2 + start homologue
+  int32_t pad;
+};
+
 // Crossover jobs of the surviving offspring whose crossover was deferred (alive[] bit 1):
 // the rank among them picks the row from the top of the free stack.  Offspring that died
 // at age 0 never get a row; offspring that already have one (their mate was a ghost: the
@@ -564,8 +573,8 @@ k_xo_jobs_surv(int64_t N, int64_t first, int32_t* __restrict__ grow,
                const int32_t* __restrict__ off_parent, const int32_t* __restrict__ off_keys,
                const uint8_t* __restrict__ off_start, const int32_t* __restrict__ free_rows,
                int64_t n_free, GnxHalves H, const int32_t* __restrict__ bp_off,
-               const int32_t* __restrict__ bp_loci, GnxXoJob* __restrict__ jobs,
-               int32_t* __restrict__ n_jobs) {
+               const int32_t* __restrict__ bp_loci, int32_t* __restrict__ n_jobs,
+               GnxXoPlan* __restrict__ plan) {
   __shared__ int lds[16];
   __shared__ int s_pop, s_job;
   const int64_t b = first / GNX_CB + blockIdx.x;
@@ -646,36 +655,68 @@ k_xo_jobs_surv(int64_t N, int64_t first, int32_t* __restrict__ grow,
   }
   __syncthreads();
   const int pop0 = s_pop, job0 = s_job;
+  // the plan of every surviving offspring; k_xo_jobs_write carries it out, one thread per
+  // logical block
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    if (!fx[r]) continue;
-    int pi = of[r], ji = oj[r];
+    const int64_t i = base + r * 256 + threadIdx.x;
+    if (i < first || i >= N) continue;
+    GnxXoPlan P;
+    P.row = fx[r] ? row[r] : -1;
+    P.pop = pop0 - 1 - of[r];          // stack index of its first fresh block (they go downwards)
+    P.job = job0 + oj[r];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      const bool local = prow[r][p] >= 0;
-      const int64_t lh = (int64_t)row[r] * 2 + p;
-      const int64_t ph0 = (int64_t)(local ? prow[r][p] : 0) * 2 * NB;
-      for (int q = 0; q < NB; ++q) {
-        if ((mixed[r][p] >> q) & 1u) {
-          const int32_t dst = H.stack[pop0 - 1 - pi++];
-          H.hmap[lh * NB + q] = (int32_t)((uint32_t)dst | GNX_OWN);
-          if (local) {
-            GnxXoJob j;
-            j.ph0 = GNX_BLK(H.hmap[ph0 + q]);
-            j.ph1 = GNX_BLK(H.hmap[ph0 + NB + q]);
-            j.dst = dst;
-            j.ks = ks[r][p] | (q << 24);
-            jobs[job0 + ji++] = j;
-          }
-        } else {
-          // shared with the parent: neither may take a mutation in place from now on
-          const int64_t plb = ph0 + ((sel[r][p] >> q) & 1u) * NB + q;
-          const int32_t e = H.hmap[plb];
-          H.hmap[lh * NB + q] = GNX_BLK(e);
-          if (e < 0) H.hmap[plb] = GNX_BLK(e);   // (only the first child to share it writes)
-        }
-      }
+      P.prow[p] = prow[r][p];
+      P.mixsel[p] = (mixed[r][p] & 0xffffu) | (sel[r][p] << 16);
+      P.ks[p] = ks[r][p];
     }
+    plan[i - first] = P;
+  }
+}
+
+// One thread per logical block of every offspring that got a row: the block refers to the
+// parent's block where the path has no switch point (neither may take a mutation in place
+// from now on), or takes a fresh block and, with a local parent, a job.  Which fresh block
+// and which job slot follow from the plan's offsets and the ranks of the block among the
+// offspring's cut blocks - no thread waits for another.
+__global__ void __launch_bounds__(256)
+k_xo_jobs_write(int64_t B, GnxHalves H, const GnxXoPlan* __restrict__ plan,
+                GnxXoJob* __restrict__ jobs) {
+  const int NB = H.NB;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * 2 * NB) return;
+  const int64_t k = t / (2 * NB);
+  const int rem = (int)(t - k * 2 * NB);
+  const int p = rem / NB, q = rem - p * NB;
+  const GnxXoPlan P = plan[k];
+  if (P.row < 0) return;
+  const unsigned int all = (1u << NB) - 1u;
+  const unsigned int m0 = P.mixsel[0] & all, m1 = P.mixsel[1] & all;
+  const unsigned int mixed = p ? m1 : m0, sel = (unsigned int)P.mixsel[p] >> 16;
+  const unsigned int below = (1u << q) - 1u;
+  const bool local = P.prow[p] >= 0;
+  const int64_t lb = ((int64_t)P.row * 2 + p) * NB + q;
+  const int64_t ph0 = (int64_t)(local ? P.prow[p] : 0) * 2 * NB;
+  if ((mixed >> q) & 1u) {
+    // rank among the offspring's cut blocks (gamete 0 first), among its jobs likewise
+    const int fr = (p ? __popc(m0) : 0) + __popc(mixed & below);
+    const int jr = (p && P.prow[0] >= 0 ? __popc(m0) : 0) + __popc(mixed & below);
+    const int32_t dst = H.stack[P.pop - fr];
+    H.hmap[lb] = (int32_t)((uint32_t)dst | GNX_OWN);
+    if (local) {
+      GnxXoJob j;
+      j.ph0 = GNX_BLK(H.hmap[ph0 + q]);
+      j.ph1 = GNX_BLK(H.hmap[ph0 + NB + q]);
+      j.dst = dst;
+      j.ks = P.ks[p] | (q << 24);
+      jobs[P.job + jr] = j;
+    }
+  } else {
+    const int64_t plb = ph0 + ((sel >> q) & 1u) * NB + q;
+    const int32_t e = H.hmap[plb];
+    H.hmap[lb] = GNX_BLK(e);
+    if (e < 0) H.hmap[plb] = GNX_BLK(e);     // (only the first child to share it writes)
   }
 }
 
@@ -732,8 +773,10 @@ void gnx_launch_xo_jobs_surv(gnx_state* h, int64_t first_slot, const int32_t* d_
   hipLaunchKernelGGL(k_xo_jobs_surv, dim3(nbj), dim3(256), 0, h->stream, N, first_slot,
                      h->soa[h->cur].grow, d_alive, d_blk_off + 2 * h->blk_stride, h->off_parent,
                      h->off_keys, h->off_start, h->free_rows, h->n_free, gnx_halves(h),
-                     gnx_alias_bp(h), gnx_alias_loci(h), (GnxXoJob*)h->jobs[buf],
-                     h->n_jobs_dev[buf]);
+                     gnx_alias_bp(h), gnx_alias_loci(h), h->n_jobs_dev[buf], (GnxXoPlan*)h->xo_plan);
+  const int64_t B = N - first_slot;
+  hipLaunchKernelGGL(k_xo_jobs_write, dim3(gnx_grid(B * 2 * h->NB, 256)), dim3(256), 0, h->stream,
+                     B, gnx_halves(h), (const GnxXoPlan*)h->xo_plan, (GnxXoJob*)h->jobs[buf]);
 }
 
 // The id-ordered index follows the compaction: entry k (slot ord[k], or slot k itself for the
