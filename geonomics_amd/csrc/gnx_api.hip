@@ -302,6 +302,7 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
                           (double)h->cfg.cap_rows * h->row_spread * 2.0 * want >= 2.0e9))
         --want;
       h->NB = want;
+      h->NB_alloc = want;
     }
     const size_t halves = (size_t)h->cfg.cap_rows * h->row_spread * 2 * h->NB;
     GNXCHK(dalloc(&h->hmap, halves));
@@ -722,6 +723,10 @@ extern "C" int gnx_set_recomb_paths(gnx_state* h, int32_t n, const uint64_t* pat
     max_bp = std::max(max_bp, cnt);
   }
   h->sparse_paths = max_bp <= GNX_SPARSE_MAX_BP;
+  // dense masks switch in every block: nothing can be shared, and whole homologues stream
+  // better than 1.8-KB pieces (6.9 against 6.6 TB/s) - one block per homologue then, as long
+  // as no genome has been laid out yet
+  if (!h->genomes_assigned) h->NB = h->sparse_paths ? h->NB_alloc : 1;
   h->n_paths = n;
   // padding bits beyond L must be zero so children keep zero padding
   std::vector<uint64_t> clean(paths, paths + (size_t)n * W64);

@@ -140,6 +140,7 @@ struct gnx_state {
   int32_t* gc_cnt = nullptr;           // block counts / offsets of the collector's sweep
   int32_t* gc_off = nullptr;
   int NB = 1;                          // blocks per homologue (gnx_half.h), BW = W64 / NB words
+  int NB_alloc = 1;                    // what the tables were sized for (NB <= NB_alloc)
   hipStream_t stream3 = nullptr;       // the compaction of the id-ordered sort index
   hipEvent_t ev_compact = nullptr;
   bool alias_xo = true;          // blocks without a switch point are shared with the parent
