@@ -19,8 +19,15 @@ for _ in range(3):
     dev.step(True, False)
 bench.setup_genomes(dev, cfg, 42)
 t0 = time.time()
+import numpy as np                                      # noqa: E402
+n_mut = int(os.environ.get('GNX_SOAK_MUTATE', '0'))    # random mutations per step (copy-on-write)
+rng = np.random.RandomState(1)
 for t in range(1, steps + 1):
     dev.step(False, True)
+    if n_mut:
+        dev.mutate(rng.randint(0, dev.N, n_mut).astype(np.int64),
+                   rng.randint(0, cfg['L'], n_mut).astype(np.int32),
+                   rng.randint(0, 2, n_mut).astype(np.uint8))
     if t % every == 0 or t == steps:
         rows, broken, refs, used, free, total = (int(v) for v in dev.debug_halves())
         n, b, d = dev.counts()
