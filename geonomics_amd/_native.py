@@ -46,6 +46,7 @@ EXPORTS = [
     'gnx_tile_offspring_dev', 'gnx_tile_group_requests', 'gnx_tile_serve_gametes_dev',
     'gnx_tile_put_gametes_dev', 'gnx_tile_bins_ptr', 'gnx_set_k_raster', 'gnx_last_births', 'gnx_set_positions', 'gnx_n_slots', 'gnx_stats_ld_counts',
     'gnx_set_defer_crossover', 'gnx_last_crossover_births', 'gnx_set_crossover_overlap', 'gnx_set_crossover_split', 'gnx_debug_halves', 'gnx_spatial_diff_sums', 'gnx_last_crossover_jobs',
+    'gnx_genome_info',
 ]
 
 
@@ -304,6 +305,14 @@ class Device:
         out = np.zeros(6, np.int64)
         self._chk(self.lib.gnx_debug_halves(self.h, _ptr(out, C.c_int64)))
         return out
+
+    def genome_info(self):
+        """host-side view of the genome blocks, no device access: dict(NB, BW, gc_runs,
+        row_spread, sparse, free_blocks_est, free_rows, deferred)"""
+        out = np.zeros(8, np.int64)
+        self._chk(self.lib.gnx_genome_info(self.h, _ptr(out, C.c_int64)))
+        return dict(zip(('NB', 'BW', 'gc_runs', 'row_spread', 'sparse', 'free_blocks_est',
+                         'free_rows', 'deferred'), (int(v) for v in out)))
 
     def set_crossover_split(self, wide_per_1024):
         """share (/1024) of a deferred crossover's jobs that runs at full width before the next

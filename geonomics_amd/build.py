@@ -15,7 +15,16 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libgnxhip.so')
 SOURCES = ['gnx_api.hip', 'gnx_kernels_pop.hip', 'gnx_kernels_genome.hip',
            'gnx_kernels_demog.hip', 'gnx_tile.hip', 'gnx_stats.hip', 'gnx_prim.hip']
-HEADERS = ['gnx_internal.h', 'gnx_rng.h', 'gnx_xo.h', os.path.join('..', '..', 'include', 'gnx_hip.h')]
+
+
+def _headers():
+    # every header under csrc/ plus the public C-ABI header: editing any of
+    # them marks every object stale (an old .so must never travel to the GPU box)
+    import glob
+    return sorted(glob.glob(os.path.join(CSRC, '*.h'))) + \
+        sorted(glob.glob(os.path.join(HERE, '..', 'include', '*.h')))
+
+
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
          # IEEE-exact f32/f64 arithmetic (no fma contraction): the parity tests
          # compare against numpy evaluating the same expressions
@@ -40,7 +49,7 @@ def build(force=False, verbose=True):
     hipcc = _hipcc()
     objdir = os.path.join(CSRC, '_obj')
     os.makedirs(objdir, exist_ok=True)
-    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    hdrs = _headers()
     objs = []
     procs = []
     for src in SOURCES:

@@ -409,6 +409,7 @@ extern "C" void gnx_destroy(gnx_state* h) {
   (void)gnx_xo_launch_pending(h);
   (void)hipStreamSynchronize(h->stream);
   if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+  if (h->stream3) (void)hipStreamSynchronize(h->stream3);    // reads ord / newslot
   for (int k = 0; k < 2; ++k) {
     (void)hipFree(h->jobs[k]);
     (void)hipFree(h->n_jobs_dev[k]);
@@ -692,6 +693,11 @@ extern "C" int gnx_set_recomb_paths(gnx_state* h, int32_t n, const uint64_t* pat
     return 1;
   }
   const int W64 = h->W64, L = h->cfg.L;
+  // a crossover job packs path * 2 + start homologue into the low 24 bits of GnxXoJob.ks
+  if (n >= (1 << 23)) {
+    gnx_set_error("gnx_set_recomb_paths: at most %d cached paths (got %d)", (1 << 23) - 1, n);
+    return 1;
+  }
   GNXCHK(gnx_xo_join(h));
   HIPCHK(hipStreamSynchronize(h->stream));
   (void)hipFree(h->paths);

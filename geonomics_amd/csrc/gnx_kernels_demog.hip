@@ -859,6 +859,9 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
     GNXCHK(gnx_l_crossover_survivors(h, xo_first, xo_B, h->flag, h->blk_off));
     if (h->xo_sort_waits && h->xo_wait_at == 2) GNXCHK(gnx_xo_wait_inflight(h));
   }
+  // the index's compaction of the PREVIOUS mortality round (stream3) still reads newslot when
+  // no cell sort has waited for it in between (gnx_op_mortality right after a step)
+  if (ord_keep && h->ord_inflight) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ord, 0));
   gnx_time_begin(h);
   hipLaunchKernelGGL(k_compact, dim3(nb), dim3(256), 0, h->stream, N, c.cap_inds, h->flag,
                      h->flag2, h->blk_off, h->blk_stride, h->cnt_dev, a, b, c.n_layers, c.n_traits,

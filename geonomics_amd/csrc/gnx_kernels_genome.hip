@@ -817,3 +817,15 @@ extern "C" int gnx_debug_halves(gnx_state* h, int64_t* out) {
   out[5] = 2 * h->cfg.cap_rows * h->NB;
   return 0;
 }
+
+extern "C" int gnx_genome_info(gnx_state* h, int64_t* out) {
+  out[0] = h->NB;
+  out[1] = h->NB > 0 ? h->W64 / h->NB : 0;
+  out[2] = h->gc_runs;
+  out[3] = h->row_spread;
+  out[4] = h->sparse_paths ? 1 : 0;
+  out[5] = h->half_free_est;
+  out[6] = h->n_free;
+  out[7] = h->xo_deferred ? 1 : 0;
+  return 0;
+}

@@ -397,6 +397,23 @@ extern "C" int gnx_tile_offspring(gnx_state* h, int32_t burn, int64_t id_base,
   return 0;
 }
 
+// The gamete service reads parents' genome blocks.  Last step's deferred crossover, which
+// writes the blocks of last step's surviving newborns (parents already), may still be running
+// on stream2 (gnx_set_crossover_overlap(1), GNX_XO_SORT_WAIT=0, a split launch): the serving
+// stream waits for it unless it IS stream2 (SideStream: in order behind the crossover anyway).
+static int serve_wait_crossover(gnx_state* h, hipStream_t main_stream) {
+  if (h->stream == h->stream2 && h->stream2 != nullptr) {
+    // a crossover not launched yet would be launched on stream2 behind `main_stream`'s work
+    hipStream_t cur = h->stream;
+    h->stream = main_stream;
+    int rc = gnx_xo_launch_pending(h);
+    h->stream = cur;
+    return rc;
+  }
+  GNXCHK(gnx_xo_launch_pending(h));
+  return gnx_xo_wait_inflight(h);
+}
+
 extern "C" int gnx_tile_get_requests(gnx_state* h, int64_t* pid, int32_t* child_k, int32_t* key,
                                      uint8_t* start, float* px, float* py) {
   SideStream side(h);
@@ -479,6 +496,7 @@ extern "C" int gnx_tile_serve_gametes(gnx_state* h, int64_t n, const int64_t* pa
     }
   int64_t N = h->N;
   GnxSoA s = h->soa[h->cur];
+  GNXCHK(serve_wait_crossover(h, side.saved));
   hipLaunchKernelGGL(k_id_keys, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, s.id,
                      h->key64[0], h->perm[0]);
   GNXCHK(gnx_prim_sort64(h->sort64_tmp, h->sort64_tmp_bytes, h->key64[0], h->key64[1], h->perm[0],
@@ -1049,6 +1067,7 @@ extern "C" int gnx_tile_serve_gametes_dev(gnx_state* h, int64_t n, const void* r
   }
   const int64_t N = h->N;
   GnxSoA s = h->soa[h->cur];
+  GNXCHK(serve_wait_crossover(h, side.saved));
   hipLaunchKernelGGL(k_id_keys, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, s.id,
                      h->key64[0], h->perm[0]);
   GNXCHK(gnx_prim_sort64(h->sort64_tmp, h->sort64_tmp_bytes, h->key64[0], h->key64[1], h->perm[0],

@@ -208,6 +208,11 @@ int gnx_set_crossover_split(gnx_state* h, int32_t wide_per_1024);
  * broken references, collections so far, physical blocks in use, free physical blocks,
  * physical blocks in all.  Consistent iff out[1] == 0 and out[3] + out[4] == out[5]. */
 int gnx_debug_halves(gnx_state* h, int64_t* out);
+/* The same bookkeeping as the host sees it, WITHOUT touching the device (no join of a
+ * crossover in flight, no collection): out[8] = blocks per homologue, words per block,
+ * collections so far, row spread, sparse paths (0 / 1), free blocks the host counts on,
+ * free logical rows, 1 while offspring still wait for their deferred crossover.        */
+int gnx_genome_info(gnx_state* h, int64_t* out);
 /* measurement: the job list of the last crossover, 16 bytes per copied block {the
  * parent's two physical blocks, the block written, (path * 2 + start homologue) | block
  * index << 24} (csrc/gnx_xo.h); blocks without a switch point are not in it            */
