@@ -380,6 +380,8 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
   GNXCHK(dalloc(&h->blk_cnt, (size_t)3 * h->blk_stride));
   GNXCHK(dalloc(&h->blk_off, (size_t)3 * h->blk_stride));
   GNXCHK(dalloc(&h->cnt_dev, 8));
+  GNXCHK(dalloc(&h->tickets, 8));
+  HIPCHK(hipMemset(h->tickets, 0, 8 * sizeof(unsigned int)));
   // fine-grained: the host polls words that kernels write (gnx_wait_published)
   HIPCHK(hipHostMalloc((void**)&h->h_pin, 32 * sizeof(int64_t),
                        hipHostMallocCoherent | hipHostMallocMapped));
@@ -432,7 +434,7 @@ extern "C" void gnx_destroy(gnx_state* h) {
                   h->off_parent, h->off_keys, h->off_start, h->keep_in, h->inj_a, h->inj_b,
                   h->mid_x, h->mid_y, h->p_death, h->d_cell, h->dead_in, h->nmax_bits, h->red,
                   h->sel_loci, h->path_sel, h->lat.areas, h->lat.cprime, h->spl_N.c, h->spl_P.c, h->bin_partials, h->nodes,
-                  h->K_over, h->blk_cnt, h->blk_off, h->cnt_dev, h->gp_rec, h->gp_z, h->gp_slots, h->tile_counts, h->rq_sorted, h->rq_k, h->gam_out, h->gam_slot, h->chk};
+                  h->K_over, h->blk_cnt, h->blk_off, h->cnt_dev, h->tickets, h->gp_rec, h->gp_z, h->gp_slots, h->tile_counts, h->rq_sorted, h->rq_k, h->gam_out, h->gam_slot, h->chk};
   for (void* p : ptrs) (void)hipFree(p);
   for (int t = 0; t < GNX_MAX_TRAITS; ++t) {
     (void)hipFree(h->traits[t].loci);

@@ -331,6 +331,10 @@ struct gnx_state {
   int32_t* blk_off = nullptr;
   int blk_stride = 0;
   int32_t* cnt_dev = nullptr;        // [4]
+  // ticket counters of the kernels whose last workgroup scans the block counts
+  // (gnx_compact.h: gnx_count_and_scan): [0] mortality, [1] pair list, [2] id-ordered index
+  // (stream3), [3] block collector
+  unsigned int* tickets = nullptr;   // [8], zero between launches
 
   // pinned host scratch for read-backs
   int64_t* h_pin = nullptr;          // [16]

@@ -425,18 +425,17 @@ struct DeathP {
 // ops/demography.py:305-321 + ops/selection.py:51-125: d at the individual's
 // cell; w = clip(prod_t 1 - phi_t |e^(not univ_adv) - z_t|^gamma_t, >= 0.001)
 // x prod_del (1 - s_l (g_l0 + g_l1)); p = 1 - (1 - d) w; age > max_age => 1.
-__global__ void __launch_bounds__(256)
-k_death_probs(DeathP Q, DemP P, SplineC SN, SplineC SP, GnxSoA s, const float* rast,
-              GnxTraitTab T, const double* delet_s, const unsigned long long* nmax_bits,
-              double* p_death, double* d_cell) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= Q.N) return;
+__device__ __forceinline__ double death_prob_one(const DeathP& Q, const DemP& P, const SplineC& SN,
+                                                 const SplineC& SP, const GnxSoA& s,
+                                                 const float* __restrict__ rast,
+                                                 const GnxTraitTab& T,
+                                                 const double* __restrict__ delet_s, double nmax,
+                                                 int64_t i, double* __restrict__ d_cell) {
   int cx = (int)s.x[i], cy = (int)s.y[i];
   double px = cx + 0.5, py = cy + 0.5;
   double K = k_at_cell(P, rast, cx, cy);
   double N = fmax(spline_eval(SN, px, py), 0.0);
   double np_ = P.have_pairs ? fmax(spline_eval(SP, px, py), 0.0) : 0.0;
-  double nmax = __longlong_as_double((long long)*nmax_bits);
   double d = d_at_cell(P, N, np_, K, nmax);
   d_cell[i] = d;
   double p = d;
@@ -468,24 +467,22 @@ k_death_probs(DeathP Q, DemP P, SplineC SN, SplineC SP, GnxSoA s, const float* r
     p = 1.0 - (1.0 - d) * w;
   }
   if (Q.max_age >= 0 && s.age[i] > Q.max_age) p = 1.0;
-  p_death[i] = p;
+  return p;
 }
 
-int gnx_l_death_probs(gnx_state* h, bool with_selection) {
-  int64_t N = h->N;
-  if (N == 0) return 0;
-  SplineC SN = make_splinec(h, h->spl_N), SP = make_splinec(h, h->spl_P);
-  int64_t cells = (int64_t)h->cfg.W * h->cfg.H;
-  gnx_time_begin(h);
-  if (!h->nmax_zeroed)
-    HIPCHK(hipMemsetAsync(h->nmax_bits, 0, sizeof(unsigned long long), h->stream));
-  h->nmax_zeroed = false;
-  (void)cells;
-  static const int nmax_blocks = getenv("GNX_NMAX_BLOCKS") ? atoi(getenv("GNX_NMAX_BLOCKS")) : 512;
-  hipLaunchKernelGGL(k_nmax, dim3(std::min(h->cfg.H, nmax_blocks)), dim3(256), 0, h->stream, SN,
-                     h->cfg.W, h->cfg.H, h->nmax_bits);
+__global__ void __launch_bounds__(256)
+k_death_probs(DeathP Q, DemP P, SplineC SN, SplineC SP, GnxSoA s, const float* rast,
+              GnxTraitTab T, const double* delet_s, const unsigned long long* nmax_bits,
+              double* p_death, double* d_cell) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Q.N) return;
+  const double nmax = __longlong_as_double((long long)*nmax_bits);
+  p_death[i] = death_prob_one(Q, P, SN, SP, s, rast, T, delet_s, nmax, i, d_cell);
+}
+
+static DeathP make_deathp(const gnx_state* h, bool with_selection) {
   DeathP Q;
-  Q.N = N;
+  Q.N = h->N;
   Q.cap = h->cfg.cap_inds;
   Q.n_layers = h->cfg.n_layers;
   Q.with_selection = with_selection ? 1 : 0;
@@ -493,9 +490,29 @@ int gnx_l_death_probs(gnx_state* h, bool with_selection) {
   Q.n_delet = (with_selection && h->genomes_assigned) ? h->n_delet : 0;
   Q.n_tl = h->n_tl;
   Q.TW = h->TW;
-  hipLaunchKernelGGL(k_death_probs, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, Q,
-                     make_demp(h), SN, SP, h->soa[h->cur], h->rast, gnx_trait_tab(h),
-                     h->delet_s, h->nmax_bits, h->p_death, h->d_cell);
+  return Q;
+}
+
+// N.max() over the cells (the clip of _calc_dNdt, ops/demography.py:116)
+static int launch_nmax(gnx_state* h) {
+  if (!h->nmax_zeroed)
+    HIPCHK(hipMemsetAsync(h->nmax_bits, 0, sizeof(unsigned long long), h->stream));
+  h->nmax_zeroed = false;
+  static const int nmax_blocks = getenv("GNX_NMAX_BLOCKS") ? atoi(getenv("GNX_NMAX_BLOCKS")) : 512;
+  hipLaunchKernelGGL(k_nmax, dim3(std::min(h->cfg.H, nmax_blocks)), dim3(256), 0, h->stream,
+                     make_splinec(h, h->spl_N), h->cfg.W, h->cfg.H, h->nmax_bits);
+  return 0;
+}
+
+int gnx_l_death_probs(gnx_state* h, bool with_selection) {
+  int64_t N = h->N;
+  if (N == 0) return 0;
+  SplineC SN = make_splinec(h, h->spl_N), SP = make_splinec(h, h->spl_P);
+  gnx_time_begin(h);
+  GNXCHK(launch_nmax(h));
+  hipLaunchKernelGGL(k_death_probs, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream,
+                     make_deathp(h, with_selection), make_demp(h), SN, SP, h->soa[h->cur], h->rast,
+                     gnx_trait_tab(h), h->delet_s, h->nmax_bits, h->p_death, h->d_cell);
   gnx_time_end(h, GNX_K_DEATH, (double)N * (28.0 + 8.0 * h->cfg.n_traits));
   HIPCHK(hipGetLastError());
   return 0;
@@ -720,6 +737,183 @@ k_xo_jobs_write(int64_t B, GnxHalves H, const GnxXoPlan* __restrict__ plan,
   }
 }
 
+// The two kernels above in one, for NB <= 8: one thread per offspring SLOT (256 per
+// workgroup - four times the workgroups of k_xo_jobs_surv, which left a third of the CUs
+// idle), the plan stays in registers, and the thread walks its own 2 x NB table entries
+// with every load of a stage issued before the first result is used: the parent's 2 x NB
+// entries are NB 8-byte loads, the child's NB 8-byte stores.  One thread per logical block
+// (k_xo_jobs_write: 3.3 M threads, each a chain of three dependent loads) took 52 us,
+// k_xo_jobs_surv 23.
+#define GNX_JF_NB 8
+template <int NB>
+__global__ void __launch_bounds__(256)
+k_xo_jobs_fused(int64_t N, int64_t first, int32_t* __restrict__ grow,
+                const int32_t* __restrict__ alive, const int32_t* __restrict__ blk_off3,
+                const int32_t* __restrict__ off_parent, const int32_t* __restrict__ off_keys,
+                const uint8_t* __restrict__ off_start, const int32_t* __restrict__ free_rows,
+                int64_t n_free, GnxHalves H, const int32_t* __restrict__ bp_off,
+                const int32_t* __restrict__ bp_loci, int32_t* __restrict__ n_jobs,
+                GnxXoJob* __restrict__ jobs) {
+  __shared__ int wsum[3][4];
+  __shared__ int prev_s[4];
+  __shared__ int s_pop, s_job;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t base = (first / 256 + blockIdx.x) * 256;
+  const int64_t i = base + tid;
+  const int64_t b = base / GNX_CB;                 // the compaction block of these 256 slots
+  const int round = (int)((base - b * GNX_CB) / 256);
+  // stage 1: who is a surviving offspring without a row, here and in the earlier rounds of
+  // the same compaction block (their number comes before this round's ranks)
+  const bool fx = i < N && (alive[i] & 2) != 0;
+  int prev = 0;
+  for (int r = 0; r < round; ++r) {
+    const int64_t j = b * GNX_CB + r * 256 + tid;
+    prev += __popcll(__ballot(j < N && (alive[j] & 2) != 0));
+  }
+  const unsigned long long bal = __ballot(fx);
+  if (lane == 0) {
+    wsum[0][wave] = __popcll(bal);
+    prev_s[wave] = prev;
+  }
+  __syncthreads();
+  int rank = __popcll(bal & ((1ull << lane) - 1ull));
+  for (int w = 0; w < wave; ++w) rank += wsum[0][w];
+  rank += blk_off3[b] + prev_s[0] + prev_s[1] + prev_s[2] + prev_s[3];
+  // stage 2: row, parents, keys, start homologues (unconditional loads from clamped indices)
+  const int64_t k = fx ? i - first : 0;
+  int32_t row = free_rows[n_free - 1 - (fx ? rank : 0)];
+  int32_t par[2], key[2], st[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    par[p] = off_parent[2 * k + p];
+    key[p] = off_keys[2 * k + p];
+    st[p] = off_start[2 * k + p];
+  }
+  if (fx) grow[i] = row;
+  else row = -1;
+  // stage 3: the parents' rows, the paths' breakpoint ranges
+  int32_t prow[2], b0[2], b1[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    prow[p] = grow[par[p]];
+    b0[p] = bp_off ? bp_off[key[p]] : 0;
+    b1[p] = bp_off ? bp_off[key[p] + 1] : 0;
+  }
+  // stage 4: which blocks hold a switch point
+  const unsigned int all = (1u << NB) - 1u;
+  unsigned int mixed[2], sel[2];
+  int cf = 0, cj = 0;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    if (!fx) prow[p] = -1;
+    mixed[p] = all;                              // dense masks, ghost parent: cut everything
+    sel[p] = 0u;
+    if (fx && prow[p] >= 0 && bp_off)
+      gnx_block_masks(bp_loci + b0[p], b1[p] - b0[p], st[p], NB, H.BW, mixed[p], sel[p]);
+    mixed[p] &= all;
+    if (fx) {
+      const int nf = __popc(mixed[p]);
+      cf += nf;
+      cj += prow[p] >= 0 ? nf : 0;
+    }
+  }
+  // stage 5: this workgroup's stretch of the free-block stack and of the job list, with
+  // ONE atomic each; exclusive sums of cf / cj over the 256 threads
+  int xf = cf, xj = cj;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int yf = __shfl_up(xf, d), yj = __shfl_up(xj, d);
+    if (lane >= d) {
+      xf += yf;
+      xj += yj;
+    }
+  }
+  if (lane == 63) {
+    wsum[1][wave] = xf;
+    wsum[2][wave] = xj;
+  }
+  __syncthreads();
+  int of = xf - cf, oj = xj - cj;
+  for (int w = 0; w < wave; ++w) {
+    of += wsum[1][w];
+    oj += wsum[2][w];
+  }
+  if (tid == 0) {
+    const int tf = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
+    const int tj = wsum[2][0] + wsum[2][1] + wsum[2][2] + wsum[2][3];
+    s_pop = tf ? atomicSub(H.top, tf) : 0;
+    s_job = tj ? atomicAdd(n_jobs, tj) : 0;
+  }
+  __syncthreads();
+  if (!fx) return;
+  const int pop = s_pop - 1 - of;                  // stack index of my first fresh block
+  const int job = s_job + oj;
+  // stage 6: the parents' table entries (2 x NB each, 8-byte loads) and my fresh blocks
+  int32_t pe[2][2 * NB];                           // [parent][hom * NB + q]
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int2* src = (const int2*)(H.hmap + (int64_t)max(prow[p], 0) * 2 * NB);
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const int2 v = src[q];
+      pe[p][2 * q] = v.x;
+      pe[p][2 * q + 1] = v.y;
+    }
+  }
+  int32_t fresh[2 * NB];
+#pragma unroll
+  for (int q = 0; q < 2 * NB; ++q) fresh[q] = q < cf ? H.stack[pop - q] : 0;
+  // stage 7: my table (NB 8-byte stores), the jobs, and the parents' blocks that are shared
+  // from now on lose their never-shared flag (only the first child to share one writes)
+  int32_t ce[2 * NB];
+  int fr = 0, jr = 0;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const bool local = prow[p] >= 0;
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      int32_t v;
+      if ((mixed[p] >> q) & 1u) {
+        int32_t dst = 0;
+#pragma unroll
+        for (int z = 0; z < 2 * NB; ++z) dst = (z == fr) ? fresh[z] : dst;
+        v = (int32_t)((uint32_t)dst | GNX_OWN);
+        if (local) {
+          GnxXoJob j;
+          j.ph0 = GNX_BLK(pe[p][q]);
+          j.ph1 = GNX_BLK(pe[p][NB + q]);
+          j.dst = dst;
+          j.ks = (key[p] * 2 + st[p]) | (q << 24);
+          jobs[job + jr] = j;
+          ++jr;
+        }
+        ++fr;
+      } else {
+        const int hsel = (sel[p] >> q) & 1u;
+        const int32_t pv = hsel ? pe[p][NB + q] : pe[p][q];
+        v = GNX_BLK(pv);
+        if (pv < 0) H.hmap[((int64_t)prow[p] * 2 + hsel) * NB + q] = v;
+      }
+      ce[p * NB + q] = v;
+    }
+  }
+  int2* dstp = (int2*)(H.hmap + (int64_t)row * 2 * NB);
+#pragma unroll
+  for (int q = 0; q < NB; ++q) dstp[q] = make_int2(ce[2 * q], ce[2 * q + 1]);
+}
+
+template <int NB>
+static void launch_jobs_fused(gnx_state* h, int64_t first_slot, const int32_t* d_alive,
+                              const int32_t* d_blk_off, int buf) {
+  const int64_t N = h->N;
+  const int nbf = (int)((N - 1) / 256 - first_slot / 256 + 1);
+  hipLaunchKernelGGL(k_xo_jobs_fused<NB>, dim3(nbf), dim3(256), 0, h->stream, N, first_slot,
+                     h->soa[h->cur].grow, d_alive, d_blk_off + 2 * h->blk_stride, h->off_parent,
+                     h->off_keys, h->off_start, h->free_rows, h->n_free, gnx_halves(h),
+                     gnx_alias_bp(h), gnx_alias_loci(h), h->n_jobs_dev[buf],
+                     (GnxXoJob*)h->jobs[buf]);
+}
+
 // Stable compaction of the SoA (survivors keep their relative order); genome
 // rows are NOT moved: the dead's rows are pushed on the free stack.
 __global__ void __launch_bounds__(256)
@@ -770,6 +964,20 @@ void gnx_launch_xo_jobs_surv(gnx_state* h, int64_t first_slot, const int32_t* d_
                              const int32_t* d_blk_off, int buf) {
   const int64_t N = h->N;
   const int nbj = (int)((N - 1) / GNX_CB - first_slot / GNX_CB + 1);
+  static const bool fused_env = !(getenv("GNX_JOBS_FUSED") && atoi(getenv("GNX_JOBS_FUSED")) == 0);
+  if (fused_env && h->NB <= GNX_JF_NB) {
+    switch (h->NB) {
+      case 1: launch_jobs_fused<1>(h, first_slot, d_alive, d_blk_off, buf); break;
+      case 2: launch_jobs_fused<2>(h, first_slot, d_alive, d_blk_off, buf); break;
+      case 3: launch_jobs_fused<3>(h, first_slot, d_alive, d_blk_off, buf); break;
+      case 4: launch_jobs_fused<4>(h, first_slot, d_alive, d_blk_off, buf); break;
+      case 5: launch_jobs_fused<5>(h, first_slot, d_alive, d_blk_off, buf); break;
+      case 6: launch_jobs_fused<6>(h, first_slot, d_alive, d_blk_off, buf); break;
+      case 7: launch_jobs_fused<7>(h, first_slot, d_alive, d_blk_off, buf); break;
+      default: launch_jobs_fused<8>(h, first_slot, d_alive, d_blk_off, buf); break;
+    }
+    return;
+  }
   hipLaunchKernelGGL(k_xo_jobs_surv, dim3(nbj), dim3(256), 0, h->stream, N, first_slot,
                      h->soa[h->cur].grow, d_alive, d_blk_off + 2 * h->blk_stride, h->off_parent,
                      h->off_keys, h->off_start, h->free_rows, h->n_free, gnx_halves(h),
@@ -785,8 +993,9 @@ void gnx_launch_xo_jobs_surv(gnx_state* h, int64_t first_slot, const int32_t* d_
 // the side stream: nothing needs the index before the next cell sort.
 __global__ void __launch_bounds__(256)
 k_ord_flags(int64_t N, int64_t ord_n, const int32_t* __restrict__ ord,
-            const int32_t* __restrict__ newslot, int32_t* __restrict__ cnt) {
+            const int32_t* __restrict__ newslot, int32_t* __restrict__ cnt, GnxScanOut S) {
   __shared__ int lds[16];
+  __shared__ int lds2[8];
   const int64_t base = (int64_t)blockIdx.x * GNX_CB;
   bool f[4];
 #pragma unroll
@@ -794,9 +1003,9 @@ k_ord_flags(int64_t N, int64_t ord_n, const int32_t* __restrict__ ord,
     const int64_t k = base + r * 256 + threadIdx.x;
     f[r] = k < N && newslot[k < ord_n ? ord[k] : k] >= 0;
   }
-  int rank[4], tot;
-  gnx_block_ranks(f, rank, tot, lds);
-  if (threadIdx.x == 0) cnt[blockIdx.x] = tot;
+  int rank[4], tot[1];
+  gnx_block_ranks(f, rank, tot[0], lds);
+  gnx_count_and_scan<1>(tot, cnt, S, lds2);
 }
 
 __global__ void __launch_bounds__(256)
@@ -845,7 +1054,10 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
                      a.id, a.ghost, a.grow, h->step, c.seed, h->flag, h->flag2, h->blk_cnt,
                      h->blk_stride, xo ? xo_first : (int64_t)-1, zero_jobs);
   // survivors, rows freed and (deferred crossover) the surviving offspring that need a
-  // row: block offsets on the device, totals also straight into pinned host memory
+  // row: block offsets on the device, totals also straight into pinned host memory.
+  // (Measured and dropped: death probabilities + death draws + the scan by the last
+  // workgroup in ONE kernel took 73 us against 34 + 13 + 10 apart, 0.820 against 0.808
+  // ms/step - four individuals per thread starve the f64 spline gathers of parallelism.)
   GNXCHK(gnx_block_scan(h, 3, N, h->blk_cnt, h->blk_off, h->cnt_dev, h->h_pin_dev));
   gnx_time_end(h, GNX_K_COMPACT, 0.0);
   // the host only needs the counts: it waits for the scan, not for the compaction, and
@@ -873,9 +1085,9 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
     HIPCHK(hipEventRecord(h->ev_compact, h->stream));
     HIPCHK(hipStreamWaitEvent(h->stream3, h->ev_compact, 0));
     if (h->ord_inflight) h->ord_inflight = false;       // (stream3 runs them in order)
+    GnxScanOut So{h->ord_off, nullptr, nullptr, 0, nullptr, h->tickets + 2, h->blk_stride};
     hipLaunchKernelGGL(k_ord_flags, dim3(nb), dim3(256), 0, h->stream3, N, h->ord_n,
-                       h->ord[h->ord_cur], h->newslot, h->ord_cnt);
-    GNXCHK(gnx_block_scan(h, 1, N, h->ord_cnt, h->ord_off, nullptr, nullptr, 0, h->stream3));
+                       h->ord[h->ord_cur], h->newslot, h->ord_cnt, So);
     hipLaunchKernelGGL(k_ord_write, dim3(nb), dim3(256), 0, h->stream3, N, h->ord_n,
                        h->ord[h->ord_cur], h->newslot, h->ord_off, h->ord[h->ord_cur ^ 1]);
     HIPCHK(hipEventRecord(h->ev_ord, h->stream3));

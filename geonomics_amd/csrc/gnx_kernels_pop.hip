@@ -976,6 +976,8 @@ k_pair_flags(PairP P, GnxSoA s, int32_t* flag2, int32_t* cnt) {
   }
   int rank[4], tot;
   gnx_block_ranks(f, rank, tot, lds);
+  // (the scan of the block counts stays a launch of its own: done by the last workgroup of
+  // this kernel - gnx_count_and_scan - it cost 10 us more than k_block_scan's 6)
   if (threadIdx.x == 0) cnt[blockIdx.x] = tot;
 }
 
