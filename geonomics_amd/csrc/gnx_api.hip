@@ -381,6 +381,12 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
   GNXCHK(dalloc(&h->blk_off, (size_t)3 * h->blk_stride));
   GNXCHK(dalloc(&h->cnt_dev, 8));
   GNXCHK(dalloc(&h->tickets, 8));
+  GNXCHK(dalloc(&h->nmax2, 2));
+  HIPCHK(hipMemset(h->nmax2, 0, 2 * sizeof(unsigned long long)));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_pairs, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_latP, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_perm, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_binsN, hipEventDisableTiming));
   HIPCHK(hipMemset(h->tickets, 0, 8 * sizeof(unsigned int)));
   // fine-grained: the host polls words that kernels write (gnx_wait_published)
   HIPCHK(hipHostMalloc((void**)&h->h_pin, 32 * sizeof(int64_t),
@@ -434,7 +440,7 @@ extern "C" void gnx_destroy(gnx_state* h) {
                   h->off_parent, h->off_keys, h->off_start, h->keep_in, h->inj_a, h->inj_b,
                   h->mid_x, h->mid_y, h->p_death, h->d_cell, h->dead_in, h->nmax_bits, h->red,
                   h->sel_loci, h->path_sel, h->lat.areas, h->lat.cprime, h->spl_N.c, h->spl_P.c, h->bin_partials, h->nodes,
-                  h->K_over, h->blk_cnt, h->blk_off, h->cnt_dev, h->tickets, h->gp_rec, h->gp_z, h->gp_slots, h->tile_counts, h->rq_sorted, h->rq_k, h->gam_out, h->gam_slot, h->chk};
+                  h->K_over, h->blk_cnt, h->blk_off, h->cnt_dev, h->tickets, h->nmax2, h->fb[0], h->gp_rec, h->gp_z, h->gp_slots, h->tile_counts, h->rq_sorted, h->rq_k, h->gam_out, h->gam_slot, h->chk};
   for (void* p : ptrs) (void)hipFree(p);
   for (int t = 0; t < GNX_MAX_TRAITS; ++t) {
     (void)hipFree(h->traits[t].loci);
@@ -454,6 +460,10 @@ extern "C" void gnx_destroy(gnx_state* h) {
   }
   if (h->ev_ord) (void)hipEventDestroy(h->ev_ord);
   if (h->ev_compact) (void)hipEventDestroy(h->ev_compact);
+  if (h->ev_pairs) (void)hipEventDestroy(h->ev_pairs);
+  if (h->ev_latP) (void)hipEventDestroy(h->ev_latP);
+  if (h->ev_perm) (void)hipEventDestroy(h->ev_perm);
+  if (h->ev_binsN) (void)hipEventDestroy(h->ev_binsN);
   delete h;
 }
 
@@ -567,6 +577,14 @@ static int setup_lattice(gnx_state* h) {
   // one allocation, so that a tiled run all-reduces both fields in one call
   GNXCHK(dalloc(&h->bin_partials, 2 * nb));
   h->bins_P = h->bin_partials + nb;
+  (void)hipFree(h->fb[0]);
+  GNXCHK(dalloc(&h->fb[0], 3 * nb));
+  h->fb[1] = h->fb[0] + nb;
+  h->fb[2] = h->fb[0] + 2 * nb;
+  HIPCHK(hipMemset(h->fb[0], 0, 3 * nb * sizeof(int32_t)));
+  h->fb_zero[0] = h->fb_zero[1] = h->fb_zero[2] = true;
+  h->fb_adults = false;
+  h->nmax_ready = false;
   HIPCHK(hipMemcpy(L.areas, areas.data(), nn * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(L.cprime, cp.data(), (Jm + 1) * sizeof(double), hipMemcpyHostToDevice));
   h->spl_N.valid = h->spl_P.valid = false;
@@ -973,8 +991,7 @@ extern "C" int gnx_pop_dynamics_die(gnx_state* h, int32_t burn, int32_t with_sel
   GNXCHK(need_params(h));
   int64_t D = 0;
   // 4. N density of everyone incl. offspring (structs/species.py:845-882)
-  GnxSoA s = h->soa[h->cur];
-  GNXCHK(gnx_l_density(h, h->N, s.x, s.y, &h->spl_N, nullptr));
+  GNXCHK(gnx_l_density_N(h));
   // 5-6. d at each individual's cell, fitness, death probability
   GNXCHK(gnx_l_death_probs(h, with_selection != 0 && !burn));
   // 7. mortality
@@ -1190,6 +1207,7 @@ extern "C" int gnx_download(gnx_state* h, int32_t field, void* dst, int64_t dst_
 // structs/species.py:937-939; tests/validation/wf does so every step); the environment
 // values follow as in _set_e (:913-922)
 extern "C" int gnx_set_positions(gnx_state* h, const float* x, const float* y) {
+  h->fb_adults = false;
   GNXCHK(need_params(h));
   const int64_t N = h->N;
   if (N == 0) return 0;

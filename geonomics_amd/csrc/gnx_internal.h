@@ -289,6 +289,25 @@ struct gnx_state {
   int32_t* bins_P = nullptr;         // ... of pair midpoints
   bool bins_zeroed[2]{};             // [0] individuals, [1] pairs: already cleared by k_lattice
   bool nmax_zeroed = false;          // nmax_bits already cleared by k_lattice
+  // The density path of one GPU without a counting pass (gnx_bins.h): the bins are counted
+  // beside the step's serial chain - the adults on stream3 under the mate search, the pair
+  // midpoints and their lattice on stream3 under k_offspring, the newborns by k_offspring
+  // itself - into buffers of their own: fb[0], fb[1]
+  // the individuals' (alternating from step to step: the lattice kernel of one step clears
+  // the other step's buffer, it cannot clear the one its own workgroups still read), fb[2]
+  // the pairs'.  The pairs' lattice runs on stream3 beside k_offspring.
+  int32_t* fb[3]{};
+  bool fb_zero[3]{};                 // buffer k holds zeros
+  int fb_cur = 0;                    // the individuals' buffer of this step
+  bool fb_adults = false;            // fb[fb_cur] holds the counts of ...
+  int64_t fb_count = 0;              // ... this many individuals (adults, + newborns once born)
+  unsigned long long* nmax2 = nullptr;           // [2] N.max() words, alternating like fb
+  const unsigned long long* nmax_cur = nullptr;  // the word the death probabilities read
+  bool nmax_ready = false;           // nmax_cur was filled by k_lattice_nmax
+  bool last_N_fused = false;         // the last individuals' density came from fb (gnx_get_bins)
+  hipEvent_t ev_pairs = nullptr, ev_latP = nullptr, ev_perm = nullptr, ev_binsN = nullptr;
+  bool binsN_inflight = false;       // the adults are being counted on stream3
+  bool latP_inflight = false;        // spl_P is being written on stream3
   // An index of the slots in ascending id order (ord[k] = slot of the k-th smallest id, k <
   // ord_n; slots appended since - this step's offspring - follow in slot order).  With it the
   // cell sort is a STABLE radix sort of that sequence by cell alone (2 passes instead of 4-5:
@@ -449,6 +468,15 @@ int gnx_l_spline(gnx_state* h, const int32_t* d_bins, GnxSpline* spl,
 int gnx_l_spline_z(gnx_state* h, const int32_t* d_bins, GnxSpline* spl,
                    const double* d_nodes_override, bool housekeeping);
 int gnx_l_raster(gnx_state* h, int which, double* d_out);
+// the individuals' density of the step on one GPU: lattice + N.max() from the bins the
+// step's kernels have counted, or (nobody counted: tiles, operator calls) bins + lattice
+int gnx_l_density_N(gnx_state* h);
+// the pairs' lattice from the bins k_pair_compact counted, on stream3
+int gnx_l_lattice_P_async(gnx_state* h, int64_t n_max);
+// the adults' bins (x, y: the sorted population), counted on stream3
+int gnx_l_bins_adults_async(gnx_state* h, const float* d_x, const float* d_y, int64_t N);
+int gnx_wait_latP(gnx_state* h);
+bool gnx_fused_bins(const gnx_state* h);
 int gnx_l_death_probs(gnx_state* h, bool with_selection);
 int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_out);
 int gnx_l_spatial_diff(gnx_state* h, double* mean, double* sd, double* sums = nullptr);

@@ -199,7 +199,7 @@ __device__ __forceinline__ void spline_line(int J, int64_t base, int64_t stride,
 __global__ void __launch_bounds__(256)
 k_lattice(int Jx, int Jy, int nbx, const int32_t* bins, const double* areas, double hww,
           const double* cp_g, double* C, int32_t* zero_bins, int n_zero,
-          unsigned long long* zero_word, int use_lds) {
+          unsigned long long* zero_word, int use_lds, int zero_own) {
   extern __shared__ double lat_lds[];
   const int nn = Jx * Jy;
   // housekeeping that would otherwise be launches of their own: clear the OTHER density
@@ -233,6 +233,10 @@ k_lattice(int Jx, int Jy, int nbx, const int32_t* bins, const double* areas, dou
     }
   }
   __syncthreads();
+  // (the bins counted by the step's own kernels, gnx_bins.h: read, now cleared for their
+  // next use - this is the only workgroup that touches them)
+  if (bins && zero_own)
+    for (int k = threadIdx.x; k < nn; k += blockDim.x) const_cast<int32_t*>(bins)[k] = 0;
   for (int line = threadIdx.x; line < Jy; line += blockDim.x)
     spline_line(Jx, (int64_t)line * Jx, 1, hww, cp, V, Mx);
   for (int line = threadIdx.x; line < Jx; line += blockDim.x)
@@ -273,7 +277,7 @@ int gnx_l_spline_z(gnx_state* h, const int32_t* d_bins, GnxSpline* spl,
     hipLaunchKernelGGL(k_lattice, dim3(1), dim3(256), use_lds ? lds_bytes : 0, h->stream, L.Jx,
                        L.Jy, L.nbx, d_nodes_override ? nullptr : d_bins, L.areas, L.hww, L.cprime,
                        V, zb, zb ? L.nbx * L.nby : 0,
-                       (housekeeping && spl == &h->spl_N) ? h->nmax_bits : nullptr, use_lds);
+                       (housekeeping && spl == &h->spl_N) ? h->nmax_bits : nullptr, use_lds, 0);
     if (zb) h->bins_zeroed[other] = true;
     if (housekeeping && spl == &h->spl_N) h->nmax_zeroed = true;
     HIPCHK(hipGetLastError());
@@ -309,14 +313,46 @@ int gnx_l_density(gnx_state* h, int64_t n, const float* d_x, const float* d_y, G
 }
 
 // ---------------------------------------------------------------- rasters
-// max over all cells of N (needed by _calc_dNdt's clip, ops/demography.py:116)
-__global__ void __launch_bounds__(256)
-k_nmax(SplineC S, int W, int H, unsigned long long* out_bits) {
-  __shared__ double red[256];
+// max over all cells of N (needed by _calc_dNdt's clip, ops/demography.py:116).
+// Row by row: along a raster row the lattice row i and the fraction ty are fixed, so the
+// bicubic spline collapses to a 1-d spline along x whose node values A[j] and second
+// derivatives Bm[j] are the y-interpolants of (V, My) and (Mx, Mxy) at column j - 4 LDS
+// reads and one spl1 per cell instead of 16 loads and five (the interpolation operators
+// commute: the same polynomial as spline_eval, rounded in another order).  Every
+// workgroup of both kernels below calls this with the same arithmetic, so N.max() does not
+// depend on which of them computed it.  AB: LDS, 2 * Jx doubles.
+__device__ __forceinline__ double nmax_rows(const double* __restrict__ C, int Jx, int Jy,
+                                            double hww, int W, int H, int row0, int row_stride,
+                                            double* AB) {
+  const int nn = Jx * Jy;
+  const double* V = C;
+  const double* Mx = C + nn;
+  const double* My = C + 2 * (int64_t)nn;
+  const double* Mxy = C + 3 * (int64_t)nn;
+  const double inv_hww = 1.0 / hww, h2_6 = hww * hww / 6.0;
   double m = 0.0;
-  // rows strided over the blocks, columns over the threads: no index division per cell
-  for (int cy = blockIdx.x; cy < H; cy += gridDim.x)
-    for (int cx = threadIdx.x; cx < W; cx += 256) m = fmax(m, spline_eval(S, cx + 0.5, cy + 0.5));
+  for (int cy = row0; cy < H; cy += row_stride) {
+    const double fy = (cy + 0.5) * inv_hww;
+    const int i = min(max((int)floor(fy), 0), Jy - 2);
+    const double ty = fy - i;
+    __syncthreads();
+    for (int j = threadIdx.x; j < Jx; j += blockDim.x) {
+      const int a = i * Jx + j, b = a + Jx;
+      AB[j] = spl1(V[a], V[b], My[a], My[b], ty, h2_6);
+      AB[Jx + j] = spl1(Mx[a], Mx[b], Mxy[a], Mxy[b], ty, h2_6);
+    }
+    __syncthreads();
+    for (int cx = threadIdx.x; cx < W; cx += blockDim.x) {
+      const double fx = (cx + 0.5) * inv_hww;
+      const int j = min(max((int)floor(fx), 0), Jx - 2);
+      const double tx = fx - j;
+      m = fmax(m, spl1(AB[j], AB[j + 1], AB[Jx + j], AB[Jx + j + 1], tx, h2_6));
+    }
+  }
+  return m;
+}
+
+__device__ __forceinline__ void nmax_publish(double m, unsigned long long* out_bits, double* red) {
   red[threadIdx.x] = m;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
@@ -325,6 +361,64 @@ k_nmax(SplineC S, int W, int H, unsigned long long* out_bits) {
   }
   // non-negative doubles order like their bit patterns
   if (threadIdx.x == 0) atomicMax(out_bits, (unsigned long long)__double_as_longlong(red[0]));
+}
+
+__global__ void __launch_bounds__(256)
+k_nmax(SplineC S, int W, int H, unsigned long long* out_bits) {
+  extern __shared__ double nmax_lds[];          // AB [2 * Jx] + red [256]
+  const double m = nmax_rows(S.V, S.Jx, S.Jy, S.hww, W, H, blockIdx.x, gridDim.x, nmax_lds);
+  nmax_publish(m, out_bits, nmax_lds + 2 * S.Jx);
+}
+
+// Lattice + N.max() of the individuals' density in ONE launch (one GPU, bins counted by the
+// step's kernels): every workgroup builds the whole lattice in its LDS (a few microseconds
+// of serial sweeps whichever way - redundantly, but in parallel), workgroup 0 writes the
+// coefficients out for the death probabilities, and all of them share the raster rows of
+// N.max().  The bins these workgroups read cannot be cleared here; the OTHER step's buffer
+// and N.max() word are (fb / nmax2 alternate).
+__global__ void __launch_bounds__(256)
+k_lattice_nmax(int Jx, int Jy, int nbx, const int32_t* __restrict__ bins,
+               const double* __restrict__ areas, double hww, const double* __restrict__ cp_g,
+               double* __restrict__ C, int W, int H, unsigned long long* __restrict__ out_bits,
+               int32_t* __restrict__ zero_bins, unsigned long long* __restrict__ zero_word) {
+  extern __shared__ double lat_lds[];
+  const int nn = Jx * Jy;
+  const int Jm = max(Jx, Jy);
+  double* V = lat_lds;
+  double* Mx = V + nn;
+  double* My = V + 2 * nn;
+  double* Mxy = V + 3 * nn;
+  double* cp = lat_lds + 4 * nn;                // [Jm + 1]
+  double* AB = cp + Jm + 1;                     // [2 * Jx]
+  double* red = AB + 2 * Jx;                    // [256]
+  if (blockIdx.x == 0) {
+    for (int k = threadIdx.x; k < nn; k += blockDim.x) zero_bins[k] = 0;
+    if (threadIdx.x == 0) *zero_word = 0ull;
+  }
+  for (int k = threadIdx.x; k <= Jm; k += blockDim.x) cp[k] = cp_g[k];
+  for (int idx = threadIdx.x; idx < nn; idx += blockDim.x) {
+    const int i = idx / Jx, j = idx - i * Jx;
+    long long cnt = 0;
+    for (int di = -1; di <= 0; ++di)
+      for (int dj = -1; dj <= 0; ++dj) {
+        const int ii = i + di, jj = j + dj;
+        if (ii >= 0 && jj >= 0) cnt += bins[ii * nbx + jj];
+      }
+    V[idx] = (double)cnt / areas[idx];
+  }
+  __syncthreads();
+  for (int line = threadIdx.x; line < Jy; line += blockDim.x)
+    spline_line(Jx, (int64_t)line * Jx, 1, hww, cp, V, Mx);
+  for (int line = threadIdx.x; line < Jx; line += blockDim.x)
+    spline_line(Jy, line, Jx, hww, cp, V, My);
+  __syncthreads();
+  for (int line = threadIdx.x; line < Jy; line += blockDim.x)
+    spline_line(Jx, (int64_t)line * Jx, 1, hww, cp, My, Mxy);
+  __syncthreads();
+  if (blockIdx.x == 0)
+    for (int idx = threadIdx.x; idx < 4 * nn; idx += blockDim.x) C[idx] = lat_lds[idx];
+  const double m = nmax_rows(lat_lds, Jx, Jy, hww, W, H, blockIdx.x, gridDim.x, AB);
+  nmax_publish(m, out_bits, red);
 }
 
 struct DemP {
@@ -408,10 +502,11 @@ int gnx_l_raster(gnx_state* h, int which, double* d_out) {
     gnx_set_error("density rasters are available after the first pop_dynamics call");
     return 3;
   }
+  GNXCHK(gnx_wait_latP(h));
   SplineC SN = make_splinec(h, h->spl_N), SP = make_splinec(h, h->spl_P);
   int64_t cells = (int64_t)h->cfg.W * h->cfg.H;
   hipLaunchKernelGGL(k_raster, dim3(gnx_grid(cells, 256)), dim3(256), 0, h->stream, which, SN, SP,
-                     make_demp(h), h->rast, h->nmax_bits, d_out);
+                     make_demp(h), h->rast, h->nmax_cur ? h->nmax_cur : h->nmax_bits, d_out);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -499,8 +594,119 @@ static int launch_nmax(gnx_state* h) {
     HIPCHK(hipMemsetAsync(h->nmax_bits, 0, sizeof(unsigned long long), h->stream));
   h->nmax_zeroed = false;
   static const int nmax_blocks = getenv("GNX_NMAX_BLOCKS") ? atoi(getenv("GNX_NMAX_BLOCKS")) : 512;
-  hipLaunchKernelGGL(k_nmax, dim3(std::min(h->cfg.H, nmax_blocks)), dim3(256), 0, h->stream,
+  hipLaunchKernelGGL(k_nmax, dim3(std::min(h->cfg.H, nmax_blocks)), dim3(256),
+                     (size_t)(2 * h->lat.Jx + 256) * sizeof(double), h->stream,
                      make_splinec(h, h->spl_N), h->cfg.W, h->cfg.H, h->nmax_bits);
+  h->nmax_cur = h->nmax_bits;
+  return 0;
+}
+
+// ---- the density path without a counting pass (gnx_bins.h, gnx_internal.h: fb) ----------
+bool gnx_fused_bins(const gnx_state* h) {
+  static const bool on = !(getenv("GNX_FUSED_BINS") && atoi(getenv("GNX_FUSED_BINS")) == 0);
+  const int64_t nn = (int64_t)h->lat.Jx * h->lat.Jy;
+  const size_t lds = ((size_t)4 * nn + std::max(h->lat.Jx, h->lat.Jy) + 1 + 2 * h->lat.Jx + 256) *
+                     sizeof(double);
+  return on && !h->tiled && h->fb[0] != nullptr && h->stream3 != nullptr && lds <= 64 * 1024 &&
+         (size_t)h->lat.nbx * h->lat.nby * sizeof(int32_t) <= 48 * 1024;
+}
+
+int gnx_wait_latP(gnx_state* h) {
+  if (h->latP_inflight) {
+    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_latP, 0));
+    h->latP_inflight = false;
+  }
+  return 0;
+}
+
+// the pairs' bins and lattice on stream3 (n_max bounds the grid, the pair count itself is
+// read on the device): they run beside k_offspring, the death probabilities wait for them
+int gnx_l_lattice_P_async(gnx_state* h, int64_t n_max) {
+  const GnxLattice& L = h->lat;
+  const int64_t nn = (int64_t)L.Jx * L.Jy;
+  const int nb = L.nbx * L.nby;
+  const size_t lds_bytes = ((size_t)4 * nn + std::max(L.Jx, L.Jy) + 1) * sizeof(double);
+  GNXCHK(gnx_wait_latP(h));        // (a lattice of the last pair list nobody waited for)
+  HIPCHK(hipEventRecord(h->ev_pairs, h->stream));
+  HIPCHK(hipStreamWaitEvent(h->stream3, h->ev_pairs, 0));
+  if (!h->fb_zero[2])
+    HIPCHK(hipMemsetAsync(h->fb[2], 0, (size_t)nb * sizeof(int32_t), h->stream3));
+  const int blocks = (int)std::min<int64_t>(BIN_BLOCKS, std::max<int64_t>(1, (n_max + 255) / 256));
+  hipLaunchKernelGGL(k_bins, dim3(blocks), dim3(256), (size_t)nb * sizeof(int32_t), h->stream3,
+                     n_max, (const int32_t*)h->cnt_dev, (const float*)h->mid_x,
+                     (const float*)h->mid_y, (const uint8_t*)nullptr, 1.0 / L.hww, L.nbx, L.nby,
+                     h->fb[2]);
+  hipLaunchKernelGGL(k_lattice, dim3(1), dim3(256), lds_bytes, h->stream3, L.Jx, L.Jy, L.nbx,
+                     (const int32_t*)h->fb[2], L.areas, L.hww, L.cprime, h->spl_P.c,
+                     (int32_t*)nullptr, 0, (unsigned long long*)nullptr, 1, 1);
+  HIPCHK(hipEventRecord(h->ev_latP, h->stream3));
+  HIPCHK(hipGetLastError());
+  h->latP_inflight = true;
+  h->fb_zero[2] = true;
+  h->spl_P.valid = true;
+  return 0;
+}
+
+int gnx_l_bins_adults_async(gnx_state* h, const float* d_x, const float* d_y, int64_t N) {
+  if (!(h->have_sp && gnx_fused_bins(h))) {
+    h->fb_adults = false;
+    return 0;
+  }
+  const GnxLattice& L = h->lat;
+  const int nb = L.nbx * L.nby;
+  const int cur = h->fb_cur;
+  // (clear unless somebody counted and nobody consumed; on `stream`, ahead of k_offspring's
+  // counts of the newborns)
+  if (!h->fb_zero[cur])
+    HIPCHK(hipMemsetAsync(h->fb[cur], 0, (size_t)nb * sizeof(int32_t), h->stream));
+  HIPCHK(hipEventRecord(h->ev_perm, h->stream));
+  HIPCHK(hipStreamWaitEvent(h->stream3, h->ev_perm, 0));
+  const int blocks = (int)std::min<int64_t>(BIN_BLOCKS, std::max<int64_t>(1, (N + 255) / 256));
+  hipLaunchKernelGGL(k_bins, dim3(blocks), dim3(256), (size_t)nb * sizeof(int32_t), h->stream3, N,
+                     (const int32_t*)nullptr, d_x, d_y, (const uint8_t*)nullptr, 1.0 / L.hww, L.nbx,
+                     L.nby, h->fb[cur]);
+  HIPCHK(hipEventRecord(h->ev_binsN, h->stream3));
+  HIPCHK(hipGetLastError());
+  h->binsN_inflight = true;
+  h->fb_zero[cur] = false;
+  h->fb_adults = true;
+  h->fb_count = N;
+  return 0;
+}
+
+int gnx_l_density_N(gnx_state* h) {
+  GnxSoA s = h->soa[h->cur];
+  if (!(gnx_fused_bins(h) && h->fb_adults && h->fb_count == h->N)) {
+    // nobody counted (tiles, operator calls, a population that changed since the sort)
+    h->fb_adults = false;
+    h->nmax_ready = false;
+    h->last_N_fused = false;
+    return gnx_l_density(h, h->N, s.x, s.y, &h->spl_N, nullptr);
+  }
+  const GnxLattice& L = h->lat;
+  const int64_t nn = (int64_t)L.Jx * L.Jy;
+  const size_t lds_bytes = ((size_t)4 * nn + std::max(L.Jx, L.Jy) + 1 + 2 * L.Jx + 256) * sizeof(double);
+  const int cur = h->fb_cur;
+  if (h->binsN_inflight) {
+    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_binsN, 0));
+    h->binsN_inflight = false;
+  }
+  static const int blocks_env = getenv("GNX_LATN_BLOCKS") ? atoi(getenv("GNX_LATN_BLOCKS")) : 256;
+  gnx_time_begin(h);
+  hipLaunchKernelGGL(k_lattice_nmax, dim3(std::max(1, std::min(h->cfg.H, blocks_env))), dim3(256),
+                     lds_bytes, h->stream, L.Jx, L.Jy, L.nbx, (const int32_t*)h->fb[cur], L.areas,
+                     L.hww, L.cprime, h->spl_N.c, h->cfg.W, h->cfg.H, h->nmax2 + cur,
+                     h->fb[cur ^ 1], h->nmax2 + (cur ^ 1));
+  gnx_time_end(h, GNX_K_DENSITY, (double)h->N * 8.0);
+  HIPCHK(hipGetLastError());
+  h->spl_N.valid = true;
+  h->nmax_cur = h->nmax2 + cur;
+  h->nmax_ready = true;
+  h->fb_zero[cur] = false;
+  h->fb_zero[cur ^ 1] = true;
+  h->fb_cur = cur ^ 1;
+  h->fb_adults = false;
+  h->last_N_fused = true;
   return 0;
 }
 
@@ -508,11 +714,13 @@ int gnx_l_death_probs(gnx_state* h, bool with_selection) {
   int64_t N = h->N;
   if (N == 0) return 0;
   SplineC SN = make_splinec(h, h->spl_N), SP = make_splinec(h, h->spl_P);
+  GNXCHK(gnx_wait_latP(h));
   gnx_time_begin(h);
-  GNXCHK(launch_nmax(h));
+  if (!h->nmax_ready) GNXCHK(launch_nmax(h));
+  h->nmax_ready = false;
   hipLaunchKernelGGL(k_death_probs, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream,
                      make_deathp(h, with_selection), make_demp(h), SN, SP, h->soa[h->cur], h->rast,
-                     gnx_trait_tab(h), h->delet_s, h->nmax_bits, h->p_death, h->d_cell);
+                     gnx_trait_tab(h), h->delet_s, h->nmax_cur, h->p_death, h->d_cell);
   gnx_time_end(h, GNX_K_DEATH, (double)N * (28.0 + 8.0 * h->cfg.n_traits));
   HIPCHK(hipGetLastError());
   return 0;

@@ -5,6 +5,7 @@
 #include "gnx_rng.h"
 #include "gnx_compact.h"
 #include "gnx_tb.h"
+#include "gnx_bins.h"
 
 // ---------------------------------------------------------------- helpers
 // bits that hold every resident id (ids are handed out upwards from max_id)
@@ -309,6 +310,7 @@ k_move(MoveP P, GnxSoA s, const float* rast, const float* inj_theta, const float
 int gnx_l_move(gnx_state* h, bool inc_age, const float* inj_theta, const float* inj_dist,
                float* out_theta, float* out_dist, bool apply) {
   if (h->N == 0) return 0;
+  if (apply) h->fb_adults = false;        // bins counted before a movement are stale
   const gnx_config& c = h->cfg;
   const gnx_species_params& sp = h->sp;
   MoveP P;
@@ -408,8 +410,9 @@ __global__ void k_permute(int64_t N, int64_t cap, const int32_t* perm, GnxSoA a,
     ord_new[kk] = (int32_t)i;                   // and the slot it is in now
     perm_out[i] = (int32_t)j;                   // (the sort permutation, as the other path leaves it)
   }
-  b.x[i] = a.x[j];
-  b.y[i] = a.y[j];
+  const float px = a.x[j], py = a.y[j];
+  b.x[i] = px;
+  b.y[i] = py;
   b.age[i] = a.age[j];
   b.sex[i] = a.sex[j];
   const int64_t idv = a.id[j];
@@ -418,7 +421,7 @@ __global__ void k_permute(int64_t N, int64_t cap, const int32_t* perm, GnxSoA a,
   const uint32_t tg = gnx_ind_tag(pair_seed, (unsigned long long)idv);
   tag[i] = tg;
   // packed candidate record for the mate search: one 16-byte load per candidate
-  cand[i] = make_uint4(__float_as_uint(a.x[j]), __float_as_uint(a.y[j]), tg, (uint32_t)idv);
+  cand[i] = make_uint4(__float_as_uint(px), __float_as_uint(py), tg, (uint32_t)idv);
   b.fit[i] = a.fit[j];
   b.grow[i] = a.grow[j];
   b.ghost[i] = a.ghost[j];
@@ -494,6 +497,9 @@ int gnx_l_sort_by_cell(gnx_state* h) {
                      h->ord[h->ord_cur ^ 1], h->perm[1]);
   gnx_time_end(h, GNX_K_PERMUTE,
                (double)N * 2.0 * (33.0 + 4.0 * c.n_layers + 4.0 * c.n_traits + 16.0 * h->TW));
+  // the individuals' density bins (positions are final for this step): counted on stream3,
+  // beside the mate search, when the step's density path is the fused one (gnx_internal.h: fb)
+  GNXCHK(gnx_l_bins_adults_async(h, b.x, b.y, N));
   if (ordm) {
     h->ord_cur ^= 1;
     h->ord_n = N;
@@ -1082,7 +1088,11 @@ int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out, 
                      h->mid_x, h->mid_y, h->key64[0]);
   gnx_time_end(h, GNX_K_PAIRS, (double)N * 40.0);
   HIPCHK(hipGetLastError());
-  if (with_density) {
+  // the pair midpoints' density (ops/demography.py:60-91): on one GPU bins + lattice run on
+  // stream3 beside k_offspring and the death probabilities wait for them
+  if (with_density && gnx_fused_bins(h)) {
+    GNXCHK(gnx_l_lattice_P_async(h, N));
+  } else if (with_density) {
     // the density of the pair midpoints reads the pair count on the device (at most N
     // pairs: the grid's bound) while the host waits for its copy in pinned memory
     const bool lds_bins = (size_t)h->lat.nbx * h->lat.nby * sizeof(int32_t) <= 48 * 1024;
@@ -1150,6 +1160,7 @@ struct OffP {
   int fuse_tb, TW;
   const uint64_t* path_sel;
   const uint8_t* dom;
+  GnxBinP bins;          // the individuals' density bins (the newborns join the adults)
 };
 
 // gamete requests of a tiled run: the mate is a ghost (it lives on a neighbour
@@ -1270,6 +1281,7 @@ k_offspring(OffP P, GnxSoA s, const float* rast, const int32_t* pairs, const int
       if (T.n_traits > 0) gnx_phenotype_tb(t0, t0 + P.TW, T, P.dom, P.cap, slot, s.z);
     }
   }
+  if (P.bins.bins) gnx_bin_add(P.bins.bins, gnx_bin_of(P.bins, ox, oy), true);
 }
 
 // appends B offspring whose parents/keys/starts were uploaded to
@@ -1390,6 +1402,14 @@ int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* 
     Q.TW = h->TW;
     Q.path_sel = h->path_sel;
     Q.dom = h->dom;
+    // (the adults were counted by k_permute of this very population)
+    Q.bins = GnxBinP{nullptr, 1.0 / h->lat.hww, h->lat.nbx, h->lat.nby};
+    if (gnx_fused_bins(h) && h->fb_adults && h->fb_count == h->N) {
+      Q.bins.bins = h->fb[h->fb_cur];
+      h->fb_count += B;
+    } else {
+      h->fb_adults = false;
+    }
     GnxReq rq{};
     if (tiled && genomes) {
       rq.pid = h->req_pid;

@@ -355,7 +355,10 @@ extern "C" int gnx_tile_pair_info(gnx_state* h, int64_t* focal_ids, int32_t* n_b
 extern "C" int gnx_get_bins(gnx_state* h, int32_t which, int32_t* out) {
   size_t nb = (size_t)h->lat.nbx * h->lat.nby;
   HIPCHK(hipStreamSynchronize(h->stream));
-  GNXCHK(gnx_d2h(h, out, which ? h->bins_P : h->bin_partials, nb * sizeof(int32_t)));
+  // the individuals' counts of the last density: where the step's own kernels counted them
+  // (one GPU, gnx_bins.h; intact until the next step's lattice), or the counting pass's bins
+  const int32_t* src = which ? h->bins_P : (h->last_N_fused ? h->fb[h->fb_cur ^ 1] : h->bin_partials);
+  GNXCHK(gnx_d2h(h, out, src, nb * sizeof(int32_t)));
   return 0;
 }
 
@@ -363,6 +366,7 @@ extern "C" int gnx_set_bins(gnx_state* h, int32_t which, const int32_t* in) {
   size_t nb = (size_t)h->lat.nbx * h->lat.nby;
   GNXCHK(gnx_h2d(h, which ? h->bins_P : h->bin_partials, in, nb * sizeof(int32_t)));
   h->bins_zeroed[which ? 1 : 0] = false;
+  if (!which) h->last_N_fused = false;
   return 0;
 }
 
@@ -591,6 +595,7 @@ extern "C" int gnx_tile_finish_births(gnx_state* h, int32_t burn) {
     GNXCHK(gnx_l_phenotype(h, h->birth_first_slot, B));
   }
   GnxSoA s = h->soa[h->cur];
+  h->last_N_fused = false;
   GNXCHK(gnx_l_bins(h, h->N, s.x, s.y, s.ghost, h->bin_partials));
   return 0;
 }
