@@ -261,26 +261,70 @@ def model_api_measure(cfg, name, steps, warmup=5):
     return out, mod
 
 
-def measured_copy_bandwidth(torch, nbytes=16 << 30, reps=5):
-    """read + write bytes / time of a 16-GiB device-to-device copy (GB/s); the buffers are
-    large on purpose: on this part the rate of a streaming kernel grows with the span of
-    HBM it touches (profiles/r02_xo_lab_footprint.txt)"""
+def measured_copy_bandwidth(nbytes=8 << 30, reps=5):
+    """read + write bytes / time of the library's hand-written copy kernel (16 bytes per lane
+    and access, non-temporal, csrc/gnx_stats.hip: gnx_measure_copy) over two 8-GiB buffers;
+    the buffers are large on purpose: on this part the rate of a streaming kernel grows with
+    the span of HBM it touches (profiles/r02_xo_lab_footprint.txt)"""
     try:
-        a = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
-        b = torch.empty_like(a)
-        b.copy_(a)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            b.copy_(a)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
-        del a, b
-        return 2.0 * nbytes / (ms * 1e-3) / 1e9
+        from geonomics_amd import _native as nat
+        return nat.measure_copy(nbytes, reps)
     except Exception:
         return None
+
+
+def kernel_profile(dev, do_step, n_steps=10):
+    """per-kernel-family HIP-event time and algorithmic bytes per step (the
+    library's own accounting) over n_steps extra steps OUTSIDE the timed region"""
+    dev.profiling(1)
+    for _ in range(n_steps):
+        do_step(False)
+    dev.synchronize()
+    kt = dev.kernel_times()
+    dev.profiling(False)
+    fam = {k: {'ms_per_step': v['ms'] / n_steps, 'bytes_per_step': v['bytes'] / n_steps,
+               'GBps': (v['bytes'] / (v['ms'] * 1e-3) / 1e9) if v['ms'] > 0 else 0.0}
+           for k, v in kt.items() if v['launches'] > 0}
+    return fam
+
+
+def measure_other_workload(name, steps=30, warmup=5):
+    """a short run of another BASELINE configuration on the same box (N = 1): ms/step,
+    individual-timesteps/s, the dominant kernel family and its rate"""
+    cfg = WORKLOADS[name]
+    t0 = time.time()
+    dev, _, _ = build_device(cfg, seed=42, device=0)
+    for _ in range(3):
+        dev.step(True, False)
+    setup_genomes(dev, cfg, seed=42)
+    for _ in range(warmup):
+        dev.step(False, True)
+    dev.synchronize()
+    setup = time.time() - t0
+    t1 = time.perf_counter()
+    n = births = 0
+    for _ in range(steps):
+        n += dev.N
+        dev.step(False, True)
+        births += dev.counts()[1]
+    dev.synchronize()
+    dt = time.perf_counter() - t1
+    fam = kernel_profile(dev, lambda burn: dev.step(burn, not burn), 10)
+    dev.close()
+    dom = max(fam, key=lambda k: fam[k]['ms_per_step'])
+    dense = cfg.get('paths') == 'dense'
+    out = {'workload': '%s: %dx%d, N0=%d, L=%d, %d traits, move_surf=%s, %s' % (
+               name, cfg['W'], cfg['H'], cfg['N'], cfg['L'], cfg['n_traits'], cfg['move_surf'],
+               'r=0.5 (dense masks)' if dense else 'r=1/L'),
+           'steps': steps, 'warmup': warmup, 'ms_per_step': 1e3 * dt / steps,
+           'value': n / dt, 'unit': 'individual-timesteps/s', 'mean_N': n / steps,
+           'births_per_step': births / steps, 'setup_s': round(setup, 1),
+           'dominant_kernel': dom, 'dominant_ms_per_step': fam[dom]['ms_per_step'],
+           'dominant_GBps': fam[dom]['GBps'], 'dominant_frac': fam[dom]['GBps'] / 8000.0,
+           'bytes_per_step': sum(v['bytes_per_step'] for v in fam.values()),
+           'kernel_ms_per_step': {k: round(v['ms_per_step'], 4) for k, v in fam.items()}}
+    out['step_frac'] = out['bytes_per_step'] / (out['ms_per_step'] * 1e-3) / 1e9 / 8000.0
+    return out
 
 
 def spawn_ranks(args):
@@ -348,6 +392,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-model-api', action='store_true',
                     help='skip the second measurement through Model.walk (N = 1 only)')
+    ap.add_argument('--no-other-workloads', action='store_true',
+                    help='skip the short runs of BASELINE configs[1], [2] and the dense-mask '
+                         'variant (N = 1, default workload only)')
     args = ap.parse_args()
 
     env_world = os.environ.get('WORLD_SIZE')
@@ -500,6 +547,9 @@ def main():
                               'movement wait for it)')
         alt = other_mode(1, 'crossover (8 workgroups per CU) beside the whole next step: nothing waits '
                              'for it but the next crossover')
+    fam = None
+    if stepper is None:
+        fam = kernel_profile(dev, do_step, 10)
     phases = None
     if stepper is not None:
         # per-phase host wall time of the tile protocol, from a few extra steps with a
@@ -537,7 +587,7 @@ def main():
                     break
             except Exception:
                 continue
-        copy_gbps = measured_copy_bandwidth(torch)
+        copy_gbps = measured_copy_bandwidth()
         dense = cfg.get('paths') == 'dense'
         per_gamete = (4.0 if dense else 2.0) * dev.W64 * 8.0
         out = {
@@ -582,7 +632,14 @@ def main():
                     xo['bytes'] / max(xo['launches'], 1) / per_gamete,
                 'share_of_the_survivors_gametes_not_copied':
                     1.0 - (xo['bytes'] / per_gamete) / max(2.0 * xo_births, 1.0),
-                # also quote a device-to-device copy measured on this box
+                # SURVEY 8(d)'s figure for the same launch: every birth cut in full, L bytes
+                # each (4 homologue reads + 2 masks + 2 writes) - what the kernel would move
+                # without the deferral behind the death draws and without shared blocks
+                'survey_bytes_per_launch': births / args.steps * cfg['L'],
+                'work_avoided_factor': (births / args.steps * cfg['L']) /
+                                       max(xo['bytes'] / max(xo['launches'], 1), 1.0),
+                # also quote a device-to-device copy measured on this box (the
+                # library's own 16-byte-per-lane copy kernel, two 8-GiB buffers)
                 'measured_copy_GBps': copy_gbps,
                 'frac_of_measured_copy': (ach / copy_gbps) if copy_gbps else None,
             },
@@ -591,6 +648,21 @@ def main():
             'kernel_ms_per_step': {k: v['ms'] / args.steps for k, v in kt.items()
                                    if v['launches'] > 0},
         }
+        if fam is not None:
+            # the whole step against the roofline: every kernel family's algorithmic bytes
+            # (the crossover's as moved) over the timed region's ms per step
+            step_bytes = sum(v['bytes_per_step'] for v in fam.values())
+            out['roofline']['step'] = {
+                'algorithmic_bytes_per_step': step_bytes,
+                'achieved': step_bytes / (out['ms_per_step'] * 1e-3) / 1e9,
+                'peak': peak, 'unit': 'GB/s',
+                'frac': step_bytes / (out['ms_per_step'] * 1e-3) / 1e9 / peak,
+                'kernel_ms_sum': sum(v['ms_per_step'] for v in fam.values()),
+                'families': {k: {'ms': round(v['ms_per_step'], 4),
+                                 'MB': round(v['bytes_per_step'] / 1e6, 2)}
+                             for k, v in fam.items()},
+                'note': 'bytes and per-family times from 10 extra steps with every kernel '
+                        'family bracketed by HIP events, outside the timed region'}
         if phases is not None:
             out['tile_phase_ms_per_step'] = phases
         if alone is not None:
@@ -602,9 +674,21 @@ def main():
             ref = ref_cpu_number()
             if ref is not None:
                 out['cpu_baseline']['reference'] = ref
+        if (world == 1 and args.workload == 'c4_metric' and not args.no_other_workloads
+                and stepper is None):
+            # BASELINE configs[1], [2] and the template's recombination default, short runs
+            dev.close()
+            dev = None
+            out['other_workloads'] = {}
+            for name in ('c2', 'c3', 'c4_dense'):
+                try:
+                    out['other_workloads'][name] = measure_other_workload(name)
+                except Exception as e:
+                    out['other_workloads'][name] = {'error': '%s: %s' % (type(e).__name__, e)}
         if world == 1 and not args.no_model_api:
             # the same workload through the drop-in API, at the model's own equilibrium
-            dev.close()
+            if dev is not None:
+                dev.close()
             dev = None
             try:
                 out['model_api'], _ = model_api_measure(cfg, args.workload, min(args.steps, 40))

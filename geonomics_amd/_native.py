@@ -46,7 +46,7 @@ EXPORTS = [
     'gnx_tile_offspring_dev', 'gnx_tile_group_requests', 'gnx_tile_serve_gametes_dev',
     'gnx_tile_put_gametes_dev', 'gnx_tile_bins_ptr', 'gnx_set_k_raster', 'gnx_last_births', 'gnx_set_positions', 'gnx_n_slots', 'gnx_stats_ld_counts',
     'gnx_set_defer_crossover', 'gnx_last_crossover_births', 'gnx_set_crossover_overlap', 'gnx_set_crossover_split', 'gnx_debug_halves', 'gnx_spatial_diff_sums', 'gnx_last_crossover_jobs',
-    'gnx_genome_info',
+    'gnx_genome_info', 'gnx_measure_copy',
 ]
 
 
@@ -709,6 +709,16 @@ class Device:
                                                C.byref(by)))
             out[name] = dict(ms=ms.value, launches=n.value, bytes=by.value)
         return out
+
+
+def measure_copy(nbytes=8 << 30, reps=5):
+    """GB/s (read + written) of the library's own 16-byte-per-lane copy kernel on the current
+    device: the box's streaming rate beside the 8 TB/s of the data sheet"""
+    lib = load()
+    out = C.c_double()
+    if lib.gnx_measure_copy(C.c_int64(int(nbytes)), int(reps), C.byref(out)):
+        raise GnxError(lib.gnx_last_error().decode())
+    return out.value
 
 
 def default_species_params(**kw):

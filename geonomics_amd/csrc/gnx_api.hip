@@ -66,8 +66,12 @@ int gnx_wait_published(gnx_state* h, int slot, int64_t seq) {
   return 0;
 }
 
-void gnx_time_begin(gnx_state* h) {
+void gnx_time_begin(gnx_state* h, int kernel) {
   if (!h->profiling) return;
+  if (h->profile_only >= 0 && kernel != h->profile_only) {
+    h->ev_open = nullptr;
+    return;
+  }
   h->ev_open = timer_event(h);
   (void)hipEventRecord(h->ev_open, h->stream);
 }

@@ -396,7 +396,10 @@ int gnx_publish(gnx_state* h, int slot, const int32_t* a, const int32_t* b = nul
                 const int32_t* c = nullptr, const int32_t* d = nullptr);
 
 // RAII-less scoped timer helpers (events on h->stream)
-void gnx_time_begin(gnx_state* h);
+// kernel: the family about to be timed, when the caller knows it - with only one family
+// profiled (bench.py's timed region) the others record no event at all: an event record
+// is a packet of its own on the stream, a few microseconds each
+void gnx_time_begin(gnx_state* h, int kernel = -1);
 void gnx_time_end(gnx_state* h, int kernel, double bytes);
 
 // host <-> device copies through the pinned staging buffer (pageable hipMemcpy

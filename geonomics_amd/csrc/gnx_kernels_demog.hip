@@ -1265,7 +1265,9 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
   // row: block offsets on the device, totals also straight into pinned host memory.
   // (Measured and dropped: death probabilities + death draws + the scan by the last
   // workgroup in ONE kernel took 73 us against 34 + 13 + 10 apart, 0.820 against 0.808
-  // ms/step - four individuals per thread starve the f64 spline gathers of parallelism.)
+  // ms/step - four individuals per thread starve the f64 spline gathers of parallelism;
+  // with one individual per thread of a 1024-thread workgroup and the scan left apart the
+  // step takes the same 0.766 ms either way: the launches are not what the chain costs.)
   GNXCHK(gnx_block_scan(h, 3, N, h->blk_cnt, h->blk_off, h->cnt_dev, h->h_pin_dev));
   gnx_time_end(h, GNX_K_COMPACT, 0.0);
   // the host only needs the counts: it waits for the scan, not for the compaction, and

@@ -153,7 +153,7 @@ int gnx_l_crossover_all(gnx_state* h, int64_t first_slot, int64_t B) {
     HIPCHK(hipEventRecord(h->ev_jobs, h->stream));
     HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_jobs, 0));
   }
-  gnx_time_begin(h);
+  gnx_time_begin(h, GNX_K_CROSSOVER);
   GNXCHK(xo_launch(h, h->stream, buf, 2 * B, false));
   gnx_time_end(h, GNX_K_CROSSOVER, 0.0);   // bytes: the kernels count the gametes they copy
   h->n_free -= B;
@@ -203,7 +203,7 @@ int gnx_l_crossover_requests(gnx_state* h, int64_t first_slot, int64_t n_req) {
     HIPCHK(hipEventRecord(h->ev_jobs, h->stream));
     HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_jobs, 0));
   }
-  gnx_time_begin(h);
+  gnx_time_begin(h, GNX_K_CROSSOVER);
   GNXCHK(xo_launch(h, h->stream, buf, n_req, false));
   gnx_time_end(h, GNX_K_CROSSOVER, 0.0);
   h->n_free -= n_req;
@@ -245,7 +245,7 @@ int gnx_l_crossover_pending(gnx_state* h, int64_t first_slot, int64_t B) {
   GNXCHK(gnx_half_reserve(h, 2 * (int64_t)h->NB * B));
   HIPCHK(hipMemsetAsync(h->n_jobs_dev[buf], 0, sizeof(int32_t), h->stream));
   gnx_launch_xo_jobs_surv(h, first_slot, h->flag, h->blk_off, buf);
-  gnx_time_begin(h);
+  gnx_time_begin(h, GNX_K_CROSSOVER);
   GNXCHK(xo_launch(h, h->stream, buf, 2 * B, false));
   HIPCHK(hipStreamSynchronize(h->stream));
   const int64_t S = h->h_pin[8];
@@ -271,14 +271,14 @@ int gnx_xo_launch_pending(gnx_state* h) {
   // which are latency-bound chains and leave the memory system idle.
   const int split = (h->xo_sort_waits && h->xo_split > 0 && h->xo_split < 1024) ? h->xo_split : 0;
   h->xo_last_split = split;
-  gnx_time_begin(h);
+  gnx_time_begin(h, GNX_K_CROSSOVER);
   int rc = xo_launch(h, h->stream2, buf, h->xo_ready_jobs, !h->xo_sort_waits, 0,
                      split ? split : 1024);
   gnx_time_end(h, GNX_K_CROSSOVER, 0.0);
   if (split && !rc) {
     HIPCHK(hipEventRecord(h->ev_xo_wide[buf], h->stream2));
     h->xo_wide_inflight[buf] = true;
-    gnx_time_begin(h);
+    gnx_time_begin(h, GNX_K_CROSSOVER);
     rc = xo_launch(h, h->stream2, buf, h->xo_ready_jobs, true, split, 1024);
     gnx_time_end(h, GNX_K_CROSSOVER_TAIL, 0.0);
   }

@@ -201,3 +201,69 @@ extern "C" int gnx_stats_ld(gnx_state* h, int32_t n_loci, const int32_t* loci, d
   HIPCHK(hipGetLastError());
   return rc;
 }
+
+// ---------------------------------------------------------------- box copy rate (bench.py)
+struct alignas(16) gnx_b16 {
+  unsigned long long a, b;
+};
+
+template <int U>
+__global__ void __launch_bounds__(256)
+k_copy16(int64_t n16, const gnx_b16* __restrict__ in, gnx_b16* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * 256 * U;
+  for (int64_t i0 = (int64_t)blockIdx.x * 256 * U + threadIdx.x; i0 < n16; i0 += stride) {
+    gnx_b16 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + u * 256;
+      if (i < n16) {
+        v[u].a = __builtin_nontemporal_load(&in[i].a);
+        v[u].b = __builtin_nontemporal_load(&in[i].b);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + u * 256;
+      if (i < n16) {
+        __builtin_nontemporal_store(v[u].a, &out[i].a);
+        __builtin_nontemporal_store(v[u].b, &out[i].b);
+      }
+    }
+  }
+}
+
+extern "C" int gnx_measure_copy(int64_t bytes, int32_t reps, double* gbps) {
+  *gbps = 0.0;
+  if (bytes < 4096 || reps < 1) {
+    gnx_set_error("gnx_measure_copy: bytes >= 4096 and reps >= 1");
+    return 1;
+  }
+  gnx_b16 *a = nullptr, *b = nullptr;
+  HIPCHK(hipMalloc((void**)&a, (size_t)bytes));
+  if (hipMalloc((void**)&b, (size_t)bytes) != hipSuccess) {
+    (void)hipFree(a);
+    gnx_set_error("gnx_measure_copy: out of memory");
+    return 1;
+  }
+  const int64_t n16 = bytes / 16;
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipMemsetAsync(a, 1, (size_t)bytes, nullptr));
+  const int grid = 256 * 16;          // 16 workgroups per CU, 4 chunks in flight per lane
+  hipLaunchKernelGGL(k_copy16<4>, dim3(grid), dim3(256), 0, nullptr, n16, a, b);
+  HIPCHK(hipEventRecord(e0, nullptr));
+  for (int r = 0; r < reps; ++r)
+    hipLaunchKernelGGL(k_copy16<4>, dim3(grid), dim3(256), 0, nullptr, n16, a, b);
+  HIPCHK(hipEventRecord(e1, nullptr));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(a);
+  (void)hipFree(b);
+  HIPCHK(hipGetLastError());
+  if (ms > 0.f) *gbps = 2.0 * (double)n16 * 16.0 * reps / (ms * 1e-3) / 1e9;
+  return 0;
+}

@@ -385,6 +385,11 @@ int gnx_profiling(gnx_state* h, int32_t on);
  * measured on the handle's stream; resets the accumulator                   */
 int gnx_kernel_time(gnx_state* h, int32_t kernel, double* ms, int64_t* launches,
                     double* algorithmic_bytes);
+/* The box's own streaming rate, for the roofline line ("a measured
+ * device-to-device copy"): a hand-written copy kernel, 16 bytes per lane and access,
+ * grid-stride, over two buffers of `bytes` bytes each, `reps` launches timed with HIP
+ * events on the current device; *gbps = (read + written bytes) / mean launch time.      */
+int gnx_measure_copy(int64_t bytes, int32_t reps, double* gbps);
 
 #ifdef __cplusplus
 }

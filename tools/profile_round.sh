@@ -13,10 +13,10 @@ export GNX_BENCH_NO_ALT=1
 OUT=$ROOT/gpurun_out
 cd "$ROOT"
 rm -rf $OUT/prof_$TAG $OUT/pmc_fetch_$TAG $OUT/pmc_write_$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o run -- python3 bench.py --workload $WL --steps 20 --warmup 5 --no-cpu-baseline --no-model-api > $OUT/prof_${TAG}_bench.json 2> $OUT/prof_${TAG}.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o run -- python3 bench.py --workload $WL --steps 20 --warmup 5 --no-cpu-baseline --no-model-api --no-other-workloads > $OUT/prof_${TAG}_bench.json 2> $OUT/prof_${TAG}.err
 echo "kernel stats done"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$TAG -o run -- python3 bench.py --workload $WL --steps 6 --warmup 2 --no-cpu-baseline --no-model-api > $OUT/pmc_fetch_${TAG}.json 2> $OUT/pmc_fetch_${TAG}.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$TAG -o run -- python3 bench.py --workload $WL --steps 6 --warmup 2 --no-cpu-baseline --no-model-api --no-other-workloads > $OUT/pmc_fetch_${TAG}.json 2> $OUT/pmc_fetch_${TAG}.err
 echo "pmc fetch done"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_$TAG -o run -- python3 bench.py --workload $WL --steps 6 --warmup 2 --no-cpu-baseline --no-model-api > $OUT/pmc_write_${TAG}.json 2> $OUT/pmc_write_${TAG}.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_$TAG -o run -- python3 bench.py --workload $WL --steps 6 --warmup 2 --no-cpu-baseline --no-model-api --no-other-workloads > $OUT/pmc_write_${TAG}.json 2> $OUT/pmc_write_${TAG}.err
 echo "pmc write done"
 python3 tools/pmc_summary.py $TAG $WL
