@@ -263,7 +263,10 @@ def pop_dynamics(s, burn=False, with_selection=True):
     B = mate(s, pairs, burn)
     VN = s.lat.node_density(s.x, s.y)
     pd_, _ = death_probs(s, with_selection and not burn, VN, VP)
-    dead = D.death_draws(s.seed, s.id, s.step).astype(np.float64) < pd_
+    u = D.death_draws(s.seed, s.id, s.step).astype(np.float64)
+    dead = u < pd_
+    # (kept for the tests that explain where a device run and this one part ways)
+    s.last_death = dict(ids=s.id.copy(), u=u, p=pd_.copy())
     keep = ~dead
     _permute(s, np.nonzero(keep)[0])
     s.n_births.append(B)

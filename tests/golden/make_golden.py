@@ -545,9 +545,10 @@ def g11_conductance():
 def g10_envelopes():
     """Whole-model envelopes from the reference: neutral 2-layer model, real
     burn-in (ADF stubbed to pass; paired t-tests active), 100 main steps,
-    8 seeds (each with its own randomly drawn trait architecture)."""
+    24 seeds (each with its own randomly drawn trait architecture; 8 in round 2: the
+    tolerances of the whole-model tests follow the sampling error of the seed means)."""
     out = {}
-    for s in range(1, 9):
+    for s in range(1, 25):
         mod = make_ref_model(dim=(30, 30), N=300, L=60, traits=True,
                              K_factor=0.5, r_alpha=0.5, n_recomb=60, seed=s,
                              mating_radius=4)
@@ -569,6 +570,7 @@ def g10_envelopes():
             out['s%i_t%i_alpha' % (s, t)] = np.asarray(trt.alpha, dtype=float)
             out['s%i_t%i_par' % (s, t)] = np.array(
                 [trt.lyr_num, trt.phi, trt.gamma, float(trt.univ_adv)])
+    out['n_seeds'] = np.array([24])
     save('g10_envelopes', **out)
 
 
@@ -823,14 +825,58 @@ def g16_spatial_tester():
     save('g16_spatial_tester', **out)
 
 
+def g17_pedigree_segments():
+    """The tree-sequence edge rows of a gamete (use_tskit=True): Recombinations._set_seg_info
+    and _get_seg_info (structs/genome.py:209-281) called as ops/mating.py:141-148 calls
+    them - (start homologue, event key, the parent's two node ids) -> (parent node, left,
+    right) per segment.  Pure numpy in the reference; tskit only stores the rows
+    (structs/species.py:731-736).  Breakpoint jitter off (it adds uniform noise)."""
+    out = {}
+    for tag, (L, n, alpha) in {'sparse': (300, 25, 0.01), 'homog': (190, 10, None),
+                               'free': (64, 8, 0.5)}.items():
+        np.random.seed(11)
+        rec = ref_genome.Recombinations(L, None, n, alpha, None, None, False)
+        np.random.seed(12)
+        rec._set_events(True, np.array([], dtype=int), True)       # use_tskit: breakpoints kept
+        bps = [np.asarray(rec._breakpoints[k], dtype=np.int64) for k in range(n)]
+        rng = np.random.RandomState(3)
+        keys, starts, nodes0 = [], [], []
+        seg_node, seg_left, seg_right, seg_n = [], [], [], []
+        for k in range(n):
+            for st in (0, 1):
+                pid = int(rng.randint(0, 500))
+                node_ids = np.array([2 * pid, 2 * pid + 1])
+                segs = [*rec._get_seg_info(start_homologue=st, event_key=k, node_ids=node_ids)]
+                keys.append(k)
+                starts.append(st)
+                nodes0.append(2 * pid)
+                seg_n.append(len(segs))
+                seg_node += [int(sg[0]) for sg in segs]
+                seg_left += [float(sg[1]) for sg in segs]
+                seg_right += [float(sg[2]) for sg in segs]
+        out[tag + '_L'] = np.array([L])
+        out[tag + '_bp_off'] = np.concatenate([[0], np.cumsum([b.size for b in bps])]).astype(np.int64)
+        out[tag + '_bp_loci'] = (np.concatenate(bps) if bps else np.zeros(0)).astype(np.int64)
+        out[tag + '_keys'] = np.array(keys)
+        out[tag + '_starts'] = np.array(starts)
+        out[tag + '_parent_node0'] = np.array(nodes0)
+        out[tag + '_seg_n'] = np.array(seg_n)
+        out[tag + '_seg_node'] = np.array(seg_node)
+        out[tag + '_seg_left'] = np.array(seg_left)
+        out[tag + '_seg_right'] = np.array(seg_right)
+        print('g17', tag, 'gametes', len(keys), 'segments', len(seg_node), flush=True)
+    save('g17_pedigree_segments', **out)
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g7', 'g8', 'g9',
-                             'g10', 'g11', 'g12', 'g13', 'g14', 'g15', 'g16']
+                             'g10', 'g11', 'g12', 'g13', 'g14', 'g15', 'g16', 'g17']
     fns = {'g1': g1_crossover, 'g2': g2_recomb_paths,
            'g3': g3_phenotype_fitness, 'g4': g4_density,
            'g5': g5_demography, 'g7': g7_movement, 'g8': g8_pairing,
            'g9': g9_starting_genomes, 'g10': g10_envelopes,
            'g11': g11_conductance, 'g12': g12_stats, 'g13': g13_change,
-           'g14': g14_data, 'g15': g15_wf, 'g16': g16_spatial_tester}
+           'g14': g14_data, 'g15': g15_wf, 'g16': g16_spatial_tester,
+           'g17': g17_pedigree_segments}
     for w in which:
         fns[w]()

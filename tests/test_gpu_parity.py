@@ -323,8 +323,9 @@ def test_density_vs_oracle_and_reference(tag):
     # vs the reference's griddata raster: stated tolerance
     ref = np.clip(g[tag + '_dens'], 0, None)
     diff = np.abs(rast - ref)
-    assert diff.mean() <= 0.015 * ref.mean()
-    assert diff.max() <= 0.06 * ref.max()
+    from test_oracle_golden import DENSITY_BOUNDS       # per fixture, measured x 1.15
+    assert diff.mean() <= DENSITY_BOUNDS[tag][0] * ref.mean()
+    assert diff.max() <= DENSITY_BOUNDS[tag][1] * ref.max()
     # empty input -> zero raster
     nodes0, rast0 = dev.op_density(np.zeros(0), np.zeros(0))
     assert (nodes0 == 0).all() and (rast0 == 0).all()
@@ -628,13 +629,17 @@ def test_whole_model_envelopes_vs_reference_on_device():
     ref = dict(burn=[], first=[], main=[])
     mine = dict(burn=[], first=[], main=[])
     drift_ref, drift_mine = [], []
-    for s in range(1, 9):
+    n_seeds = int(g['n_seeds'][0])
+    # two device runs per reference run (the device's side of every ratio then carries
+    # half the sampling variance of the reference's 24 runs)
+    for s, seed0 in [(s, seed0) for seed0 in (200, 700) for s in range(1, n_seeds + 1)]:
         nb = int(g['s%i_nburn' % s][0])
         R = g['s%i_Nt' % s]
-        ref['burn'].append(R[10:nb].mean())
-        ref['first'].append(R[nb:nb + 20].mean())
-        ref['main'].append(R[-50:].mean())
-        dev = make_dev(W, H, rasts=rasts, L=L, n_traits=3, cap=4096, seed=200 + s,
+        if seed0 == 200:
+            ref['burn'].append(R[10:nb].mean())
+            ref['first'].append(R[nb:nb + 20].mean())
+            ref['main'].append(R[-50:].mean())
+        dev = make_dev(W, H, rasts=rasts, L=L, n_traits=3, cap=4096, seed=seed0 + s,
                        mating_radius=4.0, K_factor=0.5)
         for t in range(3):
             par = g['s%i_t%i_par' % (s, t)]
@@ -661,29 +666,37 @@ def test_whole_model_envelopes_vs_reference_on_device():
         neutral = np.setdiff1d(np.arange(L), sel)
         c1, _ = dev.stats_locus_counts()
         drift_mine.append((c1 / (2.0 * dev.N))[neutral] - 0.5)
-        drift_ref.append(g['s%i_freq' % s][neutral] - 0.5)
+        if seed0 == 200:
+            drift_ref.append(g['s%i_freq' % s][neutral] - 0.5)
         dev.close()
     v_ref = np.mean(np.concatenate(drift_ref) ** 2)
     v_mine = np.mean(np.concatenate(drift_mine) ** 2)
-    # ~380 independent loci each: the two variance estimates carry ~7 % sampling error
-    assert 0.7 < v_mine / v_ref < 1.4, (v_mine, v_ref)
+    # 24 reference runs x 48 neutral loci, twice as many device runs: the ratio carries ~6 %
+    # sampling error (the numpy oracle under three seed sets: 0.98, 0.92, 1.00)
     m = {k: (np.mean(ref[k]), np.mean(mine[k])) for k in ref}
-    assert abs(m['burn'][1] / m['burn'][0] - 1) < 0.04, m
-    assert abs(m['first'][1] / m['first'][0] - 1) < 0.15, m
-    assert abs(m['main'][1] / m['main'][0] - 1) < 0.15, m
+    print('drift variance ratio %.3f' % (v_mine / v_ref),
+          {k: round(v[1] / v[0] - 1, 4) for k, v in m.items()})
+    assert 0.85 < v_mine / v_ref < 1.18, (v_mine, v_ref)
+    assert abs(m['burn'][1] / m['burn'][0] - 1) < 0.03, m
+    assert abs(m['first'][1] / m['first'][0] - 1) < 0.06, m
+    assert abs(m['main'][1] / m['main'][0] - 1) < 0.06, m
 
 
 def test_device_step_matches_oracle_step_counts():
-    """The oracle's whole step uses the device's random streams: populations
-    evolve through the same integer decisions; only float rounding (logf/cosf)
-    can flip a decision (an individual on the other side of a hash-cell border
-    changes the candidate list its neighbours index into, so the two runs drift
-    apart step by step).  The first steps must agree exactly, the later ones
-    within sampling noise."""
+    """The oracle's whole step uses the device's random streams, so the two populations go
+    through the same integer decisions: births, deaths and the set of living ids must agree
+    EXACTLY, step after step, until a decision sits on a rounding tie - the device's
+    logf / cosf / f32 expressions differ from numpy's in the last bits.  The first step
+    that differs must show such a tie, and the test names it: a death draw u within 1e-5
+    of its probability p, an individual whose two positions fall into different hash or
+    raster cells, or a pair of individuals within 1e-4 of the mating radius.  After the
+    first flip the two runs are different populations and only their statistics are
+    compared."""
     import gnx_step as S
     nat = native()
     W = H = 40
     L = 128
+    radius = 3.0
     rasts = np.stack([np.ones((H, W)), np.tile(np.linspace(0, 1, W), (H, 1))]).astype(np.float32)
     rng = np.random.RandomState(4)
     paths = O.pack_bits(O.recomb_paths((rng.rand(32, L) < 0.02).astype(np.uint8)
@@ -692,33 +705,81 @@ def test_device_step_matches_oracle_step_counts():
     alpha = np.array([0.1, -0.1, 0.1, -0.1])
     seed = 31
     dev = make_dev(W, H, rasts=rasts, L=L, n_traits=1, cap=8192, seed=seed,
-                   mating_radius=3.0, K_factor=0.6)
+                   mating_radius=radius, K_factor=0.6)
     dev.set_trait(0, loci, alpha, 1, 0.05, 1.0, False)
     dev.set_recomb_paths(paths)
     dev.init_population(900)
-    st = S.State(rasts, S.Params(mating_radius=3.0, K_factor=0.6), seed, L=L,
+    st = S.State(rasts, S.Params(mating_radius=radius, K_factor=0.6), seed, L=L,
                  traits=[dict(loci=loci, alpha=alpha, layer=1, phi=0.05, gamma=1.0,
                               univ_adv=False)], paths_packed=paths)
     st.init_population(900)
     np.testing.assert_array_equal(dev.download(nat.F_X), st.x)
-    same = 0
-    tot = 0
+
+    def by_id(ids, *arrs):
+        o = np.argsort(ids)
+        return (ids[o],) + tuple(a[o] for a in arrs)
+
+    def witness(xd, yd, xo, yo, ids, death):
+        """a rounding tie that explains a differing decision of this step, or None"""
+        cs = radius * (1.0 + 1e-9)
+        for name, ad, ao in (('hash cell x', xd / cs, xo / cs), ('hash cell y', yd / cs, yo / cs),
+                             ('raster cell x', xd, xo), ('raster cell y', yd, yo)):
+            k = np.nonzero(np.floor(ad) != np.floor(ao))[0]
+            if k.size:
+                return 'id %d: %s, device %r oracle %r' % (ids[k[0]], name, ad[k[0]], ao[k[0]])
+        d = np.hypot(xo[:, None] - xo[None, :], yo[:, None] - yo[None, :])
+        i, j = np.nonzero(np.abs(d - radius) < 1e-4)
+        if i.size:
+            return 'ids %d, %d: distance %r against radius %r' % (ids[i[0]], ids[j[0]],
+                                                                  d[i[0], j[0]], radius)
+        m = np.abs(death['u'] - death['p'])
+        k = int(np.argmin(m))
+        if m[k] < 1e-5:
+            return 'id %d: death draw u = %r against p = %r' % (death['ids'][k], death['u'][k],
+                                                              death['p'][k])
+        return None
+
+    synced, exact_steps, first_flip = True, 0, None
     for t in range(20):
         burn = t < 10
         if t == 10:
-            n = O.starting_mutation_counts(dev.N, np.full(L, 0.5))
-            dev.assign_genomes(n)
+            dev.assign_genomes(O.starting_mutation_counts(dev.N, np.full(L, 0.5)))
             st.assign_genomes(O.starting_mutation_counts(st.N, np.full(L, 0.5)))
-        dev.step(burn, not burn)
-        _, B, Dth = S.step(st, burn=burn, with_selection=not burn)
+        dev.age()
+        dev.move()
+        st.Nt.append(st.N)
+        S.move(st, inc_age=True)
+        if synced:
+            ids_d, xd, yd = by_id(dev.download(nat.F_ID), dev.download(nat.F_X),
+                                  dev.download(nat.F_Y))
+            ids_o, xo, yo = by_id(st.id.copy(), st.x.copy(), st.y.copy())
+            np.testing.assert_array_equal(ids_d, ids_o)
+            assert max(np.abs(xd - xo).max(), np.abs(yd - yo).max()) < 2e-4     # f32 cosf/logf
+        dev.pop_dynamics(burn, not burn)
+        dev.step_index = dev.step_index + 1
+        _, B, Dth = S.pop_dynamics(st, burn, not burn)
+        st.step += 1
         n_dev, b_dev, d_dev = dev.counts()
-        tot += 1
-        same += (b_dev == B) and (d_dev == Dth)
-        tol = 0.03 if t < 4 else 0.2
-        assert abs(b_dev - B) <= max(3, tol * B), (t, b_dev, B)
-        assert abs(d_dev - Dth) <= max(4, tol * Dth), (t, d_dev, Dth)
-        assert abs(n_dev - st.N) <= max(6, (0.03 if t < 4 else 0.08) * st.N)
-    assert same >= 3          # the first steps agree exactly before rounding flips accumulate
+        if synced:
+            same = (b_dev == B and d_dev == Dth and
+                    np.array_equal(np.sort(dev.download(nat.F_ID)), np.sort(st.id)))
+            if same:
+                exact_steps += 1
+            else:
+                w = witness(xd.astype(np.float64), yd.astype(np.float64), xo.astype(np.float64),
+                            yo.astype(np.float64), ids_o, st.last_death)
+                assert w is not None, (
+                    'step %d: births %d / %d, deaths %d / %d differ and no decision of the '
+                    'step sits on a rounding tie' % (t, b_dev, B, d_dev, Dth))
+                first_flip = (t, w)
+                synced = False
+        else:
+            # two different (equally distributed) populations from here on
+            assert abs(b_dev - B) <= max(6, 0.2 * B), (t, b_dev, B, first_flip)
+            assert abs(d_dev - Dth) <= max(6, 0.2 * Dth), (t, d_dev, Dth, first_flip)
+            assert abs(n_dev - st.N) <= max(8, 0.08 * st.N), (t, n_dev, st.N, first_flip)
+    assert exact_steps >= 3, first_flip   # the first steps agree exactly before a tie turns up
+    print('exact steps:', exact_steps, 'first flip:', first_flip)
     dev.close()
 
 

@@ -98,6 +98,10 @@ def test_deleterious_fitness():
 
 
 # ------------------------------------------------------------------ A13
+# (mean |diff| / mean density, max |diff| / peak density) against the reference's raster
+DENSITY_BOUNDS = {'a': (0.0125, 0.055), 'b': (0.010, 0.015), 'c': (0.011, 0.040), 'd': (0.006, 0.025)}
+
+
 @pytest.mark.parametrize('tag', ['a', 'b', 'c', 'd'])
 def test_density_nodes_exact_and_raster_tolerance(tag):
     g = load_golden('g4_density')
@@ -116,15 +120,18 @@ def test_density_nodes_exact_and_raster_tolerance(tag):
                                rtol=1e-12)
     np.testing.assert_allclose(V[ii, jj], g[tag + '_node_vals'], rtol=1e-12)
     # raster: natural bicubic spline vs the reference's Clough-Tocher griddata.
-    # Stated tolerance (density): mean |diff| <= 1.5 % of the mean
-    # density, max |diff| <= 6 % of the peak density.
+    # Stated tolerance (density), per fixture: (mean |diff| / mean density,
+    # max |diff| / peak density) measured a 1.06 % / 4.9 %, b 0.81 % / 1.2 %, c 0.91 % / 3.5 %,
+    # d 0.46 % / 2.1 % - the rougher the node field (a: 24 individuals per window, b: 47,
+    # d: 90), the more the two interpolants differ between the nodes.
     ref = np.clip(g[tag + '_dens'], 0, None)
     mine = O.density_raster(lat, x, y)
     assert mine.shape == ref.shape
     assert not np.isnan(ref).any()
     diff = np.abs(mine - ref)
-    assert diff.mean() <= 0.015 * ref.mean(), (diff.mean(), ref.mean())
-    assert diff.max() <= 0.06 * ref.max(), (diff.max(), ref.max())
+    b_mean, b_max = DENSITY_BOUNDS[tag]
+    assert diff.mean() <= b_mean * ref.mean(), (diff.mean(), ref.mean())
+    assert diff.max() <= b_max * ref.max(), (diff.max(), ref.max())
 
 
 # ------------------------------------------------------------------ A14
@@ -348,7 +355,7 @@ def _g10_traits(g, s):
 
 def test_whole_model_envelopes_vs_reference():
     """Whole-loop statistics of the oracle step (same operators, device random
-    streams) against 8 reference runs of the same model (30x30, 2 layers, N0 300,
+    streams) against 24 reference runs of the same model (30x30, 2 layers, N0 300,
     K_factor 0.5, radius 4, L 60, r 0.5, 3 traits; each run's own trait
     architecture).  Trajectories cannot match stream for stream; the means must."""
     import gnx_step as S
@@ -361,7 +368,8 @@ def test_whole_model_envelopes_vs_reference():
                                        * (np.arange(L) > 0)))
     ref = dict(burn=[], first=[], main=[], br=[])
     mine = dict(burn=[], first=[], main=[], br=[])
-    for s in range(1, 9):
+    drift_ref, drift_mine = [], []
+    for s in range(1, int(g['n_seeds'][0]) + 1):
         nb = int(g['s%i_nburn' % s][0])
         R = g['s%i_Nt' % s]
         ref['burn'].append(R[10:nb].mean())
@@ -382,11 +390,22 @@ def test_whole_model_envelopes_vs_reference():
         mine['first'].append(Nt[60:80].mean())
         mine['main'].append(Nt[-50:].mean())
         mine['br'].append((np.array(st.n_births[10:60]) / np.array(st.Nt[10:60])).mean())
+        # genetic drift of the neutral loci over the 100 main steps (start 0.5)
+        sel = np.concatenate([tr['loci'] for tr in _g10_traits(g, s)])
+        neutral = np.setdiff1d(np.arange(L), sel)
+        drift_mine.append(O.unpack_genomes(st.geno, L).mean(axis=(0, 2))[neutral] - 0.5)
+        drift_ref.append(g['s%i_freq' % s][neutral] - 0.5)
+    v_ref = np.mean(np.concatenate(drift_ref) ** 2)
+    v_mine = np.mean(np.concatenate(drift_mine) ** 2)
+    # 1152 loci on either side: ~6 % sampling error of the ratio (measured 0.98)
+    assert 0.85 < v_mine / v_ref < 1.18, (v_mine, v_ref)
     m = {k: (np.mean(ref[k]), np.mean(mine[k])) for k in ref}
-    assert abs(m['burn'][1] / m['burn'][0] - 1) < 0.04, m      # measured -1.3 %
-    assert abs(m['br'][1] / m['br'][0] - 1) < 0.04, m
-    assert abs(m['first'][1] / m['first'][0] - 1) < 0.15, m    # measured -3.6 %
-    assert abs(m['main'][1] / m['main'][0] - 1) < 0.15, m      # measured +3.5 %
+    # 24 seeds: the seed means carry ~1 % sampling error on either side; measured
+    # burn -1.0 %, births / N -0.6 %, first 20 main steps -0.0 %, last 50 main steps +1.3 %
+    assert abs(m['burn'][1] / m['burn'][0] - 1) < 0.03, m
+    assert abs(m['br'][1] / m['br'][0] - 1) < 0.03, m
+    assert abs(m['first'][1] / m['first'][0] - 1) < 0.05, m
+    assert abs(m['main'][1] / m['main'][0] - 1) < 0.05, m
 
 
 # ---- g12: statistics (reference sim/stats.py) ---------------------------------------
