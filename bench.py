@@ -456,11 +456,17 @@ def main():
                                fixed_births=1)
         stepper.profile = False
 
+    v2 = stepper is not None and stepper.v2
+
     def do_step(burn):
+        """-> (population at the START of the step - global on tiles -, births)"""
         if stepper is None:
             n0 = dev.N
             dev.step(burn, not burn)
             return n0, dev.counts()[1]
+        if v2:       # the counts that ride on the step's own all-reduce: no extra collective
+            n, b, _ = stepper.step(burn, not burn, exact=False)
+            return n, b
         n, b, _ = stepper.step(burn, not burn)
         return n, b
 
@@ -477,7 +483,7 @@ def main():
     n_glob = None
     for _ in range(args.warmup):
         n_glob, _ = do_step(False)
-    if stepper is not None and n_glob is None:
+    if stepper is not None and n_glob is None and not v2:
         n_glob = int(stepper.comm.allreduce_sum(np.array([dev.N], np.int64))[0])
 
     def barrier():
@@ -494,8 +500,8 @@ def main():
     births = 0
     xo_births = 0
     for _ in range(args.steps):
-        if stepper is None:
-            n0, b = do_step(False)          # population at the start of the step
+        if stepper is None or v2:
+            n0, b = do_step(False)          # (global) population at the start of the step
             ind_steps += n0
         else:
             ind_steps += n_glob             # global population at the start of the step

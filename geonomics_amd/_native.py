@@ -47,6 +47,9 @@ EXPORTS = [
     'gnx_tile_put_gametes_dev', 'gnx_tile_bins_ptr', 'gnx_set_k_raster', 'gnx_last_births', 'gnx_set_positions', 'gnx_n_slots', 'gnx_stats_ld_counts',
     'gnx_set_defer_crossover', 'gnx_last_crossover_births', 'gnx_set_crossover_overlap', 'gnx_set_crossover_split', 'gnx_debug_halves', 'gnx_spatial_diff_sums', 'gnx_last_crossover_jobs',
     'gnx_genome_info', 'gnx_measure_copy',
+    'gnx_stream_ptr', 'gnx_tile2_move_route', 'gnx_tile2_route_ptrs', 'gnx_tile2_import',
+    'gnx_tile2_pairs', 'gnx_tile2_offspring', 'gnx_tile2_serve', 'gnx_tile2_put',
+    'gnx_tile2_finish_births', 'gnx_tile2_die', 'gnx_tile_pair_ptrs_nosync',
 ]
 
 
@@ -173,7 +176,14 @@ class Device:
         assert k.shape == (self.H, self.W), k.shape
         self._chk(self.lib.gnx_set_k_raster(self.h, _ptr(k, C.c_double)))
 
+    @property
+    def births_fixed_lambda(self):
+        """births per pair when n_births_fixed (structs/species.py:604-609), else 0"""
+        sp = getattr(self, '_sp', None)
+        return int(sp.n_births_lambda) if (sp is not None and sp.n_births_fixed) else 0
+
     def set_species_params(self, sp):
+        self._sp = sp
         self.sp = sp
         self._chk(self.lib.gnx_set_species_params(self.h, C.byref(sp)))
 
@@ -628,6 +638,13 @@ class Device:
         self._chk(self.lib.gnx_tile_pair_ptrs(self.h, C.byref(n), C.byref(a), C.byref(b)))
         return n.value, a.value or 0, b.value or 0
 
+    def tile_pair_ptrs_nosync(self):
+        """the same addresses without waiting for the stream (tile2: the consumer is ordered
+        behind the library's stream)"""
+        n, a, b = C.c_int64(), C.c_void_p(), C.c_void_p()
+        self._chk(self.lib.gnx_tile_pair_ptrs_nosync(self.h, C.byref(n), C.byref(a), C.byref(b)))
+        return n.value, a.value or 0, b.value or 0
+
     def tile_offspring_dev(self, burn, id_base, goff_ptr):
         n = C.c_int64()
         self._chk(self.lib.gnx_tile_offspring_dev(self.h, int(bool(burn)),
@@ -656,6 +673,66 @@ class Device:
         a, n = C.c_void_p(), C.c_int64()
         self._chk(self.lib.gnx_tile_bins_ptr(self.h, C.byref(a), C.byref(n)))
         return a.value, n.value
+
+    # -- tile2: the device-driven protocol (include/gnx_hip.h) -------------------------
+    def stream_ptr(self):
+        a = C.c_void_p()
+        self._chk(self.lib.gnx_stream_ptr(self.h, C.byref(a)))
+        return a.value or 0
+
+    def tile2_move_route(self, move):
+        """-> counts int64 [2][R*C]: migrants per rank, ghosts per rank (one host wait)"""
+        T = max(getattr(self, '_n_tiles', 1), 1)
+        cnt = np.zeros(2 * T, np.int64)
+        self._chk(self.lib.gnx_tile2_move_route(self.h, int(bool(move)), _ptr(cnt, C.c_int64)))
+        return cnt.reshape(2, T)
+
+    def tile2_route_ptrs(self):
+        a, b, c, d = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._chk(self.lib.gnx_tile2_route_ptrs(self.h, C.byref(a), C.byref(b), C.byref(c),
+                                                C.byref(d)))
+        return a.value or 0, b.value or 0, c.value or 0, d.value or 0
+
+    def tile2_import(self, n_mig, rec, z, geno, n_ghost, ghost_rec):
+        self._chk(self.lib.gnx_tile2_import(
+            self.h, C.c_int64(int(n_mig)), C.c_void_p(rec or None), C.c_void_p(z or None),
+            C.c_void_p(geno or None), C.c_int64(int(n_ghost)), C.c_void_p(ghost_rec or None)))
+
+    def tile2_pairs(self, burn):
+        """-> P, births, gamete requests per owning rank int64 [R*C]"""
+        T = max(getattr(self, '_n_tiles', 1), 1)
+        cnt = np.zeros(2 + T, np.int64)
+        self._chk(self.lib.gnx_tile2_pairs(self.h, int(bool(burn)), _ptr(cnt, C.c_int64)))
+        self._n_pairs = int(cnt[0])
+        return int(cnt[0]), int(cnt[1]), cnt[2:]
+
+    def tile2_offspring(self, burn, id_base, goff_ptr):
+        a = C.c_void_p()
+        self._chk(self.lib.gnx_tile2_offspring(self.h, int(bool(burn)), C.c_int64(int(id_base)),
+                                               C.c_void_p(goff_ptr or None), C.byref(a)))
+        return a.value or 0
+
+    def tile2_serve(self, n, req_ptr):
+        a = C.c_void_p()
+        self._chk(self.lib.gnx_tile2_serve(self.h, C.c_int64(int(n)), C.c_void_p(req_ptr or None),
+                                           C.byref(a)))
+        return a.value or 0
+
+    def tile2_put(self, n, data_ptr):
+        self._chk(self.lib.gnx_tile2_put(self.h, C.c_int64(int(n)), C.c_void_p(data_ptr or None)))
+
+    def tile2_finish_births(self, burn):
+        a, n = C.c_void_p(), C.c_int64()
+        self._chk(self.lib.gnx_tile2_finish_births(self.h, int(bool(burn)), C.byref(a),
+                                                   C.byref(n)))
+        return a.value or 0, n.value
+
+    def tile2_die(self, burn, with_selection, have_pairs):
+        """-> the all-reduced (N before this step's deaths, births, deaths of the previous step)"""
+        tot = np.zeros(3, np.int64)
+        self._chk(self.lib.gnx_tile2_die(self.h, int(bool(burn)), int(bool(with_selection)),
+                                         int(bool(have_pairs)), _ptr(tot, C.c_int64)))
+        return int(tot[0]), int(tot[1]), int(tot[2])
 
     def last_births(self, with_gametes=True):
         """offspring of the last pop_dynamics_mate (call before pop_dynamics_die):

@@ -452,6 +452,9 @@ extern "C" void gnx_destroy(gnx_state* h) {
     (void)hipFree(h->traits[t].phi_rast);
   }
   (void)hipHostFree(h->h_pin);
+  if (h->h_route_pin) (void)hipHostFree(h->h_route_pin);
+  (void)hipFree(h->gh_rec);
+  (void)hipFree(h->route_cnt);
   if (h->h_stage) (void)hipHostFree(h->h_stage);
   for (int k = 0; k < GNX_K_COUNT; ++k) timers_resolve(h, k);
   for (hipEvent_t e : h->ev_free) (void)hipEventDestroy(e);
@@ -579,7 +582,7 @@ static int setup_lattice(gnx_state* h) {
   GNXCHK(dalloc(&h->nodes, nn));
   size_t nb = (size_t)L.nbx * L.nby;
   // one allocation, so that a tiled run all-reduces both fields in one call
-  GNXCHK(dalloc(&h->bin_partials, 2 * nb));
+  GNXCHK(dalloc(&h->bin_partials, 2 * nb + 4));     // (+ the tile2 counter words)
   h->bins_P = h->bin_partials + nb;
   (void)hipFree(h->fb[0]);
   GNXCHK(dalloc(&h->fb[0], 3 * nb));

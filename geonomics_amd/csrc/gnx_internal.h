@@ -262,6 +262,22 @@ struct gnx_state {
   int32_t* gam_slot = nullptr;
   int64_t gam_cap = 0;
   int64_t* chk = nullptr;            // [2] device-side record check: bad count, max id
+  // tile2 protocol (gnx_tile.hip, "device-driven"): emigrants stay in their slots until the
+  // cell sort, which gives them a key behind every cell (tile_evict individuals) and the
+  // population shrinks by that many; gamete requests are counted with the pairs, so the
+  // offspring kernel's own count is not read back (n_req_known >= 0)
+  int64_t tile_evict = 0;
+  float evict_box[4]{};              // own tile [x0, x1) x [y0, y1)
+  int64_t n_req_known = -1;
+  gnx_ind_rec* gh_rec = nullptr;     // ghosts routed to other tiles, grouped by rank
+  int64_t gh_cap = 0;
+  int32_t* route_cnt = nullptr;      // [4 * GNX_MAX_TILES + 8] counts / offsets of the routing
+  int64_t route_n_mig = 0, route_n_gh = 0;
+  int64_t prev_deaths = 0;           // deaths of the previous step (counter all-reduce)
+  int32_t* h_route_pin = nullptr;    // pinned host words of the tile2 read-backs
+  int32_t* h_route_pin_dev = nullptr;
+  std::vector<int64_t> req_by_rank;  // gamete requests per owning rank (gnx_tile2_pairs)
+  bool rq_is2 = false;               // rq_sorted holds 24-byte gnx_gamete_req2 records
 
   // pairing / mating scratch (capacity cap_inds)
   int32_t* mate = nullptr;

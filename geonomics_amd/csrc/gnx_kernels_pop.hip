@@ -385,6 +385,29 @@ __global__ void k_keys(int64_t N, const float* x, const float* y, const int64_t*
   idx[i] = (int32_t)i;
 }
 
+// tile2: an individual that left the tile (and is no ghost) sorts behind every cell - the
+// sort that orders the population also removes the emigrants (no compaction of its own)
+__global__ void k_keys_evict(int64_t N, const float* x, const float* y, const int64_t* id,
+                             const uint8_t* ghost, float x0, float x1, float y0, float y1,
+                             double inv_cs, int ncx, int ncy, int idbits, uint64_t* key,
+                             int32_t* idx) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const float xi = x[i], yi = y[i];
+  const bool out = !ghost[i] && (xi < x0 || xi >= x1 || yi < y0 || yi >= y1);
+  const uint64_t cell = out ? (uint64_t)(ncx * ncy) : (uint64_t)gnx_cell_of(xi, yi, inv_cs, ncx, ncy);
+  key[i] = (cell << idbits) | (uint64_t)id[i];
+  idx[i] = (int32_t)i;
+}
+
+// the evicted individuals' genome rows go back on the free stack (their blocks return
+// through the collector); they sit in the slots [N, N + n) behind the population
+__global__ void k_free_tail(int64_t N, int64_t n, const int32_t* grow, int32_t* free_rows,
+                            int64_t n_free) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) free_rows[n_free + k] = grow[N + k];
+}
+
 __global__ void k_permute(int64_t N, int64_t cap, const int32_t* perm, GnxSoA a, GnxSoA b,
                           int n_layers, int n_traits, int tbw, unsigned long long pair_seed,
                           uint32_t* tag, uint4* cand, uint64_t* key, int idbits,
@@ -463,7 +486,7 @@ int gnx_l_sort_by_cell(gnx_state* h) {
   GnxSoA a = h->soa[h->cur], b = h->soa[h->cur ^ 1];
   const int idbits = gnx_id_bits(h);
   const bool alone = h->xo_sort_waits || !h->xo_running;
-  const bool ordm = h->keys_fresh ? h->keys_ordmode : gnx_ord_sort(h);
+  const bool ordm = h->tile_evict > 0 ? false : (h->keys_fresh ? h->keys_ordmode : gnx_ord_sort(h));
   gnx_time_begin(h);
   if (ordm) {
     // stable sort of the id-ordered index by cell alone (gnx_internal.h)
@@ -479,11 +502,20 @@ int gnx_l_sort_by_cell(gnx_state* h) {
     GNXCHK(gnx_prim_sort32_bits(h->sort64_tmp, h->sort64_tmp_bytes, h->keyk[0], h->keyk[1],
                                 h->valk[0], h->valk[1], (size_t)N, h->key_bits, h->stream, alone));
   } else {
-    if (!h->keys_fresh)
+    int cell_bits = h->key_bits;
+    if (h->tile_evict > 0) {
+      // (one more cell value: the emigrants')
+      while ((1ll << cell_bits) <= (int64_t)h->ncx * h->ncy) ++cell_bits;
+      hipLaunchKernelGGL(k_keys_evict, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, a.x, a.y,
+                         a.id, a.ghost, h->evict_box[0], h->evict_box[1], h->evict_box[2],
+                         h->evict_box[3], h->inv_cs, h->ncx, h->ncy, idbits, h->key64[0],
+                         h->perm[0]);
+    } else if (!h->keys_fresh) {
       hipLaunchKernelGGL(k_keys, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, a.x, a.y, a.id,
                          h->inv_cs, h->ncx, h->ncy, idbits, h->key64[0], h->perm[0]);
+    }
     GNXCHK(gnx_prim_sort64_bits(h->sort64_tmp, h->sort64_tmp_bytes, h->key64[0], h->key64[1],
-                                h->perm[0], h->perm[1], (size_t)N, idbits + h->key_bits,
+                                h->perm[0], h->perm[1], (size_t)N, idbits + cell_bits,
                                 h->stream, alone));
   }
   h->keys_fresh = false;
@@ -521,6 +553,19 @@ int gnx_l_sort_by_cell(gnx_state* h) {
   }
   HIPCHK(hipGetLastError());
   h->cur ^= 1;
+  if (h->tile_evict > 0) {
+    // the emigrants are the last tile_evict slots of the sorted population: gone
+    const int64_t n = h->tile_evict;
+    h->tile_evict = 0;
+    h->N -= n;
+    if (h->genomes_assigned && c.L > 0) {
+      hipLaunchKernelGGL(k_free_tail, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, h->N, n,
+                         h->soa[h->cur].grow, h->free_rows, h->n_free);
+      h->n_free += n;
+    }
+    h->ord_valid = false;
+    h->fb_adults = false;
+  }
   if (h->xo_launch_policy == 1) GNXCHK(gnx_xo_launch_pending(h));
   return 0;
 }
@@ -1429,10 +1474,15 @@ int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* 
                                                   4.0 * c.n_traits));
     if (tiled && genomes) {
       // the number of gamete requests is known before the crossover is launched: the host
-      // layer serves the neighbour tiles while the crossover runs
-      GNXCHK(gnx_publish(h, 0, h->req_count));
-      HIPCHK(hipStreamSynchronize(h->stream));
-      h->n_req = h->h_pin[0];
+      // layer serves the neighbour tiles while the crossover runs.  (tile2: it was counted
+      // with the pair list - no read-back here)
+      if (h->n_req_known >= 0) {
+        h->n_req = h->n_req_known;
+      } else {
+        GNXCHK(gnx_publish(h, 0, h->req_count));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->n_req = h->h_pin[0];
+      }
     }
   }
   HIPCHK(hipGetLastError());

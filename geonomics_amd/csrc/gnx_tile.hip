@@ -18,6 +18,7 @@
 // All random draws are keyed by individual id, all choices are order-
 // independent, so a tiled run reproduces the single-GPU run bit for bit.
 #include <algorithm>
+#include <atomic>
 #include "gnx_internal.h"
 #include "gnx_rng.h"
 
@@ -1123,5 +1124,630 @@ extern "C" int gnx_tile_bins_ptr(gnx_state* h, void** bins, int64_t* n_total) {
   HIPCHK(hipStreamSynchronize(h->stream));
   *bins = h->bin_partials;
   *n_total = 2 * (int64_t)h->lat.nbx * h->lat.nby;
+  return 0;
+}
+
+// =====================================================================================
+// tile2: the device-driven protocol (include/gnx_hip.h).  Per step the host waits for the
+// device three times (routing counts, pair / request counts, survivor count); payloads are
+// grouped, exchanged and imported in device memory, and nothing else blocks the host.
+// =====================================================================================
+#define GNX_TILE_DIM 64          // tiles per axis the routing kernels hold spans for
+
+struct RouteGeo {
+  int R, C, tw, th, me, ncx, ncy;
+  double inv_cs;
+  // hash-cell span of tile column c / row r, widened by the halo's two rings
+  int cx0[GNX_TILE_DIM], cx1[GNX_TILE_DIM], cy0[GNX_TILE_DIM], cy1[GNX_TILE_DIM];
+};
+
+static int route_geo(const gnx_state* h, RouteGeo* g) {
+  if (h->tile_R > GNX_TILE_DIM || h->tile_C > GNX_TILE_DIM) {
+    gnx_set_error("tile2: at most %d tiles per axis", GNX_TILE_DIM);
+    return 1;
+  }
+  g->R = h->tile_R;
+  g->C = h->tile_C;
+  g->tw = h->cfg.W / h->tile_C;
+  g->th = h->cfg.H / h->tile_R;
+  g->me = h->tile_r * h->tile_C + h->tile_c;
+  g->ncx = h->ncx;
+  g->ncy = h->ncy;
+  g->inv_cs = h->inv_cs;
+  const int ring = 2 * h->cell_ref;       // two mating radii, in cells (halo_spans)
+  for (int c = 0; c < g->C; ++c) {
+    const float x0 = (float)(c * g->tw), x1 = nextafterf((float)((c + 1) * g->tw), 0.f);
+    g->cx0[c] = std::min(h->ncx - 1, (int)((double)x0 * h->inv_cs)) - ring;
+    g->cx1[c] = std::min(h->ncx - 1, (int)((double)x1 * h->inv_cs)) + ring;
+  }
+  for (int r = 0; r < g->R; ++r) {
+    const float y0 = (float)(r * g->th), y1 = nextafterf((float)((r + 1) * g->th), 0.f);
+    g->cy0[r] = std::min(h->ncy - 1, (int)((double)y0 * h->inv_cs)) - ring;
+    g->cy1[r] = std::min(h->ncy - 1, (int)((double)y1 * h->inv_cs)) + ring;
+  }
+  return 0;
+}
+
+// index inside the group of rank `dest` for every lane with dest >= 0: one atomic per wave
+// and distinct destination (lanes of a wave mostly share theirs)
+__device__ __forceinline__ int route_append(int32_t* __restrict__ counts, int dest) {
+  unsigned long long todo = __ballot(dest >= 0);
+  const int lane = threadIdx.x & 63;
+  int idx = -1;
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int d = __shfl(dest, leader);
+    const unsigned long long same = __ballot(dest == d);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&counts[d], (int)__popcll(same));
+    base = __shfl(base, leader);
+    if (dest == d) idx = base + (int)__popcll(same & ((1ull << lane) - 1ull));
+    todo &= ~same;
+  }
+  return idx;
+}
+
+// Where every individual of the tile goes after the movement: to the tile that owns its
+// position if that is another one (direction 4 below), and as a ghost to every tile
+// around its OWNER whose widened cell span holds its cell.  Pass 1 counts per destination
+// rank (cnt[0 .. T) migrants, cnt[T .. 2T) ghosts), pass 2 writes behind the groups'
+// offsets (order inside a group: whatever the atomics give; receivers sort by cell and id).
+template <bool WRITE>
+__global__ void __launch_bounds__(256)
+k_route(int64_t N, int64_t cap, GnxSoA s, RouteGeo g, int n_traits, int32_t* __restrict__ cnt,
+        const int32_t* __restrict__ offs, gnx_ind_rec* __restrict__ mig_rec,
+        float* __restrict__ mig_z, int64_t* __restrict__ mig_slot,
+        gnx_ind_rec* __restrict__ gh_rec, int64_t mig_cap, int64_t gh_cap) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool act = i < N && !s.ghost[i];
+  const int T = g.R * g.C;
+  float x = 0.f, y = 0.f;
+  int oc = 0, orow = 0, cx = 0, cy = 0;
+  if (act) {
+    x = s.x[i];
+    y = s.y[i];
+    oc = tile_index(x, g.tw, g.C);
+    orow = tile_index(y, g.th, g.R);
+    cx = min(g.ncx - 1, (int)((double)x * g.inv_cs));
+    cy = min(g.ncy - 1, (int)((double)y * g.inv_cs));
+  }
+  const int owner = orow * g.C + oc;
+  gnx_ind_rec r;
+  if (WRITE && act) {
+    r.x = x;
+    r.y = y;
+    r.age = s.age[i];
+    r.sex = s.sex[i];
+    r.id = s.id[i];
+    r.fit = s.fit[i];
+    r.nbr_mask = 0;
+  }
+  for (int k = 0; k < 9; ++k) {
+    int dest = -1;
+    if (act) {
+      if (k == 4) {
+        if (owner != g.me) dest = owner;                    // a migrant
+      } else {
+        const int rr = orow + k / 3 - 1, cc = oc + k % 3 - 1;
+        if (rr >= 0 && rr < g.R && cc >= 0 && cc < g.C && cx >= g.cx0[cc] && cx <= g.cx1[cc] &&
+            cy >= g.cy0[rr] && cy <= g.cy1[rr])
+          dest = rr * g.C + cc;                             // a ghost there
+      }
+    }
+    if (__ballot(dest >= 0) == 0ull) continue;
+    const int grp = (k == 4) ? 0 : T;
+    const int idx = route_append(cnt + grp, dest);
+    if (WRITE && dest >= 0) {
+      const int64_t q = (int64_t)offs[grp + dest] + idx;
+      if (k == 4) {
+        if (q < mig_cap) {
+          mig_rec[q] = r;
+          mig_slot[q] = i;
+          if (mig_z)
+            for (int t = 0; t < n_traits; ++t) mig_z[q * n_traits + t] = s.z[(int64_t)t * cap + i];
+        }
+      } else if (q < gh_cap) {
+        gh_rec[q] = r;
+      }
+    }
+  }
+}
+
+// exclusive offsets of the 2 x T groups, totals, and all of it to pinned host memory
+__global__ void k_route_offsets(int T, int32_t* cnt /*[2T counts | 2T offsets | 2 totals]*/,
+                                int32_t* host, int n_extra, int seq) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int grp = 0; grp < 2; ++grp) {
+    int run = 0;
+    for (int p = 0; p < T; ++p) {
+      cnt[2 * T + grp * T + p] = run;
+      run += cnt[grp * T + p];
+    }
+    cnt[4 * T + grp] = run;
+  }
+  for (int p = 0; p < 2 * T + n_extra; ++p)
+    __hip_atomic_store(&host[p], cnt[p < 2 * T ? p : 4 * T + (p - 2 * T)], __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __hip_atomic_store(&host[2 * GNX_MAX_TILES + 7], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// plain counters -> pinned host words behind whatever the stream holds so far
+__global__ void k_publish_words(int n, const int32_t* src, int32_t* host, int seq) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int p = 0; p < n; ++p)
+    __hip_atomic_store(&host[p], src[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __hip_atomic_store(&host[2 * GNX_MAX_TILES + 7], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+static int tile2_buffers(gnx_state* h) {
+  if (!h->route_cnt) {
+    GNXCHK(dalloc_t(&h->route_cnt, (size_t)4 * GNX_MAX_TILES + 8));
+    HIPCHK(hipHostMalloc((void**)&h->h_route_pin, (2 * GNX_MAX_TILES + 8) * sizeof(int32_t),
+                         hipHostMallocCoherent | hipHostMallocMapped));
+    memset(h->h_route_pin, 0, (2 * GNX_MAX_TILES + 8) * sizeof(int32_t));
+    HIPCHK(hipHostGetDevicePointer((void**)&h->h_route_pin_dev, h->h_route_pin, 0));
+  }
+  if (!h->chk) GNXCHK(dalloc_t(&h->chk, 2));
+  return 0;
+}
+
+// the host spins on the sequence word the publishing kernel writes last
+static int tile2_wait(gnx_state* h, int seq) {
+  volatile int32_t* word = h->h_route_pin + 2 * GNX_MAX_TILES + 7;
+  for (long spin = 0;; ++spin) {
+    if (*word == seq) break;
+    if (spin > 2000000) {                 // (~20 ms of spinning: fall back to the driver)
+      HIPCHK(hipStreamSynchronize(h->stream));
+      if (*word != seq) {
+        gnx_set_error("tile2: the device counters never arrived");
+        return 1;
+      }
+      break;
+    }
+    __builtin_ia32_pause();
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return 0;
+}
+
+extern "C" int gnx_stream_ptr(gnx_state* h, void** stream) {
+  *stream = (void*)h->stream;
+  return 0;
+}
+
+extern "C" int gnx_tile2_move_route(gnx_state* h, int32_t move, int64_t* counts) {
+  GNXCHK(check_tiles(h, "gnx_tile2_move_route"));
+  const int T = n_tiles(h);
+  for (int p = 0; p < 2 * T; ++p) counts[p] = 0;
+  h->route_n_mig = h->route_n_gh = 0;
+  h->st_has_geno = false;
+  if (h->n_ghost) {
+    gnx_set_error("gnx_tile2_move_route: ghosts are resident");
+    return 1;
+  }
+  GNXCHK(tile2_buffers(h));
+  HIPCHK(hipMemsetAsync(h->chk, 0, 2 * sizeof(int64_t), h->stream));
+  if (move && h->sp.move)
+    GNXCHK(gnx_l_move(h, true, nullptr, nullptr, nullptr, nullptr, true));
+  else
+    GNXCHK(gnx_l_age(h));
+  const int64_t N = h->N;
+  if (N == 0 || T == 1) return 0;          // one tile: nobody leaves, nobody borders
+  RouteGeo g;
+  GNXCHK(route_geo(h, &g));
+  GnxSoA s = h->soa[h->cur];
+  const int nt = h->cfg.n_traits;
+  HIPCHK(hipMemsetAsync(h->route_cnt, 0, (size_t)2 * T * sizeof(int32_t), h->stream));
+  hipLaunchKernelGGL(k_route<false>, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N,
+                     h->cfg.cap_inds, s, g, nt, h->route_cnt, (const int32_t*)nullptr,
+                     (gnx_ind_rec*)nullptr, (float*)nullptr, (int64_t*)nullptr,
+                     (gnx_ind_rec*)nullptr, (int64_t)0, (int64_t)0);
+  const int seq = (int)(++h->pin_seq & 0x3fffffff);
+  hipLaunchKernelGGL(k_route_offsets, dim3(1), dim3(64), 0, h->stream, T, h->route_cnt,
+                     h->h_route_pin_dev, 2, seq);
+  HIPCHK(hipGetLastError());
+  GNXCHK(tile2_wait(h, seq));                                   // wait 1 of the step
+  int64_t n_mig = 0, n_gh = 0;
+  for (int p = 0; p < T; ++p) {
+    counts[p] = h->h_route_pin[p];
+    counts[T + p] = h->h_route_pin[T + p];
+    n_mig += counts[p];
+    n_gh += counts[T + p];
+  }
+  if (counts[g.me] != 0) {
+    gnx_set_error("tile2: %lld migrants routed to their own tile", (long long)counts[g.me]);
+    return 1;
+  }
+  h->route_n_mig = n_mig;
+  h->route_n_gh = n_gh;
+  if (n_mig == 0 && n_gh == 0) return 0;
+  // grow-only staging (the host knows the totals before anything is written)
+  if (n_mig > h->gp_cap) {
+    (void)hipFree(h->gp_rec);
+    (void)hipFree(h->gp_z);
+    (void)hipFree(h->gp_slots);
+    h->gp_cap = n_mig + n_mig / 4 + 1024;
+    GNXCHK(dalloc_t(&h->gp_rec, (size_t)h->gp_cap));
+    GNXCHK(dalloc_t(&h->gp_z, (size_t)h->gp_cap * std::max(nt, 1)));
+    GNXCHK(dalloc_t(&h->gp_slots, (size_t)h->gp_cap));
+  }
+  if (n_gh > h->gh_cap) {
+    (void)hipFree(h->gh_rec);
+    h->gh_cap = n_gh + n_gh / 4 + 4096;
+    GNXCHK(dalloc_t(&h->gh_rec, (size_t)h->gh_cap));
+  }
+  HIPCHK(hipMemsetAsync(h->route_cnt, 0, (size_t)2 * T * sizeof(int32_t), h->stream));
+  hipLaunchKernelGGL(k_route<true>, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N,
+                     h->cfg.cap_inds, s, g, nt, h->route_cnt,
+                     (const int32_t*)(h->route_cnt + 2 * T), h->gp_rec, nt ? h->gp_z : nullptr,
+                     h->gp_slots, h->gh_rec, h->gp_cap, h->gh_cap);
+  if (n_mig > 0 && has_rows(h)) {
+    if (n_mig > h->st_geno_cap) {
+      (void)hipFree(h->st_geno);
+      h->st_geno_cap = n_mig + n_mig / 4 + 64;
+      GNXCHK(dalloc_t(&h->st_geno, (size_t)h->st_geno_cap * 2 * h->W64));
+    }
+    GNXCHK(gnx_l_gather_genomes(h, n_mig, h->gp_slots, h->st_geno));
+    h->st_has_geno = true;
+  }
+  HIPCHK(hipGetLastError());
+  // the emigrants leave with the cell sort (gnx_l_sort_by_cell)
+  h->tile_evict = n_mig;
+  const TileBox tb = tile_box(h);
+  h->evict_box[0] = tb.x0;
+  h->evict_box[1] = tb.x1;
+  h->evict_box[2] = tb.y0;
+  h->evict_box[3] = tb.y1;
+  h->fb_adults = false;
+  return 0;
+}
+
+extern "C" int gnx_tile2_route_ptrs(gnx_state* h, void** mig_rec, void** mig_z, void** mig_geno,
+                                    void** ghost_rec) {
+  *mig_rec = h->route_n_mig ? (void*)h->gp_rec : nullptr;
+  *mig_z = (h->route_n_mig && h->cfg.n_traits) ? (void*)h->gp_z : nullptr;
+  *mig_geno = (h->route_n_mig && h->st_has_geno) ? (void*)h->st_geno : nullptr;
+  *ghost_rec = h->route_n_gh ? (void*)h->gh_rec : nullptr;
+  return 0;
+}
+
+// records off the landscape are counted on the device (chk[0]) and reported by gnx_tile2_die
+__global__ void k_check_rec2(int64_t n, const gnx_ind_rec* rec, int W, int H, int64_t* chk) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const gnx_ind_rec r = rec[k];
+  if (!(r.x >= 0 && r.x < W && r.y >= 0 && r.y < H)) atomicAdd((unsigned long long*)&chk[0], 1ull);
+}
+
+static int import2(gnx_state* h, int64_t n, const gnx_ind_rec* d_rec, const float* d_z,
+                   const uint64_t* d_g, int ghost) {
+  if (n == 0) return 0;
+  const gnx_config& c = h->cfg;
+  const bool rows = has_rows(h) && !ghost;
+  if (h->N + n > c.cap_inds || (rows && n > h->n_free)) {
+    gnx_set_error("capacity exceeded importing %lld individuals (N=%lld cap=%lld free rows %lld)",
+                  (long long)n, (long long)h->N, (long long)c.cap_inds, (long long)h->n_free);
+    return 2;
+  }
+  if (rows && !d_g) {
+    gnx_set_error("import: genomes are assigned on this tile but none were sent");
+    return 1;
+  }
+  hipLaunchKernelGGL(k_check_rec2, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, n, d_rec, c.W,
+                     c.H, h->chk);
+  GnxSoA s = h->soa[h->cur];
+  if (rows) GNXCHK(gnx_half_reserve(h, 2 * (int64_t)h->NB * n));
+  hipLaunchKernelGGL(k_unpack, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, h->N, n,
+                     c.cap_inds, s, d_rec, (d_z && c.n_traits) ? d_z : nullptr, c.n_traits,
+                     c.n_layers, h->rast, c.W, c.H, h->free_rows, h->n_free, rows ? 1 : 0, ghost,
+                     gnx_halves(h));
+  if (rows) {
+    GNXCHK(gnx_l_scatter_genomes(h, n, (const uint64_t*)d_g, h->N));
+    h->n_free -= n;
+    GNXCHK(gnx_l_tb_from_rows(h, h->N, n, nullptr, nullptr));
+  }
+  h->N += n;
+  h->ord_valid = false;
+  if (ghost) h->n_ghost += n;
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int gnx_tile2_import(gnx_state* h, int64_t n_mig, const void* rec, const void* z,
+                                const void* geno, int64_t n_ghost, const void* ghost_rec) {
+  GNXCHK(tile2_buffers(h));
+  GNXCHK(import2(h, n_mig, (const gnx_ind_rec*)rec, (const float*)z, (const uint64_t*)geno, 0));
+  GNXCHK(import2(h, n_ghost, (const gnx_ind_rec*)ghost_rec, nullptr, nullptr, 1));
+  return 0;
+}
+
+// gamete requests this tile is going to make, per owning rank: births of the pairs whose
+// mate is a ghost (the mate's position names its owner)
+__global__ void k_req_count(int64_t P, const int32_t* __restrict__ pairs,
+                            const uint8_t* __restrict__ ghost, const float* __restrict__ x,
+                            const float* __restrict__ y, int tw, int th, int R, int C,
+                            int fixed_nb, const int32_t* __restrict__ nbirths,
+                            int32_t* __restrict__ cnt) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int m = pairs[2 * p + 1];
+  if (!ghost[m]) return;
+  const int owner = tile_index(y[m], th, R) * C + tile_index(x[m], tw, C);
+  atomicAdd(&cnt[owner], fixed_nb > 0 ? fixed_nb : nbirths[p]);
+}
+
+extern "C" int gnx_tile2_pairs(gnx_state* h, int32_t burn, int64_t* counts) {
+  if (!h->have_sp) {
+    gnx_set_error("species parameters not set");
+    return 1;
+  }
+  if (h->sp.mating_radius < 0) {
+    gnx_set_error("panmixia (mating_radius None) is not supported on a tiled landscape");
+    return 1;
+  }
+  GNXCHK(tile2_buffers(h));
+  const int T = n_tiles(h);
+  for (int p = 0; p < 2 + T; ++p) counts[p] = 0;
+  h->req_by_rank.assign(T, 0);
+  int64_t P = 0, B = 0;
+  GNXCHK(gnx_l_sort_by_cell(h));                 // (emigrants leave here)
+  GNXCHK(gnx_l_find_pairs(h, nullptr, &P));      // wait 2 of the step: the pair count
+  GNXCHK(gnx_l_bins(h, P, h->mid_x, h->mid_y, nullptr, h->bins_P));
+  GNXCHK(gnx_l_births(h, &B));
+  counts[0] = P;
+  counts[1] = B;
+  const bool genomes = !burn && h->cfg.L > 0 && h->genomes_assigned;
+  h->n_req_known = 0;
+  if (P > 0 && T > 1 && genomes) {
+    GnxSoA s = h->soa[h->cur];
+    HIPCHK(hipMemsetAsync(h->route_cnt, 0, (size_t)T * sizeof(int32_t), h->stream));
+    hipLaunchKernelGGL(k_req_count, dim3(gnx_grid(P, 256)), dim3(256), 0, h->stream, P, h->pairs,
+                       s.ghost, s.x, s.y, h->cfg.W / h->tile_C, h->cfg.H / h->tile_R, h->tile_R,
+                       h->tile_C, h->sp.n_births_fixed ? (int)h->sp.n_births_lambda : 0,
+                       h->nbirths, h->route_cnt);
+    const int seq = (int)(++h->pin_seq & 0x3fffffff);
+    hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, h->stream, T, h->route_cnt,
+                       h->h_route_pin_dev, seq);
+    HIPCHK(hipGetLastError());
+    GNXCHK(tile2_wait(h, seq));                  // (a few microseconds behind wait 2)
+    for (int p = 0; p < T; ++p) {
+      counts[2 + p] = h->h_route_pin[p];
+      h->req_by_rank[p] = h->h_route_pin[p];
+      h->n_req_known += h->h_route_pin[p];
+    }
+  }
+  return 0;
+}
+
+__global__ void k_pack_requests2(int64_t n, const int32_t* idx, const int64_t* pid,
+                                 const int32_t* key, const uint8_t* start, const float* px,
+                                 const float* py, const int32_t* child_k, gnx_gamete_req2* out,
+                                 int32_t* k_out) {
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  int i = idx[q];
+  gnx_gamete_req2 r;
+  r.parent_id = pid[i];
+  r.key = key[i];
+  r.start = start[i];
+  r.px = px[i];
+  r.py = py[i];
+  out[q] = r;
+  k_out[q] = child_k[i];
+}
+
+extern "C" int gnx_tile2_offspring(gnx_state* h, int32_t burn, int64_t id_base,
+                                   const void* pair_goff_dev, void** req_dev) {
+  *req_dev = nullptr;
+  int64_t P = h->n_pairs, B = 0;
+  h->birth_first_slot = h->N;
+  h->n_req = 0;
+  if (P > 0 && pair_goff_dev)
+    HIPCHK(hipMemcpyAsync(h->pair_goff, pair_goff_dev, P * sizeof(int64_t),
+                          hipMemcpyDeviceToDevice, h->stream));
+  int rc = gnx_l_mate(h, burn != 0, false, 0, &B, id_base, true);
+  h->n_req_known = -1;
+  GNXCHK(rc);
+  h->last_births = B;
+  if (B == 0) h->n_req = 0;
+  h->xo_pending = false;                    // (tile2 serves on the main stream)
+  const int64_t n = h->n_req;
+  if (n == 0) return 0;
+  if (n > h->rq_cap) {
+    (void)hipFree(h->rq_sorted);
+    (void)hipFree(h->rq_k);
+    h->rq_cap = n + n / 4 + 1024;
+    gnx_gamete_req2* p = nullptr;           // (24-byte records fit the 16-byte ones' buffer too)
+    GNXCHK(dalloc_t(&p, (size_t)h->rq_cap));
+    h->rq_sorted = p;
+    GNXCHK(dalloc_t(&h->rq_k, (size_t)h->rq_cap));
+    h->rq_is2 = true;
+  } else if (!h->rq_is2) {                  // sized for 16-byte records by the other protocol
+    (void)hipFree(h->rq_sorted);
+    gnx_gamete_req2* p = nullptr;
+    GNXCHK(dalloc_t(&p, (size_t)h->rq_cap));
+    h->rq_sorted = p;
+    h->rq_is2 = true;
+  }
+  // grouped by the rank that owns the ghost mate (counts: gnx_tile2_pairs, on the host)
+  hipLaunchKernelGGL(k_req_owner, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, n, h->req_px,
+                     h->req_py, h->cfg.W / h->tile_C, h->cfg.H / h->tile_R, h->tile_R, h->tile_C,
+                     h->key[0], h->perm[0]);
+  int bits = 1;
+  while ((1 << bits) < n_tiles(h)) ++bits;
+  GNXCHK(gnx_prim_sort(h->sort_tmp, h->sort_tmp_bytes, h->key[0], h->key[1], h->perm[0],
+                       h->perm[1], (size_t)n, bits, h->stream));
+  hipLaunchKernelGGL(k_pack_requests2, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, n,
+                     h->perm[1], h->req_pid, h->req_key, h->req_start, h->req_px, h->req_py,
+                     h->req_k, (gnx_gamete_req2*)h->rq_sorted, h->rq_k);
+  HIPCHK(hipGetLastError());
+  *req_dev = h->rq_sorted;
+  return 0;
+}
+
+// the requested parent's slot: the population is sorted by (hash cell, id), so the
+// parent's position names its cell and a binary search inside the cell finds the id
+// (round 2: a 64-bit sort of every id of the tile per step)
+__global__ void k_lookup_req2(int64_t n, const gnx_gamete_req2* __restrict__ req, int n_paths,
+                              double inv_cs, int ncx, int ncy,
+                              const int32_t* __restrict__ cell_start,
+                              const int64_t* __restrict__ id, const uint8_t* __restrict__ ghost,
+                              int32_t* __restrict__ out_slot, int64_t* __restrict__ chk) {
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const gnx_gamete_req2 r = req[q];
+  const int cx = min(ncx - 1, max(0, (int)((double)r.px * inv_cs)));
+  const int cy = min(ncy - 1, max(0, (int)((double)r.py * inv_cs)));
+  const int c = cy * ncx + cx;
+  int lo = cell_start[c], hi = cell_start[c + 1];
+  const int end = hi;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (id[mid] < r.parent_id) lo = mid + 1; else hi = mid;
+  }
+  const bool ok = lo < end && id[lo] == r.parent_id && !ghost[lo] && r.key >= 0 &&
+                  r.key < n_paths && (r.start == 0 || r.start == 1);
+  out_slot[q] = ok ? lo : 0;
+  if (!ok) atomicAdd((unsigned long long*)&chk[1], 1ull);
+}
+
+__global__ void __launch_bounds__(256)
+k_make_gametes_req2(int64_t n, int W16, const u64x2* __restrict__ G,
+                    const int32_t* __restrict__ grow, GnxHalves H,
+                    const int32_t* __restrict__ slot, const gnx_gamete_req2* __restrict__ req,
+                    const u64x2* __restrict__ paths, u64x2* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (q >= n) return;
+  const int prow = grow[slot[q]];
+  const gnx_gamete_req2 r = req[q];
+  const u64 s = r.start ? ~0ull : 0ull;
+  const int64_t lh0 = (int64_t)max(prow, 0) * 2;
+  const int key = min(max(r.key, 0), 0x7fffffff);
+  const u64x2* pm = paths + (int64_t)key * W16;
+  for (int c = lane; c < W16; c += 64) {
+    u64x2 m = pm[c];
+    m.a ^= s;
+    m.b ^= s;
+    const u64x2 a = G[gnx_chunk_at(H, lh0, c)], b = G[gnx_chunk_at(H, lh0 + 1, c)];
+    u64x2 o;
+    o.a = (a.a & ~m.a) | (b.a & m.a);
+    o.b = (a.b & ~m.b) | (b.b & m.b);
+    out[q * W16 + c] = o;
+  }
+}
+
+extern "C" int gnx_tile2_serve(gnx_state* h, int64_t n, const void* req_dev, void** out_dev) {
+  *out_dev = nullptr;
+  if (n == 0) return 0;
+  if (!has_rows(h) || h->n_paths == 0) {
+    gnx_set_error("gnx_tile2_serve: genomes / paths not set");
+    return 1;
+  }
+  GNXCHK(tile2_buffers(h));
+  if (n > h->gam_cap) {
+    (void)hipFree(h->gam_out);
+    (void)hipFree(h->gam_slot);
+    h->gam_cap = n + n / 4 + 256;
+    GNXCHK(dalloc_t(&h->gam_out, (size_t)h->gam_cap * h->W64));
+    GNXCHK(dalloc_t(&h->gam_slot, (size_t)h->gam_cap + 1));
+  }
+  // last step's deferred crossover wrote blocks of individuals that are parents now
+  GNXCHK(gnx_xo_launch_pending(h));
+  GNXCHK(gnx_xo_wait_inflight(h));
+  GnxSoA s = h->soa[h->cur];
+  hipLaunchKernelGGL(k_lookup_req2, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, n,
+                     (const gnx_gamete_req2*)req_dev, h->n_paths, h->inv_cs, h->ncx, h->ncy,
+                     h->cell_start, s.id, s.ghost, h->gam_slot, h->chk);
+  const int W16 = h->W64 / 2;
+  hipLaunchKernelGGL(k_make_gametes_req2, dim3(gnx_grid(n * 64, 256)), dim3(256), 0, h->stream, n,
+                     W16, (const u64x2*)h->G, s.grow, gnx_halves(h), h->gam_slot,
+                     (const gnx_gamete_req2*)req_dev, (const u64x2*)h->paths, (u64x2*)h->gam_out);
+  HIPCHK(hipGetLastError());
+  *out_dev = h->gam_out;
+  return 0;
+}
+
+extern "C" int gnx_tile2_put(gnx_state* h, int64_t n, const void* data_dev) {
+  if (n == 0) return 0;
+  if (n != h->n_req) {
+    gnx_set_error("gnx_tile2_put: %lld gametes for %lld requests", (long long)n,
+                  (long long)h->n_req);
+    return 1;
+  }
+  const int W16 = h->W64 / 2;
+  hipLaunchKernelGGL(k_put_gametes, dim3(gnx_grid(n * W16, 256, 256 * 32)), dim3(256), 0, h->stream,
+                     n, W16, (const u64x2*)data_dev, (u64x2*)h->G, h->soa[h->cur].grow,
+                     gnx_halves(h), h->birth_first_slot, h->rq_k);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+__global__ void k_set_words(int32_t* dst, int a, int b, int c, int d) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    dst[0] = a;
+    dst[1] = b;
+    dst[2] = c;
+    dst[3] = d;
+  }
+}
+
+extern "C" int gnx_tile2_finish_births(gnx_state* h, int32_t burn, void** reduce_dev,
+                                       int64_t* n_words) {
+  GNXCHK(gnx_tile_finish_births(h, burn));
+  const int64_t nb = (int64_t)h->lat.nbx * h->lat.nby;
+  // this tile's own individuals (ghosts are resident), births, deaths of the previous step
+  hipLaunchKernelGGL(k_set_words, dim3(1), dim3(64), 0, h->stream, h->bin_partials + 2 * nb,
+                     (int)(h->N - h->n_ghost), (int)h->last_births, (int)h->prev_deaths, 0);
+  HIPCHK(hipGetLastError());
+  *reduce_dev = h->bin_partials;
+  *n_words = 2 * nb + 4;
+  return 0;
+}
+
+extern "C" int gnx_tile2_die(gnx_state* h, int32_t burn, int32_t with_selection,
+                             int32_t have_pairs, int64_t* totals) {
+  GNXCHK(tile2_buffers(h));
+  const int64_t nb = (int64_t)h->lat.nbx * h->lat.nby;
+  // the reduced counter words and the deferred checks ride to the host behind the
+  // mortality's own wait (wait 3 of the step)
+  hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, h->stream, 4, h->bin_partials + 2 * nb,
+                     h->h_route_pin_dev, 0);
+  hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, h->stream, 4,
+                     (const int32_t*)h->chk, h->h_route_pin_dev + 8, 0);
+  if (have_pairs)
+    GNXCHK(gnx_l_spline(h, h->bins_P, &h->spl_P, nullptr));
+  else
+    h->spl_P.valid = false;
+  GNXCHK(gnx_l_spline(h, h->bin_partials, &h->spl_N, nullptr));
+  GNXCHK(gnx_l_death_probs(h, with_selection != 0 && !burn));
+  int64_t D = 0;
+  GNXCHK(gnx_l_mortality(h, nullptr, &D));
+  h->last_deaths = D;
+  h->prev_deaths = D;
+  // (the words were published before the kernels the mortality waited for)
+  std::atomic_thread_fence(std::memory_order_acquire);
+  for (int k = 0; k < 3; ++k) totals[k] = h->h_route_pin[k];
+  const int64_t bad_rec = (int64_t)(uint32_t)h->h_route_pin[8] | ((int64_t)h->h_route_pin[9] << 32);
+  const int64_t bad_req = (int64_t)(uint32_t)h->h_route_pin[10] | ((int64_t)h->h_route_pin[11] << 32);
+  if (bad_rec || bad_req) {
+    gnx_set_error("tile2: %lld imported records off the landscape, %lld gamete requests for a "
+                  "parent that does not live on this tile (or a path / start out of range)",
+                  (long long)bad_rec, (long long)bad_req);
+    return 1;
+  }
+  return 0;
+}
+
+extern "C" int gnx_tile_pair_ptrs_nosync(gnx_state* h, int64_t* n_pairs, void** focal_ids,
+                                         void** n_births) {
+  const int64_t P = h->n_pairs;
+  *n_pairs = P;
+  *focal_ids = P ? (void*)h->key64[0] : nullptr;
+  *n_births = (P && !h->sp.n_births_fixed) ? (void*)h->nbirths : nullptr;
   return 0;
 }

@@ -123,6 +123,7 @@ class Comm:
         if dist is None or not dist.is_initialized():
             self.rank, self.world, self.device = 0, 1, 'cpu'
             self.dist = None
+            self.stream_ordered = True
         else:
             self.rank = dist.get_rank()
             self.world = dist.get_world_size()
@@ -131,6 +132,8 @@ class Comm:
             # can force device tensors over another backend (GNX_COMM_DEVICE=cuda)
             self.device = os.environ.get('GNX_COMM_DEVICE') or (
                 'cuda' if dist.get_backend() == 'nccl' else 'cpu')
+            # RCCL's operations are ordered on streams; gloo touches the buffers from the host
+            self.stream_ordered = dist.get_backend() == 'nccl'
 
     def _t(self, a):
         import torch
@@ -221,6 +224,84 @@ class Comm:
         import torch
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         torch.cuda.current_stream().synchronize()
+        return t
+
+    # -- tile2: nothing here blocks the host except the count all-gathers -----------------
+    def host_allgather(self, a):
+        """every rank's int64 vector (same length everywhere) -> int64 [world][len] on the
+        host.  The vectors are a few dozen words; they travel through a CPU (gloo) group
+        when there is one beside RCCL, so that no GPU stream is waited for."""
+        a = np.ascontiguousarray(a, dtype=np.int64)
+        if self.dist is None:
+            return a[None, :]
+        import torch
+        grp = self._host_group()
+        if grp is not None:
+            t = torch.from_numpy(a)
+            out = [torch.zeros_like(t) for _ in range(self.world)]
+            self.dist.all_gather(out, t, group=grp)
+            return torch.stack(out).numpy()
+        t = torch.from_numpy(a).to(self.device)
+        out = [torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return torch.stack(out).cpu().numpy()
+
+    def _host_group(self):
+        if not hasattr(self, '_hgrp'):
+            self._hgrp = None
+            try:
+                if self.dist.get_backend() != 'gloo':
+                    self._hgrp = self.dist.new_group(backend='gloo')
+            except Exception:
+                self._hgrp = None
+        return self._hgrp
+
+    def exchange_multi(self, groups):
+        """groups: [(parts, mat)] as for exchange_dev, all in ONE batch of isend / irecv and
+        without a host synchronisation: the received tensors are valid for work enqueued on
+        the current stream (req.wait() orders the stream behind RCCL, it does not block)."""
+        import torch
+        me = self.rank
+        ops, out = [], []
+        for parts, mat in groups:
+            soff = np.concatenate([[0], np.cumsum(mat[me])])
+            roff = np.concatenate([[0], np.cumsum(mat[:, me])])
+            recv = []
+            for t, unit in parts:
+                r = torch.empty(int(roff[-1]) * unit, dtype=torch.uint8, device=t.device)
+                recv.append(r)
+                for peer in range(self.world):
+                    if peer == me:
+                        if mat[me, me]:
+                            r[roff[me] * unit:roff[me + 1] * unit] = \
+                                t[soff[me] * unit:soff[me + 1] * unit]
+                        continue
+                    if mat[me, peer]:
+                        ops.append(self.dist.P2POp(
+                            self.dist.isend, t[soff[peer] * unit:soff[peer + 1] * unit], peer))
+                    if mat[peer, me]:
+                        ops.append(self.dist.P2POp(
+                            self.dist.irecv, r[roff[peer] * unit:roff[peer + 1] * unit], peer))
+            out.append(recv)
+        if ops:
+            for req in self.dist.batch_isend_irecv(ops):
+                req.wait()
+        return out
+
+    def allgather_known(self, t, ns):
+        """all ranks' 1-d int64 device tensors whose lengths ns[r] every rank knows already
+        -> list of tensors (no count exchange, no host synchronisation)"""
+        import torch
+        m = max(int(max(ns)), 1)
+        buf = torch.zeros(m, dtype=torch.int64, device=t.device)
+        buf[:t.numel()] = t
+        out = [torch.empty_like(buf) for _ in range(self.world)]
+        self.dist.all_gather(out, buf)
+        return [o[:int(k)] for o, k in zip(out, ns)]
+
+    def allreduce_async_(self, t):
+        """sum all-reduce in place, ordered on the current stream (no host wait)"""
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return t
 
     def alltoallv(self, send):
@@ -315,6 +396,14 @@ class TiledStepper:
         self.profile = bool(os.environ.get('GNX_TILE_PROFILE'))
         self.phase_s = {}
         self._t0 = 0.0
+        # the device-driven protocol (tile2, include/gnx_hip.h): the HIP shard with a
+        # transport that moves device memory, or a single tile
+        self.v2 = (hasattr(shard, 'dev') and os.environ.get('GNX_TILE_V2', '1') != '0' and
+                   (comm.world == 1 or self.dev_transport))
+        self._ext = None           # the library's stream as a torch stream
+        self._keep = []            # tensors the library reads until the end of the step
+        self._n_start = None       # global population at the start of the coming step
+        self._pre = None           # global population before the last step's deaths
 
     def rank_of(self, x, y):
         c = np.minimum(self.C - 1, (np.asarray(x) // self.tw).astype(np.int64))
@@ -573,9 +662,155 @@ class TiledStepper:
             self.phase_s[name] = self.phase_s.get(name, 0.0) + now - self._t0
         self._t0 = now
 
-    def step(self, burn, with_selection, after_births=None):
+    # -- tile2: one time step, three host waits -----------------------------------------
+    def _lib_to_torch(self):
+        """collectives enqueued from here on see what the library has enqueued so far: a
+        stream dependency under RCCL; a transport that reads device memory from the host
+        (the gloo rehearsals) needs the work done"""
+        import torch
+        if not getattr(self.comm, 'stream_ordered', True):
+            self.shard.dev.synchronize()
+            return
+        if self._ext is None:
+            self._ext = torch.cuda.ExternalStream(self.shard.dev.stream_ptr())
+        torch.cuda.current_stream().wait_stream(self._ext)
+
+    def _torch_to_lib(self):
+        """library work enqueued from here on sees what torch / RCCL have enqueued so far"""
+        import torch
+        if not getattr(self.comm, 'stream_ordered', True):
+            torch.cuda.current_stream().synchronize()
+            return
+        if self._ext is None:
+            self._ext = torch.cuda.ExternalStream(self.shard.dev.stream_ptr())
+        self._ext.wait_stream(torch.cuda.current_stream())
+
+    def _step_v2(self, burn, with_selection, after_births, exact):
+        import torch
+        sh, dev, comm = self.shard, self.shard.dev, self.comm
+        w, me = comm.world, comm.rank
+        nt, W64 = sh.n_traits, sh.W64
+        geno = sh.has_genomes
+        self._tick(None)
+        self._keep = []
+        # 1. age + movement, routing (wait 1), ONE exchange: migrants and ghosts
+        cnt = dev.tile2_move_route(self.move)
+        self._tick('move + route')
+        if w > 1:
+            mats = comm.host_allgather(cnt.reshape(-1)).reshape(w, 2, w)
+            m_mig, m_gh = mats[:, 0, :], mats[:, 1, :]
+            p_rec, p_z, p_g, p_gh = dev.tile2_route_ptrs()
+            n_mig, n_gh = int(cnt[0].sum()), int(cnt[1].sum())
+            parts = [(dev_bytes(p_rec, n_mig * 32), 32)]
+            if nt:
+                parts.append((dev_bytes(p_z, n_mig * 4 * nt), 4 * nt))
+            if geno:
+                parts.append((dev_bytes(p_g, n_mig * 16 * W64), 16 * W64))
+            ghosts = [(dev_bytes(p_gh, n_gh * 32), 32)]
+            self.bytes_sent += sum(t.numel() for t, _ in parts) + n_gh * 32
+            self._lib_to_torch()
+            got_m, got_g = comm.exchange_multi([(parts, m_mig), (ghosts, m_gh)])
+            self._keep += got_m + got_g
+            self._torch_to_lib()
+            dev.tile2_import(int(m_mig[:, me].sum()), got_m[0].data_ptr(),
+                             got_m[1].data_ptr() if nt else 0,
+                             got_m[-1].data_ptr() if geno else 0,
+                             int(m_gh[:, me].sum()), got_g[0].data_ptr())
+        self._tick('exchange + import')
+        # 2. pairs (wait 2); pair order and gamete requests from ONE count all-gather
+        P, B, req = dev.tile2_pairs(burn)
+        self._tick('pairs')
+        # births per pair when they are fixed (the species' parameters, the same on every
+        # rank), else 0: Poisson counts travel with the pair keys
+        lam = self.fixed_births or dev.births_fixed_lambda
+        P_, p_ids, p_nb = dev.tile_pair_ptrs_nosync()
+        if w > 1:
+            mat2 = comm.host_allgather(np.concatenate([[P, B], req]))
+            Ps, Bs, m_req = mat2[:, 0], mat2[:, 1], mat2[:, 2:]
+            total_births, total_pairs = int(Bs.sum()), int(Ps.sum())
+            mine = dev_bytes(p_ids, P * 8).view(torch.int64)
+            self._lib_to_torch()
+            all_ids = comm.allgather_known(mine, Ps)
+            all_nb = None
+            if not lam:
+                nb = dev_bytes(p_nb, P * 4).view(torch.int32).to(torch.int64) if P else mine
+                all_nb = comm.allgather_known(nb, Ps)
+            goff = torch.zeros(max(P, 1), dtype=torch.int64, device=mine.device)[:P]
+            for r in range(w):
+                li = all_ids[r]
+                if not P or not li.numel():
+                    continue
+                if lam:
+                    goff += torch.searchsorted(li, mine) * int(lam)
+                else:
+                    cum = torch.zeros(li.numel() + 1, dtype=torch.int64, device=mine.device)
+                    cum[1:] = torch.cumsum(all_nb[r], 0)
+                    goff += cum[torch.searchsorted(li, mine)]
+        else:
+            total_births, total_pairs = B, P
+            dev_t = torch.device('cuda')
+            if lam or not P:
+                goff = torch.arange(P, dtype=torch.int64, device=dev_t) * int(lam)
+            else:
+                self._lib_to_torch()
+                nb = dev_bytes(p_nb, P * 4).view(torch.int32).to(torch.int64)
+                goff = torch.cumsum(nb, 0) - nb
+        self._keep.append(goff)
+        self._torch_to_lib()
+        p_req = dev.tile2_offspring(burn, self.max_id + 1, goff.data_ptr() if P else 0)
+        self.max_id += total_births
+        sh.set_max_id(self.max_id)
+        self._tick('offspring')
+        # gametes of ghost mates: requests out, gametes back
+        if w > 1 and not burn and geno:
+            n_req = int(req.sum())
+            self._lib_to_torch()
+            (got_r,), = comm.exchange_multi([([(dev_bytes(p_req, n_req * 24), 24)], m_req)])
+            self._keep.append(got_r)
+            m = int(m_req[:, me].sum())
+            self._torch_to_lib()
+            p_out = dev.tile2_serve(m, got_r.data_ptr() if m else 0)
+            self.bytes_sent += m * 8 * W64
+            self._lib_to_torch()
+            (back,), = comm.exchange_multi([([(dev_bytes(p_out, m * 8 * W64), 8 * W64)],
+                                            m_req.T.copy())])
+            self._keep.append(back)
+            self._torch_to_lib()
+            if n_req:
+                dev.tile2_put(n_req, back.data_ptr())
+        self._tick('gametes')
+        ptr, n_words = dev.tile2_finish_births(burn)
+        if after_births is not None and total_births > 0:
+            after_births(self.max_id - total_births + 1, total_births)
+        # ONE all-reduce: both density fields and the counters
+        if w > 1:
+            self._lib_to_torch()
+            comm.allreduce_async_(dev_bytes(ptr, n_words * 4).view(torch.int32))
+            self._torch_to_lib()
+        self._tick('finish + all-reduce')
+        # 3. densities, death probabilities, mortality (wait 3)
+        n_pre, b_glob, d_prev = dev.tile2_die(burn, with_selection, total_pairs > 0)
+        sh.advance_step()
+        self._keep = []
+        self._tick('die')
+        if exact:
+            n, b, d = sh.counts()
+            tot = comm.allreduce_sum(np.array([n, b, d], dtype=np.int64)) if w > 1 else (n, b, d)
+            return int(tot[0]), int(tot[1]), int(tot[2])
+        # (N at the start of this step = N before the previous step's deaths - those deaths)
+        n_start = (self._pre - d_prev) if self._pre is not None else n_pre - b_glob
+        self._pre = n_pre
+        return int(n_start), int(b_glob), int(d_prev)
+
+    def step(self, burn, with_selection, after_births=None, exact=True):
         """one time step; `after_births(first_id, total_births)` runs once every
-        offspring of the step has its genome and phenotype (mutations go there)"""
+        offspring of the step has its genome and phenotype (mutations go there).
+        Returns the global (N after the step, births, deaths).  With exact=False the
+        device-driven protocol skips the collective those take and returns the counts
+        that rode on the step's own all-reduce: (N at the START of the step, births,
+        deaths of the PREVIOUS step)."""
+        if self.v2:
+            return self._step_v2(burn, with_selection, after_births, exact)
         sh = self.shard
         self._tick(None)
         sh.age_and_move(self.move)

@@ -350,6 +350,8 @@ int gnx_tile_import_dev(gnx_state* h, int64_t n, const void* rec, const void* z,
 int gnx_tile_import_ghosts_dev(gnx_state* h, int64_t n, const void* rec);
 /* order keys (cell << 40 | focal id) int64[P] ascending; n_births int32[P] or NULL    */
 int gnx_tile_pair_ptrs(gnx_state* h, int64_t* n_pairs, void** focal_ids, void** n_births);
+/* the same without waiting for the handle's stream (tile2)                             */
+int gnx_tile_pair_ptrs_nosync(gnx_state* h, int64_t* n_pairs, void** focal_ids, void** n_births);
 int gnx_tile_offspring_dev(gnx_state* h, int32_t burn, int64_t id_base,
                            const void* pair_goff_dev /*int64[P]*/, int64_t* n_requests);
 /* this step's gamete requests grouped by owner rank: gnx_gamete_req[n_requests] */
@@ -360,6 +362,59 @@ int gnx_tile_serve_gametes_dev(gnx_state* h, int64_t n, const void* req_dev,
 int gnx_tile_put_gametes_dev(gnx_state* h, int64_t n, const void* data_dev);
 /* int32 [2][bin_count]: individuals, pair midpoints (all-reduce in place)     */
 int gnx_tile_bins_ptr(gnx_state* h, void** bins, int64_t* n_total);
+
+/* ---- the device-driven tile protocol ("tile2"): the host waits for the device three
+ * times per step - for the routing counts, for the pair / request counts and for the
+ * survivor count - and every payload stays in device memory.  Entry points marked (no
+ * wait) only enqueue work on the handle's stream (gnx_stream_ptr: the host layer orders
+ * its collectives behind it with stream dependencies, never with a host synchronisation);
+ * buffers the caller hands in must stay alive until gnx_tile2_die returns.
+ *   gnx_tile2_move_route -> [counts all-gather, ONE batch of sends: migrants + ghosts] ->
+ *   gnx_tile2_import -> gnx_tile2_pairs -> [counts all-gather, pair keys all-gather] ->
+ *   gnx_tile2_offspring -> [requests] -> gnx_tile2_serve -> [gametes] -> gnx_tile2_put ->
+ *   gnx_tile2_finish_births -> [ONE all-reduce: both bin fields + counters] -> gnx_tile2_die */
+typedef struct {
+  int64_t parent_id;
+  int32_t key;      /* recombination path */
+  int32_t start;    /* starting homologue, 0 / 1 */
+  float px, py;     /* the parent's position (its hash cell locates it on the owning tile) */
+} gnx_gamete_req2;
+/* the HIP stream the handle enqueues on (torch.cuda.ExternalStream)                       */
+int gnx_stream_ptr(gnx_state* h, void** stream);
+/* age (+ movement), then the route of every individual: one that left the tile goes to
+ * the tile that owns its new position, with its genome, and every individual in a hash
+ * cell within two cells of a neighbour tile goes there as a ghost - emigrants included
+ * (relative to their NEW tile; this tile can be among the receivers), so the halo does not
+ * wait for the migrants' arrival.  Grouped by destination rank on the device.
+ * counts[2 * R*C] = migrants per rank, ghosts per rank.  Emigrants stay in their slots
+ * until the cell sort of gnx_tile2_pairs moves them behind the population.  One wait.     */
+int gnx_tile2_move_route(gnx_state* h, int32_t move, int64_t* counts);
+int gnx_tile2_route_ptrs(gnx_state* h, void** mig_rec, void** mig_z, void** mig_geno,
+                         void** ghost_rec);
+/* arrivals (device buffers): migrants rec / z / geno [n_mig], ghosts rec [n_ghost]; (no wait) */
+int gnx_tile2_import(gnx_state* h, int64_t n_mig, const void* rec, const void* z,
+                     const void* geno, int64_t n_ghost, const void* ghost_rec);
+/* cell sort (emigrants leave, their genome rows return to the free stack), mate search, pair
+ * list, births.  counts[2 + R*C] = pairs, births, gamete requests per owning rank.  One
+ * wait (two more with Poisson-distributed births).                                      */
+int gnx_tile2_pairs(gnx_state* h, int32_t burn, int64_t* counts);
+/* offspring; *req_dev = gnx_gamete_req2[] grouped by owning rank as counted by
+ * gnx_tile2_pairs; (no wait)                                                             */
+int gnx_tile2_offspring(gnx_state* h, int32_t burn, int64_t id_base,
+                        const void* pair_goff_dev /*int64[P]*/, void** req_dev);
+/* gametes for n requests of other tiles: *out_dev = u64[n][W64]; (no wait)                */
+int gnx_tile2_serve(gnx_state* h, int64_t n, const void* req_dev, void** out_dev);
+/* the answers to this tile's requests, in the grouped request order; (no wait)          */
+int gnx_tile2_put(gnx_state* h, int64_t n, const void* data_dev);
+/* phenotypes of the offspring, bins of the tile's own individuals; *reduce_dev = int32
+ * [2 * bin_count + 4]: both bin fields, then this tile's N, births, deaths of the PREVIOUS
+ * step and 0 - one all-reduce(sum) in place for all of it; (no wait)                     */
+int gnx_tile2_finish_births(gnx_state* h, int32_t burn, void** reduce_dev, int64_t* n_words);
+/* densities from the reduced bins, death probabilities, mortality; checks what the
+ * (no wait) calls could not report (records off the landscape, unknown parents).  One wait.
+ * totals[3] = the all-reduced N, births, deaths-of-the-previous-step words.              */
+int gnx_tile2_die(gnx_state* h, int32_t burn, int32_t with_selection, int32_t have_pairs,
+                  int64_t* totals);
 
 /* ---- pedigree (reference structs/species.py:692-736: rows of the tskit tables) --
  * the offspring of the last gnx_pop_dynamics_mate, in birth order; call it before

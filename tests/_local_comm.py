@@ -81,3 +81,16 @@ class LocalComm:
     def alltoallv(self, send):
         got = self._swap([np.asarray(s).copy() for s in send])
         return [got[p][self.rank] for p in range(self.world)]
+
+    # -- tile2 (parallel.py: Comm.host_allgather / exchange_multi / allgather_known) ------
+    def host_allgather(self, a):
+        return np.stack(self._swap(np.ascontiguousarray(a, dtype=np.int64).copy()))
+
+    def exchange_multi(self, groups):
+        return [self.exchange_dev(parts, mat) for parts, mat in groups]
+
+    def allgather_known(self, t, ns):
+        return self.allgather_var(t)
+
+    def allreduce_async_(self, t):
+        return self.allreduce_dev_(t)
