@@ -31,10 +31,19 @@ class LocalComm:
         self.hub.barrier.wait()
         return out
 
+    # like RCCL: operations are ordered on streams, nothing waits for the device.  Every
+    # thread's torch work goes to the one default stream of the process, so "every rank has
+    # ENQUEUED its copies" (a barrier of the threads) is all a producer needs to know before
+    # it orders its own stream behind the default stream (TiledStepper._torch_to_lib).
+    # GNX_LOCALCOMM_SYNC=1: drain the device at every collective (round 2's behaviour).
+    stream_ordered = True
+
     def _done(self):
         """nobody reuses a posted buffer before every rank has copied from it"""
+        import os
         import torch
-        torch.cuda.synchronize()
+        if os.environ.get('GNX_LOCALCOMM_SYNC'):
+            torch.cuda.synchronize()
         self.hub.barrier.wait()
 
     # host-side small collectives
@@ -59,7 +68,9 @@ class LocalComm:
         total = torch.stack([p.clone() for p in posted]).sum(0).to(t.dtype)
         self._done()
         t.copy_(total)
-        torch.cuda.synchronize()
+        import os
+        if os.environ.get('GNX_LOCALCOMM_SYNC'):
+            torch.cuda.synchronize()
         return t
 
     def exchange_dev(self, parts, mat):
