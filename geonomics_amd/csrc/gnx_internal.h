@@ -340,6 +340,9 @@ struct gnx_state {
   uint32_t* cell32 = nullptr;    // [cap] hash cell of each slot (k_move / k_keys)
   uint32_t* keyk[2]{};           // cells in id order / sorted
   int32_t* valk[2]{};            // id ranks in id order / sorted
+  void* os_scratch = nullptr;    // gnx_os_sort32: histograms, look-back states, block counters
+  uint32_t* os_ktmp = nullptr;   // ... and the pairs between two digit places
+  int32_t* os_vtmp = nullptr;
   int32_t* ord_cnt = nullptr;    // block counts / offsets of the index's own compaction
   int32_t* ord_off = nullptr;
   hipEvent_t ev_ord = nullptr;
@@ -509,6 +512,11 @@ int gnx_l_scatter_genomes(gnx_state* h, int64_t n, const uint64_t* d_in, int64_t
 int gnx_block_scan(gnx_state* h, int K, int64_t n_items, const int32_t* cnt, int32_t* off,
                    int32_t* out, int64_t* host, int64_t seq = 0, hipStream_t st = nullptr,
                    const int32_t* extra = nullptr);
+// the step's cell sort over the id-ordered index: Onesweep with one fill (gnx_prim.hip)
+size_t gnx_os_scratch_bytes(size_t n, int end_bit);
+int gnx_os_sort32(void* scratch, uint32_t* ktmp, int32_t* vtmp, const uint32_t* kin,
+                  uint32_t* kout, const int32_t* vin, int32_t* vout, size_t n, int end_bit,
+                  hipStream_t s, int variant);
 int gnx_prim_sort32_bits(void* tmp, size_t bytes, const uint32_t* kin, uint32_t* kout,
                          const int32_t* vin, int32_t* vout, size_t n, int end_bit,
                          hipStream_t s, bool alone);

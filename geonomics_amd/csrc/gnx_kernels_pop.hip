@@ -499,8 +499,13 @@ int gnx_l_sort_by_cell(gnx_state* h) {
     }
     hipLaunchKernelGGL(k_keys_ord, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, h->ord_n,
                        h->ord[h->ord_cur], h->cell32, h->keyk[0], h->valk[0]);
-    GNXCHK(gnx_prim_sort32_bits(h->sort64_tmp, h->sort64_tmp_bytes, h->keyk[0], h->keyk[1],
-                                h->valk[0], h->valk[1], (size_t)N, h->key_bits, h->stream, alone));
+    static const int os_variant = getenv("GNX_OS_SORT") ? atoi(getenv("GNX_OS_SORT")) : 2;
+    if (os_variant >= 0 && h->key_bits <= 24)
+      GNXCHK(gnx_os_sort32(h->os_scratch, h->os_ktmp, h->os_vtmp, h->keyk[0], h->keyk[1],
+                           h->valk[0], h->valk[1], (size_t)N, h->key_bits, h->stream, os_variant));
+    else
+      GNXCHK(gnx_prim_sort32_bits(h->sort64_tmp, h->sort64_tmp_bytes, h->keyk[0], h->keyk[1],
+                                  h->valk[0], h->valk[1], (size_t)N, h->key_bits, h->stream, alone));
   } else {
     int cell_bits = h->key_bits;
     if (h->tile_evict > 0) {

@@ -113,6 +113,103 @@ int gnx_prim_sort32_bits(void* tmp, size_t bytes, const uint32_t* kin, uint32_t*
   return 0;
 }
 
+// ---------------------------------------------------------------- the step's cell sort
+// Stable LSD radix sort of (32-bit key, 32-bit value) pairs by the low `end_bit` key bits,
+// built from rocPRIM's Onesweep device functions (histogram of every digit place in one pass
+// over the keys, one decoupled-look-back pass per place) but launched here: rocPRIM's own
+// driver clears its histogram, its look-back states and its block counter with a fill
+// kernel each per place - six fills and four kernels for the two places of the step's
+// 16-bit cell keys; here the scratch of all places is one contiguous region cleared by ONE
+// fill (5 launches instead of 10; at 10^5 individuals the launches are the sort).
+namespace gnx_os {
+using lookback_t = rocprim::detail::onesweep_lookback_state;
+using obid_t = rocprim::detail::ordered_block_id<unsigned int>;
+
+template <unsigned BS, unsigned IPT, unsigned RB>
+__global__ void __launch_bounds__(BS)
+k_hist(const uint32_t* keys, unsigned int* offs, unsigned int size, unsigned int full_blocks,
+       unsigned int begin_bit, unsigned int end_bit) {
+  rocprim::detail::onesweep_histograms<BS, IPT, RB, false>(keys, offs, size, full_blocks,
+                                                          rocprim::identity_decomposer{}, begin_bit,
+                                                          end_bit);
+}
+
+template <unsigned BS, unsigned RB>
+__global__ void __launch_bounds__(BS) k_scan(unsigned int* offs) {
+  rocprim::detail::onesweep_scan_histograms<BS, RB>(offs);
+}
+
+template <unsigned BS, unsigned IPT, unsigned RB>
+__global__ void __launch_bounds__(BS)
+k_iter(const uint32_t* kin, uint32_t* kout, const int32_t* vin, int32_t* vout, unsigned int size,
+       unsigned int* offs_in, unsigned int* offs_out, lookback_t* lb, unsigned int bit,
+       unsigned int cur_bits, unsigned int full_blocks, obid_t ob) {
+  rocprim::detail::onesweep_iteration<BS, IPT, RB, false, rocprim::block_radix_rank_algorithm::match>(
+      kin, kout, vin, vout, size, offs_in, offs_out, lb, rocprim::identity_decomposer{}, bit, cur_bits,
+      full_blocks, ob);
+}
+
+template <unsigned BS, unsigned IPT, unsigned RB>
+static size_t scratch_words(size_t n, int end_bit) {
+  const size_t places = (end_bit + RB - 1) / RB, radix = 1u << RB;
+  const size_t blocks = (n + BS * IPT - 1) / (BS * IPT);
+  return places * radix + radix + places * blocks * radix + places + 16;
+}
+
+template <unsigned BS, unsigned IPT, unsigned RB>
+static int sort(void* scratch, uint32_t* ktmp, int32_t* vtmp, const uint32_t* kin, uint32_t* kout,
+                const int32_t* vin, int32_t* vout, size_t n, int end_bit, hipStream_t s) {
+  const unsigned int places = (end_bit + RB - 1) / RB, radix = 1u << RB;
+  const unsigned int items = BS * IPT;
+  const unsigned int blocks = (unsigned int)((n + items - 1) / items);
+  const unsigned int full_blocks = (unsigned int)(n / items);
+  unsigned int* hist = (unsigned int*)scratch;                 // [places][radix]
+  unsigned int* offs_tmp = hist + (size_t)places * radix;      // [radix]
+  lookback_t* lb = (lookback_t*)(offs_tmp + radix);            // [places][blocks * radix]
+  unsigned int* bid = (unsigned int*)(lb + (size_t)places * blocks * radix);   // [places]
+  static_assert(sizeof(lookback_t) == sizeof(unsigned int), "look-back state is one word");
+  HIPCHK(hipMemsetAsync(scratch, 0, scratch_words<BS, IPT, RB>(n, end_bit) * sizeof(unsigned int), s));
+  hipLaunchKernelGGL((k_hist<BS, IPT, RB>), dim3(blocks), dim3(BS), 0, s, kin, hist, (unsigned int)n,
+                     full_blocks, 0u, (unsigned int)end_bit);
+  hipLaunchKernelGGL((k_scan<BS, RB>), dim3(places), dim3(BS), 0, s, hist);
+  bool to_output = (places - 1) % 2 == 0;
+  const uint32_t* ki = kin;
+  const int32_t* vi = vin;
+  for (unsigned int place = 0, bit = 0; place < places; ++place, bit += RB) {
+    uint32_t* ko = to_output ? kout : ktmp;
+    int32_t* vo = to_output ? vout : vtmp;
+    const unsigned int cur = std::min<unsigned int>(RB, (unsigned int)end_bit - bit);
+    hipLaunchKernelGGL((k_iter<BS, IPT, RB>), dim3(blocks), dim3(BS), 0, s, ki, ko, vi, vo,
+                       (unsigned int)n, hist + (size_t)place * radix, offs_tmp,
+                       lb + (size_t)place * blocks * radix, bit, cur, full_blocks,
+                       obid_t::create(bid + place));
+    ki = ko;
+    vi = vo;
+    to_output = !to_output;
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+}  // namespace gnx_os
+
+// variant 0: 256 threads x 12 keys, 8-bit digits; 1: 512 x 8, 8 bits; 2: 1024 x 6, 10 bits
+size_t gnx_os_scratch_bytes(size_t n, int end_bit) {
+  size_t w = std::max({gnx_os::scratch_words<256, 12, 8>(n, end_bit),
+                       gnx_os::scratch_words<512, 8, 8>(n, end_bit),
+                       gnx_os::scratch_words<1024, 6, 10>(n, end_bit)});
+  return w * sizeof(unsigned int);
+}
+
+int gnx_os_sort32(void* scratch, uint32_t* ktmp, int32_t* vtmp, const uint32_t* kin,
+                  uint32_t* kout, const int32_t* vin, int32_t* vout, size_t n, int end_bit,
+                  hipStream_t s, int variant) {
+  switch (variant) {
+    case 1: return gnx_os::sort<512, 8, 8>(scratch, ktmp, vtmp, kin, kout, vin, vout, n, end_bit, s);
+    case 2: return gnx_os::sort<1024, 6, 10>(scratch, ktmp, vtmp, kin, kout, vin, vout, n, end_bit, s);
+    default: return gnx_os::sort<256, 12, 8>(scratch, ktmp, vtmp, kin, kout, vin, vout, n, end_bit, s);
+  }
+}
+
 // ---------------------------------------------------------------- block-count scan
 // Exclusive scan of K (<= 3) count arrays (cnt[k * stride + b], b < nb) into
 // off[k * stride + b], off[k * stride + nb] = total.  One workgroup of 1024 threads.
