@@ -296,13 +296,16 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
     }
     GNXCHK(dalloc(&h->free_rows, (size_t)h->cfg.cap_rows));
     // blocks per homologue: the largest divisor of the 128-byte lines per homologue that is
-    // not above 8 (L = 10^5: 98 lines, 7 blocks of 1.8 KB; GNX_HALF_BLOCKS asks for another
-    // one), as long as the block numbers fit 31 bits
+    // not above 16 and leaves blocks of at least 2 lines (L = 10^5: 98 lines, 14 blocks of
+    // 896 bytes; L = 10^4: 10 lines, 5 blocks of 256 bytes; GNX_HALF_BLOCKS asks for another one), as long as the block numbers fit 31
+    // bits.  Measured at the metric workload (tools/ab.sh): 7 blocks 0.745 ms/step, 14 blocks
+    // 0.670 - a switch point costs a block half the size, the tables twice the entries.
     {
       const int lines = h->W64 / 16;
-      int want = getenv("GNX_HALF_BLOCKS") ? atoi(getenv("GNX_HALF_BLOCKS")) : 8;
+      const bool asked = getenv("GNX_HALF_BLOCKS") != nullptr;
+      int want = asked ? atoi(getenv("GNX_HALF_BLOCKS")) : GNX_MAX_NB;
       want = std::max(1, std::min(want, GNX_MAX_NB));
-      while (want > 1 && (lines % want ||
+      while (want > 1 && (lines % want || (!asked && lines / want < 2) ||
                           (double)h->cfg.cap_rows * h->row_spread * 2.0 * want >= 2.0e9))
         --want;
       h->NB = want;

@@ -945,14 +945,14 @@ k_xo_jobs_write(int64_t B, GnxHalves H, const GnxXoPlan* __restrict__ plan,
   }
 }
 
-// The two kernels above in one, for NB <= 8: one thread per offspring SLOT (256 per
+// The two kernels above in one (NB <= 16): one thread per offspring SLOT (256 per
 // workgroup - four times the workgroups of k_xo_jobs_surv, which left a third of the CUs
 // idle), the plan stays in registers, and the thread walks its own 2 x NB table entries
 // with every load of a stage issued before the first result is used: the parent's 2 x NB
 // entries are NB 8-byte loads, the child's NB 8-byte stores.  One thread per logical block
 // (k_xo_jobs_write: 3.3 M threads, each a chain of three dependent loads) took 52 us,
 // k_xo_jobs_surv 23.
-#define GNX_JF_NB 8
+#define GNX_JF_NB 16
 template <int NB>
 __global__ void __launch_bounds__(256)
 k_xo_jobs_fused(int64_t N, int64_t first, int32_t* __restrict__ grow,
@@ -1182,7 +1182,15 @@ void gnx_launch_xo_jobs_surv(gnx_state* h, int64_t first_slot, const int32_t* d_
       case 5: launch_jobs_fused<5>(h, first_slot, d_alive, d_blk_off, buf); break;
       case 6: launch_jobs_fused<6>(h, first_slot, d_alive, d_blk_off, buf); break;
       case 7: launch_jobs_fused<7>(h, first_slot, d_alive, d_blk_off, buf); break;
-      default: launch_jobs_fused<8>(h, first_slot, d_alive, d_blk_off, buf); break;
+      case 8: launch_jobs_fused<8>(h, first_slot, d_alive, d_blk_off, buf); break;
+      case 9: launch_jobs_fused<9>(h, first_slot, d_alive, d_blk_off, buf); break;
+      case 10: launch_jobs_fused<10>(h, first_slot, d_alive, d_blk_off, buf); break;
+      case 11: launch_jobs_fused<11>(h, first_slot, d_alive, d_blk_off, buf); break;
+      case 12: launch_jobs_fused<12>(h, first_slot, d_alive, d_blk_off, buf); break;
+      case 13: launch_jobs_fused<13>(h, first_slot, d_alive, d_blk_off, buf); break;
+      case 14: launch_jobs_fused<14>(h, first_slot, d_alive, d_blk_off, buf); break;
+      case 15: launch_jobs_fused<15>(h, first_slot, d_alive, d_blk_off, buf); break;
+      default: launch_jobs_fused<16>(h, first_slot, d_alive, d_blk_off, buf); break;
     }
     return;
   }

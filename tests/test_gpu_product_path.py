@@ -2,7 +2,7 @@
 
 `gnx_op_crossover` (the immediate job builder) is matched against the reference's outputs in
 test_gpu_parity.py.  A time step of the product takes another route: the crossover is
-deferred behind the death draws (survivors only, second stream), a homologue is 7 blocks at
+deferred behind the death draws (survivors only, second stream), a homologue is 14 blocks at
 L = 10^5 and a block without a switch point refers to the parent's block, blocks nobody
 alive refers to come back through a mark-and-sweep collection that fires when the free
 stack runs low, and mutations copy a shared block first.  Here that route itself is
@@ -23,13 +23,14 @@ from test_gpu_parity import native
 
 pytestmark = pytest.mark.gpu
 
-L = 100000          # 1568 words per homologue = 98 lines of 128 bytes: 7 blocks of 14 lines
+L = 100000          # 1568 words per homologue = 98 lines of 128 bytes: 14 blocks of 7 lines
+NB = 14
 W = H = 40
 N0 = 1500          # settles at ~1530 after mortality (K_factor 1.0), ~310 births per step
-STEPS = 60
-# Rows for N + a step's births and little more: 2 * 7 * 2050 physical blocks, of which the living
+STEPS = 130
+# Rows for N + a step's births and little more: 2 * NB * 2050 physical blocks, of which the living
 # refer to about half at the steady state, so the free stack drops below what a step's job
-# builder may take (2 * 7 * births) every ~18 steps and the collector runs: 3 times in 60 steps
+# builder may take (2 * NB * births) every ~45 steps and the collector runs: 3 times in 130 steps
 # with sparse paths, in almost every step with dense masks (one block per homologue, none shared).
 CAP_ROWS = 2050
 
@@ -143,13 +144,13 @@ def _split_step(dev, host, t, mutate_rng=None, trait_loci=()):
 
 @pytest.mark.parametrize('overlap', [0, 1])
 def test_model_step_path_matches_oracle_crossover(overlap):
-    """the split step of the Model API: deferred + 7 shared blocks + natural collections +
+    """the split step of the Model API: deferred + 14 shared blocks + natural collections +
     mutations in every third step; genomes == oracle replay at every checkpoint"""
     nat = native()
     paths = _paths(False)
     dev, g = _make(paths, overlap=overlap)
     info = dev.genome_info()
-    assert info['NB'] == 7 and info['sparse'] == 1 and info['BW'] * 7 == dev.W64
+    assert info['NB'] == NB and info['sparse'] == 1 and info['BW'] * NB == dev.W64
     host = HostGenomes(np.arange(N0), g, paths)
     rng = np.random.RandomState(11)
     births = muts = not_cut = 0
@@ -158,12 +159,12 @@ def test_model_step_path_matches_oracle_crossover(overlap):
         births += B
         muts += m
         not_cut += B - dev.last_crossover_births
-        if t % 12 == 11 or t == STEPS - 1:
+        if t % 26 == 25 or t == STEPS - 1:
             host.check(dev, nat, 'step %d' % t)
     gc = dev.genome_info()['gc_runs']
     assert gc >= 2, 'the collector never ran on its own (gc_runs = %d)' % gc
-    assert births > 10000 and muts > 150
-    assert not_cut > 500            # offspring that died at age 0 never got a genome
+    assert births > 25000 and muts > 300
+    assert not_cut > 1500           # offspring that died at age 0 never got a genome
     # bookkeeping after all that: nothing broken, used + free = all, blocks are shared
     rows, broken, _, used, free, total = (int(v) for v in dev.debug_halves())
     assert broken == 0 and used + free == total and used < 2 * rows
@@ -181,13 +182,13 @@ def test_fused_step_path_matches_oracle_crossover(dense, overlap):
     a, g = _make(paths, overlap=overlap)
     b, _ = _make(paths, overlap=0)
     info = a.genome_info()
-    assert info['NB'] == (1 if dense else 7) and info['sparse'] == (0 if dense else 1)
+    assert info['NB'] == (1 if dense else NB) and info['sparse'] == (0 if dense else 1)
     host = HostGenomes(np.arange(N0), g, paths)
     for t in range(STEPS):
         a.step(False, True)
         _split_step(b, host, t)
         assert a.counts() == b.counts(), t
-        if t % 15 == 14 or t == STEPS - 1:
+        if t % 32 == 31 or t == STEPS - 1:
             np.testing.assert_array_equal(np.sort(a.download(nat.F_ID)),
                                           np.sort(b.download(nat.F_ID)))
             # (check a first: checking prunes the dead from the host copy, same for both)
@@ -196,7 +197,7 @@ def test_fused_step_path_matches_oracle_crossover(dense, overlap):
     for dev in (a, b):
         gc = dev.genome_info()['gc_runs']
         assert gc >= 2, 'the collector never ran on its own (gc_runs = %d)' % gc
-    assert host.born > 10000
+    assert host.born > 25000
     a.close()
     b.close()
 
@@ -253,7 +254,7 @@ def test_two_tiles_match_oracle_crossover():
                         for rec in pending[r]:
                             host.births(*rec)
                 hub.barrier.wait()
-                if t % 20 == 19:
+                if t % 26 == 25 or t == STEPS - 1:
                     with lock:
                         ids = dev.download(nat.F_ID)
                         got = dev.download(nat.F_GENO)
@@ -275,5 +276,5 @@ def test_two_tiles_match_oracle_crossover():
         th.join()
     if errs:
         raise errs[0]
-    assert min(sizes) > 1000 and host.born > 10000
+    assert min(sizes) > 1000 and host.born > 25000
     assert min(gcs) >= 2, gcs
