@@ -406,6 +406,7 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
   if (cfg->L > 0) {
     for (int k = 0; k < 2; ++k) {
       HIPCHK(hipMalloc(&h->jobs[k], (size_t)cap * 2 * h->NB * 16));     // a job per cut block
+      HIPCHK(hipMalloc(&h->jobs_bp[k], (size_t)cap * 2 * h->NB * 8));
       GNXCHK(dalloc(&h->n_jobs_dev[k], 1));
       HIPCHK(hipEventCreateWithFlags(&h->ev_xo_done[k], hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&h->ev_xo_wide[k], hipEventDisableTiming));
@@ -430,6 +431,7 @@ extern "C" void gnx_destroy(gnx_state* h) {
   if (h->stream3) (void)hipStreamSynchronize(h->stream3);    // reads ord / newslot
   for (int k = 0; k < 2; ++k) {
     (void)hipFree(h->jobs[k]);
+    (void)hipFree(h->jobs_bp[k]);
     (void)hipFree(h->n_jobs_dev[k]);
     if (h->ev_xo_done[k]) (void)hipEventDestroy(h->ev_xo_done[k]);
     if (h->ev_xo_wide[k]) (void)hipEventDestroy(h->ev_xo_wide[k]);

@@ -181,6 +181,8 @@ struct gnx_state {
   int64_t xo_first = 0, xo_B = 0;
   void* jobs[2]{};               // GnxXoJob [2 * cap] each, double-buffered
   int32_t* n_jobs_dev[2]{};
+  void* jobs_bp[2]{};            // GnxJobBp beside every job: the switch points inside its block
+  bool jobs_inline[2]{};         // ... written for this buffer's jobs (the fused builder does)
   int jobs_cur = 0;
   hipEvent_t ev_jobs = nullptr, ev_xo_done[2]{};
   hipEvent_t ev_counts = nullptr;   // the step's counts have reached pinned host memory

@@ -961,7 +961,7 @@ k_xo_jobs_fused(int64_t N, int64_t first, int32_t* __restrict__ grow,
                 const uint8_t* __restrict__ off_start, const int32_t* __restrict__ free_rows,
                 int64_t n_free, GnxHalves H, const int32_t* __restrict__ bp_off,
                 const int32_t* __restrict__ bp_loci, int32_t* __restrict__ n_jobs,
-                GnxXoJob* __restrict__ jobs) {
+                GnxXoJob* __restrict__ jobs, GnxJobBp* __restrict__ jobs_bp) {
   __shared__ int wsum[3][4];
   __shared__ int prev_s[4];
   __shared__ int s_pop, s_job;
@@ -1093,6 +1093,25 @@ k_xo_jobs_fused(int64_t N, int64_t first, int32_t* __restrict__ grow,
           j.dst = dst;
           j.ks = (key[p] * 2 + st[p]) | (q << 24);
           jobs[job + jr] = j;
+          // the switch points inside this block ride with the job (gnx_xo.h: GnxJobBp)
+          GnxJobBp ib;
+          ib.bp[0] = ib.bp[1] = ib.bp[2] = 0;
+          int nin = 0;
+          if (bp_off) {
+            const int lpb = H.BW * 64;
+            for (int z = b0[p]; z < b1[p]; ++z) {
+              const int l = bp_loci[z];
+              if (min(l / lpb, NB - 1) == q) {
+                if (nin < 3) ib.bp[nin] = (uint16_t)(l - q * lpb);
+                ++nin;
+              }
+            }
+          }
+          // (offsets are 16 bits: a block of more than 65 536 loci looks its path up)
+          const bool inl = bp_off != nullptr && nin <= 3 && H.BW * 64 <= 65536;
+          ib.meta = (uint16_t)((inl ? nin : 0) | (((sel[p] >> q) & 1u) << 2) |
+                               (inl ? 0u : GNX_BP_MORE));
+          jobs_bp[job + jr] = ib;
           ++jr;
         }
         ++fr;
@@ -1119,7 +1138,8 @@ static void launch_jobs_fused(gnx_state* h, int64_t first_slot, const int32_t* d
                      h->soa[h->cur].grow, d_alive, d_blk_off + 2 * h->blk_stride, h->off_parent,
                      h->off_keys, h->off_start, h->free_rows, h->n_free, gnx_halves(h),
                      gnx_alias_bp(h), gnx_alias_loci(h), h->n_jobs_dev[buf],
-                     (GnxXoJob*)h->jobs[buf]);
+                     (GnxXoJob*)h->jobs[buf], (GnxJobBp*)h->jobs_bp[buf]);
+  h->jobs_inline[buf] = true;
 }
 
 // Stable compaction of the SoA (survivors keep their relative order); genome
@@ -1194,6 +1214,7 @@ void gnx_launch_xo_jobs_surv(gnx_state* h, int64_t first_slot, const int32_t* d_
     }
     return;
   }
+  h->jobs_inline[buf] = false;
   hipLaunchKernelGGL(k_xo_jobs_surv, dim3(nbj), dim3(256), 0, h->stream, N, first_slot,
                      h->soa[h->cur].grow, d_alive, d_blk_off + 2 * h->blk_stride, h->off_parent,
                      h->off_keys, h->off_start, h->free_rows, h->n_free, gnx_halves(h),

@@ -51,14 +51,16 @@ template <int U>
 static void xo_launch_sparse(gnx_state* h, hipStream_t st, int grid, int buf, bool nt, int lo,
                              int hi, unsigned long long* acc) {
   const int W16 = h->W64 / 2 / h->NB;       // chunks per block
+  static const bool inline_env = !(getenv("GNX_XO_INLINE_BP") && atoi(getenv("GNX_XO_INLINE_BP")) == 0);
+  const GnxJobBp* ib = (h->jobs_inline[buf] && inline_env) ? (const GnxJobBp*)h->jobs_bp[buf] : nullptr;
   if (nt)
     hipLaunchKernelGGL((k_xo_sparse<U, true>), dim3(grid), dim3(256), 0, st, h->n_jobs_dev[buf],
                        W16, (const u64x2*)h->G, (u64x2*)h->G, (const GnxXoJob*)h->jobs[buf],
-                       h->bp_off, h->bp_loci, lo, hi, acc);
+                       h->bp_off, h->bp_loci, lo, hi, acc, ib);
   else
     hipLaunchKernelGGL((k_xo_sparse<U, false>), dim3(grid), dim3(256), 0, st, h->n_jobs_dev[buf],
                        W16, (const u64x2*)h->G, (u64x2*)h->G, (const GnxXoJob*)h->jobs[buf],
-                       h->bp_off, h->bp_loci, lo, hi, acc);
+                       h->bp_off, h->bp_loci, lo, hi, acc, ib);
 }
 
 // the crossover of job buffer `buf` on stream `st` (the share [lo, hi) / 1024 of its jobs);
@@ -143,6 +145,7 @@ int gnx_l_crossover_all(gnx_state* h, int64_t first_slot, int64_t B) {
   GnxSoA s = h->soa[h->cur];
   GNXCHK(gnx_half_reserve(h, 2 * (int64_t)h->NB * B));
   HIPCHK(hipMemsetAsync(h->n_jobs_dev[buf], 0, sizeof(int32_t), h->stream));
+  h->jobs_inline[buf] = false;
   hipLaunchKernelGGL(k_xo_jobs_all, dim3(gnx_grid(B, 256)), dim3(256), 0, h->stream, B, first_slot,
                      s.grow, h->off_parent, h->off_keys, h->off_start, h->free_rows, h->n_free,
                      gnx_halves(h), gnx_alias_bp(h), gnx_alias_loci(h), (GnxXoJob*)h->jobs[buf],
@@ -195,6 +198,7 @@ int gnx_l_crossover_requests(gnx_state* h, int64_t first_slot, int64_t n_req) {
   const int buf = h->jobs_cur;
   GNXCHK(gnx_half_reserve(h, 2 * (int64_t)h->NB * n_req));
   HIPCHK(hipMemsetAsync(h->n_jobs_dev[buf], 0, sizeof(int32_t), h->stream));
+  h->jobs_inline[buf] = false;
   hipLaunchKernelGGL(k_xo_jobs_req, dim3(gnx_grid(n_req, 256)), dim3(256), 0, h->stream, (int)n_req,
                      first_slot, h->soa[h->cur].grow, h->req_k, h->off_parent, h->off_keys,
                      h->off_start, h->free_rows, h->n_free, gnx_halves(h), gnx_alias_bp(h),

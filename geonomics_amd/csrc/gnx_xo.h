@@ -118,6 +118,42 @@ __device__ __forceinline__ u64x2 xo_mask_lanes(int c, u64 s, int mybp, int nbp) 
   return m;
 }
 
+// The switch points that fall INSIDE a job's block, packed next to the job (round 3): loci
+// relative to the block's first locus, 16 bits each (a block is at most 65 536 loci), the
+// homologue the gamete is on at the block's start, and how many there are.  More than three
+// in one block (GNX_BP_MORE): the kernel looks the path's list up as before.  With them the
+// wave needs no look-up in bp_off / bp_loci before its first streaming load - two dependent
+// loads less per 896-byte job - and the list is not fetched at all.
+#define GNX_BP_MORE 0x8u
+struct alignas(8) GnxJobBp {
+  uint16_t bp[3];
+  uint16_t meta;      // bits 0-1: how many (0 .. 3), bit 2: homologue at the block's start, bit 3: GNX_BP_MORE
+};
+
+// mask of chunk c of the BLOCK (loci [128c, 128c+128) relative to its start) from <= 3
+// scalar switch points: the arithmetic of xo_mask_lanes
+__device__ __forceinline__ u64x2 xo_mask_inline(int c, u64 s, int b0, int b1, int b2, int n) {
+  const int lo = c * 128;
+  u64 par = s;
+  u64x2 m;
+  m.a = 0;
+  m.b = 0;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int bpl = q == 0 ? b0 : (q == 1 ? b1 : b2);
+    if (q < n) {
+      const int d = bpl - lo;
+      par ^= d < 0 ? ~0ull : 0ull;
+      const u64 fa = ~0ull << (d & 63);
+      m.a ^= (d >= 0 && d < 64) ? fa : 0ull;
+      m.b ^= (d >= 0 && d < 64) ? ~0ull : ((d >= 64 && d < 128) ? fa : 0ull);
+    }
+  }
+  m.a ^= par;
+  m.b ^= par;
+  return m;
+}
+
 // homologue (0/1) the gamete copies at locus l
 __device__ __forceinline__ int xo_sel_sparse(int l, int start, int mybp, int nbp) {
   int sel = start;
@@ -133,7 +169,8 @@ __global__ void __launch_bounds__(256)
 k_xo_sparse(const int32_t* __restrict__ n_jobs_p, int W16, const u64x2* __restrict__ G,
             u64x2* __restrict__ Gout, const GnxXoJob* __restrict__ jobs,
             const int32_t* __restrict__ bp_off, const int32_t* __restrict__ bp_loci,
-            int part_lo, int part_hi, unsigned long long* __restrict__ acc) {
+            int part_lo, int part_hi, unsigned long long* __restrict__ acc,
+            const GnxJobBp* __restrict__ jobs_bp) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   // this launch's share of the job list, in 1/1024ths of the (device-resident) count
@@ -144,8 +181,22 @@ k_xo_sparse(const int32_t* __restrict__ n_jobs_p, int W16, const u64x2* __restri
   // gametes copied by the launches so far (the host prices them when it reads the timers)
   if (acc && blockIdx.x == 0 && threadIdx.x == 0 && n_jobs > j_lo)
     atomicAdd(acc, (unsigned long long)(n_jobs - j_lo));
-  for (int j = j_lo + (int)blockIdx.x * 4 + wv; j < n_jobs; j += n_waves) {
-    const GnxXoJob jb = jobs[j];
+  // software pipeline over the wave's jobs: the NEXT job's record (and its switch points) are
+  // fetched before the current job streams, so a job's latency is the data's alone
+  int j = j_lo + (int)blockIdx.x * 4 + wv;
+  GnxXoJob jb_n;
+  uint2 w_n = make_uint2(0u, GNX_BP_MORE << 16);
+  if (j < n_jobs) {
+    jb_n = jobs[j];
+    if (jobs_bp) w_n = *(const uint2*)(jobs_bp + j);
+  }
+  for (; j < n_jobs; j += n_waves) {
+    const GnxXoJob jb = jb_n;
+    const uint2 w = w_n;
+    if (j + n_waves < n_jobs) {
+      jb_n = jobs[j + n_waves];
+      if (jobs_bp) w_n = *(const uint2*)(jobs_bp + j + n_waves);
+    }
     const int ph0 = __builtin_amdgcn_readfirstlane(jb.ph0);
     const int ph1 = __builtin_amdgcn_readfirstlane(jb.ph1);
     const int dsth = __builtin_amdgcn_readfirstlane(jb.dst);
@@ -156,6 +207,44 @@ k_xo_sparse(const int32_t* __restrict__ n_jobs_p, int W16, const u64x2* __restri
     const u64x2* h0 = G + (int64_t)ph0 * W16;  // (W16 = chunks per BLOCK)
     const u64x2* h1 = G + (int64_t)ph1 * W16;
     u64x2* dst = Gout + (int64_t)dsth * W16;
+    // the block's own switch points ride with the job (fused builder): no look-ups
+    const unsigned int ib_lo = __builtin_amdgcn_readfirstlane(w.x);
+    const unsigned int ib_hi = __builtin_amdgcn_readfirstlane(w.y);
+    if (!((ib_hi >> 16) & GNX_BP_MORE)) {
+      const int b0 = (int)(ib_lo & 0xffffu), b1 = (int)(ib_lo >> 16), b2 = (int)(ib_hi & 0xffffu);
+      const int n = (int)((ib_hi >> 16) & 3u);
+      const u64 sb = ((ib_hi >> 16) & 4u) ? ~0ull : 0ull;
+      for (int c0 = lane; c0 < W16; c0 += 64 * U) {
+        u64x2 v[U];
+        bool mixed = false;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int c = min(c0 + u * 64, W16 - 1);
+          const u64x2 m = xo_mask_inline(c, sb, b0, b1, b2, n);
+          const bool one = (m.a & m.b) == ~0ull;
+          mixed |= !one && (m.a | m.b) != 0ull;
+          v[u] = xo_load<NT_LD>((one ? h1 : h0) + c);
+        }
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(mixed) != 0ull, 0)) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int c = min(c0 + u * 64, W16 - 1);
+            const u64x2 m = xo_mask_inline(c, sb, b0, b1, b2, n);
+            if ((m.a & m.b) != ~0ull && (m.a | m.b) != 0ull) {
+              const u64x2 b = h1[c];
+              v[u].a = (v[u].a & ~m.a) | (b.a & m.a);
+              v[u].b = (v[u].b & ~m.b) | (b.b & m.b);
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int c = c0 + u * 64;
+          if (c < W16) xo_store(dst + c, v[u]);
+        }
+      }
+      continue;
+    }
     const int bp0 = __builtin_amdgcn_readfirstlane(bp_off[key]);
     const int nbp = __builtin_amdgcn_readfirstlane(bp_off[key + 1]) - bp0;
     const int mybp = lane < nbp ? bp_loci[bp0 + lane] : 0x7fffffff;

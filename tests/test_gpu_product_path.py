@@ -202,10 +202,13 @@ def test_fused_step_path_matches_oracle_crossover(dense, overlap):
     b.close()
 
 
-def test_two_tiles_match_oracle_crossover():
+@pytest.mark.parametrize('overlap', [0, 1])
+def test_two_tiles_match_oracle_crossover(overlap):
     """two tiles (threads of this process, device-resident transport) through gnx_tile_*:
     deferred crossover per tile, gametes of ghost mates cut on the owning tile, migrants
-    carrying their genomes.  Each tile's births are read in the stepper's after-births hook."""
+    carrying their genomes.  Each tile's births are read in the stepper's after-births hook.
+    overlap = 1: the crossover runs beside the whole next step, i.e. it may still be in flight
+    when the tile serves its neighbours' gamete requests (the service waits for it)."""
     import torch
     from _local_comm import Hub, LocalComm
     from geonomics_amd.parallel import DeviceShard, TiledStepper
@@ -229,7 +232,8 @@ def test_two_tiles_match_oracle_crossover():
         try:
             torch.cuda.set_device(0)
             comm = LocalComm(hub, rank)
-            dev, _ = _make(paths, cap_inds=4096, cap_rows=2150, N=N, W=Wt, H=Ht, upload=False)
+            dev, _ = _make(paths, cap_inds=4096, cap_rows=2150, N=N, W=Wt, H=Ht, upload=False,
+                           overlap=overlap)
             shard = DeviceShard(dev)
             stepper = TiledStepper(shard, comm, Wt, Ht, 3.0, move=True, max_id=N - 1,
                                    fixed_births=1)

@@ -44,3 +44,16 @@ def test_tiled_oracle_run_is_bit_identical_to_single_tile(tmp_path, world, mode)
     assert many['bytes_sent'] > 0 and one['bytes_sent'] == 0
     # genomes carry real variation (the check is not vacuous)
     assert 0.3 < np.unpackbits(one['geno'].view(np.uint8)).mean() * (one['geno'].shape[2] * 64 / 192) < 0.7
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_tile2_comm_helpers(world):
+    """the collective helpers of the device-driven tile protocol (host count all-gather, the
+    one-batch multi-group exchange incl. messages to oneself, the padded all-gather of known
+    lengths, the in-place all-reduce) over gloo on CPU tensors"""
+    port = free_port()
+    worker = os.path.join(HERE, '_comm_worker.py')
+    procs = [subprocess.Popen([sys.executable, worker, str(world), str(r), str(port)])
+             for r in range(world)]
+    from _procs import wait_all
+    assert wait_all(procs) == [0] * world

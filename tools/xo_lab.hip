@@ -349,7 +349,7 @@ int main(int argc, char** argv) {
 #define SPARSE(U, NT, BPC, KIND)                                                                  \
   add(std::string("xo_sparse U=" #U " nt=" #NT " bpc=" #BPC " ") + kn[KIND], [=]() {             \
     hipLaunchKernelGGL((k_xo_sparse<U, NT>), dim3(256 * BPC), dim3(256), 0, 0, d_njobs, W16, G, G, \
-                       d_jobs[KIND], d_bpoff, d_bploci, 0, 1024, nullptr); }, sparse_bytes)
+                       d_jobs[KIND], d_bpoff, d_bploci, 0, 1024, nullptr, (const GnxJobBp*)nullptr); }, sparse_bytes)
 #define DENSE(U, NT, BPC, KIND)                                                                   \
   add(std::string("xo_dense U=" #U " nt=" #NT " bpc=" #BPC " ") + kn[KIND], [=]() {              \
     hipLaunchKernelGGL((k_xo_dense<U, NT>), dim3(256 * BPC), dim3(256), 0, 0, d_njobs, W16, G, G,  \
