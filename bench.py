@@ -669,6 +669,18 @@ def main():
                              for k, v in fam.items()},
                 'note': 'bytes and per-family times from 10 extra steps with every kernel '
                         'family bracketed by HIP events, outside the timed region'}
+            # what shares HBM with the crossover while it runs: the mortality compaction (it
+            # runs entirely inside the launch) and the next step's movement (it starts ~60 us
+            # into the launch and outlasts it by a few tens of microseconds, so the combined
+            # rate below is an upper bound of the window's traffic)
+            beside = sum(fam[k]['bytes_per_step'] for k in ('compact', 'move') if k in fam)
+            lms = xo['ms'] / max(xo['launches'], 1)
+            if lms > 0:
+                out['roofline']['beside_the_crossover'] = {
+                    'families': ['compact', 'move'], 'bytes_per_step': beside,
+                    'crossover_plus_beside_GBps': (xo['bytes'] / max(xo['launches'], 1) + beside)
+                    / (lms * 1e-3) / 1e9,
+                    'frac': (xo['bytes'] / max(xo['launches'], 1) + beside) / (lms * 1e-3) / 1e9 / peak}
         if phases is not None:
             out['tile_phase_ms_per_step'] = phases
         if alone is not None:
