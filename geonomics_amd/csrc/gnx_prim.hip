@@ -218,40 +218,55 @@ __global__ void __launch_bounds__(1024)
 k_block_scan(int K, int nb, int stride, const int32_t* __restrict__ cnt, int32_t* __restrict__ off,
              int32_t* __restrict__ out, int64_t* __restrict__ host, long long seq,
              const int32_t* __restrict__ extra) {
-  __shared__ int wsum[16];
-  __shared__ int carry_s;
+  // all K (<= 3) arrays in one sweep: two barriers per 1024 blocks instead of three per array
+  __shared__ int wsum[3][16];
+  __shared__ int carry_s[3];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int totals[3] = {0, 0, 0};
-  for (int k = 0; k < K; ++k) {
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (int b0 = 0; b0 < nb; b0 += 1024) {
-      const int b = b0 + tid;
-      const int v = b < nb ? cnt[k * stride + b] : 0;
-      int x = v;                                  // inclusive scan inside the wave
+  if (tid < 3) carry_s[tid] = 0;
+  __syncthreads();
+  for (int b0 = 0; b0 < nb; b0 += 1024) {
+    const int b = b0 + tid;
+    int v[3], x[3];
 #pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const int y = __shfl_up(x, d);
-        if (lane >= d) x += y;
-      }
-      if (lane == 63) wsum[wave] = x;
-      __syncthreads();
-      int woff = 0;
-      for (int w = 0; w < wave; ++w) woff += wsum[w];
-      const int carry = carry_s;
-      if (b < nb) off[k * stride + b] = carry + woff + x - v;
-      __syncthreads();
-      if (tid == 1023) carry_s = carry + woff + x;
-      __syncthreads();
+    for (int k = 0; k < 3; ++k) {
+      v[k] = (k < K && b < nb) ? cnt[k * stride + b] : 0;
+      x[k] = v[k];
     }
-    totals[k] = carry_s;
-    if (tid == 0) off[k * stride + nb] = carry_s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int y = __shfl_up(x[k], d);
+        if (lane >= d) x[k] += y;
+      }
+    }
+    if (lane == 63) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) wsum[k][wave] = x[k];
+    }
+    __syncthreads();
+    int tot[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      int woff = 0, t = 0;
+      for (int w = 0; w < 16; ++w) {
+        const int s = wsum[k][w];
+        woff += w < wave ? s : 0;
+        t += s;
+      }
+      tot[k] = t;
+      if (k < K && b < nb) off[k * stride + b] = carry_s[k] + woff + x[k] - v[k];
+    }
+    __syncthreads();
+    if (tid < 3) carry_s[tid] += tot[tid];
     __syncthreads();
   }
   if (tid == 0) {
     for (int k = 0; k < 3; ++k) {
-      if (out) out[k] = totals[k];
-      if (host) host[k] = totals[k];
+      const int total = k < K ? carry_s[k] : 0;
+      if (k < K) off[k * stride + nb] = total;
+      if (out) out[k] = total;
+      if (host) host[k] = total;
     }
     if (host && extra) host[12] = (int64_t)*extra;    // one more word for the host
     // a host that polls host[3] for `seq` (gnx_wait_published) sees the totals first
