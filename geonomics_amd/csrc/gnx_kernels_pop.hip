@@ -176,7 +176,11 @@ __device__ __forceinline__ float surf_sample(const float n[8], int mode, float k
     } else {
       pick = min(7, (int)(u * 8.0f));
     }
-    loc = c_queen_dirs[pick];
+    // (a select chain: a __constant__ table indexed per lane is read by a scalar loop over the
+    // wave's distinct indices)
+    loc = c_queen_dirs[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) loc = (pick == k) ? c_queen_dirs[k] : loc;
   } else {
     float acc = 0.f;
     int cnt = 0;
@@ -216,20 +220,38 @@ __device__ __forceinline__ bool surf_neighbours_lds(const float* rast, int W, in
     box[3] = -1;
   }
   __syncthreads();
-  if (act) {
-    atomicMin(&box[0], cx);
-    atomicMax(&box[1], cx);
-    atomicMin(&box[2], cy);
-    atomicMax(&box[3], cy);
+  {
+    // the wave's own bounding box by shuffles, then ONE lane per wave touches the LDS words
+    // (256 lanes on four LDS words serialise: that, not the tile, was the surface's cost)
+    int lx = act ? cx : 0x7fffffff, hx = act ? cx : -1, ly = act ? cy : 0x7fffffff, hy = act ? cy : -1;
+    lx = wave_min_i(lx);
+    hx = wave_max_i(hx);
+    ly = wave_min_i(ly);
+    hy = wave_max_i(hy);
+    if ((threadIdx.x & 63) == 0 && hx >= 0) {
+      atomicMin(&box[0], lx);
+      atomicMax(&box[1], hx);
+      atomicMin(&box[2], ly);
+      atomicMax(&box[3], hy);
+    }
   }
   __syncthreads();
   const int x0 = box[0] - 1, x1 = box[1] + 1, y0 = box[2] - 1, y1 = box[3] + 1;
   const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
   if (box[1] < 0 || (int64_t)bw * bh > tile_floats) return false;   // block-uniform
-  for (int t = threadIdx.x; t < bw * bh; t += blockDim.x) {
-    int ty = t / bw, tx = t - ty * bw;
-    int yy = y0 + ty, xx = x0 + tx;
-    tile[t] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? rast[(int64_t)yy * W + xx] : 0.f;
+  // a wave per window row, lanes along it: coalesced row reads and no index division (the
+  // flat t / bw form cost ~300 vector instructions per wave, PMC SQ_INSTS_VALU)
+  {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    for (int ty = wave; ty < bh; ty += n_waves) {
+      const int yy = y0 + ty;
+      const bool row_in = yy >= 0 && yy < H;
+      const float* src = rast + (int64_t)(row_in ? yy : 0) * W;
+      for (int tx = lane; tx < bw; tx += 64) {
+        const int xx = x0 + tx;
+        tile[ty * bw + tx] = (row_in && xx >= 0 && xx < W) ? src[xx] : 0.f;
+      }
+    }
   }
   __syncthreads();
   if (act) {

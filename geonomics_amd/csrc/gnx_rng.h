@@ -99,7 +99,13 @@ __device__ __forceinline__ float gnx_vonmises(GnxStream& s, float mu, float kapp
   res += mu;
   bool neg = res < 0.0f;
   float m = fabsf(res);
-  m = fmodf(m + GNX_PI_F, 2.0f * GNX_PI_F) - GNX_PI_F;
+  // (fmodf(m + pi, 2 pi) - pi: m + pi < 4 pi unless |mu| is huge, and t - 2 pi is exact for t in
+  // [2 pi, 4 pi) (Sterbenz), i.e. the same bits as fmodf without its division loop)
+  float t = m + GNX_PI_F;
+  const float two_pi = 2.0f * GNX_PI_F;
+  if (t >= 2.0f * two_pi) t = fmodf(t, two_pi);
+  else if (t >= two_pi) t -= two_pi;
+  m = t - GNX_PI_F;
   return neg ? -m : m;
 }
 
