@@ -1068,9 +1068,9 @@ k_xo_jobs_fused(int64_t N, int64_t first, int32_t* __restrict__ grow,
       pe[p][2 * q + 1] = v.y;
     }
   }
-  int32_t fresh[2 * NB];
-#pragma unroll
-  for (int q = 0; q < 2 * NB; ++q) fresh[q] = q < cf ? H.stack[pop - q] : 0;
+  // (the fresh blocks are read where they are needed, ~2 per offspring: holding 2 NB of them
+  // in registers and picking with a select chain cost (2 NB)^2 selects per thread - PMC:
+  // 4 300 vector instructions per wave at NB = 14)
   // stage 7: my table (NB 8-byte stores), the jobs, and the parents' blocks that are shared
   // from now on lose their never-shared flag (only the first child to share one writes)
   int32_t ce[2 * NB];
@@ -1082,9 +1082,7 @@ k_xo_jobs_fused(int64_t N, int64_t first, int32_t* __restrict__ grow,
     for (int q = 0; q < NB; ++q) {
       int32_t v;
       if ((mixed[p] >> q) & 1u) {
-        int32_t dst = 0;
-#pragma unroll
-        for (int z = 0; z < 2 * NB; ++z) dst = (z == fr) ? fresh[z] : dst;
+        const int32_t dst = H.stack[pop - fr];
         v = (int32_t)((uint32_t)dst | GNX_OWN);
         if (local) {
           GnxXoJob j;
@@ -1094,24 +1092,30 @@ k_xo_jobs_fused(int64_t N, int64_t first, int32_t* __restrict__ grow,
           j.ks = (key[p] * 2 + st[p]) | (q << 24);
           jobs[job + jr] = j;
           // the switch points inside this block ride with the job (gnx_xo.h: GnxJobBp)
-          GnxJobBp ib;
-          ib.bp[0] = ib.bp[1] = ib.bp[2] = 0;
+          // (scalars and range compares: a record indexed by a running count lands in LDS, and
+          // a division per switch point is 20 instructions)
+          unsigned int o0 = 0, o1 = 0, o2 = 0;
           int nin = 0;
           if (bp_off) {
             const int lpb = H.BW * 64;
+            const int lo = q * lpb, hi = (q == NB - 1) ? 0x7fffffff : lo + lpb;
             for (int z = b0[p]; z < b1[p]; ++z) {
               const int l = bp_loci[z];
-              if (min(l / lpb, NB - 1) == q) {
-                if (nin < 3) ib.bp[nin] = (uint16_t)(l - q * lpb);
+              if (l >= lo && l < hi) {
+                const unsigned int o = (unsigned int)(l - lo);
+                o0 = nin == 0 ? o : o0;
+                o1 = nin == 1 ? o : o1;
+                o2 = nin == 2 ? o : o2;
                 ++nin;
               }
             }
           }
           // (offsets are 16 bits: a block of more than 65 536 loci looks its path up)
           const bool inl = bp_off != nullptr && nin <= 3 && H.BW * 64 <= 65536;
-          ib.meta = (uint16_t)((inl ? nin : 0) | (((sel[p] >> q) & 1u) << 2) |
-                               (inl ? 0u : GNX_BP_MORE));
-          jobs_bp[job + jr] = ib;
+          const unsigned int meta = (inl ? (unsigned int)nin : 0u) | (((sel[p] >> q) & 1u) << 2) |
+                                    (inl ? 0u : GNX_BP_MORE);
+          *(uint2*)(jobs_bp + job + jr) = make_uint2((o0 & 0xffffu) | (o1 << 16),
+                                                     (o2 & 0xffffu) | (meta << 16));
           ++jr;
         }
         ++fr;
