@@ -1007,18 +1007,51 @@ k_xo_jobs_fused(int64_t N, int64_t first, int32_t* __restrict__ grow,
     b0[p] = bp_off ? bp_off[key[p]] : 0;
     b1[p] = bp_off ? bp_off[key[p] + 1] : 0;
   }
-  // stage 4: which blocks hold a switch point
+  // stage 4: which blocks hold a switch point.  The first four switch points of each path are
+  // loaded once into registers (stage 7 looks them up again, block by block), and the block of
+  // a locus comes from a float reciprocal with an exact correction (loci < 2^24) instead of an
+  // integer division
   const unsigned int all = (1u << NB) - 1u;
+  const int lpb = H.BW * 64;
+  const float inv_lpb = 1.0f / (float)lpb;
+  auto blk_of = [&](int l) {
+    int q = (int)((float)l * inv_lpb);
+    q -= (q * lpb > l) ? 1 : 0;
+    q += ((q + 1) * lpb <= l) ? 1 : 0;
+    return min(q, NB - 1);
+  };
   unsigned int mixed[2], sel[2];
+  int32_t bl[2][4];
+  int nbp[2];
   int cf = 0, cj = 0;
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     if (!fx) prow[p] = -1;
+    nbp[p] = (bp_off && prow[p] >= 0) ? b1[p] - b0[p] : 0;
+#pragma unroll
+    for (int z = 0; z < 4; ++z) bl[p][z] = z < nbp[p] ? bp_loci[b0[p] + z] : 0;
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
     mixed[p] = all;                              // dense masks, ghost parent: cut everything
     sel[p] = 0u;
-    if (fx && prow[p] >= 0 && bp_off)
-      gnx_block_masks(bp_loci + b0[p], b1[p] - b0[p], st[p], NB, H.BW, mixed[p], sel[p]);
-    mixed[p] &= all;
+    if (fx && prow[p] >= 0 && bp_off) {
+      unsigned int mx = 0u, sl = st[p] ? all : 0u;
+#pragma unroll
+      for (int z = 0; z < 4; ++z)
+        if (z < nbp[p]) {
+          const int blk = blk_of(bl[p][z]);
+          mx |= 1u << blk;
+          sl ^= all & ~((2u << blk) - 1u);        // every later block starts on the other homologue
+        }
+      for (int z = 4; z < nbp[p]; ++z) {
+        const int blk = blk_of(bp_loci[b0[p] + z]);
+        mx |= 1u << blk;
+        sl ^= all & ~((2u << blk) - 1u);
+      }
+      mixed[p] = mx;
+      sel[p] = sl & all;
+    }
     if (fx) {
       const int nf = __popc(mixed[p]);
       cf += nf;
@@ -1056,7 +1089,10 @@ k_xo_jobs_fused(int64_t N, int64_t first, int32_t* __restrict__ grow,
   if (!fx) return;
   const int pop = s_pop - 1 - of;                  // stack index of my first fresh block
   const int job = s_job + oj;
-  // stage 6: the parents' table entries (2 x NB each, 8-byte loads) and my fresh blocks
+  // stage 6: the parents' table entries (2 x NB each, 8-byte loads) and my first six fresh
+  // blocks, all issued before anything is used.  (All 2 NB fresh blocks in registers cost a
+  // (2 NB)^2 select chain - PMC: 4 300 vector instructions per wave at NB = 14; one load per
+  // block inside stage 7 put a memory round trip into each of its 2 NB iterations.)
   int32_t pe[2][2 * NB];                           // [parent][hom * NB + q]
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
@@ -1068,69 +1104,95 @@ k_xo_jobs_fused(int64_t N, int64_t first, int32_t* __restrict__ grow,
       pe[p][2 * q + 1] = v.y;
     }
   }
-  // (the fresh blocks are read where they are needed, ~2 per offspring: holding 2 NB of them
-  // in registers and picking with a select chain cost (2 NB)^2 selects per thread - PMC:
-  // 4 300 vector instructions per wave at NB = 14)
-  // stage 7: my table (NB 8-byte stores), the jobs, and the parents' blocks that are shared
-  // from now on lose their never-shared flag (only the first child to share one writes)
+  constexpr int NF = 6;
+  // (six scalars, not an array: the compiler turns a select chain over an array captured by
+  // reference into an indexed load from scratch)
+  const int32_t f0 = 0 < cf ? H.stack[pop] : 0, f1 = 1 < cf ? H.stack[pop - 1] : 0,
+                f2 = 2 < cf ? H.stack[pop - 2] : 0, f3 = 3 < cf ? H.stack[pop - 3] : 0,
+                f4 = 4 < cf ? H.stack[pop - 4] : 0, f5 = 5 < cf ? H.stack[pop - 5] : 0;
+  const int32_t* stack = H.stack;
+  auto fresh_at = [=](int fr) {
+    int32_t d = f0;
+    d = fr == 1 ? f1 : d;
+    d = fr == 2 ? f2 : d;
+    d = fr == 3 ? f3 : d;
+    d = fr == 4 ? f4 : d;
+    d = fr == 5 ? f5 : d;
+    if (fr >= NF) d = stack[pop - fr];
+    return d;
+  };
+  // stage 7a: my table (NB 8-byte stores); the parents' blocks that are shared from now on
+  // lose their never-shared flag (only the first child to share one writes).  Branch-free but
+  // for the stores: every wave has some lane on either side of every block.
   int32_t ce[2 * NB];
-  int fr = 0, jr = 0;
+  int fr = 0;
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
-    const bool local = prow[p] >= 0;
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
-      int32_t v;
-      if ((mixed[p] >> q) & 1u) {
-        const int32_t dst = H.stack[pop - fr];
-        v = (int32_t)((uint32_t)dst | GNX_OWN);
-        if (local) {
-          GnxXoJob j;
-          j.ph0 = GNX_BLK(pe[p][q]);
-          j.ph1 = GNX_BLK(pe[p][NB + q]);
-          j.dst = dst;
-          j.ks = (key[p] * 2 + st[p]) | (q << 24);
-          jobs[job + jr] = j;
-          // the switch points inside this block ride with the job (gnx_xo.h: GnxJobBp)
-          // (scalars and range compares: a record indexed by a running count lands in LDS, and
-          // a division per switch point is 20 instructions)
-          unsigned int o0 = 0, o1 = 0, o2 = 0;
-          int nin = 0;
-          if (bp_off) {
-            const int lpb = H.BW * 64;
-            const int lo = q * lpb, hi = (q == NB - 1) ? 0x7fffffff : lo + lpb;
-            for (int z = b0[p]; z < b1[p]; ++z) {
-              const int l = bp_loci[z];
-              if (l >= lo && l < hi) {
-                const unsigned int o = (unsigned int)(l - lo);
-                o0 = nin == 0 ? o : o0;
-                o1 = nin == 1 ? o : o1;
-                o2 = nin == 2 ? o : o2;
-                ++nin;
-              }
-            }
-          }
-          // (offsets are 16 bits: a block of more than 65 536 loci looks its path up)
-          const bool inl = bp_off != nullptr && nin <= 3 && H.BW * 64 <= 65536;
-          const unsigned int meta = (inl ? (unsigned int)nin : 0u) | (((sel[p] >> q) & 1u) << 2) |
-                                    (inl ? 0u : GNX_BP_MORE);
-          *(uint2*)(jobs_bp + job + jr) = make_uint2((o0 & 0xffffu) | (o1 << 16),
-                                                     (o2 & 0xffffu) | (meta << 16));
-          ++jr;
-        }
-        ++fr;
-      } else {
-        const int hsel = (sel[p] >> q) & 1u;
-        const int32_t pv = hsel ? pe[p][NB + q] : pe[p][q];
-        v = GNX_BLK(pv);
-        if (pv < 0) H.hmap[((int64_t)prow[p] * 2 + hsel) * NB + q] = v;
-      }
-      ce[p * NB + q] = v;
+      const bool cut = ((mixed[p] >> q) & 1u) != 0u;
+      const int hsel = (sel[p] >> q) & 1u;
+      const int32_t pv = hsel ? pe[p][NB + q] : pe[p][q];
+      const int32_t sv = GNX_BLK(pv);
+      if (!cut && pv < 0) H.hmap[((int64_t)prow[p] * 2 + hsel) * NB + q] = sv;
+      const int32_t fv = (int32_t)((uint32_t)fresh_at(cut ? fr : 0) | GNX_OWN);
+      ce[p * NB + q] = cut ? fv : sv;
+      fr += cut ? 1 : 0;
     }
   }
   int2* dstp = (int2*)(H.hmap + (int64_t)row * 2 * NB);
 #pragma unroll
   for (int q = 0; q < NB; ++q) dstp[q] = make_int2(ce[2 * q], ce[2 * q + 1]);
+  // stage 7b: one job per cut block of a local parent, walking the set bits (about two per
+  // homologue) rather than all 2 NB blocks; the switch points inside the block ride with the
+  // job (gnx_xo.h: GnxJobBp), taken from the registers of stage 4
+  int jr = 0;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    if (prow[p] < 0) continue;
+    const int fbase = p ? __popc(mixed[0]) : 0;
+    unsigned int m = mixed[p];
+    while (m) {
+      const int q = __ffs(m) - 1;
+      m &= m - 1u;
+      const int32_t dst = fresh_at(fbase + __popc(mixed[p] & ((1u << q) - 1u)));
+      int32_t e0 = pe[p][0], e1 = pe[p][NB];
+#pragma unroll
+      for (int q2 = 1; q2 < NB; ++q2) {
+        e0 = q == q2 ? pe[p][q2] : e0;
+        e1 = q == q2 ? pe[p][NB + q2] : e1;
+      }
+      GnxXoJob j;
+      j.ph0 = GNX_BLK(e0);
+      j.ph1 = GNX_BLK(e1);
+      j.dst = dst;
+      j.ks = (key[p] * 2 + st[p]) | (q << 24);
+      jobs[job + jr] = j;
+      unsigned int o0 = 0, o1 = 0, o2 = 0;
+      int nin = 0;
+      const int lo = q * lpb, hi = (q == NB - 1) ? 0x7fffffff : lo + lpb;
+      auto take = [&](int l) {
+        if (l >= lo && l < hi) {
+          const unsigned int o = (unsigned int)(l - lo);
+          o0 = nin == 0 ? o : o0;
+          o1 = nin == 1 ? o : o1;
+          o2 = nin == 2 ? o : o2;
+          ++nin;
+        }
+      };
+#pragma unroll
+      for (int z = 0; z < 4; ++z)
+        if (z < nbp[p]) take(bl[p][z]);
+      for (int z = 4; z < nbp[p]; ++z) take(bp_loci[b0[p] + z]);
+      // (offsets are 16 bits: a block of more than 65 536 loci looks its path up)
+      const bool inl = bp_off != nullptr && nin <= 3 && lpb <= 65536;
+      const unsigned int meta = (inl ? (unsigned int)nin : 0u) | (((sel[p] >> q) & 1u) << 2) |
+                                (inl ? 0u : GNX_BP_MORE);
+      *(uint2*)(jobs_bp + job + jr) = make_uint2((o0 & 0xffffu) | (o1 << 16),
+                                                 (o2 & 0xffffu) | (meta << 16));
+      ++jr;
+    }
+  }
 }
 
 template <int NB>
