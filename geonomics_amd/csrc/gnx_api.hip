@@ -337,7 +337,12 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
     GNXCHK(dalloc(&h->valk[k], cap));
   }
   GNXCHK(dalloc(&h->newslot, cap));
-  HIPCHK(hipMalloc(&h->os_scratch, gnx_os_scratch_bytes((size_t)cap, 24)));
+  {
+    // (zero between sorts: k_permute wipes what a sort dirtied; + 16: the wipe is in uint4s)
+    const size_t nb = gnx_os_scratch_bytes((size_t)cap, 24) + 16;
+    HIPCHK(hipMalloc(&h->os_scratch, nb));
+    HIPCHK(hipMemset(h->os_scratch, 0, nb));
+  }
   GNXCHK(dalloc(&h->os_ktmp, cap));
   GNXCHK(dalloc(&h->os_vtmp, cap));
   GNXCHK(dalloc(&h->cell32, cap));

@@ -516,6 +516,13 @@ int gnx_block_scan(gnx_state* h, int K, int64_t n_items, const int32_t* cnt, int
                    const int32_t* extra = nullptr);
 // the step's cell sort over the id-ordered index: Onesweep with one fill (gnx_prim.hip)
 size_t gnx_os_scratch_bytes(size_t n, int end_bit);
+size_t gnx_os_words_used(size_t n, int end_bit);
+int gnx_os_keys_hist(void* scratch, unsigned int* ticket, int64_t N, int64_t ord_n,
+                     const int32_t* ord, const uint32_t* cell32, uint32_t* key, int32_t* val,
+                     int end_bit, hipStream_t s);
+int gnx_os_sort32_ranked(void* scratch, uint32_t* ktmp, int32_t* vtmp, const uint32_t* kin,
+                         uint32_t* kout, const int32_t* vin, int32_t* vout, size_t n, int end_bit,
+                         hipStream_t s);
 int gnx_os_sort32(void* scratch, uint32_t* ktmp, int32_t* vtmp, const uint32_t* kin,
                   uint32_t* kout, const int32_t* vin, int32_t* vout, size_t n, int end_bit,
                   hipStream_t s, int variant);

@@ -435,8 +435,13 @@ __global__ void k_permute(int64_t N, int64_t cap, const int32_t* perm, GnxSoA a,
                           uint32_t* tag, uint4* cand, uint64_t* key, int idbits,
                           int32_t* cell_start, int ncells, const uint32_t* __restrict__ cellk,
                           const int32_t* __restrict__ ord, int64_t ord_n,
-                          int32_t* __restrict__ ord_new, int32_t* __restrict__ perm_out) {
+                          int32_t* __restrict__ ord_new, int32_t* __restrict__ perm_out,
+                          uint4* __restrict__ wipe, int64_t wipe_n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // the radix sort's scratch (histograms, look-back states) is zero again for the next sort:
+  // no fill kernels in front of it (two, 6 us each, on the step's critical path)
+  for (int64_t w = i; w < wipe_n; w += (int64_t)gridDim.x * blockDim.x)
+    wipe[w] = make_uint4(0u, 0u, 0u, 0u);
   if (i >= N) return;
   // sorted (cell << idbits | id) keys with the slots as values, or - the sort ran over the
   // id-ordered index - sorted cells (cellk) with id ranks as values
@@ -510,6 +515,7 @@ int gnx_l_sort_by_cell(gnx_state* h) {
   const bool alone = h->xo_sort_waits || !h->xo_running;
   const bool ordm = h->tile_evict > 0 ? false : (h->keys_fresh ? h->keys_ordmode : gnx_ord_sort(h));
   gnx_time_begin(h);
+  int64_t wipe_words = 0;       // of os_scratch, dirtied by this sort
   if (ordm) {
     // stable sort of the id-ordered index by cell alone (gnx_internal.h)
     if (!h->keys_fresh)
@@ -519,15 +525,28 @@ int gnx_l_sort_by_cell(gnx_state* h) {
       HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ord, 0));
       h->ord_inflight = false;
     }
+    static const int os_variant = getenv("GNX_OS_SORT") ? atoi(getenv("GNX_OS_SORT")) : 2;
+    static const bool os_fused = !getenv("GNX_OS_FUSED") || atoi(getenv("GNX_OS_FUSED")) != 0;
+    if (os_variant == 2 && os_fused && h->key_bits <= 24) {
+      // keys, histograms and their scans in one launch, then the two or three passes; the
+      // scratch is zero on entry (allocation, k_permute below)
+      GNXCHK(gnx_os_keys_hist(h->os_scratch, h->tickets + 3, N, h->ord_n, h->ord[h->ord_cur],
+                              h->cell32, h->keyk[0], h->valk[0], h->key_bits, h->stream));
+      GNXCHK(gnx_os_sort32_ranked(h->os_scratch, h->os_ktmp, h->os_vtmp, h->keyk[0], h->keyk[1],
+                                  h->valk[0], h->valk[1], (size_t)N, h->key_bits, h->stream));
+      wipe_words = (int64_t)gnx_os_words_used((size_t)N, h->key_bits);
+    } else {
     hipLaunchKernelGGL(k_keys_ord, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, h->ord_n,
                        h->ord[h->ord_cur], h->cell32, h->keyk[0], h->valk[0]);
-    static const int os_variant = getenv("GNX_OS_SORT") ? atoi(getenv("GNX_OS_SORT")) : 2;
-    if (os_variant >= 0 && h->key_bits <= 24)
+    if (os_variant >= 0 && h->key_bits <= 24) {
+      wipe_words = (int64_t)(gnx_os_scratch_bytes((size_t)N, h->key_bits) / 4);
       GNXCHK(gnx_os_sort32(h->os_scratch, h->os_ktmp, h->os_vtmp, h->keyk[0], h->keyk[1],
                            h->valk[0], h->valk[1], (size_t)N, h->key_bits, h->stream, os_variant));
-    else
+    } else {
       GNXCHK(gnx_prim_sort32_bits(h->sort64_tmp, h->sort64_tmp_bytes, h->keyk[0], h->keyk[1],
                                   h->valk[0], h->valk[1], (size_t)N, h->key_bits, h->stream, alone));
+    }
+    }
   } else {
     int cell_bits = h->key_bits;
     if (h->tile_evict > 0) {
@@ -553,7 +572,7 @@ int gnx_l_sort_by_cell(gnx_state* h) {
                      a.tb ? 2 * h->TW : 0, gnx_pair_seed(c.seed, h->step), h->tag, (uint4*)h->cand,
                      h->key64[1], idbits, h->cell_start, h->ncx * h->ncy,
                      ordm ? h->keyk[1] : nullptr, h->ord[h->ord_cur], h->ord_n,
-                     h->ord[h->ord_cur ^ 1], h->perm[1]);
+                     h->ord[h->ord_cur ^ 1], h->perm[1], (uint4*)h->os_scratch, (wipe_words + 3) / 4);
   gnx_time_end(h, GNX_K_PERMUTE,
                (double)N * 2.0 * (33.0 + 4.0 * c.n_layers + 4.0 * c.n_traits + 16.0 * h->TW));
   // the individuals' density bins (positions are final for this step): counted on stream3,

@@ -190,7 +190,131 @@ static int sort(void* scratch, uint32_t* ktmp, int32_t* vtmp, const uint32_t* ki
   HIPCHK(hipGetLastError());
   return 0;
 }
+// Keys of the id-ordered sequence (entry k is slot ord[k] for k < ord_n, else slot k itself:
+// offspring appended since the index was last compacted), their digit histograms and - in the
+// workgroup that finishes last (ticket) - the exclusive scans of the histograms, i.e. what
+// k_keys_ord + k_hist + k_scan left behind, in one launch.  hist: [places][2^RB], zero on
+// entry (the caller keeps the scratch clean: k_permute wipes it after every sort).
+// The counts travel as agent-scope atomics that have completed (s_waitcnt) before the ticket
+// is taken; no release fence (gnx_compact.h: that is an L2 write-back).
+template <unsigned RB, unsigned IPT>
+__global__ void __launch_bounds__(1024)
+k_keys_hist(long long N, long long ord_n, const int32_t* __restrict__ ord,
+            const uint32_t* __restrict__ cell32, uint32_t* __restrict__ key,
+            int32_t* __restrict__ val, unsigned int* __restrict__ hist, int places,
+            unsigned int* __restrict__ ticket) {
+  constexpr unsigned R = 1u << RB;
+  static_assert(R == 1024, "one digit per thread");
+  __shared__ unsigned int lh[3][R];
+  __shared__ unsigned int wsum[16];
+  __shared__ int last;
+  const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int pl = 0; pl < places; ++pl) lh[pl][tid] = 0u;
+  __syncthreads();
+  const long long base = (long long)blockIdx.x * (1024 * IPT);
+  int32_t slot[IPT];
+  uint32_t c[IPT];
+#pragma unroll
+  for (unsigned r = 0; r < IPT; ++r) {
+    const long long k = base + r * 1024 + tid;
+    slot[r] = k < N ? (k < ord_n ? ord[k] : (int32_t)k) : -1;
+  }
+#pragma unroll
+  for (unsigned r = 0; r < IPT; ++r) c[r] = slot[r] >= 0 ? cell32[slot[r]] : 0u;
+#pragma unroll
+  for (unsigned r = 0; r < IPT; ++r) {
+    const long long k = base + r * 1024 + tid;
+    if (slot[r] < 0) continue;
+    key[k] = c[r];
+    val[k] = (int32_t)k;
+    for (int pl = 0; pl < places; ++pl) atomicAdd(&lh[pl][(c[r] >> (pl * RB)) & (R - 1u)], 1u);
+  }
+  __syncthreads();
+  for (int pl = 0; pl < places; ++pl) {
+    const unsigned int v = lh[pl][tid];
+    if (v) __hip_atomic_fetch_add(&hist[pl * R + tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = t == gridDim.x - 1u;
+    if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!last) return;
+  for (int pl = 0; pl < places; ++pl) {
+    const unsigned int v = __hip_atomic_load(&hist[pl * R + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned int y = __shfl_up(x, d);
+      if (lane >= (unsigned)d) x += y;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    unsigned int woff = 0;
+    for (unsigned w = 0; w < 16; ++w) woff += w < wave ? wsum[w] : 0u;
+    hist[pl * R + tid] = woff + x - v;
+  }
+}
+
+// the passes alone: histograms already counted and scanned in `scratch` (k_keys_hist), the
+// rest of it zero
+template <unsigned BS, unsigned IPT, unsigned RB>
+static int sort_ranked(void* scratch, uint32_t* ktmp, int32_t* vtmp, const uint32_t* kin,
+                       uint32_t* kout, const int32_t* vin, int32_t* vout, size_t n, int end_bit,
+                       hipStream_t s) {
+  const unsigned int places = (end_bit + RB - 1) / RB, radix = 1u << RB;
+  const unsigned int items = BS * IPT;
+  const unsigned int blocks = (unsigned int)((n + items - 1) / items);
+  const unsigned int full_blocks = (unsigned int)(n / items);
+  unsigned int* hist = (unsigned int*)scratch;
+  unsigned int* offs_tmp = hist + (size_t)places * radix;
+  lookback_t* lb = (lookback_t*)(offs_tmp + radix);
+  unsigned int* bid = (unsigned int*)(lb + (size_t)places * blocks * radix);
+  bool to_output = (places - 1) % 2 == 0;
+  const uint32_t* ki = kin;
+  const int32_t* vi = vin;
+  for (unsigned int place = 0, bit = 0; place < places; ++place, bit += RB) {
+    uint32_t* ko = to_output ? kout : ktmp;
+    int32_t* vo = to_output ? vout : vtmp;
+    const unsigned int cur = std::min<unsigned int>(RB, (unsigned int)end_bit - bit);
+    hipLaunchKernelGGL((k_iter<BS, IPT, RB>), dim3(blocks), dim3(BS), 0, s, ki, ko, vi, vo,
+                       (unsigned int)n, hist + (size_t)place * radix, offs_tmp,
+                       lb + (size_t)place * blocks * radix, bit, cur, full_blocks,
+                       obid_t::create(bid + place));
+    ki = ko;
+    vi = vo;
+    to_output = !to_output;
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
 }  // namespace gnx_os
+
+// the fused front of the cell sort (variant 2's geometry: 1024 x 6 keys, 10-bit digits)
+size_t gnx_os_words_used(size_t n, int end_bit) {
+  return gnx_os::scratch_words<1024, 6, 10>(n, end_bit);
+}
+int gnx_os_keys_hist(void* scratch, unsigned int* ticket, int64_t N, int64_t ord_n,
+                     const int32_t* ord, const uint32_t* cell32, uint32_t* key, int32_t* val,
+                     int end_bit, hipStream_t s) {
+  const int places = (end_bit + 9) / 10;
+  if (places > 3) return 1;
+  // (2, 3, 4, 8 keys per thread instead of 6: the same step time, profiles/r03_ab_runs.txt)
+  const unsigned int blocks = (unsigned int)((N + 6143) / 6144);
+  hipLaunchKernelGGL((gnx_os::k_keys_hist<10, 6>), dim3(blocks), dim3(1024), 0, s, (long long)N,
+                     (long long)ord_n, ord, cell32, key, val, (unsigned int*)scratch, places, ticket);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int gnx_os_sort32_ranked(void* scratch, uint32_t* ktmp, int32_t* vtmp, const uint32_t* kin,
+                         uint32_t* kout, const int32_t* vin, int32_t* vout, size_t n, int end_bit,
+                         hipStream_t s) {
+  return gnx_os::sort_ranked<1024, 6, 10>(scratch, ktmp, vtmp, kin, kout, vin, vout, n, end_bit, s);
+}
 
 // variant 0: 256 threads x 12 keys, 8-bit digits; 1: 512 x 8, 8 bits; 2: 1024 x 6, 10 bits
 size_t gnx_os_scratch_bytes(size_t n, int end_bit) {
