@@ -41,7 +41,25 @@ static hipEvent_t timer_event(gnx_state* h) {
   return e;
 }
 
+// GNX_HOST_TIMES=1: where the host's time goes (printed by gnx_destroy): in gnx_step as a
+// whole, and of that waiting for device counts
+double g_host_step_s = 0.0, g_host_wait_s = 0.0;
+long long g_host_steps = 0;
+bool gnx_host_times() {
+  static const bool on = getenv("GNX_HOST_TIMES") && atoi(getenv("GNX_HOST_TIMES")) != 0;
+  return on;
+}
+struct GnxHostWait {
+  std::chrono::steady_clock::time_point t0;
+  GnxHostWait() { if (gnx_host_times()) t0 = std::chrono::steady_clock::now(); }
+  ~GnxHostWait() {
+    if (gnx_host_times())
+      g_host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+};
+
 int gnx_wait_published(gnx_state* h, int slot, int64_t seq) {
+  GnxHostWait hw;
   volatile int64_t* word = h->h_pin + slot + 3;
   static const bool poll = !(getenv("GNX_POLL") && atoi(getenv("GNX_POLL")) == 0);
   if (!poll) {
@@ -337,6 +355,8 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
     GNXCHK(dalloc(&h->valk[k], cap));
   }
   GNXCHK(dalloc(&h->newslot, cap));
+  GNXCHK(dalloc(&h->fill_cnt, 4));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_fill, hipEventDisableTiming));
   {
     // (zero between sorts: k_permute wipes what a sort dirtied; + 16: the wipe is in uint4s)
     const size_t nb = gnx_os_scratch_bytes((size_t)cap, 24) + 16;
@@ -430,6 +450,9 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
 
 extern "C" void gnx_destroy(gnx_state* h) {
   if (!h) return;
+  if (gnx_host_times() && g_host_steps > 0)
+    fprintf(stderr, "[gnx host times] %lld steps: %.1f us/step in gnx_step, %.1f us of it waiting for counts\n",
+            g_host_steps, 1e6 * g_host_step_s / g_host_steps, 1e6 * g_host_wait_s / g_host_steps);
   (void)gnx_xo_launch_pending(h);
   (void)hipStreamSynchronize(h->stream);
   if (h->stream2) (void)hipStreamSynchronize(h->stream2);
@@ -449,7 +472,7 @@ extern "C" void gnx_destroy(gnx_state* h) {
     (void)hipFree(h->perm[k]);
     (void)hipFree(h->counts_rast[k]);
   }
-  void* ptrs[] = {h->os_scratch, h->os_ktmp, h->os_vtmp, h->ord[0], h->ord[1], h->keyk[0], h->keyk[1], h->valk[0], h->valk[1], h->newslot, h->cell32, h->ord_cnt, h->ord_off, h->xo_plan, h->gc_cnt, h->gc_off, h->half_mark, h->hmap, h->half_free, h->half_top, h->xo_jobs_acc, h->rast, h->G, h->free_rows, h->paths, h->bp_off, h->bp_loci, h->dom,
+  void* ptrs[] = {h->os_scratch, h->os_ktmp, h->os_vtmp, h->fill_cnt, h->ord[0], h->ord[1], h->keyk[0], h->keyk[1], h->valk[0], h->valk[1], h->newslot, h->cell32, h->ord_cnt, h->ord_off, h->xo_plan, h->gc_cnt, h->gc_off, h->half_mark, h->hmap, h->half_free, h->half_top, h->xo_jobs_acc, h->rast, h->G, h->free_rows, h->paths, h->bp_off, h->bp_loci, h->dom,
                   h->delet_loci, h->delet_s, h->cell_start, h->tag, h->cand, h->sort64_tmp, h->key64[0], h->key64[1], h->pairs2,
                   h->pair_goff, h->st_rec, h->st_z, h->st_geno, h->st_slots, h->req_pid, h->req_k, h->req_key, h->req_start, h->req_px, h->req_py,
                   h->req_count, h->sort_tmp, h->scan_tmp, h->mate,
@@ -480,6 +503,7 @@ extern "C" void gnx_destroy(gnx_state* h) {
   }
   if (h->ev_ord) (void)hipEventDestroy(h->ev_ord);
   if (h->ev_compact) (void)hipEventDestroy(h->ev_compact);
+  if (h->ev_fill) (void)hipEventDestroy(h->ev_fill);
   if (h->ev_pairs) (void)hipEventDestroy(h->ev_pairs);
   if (h->ev_latP) (void)hipEventDestroy(h->ev_latP);
   if (h->ev_perm) (void)hipEventDestroy(h->ev_perm);
@@ -1027,6 +1051,15 @@ extern "C" int gnx_pop_dynamics(gnx_state* h, int32_t burn, int32_t with_selecti
 
 extern "C" int gnx_step(gnx_state* h, int32_t burn, int32_t with_selection) {
   GNXCHK(need_params(h));
+  struct T {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~T() {
+      if (gnx_host_times()) {
+        g_host_step_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        ++g_host_steps;
+      }
+    }
+  } timer;
   if (h->sp.move) {
     h->move_writes_keys = h->sp.mating_radius >= 0;     // the cell sort follows at once
     int rc = gnx_l_move(h, true, nullptr, nullptr, nullptr, nullptr, true);

@@ -339,6 +339,9 @@ struct gnx_state {
   int ord_cur = 0;
   int32_t* ord[2]{};
   int32_t* newslot = nullptr;    // [cap] where the last compaction put each slot (-1: dead)
+  int32_t* fill_cnt = nullptr;   // in-place compaction: the number of movers (device)
+  hipEvent_t ev_fill = nullptr;  // its hole / mover lists are written (stream3)
+  int64_t fill_guess = 0;        // slots the last mortality round emptied (sizes k_fill's grid)
   uint32_t* cell32 = nullptr;    // [cap] hash cell of each slot (k_move / k_keys)
   uint32_t* keyk[2]{};           // cells in id order / sorted
   int32_t* valk[2]{};            // id ranks in id order / sorted
@@ -515,6 +518,8 @@ int gnx_block_scan(gnx_state* h, int K, int64_t n_items, const int32_t* cnt, int
                    int32_t* out, int64_t* host, int64_t seq = 0, hipStream_t st = nullptr,
                    const int32_t* extra = nullptr);
 // the step's cell sort over the id-ordered index: Onesweep with one fill (gnx_prim.hip)
+extern double g_host_step_s, g_host_wait_s;      // GNX_HOST_TIMES=1 (gnx_api.hip)
+bool gnx_host_times();
 size_t gnx_os_scratch_bytes(size_t n, int end_bit);
 size_t gnx_os_words_used(size_t n, int end_bit);
 int gnx_os_keys_hist(void* scratch, unsigned int* ticket, int64_t N, int64_t ord_n,

@@ -11,6 +11,7 @@
 // the natural bicubic spline through the same nodes (tolerance: DESIGN.md).
 // All density arithmetic is f64 so it matches the numpy oracle to ~1e-12.
 #include "gnx_internal.h"
+#include <chrono>
 #include "gnx_rng.h"
 #include "gnx_compact.h"
 #include "gnx_half.h"
@@ -1254,6 +1255,106 @@ k_compact(int64_t N, int64_t cap, const int32_t* alive, const int32_t* dead_row,
   }
 }
 
+// In-place compaction (one device, no tiles): the survivors of the tail [S, N) - S = the number
+// of survivors; the tail is mostly this step's offspring - move into the holes the dead left in
+// [0, S); everybody else stays where it is.  About 2 x deaths records move instead of every
+// survivor (k_compact copies the whole population to the other buffer: 262 MB a step on the
+// metric workload, 53 us on the step's critical chain).  Slot order means nothing between a
+// compaction and the next cell sort: every draw is keyed by id, the sort runs over the
+// id-ordered index (which follows through newslot), offspring ids follow the pair keys.
+//   k_fill_lists (stream3, beside the crossover's job builder): holes and movers in slot order
+//     (hole r takes mover r), newslot of everybody who stays or dies, the dead's genome rows
+//   k_fill: the moves, the movers' newslot, the rows onto the free stack (the job builder
+//     has popped its rows from the same stretch by then)
+__global__ void __launch_bounds__(256)
+k_fill_lists(int64_t N, const int32_t* __restrict__ alive, const int32_t* __restrict__ dead_row,
+             const int32_t* __restrict__ blk_off, int stride, const int32_t* __restrict__ cnts,
+             const int32_t* __restrict__ grow, int has_rows, int32_t* __restrict__ holes,
+             int32_t* __restrict__ movers, int32_t* __restrict__ rows_tmp,
+             int32_t* __restrict__ newslot, int32_t* __restrict__ n_move) {
+  __shared__ int lds[16];
+  __shared__ int sb_s[4];
+  const int64_t S = cnts[0];
+  const int64_t base = (int64_t)blockIdx.x * GNX_CB;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  bool fa[4], fd[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    fa[r] = i < N && (alive[i] & 1) != 0;
+    fd[r] = i < N && dead_row[i] != 0;
+  }
+  int ra[4], rd[4], ta, td;
+  gnx_block_ranks(fa, ra, ta, lds);
+  gnx_block_ranks(fd, rd, td, lds);
+  const int32_t oa = blk_off[blockIdx.x], od = blk_off[stride + blockIdx.x];
+  // the survivors before slot S (blocks that reach into the tail; uniform per block)
+  int sb = 0;
+  if (base + GNX_CB > S && S < N) {
+    const int64_t bS = S / GNX_CB;
+    const int within = (int)(S - bS * GNX_CB);
+    int c = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int q = r * 256 + threadIdx.x;
+      c += __popcll(__ballot(q < within && (alive[bS * GNX_CB + q] & 1) != 0));
+    }
+    if (lane == 0) sb_s[wave] = c;
+    __syncthreads();
+    sb = blk_off[bS] + sb_s[0] + sb_s[1] + sb_s[2] + sb_s[3];
+  }
+  if (threadIdx.x == 0 && blockIdx.x == (unsigned int)min((long long)(S / GNX_CB), (long long)gridDim.x - 1))
+    *n_move = S < N ? (int32_t)(S - sb) : 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    if (i >= N) continue;
+    const int k = oa + ra[r];                       // survivors before i
+    if (fa[r]) {
+      if (i < S) {
+        if (newslot) newslot[i] = (int32_t)i;
+      } else {
+        movers[k - sb] = (int32_t)i;                // (newslot: k_fill)
+      }
+    } else {
+      if (newslot) newslot[i] = -1;
+      if (i < S) holes[i - k] = (int32_t)i;
+    }
+    if (has_rows && fd[r]) rows_tmp[od + rd[r]] = grow[i];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_fill(int64_t cap, const int32_t* __restrict__ n_move, const int32_t* __restrict__ holes,
+       const int32_t* __restrict__ movers, const int32_t* __restrict__ cnts, GnxSoA a, int n_layers,
+       int n_traits, int tbw, const int32_t* __restrict__ rows_tmp, int32_t* __restrict__ free_rows,
+       int64_t n_free, int has_rows, int xo, int32_t* __restrict__ newslot) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t H = *n_move;
+  for (int64_t r = t0; r < H; r += stride) {
+    const int64_t i = movers[r], k = holes[r];
+    if (newslot) newslot[i] = (int32_t)k;
+    a.x[k] = a.x[i];
+    a.y[k] = a.y[i];
+    a.age[k] = a.age[i];
+    a.sex[k] = a.sex[i];
+    a.id[k] = a.id[i];
+    a.fit[k] = a.fit[i];
+    a.grow[k] = a.grow[i];
+    a.ghost[k] = 0;
+    for (int l = 0; l < n_layers; ++l) a.e[(int64_t)l * cap + k] = a.e[(int64_t)l * cap + i];
+    for (int t = 0; t < n_traits; ++t) a.z[(int64_t)t * cap + k] = a.z[(int64_t)t * cap + i];
+    for (int w = 0; w < tbw; ++w) a.tb[k * tbw + w] = a.tb[i * tbw + w];
+  }
+  if (has_rows) {
+    // deferred crossover: the surviving offspring have just popped one row each from the top
+    if (xo) n_free -= cnts[2];
+    const int64_t D = cnts[1];
+    for (int64_t r = t0; r < D; r += stride) free_rows[n_free + r] = rows_tmp[r];
+  }
+}
+
 void gnx_launch_xo_jobs_surv(gnx_state* h, int64_t first_slot, const int32_t* d_alive,
                              const int32_t* d_blk_off, int buf) {
   const int64_t N = h->N;
@@ -1369,6 +1470,21 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
   // enqueues the next step's first kernels while the compaction still runs
   HIPCHK(hipEventRecord(h->ev_counts, h->stream));
   int has_rows = (h->genomes_assigned && c.L > 0) ? 1 : 0;
+  // in-place compaction (k_fill_lists above): its lists are made on stream3 while this stream
+  // builds the crossover's jobs
+  static const bool fill_env = !(getenv("GNX_COMPACT_FILL") && atoi(getenv("GNX_COMPACT_FILL")) == 0);
+  // (a caller that names the dead by position - gnx_op_mortality - gets the survivors back in
+  // their order: the stable compaction)
+  const bool fill = fill_env && !h->tiled && h->stream3 != nullptr && h->n_ghost == 0 &&
+                    d_dead_inject == nullptr;
+  if (fill) {
+    HIPCHK(hipStreamWaitEvent(h->stream3, h->ev_counts, 0));
+    hipLaunchKernelGGL(k_fill_lists, dim3(nb), dim3(256), 0, h->stream3, N, h->flag, h->flag2,
+                       h->blk_off, h->blk_stride, h->cnt_dev, a.grow, has_rows,
+                       (int32_t*)h->os_ktmp, (int32_t*)h->os_ktmp + c.cap_inds / 2,
+                       (int32_t*)h->os_vtmp, ord_keep ? h->newslot : nullptr, h->fill_cnt);
+    HIPCHK(hipEventRecord(h->ev_fill, h->stream3));
+  }
   // deferred crossover of this step's births: rows and jobs for the survivors, the kernel
   // itself on stream2 (it runs on under the compaction and the next step's movement)
   if (xo) {
@@ -1380,12 +1496,25 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
   // no cell sort has waited for it in between (gnx_op_mortality right after a step)
   if (ord_keep && h->ord_inflight) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ord, 0));
   gnx_time_begin(h);
+  const double rec_bytes = 34.0 + 4.0 * c.n_layers + 4.0 * c.n_traits + 16.0 * h->TW;
+  if (fill) {
+    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_fill, 0));
+    const int64_t guess = std::max<int64_t>(h->fill_guess * 2, 4096);      // (grid-stride: any count)
+    const int fb_ = (int)std::min<int64_t>(gnx_grid(std::min<int64_t>(guess, N), 256), 8192);
+    hipLaunchKernelGGL(k_fill, dim3(fb_), dim3(256), 0, h->stream, c.cap_inds, h->fill_cnt,
+                       (const int32_t*)h->os_ktmp, (const int32_t*)h->os_ktmp + c.cap_inds / 2,
+                       h->cnt_dev, a, c.n_layers, c.n_traits, a.tb ? 2 * h->TW : 0,
+                       (const int32_t*)h->os_vtmp, h->free_rows, h->n_free, has_rows, xo ? 1 : 0,
+                       ord_keep ? h->newslot : nullptr);
+    // flags and offsets of everybody, the records of about as many movers as the last round had deaths
+    gnx_time_end(h, GNX_K_COMPACT, (double)N * 16.0 + (double)h->fill_guess * (16.0 + 2.0 * rec_bytes));
+  } else {
   hipLaunchKernelGGL(k_compact, dim3(nb), dim3(256), 0, h->stream, N, c.cap_inds, h->flag,
                      h->flag2, h->blk_off, h->blk_stride, h->cnt_dev, a, b, c.n_layers, c.n_traits,
                      a.tb ? 2 * h->TW : 0, h->free_rows, h->n_free, has_rows, xo ? 1 : 0,
                      ord_keep ? h->newslot : nullptr);
-  gnx_time_end(h, GNX_K_COMPACT, (double)N * (24.0 + 2.0 * (34.0 + 4.0 * c.n_layers +
-                                                             4.0 * c.n_traits + 16.0 * h->TW)));
+  gnx_time_end(h, GNX_K_COMPACT, (double)N * (24.0 + 2.0 * rec_bytes));
+  }
   if (ord_keep) {
     HIPCHK(hipEventRecord(h->ev_compact, h->stream));
     HIPCHK(hipStreamWaitEvent(h->stream3, h->ev_compact, 0));
@@ -1403,7 +1532,12 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
   }
   HIPCHK(hipGetLastError());
   if (xo && h->xo_sort_waits && h->xo_wait_at == 3) GNXCHK(gnx_xo_wait_inflight(h));
-  HIPCHK(hipEventSynchronize(h->ev_counts));
+  {
+    const bool ht = gnx_host_times();
+    const auto t0 = std::chrono::steady_clock::now();
+    HIPCHK(hipEventSynchronize(h->ev_counts));
+    if (ht) g_host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
   const int64_t survivors = h->h_pin[0];
   const int64_t rows_freed = h->h_pin[1];
   if (xo) {
@@ -1413,9 +1547,10 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
   }
   if (has_rows) h->n_free += rows_freed;
   *deaths_out = N - h->n_ghost - survivors;       // ghosts are dropped, not counted
+  h->fill_guess = N - survivors;
   h->N = survivors;
   h->n_ghost = 0;
-  h->cur ^= 1;
+  if (!fill) h->cur ^= 1;
   if (ord_keep) h->ord_n = survivors;
   return 0;
 }

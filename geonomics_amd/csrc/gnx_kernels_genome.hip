@@ -475,7 +475,8 @@ int gnx_l_phenotype(gnx_state* h, int64_t first_slot, int64_t n) {
 // decisions IS the u64 genome word (row of individual q/2, homologue q%2).
 __global__ void __launch_bounds__(256)
 k_assign_genomes(int64_t N, int L, int W64, u64* G, const int32_t* grow, GnxHalves H,
-                 const int32_t* n_per_site, unsigned long long site_seed) {
+                 const int32_t* n_per_site, unsigned long long site_seed,
+                 const int32_t* __restrict__ order) {
   const int lane = threadIdx.x & 63;
   const int64_t word = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (word >= W64) return;          // uniform per wave
@@ -491,8 +492,16 @@ k_assign_genomes(int64_t N, int L, int W64, u64* G, const int32_t* grow, GnxHalv
     }
     remaining -= take ? 1 : 0;
     u64 w = __ballot(take);
-    if (lane == 0) G[gnx_word_at(H, (int64_t)grow[q >> 1] * 2 + (q & 1), (int)word)] = w;
+    // homologue q belongs to the (q / 2)-th individual in ID order (the order the reference
+    // walks its individuals in, structs/genome.py:1132-1133): slot order means nothing
+    const int64_t slot = order ? order[q >> 1] : (q >> 1);
+    if (lane == 0) G[gnx_word_at(H, (int64_t)grow[slot] * 2 + (q & 1), (int)word)] = w;
   }
+}
+
+__global__ void k_iota32(int64_t N, int32_t* v) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) v[i] = (int32_t)i;
 }
 
 __global__ void k_assign_rows(int64_t N, int64_t cap_rows, int spread, int32_t* grow,
@@ -532,10 +541,21 @@ int gnx_l_assign_genomes(gnx_state* h, const int32_t* d_n_per_site) {
   h->n_free = c.cap_rows - N;
   h->half_free_est = 2 * (int64_t)h->NB * (c.cap_rows - N);
   if (N > 0 && d_n_per_site) {
+    // the slots in id order (a tile keeps its slot order: its stepper assigns by global rank)
+    const int32_t* order = nullptr;
+    if (!h->tiled) {
+      int idbits = 1;
+      while (idbits < 40 && (h->max_id >> idbits) != 0) ++idbits;
+      hipLaunchKernelGGL(k_iota32, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, h->perm[0]);
+      GNXCHK(gnx_prim_sort64_bits(h->sort64_tmp, h->sort64_tmp_bytes, (const uint64_t*)s.id,
+                                  h->key64[0], h->perm[0], h->os_vtmp, (size_t)N, idbits,
+                                  h->stream, true));
+      order = h->os_vtmp;
+    }
     int64_t threads = (int64_t)h->W64 * 64;
     hipLaunchKernelGGL(k_assign_genomes, dim3(gnx_grid(threads, 256)), dim3(256), 0, h->stream, N,
                        c.L, h->W64, (u64*)h->G, s.grow, gnx_halves(h), d_n_per_site,
-                       gnx_site_seed(c.seed));
+                       gnx_site_seed(c.seed), order);
   }
   HIPCHK(hipGetLastError());
   h->genomes_assigned = true;

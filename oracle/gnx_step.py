@@ -99,7 +99,13 @@ class State:
         self._set_z(np.arange(self.N))
 
     def assign_genomes(self, n_per_site):
-        self.set_genomes(O.starting_genomes(self.N, self.L, n_per_site, self.seed))
+        # the k-th genome drawn goes to the individual with the k-th smallest id: the order
+        # the reference walks its individuals in (a dict in insertion = id order,
+        # structs/genome.py:1132-1133), whatever order the slots are in
+        g = O.starting_genomes(self.N, self.L, n_per_site, self.seed)
+        out = np.empty_like(g)
+        out[np.argsort(self.id, kind='stable')] = g
+        self.set_genomes(out)
 
     def _set_z(self, idx):
         for t, tr in enumerate(self.traits):
