@@ -76,6 +76,69 @@ struct GnxSoA {
   uint64_t* tb;
 };
 
+// One individual's record in registers.  The kernels that move records (k_permute,
+// k_compact, k_fill) load ALL of it before they store any of it: written column by column
+// (b.x[k] = a.x[i]; b.y[k] = a.y[i]; ...) every load waits for the store before it - the
+// compiler cannot know that the two views never overlap - and a thread makes a dozen
+// dependent memory round trips instead of one.  Up to 4 layers, 4 traits and 4 words of the
+// selected-locus table ride in registers; more than that is copied by gnx_rec_rest.
+struct GnxRec {
+  float x, y, fit;
+  int32_t age, grow;
+  int64_t id;
+  uint8_t sex, ghost;
+  float e[4], z[4];
+  uint64_t tb[4];
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ GnxRec gnx_rec_load(const GnxSoA& a, int64_t i, int64_t cap, int nl,
+                                               int nt, int tbw) {
+  GnxRec r;
+  r.x = a.x[i];
+  r.y = a.y[i];
+  r.age = a.age[i];
+  r.sex = a.sex[i];
+  r.id = a.id[i];
+  r.fit = a.fit[i];
+  r.grow = a.grow[i];
+  r.ghost = a.ghost[i];
+#pragma unroll
+  for (int l = 0; l < 4; ++l) r.e[l] = l < nl ? a.e[(int64_t)l * cap + i] : 0.0f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) r.z[t] = t < nt ? a.z[(int64_t)t * cap + i] : 0.0f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) r.tb[w] = w < tbw ? a.tb[i * tbw + w] : 0ull;
+  return r;
+}
+__device__ __forceinline__ void gnx_rec_store(const GnxSoA& b, int64_t k, int64_t cap, int nl, int nt,
+                                              int tbw, const GnxRec& r) {
+  b.x[k] = r.x;
+  b.y[k] = r.y;
+  b.age[k] = r.age;
+  b.sex[k] = r.sex;
+  b.id[k] = r.id;
+  b.fit[k] = r.fit;
+  b.grow[k] = r.grow;
+  b.ghost[k] = r.ghost;
+#pragma unroll
+  for (int l = 0; l < 4; ++l)
+    if (l < nl) b.e[(int64_t)l * cap + k] = r.e[l];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    if (t < nt) b.z[(int64_t)t * cap + k] = r.z[t];
+#pragma unroll
+  for (int w = 0; w < 4; ++w)
+    if (w < tbw) b.tb[k * tbw + w] = r.tb[w];
+}
+// layers, traits and table words beyond the four that GnxRec holds
+__device__ __forceinline__ void gnx_rec_rest(const GnxSoA& a, int64_t i, const GnxSoA& b, int64_t k,
+                                             int64_t cap, int nl, int nt, int tbw) {
+  for (int l = 4; l < nl; ++l) b.e[(int64_t)l * cap + k] = a.e[(int64_t)l * cap + i];
+  for (int t = 4; t < nt; ++t) b.z[(int64_t)t * cap + k] = a.z[(int64_t)t * cap + i];
+  for (int w = 4; w < tbw; ++w) b.tb[k * tbw + w] = a.tb[i * tbw + w];
+}
+#endif
+
 // Density lattice (utils/spatial.py _DensityGridStack restated)
 struct GnxLattice {
   int Jx = 0, Jy = 0;     // nodes per axis

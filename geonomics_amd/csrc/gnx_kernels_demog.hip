@@ -1238,17 +1238,10 @@ k_compact(int64_t N, int64_t cap, const int32_t* alive, const int32_t* dead_row,
     if (newslot && i < N) newslot[i] = fa[r] ? oa + ra[r] : -1;   // for the id-ordered index
     if (fa[r]) {
       const int64_t k = oa + ra[r];            // survivors before i
-      b.x[k] = a.x[i];
-      b.y[k] = a.y[i];
-      b.age[k] = a.age[i];
-      b.sex[k] = a.sex[i];
-      b.id[k] = a.id[i];
-      b.fit[k] = a.fit[i];
-      b.grow[k] = a.grow[i];
-      b.ghost[k] = 0;
-      for (int l = 0; l < n_layers; ++l) b.e[(int64_t)l * cap + k] = a.e[(int64_t)l * cap + i];
-      for (int t = 0; t < n_traits; ++t) b.z[(int64_t)t * cap + k] = a.z[(int64_t)t * cap + i];
-      for (int w = 0; w < tbw; ++w) b.tb[k * tbw + w] = a.tb[i * tbw + w];
+      GnxRec rec = gnx_rec_load(a, i, cap, n_layers, n_traits, tbw);
+      rec.ghost = 0;
+      gnx_rec_store(b, k, cap, n_layers, n_traits, tbw, rec);
+      gnx_rec_rest(a, i, b, k, cap, n_layers, n_traits, tbw);
     } else if (has_rows && fd[r]) {
       free_rows[n_free + od + rd[r]] = a.grow[i];
     }
@@ -1334,18 +1327,11 @@ k_fill(int64_t cap, const int32_t* __restrict__ n_move, const int32_t* __restric
   const int64_t H = *n_move;
   for (int64_t r = t0; r < H; r += stride) {
     const int64_t i = movers[r], k = holes[r];
+    GnxRec rec = gnx_rec_load(a, i, cap, n_layers, n_traits, tbw);
+    rec.ghost = 0;
     if (newslot) newslot[i] = (int32_t)k;
-    a.x[k] = a.x[i];
-    a.y[k] = a.y[i];
-    a.age[k] = a.age[i];
-    a.sex[k] = a.sex[i];
-    a.id[k] = a.id[i];
-    a.fit[k] = a.fit[i];
-    a.grow[k] = a.grow[i];
-    a.ghost[k] = 0;
-    for (int l = 0; l < n_layers; ++l) a.e[(int64_t)l * cap + k] = a.e[(int64_t)l * cap + i];
-    for (int t = 0; t < n_traits; ++t) a.z[(int64_t)t * cap + k] = a.z[(int64_t)t * cap + i];
-    for (int w = 0; w < tbw; ++w) a.tb[k * tbw + w] = a.tb[i * tbw + w];
+    gnx_rec_store(a, k, cap, n_layers, n_traits, tbw, rec);
+    gnx_rec_rest(a, i, a, k, cap, n_layers, n_traits, tbw);
   }
   if (has_rows) {
     // deferred crossover: the surviving offspring have just popped one row each from the top

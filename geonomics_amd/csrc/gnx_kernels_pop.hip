@@ -460,24 +460,16 @@ __global__ void k_permute(int64_t N, int64_t cap, const int32_t* perm, GnxSoA a,
     ord_new[kk] = (int32_t)i;                   // and the slot it is in now
     perm_out[i] = (int32_t)j;                   // (the sort permutation, as the other path leaves it)
   }
-  const float px = a.x[j], py = a.y[j];
-  b.x[i] = px;
-  b.y[i] = py;
-  b.age[i] = a.age[j];
-  b.sex[i] = a.sex[j];
-  const int64_t idv = a.id[j];
-  b.id[i] = idv;
-  if (cellk) key[i] = ((uint64_t)cellk[i] << idbits) | (uint64_t)idv;   // what the pair list reads
-  const uint32_t tg = gnx_ind_tag(pair_seed, (unsigned long long)idv);
+  // the whole record in registers before the first store (GnxRec, gnx_internal.h)
+  const GnxRec r = gnx_rec_load(a, j, cap, n_layers, n_traits, tbw);       // tbw = 2 * TW
+  const uint32_t ck = cellk ? cellk[i] : 0u;
+  gnx_rec_store(b, i, cap, n_layers, n_traits, tbw, r);
+  if (cellk) key[i] = ((uint64_t)ck << idbits) | (uint64_t)r.id;   // what the pair list reads
+  const uint32_t tg = gnx_ind_tag(pair_seed, (unsigned long long)r.id);
   tag[i] = tg;
   // packed candidate record for the mate search: one 16-byte load per candidate
-  cand[i] = make_uint4(__float_as_uint(px), __float_as_uint(py), tg, (uint32_t)idv);
-  b.fit[i] = a.fit[j];
-  b.grow[i] = a.grow[j];
-  b.ghost[i] = a.ghost[j];
-  for (int l = 0; l < n_layers; ++l) b.e[(int64_t)l * cap + i] = a.e[(int64_t)l * cap + j];
-  for (int t = 0; t < n_traits; ++t) b.z[(int64_t)t * cap + i] = a.z[(int64_t)t * cap + j];
-  for (int w = 0; w < tbw; ++w) b.tb[i * tbw + w] = a.tb[j * tbw + w];     // tbw = 2 * TW
+  cand[i] = make_uint4(__float_as_uint(r.x), __float_as_uint(r.y), tg, (uint32_t)r.id);
+  gnx_rec_rest(a, j, b, i, cap, n_layers, n_traits, tbw);
 }
 
 __global__ void k_cells(int64_t N, const float* x, const float* y, double inv_cs, int ncx, int ncy,
@@ -1304,6 +1296,29 @@ k_offspring(OffP P, GnxSoA s, const float* rast, const int32_t* pairs, const int
   unsigned long long oid = (unsigned long long)(P.id_base + gk);
   float mx = (s.x[i] + s.x[m]) / 2.0f;
   float my = (s.y[i] + s.y[m]) / 2.0f;
+  // the draws that do not depend on the position, and - one GPU, at most 128 selected loci -
+  // the parents' alleles at the selected loci and the two paths' homologue choices there:
+  // loaded now, beside the dispersal's own chain of dependent loads, used at the end
+  const uint4 r = gnx_rand4(P.seed, oid, P.step, OP_OFFSPRING, 0);
+  const uint8_t st0 = (uint8_t)(r.x & 1u), st1 = (uint8_t)((r.x >> 1) & 1u);
+  const int32_t k0 = (int32_t)(((unsigned long long)r.y * (unsigned long long)P.n_paths) >> 32);
+  const int32_t k1 = (int32_t)(((unsigned long long)r.z * (unsigned long long)P.n_paths) >> 32);
+  const bool tb_regs = P.genomes && P.fuse_tb && P.TW > 0 && P.TW <= 2;
+  uint64_t pi[4] = {0, 0, 0, 0}, pm[4] = {0, 0, 0, 0}, ps0[2] = {0, 0}, ps1[2] = {0, 0};
+  if (tb_regs) {
+    const uint64_t* ti = s.tb + (int64_t)i * 2 * P.TW;
+    const uint64_t* tm = s.tb + (int64_t)m * 2 * P.TW;
+    for (int w = 0; w < 2; ++w) {
+      if (w < P.TW) {
+        pi[w] = ti[w];
+        pi[2 + w] = ti[P.TW + w];
+        pm[w] = tm[w];
+        pm[2 + w] = tm[P.TW + w];
+        ps0[w] = P.path_sel[(int64_t)k0 * P.TW + w];
+        ps1[w] = P.path_sel[(int64_t)k1 * P.TW + w];
+      }
+    }
+  }
   float ox = mx, oy = my;
   for (int a = 0; a < GNX_DISP_ATTEMPTS; ++a) {
     float theta = 0.f;
@@ -1317,7 +1332,6 @@ k_offspring(OffP P, GnxSoA s, const float* rast, const int32_t* pairs, const int
     float dist = gnx_distance(P.distr, P.p1, P.p2, r);
     if (disperse_once(mx, my, theta, dist, P.rrx, P.rry, P.xmax, P.ymax, ox, oy)) break;
   }
-  uint4 r = gnx_rand4(P.seed, oid, P.step, OP_OFFSPRING, 0);
   // sex (structs/species.py:659-662 then structs/individual.py:110-115): a
   // drawn 0 is falsy in `if sex:` and is replaced by a Bernoulli(0.5) draw -
   // kept as is; unsexed species carry a Bernoulli(0.5) sex.
@@ -1345,9 +1359,6 @@ k_offspring(OffP P, GnxSoA s, const float* rast, const int32_t* pairs, const int
   if (P.genomes) {
     // start homologues ~ Bernoulli(.5) x2 (ops/mating.py:133); keys ~
     // randint(0, n_paths) x2 (structs/species.py:625)
-    const uint8_t st0 = (uint8_t)(r.x & 1u), st1 = (uint8_t)((r.x >> 1) & 1u);
-    const int32_t k0 = (int32_t)(((unsigned long long)r.y * (unsigned long long)P.n_paths) >> 32);
-    const int32_t k1 = (int32_t)(((unsigned long long)r.z * (unsigned long long)P.n_paths) >> 32);
     off_start[2 * k] = st0;
     off_start[2 * k + 1] = st1;
     off_keys[2 * k] = k0;
@@ -1361,7 +1372,22 @@ k_offspring(OffP P, GnxSoA s, const float* rast, const int32_t* pairs, const int
       rq.px[q] = s.x[m];
       rq.py[q] = s.y[m];
     }
-    if (P.fuse_tb) {
+    if (tb_regs) {
+      // (gnx_gamete_tb / gnx_phenotype_tb on the words loaded above)
+      uint64_t* t0 = s.tb + slot * 2 * P.TW;
+      uint64_t g0[2], g1[2];
+      const uint64_t s0 = st0 ? ~0ull : 0ull, s1 = st1 ? ~0ull : 0ull;
+      for (int w = 0; w < 2; ++w) {
+        const uint64_t m0 = ps0[w] ^ s0, m1 = ps1[w] ^ s1;
+        g0[w] = (pi[w] & ~m0) | (pi[2 + w] & m0);
+        g1[w] = (pm[w] & ~m1) | (pm[2 + w] & m1);
+        if (w < P.TW) {
+          t0[w] = g0[w];
+          t0[P.TW + w] = g1[w];
+        }
+      }
+      if (T.n_traits > 0) gnx_phenotype_words(g0[0], g0[1], g1[0], g1[1], T, P.dom, P.cap, slot, s.z);
+    } else if (P.fuse_tb) {
       uint64_t* t0 = s.tb + slot * 2 * P.TW;
       if (P.TW > 0) {
         gnx_gamete_tb(P.TW, s.tb + (int64_t)i * 2 * P.TW, P.path_sel + (int64_t)k0 * P.TW, st0 != 0,

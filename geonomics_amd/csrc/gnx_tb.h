@@ -39,3 +39,26 @@ __device__ __forceinline__ void gnx_phenotype_tb(const uint64_t* t0, const uint6
     z[(int64_t)t * cap + slot] = (float)(nl > 1 ? 0.5 + acc : g0);
   }
 }
+
+// the same from registers: the individual's homologues at the selected loci as at most two
+// words each (TW <= 2: up to 128 selected loci); identical arithmetic, no loads of the alleles
+__device__ __forceinline__ void gnx_phenotype_words(uint64_t t0a, uint64_t t0b, uint64_t t1a,
+                                                    uint64_t t1b, const GnxTraitTab& T,
+                                                    const uint8_t* dom, int64_t cap, int64_t slot,
+                                                    float* z) {
+  int e = 0;
+  for (int t = 0; t < T.n_traits; ++t) {
+    const int nl = T.n_loci[t];
+    double acc = 0.0, g0 = 0.0;
+    for (int j = 0; j < nl; ++j, ++e) {
+      const uint64_t w0 = (e >> 6) ? t0b : t0a, w1 = (e >> 6) ? t1b : t1a;
+      const int a = (int)((w0 >> (e & 63)) & 1ull);
+      const int b = (int)((w1 >> (e & 63)) & 1ull);
+      double gt = 0.5 * (double)(a + b);
+      if (dom) gt = fmin(gt * (1.0 + (double)dom[T.loci[t][j]]), 1.0);
+      if (j == 0) g0 = gt;
+      acc = acc + gt * T.alpha[t][j];
+    }
+    z[(int64_t)t * cap + slot] = (float)(nl > 1 ? 0.5 + acc : g0);
+  }
+}
