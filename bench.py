@@ -557,7 +557,7 @@ def main():
     if stepper is None:
         fam = kernel_profile(dev, do_step, 10)
     phases = None
-    if stepper is not None:
+    if stepper is not None and not os.environ.get('GNX_BENCH_NO_PHASES'):
         # per-phase host wall time of the tile protocol, from a few extra steps with a
         # device synchronisation at every phase mark (outside the timed region)
         stepper.profile = True

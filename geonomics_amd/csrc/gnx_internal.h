@@ -294,6 +294,7 @@ struct gnx_state {
   uint64_t* key64[2]{};          // 64-bit sort keys (focal ids of pairs; id -> slot lookups)
   int32_t* pairs2 = nullptr;     // pairs in ascending focal-id order
   int64_t* pair_goff = nullptr;  // tiled runs: global offspring offset of each local pair
+  bool pair_goff_local = false;   // tile2, one tile: offspring ids from the local pair offsets
   int64_t n_births_pending = 0;  // births of the current pair list
   // gamete requests (tiled runs)
   int64_t* req_pid = nullptr;
@@ -370,6 +371,7 @@ struct gnx_state {
   int32_t* bins_P = nullptr;         // ... of pair midpoints
   bool bins_zeroed[2]{};             // [0] individuals, [1] pairs: already cleared by k_lattice
   bool nmax_zeroed = false;          // nmax_bits already cleared by k_lattice
+  bool req_zeroed = false;           // req_count already cleared (tile2: k_tile2_zero)
   // The density path of one GPU without a counting pass (gnx_bins.h): the bins are counted
   // beside the step's serial chain - the adults on stream3 under the mate search, the pair
   // midpoints and their lattice on stream3 under k_offspring, the newborns by k_offspring

@@ -1536,11 +1536,12 @@ int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* 
       rq.px = h->req_px;
       rq.py = h->req_py;
       rq.count = h->req_count;
-      HIPCHK(hipMemsetAsync(h->req_count, 0, sizeof(int32_t), h->stream));
+      if (!h->req_zeroed) HIPCHK(hipMemsetAsync(h->req_count, 0, sizeof(int32_t), h->stream));
+      h->req_zeroed = false;
     }
     gnx_time_begin(h);
     hipLaunchKernelGGL(k_offspring, dim3(gnx_grid(B, 256)), dim3(256), 0, h->stream, Q, s, h->rast,
-                       h->pairs, h->off_pair, h->boff, tiled ? h->pair_goff : nullptr,
+                       h->pairs, h->off_pair, h->boff, (tiled && !h->pair_goff_local) ? h->pair_goff : nullptr,
                        h->off_parent, h->off_keys, h->off_start, rq, gnx_trait_tab(h));
     gnx_time_end(h, GNX_K_OFFSPRING, (double)B * (60.0 + 8.0 * c.n_layers + 48.0 * h->TW +
                                                   4.0 * c.n_traits));

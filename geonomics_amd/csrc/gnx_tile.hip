@@ -1283,6 +1283,30 @@ __global__ void k_publish_words(int n, const int32_t* src, int32_t* host, int se
   __hip_atomic_store(&host[2 * GNX_MAX_TILES + 7], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// the step's small accumulators in one launch instead of a fill kernel each: the deferred
+// checks, both density fields' bins with the four counter words behind them, the N.max()
+// word, the gamete-request counter
+__global__ void k_tile2_zero(int32_t* p0, int n0, int32_t* p1, int n1, int32_t* p2, int n2,
+                             int32_t* p3, int n3) {
+  const int stride = gridDim.x * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n1; i += stride) p1[i] = 0;
+  if (blockIdx.x == 0) {
+    if ((int)threadIdx.x < n0) p0[threadIdx.x] = 0;
+    if ((int)threadIdx.x < n2) p2[threadIdx.x] = 0;
+    if ((int)threadIdx.x < n3) p3[threadIdx.x] = 0;
+  }
+}
+
+// two groups of words for the host that needs no sequence number (a later wait covers them)
+__global__ void k_publish_words2(int n1, const int32_t* src1, int32_t* host1, int n2,
+                                 const int32_t* src2, int32_t* host2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int p = 0; p < n1; ++p)
+    __hip_atomic_store(&host1[p], src1[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  for (int p = 0; p < n2; ++p)
+    __hip_atomic_store(&host2[p], src2[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 static int tile2_buffers(gnx_state* h) {
   if (!h->route_cnt) {
     GNXCHK(dalloc_t(&h->route_cnt, (size_t)4 * GNX_MAX_TILES + 8));
@@ -1330,7 +1354,18 @@ extern "C" int gnx_tile2_move_route(gnx_state* h, int32_t move, int64_t* counts)
     return 1;
   }
   GNXCHK(tile2_buffers(h));
-  HIPCHK(hipMemsetAsync(h->chk, 0, 2 * sizeof(int64_t), h->stream));
+  {
+    // (everything that read last step's values ran before this on the same stream)
+    const int nb = h->lat.nbx * h->lat.nby;
+    const bool bins = h->have_sp && h->bin_partials != nullptr;
+    hipLaunchKernelGGL(k_tile2_zero, dim3(8), dim3(256), 0, h->stream, (int32_t*)h->chk, 4,
+                       bins ? h->bin_partials : nullptr, bins ? 2 * nb + 4 : 0,
+                       (int32_t*)h->nmax_bits, h->nmax_bits ? 2 : 0, h->req_count,
+                       h->req_count ? 1 : 0);
+    if (bins) h->bins_zeroed[0] = h->bins_zeroed[1] = true;
+    if (h->nmax_bits) h->nmax_zeroed = true;
+    h->req_zeroed = h->req_count != nullptr;
+  }
   if (move && h->sp.move)
     GNXCHK(gnx_l_move(h, true, nullptr, nullptr, nullptr, nullptr, true));
   else
@@ -1549,7 +1584,10 @@ extern "C" int gnx_tile2_offspring(gnx_state* h, int32_t burn, int64_t id_base,
   if (P > 0 && pair_goff_dev)
     HIPCHK(hipMemcpyAsync(h->pair_goff, pair_goff_dev, P * sizeof(int64_t),
                           hipMemcpyDeviceToDevice, h->stream));
+  // (no offsets handed in - one tile: the pairs' global offsets are their local ones)
+  h->pair_goff_local = pair_goff_dev == nullptr;
   int rc = gnx_l_mate(h, burn != 0, false, 0, &B, id_base, true);
+  h->pair_goff_local = false;
   h->n_req_known = -1;
   GNXCHK(rc);
   h->last_births = B;
@@ -1715,10 +1753,8 @@ extern "C" int gnx_tile2_die(gnx_state* h, int32_t burn, int32_t with_selection,
   const int64_t nb = (int64_t)h->lat.nbx * h->lat.nby;
   // the reduced counter words and the deferred checks ride to the host behind the
   // mortality's own wait (wait 3 of the step)
-  hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, h->stream, 4, h->bin_partials + 2 * nb,
-                     h->h_route_pin_dev, 0);
-  hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, h->stream, 4,
-                     (const int32_t*)h->chk, h->h_route_pin_dev + 8, 0);
+  hipLaunchKernelGGL(k_publish_words2, dim3(1), dim3(64), 0, h->stream, 4, h->bin_partials + 2 * nb,
+                     h->h_route_pin_dev, 4, (const int32_t*)h->chk, h->h_route_pin_dev + 8);
   if (have_pairs)
     GNXCHK(gnx_l_spline(h, h->bins_P, &h->spl_P, nullptr));
   else

@@ -747,17 +747,15 @@ class TiledStepper:
                     cum[1:] = torch.cumsum(all_nb[r], 0)
                     goff += cum[torch.searchsorted(li, mine)]
         else:
+            # one tile: the pairs' global offsets are their local ones (the library's own
+            # prefix sums), nothing to compute
             total_births, total_pairs = B, P
-            dev_t = torch.device('cuda')
-            if lam or not P:
-                goff = torch.arange(P, dtype=torch.int64, device=dev_t) * int(lam)
-            else:
-                self._lib_to_torch()
-                nb = dev_bytes(p_nb, P * 4).view(torch.int32).to(torch.int64)
-                goff = torch.cumsum(nb, 0) - nb
-        self._keep.append(goff)
-        self._torch_to_lib()
-        p_req = dev.tile2_offspring(burn, self.max_id + 1, goff.data_ptr() if P else 0)
+            goff = None
+        if goff is not None:
+            self._keep.append(goff)
+            self._torch_to_lib()
+        p_req = dev.tile2_offspring(burn, self.max_id + 1,
+                                    goff.data_ptr() if (P and goff is not None) else 0)
         self.max_id += total_births
         sh.set_max_id(self.max_id)
         self._tick('offspring')

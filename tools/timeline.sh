@@ -8,6 +8,7 @@ shift; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 export GNX_BENCH_NO_ALT=1
+export GNX_BENCH_NO_PHASES=1      # (the stepper's phase marks synchronise the device)
 for kv in "$@"; do export "$kv"; done
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
