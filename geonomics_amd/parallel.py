@@ -401,6 +401,7 @@ class TiledStepper:
         self.v2 = (hasattr(shard, 'dev') and os.environ.get('GNX_TILE_V2', '1') != '0' and
                    (comm.world == 1 or self.dev_transport))
         self._ext = None           # the library's stream as a torch stream
+        self._evcache = os.environ.get('GNX_TILE_EVCACHE', '1') != '0'
         self._keep = []            # tensors the library reads until the end of the step
         self._n_start = None       # global population at the start of the coming step
         self._pre = None           # global population before the last step's deaths
@@ -671,9 +672,17 @@ class TiledStepper:
         if not getattr(self.comm, 'stream_ordered', True):
             self.shard.dev.synchronize()
             return
+        # (one event per direction, recorded again at every hand-over: Stream.wait_stream makes
+        # a new event each time, 30 us of host time a call and ten calls a step)
         if self._ext is None:
             self._ext = torch.cuda.ExternalStream(self.shard.dev.stream_ptr())
-        torch.cuda.current_stream().wait_stream(self._ext)
+            self._ev_l2t = torch.cuda.Event()
+            self._ev_t2l = torch.cuda.Event()
+        if self._evcache:
+            self._ev_l2t.record(self._ext)
+            torch.cuda.current_stream().wait_event(self._ev_l2t)
+        else:
+            torch.cuda.current_stream().wait_stream(self._ext)
 
     def _torch_to_lib(self):
         """library work enqueued from here on sees what torch / RCCL have enqueued so far"""
@@ -683,7 +692,13 @@ class TiledStepper:
             return
         if self._ext is None:
             self._ext = torch.cuda.ExternalStream(self.shard.dev.stream_ptr())
-        self._ext.wait_stream(torch.cuda.current_stream())
+            self._ev_l2t = torch.cuda.Event()
+            self._ev_t2l = torch.cuda.Event()
+        if self._evcache:
+            self._ev_t2l.record(torch.cuda.current_stream())
+            self._ext.wait_event(self._ev_t2l)
+        else:
+            self._ext.wait_stream(torch.cuda.current_stream())
 
     def _step_v2(self, burn, with_selection, after_births, exact):
         import torch

@@ -49,6 +49,11 @@ def body(rank):
         hub.barrier.wait()
         t0 = time.perf_counter()
         check = int(os.environ.get('GNX_TILE_CHECK', '0'))      # block bookkeeping every k steps
+        prof = None
+        if rank == 0 and os.environ.get('GNX_TT_CPROFILE'):      # where rank 0's host time goes
+            import cProfile
+            prof = cProfile.Profile()
+            prof.enable()
         for k in range(steps):
             n = st.step(False, True, exact=False) if st.v2 else st.step(False, True)
             if check and (k + 1) % check == 0:
@@ -60,6 +65,10 @@ def body(rank):
                           '%d physical)' % (k + 1, n, 2 * rows, used), flush=True)
         dev.synchronize()
         dt = time.perf_counter() - t0
+        if prof is not None:
+            import pstats
+            prof.disable()
+            pstats.Stats(prof).sort_stats('tottime').print_stats(28)
         out[rank] = (dt / steps * 1e3, {k: v / steps * 1e3 for k, v in st.phase_s.items()},
                      st.bytes_sent / steps, n)
         dev.close()
