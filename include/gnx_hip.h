@@ -154,7 +154,9 @@ int gnx_set_deleterious(gnx_state* h, int32_t n, const int32_t* loci,
 int gnx_upload_genomes(gnx_state* h, const uint64_t* geno /*[N][2][W64]*/);
 /* Species._set_genomes_and_tables + _make_starting_mutations
  * (structs/species.py:956-967,1087; structs/genome.py:1108-1157):
- * exactly n_per_site[l] of the 2N homologues carry a 1 at site l.           */
+ * exactly n_per_site[l] of the 2N homologues carry a 1 at site l.  The k-th
+ * genome drawn goes to the individual with the k-th smallest id (the order the
+ * reference walks its individuals in), whatever order the slots are in.     */
 int gnx_assign_genomes(gnx_state* h, const int32_t* n_per_site /*[L]*/);
 /* recompute all phenotypes (Species._set_z, structs/species.py:925)         */
 int gnx_set_z(gnx_state* h);
@@ -277,7 +279,10 @@ int gnx_density_lattice_dims(gnx_state* h, int32_t* Jx, int32_t* Jy);
 int gnx_op_death_probs(gnx_state* h, int32_t with_selection,
                        const double* nodes_N, const double* nodes_pairs,
                        double* p_death, double* d_at_cell);
-/* ops/demography.py:175-180 with an injected death mask                     */
+/* ops/demography.py:175-180 with an injected death mask (by slot); the survivors
+ * keep their order.  (The mortality of gnx_step / gnx_pop_dynamics_die leaves the
+ * survivors of the first N - deaths slots where they are and moves the others
+ * into the slots of the dead: slot order carries no meaning between steps.) */
 int gnx_op_mortality(gnx_state* h, const uint8_t* dead);
 
 /* ---- spatial tiling over several GPUs ---------------------------

@@ -172,3 +172,44 @@ def test_id_ordered_index_sort_equals_full_sort(monkeypatch):
     assert a.counts()[0] > 1500
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize('W,radius', [(30, 1.0), (200, 1.0), (1500, 1.0)])
+def test_cell_sort_digit_places(W, radius):
+    """The cell sort's fused front (k_keys_hist: keys, digit histograms and their scans in
+    one launch; csrc/gnx_prim.hip) with one, two and three 10-bit digit places (900, 4*10^4
+    and 2.25*10^6 hash cells): the sorted population is in (cell, id) order - the oracle's
+    stable sort by cell of the id-ordered population - sort after sort (the scratch is wiped
+    by k_permute, not by a fill), with ids uploaded in arbitrary order."""
+    nat = native()
+    from test_gpu_parity import upload_simple
+    rng = np.random.RandomState(W)
+    n = 20000
+    ids = rng.permutation(n * 4)[:n].astype(np.int64)
+    x = (rng.rand(n) * W).astype(np.float32)
+    y = (rng.rand(n) * W).astype(np.float32)
+    x[:500] = x[500:1000]               # crowded cells
+    y[:500] = y[500:1000]
+    dev = make_dev(W, W, cap=32768, seed=3, mating_radius=radius)
+    upload_simple(dev, x, y, ids=ids)
+    cs = radius * (1.0 + 1e-9)
+    ncx = max(1, int(np.ceil(W / cs)))
+    inv_cs = 1.0 / cs                   # (the device multiplies by the reciprocal)
+    for rep in range(3):
+        dev.op_find_pairs(None)
+        got_id = dev.download(nat.F_ID)
+        gx, gy = dev.download(nat.F_X), dev.download(nat.F_Y)
+        cx = np.minimum(ncx - 1, (gx.astype(np.float64) * inv_cs).astype(np.int64))
+        cy = np.minimum(ncx - 1, (gy.astype(np.float64) * inv_cs).astype(np.int64))
+        cell = cy * ncx + cx
+        key = cell * (4 * n) + got_id
+        assert (np.diff(key) > 0).all(), (W, rep)
+        assert np.array_equal(np.sort(got_id), np.sort(ids))
+        o = np.argsort(ids)
+        np.testing.assert_array_equal(gx[np.argsort(got_id)], x[o])
+        if rep == 0:                    # some die in between: the index is compacted, then sorted again
+            dead = (got_id % 7 == 0).astype(np.uint8)
+            dev.op_mortality(dead)
+            keep = ~np.isin(ids, got_id[dead != 0])
+            ids, x, y = ids[keep], x[keep], y[keep]
+    dev.close()
