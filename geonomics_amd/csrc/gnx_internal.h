@@ -404,6 +404,7 @@ struct gnx_state {
   int ord_cur = 0;
   int32_t* ord[2]{};
   int32_t* newslot = nullptr;    // [cap] where the last compaction put each slot (-1: dead)
+  bool compact_fill = true;      // GNX_COMPACT_FILL=0 (read at gnx_create): always the stable copy
   int32_t* fill_cnt = nullptr;   // in-place compaction: the number of movers (device)
   hipEvent_t ev_fill = nullptr;  // its hole / mover lists are written (stream3)
   int64_t fill_guess = 0;        // slots the last mortality round emptied (sizes k_fill's grid)

@@ -1458,10 +1458,9 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
   int has_rows = (h->genomes_assigned && c.L > 0) ? 1 : 0;
   // in-place compaction (k_fill_lists above): its lists are made on stream3 while this stream
   // builds the crossover's jobs
-  static const bool fill_env = !(getenv("GNX_COMPACT_FILL") && atoi(getenv("GNX_COMPACT_FILL")) == 0);
   // (a caller that names the dead by position - gnx_op_mortality - gets the survivors back in
   // their order: the stable compaction)
-  const bool fill = fill_env && !h->tiled && h->stream3 != nullptr && h->n_ghost == 0 &&
+  const bool fill = h->compact_fill && !h->tiled && h->stream3 != nullptr && h->n_ghost == 0 &&
                     d_dead_inject == nullptr;
   if (fill) {
     HIPCHK(hipStreamWaitEvent(h->stream3, h->ev_counts, 0));

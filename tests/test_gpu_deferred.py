@@ -213,3 +213,56 @@ def test_cell_sort_digit_places(W, radius):
             keep = ~np.isin(ids, got_id[dead != 0])
             ids, x, y = ids[keep], x[keep], y[keep]
     dev.close()
+
+
+def test_in_place_compaction_equals_stable_copy(monkeypatch):
+    """Mortality's compaction in place (k_fill_lists + k_fill, csrc/gnx_kernels_demog.hip: the
+    survivors of the tail fill the holes of the dead) against the stable copy
+    (GNX_COMPACT_FILL=0): the same individuals with the same positions, ages, phenotypes and
+    genomes after 15 steps with deferred crossover, id by id - and NOT the same slots."""
+    nat = native()
+    from test_gpu_parity import upload_simple
+    W = H = 40
+    L = 900
+    rng = np.random.RandomState(21)
+    n = 3000
+    ids = rng.permutation(n * 3)[:n].astype(np.int64)
+    x = (rng.rand(n) * W).astype(np.float32)
+    y = (rng.rand(n) * H).astype(np.float32)
+    g = rng.randint(0, 2 ** 62, (n, 2, 16), dtype=np.int64).astype(np.uint64)
+    g[:, :, 15] = 0
+    g[:, :, 14] &= np.uint64((1 << (L - 14 * 64)) - 1)
+    paths = O.pack_bits(O.recomb_paths((rng.rand(64, L) < 0.002).astype(np.uint8) *
+                                       (np.arange(L) > 0)))
+    rasts = np.stack([np.ones((H, W)), np.tile(np.linspace(0, 1, W), (H, 1))]).astype(np.float32)
+    devs = []
+    for flag in ('1', '0'):
+        monkeypatch.setenv('GNX_COMPACT_FILL', flag)
+        dev = make_dev(W, H, rasts=rasts, L=L, n_traits=1, cap=16384, seed=8, mating_radius=3.0,
+                       K_factor=1.9, max_age=9)
+        dev.set_trait(0, np.array([5, 300, 611, 842]), np.array([0.1, -0.1, 0.1, -0.1]), 1, 0.05,
+                      1.0, False)
+        upload_simple(dev, x, y, ids=ids)
+        dev.upload_genomes(g)
+        dev.set_recomb_paths(paths)
+        dev.set_z()
+        devs.append(dev)
+    monkeypatch.delenv('GNX_COMPACT_FILL')
+    a, b = devs
+    moved = False
+    for t in range(15):
+        for dev in devs:
+            dev.step(False, True)
+        assert a.counts() == b.counts(), t
+        ia, ib = a.download(nat.F_ID), b.download(nat.F_ID)
+        moved = moved or not np.array_equal(ia, ib)
+        oa, ob = np.argsort(ia), np.argsort(ib)
+        np.testing.assert_array_equal(ia[oa], ib[ob])
+        for f in (nat.F_X, nat.F_Y, nat.F_AGE, nat.F_FIT, nat.F_GENO):
+            np.testing.assert_array_equal(a.download(f)[oa], b.download(f)[ob], err_msg=str((t, f)))
+        for f in (nat.F_Z, nat.F_E):                  # [traits or layers][N]
+            np.testing.assert_array_equal(a.download(f)[:, oa], b.download(f)[:, ob],
+                                          err_msg=str((t, f)))
+    assert moved and a.counts()[0] > 1500
+    a.close()
+    b.close()
