@@ -954,8 +954,12 @@ k_xo_jobs_write(int64_t B, GnxHalves H, const GnxXoPlan* __restrict__ plan,
 // (k_xo_jobs_write: 3.3 M threads, each a chain of three dependent loads) took 52 us,
 // k_xo_jobs_surv 23.
 #define GNX_JF_NB 16
-template <int NB>
-__global__ void __launch_bounds__(256)
+// threads per workgroup: every workgroup takes its stretch of the free-block stack and of the
+// job list with one atomic each, all on the same two words - 815 workgroups of 256 threads
+// queue up there (64 us; 512 threads: 58 us; 1024 threads spill: 64 us)
+#define GNX_JF_TPB 512
+template <int NB, int TPB>
+__global__ void __launch_bounds__(TPB)
 k_xo_jobs_fused(int64_t N, int64_t first, int32_t* __restrict__ grow,
                 const int32_t* __restrict__ alive, const int32_t* __restrict__ blk_off3,
                 const int32_t* __restrict__ off_parent, const int32_t* __restrict__ off_keys,
@@ -963,20 +967,21 @@ k_xo_jobs_fused(int64_t N, int64_t first, int32_t* __restrict__ grow,
                 int64_t n_free, GnxHalves H, const int32_t* __restrict__ bp_off,
                 const int32_t* __restrict__ bp_loci, int32_t* __restrict__ n_jobs,
                 GnxXoJob* __restrict__ jobs, GnxJobBp* __restrict__ jobs_bp) {
-  __shared__ int wsum[3][4];
-  __shared__ int prev_s[4];
+  constexpr int WAVES = TPB / 64;
+  __shared__ int wsum[3][WAVES];
+  __shared__ int prev_s[WAVES];
   __shared__ int s_pop, s_job;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t base = (first / 256 + blockIdx.x) * 256;
+  const int64_t base = (first / TPB + blockIdx.x) * TPB;
   const int64_t i = base + tid;
-  const int64_t b = base / GNX_CB;                 // the compaction block of these 256 slots
-  const int round = (int)((base - b * GNX_CB) / 256);
+  const int64_t b = base / GNX_CB;                 // the compaction block of these TPB slots
+  const int round = (int)((base - b * GNX_CB) / TPB);
   // stage 1: who is a surviving offspring without a row, here and in the earlier rounds of
   // the same compaction block (their number comes before this round's ranks)
   const bool fx = i < N && (alive[i] & 2) != 0;
   int prev = 0;
   for (int r = 0; r < round; ++r) {
-    const int64_t j = b * GNX_CB + r * 256 + tid;
+    const int64_t j = b * GNX_CB + r * TPB + tid;
     prev += __popcll(__ballot(j < N && (alive[j] & 2) != 0));
   }
   const unsigned long long bal = __ballot(fx);
@@ -987,7 +992,9 @@ k_xo_jobs_fused(int64_t N, int64_t first, int32_t* __restrict__ grow,
   __syncthreads();
   int rank = __popcll(bal & ((1ull << lane) - 1ull));
   for (int w = 0; w < wave; ++w) rank += wsum[0][w];
-  rank += blk_off3[b] + prev_s[0] + prev_s[1] + prev_s[2] + prev_s[3];
+  rank += blk_off3[b];
+#pragma unroll
+  for (int w = 0; w < WAVES; ++w) rank += prev_s[w];
   // stage 2: row, parents, keys, start homologues (unconditional loads from clamped indices)
   const int64_t k = fx ? i - first : 0;
   int32_t row = free_rows[n_free - 1 - (fx ? rank : 0)];
@@ -1060,7 +1067,7 @@ k_xo_jobs_fused(int64_t N, int64_t first, int32_t* __restrict__ grow,
     }
   }
   // stage 5: this workgroup's stretch of the free-block stack and of the job list, with
-  // ONE atomic each; exclusive sums of cf / cj over the 256 threads
+  // ONE atomic each; exclusive sums of cf / cj over the TPB threads
   int xf = cf, xj = cj;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -1081,8 +1088,12 @@ k_xo_jobs_fused(int64_t N, int64_t first, int32_t* __restrict__ grow,
     oj += wsum[2][w];
   }
   if (tid == 0) {
-    const int tf = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
-    const int tj = wsum[2][0] + wsum[2][1] + wsum[2][2] + wsum[2][3];
+    int tf = 0, tj = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+      tf += wsum[1][w];
+      tj += wsum[2][w];
+    }
     s_pop = tf ? atomicSub(H.top, tf) : 0;
     s_job = tj ? atomicAdd(n_jobs, tj) : 0;
   }
@@ -1200,8 +1211,8 @@ template <int NB>
 static void launch_jobs_fused(gnx_state* h, int64_t first_slot, const int32_t* d_alive,
                               const int32_t* d_blk_off, int buf) {
   const int64_t N = h->N;
-  const int nbf = (int)((N - 1) / 256 - first_slot / 256 + 1);
-  hipLaunchKernelGGL(k_xo_jobs_fused<NB>, dim3(nbf), dim3(256), 0, h->stream, N, first_slot,
+  const int nbf = (int)((N - 1) / GNX_JF_TPB - first_slot / GNX_JF_TPB + 1);
+  hipLaunchKernelGGL((k_xo_jobs_fused<NB, GNX_JF_TPB>), dim3(nbf), dim3(GNX_JF_TPB), 0, h->stream, N, first_slot,
                      h->soa[h->cur].grow, d_alive, d_blk_off + 2 * h->blk_stride, h->off_parent,
                      h->off_keys, h->off_start, h->free_rows, h->n_free, gnx_halves(h),
                      gnx_alias_bp(h), gnx_alias_loci(h), h->n_jobs_dev[buf],
