@@ -550,7 +550,9 @@ def main():
                     'steps': k_alt, 'crossover_avg_launch_ms': kx['ms'] / max(kx['launches'], 1),
                     'crossover_achieved_GBps': a_gbps, 'crossover_frac': a_gbps / 8000.0}
         alone = other_mode(2, 'nothing runs beside the crossover (the compactions and the next '
-                              'movement wait for it)')
+                              'movement wait for it); one job per wave and iteration '
+                              '(k_xo_sparse<1>) - the timed region runs k_xo_sparse_pair, '
+                              'two jobs per iteration, which is the slower kernel alone')
         alt = other_mode(1, 'crossover (8 workgroups per CU) beside the whole next step: nothing waits '
                              'for it but the next crossover')
     fam = None

@@ -53,6 +53,24 @@ static void xo_launch_sparse(gnx_state* h, hipStream_t st, int grid, int buf, bo
   const int W16 = h->W64 / 2 / h->NB;       // chunks per block
   static const bool inline_env = !(getenv("GNX_XO_INLINE_BP") && atoi(getenv("GNX_XO_INLINE_BP")) == 0);
   const GnxJobBp* ib = (h->jobs_inline[buf] && inline_env) ? (const GnxJobBp*)h->jobs_bp[buf] : nullptr;
+  // two jobs per wave and iteration (gnx_xo.h: k_xo_sparse_pair) when something runs beside
+  // the crossover - the step's normal state: 0.625 against 0.636 ms/step, the launch 0.181
+  // against 0.188 ms.  With the chip to itself (gnx_set_crossover_overlap(2)) one job per
+  // iteration is the faster kernel (0.142 against 0.165 ms): GNX_XO_PAIR=0 / 2 force one.
+  static const int pair_env = getenv("GNX_XO_PAIR") ? atoi(getenv("GNX_XO_PAIR")) : 1;
+  if (U == 1 && W16 <= 64 && ib && (pair_env == 2 || (pair_env == 1 && h->xo_wait_at != 2))) {
+    // (GNX_XO_LDS: unused dynamic LDS per workgroup = a cap on the workgroups per CU)
+    static const int lds_cap = getenv("GNX_XO_LDS") ? atoi(getenv("GNX_XO_LDS")) : 0;
+    if (nt)
+      hipLaunchKernelGGL((k_xo_sparse_pair<true>), dim3(grid), dim3(256), lds_cap, st, h->n_jobs_dev[buf],
+                         W16, (const u64x2*)h->G, (u64x2*)h->G, (const GnxXoJob*)h->jobs[buf],
+                         h->bp_off, h->bp_loci, lo, hi, acc, ib);
+    else
+      hipLaunchKernelGGL((k_xo_sparse_pair<false>), dim3(grid), dim3(256), 0, st, h->n_jobs_dev[buf],
+                         W16, (const u64x2*)h->G, (u64x2*)h->G, (const GnxXoJob*)h->jobs[buf],
+                         h->bp_off, h->bp_loci, lo, hi, acc, ib);
+    return;
+  }
   if (nt)
     hipLaunchKernelGGL((k_xo_sparse<U, true>), dim3(grid), dim3(256), 0, st, h->n_jobs_dev[buf],
                        W16, (const u64x2*)h->G, (u64x2*)h->G, (const GnxXoJob*)h->jobs[buf],

@@ -283,6 +283,154 @@ k_xo_sparse(const int32_t* __restrict__ n_jobs_p, int W16, const u64x2* __restri
   }
 }
 
+// Two jobs per wave and iteration (blocks of at most 64 chunks, switch points inline): a
+// wave of k_xo_sparse<1> has ONE block's loads in flight (56 lanes x 16 B at L = 10^5), then
+// stores, then the next job; here the loads of two blocks are issued before either is
+// stored, and the records of the next two are fetched meanwhile.  A job whose block holds
+// more than three switch points (GNX_BP_MORE) takes the list path on its own.
+template <bool NT_LD>
+__device__ __forceinline__ void xo_job_lists(const GnxXoJob& jb, int W16, const u64x2* __restrict__ G,
+                                             u64x2* __restrict__ Gout,
+                                             const int32_t* __restrict__ bp_off,
+                                             const int32_t* __restrict__ bp_loci, int lane) {
+  const int ph0 = __builtin_amdgcn_readfirstlane(jb.ph0);
+  const int ph1 = __builtin_amdgcn_readfirstlane(jb.ph1);
+  const int dsth = __builtin_amdgcn_readfirstlane(jb.dst);
+  const int ks = __builtin_amdgcn_readfirstlane(jb.ks);
+  const int key = (ks & 0xffffff) >> 1;
+  const u64 s = (ks & 1) ? ~0ull : 0ull;
+  const int cb = (ks >> 24) * W16;
+  const u64x2* h0 = G + (int64_t)ph0 * W16;
+  const u64x2* h1 = G + (int64_t)ph1 * W16;
+  u64x2* dst = Gout + (int64_t)dsth * W16;
+  const int bp0 = __builtin_amdgcn_readfirstlane(bp_off[key]);
+  const int nbp = __builtin_amdgcn_readfirstlane(bp_off[key + 1]) - bp0;
+  const int mybp = lane < nbp ? bp_loci[bp0 + lane] : 0x7fffffff;
+  const int c = min(lane, W16 - 1);
+  const u64x2 m = xo_mask_lanes(cb + c, s, mybp, nbp);
+  const bool one = (m.a & m.b) == ~0ull;
+  u64x2 v = xo_load<NT_LD>((one ? h1 : h0) + c);
+  if (!one && (m.a | m.b) != 0ull) {
+    const u64x2 b = h1[c];
+    v.a = (v.a & ~m.a) | (b.a & m.a);
+    v.b = (v.b & ~m.b) | (b.b & m.b);
+  }
+  if (lane < W16) xo_store(dst + lane, v);
+}
+
+// one job whose switch points ride with it (at most three inside the block)
+template <bool NT_LD>
+__device__ __forceinline__ void xo_job_inline(const GnxXoJob& jb, unsigned int lo, unsigned int hi,
+                                              int W16, const u64x2* __restrict__ G,
+                                              u64x2* __restrict__ Gout, int lane) {
+  const u64x2* h0 = G + (int64_t)__builtin_amdgcn_readfirstlane(jb.ph0) * W16;
+  const u64x2* h1 = G + (int64_t)__builtin_amdgcn_readfirstlane(jb.ph1) * W16;
+  u64x2* dst = Gout + (int64_t)__builtin_amdgcn_readfirstlane(jb.dst) * W16;
+  const int c = min(lane, W16 - 1);
+  const u64x2 m = xo_mask_inline(c, ((hi >> 16) & 4u) ? ~0ull : 0ull, (int)(lo & 0xffffu),
+                                 (int)(lo >> 16), (int)(hi & 0xffffu), (int)((hi >> 16) & 3u));
+  const bool one = (m.a & m.b) == ~0ull;
+  u64x2 v = xo_load<NT_LD>((one ? h1 : h0) + c);
+  if (!one && (m.a | m.b) != 0ull) {
+    const u64x2 b = h1[c];
+    v.a = (v.a & ~m.a) | (b.a & m.a);
+    v.b = (v.b & ~m.b) | (b.b & m.b);
+  }
+  if (lane < W16) xo_store(dst + lane, v);
+}
+
+template <bool NT_LD>
+__global__ void __launch_bounds__(256)
+k_xo_sparse_pair(const int32_t* __restrict__ n_jobs_p, int W16, const u64x2* __restrict__ G,
+                 u64x2* __restrict__ Gout, const GnxXoJob* __restrict__ jobs,
+                 const int32_t* __restrict__ bp_off, const int32_t* __restrict__ bp_loci,
+                 int part_lo, int part_hi, unsigned long long* __restrict__ acc,
+                 const GnxJobBp* __restrict__ jobs_bp) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int n_all = *n_jobs_p;
+  const int j_lo = (int)(((long long)n_all * part_lo) >> 10);
+  const int n_jobs = (int)(((long long)n_all * part_hi) >> 10);
+  const int n_waves = (int)gridDim.x * 4;
+  if (acc && blockIdx.x == 0 && threadIdx.x == 0 && n_jobs > j_lo)
+    atomicAdd(acc, (unsigned long long)(n_jobs - j_lo));
+  int j = j_lo + (int)blockIdx.x * 4 + wv;
+  GnxXoJob rA, rB;
+  uint2 wA = make_uint2(0u, 0u), wB = make_uint2(0u, 0u);
+  if (j < n_jobs) {
+    rA = jobs[j];
+    wA = *(const uint2*)(jobs_bp + j);
+  }
+  if (j + n_waves < n_jobs) {
+    rB = jobs[j + n_waves];
+    wB = *(const uint2*)(jobs_bp + j + n_waves);
+  }
+  const int c = min(lane, W16 - 1);
+  for (; j < n_jobs; j += 2 * n_waves) {
+    const GnxXoJob jA = rA, jB = rB;
+    const uint2 iA = wA, iB = wB;
+    const bool haveB = j + n_waves < n_jobs;               // (uniform)
+    if (j + 2 * n_waves < n_jobs) {
+      rA = jobs[j + 2 * n_waves];
+      wA = *(const uint2*)(jobs_bp + j + 2 * n_waves);
+    }
+    if (j + 3 * n_waves < n_jobs) {
+      rB = jobs[j + 3 * n_waves];
+      wB = *(const uint2*)(jobs_bp + j + 3 * n_waves);
+    }
+    const unsigned int aLo = __builtin_amdgcn_readfirstlane(iA.x);
+    const unsigned int aHi = __builtin_amdgcn_readfirstlane(iA.y);
+    const unsigned int bLo = __builtin_amdgcn_readfirstlane(iB.x);
+    const unsigned int bHi = __builtin_amdgcn_readfirstlane(iB.y);
+    const bool moreA = ((aHi >> 16) & GNX_BP_MORE) != 0u;
+    const bool moreB = haveB && ((bHi >> 16) & GNX_BP_MORE) != 0u;
+    if (__builtin_expect(moreA || moreB || !haveB, 0)) {
+      // the rare shapes, one job at a time
+      if (moreA) xo_job_lists<NT_LD>(jA, W16, G, Gout, bp_off, bp_loci, lane);
+      else xo_job_inline<NT_LD>(jA, aLo, aHi, W16, G, Gout, lane);
+      if (haveB) {
+        if (moreB) xo_job_lists<NT_LD>(jB, W16, G, Gout, bp_off, bp_loci, lane);
+        else xo_job_inline<NT_LD>(jB, bLo, bHi, W16, G, Gout, lane);
+      }
+      continue;
+    }
+    // straight-line from here: masks and addresses of both jobs (pure ALU), all loads back to
+    // back - the chunk that holds a switch point (one lane per job) fetches its second
+    // homologue right away -, ONE wait, both blends, both stores.  (With a branch or a store
+    // between them the compiler drains vmcnt - stores included - before the second store.)
+    const u64x2* hA0 = G + (int64_t)__builtin_amdgcn_readfirstlane(jA.ph0) * W16 + c;
+    const u64x2* hA1 = G + (int64_t)__builtin_amdgcn_readfirstlane(jA.ph1) * W16 + c;
+    const u64x2* hB0 = G + (int64_t)__builtin_amdgcn_readfirstlane(jB.ph0) * W16 + c;
+    const u64x2* hB1 = G + (int64_t)__builtin_amdgcn_readfirstlane(jB.ph1) * W16 + c;
+    u64x2 mA = xo_mask_inline(c, ((aHi >> 16) & 4u) ? ~0ull : 0ull, (int)(aLo & 0xffffu),
+                              (int)(aLo >> 16), (int)(aHi & 0xffffu), (int)((aHi >> 16) & 3u));
+    u64x2 mB = xo_mask_inline(c, ((bHi >> 16) & 4u) ? ~0ull : 0ull, (int)(bLo & 0xffffu),
+                              (int)(bLo >> 16), (int)(bHi & 0xffffu), (int)((bHi >> 16) & 3u));
+    const bool oneA = (mA.a & mA.b) == ~0ull, oneB = (mB.a & mB.b) == ~0ull;
+    const bool mixA = !oneA && (mA.a | mA.b) != 0ull, mixB = !oneB && (mB.a | mB.b) != 0ull;
+    u64x2 xA, xB;
+    xA.a = xA.b = xB.a = xB.b = 0ull;
+    u64x2 vA = xo_load<NT_LD>(oneA ? hA1 : hA0);
+    u64x2 vB = xo_load<NT_LD>(oneB ? hB1 : hB0);
+    if (mixA) xA = *hA1;
+    if (mixB) xB = *hB1;
+    __builtin_amdgcn_s_waitcnt(0x0f70);            // vmcnt(0)
+    const u64 kA = mixA ? ~0ull : 0ull, kB = mixB ? ~0ull : 0ull;
+    mA.a &= kA;
+    mA.b &= kA;
+    mB.a &= kB;
+    mB.b &= kB;
+    vA.a = (vA.a & ~mA.a) | (xA.a & mA.a);
+    vA.b = (vA.b & ~mA.b) | (xA.b & mA.b);
+    vB.a = (vB.a & ~mB.a) | (xB.a & mB.a);
+    vB.b = (vB.b & ~mB.b) | (xB.b & mB.b);
+    if (lane < W16) {
+      xo_store(Gout + (int64_t)__builtin_amdgcn_readfirstlane(jA.dst) * W16 + lane, vA);
+      xo_store(Gout + (int64_t)__builtin_amdgcn_readfirstlane(jB.dst) * W16 + lane, vB);
+    }
+  }
+}
+
 template <int U, bool NT_LD>
 __global__ void __launch_bounds__(256)
 k_xo_dense(const int32_t* __restrict__ n_jobs_p, int W16, const u64x2* __restrict__ G,
