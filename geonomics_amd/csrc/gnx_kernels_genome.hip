@@ -59,16 +59,19 @@ static void xo_launch_sparse(gnx_state* h, hipStream_t st, int grid, int buf, bo
   // iteration is the faster kernel (0.142 against 0.165 ms): GNX_XO_PAIR=0 / 2 force one.
   static const int pair_env = getenv("GNX_XO_PAIR") ? atoi(getenv("GNX_XO_PAIR")) : 1;
   if (U == 1 && W16 <= 64 && ib && (pair_env == 2 || (pair_env == 1 && h->xo_wait_at != 2))) {
-    // (GNX_XO_LDS: unused dynamic LDS per workgroup = a cap on the workgroups per CU)
-    static const int lds_cap = getenv("GNX_XO_LDS") ? atoi(getenv("GNX_XO_LDS")) : 0;
-    if (nt)
-      hipLaunchKernelGGL((k_xo_sparse_pair<true>), dim3(grid), dim3(256), lds_cap, st, h->n_jobs_dev[buf],
-                         W16, (const u64x2*)h->G, (u64x2*)h->G, (const GnxXoJob*)h->jobs[buf],
-                         h->bp_off, h->bp_loci, lo, hi, acc, ib);
-    else
-      hipLaunchKernelGGL((k_xo_sparse_pair<false>), dim3(grid), dim3(256), 0, st, h->n_jobs_dev[buf],
-                         W16, (const u64x2*)h->G, (u64x2*)h->G, (const GnxXoJob*)h->jobs[buf],
-                         h->bp_off, h->bp_loci, lo, hi, acc, ib);
+    static const int kj = getenv("GNX_XO_GROUP") ? atoi(getenv("GNX_XO_GROUP")) : 2;
+#define GNX_XO_PAIR_LAUNCH(NT, KK)                                                                \
+  hipLaunchKernelGGL((k_xo_sparse_pair<NT, KK>), dim3(grid), dim3(256), 0, st, h->n_jobs_dev[buf], \
+                     W16, (const u64x2*)h->G, (u64x2*)h->G, (const GnxXoJob*)h->jobs[buf],        \
+                     h->bp_off, h->bp_loci, lo, hi, acc, ib)
+    if (nt) {
+      if (kj == 3) GNX_XO_PAIR_LAUNCH(true, 3);
+      else if (kj == 4) GNX_XO_PAIR_LAUNCH(true, 4);
+      else GNX_XO_PAIR_LAUNCH(true, 2);
+    } else {
+      GNX_XO_PAIR_LAUNCH(false, 2);
+    }
+#undef GNX_XO_PAIR_LAUNCH
     return;
   }
   if (nt)

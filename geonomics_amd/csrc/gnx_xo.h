@@ -283,7 +283,7 @@ k_xo_sparse(const int32_t* __restrict__ n_jobs_p, int W16, const u64x2* __restri
   }
 }
 
-// Two jobs per wave and iteration (blocks of at most 64 chunks, switch points inline): a
+// K jobs per wave and iteration (blocks of at most 64 chunks, switch points inline): a
 // wave of k_xo_sparse<1> has ONE block's loads in flight (56 lanes x 16 B at L = 10^5), then
 // stores, then the next job; here the loads of two blocks are issued before either is
 // stored, and the records of the next two are fetched meanwhile.  A job whose block holds
@@ -339,7 +339,7 @@ __device__ __forceinline__ void xo_job_inline(const GnxXoJob& jb, unsigned int l
   if (lane < W16) xo_store(dst + lane, v);
 }
 
-template <bool NT_LD>
+template <bool NT_LD, int K>
 __global__ void __launch_bounds__(256)
 k_xo_sparse_pair(const int32_t* __restrict__ n_jobs_p, int W16, const u64x2* __restrict__ G,
                  u64x2* __restrict__ Gout, const GnxXoJob* __restrict__ jobs,
@@ -355,78 +355,82 @@ k_xo_sparse_pair(const int32_t* __restrict__ n_jobs_p, int W16, const u64x2* __r
   if (acc && blockIdx.x == 0 && threadIdx.x == 0 && n_jobs > j_lo)
     atomicAdd(acc, (unsigned long long)(n_jobs - j_lo));
   int j = j_lo + (int)blockIdx.x * 4 + wv;
-  GnxXoJob rA, rB;
-  uint2 wA = make_uint2(0u, 0u), wB = make_uint2(0u, 0u);
-  if (j < n_jobs) {
-    rA = jobs[j];
-    wA = *(const uint2*)(jobs_bp + j);
-  }
-  if (j + n_waves < n_jobs) {
-    rB = jobs[j + n_waves];
-    wB = *(const uint2*)(jobs_bp + j + n_waves);
+  // the records of this iteration's K jobs (fetched during the last one)
+  GnxXoJob rec[K];
+  uint2 wrd[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    wrd[k] = make_uint2(0u, 0u);
+    if (j + k * n_waves < n_jobs) {
+      rec[k] = jobs[j + k * n_waves];
+      wrd[k] = *(const uint2*)(jobs_bp + j + k * n_waves);
+    }
   }
   const int c = min(lane, W16 - 1);
-  for (; j < n_jobs; j += 2 * n_waves) {
-    const GnxXoJob jA = rA, jB = rB;
-    const uint2 iA = wA, iB = wB;
-    const bool haveB = j + n_waves < n_jobs;               // (uniform)
-    if (j + 2 * n_waves < n_jobs) {
-      rA = jobs[j + 2 * n_waves];
-      wA = *(const uint2*)(jobs_bp + j + 2 * n_waves);
+  for (; j < n_jobs; j += K * n_waves) {
+    GnxXoJob jb[K];
+    unsigned int lo[K], hi[K];
+    bool rare = j + (K - 1) * n_waves >= n_jobs;           // (uniform) fewer than K jobs left
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      jb[k] = rec[k];
+      lo[k] = __builtin_amdgcn_readfirstlane(wrd[k].x);
+      hi[k] = __builtin_amdgcn_readfirstlane(wrd[k].y);
+      rare = rare || ((hi[k] >> 16) & GNX_BP_MORE) != 0u;
     }
-    if (j + 3 * n_waves < n_jobs) {
-      rB = jobs[j + 3 * n_waves];
-      wB = *(const uint2*)(jobs_bp + j + 3 * n_waves);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int jn = j + (K + k) * n_waves;
+      if (jn < n_jobs) {
+        rec[k] = jobs[jn];
+        wrd[k] = *(const uint2*)(jobs_bp + jn);
+      }
     }
-    const unsigned int aLo = __builtin_amdgcn_readfirstlane(iA.x);
-    const unsigned int aHi = __builtin_amdgcn_readfirstlane(iA.y);
-    const unsigned int bLo = __builtin_amdgcn_readfirstlane(iB.x);
-    const unsigned int bHi = __builtin_amdgcn_readfirstlane(iB.y);
-    const bool moreA = ((aHi >> 16) & GNX_BP_MORE) != 0u;
-    const bool moreB = haveB && ((bHi >> 16) & GNX_BP_MORE) != 0u;
-    if (__builtin_expect(moreA || moreB || !haveB, 0)) {
+    if (__builtin_expect(rare, 0)) {
       // the rare shapes, one job at a time
-      if (moreA) xo_job_lists<NT_LD>(jA, W16, G, Gout, bp_off, bp_loci, lane);
-      else xo_job_inline<NT_LD>(jA, aLo, aHi, W16, G, Gout, lane);
-      if (haveB) {
-        if (moreB) xo_job_lists<NT_LD>(jB, W16, G, Gout, bp_off, bp_loci, lane);
-        else xo_job_inline<NT_LD>(jB, bLo, bHi, W16, G, Gout, lane);
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        if (j + k * n_waves >= n_jobs) break;
+        if ((hi[k] >> 16) & GNX_BP_MORE) xo_job_lists<NT_LD>(jb[k], W16, G, Gout, bp_off, bp_loci, lane);
+        else xo_job_inline<NT_LD>(jb[k], lo[k], hi[k], W16, G, Gout, lane);
       }
       continue;
     }
-    // straight-line from here: masks and addresses of both jobs (pure ALU), all loads back to
+    // straight-line from here: masks and addresses of all K jobs (pure ALU), all loads back to
     // back - the chunk that holds a switch point (one lane per job) fetches its second
-    // homologue right away -, ONE wait, both blends, both stores.  (With a branch or a store
-    // between them the compiler drains vmcnt - stores included - before the second store.)
-    const u64x2* hA0 = G + (int64_t)__builtin_amdgcn_readfirstlane(jA.ph0) * W16 + c;
-    const u64x2* hA1 = G + (int64_t)__builtin_amdgcn_readfirstlane(jA.ph1) * W16 + c;
-    const u64x2* hB0 = G + (int64_t)__builtin_amdgcn_readfirstlane(jB.ph0) * W16 + c;
-    const u64x2* hB1 = G + (int64_t)__builtin_amdgcn_readfirstlane(jB.ph1) * W16 + c;
-    u64x2 mA = xo_mask_inline(c, ((aHi >> 16) & 4u) ? ~0ull : 0ull, (int)(aLo & 0xffffu),
-                              (int)(aLo >> 16), (int)(aHi & 0xffffu), (int)((aHi >> 16) & 3u));
-    u64x2 mB = xo_mask_inline(c, ((bHi >> 16) & 4u) ? ~0ull : 0ull, (int)(bLo & 0xffffu),
-                              (int)(bLo >> 16), (int)(bHi & 0xffffu), (int)((bHi >> 16) & 3u));
-    const bool oneA = (mA.a & mA.b) == ~0ull, oneB = (mB.a & mB.b) == ~0ull;
-    const bool mixA = !oneA && (mA.a | mA.b) != 0ull, mixB = !oneB && (mB.a | mB.b) != 0ull;
-    u64x2 xA, xB;
-    xA.a = xA.b = xB.a = xB.b = 0ull;
-    u64x2 vA = xo_load<NT_LD>(oneA ? hA1 : hA0);
-    u64x2 vB = xo_load<NT_LD>(oneB ? hB1 : hB0);
-    if (mixA) xA = *hA1;
-    if (mixB) xB = *hB1;
+    // homologue right away -, ONE wait, the blends, the stores.  (With a branch or a store
+    // between them the compiler drains vmcnt - stores included - before the next store.)
+    const u64x2 *h0[K], *h1[K];
+    u64x2 m[K], v[K], x[K];
+    bool mix[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      h0[k] = G + (int64_t)__builtin_amdgcn_readfirstlane(jb[k].ph0) * W16 + c;
+      h1[k] = G + (int64_t)__builtin_amdgcn_readfirstlane(jb[k].ph1) * W16 + c;
+      m[k] = xo_mask_inline(c, ((hi[k] >> 16) & 4u) ? ~0ull : 0ull, (int)(lo[k] & 0xffffu),
+                            (int)(lo[k] >> 16), (int)(hi[k] & 0xffffu), (int)((hi[k] >> 16) & 3u));
+      const bool one = (m[k].a & m[k].b) == ~0ull;
+      mix[k] = !one && (m[k].a | m[k].b) != 0ull;
+      if (one) h0[k] = h1[k];
+      x[k].a = x[k].b = 0ull;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = xo_load<NT_LD>(h0[k]);
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (mix[k]) x[k] = *h1[k];
     __builtin_amdgcn_s_waitcnt(0x0f70);            // vmcnt(0)
-    const u64 kA = mixA ? ~0ull : 0ull, kB = mixB ? ~0ull : 0ull;
-    mA.a &= kA;
-    mA.b &= kA;
-    mB.a &= kB;
-    mB.b &= kB;
-    vA.a = (vA.a & ~mA.a) | (xA.a & mA.a);
-    vA.b = (vA.b & ~mA.b) | (xA.b & mA.b);
-    vB.a = (vB.a & ~mB.a) | (xB.a & mB.a);
-    vB.b = (vB.b & ~mB.b) | (xB.b & mB.b);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const u64 keep = mix[k] ? ~0ull : 0ull;
+      const u64 ma = m[k].a & keep, mb = m[k].b & keep;
+      v[k].a = (v[k].a & ~ma) | (x[k].a & ma);
+      v[k].b = (v[k].b & ~mb) | (x[k].b & mb);
+    }
     if (lane < W16) {
-      xo_store(Gout + (int64_t)__builtin_amdgcn_readfirstlane(jA.dst) * W16 + lane, vA);
-      xo_store(Gout + (int64_t)__builtin_amdgcn_readfirstlane(jB.dst) * W16 + lane, vB);
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        xo_store(Gout + (int64_t)__builtin_amdgcn_readfirstlane(jb[k].dst) * W16 + lane, v[k]);
     }
   }
 }
