@@ -37,6 +37,17 @@ CAP_ROWS = 2050
 
 def _paths(dense, n_paths=192, seed=7):
     rng = np.random.RandomState(seed)
+    if dense == 'clustered':
+        # sparse paths (at most 24 switch points) whose switch points crowd: 4 .. 9 of them
+        # inside one stretch of 3000 loci - more than three in one 7168-locus block, which the
+        # crossover's jobs cannot carry inline (GNX_BP_MORE: the kernel walks the path's list)
+        cross = np.zeros((n_paths, L), np.uint8)
+        for k in range(n_paths):
+            lo = rng.randint(1, L - 3000)
+            cross[k, lo + rng.choice(3000, rng.randint(4, 10), replace=False)] = 1
+            cross[k, rng.choice(np.arange(1, L), rng.randint(0, 6), replace=False)] = 1
+        assert cross.sum(axis=1).max() <= 24
+        return O.pack_bits(O.recomb_paths(cross))
     rate = 0.5 if dense else 1.0 / L
     cross = (rng.rand(n_paths, L) < rate).astype(np.uint8)
     cross[:, 0] = 0
@@ -172,7 +183,7 @@ def test_model_step_path_matches_oracle_crossover(overlap):
     dev.close()
 
 
-@pytest.mark.parametrize('dense,overlap', [(False, 0), (False, 1), (True, 0)])
+@pytest.mark.parametrize('dense,overlap', [(False, 0), (False, 1), (True, 0), ('clustered', 0)])
 def test_fused_step_path_matches_oracle_crossover(dense, overlap):
     """gnx_step (the bench's path).  Its births cannot be read mid-step, so a twin driven
     through the split path supplies them (draws are keyed by id and step: same decisions,
@@ -182,7 +193,7 @@ def test_fused_step_path_matches_oracle_crossover(dense, overlap):
     a, g = _make(paths, overlap=overlap)
     b, _ = _make(paths, overlap=0)
     info = a.genome_info()
-    assert info['NB'] == (1 if dense else NB) and info['sparse'] == (0 if dense else 1)
+    assert info['NB'] == (1 if dense is True else NB) and info['sparse'] == (0 if dense is True else 1)
     host = HostGenomes(np.arange(N0), g, paths)
     for t in range(STEPS):
         a.step(False, True)
