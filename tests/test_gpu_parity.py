@@ -671,8 +671,9 @@ def test_whole_model_envelopes_vs_reference_on_device():
         dev.close()
     v_ref = np.mean(np.concatenate(drift_ref) ** 2)
     v_mine = np.mean(np.concatenate(drift_mine) ** 2)
-    # 24 reference runs x 48 neutral loci, twice as many device runs: the ratio carries ~6 %
-    # sampling error (the numpy oracle under three seed sets: 0.98, 0.92, 1.00)
+    # 24 reference runs, twice as many device runs: the runs are the samples (a run's loci
+    # drift together) and the ratio carries ~8 % sampling error (bootstrap over runs,
+    # tests/test_oracle_golden.py); measured 0.97, the numpy oracle 0.90 over its 48 runs
     m = {k: (np.mean(ref[k]), np.mean(mine[k])) for k in ref}
     print('drift variance ratio %.3f' % (v_mine / v_ref),
           {k: round(v[1] / v[0] - 1, 4) for k, v in m.items()})
