@@ -1079,8 +1079,41 @@ k_pair_flags(PairP P, GnxSoA s, int32_t* flag2, int32_t* cnt) {
 __global__ void __launch_bounds__(256)
 k_pair_compact(int64_t N, const int32_t* focal, const int32_t* mate, const int32_t* flag2,
                const int32_t* blk_off, const float* x, const float* y, const uint64_t* popkey,
-               int idbits, int32_t* pairs, float* mid_x, float* mid_y, uint64_t* key) {
+               int idbits, int32_t* pairs, float* mid_x, float* mid_y, uint64_t* key,
+               const int32_t* __restrict__ cnt, int32_t* __restrict__ total_dev,
+               int64_t* __restrict__ host, long long seq, const int32_t* __restrict__ extra) {
   __shared__ int lds[16];
+  __shared__ int psum[4];
+  // cnt != null: no scan kernel ran - every workgroup adds up the block counts before its own
+  // (a few coalesced loads from L2: 1 210 counts at the metric size), and workgroup 0, the
+  // first to start, adds up all of them and hands the total to the host and to the device
+  // (k_block_scan as a launch of its own: 8 us + two dispatch gaps on the step's chain)
+  int self_off = 0;
+  if (cnt) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int upto = blockIdx.x == 0 ? (int)gridDim.x : (int)blockIdx.x;
+    int part = 0;
+    for (int i = threadIdx.x; i < upto; i += 256) part += cnt[i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d);
+    if (lane == 0) psum[wave] = part;
+    __syncthreads();
+    const int sum = psum[0] + psum[1] + psum[2] + psum[3];
+    self_off = blockIdx.x == 0 ? 0 : sum;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      *total_dev = sum;
+      if (host) {
+        // (system-scope stores that have completed before the sequence number goes out: no
+        // release fence, which would write this XCD's L2 back - gnx_compact.h)
+        __hip_atomic_store(&host[0], (int64_t)sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (extra)
+          __hip_atomic_store(&host[12], (int64_t)*extra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (seq)
+          __hip_atomic_store(&host[3], (int64_t)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
   const int64_t base = (int64_t)blockIdx.x * GNX_CB;
   bool f[4];
 #pragma unroll
@@ -1090,7 +1123,7 @@ k_pair_compact(int64_t N, const int32_t* focal, const int32_t* mate, const int32
   }
   int rank[4], tot;
   gnx_block_ranks(f, rank, tot, lds);
-  const int32_t bo = blk_off[blockIdx.x];
+  const int32_t bo = cnt ? self_off : blk_off[blockIdx.x];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t i = base + r * 256 + threadIdx.x;
@@ -1163,12 +1196,17 @@ int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out, 
   const int64_t seq = ++h->pin_seq;
   // (the height of the free-block stack rides along: the host's count of it is exact again)
   const bool with_top = h->half_top && h->genomes_assigned;
-  GNXCHK(gnx_block_scan(h, 1, N, h->blk_cnt, h->blk_off, h->cnt_dev, h->h_pin_dev + 4, seq, nullptr,
-                        with_top ? h->half_top : nullptr));
+  static const bool self_scan = !(getenv("GNX_PAIR_SELFSCAN") && atoi(getenv("GNX_PAIR_SELFSCAN")) == 0);
+  if (!self_scan)
+    GNXCHK(gnx_block_scan(h, 1, N, h->blk_cnt, h->blk_off, h->cnt_dev, h->h_pin_dev + 4, seq, nullptr,
+                          with_top ? h->half_top : nullptr));
   // (the population was sorted by gnx_l_sort_by_cell with this idbits: max_id has not moved)
   hipLaunchKernelGGL(k_pair_compact, dim3(nb), dim3(256), 0, h->stream, N, focal, h->mate,
                      h->flag2, h->blk_off, s.x, s.y, h->key64[1], gnx_id_bits(h), h->pairs,
-                     h->mid_x, h->mid_y, h->key64[0]);
+                     h->mid_x, h->mid_y, h->key64[0],
+                     self_scan ? (const int32_t*)h->blk_cnt : (const int32_t*)nullptr, h->cnt_dev,
+                     h->h_pin_dev + 4, (long long)seq,
+                     with_top ? (const int32_t*)h->half_top : (const int32_t*)nullptr);
   gnx_time_end(h, GNX_K_PAIRS, (double)N * 40.0);
   HIPCHK(hipGetLastError());
   // the pair midpoints' density (ops/demography.py:60-91): on one GPU bins + lattice run on
