@@ -357,6 +357,7 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
   GNXCHK(dalloc(&h->newslot, cap));
   GNXCHK(dalloc(&h->fill_cnt, 4));
   HIPCHK(hipEventCreateWithFlags(&h->ev_fill, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_alive, hipEventDisableTiming));
   {
     // (zero between sorts: k_permute wipes what a sort dirtied; + 16: the wipe is in uint4s)
     const size_t nb = gnx_os_scratch_bytes((size_t)cap, 24) + 16;
@@ -505,6 +506,7 @@ extern "C" void gnx_destroy(gnx_state* h) {
   if (h->ev_ord) (void)hipEventDestroy(h->ev_ord);
   if (h->ev_compact) (void)hipEventDestroy(h->ev_compact);
   if (h->ev_fill) (void)hipEventDestroy(h->ev_fill);
+  if (h->ev_alive) (void)hipEventDestroy(h->ev_alive);
   if (h->ev_pairs) (void)hipEventDestroy(h->ev_pairs);
   if (h->ev_latP) (void)hipEventDestroy(h->ev_latP);
   if (h->ev_perm) (void)hipEventDestroy(h->ev_perm);

@@ -405,6 +405,8 @@ struct gnx_state {
   int32_t* ord[2]{};
   int32_t* newslot = nullptr;    // [cap] where the last compaction put each slot (-1: dead)
   bool compact_fill = true;      // GNX_COMPACT_FILL=0 (read at gnx_create): always the stable copy
+  bool jobs_self_scan = false;   // the job builder adds up the block counts itself (scan on stream3)
+  hipEvent_t ev_alive = nullptr; // the death draws and their block counts are written
   int32_t* fill_cnt = nullptr;   // in-place compaction: the number of movers (device)
   hipEvent_t ev_fill = nullptr;  // its hole / mover lists are written (stream3)
   int64_t fill_guess = 0;        // slots the last mortality round emptied (sizes k_fill's grid)

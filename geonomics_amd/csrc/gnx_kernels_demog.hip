@@ -966,10 +966,12 @@ k_xo_jobs_fused(int64_t N, int64_t first, int32_t* __restrict__ grow,
                 const uint8_t* __restrict__ off_start, const int32_t* __restrict__ free_rows,
                 int64_t n_free, GnxHalves H, const int32_t* __restrict__ bp_off,
                 const int32_t* __restrict__ bp_loci, int32_t* __restrict__ n_jobs,
-                GnxXoJob* __restrict__ jobs, GnxJobBp* __restrict__ jobs_bp) {
+                GnxXoJob* __restrict__ jobs, GnxJobBp* __restrict__ jobs_bp,
+                const int32_t* __restrict__ cnt3) {
   constexpr int WAVES = TPB / 64;
   __shared__ int wsum[3][WAVES];
   __shared__ int prev_s[WAVES];
+  __shared__ int psum[WAVES];
   __shared__ int s_pop, s_job;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t base = (first / TPB + blockIdx.x) * TPB;
@@ -984,15 +986,29 @@ k_xo_jobs_fused(int64_t N, int64_t first, int32_t* __restrict__ grow,
     const int64_t j = b * GNX_CB + r * TPB + tid;
     prev += __popcll(__ballot(j < N && (alive[j] & 2) != 0));
   }
+  // cnt3 != null: the block counts have not been scanned (the scan runs on the side stream,
+  // for the compaction and the host) - this workgroup adds up the counts before its
+  // compaction block itself: a few coalesced loads, and one launch less on the step's chain
+  int part = 0;
+  if (cnt3)
+    for (int q = tid; q < (int)b; q += TPB) part += cnt3[q];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d);
   const unsigned long long bal = __ballot(fx);
   if (lane == 0) {
     wsum[0][wave] = __popcll(bal);
     prev_s[wave] = prev;
+    psum[wave] = part;
   }
   __syncthreads();
   int rank = __popcll(bal & ((1ull << lane) - 1ull));
   for (int w = 0; w < wave; ++w) rank += wsum[0][w];
-  rank += blk_off3[b];
+  if (cnt3) {
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) rank += psum[w];
+  } else {
+    rank += blk_off3[b];
+  }
 #pragma unroll
   for (int w = 0; w < WAVES; ++w) rank += prev_s[w];
   // stage 2: row, parents, keys, start homologues (unconditional loads from clamped indices)
@@ -1216,7 +1232,9 @@ static void launch_jobs_fused(gnx_state* h, int64_t first_slot, const int32_t* d
                      h->soa[h->cur].grow, d_alive, d_blk_off + 2 * h->blk_stride, h->off_parent,
                      h->off_keys, h->off_start, h->free_rows, h->n_free, gnx_halves(h),
                      gnx_alias_bp(h), gnx_alias_loci(h), h->n_jobs_dev[buf],
-                     (GnxXoJob*)h->jobs[buf], (GnxJobBp*)h->jobs_bp[buf]);
+                     (GnxXoJob*)h->jobs[buf], (GnxJobBp*)h->jobs_bp[buf],
+                     h->jobs_self_scan ? (const int32_t*)(h->blk_cnt + 2 * h->blk_stride)
+                                       : (const int32_t*)nullptr);
   h->jobs_inline[buf] = true;
 }
 
@@ -1352,12 +1370,16 @@ k_fill(int64_t cap, const int32_t* __restrict__ n_move, const int32_t* __restric
   }
 }
 
+static bool jobs_fused_ok(const gnx_state* h) {
+  static const bool fused_env = !(getenv("GNX_JOBS_FUSED") && atoi(getenv("GNX_JOBS_FUSED")) == 0);
+  return fused_env && h->NB <= GNX_JF_NB;
+}
+
 void gnx_launch_xo_jobs_surv(gnx_state* h, int64_t first_slot, const int32_t* d_alive,
                              const int32_t* d_blk_off, int buf) {
   const int64_t N = h->N;
   const int nbj = (int)((N - 1) / GNX_CB - first_slot / GNX_CB + 1);
-  static const bool fused_env = !(getenv("GNX_JOBS_FUSED") && atoi(getenv("GNX_JOBS_FUSED")) == 0);
-  if (fused_env && h->NB <= GNX_JF_NB) {
+  if (jobs_fused_ok(h)) {
     switch (h->NB) {
       case 1: launch_jobs_fused<1>(h, first_slot, d_alive, d_blk_off, buf); break;
       case 2: launch_jobs_fused<2>(h, first_slot, d_alive, d_blk_off, buf); break;
@@ -1461,20 +1483,34 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
   // ms/step - four individuals per thread starve the f64 spline gathers of parallelism;
   // with one individual per thread of a 1024-thread workgroup and the scan left apart the
   // step takes the same 0.766 ms either way: the launches are not what the chain costs.)
-  GNXCHK(gnx_block_scan(h, 3, N, h->blk_cnt, h->blk_off, h->cnt_dev, h->h_pin_dev));
-  gnx_time_end(h, GNX_K_COMPACT, 0.0);
-  // the host only needs the counts: it waits for the scan, not for the compaction, and
-  // enqueues the next step's first kernels while the compaction still runs
-  HIPCHK(hipEventRecord(h->ev_counts, h->stream));
-  int has_rows = (h->genomes_assigned && c.L > 0) ? 1 : 0;
   // in-place compaction (k_fill_lists above): its lists are made on stream3 while this stream
   // builds the crossover's jobs
   // (a caller that names the dead by position - gnx_op_mortality - gets the survivors back in
   // their order: the stable compaction)
   const bool fill = h->compact_fill && !h->tiled && h->stream3 != nullptr && h->n_ghost == 0 &&
                     d_dead_inject == nullptr;
+  // ... and then the scan of the block counts moves there too: the job builder adds up the
+  // counts it needs itself (k_xo_jobs_fused: cnt3), the lists and the host get theirs from
+  // stream3, and this stream goes from the death draws straight to the job builder
+  static const bool side_scan_env = !(getenv("GNX_SIDE_SCAN") && atoi(getenv("GNX_SIDE_SCAN")) == 0);
+  const bool side_scan = side_scan_env && fill && xo && xo_B > 0 && jobs_fused_ok(h);
+  if (side_scan) {
+    HIPCHK(hipEventRecord(h->ev_alive, h->stream));
+    HIPCHK(hipStreamWaitEvent(h->stream3, h->ev_alive, 0));
+    GNXCHK(gnx_block_scan(h, 3, N, h->blk_cnt, h->blk_off, h->cnt_dev, h->h_pin_dev, 0, h->stream3));
+    gnx_time_end(h, GNX_K_COMPACT, 0.0);
+    HIPCHK(hipEventRecord(h->ev_counts, h->stream3));
+  } else {
+    GNXCHK(gnx_block_scan(h, 3, N, h->blk_cnt, h->blk_off, h->cnt_dev, h->h_pin_dev));
+    gnx_time_end(h, GNX_K_COMPACT, 0.0);
+    // the host only needs the counts: it waits for the scan, not for the compaction, and
+    // enqueues the next step's first kernels while the compaction still runs
+    HIPCHK(hipEventRecord(h->ev_counts, h->stream));
+  }
+  h->jobs_self_scan = side_scan;
+  int has_rows = (h->genomes_assigned && c.L > 0) ? 1 : 0;
   if (fill) {
-    HIPCHK(hipStreamWaitEvent(h->stream3, h->ev_counts, 0));
+    if (!side_scan) HIPCHK(hipStreamWaitEvent(h->stream3, h->ev_counts, 0));
     hipLaunchKernelGGL(k_fill_lists, dim3(nb), dim3(256), 0, h->stream3, N, h->flag, h->flag2,
                        h->blk_off, h->blk_stride, h->cnt_dev, a.grow, has_rows,
                        (int32_t*)h->os_ktmp, (int32_t*)h->os_ktmp + c.cap_inds / 2,
@@ -1486,6 +1522,7 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
   if (xo) {
     h->xo_deferred = false;
     GNXCHK(gnx_l_crossover_survivors(h, xo_first, xo_B, h->flag, h->blk_off));
+    h->jobs_self_scan = false;
     if (h->xo_sort_waits && h->xo_wait_at == 2) GNXCHK(gnx_xo_wait_inflight(h));
   }
   // the index's compaction of the PREVIOUS mortality round (stream3) still reads newslot when
