@@ -101,8 +101,14 @@ __global__ void k_spline_m(int Jx, int Jy, int along_x, double h, const double* 
     M[base + k * stride] = dp;
     dprev = dp;
   }
-  for (int k = J - 3; k >= 1; --k)
-    M[base + k * stride] -= cp[k] * M[base + (k + 1) * stride];
+  // (the value above rides in a register: read back from LDS every step of the chain waited
+  // for the step before's store)
+  double mnext = dprev;                          // = M[J - 2]
+  for (int k = J - 3; k >= 1; --k) {
+    const double m = M[base + k * stride] - cp[k] * mnext;
+    M[base + k * stride] = m;
+    mnext = m;
+  }
 }
 
 struct SplineC {
@@ -190,9 +196,30 @@ __device__ __forceinline__ void spline_line(int J, int64_t base, int64_t stride,
     M[base + k * stride] = dp;
     dprev = dp;
   }
-  for (int k = J - 3; k >= 1; --k)
-    M[base + k * stride] -= cp[k] * M[base + (k + 1) * stride];
+  // (the value above rides in a register: read back from LDS every step of the chain waited
+  // for the step before's store)
+  double mnext = dprev;                          // = M[J - 2]
+  for (int k = J - 3; k >= 1; --k) {
+    const double m = M[base + k * stride] - cp[k] * mnext;
+    M[base + k * stride] = m;
+    mnext = m;
+  }
 }
+
+// rows of V -> Mx on the first half of the workgroup, columns of V -> My on the second, at
+// the same time (one after the other on the same threads: twice the serial sweeps)
+__device__ __forceinline__ void spline_rows_and_cols(int Jx, int Jy, double hww, const double* cp,
+                                                     const double* V, double* Mx, double* My) {
+  const int half = blockDim.x / 2;
+  if ((int)threadIdx.x < half) {
+    for (int line = threadIdx.x; line < Jy; line += half)
+      spline_line(Jx, (int64_t)line * Jx, 1, hww, cp, V, Mx);
+  } else {
+    for (int line = threadIdx.x - half; line < Jx; line += half)
+      spline_line(Jy, line, Jx, hww, cp, V, My);
+  }
+}
+
 
 // use_lds: the four coefficient planes and the Thomas factors live in LDS while the
 // (dependent, one line per thread) sweeps run - a global round trip per element of a
@@ -238,10 +265,7 @@ k_lattice(int Jx, int Jy, int nbx, const int32_t* bins, const double* areas, dou
   // next use - this is the only workgroup that touches them)
   if (bins && zero_own)
     for (int k = threadIdx.x; k < nn; k += blockDim.x) const_cast<int32_t*>(bins)[k] = 0;
-  for (int line = threadIdx.x; line < Jy; line += blockDim.x)
-    spline_line(Jx, (int64_t)line * Jx, 1, hww, cp, V, Mx);
-  for (int line = threadIdx.x; line < Jx; line += blockDim.x)
-    spline_line(Jy, line, Jx, hww, cp, V, My);
+  spline_rows_and_cols(Jx, Jy, hww, cp, V, Mx, My);
   __syncthreads();
   for (int line = threadIdx.x; line < Jy; line += blockDim.x)
     spline_line(Jx, (int64_t)line * Jx, 1, hww, cp, My, Mxy);
@@ -408,10 +432,7 @@ k_lattice_nmax(int Jx, int Jy, int nbx, const int32_t* __restrict__ bins,
     V[idx] = (double)cnt / areas[idx];
   }
   __syncthreads();
-  for (int line = threadIdx.x; line < Jy; line += blockDim.x)
-    spline_line(Jx, (int64_t)line * Jx, 1, hww, cp, V, Mx);
-  for (int line = threadIdx.x; line < Jx; line += blockDim.x)
-    spline_line(Jy, line, Jx, hww, cp, V, My);
+  spline_rows_and_cols(Jx, Jy, hww, cp, V, Mx, My);
   __syncthreads();
   for (int line = threadIdx.x; line < Jy; line += blockDim.x)
     spline_line(Jx, (int64_t)line * Jx, 1, hww, cp, My, Mxy);
