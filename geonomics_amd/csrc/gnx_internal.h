@@ -406,6 +406,10 @@ struct gnx_state {
   int32_t* newslot = nullptr;    // [cap] where the last compaction put each slot (-1: dead)
   bool compact_fill = true;      // GNX_COMPACT_FILL=0 (read at gnx_create): always the stable copy
   bool jobs_self_scan = false;   // the job builder adds up the block counts itself (scan on stream3)
+  bool ord_covers_xo = false;    // ev_ord was recorded behind a wait for the crossover in flight
+  bool fb_pending = false;       // the adults' density bins are still to be counted (stream3)
+  const float *fbp_x = nullptr, *fbp_y = nullptr;
+  int64_t fbp_N = 0;
   hipEvent_t ev_alive = nullptr; // the death draws and their block counts are written
   int32_t* fill_cnt = nullptr;   // in-place compaction: the number of movers (device)
   hipEvent_t ev_fill = nullptr;  // its hole / mover lists are written (stream3)
@@ -569,6 +573,8 @@ int gnx_l_density_N(gnx_state* h);
 // the pairs' lattice from the bins k_pair_compact counted, on stream3
 int gnx_l_lattice_P_async(gnx_state* h, int64_t n_max);
 // the adults' bins (x, y: the sorted population), counted on stream3
+int gnx_bins_adults_launch(gnx_state* h);
+void gnx_bins_adults_drop(gnx_state* h);
 int gnx_l_bins_adults_async(gnx_state* h, const float* d_x, const float* d_y, int64_t N);
 int gnx_wait_latP(gnx_state* h);
 bool gnx_fused_bins(const gnx_state* h);

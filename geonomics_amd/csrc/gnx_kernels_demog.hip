@@ -651,6 +651,9 @@ int gnx_l_lattice_P_async(gnx_state* h, int64_t n_max) {
   GNXCHK(gnx_wait_latP(h));        // (a lattice of the last pair list nobody waited for)
   HIPCHK(hipEventRecord(h->ev_pairs, h->stream));
   HIPCHK(hipStreamWaitEvent(h->stream3, h->ev_pairs, 0));
+  // the adults' bins ride behind the same event (positions are final since the cell sort;
+  // an event of their own right after k_permute cost the main stream a record)
+  GNXCHK(gnx_bins_adults_launch(h));
   if (!h->fb_zero[2])
     HIPCHK(hipMemsetAsync(h->fb[2], 0, (size_t)nb * sizeof(int32_t), h->stream3));
   const int blocks = (int)std::min<int64_t>(BIN_BLOCKS, std::max<int64_t>(1, (n_max + 255) / 256));
@@ -681,19 +684,42 @@ int gnx_l_bins_adults_async(gnx_state* h, const float* d_x, const float* d_y, in
   // counts of the newborns)
   if (!h->fb_zero[cur])
     HIPCHK(hipMemsetAsync(h->fb[cur], 0, (size_t)nb * sizeof(int32_t), h->stream));
-  HIPCHK(hipEventRecord(h->ev_perm, h->stream));
-  HIPCHK(hipStreamWaitEvent(h->stream3, h->ev_perm, 0));
-  const int blocks = (int)std::min<int64_t>(BIN_BLOCKS, std::max<int64_t>(1, (N + 255) / 256));
-  hipLaunchKernelGGL(k_bins, dim3(blocks), dim3(256), (size_t)nb * sizeof(int32_t), h->stream3, N,
-                     (const int32_t*)nullptr, d_x, d_y, (const uint8_t*)nullptr, 1.0 / L.hww, L.nbx,
-                     L.nby, h->fb[cur]);
-  HIPCHK(hipEventRecord(h->ev_binsN, h->stream3));
-  HIPCHK(hipGetLastError());
-  h->binsN_inflight = true;
+  // launched on stream3 by whoever orders stream3 behind this stream next: the pairs' density
+  // (gnx_l_lattice_P_async), or gnx_l_density_N with an event of its own
+  h->fbp_x = d_x;
+  h->fbp_y = d_y;
+  h->fbp_N = N;
+  h->fb_pending = true;
   h->fb_zero[cur] = false;
   h->fb_adults = true;
   h->fb_count = N;
   return 0;
+}
+
+// stream3 is ordered behind the cell sort on `stream`: count the adults there
+int gnx_bins_adults_launch(gnx_state* h) {
+  if (!h->fb_pending) return 0;
+  h->fb_pending = false;
+  const GnxLattice& L = h->lat;
+  const int nb = L.nbx * L.nby;
+  const int64_t N = h->fbp_N;
+  const int blocks = (int)std::min<int64_t>(BIN_BLOCKS, std::max<int64_t>(1, (N + 255) / 256));
+  hipLaunchKernelGGL(k_bins, dim3(blocks), dim3(256), (size_t)nb * sizeof(int32_t), h->stream3, N,
+                     (const int32_t*)nullptr, h->fbp_x, h->fbp_y, (const uint8_t*)nullptr,
+                     1.0 / L.hww, L.nbx, L.nby, h->fb[h->fb_cur]);
+  HIPCHK(hipEventRecord(h->ev_binsN, h->stream3));
+  HIPCHK(hipGetLastError());
+  h->binsN_inflight = true;
+  return 0;
+}
+
+// positions or slots are about to change and nobody has counted: forget it (the density
+// counts everybody itself then)
+void gnx_bins_adults_drop(gnx_state* h) {
+  if (h->fb_pending) {
+    h->fb_pending = false;
+    h->fb_adults = false;
+  }
 }
 
 int gnx_l_density_N(gnx_state* h) {
@@ -709,6 +735,11 @@ int gnx_l_density_N(gnx_state* h) {
   const int64_t nn = (int64_t)L.Jx * L.Jy;
   const size_t lds_bytes = ((size_t)4 * nn + std::max(L.Jx, L.Jy) + 1 + 2 * L.Jx + 256) * sizeof(double);
   const int cur = h->fb_cur;
+  if (h->fb_pending) {           // (no pairs' density this step: an event of their own)
+    HIPCHK(hipEventRecord(h->ev_perm, h->stream));
+    HIPCHK(hipStreamWaitEvent(h->stream3, h->ev_perm, 0));
+    GNXCHK(gnx_bins_adults_launch(h));
+  }
   if (h->binsN_inflight) {
     HIPCHK(hipStreamWaitEvent(h->stream, h->ev_binsN, 0));
     h->binsN_inflight = false;
@@ -1477,6 +1508,7 @@ k_ord_write(int64_t N, int64_t ord_n, const int32_t* __restrict__ ord,
 int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_out) {
   int64_t N = h->N;
   *deaths_out = 0;
+  gnx_bins_adults_drop(h);
   if (N == 0) return 0;
   const gnx_config& c = h->cfg;
   GnxSoA a = h->soa[h->cur], b = h->soa[h->cur ^ 1];
@@ -1578,6 +1610,14 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
                        h->ord[h->ord_cur], h->newslot, h->ord_cnt, So);
     hipLaunchKernelGGL(k_ord_write, dim3(nb), dim3(256), 0, h->stream3, N, h->ord_n,
                        h->ord[h->ord_cur], h->newslot, h->ord_off, h->ord[h->ord_cur ^ 1]);
+    // the cell sort waits for the crossover AND for this: stream3 waits for the crossover here,
+    // where nothing waits for stream3, and the sort's stream waits for one event instead of two
+    h->ord_covers_xo = false;
+    if (h->xo_sort_waits && !h->xo_last_split && h->xo_ready_buf < 0) {
+      for (int k = 0; k < 2; ++k)
+        if (h->xo_inflight[k]) HIPCHK(hipStreamWaitEvent(h->stream3, h->ev_xo_done[k], 0));
+      h->ord_covers_xo = true;
+    }
     HIPCHK(hipEventRecord(h->ev_ord, h->stream3));
     h->ord_inflight = true;
     h->ord_cur ^= 1;

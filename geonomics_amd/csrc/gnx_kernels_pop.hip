@@ -332,7 +332,10 @@ k_move(MoveP P, GnxSoA s, const float* rast, const float* inj_theta, const float
 int gnx_l_move(gnx_state* h, bool inc_age, const float* inj_theta, const float* inj_dist,
                float* out_theta, float* out_dist, bool apply) {
   if (h->N == 0) return 0;
-  if (apply) h->fb_adults = false;        // bins counted before a movement are stale
+  if (apply) {                            // bins counted before a movement are stale
+    h->fb_adults = false;
+    h->fb_pending = false;
+  }
   const gnx_config& c = h->cfg;
   const gnx_species_params& sp = h->sp;
   MoveP P;
@@ -498,9 +501,20 @@ __global__ void k_iota(int64_t N, int32_t* v) {
 // Sort of the whole SoA by (hash cell, id); cell size >= mating radius.
 int gnx_l_sort_by_cell(gnx_state* h) {
   int64_t N = h->N;
+  gnx_bins_adults_drop(h);
   if (N == 0) return 0;
   GNXCHK(gnx_xo_flush_deferred(h));   // slots move: offspring still waiting for their crossover get it now
-  if (h->xo_sort_waits) GNXCHK(gnx_xo_wait_wide(h));   // the radix sort runs alone, or beside a narrow tail
+  // the radix sort runs alone, or beside a narrow tail.  (The index's compaction on stream3
+  // has already waited for the crossover it was launched with - gnx_l_mortality - and this
+  // stream is about to wait for that compaction: one event covers both.)
+  const bool xo_covered = h->xo_sort_waits && h->ord_covers_xo && h->ord_inflight && h->tile_evict == 0 &&
+                          (h->keys_fresh ? h->keys_ordmode : gnx_ord_sort(h));
+  if (xo_covered) {
+    for (int k = 0; k < 2; ++k) h->xo_inflight[k] = h->xo_wide_inflight[k] = false;
+    h->ord_covers_xo = false;
+  } else if (h->xo_sort_waits) {
+    GNXCHK(gnx_xo_wait_wide(h));
+  }
   const gnx_config& c = h->cfg;
   GnxSoA a = h->soa[h->cur], b = h->soa[h->cur ^ 1];
   const int idbits = gnx_id_bits(h);
