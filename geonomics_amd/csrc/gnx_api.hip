@@ -1088,16 +1088,6 @@ extern "C" int gnx_step(gnx_state* h, int32_t burn, int32_t with_selection) {
   } else {
     GNXCHK(gnx_l_age(h));
   }
-  {
-    // (experiment: what an event record / a wait on a recorded event costs the stream)
-    static const int dummy = getenv("GNX_DUMMY_EVENTS") ? atoi(getenv("GNX_DUMMY_EVENTS")) : 0;
-    static const int dummyw = getenv("GNX_DUMMY_WAITS") ? atoi(getenv("GNX_DUMMY_WAITS")) : 0;
-    for (int k = 0; k < dummy; ++k) HIPCHK(hipEventRecord(h->ev_alive, h->stream));
-    for (int k = 0; k < dummyw; ++k) {
-      HIPCHK(hipEventRecord(h->ev_alive, h->stream3));
-      HIPCHK(hipStreamWaitEvent(h->stream, h->ev_alive, 0));
-    }
-  }
   GNXCHK(gnx_pop_dynamics(h, burn, with_selection));
   h->step += 1;
   return 0;
