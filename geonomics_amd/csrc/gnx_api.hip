@@ -375,6 +375,7 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
   GNXCHK(dalloc(&h->fill_cnt, 4));
   HIPCHK(hipEventCreateWithFlags(&h->ev_fill, gnx_order_event_flags()));
   HIPCHK(hipEventCreateWithFlags(&h->ev_alive, gnx_order_event_flags()));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_perm_rest, gnx_order_event_flags()));
   {
     // (zero between sorts: k_permute wipes what a sort dirtied; + 16: the wipe is in uint4s)
     const size_t nb = gnx_os_scratch_bytes((size_t)cap, 24) + 16;
@@ -524,6 +525,7 @@ extern "C" void gnx_destroy(gnx_state* h) {
   if (h->ev_compact) (void)hipEventDestroy(h->ev_compact);
   if (h->ev_fill) (void)hipEventDestroy(h->ev_fill);
   if (h->ev_alive) (void)hipEventDestroy(h->ev_alive);
+  if (h->ev_perm_rest) (void)hipEventDestroy(h->ev_perm_rest);
   if (h->ev_pairs) (void)hipEventDestroy(h->ev_pairs);
   if (h->ev_latP) (void)hipEventDestroy(h->ev_latP);
   if (h->ev_perm) (void)hipEventDestroy(h->ev_perm);
@@ -1038,11 +1040,15 @@ extern "C" int gnx_pop_dynamics_mate(gnx_state* h, int32_t burn) {
   GNXCHK(check_recomb_ready(h, burn != 0));
   int64_t P = 0, B = 0;
   // 1. mating pairs (cell-sorted population)
-  GNXCHK(gnx_l_sort_by_cell(h));
+  //    (the columns the mate search and the pair list do not read are permuted on the side
+  //    stream meanwhile, and waited for before the births)
+  GNXCHK(gnx_l_sort_by_cell(h, true));
   // 2. n_pairs density of the pair midpoints (ops/demography.py:60-91), launched inside
   //    find_pairs while the pair count travels to the host
   static const bool early = !(getenv("GNX_EARLY_DENSITY") && atoi(getenv("GNX_EARLY_DENSITY")) == 0);
-  GNXCHK(gnx_l_find_pairs(h, nullptr, &P, early));
+  int rc_pairs = gnx_l_find_pairs(h, nullptr, &P, early);
+  GNXCHK(gnx_wait_permute_rest(h));
+  GNXCHK(rc_pairs);
   if (P > 0 && !h->spl_P.valid)
     GNXCHK(gnx_l_density(h, P, h->mid_x, h->mid_y, &h->spl_P, nullptr));
   // 3. births: dispersal, crossover, phenotype

@@ -407,6 +407,8 @@ struct gnx_state {
   bool compact_fill = true;      // GNX_COMPACT_FILL=0 (read at gnx_create): always the stable copy
   bool jobs_self_scan = false;   // the job builder adds up the block counts itself (scan on stream3)
   bool ord_covers_xo = false;    // ev_ord was recorded behind a wait for the crossover in flight
+  bool perm_rest_inflight = false;  // k_permute_rest (stream3) has not been waited for
+  hipEvent_t ev_perm_rest = nullptr;
   bool fb_pending = false;       // the adults' density bins are still to be counted (stream3)
   const float *fbp_x = nullptr, *fbp_y = nullptr;
   int64_t fbp_N = 0;
@@ -509,7 +511,8 @@ int gnx_l_gather_e(gnx_state* h, int64_t first, int64_t n);
 int gnx_l_age(gnx_state* h);
 int gnx_l_move(gnx_state* h, bool inc_age, const float* inj_theta, const float* inj_dist,
                float* out_theta, float* out_dist, bool apply);
-int gnx_l_sort_by_cell(gnx_state* h);
+int gnx_l_sort_by_cell(gnx_state* h, bool split_rest = false);
+int gnx_wait_permute_rest(gnx_state* h);
 // with_density: the n_pairs density (ops/demography.py:60-91) is launched before the host
 // has read the pair count back, so the GPU works through the round trip
 int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out,

@@ -439,7 +439,7 @@ __global__ void k_permute(int64_t N, int64_t cap, const int32_t* perm, GnxSoA a,
                           int32_t* cell_start, int ncells, const uint32_t* __restrict__ cellk,
                           const int32_t* __restrict__ ord, int64_t ord_n,
                           int32_t* __restrict__ ord_new, int32_t* __restrict__ perm_out,
-                          uint4* __restrict__ wipe, int64_t wipe_n) {
+                          uint4* __restrict__ wipe, int64_t wipe_n, int hot_only) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   // the radix sort's scratch (histograms, look-back states) is zero again for the next sort:
   // no fill kernels in front of it (two, 6 us each, on the step's critical path)
@@ -463,15 +463,64 @@ __global__ void k_permute(int64_t N, int64_t cap, const int32_t* perm, GnxSoA a,
     ord_new[kk] = (int32_t)i;                   // and the slot it is in now
     perm_out[i] = (int32_t)j;                   // (the sort permutation, as the other path leaves it)
   }
-  // the whole record in registers before the first store (GnxRec, gnx_internal.h)
-  const GnxRec r = gnx_rec_load(a, j, cap, n_layers, n_traits, tbw);       // tbw = 2 * TW
   const uint32_t ck = cellk ? cellk[i] : 0u;
-  gnx_rec_store(b, i, cap, n_layers, n_traits, tbw, r);
+  GnxRec r;
+  if (hot_only) {
+    // what the mate search and the pair list read: position, age, sex, id, ghost flag; the
+    // other columns follow on the side stream (k_permute_rest) while those run
+    r.x = a.x[j];
+    r.y = a.y[j];
+    r.age = a.age[j];
+    r.sex = a.sex[j];
+    r.id = a.id[j];
+    r.ghost = a.ghost[j];
+    b.x[i] = r.x;
+    b.y[i] = r.y;
+    b.age[i] = r.age;
+    b.sex[i] = r.sex;
+    b.id[i] = r.id;
+    b.ghost[i] = r.ghost;
+  } else {
+    // the whole record in registers before the first store (GnxRec, gnx_internal.h)
+    r = gnx_rec_load(a, j, cap, n_layers, n_traits, tbw);       // tbw = 2 * TW
+    gnx_rec_store(b, i, cap, n_layers, n_traits, tbw, r);
+  }
   if (cellk) key[i] = ((uint64_t)ck << idbits) | (uint64_t)r.id;   // what the pair list reads
   const uint32_t tg = gnx_ind_tag(pair_seed, (unsigned long long)r.id);
   tag[i] = tg;
   // packed candidate record for the mate search: one 16-byte load per candidate
   cand[i] = make_uint4(__float_as_uint(r.x), __float_as_uint(r.y), tg, (uint32_t)r.id);
+  if (!hot_only) gnx_rec_rest(a, j, b, i, cap, n_layers, n_traits, tbw);
+}
+
+// the columns k_permute(hot_only) left behind: fitness, genome row, environment,
+// phenotypes, alleles at the selected loci; perm[i] = the slot sorted position i came from
+__global__ void k_permute_rest(int64_t N, int64_t cap, const int32_t* __restrict__ perm, GnxSoA a,
+                               GnxSoA b, int n_layers, int n_traits, int tbw) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int64_t j = perm[i];
+  const float fit = a.fit[j];
+  const int32_t grow = a.grow[j];
+  float e[4], z[4];
+  uint64_t tb[4];
+#pragma unroll
+  for (int l = 0; l < 4; ++l) e[l] = l < n_layers ? a.e[(int64_t)l * cap + j] : 0.0f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) z[t] = t < n_traits ? a.z[(int64_t)t * cap + j] : 0.0f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) tb[w] = w < tbw ? a.tb[j * tbw + w] : 0ull;
+  b.fit[i] = fit;
+  b.grow[i] = grow;
+#pragma unroll
+  for (int l = 0; l < 4; ++l)
+    if (l < n_layers) b.e[(int64_t)l * cap + i] = e[l];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    if (t < n_traits) b.z[(int64_t)t * cap + i] = z[t];
+#pragma unroll
+  for (int w = 0; w < 4; ++w)
+    if (w < tbw) b.tb[i * tbw + w] = tb[w];
   gnx_rec_rest(a, j, b, i, cap, n_layers, n_traits, tbw);
 }
 
@@ -498,10 +547,20 @@ __global__ void k_iota(int64_t N, int32_t* v) {
   if (i < N) v[i] = (int32_t)i;
 }
 
+// the side stream's share of the last cell sort's permutation has arrived
+int gnx_wait_permute_rest(gnx_state* h) {
+  if (h->perm_rest_inflight) {
+    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_perm_rest, 0));
+    h->perm_rest_inflight = false;
+  }
+  return 0;
+}
+
 // Sort of the whole SoA by (hash cell, id); cell size >= mating radius.
-int gnx_l_sort_by_cell(gnx_state* h) {
+int gnx_l_sort_by_cell(gnx_state* h, bool split_rest) {
   int64_t N = h->N;
   gnx_bins_adults_drop(h);
+  GNXCHK(gnx_wait_permute_rest(h));
   if (N == 0) return 0;
   GNXCHK(gnx_xo_flush_deferred(h));   // slots move: offspring still waiting for their crossover get it now
   // the radix sort runs alone, or beside a narrow tail.  (The index's compaction on stream3
@@ -573,12 +632,25 @@ int gnx_l_sort_by_cell(gnx_state* h) {
   h->keys_fresh = false;
   gnx_time_end(h, GNX_K_SORT, (double)N * 40.0);
   gnx_time_begin(h);
+  static const bool split_env = !(getenv("GNX_PERMUTE_SPLIT") && atoi(getenv("GNX_PERMUTE_SPLIT")) == 0);
+  const bool split = split_rest && split_env && ordm && !h->tiled && h->stream3 != nullptr;
   hipLaunchKernelGGL(k_permute, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, c.cap_inds,
                      ordm ? h->valk[1] : h->perm[1], a, b, c.n_layers, c.n_traits,
                      a.tb ? 2 * h->TW : 0, gnx_pair_seed(c.seed, h->step), h->tag, (uint4*)h->cand,
                      h->key64[1], idbits, h->cell_start, h->ncx * h->ncy,
                      ordm ? h->keyk[1] : nullptr, h->ord[h->ord_cur], h->ord_n,
-                     h->ord[h->ord_cur ^ 1], h->perm[1], (uint4*)h->os_scratch, (wipe_words + 3) / 4);
+                     h->ord[h->ord_cur ^ 1], h->perm[1], (uint4*)h->os_scratch, (wipe_words + 3) / 4,
+                     split ? 1 : 0);
+  if (split) {
+    // the columns nobody reads before the births follow on stream3, beside the mate search and
+    // the pair list; whoever asked for the split waits (gnx_wait_permute_rest)
+    HIPCHK(hipEventRecord(h->ev_perm, h->stream));
+    HIPCHK(hipStreamWaitEvent(h->stream3, h->ev_perm, 0));
+    hipLaunchKernelGGL(k_permute_rest, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream3, N,
+                       c.cap_inds, h->perm[1], a, b, c.n_layers, c.n_traits, a.tb ? 2 * h->TW : 0);
+    HIPCHK(hipEventRecord(h->ev_perm_rest, h->stream3));
+    h->perm_rest_inflight = true;
+  }
   gnx_time_end(h, GNX_K_PERMUTE,
                (double)N * 2.0 * (33.0 + 4.0 * c.n_layers + 4.0 * c.n_traits + 16.0 * h->TW));
   // the individuals' density bins (positions are final for this step): counted on stream3,
