@@ -461,6 +461,7 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
   h->defer_xo = !(getenv("GNX_DEFER_XO") && atoi(getenv("GNX_DEFER_XO")) == 0);
   if (getenv("GNX_XO_LAUNCH")) h->xo_launch_policy = atoi(getenv("GNX_XO_LAUNCH"));
   if (getenv("GNX_COMPACT_FILL")) h->compact_fill = atoi(getenv("GNX_COMPACT_FILL")) != 0;
+  if (getenv("GNX_PERMUTE_SPLIT")) h->permute_split = atoi(getenv("GNX_PERMUTE_SPLIT")) != 0;
   if (getenv("GNX_XO_SORT_WAIT")) h->xo_sort_waits = atoi(getenv("GNX_XO_SORT_WAIT")) != 0;
   if (getenv("GNX_XO_WAIT")) h->xo_wait_at = atoi(getenv("GNX_XO_WAIT"));
   if (getenv("GNX_XO_SPLIT")) h->xo_split = std::min(1024, std::max(0, atoi(getenv("GNX_XO_SPLIT"))));

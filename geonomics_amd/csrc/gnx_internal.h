@@ -407,6 +407,7 @@ struct gnx_state {
   bool compact_fill = true;      // GNX_COMPACT_FILL=0 (read at gnx_create): always the stable copy
   bool jobs_self_scan = false;   // the job builder adds up the block counts itself (scan on stream3)
   bool ord_covers_xo = false;    // ev_ord was recorded behind a wait for the crossover in flight
+  bool permute_split = true;        // GNX_PERMUTE_SPLIT=0 (read at gnx_create): one k_permute for every column
   bool perm_rest_inflight = false;  // k_permute_rest (stream3) has not been waited for
   hipEvent_t ev_perm_rest = nullptr;
   bool fb_pending = false;       // the adults' density bins are still to be counted (stream3)

@@ -632,8 +632,7 @@ int gnx_l_sort_by_cell(gnx_state* h, bool split_rest) {
   h->keys_fresh = false;
   gnx_time_end(h, GNX_K_SORT, (double)N * 40.0);
   gnx_time_begin(h);
-  static const bool split_env = !(getenv("GNX_PERMUTE_SPLIT") && atoi(getenv("GNX_PERMUTE_SPLIT")) == 0);
-  const bool split = split_rest && split_env && ordm && !h->tiled && h->stream3 != nullptr;
+  const bool split = split_rest && h->permute_split && ordm && !h->tiled && h->stream3 != nullptr;
   hipLaunchKernelGGL(k_permute, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, c.cap_inds,
                      ordm ? h->valk[1] : h->perm[1], a, b, c.n_layers, c.n_traits,
                      a.tb ? 2 * h->TW : 0, gnx_pair_seed(c.seed, h->step), h->tag, (uint4*)h->cand,

@@ -237,7 +237,10 @@ def test_in_place_compaction_equals_stable_copy(monkeypatch):
     rasts = np.stack([np.ones((H, W)), np.tile(np.linspace(0, 1, W), (H, 1))]).astype(np.float32)
     devs = []
     for flag in ('1', '0'):
+        # (the stable copy's twin also permutes every column in one kernel: the split
+        # permutation - k_permute + k_permute_rest on the side stream - is compared as well)
         monkeypatch.setenv('GNX_COMPACT_FILL', flag)
+        monkeypatch.setenv('GNX_PERMUTE_SPLIT', flag)
         dev = make_dev(W, H, rasts=rasts, L=L, n_traits=1, cap=16384, seed=8, mating_radius=3.0,
                        K_factor=1.9, max_age=9)
         dev.set_trait(0, np.array([5, 300, 611, 842]), np.array([0.1, -0.1, 0.1, -0.1]), 1, 0.05,
@@ -248,6 +251,7 @@ def test_in_place_compaction_equals_stable_copy(monkeypatch):
         dev.set_z()
         devs.append(dev)
     monkeypatch.delenv('GNX_COMPACT_FILL')
+    monkeypatch.delenv('GNX_PERMUTE_SPLIT')
     a, b = devs
     moved = False
     for t in range(15):
