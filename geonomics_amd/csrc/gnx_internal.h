@@ -409,6 +409,9 @@ struct gnx_state {
   bool ord_covers_xo = false;    // ev_ord was recorded behind a wait for the crossover in flight
   bool permute_split = true;        // GNX_PERMUTE_SPLIT=0 (read at gnx_create): one k_permute for every column
   bool perm_rest_inflight = false;  // k_permute_rest (stream3) has not been waited for
+  bool perm_rest_pending = false;   // ... has not been launched yet
+  GnxSoA perm_rest_a{}, perm_rest_b{};
+  int64_t perm_rest_N = 0;
   hipEvent_t ev_perm_rest = nullptr;
   bool fb_pending = false;       // the adults' density bins are still to be counted (stream3)
   const float *fbp_x = nullptr, *fbp_y = nullptr;
@@ -514,6 +517,7 @@ int gnx_l_move(gnx_state* h, bool inc_age, const float* inj_theta, const float* 
                float* out_theta, float* out_dist, bool apply);
 int gnx_l_sort_by_cell(gnx_state* h, bool split_rest = false);
 int gnx_wait_permute_rest(gnx_state* h);
+int gnx_permute_rest_launch(gnx_state* h);
 // with_density: the n_pairs density (ops/demography.py:60-91) is launched before the host
 // has read the pair count back, so the GPU works through the round trip
 int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out,

@@ -547,8 +547,25 @@ __global__ void k_iota(int64_t N, int32_t* v) {
   if (i < N) v[i] = (int32_t)i;
 }
 
+// stream3 takes the columns k_permute(hot_only) left behind, from here on in `stream`'s order
+int gnx_permute_rest_launch(gnx_state* h) {
+  if (!h->perm_rest_pending) return 0;
+  h->perm_rest_pending = false;
+  const gnx_config& c = h->cfg;
+  HIPCHK(hipEventRecord(h->ev_perm, h->stream));
+  HIPCHK(hipStreamWaitEvent(h->stream3, h->ev_perm, 0));
+  hipLaunchKernelGGL(k_permute_rest, dim3(gnx_grid(h->perm_rest_N, 256)), dim3(256), 0, h->stream3,
+                     h->perm_rest_N, c.cap_inds, h->perm[1], h->perm_rest_a, h->perm_rest_b,
+                     c.n_layers, c.n_traits, h->perm_rest_a.tb ? 2 * h->TW : 0);
+  HIPCHK(hipEventRecord(h->ev_perm_rest, h->stream3));
+  HIPCHK(hipGetLastError());
+  h->perm_rest_inflight = true;
+  return 0;
+}
+
 // the side stream's share of the last cell sort's permutation has arrived
 int gnx_wait_permute_rest(gnx_state* h) {
+  GNXCHK(gnx_permute_rest_launch(h));
   if (h->perm_rest_inflight) {
     HIPCHK(hipStreamWaitEvent(h->stream, h->ev_perm_rest, 0));
     h->perm_rest_inflight = false;
@@ -642,13 +659,15 @@ int gnx_l_sort_by_cell(gnx_state* h, bool split_rest) {
                      split ? 1 : 0);
   if (split) {
     // the columns nobody reads before the births follow on stream3, beside the mate search and
-    // the pair list; whoever asked for the split waits (gnx_wait_permute_rest)
-    HIPCHK(hipEventRecord(h->ev_perm, h->stream));
-    HIPCHK(hipStreamWaitEvent(h->stream3, h->ev_perm, 0));
-    hipLaunchKernelGGL(k_permute_rest, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream3, N,
-                       c.cap_inds, h->perm[1], a, b, c.n_layers, c.n_traits, a.tb ? 2 * h->TW : 0);
-    HIPCHK(hipEventRecord(h->ev_perm_rest, h->stream3));
-    h->perm_rest_inflight = true;
+    // the pair list; whoever asked for the split waits (gnx_wait_permute_rest).
+    // (GNX_PERMUTE_REST_AT=1: only behind the mate search, whose random 16-byte loads they
+    // slow - 0.596 against 0.592 ms/step: they are then late for the births)
+    h->perm_rest_a = a;
+    h->perm_rest_b = b;
+    h->perm_rest_N = N;
+    h->perm_rest_pending = true;
+    static const int rest_at = getenv("GNX_PERMUTE_REST_AT") ? atoi(getenv("GNX_PERMUTE_REST_AT")) : 0;
+    if (rest_at == 0) GNXCHK(gnx_permute_rest_launch(h));
   }
   gnx_time_end(h, GNX_K_PERMUTE,
                (double)N * 2.0 * (33.0 + 4.0 * c.n_layers + 4.0 * c.n_traits + 16.0 * h->TW));
@@ -1272,6 +1291,7 @@ int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out, 
                          h->inv_cs, h->cell_start, h->ncx, h->ncy, h->cell_ref, r, r2, easy, h->mate);
   }
   gnx_time_end(h, GNX_K_FIND_MATES, (double)N * 16.0);
+  GNXCHK(gnx_permute_rest_launch(h));       // (GNX_PERMUTE_REST_AT=1: not before the mate search)
   gnx_time_begin(h);
   const int nb = (int)((N + GNX_CB - 1) / GNX_CB);
   PairP pp{N, focal, h->mate, d_keep, (float)sp.b, sexed, sp.repro_age[0], sp.repro_age[1],
