@@ -271,10 +271,17 @@ k_move(MoveP P, GnxSoA s, const float* rast, const float* inj_theta, const float
   __shared__ int surf_box[4];
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool act = i < P.N;
+  // every load that does not depend on the draw goes out with the position: beside the
+  // crossover a memory round trip costs several microseconds, and id and age each had one of
+  // their own further down the thread's chain
   float x = 0.f, y = 0.f;
+  unsigned long long id = 0ull;
+  int32_t age0 = 0;
   if (act) {
     x = s.x[i];
     y = s.y[i];
+    id = (unsigned long long)s.id[i];
+    if (P.apply && P.inc_age) age0 = s.age[i];
   }
   float nb[8];
   bool have_nb = false;
@@ -285,7 +292,6 @@ k_move(MoveP P, GnxSoA s, const float* rast, const float* inj_theta, const float
     if (!have_nb && act) surf_neighbours(cond, P.W, P.H, (int)x, (int)y, nb);
   }
   if (!act) return;
-  unsigned long long id = (unsigned long long)s.id[i];
   float theta, dist;
   if (inj_theta) {
     theta = inj_theta[i];
@@ -313,7 +319,7 @@ k_move(MoveP P, GnxSoA s, const float* rast, const float* inj_theta, const float
   float ny = fminf(fmaxf(y + dy, 0.0f), P.ymax);
   s.x[i] = nx;
   s.y[i] = ny;
-  if (P.inc_age) s.age[i] += 1;
+  if (P.inc_age) s.age[i] = age0 + 1;
   int cx = (int)nx, cy = (int)ny;
   for (int l = 0; l < P.n_layers; ++l)
     s.e[(int64_t)l * P.cap + i] = rast[((int64_t)l * P.H + cy) * P.W + cx];
