@@ -492,8 +492,7 @@ __global__ void k_permute(int64_t N, int64_t cap, const int32_t* perm, GnxSoA a,
     gnx_rec_store(b, i, cap, n_layers, n_traits, tbw, r);
   }
   if (cellk) key[i] = ((uint64_t)ck << idbits) | (uint64_t)r.id;   // what the pair list reads
-  const uint32_t tg = gnx_ind_tag(pair_seed, (unsigned long long)r.id);
-  tag[i] = tg;
+  const uint32_t tg = gnx_ind_tag(pair_seed, (unsigned long long)r.id);   // (rides in the candidate record)
   // packed candidate record for the mate search: one 16-byte load per candidate
   cand[i] = make_uint4(__float_as_uint(r.x), __float_as_uint(r.y), tg, (uint32_t)r.id);
   if (!hot_only) gnx_rec_rest(a, j, b, i, cap, n_layers, n_traits, tbw);
