@@ -46,7 +46,8 @@ EXPORTS = [
     'gnx_tile_offspring_dev', 'gnx_tile_group_requests', 'gnx_tile_serve_gametes_dev',
     'gnx_tile_put_gametes_dev', 'gnx_tile_bins_ptr', 'gnx_set_k_raster', 'gnx_last_births', 'gnx_set_positions', 'gnx_n_slots', 'gnx_stats_ld_counts',
     'gnx_set_defer_crossover', 'gnx_last_crossover_births', 'gnx_set_crossover_overlap', 'gnx_set_crossover_split', 'gnx_debug_halves', 'gnx_spatial_diff_sums', 'gnx_last_crossover_jobs',
-    'gnx_genome_info', 'gnx_measure_copy',
+    'gnx_genome_info', 'gnx_measure_copy', 'gnx_totals', 'gnx_reset_totals',
+    'gnx_step_begin', 'gnx_step_mid', 'gnx_step_end', 'gnx_step_many',
     'gnx_stream_ptr', 'gnx_tile2_move_route', 'gnx_tile2_route_ptrs', 'gnx_tile2_import',
     'gnx_tile2_pairs', 'gnx_tile2_offspring', 'gnx_tile2_serve', 'gnx_tile2_put',
     'gnx_tile2_finish_births', 'gnx_tile2_die', 'gnx_tile_pair_ptrs_nosync',
@@ -279,10 +280,30 @@ class Device:
         self._chk(self.lib.gnx_step(self.h, int(bool(burn)),
                                     int(bool(with_selection))))
 
+    def step_begin(self, burn):
+        self._chk(self.lib.gnx_step_begin(self.h, int(bool(burn))))
+
+    def step_mid(self, burn, with_selection):
+        self._chk(self.lib.gnx_step_mid(self.h, int(bool(burn)), int(bool(with_selection))))
+
+    def step_end(self, burn):
+        self._chk(self.lib.gnx_step_end(self.h, int(bool(burn))))
+
     def counts(self):
         n, b, d = C.c_int64(), C.c_int64(), C.c_int64()
         self._chk(self.lib.gnx_counts(self.h, C.byref(n), C.byref(b), C.byref(d)))
         return n.value, b.value, d.value
+
+    def totals(self):
+        """dict(steps, ind_steps, births, deaths, xo_births) summed over the gnx_step calls
+        since reset_totals() - host-side bookkeeping of the library, no device access"""
+        out = np.zeros(6, np.int64)
+        self._chk(self.lib.gnx_totals(self.h, _ptr(out, C.c_int64)))
+        return dict(zip(('steps', 'ind_steps', 'births', 'deaths', 'xo_births'),
+                        (int(v) for v in out)))
+
+    def reset_totals(self):
+        self._chk(self.lib.gnx_reset_totals(self.h))
 
     @property
     def N(self):
@@ -796,6 +817,16 @@ def measure_copy(nbytes=8 << 30, reps=5):
     if lib.gnx_measure_copy(C.c_int64(int(nbytes)), int(reps), C.byref(out)):
         raise GnxError(lib.gnx_last_error().decode())
     return out.value
+
+
+def step_many(devs, burn, with_selection):
+    """one time step of several independent Devices (the iterations of one model), their
+    kernels side by side on the handles' own streams (gnx_step_many)"""
+    if not devs:
+        return
+    arr = (C.c_void_p * len(devs))(*[d.h for d in devs])
+    devs[0]._chk(devs[0].lib.gnx_step_many(arr, len(devs), int(bool(burn)),
+                                           int(bool(with_selection))))
 
 
 def default_species_params(**kw):

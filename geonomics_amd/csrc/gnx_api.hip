@@ -1076,17 +1076,34 @@ extern "C" int gnx_pop_dynamics(gnx_state* h, int32_t burn, int32_t with_selecti
   return gnx_pop_dynamics_die(h, burn, with_selection);
 }
 
-extern "C" int gnx_step(gnx_state* h, int32_t burn, int32_t with_selection) {
-  GNXCHK(need_params(h));
-  struct T {
-    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-    ~T() {
-      if (gnx_host_times()) {
-        g_host_step_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        ++g_host_steps;
-      }
+// One step in three parts, so that several handles can be stepped side by side from one
+// host thread (gnx_step_many): _begin enqueues age, movement, cell sort, mate search and the
+// pair list; _mid reads the pair count and enqueues births, densities, death probabilities,
+// death draws, compaction and the crossover; _end reads the survivor counts.  Each handle
+// has its own three streams: what one handle enqueues runs beside the others' kernels.
+struct GnxStepTimer {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  bool count;
+  explicit GnxStepTimer(bool c) : count(c) {}
+  ~GnxStepTimer() {
+    if (gnx_host_times()) {
+      g_host_step_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (count) ++g_host_steps;
     }
-  } timer;
+  }
+};
+
+extern "C" int gnx_step_begin(gnx_state* h, int32_t burn) {
+  GNXCHK(need_params(h));
+  GNXCHK(check_recomb_ready(h, burn != 0));
+  GnxStepTimer timer(true);
+  if (h->mort_wait || h->pairs_wait) {
+    gnx_set_error("gnx_step_begin: the previous step of this handle was not finished (gnx_step_end)");
+    return 1;
+  }
+  h->tot[0] += 1;
+  h->tot[1] += h->N - h->n_ghost;
+  h->last_xo_births = 0;
   if (h->sp.move) {
     h->move_writes_keys = h->sp.mating_radius >= 0;     // the cell sort follows at once
     int rc = gnx_l_move(h, true, nullptr, nullptr, nullptr, nullptr, true);
@@ -1095,8 +1112,68 @@ extern "C" int gnx_step(gnx_state* h, int32_t burn, int32_t with_selection) {
   } else {
     GNXCHK(gnx_l_age(h));
   }
-  GNXCHK(gnx_pop_dynamics(h, burn, with_selection));
+  // mating pairs (cell-sorted population; the columns the mate search and the pair list do
+  // not read are permuted on the side stream meanwhile, and waited for before the births);
+  // the n_pairs density of the pair midpoints (ops/demography.py:60-91) is launched with the
+  // pair list, while the pair count travels to the host
+  GNXCHK(gnx_l_sort_by_cell(h, true));
+  static const bool early = !(getenv("GNX_EARLY_DENSITY") && atoi(getenv("GNX_EARLY_DENSITY")) == 0);
+  int rc_pairs = gnx_l_find_pairs_enqueue(h, nullptr, early);
+  GNXCHK(gnx_wait_permute_rest(h));
+  return rc_pairs;
+}
+
+extern "C" int gnx_step_mid(gnx_state* h, int32_t burn, int32_t with_selection) {
+  GnxStepTimer timer(false);
+  int64_t P = 0, B = 0;
+  GNXCHK(gnx_l_find_pairs_finish(h, &P));
+  if (P > 0 && !h->spl_P.valid)
+    GNXCHK(gnx_l_density(h, P, h->mid_x, h->mid_y, &h->spl_P, nullptr));
+  // births: dispersal, alleles at the selected loci, phenotype
+  GNXCHK(gnx_l_mate(h, burn != 0, false, 0, &B));
+  h->last_births = B;
+  // N density of everyone incl. offspring (structs/species.py:845-882); d at each
+  // individual's cell, fitness, death probability; mortality
+  GNXCHK(gnx_l_density_N(h));
+  GNXCHK(gnx_l_death_probs(h, with_selection != 0 && !burn));
+  return gnx_l_mortality_enqueue(h, nullptr);
+}
+
+extern "C" int gnx_step_end(gnx_state* h, int32_t burn) {
+  GnxStepTimer timer(false);
+  int64_t D = 0;
+  GNXCHK(gnx_l_mortality_finish(h, &D));
+  h->last_deaths = D;
   h->step += 1;
+  h->tot[2] += h->last_births;
+  h->tot[3] += h->last_deaths;
+  if (!burn) h->tot[4] += h->last_xo_births;
+  return 0;
+}
+
+extern "C" int gnx_step(gnx_state* h, int32_t burn, int32_t with_selection) {
+  GNXCHK(gnx_step_begin(h, burn));
+  GNXCHK(gnx_step_mid(h, burn, with_selection));
+  return gnx_step_end(h, burn);
+}
+
+// n independent handles (the iterations of one model, sim/model.py:866-953 - the reference
+// runs them one after another and notes at :924-925 that they could be farmed out), one step
+// each: all first thirds, then all second thirds, then all last thirds.
+extern "C" int gnx_step_many(gnx_state** hs, int32_t n, int32_t burn, int32_t with_selection) {
+  for (int k = 0; k < n; ++k) GNXCHK(gnx_step_begin(hs[k], burn));
+  for (int k = 0; k < n; ++k) GNXCHK(gnx_step_mid(hs[k], burn, with_selection));
+  for (int k = 0; k < n; ++k) GNXCHK(gnx_step_end(hs[k], burn));
+  return 0;
+}
+
+extern "C" int gnx_totals(gnx_state* h, int64_t* out) {
+  for (int k = 0; k < 6; ++k) out[k] = h->tot[k];
+  return 0;
+}
+
+extern "C" int gnx_reset_totals(gnx_state* h) {
+  for (int k = 0; k < 6; ++k) h->tot[k] = 0;
   return 0;
 }
 

@@ -176,6 +176,7 @@ struct gnx_state {
   int64_t max_id = -1;
   int64_t step = 0;            // global step counter (RNG addressing)
   int64_t last_births = 0, last_deaths = 0;
+  int64_t tot[6]{};            // gnx_totals: steps, sum of N at step start, births, deaths, crossover births
   int64_t n_ghost = 0;         // ghosts currently resident (counted in N)
 
   GnxSoA soa[2]{};
@@ -363,6 +364,16 @@ struct gnx_state {
   float* mid_x = nullptr;        // pair midpoints
   float* mid_y = nullptr;
   int64_t n_pairs = 0;
+  // the two host read-backs of a step, each split into the half that enqueues and the half
+  // that waits (gnx_step_begin / _mid / _end; several handles stepped side by side enqueue
+  // all their first halves before any of them waits): what the first half left behind
+  bool pairs_wait = false;           // gnx_l_find_pairs_enqueue ran, its count is not read yet
+  int64_t pairs_seq = 0;
+  bool pairs_with_top = false, pairs_with_density = false;
+  bool mort_wait = false;            // gnx_l_mortality_enqueue ran, its counts are not read yet
+  bool mort_xo = false, mort_fill = false, mort_ord_keep = false;
+  int mort_has_rows = 0;
+  int64_t mort_N = 0;
 
   // density
   GnxLattice lat;
@@ -522,6 +533,9 @@ int gnx_permute_rest_launch(gnx_state* h);
 // has read the pair count back, so the GPU works through the round trip
 int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out,
                      bool with_density = false);
+// ... in two halves: everything enqueued / the pair count read
+int gnx_l_find_pairs_enqueue(gnx_state* h, const uint8_t* d_keep, bool with_density);
+int gnx_l_find_pairs_finish(gnx_state* h, int64_t* n_pairs_out);
 int gnx_l_births(gnx_state* h, int64_t* births_out);
 int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* births_out,
                int64_t id_base = -1, bool tiled = false);
@@ -588,6 +602,10 @@ int gnx_wait_latP(gnx_state* h);
 bool gnx_fused_bins(const gnx_state* h);
 int gnx_l_death_probs(gnx_state* h, bool with_selection);
 int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_out);
+// ... in two halves: death draws, compaction, crossover jobs and launch enqueued / the
+// survivor counts read and the host's bookkeeping brought up to date
+int gnx_l_mortality_enqueue(gnx_state* h, const uint8_t* d_dead_inject);
+int gnx_l_mortality_finish(gnx_state* h, int64_t* deaths_out);
 int gnx_l_spatial_diff(gnx_state* h, double* mean, double* sd, double* sums = nullptr);
 int gnx_l_gather_genomes(gnx_state* h, int64_t n, const int64_t* d_slots, uint64_t* d_out);
 // genomes d_in [n][2][W64] -> the rows of slots [first_slot, first_slot + n)

@@ -1506,8 +1506,14 @@ k_ord_write(int64_t N, int64_t ord_n, const int32_t* __restrict__ ord,
 }
 
 int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_out) {
-  int64_t N = h->N;
   *deaths_out = 0;
+  GNXCHK(gnx_l_mortality_enqueue(h, d_dead_inject));
+  return gnx_l_mortality_finish(h, deaths_out);
+}
+
+int gnx_l_mortality_enqueue(gnx_state* h, const uint8_t* d_dead_inject) {
+  int64_t N = h->N;
+  h->mort_wait = false;
   gnx_bins_adults_drop(h);
   if (N == 0) return 0;
   const gnx_config& c = h->cfg;
@@ -1626,6 +1632,22 @@ int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_
   }
   HIPCHK(hipGetLastError());
   if (xo && h->xo_sort_waits && h->xo_wait_at == 3) GNXCHK(gnx_xo_wait_inflight(h));
+  h->mort_wait = true;
+  h->mort_xo = xo;
+  h->mort_fill = fill;
+  h->mort_ord_keep = ord_keep;
+  h->mort_has_rows = has_rows;
+  h->mort_N = N;
+  return 0;
+}
+
+int gnx_l_mortality_finish(gnx_state* h, int64_t* deaths_out) {
+  *deaths_out = 0;
+  if (!h->mort_wait) return 0;
+  h->mort_wait = false;
+  const bool xo = h->mort_xo, fill = h->mort_fill, ord_keep = h->mort_ord_keep;
+  const int has_rows = h->mort_has_rows;
+  const int64_t N = h->mort_N;
   {
     const bool ht = gnx_host_times();
     const auto t0 = std::chrono::steady_clock::now();

@@ -1265,9 +1265,20 @@ __global__ void k_panmixia(int64_t N, const int64_t* id, long long step, unsigne
 }
 
 int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out, bool with_density) {
+  int rc = gnx_l_find_pairs_enqueue(h, d_keep, with_density);
+  // (the caller of the whole thing orders the side stream's columns before it looks at the
+  // error: keep that order)
+  if (rc) {
+    *n_pairs_out = 0;
+    return rc;
+  }
+  return gnx_l_find_pairs_finish(h, n_pairs_out);
+}
+
+int gnx_l_find_pairs_enqueue(gnx_state* h, const uint8_t* d_keep, bool with_density) {
   int64_t N = h->N;
-  *n_pairs_out = 0;
   h->n_pairs = 0;
+  h->pairs_wait = false;
   if (N == 0) return 0;
   const gnx_species_params& sp = h->sp;
   GnxSoA s = h->soa[h->cur];
@@ -1332,13 +1343,24 @@ int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out, 
     else
       with_density = false;
   }
+  h->pairs_wait = true;
+  h->pairs_seq = seq;
+  h->pairs_with_top = with_top;
+  h->pairs_with_density = with_density;
+  return 0;
+}
+
+int gnx_l_find_pairs_finish(gnx_state* h, int64_t* n_pairs_out) {
+  *n_pairs_out = 0;
+  if (!h->pairs_wait) return 0;
+  h->pairs_wait = false;
   // the pair count comes from the scan kernel through pinned memory; the kernels queued
   // behind it (pair list, midpoint density) keep the GPU busy while the host goes on
-  GNXCHK(gnx_wait_published(h, 4, seq));
+  GNXCHK(gnx_wait_published(h, 4, h->pairs_seq));
   h->n_pairs = h->h_pin[4];
-  if (with_top) h->half_free_est = h->h_pin[16];
+  if (h->pairs_with_top) h->half_free_est = h->h_pin[16];
   *n_pairs_out = h->n_pairs;
-  if (!with_density) h->spl_P.valid = false;
+  if (!h->pairs_with_density) h->spl_P.valid = false;
   else if (h->n_pairs == 0) h->spl_P.valid = false;
   if (h->xo_launch_policy == 2) GNXCHK(gnx_xo_launch_pending(h));
   return 0;

@@ -184,7 +184,25 @@ int gnx_pop_dynamics_die(gnx_state* h, int32_t burn, int32_t with_selection);
 /* whole fn-queue entry for one step: age, move (if params.move), pop dynamics
  * (sim/model.py:603-667)                                                    */
 int gnx_step(gnx_state* h, int32_t burn, int32_t with_selection);
+/* gnx_step in three parts - _begin: age, movement, cell sort, mate search, pair list
+ * enqueued; _mid: pair count read, births, densities, death probabilities, death draws,
+ * compaction and crossover enqueued; _end: survivor counts read - and gnx_step_many: one
+ * step of n INDEPENDENT handles (the iterations of a model, sim/model.py:866-953, whose
+ * TODO at :924-925 wants them farmed out), all first parts, then all second, then all
+ * third, so that the handles' kernels run side by side on their own streams while one
+ * host thread drives them.  Same results as gnx_step on each handle.                     */
+int gnx_step_begin(gnx_state* h, int32_t burn);
+int gnx_step_mid(gnx_state* h, int32_t burn, int32_t with_selection);
+int gnx_step_end(gnx_state* h, int32_t burn);
+int gnx_step_many(gnx_state** hs, int32_t n, int32_t burn, int32_t with_selection);
 int gnx_counts(gnx_state* h, int64_t* N, int64_t* births, int64_t* deaths);
+/* Running totals over the gnx_step calls since the last gnx_reset_totals (what Species.Nt /
+ * n_births / n_deaths accumulate step by step, structs/species.py:554,  kept in the library
+ * so that a driver loop need not call back between steps): out[6] = steps, sum of N at the
+ * START of each step (the metric's individual-timesteps), births, deaths, births whose
+ * genomes the crossover wrote, 0.  Host-side bookkeeping only: no device access.         */
+int gnx_totals(gnx_state* h, int64_t* out);
+int gnx_reset_totals(gnx_state* h);
 /* Where the new offspring's genomes are cut (ops/mating.py:130-214, the crossover).
  * on (default, one GPU): after the step's death draws, for the offspring that survive
  * them only, on a second HIP stream under the next step's kernels - offspring that die at

@@ -115,6 +115,67 @@ def test_offspring_and_dispersal_draws_match_oracle(sexed):
     dev.close()
 
 
+@pytest.mark.parametrize('distr,p1,p2', [('lognormal', -1.0, 0.6), ('wald', 1.5, 2.0),
+                                         ('levy', 0.0, 0.3)])
+@pytest.mark.parametrize('surf', ['none', 'mixture', 'unimodal'])
+def test_dispersal_surface_and_distance_distributions(surf, distr, p1, p2):
+    """A11, the branches of _do_dispersal nobody had run (ops/movement.py:98-141): the
+    offspring's direction drawn from a dispersal surface at the parents' midpoint
+    (spp._disp_surf, :104-108; utils/spatial.py:182-184 - stream OP_DISP_SURF, eight blocks
+    per attempt) instead of the uniform angle, and wald / levy dispersal distances
+    (:110-118) beside lognormal.  Device positions == the oracle's restatement of the same
+    streams through O.dispersal (retry loop included)."""
+    nat = native()
+    rng = np.random.RandomState(31 + len(distr))
+    W = H = 40
+    seed, step = 606, 7
+    n = 3000
+    x, y, ids = _population(rng, n, W, H)
+    x[:400] = rng.rand(400).astype(np.float32) * 0.05      # parents on the low edge: retries
+    rast = rng.rand(H, W).astype(np.float32)
+    rast[rng.rand(H, W) < 0.15] = 0.0                       # zero-conductance cells too
+    rasts = np.stack([np.ones((H, W), np.float32), rast])
+    kw = {}
+    if surf != 'none':
+        kw = dict(disp_surf=nat.SURF_MIXTURE if surf == 'mixture' else nat.SURF_UNIMODAL,
+                  disp_surf_layer=1, disp_surf_kappa=9.0)
+    dev = make_dev(W, H, rasts=rasts, cap=4 * n, seed=seed, mating_radius=3.0,
+                   disp_distr=nat.DIST[distr], disp_p1=p1, disp_p2=p2, K_factor=2.0, **kw)
+    upload_simple(dev, x, y, ids=ids)
+    dev.step_index = step
+    dev.pop_dynamics_mate(True)
+    child, par, _, _, xy = dev.last_births(with_gametes=False)
+    B = child.size
+    assert B > 150
+    ppos = {int(i): (a, b) for i, a, b in zip(ids, x, y)}
+    mx = np.array([(ppos[int(a)][0] + ppos[int(b)][0]) / np.float32(2) for a, b in par],
+                  np.float32)
+    my = np.array([(ppos[int(a)][1] + ppos[int(b)][1]) / np.float32(2) for a, b in par],
+                  np.float32)
+    th, ds = D.dispersal_draws(seed, child, step, distr, p1, p2)
+    if surf != 'none':
+        th = np.stack([D.surf_directions(seed, child, step, P.OP_DISP_SURF, rast, mx, my,
+                                         surf == 'mixture', 9.0, first_blk=8 * a)
+                       for a in range(th.shape[0])])
+    ox, oy, used = O.dispersal(mx, my, th, ds, (W, H), dtype=np.float32)
+    assert (used > 0).sum() > 3                              # the retry loop ran
+    # where the oracle's own rounding cannot move the result: moderate distances (levy's
+    # p2 / z^2 amplifies the ulps of z), directions away from a pick's rounding tie
+    du = ds[used, np.arange(B)]
+    ok = du < 5.0
+    assert ok.mean() > 0.5
+    err = np.maximum(np.abs(xy[:, 0] - ox), np.abs(xy[:, 1] - oy))
+    tol = 2e-2 if distr == 'levy' else 5e-3
+    assert (err[ok] < tol).mean() > 0.998, (surf, distr, np.sort(err[ok])[-5:])
+    assert (xy >= 0).all() and (xy[:, 0] <= W - 0.001 + 1e-4).all()
+    if surf != 'none':
+        # and the surface matters: not the uniform angles of the plain branch
+        th_u, _ = D.dispersal_draws(seed, child, step, distr, p1, p2)
+        ux, uy, _ = O.dispersal(mx, my, th_u, ds, (W, H), dtype=np.float32)
+        assert (np.abs(xy[:, 0] - ux)[ok] > 1e-2).mean() > 0.5
+    dev.close()
+
+
 def test_death_draws_match_oracle():
     """k_alive: dead = u(id, step, OP_DEATH) < p_death.  With d_min = d_max the death
     probability is the same constant for everybody (ops/demography.py:158-164, no

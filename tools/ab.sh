@@ -10,7 +10,7 @@ OUT=gpurun_out/$TAG/ab.txt
 : > $OUT
 for r in $(seq 1 $ROUNDS); do
   for v in "$@"; do
-    res=$(env $v python3 tools/kbench.py --genomes --steps ${AB_STEPS:-100} --no-profile 2>/dev/null | head -1)
+    res=$(env $v python3 tools/kbench.py --workload ${AB_WORKLOAD:-c4_metric} --genomes --steps ${AB_STEPS:-100} --no-profile 2>/dev/null | head -1)
     echo "[$v] $res" | tee -a $OUT
   done
 done

@@ -33,12 +33,12 @@ dev.profiling(not a.no_profile)
 import time
 dev.synchronize()
 t0 = time.perf_counter()
-n = 0
+dev.reset_totals()
 for _ in range(a.steps):
-    n += dev.N
     dev.step(not a.genomes, a.genomes)
 dev.synchronize()
 dt = time.perf_counter() - t0
+n = dev.totals()['ind_steps']
 kt = dev.kernel_times()
 print('N=%d  ms/step=%.3f  ind-steps/s=%.3e' % (dev.N, 1e3 * dt / a.steps, n / dt))
 for k, v in kt.items():
