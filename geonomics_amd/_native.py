@@ -48,6 +48,7 @@ EXPORTS = [
     'gnx_set_defer_crossover', 'gnx_last_crossover_births', 'gnx_set_crossover_overlap', 'gnx_set_crossover_split', 'gnx_debug_halves', 'gnx_spatial_diff_sums', 'gnx_last_crossover_jobs',
     'gnx_genome_info', 'gnx_measure_copy', 'gnx_totals', 'gnx_reset_totals',
     'gnx_step_begin', 'gnx_step_mid', 'gnx_step_end', 'gnx_step_many',
+    'gnx_walk', 'gnx_walk_many', 'gnx_walk_history',
     'gnx_stream_ptr', 'gnx_tile2_move_route', 'gnx_tile2_route_ptrs', 'gnx_tile2_import',
     'gnx_tile2_pairs', 'gnx_tile2_offspring', 'gnx_tile2_serve', 'gnx_tile2_put',
     'gnx_tile2_finish_births', 'gnx_tile2_die', 'gnx_tile_pair_ptrs_nosync',
@@ -105,6 +106,7 @@ def load():
     lib.gnx_step_index.restype = C.c_int64
     lib.gnx_n_slots.restype = C.c_int64
     lib.gnx_last_crossover_births.restype = C.c_int64
+    lib.gnx_walk_history.restype = C.c_int64
     lib.gnx_destroy.restype = None
     _lib = lib
     return lib
@@ -134,18 +136,33 @@ class Device:
                           cap_inds=int(cap_inds),
                           cap_rows=int(cap_inds if cap_rows is None else cap_rows),
                           seed=int(seed) & 0xFFFFFFFFFFFFFFFF, device=device)
-        self.h = C.c_void_p()
         self.W, self.H, self.n_layers, self.L = W, H, n_layers, L
         self.n_traits = n_traits
         self.W64 = self.lib.gnx_words_per_hom(L) if L > 0 else 0
-        rc = self.lib.gnx_create(C.byref(self.cfg), C.byref(self.h))
+        h = C.c_void_p()
+        rc = self.lib.gnx_create(C.byref(self.cfg), C.byref(h))
         if rc:
             raise GnxError(self.lib.gnx_last_error().decode())
+        self.h = h
+
+    @property
+    def h(self):
+        """the opaque handle; a Device that was closed raises instead of handing the
+        library a null pointer"""
+        h = self.__dict__.get('_h')
+        if h is None or not h:
+            raise GnxError('this Device was closed (gnx_destroy): no device state behind it')
+        return h
+
+    @h.setter
+    def h(self, v):
+        self.__dict__['_h'] = v
 
     def close(self):
-        if getattr(self, 'h', None) is not None and self.h:
-            self.lib.gnx_destroy(self.h)
-            self.h = C.c_void_p()
+        h = self.__dict__.get('_h')
+        if h is not None and h:
+            self.lib.gnx_destroy(h)
+            self.__dict__['_h'] = None
 
     def __del__(self):
         try:
@@ -280,6 +297,21 @@ class Device:
         self._chk(self.lib.gnx_step(self.h, int(bool(burn)),
                                     int(bool(with_selection))))
 
+    def walk(self, T, burn, with_selection):
+        """T time steps in one call, counts kept on the device (gnx_walk): no read-back and
+        one graph launch per step"""
+        self._chk(self.lib.gnx_walk(self.h, C.c_int64(int(T)), int(bool(burn)),
+                                    int(bool(with_selection))))
+
+    def walk_history(self, max_steps=1 << 16):
+        """(N at the start, births, deaths) of the last walk's steps, int64 arrays"""
+        n = np.zeros(max_steps, np.int64)
+        b = np.zeros(max_steps, np.int64)
+        d = np.zeros(max_steps, np.int64)
+        k = self.lib.gnx_walk_history(self.h, C.c_int64(max_steps), _ptr(n, C.c_int64),
+                                      _ptr(b, C.c_int64), _ptr(d, C.c_int64))
+        return n[:k], b[:k], d[:k]
+
     def step_begin(self, burn):
         self._chk(self.lib.gnx_step_begin(self.h, int(bool(burn))))
 
@@ -295,11 +327,11 @@ class Device:
         return n.value, b.value, d.value
 
     def totals(self):
-        """dict(steps, ind_steps, births, deaths, xo_births) summed over the gnx_step calls
+        """dict(steps, ind_steps, births, deaths, xo_births, dd_steps) summed over the gnx_step calls
         since reset_totals() - host-side bookkeeping of the library, no device access"""
         out = np.zeros(6, np.int64)
         self._chk(self.lib.gnx_totals(self.h, _ptr(out, C.c_int64)))
-        return dict(zip(('steps', 'ind_steps', 'births', 'deaths', 'xo_births'),
+        return dict(zip(('steps', 'ind_steps', 'births', 'deaths', 'xo_births', 'dd_steps'),
                         (int(v) for v in out)))
 
     def reset_totals(self):
@@ -827,6 +859,15 @@ def step_many(devs, burn, with_selection):
     arr = (C.c_void_p * len(devs))(*[d.h for d in devs])
     devs[0]._chk(devs[0].lib.gnx_step_many(arr, len(devs), int(bool(burn)),
                                            int(bool(with_selection))))
+
+
+def walk_many(devs, T, burn, with_selection):
+    """T time steps of several independent Devices side by side (gnx_walk_many)"""
+    if not devs:
+        return
+    arr = (C.c_void_p * len(devs))(*[d.h for d in devs])
+    devs[0]._chk(devs[0].lib.gnx_walk_many(arr, len(devs), C.c_int64(int(T)), int(bool(burn)),
+                                            int(bool(with_selection))))
 
 
 def default_species_params(**kw):

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libgnxhip.so')
 SOURCES = ['gnx_api.hip', 'gnx_kernels_pop.hip', 'gnx_kernels_genome.hip',
-           'gnx_kernels_demog.hip', 'gnx_tile.hip', 'gnx_stats.hip', 'gnx_prim.hip']
+           'gnx_kernels_demog.hip', 'gnx_tile.hip', 'gnx_stats.hip', 'gnx_prim.hip', 'gnx_dd.hip']
 
 
 def _headers():

@@ -130,6 +130,7 @@ void gnx_time_end(gnx_state* h, int kernel, double bytes) {
 static void timers_resolve(gnx_state* h, int kernel) {
   (void)gnx_xo_launch_pending(h);
   (void)hipStreamSynchronize(h->stream);
+  gnx_dd_destroy(h);
   if (h->stream2) (void)hipStreamSynchronize(h->stream2);
   for (auto& pr : h->ev_pending[kernel]) {
     float ms = 0.f;
@@ -476,6 +477,7 @@ extern "C" void gnx_destroy(gnx_state* h) {
             g_host_steps, 1e6 * g_host_step_s / g_host_steps, 1e6 * g_host_wait_s / g_host_steps);
   (void)gnx_xo_launch_pending(h);
   (void)hipStreamSynchronize(h->stream);
+  gnx_dd_destroy(h);
   if (h->stream2) (void)hipStreamSynchronize(h->stream2);
   if (h->stream3) (void)hipStreamSynchronize(h->stream3);    // reads ord / newslot
   for (int k = 0; k < 2; ++k) {
@@ -577,6 +579,7 @@ extern "C" int gnx_upload_layer(gnx_state* h, int32_t layer, const float* rast) 
 // explicit carrying-capacity raster (Species.K after a demographic change event,
 // ops/change.py:633-651); NULL returns to rast[K_layer] * K_factor
 extern "C" int gnx_set_k_raster(gnx_state* h, const double* K) {
+  h->cfg_epoch += 1;
   size_t n = (size_t)h->cfg.W * h->cfg.H;
   HIPCHK(hipStreamSynchronize(h->stream));
   if (!K) {
@@ -685,6 +688,7 @@ static int setup_hash_grid(gnx_state* h) {
 }
 
 extern "C" int gnx_set_species_params(gnx_state* h, const gnx_species_params* p) {
+  h->cfg_epoch += 1;
   if (p->K_layer < 0 || p->K_layer >= h->cfg.n_layers ||
       (p->move_surf && (p->move_surf_layer < 0 || p->move_surf_layer >= h->cfg.n_layers)) ||
       (p->disp_surf && (p->disp_surf_layer < 0 || p->disp_surf_layer >= h->cfg.n_layers))) {
@@ -717,6 +721,7 @@ static int need_params(gnx_state* h) {
 
 extern "C" int gnx_upload_population(gnx_state* h, int64_t N, const float* x, const float* y,
                                      const int32_t* age, const uint8_t* sex, const int64_t* id) {
+  h->cfg_epoch += 1;
   if (N > h->cfg.cap_inds) {
     gnx_set_error("gnx_upload_population: N %lld > cap_inds %lld", (long long)N,
                   (long long)h->cfg.cap_inds);
@@ -762,6 +767,7 @@ extern "C" int gnx_upload_population(gnx_state* h, int64_t N, const float* x, co
 }
 
 extern "C" int gnx_init_population(gnx_state* h, int64_t N) {
+  h->cfg_epoch += 1;
   if (N > h->cfg.cap_inds) {
     gnx_set_error("gnx_init_population: N > cap_inds");
     return 1;
@@ -775,6 +781,7 @@ extern "C" int gnx_init_population(gnx_state* h, int64_t N) {
 
 // ---------------------------------------------------------------- genomic architecture
 extern "C" int gnx_set_recomb_paths(gnx_state* h, int32_t n, const uint64_t* paths) {
+  h->cfg_epoch += 1;
   if (h->cfg.L == 0 || n <= 0) {
     gnx_set_error("gnx_set_recomb_paths: species has no genome or n <= 0");
     return 1;
@@ -841,6 +848,7 @@ extern "C" int gnx_set_recomb_paths(gnx_state* h, int32_t n, const uint64_t* pat
 extern "C" int gnx_set_trait(gnx_state* h, int32_t t, int32_t n_loci, const int32_t* loci,
                              const double* alpha, int32_t layer, double phi,
                              const float* phi_rast, double gamma, int32_t univ_adv) {
+  h->cfg_epoch += 1;
   if (t < 0 || t >= h->cfg.n_traits || n_loci <= 0 || layer < 0 || layer >= h->cfg.n_layers) {
     gnx_set_error("gnx_set_trait: bad trait index, locus count or layer");
     return 1;
@@ -879,6 +887,7 @@ extern "C" int gnx_set_trait(gnx_state* h, int32_t t, int32_t n_loci, const int3
 // (GnxSoA.tb): rebuilt whenever a trait or the deleterious loci change (also after
 // non-neutral mutations, structs/genome.py:753-788).
 int gnx_l_rebuild_sel(gnx_state* h) {
+  h->cfg_epoch += 1;
   std::vector<int32_t> all;
   for (int q = 0; q < h->cfg.n_traits; ++q)
     all.insert(all.end(), h->h_trait_loci[q].begin(), h->h_trait_loci[q].end());
@@ -912,6 +921,7 @@ int gnx_l_rebuild_sel(gnx_state* h) {
 }
 
 extern "C" int gnx_set_dominance(gnx_state* h, const uint8_t* dom) {
+  h->cfg_epoch += 1;
   HIPCHK(hipStreamSynchronize(h->stream));
   (void)hipFree(h->dom);
   h->dom = nullptr;
@@ -926,6 +936,7 @@ extern "C" int gnx_set_dominance(gnx_state* h, const uint8_t* dom) {
 
 extern "C" int gnx_set_deleterious(gnx_state* h, int32_t n, const int32_t* loci,
                                    const double* s) {
+  h->cfg_epoch += 1;
   HIPCHK(hipStreamSynchronize(h->stream));
   (void)hipFree(h->delet_loci);
   (void)hipFree(h->delet_s);
@@ -957,6 +968,7 @@ static int need_genome(gnx_state* h) {
 }
 
 extern "C" int gnx_upload_genomes(gnx_state* h, const uint64_t* geno) {
+  h->cfg_epoch += 1;
   GNXCHK(need_genome(h));
   GNXCHK(gnx_l_assign_genomes(h, nullptr));     // rows 0..N-1 in slot order
   const size_t rowb = (size_t)2 * h->W64 * 8;
@@ -979,6 +991,7 @@ extern "C" int gnx_upload_genomes(gnx_state* h, const uint64_t* geno) {
 }
 
 extern "C" int gnx_assign_genomes(gnx_state* h, const int32_t* n_per_site) {
+  h->cfg_epoch += 1;
   GNXCHK(need_genome(h));
   int32_t* d = nullptr;
   GNXCHK(dalloc(&d, h->cfg.L));
@@ -1225,6 +1238,7 @@ extern "C" int gnx_counts(gnx_state* h, int64_t* N, int64_t* births, int64_t* de
 }
 
 extern "C" int gnx_set_defer_crossover(gnx_state* h, int32_t on) {
+  h->cfg_epoch += 1;
   GNXCHK(gnx_xo_join(h));
   h->defer_xo = on != 0;
   return 0;
@@ -1247,6 +1261,7 @@ extern "C" int gnx_last_crossover_jobs(gnx_state* h, void* dst, int64_t max_jobs
 }
 
 extern "C" int gnx_set_crossover_overlap(gnx_state* h, int32_t mode) {
+  h->cfg_epoch += 1;
   GNXCHK(gnx_xo_join(h));
   static const int wait_env = getenv("GNX_XO_WAIT") ? atoi(getenv("GNX_XO_WAIT")) : 1;
   h->xo_sort_waits = mode != 1;
@@ -1257,6 +1272,7 @@ extern "C" int gnx_set_crossover_overlap(gnx_state* h, int32_t mode) {
 // wide_per_1024 of every deferred crossover's jobs run at full width before the next cell
 // sort, the rest narrow beside the sort and what follows it (0 or 1024: one launch)
 extern "C" int gnx_set_crossover_split(gnx_state* h, int32_t wide_per_1024) {
+  h->cfg_epoch += 1;
   GNXCHK(gnx_xo_join(h));
   h->xo_split = std::min(1024, std::max(0, (int)wide_per_1024));
   return 0;

@@ -160,6 +160,50 @@ struct GnxKernelTimer {
   double bytes = 0;
 };
 
+// ---- the device-driven step (gnx_dd.hip) ------------------------------------------------
+// gnx_step keeps the population's counts on the HOST: it reads the pair count and the
+// survivor count back in every step and sizes the next kernels with them - two round trips
+// and ~45 runtime calls per step, which at 10^5 individuals cost more host time than the
+// kernels take on the GPU (GNX_HOST_TIMES: 185 us of enqueueing against ~150 us of kernels).
+// gnx_walk keeps them on the DEVICE: every kernel of the step reads what it needs from this
+// block, its grid is sized by the handle's capacity, nothing is read back - so a whole step
+// is one HIP graph, replayed.  The host looks at a copy the step's last kernel leaves in
+// pinned memory (GnxDDRec, one step or more late) for its totals, the collector and errors.
+struct GnxDD {
+  int32_t N;          // occupied slots at the start of the step (after the last compaction)
+  int32_t P;          // pairs of this step
+  int32_t B;          // births of this step
+  int32_t n_free;     // free genome rows on the stack at the start of the step
+  int32_t ord_n;      // entries of the id-ordered index
+  int32_t err;        // sticky: GNX_DD_ERR_*
+  int32_t seq;        // steps carried out since gnx_dd entered
+  int32_t pad;
+  int64_t max_id;
+  int64_t step;       // the step index of the random streams
+};
+#define GNX_DD_ERR_SLOTS 1     // N + births > cap_inds
+#define GNX_DD_ERR_ROWS 2      // surviving offspring > free genome rows
+#define GNX_DD_ERR_BLOCKS 4    // the free-block stack ran dry
+// what a step leaves for the host (pinned memory, ring of GNX_DD_RING records)
+struct GnxDDRec {
+  int64_t seq;        // written last: 1-based number of the step since gnx_dd entered
+  int32_t N0, P, B, S;        // population at the start, pairs, births, survivors
+  int32_t xo, n_free, half_top, err;   // births that got a genome, free rows / blocks after the step
+  int64_t max_id, step;
+  int64_t pad[2];
+};
+#define GNX_DD_RING 4096
+#ifdef __HIPCC__
+// N / step of a kernel of either step: from the device block when there is one
+__device__ __forceinline__ int64_t gnx_dd_n(const GnxDD* dd, int64_t n) { return dd ? (int64_t)dd->N : n; }
+__device__ __forceinline__ int64_t gnx_dd_nb(const GnxDD* dd, int64_t n) {
+  return dd ? (int64_t)dd->N + dd->B : n;                      // ... with this step's offspring
+}
+__device__ __forceinline__ long long gnx_dd_step(const GnxDD* dd, long long s) {
+  return dd ? (long long)dd->step : s;
+}
+#endif
+
 #define GNX_MAX_TILES 4096
 struct gnx_state {
   gnx_config cfg{};
@@ -475,6 +519,23 @@ struct gnx_state {
   void* h_stage = nullptr;           // pinned host staging buffer for per-step transfers
   size_t h_stage_bytes = 0;
 
+  // the device-driven step (gnx_dd.hip)
+  GnxDD* dd = nullptr;                 // device
+  GnxDDRec* dd_ring = nullptr;         // pinned host ring the steps publish into
+  GnxDDRec* dd_ring_dev = nullptr;     // the same memory as the device sees it
+  bool dd_active = false;              // between gnx_dd_enter and gnx_dd_leave
+  int64_t dd_seq = 0;                  // steps enqueued since gnx_dd_enter
+  int64_t dd_seen = 0;                 // ... whose record the host has taken into its totals
+  int64_t dd_half_est = 0;             // free blocks the host can count on (lagged bound)
+  int64_t dd_b_hi = 0;                 // largest births per step seen (the collector's bound)
+  int64_t dd_use_hi = 0;               // most free blocks a step has taken
+  void* dd_graph[1]{};                 // DDExtra (gnx_dd.hip): captured graphs, events
+  int32_t dd_err = 0;                  // sticky GNX_DD_ERR_* the steps have reported
+  std::vector<int64_t> dd_hist;        // (N at start, births, deaths) of every step of the last gnx_walk
+  // bumped by whatever changes a by-value argument or a pointer of the step's kernels
+  // (species parameters, traits, paths, K raster ...): captured graphs are dropped
+  uint64_t cfg_epoch = 1;
+
   // profiling
   bool profiling = false;
   int profile_only = -1;
@@ -611,6 +672,26 @@ int gnx_l_gather_genomes(gnx_state* h, int64_t n, const int64_t* d_slots, uint64
 // genomes d_in [n][2][W64] -> the rows of slots [first_slot, first_slot + n)
 int gnx_l_scatter_genomes(gnx_state* h, int64_t n, const uint64_t* d_in, int64_t first_slot);
 
+// ---- device-driven step (gnx_dd.hip): launchers with capacity-sized grids, counts in h->dd
+int gnx_dd_l_sort(gnx_state* h, hipStream_t st);
+int gnx_dd_l_pairs(gnx_state* h, hipStream_t st);
+int gnx_dd_l_offspring(gnx_state* h, bool genomes, int32_t* d_bins, hipStream_t st);
+int gnx_dd_l_bins_adults(gnx_state* h, int par, hipStream_t st);
+int gnx_dd_l_density_pairs(gnx_state* h, hipStream_t st);
+int gnx_dd_l_density_N(gnx_state* h, int par, hipStream_t st);
+int gnx_dd_l_death_probs(gnx_state* h, bool with_selection, int par, hipStream_t st);
+int gnx_dd_l_alive(gnx_state* h, bool xo, int buf, hipStream_t st);
+int gnx_dd_l_jobs(gnx_state* h, int buf, hipStream_t st);
+int gnx_dd_l_crossover(gnx_state* h, int buf, hipStream_t st);
+int gnx_dd_l_fill_lists(gnx_state* h, int has_rows, hipStream_t st);
+int gnx_dd_l_fill(gnx_state* h, int has_rows, bool xo, hipStream_t st);
+int gnx_dd_l_ord(gnx_state* h, hipStream_t st);
+int gnx_dd_l_end(gnx_state* h, int has_rows, bool xo, hipStream_t st);
+// the handle can take device-driven steps (else gnx_walk falls back to gnx_step)
+bool gnx_dd_eligible(const gnx_state* h, bool burn);
+int gnx_dd_leave(gnx_state* h);
+void gnx_dd_destroy(gnx_state* h);
+
 // look-back-free compaction (gnx_compact.h): block counts cnt[k * blk_stride + b], k < K
 // <= 3, -> exclusive block offsets off[...], totals to out[0..2] on the device and to
 // pinned host memory
@@ -624,7 +705,7 @@ size_t gnx_os_scratch_bytes(size_t n, int end_bit);
 size_t gnx_os_words_used(size_t n, int end_bit);
 int gnx_os_keys_hist(void* scratch, unsigned int* ticket, int64_t N, int64_t ord_n,
                      const int32_t* ord, const uint32_t* cell32, uint32_t* key, int32_t* val,
-                     int end_bit, hipStream_t s);
+                     int end_bit, hipStream_t s, const GnxDD* dd = nullptr);
 int gnx_os_sort32_ranked(void* scratch, uint32_t* ktmp, int32_t* vtmp, const uint32_t* kin,
                          uint32_t* kout, const int32_t* vin, int32_t* vout, size_t n, int end_bit,
                          hipStream_t s);

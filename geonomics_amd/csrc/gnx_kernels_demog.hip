@@ -537,6 +537,7 @@ int gnx_l_raster(gnx_state* h, int which, double* d_out) {
 struct DeathP {
   int64_t N, cap;
   int n_layers, with_selection, max_age, n_delet, n_tl, TW;
+  const GnxDD* dd;
 };
 
 // ops/demography.py:305-321 + ops/selection.py:51-125: d at the individual's
@@ -592,13 +593,14 @@ k_death_probs(DeathP Q, DemP P, SplineC SN, SplineC SP, GnxSoA s, const float* r
               GnxTraitTab T, const double* delet_s, const unsigned long long* nmax_bits,
               double* p_death, double* d_cell) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= Q.N) return;
+  if (i >= gnx_dd_nb(Q.dd, Q.N)) return;
   const double nmax = __longlong_as_double((long long)*nmax_bits);
   p_death[i] = death_prob_one(Q, P, SN, SP, s, rast, T, delet_s, nmax, i, d_cell);
 }
 
 static DeathP make_deathp(const gnx_state* h, bool with_selection) {
   DeathP Q;
+  Q.dd = nullptr;
   Q.N = h->N;
   Q.cap = h->cfg.cap_inds;
   Q.n_layers = h->cfg.n_layers;
@@ -789,9 +791,16 @@ __global__ void __launch_bounds__(256)
 k_alive(int64_t N, const double* p_death, const uint8_t* dead_in, const int64_t* id,
         const uint8_t* ghost, const int32_t* grow, long long step, unsigned long long seed,
         int32_t* alive, int32_t* dead_row, int32_t* cnt, int stride, int64_t xo_first,
-        int32_t* zero_jobs) {
+        int32_t* zero_jobs, const GnxDD* __restrict__ dd) {
   __shared__ int lds[16];
   const int64_t base = (int64_t)blockIdx.x * GNX_CB;
+  if (dd) {
+    // device-driven step: everybody incl. this step's offspring; the offspring (slots from
+    // dd->N on) wait for their crossover iff xo_first >= 0
+    N = (int64_t)dd->N + dd->B;
+    step = dd->step;
+    if (xo_first >= 0) xo_first = dd->N;
+  }
   // the job list of the deferred crossover is appended to (k_xo_jobs_surv): empty it
   if (zero_jobs && blockIdx.x == 0 && threadIdx.x == 0) *zero_jobs = 0;
   bool fa[4], fd[4], fx[4];
@@ -1019,8 +1028,14 @@ k_xo_jobs_fused(int64_t N, int64_t first, int32_t* __restrict__ grow,
                 int64_t n_free, GnxHalves H, const int32_t* __restrict__ bp_off,
                 const int32_t* __restrict__ bp_loci, int32_t* __restrict__ n_jobs,
                 GnxXoJob* __restrict__ jobs, GnxJobBp* __restrict__ jobs_bp,
-                const int32_t* __restrict__ cnt3) {
+                const int32_t* __restrict__ cnt3, GnxDD* __restrict__ dd) {
   constexpr int WAVES = TPB / 64;
+  if (dd) {
+    N = (int64_t)dd->N + dd->B;
+    first = dd->N;
+    n_free = dd->n_free;
+    if ((first / TPB + blockIdx.x) * TPB >= N) return;         // (block-uniform)
+  }
   __shared__ int wsum[3][WAVES];
   __shared__ int prev_s[WAVES];
   __shared__ int psum[WAVES];
@@ -1063,9 +1078,15 @@ k_xo_jobs_fused(int64_t N, int64_t first, int32_t* __restrict__ grow,
   }
 #pragma unroll
   for (int w = 0; w < WAVES; ++w) rank += prev_s[w];
+  // (device-driven step: nobody checked the rows on the host - running out of them is
+  // reported, the indices stay inside the stacks, the run is invalid and ends with an error)
+  if (dd && fx && rank >= n_free) {
+    dd->err |= GNX_DD_ERR_ROWS;
+    rank = 0;
+  }
   // stage 2: row, parents, keys, start homologues (unconditional loads from clamped indices)
   const int64_t k = fx ? i - first : 0;
-  int32_t row = free_rows[n_free - 1 - (fx ? rank : 0)];
+  int32_t row = free_rows[max((int64_t)0, n_free - 1 - (fx ? rank : 0))];
   int32_t par[2], key[2], st[2];
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
@@ -1166,8 +1187,15 @@ k_xo_jobs_fused(int64_t N, int64_t first, int32_t* __restrict__ grow,
     s_job = tj ? atomicAdd(n_jobs, tj) : 0;
   }
   __syncthreads();
+  if (dd && tid == 0) {
+    int tf = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) tf += wsum[1][w];
+    if (s_pop < tf) dd->err |= GNX_DD_ERR_BLOCKS;
+  }
   if (!fx) return;
-  const int pop = s_pop - 1 - of;                  // stack index of my first fresh block
+  // stack index of my first fresh block (dd: never below what this thread walks down)
+  const int pop = dd ? max(s_pop - 1 - of, cf) : s_pop - 1 - of;
   const int job = s_job + oj;
   // stage 6: the parents' table entries (2 x NB each, 8-byte loads) and my first six fresh
   // blocks, all issued before anything is used.  (All 2 NB fresh blocks in registers cost a
@@ -1279,14 +1307,18 @@ template <int NB>
 static void launch_jobs_fused(gnx_state* h, int64_t first_slot, const int32_t* d_alive,
                               const int32_t* d_blk_off, int buf) {
   const int64_t N = h->N;
-  const int nbf = (int)((N - 1) / GNX_JF_TPB - first_slot / GNX_JF_TPB + 1);
+  // (device-driven step: first slot and N come from the device, the grid covers what a step's
+  // births can take - half the capacity - and the workgroups behind them leave at once)
+  const bool ddm = h->dd_active;
+  const int nbf = ddm ? (int)(h->cfg.cap_inds / 2 / GNX_JF_TPB + 2)
+                      : (int)((N - 1) / GNX_JF_TPB - first_slot / GNX_JF_TPB + 1);
   hipLaunchKernelGGL((k_xo_jobs_fused<NB, GNX_JF_TPB>), dim3(nbf), dim3(GNX_JF_TPB), 0, h->stream, N, first_slot,
                      h->soa[h->cur].grow, d_alive, d_blk_off + 2 * h->blk_stride, h->off_parent,
                      h->off_keys, h->off_start, h->free_rows, h->n_free, gnx_halves(h),
                      gnx_alias_bp(h), gnx_alias_loci(h), h->n_jobs_dev[buf],
                      (GnxXoJob*)h->jobs[buf], (GnxJobBp*)h->jobs_bp[buf],
                      h->jobs_self_scan ? (const int32_t*)(h->blk_cnt + 2 * h->blk_stride)
-                                       : (const int32_t*)nullptr);
+                                       : (const int32_t*)nullptr, ddm ? h->dd : (GnxDD*)nullptr);
   h->jobs_inline[buf] = true;
 }
 
@@ -1345,9 +1377,11 @@ k_fill_lists(int64_t N, const int32_t* __restrict__ alive, const int32_t* __rest
              const int32_t* __restrict__ blk_off, int stride, const int32_t* __restrict__ cnts,
              const int32_t* __restrict__ grow, int has_rows, int32_t* __restrict__ holes,
              int32_t* __restrict__ movers, int32_t* __restrict__ rows_tmp,
-             int32_t* __restrict__ newslot, int32_t* __restrict__ n_move) {
+             int32_t* __restrict__ newslot, int32_t* __restrict__ n_move,
+             const GnxDD* __restrict__ dd) {
   __shared__ int lds[16];
   __shared__ int sb_s[4];
+  N = gnx_dd_nb(dd, N);
   const int64_t S = cnts[0];
   const int64_t base = (int64_t)blockIdx.x * GNX_CB;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1402,7 +1436,9 @@ __global__ void __launch_bounds__(256)
 k_fill(int64_t cap, const int32_t* __restrict__ n_move, const int32_t* __restrict__ holes,
        const int32_t* __restrict__ movers, const int32_t* __restrict__ cnts, GnxSoA a, int n_layers,
        int n_traits, int tbw, const int32_t* __restrict__ rows_tmp, int32_t* __restrict__ free_rows,
-       int64_t n_free, int has_rows, int xo, int32_t* __restrict__ newslot) {
+       int64_t n_free, int has_rows, int xo, int32_t* __restrict__ newslot,
+       const GnxDD* __restrict__ dd) {
+  if (dd) n_free = dd->n_free;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t H = *n_move;
@@ -1468,9 +1504,14 @@ void gnx_launch_xo_jobs_surv(gnx_state* h, int64_t first_slot, const int32_t* d_
 // the side stream: nothing needs the index before the next cell sort.
 __global__ void __launch_bounds__(256)
 k_ord_flags(int64_t N, int64_t ord_n, const int32_t* __restrict__ ord,
-            const int32_t* __restrict__ newslot, int32_t* __restrict__ cnt, GnxScanOut S) {
+            const int32_t* __restrict__ newslot, int32_t* __restrict__ cnt, GnxScanOut S,
+            const GnxDD* __restrict__ dd) {
   __shared__ int lds[16];
   __shared__ int lds2[8];
+  if (dd) {
+    N = (int64_t)dd->N + dd->B;
+    ord_n = dd->ord_n;
+  }
   const int64_t base = (int64_t)blockIdx.x * GNX_CB;
   bool f[4];
 #pragma unroll
@@ -1486,8 +1527,12 @@ k_ord_flags(int64_t N, int64_t ord_n, const int32_t* __restrict__ ord,
 __global__ void __launch_bounds__(256)
 k_ord_write(int64_t N, int64_t ord_n, const int32_t* __restrict__ ord,
             const int32_t* __restrict__ newslot, const int32_t* __restrict__ off,
-            int32_t* __restrict__ ord_new) {
+            int32_t* __restrict__ ord_new, const GnxDD* __restrict__ dd) {
   __shared__ int lds[16];
+  if (dd) {
+    N = (int64_t)dd->N + dd->B;
+    ord_n = dd->ord_n;
+  }
   const int64_t base = (int64_t)blockIdx.x * GNX_CB;
   bool f[4];
   int32_t ns[4];
@@ -1534,7 +1579,7 @@ int gnx_l_mortality_enqueue(gnx_state* h, const uint8_t* d_dead_inject) {
   gnx_time_begin(h);
   hipLaunchKernelGGL(k_alive, dim3(nb), dim3(256), 0, h->stream, N, h->p_death, d_dead_inject,
                      a.id, a.ghost, a.grow, h->step, c.seed, h->flag, h->flag2, h->blk_cnt,
-                     h->blk_stride, xo ? xo_first : (int64_t)-1, zero_jobs);
+                     h->blk_stride, xo ? xo_first : (int64_t)-1, zero_jobs, (const GnxDD*)nullptr);
   // survivors, rows freed and (deferred crossover) the surviving offspring that need a
   // row: block offsets on the device, totals also straight into pinned host memory.
   // (Measured and dropped: death probabilities + death draws + the scan by the last
@@ -1573,7 +1618,8 @@ int gnx_l_mortality_enqueue(gnx_state* h, const uint8_t* d_dead_inject) {
     hipLaunchKernelGGL(k_fill_lists, dim3(nb), dim3(256), 0, h->stream3, N, h->flag, h->flag2,
                        h->blk_off, h->blk_stride, h->cnt_dev, a.grow, has_rows,
                        (int32_t*)h->os_ktmp, (int32_t*)h->os_ktmp + c.cap_inds / 2,
-                       (int32_t*)h->os_vtmp, ord_keep ? h->newslot : nullptr, h->fill_cnt);
+                       (int32_t*)h->os_vtmp, ord_keep ? h->newslot : nullptr, h->fill_cnt,
+                       (const GnxDD*)nullptr);
     HIPCHK(hipEventRecord(h->ev_fill, h->stream3));
   }
   // deferred crossover of this step's births: rows and jobs for the survivors, the kernel
@@ -1597,7 +1643,7 @@ int gnx_l_mortality_enqueue(gnx_state* h, const uint8_t* d_dead_inject) {
                        (const int32_t*)h->os_ktmp, (const int32_t*)h->os_ktmp + c.cap_inds / 2,
                        h->cnt_dev, a, c.n_layers, c.n_traits, a.tb ? 2 * h->TW : 0,
                        (const int32_t*)h->os_vtmp, h->free_rows, h->n_free, has_rows, xo ? 1 : 0,
-                       ord_keep ? h->newslot : nullptr);
+                       ord_keep ? h->newslot : nullptr, (const GnxDD*)nullptr);
     // flags and offsets of everybody, the records of about as many movers as the last round had deaths
     gnx_time_end(h, GNX_K_COMPACT, (double)N * 16.0 + (double)h->fill_guess * (16.0 + 2.0 * rec_bytes));
   } else {
@@ -1613,9 +1659,10 @@ int gnx_l_mortality_enqueue(gnx_state* h, const uint8_t* d_dead_inject) {
     if (h->ord_inflight) h->ord_inflight = false;       // (stream3 runs them in order)
     GnxScanOut So{h->ord_off, nullptr, nullptr, 0, nullptr, h->tickets + 2, h->blk_stride};
     hipLaunchKernelGGL(k_ord_flags, dim3(nb), dim3(256), 0, h->stream3, N, h->ord_n,
-                       h->ord[h->ord_cur], h->newslot, h->ord_cnt, So);
+                       h->ord[h->ord_cur], h->newslot, h->ord_cnt, So, (const GnxDD*)nullptr);
     hipLaunchKernelGGL(k_ord_write, dim3(nb), dim3(256), 0, h->stream3, N, h->ord_n,
-                       h->ord[h->ord_cur], h->newslot, h->ord_off, h->ord[h->ord_cur ^ 1]);
+                       h->ord[h->ord_cur], h->newslot, h->ord_off, h->ord[h->ord_cur ^ 1],
+                       (const GnxDD*)nullptr);
     // the cell sort waits for the crossover AND for this: stream3 waits for the crossover here,
     // where nothing waits for stream3, and the sort's stream waits for one event instead of two
     h->ord_covers_xo = false;
@@ -1668,6 +1715,174 @@ int gnx_l_mortality_finish(gnx_state* h, int64_t* deaths_out) {
   h->n_ghost = 0;
   if (!fill) h->cur ^= 1;
   if (ord_keep) h->ord_n = survivors;
+  return 0;
+}
+
+// ---------------------------------------------------------------- device-driven step
+// (gnx_dd.hip) the density, death and mortality kernels with capacity-sized grids and their
+// counts read from h->dd; `par` = the step's parity (which of the alternating buffers)
+int gnx_dd_l_bins_adults(gnx_state* h, int par, hipStream_t st) {
+  const GnxLattice& L = h->lat;
+  const int nb = L.nbx * L.nby;
+  GnxSoA s = h->soa[h->cur];
+  const int64_t cap = h->cfg.cap_inds;
+  const int blocks = (int)std::min<int64_t>(BIN_BLOCKS, std::max<int64_t>(1, (cap + 255) / 256));
+  hipLaunchKernelGGL(k_bins, dim3(blocks), dim3(256), (size_t)nb * sizeof(int32_t), st, cap,
+                     (const int32_t*)&h->dd->N, (const float*)s.x, (const float*)s.y,
+                     (const uint8_t*)nullptr, 1.0 / L.hww, L.nbx, L.nby, h->fb[par]);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// the pair midpoints' bins and lattice (fb[2], cleared again by the lattice kernel)
+int gnx_dd_l_density_pairs(gnx_state* h, hipStream_t st) {
+  const GnxLattice& L = h->lat;
+  const int64_t nn = (int64_t)L.Jx * L.Jy;
+  const int nb = L.nbx * L.nby;
+  const size_t lds_bytes = ((size_t)4 * nn + std::max(L.Jx, L.Jy) + 1) * sizeof(double);
+  const int64_t cap = h->cfg.cap_inds;
+  const int blocks = (int)std::min<int64_t>(BIN_BLOCKS, std::max<int64_t>(1, (cap / 2 + 255) / 256));
+  hipLaunchKernelGGL(k_bins, dim3(blocks), dim3(256), (size_t)nb * sizeof(int32_t), st, cap,
+                     (const int32_t*)&h->dd->P, (const float*)h->mid_x, (const float*)h->mid_y,
+                     (const uint8_t*)nullptr, 1.0 / L.hww, L.nbx, L.nby, h->fb[2]);
+  hipLaunchKernelGGL(k_lattice, dim3(1), dim3(256), lds_bytes, st, L.Jx, L.Jy, L.nbx,
+                     (const int32_t*)h->fb[2], L.areas, L.hww, L.cprime, h->spl_P.c,
+                     (int32_t*)nullptr, 0, (unsigned long long*)nullptr, 1, 1);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// lattice + N.max() of everybody (adults + newborns in fb[par]); clears the other parity's
+// bins and N.max() word for the next step
+int gnx_dd_l_density_N(gnx_state* h, int par, hipStream_t st) {
+  const GnxLattice& L = h->lat;
+  const int64_t nn = (int64_t)L.Jx * L.Jy;
+  const size_t lds_bytes = ((size_t)4 * nn + std::max(L.Jx, L.Jy) + 1 + 2 * L.Jx + 256) * sizeof(double);
+  static const int blocks_env = getenv("GNX_LATN_BLOCKS") ? atoi(getenv("GNX_LATN_BLOCKS")) : 256;
+  hipLaunchKernelGGL(k_lattice_nmax, dim3(std::max(1, std::min(h->cfg.H, blocks_env))), dim3(256),
+                     lds_bytes, st, L.Jx, L.Jy, L.nbx, (const int32_t*)h->fb[par], L.areas, L.hww,
+                     L.cprime, h->spl_N.c, h->cfg.W, h->cfg.H, h->nmax2 + par, h->fb[par ^ 1],
+                     h->nmax2 + (par ^ 1));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int gnx_dd_l_death_probs(gnx_state* h, bool with_selection, int par, hipStream_t st) {
+  h->spl_N.valid = h->spl_P.valid = true;
+  SplineC SN = make_splinec(h, h->spl_N), SP = make_splinec(h, h->spl_P);
+  DeathP Q = make_deathp(h, with_selection);
+  Q.dd = h->dd;
+  hipLaunchKernelGGL(k_death_probs, dim3(gnx_grid(h->cfg.cap_inds, 256)), dim3(256), 0, st, Q,
+                     make_demp(h), SN, SP, h->soa[h->cur], h->rast, gnx_trait_tab(h), h->delet_s,
+                     (const unsigned long long*)(h->nmax2 + par), h->p_death, h->d_cell);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// death draws and block counts (xo: the surviving offspring wait for their genome rows;
+// the job list of buffer `buf` is emptied), then the scan of the block counts
+int gnx_dd_l_alive(gnx_state* h, bool xo, int buf, hipStream_t st) {
+  const gnx_config& c = h->cfg;
+  GnxSoA a = h->soa[h->cur];
+  const int nb = (int)((c.cap_inds + GNX_CB - 1) / GNX_CB);
+  hipLaunchKernelGGL(k_alive, dim3(nb), dim3(256), 0, st, (int64_t)c.cap_inds, h->p_death,
+                     (const uint8_t*)nullptr, a.id, a.ghost, a.grow, 0ll, c.seed, h->flag, h->flag2,
+                     h->blk_cnt, h->blk_stride, xo ? (int64_t)0 : (int64_t)-1,
+                     xo ? h->n_jobs_dev[buf] : (int32_t*)nullptr, (const GnxDD*)h->dd);
+  GNXCHK(gnx_block_scan(h, 3, c.cap_inds, h->blk_cnt, h->blk_off, h->cnt_dev, nullptr, 0, st));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int gnx_dd_l_jobs(gnx_state* h, int buf, hipStream_t st) {
+  hipStream_t keep = h->stream;
+  h->stream = st;
+  h->jobs_self_scan = false;
+  gnx_launch_xo_jobs_surv(h, 0, h->flag, h->blk_off, buf);
+  h->stream = keep;
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int gnx_dd_l_fill_lists(gnx_state* h, int has_rows, hipStream_t st) {
+  const gnx_config& c = h->cfg;
+  const int nb = (int)((c.cap_inds + GNX_CB - 1) / GNX_CB);
+  hipLaunchKernelGGL(k_fill_lists, dim3(nb), dim3(256), 0, st, (int64_t)c.cap_inds, h->flag, h->flag2,
+                     h->blk_off, h->blk_stride, h->cnt_dev, h->soa[h->cur].grow, has_rows,
+                     (int32_t*)h->os_ktmp, (int32_t*)h->os_ktmp + c.cap_inds / 2,
+                     (int32_t*)h->os_vtmp, h->newslot, h->fill_cnt, (const GnxDD*)h->dd);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int gnx_dd_l_fill(gnx_state* h, int has_rows, bool xo, hipStream_t st) {
+  const gnx_config& c = h->cfg;
+  GnxSoA a = h->soa[h->cur];
+  const int grid = (int)std::min<int64_t>(gnx_grid(std::max<int64_t>(c.cap_inds / 8, 4096), 256), 8192);
+  hipLaunchKernelGGL(k_fill, dim3(grid), dim3(256), 0, st, (int64_t)c.cap_inds, h->fill_cnt,
+                     (const int32_t*)h->os_ktmp, (const int32_t*)h->os_ktmp + c.cap_inds / 2,
+                     h->cnt_dev, a, c.n_layers, c.n_traits, a.tb ? 2 * h->TW : 0,
+                     (const int32_t*)h->os_vtmp, h->free_rows, (int64_t)0, has_rows, xo ? 1 : 0,
+                     h->newslot, (const GnxDD*)h->dd);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// the id-ordered index follows the compaction (flips ord_cur)
+int gnx_dd_l_ord(gnx_state* h, hipStream_t st) {
+  const gnx_config& c = h->cfg;
+  const int nb = (int)((c.cap_inds + GNX_CB - 1) / GNX_CB);
+  GnxScanOut So{h->ord_off, nullptr, nullptr, 0, nullptr, h->tickets + 2, h->blk_stride};
+  hipLaunchKernelGGL(k_ord_flags, dim3(nb), dim3(256), 0, st, (int64_t)c.cap_inds, (int64_t)0,
+                     h->ord[h->ord_cur], h->newslot, h->ord_cnt, So, (const GnxDD*)h->dd);
+  hipLaunchKernelGGL(k_ord_write, dim3(nb), dim3(256), 0, st, (int64_t)c.cap_inds, (int64_t)0,
+                     h->ord[h->ord_cur], h->newslot, h->ord_off, h->ord[h->ord_cur ^ 1],
+                     (const GnxDD*)h->dd);
+  HIPCHK(hipGetLastError());
+  h->ord_cur ^= 1;
+  return 0;
+}
+
+// The step's last kernel: the device block moves on to the next step and a record of this
+// one goes to pinned host memory (the host reads it when it likes - nothing waits for it).
+__global__ void k_dd_end(GnxDD* dd, const int32_t* __restrict__ cnts, const int32_t* __restrict__ half_top,
+                         GnxDDRec* __restrict__ ring, int has_rows, int xo) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int32_t S = cnts[0], freed = cnts[1], X = xo ? cnts[2] : 0;
+  GnxDDRec r;
+  r.N0 = dd->N;
+  r.P = dd->P;
+  r.B = dd->B;
+  r.S = S;
+  r.xo = X;
+  const int32_t n_free = dd->n_free - X + (has_rows ? freed : 0);
+  r.n_free = n_free;
+  r.half_top = half_top ? *half_top : 0;
+  r.err = dd->err;
+  r.max_id = dd->max_id + dd->B;
+  r.step = dd->step;
+  const int32_t seq = dd->seq + 1;
+  dd->N = S;
+  dd->ord_n = S;
+  dd->n_free = n_free;
+  dd->max_id = r.max_id;
+  dd->step = dd->step + 1;
+  dd->seq = seq;
+  dd->P = 0;
+  dd->B = 0;
+  GnxDDRec* slot = ring + ((seq - 1) % GNX_DD_RING);
+  __hip_atomic_store(&slot->seq, (int64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  int64_t* w = (int64_t*)slot;
+  const int64_t* v = (const int64_t*)&r;
+  for (int k = 1; k < (int)(sizeof(GnxDDRec) / 8); ++k)
+    __hip_atomic_store(&w[k], v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&slot->seq, (int64_t)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int gnx_dd_l_end(gnx_state* h, int has_rows, bool xo, hipStream_t st) {
+  hipLaunchKernelGGL(k_dd_end, dim3(1), dim3(64), 0, st, h->dd, (const int32_t*)h->cnt_dev,
+                     (const int32_t*)h->half_top, h->dd_ring_dev, has_rows, xo ? 1 : 0);
+  HIPCHK(hipGetLastError());
   return 0;
 }
 

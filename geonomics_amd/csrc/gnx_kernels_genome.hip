@@ -136,6 +136,13 @@ static int xo_launch(gnx_state* h, hipStream_t st, int buf, int64_t max_jobs, bo
   return 0;
 }
 
+// device-driven step (gnx_dd.hip): the crossover of job buffer `buf`, job count on the device
+int gnx_dd_l_crossover(gnx_state* h, int buf, hipStream_t st) {
+  // (at most every second individual is a parent of a kept pair: half the capacity in births,
+  // two gametes each; the kernel is job-strided, the bound only sizes the grid)
+  return xo_launch(h, st, buf, h->cfg.cap_inds / 4, false);
+}
+
 // algorithmic bytes per birth whose two gametes are both copied.  Dense masks:
 // 4 parental homologues + 2 masks read, 2 homologues written = 8 * L/8 = L bytes.  Sparse
 // paths: each gamete chunk copies ONE parental homologue (the other is never needed, the

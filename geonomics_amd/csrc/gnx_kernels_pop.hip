@@ -127,6 +127,7 @@ struct MoveP {
   int ncx, ncy, idbits;
   uint32_t* cell32;
   int tile_floats;
+  const GnxDD* dd;           // device-driven step: N and the step index live on the device
 };
 
 __constant__ float c_queen_dirs[8] = {-2.35619449019234492885f, -1.57079632679489661923f,
@@ -270,6 +271,8 @@ k_move(MoveP P, GnxSoA s, const float* rast, const float* inj_theta, const float
   extern __shared__ float surf_tile[];       // P.tile_floats floats
   __shared__ int surf_box[4];
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  P.N = gnx_dd_n(P.dd, P.N);
+  P.step = gnx_dd_step(P.dd, P.step);
   const bool act = i < P.N;
   // every load that does not depend on the draw goes out with the position: beside the
   // crossover a memory round trip costs several microseconds, and id and age each had one of
@@ -337,7 +340,9 @@ k_move(MoveP P, GnxSoA s, const float* rast, const float* inj_theta, const float
 
 int gnx_l_move(gnx_state* h, bool inc_age, const float* inj_theta, const float* inj_dist,
                float* out_theta, float* out_dist, bool apply) {
-  if (h->N == 0) return 0;
+  // device-driven step (gnx_dd.hip): the grid covers the capacity, the kernel reads N itself
+  const bool ddm = h->dd_active;
+  if (!ddm && h->N == 0) return 0;
   if (apply) {                            // bins counted before a movement are stale
     h->fb_adults = false;
     h->fb_pending = false;
@@ -345,6 +350,7 @@ int gnx_l_move(gnx_state* h, bool inc_age, const float* inj_theta, const float* 
   const gnx_config& c = h->cfg;
   const gnx_species_params& sp = h->sp;
   MoveP P;
+  P.dd = ddm ? h->dd : nullptr;
   P.N = h->N;
   P.cap = c.cap_inds;
   P.W = c.W;
@@ -384,7 +390,7 @@ int gnx_l_move(gnx_state* h, bool inc_age, const float* inj_theta, const float* 
   static const int tile_env = getenv("GNX_MOVE_TILE") ? atoi(getenv("GNX_MOVE_TILE")) : 2048;
   P.tile_floats = sp.move_surf != GNX_SURF_NONE ? std::max(256, std::min(tile_env, 12288)) : 0;
   gnx_time_begin(h);
-  hipLaunchKernelGGL(k_move, dim3(gnx_grid(h->N, 256)), dim3(256),
+  hipLaunchKernelGGL(k_move, dim3(gnx_grid(ddm ? (int64_t)c.cap_inds : h->N, 256)), dim3(256),
                      (size_t)P.tile_floats * sizeof(float), h->stream, P,
                      h->soa[h->cur], h->rast, inj_theta, inj_dist, out_theta, out_dist);
   // per individual: x,y rw 16 + id 8 + age rw 8 + e store 4*n_lyr + raster gathers 4*n_lyr
@@ -445,8 +451,16 @@ __global__ void k_permute(int64_t N, int64_t cap, const int32_t* perm, GnxSoA a,
                           int32_t* cell_start, int ncells, const uint32_t* __restrict__ cellk,
                           const int32_t* __restrict__ ord, int64_t ord_n,
                           int32_t* __restrict__ ord_new, int32_t* __restrict__ perm_out,
-                          uint4* __restrict__ wipe, int64_t wipe_n, int hot_only) {
+                          uint4* __restrict__ wipe, int64_t wipe_n, int hot_only,
+                          const GnxDD* __restrict__ dd) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (dd) {
+    // device-driven step: the sort ran over the handle's capacity, the entries behind the
+    // population carry the largest key and came out behind it
+    N = dd->N;
+    ord_n = dd->ord_n;
+    pair_seed = gnx_pair_seed(pair_seed, dd->step);      // (pair_seed = the seed here)
+  }
   // the radix sort's scratch (histograms, look-back states) is zero again for the next sort:
   // no fill kernels in front of it (two, 6 us each, on the step's critical path)
   for (int64_t w = i; w < wipe_n; w += (int64_t)gridDim.x * blockDim.x)
@@ -661,7 +675,7 @@ int gnx_l_sort_by_cell(gnx_state* h, bool split_rest) {
                      h->key64[1], idbits, h->cell_start, h->ncx * h->ncy,
                      ordm ? h->keyk[1] : nullptr, h->ord[h->ord_cur], h->ord_n,
                      h->ord[h->ord_cur ^ 1], h->perm[1], (uint4*)h->os_scratch, (wipe_words + 3) / 4,
-                     split ? 1 : 0);
+                     split ? 1 : 0, (const GnxDD*)nullptr);
   if (split) {
     // the columns nobody reads before the births follow on stream3, beside the mate search and
     // the pair list; whoever asked for the split waits (gnx_wait_permute_rest).
@@ -774,6 +788,7 @@ struct FocalP {
   int sexed, ra_f;
   long long step;
   unsigned long long seed;
+  const GnxDD* dd;
 };
 
 // the three row ranges of a focal individual's 3x3 block of cells (an absent row has
@@ -824,6 +839,9 @@ k_find_mates(FocalP fp, GnxSoA s, const uint4* __restrict__ cand, double inv_cs,
   __shared__ int32_t n_hard_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t base = (int64_t)blockIdx.x * FM_PER_BLOCK;
+  fp.N = gnx_dd_n(fp.dd, fp.N);
+  fp.step = gnx_dd_step(fp.dd, fp.step);
+  if (base >= fp.N) return;                     // (block-uniform)
   // phase 1: block-local, order-preserving list of the individuals that need a mate
   // (all four rounds' loads and draws first, then one exchange of the wave counts)
   constexpr int ROUNDS = FM_PER_BLOCK / 256;
@@ -1129,6 +1147,7 @@ struct PairP {
   int sexed, ra_f, ra_m, dedup;
   long long step;
   unsigned long long seed;
+  const GnxDD* dd;
 };
 
 __device__ __forceinline__ bool pair_ok(const PairP& P, const GnxSoA& s, int64_t i) {
@@ -1156,6 +1175,8 @@ __global__ void __launch_bounds__(256)
 k_pair_flags(PairP P, GnxSoA s, int32_t* flag2, int32_t* cnt) {
   __shared__ int lds[16];
   const int64_t base = (int64_t)blockIdx.x * GNX_CB;
+  P.N = gnx_dd_n(P.dd, P.N);
+  P.step = gnx_dd_step(P.dd, P.step);
   bool f[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -1190,9 +1211,11 @@ k_pair_compact(int64_t N, const int32_t* focal, const int32_t* mate, const int32
                const int32_t* blk_off, const float* x, const float* y, const uint64_t* popkey,
                int idbits, int32_t* pairs, float* mid_x, float* mid_y, uint64_t* key,
                const int32_t* __restrict__ cnt, int32_t* __restrict__ total_dev,
-               int64_t* __restrict__ host, long long seq, const int32_t* __restrict__ extra) {
+               int64_t* __restrict__ host, long long seq, const int32_t* __restrict__ extra,
+               GnxDD* __restrict__ dd, int dd_births, int64_t dd_cap) {
   __shared__ int lds[16];
   __shared__ int psum[4];
+  if (dd) N = dd->N;
   // cnt != null: no scan kernel ran - every workgroup adds up the block counts before its own
   // (a few coalesced loads from L2: 1 210 counts at the metric size), and workgroup 0, the
   // first to start, adds up all of them and hands the total to the host and to the device
@@ -1211,6 +1234,17 @@ k_pair_compact(int64_t N, const int32_t* focal, const int32_t* mate, const int32
     self_off = blockIdx.x == 0 ? 0 : sum;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       *total_dev = sum;
+      if (dd) {
+        // device-driven step: pairs and births of the step (a fixed number per pair), and the
+        // slots they need - a step whose offspring do not fit appends none and says so
+        int64_t births = (int64_t)sum * dd_births;
+        if ((int64_t)dd->N + births > dd_cap) {
+          dd->err |= GNX_DD_ERR_SLOTS;
+          births = 0;
+        }
+        dd->P = sum;
+        dd->B = (int32_t)births;
+      }
       if (host) {
         // (system-scope stores that have completed before the sequence number goes out: no
         // release fence, which would write this XCD's L2 back - gnx_compact.h)
@@ -1327,7 +1361,8 @@ int gnx_l_find_pairs_enqueue(gnx_state* h, const uint8_t* d_keep, bool with_dens
                      h->mid_x, h->mid_y, h->key64[0],
                      self_scan ? (const int32_t*)h->blk_cnt : (const int32_t*)nullptr, h->cnt_dev,
                      h->h_pin_dev + 4, (long long)seq,
-                     with_top ? (const int32_t*)h->half_top : (const int32_t*)nullptr);
+                     with_top ? (const int32_t*)h->half_top : (const int32_t*)nullptr,
+                     (GnxDD*)nullptr, 0, (int64_t)0);
   gnx_time_end(h, GNX_K_PAIRS, (double)N * 40.0);
   HIPCHK(hipGetLastError());
   // the pair midpoints' density (ops/demography.py:60-91): on one GPU bins + lattice run on
@@ -1414,6 +1449,7 @@ struct OffP {
   const uint64_t* path_sel;
   const uint8_t* dom;
   GnxBinP bins;          // the individuals' density bins (the newborns join the adults)
+  const GnxDD* dd;       // device-driven step: N, B, first id and step index from the device
 };
 
 // gamete requests of a tiled run: the mate is a ghost (it lives on a neighbour
@@ -1450,6 +1486,12 @@ k_offspring(OffP P, GnxSoA s, const float* rast, const int32_t* pairs, const int
             const int32_t* boff, const int64_t* goff,
             int32_t* off_parent, int32_t* off_keys, uint8_t* off_start, GnxReq rq, GnxTraitTab T) {
   int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (P.dd) {
+    P.N = P.dd->N;
+    P.B = P.dd->B;
+    P.id_base = P.dd->max_id + 1;
+    P.step = P.dd->step;
+  }
   if (k >= P.B) return;
   int64_t p, ord;
   if (P.fixed_nb > 0) {
@@ -1627,6 +1669,44 @@ int gnx_l_births(gnx_state* h, int64_t* births_out) {
   return 0;
 }
 
+static OffP gnx_make_offp(gnx_state* h, bool genomes, bool tiled, int64_t id_base, int64_t B) {
+  const gnx_config& c = h->cfg;
+  const gnx_species_params& sp = h->sp;
+  OffP Q;
+  Q.dd = nullptr;
+  Q.N = h->N;
+  Q.B = B;
+  Q.cap = c.cap_inds;
+  Q.W = c.W;
+  Q.H = c.H;
+  Q.n_layers = c.n_layers;
+  Q.xmax = (float)(c.W - 0.001);
+  Q.ymax = (float)(c.H - 0.001);
+  Q.rrx = (float)sp.res_ratio[0];
+  Q.rry = (float)sp.res_ratio[1];
+  Q.distr = sp.disp_distr;
+  Q.p1 = (float)sp.disp_p1;
+  Q.p2 = (float)sp.disp_p2;
+  Q.surf = sp.disp_surf;
+  Q.surf_layer = sp.disp_surf_layer;
+  Q.surf_kappa = (float)sp.disp_surf_kappa;
+  Q.sexed = sp.sexed;
+  Q.p_male = (float)sp.p_male;
+  Q.fixed_nb = sp.n_births_fixed ? (int)sp.n_births_lambda : 0;
+  Q.genomes = genomes ? 1 : 0;
+  Q.n_paths = h->n_paths;
+  Q.id_base = id_base >= 0 ? id_base : h->max_id + 1;
+  Q.n_free = h->n_free;
+  Q.step = h->step;
+  Q.seed = c.seed;
+  Q.fuse_tb = (genomes && !tiled) ? 1 : 0;
+  Q.TW = h->TW;
+  Q.path_sel = h->path_sel;
+  Q.dom = h->dom;
+  Q.bins = GnxBinP{nullptr, 1.0 / h->lat.hww, h->lat.nbx, h->lat.nby};
+  return Q;
+}
+
 // Appends the offspring of the current pair list (or, inject: of the uploaded
 // parent list).  tiled: births were counted by gnx_l_births, offspring ids are
 // id_base + pair_goff[pair] + ordinal, gametes of ghost mates are requested,
@@ -1634,7 +1714,6 @@ int gnx_l_births(gnx_state* h, int64_t* births_out) {
 int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* births_out,
                int64_t id_base, bool tiled) {
   const gnx_config& c = h->cfg;
-  const gnx_species_params& sp = h->sp;
   GnxSoA s = h->soa[h->cur];
   *births_out = 0;
   int64_t B = 0;
@@ -1659,38 +1738,8 @@ int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* 
                     (long long)h->N, (long long)B, (long long)c.cap_inds, (long long)h->n_free);
       return 2;
     }
-    OffP Q;
-    Q.N = h->N;
-    Q.B = B;
-    Q.cap = c.cap_inds;
-    Q.W = c.W;
-    Q.H = c.H;
-    Q.n_layers = c.n_layers;
-    Q.xmax = (float)(c.W - 0.001);
-    Q.ymax = (float)(c.H - 0.001);
-    Q.rrx = (float)sp.res_ratio[0];
-    Q.rry = (float)sp.res_ratio[1];
-    Q.distr = sp.disp_distr;
-    Q.p1 = (float)sp.disp_p1;
-    Q.p2 = (float)sp.disp_p2;
-    Q.surf = sp.disp_surf;
-    Q.surf_layer = sp.disp_surf_layer;
-    Q.surf_kappa = (float)sp.disp_surf_kappa;
-    Q.sexed = sp.sexed;
-    Q.p_male = (float)sp.p_male;
-    Q.fixed_nb = sp.n_births_fixed ? (int)sp.n_births_lambda : 0;
-    Q.genomes = genomes ? 1 : 0;
-    Q.n_paths = h->n_paths;
-    Q.id_base = id_base >= 0 ? id_base : h->max_id + 1;
-    Q.n_free = h->n_free;
-    Q.step = h->step;
-    Q.seed = c.seed;
-    Q.fuse_tb = (genomes && !tiled) ? 1 : 0;
-    Q.TW = h->TW;
-    Q.path_sel = h->path_sel;
-    Q.dom = h->dom;
+    OffP Q = gnx_make_offp(h, genomes, tiled, id_base, B);
     // (the adults were counted by k_permute of this very population)
-    Q.bins = GnxBinP{nullptr, 1.0 / h->lat.hww, h->lat.nbx, h->lat.nby};
     if (gnx_fused_bins(h) && h->fb_adults && h->fb_count == h->N) {
       Q.bins.bins = h->fb[h->fb_cur];
       h->fb_count += B;
@@ -1752,6 +1801,79 @@ int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* 
   h->N += B;
   if (!tiled) h->max_id += B;
   *births_out = B;
+  return 0;
+}
+
+// ---------------------------------------------------------------- device-driven step
+// The launchers of gnx_dd.hip's step: the kernels above with their grids sized by the
+// handle's capacity and their counts read from h->dd on the device; no host state moves.
+int gnx_dd_l_sort(gnx_state* h, hipStream_t st) {
+  const gnx_config& c = h->cfg;
+  const int64_t n_fixed = c.cap_inds;
+  GnxSoA a = h->soa[h->cur], b = h->soa[h->cur ^ 1];
+  // stable sort of the id-ordered index by cell alone, over the capacity: entries behind the
+  // population carry the largest key (k_keys_hist)
+  GNXCHK(gnx_os_keys_hist(h->os_scratch, h->tickets + 3, n_fixed, 0, h->ord[h->ord_cur], h->cell32,
+                          h->keyk[0], h->valk[0], h->key_bits, st, h->dd));
+  GNXCHK(gnx_os_sort32_ranked(h->os_scratch, h->os_ktmp, h->os_vtmp, h->keyk[0], h->keyk[1],
+                              h->valk[0], h->valk[1], (size_t)n_fixed, h->key_bits, st));
+  const int64_t wipe_words = (int64_t)gnx_os_words_used((size_t)n_fixed, h->key_bits);
+  hipLaunchKernelGGL(k_permute, dim3(gnx_grid(n_fixed, 256)), dim3(256), 0, st, n_fixed, c.cap_inds,
+                     h->valk[1], a, b, c.n_layers, c.n_traits, a.tb ? 2 * h->TW : 0,
+                     (unsigned long long)c.seed, h->tag, (uint4*)h->cand, h->key64[1], 40,
+                     h->cell_start, h->ncx * h->ncy, h->keyk[1], h->ord[h->ord_cur], (int64_t)0,
+                     h->ord[h->ord_cur ^ 1], h->perm[1], (uint4*)h->os_scratch, (wipe_words + 3) / 4,
+                     0, (const GnxDD*)h->dd);
+  HIPCHK(hipGetLastError());
+  h->ord_cur ^= 1;
+  h->cur ^= 1;
+  return 0;
+}
+
+int gnx_dd_l_pairs(gnx_state* h, hipStream_t st) {
+  const gnx_species_params& sp = h->sp;
+  const int64_t cap = h->cfg.cap_inds;
+  GnxSoA s = h->soa[h->cur];
+  const float r = (float)sp.mating_radius, r2 = r * r;
+  FocalP fp{cap, nullptr, (float)sp.b, sp.sexed, sp.repro_age[0], 0, h->cfg.seed, h->dd};
+  dim3 grid(gnx_grid(cap, FM_PER_BLOCK)), blk(256);
+  const uint4* cd = (const uint4*)h->cand;
+  static const int easy = getenv("GNX_FM_EASY") ? std::max(1, atoi(getenv("GNX_FM_EASY"))) : 2;
+  if (sp.mate_mode == GNX_MATE_NEAREST)
+    hipLaunchKernelGGL(k_find_mates<GNX_MATE_NEAREST>, grid, blk, 0, st, fp, s, cd, h->inv_cs,
+                       h->cell_start, h->ncx, h->ncy, h->cell_ref, r, r2, easy, h->mate);
+  else if (sp.mate_mode == GNX_MATE_INVERSE)
+    hipLaunchKernelGGL(k_find_mates<GNX_MATE_INVERSE>, grid, blk, 0, st, fp, s, cd, h->inv_cs,
+                       h->cell_start, h->ncx, h->ncy, h->cell_ref, r, r2, easy, h->mate);
+  else
+    hipLaunchKernelGGL(k_find_mates<GNX_MATE_UNIFORM>, grid, blk, 0, st, fp, s, cd, h->inv_cs,
+                       h->cell_start, h->ncx, h->ncy, h->cell_ref, r, r2, easy, h->mate);
+  const int nb = (int)((cap + GNX_CB - 1) / GNX_CB);
+  PairP pp{cap, nullptr, h->mate, nullptr, (float)sp.b, sp.sexed, sp.repro_age[0], sp.repro_age[1],
+           sp.sexed ? 0 : 1, 0, h->cfg.seed, h->dd};
+  hipLaunchKernelGGL(k_pair_flags, dim3(nb), dim3(256), 0, st, pp, s, h->flag2, h->blk_cnt);
+  // the pair list, in slot order; workgroup 0 adds up the block counts and leaves the pair
+  // count, the births (a fixed number per pair) and the capacity check in the device block
+  hipLaunchKernelGGL(k_pair_compact, dim3(nb), dim3(256), 0, st, cap, (const int32_t*)nullptr,
+                     h->mate, h->flag2, h->blk_off, s.x, s.y, h->key64[1], 40, h->pairs, h->mid_x,
+                     h->mid_y, h->key64[0], (const int32_t*)h->blk_cnt, h->cnt_dev,
+                     (int64_t*)nullptr, 0ll, (const int32_t*)nullptr, h->dd,
+                     (int)sp.n_births_lambda, (int64_t)cap);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int gnx_dd_l_offspring(gnx_state* h, bool genomes, int32_t* d_bins, hipStream_t st) {
+  OffP Q = gnx_make_offp(h, genomes, false, 0, 0);
+  Q.dd = h->dd;
+  Q.bins.bins = d_bins;
+  // (a pair has a fixed number of births here: at most every second individual is a focal one
+  // of a kept pair, so the capacity bounds the grid generously; the kernel reads B itself)
+  hipLaunchKernelGGL(k_offspring, dim3(gnx_grid(h->cfg.cap_inds, 256)), dim3(256), 0, st, Q,
+                     h->soa[h->cur], h->rast, h->pairs, h->off_pair, h->boff,
+                     (const int64_t*)nullptr, h->off_parent, h->off_keys, h->off_start, GnxReq{},
+                     gnx_trait_tab(h));
+  HIPCHK(hipGetLastError());
   return 0;
 }
 

@@ -202,8 +202,16 @@ __global__ void __launch_bounds__(1024)
 k_keys_hist(long long N, long long ord_n, const int32_t* __restrict__ ord,
             const uint32_t* __restrict__ cell32, uint32_t* __restrict__ key,
             int32_t* __restrict__ val, unsigned int* __restrict__ hist, int places,
-            unsigned int* __restrict__ ticket) {
+            unsigned int* __restrict__ ticket, long long n_fixed, unsigned int sentinel,
+            const GnxDD* __restrict__ dd) {
   constexpr unsigned R = 1u << RB;
+  // device-driven step: the population's size lives on the device and the sort runs over a
+  // fixed n_fixed >= N entries; those behind the population carry the largest key, so the
+  // stable sort leaves them behind everybody
+  if (dd) {
+    N = dd->N;
+    ord_n = dd->ord_n;
+  }
   static_assert(R == 1024, "one digit per thread");
   __shared__ unsigned int lh[3][R];
   __shared__ unsigned int wsum[16];
@@ -220,11 +228,11 @@ k_keys_hist(long long N, long long ord_n, const int32_t* __restrict__ ord,
     slot[r] = k < N ? (k < ord_n ? ord[k] : (int32_t)k) : -1;
   }
 #pragma unroll
-  for (unsigned r = 0; r < IPT; ++r) c[r] = slot[r] >= 0 ? cell32[slot[r]] : 0u;
+  for (unsigned r = 0; r < IPT; ++r) c[r] = slot[r] >= 0 ? cell32[slot[r]] : sentinel;
 #pragma unroll
   for (unsigned r = 0; r < IPT; ++r) {
     const long long k = base + r * 1024 + tid;
-    if (slot[r] < 0) continue;
+    if (slot[r] < 0 && k >= n_fixed) continue;
     key[k] = c[r];
     val[k] = (int32_t)k;
     for (int pl = 0; pl < places; ++pl) atomicAdd(&lh[pl][(c[r] >> (pl * RB)) & (R - 1u)], 1u);
@@ -300,13 +308,16 @@ size_t gnx_os_words_used(size_t n, int end_bit) {
 }
 int gnx_os_keys_hist(void* scratch, unsigned int* ticket, int64_t N, int64_t ord_n,
                      const int32_t* ord, const uint32_t* cell32, uint32_t* key, int32_t* val,
-                     int end_bit, hipStream_t s) {
+                     int end_bit, hipStream_t s, const GnxDD* dd) {
   const int places = (end_bit + 9) / 10;
   if (places > 3) return 1;
   // (2, 3, 4, 8 keys per thread instead of 6: the same step time, profiles/r03_ab_runs.txt)
+  // dd: N is the fixed number of entries the sort runs over, the population's own size is read
+  // on the device
   const unsigned int blocks = (unsigned int)((N + 6143) / 6144);
   hipLaunchKernelGGL((gnx_os::k_keys_hist<10, 6>), dim3(blocks), dim3(1024), 0, s, (long long)N,
-                     (long long)ord_n, ord, cell32, key, val, (unsigned int*)scratch, places, ticket);
+                     (long long)ord_n, ord, cell32, key, val, (unsigned int*)scratch, places, ticket,
+                     (long long)N, (1u << end_bit) - 1u, dd);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -88,6 +88,8 @@ class Model:
             self._orig_comm_snap = self._snapshot_comm()
         self.burn_fn_queue = None
         self.main_fn_queue = None
+        self.iteration_log = {}
+        self.iteration_times = {}       # it -> wall-clock (start, end) of its main phase
 
     def __str__(self):
         return ('%s\nModel name: %s\nLayers: %s\nSpecies: %s\nNumber of iterations: %i\n'
@@ -136,7 +138,9 @@ class Model:
             self._dev_seed = int(np.random.randint(0, 2 ** 31 - 1))
 
     def _set_it(self):
-        self.it = self.its.pop()
+        # (a lane of a concurrent run has already taken its iteration off the shared list)
+        nxt = self.__dict__.pop('_next_it', None)
+        self.it = self.its.pop() if nxt is None else nxt
 
     def _set_t(self):
         self.t += 1
@@ -346,7 +350,10 @@ class Model:
         for spp in self.comm.values():
             spp._reset_t()
         self._set_reassign_genomes()
-        if repeat_burn or self.it <= 0:
+        # (a Community made anew for this iteration needs a queue bound to ITS Species:
+        # the reference's condition - repeat_burn or the first iteration - leaves the old
+        # queue in place, whose entries here would call into a closed device)
+        if repeat_burn or self.it <= 0 or rand_comm or self.burn_fn_queue is None:
             self.burn_fn_queue = self._make_fn_queue(burn=True)
         self.main_fn_queue = self._make_fn_queue(burn=False)
 
@@ -430,8 +437,18 @@ class Model:
                            if spp.extinct), self.it), flush=True)
         return extinct
 
+    def _iter_seed(self, it):
+        """the host-side random stream of iteration it >= 1 (community / genomic
+        architecture / mutation / sampling draws).  The reference draws every iteration from
+        one global stream in turn (sim/model.py:364-366), which chains them; here each
+        iteration starts its own stream, so iterations can run in any order - and side by
+        side (run(concurrent=K)) - with the results of a sequential run."""
+        return (int(self._dev_seed) * 1000003 + 7919 * int(it) + 12345) % (2 ** 32)
+
     def _set_next_iteration(self):
         self._set_it()
+        if self.it > 0:
+            self._rng.seed(self._iter_seed(self.it))
         if self._verbose:
             print('~' * self.__term_width__ + '\n\n')
             print('Setting up iteration %i...\n\n' % self.it, flush=True)
@@ -440,6 +457,12 @@ class Model:
 
     def _do_next_iteration(self):
         """reference sim/model.py:808-858"""
+        self._iteration_burn()
+        self._iteration_main()
+
+    def _iteration_burn(self):
+        """set the next iteration up and burn it in (when this iteration has a burn-in of
+        its own: reference sim/model.py:808-840)"""
         self._set_next_iteration()
         if self.rand_comm or (not self.rand_comm and self.repeat_burn) or self.it == 0:
             if self._verbose:
@@ -449,6 +472,9 @@ class Model:
                     break
             if not self.rand_comm and not self.repeat_burn and self.n_its > 1:
                 self._orig_comm_snap = self._snapshot_comm()
+
+    def _iteration_main(self):
+        """the T main timesteps of the iteration (reference sim/model.py:841-858)"""
         if self._verbose:
             print('Running main model, iteration %i...\n\n' % self.it, flush=True)
         if np.any([spp.extinct for spp in self.comm.values()]):
@@ -456,18 +482,141 @@ class Model:
                 print("WARNING: At least one Species went extinct during the burn-in. "
                       "Cannot run main phase for iteration %i.\n\n" % self.it, flush=True)
             return
+        import time
+        t0 = time.perf_counter()
         for _ in range(self.T):
             if self._do_timestep('main'):
                 break
+        self.iteration_times[self.it] = (t0, time.perf_counter())
+        self._log_iteration()
+
+    def _log_iteration(self):
+        """per-iteration record (shared by the lanes of a concurrent run): population
+        sizes, births and deaths of every Species over the whole iteration"""
+        self.iteration_log[self.it] = {
+            spp.name: {'Nt': list(spp.Nt), 'n_births': list(spp.n_births),
+                       'n_deaths': list(spp.n_deaths), 'extinct': bool(spp.extinct)}
+            for spp in self.comm.values()}
+        hook = getattr(self, '_on_iteration_end', None)
+        if hook is not None:
+            hook(self)
+
+    # -- iterations side by side on one GPU ---------------------------------------------
+    # The reference walks its n_its iterations one after another and notes that they could
+    # be farmed out (sim/model.py:866-953, TODO at :924-925).  A model of 10^5 individuals
+    # fills a tenth of an MI355X: K iterations run as K "lanes" - clones of this Model, each
+    # with its own Community (device handle, three HIP streams of its own), landscape
+    # copy where the landscape changes, collectors and random stream - on K host threads;
+    # every call into libgnxhip.so releases the interpreter lock, so while one lane waits for
+    # a count its siblings enqueue, and the lanes' kernels share the chip.
+    def _concurrency(self, concurrent):
+        """lanes of run(): the argument, else GNX_CONCURRENT_ITS, else 1.  (Not more by
+        default: on ROCm 7.2 kernels of different handles barely overlap and the lanes' runtime
+        calls contend - measured 0.4-1.1 x the sequential rate, tools/its_bench.py)"""
+        if concurrent is None:
+            concurrent = int(os.environ.get('GNX_CONCURRENT_ITS', '1'))
+        k = max(1, min(int(concurrent), len(self.its)))
+        if self._comm is not None or self._device != 0:
+            k = 1           # tiles: one Species already spans the GPUs
+        return k
+
+    def _spawn_lane(self, template_comm, share_comm=False):
+        lane = copy.copy(self)
+        lane._is_lane = True
+        lane._verbose = False
+        lane._never_been_run = self._never_been_run if share_comm else False
+        if share_comm:
+            return lane           # the first iteration runs on the Community of make_model
+        # a random stream of its own (seeded per iteration, _set_next_iteration); everything
+        # the lane builds draws from it
+        lane._rng = np.random.RandomState(0)
+        if self._orig_land_copy is not None:
+            lane.land = copy.deepcopy(self._orig_land_copy)
+        if self.rand_comm:
+            lane.comm = {}        # _reset_community makes the iteration's Community
+        else:
+            # a Community of its own to restore the snapshot into; the genomic architecture
+            # persists across iterations (unless rand_genarch), so it is the template's
+            lane.comm = lane._make_community(False)
+            for k, spp in lane.comm.items():
+                src = template_comm[k]
+                if src.gen_arch is not None:
+                    spp.gen_arch = copy.deepcopy(src.gen_arch)
+                    spp._upload_gen_arch()
+        return lane
+
+    def _lane_loop(self, first_main_only=False):
+        """what run() does, on this lane, until the shared list of iterations is empty"""
+        first = first_main_only
+        while first or len(self.its) > 0:
+            try:
+                if first:
+                    first = False
+                    self._iteration_main()
+                else:
+                    try:
+                        self._next_it = self.its.pop()
+                    except IndexError:          # a sibling took the last iteration
+                        break
+                    self._iteration_burn()
+                    self._iteration_main()
+            except Exception as e:
+                msg = ('XXXX\tAn error occurred during iteration %i, timestep %i.\n'
+                       % (self.it, self.t if getattr(self.comm, 'burned', False)
+                          else self.burn_t))
+                print(msg)
+                print('Error message:\n\t%s\n\n' % e)
+                traceback.print_exc(file=sys.stdout)
+
+    def _run_concurrent(self, k):
+        import threading
+        last_it = max(self.its)
+        lanes = [self._spawn_lane(self.comm, share_comm=True)]
+        # the burned-in Community every later iteration starts from is a product of the
+        # first iteration's burn-in: that part runs before the siblings exist
+        first_main_only = False
+        if 0 in self.its and not self.rand_comm and not self.repeat_burn:
+            lanes[0]._iteration_burn()
+            self._orig_comm_snap = lanes[0]._orig_comm_snap
+            self._never_been_run = False
+            first_main_only = True
+        for _ in range(k - 1):
+            lanes.append(self._spawn_lane(lanes[0].comm))
+        threads = [threading.Thread(target=lane._lane_loop,
+                                    args=(first_main_only and n == 0,))
+                   for n, lane in enumerate(lanes)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        # the model is left as the sequential run leaves it: in the state of the last iteration
+        keep = [lane for lane in lanes if lane.it == last_it]
+        keep = keep[0] if keep else lanes[0]
+        for lane in lanes:
+            if lane is not keep:
+                for spp in (lane.comm.values() if lane.comm else []):
+                    if not any(spp is s for s in keep.comm.values()):
+                        spp._dev.close()
+        for name in ('comm', 'land', 't', 'burn_t', 'it', '_rng', '_stats_collector',
+                     '_data_collector', 'reassign_genomes', '_orig_comm_snap',
+                     '_orig_land_copy', 'orig_land'):
+            setattr(self, name, getattr(keep, name))
+        self._never_been_run = False
+        self.burn_fn_queue = self._make_fn_queue(burn=True)
+        self.main_fn_queue = self._make_fn_queue(burn=False)
 
     # -- public API ---------------------------------------------------------------------
-    def run(self, verbose=False):
+    def run(self, verbose=False, concurrent=None):
         """Run all iterations: burn-in then T main timesteps each
-        (reference sim/model.py:866-961)."""
+        (reference sim/model.py:866-961).  concurrent=K (or GNX_CONCURRENT_ITS=K) runs up
+        to K iterations side by side on the GPU, with the results of the sequential run."""
         self._verbose = verbose and self._rank == 0
         if self._verbose:
             print('\n\n' + '#' * self.__term_width__ + '\n\n')
             print('Running model "%s"...\n\n' % self.name, flush=True)
+        k = self._concurrency(concurrent)
+        if k > 1:
+            self._run_concurrent(k)
         while len(self.its) > 0:
             try:
                 self._do_next_iteration()

@@ -195,12 +195,35 @@ int gnx_step_begin(gnx_state* h, int32_t burn);
 int gnx_step_mid(gnx_state* h, int32_t burn, int32_t with_selection);
 int gnx_step_end(gnx_state* h, int32_t burn);
 int gnx_step_many(gnx_state** hs, int32_t n, int32_t burn, int32_t with_selection);
+/* T time steps without the host in the loop - Model.walk(T) of the reference
+ * (sim/model.py:966-1161: T times _do_timestep over the function queue, :699-744).
+ * gnx_step reads the pair count and the survivor count back in every step and sizes the
+ * next kernels with them; gnx_walk keeps every count of the step in device memory, sizes
+ * the grids by the handle's capacity and replays one captured HIP graph per step: one
+ * runtime call and no read-back per step (at 10^5 individuals - BASELINE configs[1], [2] -
+ * the host-driven step is bound by the ~45 runtime calls it makes, not by its kernels).
+ * Same draws, same canonical orders, same kernels: the population equals the one T calls of
+ * gnx_step leave, id by id.  A handle the device-driven step does not cover (tiles,
+ * panmixia, Poisson births, no movement, profiling on; GNX_DD=0) walks through gnx_step.
+ * The population must fit the capacity throughout: a step whose offspring do not fit is
+ * reported as an error when the walk ends.
+ * gnx_walk_many: the same for n INDEPENDENT handles (the iterations of one model,
+ * sim/model.py:866-953, TODO at :924-925), step t of every handle enqueued before step
+ * t + 1 of any, so that their kernels share the chip.
+ * gnx_walk_history: (N at the start, births, deaths) of the last max_steps steps of the
+ * last walk - Species.Nt / n_births / n_deaths (structs/species.py:374-380, 554) - returns
+ * how many were written.                                                                  */
+int gnx_walk(gnx_state* h, int64_t T, int32_t burn, int32_t with_selection);
+int gnx_walk_many(gnx_state** hs, int32_t n, int64_t T, int32_t burn, int32_t with_selection);
+int64_t gnx_walk_history(gnx_state* h, int64_t max_steps, int64_t* n_start, int64_t* births,
+                         int64_t* deaths);
 int gnx_counts(gnx_state* h, int64_t* N, int64_t* births, int64_t* deaths);
 /* Running totals over the gnx_step calls since the last gnx_reset_totals (what Species.Nt /
  * n_births / n_deaths accumulate step by step, structs/species.py:554,  kept in the library
  * so that a driver loop need not call back between steps): out[6] = steps, sum of N at the
  * START of each step (the metric's individual-timesteps), births, deaths, births whose
- * genomes the crossover wrote, 0.  Host-side bookkeeping only: no device access.         */
+ * genomes the crossover wrote, steps that gnx_walk took the device-driven way.  Host-side
+ * bookkeeping only: no device access.                                                       */
 int gnx_totals(gnx_state* h, int64_t* out);
 int gnx_reset_totals(gnx_state* h);
 /* Where the new offspring's genomes are cut (ops/mating.py:130-214, the crossover).

@@ -270,3 +270,88 @@ def test_in_place_compaction_equals_stable_copy(monkeypatch):
     assert moved and a.counts()[0] > 1500
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize('variant', ['sparse', 'dense', 'no_graph'])
+def test_small_path_equals_default_path(variant, monkeypatch):
+    """gnx_walk - every count of the step on the device, grids sized by the capacity, one
+    captured HIP graph per step, no read-back (the path BASELINE configs[1] and [2] take) -
+    against T calls of gnx_step, the many-kernel host-driven path: same seeds -> the same
+    population, id by id (positions, ages, phenotypes, fitness, genotypes), the same counts
+    in every step, burn-in steps and main steps, walks cut into pieces with host-driven
+    steps, a mutation and a forced block collection in between."""
+    if variant == 'no_graph':
+        monkeypatch.setenv('GNX_DD_GRAPH', '0')
+    dense = variant == 'dense'
+    a, nat = _model(True, dense=dense, seed=31)
+    b, _ = _model(True, dense=dense, seed=31)
+    hist = []
+
+    def both(T, burn=False):
+        for _ in range(T):
+            n0 = a.N
+            a.step(burn, not burn)
+            hist.append((n0, a.counts()[1], a.counts()[2]))
+        b.walk(T, burn, not burn)
+
+    both(7)
+    assert a.counts()[0] == b.counts()[0]
+    n, births, deaths = b.walk_history()
+    assert [tuple(int(v) for v in r) for r in zip(n, births, deaths)] == hist[-7:]
+    sa, sb = _state(a, nat), _state(b, nat)
+    for k in sa:
+        np.testing.assert_array_equal(sa[k], sb[k], err_msg=k)
+    # a mutation (host-side access to the genomes), a host-driven step on both, a collection
+    victim = sa['ids'][5]
+    for dev in (a, b):
+        slot = np.nonzero(dev.download(nat.F_ID) == victim)[0].astype(np.int64)
+        dev.mutate(slot, np.array([11], np.int32), np.array([1], np.uint8))
+        dev.step(False, True)
+    assert b.debug_halves()[1] == 0          # (runs a collection of the shared genome blocks)
+    both(9)
+    both(1)
+    both(2)
+    assert a.counts() == b.counts()
+    ta, tb = a.totals(), b.totals()
+    assert tb.pop('dd_steps') >= 16 and ta.pop('dd_steps') == 0     # b really took the other path
+    assert ta == tb, (ta, tb)
+    sa, sb = _state(a, nat), _state(b, nat)
+    for k in sa:
+        np.testing.assert_array_equal(sa[k], sb[k], err_msg=k)
+    for dev in (a, b):
+        rows = dev.download(nat.F_GROW)
+        assert rows.min() >= 0 and np.unique(rows).size == rows.size
+        assert dev.debug_halves()[1] == 0    # no broken block references
+    a.close()
+    b.close()
+
+
+def test_small_path_burn_in_and_growth():
+    """device-driven burn-in steps (no genomes) from a small founder population that grows
+    several-fold to its carrying capacity: counts per step equal the host-driven path's"""
+    nat = native()
+    W = H = 40
+    rasts = np.stack([np.ones((H, W)), np.tile(np.linspace(0, 1, W), (H, 1))]).astype(np.float32)
+
+    def mk():
+        dev = make_dev(W, H, rasts=rasts, L=0, n_traits=0, cap=16384, seed=4, mating_radius=3.0,
+                       K_factor=2.0)
+        dev.init_population(400)
+        return dev
+
+    a, b = mk(), mk()
+    seq = []
+    for _ in range(40):
+        n0 = a.N
+        a.step(True, False)
+        seq.append((n0, a.counts()[1], a.counts()[2]))
+    b.walk(40, True, False)
+    n, births, deaths = b.walk_history()
+    assert [tuple(int(v) for v in r) for r in zip(n, births, deaths)] == seq
+    assert a.N == b.N > 1500
+    assert b.totals()['dd_steps'] >= 38
+    for f in (nat.F_ID, nat.F_X, nat.F_Y, nat.F_AGE):
+        ia, ib = np.argsort(a.download(nat.F_ID)), np.argsort(b.download(nat.F_ID))
+        np.testing.assert_array_equal(a.download(f)[ia], b.download(f)[ib])
+    a.close()
+    b.close()

@@ -104,6 +104,49 @@ def test_run_iterations_and_reproducibility():
     assert a[0] != c[0]
 
 
+@pytest.mark.parametrize('variant', ['snapshot', 'rand_comm', 'mutation', 'repeat_burn'])
+def test_concurrent_iterations_equal_sequential(variant):
+    """Model.run(concurrent=K): the iterations of one model side by side on the GPU (the
+    reference runs them in turn and notes they could be farmed out, sim/model.py:866-953,
+    TODO at :924-925) - every iteration ends in the state the sequential run leaves it in:
+    population sizes, births, deaths over the whole iteration, ids, positions, genotypes."""
+    import geonomics_amd as gnx
+
+    def run(k):
+        p = small_params(seed=9, n_its=4, T=8)
+        if variant == 'rand_comm':
+            p['model']['its']['rand_comm'] = True
+        if variant == 'repeat_burn':
+            p['model']['its']['repeat_burn'] = True
+        if variant == 'mutation':
+            p['comm']['species']['spp_0']['gen_arch'].update({'mu_neut': 1e-3, 'mu_delet': 0})
+        mod = gnx.make_model(p)
+        ends = {}
+
+        def at_end(lane):
+            spp = lane.comm[0]
+            ends[lane.it] = (np.array([*spp]), lane.get_coords(),
+                             lane.get_genotypes(biallelic=True))
+        mod._on_iteration_end = at_end
+        mod.run(verbose=False, concurrent=k)
+        return mod, ends
+
+    m1, e1 = run(1)
+    m3, e3 = run(3)
+    assert sorted(m1.iteration_log) == sorted(m3.iteration_log) == [0, 1, 2, 3]
+    assert m1.iteration_log == m3.iteration_log
+    for it in range(4):
+        for a, b in zip(e1[it], e3[it]):
+            np.testing.assert_array_equal(a, b)
+    # the iterations differ from each other, and the model is left in the last one's state
+    assert m1.iteration_log[1] != m1.iteration_log[2]
+    assert m3.it == 3 and m3.t == 7
+    np.testing.assert_array_equal(np.array([*m3.comm[0]]), e3[3][0])
+    m3.walk(2, 'main', verbose=False)           # and goes on from there
+    m1.walk(2, 'main', verbose=False)
+    assert m3.comm[0].Nt == m1.comm[0].Nt
+
+
 def test_dispersal_surface_in_the_params_dict():
     """movement.disp_surf of the parameters file (sim/params.py template; reference
     ops/movement.py:104-108): the model hands it to the device and offspring disperse up the

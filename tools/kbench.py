@@ -15,6 +15,7 @@ ap.add_argument('--steps', type=int, default=10)
 ap.add_argument('--genomes', action='store_true')
 ap.add_argument('--no-traits', action='store_true')
 ap.add_argument('--no-profile', action='store_true')
+ap.add_argument('--walk', action='store_true', help='gnx_walk: counts on the device, one graph launch per step')
 a = ap.parse_args()
 cfg = dict(bench.WORKLOADS[a.workload])
 if not a.genomes:
@@ -34,13 +35,17 @@ import time
 dev.synchronize()
 t0 = time.perf_counter()
 dev.reset_totals()
-for _ in range(a.steps):
-    dev.step(not a.genomes, a.genomes)
+if a.walk:
+    dev.walk(a.steps, not a.genomes, a.genomes)
+else:
+    for _ in range(a.steps):
+        dev.step(not a.genomes, a.genomes)
 dev.synchronize()
 dt = time.perf_counter() - t0
-n = dev.totals()['ind_steps']
+tot = dev.totals()
+n = tot['ind_steps']
 kt = dev.kernel_times()
-print('N=%d  ms/step=%.3f  ind-steps/s=%.3e' % (dev.N, 1e3 * dt / a.steps, n / dt))
+print('N=%d  ms/step=%.3f  ind-steps/s=%.3e  dd_steps=%d' % (dev.N, 1e3 * dt / a.steps, n / dt, tot['dd_steps']))
 for k, v in kt.items():
     gbs = v['bytes'] / (v['ms'] * 1e-3) / 1e9 if v['ms'] > 0 else 0.0
     print('  %-14s %8.3f ms/step  (%d launches)  %8.1f MB/launch  %7.0f GB/s' % (
