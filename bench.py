@@ -303,12 +303,19 @@ def measure_other_workload(name, steps=30, warmup=5):
     setup = time.time() - t0
     dev.reset_totals()
     t1 = time.perf_counter()
-    for _ in range(steps):
-        dev.step(False, True)
+    # gnx_walk: `steps` time steps in one call; the library takes the device-driven path (counts
+    # on the device, one graph launch per step) for populations of this size
+    dev.walk(steps, False, True)
     dev.synchronize()
     dt = time.perf_counter() - t1
     tot = dev.totals()               # accumulated inside the library: nothing read per step
     n, births = tot['ind_steps'], tot['births']
+    # ... and the same steps the host-driven way (gnx_step: two count read-backs per step)
+    t2 = time.perf_counter()
+    for _ in range(steps):
+        dev.step(False, True)
+    dev.synchronize()
+    dt_host = time.perf_counter() - t2
     fam = kernel_profile(dev, lambda burn: dev.step(burn, not burn), 10)
     dev.close()
     dom = max(fam, key=lambda k: fam[k]['ms_per_step'])
@@ -322,7 +329,12 @@ def measure_other_workload(name, steps=30, warmup=5):
            'dominant_kernel': dom, 'dominant_ms_per_step': fam[dom]['ms_per_step'],
            'dominant_GBps': fam[dom]['GBps'], 'dominant_frac': fam[dom]['GBps'] / 8000.0,
            'bytes_per_step': sum(v['bytes_per_step'] for v in fam.values()),
-           'kernel_ms_per_step': {k: round(v['ms_per_step'], 4) for k, v in fam.items()}}
+           'kernel_ms_per_step': {k: round(v['ms_per_step'], 4) for k, v in fam.items()},
+           # which way gnx_walk took the steps, and the same steps through gnx_step
+           'path': ('gnx_walk, device-driven: counts on the device, one HIP graph launch per '
+                    'step, no read-back' if tot['dd_steps'] > 0 else
+                    'gnx_walk, host-driven (gnx_step per step)'),
+           'ms_per_step_gnx_step': 1e3 * dt_host / steps}
     out['step_frac'] = out['bytes_per_step'] / (out['ms_per_step'] * 1e-3) / 1e9 / 8000.0
     return out
 
@@ -504,8 +516,7 @@ def main():
         # births that got a genome are summed inside the library (gnx_totals) and read once,
         # behind the synchronisation that closes the timed region
         dev.reset_totals()
-        for _ in range(args.steps):
-            dev.step(False, True)
+        dev.walk(args.steps, False, True)       # (10^6 individuals: gnx_step per step inside)
     else:
         for _ in range(args.steps):
             if v2:

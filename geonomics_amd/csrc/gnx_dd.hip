@@ -27,6 +27,12 @@ struct DDExtra {             // host-side state of the device-driven mode
   GraphMap graphs;
   hipEvent_t ev[8]{};
   bool have_ev = false;
+  // Streams the step is CAPTURED on (the graph is launched on the handle's own stream).  They
+  // are non-blocking: while a blocking stream captures, any hipMemcpy on the legacy stream -
+  // another handle's, on another host thread - fails ("would make the legacy stream depend on
+  // a capturing blocking stream").
+  hipStream_t cap[3]{};
+  bool capturing = false;
   uint64_t epoch = 0;        // h's configuration epoch the graphs were captured under
 };
 
@@ -44,8 +50,14 @@ bool env_on(const char* name, bool dflt) {
 unsigned gnx_order_event_flags();
 
 bool gnx_dd_eligible(const gnx_state* h, bool burn) {
-  const bool on = env_on("GNX_DD", true);
-  if (!on || !h->have_sp || h->tiled || h->profiling) return false;
+  // GNX_DD=0: never; 2: whatever the size.  By default populations whose step the host cannot
+  // enqueue as fast as the GPU runs it (capacity up to GNX_DD_MAX_CAP slots, 600 000): at 10^6
+  // individuals the host-driven step is the faster one - its crossover runs under the next
+  // step's movement and its grids fit the population (0.60 against 0.70 ms per step)
+  const int mode = getenv("GNX_DD") ? atoi(getenv("GNX_DD")) : 1;
+  static const int64_t max_cap = getenv("GNX_DD_MAX_CAP") ? atoll(getenv("GNX_DD_MAX_CAP")) : 600000;
+  if (mode == 0 || !h->have_sp || h->tiled || h->profiling) return false;
+  if (mode != 2 && h->cfg.cap_inds > max_cap) return false;
   const gnx_species_params& sp = h->sp;
   if (sp.mating_radius < 0 || !sp.n_births_fixed || !sp.move) return false;
   if (!h->ord_mode || h->key_bits > 24 || !h->compact_fill || !h->defer_xo) return false;
@@ -61,6 +73,7 @@ static int dd_events(gnx_state* h) {
   DDExtra* x = extra(h);
   if (x->have_ev) return 0;
   for (int k = 0; k < 8; ++k) HIPCHK(hipEventCreateWithFlags(&x->ev[k], gnx_order_event_flags()));
+  for (int k = 0; k < 3; ++k) HIPCHK(hipStreamCreateWithFlags(&x->cap[k], hipStreamNonBlocking));
   x->have_ev = true;
   return 0;
 }
@@ -70,9 +83,21 @@ static int dd_events(gnx_state* h) {
 static int dd_enqueue_step(gnx_state* h, bool burn, bool sel) {
   DDExtra* x = extra(h);
   const gnx_config& c = h->cfg;
-  // GNX_DD_STREAMS=1: the whole step on one stream (a linear graph)
-  const bool one = getenv("GNX_DD_STREAMS") && atoi(getenv("GNX_DD_STREAMS")) == 1;
-  hipStream_t s1 = h->stream, s2 = one ? s1 : h->stream2, s3 = one ? s1 : h->stream3;
+  // The whole step on ONE stream: a linear graph replays at ~2 us per node, one with side
+  // branches at ~30 (ROCm 7.2, tools/launch_micro.hip and DESIGN 4.4: 0.21 against 1.0 ms per
+  // step at 10^5 individuals) - and an event hand-over costs the host 12 us where a launch
+  // costs 3.  GNX_DD_STREAMS=3: the densities and the lists on the side streams as in gnx_step.
+  const bool one = !(getenv("GNX_DD_STREAMS") && atoi(getenv("GNX_DD_STREAMS")) == 3);
+  hipStream_t s1 = x->capturing ? x->cap[0] : h->stream;
+  hipStream_t s2 = one ? s1 : (x->capturing ? x->cap[1] : h->stream2);
+  hipStream_t s3 = one ? s1 : (x->capturing ? x->cap[2] : h->stream3);
+  hipStream_t own = h->stream;
+  h->stream = s1;                 // (the launchers that take no stream argument)
+  struct Restore {
+    gnx_state* h;
+    hipStream_t s;
+    ~Restore() { h->stream = s; }
+  } restore{h, own};
   const bool genomes = !burn && c.L > 0 && h->genomes_assigned;
   const bool xo = genomes;
   const int has_rows = (h->genomes_assigned && c.L > 0) ? 1 : 0;
@@ -115,9 +140,8 @@ static int dd_enqueue_step(gnx_state* h, bool burn, bool sel) {
   }
   HIPCHK(hipStreamWaitEvent(s1, x->ev[4], 0));
   GNXCHK(gnx_dd_l_fill(h, has_rows, xo, s1));
-  GNXCHK(gnx_dd_l_ord(h, s1));
   if (xo) HIPCHK(hipStreamWaitEvent(s1, x->ev[6], 0));
-  GNXCHK(gnx_dd_l_end(h, has_rows, xo, s1));
+  GNXCHK(gnx_dd_l_ord_end(h, has_rows, xo, s1));
   if (xo) h->jobs_cur ^= 1;
   h->fb_cur ^= 1;
   return 0;
@@ -152,9 +176,11 @@ static int dd_launch_step(gnx_state* h, bool burn, bool sel) {
   if (it == x->graphs.end()) {
     hipGraph_t g = nullptr;
     const int cur0 = h->cur, ord0 = h->ord_cur, jobs0 = h->jobs_cur, fb0 = h->fb_cur;
-    HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    HIPCHK(hipStreamBeginCapture(x->cap[0], hipStreamCaptureModeThreadLocal));
+    x->capturing = true;
     int rc = dd_enqueue_step(h, burn, sel);
-    hipError_t e = hipStreamEndCapture(h->stream, &g);
+    x->capturing = false;
+    hipError_t e = hipStreamEndCapture(x->cap[0], &g);
     // (the capture enqueued nothing: the host's parities are those before it)
     h->cur = cur0;
     h->ord_cur = ord0;
@@ -331,8 +357,10 @@ void gnx_dd_destroy(gnx_state* h) {
   if (h->dd_graph[0]) {
     dd_drop_graphs(h);
     DDExtra* x = extra(h);
-    if (x->have_ev)
+    if (x->have_ev) {
       for (int k = 0; k < 8; ++k) (void)hipEventDestroy(x->ev[k]);
+      for (int k = 0; k < 3; ++k) (void)hipStreamDestroy(x->cap[k]);
+    }
     delete x;
     h->dd_graph[0] = nullptr;
   }

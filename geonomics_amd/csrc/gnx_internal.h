@@ -685,8 +685,7 @@ int gnx_dd_l_jobs(gnx_state* h, int buf, hipStream_t st);
 int gnx_dd_l_crossover(gnx_state* h, int buf, hipStream_t st);
 int gnx_dd_l_fill_lists(gnx_state* h, int has_rows, hipStream_t st);
 int gnx_dd_l_fill(gnx_state* h, int has_rows, bool xo, hipStream_t st);
-int gnx_dd_l_ord(gnx_state* h, hipStream_t st);
-int gnx_dd_l_end(gnx_state* h, int has_rows, bool xo, hipStream_t st);
+int gnx_dd_l_ord_end(gnx_state* h, int has_rows, bool xo, hipStream_t st);
 // the handle can take device-driven steps (else gnx_walk falls back to gnx_step)
 bool gnx_dd_eligible(const gnx_state* h, bool burn);
 int gnx_dd_leave(gnx_state* h);

@@ -405,10 +405,17 @@ __global__ void __launch_bounds__(256)
 k_lattice_nmax(int Jx, int Jy, int nbx, const int32_t* __restrict__ bins,
                const double* __restrict__ areas, double hww, const double* __restrict__ cp_g,
                double* __restrict__ C, int W, int H, unsigned long long* __restrict__ out_bits,
-               int32_t* __restrict__ zero_bins, unsigned long long* __restrict__ zero_word) {
+               int32_t* __restrict__ zero_bins, unsigned long long* __restrict__ zero_word,
+               int32_t* __restrict__ binsP, double* __restrict__ CP) {
   extern __shared__ double lat_lds[];
   const int nn = Jx * Jy;
   const int Jm = max(Jx, Jy);
+  // binsP (device-driven step): one workgroup more than the individuals' field needs builds
+  // the PAIRS' lattice from binsP meanwhile (a launch of one workgroup otherwise, 11 us on
+  // the step's chain), writes it to CP and clears binsP for their next use
+  const bool isP = binsP != nullptr && blockIdx.x == gridDim.x - 1;
+  const int nbN = binsP != nullptr ? (int)gridDim.x - 1 : (int)gridDim.x;
+  if (isP) bins = binsP;
   double* V = lat_lds;
   double* Mx = V + nn;
   double* My = V + 2 * nn;
@@ -437,9 +444,14 @@ k_lattice_nmax(int Jx, int Jy, int nbx, const int32_t* __restrict__ bins,
   for (int line = threadIdx.x; line < Jy; line += blockDim.x)
     spline_line(Jx, (int64_t)line * Jx, 1, hww, cp, My, Mxy);
   __syncthreads();
+  if (isP) {
+    for (int idx = threadIdx.x; idx < 4 * nn; idx += blockDim.x) CP[idx] = lat_lds[idx];
+    for (int k = threadIdx.x; k < nn; k += blockDim.x) binsP[k] = 0;
+    return;
+  }
   if (blockIdx.x == 0)
     for (int idx = threadIdx.x; idx < 4 * nn; idx += blockDim.x) C[idx] = lat_lds[idx];
-  const double m = nmax_rows(lat_lds, Jx, Jy, hww, W, H, blockIdx.x, gridDim.x, AB);
+  const double m = nmax_rows(lat_lds, Jx, Jy, hww, W, H, blockIdx.x, nbN, AB);
   nmax_publish(m, out_bits, red);
 }
 
@@ -751,7 +763,7 @@ int gnx_l_density_N(gnx_state* h) {
   hipLaunchKernelGGL(k_lattice_nmax, dim3(std::max(1, std::min(h->cfg.H, blocks_env))), dim3(256),
                      lds_bytes, h->stream, L.Jx, L.Jy, L.nbx, (const int32_t*)h->fb[cur], L.areas,
                      L.hww, L.cprime, h->spl_N.c, h->cfg.W, h->cfg.H, h->nmax2 + cur,
-                     h->fb[cur ^ 1], h->nmax2 + (cur ^ 1));
+                     h->fb[cur ^ 1], h->nmax2 + (cur ^ 1), (int32_t*)nullptr, (double*)nullptr);
   gnx_time_end(h, GNX_K_DENSITY, (double)h->N * 8.0);
   HIPCHK(hipGetLastError());
   h->spl_N.valid = true;
@@ -791,8 +803,9 @@ __global__ void __launch_bounds__(256)
 k_alive(int64_t N, const double* p_death, const uint8_t* dead_in, const int64_t* id,
         const uint8_t* ghost, const int32_t* grow, long long step, unsigned long long seed,
         int32_t* alive, int32_t* dead_row, int32_t* cnt, int stride, int64_t xo_first,
-        int32_t* zero_jobs, const GnxDD* __restrict__ dd) {
+        int32_t* zero_jobs, const GnxDD* __restrict__ dd, GnxScanOut scan) {
   __shared__ int lds[16];
+  __shared__ int lds2[8];
   const int64_t base = (int64_t)blockIdx.x * GNX_CB;
   if (dd) {
     // device-driven step: everybody incl. this step's offspring; the offspring (slots from
@@ -834,6 +847,13 @@ k_alive(int64_t N, const double* p_death, const uint8_t* dead_in, const int64_t*
   gnx_block_ranks(fa, rank, ta, lds);
   gnx_block_ranks(fd, rank, td, lds);
   gnx_block_ranks(fx, rank, tx, lds);
+  if (scan.ticket) {
+    // (device-driven step: the workgroup that finishes last turns the counts into offsets and
+    // totals - no k_block_scan launch)
+    const int v[3] = {ta, td, tx};
+    gnx_count_and_scan<3>(v, cnt, scan, lds2);
+    return;
+  }
   if (threadIdx.x == 0) {
     cnt[blockIdx.x] = ta;
     cnt[stride + blockIdx.x] = td;
@@ -1498,6 +1518,50 @@ void gnx_launch_xo_jobs_surv(gnx_state* h, int64_t first_slot, const int32_t* d_
                      B, gnx_halves(h), (const GnxXoPlan*)h->xo_plan, (GnxXoJob*)h->jobs[buf]);
 }
 
+// The end of a device-driven step (the last workgroup of its last kernel): the device block
+// moves on to the next step and a record of this one goes to pinned host memory (the host
+// reads it when it likes - nothing waits for it).
+struct GnxDDEnd {
+  GnxDD* dd;
+  const int32_t* cnts;
+  const int32_t* half_top;
+  GnxDDRec* ring;
+  int has_rows, xo;
+  unsigned int* ticket;
+};
+__device__ __forceinline__ void gnx_dd_end_step(const GnxDDEnd& E) {
+  GnxDD* dd = E.dd;
+  const int32_t S = E.cnts[0], freed = E.cnts[1], X = E.xo ? E.cnts[2] : 0;
+  GnxDDRec r;
+  r.N0 = dd->N;
+  r.P = dd->P;
+  r.B = dd->B;
+  r.S = S;
+  r.xo = X;
+  const int32_t n_free = dd->n_free - X + (E.has_rows ? freed : 0);
+  r.n_free = n_free;
+  r.half_top = E.half_top ? *E.half_top : 0;
+  r.err = dd->err;
+  r.max_id = dd->max_id + dd->B;
+  r.step = dd->step;
+  const int32_t seq = dd->seq + 1;
+  dd->N = S;
+  dd->ord_n = S;
+  dd->n_free = n_free;
+  dd->max_id = r.max_id;
+  dd->step = dd->step + 1;
+  dd->seq = seq;
+  dd->P = 0;
+  dd->B = 0;
+  GnxDDRec* slot = E.ring + ((seq - 1) % GNX_DD_RING);
+  __hip_atomic_store(&slot->seq, (int64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  int64_t* w = (int64_t*)slot;
+  const int64_t* v = (const int64_t*)&r;
+  for (int k = 1; k < (int)(sizeof(GnxDDRec) / 8); ++k)
+    __hip_atomic_store(&w[k], v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&slot->seq, (int64_t)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // The id-ordered index follows the compaction: entry k (slot ord[k], or slot k itself for the
 // entries appended since the last sort) stays iff its slot survived, and then names the
 // slot's new place.  Same three-launch compaction as the population's (gnx_compact.h), on
@@ -1527,8 +1591,9 @@ k_ord_flags(int64_t N, int64_t ord_n, const int32_t* __restrict__ ord,
 __global__ void __launch_bounds__(256)
 k_ord_write(int64_t N, int64_t ord_n, const int32_t* __restrict__ ord,
             const int32_t* __restrict__ newslot, const int32_t* __restrict__ off,
-            int32_t* __restrict__ ord_new, const GnxDD* __restrict__ dd) {
+            int32_t* __restrict__ ord_new, const GnxDD* __restrict__ dd, GnxDDEnd E) {
   __shared__ int lds[16];
+  __shared__ int last_s;
   if (dd) {
     N = (int64_t)dd->N + dd->B;
     ord_n = dd->ord_n;
@@ -1548,6 +1613,17 @@ k_ord_write(int64_t N, int64_t ord_n, const int32_t* __restrict__ ord,
 #pragma unroll
   for (int r = 0; r < 4; ++r)
     if (f[r]) ord_new[o + rank[r]] = ns[r];
+  if (!E.dd) return;
+  // device-driven step: this is its last kernel, and the workgroup that finishes last moves
+  // the device block on to the next step (every workgroup has read it by then)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int t = __hip_atomic_fetch_add(E.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_s = t == gridDim.x - 1u;
+    if (last_s) __hip_atomic_store(E.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (last_s && threadIdx.x == 0) gnx_dd_end_step(E);
 }
 
 int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_out) {
@@ -1579,7 +1655,8 @@ int gnx_l_mortality_enqueue(gnx_state* h, const uint8_t* d_dead_inject) {
   gnx_time_begin(h);
   hipLaunchKernelGGL(k_alive, dim3(nb), dim3(256), 0, h->stream, N, h->p_death, d_dead_inject,
                      a.id, a.ghost, a.grow, h->step, c.seed, h->flag, h->flag2, h->blk_cnt,
-                     h->blk_stride, xo ? xo_first : (int64_t)-1, zero_jobs, (const GnxDD*)nullptr);
+                     h->blk_stride, xo ? xo_first : (int64_t)-1, zero_jobs, (const GnxDD*)nullptr,
+                     GnxScanOut{});
   // survivors, rows freed and (deferred crossover) the surviving offspring that need a
   // row: block offsets on the device, totals also straight into pinned host memory.
   // (Measured and dropped: death probabilities + death draws + the scan by the last
@@ -1662,7 +1739,7 @@ int gnx_l_mortality_enqueue(gnx_state* h, const uint8_t* d_dead_inject) {
                        h->ord[h->ord_cur], h->newslot, h->ord_cnt, So, (const GnxDD*)nullptr);
     hipLaunchKernelGGL(k_ord_write, dim3(nb), dim3(256), 0, h->stream3, N, h->ord_n,
                        h->ord[h->ord_cur], h->newslot, h->ord_off, h->ord[h->ord_cur ^ 1],
-                       (const GnxDD*)nullptr);
+                       (const GnxDD*)nullptr, GnxDDEnd{});
     // the cell sort waits for the crossover AND for this: stream3 waits for the crossover here,
     // where nothing waits for stream3, and the sort's stream waits for one event instead of two
     h->ord_covers_xo = false;
@@ -1734,35 +1811,31 @@ int gnx_dd_l_bins_adults(gnx_state* h, int par, hipStream_t st) {
   return 0;
 }
 
-// the pair midpoints' bins and lattice (fb[2], cleared again by the lattice kernel)
+// the pair midpoints' bins (fb[2]); their lattice is built by an extra workgroup of
+// k_lattice_nmax (gnx_dd_l_density_N), which clears fb[2] again
 int gnx_dd_l_density_pairs(gnx_state* h, hipStream_t st) {
   const GnxLattice& L = h->lat;
-  const int64_t nn = (int64_t)L.Jx * L.Jy;
   const int nb = L.nbx * L.nby;
-  const size_t lds_bytes = ((size_t)4 * nn + std::max(L.Jx, L.Jy) + 1) * sizeof(double);
   const int64_t cap = h->cfg.cap_inds;
   const int blocks = (int)std::min<int64_t>(BIN_BLOCKS, std::max<int64_t>(1, (cap / 2 + 255) / 256));
   hipLaunchKernelGGL(k_bins, dim3(blocks), dim3(256), (size_t)nb * sizeof(int32_t), st, cap,
                      (const int32_t*)&h->dd->P, (const float*)h->mid_x, (const float*)h->mid_y,
                      (const uint8_t*)nullptr, 1.0 / L.hww, L.nbx, L.nby, h->fb[2]);
-  hipLaunchKernelGGL(k_lattice, dim3(1), dim3(256), lds_bytes, st, L.Jx, L.Jy, L.nbx,
-                     (const int32_t*)h->fb[2], L.areas, L.hww, L.cprime, h->spl_P.c,
-                     (int32_t*)nullptr, 0, (unsigned long long*)nullptr, 1, 1);
   HIPCHK(hipGetLastError());
   return 0;
 }
 
-// lattice + N.max() of everybody (adults + newborns in fb[par]); clears the other parity's
-// bins and N.max() word for the next step
+// lattice + N.max() of everybody (adults + newborns in fb[par]) and, in one more workgroup,
+// the pairs' lattice; clears the other parity's bins and N.max() word for the next step
 int gnx_dd_l_density_N(gnx_state* h, int par, hipStream_t st) {
   const GnxLattice& L = h->lat;
   const int64_t nn = (int64_t)L.Jx * L.Jy;
   const size_t lds_bytes = ((size_t)4 * nn + std::max(L.Jx, L.Jy) + 1 + 2 * L.Jx + 256) * sizeof(double);
   static const int blocks_env = getenv("GNX_LATN_BLOCKS") ? atoi(getenv("GNX_LATN_BLOCKS")) : 256;
-  hipLaunchKernelGGL(k_lattice_nmax, dim3(std::max(1, std::min(h->cfg.H, blocks_env))), dim3(256),
+  hipLaunchKernelGGL(k_lattice_nmax, dim3(std::max(1, std::min(h->cfg.H, blocks_env)) + 1), dim3(256),
                      lds_bytes, st, L.Jx, L.Jy, L.nbx, (const int32_t*)h->fb[par], L.areas, L.hww,
                      L.cprime, h->spl_N.c, h->cfg.W, h->cfg.H, h->nmax2 + par, h->fb[par ^ 1],
-                     h->nmax2 + (par ^ 1));
+                     h->nmax2 + (par ^ 1), h->fb[2], h->spl_P.c);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1788,8 +1861,9 @@ int gnx_dd_l_alive(gnx_state* h, bool xo, int buf, hipStream_t st) {
   hipLaunchKernelGGL(k_alive, dim3(nb), dim3(256), 0, st, (int64_t)c.cap_inds, h->p_death,
                      (const uint8_t*)nullptr, a.id, a.ghost, a.grow, 0ll, c.seed, h->flag, h->flag2,
                      h->blk_cnt, h->blk_stride, xo ? (int64_t)0 : (int64_t)-1,
-                     xo ? h->n_jobs_dev[buf] : (int32_t*)nullptr, (const GnxDD*)h->dd);
-  GNXCHK(gnx_block_scan(h, 3, c.cap_inds, h->blk_cnt, h->blk_off, h->cnt_dev, nullptr, 0, st));
+                     xo ? h->n_jobs_dev[buf] : (int32_t*)nullptr, (const GnxDD*)h->dd,
+                     GnxScanOut{h->blk_off, h->cnt_dev, nullptr, 0, nullptr, h->tickets + 0,
+                                h->blk_stride});
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1828,8 +1902,9 @@ int gnx_dd_l_fill(gnx_state* h, int has_rows, bool xo, hipStream_t st) {
   return 0;
 }
 
-// the id-ordered index follows the compaction (flips ord_cur)
-int gnx_dd_l_ord(gnx_state* h, hipStream_t st) {
+// the id-ordered index follows the compaction (flips ord_cur); the last workgroup of the second
+// kernel ends the step (gnx_dd_end_step)
+int gnx_dd_l_ord_end(gnx_state* h, int has_rows, bool xo, hipStream_t st) {
   const gnx_config& c = h->cfg;
   const int nb = (int)((c.cap_inds + GNX_CB - 1) / GNX_CB);
   GnxScanOut So{h->ord_off, nullptr, nullptr, 0, nullptr, h->tickets + 2, h->blk_stride};
@@ -1837,52 +1912,11 @@ int gnx_dd_l_ord(gnx_state* h, hipStream_t st) {
                      h->ord[h->ord_cur], h->newslot, h->ord_cnt, So, (const GnxDD*)h->dd);
   hipLaunchKernelGGL(k_ord_write, dim3(nb), dim3(256), 0, st, (int64_t)c.cap_inds, (int64_t)0,
                      h->ord[h->ord_cur], h->newslot, h->ord_off, h->ord[h->ord_cur ^ 1],
-                     (const GnxDD*)h->dd);
+                     (const GnxDD*)h->dd,
+                     GnxDDEnd{h->dd, h->cnt_dev, h->half_top, h->dd_ring_dev, has_rows, xo ? 1 : 0,
+                              h->tickets + 4});
   HIPCHK(hipGetLastError());
   h->ord_cur ^= 1;
-  return 0;
-}
-
-// The step's last kernel: the device block moves on to the next step and a record of this
-// one goes to pinned host memory (the host reads it when it likes - nothing waits for it).
-__global__ void k_dd_end(GnxDD* dd, const int32_t* __restrict__ cnts, const int32_t* __restrict__ half_top,
-                         GnxDDRec* __restrict__ ring, int has_rows, int xo) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const int32_t S = cnts[0], freed = cnts[1], X = xo ? cnts[2] : 0;
-  GnxDDRec r;
-  r.N0 = dd->N;
-  r.P = dd->P;
-  r.B = dd->B;
-  r.S = S;
-  r.xo = X;
-  const int32_t n_free = dd->n_free - X + (has_rows ? freed : 0);
-  r.n_free = n_free;
-  r.half_top = half_top ? *half_top : 0;
-  r.err = dd->err;
-  r.max_id = dd->max_id + dd->B;
-  r.step = dd->step;
-  const int32_t seq = dd->seq + 1;
-  dd->N = S;
-  dd->ord_n = S;
-  dd->n_free = n_free;
-  dd->max_id = r.max_id;
-  dd->step = dd->step + 1;
-  dd->seq = seq;
-  dd->P = 0;
-  dd->B = 0;
-  GnxDDRec* slot = ring + ((seq - 1) % GNX_DD_RING);
-  __hip_atomic_store(&slot->seq, (int64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  int64_t* w = (int64_t*)slot;
-  const int64_t* v = (const int64_t*)&r;
-  for (int k = 1; k < (int)(sizeof(GnxDDRec) / 8); ++k)
-    __hip_atomic_store(&w[k], v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __hip_atomic_store(&slot->seq, (int64_t)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-int gnx_dd_l_end(gnx_state* h, int has_rows, bool xo, hipStream_t st) {
-  hipLaunchKernelGGL(k_dd_end, dim3(1), dim3(64), 0, st, h->dd, (const int32_t*)h->cnt_dev,
-                     (const int32_t*)h->half_top, h->dd_ring_dev, has_rows, xo ? 1 : 0);
-  HIPCHK(hipGetLastError());
   return 0;
 }
 

@@ -88,6 +88,7 @@ class Model:
             self._orig_comm_snap = self._snapshot_comm()
         self.burn_fn_queue = None
         self.main_fn_queue = None
+        self._lanes_active = False
         self.iteration_log = {}
         self.iteration_times = {}       # it -> wall-clock (start, end) of its main phase
 
@@ -473,6 +474,31 @@ class Model:
             if not self.rand_comm and not self.repeat_burn and self.n_its > 1:
                 self._orig_comm_snap = self._snapshot_comm()
 
+    def _walk_main_on_device(self, T):
+        """T main timesteps without the function queue, when nothing in it needs the host
+        between two steps (one Species that neither mutates nor records a pedigree; no change
+        events, no data or statistics collection, no per-step printing): the queue's
+        _set_t / _set_age_stage / _do_movement / _do_pop_dynamics / _set_Nt entries
+        (reference sim/model.py:603-667) T times in one call into the library.  Returns the
+        number of timesteps taken, or None when the queue has to be walked."""
+        if os.environ.get('GNX_MODEL_WALK', '1') == '0' or self._verbose or T < 2:
+            return None
+        # (lanes of a concurrent run share the process: while one host thread captures a step's
+        # graph, HIP refuses the other threads' plain hipMemcpy / hipMemset calls)
+        if getattr(self, '_is_lane', False) and self._lanes_active:
+            return None
+        if len(self.comm) != 1 or self.land._changer is not None:
+            return None
+        if self._data_collector is not None or self._stats_collector is not None:
+            return None
+        spp = self.comm[0]
+        if not (self.comm.burned and spp._move and spp._can_walk_on_device()):
+            return None
+        done = spp._walk_on_device(T)
+        self.t += done
+        self.comm.t += done
+        return done
+
     def _iteration_main(self):
         """the T main timesteps of the iteration (reference sim/model.py:841-858)"""
         if self._verbose:
@@ -484,8 +510,9 @@ class Model:
             return
         import time
         t0 = time.perf_counter()
-        for _ in range(self.T):
-            if self._do_timestep('main'):
+        done = self._walk_main_on_device(self.T) or 0
+        for _ in range(self.T - done):
+            if np.any([spp.extinct for spp in self.comm.values()]) or self._do_timestep('main'):
                 break
         self.iteration_times[self.it] = (t0, time.perf_counter())
         self._log_iteration()
@@ -582,6 +609,8 @@ class Model:
             first_main_only = True
         for _ in range(k - 1):
             lanes.append(self._spawn_lane(lanes[0].comm))
+        for lane in lanes:
+            lane._lanes_active = True
         threads = [threading.Thread(target=lane._lane_loop,
                                     args=(first_main_only and n == 0,))
                    for n, lane in enumerate(lanes)]
@@ -597,6 +626,7 @@ class Model:
                 for spp in (lane.comm.values() if lane.comm else []):
                     if not any(spp is s for s in keep.comm.values()):
                         spp._dev.close()
+        keep._lanes_active = False
         for name in ('comm', 'land', 't', 'burn_t', 'it', '_rng', '_stats_collector',
                      '_data_collector', 'reassign_genomes', '_orig_comm_snap',
                      '_orig_land_copy', 'orig_land'):
@@ -647,6 +677,10 @@ class Model:
         self._verbose = verbose and self._rank == 0
         if self._verbose:
             print('\n')
+        if mode == 'main' and self.main_fn_queue is not None:
+            T -= self._walk_main_on_device(T) or 0
+            if np.any([spp.extinct for spp in self.comm.values()]):
+                T = 0
         for _ in range(T):
             if mode == 'burn' and self.comm.burned:
                 break

@@ -426,6 +426,36 @@ class Species:
         if self._check_extinct():
             self.extinct = True
 
+    def _can_walk_on_device(self):
+        """nothing in this Species' time step needs the host between two steps: no mutation
+        (host draws), no pedigree recording, no scheduled parameter changes"""
+        return (self.burned and not self.extinct and not self.mutate and self._tt is None and
+                self._changer is None and getattr(self, '_comm', None) is None)
+
+    def _walk_on_device(self, T):
+        """T main time steps in ONE call into the library (gnx_walk: _set_age_stage,
+        _do_movement, _do_pop_dynamics T times, reference structs/species.py:567-585, 822-833):
+        Nt, n_births and n_deaths of every step come back afterwards in one piece.  Returns
+        the number of steps taken (fewer than T if the Species went extinct)."""
+        dev = self._dev
+        with_selection = self.selection and self.burned
+        dev.walk(T, False, with_selection)
+        n0, births, deaths = dev.walk_history(T)
+        done = 0
+        for a, b, d in zip(n0.tolist(), births.tolist(), deaths.tolist()):
+            if a == 0:
+                break
+            self.n_births.append(int(b))
+            self.n_deaths.append(int(d))
+            self.Nt.append(int(a + b - d))
+            self.max_ind_idx += int(b)
+            self.t += 1
+            done += 1
+            if a + b - d == 0:
+                self.extinct = True
+                break
+        return done
+
     def _grow_device(self, factor=2.0):
         """a larger device state with the same population (capacity is an implementation
         detail of the build: GNX_CAP_FACTOR sets the initial headroom)"""
