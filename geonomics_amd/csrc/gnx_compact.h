@@ -13,6 +13,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// The cross-workgroup hand-overs below (gnx_count_and_scan, and k_keys_hist / k_pair_compact
+// which follow the same recipe) order their stores with `s_waitcnt vmcnt(0)` instead of a
+// release fence: on gfx9 (CDNA) vmcnt counts stores too and agent / system-scope atomic stores
+// write through, which is NOT what the HIP memory model promises on other targets.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
+#error "gnx_compact.h: the s_waitcnt-ordered hand-overs are written for gfx942 / gfx950 (CDNA3 / CDNA4) only"
+#endif
+
 #define GNX_CB 1024
 
 // exclusive ranks of the flagged items of this block, in item order; lds: int[16]

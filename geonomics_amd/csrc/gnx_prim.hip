@@ -121,6 +121,14 @@ int gnx_prim_sort32_bits(void* tmp, size_t bytes, const uint32_t* kin, uint32_t*
 // kernel each per place - six fills and four kernels for the two places of the step's
 // 16-bit cell keys; here the scratch of all places is one contiguous region cleared by ONE
 // fill (5 launches instead of 10; at 10^5 individuals the launches are the sort).
+// (built on rocprim::detail: the Onesweep device functions and their scratch layout are not a
+// public interface - checked against the rocPRIM of ROCm 7.x; another major version has to be
+// looked at before this compiles)
+#include <rocprim/rocprim_version.hpp>
+#define GNX_ROCPRIM_MAJOR 4
+static_assert(ROCPRIM_VERSION_MAJOR == GNX_ROCPRIM_MAJOR,
+              "gnx_prim.hip: rocPRIM major version changed - re-check rocprim::detail::onesweep_* "
+              "(signatures, look-back state, block-id usage) against gnx_os, then bump GNX_ROCPRIM_MAJOR");
 namespace gnx_os {
 using lookback_t = rocprim::detail::onesweep_lookback_state;
 using obid_t = rocprim::detail::ordered_block_id<unsigned int>;

@@ -1761,11 +1761,15 @@ extern "C" int gnx_tile2_die(gnx_state* h, int32_t burn, int32_t with_selection,
     h->spl_P.valid = false;
   GNXCHK(gnx_l_spline(h, h->bin_partials, &h->spl_N, nullptr));
   GNXCHK(gnx_l_death_probs(h, with_selection != 0 && !burn));
+  const int64_t N_before = h->N;
   int64_t D = 0;
   GNXCHK(gnx_l_mortality(h, nullptr, &D));
   h->last_deaths = D;
   h->prev_deaths = D;
-  // (the words were published before the kernels the mortality waited for)
+  // (the words were published before the kernels the mortality waited for - unless this tile
+  // is empty: gnx_l_death_probs and gnx_l_mortality return at once for N == 0, a legitimate
+  // state of one tile of many, and nothing has waited for the stream yet)
+  if (N_before == 0) HIPCHK(hipStreamSynchronize(h->stream));
   std::atomic_thread_fence(std::memory_order_acquire);
   for (int k = 0; k < 3; ++k) totals[k] = h->h_route_pin[k];
   const int64_t bad_rec = (int64_t)(uint32_t)h->h_route_pin[8] | ((int64_t)h->h_route_pin[9] << 32);

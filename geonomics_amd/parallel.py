@@ -134,6 +134,21 @@ class Comm:
                 'cuda' if dist.get_backend() == 'nccl' else 'cpu')
             # RCCL's operations are ordered on streams; gloo touches the buffers from the host
             self.stream_ordered = dist.get_backend() == 'nccl'
+            # the CPU side group of host_allgather is made HERE, by every rank (new_group is a
+            # collective), and the ranks agree on whether they all have it: a rank that fell
+            # back to the default group while the others use the side group would deadlock
+            self._hgrp = None
+            if dist.get_backend() != 'gloo':
+                import torch
+                ok = 1
+                try:
+                    self._hgrp = dist.new_group(backend='gloo')
+                except Exception:
+                    ok = 0
+                flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:
+                    self._hgrp = None
 
     def _t(self, a):
         import torch
@@ -247,14 +262,7 @@ class Comm:
         return torch.stack(out).cpu().numpy()
 
     def _host_group(self):
-        if not hasattr(self, '_hgrp'):
-            self._hgrp = None
-            try:
-                if self.dist.get_backend() != 'gloo':
-                    self._hgrp = self.dist.new_group(backend='gloo')
-            except Exception:
-                self._hgrp = None
-        return self._hgrp
+        return getattr(self, '_hgrp', None)
 
     def exchange_multi(self, groups):
         """groups: [(parts, mat)] as for exchange_dev, all in ONE batch of isend / irecv and

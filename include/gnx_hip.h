@@ -437,7 +437,11 @@ int gnx_stream_ptr(gnx_state* h, void** stream);
 int gnx_tile2_move_route(gnx_state* h, int32_t move, int64_t* counts);
 int gnx_tile2_route_ptrs(gnx_state* h, void** mig_rec, void** mig_z, void** mig_geno,
                          void** ghost_rec);
-/* arrivals (device buffers): migrants rec / z / geno [n_mig], ghosts rec [n_ghost]; (no wait) */
+/* arrivals (device buffers): migrants rec / z / geno [n_mig], ghosts rec [n_ghost]; (no wait).
+ * Capacity: the emigrants of this step still hold their slots and genome rows when the
+ * arrivals are appended (they leave with the cell sort of gnx_tile2_pairs), so cap_inds must
+ * hold residents + emigrants + immigrants + ghosts (+ the step's births) and cap_rows
+ * residents + emigrants + immigrants; "capacity exceeded importing ..." otherwise.          */
 int gnx_tile2_import(gnx_state* h, int64_t n_mig, const void* rec, const void* z,
                      const void* geno, int64_t n_ghost, const void* ghost_rec);
 /* cell sort (emigrants leave, their genome rows return to the free stack), mate search, pair
