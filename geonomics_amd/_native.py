@@ -49,6 +49,9 @@ EXPORTS = [
     'gnx_genome_info', 'gnx_measure_copy', 'gnx_totals', 'gnx_reset_totals',
     'gnx_step_begin', 'gnx_step_mid', 'gnx_step_end', 'gnx_step_many',
     'gnx_walk', 'gnx_walk_many', 'gnx_walk_history',
+    'gnx_comm_unique_id', 'gnx_comm_init_rccl', 'gnx_comm_init_single', 'gnx_comm_local_create',
+    'gnx_comm_local_join', 'gnx_comm_local_abort', 'gnx_comm_local_destroy', 'gnx_comm_free',
+    'gnx_comm_bytes_sent', 'gnx_tile_step',
     'gnx_stream_ptr', 'gnx_tile2_move_route', 'gnx_tile2_route_ptrs', 'gnx_tile2_import',
     'gnx_tile2_pairs', 'gnx_tile2_offspring', 'gnx_tile2_serve', 'gnx_tile2_put',
     'gnx_tile2_finish_births', 'gnx_tile2_die', 'gnx_tile_pair_ptrs_nosync',
@@ -107,6 +110,7 @@ def load():
     lib.gnx_n_slots.restype = C.c_int64
     lib.gnx_last_crossover_births.restype = C.c_int64
     lib.gnx_walk_history.restype = C.c_int64
+    lib.gnx_comm_bytes_sent.restype = C.c_int64
     lib.gnx_destroy.restype = None
     _lib = lib
     return lib
@@ -311,6 +315,32 @@ class Device:
         k = self.lib.gnx_walk_history(self.h, C.c_int64(max_steps), _ptr(n, C.c_int64),
                                       _ptr(b, C.c_int64), _ptr(d, C.c_int64))
         return n[:k], b[:k], d[:k]
+
+    # -- one tiled step per call, exchanges issued by the library (csrc/gnx_comm.hip) -------
+    def comm_init_rccl(self, unique_id, rank, world):
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        self._chk(self.lib.gnx_comm_init_rccl(self.h, buf, int(rank), int(world)))
+
+    def comm_init_single(self):
+        self._chk(self.lib.gnx_comm_init_single(self.h))
+
+    def comm_local_join(self, group, rank):
+        self._chk(self.lib.gnx_comm_local_join(self.h, group, int(rank)))
+
+    def comm_free(self):
+        self._chk(self.lib.gnx_comm_free(self.h))
+
+    @property
+    def comm_bytes_sent(self):
+        return int(self.lib.gnx_comm_bytes_sent(self.h))
+
+    def tile_step(self, burn, with_selection, exact=True):
+        """one time step of this tile and, through its communicator, of the whole tiled
+        landscape (gnx_tile_step) -> (N, births, deaths), see include/gnx_hip.h"""
+        out = np.zeros(3, np.int64)
+        self._chk(self.lib.gnx_tile_step(self.h, int(bool(burn)), int(bool(with_selection)),
+                                         int(bool(exact)), _ptr(out, C.c_int64)))
+        return int(out[0]), int(out[1]), int(out[2])
 
     def step_begin(self, burn):
         self._chk(self.lib.gnx_step_begin(self.h, int(bool(burn))))
@@ -859,6 +889,32 @@ def step_many(devs, burn, with_selection):
     arr = (C.c_void_p * len(devs))(*[d.h for d in devs])
     devs[0]._chk(devs[0].lib.gnx_step_many(arr, len(devs), int(bool(burn)),
                                            int(bool(with_selection))))
+
+
+def comm_unique_id():
+    """128 bytes from ncclGetUniqueId (rank 0 makes them, every rank joins with them)"""
+    lib = load()
+    buf = (C.c_uint8 * 128)()
+    if lib.gnx_comm_unique_id(buf):
+        raise GnxError(lib.gnx_last_error().decode())
+    return bytes(buf)
+
+
+def comm_local_create(world):
+    """meeting point of `world` tiles that live in this process (the one-GPU tests)"""
+    lib = load()
+    g = C.c_void_p()
+    if lib.gnx_comm_local_create(int(world), C.byref(g)):
+        raise GnxError(lib.gnx_last_error().decode())
+    return g
+
+
+def comm_local_abort(group):
+    load().gnx_comm_local_abort(group)
+
+
+def comm_local_destroy(group):
+    load().gnx_comm_local_destroy(group)
 
 
 def walk_many(devs, T, burn, with_selection):

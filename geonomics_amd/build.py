@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libgnxhip.so')
 SOURCES = ['gnx_api.hip', 'gnx_kernels_pop.hip', 'gnx_kernels_genome.hip',
-           'gnx_kernels_demog.hip', 'gnx_tile.hip', 'gnx_stats.hip', 'gnx_prim.hip', 'gnx_dd.hip']
+           'gnx_kernels_demog.hip', 'gnx_tile.hip', 'gnx_stats.hip', 'gnx_prim.hip', 'gnx_dd.hip', 'gnx_comm.hip']
 
 
 def _headers():
@@ -65,7 +65,7 @@ def build(force=False, verbose=True):
         if p.wait() != 0:
             raise RuntimeError('hipcc failed on %s' % src)
     if force or procs or _stale(LIB, objs):
-        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-ldl', '-lpthread']
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)

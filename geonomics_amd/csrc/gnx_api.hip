@@ -130,7 +130,6 @@ void gnx_time_end(gnx_state* h, int kernel, double bytes) {
 static void timers_resolve(gnx_state* h, int kernel) {
   (void)gnx_xo_launch_pending(h);
   (void)hipStreamSynchronize(h->stream);
-  gnx_dd_destroy(h);
   if (h->stream2) (void)hipStreamSynchronize(h->stream2);
   for (auto& pr : h->ev_pending[kernel]) {
     float ms = 0.f;
@@ -478,6 +477,7 @@ extern "C" void gnx_destroy(gnx_state* h) {
   (void)gnx_xo_launch_pending(h);
   (void)hipStreamSynchronize(h->stream);
   gnx_dd_destroy(h);
+  (void)gnx_comm_free(h);
   if (h->stream2) (void)hipStreamSynchronize(h->stream2);
   if (h->stream3) (void)hipStreamSynchronize(h->stream3);    // reads ord / newslot
   for (int k = 0; k < 2; ++k) {

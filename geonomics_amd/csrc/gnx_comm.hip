@@ -1,0 +1,607 @@
+// One tiled time step as ONE call into the library, the exchanges issued by the library itself
+// on the handle's own stream: gnx_tile_step (include/gnx_hip.h).
+//
+// Round 3's tiled step was driven from Python (geonomics_amd/parallel.py: TiledStepper._step_v2):
+// the tile2 entry points of gnx_tile.hip composed with torch.distributed collectives - two
+// gloo all-gathers of counts, batches of P2POp sends, an all-gather of pair keys with
+// torch.searchsorted behind it, ~10 hand-overs between torch's stream and the library's.
+// Here the same protocol runs in C: neighbour exchanges are grouped
+// ncclSend / ncclRecv on h->stream (RCCL over xGMI: point-to-point links, so the byte movers
+// are p2p messages between neighbour tiles and the only collectives are KB-sized), the count
+// exchanges are a KB-sized ncclAllGather whose result reaches the host through pinned memory,
+// the pairs' global offspring offsets come from a kernel of binary searches.  No torch, no
+// Python between the phases of a step.
+//
+// The reference has no counterpart: it is a single process (sim/model.py:924-925 is a TODO
+// about farming iterations out); the partitioning is SURVEY 8(e)'s.
+//
+// Transports: RCCL (librccl, loaded when a communicator is made), and - for the tests on a
+// one-GPU box, where RCCL refuses two ranks on one device - "local": the tiles are handles
+// of one process driven by one host thread each, and the exchanges are device-to-device
+// copies between them behind a barrier of the threads.  Everything but the ncclSend /
+// ncclRecv / ncclAllGather / ncclAllReduce calls themselves is the same code.
+#include <dlfcn.h>
+#include <pthread.h>
+#include <chrono>
+#include <mutex>
+#include <condition_variable>
+#include <rccl/rccl.h>
+#include "gnx_internal.h"
+
+namespace {
+
+// ---- librccl, loaded on demand (the library itself does not link it) ----------------------
+struct Rccl {
+  void* lib = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+
+int rccl_load() {
+  std::lock_guard<std::mutex> lk(g_rccl_mu);
+  if (g_rccl.lib) return 0;
+  void* lib = nullptr;
+  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (lib) break;
+  }
+  if (!lib) {
+    gnx_set_error("librccl.so not found (%s)", dlerror());
+    return 1;
+  }
+#define GNX_SYM(f)                                                              \
+  g_rccl.f = (decltype(g_rccl.f))dlsym(lib, "nccl" #f);                         \
+  if (!g_rccl.f) {                                                              \
+    gnx_set_error("librccl.so has no nccl" #f);                                 \
+    return 1;                                                                   \
+  }
+  GNX_SYM(GetUniqueId) GNX_SYM(CommInitRank) GNX_SYM(CommDestroy) GNX_SYM(GetErrorString)
+  GNX_SYM(GroupStart) GNX_SYM(GroupEnd) GNX_SYM(Send) GNX_SYM(Recv) GNX_SYM(AllGather)
+  GNX_SYM(AllReduce)
+#undef GNX_SYM
+  g_rccl.lib = lib;
+  return 0;
+}
+
+#define NCCLCHK(expr)                                                                   \
+  do {                                                                                  \
+    ncclResult_t _r = (expr);                                                           \
+    if (_r != ncclSuccess) {                                                            \
+      gnx_set_error("%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(_r), __FILE__, \
+                    __LINE__);                                                          \
+      return 1;                                                                         \
+    }                                                                                   \
+  } while (0)
+
+// ---- the local transport's meeting point ----------------------------------------------------
+struct LocalGroup {
+  int world = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  int waiting = 0;
+  long generation = 0;
+  bool aborted = false;
+  // what the ranks post for each other between two barriers
+  std::vector<std::vector<int64_t>> vec;           // small host vectors
+  std::vector<std::vector<const void*>> ptr;       // device pointers of the posted parts
+  explicit LocalGroup(int w) : world(w), vec(w), ptr(w) {}
+  int barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    if (aborted) return 1;
+    const long gen = generation;
+    if (++waiting == world) {
+      waiting = 0;
+      ++generation;
+      cv.notify_all();
+      return 0;
+    }
+    const bool ok = cv.wait_for(lk, std::chrono::seconds(60),
+                                [&] { return generation != gen || aborted; });
+    if (!ok || aborted) {
+      aborted = true;
+      cv.notify_all();
+      return 1;
+    }
+    return 0;
+  }
+  void abort() {
+    std::lock_guard<std::mutex> lk(mu);
+    aborted = true;
+    cv.notify_all();
+  }
+};
+
+enum { COMM_SINGLE = 0, COMM_RCCL = 1, COMM_LOCAL = 2 };
+enum { RB_MIG_REC, RB_MIG_Z, RB_MIG_GENO, RB_GHOST, RB_REQ, RB_GAMETES, RB_KEYS, RB_GOFF, RB_PAD,
+       RB_VEC_SEND, RB_VEC_RECV, RB_COUNT };
+
+struct Comm {
+  int kind = COMM_SINGLE, rank = 0, world = 1;
+  ncclComm_t nccl = nullptr;
+  LocalGroup* grp = nullptr;
+  void* rbuf[RB_COUNT]{};
+  size_t rcap[RB_COUNT]{};
+  int64_t* pin = nullptr;          // pinned host words [2][4096]: vectors out / in
+  int64_t* pin_dev = nullptr;
+  int64_t pre = -1;                // global population before the last step's deaths
+  int64_t bytes_sent = 0;
+  int64_t steps = 0;
+};
+
+Comm* comm_of(gnx_state* h) { return (Comm*)h->tile_comm; }
+
+int rb_need(Comm* c, int k, size_t bytes) {
+  if (bytes <= c->rcap[k]) return 0;
+  if (c->rbuf[k]) HIPCHK(hipFree(c->rbuf[k]));       // (waits for the device: nobody reads it)
+  c->rcap[k] = bytes + bytes / 4 + 4096;
+  HIPCHK(hipMalloc(&c->rbuf[k], c->rcap[k]));
+  return 0;
+}
+
+__global__ void k_copy_i64(int n, const int64_t* __restrict__ src, int64_t* __restrict__ dst) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) dst[k] = src[k];
+}
+
+__global__ void k_sum_i32(int n, int world, const int32_t* __restrict__ all, int32_t* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  int32_t s = 0;
+  for (int r = 0; r < world; ++r) s += all[(int64_t)r * n + k];
+  out[k] = s;
+}
+
+// global offspring offset of every local pair: pairs are numbered in the order of their keys
+// (hash cell << 40 | focal id, ascending on every tile) over ALL tiles; the offset of a pair
+// is the births of all pairs with a smaller key = sum over tiles of (its rank in that tile's
+// key list) x (births per pair)
+__global__ void k_pair_goff(int64_t P, const int64_t* __restrict__ mine, int world,
+                            const int64_t* __restrict__ all, int64_t stride,
+                            const int64_t* __restrict__ counts, int64_t counts_stride, int64_t lam,
+                            int64_t* __restrict__ goff) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int64_t key = mine[p];
+  int64_t acc = 0;
+  for (int r = 0; r < world; ++r) {
+    const int64_t* li = all + (int64_t)r * stride;
+    int64_t lo = 0, hi = counts[(int64_t)r * counts_stride];
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (li[mid] < key) lo = mid + 1;
+      else hi = mid;
+    }
+    acc += lo;
+  }
+  goff[p] = acc * lam;
+}
+
+// every rank's vector of n int64 words -> out[world][n] on the host; the gathered words stay in
+// device memory too (rbuf[RB_VEC_RECV]).  RCCL: one KB-sized all-gather on the handle's stream
+// and one wait for it; the words travel to and from the host through pinned memory.
+int host_allgather(gnx_state* h, const int64_t* vec, int n, int64_t* out) {
+  Comm* c = comm_of(h);
+  const int w = c->world;
+  if (w == 1) {
+    for (int k = 0; k < n; ++k) out[k] = vec[k];
+    return 0;
+  }
+  GNXCHK(rb_need(c, RB_VEC_RECV, (size_t)w * n * 8));
+  if (c->kind == COMM_LOCAL) {
+    LocalGroup* g = c->grp;
+    g->vec[c->rank].assign(vec, vec + n);
+    if (g->barrier()) {
+      gnx_set_error("local tile group: a rank failed or never arrived");
+      return 1;
+    }
+    for (int r = 0; r < w; ++r)
+      for (int k = 0; k < n; ++k) out[(int64_t)r * n + k] = g->vec[r][k];
+    if (g->barrier()) return 1;
+    HIPCHK(hipMemcpyAsync(c->rbuf[RB_VEC_RECV], out, (size_t)w * n * 8, hipMemcpyHostToDevice,
+                          h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));          // (`out` is the caller's)
+    return 0;
+  }
+  GNXCHK(rb_need(c, RB_VEC_SEND, (size_t)n * 8));
+  for (int k = 0; k < n; ++k) c->pin[k] = vec[k];
+  hipLaunchKernelGGL(k_copy_i64, dim3((n + 63) / 64), dim3(64), 0, h->stream, n,
+                     (const int64_t*)c->pin_dev, (int64_t*)c->rbuf[RB_VEC_SEND]);
+  NCCLCHK(g_rccl.AllGather(c->rbuf[RB_VEC_SEND], c->rbuf[RB_VEC_RECV], (size_t)n, ncclInt64,
+                           c->nccl, h->stream));
+  hipLaunchKernelGGL(k_copy_i64, dim3((w * n + 63) / 64), dim3(64), 0, h->stream, w * n,
+                     (const int64_t*)c->rbuf[RB_VEC_RECV], c->pin_dev + 4096);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int k = 0; k < w * n; ++k) out[k] = c->pin[4096 + k];
+  return 0;
+}
+
+struct Part {
+  const void* send;     // grouped by destination rank
+  size_t unit;          // bytes per element
+  int rb;               // receive buffer
+};
+
+// mat[src * w + dst] = elements src sends to dst; every part moves with the same counts.  One
+// group of sends and receives for all parts (RCCL), nothing waits for the device.
+int exchange(gnx_state* h, const Part* parts, int n_parts, const int64_t* mat) {
+  Comm* c = comm_of(h);
+  const int w = c->world, me = c->rank;
+  int64_t n_in = 0;
+  for (int r = 0; r < w; ++r) n_in += mat[(int64_t)r * w + me];
+  for (int k = 0; k < n_parts; ++k) GNXCHK(rb_need(c, parts[k].rb, (size_t)n_in * parts[k].unit));
+  if (c->kind == COMM_LOCAL) {
+    LocalGroup* g = c->grp;
+    HIPCHK(hipStreamSynchronize(h->stream));          // what this rank posts is written
+    g->ptr[me].assign(n_parts, nullptr);
+    for (int k = 0; k < n_parts; ++k) g->ptr[me][k] = parts[k].send;
+    if (g->barrier()) {
+      gnx_set_error("local tile group: a rank failed or never arrived");
+      return 1;
+    }
+    int64_t roff = 0;
+    for (int peer = 0; peer < w; ++peer) {
+      const int64_t n = mat[(int64_t)peer * w + me];
+      int64_t soff = 0;
+      for (int q = 0; q < me; ++q) soff += mat[(int64_t)peer * w + q];
+      if (n > 0)
+        for (int k = 0; k < n_parts; ++k) {
+          c->bytes_sent += n * (int64_t)parts[k].unit;          // (counted by the receiver here)
+          HIPCHK(hipMemcpyAsync((char*)c->rbuf[parts[k].rb] + roff * parts[k].unit,
+                                (const char*)g->ptr[peer][k] + soff * parts[k].unit,
+                                (size_t)n * parts[k].unit, hipMemcpyDeviceToDevice, h->stream));
+        }
+      roff += n;
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));          // nobody reuses a posted buffer before this
+    if (g->barrier()) return 1;
+    return 0;
+  }
+  NCCLCHK(g_rccl.GroupStart());
+  int64_t roff = 0, soff = 0;
+  for (int peer = 0; peer < w; ++peer) {
+    const int64_t n_out = mat[(int64_t)me * w + peer], n_from = mat[(int64_t)peer * w + me];
+    for (int k = 0; k < n_parts; ++k) {
+      if (peer == me) {
+        if (n_out > 0)
+          HIPCHK(hipMemcpyAsync((char*)c->rbuf[parts[k].rb] + roff * parts[k].unit,
+                                (const char*)parts[k].send + soff * parts[k].unit,
+                                (size_t)n_out * parts[k].unit, hipMemcpyDeviceToDevice, h->stream));
+        continue;
+      }
+      if (n_out > 0) {
+        NCCLCHK(g_rccl.Send((const char*)parts[k].send + soff * parts[k].unit,
+                            (size_t)n_out * parts[k].unit, ncclChar, peer, c->nccl, h->stream));
+        c->bytes_sent += n_out * (int64_t)parts[k].unit;
+      }
+      if (n_from > 0)
+        NCCLCHK(g_rccl.Recv((char*)c->rbuf[parts[k].rb] + roff * parts[k].unit,
+                            (size_t)n_from * parts[k].unit, ncclChar, peer, c->nccl, h->stream));
+    }
+    soff += n_out;
+    roff += n_from;
+  }
+  NCCLCHK(g_rccl.GroupEnd());
+  return 0;
+}
+
+// every rank's int64 device array (lengths counts[r * cs], known everywhere) -> rbuf[RB_KEYS]
+// [world][stride]; returns the stride
+int allgather_keys(gnx_state* h, const int64_t* mine, const int64_t* counts, int cs, int64_t* stride_out) {
+  Comm* c = comm_of(h);
+  const int w = c->world, me = c->rank;
+  int64_t m = 1;
+  for (int r = 0; r < w; ++r) m = std::max(m, counts[(int64_t)r * cs]);
+  *stride_out = m;
+  GNXCHK(rb_need(c, RB_KEYS, (size_t)w * m * 8));
+  const int64_t P = counts[(int64_t)me * cs];
+  if (c->kind == COMM_LOCAL) {
+    LocalGroup* g = c->grp;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    g->ptr[me].assign(1, mine);
+    if (g->barrier()) {
+      gnx_set_error("local tile group: a rank failed or never arrived");
+      return 1;
+    }
+    for (int r = 0; r < w; ++r) {
+      const int64_t n = counts[(int64_t)r * cs];
+      if (n > 0)
+        HIPCHK(hipMemcpyAsync((int64_t*)c->rbuf[RB_KEYS] + (int64_t)r * m, g->ptr[r][0], (size_t)n * 8,
+                              hipMemcpyDeviceToDevice, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (g->barrier()) return 1;
+    return 0;
+  }
+  // equal counts for the collective: this rank's keys in a buffer of the common stride
+  GNXCHK(rb_need(c, RB_PAD, (size_t)m * 8));
+  if (P > 0)
+    HIPCHK(hipMemcpyAsync(c->rbuf[RB_PAD], mine, (size_t)P * 8, hipMemcpyDeviceToDevice, h->stream));
+  NCCLCHK(g_rccl.AllGather(c->rbuf[RB_PAD], c->rbuf[RB_KEYS], (size_t)m, ncclInt64, c->nccl, h->stream));
+  c->bytes_sent += m * 8;
+  return 0;
+}
+
+// int32 words summed over the ranks, in place (both density fields and the counters)
+int allreduce_i32(gnx_state* h, int32_t* buf, int64_t n) {
+  Comm* c = comm_of(h);
+  const int w = c->world, me = c->rank;
+  if (w == 1) return 0;
+  if (c->kind == COMM_LOCAL) {
+    LocalGroup* g = c->grp;
+    GNXCHK(rb_need(c, RB_PAD, (size_t)w * n * 4));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    g->ptr[me].assign(1, buf);
+    if (g->barrier()) {
+      gnx_set_error("local tile group: a rank failed or never arrived");
+      return 1;
+    }
+    for (int r = 0; r < w; ++r)
+      HIPCHK(hipMemcpyAsync((int32_t*)c->rbuf[RB_PAD] + (int64_t)r * n, g->ptr[r][0], (size_t)n * 4,
+                            hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (g->barrier()) return 1;                       // everybody has read everybody's words
+    hipLaunchKernelGGL(k_sum_i32, dim3((int)((n + 255) / 256)), dim3(256), 0, h->stream, (int)n, w,
+                       (const int32_t*)c->rbuf[RB_PAD], buf);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  NCCLCHK(g_rccl.AllReduce(buf, buf, (size_t)n, ncclInt32, ncclSum, c->nccl, h->stream));
+  return 0;
+}
+
+int comm_new(gnx_state* h, Comm** out) {
+  if (h->tile_comm) {
+    gnx_set_error("this handle already has a tile communicator");
+    return 1;
+  }
+  Comm* c = new Comm();
+  if (hipHostMalloc((void**)&c->pin, 2 * 4096 * sizeof(int64_t),
+                    hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&c->pin_dev, c->pin, 0) != hipSuccess) {
+    delete c;
+    gnx_set_error("pinned memory for the tile communicator");
+    return 1;
+  }
+  h->tile_comm = c;
+  *out = c;
+  return 0;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- communicators
+extern "C" int gnx_comm_unique_id(uint8_t* out128) {
+  GNXCHK(rccl_load());
+  ncclUniqueId id;
+  NCCLCHK(g_rccl.GetUniqueId(&id));
+  static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+  memcpy(out128, &id, sizeof(id));
+  return 0;
+}
+
+extern "C" int gnx_comm_init_rccl(gnx_state* h, const uint8_t* id128, int32_t rank, int32_t world) {
+  GNXCHK(rccl_load());
+  HIPCHK(hipSetDevice(h->cfg.device));
+  Comm* c = nullptr;
+  GNXCHK(comm_new(h, &c));
+  c->kind = world > 1 ? COMM_RCCL : COMM_SINGLE;
+  c->rank = rank;
+  c->world = world;
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  // (a one-rank communicator too: bench.py --gpus 1 goes through the same calls)
+  NCCLCHK(g_rccl.CommInitRank(&c->nccl, world, id, rank));
+  if (world > 1) c->kind = COMM_RCCL;
+  return 0;
+}
+
+extern "C" int gnx_comm_init_single(gnx_state* h) {
+  Comm* c = nullptr;
+  GNXCHK(comm_new(h, &c));
+  return 0;
+}
+
+extern "C" int gnx_comm_local_create(int32_t world, void** group) {
+  *group = new LocalGroup(world);
+  return 0;
+}
+
+extern "C" int gnx_comm_local_join(gnx_state* h, void* group, int32_t rank) {
+  LocalGroup* g = (LocalGroup*)group;
+  if (rank < 0 || rank >= g->world) {
+    gnx_set_error("gnx_comm_local_join: rank %d of %d", rank, g->world);
+    return 1;
+  }
+  Comm* c = nullptr;
+  GNXCHK(comm_new(h, &c));
+  c->kind = g->world > 1 ? COMM_LOCAL : COMM_SINGLE;
+  c->rank = rank;
+  c->world = g->world;
+  c->grp = g;
+  return 0;
+}
+
+extern "C" int gnx_comm_local_abort(void* group) {
+  ((LocalGroup*)group)->abort();
+  return 0;
+}
+
+extern "C" int gnx_comm_local_destroy(void* group) {
+  delete (LocalGroup*)group;
+  return 0;
+}
+
+extern "C" int gnx_comm_free(gnx_state* h) {
+  Comm* c = comm_of(h);
+  if (!c) return 0;
+  (void)hipStreamSynchronize(h->stream);
+  for (int k = 0; k < RB_COUNT; ++k)
+    if (c->rbuf[k]) (void)hipFree(c->rbuf[k]);
+  if (c->nccl) (void)g_rccl.CommDestroy(c->nccl);
+  if (c->pin) (void)hipHostFree(c->pin);
+  delete c;
+  h->tile_comm = nullptr;
+  return 0;
+}
+
+extern "C" int64_t gnx_comm_bytes_sent(gnx_state* h) {
+  Comm* c = comm_of(h);
+  return c ? c->bytes_sent : 0;
+}
+
+// ---------------------------------------------------------------- the step
+// One time step of this tile (gnx_tile_set) and, through the communicator, of the whole
+// tiled landscape: age + movement, routing of emigrants and ghosts, ONE batch of neighbour
+// sends, import, cell sort + mate search + pairs, global offspring offsets, births, gamete
+// service for ghost mates, ONE all-reduce of both density fields and the counters, densities,
+// death probabilities, mortality.  out[3]: exact != 0 -> the global (N after the step, births,
+// deaths) at the price of one more KB-sized collective; else the counts that rode on the
+// step's own all-reduce: (N at the START of the step, births, deaths of the PREVIOUS step).
+extern "C" int gnx_tile_step(gnx_state* h, int32_t burn, int32_t with_selection, int32_t exact,
+                             int64_t* out) {
+  Comm* c = comm_of(h);
+  if (!c) {
+    gnx_set_error("gnx_tile_step: no communicator (gnx_comm_init_rccl / _single / gnx_comm_local_join)");
+    return 1;
+  }
+  if (!h->have_sp) {
+    gnx_set_error("species parameters not set");
+    return 1;
+  }
+  if (!h->sp.n_births_fixed && c->world > 1) {
+    gnx_set_error("gnx_tile_step: Poisson births travel with the pair keys through the host layer "
+                  "(TiledStepper, GNX_TILE_V3=0)");
+    return 3;
+  }
+  const int w = c->world, me = c->rank, T = h->tile_R * h->tile_C;
+  if (T != w) {
+    gnx_set_error("gnx_tile_step: %d tiles but %d ranks", T, w);
+    return 1;
+  }
+  const int nt = h->cfg.n_traits, W64 = h->W64;
+  const bool geno = h->genomes_assigned && h->cfg.L > 0;
+  std::vector<int64_t> cnt(2 * T + 4), mats((size_t)w * (2 * T + 4));
+  // 1. age + movement, routing (wait 1), ONE exchange: migrants and ghosts
+  GNXCHK(gnx_tile2_move_route(h, 1, cnt.data()));
+  if (w > 1) {
+    GNXCHK(host_allgather(h, cnt.data(), 2 * T, mats.data()));
+    std::vector<int64_t> m_mig((size_t)w * w), m_gh((size_t)w * w);
+    for (int s = 0; s < w; ++s)
+      for (int d = 0; d < w; ++d) {
+        m_mig[(size_t)s * w + d] = mats[(size_t)s * 2 * T + d];
+        m_gh[(size_t)s * w + d] = mats[(size_t)s * 2 * T + T + d];
+      }
+    void *p_rec, *p_z, *p_g, *p_gh;
+    GNXCHK(gnx_tile2_route_ptrs(h, &p_rec, &p_z, &p_g, &p_gh));
+    Part parts[3];
+    int np = 0;
+    parts[np++] = Part{p_rec, 32, RB_MIG_REC};
+    if (nt) parts[np++] = Part{p_z, (size_t)4 * nt, RB_MIG_Z};
+    if (geno) parts[np++] = Part{p_g, (size_t)16 * W64, RB_MIG_GENO};
+    GNXCHK(exchange(h, parts, np, m_mig.data()));
+    Part gh{p_gh, 32, RB_GHOST};
+    GNXCHK(exchange(h, &gh, 1, m_gh.data()));
+    int64_t in_mig = 0, in_gh = 0;
+    for (int s = 0; s < w; ++s) {
+      in_mig += m_mig[(size_t)s * w + me];
+      in_gh += m_gh[(size_t)s * w + me];
+    }
+    GNXCHK(gnx_tile2_import(h, in_mig, c->rbuf[RB_MIG_REC], nt ? c->rbuf[RB_MIG_Z] : nullptr,
+                            geno ? c->rbuf[RB_MIG_GENO] : nullptr, in_gh, c->rbuf[RB_GHOST]));
+  }
+  // 2. pairs (wait 2); pair order and gamete requests from ONE count exchange
+  std::vector<int64_t> pc(2 + T);
+  GNXCHK(gnx_tile2_pairs(h, burn, pc.data()));
+  const int64_t P = pc[0], B = pc[1];
+  int64_t total_births = B, total_pairs = P;
+  const void* goff = nullptr;
+  std::vector<int64_t> m_req((size_t)w * w, 0);
+  if (w > 1) {
+    const int cs = 2 + T;
+    GNXCHK(host_allgather(h, pc.data(), cs, mats.data()));
+    total_births = total_pairs = 0;
+    for (int r = 0; r < w; ++r) {
+      total_pairs += mats[(size_t)r * cs];
+      total_births += mats[(size_t)r * cs + 1];
+      for (int d = 0; d < w; ++d) m_req[(size_t)r * w + d] = mats[(size_t)r * cs + 2 + d];
+    }
+    int64_t P_, stride = 1;
+    void *p_ids, *p_nb;
+    GNXCHK(gnx_tile_pair_ptrs_nosync(h, &P_, &p_ids, &p_nb));
+    GNXCHK(allgather_keys(h, (const int64_t*)p_ids, mats.data(), cs, &stride));
+    if (P > 0) {
+      GNXCHK(rb_need(c, RB_GOFF, (size_t)P * 8));
+      // (the gathered counts are in device memory as well: host_allgather left them there)
+      hipLaunchKernelGGL(k_pair_goff, dim3(gnx_grid(P, 256)), dim3(256), 0, h->stream, P,
+                         (const int64_t*)p_ids, w, (const int64_t*)c->rbuf[RB_KEYS], stride,
+                         (const int64_t*)c->rbuf[RB_VEC_RECV], (int64_t)cs,
+                         (int64_t)h->sp.n_births_lambda, (int64_t*)c->rbuf[RB_GOFF]);
+      HIPCHK(hipGetLastError());
+      goff = c->rbuf[RB_GOFF];
+    }
+  }
+  void* p_req = nullptr;
+  const int64_t id_base = h->max_id + 1;        // (the global maximum: every rank keeps it)
+  GNXCHK(gnx_tile2_offspring(h, burn, id_base, goff, &p_req));
+  GNXCHK(gnx_set_max_id(h, id_base - 1 + total_births));
+  // gametes of ghost mates: requests out, gametes back
+  if (w > 1 && !burn && geno) {
+    int64_t n_req = 0, m = 0;
+    for (int d = 0; d < w; ++d) n_req += m_req[(size_t)me * w + d];
+    for (int s = 0; s < w; ++s) m += m_req[(size_t)s * w + me];
+    Part rq{p_req, 24, RB_REQ};
+    GNXCHK(exchange(h, &rq, 1, m_req.data()));
+    void* p_out = nullptr;
+    GNXCHK(gnx_tile2_serve(h, m, m ? c->rbuf[RB_REQ] : nullptr, &p_out));
+    std::vector<int64_t> m_back((size_t)w * w);
+    for (int s = 0; s < w; ++s)
+      for (int d = 0; d < w; ++d) m_back[(size_t)s * w + d] = m_req[(size_t)d * w + s];
+    Part gm{p_out, (size_t)8 * W64, RB_GAMETES};
+    GNXCHK(exchange(h, &gm, 1, m_back.data()));
+    if (n_req) GNXCHK(gnx_tile2_put(h, n_req, c->rbuf[RB_GAMETES]));
+  }
+  void* red = nullptr;
+  int64_t n_words = 0;
+  GNXCHK(gnx_tile2_finish_births(h, burn, &red, &n_words));
+  // ONE all-reduce: both density fields and the counters
+  GNXCHK(allreduce_i32(h, (int32_t*)red, n_words));
+  // 3. densities, death probabilities, mortality (wait 3)
+  int64_t tot[3] = {0, 0, 0};
+  GNXCHK(gnx_tile2_die(h, burn, with_selection, total_pairs > 0 ? 1 : 0, tot));
+  h->step += 1;
+  c->steps += 1;
+  if (exact) {
+    int64_t mine[3];
+    GNXCHK(gnx_counts(h, &mine[0], &mine[1], &mine[2]));
+    if (w > 1) {
+      std::vector<int64_t> g((size_t)w * 3);
+      GNXCHK(host_allgather(h, mine, 3, g.data()));
+      mine[0] = mine[1] = mine[2] = 0;
+      for (int r = 0; r < w; ++r)
+        for (int k = 0; k < 3; ++k) mine[k] += g[(size_t)r * 3 + k];
+    }
+    out[0] = mine[0];
+    out[1] = mine[1];
+    out[2] = mine[2];
+    c->pre = -1;
+    return 0;
+  }
+  // (N at the start of this step = N before the previous step's deaths - those deaths)
+  const int64_t n_pre = tot[0], b_glob = tot[1], d_prev = tot[2];
+  out[0] = c->pre >= 0 ? c->pre - d_prev : n_pre - b_glob;
+  out[1] = b_glob;
+  out[2] = d_prev;
+  c->pre = n_pre;
+  return 0;
+}

@@ -519,6 +519,7 @@ struct gnx_state {
   void* h_stage = nullptr;           // pinned host staging buffer for per-step transfers
   size_t h_stage_bytes = 0;
 
+  void* tile_comm = nullptr;           // gnx_comm.hip: the tile communicator (RCCL / local)
   // the device-driven step (gnx_dd.hip)
   GnxDD* dd = nullptr;                 // device
   GnxDDRec* dd_ring = nullptr;         // pinned host ring the steps publish into

@@ -408,11 +408,41 @@ class TiledStepper:
         # transport that moves device memory, or a single tile
         self.v2 = (hasattr(shard, 'dev') and os.environ.get('GNX_TILE_V2', '1') != '0' and
                    (comm.world == 1 or self.dev_transport))
+        # One C call per step, the exchanges issued by the library itself on its own stream
+        # (gnx_tile_step, csrc/gnx_comm.hip: grouped ncclSend / ncclRecv, KB-sized collectives,
+        # no torch.distributed call and no Python between the phases of a step).  Needs a fixed
+        # number of births per pair on several tiles (Poisson counts travel with the pair keys
+        # through _step_v2) and no per-step hook (mutations: after_births).  GNX_TILE_V3=0: off.
+        self.v3 = False
+        if self.v2 and os.environ.get('GNX_TILE_V3', '1') != '0':
+            self.v3 = self._join_library_comm()
         self._ext = None           # the library's stream as a torch stream
         self._evcache = os.environ.get('GNX_TILE_EVCACHE', '1') != '0'
         self._keep = []            # tensors the library reads until the end of the step
         self._n_start = None       # global population at the start of the coming step
         self._pre = None           # global population before the last step's deaths
+
+    def _join_library_comm(self):
+        dev, comm = self.shard.dev, self.comm
+        if comm.world > 1 and not (self.fixed_births or dev.births_fixed_lambda):
+            return False
+        try:
+            group = getattr(comm, 'local_group', None)
+            if comm.world == 1:
+                dev.comm_init_single()
+            elif group is not None:               # tiles as threads of one process (tests)
+                dev.comm_local_join(group, comm.rank)
+            elif comm.dist is not None and comm.dist.get_backend() == 'nccl':
+                # rank 0 makes the RCCL id; it travels once, through the launcher's own group
+                box = [nat.comm_unique_id() if comm.rank == 0 else None]
+                comm.dist.broadcast_object_list(box, src=0)
+                dev.comm_init_rccl(box[0], comm.rank, comm.world)
+            else:
+                return False
+        except nat.GnxError:
+            return False
+        dev.set_max_id(self.max_id)
+        return True
 
     def rank_of(self, x, y):
         c = np.minimum(self.C - 1, (np.asarray(x) // self.tw).astype(np.int64))
@@ -830,7 +860,15 @@ class TiledStepper:
         device-driven protocol skips the collective those take and returns the counts
         that rode on the step's own all-reduce: (N at the START of the step, births,
         deaths of the PREVIOUS step)."""
+        if self.v3 and after_births is None:
+            n, b, d = self.shard.dev.tile_step(burn, with_selection, exact)
+            self.max_id += b
+            self.bytes_sent = self.shard.dev.comm_bytes_sent
+            return n, b, d
         if self.v2:
+            if self.v3:
+                # (the library keeps the global maximum id while it drives the steps)
+                self.shard.set_max_id(self.max_id)
             return self._step_v2(burn, with_selection, after_births, exact)
         sh = self.shard
         self._tick(None)

@@ -439,21 +439,29 @@ class Species:
         the number of steps taken (fewer than T if the Species went extinct)."""
         dev = self._dev
         with_selection = self.selection and self.burned
-        dev.walk(T, False, with_selection)
-        n0, births, deaths = dev.walk_history(T)
         done = 0
-        for a, b, d in zip(n0.tolist(), births.tolist(), deaths.tolist()):
-            if a == 0:
+        while done < T and not self.extinct:
+            # the device-driven steps cannot grow the device state (the queue's steps can,
+            # _grow_device): they run in pieces, and only while the population leaves a third
+            # of the capacity free - a piece whose births would not fit ends in an error
+            if len(self) > 0.66 * self._cap:
                 break
-            self.n_births.append(int(b))
-            self.n_deaths.append(int(d))
-            self.Nt.append(int(a + b - d))
-            self.max_ind_idx += int(b)
-            self.t += 1
-            done += 1
-            if a + b - d == 0:
-                self.extinct = True
-                break
+            chunk = min(T - done, 256)
+            dev.walk(chunk, False, with_selection)
+            n0, births, deaths = dev.walk_history(chunk)
+            for a, b, d in zip(n0.tolist(), births.tolist(), deaths.tolist()):
+                if a == 0:
+                    self.extinct = True
+                    break
+                self.n_births.append(int(b))
+                self.n_deaths.append(int(d))
+                self.Nt.append(int(a + b - d))
+                self.max_ind_idx += int(b)
+                self.t += 1
+                done += 1
+                if a + b - d == 0:
+                    self.extinct = True
+                    break
         return done
 
     def _grow_device(self, factor=2.0):

@@ -466,6 +466,38 @@ int gnx_tile2_finish_births(gnx_state* h, int32_t burn, void** reduce_dev, int64
 int gnx_tile2_die(gnx_state* h, int32_t burn, int32_t with_selection, int32_t have_pairs,
                   int64_t* totals);
 
+/* ---- one tiled time step per call, the exchanges issued by the library (csrc/gnx_comm.hip).
+ * The tile2 protocol above composed in C: grouped ncclSend / ncclRecv to the neighbour tiles
+ * on the handle's own stream (RCCL over xGMI), KB-sized ncclAllGather for the counts and the
+ * pairs' order keys, ONE ncclAllReduce for both density fields and the counters, the pairs'
+ * global offspring offsets by a kernel of binary searches - no torch.distributed call, no
+ * Python between the phases of a step.  The reference has no counterpart (one process;
+ * sim/model.py:924-925 is a TODO).
+ *   gnx_comm_unique_id: rank 0 makes the id (ncclGetUniqueId, 128 bytes) and hands it to the
+ *     other ranks by whatever channel the launcher has (bench.py: torch.distributed broadcast);
+ *   gnx_comm_init_rccl: every rank joins (ncclCommInitRank; world 1 is allowed);
+ *   gnx_comm_init_single: one tile, no communicator at all;
+ *   gnx_comm_local_*: the tiles are handles of ONE process driven by one host thread each and
+ *     the exchanges are device-to-device copies behind a barrier of the threads - the tests of
+ *     the one-GPU box, where RCCL refuses two ranks on one device; everything but the nccl*
+ *     calls themselves is the same code;
+ *   gnx_tile_step: one step.  out[3]: exact != 0 -> the global (N after the step, births,
+ *     deaths), one more KB-sized collective; else what rode on the step's own all-reduce:
+ *     (N at the START of the step, births, deaths of the PREVIOUS step).  Births per pair must
+ *     be fixed (Poisson births travel with the pair keys through the host layer: returns 3).
+ *   The global maximum id (gnx_set_max_id) must be the same on every rank before the first
+ *   step; the library keeps it.                                                             */
+int gnx_comm_unique_id(uint8_t* out128);
+int gnx_comm_init_rccl(gnx_state* h, const uint8_t* id128, int32_t rank, int32_t world);
+int gnx_comm_init_single(gnx_state* h);
+int gnx_comm_local_create(int32_t world, void** group);
+int gnx_comm_local_join(gnx_state* h, void* group, int32_t rank);
+int gnx_comm_local_abort(void* group);
+int gnx_comm_local_destroy(void* group);
+int gnx_comm_free(gnx_state* h);
+int64_t gnx_comm_bytes_sent(gnx_state* h);
+int gnx_tile_step(gnx_state* h, int32_t burn, int32_t with_selection, int32_t exact, int64_t* out);
+
 /* ---- pedigree (reference structs/species.py:692-736: rows of the tskit tables) --
  * the offspring of the last gnx_pop_dynamics_mate, in birth order; call it before
  * gnx_pop_dynamics_die.  keys / starts: recombination path and start homologue of

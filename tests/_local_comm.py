@@ -11,10 +11,22 @@ import numpy as np
 
 
 class Hub:
-    def __init__(self, world):
+    def __init__(self, world, library_group=False):
         self.world = world
         self.barrier = threading.Barrier(world)
         self.slots = [None] * world
+        # library_group: the tiles also meet inside libgnxhip.so (gnx_comm_local_*), so that
+        # TiledStepper can hand the whole step to gnx_tile_step
+        self.group = None
+        if library_group:
+            from geonomics_amd import _native as nat
+            self.group = nat.comm_local_create(world)
+
+    def abort(self):
+        self.barrier.abort()
+        if self.group is not None:
+            from geonomics_amd import _native as nat
+            nat.comm_local_abort(self.group)
 
 
 class LocalComm:
@@ -23,6 +35,7 @@ class LocalComm:
     def __init__(self, hub, rank):
         self.hub, self.rank, self.world = hub, rank, hub.world
         self.dist = None
+        self.local_group = hub.group
 
     def _swap(self, obj):
         self.hub.slots[self.rank] = obj

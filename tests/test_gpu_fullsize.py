@@ -117,7 +117,7 @@ def test_step_invariants_at_baseline_sizes(workload):
     assert run() == run()
 
 
-def _tiles_equal_one_device(cfg, grid, n_paths, n_burn, n_main, nbits):
+def _tiles_equal_one_device(cfg, grid, n_paths, n_burn, n_main, nbits, library=False):
     """A landscape of grid[0] x grid[1] tiles of `cfg`, once on one device and once as
     tiles (threads of this process, tests/_local_comm.py in place of RCCL, device-resident
     transport).  Genomes carry each founder's id (both homologues, an otherwise empty
@@ -156,7 +156,7 @@ def _tiles_equal_one_device(cfg, grid, n_paths, n_burn, n_main, nbits):
                     c1=c1.astype(np.int64), ch=ch.astype(np.int64))
 
     def run(world):
-        hub = Hub(world)
+        hub = Hub(world, library_group=library and world > 1)
         res, errs = [None] * world, []
 
         def body(rank):
@@ -174,6 +174,8 @@ def _tiles_equal_one_device(cfg, grid, n_paths, n_burn, n_main, nbits):
                 st = TiledStepper(shard, comm, cfg['W'] * C, cfg['H'] * R, 10.0, move=True,
                                   max_id=n_tiles * cfg['N'] - 1,
                                   grid=grid if world > 1 else (1, 1), fixed_births=1)
+                if world > 1:
+                    assert st.v3 == library
                 hist = [st.step(True, False) for _ in range(n_burn)]
                 tag_genomes(dev)
                 shard.has_genomes = True
@@ -182,7 +184,7 @@ def _tiles_equal_one_device(cfg, grid, n_paths, n_burn, n_main, nbits):
                 dev.close()
             except BaseException as e:       # noqa: BLE001
                 errs.append(e)
-                hub.barrier.abort()
+                hub.abort()
         ths = [threading.Thread(target=body, args=(r,)) for r in range(world)]
         [t.start() for t in ths]
         [t.join(timeout=800) for t in ths]
@@ -226,8 +228,10 @@ def test_c5_eight_tiles_equal_one_device_at_size():
     device copies in place of RCCL; the result equals the one-device run bit for bit."""
     import bench
     cfg = dict(bench.WORKLOADS['c5_tile'], L=10_000, n_paths=2000)
+    # (library=True: every step is ONE gnx_tile_step call, the library issues the exchanges -
+    # csrc/gnx_comm.hip; the two-tile test above goes through the Python-driven protocol)
     one, many = _tiles_equal_one_device(cfg, (2, 4), n_paths=2000, n_burn=2, n_main=2,
-                                        nbits=24)
+                                        nbits=24, library=True)
     assert len(one[0]['ids']) > 9_000_000
     sizes = [len(r[0]['ids']) for r in many]
     assert min(sizes) > 500_000                           # every tile carries its share

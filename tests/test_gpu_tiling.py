@@ -72,7 +72,7 @@ def test_single_tile_stepper_equals_gnx_step():
 
 
 # ---- device-resident transport (what RCCL carries on a multi-GPU node) -----------------
-def _run_threads(world, steps, fixed):
+def _run_threads(world, steps, fixed, library=False):
     """`world` tiles as threads of this process, LocalComm between them; the
     same schedule as _tiling_worker.run; returns the gathered final population."""
     import threading
@@ -83,7 +83,9 @@ def _run_threads(world, steps, fixed):
     from geonomics_amd.parallel import Comm, TiledStepper
     import gnx_oracle as O
     cfg = config()
-    hub = Hub(world)
+    # library: the tiles meet inside libgnxhip.so as well and the stepper hands every step to
+    # gnx_tile_step (one C call per step, exchanges issued by the library)
+    hub = Hub(world, library_group=library and world > 1)
     res, errs = [None] * world, []
 
     def body(rank):
@@ -94,6 +96,8 @@ def _run_threads(world, steps, fixed):
             stepper = TiledStepper(shard, comm, cfg['W'], cfg['H'], cfg['radius'], move=True,
                                    max_id=cfg['N0'] - 1, fixed_births=1 if fixed else 0)
             assert stepper.dev_transport == (world > 1)
+            if world > 1:
+                assert stepper.v3 == bool(library and fixed)
             shard.export_migrants()
             hist = []
             for t in range(steps):
@@ -114,7 +118,7 @@ def _run_threads(world, steps, fixed):
             dev.close()
         except BaseException as e:       # noqa: BLE001 - re-raised in the main thread
             errs.append(e)
-            hub.barrier.abort()
+            hub.abort()
 
     ths = [threading.Thread(target=body, args=(r,)) for r in range(world)]
     for t in ths:
@@ -141,6 +145,46 @@ def test_device_resident_transport_is_bit_identical(world, fixed):
     for k in ('ids', 'x', 'y', 'age', 'z', 'geno'):
         np.testing.assert_array_equal(one[k], many[k], err_msg=k)
     assert many['bytes_sent'] > 0 and len(one['ids']) > 500
+
+
+@pytest.mark.parametrize('world', [2, 4, 8])
+def test_library_tile_step_is_bit_identical(world):
+    """gnx_tile_step: the whole tiled step in ONE call into the library, which issues the
+    exchanges itself (csrc/gnx_comm.hip).  On this one-GPU box the tiles are threads of one
+    process and the transport is the library's local one (device copies behind a barrier of
+    the threads; on a node it is grouped ncclSend / ncclRecv on the same code path): the tiled
+    run equals the one-tile run bit for bit, and equals the run the Python-driven protocol
+    (TiledStepper._step_v2) gives."""
+    steps = 8
+    one = _run_threads(1, steps, True)
+    many = _run_threads(world, steps, True, library=True)
+    assert one['hist'].tolist() == many['hist'].tolist()
+    for k in ('ids', 'x', 'y', 'age', 'z', 'geno'):
+        np.testing.assert_array_equal(one[k], many[k], err_msg=k)
+    assert len(one['ids']) > 500
+
+
+def test_rccl_world1_through_the_library():
+    """a one-rank RCCL communicator made by the library itself (ncclGetUniqueId,
+    ncclCommInitRank through the dlopen-ed librccl) and steps through gnx_tile_step: what a
+    one-GPU box can run of the RCCL path; equals gnx_step."""
+    from _tiling_worker import config, make_device_shard
+    from geonomics_amd import _native as nat
+    cfg = config()
+    sh, dev_a = make_device_shard(cfg)
+    _, dev_b = make_device_shard(cfg)
+    dev_a.tile_set(1, 1, 0, 0)
+    dev_a.comm_init_rccl(nat.comm_unique_id(), 0, 1)
+    dev_a.set_max_id(cfg['N0'] - 1)
+    for t in range(6):
+        n, b, d = dev_a.tile_step(True, False, True)
+        dev_b.step(True, False)
+        assert (n, b, d) == dev_b.counts()
+    oa, ob = np.argsort(dev_a.download(nat.F_ID)), np.argsort(dev_b.download(nat.F_ID))
+    for f in (nat.F_ID, nat.F_X, nat.F_Y, nat.F_AGE):
+        np.testing.assert_array_equal(dev_a.download(f)[oa], dev_b.download(f)[ob])
+    dev_a.close()
+    dev_b.close()
 
 
 def test_device_transport_equals_host_transport(tmp_path):

@@ -107,19 +107,22 @@ int main() {
     CHK(hipGraphExecDestroy(ex));
     CHK(hipGraphDestroy(g));
   }
-  // (f) S streams side by side, each K kernels of ~5 us on 64 workgroups: do they overlap?
-  {
+  // (f) S streams side by side, each K kernels on `wgs` workgroups: do they overlap?
+  for (int shape = 0; shape < 3; ++shape) {
+    const int wgs = shape == 0 ? 64 : 1024;
+    const int iters = shape == 2 ? 4000 : 250;
+    printf("-- kernels of %d workgroups x 256 threads, %d iterations each\n", wgs, iters);
     const int S = 8;
     hipStream_t st[S];
     hipGraphExec_t gx[S];
     int* buf = nullptr;
-    CHK(hipMalloc(&buf, S * 64 * 256 * sizeof(int)));
+    CHK(hipMalloc(&buf, (size_t)S * 1024 * 256 * sizeof(int)));
     for (int q = 0; q < S; ++q) CHK(hipStreamCreateWithFlags(&st[q], hipStreamNonBlocking));
     for (int q = 0; q < S; ++q) {
       hipGraph_t g;
       CHK(hipStreamBeginCapture(st[q], hipStreamCaptureModeThreadLocal));
       for (int k = 0; k < K; ++k)
-        hipLaunchKernelGGL(k_work, dim3(64), dim3(256), 0, st[q], buf + q * 64 * 256, 4000);
+        hipLaunchKernelGGL(k_work, dim3(wgs), dim3(256), 0, st[q], buf + (size_t)q * 1024 * 256, iters);
       CHK(hipStreamEndCapture(st[q], &g));
       CHK(hipGraphInstantiate(&gx[q], g, nullptr, nullptr, 0));
       CHK(hipGraphDestroy(g));
@@ -132,7 +135,7 @@ int main() {
           for (int q = 0; q < use; ++q) {
             if (mode == 0) {
               for (int k = 0; k < K; ++k)
-                hipLaunchKernelGGL(k_work, dim3(64), dim3(256), 0, st[q], buf + q * 64 * 256, 4000);
+                hipLaunchKernelGGL(k_work, dim3(wgs), dim3(256), 0, st[q], buf + (size_t)q * 1024 * 256, iters);
             } else {
               CHK(hipGraphLaunch(gx[q], st[q]));
             }
@@ -145,6 +148,11 @@ int main() {
                1e6 * (t2 - t0) / (40 * use));
       }
     }
+    for (int q = 0; q < S; ++q) {
+      CHK(hipGraphExecDestroy(gx[q]));
+      CHK(hipStreamDestroy(st[q]));
+    }
+    CHK(hipFree(buf));
   }
   // (e) a persistent kernel with 25 grid barriers, 256 and 64 workgroups of 256 / 1024 threads
   unsigned int* ctr = nullptr;

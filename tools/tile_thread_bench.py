@@ -25,7 +25,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 workload = sys.argv[3] if len(sys.argv) > 3 else 'c4_metric'
 cfg = bench.WORKLOADS[workload]
 grid = tile_grid(world)
-hub = Hub(world)
+hub = Hub(world, library_group=os.environ.get('GNX_TILE_V3', '1') != '0')
 out = [None] * world
 
 
@@ -73,7 +73,7 @@ def body(rank):
                      st.bytes_sent / steps, n)
         dev.close()
     except BaseException:
-        hub.barrier.abort()
+        hub.abort()
         raise
 
 
