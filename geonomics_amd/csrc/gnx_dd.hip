@@ -109,15 +109,18 @@ static int dd_enqueue_step(gnx_state* h, bool burn, bool sel) {
   h->move_writes_keys = false;
   GNXCHK(rc);
   // mating pairs over the cell-sorted population; the adults' density bins beside the search
-  GNXCHK(gnx_dd_l_sort(h, s1));
+  // (one stream: the two fields' bins are counted by k_permute and k_pair_compact themselves -
+  // two launches of ~5 us less on a chain of ~20; GNX_DD_FUSE_BINS=0: launches of their own)
+  const bool fuse_bins = one && !(getenv("GNX_DD_FUSE_BINS") && atoi(getenv("GNX_DD_FUSE_BINS")) == 0);
+  GNXCHK(gnx_dd_l_sort(h, fuse_bins ? h->fb[par] : nullptr, s1));
   HIPCHK(hipEventRecord(x->ev[0], s1));
   HIPCHK(hipStreamWaitEvent(s3, x->ev[0], 0));
-  GNXCHK(gnx_dd_l_bins_adults(h, par, s3));
-  GNXCHK(gnx_dd_l_pairs(h, s1));
+  if (!fuse_bins) GNXCHK(gnx_dd_l_bins_adults(h, par, s3));
+  GNXCHK(gnx_dd_l_pairs(h, fuse_bins ? h->fb[2] : nullptr, s1));
   // the pairs' density beside the births
   HIPCHK(hipEventRecord(x->ev[1], s1));
   HIPCHK(hipStreamWaitEvent(s3, x->ev[1], 0));
-  GNXCHK(gnx_dd_l_density_pairs(h, s3));
+  if (!fuse_bins) GNXCHK(gnx_dd_l_density_pairs(h, s3));
   HIPCHK(hipEventRecord(x->ev[2], s3));
   GNXCHK(gnx_dd_l_offspring(h, genomes, h->fb[par], s1));
   // densities, death probabilities, death draws
@@ -174,6 +177,7 @@ static int dd_launch_step(gnx_state* h, bool burn, bool sel) {
   const uint32_t key = dd_key(h, burn, sel);
   auto it = x->graphs.find(key);
   if (it == x->graphs.end()) {
+    const auto tc0 = std::chrono::steady_clock::now();
     hipGraph_t g = nullptr;
     const int cur0 = h->cur, ord0 = h->ord_cur, jobs0 = h->jobs_cur, fb0 = h->fb_cur;
     HIPCHK(hipStreamBeginCapture(x->cap[0], hipStreamCaptureModeThreadLocal));
@@ -202,6 +206,9 @@ static int dd_launch_step(gnx_state* h, bool burn, bool sel) {
       return 1;
     }
     it = x->graphs.emplace(key, ex).first;
+    if (env_on("GNX_DD_DEBUG", false))
+      fprintf(stderr, "[gnx dd] graph %u captured and instantiated in %.2f ms\n", key,
+              1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count());
   }
   HIPCHK(hipGraphLaunch(it->second, h->stream));
   dd_flip(h, burn);
@@ -272,6 +279,15 @@ static int dd_wait_all_seen(gnx_state* h) {
 }
 
 static int dd_enter(gnx_state* h) {
+  const auto te0 = std::chrono::steady_clock::now();
+  struct Report {
+    std::chrono::steady_clock::time_point t0;
+    ~Report() {
+      if (env_on("GNX_DD_DEBUG", false))
+        fprintf(stderr, "[gnx dd] enter took %.2f ms\n",
+                1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
+  } report{te0};
   GNXCHK(gnx_xo_join(h));
   GNXCHK(gnx_wait_permute_rest(h));
   gnx_bins_adults_drop(h);
@@ -314,6 +330,9 @@ static int dd_enter(gnx_state* h) {
 
 int gnx_dd_leave(gnx_state* h) {
   if (!h->dd_active) return 0;
+  if (env_on("GNX_DD_DEBUG", false))
+    fprintf(stderr, "[gnx dd] leave: %lld steps enqueued, %lld seen, collections so far %lld\n",
+            (long long)h->dd_seq, (long long)h->dd_seen, (long long)h->gc_runs);
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipStreamSynchronize(h->stream2));
   HIPCHK(hipStreamSynchronize(h->stream3));

@@ -674,8 +674,9 @@ int gnx_l_gather_genomes(gnx_state* h, int64_t n, const int64_t* d_slots, uint64
 int gnx_l_scatter_genomes(gnx_state* h, int64_t n, const uint64_t* d_in, int64_t first_slot);
 
 // ---- device-driven step (gnx_dd.hip): launchers with capacity-sized grids, counts in h->dd
-int gnx_dd_l_sort(gnx_state* h, hipStream_t st);
-int gnx_dd_l_pairs(gnx_state* h, hipStream_t st);
+// d_bins: density bins counted in the same launch (adults / pair midpoints), or null
+int gnx_dd_l_sort(gnx_state* h, int32_t* d_bins, hipStream_t st);
+int gnx_dd_l_pairs(gnx_state* h, int32_t* d_bins, hipStream_t st);
 int gnx_dd_l_offspring(gnx_state* h, bool genomes, int32_t* d_bins, hipStream_t st);
 int gnx_dd_l_bins_adults(gnx_state* h, int par, hipStream_t st);
 int gnx_dd_l_density_pairs(gnx_state* h, hipStream_t st);
@@ -702,13 +703,13 @@ int gnx_block_scan(gnx_state* h, int K, int64_t n_items, const int32_t* cnt, int
 extern double g_host_step_s, g_host_wait_s;      // GNX_HOST_TIMES=1 (gnx_api.hip)
 bool gnx_host_times();
 size_t gnx_os_scratch_bytes(size_t n, int end_bit);
-size_t gnx_os_words_used(size_t n, int end_bit);
+size_t gnx_os_words_used(size_t n, int end_bit, int geometry = 0);
 int gnx_os_keys_hist(void* scratch, unsigned int* ticket, int64_t N, int64_t ord_n,
                      const int32_t* ord, const uint32_t* cell32, uint32_t* key, int32_t* val,
-                     int end_bit, hipStream_t s, const GnxDD* dd = nullptr);
+                     int end_bit, hipStream_t s, const GnxDD* dd = nullptr, int geometry = 0);
 int gnx_os_sort32_ranked(void* scratch, uint32_t* ktmp, int32_t* vtmp, const uint32_t* kin,
                          uint32_t* kout, const int32_t* vin, int32_t* vout, size_t n, int end_bit,
-                         hipStream_t s);
+                         hipStream_t s, int geometry = 0);
 int gnx_os_sort32(void* scratch, uint32_t* ktmp, int32_t* vtmp, const uint32_t* kin,
                   uint32_t* kout, const int32_t* vin, int32_t* vout, size_t n, int end_bit,
                   hipStream_t s, int variant);

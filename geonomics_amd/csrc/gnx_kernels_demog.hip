@@ -1381,6 +1381,36 @@ k_compact(int64_t N, int64_t cap, const int32_t* alive, const int32_t* dead_row,
   }
 }
 
+// Which entries of the id-ordered index survive (k_ord_flags; also the tail of k_fill_lists in
+// the device-driven step): entry k names slot ord[k] (or slot k itself behind the index); it
+// stays iff that slot's individual is alive - newslot >= 0 once the compaction has run, or the
+// death draws' own flags before it has.
+struct GnxOrdF {
+  const int32_t* ord;
+  const int32_t* newslot;      // or null: use alive
+  const int32_t* alive;
+  int32_t* cnt;
+  GnxScanOut S;
+};
+__device__ __forceinline__ void gnx_ord_flags_body(int64_t N, int64_t ord_n, const GnxOrdF& F,
+                                                   int* lds, int* lds2) {
+  const int64_t base = (int64_t)blockIdx.x * GNX_CB;
+  bool f[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t k = base + r * 256 + threadIdx.x;
+    if (k < N) {
+      const int64_t slot = k < ord_n ? F.ord[k] : k;
+      f[r] = F.newslot ? F.newslot[slot] >= 0 : (F.alive[slot] & 1) != 0;
+    } else {
+      f[r] = false;
+    }
+  }
+  int rank[4], tot[1];
+  gnx_block_ranks(f, rank, tot[0], lds);
+  gnx_count_and_scan<1>(tot, F.cnt, F.S, lds2);
+}
+
 // In-place compaction (one device, no tiles): the survivors of the tail [S, N) - S = the number
 // of survivors; the tail is mostly this step's offspring - move into the holes the dead left in
 // [0, S); everybody else stays where it is.  About 2 x deaths records move instead of every
@@ -1398,9 +1428,10 @@ k_fill_lists(int64_t N, const int32_t* __restrict__ alive, const int32_t* __rest
              const int32_t* __restrict__ grow, int has_rows, int32_t* __restrict__ holes,
              int32_t* __restrict__ movers, int32_t* __restrict__ rows_tmp,
              int32_t* __restrict__ newslot, int32_t* __restrict__ n_move,
-             const GnxDD* __restrict__ dd) {
+             const GnxDD* __restrict__ dd, GnxOrdF ordf) {
   __shared__ int lds[16];
   __shared__ int sb_s[4];
+  __shared__ int lds2[8];
   N = gnx_dd_nb(dd, N);
   const int64_t S = cnts[0];
   const int64_t base = (int64_t)blockIdx.x * GNX_CB;
@@ -1449,6 +1480,12 @@ k_fill_lists(int64_t N, const int32_t* __restrict__ alive, const int32_t* __rest
       if (i < S) holes[i - k] = (int32_t)i;
     }
     if (has_rows && fd[r]) rows_tmp[od + rd[r]] = grow[i];
+  }
+  // (device-driven step: the index's flags and block counts in the same launch - they only
+  // need the death draws)
+  if (ordf.ord) {
+    __syncthreads();
+    gnx_ord_flags_body(N, dd ? (int64_t)dd->ord_n : N, ordf, lds, lds2);
   }
 }
 
@@ -1576,16 +1613,7 @@ k_ord_flags(int64_t N, int64_t ord_n, const int32_t* __restrict__ ord,
     N = (int64_t)dd->N + dd->B;
     ord_n = dd->ord_n;
   }
-  const int64_t base = (int64_t)blockIdx.x * GNX_CB;
-  bool f[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int64_t k = base + r * 256 + threadIdx.x;
-    f[r] = k < N && newslot[k < ord_n ? ord[k] : k] >= 0;
-  }
-  int rank[4], tot[1];
-  gnx_block_ranks(f, rank, tot[0], lds);
-  gnx_count_and_scan<1>(tot, cnt, S, lds2);
+  gnx_ord_flags_body(N, ord_n, GnxOrdF{ord, newslot, nullptr, cnt, S}, lds, lds2);
 }
 
 __global__ void __launch_bounds__(256)
@@ -1696,7 +1724,7 @@ int gnx_l_mortality_enqueue(gnx_state* h, const uint8_t* d_dead_inject) {
                        h->blk_off, h->blk_stride, h->cnt_dev, a.grow, has_rows,
                        (int32_t*)h->os_ktmp, (int32_t*)h->os_ktmp + c.cap_inds / 2,
                        (int32_t*)h->os_vtmp, ord_keep ? h->newslot : nullptr, h->fill_cnt,
-                       (const GnxDD*)nullptr);
+                       (const GnxDD*)nullptr, GnxOrdF{});
     HIPCHK(hipEventRecord(h->ev_fill, h->stream3));
   }
   // deferred crossover of this step's births: rows and jobs for the survivors, the kernel
@@ -1884,7 +1912,10 @@ int gnx_dd_l_fill_lists(gnx_state* h, int has_rows, hipStream_t st) {
   hipLaunchKernelGGL(k_fill_lists, dim3(nb), dim3(256), 0, st, (int64_t)c.cap_inds, h->flag, h->flag2,
                      h->blk_off, h->blk_stride, h->cnt_dev, h->soa[h->cur].grow, has_rows,
                      (int32_t*)h->os_ktmp, (int32_t*)h->os_ktmp + c.cap_inds / 2,
-                     (int32_t*)h->os_vtmp, h->newslot, h->fill_cnt, (const GnxDD*)h->dd);
+                     (int32_t*)h->os_vtmp, h->newslot, h->fill_cnt, (const GnxDD*)h->dd,
+                     GnxOrdF{h->ord[h->ord_cur], nullptr, h->flag, h->ord_cnt,
+                             GnxScanOut{h->ord_off, nullptr, nullptr, 0, nullptr, h->tickets + 2,
+                                        h->blk_stride}});
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1907,9 +1938,7 @@ int gnx_dd_l_fill(gnx_state* h, int has_rows, bool xo, hipStream_t st) {
 int gnx_dd_l_ord_end(gnx_state* h, int has_rows, bool xo, hipStream_t st) {
   const gnx_config& c = h->cfg;
   const int nb = (int)((c.cap_inds + GNX_CB - 1) / GNX_CB);
-  GnxScanOut So{h->ord_off, nullptr, nullptr, 0, nullptr, h->tickets + 2, h->blk_stride};
-  hipLaunchKernelGGL(k_ord_flags, dim3(nb), dim3(256), 0, st, (int64_t)c.cap_inds, (int64_t)0,
-                     h->ord[h->ord_cur], h->newslot, h->ord_cnt, So, (const GnxDD*)h->dd);
+  // (the flags and block offsets of the index were made by k_fill_lists)
   hipLaunchKernelGGL(k_ord_write, dim3(nb), dim3(256), 0, st, (int64_t)c.cap_inds, (int64_t)0,
                      h->ord[h->ord_cur], h->newslot, h->ord_off, h->ord[h->ord_cur ^ 1],
                      (const GnxDD*)h->dd,

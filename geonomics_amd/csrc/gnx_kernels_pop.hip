@@ -452,7 +452,7 @@ __global__ void k_permute(int64_t N, int64_t cap, const int32_t* perm, GnxSoA a,
                           const int32_t* __restrict__ ord, int64_t ord_n,
                           int32_t* __restrict__ ord_new, int32_t* __restrict__ perm_out,
                           uint4* __restrict__ wipe, int64_t wipe_n, int hot_only,
-                          const GnxDD* __restrict__ dd) {
+                          const GnxDD* __restrict__ dd, GnxBinP bins) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (dd) {
     // device-driven step: the sort ran over the handle's capacity, the entries behind the
@@ -510,6 +510,9 @@ __global__ void k_permute(int64_t N, int64_t cap, const int32_t* perm, GnxSoA a,
   // packed candidate record for the mate search: one 16-byte load per candidate
   cand[i] = make_uint4(__float_as_uint(r.x), __float_as_uint(r.y), tg, (uint32_t)r.id);
   if (!hot_only) gnx_rec_rest(a, j, b, i, cap, n_layers, n_traits, tbw);
+  // (device-driven step at small sizes: the adults' density bins here instead of a launch of
+  // their own - the wave's lanes are neighbours in space: one atomic per distinct bin)
+  if (bins.bins) gnx_bin_add(bins.bins, gnx_bin_of(bins, r.x, r.y), true);
 }
 
 // the columns k_permute(hot_only) left behind: fitness, genome row, environment,
@@ -675,7 +678,7 @@ int gnx_l_sort_by_cell(gnx_state* h, bool split_rest) {
                      h->key64[1], idbits, h->cell_start, h->ncx * h->ncy,
                      ordm ? h->keyk[1] : nullptr, h->ord[h->ord_cur], h->ord_n,
                      h->ord[h->ord_cur ^ 1], h->perm[1], (uint4*)h->os_scratch, (wipe_words + 3) / 4,
-                     split ? 1 : 0, (const GnxDD*)nullptr);
+                     split ? 1 : 0, (const GnxDD*)nullptr, GnxBinP{nullptr, 0.0, 0, 0});
   if (split) {
     // the columns nobody reads before the births follow on stream3, beside the mate search and
     // the pair list; whoever asked for the split waits (gnx_wait_permute_rest).
@@ -1212,7 +1215,7 @@ k_pair_compact(int64_t N, const int32_t* focal, const int32_t* mate, const int32
                int idbits, int32_t* pairs, float* mid_x, float* mid_y, uint64_t* key,
                const int32_t* __restrict__ cnt, int32_t* __restrict__ total_dev,
                int64_t* __restrict__ host, long long seq, const int32_t* __restrict__ extra,
-               GnxDD* __restrict__ dd, int dd_births, int64_t dd_cap) {
+               GnxDD* __restrict__ dd, int dd_births, int64_t dd_cap, GnxBinP bins) {
   __shared__ int lds[16];
   __shared__ int psum[4];
   if (dd) N = dd->N;
@@ -1270,16 +1273,22 @@ k_pair_compact(int64_t N, const int32_t* focal, const int32_t* mate, const int32
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t i = base + r * 256 + threadIdx.x;
-    if (!f[r]) continue;
-    const int p = bo + rank[r];
-    const int m = mate[i];
-    const int fo = focal ? focal[i] : (int)i;
-    pairs[2 * p] = fo;
-    pairs[2 * p + 1] = m;
-    mid_x[p] = (x[fo] + x[m]) / 2.0f;
-    mid_y[p] = (y[fo] + y[m]) / 2.0f;
-    const uint64_t k = popkey[i];
-    key[p] = ((k >> idbits) << 40) | (k & ((1ull << idbits) - 1ull));
+    int bin = 0;
+    if (f[r]) {
+      const int p = bo + rank[r];
+      const int m = mate[i];
+      const int fo = focal ? focal[i] : (int)i;
+      pairs[2 * p] = fo;
+      pairs[2 * p + 1] = m;
+      const float mx = (x[fo] + x[m]) / 2.0f, my = (y[fo] + y[m]) / 2.0f;
+      mid_x[p] = mx;
+      mid_y[p] = my;
+      const uint64_t k = popkey[i];
+      key[p] = ((k >> idbits) << 40) | (k & ((1ull << idbits) - 1ull));
+      if (bins.bins) bin = gnx_bin_of(bins, mx, my);
+    }
+    // (device-driven step at small sizes: the pair midpoints' density bins in the same launch)
+    if (bins.bins) gnx_bin_add(bins.bins, bin, f[r]);
   }
 }
 
@@ -1362,7 +1371,7 @@ int gnx_l_find_pairs_enqueue(gnx_state* h, const uint8_t* d_keep, bool with_dens
                      self_scan ? (const int32_t*)h->blk_cnt : (const int32_t*)nullptr, h->cnt_dev,
                      h->h_pin_dev + 4, (long long)seq,
                      with_top ? (const int32_t*)h->half_top : (const int32_t*)nullptr,
-                     (GnxDD*)nullptr, 0, (int64_t)0);
+                     (GnxDD*)nullptr, 0, (int64_t)0, GnxBinP{nullptr, 0.0, 0, 0});
   gnx_time_end(h, GNX_K_PAIRS, (double)N * 40.0);
   HIPCHK(hipGetLastError());
   // the pair midpoints' density (ops/demography.py:60-91): on one GPU bins + lattice run on
@@ -1807,30 +1816,33 @@ int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* 
 // ---------------------------------------------------------------- device-driven step
 // The launchers of gnx_dd.hip's step: the kernels above with their grids sized by the
 // handle's capacity and their counts read from h->dd on the device; no host state moves.
-int gnx_dd_l_sort(gnx_state* h, hipStream_t st) {
+int gnx_dd_l_sort(gnx_state* h, int32_t* d_bins, hipStream_t st) {
   const gnx_config& c = h->cfg;
   const int64_t n_fixed = c.cap_inds;
   GnxSoA a = h->soa[h->cur], b = h->soa[h->cur ^ 1];
   // stable sort of the id-ordered index by cell alone, over the capacity: entries behind the
   // population carry the largest key (k_keys_hist)
+  static const int geo = getenv("GNX_DD_SORT_GEO") ? atoi(getenv("GNX_DD_SORT_GEO")) : 1;
+  const int geometry = (geo == 1 && n_fixed <= (1 << 21)) ? 1 : 0;
   GNXCHK(gnx_os_keys_hist(h->os_scratch, h->tickets + 3, n_fixed, 0, h->ord[h->ord_cur], h->cell32,
-                          h->keyk[0], h->valk[0], h->key_bits, st, h->dd));
+                          h->keyk[0], h->valk[0], h->key_bits, st, h->dd, geometry));
   GNXCHK(gnx_os_sort32_ranked(h->os_scratch, h->os_ktmp, h->os_vtmp, h->keyk[0], h->keyk[1],
-                              h->valk[0], h->valk[1], (size_t)n_fixed, h->key_bits, st));
-  const int64_t wipe_words = (int64_t)gnx_os_words_used((size_t)n_fixed, h->key_bits);
+                              h->valk[0], h->valk[1], (size_t)n_fixed, h->key_bits, st, geometry));
+  const int64_t wipe_words = (int64_t)gnx_os_words_used((size_t)n_fixed, h->key_bits, geometry);
   hipLaunchKernelGGL(k_permute, dim3(gnx_grid(n_fixed, 256)), dim3(256), 0, st, n_fixed, c.cap_inds,
                      h->valk[1], a, b, c.n_layers, c.n_traits, a.tb ? 2 * h->TW : 0,
                      (unsigned long long)c.seed, h->tag, (uint4*)h->cand, h->key64[1], 40,
                      h->cell_start, h->ncx * h->ncy, h->keyk[1], h->ord[h->ord_cur], (int64_t)0,
                      h->ord[h->ord_cur ^ 1], h->perm[1], (uint4*)h->os_scratch, (wipe_words + 3) / 4,
-                     0, (const GnxDD*)h->dd);
+                     0, (const GnxDD*)h->dd,
+                     GnxBinP{d_bins, 1.0 / h->lat.hww, h->lat.nbx, h->lat.nby});
   HIPCHK(hipGetLastError());
   h->ord_cur ^= 1;
   h->cur ^= 1;
   return 0;
 }
 
-int gnx_dd_l_pairs(gnx_state* h, hipStream_t st) {
+int gnx_dd_l_pairs(gnx_state* h, int32_t* d_bins, hipStream_t st) {
   const gnx_species_params& sp = h->sp;
   const int64_t cap = h->cfg.cap_inds;
   GnxSoA s = h->soa[h->cur];
@@ -1858,7 +1870,8 @@ int gnx_dd_l_pairs(gnx_state* h, hipStream_t st) {
                      h->mate, h->flag2, h->blk_off, s.x, s.y, h->key64[1], 40, h->pairs, h->mid_x,
                      h->mid_y, h->key64[0], (const int32_t*)h->blk_cnt, h->cnt_dev,
                      (int64_t*)nullptr, 0ll, (const int32_t*)nullptr, h->dd,
-                     (int)sp.n_births_lambda, (int64_t)cap);
+                     (int)sp.n_births_lambda, (int64_t)cap,
+                     GnxBinP{d_bins, 1.0 / h->lat.hww, h->lat.nbx, h->lat.nby});
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -311,14 +311,25 @@ static int sort_ranked(void* scratch, uint32_t* ktmp, int32_t* vtmp, const uint3
 }  // namespace gnx_os
 
 // the fused front of the cell sort (variant 2's geometry: 1024 x 6 keys, 10-bit digits)
-size_t gnx_os_words_used(size_t n, int end_bit) {
-  return gnx_os::scratch_words<1024, 6, 10>(n, end_bit);
+size_t gnx_os_words_used(size_t n, int end_bit, int geometry) {
+  return geometry == 1 ? gnx_os::scratch_words<512, 4, 10>(n, end_bit)
+                       : gnx_os::scratch_words<1024, 6, 10>(n, end_bit);
 }
 int gnx_os_keys_hist(void* scratch, unsigned int* ticket, int64_t N, int64_t ord_n,
                      const int32_t* ord, const uint32_t* cell32, uint32_t* key, int32_t* val,
-                     int end_bit, hipStream_t s, const GnxDD* dd) {
+                     int end_bit, hipStream_t s, const GnxDD* dd, int geometry) {
   const int places = (end_bit + 9) / 10;
   if (places > 3) return 1;
+  if (geometry == 1) {
+    // small populations: 2 048 keys per workgroup instead of 6 144 - three times the workgroups
+    // for a sort that is all latency at 10^5 keys (43 workgroups on 256 CUs otherwise)
+    const unsigned int blocks = (unsigned int)((N + 2047) / 2048);
+    hipLaunchKernelGGL((gnx_os::k_keys_hist<10, 2>), dim3(blocks), dim3(1024), 0, s, (long long)N,
+                       (long long)ord_n, ord, cell32, key, val, (unsigned int*)scratch, places, ticket,
+                       (long long)N, (1u << end_bit) - 1u, dd);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   // (2, 3, 4, 8 keys per thread instead of 6: the same step time, profiles/r03_ab_runs.txt)
   // dd: N is the fixed number of entries the sort runs over, the population's own size is read
   // on the device
@@ -331,7 +342,9 @@ int gnx_os_keys_hist(void* scratch, unsigned int* ticket, int64_t N, int64_t ord
 }
 int gnx_os_sort32_ranked(void* scratch, uint32_t* ktmp, int32_t* vtmp, const uint32_t* kin,
                          uint32_t* kout, const int32_t* vin, int32_t* vout, size_t n, int end_bit,
-                         hipStream_t s) {
+                         hipStream_t s, int geometry) {
+  if (geometry == 1)
+    return gnx_os::sort_ranked<512, 4, 10>(scratch, ktmp, vtmp, kin, kout, vin, vout, n, end_bit, s);
   return gnx_os::sort_ranked<1024, 6, 10>(scratch, ktmp, vtmp, kin, kout, vin, vout, n, end_bit, s);
 }
 
@@ -339,7 +352,9 @@ int gnx_os_sort32_ranked(void* scratch, uint32_t* ktmp, int32_t* vtmp, const uin
 size_t gnx_os_scratch_bytes(size_t n, int end_bit) {
   size_t w = std::max({gnx_os::scratch_words<256, 12, 8>(n, end_bit),
                        gnx_os::scratch_words<512, 8, 8>(n, end_bit),
-                       gnx_os::scratch_words<1024, 6, 10>(n, end_bit)});
+                       gnx_os::scratch_words<1024, 6, 10>(n, end_bit),
+                       // (the small geometry: only ever used below GNX_DD_MAX_CAP slots)
+                       gnx_os::scratch_words<512, 4, 10>(std::min<size_t>(n, 1u << 21), end_bit)});
   return w * sizeof(unsigned int);
 }
 
