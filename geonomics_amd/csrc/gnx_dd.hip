@@ -234,10 +234,19 @@ static void dd_consume(gnx_state* h) {
     h->n_pairs = r->P;
     h->fill_guess = deaths;
     h->dd_b_hi = std::max<int64_t>(h->dd_b_hi, r->B);
-    // (blocks only come back through the collector: the stack's height falls by what the step
-    // took)
-    h->dd_use_hi = std::max<int64_t>(h->dd_use_hi, h->dd_half_est - r->half_top);
-    h->dd_half_est = r->half_top;
+    // (blocks only come back through the collector: between two consecutive records with no
+    // collection in between the stack's height falls by what the step took)
+    if (h->dd_top_seq == want - 1 && h->dd_gc_seq != want - 1 && h->dd_top_seq > 0)
+      h->dd_use_hi = std::max<int64_t>(h->dd_use_hi, h->dd_top_last - r->half_top);
+    if (h->dd_gc_seq == want - 1 && h->dd_gc_seq > 0)
+      h->dd_post_gc = r->half_top + h->dd_use_hi;         // the height that collection left
+    h->dd_top_last = r->half_top;
+    h->dd_top_seq = want;
+    // (a step that ran before the last collection tells nothing about the stack behind it)
+    if (want > h->dd_gc_seq) {
+      h->dd_half_est = r->half_top;
+      h->dd_est_seq = want;
+    }
     if (r->err) h->dd_err |= r->err;            // (sticky; looked at by dd_check)
     h->dd_hist.push_back(r->N0);
     h->dd_hist.push_back(r->B);
@@ -323,6 +332,12 @@ static int dd_enter(gnx_state* h) {
   h->dd_seq = h->dd_seen = 0;
   h->dd_b_hi = std::max<int64_t>(h->last_births, h->N / 4);
   h->dd_use_hi = 0;
+  h->dd_gc_seq = 0;
+  h->dd_est_seq = 0;
+  h->dd_top_seq = 0;
+  h->dd_top_last = 0;
+  h->dd_post_gc = 0;
+  h->dd_gc_wait = false;
   h->dd_err = 0;
   h->dd_active = true;
   return 0;
@@ -389,23 +404,37 @@ void gnx_dd_destroy(gnx_state* h) {
   h->dd_ring = nullptr;
 }
 
-// the free-block stack holds what the steps the host has not heard from yet, and the next one,
-// can take at most; else the collector runs (host-driven: the mode is left and entered again)
-static int dd_blocks(gnx_state* h, bool burn) {
-  if (burn || !h->half_top || !h->genomes_assigned || h->cfg.L <= 0) return 0;
+// The free-block stack holds what the next step can take at most; else the collector is
+// enqueued in front of it (gnx_gc: behind the steps enqueued so far, nobody waits for it).
+// The host reasons about the stack's height at the TAIL of its queue: the height the last
+// record reported, less what the steps enqueued since can have taken.
+static int64_t dd_per_step(const gnx_state* h) {
   // what a step takes: every block of every birth's two gametes at most; once steps have been
   // observed, twice the most any of them took (a step takes one block per switch point of its
   // surviving offspring's gametes - a sum of ~10^4 .. 10^5 draws; should a step ever want more
   // than the stack holds, its kernels stay inside the stack and the walk ends with an error)
   const int64_t worst = 2ll * h->NB * (h->dd_b_hi + h->dd_b_hi / 4 + 1024);
-  const int64_t per_step = h->dd_use_hi > 0 ? std::min(worst, 2 * h->dd_use_hi + 4096) : worst;
-  const int64_t pending = h->dd_seq - h->dd_seen + 1;
-  if (h->dd_half_est - pending * per_step >= per_step) return 0;
-  GNXCHK(dd_wait_all_seen(h));
-  if (h->dd_half_est >= 3 * per_step) return 0;
-  GNXCHK(gnx_dd_leave(h));
+  return h->dd_use_hi > 0 ? std::min(worst, 2 * h->dd_use_hi + 4096) : worst;
+}
+
+static int dd_blocks(gnx_state* h, bool burn) {
+  if (burn || !h->half_top || !h->genomes_assigned || h->cfg.L <= 0) return 0;
+  const int64_t per_step = dd_per_step(h);
+  // steps enqueued behind the state dd_half_est describes (a record's, or a collection's)
+  const int64_t since = h->dd_seq - std::max(h->dd_est_seq, h->dd_gc_seq);
+  if (h->dd_half_est - since * per_step >= 2 * per_step) return 0;
   GNXCHK(gnx_gc(h));
-  return dd_enter(h);
+  h->dd_gc_seq = h->dd_seq;
+  if (h->dd_post_gc > 0) {
+    // (the living change slowly: about what the last collection left, less a tenth)
+    h->dd_half_est = h->dd_post_gc - h->dd_post_gc / 10;
+  } else {
+    // the first collection of this walk: the step behind it reports the height before the host
+    // enqueues any further (one wait, once)
+    h->dd_half_est = 1ll << 50;
+    h->dd_gc_wait = true;
+  }
+  return 0;
 }
 
 static int dd_one(gnx_state* h, bool burn, bool sel) {
@@ -416,6 +445,10 @@ static int dd_one(gnx_state* h, bool burn, bool sel) {
   if (h->dd_seq - h->dd_seen > GNX_DD_RING / 4) GNXCHK(dd_wait_all_seen(h));
   GNXCHK(dd_launch_step(h, burn, sel));
   h->dd_seq += 1;
+  if (h->dd_gc_wait) {
+    h->dd_gc_wait = false;
+    GNXCHK(dd_wait_all_seen(h));
+  }
   return 0;
 }
 

@@ -530,6 +530,11 @@ struct gnx_state {
   int64_t dd_half_est = 0;             // free blocks the host can count on (lagged bound)
   int64_t dd_b_hi = 0;                 // largest births per step seen (the collector's bound)
   int64_t dd_use_hi = 0;               // most free blocks a step has taken
+  int64_t dd_gc_seq = 0;               // steps enqueued before the last collection
+  int64_t dd_top_last = 0, dd_top_seq = 0;   // the last record's stack height and step
+  int64_t dd_est_seq = 0;              // the step whose record dd_half_est comes from
+  int64_t dd_post_gc = 0;              // free blocks the last collection left (0: none yet)
+  bool dd_gc_wait = false;             // the next step's record is waited for
   void* dd_graph[1]{};                 // DDExtra (gnx_dd.hip): captured graphs, events
   int32_t dd_err = 0;                  // sticky GNX_DD_ERR_* the steps have reported
   std::vector<int64_t> dd_hist;        // (N at start, births, deaths) of every step of the last gnx_walk

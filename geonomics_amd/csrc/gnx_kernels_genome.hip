@@ -727,7 +727,8 @@ int gnx_l_gather_genomes(gnx_state* h, int64_t n, const int64_t* d_slots, uint64
 // writes blocks of the living and reads blocks that, at worst, go on the stack now and are
 // written again by a later crossover behind it on the same stream.
 __global__ void k_gc_mark(int64_t N, const int32_t* __restrict__ grow, GnxHalves H,
-                          uint8_t* __restrict__ mark) {
+                          uint8_t* __restrict__ mark, const GnxDD* __restrict__ dd) {
+  N = gnx_dd_n(dd, N);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int per = 2 * H.NB;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < N * per; t += stride) {
@@ -790,18 +791,26 @@ int gnx_gc(gnx_state* h) {
   const int per = 2 * h->NB;
   const int64_t n = (int64_t)h->cfg.cap_rows * per;
   const int nb = (int)((n + GNX_CB - 1) / GNX_CB);
-  if (h->N > 0)
+  // device-driven step: between two steps, behind everything enqueued so far; the population's
+  // size is read on the device and nothing is read back (the next step's record carries the
+  // stack's new height)
+  const bool ddm = h->dd_active;
+  if (h->N > 0 || ddm)
     hipLaunchKernelGGL(k_gc_mark, dim3(2048), dim3(256), 0, h->stream, h->N, h->soa[h->cur].grow,
-                       gnx_halves(h), h->half_mark);
+                       gnx_halves(h), h->half_mark, ddm ? (const GnxDD*)h->dd : nullptr);
   hipLaunchKernelGGL(k_gc_count, dim3(nb), dim3(256), 0, h->stream, n, per, h->row_spread,
                      (const uint8_t*)h->half_mark, h->gc_cnt);
   GNXCHK(gnx_block_scan(h, 1, n, h->gc_cnt, h->gc_off, nullptr, nullptr));
   hipLaunchKernelGGL(k_gc_write, dim3(nb), dim3(256), 0, h->stream, n, per, h->row_spread,
                      h->half_mark, (const int32_t*)h->gc_off, nb, h->half_free, h->half_top);
+  h->gc_runs += 1;
+  if (ddm) {
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   int32_t top = 0;
   GNXCHK(gnx_d2h(h, &top, h->half_top, sizeof(top)));
   h->half_free_est = top;
-  h->gc_runs += 1;
   return 0;
 }
 
@@ -855,7 +864,7 @@ extern "C" int gnx_debug_halves(gnx_state* h, int64_t* out) {
   // marks as the collector would set them (its sweep clears them again)
   if (h->N > 0)
     hipLaunchKernelGGL(k_gc_mark, dim3(2048), dim3(256), 0, h->stream, h->N, h->soa[h->cur].grow,
-                       gnx_halves(h), h->half_mark);
+                       gnx_halves(h), h->half_mark, (const GnxDD*)nullptr);
   hipLaunchKernelGGL(k_half_check, dim3(1024), dim3(256), 0, h->stream, h->N, h->soa[h->cur].grow,
                      gnx_halves(h), n_halves, (const uint8_t*)h->half_mark, d);
   unsigned long long host[5];
