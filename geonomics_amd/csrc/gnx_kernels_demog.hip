@@ -1696,8 +1696,12 @@ int gnx_l_mortality_enqueue(gnx_state* h, const uint8_t* d_dead_inject) {
   // builds the crossover's jobs
   // (a caller that names the dead by position - gnx_op_mortality - gets the survivors back in
   // their order: the stable compaction)
-  const bool fill = h->compact_fill && !h->tiled && h->stream3 != nullptr && h->n_ghost == 0 &&
-                    d_dead_inject == nullptr;
+  // (tiles too since round 4: the ghosts are dead to the compaction like anybody the draws took,
+  // and nothing on a tile depends on the survivors' order either - GNX_TILE_FILL=0: the stable
+  // copy there)
+  static const bool tile_fill = !(getenv("GNX_TILE_FILL") && atoi(getenv("GNX_TILE_FILL")) == 0);
+  const bool fill = h->compact_fill && (tile_fill || (!h->tiled && h->n_ghost == 0)) &&
+                    h->stream3 != nullptr && d_dead_inject == nullptr;
   // ... and then the scan of the block counts moves there too: the job builder adds up the
   // counts it needs itself (k_xo_jobs_fused: cnt3), the lists and the host get theirs from
   // stream3, and this stream goes from the death draws straight to the job builder
