@@ -1391,6 +1391,7 @@ struct GnxOrdF {
   const int32_t* alive;
   int32_t* cnt;
   GnxScanOut S;
+  int64_t ord_n;               // entries of the index (host-driven step; the device block's else)
 };
 __device__ __forceinline__ void gnx_ord_flags_body(int64_t N, int64_t ord_n, const GnxOrdF& F,
                                                    int* lds, int* lds2) {
@@ -1485,7 +1486,7 @@ k_fill_lists(int64_t N, const int32_t* __restrict__ alive, const int32_t* __rest
   // need the death draws)
   if (ordf.ord) {
     __syncthreads();
-    gnx_ord_flags_body(N, dd ? (int64_t)dd->ord_n : N, ordf, lds, lds2);
+    gnx_ord_flags_body(N, dd ? (int64_t)dd->ord_n : ordf.ord_n, ordf, lds, lds2);
   }
 }
 
@@ -1613,7 +1614,7 @@ k_ord_flags(int64_t N, int64_t ord_n, const int32_t* __restrict__ ord,
     N = (int64_t)dd->N + dd->B;
     ord_n = dd->ord_n;
   }
-  gnx_ord_flags_body(N, ord_n, GnxOrdF{ord, newslot, nullptr, cnt, S}, lds, lds2);
+  gnx_ord_flags_body(N, ord_n, GnxOrdF{ord, newslot, nullptr, cnt, S, ord_n}, lds, lds2);
 }
 
 __global__ void __launch_bounds__(256)
@@ -1722,13 +1723,23 @@ int gnx_l_mortality_enqueue(gnx_state* h, const uint8_t* d_dead_inject) {
   }
   h->jobs_self_scan = side_scan;
   int has_rows = (h->genomes_assigned && c.L > 0) ? 1 : 0;
+  // GNX_ORD_FUSED=1: the index's flags and block offsets with the compaction's lists (they need
+  // the death draws, not the compaction) - what the device-driven step does; here it lengthens
+  // the lists the compaction and with it the next movement wait for: 0.587 against 0.582 ms/step
+  // (profiles/r04_ab_runs.txt), so k_ord_flags stays a launch of its own beside the crossover
+  static const bool ord_fused_env = getenv("GNX_ORD_FUSED") && atoi(getenv("GNX_ORD_FUSED")) != 0;
+  const bool ord_fused = ord_fused_env && fill && ord_keep;
   if (fill) {
     if (!side_scan) HIPCHK(hipStreamWaitEvent(h->stream3, h->ev_counts, 0));
     hipLaunchKernelGGL(k_fill_lists, dim3(nb), dim3(256), 0, h->stream3, N, h->flag, h->flag2,
                        h->blk_off, h->blk_stride, h->cnt_dev, a.grow, has_rows,
                        (int32_t*)h->os_ktmp, (int32_t*)h->os_ktmp + c.cap_inds / 2,
                        (int32_t*)h->os_vtmp, ord_keep ? h->newslot : nullptr, h->fill_cnt,
-                       (const GnxDD*)nullptr, GnxOrdF{});
+                       (const GnxDD*)nullptr,
+                       ord_fused ? GnxOrdF{h->ord[h->ord_cur], nullptr, h->flag, h->ord_cnt,
+                                           GnxScanOut{h->ord_off, nullptr, nullptr, 0, nullptr,
+                                                      h->tickets + 2, h->blk_stride}, h->ord_n}
+                                 : GnxOrdF{});
     HIPCHK(hipEventRecord(h->ev_fill, h->stream3));
   }
   // deferred crossover of this step's births: rows and jobs for the survivors, the kernel
@@ -1767,8 +1778,9 @@ int gnx_l_mortality_enqueue(gnx_state* h, const uint8_t* d_dead_inject) {
     HIPCHK(hipStreamWaitEvent(h->stream3, h->ev_compact, 0));
     if (h->ord_inflight) h->ord_inflight = false;       // (stream3 runs them in order)
     GnxScanOut So{h->ord_off, nullptr, nullptr, 0, nullptr, h->tickets + 2, h->blk_stride};
-    hipLaunchKernelGGL(k_ord_flags, dim3(nb), dim3(256), 0, h->stream3, N, h->ord_n,
-                       h->ord[h->ord_cur], h->newslot, h->ord_cnt, So, (const GnxDD*)nullptr);
+    if (!ord_fused)
+      hipLaunchKernelGGL(k_ord_flags, dim3(nb), dim3(256), 0, h->stream3, N, h->ord_n,
+                         h->ord[h->ord_cur], h->newslot, h->ord_cnt, So, (const GnxDD*)nullptr);
     hipLaunchKernelGGL(k_ord_write, dim3(nb), dim3(256), 0, h->stream3, N, h->ord_n,
                        h->ord[h->ord_cur], h->newslot, h->ord_off, h->ord[h->ord_cur ^ 1],
                        (const GnxDD*)nullptr, GnxDDEnd{});
@@ -1919,7 +1931,7 @@ int gnx_dd_l_fill_lists(gnx_state* h, int has_rows, hipStream_t st) {
                      (int32_t*)h->os_vtmp, h->newslot, h->fill_cnt, (const GnxDD*)h->dd,
                      GnxOrdF{h->ord[h->ord_cur], nullptr, h->flag, h->ord_cnt,
                              GnxScanOut{h->ord_off, nullptr, nullptr, 0, nullptr, h->tickets + 2,
-                                        h->blk_stride}});
+                                        h->blk_stride}, 0});
   HIPCHK(hipGetLastError());
   return 0;
 }
