@@ -301,12 +301,38 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
   for (int k = 0; k < 2; ++k) GNXCHK(alloc_soa(&h->soa[k], cap, cfg->n_layers, cfg->n_traits));
   GNXCHK(dalloc(&h->rast, (size_t)cfg->n_layers * cfg->W * cfg->H));
   if (cfg->L > 0) {
+    // blocks per homologue: the largest divisor of the 128-byte lines per homologue that is
+    // not above 16 and leaves blocks of at least 2 lines (L = 10^5: 98 lines, 14 blocks of
+    // 896 bytes; L = 10^4: 10 lines, 5 blocks of 256 bytes; GNX_HALF_BLOCKS asks for another one), as long as the block numbers fit 31
+    // bits.  Measured at the metric workload (tools/ab.sh): 7 blocks 0.745 ms/step, 14 blocks
+    // 0.670 - a switch point costs a block half the size, the tables twice the entries.
+    // GNX_BLOCK_LINES=k: blocks of exactly k lines (k = 8: 1 024 bytes, every lane of the
+    // crossover's waves carries a chunk) - the last block reaches past the homologue, the table
+    // is laid out for NB * k lines per homologue (13 x 8 = 104 instead of 98 at L = 10^5)
+    {
+      const int lines = h->W64 / 16;
+      const bool asked = getenv("GNX_HALF_BLOCKS") != nullptr;
+      int want = asked ? atoi(getenv("GNX_HALF_BLOCKS")) : GNX_MAX_NB;
+      want = std::max(1, std::min(want, GNX_MAX_NB));
+      while (want > 1 && (lines % want || (!asked && lines / want < 2) ||
+                          (double)h->cfg.cap_rows * 4 * 2.0 * want >= 2.0e9))
+        --want;
+      h->NB = want;
+      h->BW = h->W64 / want;
+      const int bl = getenv("GNX_BLOCK_LINES") ? atoi(getenv("GNX_BLOCK_LINES")) : 0;
+      if (bl > 0 && (lines + bl - 1) / bl <= GNX_MAX_NB && (lines + bl - 1) / bl >= 1) {
+        h->NB = (lines + bl - 1) / bl;
+        h->BW = 16 * bl;
+      }
+      h->NB_alloc = h->NB;
+      h->BW_alloc = h->BW;
+    }
     // spread the table over up to four times its size when the device has the room
     // (GNX_ROW_SPREAD overrides: 1 = compact).  2x is not enough to be safe: the rate then
     // depends on where the driver happens to place the allocation (4.9 or 5.95 TB/s from one
     // process to the next, profiles/r02_xo_lab_footprint.txt); 3x and 4x are steady.
     {
-      const size_t need = (size_t)h->cfg.cap_rows * 2 * h->W64 * 8;
+      const size_t need = (size_t)h->cfg.cap_rows * 2 * std::max(h->W64, h->NB * h->BW) * 8;
       size_t free_b = 0, total_b = 0;
       (void)hipMemGetInfo(&free_b, &total_b);
       int want = getenv("GNX_ROW_SPREAD") ? atoi(getenv("GNX_ROW_SPREAD")) : 4;
@@ -330,22 +356,6 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
       h->row_spread = want;
     }
     GNXCHK(dalloc(&h->free_rows, (size_t)h->cfg.cap_rows));
-    // blocks per homologue: the largest divisor of the 128-byte lines per homologue that is
-    // not above 16 and leaves blocks of at least 2 lines (L = 10^5: 98 lines, 14 blocks of
-    // 896 bytes; L = 10^4: 10 lines, 5 blocks of 256 bytes; GNX_HALF_BLOCKS asks for another one), as long as the block numbers fit 31
-    // bits.  Measured at the metric workload (tools/ab.sh): 7 blocks 0.745 ms/step, 14 blocks
-    // 0.670 - a switch point costs a block half the size, the tables twice the entries.
-    {
-      const int lines = h->W64 / 16;
-      const bool asked = getenv("GNX_HALF_BLOCKS") != nullptr;
-      int want = asked ? atoi(getenv("GNX_HALF_BLOCKS")) : GNX_MAX_NB;
-      want = std::max(1, std::min(want, GNX_MAX_NB));
-      while (want > 1 && (lines % want || (!asked && lines / want < 2) ||
-                          (double)h->cfg.cap_rows * h->row_spread * 2.0 * want >= 2.0e9))
-        --want;
-      h->NB = want;
-      h->NB_alloc = want;
-    }
     const size_t halves = (size_t)h->cfg.cap_rows * h->row_spread * 2 * h->NB;
     GNXCHK(dalloc(&h->hmap, halves));
     GNXCHK(dalloc(&h->half_mark, halves));
@@ -826,7 +836,10 @@ extern "C" int gnx_set_recomb_paths(gnx_state* h, int32_t n, const uint64_t* pat
   // dense masks switch in every block: nothing can be shared, and whole homologues stream
   // better than 1.8-KB pieces (6.9 against 6.6 TB/s) - one block per homologue then, as long
   // as no genome has been laid out yet
-  if (!h->genomes_assigned) h->NB = h->sparse_paths ? h->NB_alloc : 1;
+  if (!h->genomes_assigned) {
+    h->NB = h->sparse_paths ? h->NB_alloc : 1;
+    h->BW = h->sparse_paths ? h->BW_alloc : h->W64;
+  }
   h->n_paths = n;
   // padding bits beyond L must be zero so children keep zero padding
   std::vector<uint64_t> clean(paths, paths + (size_t)n * W64);

@@ -249,6 +249,9 @@ struct gnx_state {
   int32_t* gc_off = nullptr;
   int NB = 1;                          // blocks per homologue (gnx_half.h), BW = W64 / NB words
   int NB_alloc = 1;                    // what the tables were sized for (NB <= NB_alloc)
+  // words per block.  W64 / NB, or - GNX_BLOCK_LINES - whole 128-byte lines with a last block
+  // that reaches past the homologue (NB * BW > W64: its tail is padding nobody reads)
+  int BW = 0, BW_alloc = 0;
   hipStream_t stream3 = nullptr;       // the compaction of the id-ordered sort index
   hipEvent_t ev_compact = nullptr;
   bool alias_xo = true;          // blocks without a switch point are shared with the parent
@@ -554,7 +557,7 @@ struct gnx_state {
 GnxTraitTab gnx_trait_tab(const gnx_state* h);
 
 static inline GnxHalves gnx_halves(const gnx_state* h) {
-  return GnxHalves{h->hmap, h->half_free, h->half_top, h->NB, h->W64 / h->NB};
+  return GnxHalves{h->hmap, h->half_free, h->half_top, h->NB, h->BW > 0 ? h->BW : h->W64 / h->NB};
 }
 // Before a kernel that pops up to `blocks` physical blocks: the free stack holds that many
 // (a mark-and-sweep collection runs first if the host cannot be sure, gnx_gc).

@@ -50,7 +50,7 @@ void gnx_launch_xo_jobs_surv(gnx_state* h, int64_t first_slot, const int32_t* d_
 template <int U>
 static void xo_launch_sparse(gnx_state* h, hipStream_t st, int grid, int buf, bool nt, int lo,
                              int hi, unsigned long long* acc) {
-  const int W16 = h->W64 / 2 / h->NB;       // chunks per block
+  const int W16 = (h->BW > 0 ? h->BW : h->W64 / h->NB) / 2;       // chunks per block
   static const bool inline_env = !(getenv("GNX_XO_INLINE_BP") && atoi(getenv("GNX_XO_INLINE_BP")) == 0);
   const GnxJobBp* ib = (h->jobs_inline[buf] && inline_env) ? (const GnxJobBp*)h->jobs_bp[buf] : nullptr;
   // two jobs per wave and iteration (gnx_xo.h: k_xo_sparse_pair) when something runs beside
@@ -104,7 +104,7 @@ static int xo_launch(gnx_state* h, hipStream_t st, int buf, int64_t max_jobs, bo
   const int bpc = narrow ? tail_bpc : (bpc_env ? bpc_env : 32);
   // the narrow share of a split launch is accounted for on its own
   unsigned long long* acc = h->xo_jobs_acc ? h->xo_jobs_acc + ((narrow && lo > 0) ? 1 : 0) : nullptr;
-  const int W16 = h->W64 / 2 / h->NB;       // chunks per block
+  const int W16 = (h->BW > 0 ? h->BW : h->W64 / h->NB) / 2;       // chunks per block
   const int grid = gnx_grid(max_jobs * h->NB, 4, 256 * bpc);
   if (h->sparse_paths) {
     // (blocks shorter than a homologue: as many loads in flight as the block has chunks)
@@ -882,7 +882,7 @@ extern "C" int gnx_debug_halves(gnx_state* h, int64_t* out) {
 
 extern "C" int gnx_genome_info(gnx_state* h, int64_t* out) {
   out[0] = h->NB;
-  out[1] = h->NB > 0 ? h->W64 / h->NB : 0;
+  out[1] = h->BW > 0 ? h->BW : (h->NB > 0 ? h->W64 / h->NB : 0);
   out[2] = h->gc_runs;
   out[3] = h->row_spread;
   out[4] = h->sparse_paths ? 1 : 0;
