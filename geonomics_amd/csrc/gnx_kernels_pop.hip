@@ -209,10 +209,13 @@ __device__ __forceinline__ float surf_direction(const float* rast, int W, int H,
 // outside the landscape = the reference's zero-embedding) and every lane reads
 // its 8 neighbours from LDS.  A block whose box does not fit (e.g. the unsorted
 // tail of newborns) falls back to global gathers.  Returns false on fallback.
+// IPT individuals per thread (act / cx / cy / n per individual).
 #define SURF_TILE_FLOATS 8192
-__device__ __forceinline__ bool surf_neighbours_lds(const float* rast, int W, int H, bool act,
-                                                    int cx, int cy, float* tile, int tile_floats,
-                                                    int* box, float n[8]) {
+template <int IPT>
+__device__ __forceinline__ bool surf_neighbours_lds(const float* rast, int W, int H,
+                                                    const bool act[IPT], const int cx[IPT],
+                                                    const int cy[IPT], float* tile, int tile_floats,
+                                                    int* box, float n[IPT][8]) {
   // box = {xmin, xmax, ymin, ymax} in LDS
   if (threadIdx.x == 0) {
     box[0] = 0x7fffffff;
@@ -224,7 +227,15 @@ __device__ __forceinline__ bool surf_neighbours_lds(const float* rast, int W, in
   {
     // the wave's own bounding box by shuffles, then ONE lane per wave touches the LDS words
     // (256 lanes on four LDS words serialise: that, not the tile, was the surface's cost)
-    int lx = act ? cx : 0x7fffffff, hx = act ? cx : -1, ly = act ? cy : 0x7fffffff, hy = act ? cy : -1;
+    int lx = 0x7fffffff, hx = -1, ly = 0x7fffffff, hy = -1;
+#pragma unroll
+    for (int u = 0; u < IPT; ++u)
+      if (act[u]) {
+        lx = min(lx, cx[u]);
+        hx = max(hx, cx[u]);
+        ly = min(ly, cy[u]);
+        hy = max(hy, cy[u]);
+      }
     lx = wave_min_i(lx);
     hx = wave_max_i(hx);
     ly = wave_min_i(ly);
@@ -255,85 +266,132 @@ __device__ __forceinline__ bool surf_neighbours_lds(const float* rast, int W, in
     }
   }
   __syncthreads();
-  if (act) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-      n[k] = tile[(cy + c_queen_dy[k] - y0) * bw + (cx + c_queen_dx[k] - x0)];
-  }
+  for (int u = 0; u < IPT; ++u)
+    if (act[u]) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        n[u][k] = tile[(cy[u] + c_queen_dy[k] - y0) * bw + (cx[u] + c_queen_dx[k] - x0)];
+    }
   return true;
 }
 
 // ops/movement.py:34-95 + Species._set_e (structs/species.py:913-922).
 // Optionally increments age first (Species._set_age_stage, :567-569).
+// IPT individuals per thread, interleaved (thread t of a workgroup takes the workgroup's
+// individuals t, t + 256, ...: every access stays coalesced): with two, a wave has twice the
+// loads in flight at every step of its chain of dependent round trips - beside the crossover
+// (the step's normal state) the kernel is bound by those round trips.
+template <int IPT>
 __global__ void __launch_bounds__(256)
 k_move(MoveP P, GnxSoA s, const float* rast, const float* inj_theta, const float* inj_dist,
        float* out_theta, float* out_dist) {
   extern __shared__ float surf_tile[];       // P.tile_floats floats
   __shared__ int surf_box[4];
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   P.N = gnx_dd_n(P.dd, P.N);
   P.step = gnx_dd_step(P.dd, P.step);
-  const bool act = i < P.N;
+  const int64_t base = (int64_t)blockIdx.x * (256 * IPT) + threadIdx.x;
+  int64_t i[IPT];
+  bool act[IPT];
   // every load that does not depend on the draw goes out with the position: beside the
   // crossover a memory round trip costs several microseconds, and id and age each had one of
   // their own further down the thread's chain
-  float x = 0.f, y = 0.f;
-  unsigned long long id = 0ull;
-  int32_t age0 = 0;
-  if (act) {
-    x = s.x[i];
-    y = s.y[i];
-    id = (unsigned long long)s.id[i];
-    if (P.apply && P.inc_age) age0 = s.age[i];
+  float x[IPT], y[IPT];
+  unsigned long long id[IPT];
+  int32_t age0[IPT];
+  int cx[IPT], cy[IPT];
+#pragma unroll
+  for (int u = 0; u < IPT; ++u) {
+    i[u] = base + u * 256;
+    act[u] = i[u] < P.N;
+    x[u] = y[u] = 0.f;
+    id[u] = 0ull;
+    age0[u] = 0;
+    if (act[u]) {
+      x[u] = s.x[i[u]];
+      y[u] = s.y[i[u]];
+      id[u] = (unsigned long long)s.id[i[u]];
+      if (P.apply && P.inc_age) age0[u] = s.age[i[u]];
+    }
   }
-  float nb[8];
-  bool have_nb = false;
+#pragma unroll
+  for (int u = 0; u < IPT; ++u) {
+    cx[u] = (int)x[u];
+    cy[u] = (int)y[u];
+  }
+  float nb[IPT][8];
   if (P.surf != GNX_SURF_NONE && !inj_theta) {     // block-uniform condition
     const float* cond = rast + (int64_t)P.surf_layer * P.H * P.W;
-    have_nb = surf_neighbours_lds(cond, P.W, P.H, act, (int)x, (int)y, surf_tile, P.tile_floats,
-                                  surf_box, nb);
-    if (!have_nb && act) surf_neighbours(cond, P.W, P.H, (int)x, (int)y, nb);
-  }
-  if (!act) return;
-  float theta, dist;
-  if (inj_theta) {
-    theta = inj_theta[i];
-    dist = inj_dist[i];
-  } else {
-    if (P.surf != GNX_SURF_NONE) {
-      GnxStream st(P.seed, id, P.step, OP_MOVE_SURF);
-      theta = surf_sample(nb, P.surf, P.surf_kappa, st);
-    } else {
-      GnxStream st(P.seed, id, P.step, OP_MOVE_DIR);
-      theta = gnx_vonmises(st, P.mu, P.kappa);
+    const bool have_nb = surf_neighbours_lds<IPT>(cond, P.W, P.H, act, cx, cy, surf_tile,
+                                                  P.tile_floats, surf_box, nb);
+    if (!have_nb) {
+#pragma unroll
+      for (int u = 0; u < IPT; ++u)
+        if (act[u]) surf_neighbours(cond, P.W, P.H, cx[u], cy[u], nb[u]);
     }
-    dist = gnx_distance(P.distr, P.p1, P.p2, gnx_rand4(P.seed, id, P.step, OP_MOVE_DIST, 0));
   }
-  if (out_theta) {
-    out_theta[i] = theta;
-    out_dist[i] = dist;
+  float nx[IPT], ny[IPT];
+#pragma unroll
+  for (int u = 0; u < IPT; ++u) {
+    nx[u] = ny[u] = 0.f;
+    if (!act[u]) continue;
+    float theta, dist;
+    if (inj_theta) {
+      theta = inj_theta[i[u]];
+      dist = inj_dist[i[u]];
+    } else {
+      if (P.surf != GNX_SURF_NONE) {
+        GnxStream st(P.seed, id[u], P.step, OP_MOVE_SURF);
+        theta = surf_sample(nb[u], P.surf, P.surf_kappa, st);
+      } else {
+        GnxStream st(P.seed, id[u], P.step, OP_MOVE_DIR);
+        theta = gnx_vonmises(st, P.mu, P.kappa);
+      }
+      dist = gnx_distance(P.distr, P.p1, P.p2, gnx_rand4(P.seed, id[u], P.step, OP_MOVE_DIST, 0));
+    }
+    if (out_theta) {
+      out_theta[i[u]] = theta;
+      out_dist[i[u]] = dist;
+    }
+    float dx = cosf(theta) * dist;
+    float dy = sinf(theta) * dist;
+    if (P.rrx != 1.0f) dx *= P.rrx;
+    if (P.rry != 1.0f) dy *= P.rry;
+    nx[u] = fminf(fmaxf(x[u] + dx, 0.0f), P.xmax);
+    ny[u] = fminf(fmaxf(y[u] + dy, 0.0f), P.ymax);
   }
   if (!P.apply) return;
-  float dx = cosf(theta) * dist;
-  float dy = sinf(theta) * dist;
-  if (P.rrx != 1.0f) dx *= P.rrx;
-  if (P.rry != 1.0f) dy *= P.rry;
-  float nx = fminf(fmaxf(x + dx, 0.0f), P.xmax);
-  float ny = fminf(fmaxf(y + dy, 0.0f), P.ymax);
-  s.x[i] = nx;
-  s.y[i] = ny;
-  if (P.inc_age) s.age[i] = age0 + 1;
-  int cx = (int)nx, cy = (int)ny;
-  for (int l = 0; l < P.n_layers; ++l)
-    s.e[(int64_t)l * P.cap + i] = rast[((int64_t)l * P.H + cy) * P.W + cx];
-  if (P.key || P.cell32) {
-    const int hx = min(P.ncx - 1, (int)((double)nx * P.inv_cs));
-    const int hy = min(P.ncy - 1, (int)((double)ny * P.inv_cs));
-    if (P.cell32) {               // the sort runs over the id-ordered index: the cell is all it needs
-      P.cell32[i] = (uint32_t)(hy * P.ncx + hx);
-    } else {
-      P.key[i] = ((uint64_t)(hy * P.ncx + hx) << P.idbits) | (uint64_t)id;
-      P.idx[i] = (int32_t)i;
+  // the environment at the new cells: all gathers of the thread before its first store
+  float e[IPT][4];
+#pragma unroll
+  for (int u = 0; u < IPT; ++u) {
+    const int ncx = (int)nx[u], ncy = (int)ny[u];
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+      e[u][l] = (act[u] && l < P.n_layers) ? rast[((int64_t)l * P.H + ncy) * P.W + ncx] : 0.f;
+  }
+#pragma unroll
+  for (int u = 0; u < IPT; ++u) {
+    if (!act[u]) continue;
+    const int64_t k = i[u];
+    s.x[k] = nx[u];
+    s.y[k] = ny[u];
+    if (P.inc_age) s.age[k] = age0[u] + 1;
+    const int ncx = (int)nx[u], ncy = (int)ny[u];
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+      if (l < P.n_layers) s.e[(int64_t)l * P.cap + k] = e[u][l];
+    for (int l = 4; l < P.n_layers; ++l)
+      s.e[(int64_t)l * P.cap + k] = rast[((int64_t)l * P.H + ncy) * P.W + ncx];
+    if (P.key || P.cell32) {
+      const int hx = min(P.ncx - 1, (int)((double)nx[u] * P.inv_cs));
+      const int hy = min(P.ncy - 1, (int)((double)ny[u] * P.inv_cs));
+      if (P.cell32) {               // the sort runs over the id-ordered index: the cell is all it needs
+        P.cell32[k] = (uint32_t)(hy * P.ncx + hx);
+      } else {
+        P.key[k] = ((uint64_t)(hy * P.ncx + hx) << P.idbits) | (uint64_t)id[u];
+        P.idx[k] = (int32_t)k;
+      }
     }
   }
 }
@@ -388,11 +446,22 @@ int gnx_l_move(gnx_state* h, bool inc_age, const float* inj_theta, const float* 
   // windows let more workgroups share a CU while the kernel crawls beside the crossover
   // (2048 floats by default: 0.795 against 0.805-0.84 ms/step with 8192, no further gain below)
   static const int tile_env = getenv("GNX_MOVE_TILE") ? atoi(getenv("GNX_MOVE_TILE")) : 2048;
-  P.tile_floats = sp.move_surf != GNX_SURF_NONE ? std::max(256, std::min(tile_env, 12288)) : 0;
+  // (per 256 individuals of the workgroup: two per thread cover twice the stretch of cells)
+  static const int ipt_env = getenv("GNX_MOVE_IPT") ? atoi(getenv("GNX_MOVE_IPT")) : 2;
+  P.tile_floats = sp.move_surf != GNX_SURF_NONE
+                      ? std::max(256, std::min(tile_env * (ipt_env == 2 ? 2 : 1), 12288)) : 0;
   gnx_time_begin(h);
-  hipLaunchKernelGGL(k_move, dim3(gnx_grid(ddm ? (int64_t)c.cap_inds : h->N, 256)), dim3(256),
-                     (size_t)P.tile_floats * sizeof(float), h->stream, P,
-                     h->soa[h->cur], h->rast, inj_theta, inj_dist, out_theta, out_dist);
+  // individuals per thread (GNX_MOVE_IPT; 2 by default: profiles/r04_ab_runs.txt)
+  static const int ipt = getenv("GNX_MOVE_IPT") ? atoi(getenv("GNX_MOVE_IPT")) : 2;
+  const int64_t n_grid = ddm ? (int64_t)c.cap_inds : h->N;
+  if (ipt == 2)
+    hipLaunchKernelGGL(k_move<2>, dim3(gnx_grid(n_grid, 512)), dim3(256),
+                       (size_t)P.tile_floats * sizeof(float), h->stream, P,
+                       h->soa[h->cur], h->rast, inj_theta, inj_dist, out_theta, out_dist);
+  else
+    hipLaunchKernelGGL(k_move<1>, dim3(gnx_grid(n_grid, 256)), dim3(256),
+                       (size_t)P.tile_floats * sizeof(float), h->stream, P,
+                       h->soa[h->cur], h->rast, inj_theta, inj_dist, out_theta, out_dist);
   // per individual: x,y rw 16 + id 8 + age rw 8 + e store 4*n_lyr + raster gathers 4*n_lyr
   // (+36 for the 3x3 conductance neighbourhood)
   gnx_time_end(h, GNX_K_MOVE,
