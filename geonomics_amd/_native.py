@@ -51,7 +51,7 @@ EXPORTS = [
     'gnx_walk', 'gnx_walk_many', 'gnx_walk_history',
     'gnx_comm_unique_id', 'gnx_comm_init_rccl', 'gnx_comm_init_single', 'gnx_comm_local_create',
     'gnx_comm_local_join', 'gnx_comm_local_abort', 'gnx_comm_local_destroy', 'gnx_comm_free',
-    'gnx_comm_bytes_sent', 'gnx_tile_step',
+    'gnx_comm_bytes_sent', 'gnx_tile_step', 'gnx_set_id_order',
     'gnx_stream_ptr', 'gnx_tile2_move_route', 'gnx_tile2_route_ptrs', 'gnx_tile2_import',
     'gnx_tile2_pairs', 'gnx_tile2_offspring', 'gnx_tile2_serve', 'gnx_tile2_put',
     'gnx_tile2_finish_births', 'gnx_tile2_die', 'gnx_tile_pair_ptrs_nosync',
@@ -326,6 +326,10 @@ class Device:
 
     def comm_local_join(self, group, rank):
         self._chk(self.lib.gnx_comm_local_join(self.h, group, int(rank)))
+
+    def set_id_order(self, mode):
+        """0: offspring ids in (hash cell, focal id) order (default); 1: virtual-tile-major"""
+        self._chk(self.lib.gnx_set_id_order(self.h, int(mode)))
 
     def comm_free(self):
         self._chk(self.lib.gnx_comm_free(self.h))

@@ -488,6 +488,11 @@ extern "C" void gnx_destroy(gnx_state* h) {
   (void)hipStreamSynchronize(h->stream);
   gnx_dd_destroy(h);
   (void)gnx_comm_free(h);
+  {
+    void* vt[] = {h->vt_cls, h->vt_rank, h->vt_blk_cnt, h->vt_blk_off, h->vt_count, h->vt_base};
+    for (void* q : vt)
+      if (q) (void)hipFree(q);
+  }
   if (h->stream2) (void)hipStreamSynchronize(h->stream2);
   if (h->stream3) (void)hipStreamSynchronize(h->stream3);    // reads ord / newslot
   for (int k = 0; k < 2; ++k) {
@@ -1078,6 +1083,10 @@ extern "C" int gnx_pop_dynamics_mate(gnx_state* h, int32_t burn) {
   GNXCHK(rc_pairs);
   if (P > 0 && !h->spl_P.valid)
     GNXCHK(gnx_l_density(h, P, h->mid_x, h->mid_y, &h->spl_P, nullptr));
+  if (h->id_order == 1 && P > 0) {
+    GNXCHK(gnx_l_pair_cls(h, P, true));
+    GNXCHK(gnx_l_pair_goff_vt(h, P));
+  }
   // 3. births: dispersal, crossover, phenotype
   GNXCHK(gnx_l_mate(h, burn != 0, false, 0, &B));
   h->last_births = B;
@@ -1155,6 +1164,11 @@ extern "C" int gnx_step_mid(gnx_state* h, int32_t burn, int32_t with_selection) 
   GNXCHK(gnx_l_find_pairs_finish(h, &P));
   if (P > 0 && !h->spl_P.valid)
     GNXCHK(gnx_l_density(h, P, h->mid_x, h->mid_y, &h->spl_P, nullptr));
+  // (tile-major offspring ids, gnx_set_id_order: the pairs' offsets from this device's own counts)
+  if (h->id_order == 1 && P > 0) {
+    GNXCHK(gnx_l_pair_cls(h, P, true));
+    GNXCHK(gnx_l_pair_goff_vt(h, P));
+  }
   // births: dispersal, alleles at the selected loci, phenotype
   GNXCHK(gnx_l_mate(h, burn != 0, false, 0, &B));
   h->last_births = B;
@@ -1190,6 +1204,23 @@ extern "C" int gnx_step_many(gnx_state** hs, int32_t n, int32_t burn, int32_t wi
   for (int k = 0; k < n; ++k) GNXCHK(gnx_step_begin(hs[k], burn));
   for (int k = 0; k < n; ++k) GNXCHK(gnx_step_mid(hs[k], burn, with_selection));
   for (int k = 0; k < n; ++k) GNXCHK(gnx_step_end(hs[k], burn));
+  return 0;
+}
+
+// 0: offspring ids in the canonical (hash cell, focal id) order of the pairs over the whole
+// landscape (default); 1: virtual tile by virtual tile (gnx_kernels_pop.hip) - what
+// gnx_tile_step uses, and what a one-device run must use to reproduce a tiled run id by id
+extern "C" int gnx_set_id_order(gnx_state* h, int32_t mode) {
+  if (mode != 0 && mode != 1) {
+    gnx_set_error("gnx_set_id_order: 0 (hash cell, focal id) or 1 (virtual-tile-major)");
+    return 1;
+  }
+  if (mode == 1 && (h->cfg.W % 8 || h->cfg.H % 8)) {
+    gnx_set_error("tile-major offspring ids need landscape dimensions divisible by 8");
+    return 1;
+  }
+  h->id_order = mode;
+  h->cfg_epoch += 1;
   return 0;
 }
 

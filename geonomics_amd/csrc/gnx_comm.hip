@@ -161,45 +161,37 @@ __global__ void k_sum_i32(int n, int world, const int32_t* __restrict__ all, int
   out[k] = s;
 }
 
-// global offspring offset of every local pair: pairs are numbered in the order of their keys
-// (hash cell << 40 | focal id, ascending on every tile) over ALL tiles; the offset of a pair
-// is the births of all pairs with a smaller key = sum over tiles of (its rank in that tile's
-// key list) x (births per pair)
-__global__ void k_pair_goff(int64_t P, const int64_t* __restrict__ mine, int world,
-                            const int64_t* __restrict__ all, int64_t stride,
-                            const int64_t* __restrict__ counts, int64_t counts_stride, int64_t lam,
-                            int64_t* __restrict__ goff) {
-  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P) return;
-  const int64_t key = mine[p];
-  int64_t acc = 0;
-  for (int r = 0; r < world; ++r) {
-    const int64_t* li = all + (int64_t)r * stride;
-    int64_t lo = 0, hi = counts[(int64_t)r * counts_stride];
-    while (lo < hi) {
-      const int64_t mid = (lo + hi) >> 1;
-      if (li[mid] < key) lo = mid + 1;
-      else hi = mid;
-    }
-    acc += lo;
-  }
-  goff[p] = acc * lam;
+__global__ void k_widen_i32(int n, const int32_t* __restrict__ src, int64_t* __restrict__ dst) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) dst[k] = src[k];
 }
 
 // every rank's vector of n int64 words -> out[world][n] on the host; the gathered words stay in
-// device memory too (rbuf[RB_VEC_RECV]).  RCCL: one KB-sized all-gather on the handle's stream
-// and one wait for it; the words travel to and from the host through pinned memory.
-int host_allgather(gnx_state* h, const int64_t* vec, int n, int64_t* out) {
+// device memory too (rbuf[RB_VEC_RECV]).  The last n_tail words of the vector come from DEVICE
+// memory (int32 `tail`: counts a kernel has just left there), the others from the host.
+// RCCL: one KB-sized all-gather on the handle's stream and one wait for it; the words travel
+// to and from the host through pinned memory.
+int host_allgather(gnx_state* h, const int64_t* vec, int n, int64_t* out,
+                   const int32_t* tail = nullptr, int n_tail = 0) {
   Comm* c = comm_of(h);
   const int w = c->world;
-  if (w == 1) {
-    for (int k = 0; k < n; ++k) out[k] = vec[k];
-    return 0;
-  }
-  GNXCHK(rb_need(c, RB_VEC_RECV, (size_t)w * n * 8));
-  if (c->kind == COMM_LOCAL) {
+  const int n_host = n - n_tail;
+  if (w == 1 || c->kind == COMM_LOCAL) {
+    std::vector<int64_t> mine(vec, vec + n_host);
+    mine.resize(n, 0);
+    if (n_tail > 0) {
+      std::vector<int32_t> t32(n_tail);
+      HIPCHK(hipMemcpyAsync(t32.data(), tail, (size_t)n_tail * 4, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      for (int k = 0; k < n_tail; ++k) mine[n_host + k] = t32[k];
+    }
+    if (w == 1) {
+      for (int k = 0; k < n; ++k) out[k] = mine[k];
+      return 0;
+    }
+    GNXCHK(rb_need(c, RB_VEC_RECV, (size_t)w * n * 8));
     LocalGroup* g = c->grp;
-    g->vec[c->rank].assign(vec, vec + n);
+    g->vec[c->rank] = mine;
     if (g->barrier()) {
       gnx_set_error("local tile group: a rank failed or never arrived");
       return 1;
@@ -212,10 +204,15 @@ int host_allgather(gnx_state* h, const int64_t* vec, int n, int64_t* out) {
     HIPCHK(hipStreamSynchronize(h->stream));          // (`out` is the caller's)
     return 0;
   }
+  GNXCHK(rb_need(c, RB_VEC_RECV, (size_t)w * n * 8));
   GNXCHK(rb_need(c, RB_VEC_SEND, (size_t)n * 8));
-  for (int k = 0; k < n; ++k) c->pin[k] = vec[k];
-  hipLaunchKernelGGL(k_copy_i64, dim3((n + 63) / 64), dim3(64), 0, h->stream, n,
-                     (const int64_t*)c->pin_dev, (int64_t*)c->rbuf[RB_VEC_SEND]);
+  for (int k = 0; k < n_host; ++k) c->pin[k] = vec[k];
+  if (n_host > 0)
+    hipLaunchKernelGGL(k_copy_i64, dim3((n_host + 63) / 64), dim3(64), 0, h->stream, n_host,
+                       (const int64_t*)c->pin_dev, (int64_t*)c->rbuf[RB_VEC_SEND]);
+  if (n_tail > 0)
+    hipLaunchKernelGGL(k_widen_i32, dim3((n_tail + 63) / 64), dim3(64), 0, h->stream, n_tail, tail,
+                       (int64_t*)c->rbuf[RB_VEC_SEND] + n_host);
   NCCLCHK(g_rccl.AllGather(c->rbuf[RB_VEC_SEND], c->rbuf[RB_VEC_RECV], (size_t)n, ncclInt64,
                            c->nccl, h->stream));
   hipLaunchKernelGGL(k_copy_i64, dim3((w * n + 63) / 64), dim3(64), 0, h->stream, w * n,
@@ -292,43 +289,6 @@ int exchange(gnx_state* h, const Part* parts, int n_parts, const int64_t* mat) {
     roff += n_from;
   }
   NCCLCHK(g_rccl.GroupEnd());
-  return 0;
-}
-
-// every rank's int64 device array (lengths counts[r * cs], known everywhere) -> rbuf[RB_KEYS]
-// [world][stride]; returns the stride
-int allgather_keys(gnx_state* h, const int64_t* mine, const int64_t* counts, int cs, int64_t* stride_out) {
-  Comm* c = comm_of(h);
-  const int w = c->world, me = c->rank;
-  int64_t m = 1;
-  for (int r = 0; r < w; ++r) m = std::max(m, counts[(int64_t)r * cs]);
-  *stride_out = m;
-  GNXCHK(rb_need(c, RB_KEYS, (size_t)w * m * 8));
-  const int64_t P = counts[(int64_t)me * cs];
-  if (c->kind == COMM_LOCAL) {
-    LocalGroup* g = c->grp;
-    HIPCHK(hipStreamSynchronize(h->stream));
-    g->ptr[me].assign(1, mine);
-    if (g->barrier()) {
-      gnx_set_error("local tile group: a rank failed or never arrived");
-      return 1;
-    }
-    for (int r = 0; r < w; ++r) {
-      const int64_t n = counts[(int64_t)r * cs];
-      if (n > 0)
-        HIPCHK(hipMemcpyAsync((int64_t*)c->rbuf[RB_KEYS] + (int64_t)r * m, g->ptr[r][0], (size_t)n * 8,
-                              hipMemcpyDeviceToDevice, h->stream));
-    }
-    HIPCHK(hipStreamSynchronize(h->stream));
-    if (g->barrier()) return 1;
-    return 0;
-  }
-  // equal counts for the collective: this rank's keys in a buffer of the common stride
-  GNXCHK(rb_need(c, RB_PAD, (size_t)m * 8));
-  if (P > 0)
-    HIPCHK(hipMemcpyAsync(c->rbuf[RB_PAD], mine, (size_t)P * 8, hipMemcpyDeviceToDevice, h->stream));
-  NCCLCHK(g_rccl.AllGather(c->rbuf[RB_PAD], c->rbuf[RB_KEYS], (size_t)m, ncclInt64, c->nccl, h->stream));
-  c->bytes_sent += m * 8;
   return 0;
 }
 
@@ -479,7 +439,7 @@ extern "C" int gnx_tile_step(gnx_state* h, int32_t burn, int32_t with_selection,
     gnx_set_error("species parameters not set");
     return 1;
   }
-  if (!h->sp.n_births_fixed && c->world > 1) {
+  if (!h->sp.n_births_fixed) {
     gnx_set_error("gnx_tile_step: Poisson births travel with the pair keys through the host layer "
                   "(TiledStepper, GNX_TILE_V3=0)");
     return 3;
@@ -488,6 +448,12 @@ extern "C" int gnx_tile_step(gnx_state* h, int32_t burn, int32_t with_selection,
   if (T != w) {
     gnx_set_error("gnx_tile_step: %d tiles but %d ranks", T, w);
     return 1;
+  }
+  if (h->cfg.W % 8 || h->cfg.H % 8 || 8 % h->tile_R || 8 % h->tile_C) {
+    gnx_set_error("gnx_tile_step: tile-major offspring ids need landscape dimensions divisible by 8 "
+                  "and a tile grid that divides 8 x 8 (got %d x %d tiles of a %d x %d landscape)",
+                  h->tile_R, h->tile_C, h->cfg.W, h->cfg.H);
+    return 3;
   }
   const int nt = h->cfg.n_traits, W64 = h->W64;
   const bool geno = h->genomes_assigned && h->cfg.L > 0;
@@ -525,32 +491,37 @@ extern "C" int gnx_tile_step(gnx_state* h, int32_t burn, int32_t with_selection,
   GNXCHK(gnx_tile2_pairs(h, burn, pc.data()));
   const int64_t P = pc[0], B = pc[1];
   int64_t total_births = B, total_pairs = P;
-  const void* goff = nullptr;
   std::vector<int64_t> m_req((size_t)w * w, 0);
+  // Offspring ids are handed out virtual tile by virtual tile (gnx_set_id_order 1,
+  // gnx_kernels_pop.hip): a tile owns whole virtual tiles, the rank of a pair inside its virtual
+  // tile is a local matter, and the 64 birth counts per virtual tile ride on the count exchange -
+  // round 3 all-gathered every pair's order key for this (1.8 MB per rank at C5)
+  GNXCHK(gnx_l_pair_cls(h, P, w == 1));
   if (w > 1) {
-    const int cs = 2 + T;
-    GNXCHK(host_allgather(h, pc.data(), cs, mats.data()));
+    const int cs = 2 + T + 64;
+    std::vector<int64_t> g2((size_t)w * cs);
+    GNXCHK(host_allgather(h, pc.data(), cs, g2.data(), (const int32_t*)h->vt_count, 64));
     total_births = total_pairs = 0;
+    std::vector<int64_t> vt(64, 0);
     for (int r = 0; r < w; ++r) {
-      total_pairs += mats[(size_t)r * cs];
-      total_births += mats[(size_t)r * cs + 1];
-      for (int d = 0; d < w; ++d) m_req[(size_t)r * w + d] = mats[(size_t)r * cs + 2 + d];
+      total_pairs += g2[(size_t)r * cs];
+      total_births += g2[(size_t)r * cs + 1];
+      for (int d = 0; d < w; ++d) m_req[(size_t)r * w + d] = g2[(size_t)r * cs + 2 + d];
+      for (int q = 0; q < 64; ++q) vt[q] += g2[(size_t)r * cs + 2 + T + q];
     }
-    int64_t P_, stride = 1;
-    void *p_ids, *p_nb;
-    GNXCHK(gnx_tile_pair_ptrs_nosync(h, &P_, &p_ids, &p_nb));
-    GNXCHK(allgather_keys(h, (const int64_t*)p_ids, mats.data(), cs, &stride));
-    if (P > 0) {
-      GNXCHK(rb_need(c, RB_GOFF, (size_t)P * 8));
-      // (the gathered counts are in device memory as well: host_allgather left them there)
-      hipLaunchKernelGGL(k_pair_goff, dim3(gnx_grid(P, 256)), dim3(256), 0, h->stream, P,
-                         (const int64_t*)p_ids, w, (const int64_t*)c->rbuf[RB_KEYS], stride,
-                         (const int64_t*)c->rbuf[RB_VEC_RECV], (int64_t)cs,
-                         (int64_t)h->sp.n_births_lambda, (int64_t*)c->rbuf[RB_GOFF]);
-      HIPCHK(hipGetLastError());
-      goff = c->rbuf[RB_GOFF];
+    // the virtual tiles' base offsets, in births: an exclusive scan of 64 numbers, the same on
+    // every rank; to the device through pinned memory
+    int64_t run = 0;
+    for (int q = 0; q < 64; ++q) {
+      c->pin[q] = run * (int64_t)h->sp.n_births_lambda;
+      run += vt[q];
     }
+    hipLaunchKernelGGL(k_copy_i64, dim3(1), dim3(64), 0, h->stream, 64, (const int64_t*)c->pin_dev,
+                       h->vt_base);
+    HIPCHK(hipGetLastError());
   }
+  GNXCHK(gnx_l_pair_goff_vt(h, P));
+  const void* goff = P > 0 ? (const void*)h->pair_goff : nullptr;
   void* p_req = nullptr;
   const int64_t id_base = h->max_id + 1;        // (the global maximum: every rank keeps it)
   GNXCHK(gnx_tile2_offspring(h, burn, id_base, goff, &p_req));

@@ -343,6 +343,13 @@ struct gnx_state {
   int32_t* pairs2 = nullptr;     // pairs in ascending focal-id order
   int64_t* pair_goff = nullptr;  // tiled runs: global offspring offset of each local pair
   bool pair_goff_local = false;   // tile2, one tile: offspring ids from the local pair offsets
+  // tile-major offspring ids (gnx_set_id_order, gnx_kernels_pop.hip): virtual tile and in-tile
+  // rank of every pair, per-block and total counts per virtual tile, the tiles' base offsets
+  int id_order = 0;
+  bool pair_goff_ready = false;   // pair_goff holds this step's offsets (reset by the births)
+  uint8_t* vt_cls = nullptr;
+  int32_t *vt_rank = nullptr, *vt_blk_cnt = nullptr, *vt_blk_off = nullptr, *vt_count = nullptr;
+  int64_t* vt_base = nullptr;
   int64_t n_births_pending = 0;  // births of the current pair list
   // gamete requests (tiled runs)
   int64_t* req_pid = nullptr;
@@ -607,6 +614,8 @@ int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out,
 int gnx_l_find_pairs_enqueue(gnx_state* h, const uint8_t* d_keep, bool with_density);
 int gnx_l_find_pairs_finish(gnx_state* h, int64_t* n_pairs_out);
 int gnx_l_births(gnx_state* h, int64_t* births_out);
+int gnx_l_pair_cls(gnx_state* h, int64_t P, bool local);
+int gnx_l_pair_goff_vt(gnx_state* h, int64_t P);
 int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* births_out,
                int64_t id_base = -1, bool tiled = false);
 int gnx_l_dispersal_inject(gnx_state* h, int64_t B, int A, const float* d_mx, const float* d_my,

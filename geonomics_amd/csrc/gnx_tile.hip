@@ -1581,7 +1581,7 @@ extern "C" int gnx_tile2_offspring(gnx_state* h, int32_t burn, int64_t id_base,
   int64_t P = h->n_pairs, B = 0;
   h->birth_first_slot = h->N;
   h->n_req = 0;
-  if (P > 0 && pair_goff_dev)
+  if (P > 0 && pair_goff_dev && pair_goff_dev != (const void*)h->pair_goff)
     HIPCHK(hipMemcpyAsync(h->pair_goff, pair_goff_dev, P * sizeof(int64_t),
                           hipMemcpyDeviceToDevice, h->stream));
   // (no offsets handed in - one tile: the pairs' global offsets are their local ones)

@@ -368,7 +368,7 @@ def _cat(chunks, dtype, shape_tail=()):
 
 class TiledStepper:
     def __init__(self, shard, comm, W, H, mating_radius, move=True, max_id=-1,
-                 grid=None, fixed_births=0):
+                 grid=None, fixed_births=0, use_library=None):
         self.shard = shard
         self.comm = comm
         self.W, self.H = W, H
@@ -413,8 +413,13 @@ class TiledStepper:
         # no torch.distributed call and no Python between the phases of a step).  Needs a fixed
         # number of births per pair on several tiles (Poisson counts travel with the pair keys
         # through _step_v2) and no per-step hook (mutations: after_births).  GNX_TILE_V3=0: off.
+        # gnx_tile_step hands out offspring ids virtual tile by virtual tile (gnx_set_id_order 1),
+        # _step_v2 in the (hash cell, focal id) order of the whole landscape: two runs agree id by
+        # id when they use the same one.  use_library: None = GNX_TILE_V3 (default on).
         self.v3 = False
-        if self.v2 and os.environ.get('GNX_TILE_V3', '1') != '0':
+        if use_library is None:
+            use_library = os.environ.get('GNX_TILE_V3', '1') != '0'
+        if self.v2 and use_library:
             self.v3 = self._join_library_comm()
         self._ext = None           # the library's stream as a torch stream
         self._evcache = os.environ.get('GNX_TILE_EVCACHE', '1') != '0'
@@ -424,7 +429,10 @@ class TiledStepper:
 
     def _join_library_comm(self):
         dev, comm = self.shard.dev, self.comm
-        if comm.world > 1 and not (self.fixed_births or dev.births_fixed_lambda):
+        if not (self.fixed_births or dev.births_fixed_lambda):
+            return False
+        # (tile-major offspring ids: a fixed 8 x 8 blocking of the landscape the tiles are unions of)
+        if self.W % 8 or self.H % 8 or 8 % self.R or 8 % self.C:
             return False
         try:
             group = getattr(comm, 'local_group', None)

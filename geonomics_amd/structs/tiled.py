@@ -58,7 +58,10 @@ class TiledSpecies(Species):
         self._stepper = TiledStepper(
             self._shard, self._comm, W, H, float(self.mating_radius), move=self._move,
             max_id=N - 1,
-            fixed_births=int(self.n_births_distr_lambda) if self.n_births_fixed else 0)
+            fixed_births=int(self.n_births_distr_lambda) if self.n_births_fixed else 0,
+            # (the Model API steps with per-step hooks and promises the plain Species' ids:
+            # the Python-driven protocol, offspring ids in (hash cell, focal id) order)
+            use_library=False)
         self._shard.export_migrants()       # every rank drew all N; keep this tile's
         self._glob_N = int(N)
 

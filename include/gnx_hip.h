@@ -487,6 +487,13 @@ int gnx_tile2_die(gnx_state* h, int32_t burn, int32_t with_selection, int32_t ha
  *     be fixed (Poisson births travel with the pair keys through the host layer: returns 3).
  *   The global maximum id (gnx_set_max_id) must be the same on every rank before the first
  *   step; the library keeps it.                                                             */
+/* 0 (default): offspring ids in the canonical (hash cell, focal id) order of the pairs over the
+ * whole landscape; 1: virtual tile by virtual tile (a fixed 8 x 8 blocking of the landscape, every
+ * tile grid that divides it is a union of), inside one in that canonical order - what
+ * gnx_tile_step hands out, since the tiles then only have to tell each other 64 birth counts
+ * instead of every pair's order key; a one-device run in this order reproduces a tiled run id by
+ * id.  The reference's own order is that of a Python set (ops/mating.py:63): unspecified.      */
+int gnx_set_id_order(gnx_state* h, int32_t mode);
 int gnx_comm_unique_id(uint8_t* out128);
 int gnx_comm_init_rccl(gnx_state* h, const uint8_t* id128, int32_t rank, int32_t world);
 int gnx_comm_init_single(gnx_state* h);

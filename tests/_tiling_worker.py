@@ -71,7 +71,8 @@ def run(backend, shard_kind, world, rank, port, steps, out, fixed=True):
     else:
         shard, dev = make_device_shard(cfg, fixed)
     stepper = TiledStepper(shard, comm, cfg['W'], cfg['H'], cfg['radius'], move=True,
-                           max_id=cfg['N0'] - 1, fixed_births=1 if fixed else 0)
+                           max_id=cfg['N0'] - 1, fixed_births=1 if fixed else 0,
+                           use_library=False)     # (the gloo rehearsals: TiledStepper._step_v2)
     # keep only this tile's part of the common initial population
     stepper._migrate_initial = True
     rec, z, geno = shard.export_migrants()          # everybody outside my tile leaves

@@ -173,9 +173,9 @@ def _tiles_equal_one_device(cfg, grid, n_paths, n_burn, n_main, nbits, library=F
                 # world 1: one tile that spans the whole landscape
                 st = TiledStepper(shard, comm, cfg['W'] * C, cfg['H'] * R, 10.0, move=True,
                                   max_id=n_tiles * cfg['N'] - 1,
-                                  grid=grid if world > 1 else (1, 1), fixed_births=1)
-                if world > 1:
-                    assert st.v3 == library
+                                  grid=grid if world > 1 else (1, 1), fixed_births=1,
+                                  use_library=library)
+                assert st.v3 == library
                 hist = [st.step(True, False) for _ in range(n_burn)]
                 tag_genomes(dev)
                 shard.has_genomes = True

@@ -247,7 +247,7 @@ def test_two_tiles_match_oracle_crossover(overlap):
                            overlap=overlap)
             shard = DeviceShard(dev)
             stepper = TiledStepper(shard, comm, Wt, Ht, 3.0, move=True, max_id=N - 1,
-                                   fixed_births=1)
+                                   fixed_births=1, use_library=False)
             mine = stepper.rank_of(x, y) == rank
             dev.upload_population(x[mine], y[mine], age[mine], np.zeros(mine.sum()),
                                   np.arange(N)[mine])

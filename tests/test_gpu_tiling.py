@@ -52,6 +52,10 @@ def test_single_tile_stepper_equals_gnx_step():
     _, dev_b = make_device_shard(cfg)
     stepper = TiledStepper(sh, Comm(None), cfg['W'], cfg['H'], cfg['radius'],
                            max_id=cfg['N0'] - 1)
+    # (the stepper hands its steps to gnx_tile_step when it can - fixed births - which numbers
+    # the offspring virtual tile by virtual tile: gnx_step in the same order)
+    if stepper.v3:
+        dev_b.set_id_order(1)
     for t in range(7):
         burn = t < 3
         if t == 3:
@@ -94,10 +98,10 @@ def _run_threads(world, steps, fixed, library=False):
             comm = LocalComm(hub, rank) if world > 1 else Comm(None)
             shard, dev = make_device_shard(cfg, fixed)
             stepper = TiledStepper(shard, comm, cfg['W'], cfg['H'], cfg['radius'], move=True,
-                                   max_id=cfg['N0'] - 1, fixed_births=1 if fixed else 0)
+                                   max_id=cfg['N0'] - 1, fixed_births=1 if fixed else 0,
+                                   use_library=library)
             assert stepper.dev_transport == (world > 1)
-            if world > 1:
-                assert stepper.v3 == bool(library and fixed)
+            assert stepper.v3 == bool(library and fixed)
             shard.export_migrants()
             hist = []
             for t in range(steps):
@@ -156,7 +160,7 @@ def test_library_tile_step_is_bit_identical(world):
     run equals the one-tile run bit for bit, and equals the run the Python-driven protocol
     (TiledStepper._step_v2) gives."""
     steps = 8
-    one = _run_threads(1, steps, True)
+    one = _run_threads(1, steps, True, library=True)
     many = _run_threads(world, steps, True, library=True)
     assert one['hist'].tolist() == many['hist'].tolist()
     for k in ('ids', 'x', 'y', 'age', 'z', 'geno'):
@@ -176,6 +180,7 @@ def test_rccl_world1_through_the_library():
     dev_a.tile_set(1, 1, 0, 0)
     dev_a.comm_init_rccl(nat.comm_unique_id(), 0, 1)
     dev_a.set_max_id(cfg['N0'] - 1)
+    dev_b.set_id_order(1)            # gnx_tile_step numbers offspring virtual tile by virtual tile
     for t in range(6):
         n, b, d = dev_a.tile_step(True, False, True)
         dev_b.step(True, False)
@@ -185,6 +190,50 @@ def test_rccl_world1_through_the_library():
         np.testing.assert_array_equal(dev_a.download(f)[oa], dev_b.download(f)[ob])
     dev_a.close()
     dev_b.close()
+
+
+def test_tile_major_offspring_ids_on_one_device():
+    """gnx_set_id_order(1): offspring ids are handed out virtual tile by virtual tile (8 x 8
+    over the landscape, row-major), inside a virtual tile in the (hash cell, focal id) order of
+    the pairs - so the focal parents of the children, taken in id order, walk through the
+    virtual tiles in ascending order, every id is handed out once, and the same births happen
+    as in the default order (only their numbering differs)."""
+    from _tiling_worker import config, make_device_shard
+    from geonomics_amd import _native as nat
+    cfg = config()
+    _, a = make_device_shard(cfg)
+    _, b = make_device_shard(cfg)
+    b.set_id_order(1)
+    for t in range(3):
+        ids = b.download(nat.F_ID)
+        xb, yb = b.download(nat.F_X), b.download(nat.F_Y)
+        for dev in (a, b):
+            dev.age()
+            dev.move()
+        ids = b.download(nat.F_ID)
+        xb, yb = b.download(nat.F_X), b.download(nat.F_Y)
+        a.pop_dynamics_mate(True)
+        b.pop_dynamics_mate(True)
+        ca, pa, _, _, xya = a.last_births(with_gametes=False)
+        cb, pb, _, _, xyb = b.last_births(with_gametes=False)
+        assert len(cb) > 100
+        assert sorted(cb.tolist()) == list(range(int(cb.min()), int(cb.min()) + len(cb)))
+        if t == 0:      # (same ids so far: the same pairs in both devices, differently numbered;
+            #             from here on the draws - keyed by id - part ways)
+            key = lambda par: sorted(map(tuple, par.tolist()))
+            assert key(pa) == key(pb) and sorted(cb.tolist()) == sorted(ca.tolist())
+        # focal parents in the children's id order: ascending virtual tiles
+        o = np.argsort(cb)
+        slot = {int(i): k for k, i in enumerate(ids.tolist())}
+        fo = np.array([slot[int(p)] for p in pb[o, 0]])
+        vt = (np.minimum(7, (yb[fo] * 8 / cfg['H']).astype(int)) * 8 +
+              np.minimum(7, (xb[fo] * 8 / cfg['W']).astype(int)))
+        assert (np.diff(vt) >= 0).all() and len(set(vt.tolist())) > 8
+        for dev in (a, b):
+            dev.pop_dynamics_die(True, False)
+            dev.step_index = dev.step_index + 1
+    a.close()
+    b.close()
 
 
 def test_device_transport_equals_host_transport(tmp_path):
