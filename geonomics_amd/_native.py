@@ -52,6 +52,8 @@ EXPORTS = [
     'gnx_comm_unique_id', 'gnx_comm_init_rccl', 'gnx_comm_init_single', 'gnx_comm_local_create',
     'gnx_comm_local_join', 'gnx_comm_local_abort', 'gnx_comm_local_destroy', 'gnx_comm_free',
     'gnx_comm_bytes_sent', 'gnx_tile_step', 'gnx_set_id_order',
+    'gnx_tile2_route_begin', 'gnx_tile2_route_finish', 'gnx_tile2_requests_dev',
+    'gnx_tile2_set_requests',
     'gnx_stream_ptr', 'gnx_tile2_move_route', 'gnx_tile2_route_ptrs', 'gnx_tile2_import',
     'gnx_tile2_pairs', 'gnx_tile2_offspring', 'gnx_tile2_serve', 'gnx_tile2_put',
     'gnx_tile2_finish_births', 'gnx_tile2_die', 'gnx_tile_pair_ptrs_nosync',

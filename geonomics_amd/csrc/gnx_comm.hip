@@ -161,6 +161,11 @@ __global__ void k_sum_i32(int n, int world, const int32_t* __restrict__ all, int
   out[k] = s;
 }
 
+__global__ void k_copy_i32(int n, const int32_t* __restrict__ src, int32_t* __restrict__ dst, int zero) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) dst[k] = zero ? 0 : src[k];
+}
+
 __global__ void k_widen_i32(int n, const int32_t* __restrict__ src, int64_t* __restrict__ dst) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k < n) dst[k] = src[k];
@@ -458,10 +463,15 @@ extern "C" int gnx_tile_step(gnx_state* h, int32_t burn, int32_t with_selection,
   const int nt = h->cfg.n_traits, W64 = h->W64;
   const bool geno = h->genomes_assigned && h->cfg.L > 0;
   std::vector<int64_t> cnt(2 * T + 4), mats((size_t)w * (2 * T + 4));
-  // 1. age + movement, routing (wait 1), ONE exchange: migrants and ghosts
-  GNXCHK(gnx_tile2_move_route(h, 1, cnt.data()));
+  // 1. age + movement, the routing's counting pass; everybody's counts in ONE exchange (this
+  //    tile's own among them: the wait for them is the exchange's), then the pass that fills the
+  //    staging buffers and ONE batch of sends: migrants and ghosts
+  void* d_cnt = nullptr;
+  GNXCHK(gnx_tile2_route_begin(h, 1, &d_cnt));
   if (w > 1) {
-    GNXCHK(host_allgather(h, cnt.data(), 2 * T, mats.data()));
+    GNXCHK(host_allgather(h, nullptr, 2 * T, mats.data(), (const int32_t*)d_cnt, 2 * T));
+    for (int k = 0; k < 2 * T; ++k) cnt[k] = mats[(size_t)me * 2 * T + k];
+    GNXCHK(gnx_tile2_route_finish(h, cnt.data()));
     std::vector<int64_t> m_mig((size_t)w * w), m_gh((size_t)w * w);
     for (int s = 0; s < w; ++s)
       for (int d = 0; d < w; ++d) {
@@ -486,9 +496,14 @@ extern "C" int gnx_tile_step(gnx_state* h, int32_t burn, int32_t with_selection,
     GNXCHK(gnx_tile2_import(h, in_mig, c->rbuf[RB_MIG_REC], nt ? c->rbuf[RB_MIG_Z] : nullptr,
                             geno ? c->rbuf[RB_MIG_GENO] : nullptr, in_gh, c->rbuf[RB_GHOST]));
   }
-  // 2. pairs (wait 2); pair order and gamete requests from ONE count exchange
+  // 2. pairs (wait 2: the pair count); the gamete-request counts and the virtual tiles' birth
+  //    counts stay on the device and travel with ONE count exchange
   std::vector<int64_t> pc(2 + T);
-  GNXCHK(gnx_tile2_pairs(h, burn, pc.data()));
+  void* d_req = nullptr;
+  GNXCHK(gnx_tile2_requests_dev(h, w > 1 ? 1 : 0, &d_req));
+  const int rc_pairs = gnx_tile2_pairs(h, burn, pc.data());
+  GNXCHK(gnx_tile2_requests_dev(h, 0, nullptr));      // (the Python-driven protocol waits for them)
+  GNXCHK(rc_pairs);
   const int64_t P = pc[0], B = pc[1];
   int64_t total_births = B, total_pairs = P;
   std::vector<int64_t> m_req((size_t)w * w, 0);
@@ -498,17 +513,22 @@ extern "C" int gnx_tile_step(gnx_state* h, int32_t burn, int32_t with_selection,
   // round 3 all-gathered every pair's order key for this (1.8 MB per rank at C5)
   GNXCHK(gnx_l_pair_cls(h, P, w == 1));
   if (w > 1) {
-    const int cs = 2 + T + 64;
+    // [P, B | 64 virtual-tile counts | T request counts]: the last two from device memory
+    const bool have_req = h->n_req_known == -2;
+    hipLaunchKernelGGL(k_copy_i32, dim3((T + 63) / 64), dim3(64), 0, h->stream, T,
+                       (const int32_t*)d_req, h->vt_count + 64, have_req ? 0 : 1);
+    const int cs = 2 + 64 + T;
     std::vector<int64_t> g2((size_t)w * cs);
-    GNXCHK(host_allgather(h, pc.data(), cs, g2.data(), (const int32_t*)h->vt_count, 64));
+    GNXCHK(host_allgather(h, pc.data(), cs, g2.data(), (const int32_t*)h->vt_count, 64 + T));
     total_births = total_pairs = 0;
     std::vector<int64_t> vt(64, 0);
     for (int r = 0; r < w; ++r) {
       total_pairs += g2[(size_t)r * cs];
       total_births += g2[(size_t)r * cs + 1];
-      for (int d = 0; d < w; ++d) m_req[(size_t)r * w + d] = g2[(size_t)r * cs + 2 + d];
-      for (int q = 0; q < 64; ++q) vt[q] += g2[(size_t)r * cs + 2 + T + q];
+      for (int q = 0; q < 64; ++q) vt[q] += g2[(size_t)r * cs + 2 + q];
+      for (int d = 0; d < w; ++d) m_req[(size_t)r * w + d] = g2[(size_t)r * cs + 2 + 64 + d];
     }
+    GNXCHK(gnx_tile2_set_requests(h, &m_req[(size_t)me * w]));
     // the virtual tiles' base offsets, in births: an exclusive scan of 64 numbers, the same on
     // every rank; to the device through pinned memory
     int64_t run = 0;

@@ -399,6 +399,7 @@ struct gnx_state {
   int32_t* h_route_pin_dev = nullptr;
   std::vector<int64_t> req_by_rank;  // gamete requests per owning rank (gnx_tile2_pairs)
   bool rq_is2 = false;               // rq_sorted holds 24-byte gnx_gamete_req2 records
+  bool tile_req_on_device = false;   // gnx_tile2_pairs leaves the request counts in route_cnt (no wait)
 
   // pairing / mating scratch (capacity cap_inds)
   int32_t* mate = nullptr;

@@ -1481,7 +1481,9 @@ static int vt_buffers(gnx_state* h) {
   HIPCHK(hipMalloc((void**)&h->vt_rank, cap * sizeof(int32_t)));
   HIPCHK(hipMalloc((void**)&h->vt_blk_cnt, nb * GNX_VTN * sizeof(int32_t)));
   HIPCHK(hipMalloc((void**)&h->vt_blk_off, nb * GNX_VTN * sizeof(int32_t)));
-  HIPCHK(hipMalloc((void**)&h->vt_count, GNX_VTN * sizeof(int32_t)));
+  // (+ room behind the 64 counts for a tile's gamete-request counts: one device vector for the
+  // count exchange of gnx_tile_step)
+  HIPCHK(hipMalloc((void**)&h->vt_count, (GNX_VTN + GNX_MAX_TILES) * sizeof(int32_t)));
   HIPCHK(hipMalloc((void**)&h->vt_base, GNX_VTN * sizeof(int64_t)));
   return 0;
 }

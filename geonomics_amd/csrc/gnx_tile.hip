@@ -1265,6 +1265,7 @@ __global__ void k_route_offsets(int T, int32_t* cnt /*[2T counts | 2T offsets | 
     }
     cnt[4 * T + grp] = run;
   }
+  if (!host) return;
   for (int p = 0; p < 2 * T + n_extra; ++p)
     __hip_atomic_store(&host[p], cnt[p < 2 * T ? p : 4 * T + (p - 2 * T)], __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1343,10 +1344,15 @@ extern "C" int gnx_stream_ptr(gnx_state* h, void** stream) {
   return 0;
 }
 
-extern "C" int gnx_tile2_move_route(gnx_state* h, int32_t move, int64_t* counts) {
+// The routing in two halves (gnx_tile_step merges the wait for this tile's counts with the
+// exchange of everybody's): _begin enqueues age + movement and the counting pass and leaves
+// the 2T counts in device memory (*counts_dev, int32: migrants per rank, ghosts per rank);
+// _finish takes them from the host (counts[2T]) and enqueues the pass that fills the staging
+// buffers.  gnx_tile2_move_route = _begin, wait, _finish.
+extern "C" int gnx_tile2_route_begin(gnx_state* h, int32_t move, void** counts_dev) {
   GNXCHK(check_tiles(h, "gnx_tile2_move_route"));
   const int T = n_tiles(h);
-  for (int p = 0; p < 2 * T; ++p) counts[p] = 0;
+  *counts_dev = nullptr;
   h->route_n_mig = h->route_n_gh = 0;
   h->st_has_geno = false;
   if (h->n_ghost) {
@@ -1371,25 +1377,31 @@ extern "C" int gnx_tile2_move_route(gnx_state* h, int32_t move, int64_t* counts)
   else
     GNXCHK(gnx_l_age(h));
   const int64_t N = h->N;
+  HIPCHK(hipMemsetAsync(h->route_cnt, 0, (size_t)(4 * T + 8) * sizeof(int32_t), h->stream));
+  *counts_dev = h->route_cnt;
   if (N == 0 || T == 1) return 0;          // one tile: nobody leaves, nobody borders
   RouteGeo g;
   GNXCHK(route_geo(h, &g));
   GnxSoA s = h->soa[h->cur];
   const int nt = h->cfg.n_traits;
-  HIPCHK(hipMemsetAsync(h->route_cnt, 0, (size_t)2 * T * sizeof(int32_t), h->stream));
   hipLaunchKernelGGL(k_route<false>, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N,
                      h->cfg.cap_inds, s, g, nt, h->route_cnt, (const int32_t*)nullptr,
                      (gnx_ind_rec*)nullptr, (float*)nullptr, (int64_t*)nullptr,
                      (gnx_ind_rec*)nullptr, (int64_t)0, (int64_t)0);
-  const int seq = (int)(++h->pin_seq & 0x3fffffff);
-  hipLaunchKernelGGL(k_route_offsets, dim3(1), dim3(64), 0, h->stream, T, h->route_cnt,
-                     h->h_route_pin_dev, 2, seq);
   HIPCHK(hipGetLastError());
-  GNXCHK(tile2_wait(h, seq));                                   // wait 1 of the step
+  return 0;
+}
+
+extern "C" int gnx_tile2_route_finish(gnx_state* h, const int64_t* counts) {
+  const int T = n_tiles(h);
+  const int64_t N = h->N;
+  if (N == 0 || T == 1) return 0;
+  RouteGeo g;
+  GNXCHK(route_geo(h, &g));
+  GnxSoA s = h->soa[h->cur];
+  const int nt = h->cfg.n_traits;
   int64_t n_mig = 0, n_gh = 0;
   for (int p = 0; p < T; ++p) {
-    counts[p] = h->h_route_pin[p];
-    counts[T + p] = h->h_route_pin[T + p];
     n_mig += counts[p];
     n_gh += counts[T + p];
   }
@@ -1415,6 +1427,10 @@ extern "C" int gnx_tile2_move_route(gnx_state* h, int32_t move, int64_t* counts)
     h->gh_cap = n_gh + n_gh / 4 + 4096;
     GNXCHK(dalloc_t(&h->gh_rec, (size_t)h->gh_cap));
   }
+  // the per-destination offsets of both groups (the counting pass left the counts), then the
+  // counters again for the pass that fills
+  hipLaunchKernelGGL(k_route_offsets, dim3(1), dim3(64), 0, h->stream, T, h->route_cnt,
+                     (int32_t*)nullptr, 0, 0);
   HIPCHK(hipMemsetAsync(h->route_cnt, 0, (size_t)2 * T * sizeof(int32_t), h->stream));
   hipLaunchKernelGGL(k_route<true>, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N,
                      h->cfg.cap_inds, s, g, nt, h->route_cnt,
@@ -1439,6 +1455,21 @@ extern "C" int gnx_tile2_move_route(gnx_state* h, int32_t move, int64_t* counts)
   h->evict_box[3] = tb.y1;
   h->fb_adults = false;
   return 0;
+}
+
+extern "C" int gnx_tile2_move_route(gnx_state* h, int32_t move, int64_t* counts) {
+  const int T = n_tiles(h);
+  for (int p = 0; p < 2 * T; ++p) counts[p] = 0;
+  void* d_counts = nullptr;
+  GNXCHK(gnx_tile2_route_begin(h, move, &d_counts));
+  if (h->N == 0 || T == 1) return 0;
+  const int seq = (int)(++h->pin_seq & 0x3fffffff);
+  hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, h->stream, 2 * T,
+                     (const int32_t*)h->route_cnt, h->h_route_pin_dev, seq);
+  HIPCHK(hipGetLastError());
+  GNXCHK(tile2_wait(h, seq));                                   // wait 1 of the step
+  for (int p = 0; p < 2 * T; ++p) counts[p] = h->h_route_pin[p];
+  return gnx_tile2_route_finish(h, counts);
 }
 
 extern "C" int gnx_tile2_route_ptrs(gnx_state* h, void** mig_rec, void** mig_z, void** mig_geno,
@@ -1544,6 +1575,12 @@ extern "C" int gnx_tile2_pairs(gnx_state* h, int32_t burn, int64_t* counts) {
                        s.ghost, s.x, s.y, h->cfg.W / h->tile_C, h->cfg.H / h->tile_R, h->tile_R,
                        h->tile_C, h->sp.n_births_fixed ? (int)h->sp.n_births_lambda : 0,
                        h->nbirths, h->route_cnt);
+    HIPCHK(hipGetLastError());
+    if (h->tile_req_on_device) {
+      // (gnx_tile_step: the counts travel with its count exchange - gnx_tile2_set_requests)
+      h->n_req_known = -2;
+      return 0;
+    }
     const int seq = (int)(++h->pin_seq & 0x3fffffff);
     hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, h->stream, T, h->route_cnt,
                        h->h_route_pin_dev, seq);
@@ -1554,6 +1591,25 @@ extern "C" int gnx_tile2_pairs(gnx_state* h, int32_t burn, int64_t* counts) {
       h->req_by_rank[p] = h->h_route_pin[p];
       h->n_req_known += h->h_route_pin[p];
     }
+  }
+  return 0;
+}
+
+// gnx_tile_step: the request counts gnx_tile2_pairs left on the device (*counts_dev, int32 [T])
+// have reached the host with the count exchange
+extern "C" int gnx_tile2_requests_dev(gnx_state* h, int32_t on, void** counts_dev) {
+  h->tile_req_on_device = on != 0;
+  if (counts_dev) *counts_dev = h->route_cnt;
+  return 0;
+}
+
+extern "C" int gnx_tile2_set_requests(gnx_state* h, const int64_t* req /*[T]*/) {
+  const int T = n_tiles(h);
+  h->req_by_rank.assign(T, 0);
+  h->n_req_known = 0;
+  for (int p = 0; p < T; ++p) {
+    h->req_by_rank[p] = req[p];
+    h->n_req_known += req[p];
   }
   return 0;
 }

@@ -435,6 +435,17 @@ int gnx_stream_ptr(gnx_state* h, void** stream);
  * counts[2 * R*C] = migrants per rank, ghosts per rank.  Emigrants stay in their slots
  * until the cell sort of gnx_tile2_pairs moves them behind the population.  One wait.     */
 int gnx_tile2_move_route(gnx_state* h, int32_t move, int64_t* counts);
+/* ... in two halves, for a caller that exchanges the counts itself (gnx_tile_step: the wait for
+ * this tile's counts is the count exchange's): _begin enqueues age + movement + the counting
+ * pass, *counts_dev = int32[2 * R*C] in device memory (no wait); _finish takes this tile's counts
+ * from the host and enqueues the pass that fills the staging buffers (no wait).              */
+int gnx_tile2_route_begin(gnx_state* h, int32_t move, void** counts_dev);
+int gnx_tile2_route_finish(gnx_state* h, const int64_t* counts);
+/* gnx_tile2_pairs leaves its gamete-request counts in device memory (*counts_dev, int32[R*C])
+ * instead of waiting for them (on != 0); the caller hands them back once they have reached the
+ * host with its own exchange (gnx_tile2_set_requests) before gnx_tile2_offspring.             */
+int gnx_tile2_requests_dev(gnx_state* h, int32_t on, void** counts_dev);
+int gnx_tile2_set_requests(gnx_state* h, const int64_t* req);
 int gnx_tile2_route_ptrs(gnx_state* h, void** mig_rec, void** mig_z, void** mig_geno,
                          void** ghost_rec);
 /* arrivals (device buffers): migrants rec / z / geno [n_mig], ghosts rec [n_ghost]; (no wait).
