@@ -2,7 +2,9 @@
 """Long run of the metric workload with the bookkeeping checked along the way: the
 tables of the shared genome blocks are sound after a collection (gnx_debug_halves), blocks in use
 level off (no leak), the population stays at its carrying capacity.
-    python tools/soak.py [steps] [check every]"""
+    python tools/soak.py [steps] [check every]
+GNX_SOAK_WALK=1: the steps between two checks in one gnx_walk call each (the device-driven step
+where the handle takes it: GNX_SOAK_WORKLOAD=c2 / c3)."""
 import os
 import sys
 import time
@@ -22,8 +24,16 @@ t0 = time.time()
 import numpy as np                                      # noqa: E402
 n_mut = int(os.environ.get('GNX_SOAK_MUTATE', '0'))    # random mutations per step (copy-on-write)
 rng = np.random.RandomState(1)
-for t in range(1, steps + 1):
-    dev.step(False, True)
+walk = bool(os.environ.get('GNX_SOAK_WALK'))
+t = 0
+while t < steps:
+    if walk:
+        k = min(every - (t % every), steps - t)
+        dev.walk(k, False, True)
+        t += k
+    else:
+        dev.step(False, True)
+        t += 1
     if n_mut:
         dev.mutate(rng.randint(0, dev.N, n_mut).astype(np.int64),
                    rng.randint(0, cfg['L'], n_mut).astype(np.int32),
@@ -33,9 +43,11 @@ for t in range(1, steps + 1):
         n, b, d = dev.counts()
         ok = broken == 0 and used + free == total and used <= 2 * rows
         print('step %5d  N=%d births=%d deaths=%d  blocks: logical %d  physical in use %d '
-              '(%.1f %% shared)  free %d  %s  %.1f s' % (
+              '(%.1f %% shared)  free %d  %s  %.1f s%s' % (
                   t, n, b, d, 2 * rows, used, 100.0 * (1 - used / max(2 * rows, 1)), free,
-                  'ok' if ok else 'INCONSISTENT', time.time() - t0), flush=True)
+                  'ok' if ok else 'INCONSISTENT', time.time() - t0,
+                  '  (device-driven steps so far: %d)' % dev.totals()['dd_steps'] if walk else ''),
+              flush=True)
         if not ok:
             sys.exit(1)
 dev.close()
