@@ -347,6 +347,7 @@ struct gnx_state {
   // rank of every pair, per-block and total counts per virtual tile, the tiles' base offsets
   int id_order = 0;
   bool pair_goff_ready = false;   // pair_goff holds this step's offsets (reset by the births)
+  bool pair_goff_local_base = false;   // ... numbered from this device's own counts alone
   uint8_t* vt_cls = nullptr;
   int32_t *vt_rank = nullptr, *vt_blk_cnt = nullptr, *vt_blk_off = nullptr, *vt_count = nullptr;
   int64_t* vt_base = nullptr;

@@ -1436,29 +1436,45 @@ k_pair_cls(int64_t P, const int32_t* __restrict__ P_dev, const int32_t* __restri
   }
 }
 
-// one wave: per virtual tile the exclusive offsets of the blocks' counts and the total; with
-// `local` the virtual tiles' base offsets too (one device: nobody else has pairs), in births
-__global__ void __launch_bounds__(64)
+// per virtual tile (one lane each) the exclusive offsets of the blocks' counts and the total:
+// the 16 waves of the workgroup take a stretch of the blocks each, the stretches' totals meet in
+// LDS; with `local` the virtual tiles' base offsets too (one device: nobody else has pairs), in
+// births
+__global__ void __launch_bounds__(1024)
 k_cls_scan(int nb, const int32_t* __restrict__ P_dev, const int32_t* __restrict__ blk_cnt,
            int32_t* __restrict__ blk_off, int32_t* __restrict__ vt_count,
            int64_t* __restrict__ vt_base, int local, int64_t lam) {
-  const int c = threadIdx.x;
+  __shared__ int seg_tot[16][GNX_VTN];
+  const int c = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (P_dev) nb = (int)(((int64_t)*P_dev + GNX_CB - 1) / GNX_CB);
+  const int seg = (nb + 15) / 16;
+  const int b0 = wave * seg, b1 = min(nb, b0 + seg);
   int run = 0;
-  for (int b = 0; b < nb; ++b) {
+  for (int b = b0; b < b1; ++b) run += blk_cnt[(int64_t)b * GNX_VTN + c];
+  seg_tot[wave][c] = run;
+  __syncthreads();
+  int before = 0, total = 0;
+  for (int w = 0; w < 16; ++w) {
+    const int t = seg_tot[w][c];
+    before += w < wave ? t : 0;
+    total += t;
+  }
+  run = before;
+  for (int b = b0; b < b1; ++b) {
     const int v = blk_cnt[(int64_t)b * GNX_VTN + c];
     blk_off[(int64_t)b * GNX_VTN + c] = run;
     run += v;
   }
-  vt_count[c] = run;
+  if (wave != 0) return;
+  vt_count[c] = total;
   if (local) {
-    int xs = run;
+    int xs = total;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
       const int yv = __shfl_up(xs, d);
       if (c >= d) xs += yv;
     }
-    vt_base[c] = (int64_t)(xs - run) * lam;
+    vt_base[c] = (int64_t)(xs - total) * lam;
   }
 }
 
@@ -1503,10 +1519,11 @@ int gnx_l_pair_cls(gnx_state* h, int64_t P, bool local) {
     hipLaunchKernelGGL(k_pair_cls, dim3(nb), dim3(256), 0, h->stream, P, (const int32_t*)nullptr,
                        (const int32_t*)h->pairs, (const float*)s.x, (const float*)s.y, V, h->vt_cls,
                        h->vt_rank, h->vt_blk_cnt);
-  hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(64), 0, h->stream, nb, (const int32_t*)nullptr,
+  hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, h->stream, nb, (const int32_t*)nullptr,
                      (const int32_t*)h->vt_blk_cnt, h->vt_blk_off, h->vt_count, h->vt_base,
                      local ? 1 : 0, (int64_t)h->sp.n_births_lambda);
   HIPCHK(hipGetLastError());
+  h->pair_goff_local_base = local;
   return 0;
 }
 
@@ -1723,7 +1740,8 @@ __device__ __forceinline__ bool disperse_once(float mx, float my, float theta, f
 __global__ void __launch_bounds__(256)
 k_offspring(OffP P, GnxSoA s, const float* rast, const int32_t* pairs, const int32_t* off_pair,
             const int32_t* boff, const int64_t* goff,
-            int32_t* off_parent, int32_t* off_keys, uint8_t* off_start, GnxReq rq, GnxTraitTab T) {
+            int32_t* off_parent, int32_t* off_keys, uint8_t* off_start, GnxReq rq, GnxTraitTab T,
+            int32_t* __restrict__ ord_tail) {
   int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (P.dd) {
     P.N = P.dd->N;
@@ -1745,6 +1763,9 @@ k_offspring(OffP P, GnxSoA s, const float* rast, const int32_t* pairs, const int
   int i = pairs[2 * p], m = pairs[2 * p + 1];
   int64_t slot = P.N + k;
   unsigned long long oid = (unsigned long long)(P.id_base + gk);
+  // (tile-major ids on one device: the newborns' ids do not ascend with their slots - the
+  // id-ordered index takes its tail from here: the gk-th smallest new id sits in this slot)
+  if (ord_tail) ord_tail[gk] = (int32_t)slot;
   float mx = (s.x[i] + s.x[m]) / 2.0f;
   float my = (s.y[i] + s.y[m]) / 2.0f;
   // the draws that do not depend on the position, and - one GPU, at most 128 selected loci -
@@ -1956,6 +1977,7 @@ int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* 
   GnxSoA s = h->soa[h->cur];
   *births_out = 0;
   int64_t B = 0;
+  bool ord_tail_used = false;
   GNXCHK(gnx_xo_flush_deferred(h));
   bool genomes = !burn && c.L > 0 && h->genomes_assigned;
   if (inject) {
@@ -1997,11 +2019,18 @@ int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* 
       if (!h->req_zeroed) HIPCHK(hipMemsetAsync(h->req_count, 0, sizeof(int32_t), h->stream));
       h->req_zeroed = false;
     }
+    // tile-major ids while the id-ordered index is alive (one device, or a single tile): the
+    // index gets the newborns in id order from the kernel itself
+    int32_t* ord_tail = nullptr;
+    if (h->pair_goff_ready && h->pair_goff_local_base && h->ord_mode && h->ord_valid && !h->tiled &&
+        h->ord_n == h->N)
+      ord_tail = h->ord[h->ord_cur] + h->ord_n;
+    ord_tail_used = ord_tail != nullptr;
     gnx_time_begin(h);
     hipLaunchKernelGGL(k_offspring, dim3(gnx_grid(B, 256)), dim3(256), 0, h->stream, Q, s, h->rast,
                        h->pairs, h->off_pair, h->boff,
                        ((tiled && !h->pair_goff_local) || h->pair_goff_ready) ? h->pair_goff : nullptr,
-                       h->off_parent, h->off_keys, h->off_start, rq, gnx_trait_tab(h));
+                       h->off_parent, h->off_keys, h->off_start, rq, gnx_trait_tab(h), ord_tail);
     gnx_time_end(h, GNX_K_OFFSPRING, (double)B * (60.0 + 8.0 * c.n_layers + 48.0 * h->TW +
                                                   4.0 * c.n_traits));
     if (tiled && genomes) {
@@ -2042,9 +2071,13 @@ int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* 
   if (!tiled) h->max_id += B;
   if (h->pair_goff_ready) {
     // tile-major ids: the newborns' ids do not ascend with their slots, which is what the
-    // id-ordered index takes its unsorted tail to do - the next cell sort takes (cell, id) keys
+    // id-ordered index takes its unsorted tail to do: either k_offspring has just filed them
+    // (ord_tail), or the next cell sort takes (cell, id) keys
     h->pair_goff_ready = false;
-    h->ord_valid = false;
+    if (ord_tail_used)
+      h->ord_n += B;
+    else
+      h->ord_valid = false;
   }
   *births_out = B;
   return 0;
@@ -2127,7 +2160,7 @@ int gnx_dd_l_offspring(gnx_state* h, bool genomes, int32_t* d_bins, hipStream_t 
   hipLaunchKernelGGL(k_offspring, dim3(gnx_grid(h->cfg.cap_inds, 256)), dim3(256), 0, st, Q,
                      h->soa[h->cur], h->rast, h->pairs, h->off_pair, h->boff,
                      (const int64_t*)nullptr, h->off_parent, h->off_keys, h->off_start, GnxReq{},
-                     gnx_trait_tab(h));
+                     gnx_trait_tab(h), (int32_t*)nullptr);
   HIPCHK(hipGetLastError());
   return 0;
 }
