@@ -51,7 +51,7 @@ EXPORTS = [
     'gnx_walk', 'gnx_walk_many', 'gnx_walk_history',
     'gnx_comm_unique_id', 'gnx_comm_init_rccl', 'gnx_comm_init_single', 'gnx_comm_local_create',
     'gnx_comm_local_join', 'gnx_comm_local_abort', 'gnx_comm_local_destroy', 'gnx_comm_free',
-    'gnx_comm_bytes_sent', 'gnx_tile_step', 'gnx_set_id_order',
+    'gnx_comm_bytes_sent', 'gnx_comm_selftest', 'gnx_tile_step', 'gnx_set_id_order',
     'gnx_tile2_route_begin', 'gnx_tile2_route_finish', 'gnx_tile2_requests_dev',
     'gnx_tile2_set_requests',
     'gnx_stream_ptr', 'gnx_tile2_move_route', 'gnx_tile2_route_ptrs', 'gnx_tile2_import',
@@ -332,6 +332,10 @@ class Device:
     def set_id_order(self, mode):
         """0: offspring ids in (hash cell, focal id) order (default); 1: virtual-tile-major"""
         self._chk(self.lib.gnx_set_id_order(self.h, int(mode)))
+
+    def comm_selftest(self):
+        """known words through every operation of the transport (collective); raises GnxError"""
+        self._chk(self.lib.gnx_comm_selftest(self.h))
 
     def comm_free(self):
         self._chk(self.lib.gnx_comm_free(self.h))

@@ -136,6 +136,10 @@ struct Comm {
   int64_t pre = -1;                // global population before the last step's deaths
   int64_t bytes_sent = 0;
   int64_t steps = 0;
+  // GNX_COMM_FORCE_RCCL=1 at gnx_comm_init_rccl: a ONE-rank communicator goes through the RCCL
+  // calls too (all-gather, all-reduce, sends and receives to itself) instead of the shortcuts
+  // - what a one-GPU box can run of them
+  bool forced = false;
 };
 
 Comm* comm_of(gnx_state* h) { return (Comm*)h->tile_comm; }
@@ -181,7 +185,7 @@ int host_allgather(gnx_state* h, const int64_t* vec, int n, int64_t* out,
   Comm* c = comm_of(h);
   const int w = c->world;
   const int n_host = n - n_tail;
-  if (w == 1 || c->kind == COMM_LOCAL) {
+  if ((w == 1 && !c->forced) || c->kind == COMM_LOCAL) {
     std::vector<int64_t> mine(vec, vec + n_host);
     mine.resize(n, 0);
     if (n_tail > 0) {
@@ -269,12 +273,19 @@ int exchange(gnx_state* h, const Part* parts, int n_parts, const int64_t* mat) {
     if (g->barrier()) return 1;
     return 0;
   }
+  if (c->kind == COMM_SINGLE) {                       // one rank, no RCCL: what it sends itself
+    for (int k = 0; k < n_parts; ++k)
+      if (mat[0] > 0)
+        HIPCHK(hipMemcpyAsync(c->rbuf[parts[k].rb], parts[k].send, (size_t)mat[0] * parts[k].unit,
+                              hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+  }
   NCCLCHK(g_rccl.GroupStart());
   int64_t roff = 0, soff = 0;
   for (int peer = 0; peer < w; ++peer) {
     const int64_t n_out = mat[(int64_t)me * w + peer], n_from = mat[(int64_t)peer * w + me];
     for (int k = 0; k < n_parts; ++k) {
-      if (peer == me) {
+      if (peer == me && !c->forced) {
         if (n_out > 0)
           HIPCHK(hipMemcpyAsync((char*)c->rbuf[parts[k].rb] + roff * parts[k].unit,
                                 (const char*)parts[k].send + soff * parts[k].unit,
@@ -301,7 +312,7 @@ int exchange(gnx_state* h, const Part* parts, int n_parts, const int64_t* mat) {
 int allreduce_i32(gnx_state* h, int32_t* buf, int64_t n) {
   Comm* c = comm_of(h);
   const int w = c->world, me = c->rank;
-  if (w == 1) return 0;
+  if (w == 1 && !c->forced) return 0;
   if (c->kind == COMM_LOCAL) {
     LocalGroup* g = c->grp;
     GNXCHK(rb_need(c, RB_PAD, (size_t)w * n * 4));
@@ -367,7 +378,9 @@ extern "C" int gnx_comm_init_rccl(gnx_state* h, const uint8_t* id128, int32_t ra
   memcpy(&id, id128, sizeof(id));
   // (a one-rank communicator too: bench.py --gpus 1 goes through the same calls)
   NCCLCHK(g_rccl.CommInitRank(&c->nccl, world, id, rank));
-  if (world > 1) c->kind = COMM_RCCL;
+  const char* f = getenv("GNX_COMM_FORCE_RCCL");
+  c->forced = world == 1 && f && f[0] == '1';
+  if (world > 1 || c->forced) c->kind = COMM_RCCL;
   return 0;
 }
 
@@ -417,6 +430,111 @@ extern "C" int gnx_comm_free(gnx_state* h) {
   if (c->pin) (void)hipHostFree(c->pin);
   delete c;
   h->tile_comm = nullptr;
+  return 0;
+}
+
+// Known words through every operation of the transport - the gather of host and device words
+// (and its device copy), a ragged two-part exchange with every rank including itself, the
+// in-place sum - checked on the host.  TiledStepper runs it once when the ranks have joined:
+// a transport that does not deliver fails here, loudly, not as a wrong population later.
+extern "C" int gnx_comm_selftest(gnx_state* h) {
+  Comm* c = comm_of(h);
+  if (!c) {
+    gnx_set_error("gnx_comm_selftest: the handle has no communicator");
+    return 1;
+  }
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const int w = c->world, me = c->rank;
+  auto fail = [&](const char* what, long long got, long long want) {
+    gnx_set_error("gnx_comm_selftest (rank %d of %d): %s: got %lld, expected %lld", me, w, what,
+                  got, want);
+    return 1;
+  };
+  // -- gather: three host words and two words a kernel left on the device
+  int32_t* d_tail = nullptr;
+  HIPCHK(hipMalloc((void**)&d_tail, 64));
+  const int32_t tail[2] = {100 + me, 200 + 3 * me};
+  HIPCHK(hipMemcpyAsync(d_tail, tail, 8, hipMemcpyHostToDevice, h->stream));
+  const int64_t vec[5] = {me, 7LL * me + 1, -(int64_t)me - (1LL << 40), 0, 0};
+  std::vector<int64_t> all((size_t)w * 5);
+  int rc = host_allgather(h, vec, 5, all.data(), d_tail, 2);
+  HIPCHK(hipFree(d_tail));
+  if (rc) return rc;
+  for (int r = 0; r < w; ++r) {
+    const int64_t want[5] = {r, 7LL * r + 1, -(int64_t)r - (1LL << 40), 100 + r, 200 + 3 * r};
+    for (int k = 0; k < 5; ++k)
+      if (all[(size_t)r * 5 + k] != want[k]) return fail("gathered word", all[(size_t)r * 5 + k], want[k]);
+  }
+  if (w > 1 || c->forced) {
+    std::vector<int64_t> dev((size_t)w * 5);
+    HIPCHK(hipMemcpy(dev.data(), c->rbuf[RB_VEC_RECV], dev.size() * 8, hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < dev.size(); ++k)
+      if (dev[k] != all[k]) return fail("gathered word (device copy)", dev[k], all[k]);
+  }
+  // -- exchange: src sends 1 + (3 src + 5 dst) % 4 elements to dst, as int32 and as bytes
+  auto cnt = [](int s, int d) { return (int64_t)(1 + (3 * s + 5 * d) % 4); };
+  std::vector<int64_t> mat((size_t)w * w);
+  for (int s = 0; s < w; ++s)
+    for (int d = 0; d < w; ++d) mat[(size_t)s * w + d] = cnt(s, d);
+  std::vector<int32_t> s32;
+  std::vector<uint8_t> s8;
+  for (int d = 0; d < w; ++d)
+    for (int64_t k = 0; k < cnt(me, d); ++k) {
+      s32.push_back(me * 100000 + d * 100 + (int32_t)k);
+      s8.push_back((uint8_t)(me * 31 + d * 7 + k));
+    }
+  void *d32 = nullptr, *d8 = nullptr;
+  HIPCHK(hipMalloc(&d32, s32.size() * 4));
+  HIPCHK(hipMalloc(&d8, s8.size() + 16));
+  HIPCHK(hipMemcpyAsync(d32, s32.data(), s32.size() * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(d8, s8.data(), s8.size(), hipMemcpyHostToDevice, h->stream));
+  const Part parts[2] = {{d32, 4, RB_KEYS}, {d8, 1, RB_PAD}};
+  const int64_t sent0 = c->bytes_sent;
+  rc = exchange(h, parts, 2, mat.data());
+  if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = 1;
+  c->bytes_sent = sent0;                              // (not the population's bytes)
+  std::vector<int32_t> r32;
+  std::vector<uint8_t> r8;
+  int64_t n_in = 0;
+  for (int s = 0; s < w; ++s) n_in += cnt(s, me);
+  r32.resize((size_t)n_in);
+  r8.resize((size_t)n_in);
+  if (!rc) {
+    HIPCHK(hipMemcpy(r32.data(), c->rbuf[RB_KEYS], r32.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(r8.data(), c->rbuf[RB_PAD], r8.size(), hipMemcpyDeviceToHost));
+  }
+  HIPCHK(hipFree(d32));
+  HIPCHK(hipFree(d8));
+  if (rc) {
+    gnx_set_error("gnx_comm_selftest (rank %d of %d): the exchange failed", me, w);
+    return 1;
+  }
+  size_t at = 0;
+  for (int s = 0; s < w; ++s)
+    for (int64_t k = 0; k < cnt(s, me); ++k, ++at) {
+      if (r32[at] != s * 100000 + me * 100 + (int32_t)k)
+        return fail("exchanged int32", r32[at], s * 100000 + me * 100 + k);
+      if (r8[at] != (uint8_t)(s * 31 + me * 7 + k))
+        return fail("exchanged byte", r8[at], (uint8_t)(s * 31 + me * 7 + k));
+    }
+  // -- sum in place
+  int32_t* d_sum = nullptr;
+  HIPCHK(hipMalloc((void**)&d_sum, 8 * 4));
+  int32_t mine[8], got[8];
+  for (int k = 0; k < 8; ++k) mine[k] = me * 10 + k - 3;
+  HIPCHK(hipMemcpyAsync(d_sum, mine, sizeof(mine), hipMemcpyHostToDevice, h->stream));
+  rc = allreduce_i32(h, d_sum, 8);
+  if (!rc && hipMemcpyAsync(got, d_sum, sizeof(got), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = 1;
+  if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = 1;
+  HIPCHK(hipFree(d_sum));
+  if (rc) {
+    gnx_set_error("gnx_comm_selftest (rank %d of %d): the all-reduce failed", me, w);
+    return 1;
+  }
+  for (int k = 0; k < 8; ++k) {
+    const long long want = 10LL * w * (w - 1) / 2 + (long long)w * (k - 3);
+    if (got[k] != want) return fail("summed word", got[k], want);
+  }
   return 0;
 }
 

@@ -428,27 +428,41 @@ class TiledStepper:
         self._pre = None           # global population before the last step's deaths
 
     def _join_library_comm(self):
+        import os
         dev, comm = self.shard.dev, self.comm
         if not (self.fixed_births or dev.births_fixed_lambda):
             return False
         # (tile-major offspring ids: a fixed 8 x 8 blocking of the landscape the tiles are unions of)
         if self.W % 8 or self.H % 8 or 8 % self.R or 8 % self.C:
             return False
+        group = getattr(comm, 'local_group', None)
+        rccl = comm.dist is not None and comm.dist.get_backend() == 'nccl'
+        if comm.world > 1 and group is None and not rccl:
+            return False
+        joined, why = 1, None
         try:
-            group = getattr(comm, 'local_group', None)
             if comm.world == 1:
                 dev.comm_init_single()
             elif group is not None:               # tiles as threads of one process (tests)
                 dev.comm_local_join(group, comm.rank)
-            elif comm.dist is not None and comm.dist.get_backend() == 'nccl':
+            else:
                 # rank 0 makes the RCCL id; it travels once, through the launcher's own group
                 box = [nat.comm_unique_id() if comm.rank == 0 else None]
                 comm.dist.broadcast_object_list(box, src=0)
                 dev.comm_init_rccl(box[0], comm.rank, comm.world)
-            else:
-                return False
-        except nat.GnxError:
+        except nat.GnxError as e:
+            joined, why = 0, e
+        # every rank or none: a rank that could not join must not leave the others waiting in
+        # the library's collectives
+        if comm.world > 1 and int(comm.allreduce_sum(np.array([joined], np.int64))[0]) != comm.world:
+            if joined:
+                dev.comm_free()
             return False
+        if not joined:
+            return False
+        # known words through the transport once, before a population depends on it
+        if os.environ.get('GNX_TILE_SELFTEST', '1') != '0':
+            dev.comm_selftest()
         dev.set_max_id(self.max_id)
         return True
 

@@ -514,6 +514,13 @@ int gnx_comm_local_abort(void* group);
 int gnx_comm_local_destroy(void* group);
 int gnx_comm_free(gnx_state* h);
 int64_t gnx_comm_bytes_sent(gnx_state* h);
+/* Known words through every operation of the handle's transport (the gather of host and device
+ * words, a ragged two-part exchange with every rank including itself, the in-place sum), checked
+ * on the host; collective: every rank of the communicator calls it.  Nonzero and gnx_last_error
+ * when anything arrives wrong.  geonomics_amd.parallel.TiledStepper runs it once after the ranks
+ * have joined.  (GNX_COMM_FORCE_RCCL=1 in the environment of gnx_comm_init_rccl makes a ONE-rank
+ * communicator use the RCCL calls themselves instead of the one-rank shortcuts.) */
+int gnx_comm_selftest(gnx_state* h);
 int gnx_tile_step(gnx_state* h, int32_t burn, int32_t with_selection, int32_t exact, int64_t* out);
 
 /* ---- pedigree (reference structs/species.py:692-736: rows of the tskit tables) --

@@ -178,7 +178,15 @@ def test_rccl_world1_through_the_library():
     sh, dev_a = make_device_shard(cfg)
     _, dev_b = make_device_shard(cfg)
     dev_a.tile_set(1, 1, 0, 0)
-    dev_a.comm_init_rccl(nat.comm_unique_id(), 0, 1)
+    # the RCCL calls themselves, not the one-rank shortcuts: ncclAllGather / ncclAllReduce and
+    # a group of ncclSend / ncclRecv (to itself) carry the self-test's words and the step's
+    import os
+    os.environ['GNX_COMM_FORCE_RCCL'] = '1'
+    try:
+        dev_a.comm_init_rccl(nat.comm_unique_id(), 0, 1)
+    finally:
+        del os.environ['GNX_COMM_FORCE_RCCL']
+    dev_a.comm_selftest()
     dev_a.set_max_id(cfg['N0'] - 1)
     dev_b.set_id_order(1)            # gnx_tile_step numbers offspring virtual tile by virtual tile
     for t in range(6):
