@@ -53,6 +53,32 @@ bool gnx_host_times() {
   static const bool on = getenv("GNX_HOST_TIMES") && atoi(getenv("GNX_HOST_TIMES")) != 0;
   return on;
 }
+// GNX_HOST_TIMES=2: the host's clock where a wait for the device returns (the moment the GPU has
+// got that far) - the mean time between consecutive marks, printed by gnx_destroy: which stretch
+// of the step is slow without a profiler in the way
+static std::vector<std::pair<int, long long>> g_marks;
+void gnx_host_mark(int id) {
+  static const bool on = getenv("GNX_HOST_TIMES") && atoi(getenv("GNX_HOST_TIMES")) == 2;
+  if (!on) return;
+  g_marks.emplace_back(id, (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(
+                               std::chrono::steady_clock::now().time_since_epoch()).count());
+}
+static void host_marks_report() {
+  if (g_marks.size() < 64) return;
+  double sum[256] = {0};
+  long long n[256] = {0};
+  for (size_t k = g_marks.size() / 2; k < g_marks.size(); ++k) {
+    const int key = (g_marks[k - 1].first & 15) * 16 + (g_marks[k].first & 15);
+    sum[key] += 1e-3 * (double)(g_marks[k].second - g_marks[k - 1].second);
+    n[key] += 1;
+  }
+  for (int key = 0; key < 256; ++key)
+    if (n[key])
+      fprintf(stderr, "[gnx host marks] %d -> %d: %.1f us (%lld times)\n", key / 16, key % 16,
+              sum[key] / n[key], n[key]);
+  g_marks.clear();
+}
+
 struct GnxHostWait {
   std::chrono::steady_clock::time_point t0;
   GnxHostWait() { if (gnx_host_times()) t0 = std::chrono::steady_clock::now(); }
@@ -98,6 +124,7 @@ int gnx_wait_published(gnx_state* h, int slot, int64_t seq) {
     __builtin_ia32_pause();
   }
   std::atomic_thread_fence(std::memory_order_acquire);
+  gnx_host_mark(slot == 4 ? 1 : 3);
   return 0;
 }
 
@@ -481,6 +508,7 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
 
 extern "C" void gnx_destroy(gnx_state* h) {
   if (!h) return;
+  host_marks_report();
   if (gnx_host_times() && g_host_steps > 0)
     fprintf(stderr, "[gnx host times] %lld steps: %.1f us/step in gnx_step, %.1f us of it waiting for counts\n",
             g_host_steps, 1e6 * g_host_step_s / g_host_steps, 1e6 * g_host_wait_s / g_host_steps);

@@ -580,6 +580,9 @@ extern "C" int gnx_tile_step(gnx_state* h, int32_t burn, int32_t with_selection,
   }
   const int nt = h->cfg.n_traits, W64 = h->W64;
   const bool geno = h->genomes_assigned && h->cfg.L > 0;
+  // (gnx_totals: THIS tile's own individuals, births and deaths, as gnx_step counts them)
+  h->tot[0] += 1;
+  h->tot[1] += h->N - h->n_ghost;
   std::vector<int64_t> cnt(2 * T + 4), mats((size_t)w * (2 * T + 4));
   // 1. age + movement, the routing's counting pass; everybody's counts in ONE exchange (this
   //    tile's own among them: the wait for them is the exchange's), then the pass that fills the
@@ -688,6 +691,9 @@ extern "C" int gnx_tile_step(gnx_state* h, int32_t burn, int32_t with_selection,
   // 3. densities, death probabilities, mortality (wait 3)
   int64_t tot[3] = {0, 0, 0};
   GNXCHK(gnx_tile2_die(h, burn, with_selection, total_pairs > 0 ? 1 : 0, tot));
+  h->tot[2] += h->last_births;
+  h->tot[3] += h->last_deaths;
+  if (!burn) h->tot[4] += h->last_xo_births;
   h->step += 1;
   c->steps += 1;
   if (exact) {

@@ -663,8 +663,22 @@ int gnx_l_mutate(gnx_state* h, int n, const int64_t* d_slot, const int32_t* d_lo
 // n_dev != null: n is an upper bound (grid size), the count itself is read on the device
 int gnx_l_density(gnx_state* h, int64_t n, const float* d_x, const float* d_y, GnxSpline* spl,
                   const double* d_nodes_override, const int32_t* n_dev = nullptr);
+// four words a counting kernel leaves behind its bins (tiles: the counters of the all-reduce)
+struct GnxSetWords {
+  int32_t* dst = nullptr;
+  int32_t v[4] = {0, 0, 0, 0};
+};
+// two groups of device words for the host (pinned memory; a later wait covers them)
+struct GnxPubWords {
+  int n1 = 0;
+  const int32_t* src1 = nullptr;
+  int32_t* host1 = nullptr;
+  int n2 = 0;
+  const int32_t* src2 = nullptr;
+  int32_t* host2 = nullptr;
+};
 int gnx_l_bins(gnx_state* h, int64_t n, const float* d_x, const float* d_y, const uint8_t* d_ghost,
-               int32_t* d_bins, const int32_t* n_dev = nullptr);
+               int32_t* d_bins, const int32_t* n_dev = nullptr, const GnxSetWords* sw = nullptr);
 int gnx_l_spline(gnx_state* h, const int32_t* d_bins, GnxSpline* spl,
                  const double* d_nodes_override);
 int gnx_l_spline_z(gnx_state* h, const int32_t* d_bins, GnxSpline* spl,
@@ -719,6 +733,8 @@ int gnx_block_scan(gnx_state* h, int K, int64_t n_items, const int32_t* cnt, int
                    int32_t* out, int64_t* host, int64_t seq = 0, hipStream_t st = nullptr,
                    const int32_t* extra = nullptr);
 // the step's cell sort over the id-ordered index: Onesweep with one fill (gnx_prim.hip)
+bool gnx_l_lattices_tiled(gnx_state* h, bool have_pairs, const GnxPubWords& pub);
+void gnx_host_mark(int id);                       // GNX_HOST_TIMES=2 (gnx_api.hip)
 extern double g_host_step_s, g_host_wait_s;      // GNX_HOST_TIMES=1 (gnx_api.hip)
 bool gnx_host_times();
 size_t gnx_os_scratch_bytes(size_t n, int end_bit);

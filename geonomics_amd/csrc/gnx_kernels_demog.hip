@@ -22,8 +22,10 @@
 // ---------------------------------------------------------------- bins
 __global__ void __launch_bounds__(256)
 k_bins(int64_t n, const int32_t* n_dev, const float* x, const float* y, const uint8_t* ghost,
-       double inv_hww, int nbx, int nby, int32_t* partials) {
+       double inv_hww, int nbx, int nby, int32_t* partials, GnxSetWords sw) {
   extern __shared__ int32_t lds_hist[];
+  // (tiles: the four counter words behind the two density fields, on their way to the all-reduce)
+  if (sw.dst && blockIdx.x == 0 && threadIdx.x < 4) sw.dst[threadIdx.x] = sw.v[threadIdx.x];
   // n_dev: the count is still on its way to the host (the compaction's scan kernel left it
   // in device memory too); the grid was sized for an upper bound
   if (n_dev) n = *n_dev;
@@ -44,6 +46,10 @@ k_bins(int64_t n, const int32_t* n_dev, const float* x, const float* y, const ui
     int v = lds_hist[k];
     if (v) atomicAdd(&partials[k], v);
   }
+}
+
+__global__ void k_set_words(GnxSetWords sw) {
+  if (blockIdx.x == 0 && threadIdx.x < 4) sw.dst[threadIdx.x] = sw.v[threadIdx.x];
 }
 
 // variant for lattices too large for LDS: global atomics into partials[0]
@@ -156,7 +162,7 @@ static SplineC make_splinec(const gnx_state* h, const GnxSpline& s) {
 
 // counts n points (ghosts skipped) into the half-window bins d_bins [nby*nbx]
 int gnx_l_bins(gnx_state* h, int64_t n, const float* d_x, const float* d_y, const uint8_t* d_ghost,
-               int32_t* d_bins, const int32_t* n_dev) {
+               int32_t* d_bins, const int32_t* n_dev, const GnxSetWords* sw) {
   const GnxLattice& L = h->lat;
   const int nb = L.nbx * L.nby;
   const int field = (d_bins == h->bins_P) ? 1 : 0;
@@ -167,12 +173,16 @@ int gnx_l_bins(gnx_state* h, int64_t n, const float* d_x, const float* d_y, cons
     if ((size_t)nb * sizeof(int32_t) <= 48 * 1024) {
       int blocks = (int)std::min<int64_t>(BIN_BLOCKS, std::max<int64_t>(1, (n + 255) / 256));
       hipLaunchKernelGGL(k_bins, dim3(blocks), dim3(256), (size_t)nb * sizeof(int32_t), h->stream,
-                         n, n_dev, d_x, d_y, d_ghost, 1.0 / L.hww, L.nbx, L.nby, d_bins);
+                         n, n_dev, d_x, d_y, d_ghost, 1.0 / L.hww, L.nbx, L.nby, d_bins,
+                         sw ? *sw : GnxSetWords{});
+      sw = nullptr;
     } else {
       hipLaunchKernelGGL(k_bins_global, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, n, d_x,
                          d_y, d_ghost, 1.0 / L.hww, L.nbx, L.nby, d_bins);
     }
   }
+  if (sw)                      // (nobody to count, or a lattice too fine for the LDS kernel)
+    hipLaunchKernelGGL(k_set_words, dim3(1), dim3(64), 0, h->stream, *sw);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -406,7 +416,7 @@ k_lattice_nmax(int Jx, int Jy, int nbx, const int32_t* __restrict__ bins,
                const double* __restrict__ areas, double hww, const double* __restrict__ cp_g,
                double* __restrict__ C, int W, int H, unsigned long long* __restrict__ out_bits,
                int32_t* __restrict__ zero_bins, unsigned long long* __restrict__ zero_word,
-               int32_t* __restrict__ binsP, double* __restrict__ CP) {
+               int32_t* __restrict__ binsP, double* __restrict__ CP, GnxPubWords pub) {
   extern __shared__ double lat_lds[];
   const int nn = Jx * Jy;
   const int Jm = max(Jx, Jy);
@@ -424,8 +434,17 @@ k_lattice_nmax(int Jx, int Jy, int nbx, const int32_t* __restrict__ bins,
   double* AB = cp + Jm + 1;                     // [2 * Jx]
   double* red = AB + 2 * Jx;                    // [256]
   if (blockIdx.x == 0) {
-    for (int k = threadIdx.x; k < nn; k += blockDim.x) zero_bins[k] = 0;
-    if (threadIdx.x == 0) *zero_word = 0ull;
+    if (zero_bins)
+      for (int k = threadIdx.x; k < nn; k += blockDim.x) zero_bins[k] = 0;
+    if (zero_word && threadIdx.x == 0) *zero_word = 0ull;
+    // (tiles: the all-reduced counter words and the deferred checks go to the host from here;
+    // the mortality's wait covers them)
+    if ((int)threadIdx.x < pub.n1)
+      __hip_atomic_store(&pub.host1[threadIdx.x], pub.src1[threadIdx.x], __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((int)threadIdx.x < pub.n2)
+      __hip_atomic_store(&pub.host2[threadIdx.x], pub.src2[threadIdx.x], __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
   }
   for (int k = threadIdx.x; k <= Jm; k += blockDim.x) cp[k] = cp_g[k];
   for (int idx = threadIdx.x; idx < nn; idx += blockDim.x) {
@@ -674,7 +693,7 @@ int gnx_l_lattice_P_async(gnx_state* h, int64_t n_max) {
   hipLaunchKernelGGL(k_bins, dim3(blocks), dim3(256), (size_t)nb * sizeof(int32_t), h->stream3,
                      n_max, (const int32_t*)h->cnt_dev, (const float*)h->mid_x,
                      (const float*)h->mid_y, (const uint8_t*)nullptr, 1.0 / L.hww, L.nbx, L.nby,
-                     h->fb[2]);
+                     h->fb[2], GnxSetWords{});
   hipLaunchKernelGGL(k_lattice, dim3(1), dim3(256), lds_bytes, h->stream3, L.Jx, L.Jy, L.nbx,
                      (const int32_t*)h->fb[2], L.areas, L.hww, L.cprime, h->spl_P.c,
                      (int32_t*)nullptr, 0, (unsigned long long*)nullptr, 1, 1);
@@ -720,7 +739,7 @@ int gnx_bins_adults_launch(gnx_state* h) {
   const int blocks = (int)std::min<int64_t>(BIN_BLOCKS, std::max<int64_t>(1, (N + 255) / 256));
   hipLaunchKernelGGL(k_bins, dim3(blocks), dim3(256), (size_t)nb * sizeof(int32_t), h->stream3, N,
                      (const int32_t*)nullptr, h->fbp_x, h->fbp_y, (const uint8_t*)nullptr,
-                     1.0 / L.hww, L.nbx, L.nby, h->fb[h->fb_cur]);
+                     1.0 / L.hww, L.nbx, L.nby, h->fb[h->fb_cur], GnxSetWords{});
   HIPCHK(hipEventRecord(h->ev_binsN, h->stream3));
   HIPCHK(hipGetLastError());
   h->binsN_inflight = true;
@@ -763,7 +782,8 @@ int gnx_l_density_N(gnx_state* h) {
   hipLaunchKernelGGL(k_lattice_nmax, dim3(std::max(1, std::min(h->cfg.H, blocks_env))), dim3(256),
                      lds_bytes, h->stream, L.Jx, L.Jy, L.nbx, (const int32_t*)h->fb[cur], L.areas,
                      L.hww, L.cprime, h->spl_N.c, h->cfg.W, h->cfg.H, h->nmax2 + cur,
-                     h->fb[cur ^ 1], h->nmax2 + (cur ^ 1), (int32_t*)nullptr, (double*)nullptr);
+                     h->fb[cur ^ 1], h->nmax2 + (cur ^ 1), (int32_t*)nullptr, (double*)nullptr,
+                     GnxPubWords{});
   gnx_time_end(h, GNX_K_DENSITY, (double)h->N * 8.0);
   HIPCHK(hipGetLastError());
   h->spl_N.valid = true;
@@ -775,6 +795,32 @@ int gnx_l_density_N(gnx_state* h) {
   h->fb_adults = false;
   h->last_N_fused = true;
   return 0;
+}
+
+// Tiles: both density fields' lattices (their all-reduced bins) and N.max() in ONE launch, the
+// counter words and checks published from it - three launches of one field each and a
+// publishing kernel otherwise.  false: the lattice is too fine for it, nothing was launched.
+bool gnx_l_lattices_tiled(gnx_state* h, bool have_pairs, const GnxPubWords& pub) {
+  static const bool on = !(getenv("GNX_TILE_LATN") && atoi(getenv("GNX_TILE_LATN")) == 0);
+  const GnxLattice& L = h->lat;
+  const int64_t nn = (int64_t)L.Jx * L.Jy;
+  const size_t lds_bytes = ((size_t)4 * nn + std::max(L.Jx, L.Jy) + 1 + 2 * L.Jx + 256) * sizeof(double);
+  if (!on || lds_bytes > 64 * 1024 || !h->nmax_bits || !h->nmax_zeroed) return false;
+  static const int blocks_env = getenv("GNX_LATN_BLOCKS") ? atoi(getenv("GNX_LATN_BLOCKS")) : 256;
+  gnx_time_begin(h);
+  hipLaunchKernelGGL(k_lattice_nmax,
+                     dim3(std::max(1, std::min(h->cfg.H, blocks_env)) + (have_pairs ? 1 : 0)),
+                     dim3(256), lds_bytes, h->stream, L.Jx, L.Jy, L.nbx,
+                     (const int32_t*)h->bin_partials, L.areas, L.hww, L.cprime, h->spl_N.c, h->cfg.W,
+                     h->cfg.H, h->nmax_bits, (int32_t*)nullptr, (unsigned long long*)nullptr,
+                     have_pairs ? h->bins_P : (int32_t*)nullptr, h->spl_P.c, pub);
+  gnx_time_end(h, GNX_K_DENSITY, (double)h->N * 8.0);
+  h->spl_N.valid = true;
+  h->spl_P.valid = have_pairs;
+  h->nmax_cur = h->nmax_bits;
+  h->nmax_ready = true;
+  h->nmax_zeroed = false;
+  return true;
 }
 
 int gnx_l_death_probs(gnx_state* h, bool with_selection) {
@@ -1821,6 +1867,7 @@ int gnx_l_mortality_finish(gnx_state* h, int64_t* deaths_out) {
     const auto t0 = std::chrono::steady_clock::now();
     HIPCHK(hipEventSynchronize(h->ev_counts));
     if (ht) g_host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    gnx_host_mark(2);
   }
   const int64_t survivors = h->h_pin[0];
   const int64_t rows_freed = h->h_pin[1];
@@ -1850,7 +1897,7 @@ int gnx_dd_l_bins_adults(gnx_state* h, int par, hipStream_t st) {
   const int blocks = (int)std::min<int64_t>(BIN_BLOCKS, std::max<int64_t>(1, (cap + 255) / 256));
   hipLaunchKernelGGL(k_bins, dim3(blocks), dim3(256), (size_t)nb * sizeof(int32_t), st, cap,
                      (const int32_t*)&h->dd->N, (const float*)s.x, (const float*)s.y,
-                     (const uint8_t*)nullptr, 1.0 / L.hww, L.nbx, L.nby, h->fb[par]);
+                     (const uint8_t*)nullptr, 1.0 / L.hww, L.nbx, L.nby, h->fb[par], GnxSetWords{});
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1864,7 +1911,7 @@ int gnx_dd_l_density_pairs(gnx_state* h, hipStream_t st) {
   const int blocks = (int)std::min<int64_t>(BIN_BLOCKS, std::max<int64_t>(1, (cap / 2 + 255) / 256));
   hipLaunchKernelGGL(k_bins, dim3(blocks), dim3(256), (size_t)nb * sizeof(int32_t), st, cap,
                      (const int32_t*)&h->dd->P, (const float*)h->mid_x, (const float*)h->mid_y,
-                     (const uint8_t*)nullptr, 1.0 / L.hww, L.nbx, L.nby, h->fb[2]);
+                     (const uint8_t*)nullptr, 1.0 / L.hww, L.nbx, L.nby, h->fb[2], GnxSetWords{});
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1879,7 +1926,7 @@ int gnx_dd_l_density_N(gnx_state* h, int par, hipStream_t st) {
   hipLaunchKernelGGL(k_lattice_nmax, dim3(std::max(1, std::min(h->cfg.H, blocks_env)) + 1), dim3(256),
                      lds_bytes, st, L.Jx, L.Jy, L.nbx, (const int32_t*)h->fb[par], L.areas, L.hww,
                      L.cprime, h->spl_N.c, h->cfg.W, h->cfg.H, h->nmax2 + par, h->fb[par ^ 1],
-                     h->nmax2 + (par ^ 1), h->fb[2], h->spl_P.c);
+                     h->nmax2 + (par ^ 1), h->fb[2], h->spl_P.c, GnxPubWords{});
   HIPCHK(hipGetLastError());
   return 0;
 }

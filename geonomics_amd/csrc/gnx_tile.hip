@@ -581,7 +581,12 @@ extern "C" int gnx_tile_put_gametes(gnx_state* h, int64_t n, const int32_t* chil
 
 // phenotypes of this step's offspring (all gametes are in place) and the bins
 // of the tile's own individuals (ghosts skipped) for the N density
+static int tile_finish_births(gnx_state* h, int32_t burn, const GnxSetWords* sw);
 extern "C" int gnx_tile_finish_births(gnx_state* h, int32_t burn) {
+  return tile_finish_births(h, burn, nullptr);
+}
+
+static int tile_finish_births(gnx_state* h, int32_t burn, const GnxSetWords* sw) {
   // the service entry points return with stream2 idle; what follows is ordered behind
   // the crossover on the main stream
   h->xo_pending = false;
@@ -597,7 +602,7 @@ extern "C" int gnx_tile_finish_births(gnx_state* h, int32_t burn) {
   }
   GnxSoA s = h->soa[h->cur];
   h->last_N_fused = false;
-  GNXCHK(gnx_l_bins(h, h->N, s.x, s.y, s.ghost, h->bin_partials));
+  GNXCHK(gnx_l_bins(h, h->N, s.x, s.y, s.ghost, h->bin_partials, nullptr, sw));
   return 0;
 }
 
@@ -1781,23 +1786,18 @@ extern "C" int gnx_tile2_put(gnx_state* h, int64_t n, const void* data_dev) {
   return 0;
 }
 
-__global__ void k_set_words(int32_t* dst, int a, int b, int c, int d) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    dst[0] = a;
-    dst[1] = b;
-    dst[2] = c;
-    dst[3] = d;
-  }
-}
-
 extern "C" int gnx_tile2_finish_births(gnx_state* h, int32_t burn, void** reduce_dev,
                                        int64_t* n_words) {
-  GNXCHK(gnx_tile_finish_births(h, burn));
   const int64_t nb = (int64_t)h->lat.nbx * h->lat.nby;
-  // this tile's own individuals (ghosts are resident), births, deaths of the previous step
-  hipLaunchKernelGGL(k_set_words, dim3(1), dim3(64), 0, h->stream, h->bin_partials + 2 * nb,
-                     (int)(h->N - h->n_ghost), (int)h->last_births, (int)h->prev_deaths, 0);
-  HIPCHK(hipGetLastError());
+  // this tile's own individuals (ghosts are resident), births, deaths of the previous step:
+  // the kernel that counts the individuals leaves them behind the bins
+  GnxSetWords sw;
+  sw.dst = h->bin_partials + 2 * nb;
+  sw.v[0] = (int32_t)(h->N - h->n_ghost);
+  sw.v[1] = (int32_t)h->last_births;
+  sw.v[2] = (int32_t)h->prev_deaths;
+  sw.v[3] = 0;
+  GNXCHK(tile_finish_births(h, burn, &sw));
   *reduce_dev = h->bin_partials;
   *n_words = 2 * nb + 4;
   return 0;
@@ -1809,13 +1809,23 @@ extern "C" int gnx_tile2_die(gnx_state* h, int32_t burn, int32_t with_selection,
   const int64_t nb = (int64_t)h->lat.nbx * h->lat.nby;
   // the reduced counter words and the deferred checks ride to the host behind the
   // mortality's own wait (wait 3 of the step)
-  hipLaunchKernelGGL(k_publish_words2, dim3(1), dim3(64), 0, h->stream, 4, h->bin_partials + 2 * nb,
-                     h->h_route_pin_dev, 4, (const int32_t*)h->chk, h->h_route_pin_dev + 8);
-  if (have_pairs)
-    GNXCHK(gnx_l_spline(h, h->bins_P, &h->spl_P, nullptr));
-  else
-    h->spl_P.valid = false;
-  GNXCHK(gnx_l_spline(h, h->bin_partials, &h->spl_N, nullptr));
+  GnxPubWords pub;
+  pub.n1 = 4;
+  pub.src1 = h->bin_partials + 2 * nb;
+  pub.host1 = h->h_route_pin_dev;
+  pub.n2 = 4;
+  pub.src2 = (const int32_t*)h->chk;
+  pub.host2 = h->h_route_pin_dev + 8;
+  if (!gnx_l_lattices_tiled(h, have_pairs != 0, pub)) {
+    hipLaunchKernelGGL(k_publish_words2, dim3(1), dim3(64), 0, h->stream, 4,
+                       (const int32_t*)(h->bin_partials + 2 * nb), h->h_route_pin_dev, 4,
+                       (const int32_t*)h->chk, h->h_route_pin_dev + 8);
+    if (have_pairs)
+      GNXCHK(gnx_l_spline(h, h->bins_P, &h->spl_P, nullptr));
+    else
+      h->spl_P.valid = false;
+    GNXCHK(gnx_l_spline(h, h->bin_partials, &h->spl_N, nullptr));
+  }
   GNXCHK(gnx_l_death_probs(h, with_selection != 0 && !burn));
   const int64_t N_before = h->N;
   int64_t D = 0;

@@ -15,6 +15,7 @@ ap.add_argument('--steps', type=int, default=10)
 ap.add_argument('--genomes', action='store_true')
 ap.add_argument('--no-traits', action='store_true')
 ap.add_argument('--no-profile', action='store_true')
+ap.add_argument('--tile-step', action='store_true', help='gnx_tile_step on a 1 x 1 grid (one rank, no transport): the tile protocol alone')
 ap.add_argument('--walk', action='store_true', help='gnx_walk: counts on the device, one graph launch per step')
 a = ap.parse_args()
 cfg = dict(bench.WORKLOADS[a.workload])
@@ -30,6 +31,14 @@ if a.genomes:
     bench.setup_genomes(dev, cfg, 42)
 for _ in range(2):
     dev.step(not a.genomes, a.genomes)
+if a.tile_step:
+    dev.tile_set(1, 1, 0, 0)
+    dev.comm_init_single()
+    dev.set_max_id(int(dev.download(nat.F_ID).max()))
+    for _ in range(3):
+        dev.tile_step(not a.genomes, a.genomes, False)
+if a.walk:
+    dev.walk(4, not a.genomes, a.genomes)      # (graph capture: a fixed cost of the first call)
 dev.profiling(not a.no_profile)
 import time
 dev.synchronize()
@@ -37,6 +46,9 @@ t0 = time.perf_counter()
 dev.reset_totals()
 if a.walk:
     dev.walk(a.steps, not a.genomes, a.genomes)
+elif a.tile_step:
+    for _ in range(a.steps):
+        dev.tile_step(not a.genomes, a.genomes, False)
 else:
     for _ in range(a.steps):
         dev.step(not a.genomes, a.genomes)
