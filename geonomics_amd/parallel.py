@@ -447,10 +447,17 @@ class TiledStepper:
                 dev.comm_local_join(group, comm.rank)
             else:
                 # rank 0 makes the RCCL id; it travels once, through the launcher's own group
+                # (over the CPU side group when there is one: 128 bytes, no device involved)
                 box = [nat.comm_unique_id() if comm.rank == 0 else None]
-                comm.dist.broadcast_object_list(box, src=0)
+                hgrp = getattr(comm, '_hgrp', None)
+                if hgrp is not None:
+                    import torch
+                    comm.dist.broadcast_object_list(box, src=0, group=hgrp,
+                                                    device=torch.device('cpu'))
+                else:
+                    comm.dist.broadcast_object_list(box, src=0)
                 dev.comm_init_rccl(box[0], comm.rank, comm.world)
-        except nat.GnxError as e:
+        except Exception as e:           # (whatever it was: the ranks agree below)
             joined, why = 0, e
         # every rank or none: a rank that could not join must not leave the others waiting in
         # the library's collectives
