@@ -158,10 +158,10 @@ static void dd_flip(gnx_state* h, bool burn) {
   h->fb_cur ^= 1;               // (ord_cur flips twice per step)
 }
 
-static uint32_t dd_key(const gnx_state* h, bool burn, bool sel) {
+static uint32_t dd_key(const gnx_state* h, bool burn, bool sel, int k) {
   return (uint32_t)h->cur | (uint32_t)h->ord_cur << 1 | (uint32_t)h->jobs_cur << 2 |
          (uint32_t)h->fb_cur << 3 | (burn ? 16u : 0u) | (sel ? 32u : 0u) |
-         (h->genomes_assigned ? 64u : 0u);
+         (h->genomes_assigned ? 64u : 0u) | (uint32_t)k << 8;
 }
 
 static void dd_drop_graphs(gnx_state* h) {
@@ -170,11 +170,16 @@ static void dd_drop_graphs(gnx_state* h) {
   x->graphs.clear();
 }
 
-static int dd_launch_step(gnx_state* h, bool burn, bool sel) {
+// k consecutive steps in ONE graph (between two replays the GPU idles ~9 us - the start of a
+// graph - whatever it holds: four steps per graph share that)
+static int dd_launch_step(gnx_state* h, bool burn, bool sel, int k) {
   const bool use_graph = env_on("GNX_DD_GRAPH", true);
-  if (!use_graph) return dd_enqueue_step(h, burn, sel);
+  if (!use_graph) {
+    for (int q = 0; q < k; ++q) GNXCHK(dd_enqueue_step(h, burn, sel));
+    return 0;
+  }
   DDExtra* x = extra(h);
-  const uint32_t key = dd_key(h, burn, sel);
+  const uint32_t key = dd_key(h, burn, sel, k);
   auto it = x->graphs.find(key);
   if (it == x->graphs.end()) {
     const auto tc0 = std::chrono::steady_clock::now();
@@ -182,7 +187,8 @@ static int dd_launch_step(gnx_state* h, bool burn, bool sel) {
     const int cur0 = h->cur, ord0 = h->ord_cur, jobs0 = h->jobs_cur, fb0 = h->fb_cur;
     HIPCHK(hipStreamBeginCapture(x->cap[0], hipStreamCaptureModeThreadLocal));
     x->capturing = true;
-    int rc = dd_enqueue_step(h, burn, sel);
+    int rc = 0;
+    for (int q = 0; q < k && !rc; ++q) rc = dd_enqueue_step(h, burn, sel);
     x->capturing = false;
     hipError_t e = hipStreamEndCapture(x->cap[0], &g);
     // (the capture enqueued nothing: the host's parities are those before it)
@@ -211,7 +217,7 @@ static int dd_launch_step(gnx_state* h, bool burn, bool sel) {
               1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count());
   }
   HIPCHK(hipGraphLaunch(it->second, h->stream));
-  dd_flip(h, burn);
+  for (int q = 0; q < k; ++q) dd_flip(h, burn);
   return 0;
 }
 
@@ -417,6 +423,16 @@ static int64_t dd_per_step(const gnx_state* h) {
   return h->dd_use_hi > 0 ? std::min(worst, 2 * h->dd_use_hi + 4096) : worst;
 }
 
+// how many of the next `want` steps the stack of free blocks is certain to carry without a
+// collection (0: the collector has to run first)
+static int64_t dd_steps_in_stock(const gnx_state* h, bool burn, int64_t want) {
+  if (burn || !h->half_top || !h->genomes_assigned || h->cfg.L <= 0) return want;
+  const int64_t per_step = dd_per_step(h);
+  const int64_t since = h->dd_seq - std::max(h->dd_est_seq, h->dd_gc_seq);
+  const int64_t room = (h->dd_half_est - since * per_step) / per_step - 1;
+  return std::max<int64_t>(0, std::min(want, room));
+}
+
 static int dd_blocks(gnx_state* h, bool burn) {
   if (burn || !h->half_top || !h->genomes_assigned || h->cfg.L <= 0) return 0;
   const int64_t per_step = dd_per_step(h);
@@ -437,14 +453,22 @@ static int dd_blocks(gnx_state* h, bool burn) {
   return 0;
 }
 
-static int dd_one(gnx_state* h, bool burn, bool sel) {
+// up to `most` steps; *taken = how many were enqueued (GNX_DD_STEPS_PER_GRAPH at a time, 4 by
+// default, while the free blocks are certain to last; one otherwise)
+static int dd_some(gnx_state* h, bool burn, bool sel, int64_t most, int64_t* taken) {
+  static const int per_graph =
+      std::max(1, std::min(16, getenv("GNX_DD_STEPS_PER_GRAPH") ? atoi(getenv("GNX_DD_STEPS_PER_GRAPH")) : 4));
   dd_consume(h);
   GNXCHK(dd_check(h));
   GNXCHK(dd_blocks(h, burn));
   // (the ring holds GNX_DD_RING records: never run further ahead of the device than that)
   if (h->dd_seq - h->dd_seen > GNX_DD_RING / 4) GNXCHK(dd_wait_all_seen(h));
-  GNXCHK(dd_launch_step(h, burn, sel));
-  h->dd_seq += 1;
+  int k = 1;
+  if (!h->dd_gc_wait && most >= per_graph && dd_steps_in_stock(h, burn, per_graph) >= per_graph)
+    k = per_graph;
+  GNXCHK(dd_launch_step(h, burn, sel, k));
+  h->dd_seq += k;
+  *taken = k;
   if (h->dd_gc_wait) {
     h->dd_gc_wait = false;
     GNXCHK(dd_wait_all_seen(h));
@@ -505,11 +529,13 @@ extern "C" int gnx_walk_many(gnx_state** hs, int32_t n, int64_t T, int32_t burn,
     if (dd[k]) GNXCHK(dd_enter(hs[k]));
   }
   int rc = 0;
-  for (int64_t t = 0; t < T && !rc; ++t) {
+  for (bool any = true; any && !rc;) {
+    any = false;
     for (int k = 0; k < n && !rc; ++k) {
       if (left[k] <= 0) continue;
+      int64_t taken = 1;
       if (dd[k]) {
-        rc = dd_one(hs[k], burn != 0, with_selection != 0);
+        rc = dd_some(hs[k], burn != 0, with_selection != 0, left[k], &taken);
       } else {
         const int64_t n0 = hs[k]->N - hs[k]->n_ghost;
         rc = gnx_step(hs[k], burn, with_selection);
@@ -517,7 +543,8 @@ extern "C" int gnx_walk_many(gnx_state** hs, int32_t n, int64_t T, int32_t burn,
         hs[k]->dd_hist.push_back(hs[k]->last_births);
         hs[k]->dd_hist.push_back(hs[k]->last_deaths);
       }
-      left[k] -= 1;
+      left[k] -= taken;
+      any = any || left[k] > 0;
     }
   }
   for (int k = 0; k < n; ++k)
