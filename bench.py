@@ -646,6 +646,10 @@ def main():
                                 'bins collectives (RCCL), payloads %s' % (
                                     grid + ('device-resident' if stepper.dev_transport
                                             else 'staged through the host',))),
+                # which code drives a tiled step: the library's own communicator (one C call per
+                # step, RCCL issued by libgnxhip.so) or TiledStepper._step_v2 over torch.distributed
+                'tile_protocol': (None if stepper is None else
+                                  'gnx_tile_step' if stepper.v3 else 'torch.distributed'),
                 'landscape': '%dx%d' % (cfg['W'] * grid[1], cfg['H'] * grid[0]),
                 'N0_global': cfg['N'] * world,
                 'mean_N_global': ind_steps / args.steps, 'births_per_step_global': births / args.steps,

@@ -535,6 +535,10 @@ extern "C" int gnx_comm_selftest(gnx_state* h) {
     const long long want = 10LL * w * (w - 1) / 2 + (long long)w * (k - 3);
     if (got[k] != want) return fail("summed word", got[k], want);
   }
+  // (fault injection for the tests of what the callers do with a failure: this rank only,
+  // after every collective of the test has run)
+  const char* inj = getenv("GNX_COMM_SELFTEST_FAIL");
+  if (inj && inj[0] && atoi(inj) == me) return fail("injected failure (GNX_COMM_SELFTEST_FAIL)", 0, 1);
   return 0;
 }
 

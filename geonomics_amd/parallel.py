@@ -448,7 +448,13 @@ class TiledStepper:
             else:
                 # rank 0 makes the RCCL id; it travels once, through the launcher's own group
                 # (over the CPU side group when there is one: 128 bytes, no device involved)
-                box = [nat.comm_unique_id() if comm.rank == 0 else None]
+                # (a rank 0 that cannot make one says so with None: nobody is left in the broadcast)
+                box = [None]
+                if comm.rank == 0:
+                    try:
+                        box[0] = nat.comm_unique_id()
+                    except Exception as e:
+                        why = e
                 hgrp = getattr(comm, '_hgrp', None)
                 if hgrp is not None:
                     import torch
@@ -456,20 +462,42 @@ class TiledStepper:
                                                     device=torch.device('cpu'))
                 else:
                     comm.dist.broadcast_object_list(box, src=0)
-                dev.comm_init_rccl(box[0], comm.rank, comm.world)
+                if box[0] is None:
+                    joined = 0
+                else:
+                    dev.comm_init_rccl(box[0], comm.rank, comm.world)
         except Exception as e:           # (whatever it was: the ranks agree below)
             joined, why = 0, e
+
+        def everybody(flag):
+            if comm.world == 1:
+                return bool(flag)
+            return int(comm.allreduce_sum(np.array([1 if flag else 0], np.int64))[0]) == comm.world
+
+        def give_up(what):
+            import sys
+            if comm.rank == 0:
+                print('geonomics_amd: the tiles step through torch.distributed, not through the '
+                      'library\'s own communicator (%s: %s)' % (what, why), file=sys.stderr)
+            return False
         # every rank or none: a rank that could not join must not leave the others waiting in
         # the library's collectives
-        if comm.world > 1 and int(comm.allreduce_sum(np.array([joined], np.int64))[0]) != comm.world:
+        if not everybody(joined):
             if joined:
                 dev.comm_free()
-            return False
-        if not joined:
-            return False
-        # known words through the transport once, before a population depends on it
+            return give_up('joining failed on some rank')
+        # known words through the transport once, before a population depends on it; a transport
+        # that does not deliver them is dropped by every rank (the step then goes through
+        # TiledStepper._step_v2 and torch.distributed), loudly
         if os.environ.get('GNX_TILE_SELFTEST', '1') != '0':
-            dev.comm_selftest()
+            ok = True
+            try:
+                dev.comm_selftest()
+            except nat.GnxError as e:
+                ok, why = False, e
+            if not everybody(ok):
+                dev.comm_free()
+                return give_up('self-test failed')
         dev.set_max_id(self.max_id)
         return True
 

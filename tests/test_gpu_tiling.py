@@ -76,7 +76,7 @@ def test_single_tile_stepper_equals_gnx_step():
 
 
 # ---- device-resident transport (what RCCL carries on a multi-GPU node) -----------------
-def _run_threads(world, steps, fixed, library=False):
+def _run_threads(world, steps, fixed, library=False, expect_v3=None):
     """`world` tiles as threads of this process, LocalComm between them; the
     same schedule as _tiling_worker.run; returns the gathered final population."""
     import threading
@@ -101,7 +101,7 @@ def _run_threads(world, steps, fixed, library=False):
                                    max_id=cfg['N0'] - 1, fixed_births=1 if fixed else 0,
                                    use_library=library)
             assert stepper.dev_transport == (world > 1)
-            assert stepper.v3 == bool(library and fixed)
+            assert stepper.v3 == (bool(library and fixed) if expect_v3 is None else expect_v3)
             shard.export_migrants()
             hist = []
             for t in range(steps):
@@ -166,6 +166,17 @@ def test_library_tile_step_is_bit_identical(world):
     for k in ('ids', 'x', 'y', 'age', 'z', 'geno'):
         np.testing.assert_array_equal(one[k], many[k], err_msg=k)
     assert len(one['ids']) > 500
+
+
+def test_failed_self_test_drops_the_library_path_on_every_rank(monkeypatch):
+    """the transport's self-test fails on ONE of two ranks (fault injection in
+    gnx_comm_selftest): both drop the library's communicator, agree on it, and step through
+    TiledStepper._step_v2 - the run equals one that never asked for the library"""
+    ref = _run_threads(2, 5, True, library=False)
+    monkeypatch.setenv('GNX_COMM_SELFTEST_FAIL', '1')
+    got = _run_threads(2, 5, True, library=True, expect_v3=False)
+    for k in ('ids', 'x', 'y', 'age', 'geno'):
+        np.testing.assert_array_equal(got[k], ref[k])
 
 
 def test_rccl_world1_through_the_library():
