@@ -339,14 +339,24 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
     {
       const int lines = h->W64 / 16;
       const bool asked = getenv("GNX_HALF_BLOCKS") != nullptr;
-      int want = asked ? atoi(getenv("GNX_HALF_BLOCKS")) : GNX_MAX_NB;
+      int want = asked ? atoi(getenv("GNX_HALF_BLOCKS")) : 16;      // (more only when asked for)
       want = std::max(1, std::min(want, GNX_MAX_NB));
       while (want > 1 && (lines % want || (!asked && lines / want < 2) ||
                           (double)h->cfg.cap_rows * 4 * 2.0 * want >= 2.0e9))
         --want;
       h->NB = want;
       h->BW = h->W64 / want;
-      const int bl = getenv("GNX_BLOCK_LINES") ? atoi(getenv("GNX_BLOCK_LINES")) : 0;
+      // Long homologues (>= 40 lines; round 4): blocks of 5 lines (640 bytes), or as many lines
+      // as keep the block count within GNX_MAX_NB - the last block reaches past the homologue
+      // (L = 10^5: 20 blocks, the table laid out for 100 lines instead of 98).  Measured at the
+      // metric workload (profiles/r04_ab_runs.txt): 14 blocks of 7 lines 0.588 ms/step, 17 of 6
+      // 0.587, 20 of 5 0.565, 25 of 4 0.563 - a switch point costs 1.9 KB of traffic instead of
+      // 2.7, the crossover launch 0.147 ms instead of 0.178 for 0.49 GB instead of 0.70; with 25
+      // blocks it shrinks further (0.132 ms) but the job builder's tables grow as much.
+      // GNX_BLOCK_LINES=k: blocks of exactly k lines; 0: the divisor rule above whatever the length
+      int bl = getenv("GNX_BLOCK_LINES") ? atoi(getenv("GNX_BLOCK_LINES")) : -1;
+      if (bl < 0) bl = (!asked && lines >= 40) ? std::max(5, (lines + GNX_MAX_NB - 1) / GNX_MAX_NB) : 0;
+      if (bl > 0 && (double)h->cfg.cap_rows * 4 * 2.0 * ((lines + bl - 1) / bl) >= 2.0e9) bl = 0;
       if (bl > 0 && (lines + bl - 1) / bl <= GNX_MAX_NB && (lines + bl - 1) / bl >= 1) {
         h->NB = (lines + bl - 1) / bl;
         h->BW = 16 * bl;

@@ -62,7 +62,7 @@ bool gnx_dd_eligible(const gnx_state* h, bool burn) {
   if (sp.mating_radius < 0 || !sp.n_births_fixed || !sp.move) return false;
   if (!h->ord_mode || h->key_bits > 24 || !h->compact_fill || !h->defer_xo) return false;
   if (!h->stream2 || !h->stream3 || !gnx_fused_bins(h)) return false;
-  if (h->NB > 16 || h->n_ghost != 0 || h->id_order != 0) return false;
+  if (h->NB > GNX_MAX_NB || h->n_ghost != 0 || h->id_order != 0) return false;
   if (h->cfg.cap_inds >= (1ll << 30)) return false;
   if (h->xo_launch_policy != 0 || h->xo_split != 0) return false;
   (void)burn;

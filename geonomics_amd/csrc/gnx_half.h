@@ -25,7 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define GNX_MAX_NB 16
+#define GNX_MAX_NB 28
 
 #define GNX_OWN 0x80000000u      // table entry: the block belongs to this logical block alone
 #define GNX_BLK(e) ((int32_t)((uint32_t)(e) & 0x7fffffffu))

@@ -1080,7 +1080,19 @@ k_xo_jobs_write(int64_t B, GnxHalves H, const GnxXoPlan* __restrict__ plan,
 // entries are NB 8-byte loads, the child's NB 8-byte stores.  One thread per logical block
 // (k_xo_jobs_write: 3.3 M threads, each a chain of three dependent loads) took 52 us,
 // k_xo_jobs_surv 23.
-#define GNX_JF_NB 16
+#define GNX_JF_NB 28
+__device__ __forceinline__ int32_t gnx_fresh_at(int fr, int32_t f0, int32_t f1, int32_t f2, int32_t f3,
+                                                int32_t f4, int32_t f5,
+                                                const int32_t* __restrict__ stack, int pop) {
+  int32_t d = f0;
+  d = fr == 1 ? f1 : d;
+  d = fr == 2 ? f2 : d;
+  d = fr == 3 ? f3 : d;
+  d = fr == 4 ? f4 : d;
+  d = fr == 5 ? f5 : d;
+  if (fr >= 6) d = stack[pop - fr];
+  return d;
+}
 // threads per workgroup: every workgroup takes its stretch of the free-block stack and of the
 // job list with one atomic each, all on the same two words - 815 workgroups of 256 threads
 // queue up there (64 us; 512 threads: 58 us; 1024 threads spill: 64 us)
@@ -1177,7 +1189,7 @@ k_xo_jobs_fused(int64_t N, int64_t first, int32_t* __restrict__ grow,
   const unsigned int all = (1u << NB) - 1u;
   const int lpb = H.BW * 64;
   const float inv_lpb = 1.0f / (float)lpb;
-  auto blk_of = [&](int l) {
+  auto blk_of = [&](int l) __attribute__((always_inline)) {
     int q = (int)((float)l * inv_lpb);
     q -= (q * lpb > l) ? 1 : 0;
     q += ((q + 1) * lpb <= l) ? 1 : 0;
@@ -1278,23 +1290,15 @@ k_xo_jobs_fused(int64_t N, int64_t first, int32_t* __restrict__ grow,
       pe[p][2 * q + 1] = v.y;
     }
   }
-  constexpr int NF = 6;
   // (six scalars, not an array: the compiler turns a select chain over an array captured by
   // reference into an indexed load from scratch)
   const int32_t f0 = 0 < cf ? H.stack[pop] : 0, f1 = 1 < cf ? H.stack[pop - 1] : 0,
                 f2 = 2 < cf ? H.stack[pop - 2] : 0, f3 = 3 < cf ? H.stack[pop - 3] : 0,
                 f4 = 4 < cf ? H.stack[pop - 4] : 0, f5 = 5 < cf ? H.stack[pop - 5] : 0;
   const int32_t* stack = H.stack;
-  auto fresh_at = [=](int fr) {
-    int32_t d = f0;
-    d = fr == 1 ? f1 : d;
-    d = fr == 2 ? f2 : d;
-    d = fr == 3 ? f3 : d;
-    d = fr == 4 ? f4 : d;
-    d = fr == 5 ? f5 : d;
-    if (fr >= NF) d = stack[pop - fr];
-    return d;
-  };
+  // (a function of scalars, not a closure: with more than 20 blocks per homologue the closure
+  // object stayed in scratch and the compiler chose between its address and the stack's)
+#define fresh_at(fr_) gnx_fresh_at((fr_), f0, f1, f2, f3, f4, f5, stack, pop)
   // stage 7a: my table (NB 8-byte stores); the parents' blocks that are shared from now on
   // lose their never-shared flag (only the first child to share one writes).  Branch-free but
   // for the stores: every wave has some lane on either side of every block.
@@ -1331,10 +1335,18 @@ k_xo_jobs_fused(int64_t N, int64_t first, int32_t* __restrict__ grow,
       m &= m - 1u;
       const int32_t dst = fresh_at(fbase + __popc(mixed[p] & ((1u << q) - 1u)));
       int32_t e0 = pe[p][0], e1 = pe[p][NB];
+      if constexpr (NB <= 16) {
 #pragma unroll
-      for (int q2 = 1; q2 < NB; ++q2) {
-        e0 = q == q2 ? pe[p][q2] : e0;
-        e1 = q == q2 ? pe[p][NB + q2] : e1;
+        for (int q2 = 1; q2 < NB; ++q2) {
+          e0 = q == q2 ? pe[p][q2] : e0;
+          e1 = q == q2 ? pe[p][NB + q2] : e1;
+        }
+      } else {
+        // (more blocks: the select chain over the registers outgrows the unroller and the table
+        // in registers would move to scratch - the two entries are read again, from L2)
+        const int32_t* prw = H.hmap + (int64_t)prow[p] * 2 * NB;
+        e0 = prw[q];
+        e1 = prw[NB + q];
       }
       GnxXoJob j;
       j.ph0 = GNX_BLK(e0);
@@ -1345,7 +1357,7 @@ k_xo_jobs_fused(int64_t N, int64_t first, int32_t* __restrict__ grow,
       unsigned int o0 = 0, o1 = 0, o2 = 0;
       int nin = 0;
       const int lo = q * lpb, hi = (q == NB - 1) ? 0x7fffffff : lo + lpb;
-      auto take = [&](int l) {
+      auto take = [&](int l) __attribute__((always_inline)) {
         if (l >= lo && l < hi) {
           const unsigned int o = (unsigned int)(l - lo);
           o0 = nin == 0 ? o : o0;
@@ -1368,6 +1380,8 @@ k_xo_jobs_fused(int64_t N, int64_t first, int32_t* __restrict__ grow,
     }
   }
 }
+
+#undef fresh_at
 
 template <int NB>
 static void launch_jobs_fused(gnx_state* h, int64_t first_slot, const int32_t* d_alive,
@@ -1564,7 +1578,8 @@ k_fill(int64_t cap, const int32_t* __restrict__ n_move, const int32_t* __restric
 
 static bool jobs_fused_ok(const gnx_state* h) {
   static const bool fused_env = !(getenv("GNX_JOBS_FUSED") && atoi(getenv("GNX_JOBS_FUSED")) == 0);
-  return fused_env && h->NB <= GNX_JF_NB;
+  // (the two-kernel builder's plan packs the block masks into 16 bits each)
+  return (fused_env || h->NB > 16) && h->NB <= GNX_JF_NB;
 }
 
 void gnx_launch_xo_jobs_surv(gnx_state* h, int64_t first_slot, const int32_t* d_alive,
@@ -1588,7 +1603,19 @@ void gnx_launch_xo_jobs_surv(gnx_state* h, int64_t first_slot, const int32_t* d_
       case 13: launch_jobs_fused<13>(h, first_slot, d_alive, d_blk_off, buf); break;
       case 14: launch_jobs_fused<14>(h, first_slot, d_alive, d_blk_off, buf); break;
       case 15: launch_jobs_fused<15>(h, first_slot, d_alive, d_blk_off, buf); break;
-      default: launch_jobs_fused<16>(h, first_slot, d_alive, d_blk_off, buf); break;
+      case 16: launch_jobs_fused<16>(h, first_slot, d_alive, d_blk_off, buf); break;
+      case 17: launch_jobs_fused<17>(h, first_slot, d_alive, d_blk_off, buf); break;
+      case 20: launch_jobs_fused<20>(h, first_slot, d_alive, d_blk_off, buf); break;
+      case 18: launch_jobs_fused<18>(h, first_slot, d_alive, d_blk_off, buf); break;
+      case 19: launch_jobs_fused<19>(h, first_slot, d_alive, d_blk_off, buf); break;
+      case 21: launch_jobs_fused<21>(h, first_slot, d_alive, d_blk_off, buf); break;
+      case 22: launch_jobs_fused<22>(h, first_slot, d_alive, d_blk_off, buf); break;
+      case 23: launch_jobs_fused<23>(h, first_slot, d_alive, d_blk_off, buf); break;
+      case 24: launch_jobs_fused<24>(h, first_slot, d_alive, d_blk_off, buf); break;
+      case 25: launch_jobs_fused<25>(h, first_slot, d_alive, d_blk_off, buf); break;
+      case 26: launch_jobs_fused<26>(h, first_slot, d_alive, d_blk_off, buf); break;
+      case 27: launch_jobs_fused<27>(h, first_slot, d_alive, d_blk_off, buf); break;
+      default: launch_jobs_fused<28>(h, first_slot, d_alive, d_blk_off, buf); break;
     }
     return;
   }
@@ -2075,3 +2102,11 @@ int gnx_l_spatial_diff(gnx_state* h, double* mean, double* sd, double* sums) {
   h->counts_cur = nowi;
   return 0;
 }
+
+#ifdef GNX_JF_TRY
+// (compile test of one more instantiation of the fused job builder: hipcc -DGNX_JF_TRY=25 -c ...)
+template __global__ void k_xo_jobs_fused<GNX_JF_TRY, GNX_JF_TPB>(
+    int64_t, int64_t, int32_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*,
+    const uint8_t*, const int32_t*, int64_t, GnxHalves, const int32_t*, const int32_t*, int32_t*,
+    GnxXoJob*, GnxJobBp*, const int32_t*, GnxDD*);
+#endif

@@ -23,8 +23,9 @@ from test_gpu_parity import native
 
 pytestmark = pytest.mark.gpu
 
-L = 100000          # 1568 words per homologue = 98 lines of 128 bytes: 14 blocks of 7 lines
-NB = 14
+L = 100000          # 1568 words per homologue = 98 lines of 128 bytes: 20 blocks of 5 lines (the
+                    # last one reaches past the homologue: the table is laid out for 100 lines)
+NB = 20
 W = H = 40
 N0 = 1500          # settles at ~1530 after mortality (K_factor 1.0), ~310 births per step
 STEPS = 130
@@ -161,7 +162,7 @@ def test_model_step_path_matches_oracle_crossover(overlap):
     paths = _paths(False)
     dev, g = _make(paths, overlap=overlap)
     info = dev.genome_info()
-    assert info['NB'] == NB and info['sparse'] == 1 and info['BW'] * NB == dev.W64
+    assert info['NB'] == NB and info['sparse'] == 1 and info['BW'] == 80 and dev.W64 == 1568
     host = HostGenomes(np.arange(N0), g, paths)
     rng = np.random.RandomState(11)
     births = muts = not_cut = 0
