@@ -330,7 +330,7 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
   if (cfg->L > 0) {
     // blocks per homologue: the largest divisor of the 128-byte lines per homologue that is
     // not above 16 and leaves blocks of at least 2 lines (L = 10^5: 98 lines, 14 blocks of
-    // 896 bytes; L = 10^4: 10 lines, 5 blocks of 256 bytes; GNX_HALF_BLOCKS asks for another one), as long as the block numbers fit 31
+    // 896 bytes - round 3's layout, superseded below; L = 10^4: 10 lines, 5 blocks of 256 bytes; GNX_HALF_BLOCKS asks for another one), as long as the block numbers fit 31
     // bits.  Measured at the metric workload (tools/ab.sh): 7 blocks 0.745 ms/step, 14 blocks
     // 0.670 - a switch point costs a block half the size, the tables twice the entries.
     // GNX_BLOCK_LINES=k: blocks of exactly k lines (k = 8: 1 024 bytes, every lane of the
