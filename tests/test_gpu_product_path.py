@@ -156,7 +156,7 @@ def _split_step(dev, host, t, mutate_rng=None, trait_loci=()):
 
 @pytest.mark.parametrize('overlap', [0, 1])
 def test_model_step_path_matches_oracle_crossover(overlap):
-    """the split step of the Model API: deferred + 14 shared blocks + natural collections +
+    """the split step of the Model API: deferred + 20 shared blocks + natural collections +
     mutations in every third step; genomes == oracle replay at every checkpoint"""
     nat = native()
     paths = _paths(False)
@@ -178,6 +178,29 @@ def test_model_step_path_matches_oracle_crossover(overlap):
     assert births > 25000 and muts > 300
     assert not_cut > 1500           # offspring that died at age 0 never got a genome
     # bookkeeping after all that: nothing broken, used + free = all, blocks are shared
+    rows, broken, _, used, free, total = (int(v) for v in dev.debug_halves())
+    assert broken == 0 and used + free == total and used < 2 * rows
+    host.check(dev, nat, 'after the final collection')
+    dev.close()
+
+
+@pytest.mark.parametrize('lines,nb', [(4, 25), (6, 17), (7, 14), (8, 13)])
+def test_other_block_sizes_match_oracle_crossover(lines, nb, monkeypatch):
+    """GNX_BLOCK_LINES: blocks of 4 / 6 / 7 / 8 lines instead of the default 5 (25 / 17 / 14 / 13
+    blocks per homologue; all but 7 with a last block that reaches past the homologue; above 16
+    the fused job builder's other variant): the same replay, shorter"""
+    monkeypatch.setenv('GNX_BLOCK_LINES', str(lines))
+    nat = native()
+    paths = _paths(False)
+    dev, g = _make(paths, overlap=0)
+    info = dev.genome_info()
+    assert info['NB'] == nb and info['BW'] == 16 * lines and info['sparse'] == 1
+    host = HostGenomes(np.arange(N0), g, paths)
+    rng = np.random.RandomState(5)
+    for t in range(60):
+        _split_step(dev, host, t, rng if t % 3 == 2 else None)
+        if t % 20 == 19:
+            host.check(dev, nat, 'step %d' % t)
     rows, broken, _, used, free, total = (int(v) for v in dev.debug_halves())
     assert broken == 0 and used + free == total and used < 2 * rows
     host.check(dev, nat, 'after the final collection')
