@@ -656,7 +656,7 @@ int gnx_l_tb_from_rows(gnx_state* h, int64_t first, int64_t n, const int32_t* d_
 // tb of this step's offspring from their parents' tb and the paths' path_sel
 int gnx_l_newborn_tb(gnx_state* h, int64_t first_slot, int64_t B);
 // phenotypes of slots [first, first+n) from tb
-int gnx_l_phenotype(gnx_state* h, int64_t first_slot, int64_t n);
+int gnx_l_phenotype(gnx_state* h, int64_t first_slot, int64_t n, const int32_t* d_list = nullptr);
 int gnx_l_assign_genomes(gnx_state* h, const int32_t* d_n_per_site);
 int gnx_l_mutate(gnx_state* h, int n, const int64_t* d_slot, const int32_t* d_locus,
                  const uint8_t* d_hom);

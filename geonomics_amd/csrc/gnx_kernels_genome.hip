@@ -477,20 +477,21 @@ int gnx_l_newborn_tb(gnx_state* h, int64_t first_slot, int64_t B) {
 // ---------------------------------------------------------------- phenotype
 // (gnx_phenotype_tb) of slots [first, first + n)
 __global__ void k_phenotype(int64_t first, int64_t n, int64_t cap, int TW, const u64* tb,
-                            GnxTraitTab T, const uint8_t* dom, float* z) {
+                            GnxTraitTab T, const uint8_t* dom, float* z, const int32_t* list) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
-  const int64_t slot = first + k;
+  const int64_t slot = first + (list ? list[k] : k);
   const uint64_t* t0 = (const uint64_t*)tb + (slot * 2 + 0) * TW;
   gnx_phenotype_tb(t0, t0 + TW, T, dom, cap, slot, z);
 }
 
-int gnx_l_phenotype(gnx_state* h, int64_t first_slot, int64_t n) {
+// d_list: the n slots first_slot + d_list[k] instead of n slots in a row
+int gnx_l_phenotype(gnx_state* h, int64_t first_slot, int64_t n, const int32_t* d_list) {
   if (n == 0 || h->cfg.n_traits == 0) return 0;
   GnxSoA s = h->soa[h->cur];
   gnx_time_begin(h);
   hipLaunchKernelGGL(k_phenotype, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, first_slot, n,
-                     h->cfg.cap_inds, h->TW, (const u64*)s.tb, gnx_trait_tab(h), h->dom, s.z);
+                     h->cfg.cap_inds, h->TW, (const u64*)s.tb, gnx_trait_tab(h), h->dom, s.z, d_list);
   gnx_time_end(h, GNX_K_PHENOTYPE, (double)n * (16.0 * h->TW + 4.0 * h->cfg.n_traits));
   HIPCHK(hipGetLastError());
   return 0;

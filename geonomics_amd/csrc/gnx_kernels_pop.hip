@@ -1959,7 +1959,11 @@ static OffP gnx_make_offp(gnx_state* h, bool genomes, bool tiled, int64_t id_bas
   Q.n_free = h->n_free;
   Q.step = h->step;
   Q.seed = c.seed;
-  Q.fuse_tb = (genomes && !tiled) ? 1 : 0;
+  // (tiles too since round 4: an offspring whose mate is a ghost gets its tables and phenotype
+  // from the mate's resident slot - garbage - and again, from its finished row, once the remote
+  // gamete is in: gnx_tile_finish_births)
+  static const bool tile_fuse = !(getenv("GNX_TILE_FUSE_TB") && atoi(getenv("GNX_TILE_FUSE_TB")) == 0);
+  Q.fuse_tb = (genomes && (!tiled || tile_fuse)) ? 1 : 0;
   Q.TW = h->TW;
   Q.path_sel = h->path_sel;
   Q.dom = h->dom;
@@ -2052,7 +2056,8 @@ int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* 
     // tables; the 25-KB rows are only needed by the NEXT generation's crossover, so on one
     // GPU they are cut after this step's death draws, for the survivors only
     // (gnx_l_mortality), unless somebody asks for them earlier (gnx_xo_join)
-    const bool fused = !inject && !tiled;        // k_offspring did both already
+    static const bool tile_fuse = !(getenv("GNX_TILE_FUSE_TB") && atoi(getenv("GNX_TILE_FUSE_TB")) == 0);
+    const bool fused = !inject && (!tiled || tile_fuse);        // k_offspring did both already
     if (!fused) GNXCHK(gnx_l_newborn_tb(h, h->N, B));
     const bool defer = h->defer_xo && !inject && h->stream2 != nullptr;
     if (defer) {

@@ -598,7 +598,12 @@ static int tile_finish_births(gnx_state* h, int32_t burn, const GnxSetWords* sw)
     // (their rows are complete: the local gametes were cut on this stream, the puts were
     // waited for; no join, the other offspring's crossover stays deferred)
     GNXCHK(gnx_l_tb_from_rows(h, h->birth_first_slot, h->n_req, h->req_k, nullptr, false));
-    GNXCHK(gnx_l_phenotype(h, h->birth_first_slot, B));
+    // (everybody else's phenotype came with k_offspring)
+    static const bool tile_fuse = !(getenv("GNX_TILE_FUSE_TB") && atoi(getenv("GNX_TILE_FUSE_TB")) == 0);
+    if (tile_fuse)
+      GNXCHK(gnx_l_phenotype(h, h->birth_first_slot, h->n_req, h->req_k));
+    else
+      GNXCHK(gnx_l_phenotype(h, h->birth_first_slot, B));
   }
   GnxSoA s = h->soa[h->cur];
   h->last_N_fused = false;
