@@ -4,7 +4,8 @@ tables of the shared genome blocks are sound after a collection (gnx_debug_halve
 level off (no leak), the population stays at its carrying capacity.
     python tools/soak.py [steps] [check every]
 GNX_SOAK_WALK=1: the steps between two checks in one gnx_walk call each (the device-driven step
-where the handle takes it: GNX_SOAK_WORKLOAD=c2 / c3)."""
+where the handle takes it: GNX_SOAK_WORKLOAD=c2 / c3).  GNX_SOAK_TILE=1: every step through
+gnx_tile_step on a 1 x 1 grid (the tile protocol with tile-major offspring ids, one rank)."""
 import os
 import sys
 import time
@@ -25,12 +26,22 @@ import numpy as np                                      # noqa: E402
 n_mut = int(os.environ.get('GNX_SOAK_MUTATE', '0'))    # random mutations per step (copy-on-write)
 rng = np.random.RandomState(1)
 walk = bool(os.environ.get('GNX_SOAK_WALK'))
+tile = bool(os.environ.get('GNX_SOAK_TILE'))
+if tile:
+    from geonomics_amd import _native as nat
+    dev.tile_set(1, 1, 0, 0)
+    dev.comm_init_single()
+    dev.comm_selftest()
+    dev.set_max_id(int(dev.download(nat.F_ID).max()))
 t = 0
 while t < steps:
     if walk:
         k = min(every - (t % every), steps - t)
         dev.walk(k, False, True)
         t += k
+    elif tile:
+        dev.tile_step(False, True, False)
+        t += 1
     else:
         dev.step(False, True)
         t += 1
