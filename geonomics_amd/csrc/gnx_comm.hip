@@ -444,6 +444,10 @@ extern "C" int gnx_comm_selftest(gnx_state* h) {
     return 1;
   }
   HIPCHK(hipSetDevice(h->cfg.device));
+  struct DevBuf {                                   // (freed on every way out)
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+  } b_tail, b_32, b_8, b_sum;
   const int w = c->world, me = c->rank;
   auto fail = [&](const char* what, long long got, long long want) {
     gnx_set_error("gnx_comm_selftest (rank %d of %d): %s: got %lld, expected %lld", me, w, what,
@@ -451,14 +455,13 @@ extern "C" int gnx_comm_selftest(gnx_state* h) {
     return 1;
   };
   // -- gather: three host words and two words a kernel left on the device
-  int32_t* d_tail = nullptr;
-  HIPCHK(hipMalloc((void**)&d_tail, 64));
+  HIPCHK(hipMalloc(&b_tail.p, 64));
+  int32_t* d_tail = (int32_t*)b_tail.p;
   const int32_t tail[2] = {100 + me, 200 + 3 * me};
   HIPCHK(hipMemcpyAsync(d_tail, tail, 8, hipMemcpyHostToDevice, h->stream));
   const int64_t vec[5] = {me, 7LL * me + 1, -(int64_t)me - (1LL << 40), 0, 0};
   std::vector<int64_t> all((size_t)w * 5);
   int rc = host_allgather(h, vec, 5, all.data(), d_tail, 2);
-  HIPCHK(hipFree(d_tail));
   if (rc) return rc;
   for (int r = 0; r < w; ++r) {
     const int64_t want[5] = {r, 7LL * r + 1, -(int64_t)r - (1LL << 40), 100 + r, 200 + 3 * r};
@@ -483,9 +486,9 @@ extern "C" int gnx_comm_selftest(gnx_state* h) {
       s32.push_back(me * 100000 + d * 100 + (int32_t)k);
       s8.push_back((uint8_t)(me * 31 + d * 7 + k));
     }
-  void *d32 = nullptr, *d8 = nullptr;
-  HIPCHK(hipMalloc(&d32, s32.size() * 4));
-  HIPCHK(hipMalloc(&d8, s8.size() + 16));
+  HIPCHK(hipMalloc(&b_32.p, s32.size() * 4));
+  HIPCHK(hipMalloc(&b_8.p, s8.size() + 16));
+  void *d32 = b_32.p, *d8 = b_8.p;
   HIPCHK(hipMemcpyAsync(d32, s32.data(), s32.size() * 4, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(d8, s8.data(), s8.size(), hipMemcpyHostToDevice, h->stream));
   const Part parts[2] = {{d32, 4, RB_KEYS}, {d8, 1, RB_PAD}};
@@ -503,8 +506,6 @@ extern "C" int gnx_comm_selftest(gnx_state* h) {
     HIPCHK(hipMemcpy(r32.data(), c->rbuf[RB_KEYS], r32.size() * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(r8.data(), c->rbuf[RB_PAD], r8.size(), hipMemcpyDeviceToHost));
   }
-  HIPCHK(hipFree(d32));
-  HIPCHK(hipFree(d8));
   if (rc) {
     gnx_set_error("gnx_comm_selftest (rank %d of %d): the exchange failed", me, w);
     return 1;
@@ -518,15 +519,14 @@ extern "C" int gnx_comm_selftest(gnx_state* h) {
         return fail("exchanged byte", r8[at], (uint8_t)(s * 31 + me * 7 + k));
     }
   // -- sum in place
-  int32_t* d_sum = nullptr;
-  HIPCHK(hipMalloc((void**)&d_sum, 8 * 4));
+  HIPCHK(hipMalloc(&b_sum.p, 8 * 4));
+  int32_t* d_sum = (int32_t*)b_sum.p;
   int32_t mine[8], got[8];
   for (int k = 0; k < 8; ++k) mine[k] = me * 10 + k - 3;
   HIPCHK(hipMemcpyAsync(d_sum, mine, sizeof(mine), hipMemcpyHostToDevice, h->stream));
   rc = allreduce_i32(h, d_sum, 8);
   if (!rc && hipMemcpyAsync(got, d_sum, sizeof(got), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = 1;
   if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = 1;
-  HIPCHK(hipFree(d_sum));
   if (rc) {
     gnx_set_error("gnx_comm_selftest (rank %d of %d): the all-reduce failed", me, w);
     return 1;
