@@ -287,4 +287,8 @@ class TiledSpecies(Species):
         return self._stepper.comm.allreduce_sum(a)
 
     def _calc_density(self, normalize=False, as_layer=False, set_N=False):
-        raise NotImplementedError('Species._calc_density on a tiled landscape: use Species.N')
+        """reference structs/species.py:845-882, over the whole landscape: every rank gathers
+        everybody's positions (Species._field does) and evaluates the same density raster on
+        its own device - an observer's call, not part of a step (the step's own density comes
+        from the all-reduced bins)"""
+        return Species._calc_density(self, normalize=normalize, as_layer=as_layer, set_N=set_N)

@@ -51,12 +51,13 @@ ld = _calc_ld(spp, loci=np.arange(0, 48, 3))
 ped_ok = -1
 if spp._tt is not None:        # genotypes read back through the recorded pedigree
     ped_ok = int((spp._tt.genotypes_of(ids) == g).all())
+dens = spp._calc_density()          # (collective on tiles: every rank calls it)
 rank = int(os.environ.get('RANK', '0'))
 if rank == 0:
     np.savez(out, Nt=np.array(spp.Nt), births=np.array(spp.n_births),
              deaths=np.array(spp.n_deaths), nburn=nburn, n_at_assign=n_at_assign,
              site_counts0=g0.sum(axis=(0, 2)), n0=g0.shape[0], ids=ids, xy=xy, g=g, z=z,
-             het=np.asarray(het), K=spp.K, ped_ok=ped_ok, ld=ld, N_rast=spp.N, world=int(os.environ.get('WORLD_SIZE', 1)))
+             het=np.asarray(het), K=spp.K, ped_ok=ped_ok, ld=ld, N_rast=spp.N, dens=dens, world=int(os.environ.get('WORLD_SIZE', 1)))
 import torch.distributed as dist                           # noqa: E402
 if dist.is_initialized():
     dist.barrier()

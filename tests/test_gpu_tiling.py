@@ -337,6 +337,9 @@ def test_model_over_two_ranks_equals_single_process_when_neutral(tmp_path):
         np.testing.assert_array_equal(one[k], two[k], err_msg=k)
     np.testing.assert_array_equal(one['xy'], two['xy'])
     np.testing.assert_allclose(one['N_rast'], two['N_rast'], rtol=1e-12, atol=1e-12)
+    # Species._calc_density over the tiles: everybody's positions, the same raster on every rank
+    np.testing.assert_allclose(one['dens'], two['dens'], rtol=1e-12, atol=1e-12)
+    assert one['dens'].shape == one['N_rast'].shape and one['dens'].max() > 0
     # exact global starting counts: round(2 N p) ones per site (structs/genome.py:1124-1130)
     for r in (one, two):
         assert int(r['n0']) == int(r['n_at_assign'])
