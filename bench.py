@@ -440,7 +440,10 @@ def main():
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         else:
-            dist.init_process_group(backend)
+            # (gloo announces its connections on stdout; this program's stdout is one JSON line)
+            from geonomics_amd.parallel import _StdoutToStderr
+            with _StdoutToStderr():
+                dist.init_process_group(backend)
         # every rank on its own GPU (a launcher that put two ranks on one device would
         # give a number that is not an N-GPU number)
         mine = torch.tensor([local_rank], dtype=torch.int64,

@@ -17,6 +17,7 @@ the CPU rehearsals in tests/ drive the same stepper with the numpy oracle
 individual id and every choice is order-independent, a tiled run reproduces the
 single-tile run bit for bit (tests/test_tiling_cpu.py, tests/test_gpu_tiling.py).
 """
+import os
 import numpy as np
 
 from . import _native as nat
@@ -106,6 +107,33 @@ class DeviceShard:
         self.dev.synchronize()
 
 
+class _StdoutToStderr:
+    """file descriptor 1 points at stderr while the block runs: gloo announces every group it
+    connects on stdout ("[Gloo] Rank 0 is connected to ...", from C++), and a benchmark's stdout
+    is one JSON line"""
+
+    def __enter__(self):
+        import sys
+        try:
+            sys.stdout.flush()
+            self._saved = os.dup(1)
+            os.dup2(2, 1)
+        except OSError:
+            self._saved = None
+        return self
+
+    def __exit__(self, *exc):
+        import sys
+        if self._saved is not None:
+            try:
+                sys.stdout.flush()
+            except Exception:
+                pass
+            os.dup2(self._saved, 1)
+            os.close(self._saved)
+        return False
+
+
 class Comm:
     """Thin layer over torch.distributed: variable-size all-to-all of byte
     buffers by point-to-point messages, all-gather-v and sum all-reduce."""
@@ -142,7 +170,8 @@ class Comm:
                 import torch
                 ok = 1
                 try:
-                    self._hgrp = dist.new_group(backend='gloo')
+                    with _StdoutToStderr():
+                        self._hgrp = dist.new_group(backend='gloo')
                 except Exception:
                     ok = 0
                 flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
