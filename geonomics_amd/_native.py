@@ -57,6 +57,9 @@ EXPORTS = [
     'gnx_stream_ptr', 'gnx_tile2_move_route', 'gnx_tile2_route_ptrs', 'gnx_tile2_import',
     'gnx_tile2_pairs', 'gnx_tile2_offspring', 'gnx_tile2_serve', 'gnx_tile2_put',
     'gnx_tile2_finish_births', 'gnx_tile2_die', 'gnx_tile_pair_ptrs_nosync',
+    'gnx_tile_step_begin', 'gnx_tile_step_births', 'gnx_tile_step_end', 'gnx_comm_probe',
+    'gnx_tile2_pairs_mode', 'gnx_tile2_pairs_settle', 'gnx_tile2_settle_births',
+    'gnx_tile2_vt_counts', 'gnx_tile2_vt_bases',
 ]
 
 
@@ -332,6 +335,11 @@ class Device:
     def set_id_order(self, mode):
         """0: offspring ids in (hash cell, focal id) order (default); 1: virtual-tile-major"""
         self._chk(self.lib.gnx_set_id_order(self.h, int(mode)))
+        self._id_order = int(mode)
+
+    @property
+    def id_order(self):
+        return getattr(self, '_id_order', 0)
 
     def comm_selftest(self):
         """known words through every operation of the transport (collective); raises GnxError"""
@@ -350,7 +358,35 @@ class Device:
         out = np.zeros(3, np.int64)
         self._chk(self.lib.gnx_tile_step(self.h, int(bool(burn)), int(bool(with_selection)),
                                          int(bool(exact)), _ptr(out, C.c_int64)))
+        self._id_order = 1          # (the library numbers a tiled step's offspring tile-major)
         return int(out[0]), int(out[1]), int(out[2])
+
+    def tile_step_begin(self, burn):
+        """the tiled step up to and including the births (gnx_tile_step_begin) -> (first id,
+        number) of the step's offspring over ALL tiles; the host's work on the newborns
+        (mutations, pedigree rows) goes between this and tile_step_end"""
+        self._chk(self.lib.gnx_tile_step_begin(self.h, int(bool(burn))))
+        self._id_order = 1
+        a, b = C.c_int64(), C.c_int64()
+        self._chk(self.lib.gnx_tile_step_births(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def tile_step_end(self, burn, with_selection, exact=True):
+        out = np.zeros(3, np.int64)
+        self._chk(self.lib.gnx_tile_step_end(self.h, int(bool(burn)), int(bool(with_selection)),
+                                             int(bool(exact)), _ptr(out, C.c_int64)))
+        return int(out[0]), int(out[1]), int(out[2])
+
+    def tile2_vt_counts(self):
+        """tile-major offspring ids: this tile's births per virtual tile, int64 [64]"""
+        cnt = np.zeros(64, np.int64)
+        self._chk(self.lib.gnx_tile2_vt_counts(self.h, _ptr(cnt, C.c_int64)))
+        return cnt
+
+    def tile2_vt_bases(self, bases):
+        b = _arr(bases, np.int64)
+        assert b.size == 64
+        self._chk(self.lib.gnx_tile2_vt_bases(self.h, _ptr(b, C.c_int64)))
 
     def step_begin(self, burn):
         self._chk(self.lib.gnx_step_begin(self.h, int(bool(burn))))
@@ -646,8 +682,9 @@ class Device:
         self._chk(self.lib.gnx_set_bins(self.h, int(which), _ptr(b, C.c_int32)))
 
     def tile_offspring(self, burn, id_base, pair_goff):
-        g = _arr(pair_goff, np.int64)
-        assert g.size == self._n_pairs
+        """pair_goff None: tile-major offspring ids (tile2_vt_counts / tile2_vt_bases came first)"""
+        g = None if pair_goff is None else _arr(pair_goff, np.int64)
+        assert g is None or g.size == self._n_pairs
         n = C.c_int64()
         self._chk(self.lib.gnx_tile_offspring(self.h, int(bool(burn)), C.c_int64(int(id_base)),
                                               _ptr(g, C.c_int64), C.byref(n)))
@@ -908,6 +945,14 @@ def comm_unique_id():
     if lib.gnx_comm_unique_id(buf):
         raise GnxError(lib.gnx_last_error().decode())
     return bytes(buf)
+
+
+def comm_probe():
+    """librccl can be loaded and has every entry point the tile transport uses (raises GnxError
+    otherwise): what the ranks agree on BEFORE any of them enters Device.comm_init_rccl"""
+    lib = load()
+    if lib.gnx_comm_probe():
+        raise GnxError(lib.gnx_last_error().decode())
 
 
 def comm_local_create(world):

@@ -527,7 +527,7 @@ extern "C" void gnx_destroy(gnx_state* h) {
   gnx_dd_destroy(h);
   (void)gnx_comm_free(h);
   {
-    void* vt[] = {h->vt_cls, h->vt_rank, h->vt_blk_cnt, h->vt_blk_off, h->vt_count, h->vt_base};
+    void* vt[] = {h->vt_cls, h->vt_rank, h->vt_pblk, h->vt_blk_cnt, h->vt_blk_off, h->vt_count, h->vt_base};
     for (void* q : vt)
       if (q) (void)hipFree(q);
   }
@@ -1121,11 +1121,8 @@ extern "C" int gnx_pop_dynamics_mate(gnx_state* h, int32_t burn) {
   GNXCHK(rc_pairs);
   if (P > 0 && !h->spl_P.valid)
     GNXCHK(gnx_l_density(h, P, h->mid_x, h->mid_y, &h->spl_P, nullptr));
-  if (h->id_order == 1 && P > 0) {
-    GNXCHK(gnx_l_pair_cls(h, P, true));
-    GNXCHK(gnx_l_pair_goff_vt(h, P));
-  }
-  // 3. births: dispersal, crossover, phenotype
+  // 3. births: dispersal, crossover, phenotype (tile-major offspring ids, gnx_set_id_order: the
+  //    pairs' offsets from this device's own counts - gnx_l_mate)
   GNXCHK(gnx_l_mate(h, burn != 0, false, 0, &B));
   h->last_births = B;
   return 0;
@@ -1202,12 +1199,8 @@ extern "C" int gnx_step_mid(gnx_state* h, int32_t burn, int32_t with_selection) 
   GNXCHK(gnx_l_find_pairs_finish(h, &P));
   if (P > 0 && !h->spl_P.valid)
     GNXCHK(gnx_l_density(h, P, h->mid_x, h->mid_y, &h->spl_P, nullptr));
-  // (tile-major offspring ids, gnx_set_id_order: the pairs' offsets from this device's own counts)
-  if (h->id_order == 1 && P > 0) {
-    GNXCHK(gnx_l_pair_cls(h, P, true));
-    GNXCHK(gnx_l_pair_goff_vt(h, P));
-  }
-  // births: dispersal, alleles at the selected loci, phenotype
+  // births: dispersal, alleles at the selected loci, phenotype (tile-major offspring ids,
+  // gnx_set_id_order: the pairs' offsets from this device's own counts - gnx_l_mate)
   GNXCHK(gnx_l_mate(h, burn != 0, false, 0, &B));
   h->last_births = B;
   // N density of everyone incl. offspring (structs/species.py:845-882); d at each

@@ -22,6 +22,8 @@
 // ncclRecv / ncclAllGather / ncclAllReduce calls themselves is the same code.
 #include <dlfcn.h>
 #include <pthread.h>
+#include <unistd.h>
+#include <algorithm>
 #include <chrono>
 #include <mutex>
 #include <condition_variable>
@@ -131,8 +133,12 @@ struct Comm {
   LocalGroup* grp = nullptr;
   void* rbuf[RB_COUNT]{};
   size_t rcap[RB_COUNT]{};
-  int64_t* pin = nullptr;          // pinned host words [2][4096]: vectors out / in
+  int64_t* pin = nullptr;          // pinned host words [2][pin_words]: vectors out / in
   int64_t* pin_dev = nullptr;
+  int64_t pin_words = 0;
+  // between gnx_tile_step_begin and _end (the births' host hooks run there)
+  bool mid = false;
+  int64_t mid_pairs = 0, mid_births = 0;
   int64_t pre = -1;                // global population before the last step's deaths
   int64_t bytes_sent = 0;
   int64_t steps = 0;
@@ -213,6 +219,11 @@ int host_allgather(gnx_state* h, const int64_t* vec, int n, int64_t* out,
     HIPCHK(hipStreamSynchronize(h->stream));          // (`out` is the caller's)
     return 0;
   }
+  if (n_host > c->pin_words || (int64_t)w * n > c->pin_words) {
+    gnx_set_error("tile communicator: a gather of %d x %d words does not fit its %lld pinned words",
+                  w, n, (long long)c->pin_words);
+    return 1;
+  }
   GNXCHK(rb_need(c, RB_VEC_RECV, (size_t)w * n * 8));
   GNXCHK(rb_need(c, RB_VEC_SEND, (size_t)n * 8));
   for (int k = 0; k < n_host; ++k) c->pin[k] = vec[k];
@@ -225,10 +236,10 @@ int host_allgather(gnx_state* h, const int64_t* vec, int n, int64_t* out,
   NCCLCHK(g_rccl.AllGather(c->rbuf[RB_VEC_SEND], c->rbuf[RB_VEC_RECV], (size_t)n, ncclInt64,
                            c->nccl, h->stream));
   hipLaunchKernelGGL(k_copy_i64, dim3((w * n + 63) / 64), dim3(64), 0, h->stream, w * n,
-                     (const int64_t*)c->rbuf[RB_VEC_RECV], c->pin_dev + 4096);
+                     (const int64_t*)c->rbuf[RB_VEC_RECV], c->pin_dev + c->pin_words);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
-  for (int k = 0; k < w * n; ++k) out[k] = c->pin[4096 + k];
+  for (int k = 0; k < w * n; ++k) out[k] = c->pin[c->pin_words + k];
   return 0;
 }
 
@@ -280,31 +291,51 @@ int exchange(gnx_state* h, const Part* parts, int n_parts, const int64_t* mat) {
                               hipMemcpyDeviceToDevice, h->stream));
     return 0;
   }
-  NCCLCHK(g_rccl.GroupStart());
-  int64_t roff = 0, soff = 0;
-  for (int peer = 0; peer < w; ++peer) {
-    const int64_t n_out = mat[(int64_t)me * w + peer], n_from = mat[(int64_t)peer * w + me];
-    for (int k = 0; k < n_parts; ++k) {
-      if (peer == me && !c->forced) {
-        if (n_out > 0)
+  // (what this rank sends itself is a plain copy, outside the group)
+  {
+    int64_t roff = 0, soff = 0;
+    for (int peer = 0; peer < w; ++peer) {
+      const int64_t n_out = mat[(int64_t)me * w + peer], n_from = mat[(int64_t)peer * w + me];
+      if (peer == me && !c->forced && n_out > 0)
+        for (int k = 0; k < n_parts; ++k)
           HIPCHK(hipMemcpyAsync((char*)c->rbuf[parts[k].rb] + roff * parts[k].unit,
                                 (const char*)parts[k].send + soff * parts[k].unit,
                                 (size_t)n_out * parts[k].unit, hipMemcpyDeviceToDevice, h->stream));
-        continue;
-      }
+      soff += n_out;
+      roff += n_from;
+    }
+  }
+  NCCLCHK(g_rccl.GroupStart());
+  // an error between GroupStart and GroupEnd must not leave the group open: the first failure
+  // is remembered, the group is closed, then it is reported
+  ncclResult_t bad = ncclSuccess;
+  const char* what = "";
+  int64_t roff = 0, soff = 0;
+  for (int peer = 0; peer < w && bad == ncclSuccess; ++peer) {
+    const int64_t n_out = mat[(int64_t)me * w + peer], n_from = mat[(int64_t)peer * w + me];
+    for (int k = 0; k < n_parts && bad == ncclSuccess; ++k) {
+      if (peer == me && !c->forced) continue;
       if (n_out > 0) {
-        NCCLCHK(g_rccl.Send((const char*)parts[k].send + soff * parts[k].unit,
-                            (size_t)n_out * parts[k].unit, ncclChar, peer, c->nccl, h->stream));
+        bad = g_rccl.Send((const char*)parts[k].send + soff * parts[k].unit,
+                          (size_t)n_out * parts[k].unit, ncclChar, peer, c->nccl, h->stream);
+        what = "ncclSend";
         c->bytes_sent += n_out * (int64_t)parts[k].unit;
       }
-      if (n_from > 0)
-        NCCLCHK(g_rccl.Recv((char*)c->rbuf[parts[k].rb] + roff * parts[k].unit,
-                            (size_t)n_from * parts[k].unit, ncclChar, peer, c->nccl, h->stream));
+      if (n_from > 0 && bad == ncclSuccess) {
+        bad = g_rccl.Recv((char*)c->rbuf[parts[k].rb] + roff * parts[k].unit,
+                          (size_t)n_from * parts[k].unit, ncclChar, peer, c->nccl, h->stream);
+        what = "ncclRecv";
+      }
     }
     soff += n_out;
     roff += n_from;
   }
-  NCCLCHK(g_rccl.GroupEnd());
+  const ncclResult_t end = g_rccl.GroupEnd();
+  if (bad != ncclSuccess) {
+    gnx_set_error("%s failed: %s (tile exchange)", what, g_rccl.GetErrorString(bad));
+    return 1;
+  }
+  NCCLCHK(end);
   return 0;
 }
 
@@ -336,13 +367,16 @@ int allreduce_i32(gnx_state* h, int32_t* buf, int64_t n) {
   return 0;
 }
 
-int comm_new(gnx_state* h, Comm** out) {
+int comm_new(gnx_state* h, Comm** out, int world) {
   if (h->tile_comm) {
     gnx_set_error("this handle already has a tile communicator");
     return 1;
   }
   Comm* c = new Comm();
-  if (hipHostMalloc((void**)&c->pin, 2 * 4096 * sizeof(int64_t),
+  // the largest gather of a step: every rank's [P, B | 64 virtual-tile counts | world request
+  // counts] (gnx_tile_step), read back as world x that many words
+  c->pin_words = std::max<int64_t>(4096, (int64_t)world * (2 + 64 + world) + 64);
+  if (hipHostMalloc((void**)&c->pin, 2 * c->pin_words * sizeof(int64_t),
                     hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
       hipHostGetDevicePointer((void**)&c->pin_dev, c->pin, 0) != hipSuccess) {
     delete c;
@@ -366,18 +400,98 @@ extern "C" int gnx_comm_unique_id(uint8_t* out128) {
   return 0;
 }
 
+// librccl can be loaded and has every entry point the transport uses: what the ranks tell each
+// other BEFORE any of them enters ncclCommInitRank (a collective nobody can be called back
+// from: a rank that cannot follow would leave the others inside it)
+extern "C" int gnx_comm_probe(void) { return rccl_load(); }
+
+namespace {
+// ncclCommInitRank with a deadline.  The call blocks until every rank has arrived; a rank that
+// died on its way leaves the others inside it for ever.  Past the deadline (GNX_COMM_INIT_TIMEOUT_S,
+// default 180 s) this rank says why and ends the PROCESS with a non-zero code - the call cannot be
+// cancelled, and a process that has touched the GPU must not be replaced by another program.
+struct InitJob {
+  std::mutex mu;
+  std::condition_variable cv;
+  bool done = false;
+  ncclResult_t res = ncclSuccess;
+  ncclComm_t comm = nullptr;
+};
+void* init_thread(void* arg);
+struct InitArgs {
+  InitJob* job;
+  int device, world, rank;
+  ncclUniqueId id;
+};
+void* init_thread(void* arg) {
+  InitArgs* a = (InitArgs*)arg;
+  (void)hipSetDevice(a->device);
+  ncclComm_t comm = nullptr;
+  const ncclResult_t r = g_rccl.CommInitRank(&comm, a->world, a->id, a->rank);
+  {
+    std::lock_guard<std::mutex> lk(a->job->mu);
+    a->job->res = r;
+    a->job->comm = comm;
+    a->job->done = true;
+  }
+  a->job->cv.notify_all();
+  return nullptr;
+}
+}  // namespace
+
 extern "C" int gnx_comm_init_rccl(gnx_state* h, const uint8_t* id128, int32_t rank, int32_t world) {
   GNXCHK(rccl_load());
   HIPCHK(hipSetDevice(h->cfg.device));
+  if (world < 1 || rank < 0 || rank >= world) {
+    gnx_set_error("gnx_comm_init_rccl: rank %d of %d", rank, world);
+    return 1;
+  }
   Comm* c = nullptr;
-  GNXCHK(comm_new(h, &c));
+  GNXCHK(comm_new(h, &c, world));
   c->kind = world > 1 ? COMM_RCCL : COMM_SINGLE;
   c->rank = rank;
   c->world = world;
-  ncclUniqueId id;
-  memcpy(&id, id128, sizeof(id));
   // (a one-rank communicator too: bench.py --gpus 1 goes through the same calls)
-  NCCLCHK(g_rccl.CommInitRank(&c->nccl, world, id, rank));
+  {
+    // (job and args outlive a thread that is left behind past the deadline: never freed then)
+    InitJob* job = new InitJob();
+    InitArgs* args = new InitArgs();
+    args->job = job;
+    args->device = h->cfg.device;
+    args->world = world;
+    args->rank = rank;
+    memcpy(&args->id, id128, sizeof(args->id));
+    pthread_t th;
+    if (pthread_create(&th, nullptr, init_thread, args) != 0) {
+      (void)gnx_comm_free(h);
+      gnx_set_error("gnx_comm_init_rccl: could not start the thread that joins the communicator");
+      return 1;
+    }
+    const char* ts = getenv("GNX_COMM_INIT_TIMEOUT_S");
+    const double limit = ts && atof(ts) > 0 ? atof(ts) : 180.0;
+    std::unique_lock<std::mutex> lk(job->mu);
+    const bool ok = job->cv.wait_for(lk, std::chrono::duration<double>(limit), [&] { return job->done; });
+    if (!ok) {
+      fprintf(stderr,
+              "geonomics_amd: rank %d of %d waited %.0f s inside ncclCommInitRank for the other ranks "
+              "(GNX_COMM_INIT_TIMEOUT_S); a rank must have failed before it got there. Giving up.\n",
+              rank, world, limit);
+      fflush(stderr);
+      _exit(86);
+    }
+    lk.unlock();
+    (void)pthread_join(th, nullptr);
+    const ncclResult_t r = job->res;
+    c->nccl = job->comm;
+    delete job;
+    delete args;
+    if (r != ncclSuccess) {
+      c->nccl = nullptr;
+      gnx_set_error("ncclCommInitRank failed: %s", g_rccl.GetErrorString(r));
+      (void)gnx_comm_free(h);
+      return 1;
+    }
+  }
   const char* f = getenv("GNX_COMM_FORCE_RCCL");
   c->forced = world == 1 && f && f[0] == '1';
   if (world > 1 || c->forced) c->kind = COMM_RCCL;
@@ -386,7 +500,7 @@ extern "C" int gnx_comm_init_rccl(gnx_state* h, const uint8_t* id128, int32_t ra
 
 extern "C" int gnx_comm_init_single(gnx_state* h) {
   Comm* c = nullptr;
-  GNXCHK(comm_new(h, &c));
+  GNXCHK(comm_new(h, &c, 1));
   return 0;
 }
 
@@ -402,7 +516,7 @@ extern "C" int gnx_comm_local_join(gnx_state* h, void* group, int32_t rank) {
     return 1;
   }
   Comm* c = nullptr;
-  GNXCHK(comm_new(h, &c));
+  GNXCHK(comm_new(h, &c, g->world));
   c->kind = g->world > 1 ? COMM_LOCAL : COMM_SINGLE;
   c->rank = rank;
   c->world = g->world;
@@ -447,7 +561,7 @@ extern "C" int gnx_comm_selftest(gnx_state* h) {
   struct DevBuf {                                   // (freed on every way out)
     void* p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
-  } b_tail, b_32, b_8, b_sum;
+  } b_tail, b_32, b_8, b_sum, b_geno;
   const int w = c->world, me = c->rank;
   auto fail = [&](const char* what, long long got, long long want) {
     gnx_set_error("gnx_comm_selftest (rank %d of %d): %s: got %lld, expected %lld", me, w, what,
@@ -518,6 +632,36 @@ extern "C" int gnx_comm_selftest(gnx_state* h) {
       if (r8[at] != (uint8_t)(s * 31 + me * 7 + k))
         return fail("exchanged byte", r8[at], (uint8_t)(s * 31 + me * 7 + k));
     }
+  // -- ... and elements the size of a migrant's genome (16 x W64 bytes: 25 KB at L = 10^5), the
+  //    largest unit the step sends: the same ragged counts, every byte checked
+  {
+    const size_t unit = (size_t)std::max(16 * h->W64, 64);
+    std::vector<uint8_t> sg;
+    for (int d = 0; d < w; ++d)
+      for (int64_t k = 0; k < cnt(me, d); ++k)
+        for (size_t j = 0; j < unit; ++j)
+          sg.push_back((uint8_t)(me * 131 + d * 17 + k * 5 + j * 3 + (j >> 8)));
+    HIPCHK(hipMalloc(&b_geno.p, sg.size() + 16));
+    HIPCHK(hipMemcpyAsync(b_geno.p, sg.data(), sg.size(), hipMemcpyHostToDevice, h->stream));
+    const Part pg[1] = {{b_geno.p, unit, RB_MIG_GENO}};
+    const int64_t sent1 = c->bytes_sent;
+    rc = exchange(h, pg, 1, mat.data());
+    if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = 1;
+    c->bytes_sent = sent1;
+    if (rc) {
+      gnx_set_error("gnx_comm_selftest (rank %d of %d): the exchange of genome-sized elements failed", me, w);
+      return 1;
+    }
+    std::vector<uint8_t> rg((size_t)n_in * unit);
+    HIPCHK(hipMemcpy(rg.data(), c->rbuf[RB_MIG_GENO], rg.size(), hipMemcpyDeviceToHost));
+    size_t pos = 0;
+    for (int sr = 0; sr < w; ++sr)
+      for (int64_t k = 0; k < cnt(sr, me); ++k)
+        for (size_t j = 0; j < unit; ++j, ++pos) {
+          const uint8_t want = (uint8_t)(sr * 131 + me * 17 + k * 5 + j * 3 + (j >> 8));
+          if (rg[pos] != want) return fail("exchanged genome-sized element, byte", rg[pos], want);
+        }
+  }
   // -- sum in place
   HIPCHK(hipMalloc(&b_sum.p, 8 * 4));
   int32_t* d_sum = (int32_t*)b_sum.p;
@@ -548,28 +692,42 @@ extern "C" int64_t gnx_comm_bytes_sent(gnx_state* h) {
 }
 
 // ---------------------------------------------------------------- the step
+// [req counts | pair count] behind the 64 virtual-tile counts of h->vt_count: one device vector
+// for the second count exchange
+__global__ void k_tail_assemble(int T, const int32_t* __restrict__ req, int have_req,
+                                const int32_t* __restrict__ P_src, int32_t* __restrict__ dst) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < T) dst[k] = have_req ? req[k] : 0;
+  if (k == T) dst[T] = *P_src;
+}
+
 // One time step of this tile (gnx_tile_set) and, through the communicator, of the whole
-// tiled landscape: age + movement, routing of emigrants and ghosts, ONE batch of neighbour
-// sends, import, cell sort + mate search + pairs, global offspring offsets, births, gamete
-// service for ghost mates, ONE all-reduce of both density fields and the counters, densities,
-// death probabilities, mortality.  out[3]: exact != 0 -> the global (N after the step, births,
-// deaths) at the price of one more KB-sized collective; else the counts that rode on the
-// step's own all-reduce: (N at the START of the step, births, deaths of the PREVIOUS step).
-extern "C" int gnx_tile_step(gnx_state* h, int32_t burn, int32_t with_selection, int32_t exact,
-                             int64_t* out) {
+// tiled landscape, in two calls (gnx_tile_step = both):
+//   gnx_tile_step_begin: age + movement, routing of emigrants and ghosts, ONE batch of neighbour
+//     sends, import, cell sort + mate search + pairs, global offspring offsets, births, gamete
+//     service for ghost mates - every offspring of the step has its record, its alleles at the
+//     selected loci and its phenotype when it returns; what the host does to the newborns (the
+//     reference's mutation and pedigree recording, ops/mutation.py:169-206, structs/species.py:
+//     692-736, sit between the births and the deaths of _do_pop_dynamics) runs between the calls;
+//   gnx_tile_step_end: ONE all-reduce of both density fields and the counters, densities, death
+//     probabilities, mortality.  out[3]: exact != 0 -> the global (N after the step, births,
+//     deaths) at the price of one more KB-sized collective; else the counts that rode on the
+//     step's own all-reduce: (N at the START of the step, births, deaths of the PREVIOUS step).
+// Host waits per step on several tiles: the two count exchanges (the pair count rides on the
+// second one when every pair has the same number of births) and the survivor count.
+extern "C" int gnx_tile_step_begin(gnx_state* h, int32_t burn) {
   Comm* c = comm_of(h);
   if (!c) {
     gnx_set_error("gnx_tile_step: no communicator (gnx_comm_init_rccl / _single / gnx_comm_local_join)");
     return 1;
   }
+  if (c->mid) {
+    gnx_set_error("gnx_tile_step_begin: the previous step was not finished (gnx_tile_step_end)");
+    return 1;
+  }
   if (!h->have_sp) {
     gnx_set_error("species parameters not set");
     return 1;
-  }
-  if (!h->sp.n_births_fixed) {
-    gnx_set_error("gnx_tile_step: Poisson births travel with the pair keys through the host layer "
-                  "(TiledStepper, GNX_TILE_V3=0)");
-    return 3;
   }
   const int w = c->world, me = c->rank, T = h->tile_R * h->tile_C;
   if (T != w) {
@@ -582,8 +740,13 @@ extern "C" int gnx_tile_step(gnx_state* h, int32_t burn, int32_t with_selection,
                   h->tile_R, h->tile_C, h->cfg.W, h->cfg.H);
     return 3;
   }
+  // offspring ids virtual tile by virtual tile (gnx_set_id_order 1, gnx_kernels_pop.hip): a tile
+  // owns whole virtual tiles, the rank of a pair inside its virtual tile is a local matter, and
+  // the 64 birth counts per virtual tile ride on the count exchange
+  if (h->id_order != 1) GNXCHK(gnx_set_id_order(h, 1));
   const int nt = h->cfg.n_traits, W64 = h->W64;
   const bool geno = h->genomes_assigned && h->cfg.L > 0;
+  const bool fixed = h->sp.n_births_fixed != 0;
   // (gnx_totals: THIS tile's own individuals, births and deaths, as gnx_step counts them)
   h->tot[0] += 1;
   h->tot[1] += h->N - h->n_ghost;
@@ -621,55 +784,63 @@ extern "C" int gnx_tile_step(gnx_state* h, int32_t burn, int32_t with_selection,
     GNXCHK(gnx_tile2_import(h, in_mig, c->rbuf[RB_MIG_REC], nt ? c->rbuf[RB_MIG_Z] : nullptr,
                             geno ? c->rbuf[RB_MIG_GENO] : nullptr, in_gh, c->rbuf[RB_GHOST]));
   }
-  // 2. pairs (wait 2: the pair count); the gamete-request counts and the virtual tiles' birth
-  //    counts stay on the device and travel with ONE count exchange
+  // 2. pairs; the gamete-request counts, the virtual tiles' birth counts and - a fixed number of
+  //    births per pair - the pair count itself stay on the device and travel with ONE count
+  //    exchange (Poisson births, one tile: the pair count is waited for)
   std::vector<int64_t> pc(2 + T);
   void* d_req = nullptr;
+  const bool nowait = w > 1 && fixed;
   GNXCHK(gnx_tile2_requests_dev(h, w > 1 ? 1 : 0, &d_req));
+  GNXCHK(gnx_tile2_pairs_mode(h, nowait ? 1 : 0));
   const int rc_pairs = gnx_tile2_pairs(h, burn, pc.data());
+  GNXCHK(gnx_tile2_pairs_mode(h, 0));
   GNXCHK(gnx_tile2_requests_dev(h, 0, nullptr));      // (the Python-driven protocol waits for them)
   GNXCHK(rc_pairs);
-  const int64_t P = pc[0], B = pc[1];
+  int64_t P = pc[0], B = pc[1];
   int64_t total_births = B, total_pairs = P;
   std::vector<int64_t> m_req((size_t)w * w, 0);
-  // Offspring ids are handed out virtual tile by virtual tile (gnx_set_id_order 1,
-  // gnx_kernels_pop.hip): a tile owns whole virtual tiles, the rank of a pair inside its virtual
-  // tile is a local matter, and the 64 birth counts per virtual tile ride on the count exchange -
-  // round 3 all-gathered every pair's order key for this (1.8 MB per rank at C5)
-  GNXCHK(gnx_l_pair_cls(h, P, w == 1));
+  // (P < 0: not known on the host yet - the classification was k_pair_compact's, by slots)
+  GNXCHK(gnx_l_pair_cls(h, nowait ? -1 : P, w == 1));
   if (w > 1) {
-    // [P, B | 64 virtual-tile counts | T request counts]: the last two from device memory
+    // [B | 64 virtual-tile counts | T request counts | P]: all but the first from device memory
     const bool have_req = h->n_req_known == -2;
-    hipLaunchKernelGGL(k_copy_i32, dim3((T + 63) / 64), dim3(64), 0, h->stream, T,
-                       (const int32_t*)d_req, h->vt_count + 64, have_req ? 0 : 1);
-    const int cs = 2 + 64 + T;
+    hipLaunchKernelGGL(k_tail_assemble, dim3((T + 64) / 64), dim3(64), 0, h->stream, T,
+                       (const int32_t*)d_req, have_req ? 1 : 0, (const int32_t*)h->cnt_dev,
+                       h->vt_count + 64);
+    const int cs = 1 + 64 + T + 1;
     std::vector<int64_t> g2((size_t)w * cs);
-    GNXCHK(host_allgather(h, pc.data(), cs, g2.data(), (const int32_t*)h->vt_count, 64 + T));
+    const int64_t mine_b = B;
+    GNXCHK(host_allgather(h, &mine_b, cs, g2.data(), (const int32_t*)h->vt_count, 64 + T + 1));
+    if (nowait) {
+      // this tile's own pair count has arrived with everybody's: the bookkeeping gnx_tile2_pairs
+      // left open
+      P = g2[(size_t)me * cs + 1 + 64 + T];
+      GNXCHK(gnx_tile2_pairs_settle(h, burn, P, &B));
+    }
     total_births = total_pairs = 0;
     std::vector<int64_t> vt(64, 0);
     for (int r = 0; r < w; ++r) {
-      total_pairs += g2[(size_t)r * cs];
-      total_births += g2[(size_t)r * cs + 1];
-      for (int q = 0; q < 64; ++q) vt[q] += g2[(size_t)r * cs + 2 + q];
-      for (int d = 0; d < w; ++d) m_req[(size_t)r * w + d] = g2[(size_t)r * cs + 2 + 64 + d];
+      const int64_t Pr = g2[(size_t)r * cs + 1 + 64 + T];
+      total_pairs += Pr;
+      total_births += fixed ? Pr * (int64_t)h->sp.n_births_lambda : g2[(size_t)r * cs];
+      for (int q = 0; q < 64; ++q) vt[q] += g2[(size_t)r * cs + 1 + q];
+      for (int d = 0; d < w; ++d) m_req[(size_t)r * w + d] = g2[(size_t)r * cs + 1 + 64 + d];
     }
     GNXCHK(gnx_tile2_set_requests(h, &m_req[(size_t)me * w]));
     // the virtual tiles' base offsets, in births: an exclusive scan of 64 numbers, the same on
     // every rank; to the device through pinned memory
     int64_t run = 0;
     for (int q = 0; q < 64; ++q) {
-      c->pin[q] = run * (int64_t)h->sp.n_births_lambda;
+      c->pin[q] = run * h->vt_mul;
       run += vt[q];
     }
     hipLaunchKernelGGL(k_copy_i64, dim3(1), dim3(64), 0, h->stream, 64, (const int64_t*)c->pin_dev,
                        h->vt_base);
     HIPCHK(hipGetLastError());
   }
-  GNXCHK(gnx_l_pair_goff_vt(h, P));
-  const void* goff = P > 0 ? (const void*)h->pair_goff : nullptr;
   void* p_req = nullptr;
   const int64_t id_base = h->max_id + 1;        // (the global maximum: every rank keeps it)
-  GNXCHK(gnx_tile2_offspring(h, burn, id_base, goff, &p_req));
+  GNXCHK(gnx_tile2_offspring(h, burn, id_base, nullptr, &p_req));
   GNXCHK(gnx_set_max_id(h, id_base - 1 + total_births));
   // gametes of ghost mates: requests out, gametes back
   if (w > 1 && !burn && geno) {
@@ -687,14 +858,44 @@ extern "C" int gnx_tile_step(gnx_state* h, int32_t burn, int32_t with_selection,
     GNXCHK(exchange(h, &gm, 1, m_back.data()));
     if (n_req) GNXCHK(gnx_tile2_put(h, n_req, c->rbuf[RB_GAMETES]));
   }
+  // the offspring that took a remote gamete: their alleles at the selected loci and their
+  // phenotype from their finished rows (everybody else's came with the births)
+  GNXCHK(gnx_tile2_settle_births(h, burn));
+  c->mid = true;
+  c->mid_pairs = total_pairs;
+  c->mid_births = total_births;
+  return 0;
+}
+
+// first id and number of the offspring of ALL tiles in the step between _begin and _end
+extern "C" int gnx_tile_step_births(gnx_state* h, int64_t* first_id, int64_t* total) {
+  Comm* c = comm_of(h);
+  if (!c || !c->mid) {
+    gnx_set_error("gnx_tile_step_births: between gnx_tile_step_begin and gnx_tile_step_end");
+    return 1;
+  }
+  *total = c->mid_births;
+  *first_id = h->max_id - c->mid_births + 1;
+  return 0;
+}
+
+extern "C" int gnx_tile_step_end(gnx_state* h, int32_t burn, int32_t with_selection, int32_t exact,
+                                 int64_t* out) {
+  Comm* c = comm_of(h);
+  if (!c || !c->mid) {
+    gnx_set_error("gnx_tile_step_end: no step was begun (gnx_tile_step_begin)");
+    return 1;
+  }
+  c->mid = false;
+  const int w = c->world;
   void* red = nullptr;
   int64_t n_words = 0;
   GNXCHK(gnx_tile2_finish_births(h, burn, &red, &n_words));
   // ONE all-reduce: both density fields and the counters
   GNXCHK(allreduce_i32(h, (int32_t*)red, n_words));
-  // 3. densities, death probabilities, mortality (wait 3)
+  // 3. densities, death probabilities, mortality (the survivor count is waited for)
   int64_t tot[3] = {0, 0, 0};
-  GNXCHK(gnx_tile2_die(h, burn, with_selection, total_pairs > 0 ? 1 : 0, tot));
+  GNXCHK(gnx_tile2_die(h, burn, with_selection, c->mid_pairs > 0 ? 1 : 0, tot));
   h->tot[2] += h->last_births;
   h->tot[3] += h->last_deaths;
   if (!burn) h->tot[4] += h->last_xo_births;
@@ -723,4 +924,10 @@ extern "C" int gnx_tile_step(gnx_state* h, int32_t burn, int32_t with_selection,
   out[2] = d_prev;
   c->pre = n_pre;
   return 0;
+}
+
+extern "C" int gnx_tile_step(gnx_state* h, int32_t burn, int32_t with_selection, int32_t exact,
+                             int64_t* out) {
+  GNXCHK(gnx_tile_step_begin(h, burn));
+  return gnx_tile_step_end(h, burn, with_selection, exact, out);
 }

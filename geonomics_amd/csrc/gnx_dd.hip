@@ -62,7 +62,9 @@ bool gnx_dd_eligible(const gnx_state* h, bool burn) {
   if (sp.mating_radius < 0 || !sp.n_births_fixed || !sp.move) return false;
   if (!h->ord_mode || h->key_bits > 24 || !h->compact_fill || !h->defer_xo) return false;
   if (!h->stream2 || !h->stream3 || !gnx_fused_bins(h)) return false;
-  if (h->NB > GNX_MAX_NB || h->n_ghost != 0 || h->id_order != 0) return false;
+  // (tile-major offspring ids - gnx_set_id_order(1), the Model API's default - ride along: the
+  // classification inside k_pair_compact, one more node for the blocks' offsets)
+  if (h->NB > GNX_MAX_NB || h->n_ghost != 0) return false;
   if (h->cfg.cap_inds >= (1ll << 30)) return false;
   if (h->xo_launch_policy != 0 || h->xo_split != 0) return false;
   (void)burn;
@@ -526,7 +528,16 @@ extern "C" int gnx_walk_many(gnx_state** hs, int32_t n, int64_t T, int32_t burn,
       hs[k]->dd_hist.push_back(hs[k]->last_deaths);
     }
     dd[k] = ok && left[k] > 0;
-    if (dd[k]) GNXCHK(dd_enter(hs[k]));
+    if (dd[k]) {
+      const int rc_enter = dd_enter(hs[k]);
+      if (rc_enter) {
+        // the handles entered so far go back to their host-driven state before the error leaves
+        dd[k] = 0;
+        for (int q = 0; q < k; ++q)
+          if (dd[q]) (void)gnx_dd_leave(hs[q]);
+        return rc_enter;
+      }
+    }
   }
   int rc = 0;
   for (bool any = true; any && !rc;) {

@@ -202,6 +202,17 @@ __device__ __forceinline__ int64_t gnx_dd_nb(const GnxDD* dd, int64_t n) {
 __device__ __forceinline__ long long gnx_dd_step(const GnxDD* dd, long long s) {
   return dd ? (long long)dd->step : s;
 }
+// Which of n equal stretches of tw raster cells coordinate v falls in.  EXACT on the integer
+// boundaries k * tw: a reciprocal (v * (n / W)) puts the float just below a boundary on the
+// wrong side whenever n / W is not a power of two (W = 1000: x = 499.99997 -> stretch 4 of 8) -
+// tile ownership, the routing and the virtual tiles of the offspring ids all use this one.
+__device__ __forceinline__ int gnx_tile_index(float v, int tw, int n) {
+  int c = (int)(v / (float)tw);
+  c = max(0, min(n - 1, c));
+  while (c + 1 < n && (float)((c + 1) * tw) <= v) ++c;     // exact: boundaries are integers
+  while (c > 0 && (float)(c * tw) > v) --c;
+  return c;
+}
 #endif
 
 #define GNX_MAX_TILES 4096
@@ -346,10 +357,13 @@ struct gnx_state {
   // tile-major offspring ids (gnx_set_id_order, gnx_kernels_pop.hip): virtual tile and in-tile
   // rank of every pair, per-block and total counts per virtual tile, the tiles' base offsets
   int id_order = 0;
-  bool pair_goff_ready = false;   // pair_goff holds this step's offsets (reset by the births)
+  bool pair_goff_ready = false;   // the tile-major pieces below hold this step's offsets (reset by the births)
   bool pair_goff_local_base = false;   // ... numbered from this device's own counts alone
+  bool vt_fused = false;          // k_pair_compact classified this step's pairs (fixed births)
+  int64_t vt_mul = 1;             // births per unit of vt_rank / vt_count: lambda, or 1 (Poisson)
   uint8_t* vt_cls = nullptr;
-  int32_t *vt_rank = nullptr, *vt_blk_cnt = nullptr, *vt_blk_off = nullptr, *vt_count = nullptr;
+  int32_t *vt_rank = nullptr, *vt_pblk = nullptr, *vt_blk_cnt = nullptr, *vt_blk_off = nullptr,
+          *vt_count = nullptr;
   int64_t* vt_base = nullptr;
   int64_t n_births_pending = 0;  // births of the current pair list
   // gamete requests (tiled runs)
@@ -401,6 +415,8 @@ struct gnx_state {
   std::vector<int64_t> req_by_rank;  // gamete requests per owning rank (gnx_tile2_pairs)
   bool rq_is2 = false;               // rq_sorted holds 24-byte gnx_gamete_req2 records
   bool tile_req_on_device = false;   // gnx_tile2_pairs leaves the request counts in route_cnt (no wait)
+  bool tile_pairs_nowait = false;    // ... and does not wait for the pair count either (gnx_tile_step)
+  bool tile_births_settled = false;  // the offspring with a remote gamete have re-read their rows
 
   // pairing / mating scratch (capacity cap_inds)
   int32_t* mate = nullptr;
@@ -617,7 +633,6 @@ int gnx_l_find_pairs_enqueue(gnx_state* h, const uint8_t* d_keep, bool with_dens
 int gnx_l_find_pairs_finish(gnx_state* h, int64_t* n_pairs_out);
 int gnx_l_births(gnx_state* h, int64_t* births_out);
 int gnx_l_pair_cls(gnx_state* h, int64_t P, bool local);
-int gnx_l_pair_goff_vt(gnx_state* h, int64_t P);
 int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* births_out,
                int64_t id_base = -1, bool tiled = false);
 int gnx_l_dispersal_inject(gnx_state* h, int64_t B, int A, const float* d_mx, const float* d_my,

@@ -1452,6 +1452,10 @@ struct GnxOrdF {
   int32_t* cnt;
   GnxScanOut S;
   int64_t ord_n;               // entries of the index (host-driven step; the device block's else)
+  // device-driven step with tile-major offspring ids: k_offspring filed this step's newborns
+  // behind the index itself (their ids do not ascend with their slots) - every one of the
+  // N + B entries is explicit
+  int tail_explicit;
 };
 __device__ __forceinline__ void gnx_ord_flags_body(int64_t N, int64_t ord_n, const GnxOrdF& F,
                                                    int* lds, int* lds2) {
@@ -1546,7 +1550,8 @@ k_fill_lists(int64_t N, const int32_t* __restrict__ alive, const int32_t* __rest
   // need the death draws)
   if (ordf.ord) {
     __syncthreads();
-    gnx_ord_flags_body(N, dd ? (int64_t)dd->ord_n : ordf.ord_n, ordf, lds, lds2);
+    gnx_ord_flags_body(N, dd ? (ordf.tail_explicit ? N : (int64_t)dd->ord_n) : ordf.ord_n, ordf,
+                       lds, lds2);
   }
 }
 
@@ -1687,18 +1692,19 @@ k_ord_flags(int64_t N, int64_t ord_n, const int32_t* __restrict__ ord,
     N = (int64_t)dd->N + dd->B;
     ord_n = dd->ord_n;
   }
-  gnx_ord_flags_body(N, ord_n, GnxOrdF{ord, newslot, nullptr, cnt, S, ord_n}, lds, lds2);
+  gnx_ord_flags_body(N, ord_n, GnxOrdF{ord, newslot, nullptr, cnt, S, ord_n, 0}, lds, lds2);
 }
 
 __global__ void __launch_bounds__(256)
 k_ord_write(int64_t N, int64_t ord_n, const int32_t* __restrict__ ord,
             const int32_t* __restrict__ newslot, const int32_t* __restrict__ off,
-            int32_t* __restrict__ ord_new, const GnxDD* __restrict__ dd, GnxDDEnd E) {
+            int32_t* __restrict__ ord_new, const GnxDD* __restrict__ dd, GnxDDEnd E,
+            int tail_explicit) {
   __shared__ int lds[16];
   __shared__ int last_s;
   if (dd) {
     N = (int64_t)dd->N + dd->B;
-    ord_n = dd->ord_n;
+    ord_n = tail_explicit ? N : (int64_t)dd->ord_n;
   }
   const int64_t base = (int64_t)blockIdx.x * GNX_CB;
   bool f[4];
@@ -1811,7 +1817,7 @@ int gnx_l_mortality_enqueue(gnx_state* h, const uint8_t* d_dead_inject) {
                        (const GnxDD*)nullptr,
                        ord_fused ? GnxOrdF{h->ord[h->ord_cur], nullptr, h->flag, h->ord_cnt,
                                            GnxScanOut{h->ord_off, nullptr, nullptr, 0, nullptr,
-                                                      h->tickets + 2, h->blk_stride}, h->ord_n}
+                                                      h->tickets + 2, h->blk_stride}, h->ord_n, 0}
                                  : GnxOrdF{});
     HIPCHK(hipEventRecord(h->ev_fill, h->stream3));
   }
@@ -1856,7 +1862,7 @@ int gnx_l_mortality_enqueue(gnx_state* h, const uint8_t* d_dead_inject) {
                          h->ord[h->ord_cur], h->newslot, h->ord_cnt, So, (const GnxDD*)nullptr);
     hipLaunchKernelGGL(k_ord_write, dim3(nb), dim3(256), 0, h->stream3, N, h->ord_n,
                        h->ord[h->ord_cur], h->newslot, h->ord_off, h->ord[h->ord_cur ^ 1],
-                       (const GnxDD*)nullptr, GnxDDEnd{});
+                       (const GnxDD*)nullptr, GnxDDEnd{}, 0);
     // the cell sort waits for the crossover AND for this: stream3 waits for the crossover here,
     // where nothing waits for stream3, and the sort's stream waits for one event instead of two
     h->ord_covers_xo = false;
@@ -2005,7 +2011,7 @@ int gnx_dd_l_fill_lists(gnx_state* h, int has_rows, hipStream_t st) {
                      (int32_t*)h->os_vtmp, h->newslot, h->fill_cnt, (const GnxDD*)h->dd,
                      GnxOrdF{h->ord[h->ord_cur], nullptr, h->flag, h->ord_cnt,
                              GnxScanOut{h->ord_off, nullptr, nullptr, 0, nullptr, h->tickets + 2,
-                                        h->blk_stride}, 0});
+                                        h->blk_stride}, 0, (h->vt_fused && h->id_order == 1) ? 1 : 0});
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -2033,7 +2039,7 @@ int gnx_dd_l_ord_end(gnx_state* h, int has_rows, bool xo, hipStream_t st) {
                      h->ord[h->ord_cur], h->newslot, h->ord_off, h->ord[h->ord_cur ^ 1],
                      (const GnxDD*)h->dd,
                      GnxDDEnd{h->dd, h->cnt_dev, h->half_top, h->dd_ring_dev, has_rows, xo ? 1 : 0,
-                              h->tickets + 4});
+                              h->tickets + 4}, (h->vt_fused && h->id_order == 1) ? 1 : 0);
   HIPCHK(hipGetLastError());
   h->ord_cur ^= 1;
   return 0;

@@ -1272,6 +1272,246 @@ k_pair_flags(PairP P, GnxSoA s, int32_t* flag2, int32_t* cnt) {
   if (threadIdx.x == 0) cnt[blockIdx.x] = tot;
 }
 
+// ---------------------------------------------------------------- offspring ids, tile-major
+// gnx_set_id_order(h, 1): offspring ids are handed out virtual tile by virtual tile - a fixed
+// 8 x 8 blocking of the landscape that every tile grid dividing 8 x 8 is a union of - and
+// inside a virtual tile in the canonical (hash cell, focal id) order of the pairs.  A tile of a
+// tiled run owns whole virtual tiles, so the rank of a pair inside its virtual tile is the
+// same number on the tile and on one device, and the only thing the tiles have to tell each
+// other is how many births each virtual tile has: 64 counts that ride on the count exchange,
+// instead of an all-gather of every pair's order key (gnx_comm.hip; VERDICT r3 #1b).
+// Round 5: the Model API numbers its offspring this way on ONE device too (whenever the
+// landscape's dimensions are divisible by 8), so that a model run over several ranks equals the
+// one-process run id by id; to make that cheap the classification rides inside k_pair_compact
+// (class and in-block rank of every pair, per-block counts per class: blocks of 1024 SLOTS), one
+// small kernel scans the blocks' counts (k_cls_scan) and k_offspring adds the three numbers up
+// itself - round 4 ran three kernels of their own on the step's chain (k_pair_cls, k_cls_scan,
+// k_goff_vt).  Poisson births (ops/mating.py:120-126): the ranks are in BIRTHS, not in pairs -
+// k_pair_cls below, weighted by the pairs' birth counts, once those are drawn.
+#define GNX_VT 8
+#define GNX_VTN (GNX_VT * GNX_VT)
+
+struct GnxVtP {
+  int vw, vh;                 // raster cells per virtual tile: W / 8, H / 8 (exact: gnx_set_id_order)
+};
+__device__ __forceinline__ int gnx_vt_of(const GnxVtP& V, float x, float y) {
+  // (exact on the integer boundaries, like tile ownership: gnx_tile_index)
+  return gnx_tile_index(y, V.vh, GNX_VT) * GNX_VT + gnx_tile_index(x, V.vw, GNX_VT);
+}
+
+// what k_pair_compact leaves per pair when ids are tile-major (cls == null: nothing)
+struct GnxVtOut {
+  uint8_t* cls;               // virtual tile of the pair (by its focal individual's position)
+  int32_t* rank;              // pairs of the same virtual tile before it in its block
+  int32_t* pblk;              // the block
+  int32_t* blk_cnt;           // [blocks][64] pairs per virtual tile
+  GnxVtP V;
+};
+
+// One round of 256 items: the class ranks inside the wave and the wave's count per class.
+// The lanes of a wave are neighbours in the canonical order: one or two virtual tiles per wave.
+// WEIGHTED: ranks and counts in units of w (births), else in items (pairs).
+template <bool WEIGHTED>
+__device__ __forceinline__ void gnx_vt_wave_ranks(bool act, int c, int w, int lane, int* cnt_row,
+                                                  int& rw) {
+  unsigned long long todo = __ballot(act);
+  rw = 0;
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int lc = __shfl(c, leader);
+    const bool mine = act && c == lc;
+    const unsigned long long same = __ballot(mine);
+    if (WEIGHTED) {
+      int x = mine ? w : 0;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+      }
+      const int tot = __shfl(x, 63);
+      if (mine) rw = x - w;
+      if (lane == leader) cnt_row[lc] = tot;
+    } else {
+      if (mine) rw = __popcll(same & ((1ull << lane) - 1ull));
+      if (lane == leader) cnt_row[lc] = __popcll(same);
+    }
+    todo &= ~same;
+  }
+}
+
+// Poisson births: the virtual tile of every pair, its rank IN BIRTHS among the pairs of the same
+// virtual tile inside its block of 1024 pairs, and the block's births per virtual tile.
+// P: the pair count, or read from P_dev.
+__global__ void __launch_bounds__(256)
+k_pair_cls(int64_t P, const int32_t* __restrict__ P_dev, const int32_t* __restrict__ pairs,
+           const float* __restrict__ x, const float* __restrict__ y,
+           const int32_t* __restrict__ nbirths, GnxVtP V, uint8_t* __restrict__ cls,
+           int32_t* __restrict__ rank, int32_t* __restrict__ pblk, int32_t* __restrict__ blk_cnt) {
+  __shared__ int cnt[16][GNX_VTN];
+  if (P_dev) P = *P_dev;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int k = tid; k < 16 * GNX_VTN; k += 256) (&cnt[0][0])[k] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * GNX_CB;
+  int c[4], rw[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t p = base + r * 256 + tid;
+    const bool act = p < P;
+    c[r] = GNX_VTN;
+    int w = 0;
+    if (act) {
+      const int fo = pairs[2 * p];
+      c[r] = gnx_vt_of(V, x[fo], y[fo]);
+      w = nbirths[p];
+    }
+    gnx_vt_wave_ranks<true>(act, c[r], w, lane, cnt[r * 4 + wave], rw[r]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t p = base + r * 256 + tid;
+    if (p >= P) continue;
+    int before = 0;
+    for (int j = 0; j < r * 4 + wave; ++j) before += cnt[j][c[r]];
+    cls[p] = (uint8_t)c[r];
+    rank[p] = before + rw[r];
+    pblk[p] = (int32_t)blockIdx.x;
+  }
+  if (tid < GNX_VTN) {
+    int t = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += cnt[j][tid];
+    blk_cnt[(int64_t)blockIdx.x * GNX_VTN + tid] = t;
+  }
+}
+
+// per virtual tile (one lane each) the exclusive offsets of the blocks' counts and the total:
+// the 16 waves of the workgroup take a stretch of the blocks each, the stretches' totals meet in
+// LDS; with `local` the virtual tiles' base offsets too (one device: nobody else has pairs), in
+// births.  n_dev / dd: the item count (pairs, or slots: blocks of 1024 of them) on the device.
+__global__ void __launch_bounds__(1024)
+k_cls_scan(int nb, const int32_t* __restrict__ n_dev, const GnxDD* __restrict__ dd,
+           const int32_t* __restrict__ blk_cnt, int32_t* __restrict__ blk_off,
+           int32_t* __restrict__ vt_count, int64_t* __restrict__ vt_base, int local, int64_t lam) {
+  __shared__ int seg_tot[16][GNX_VTN];
+  const int c = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (n_dev) nb = (int)(((int64_t)*n_dev + GNX_CB - 1) / GNX_CB);
+  if (dd) nb = (int)(((int64_t)dd->N + GNX_CB - 1) / GNX_CB);
+  const int seg = (nb + 15) / 16;
+  const int b0 = wave * seg, b1 = min(nb, b0 + seg);
+  int run = 0;
+  for (int b = b0; b < b1; ++b) run += blk_cnt[(int64_t)b * GNX_VTN + c];
+  seg_tot[wave][c] = run;
+  __syncthreads();
+  int before = 0, total = 0;
+  for (int w = 0; w < 16; ++w) {
+    const int t = seg_tot[w][c];
+    before += w < wave ? t : 0;
+    total += t;
+  }
+  run = before;
+  for (int b = b0; b < b1; ++b) {
+    const int v = blk_cnt[(int64_t)b * GNX_VTN + c];
+    blk_off[(int64_t)b * GNX_VTN + c] = run;
+    run += v;
+  }
+  if (wave != 0) return;
+  vt_count[c] = total;
+  if (local) {
+    int xs = total;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int yv = __shfl_up(xs, d);
+      if (c >= d) xs += yv;
+    }
+    vt_base[c] = (int64_t)(xs - total) * lam;
+  }
+}
+
+// how k_offspring finds a pair's global offspring offset: handed in pair by pair (the
+// Python-driven tile protocol with (hash cell, focal id) ids), or tile-major from the pieces
+// above: vt_base[class] + (blk_off[block][class] + rank) * mul, or - all null - the pair's own
+// offset on this device
+struct GnxGoff {
+  const int64_t* goff;
+  const uint8_t* cls;
+  const int32_t* rank;
+  const int32_t* pblk;
+  const int32_t* blk_off;
+  const int64_t* vt_base;
+  int64_t mul;                // births per unit of rank: lambda (fixed births), 1 (Poisson)
+};
+
+static int vt_buffers(gnx_state* h) {
+  if (h->vt_cls) return 0;
+  const size_t cap = (size_t)h->cfg.cap_inds;
+  const size_t nb = cap / GNX_CB + 2;
+  HIPCHK(hipMalloc((void**)&h->vt_cls, cap));
+  HIPCHK(hipMalloc((void**)&h->vt_rank, cap * sizeof(int32_t)));
+  HIPCHK(hipMalloc((void**)&h->vt_pblk, cap * sizeof(int32_t)));
+  HIPCHK(hipMalloc((void**)&h->vt_blk_cnt, nb * GNX_VTN * sizeof(int32_t)));
+  HIPCHK(hipMalloc((void**)&h->vt_blk_off, nb * GNX_VTN * sizeof(int32_t)));
+  // (+ room behind the 64 counts for a tile's gamete-request counts: one device vector for the
+  // count exchange of gnx_tile_step)
+  HIPCHK(hipMalloc((void**)&h->vt_count, (GNX_VTN + GNX_MAX_TILES) * sizeof(int32_t)));
+  HIPCHK(hipMalloc((void**)&h->vt_base, GNX_VTN * sizeof(int64_t)));
+  return 0;
+}
+
+static GnxVtP gnx_vtp(const gnx_state* h) { return GnxVtP{h->cfg.W / GNX_VT, h->cfg.H / GNX_VT}; }
+
+// what k_pair_compact is handed when the ids are tile-major and every pair has the same
+// number of births (else nothing: the weighted classification follows the birth draws)
+static int gnx_vt_out(gnx_state* h, GnxVtOut* out) {
+  *out = GnxVtOut{nullptr, nullptr, nullptr, nullptr, GnxVtP{1, 1}};
+  h->vt_fused = false;
+  if (h->id_order != 1 || !h->sp.n_births_fixed || h->sp.mating_radius < 0) return 0;
+  GNXCHK(vt_buffers(h));
+  *out = GnxVtOut{h->vt_cls, h->vt_rank, h->vt_pblk, h->vt_blk_cnt, gnx_vtp(h)};
+  h->vt_fused = true;
+  return 0;
+}
+
+// The virtual tiles' counts (h->vt_count, device: in births / vt_mul) and the blocks' offsets
+// behind the classification - k_pair_compact's (fixed births; blocks of slots) or, Poisson
+// births, k_pair_cls's here (blocks of pairs; needs h->nbirths).  local: the virtual tiles' base
+// offsets too, from this device's own counts; else the caller sets h->vt_base (the tiles' sums).
+int gnx_l_pair_cls(gnx_state* h, int64_t P, bool local) {
+  GNXCHK(vt_buffers(h));
+  GnxSoA s = h->soa[h->cur];
+  int nb;
+  if (h->sp.n_births_fixed) {
+    // (P < 0: not known on the host - gnx_tile_step; an empty tile made no pair list at all)
+    if (!h->vt_fused && h->N > 0 && P != 0) {
+      gnx_set_error("tile-major offspring ids: the pair list was made without its classification");
+      return 1;
+    }
+    nb = (int)((h->N + GNX_CB - 1) / GNX_CB);
+    h->vt_mul = (int64_t)h->sp.n_births_lambda;
+  } else {
+    nb = (int)((P + GNX_CB - 1) / GNX_CB);
+    h->vt_mul = 1;
+    if (P > 0)
+      hipLaunchKernelGGL(k_pair_cls, dim3(nb), dim3(256), 0, h->stream, P, (const int32_t*)nullptr,
+                         (const int32_t*)h->pairs, (const float*)s.x, (const float*)s.y,
+                         (const int32_t*)h->nbirths, gnx_vtp(h), h->vt_cls, h->vt_rank, h->vt_pblk,
+                         h->vt_blk_cnt);
+  }
+  if (P == 0) nb = 0;             // (no pair list was written: counts of zero)
+  hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, h->stream, nb, (const int32_t*)nullptr,
+                     (const GnxDD*)nullptr, (const int32_t*)h->vt_blk_cnt, h->vt_blk_off,
+                     h->vt_count, h->vt_base, local ? 1 : 0, h->vt_mul);
+  HIPCHK(hipGetLastError());
+  h->pair_goff_local_base = local;
+  h->pair_goff_ready = true;
+  return 0;
+}
+
+static GnxGoff gnx_goff_vt(const gnx_state* h) {
+  return GnxGoff{nullptr, h->vt_cls, h->vt_rank, h->vt_pblk, h->vt_blk_off, h->vt_base, h->vt_mul};
+}
+
 // Pairs in slot order, i.e. in the CANONICAL (hash cell, id) order of their focal individual
 // - the order offspring ids are handed out in: it depends on positions and ids only, not
 // on storage order or on how the landscape is tiled (the reference's own order is that of
@@ -1284,10 +1524,13 @@ k_pair_compact(int64_t N, const int32_t* focal, const int32_t* mate, const int32
                int idbits, int32_t* pairs, float* mid_x, float* mid_y, uint64_t* key,
                const int32_t* __restrict__ cnt, int32_t* __restrict__ total_dev,
                int64_t* __restrict__ host, long long seq, const int32_t* __restrict__ extra,
-               GnxDD* __restrict__ dd, int dd_births, int64_t dd_cap, GnxBinP bins) {
+               GnxDD* __restrict__ dd, int dd_births, int64_t dd_cap, GnxBinP bins, GnxVtOut vt) {
   __shared__ int lds[16];
   __shared__ int psum[4];
+  __shared__ int vcnt[16][GNX_VTN];
   if (dd) N = dd->N;
+  if (vt.cls)
+    for (int k = threadIdx.x; k < 16 * GNX_VTN; k += 256) (&vcnt[0][0])[k] = 0;
   // cnt != null: no scan kernel ran - every workgroup adds up the block counts before its own
   // (a few coalesced loads from L2: 1 210 counts at the metric size), and workgroup 0, the
   // first to start, adds up all of them and hands the total to the host and to the device
@@ -1337,7 +1580,28 @@ k_pair_compact(int64_t N, const int32_t* focal, const int32_t* mate, const int32
     f[r] = i < N && flag2[i] != 0;
   }
   int rank[4], tot;
-  gnx_block_ranks(f, rank, tot, lds);
+  gnx_block_ranks(f, rank, tot, lds);            // (barriers: vcnt is zero from here on)
+  // tile-major offspring ids: the pair's virtual tile (by its focal individual's position), its
+  // rank among the block's pairs of the same virtual tile, the block's count per virtual tile
+  int vc[4] = {0, 0, 0, 0}, vrw[4] = {0, 0, 0, 0};
+  float fx[4], fy[4];
+  int fo4[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    fo4[r] = f[r] ? (focal ? focal[i] : (int)i) : 0;
+    fx[r] = f[r] ? x[fo4[r]] : 0.f;
+    fy[r] = f[r] ? y[fo4[r]] : 0.f;
+  }
+  if (vt.cls) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      vc[r] = f[r] ? gnx_vt_of(vt.V, fx[r], fy[r]) : GNX_VTN;
+      gnx_vt_wave_ranks<false>(f[r], vc[r], 1, lane, vcnt[r * 4 + wave], vrw[r]);
+    }
+    __syncthreads();
+  }
   const int32_t bo = cnt ? self_off : blk_off[blockIdx.x];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -1346,197 +1610,33 @@ k_pair_compact(int64_t N, const int32_t* focal, const int32_t* mate, const int32
     if (f[r]) {
       const int p = bo + rank[r];
       const int m = mate[i];
-      const int fo = focal ? focal[i] : (int)i;
+      const int fo = fo4[r];
       pairs[2 * p] = fo;
       pairs[2 * p + 1] = m;
-      const float mx = (x[fo] + x[m]) / 2.0f, my = (y[fo] + y[m]) / 2.0f;
+      const float mx = (fx[r] + x[m]) / 2.0f, my = (fy[r] + y[m]) / 2.0f;
       mid_x[p] = mx;
       mid_y[p] = my;
       const uint64_t k = popkey[i];
       key[p] = ((k >> idbits) << 40) | (k & ((1ull << idbits) - 1ull));
       if (bins.bins) bin = gnx_bin_of(bins, mx, my);
+      if (vt.cls) {
+        const int wave = threadIdx.x >> 6;
+        int before = 0;
+        for (int j = 0; j < r * 4 + wave; ++j) before += vcnt[j][vc[r]];
+        vt.cls[p] = (uint8_t)vc[r];
+        vt.rank[p] = before + vrw[r];
+        vt.pblk[p] = (int32_t)blockIdx.x;
+      }
     }
     // (device-driven step at small sizes: the pair midpoints' density bins in the same launch)
     if (bins.bins) gnx_bin_add(bins.bins, bin, f[r]);
   }
-}
-
-// ---------------------------------------------------------------- offspring ids, tile-major
-// gnx_set_id_order(h, 1): offspring ids are handed out virtual tile by virtual tile - a fixed
-// 8 x 8 blocking of the landscape that every tile grid dividing 8 x 8 is a union of - and
-// inside a virtual tile in the canonical (hash cell, focal id) order of the pairs.  A tile of a
-// tiled run owns whole virtual tiles, so the rank of a pair inside its virtual tile is the
-// same number on the tile and on one device, and the only thing the tiles have to tell each
-// other is how many births each virtual tile has: 64 counts that ride on the count exchange,
-// instead of an all-gather of every pair's order key (gnx_comm.hip; VERDICT r3 #1b).  The
-// default order (0: hash cell, focal id over the whole landscape) needs no extra work on one
-// device and stays the default there.
-#define GNX_VT 8
-#define GNX_VTN (GNX_VT * GNX_VT)
-
-struct GnxVtP {
-  float inv_w, inv_h;         // 1 / (W / 8), 1 / (H / 8)
-};
-__device__ __forceinline__ int gnx_vt_of(const GnxVtP& V, float x, float y) {
-  const int vx = min(GNX_VT - 1, (int)(x * V.inv_w));
-  const int vy = min(GNX_VT - 1, (int)(y * V.inv_h));
-  return vy * GNX_VT + vx;
-}
-
-// the virtual tile of every pair (by its focal individual's position), the pair's rank among
-// the pairs of the same virtual tile inside its block of 1024 pairs, and the block's count
-// per virtual tile.  P: the pair count, or read from P_dev.
-__global__ void __launch_bounds__(256)
-k_pair_cls(int64_t P, const int32_t* __restrict__ P_dev, const int32_t* __restrict__ pairs,
-           const float* __restrict__ x, const float* __restrict__ y, GnxVtP V,
-           uint8_t* __restrict__ cls, int32_t* __restrict__ rank, int32_t* __restrict__ blk_cnt) {
-  __shared__ int cnt[16][GNX_VTN];
-  if (P_dev) P = *P_dev;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int k = tid; k < 16 * GNX_VTN; k += 256) (&cnt[0][0])[k] = 0;
-  __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * GNX_CB;
-  int c[4], rw[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int64_t p = base + r * 256 + tid;
-    const bool act = p < P;
-    c[r] = GNX_VTN;
-    rw[r] = 0;
-    if (act) {
-      const int fo = pairs[2 * p];
-      c[r] = gnx_vt_of(V, x[fo], y[fo]);
-    }
-    // the lanes of a wave are neighbours in the pair list: one or two virtual tiles per wave
-    unsigned long long todo = __ballot(act);
-    while (todo) {
-      const int leader = __ffsll((long long)todo) - 1;
-      const int lc = __shfl(c[r], leader);
-      const unsigned long long same = __ballot(act && c[r] == lc);
-      if (act && c[r] == lc) rw[r] = __popcll(same & ((1ull << lane) - 1ull));
-      if (lane == leader) cnt[r * 4 + wave][lc] = __popcll(same);
-      todo &= ~same;
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int64_t p = base + r * 256 + tid;
-    if (p >= P) continue;
-    int before = 0;
-    for (int j = 0; j < r * 4 + wave; ++j) before += cnt[j][c[r]];
-    cls[p] = (uint8_t)c[r];
-    rank[p] = before + rw[r];
-  }
-  if (tid < GNX_VTN) {
+  if (vt.cls && threadIdx.x < GNX_VTN) {
     int t = 0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) t += cnt[j][tid];
-    blk_cnt[(int64_t)blockIdx.x * GNX_VTN + tid] = t;
+    for (int j = 0; j < 16; ++j) t += vcnt[j][threadIdx.x];
+    vt.blk_cnt[(int64_t)blockIdx.x * GNX_VTN + threadIdx.x] = t;
   }
-}
-
-// per virtual tile (one lane each) the exclusive offsets of the blocks' counts and the total:
-// the 16 waves of the workgroup take a stretch of the blocks each, the stretches' totals meet in
-// LDS; with `local` the virtual tiles' base offsets too (one device: nobody else has pairs), in
-// births
-__global__ void __launch_bounds__(1024)
-k_cls_scan(int nb, const int32_t* __restrict__ P_dev, const int32_t* __restrict__ blk_cnt,
-           int32_t* __restrict__ blk_off, int32_t* __restrict__ vt_count,
-           int64_t* __restrict__ vt_base, int local, int64_t lam) {
-  __shared__ int seg_tot[16][GNX_VTN];
-  const int c = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (P_dev) nb = (int)(((int64_t)*P_dev + GNX_CB - 1) / GNX_CB);
-  const int seg = (nb + 15) / 16;
-  const int b0 = wave * seg, b1 = min(nb, b0 + seg);
-  int run = 0;
-  for (int b = b0; b < b1; ++b) run += blk_cnt[(int64_t)b * GNX_VTN + c];
-  seg_tot[wave][c] = run;
-  __syncthreads();
-  int before = 0, total = 0;
-  for (int w = 0; w < 16; ++w) {
-    const int t = seg_tot[w][c];
-    before += w < wave ? t : 0;
-    total += t;
-  }
-  run = before;
-  for (int b = b0; b < b1; ++b) {
-    const int v = blk_cnt[(int64_t)b * GNX_VTN + c];
-    blk_off[(int64_t)b * GNX_VTN + c] = run;
-    run += v;
-  }
-  if (wave != 0) return;
-  vt_count[c] = total;
-  if (local) {
-    int xs = total;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int yv = __shfl_up(xs, d);
-      if (c >= d) xs += yv;
-    }
-    vt_base[c] = (int64_t)(xs - total) * lam;
-  }
-}
-
-__global__ void k_goff_vt(int64_t P, const int32_t* __restrict__ P_dev,
-                          const uint8_t* __restrict__ cls, const int32_t* __restrict__ rank,
-                          const int32_t* __restrict__ blk_off, const int64_t* __restrict__ vt_base,
-                          int64_t lam, int64_t* __restrict__ goff) {
-  if (P_dev) P = *P_dev;
-  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P) return;
-  const int c = cls[p];
-  goff[p] = vt_base[c] + (int64_t)(blk_off[(p / GNX_CB) * GNX_VTN + c] + rank[p]) * lam;
-}
-
-static int vt_buffers(gnx_state* h) {
-  if (h->vt_cls) return 0;
-  const size_t cap = (size_t)h->cfg.cap_inds;
-  const size_t nb = cap / GNX_CB + 2;
-  HIPCHK(hipMalloc((void**)&h->vt_cls, cap));
-  HIPCHK(hipMalloc((void**)&h->vt_rank, cap * sizeof(int32_t)));
-  HIPCHK(hipMalloc((void**)&h->vt_blk_cnt, nb * GNX_VTN * sizeof(int32_t)));
-  HIPCHK(hipMalloc((void**)&h->vt_blk_off, nb * GNX_VTN * sizeof(int32_t)));
-  // (+ room behind the 64 counts for a tile's gamete-request counts: one device vector for the
-  // count exchange of gnx_tile_step)
-  HIPCHK(hipMalloc((void**)&h->vt_count, (GNX_VTN + GNX_MAX_TILES) * sizeof(int32_t)));
-  HIPCHK(hipMalloc((void**)&h->vt_base, GNX_VTN * sizeof(int64_t)));
-  return 0;
-}
-
-// the pairs' virtual tiles, in-tile ranks and the tiles' counts (h->vt_count, device);
-// local: the base offsets as well, from this device's own counts
-int gnx_l_pair_cls(gnx_state* h, int64_t P, bool local) {
-  GNXCHK(vt_buffers(h));
-  if (!h->sp.n_births_fixed) {
-    gnx_set_error("tile-major offspring ids need a fixed number of births per pair");
-    return 1;
-  }
-  GnxSoA s = h->soa[h->cur];
-  const GnxVtP V{(float)GNX_VT / (float)h->cfg.W, (float)GNX_VT / (float)h->cfg.H};
-  const int nb = (int)((P + GNX_CB - 1) / GNX_CB);
-  if (P > 0)
-    hipLaunchKernelGGL(k_pair_cls, dim3(nb), dim3(256), 0, h->stream, P, (const int32_t*)nullptr,
-                       (const int32_t*)h->pairs, (const float*)s.x, (const float*)s.y, V, h->vt_cls,
-                       h->vt_rank, h->vt_blk_cnt);
-  hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, h->stream, nb, (const int32_t*)nullptr,
-                     (const int32_t*)h->vt_blk_cnt, h->vt_blk_off, h->vt_count, h->vt_base,
-                     local ? 1 : 0, (int64_t)h->sp.n_births_lambda);
-  HIPCHK(hipGetLastError());
-  h->pair_goff_local_base = local;
-  return 0;
-}
-
-// h->pair_goff from h->vt_base (this device's own, or the one the tiles agreed on)
-int gnx_l_pair_goff_vt(gnx_state* h, int64_t P) {
-  if (P > 0)
-    hipLaunchKernelGGL(k_goff_vt, dim3(gnx_grid(P, 256)), dim3(256), 0, h->stream, P,
-                       (const int32_t*)nullptr, (const uint8_t*)h->vt_cls, (const int32_t*)h->vt_rank,
-                       (const int32_t*)h->vt_blk_off, (const int64_t*)h->vt_base,
-                       (int64_t)h->sp.n_births_lambda, h->pair_goff);
-  HIPCHK(hipGetLastError());
-  h->pair_goff_ready = true;
-  return 0;
 }
 
 // panmixia (structs/species.py:2178-2194): n ~ Binomial(N, b) pairs, both
@@ -1612,13 +1712,15 @@ int gnx_l_find_pairs_enqueue(gnx_state* h, const uint8_t* d_keep, bool with_dens
     GNXCHK(gnx_block_scan(h, 1, N, h->blk_cnt, h->blk_off, h->cnt_dev, h->h_pin_dev + 4, seq, nullptr,
                           with_top ? h->half_top : nullptr));
   // (the population was sorted by gnx_l_sort_by_cell with this idbits: max_id has not moved)
+  GnxVtOut vto;
+  GNXCHK(gnx_vt_out(h, &vto));
   hipLaunchKernelGGL(k_pair_compact, dim3(nb), dim3(256), 0, h->stream, N, focal, h->mate,
                      h->flag2, h->blk_off, s.x, s.y, h->key64[1], gnx_id_bits(h), h->pairs,
                      h->mid_x, h->mid_y, h->key64[0],
                      self_scan ? (const int32_t*)h->blk_cnt : (const int32_t*)nullptr, h->cnt_dev,
                      h->h_pin_dev + 4, (long long)seq,
                      with_top ? (const int32_t*)h->half_top : (const int32_t*)nullptr,
-                     (GnxDD*)nullptr, 0, (int64_t)0, GnxBinP{nullptr, 0.0, 0, 0});
+                     (GnxDD*)nullptr, 0, (int64_t)0, GnxBinP{nullptr, 0.0, 0, 0}, vto);
   gnx_time_end(h, GNX_K_PAIRS, (double)N * 40.0);
   HIPCHK(hipGetLastError());
   // the pair midpoints' density (ops/demography.py:60-91): on one GPU bins + lattice run on
@@ -1739,7 +1841,7 @@ __device__ __forceinline__ bool disperse_once(float mx, float my, float theta, f
 // age 0, sex, environment, genome row, recombination keys, start homologues.
 __global__ void __launch_bounds__(256)
 k_offspring(OffP P, GnxSoA s, const float* rast, const int32_t* pairs, const int32_t* off_pair,
-            const int32_t* boff, const int64_t* goff,
+            const int32_t* boff, GnxGoff gf,
             int32_t* off_parent, int32_t* off_keys, uint8_t* off_start, GnxReq rq, GnxTraitTab T,
             int32_t* __restrict__ ord_tail) {
   int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1758,14 +1860,22 @@ k_offspring(OffP P, GnxSoA s, const float* rast, const int32_t* pairs, const int
     p = off_pair[k];
     ord = k - boff[p];
   }
-  // global offspring index: local k on one GPU, the pair's global offset on tiles
-  const int64_t gk = goff ? goff[p] + ord : k;
+  // global offspring index: local k on one GPU, the pair's global offset on tiles; tile-major
+  // ids: the virtual tile's base, the blocks before the pair's, the pair's rank in its block
+  int64_t gk = k;
+  if (gf.cls) {
+    const int c = gf.cls[p];
+    gk = gf.vt_base[c] + (int64_t)(gf.blk_off[(int64_t)gf.pblk[p] * GNX_VTN + c] + gf.rank[p]) * gf.mul + ord;
+  } else if (gf.goff) {
+    gk = gf.goff[p] + ord;
+  }
   int i = pairs[2 * p], m = pairs[2 * p + 1];
   int64_t slot = P.N + k;
   unsigned long long oid = (unsigned long long)(P.id_base + gk);
   // (tile-major ids on one device: the newborns' ids do not ascend with their slots - the
-  // id-ordered index takes its tail from here: the gk-th smallest new id sits in this slot)
-  if (ord_tail) ord_tail[gk] = (int32_t)slot;
+  // id-ordered index takes its tail from here: the gk-th smallest new id sits in this slot;
+  // device-driven step: the tail starts behind the dd->N entries of the index)
+  if (ord_tail) ord_tail[(P.dd ? P.N : 0) + gk] = (int32_t)slot;
   float mx = (s.x[i] + s.x[m]) / 2.0f;
   float my = (s.y[i] + s.y[m]) / 2.0f;
   // the draws that do not depend on the position, and - one GPU, at most 128 selected loci -
@@ -1995,9 +2105,19 @@ int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* 
     hipLaunchKernelGGL(k_offspring_inject, dim3(gnx_grid(B, 256)), dim3(256), 0, h->stream, h->N,
                        B, c.cap_inds, s, h->rast, c.n_layers, c.W, c.H, h->off_parent, h->max_id);
   } else {
-    if (!tiled) GNXCHK(gnx_l_births(h, &B));
+    if (!tiled) {
+      GNXCHK(gnx_l_births(h, &B));
+      // tile-major offspring ids on one device (gnx_set_id_order): the blocks' offsets behind
+      // k_pair_compact's classification, or - Poisson births - the classification itself, now
+      // that the pairs' birth counts are drawn; the virtual tiles' bases from this device alone
+      if (h->id_order == 1 && h->n_pairs > 0 && h->sp.mating_radius >= 0)
+        GNXCHK(gnx_l_pair_cls(h, h->n_pairs, true));
+    }
     B = h->n_births_pending;
-    if (B == 0) return 0;
+    if (B == 0) {
+      h->pair_goff_ready = false;
+      return 0;
+    }
     if (h->N + B > c.cap_inds || (genomes && B > h->n_free)) {
       gnx_set_error("capacity exceeded: N=%lld + births=%lld > cap_inds=%lld (free rows %lld)",
                     (long long)h->N, (long long)B, (long long)c.cap_inds, (long long)h->n_free);
@@ -2030,10 +2150,12 @@ int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* 
         h->ord_n == h->N)
       ord_tail = h->ord[h->ord_cur] + h->ord_n;
     ord_tail_used = ord_tail != nullptr;
+    GnxGoff gf{};
+    if (h->pair_goff_ready) gf = gnx_goff_vt(h);
+    else if (tiled && !h->pair_goff_local) gf.goff = h->pair_goff;
     gnx_time_begin(h);
     hipLaunchKernelGGL(k_offspring, dim3(gnx_grid(B, 256)), dim3(256), 0, h->stream, Q, s, h->rast,
-                       h->pairs, h->off_pair, h->boff,
-                       ((tiled && !h->pair_goff_local) || h->pair_goff_ready) ? h->pair_goff : nullptr,
+                       h->pairs, h->off_pair, h->boff, gf,
                        h->off_parent, h->off_keys, h->off_start, rq, gnx_trait_tab(h), ord_tail);
     gnx_time_end(h, GNX_K_OFFSPRING, (double)B * (60.0 + 8.0 * c.n_layers + 48.0 * h->TW +
                                                   4.0 * c.n_traits));
@@ -2146,12 +2268,22 @@ int gnx_dd_l_pairs(gnx_state* h, int32_t* d_bins, hipStream_t st) {
   hipLaunchKernelGGL(k_pair_flags, dim3(nb), dim3(256), 0, st, pp, s, h->flag2, h->blk_cnt);
   // the pair list, in slot order; workgroup 0 adds up the block counts and leaves the pair
   // count, the births (a fixed number per pair) and the capacity check in the device block
+  GnxVtOut vto;
+  GNXCHK(gnx_vt_out(h, &vto));
   hipLaunchKernelGGL(k_pair_compact, dim3(nb), dim3(256), 0, st, cap, (const int32_t*)nullptr,
                      h->mate, h->flag2, h->blk_off, s.x, s.y, h->key64[1], 40, h->pairs, h->mid_x,
                      h->mid_y, h->key64[0], (const int32_t*)h->blk_cnt, h->cnt_dev,
                      (int64_t*)nullptr, 0ll, (const int32_t*)nullptr, h->dd,
                      (int)sp.n_births_lambda, (int64_t)cap,
-                     GnxBinP{d_bins, 1.0 / h->lat.hww, h->lat.nbx, h->lat.nby});
+                     GnxBinP{d_bins, 1.0 / h->lat.hww, h->lat.nbx, h->lat.nby}, vto);
+  // tile-major offspring ids: the blocks' offsets and the virtual tiles' bases (the slot blocks
+  // of dd->N individuals; a block without pairs wrote zeros)
+  if (vto.cls) {
+    h->vt_mul = (int64_t)sp.n_births_lambda;
+    hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, st, 0, (const int32_t*)nullptr,
+                       (const GnxDD*)h->dd, (const int32_t*)h->vt_blk_cnt, h->vt_blk_off,
+                       h->vt_count, h->vt_base, 1, h->vt_mul);
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -2162,10 +2294,13 @@ int gnx_dd_l_offspring(gnx_state* h, bool genomes, int32_t* d_bins, hipStream_t 
   Q.bins.bins = d_bins;
   // (a pair has a fixed number of births here: at most every second individual is a focal one
   // of a kept pair, so the capacity bounds the grid generously; the kernel reads B itself)
+  // (tile-major ids: the offsets from k_pair_compact's classification; the newborns' ids do not
+  // ascend with their slots then - the kernel files them behind the index's dd->N entries)
+  const bool vt = h->vt_fused && h->id_order == 1;
   hipLaunchKernelGGL(k_offspring, dim3(gnx_grid(h->cfg.cap_inds, 256)), dim3(256), 0, st, Q,
                      h->soa[h->cur], h->rast, h->pairs, h->off_pair, h->boff,
-                     (const int64_t*)nullptr, h->off_parent, h->off_keys, h->off_start, GnxReq{},
-                     gnx_trait_tab(h), (int32_t*)nullptr);
+                     vt ? gnx_goff_vt(h) : GnxGoff{}, h->off_parent, h->off_keys, h->off_start,
+                     GnxReq{}, gnx_trait_tab(h), vt ? h->ord[h->ord_cur] : (int32_t*)nullptr);
   HIPCHK(hipGetLastError());
   return 0;
 }

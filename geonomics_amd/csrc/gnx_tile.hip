@@ -392,7 +392,9 @@ extern "C" int gnx_tile_offspring(gnx_state* h, int32_t burn, int64_t id_base,
   int64_t P = h->n_pairs, B = 0;
   h->birth_first_slot = h->N;
   h->n_req = 0;
-  if (P > 0)
+  h->tile_births_settled = false;
+  // (no offsets: tile-major ids, the pieces were made by gnx_tile2_vt_counts / _vt_bases)
+  if (P > 0 && pair_goff)
     GNXCHK(gnx_h2d(h, h->pair_goff, pair_goff, P * sizeof(int64_t)));
   GNXCHK(gnx_l_mate(h, burn != 0, false, 0, &B, id_base, true));
   h->last_births = B;
@@ -586,10 +588,14 @@ extern "C" int gnx_tile_finish_births(gnx_state* h, int32_t burn) {
   return tile_finish_births(h, burn, nullptr);
 }
 
-static int tile_finish_births(gnx_state* h, int32_t burn, const GnxSetWords* sw) {
+// the offspring that took a remote gamete re-read their alleles at the selected loci (and their
+// phenotype) from their finished rows
+static int tile_settle_births(gnx_state* h, int32_t burn) {
   // the service entry points return with stream2 idle; what follows is ordered behind
   // the crossover on the main stream
   h->xo_pending = false;
+  if (h->tile_births_settled) return 0;
+  h->tile_births_settled = true;
   int64_t B = h->last_births;
   if (B > 0 && !burn && has_rows(h)) {
     // local gametes took their alleles at the selected loci from the parents' compact
@@ -605,6 +611,16 @@ static int tile_finish_births(gnx_state* h, int32_t burn, const GnxSetWords* sw)
     else
       GNXCHK(gnx_l_phenotype(h, h->birth_first_slot, B));
   }
+  return 0;
+}
+
+// gnx_tile_step_begin ends with this: the step's offspring are complete before the host looks at
+// them (mutations, pedigree records); gnx_tile2_finish_births finds it done
+extern "C" int gnx_tile2_settle_births(gnx_state* h, int32_t burn) { return tile_settle_births(h, burn); }
+
+static int tile_finish_births(gnx_state* h, int32_t burn, const GnxSetWords* sw) {
+  GNXCHK(tile_settle_births(h, burn));
+  h->tile_births_settled = false;
   GnxSoA s = h->soa[h->cur];
   h->last_N_fused = false;
   GNXCHK(gnx_l_bins(h, h->N, s.x, s.y, s.ghost, h->bin_partials, nullptr, sw));
@@ -642,11 +658,7 @@ extern "C" int gnx_set_max_id(gnx_state* h, int64_t max_id) {
 // (R*C integers) cross PCIe.
 // =====================================================================================
 __device__ __forceinline__ int tile_index(float v, int tw, int n) {
-  int c = (int)(v / (float)tw);
-  c = max(0, min(n - 1, c));
-  while (c + 1 < n && (float)((c + 1) * tw) <= v) ++c;     // exact: boundaries are integers
-  while (c > 0 && (float)(c * tw) > v) --c;
-  return c;
+  return gnx_tile_index(v, tw, n);          // (gnx_internal.h: exact on the integer boundaries)
 }
 
 __global__ void k_dest_owner(int64_t n, const gnx_ind_rec* rec, int tw, int th, int R, int C,
@@ -961,7 +973,8 @@ extern "C" int gnx_tile_offspring_dev(gnx_state* h, int32_t burn, int64_t id_bas
   int64_t P = h->n_pairs, B = 0;
   h->birth_first_slot = h->N;
   h->n_req = 0;
-  if (P > 0) {
+  h->tile_births_settled = false;
+  if (P > 0 && pair_goff_dev) {
     HIPCHK(hipMemcpyAsync(h->pair_goff, pair_goff_dev, P * sizeof(int64_t),
                           hipMemcpyDeviceToDevice, h->stream));
     // the source belongs to the caller (a tensor it may release on return)
@@ -1547,8 +1560,9 @@ __global__ void k_req_count(int64_t P, const int32_t* __restrict__ pairs,
                             const uint8_t* __restrict__ ghost, const float* __restrict__ x,
                             const float* __restrict__ y, int tw, int th, int R, int C,
                             int fixed_nb, const int32_t* __restrict__ nbirths,
-                            int32_t* __restrict__ cnt) {
+                            int32_t* __restrict__ cnt, const int32_t* __restrict__ P_dev) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (P_dev) P = *P_dev;
   if (p >= P) return;
   const int m = pairs[2 * p + 1];
   if (!ghost[m]) return;
@@ -1571,12 +1585,42 @@ extern "C" int gnx_tile2_pairs(gnx_state* h, int32_t burn, int64_t* counts) {
   h->req_by_rank.assign(T, 0);
   int64_t P = 0, B = 0;
   GNXCHK(gnx_l_sort_by_cell(h));                 // (emigrants leave here)
+  const bool genomes = !burn && h->cfg.L > 0 && h->genomes_assigned;
+  if (h->tile_pairs_nowait && h->sp.n_births_fixed && h->N == 0) {
+    // an empty tile: the pair count that travels is a clean zero
+    HIPCHK(hipMemsetAsync(h->cnt_dev, 0, sizeof(int32_t), h->stream));
+    h->n_pairs = 0;
+    h->pairs_wait = false;
+    h->n_req_known = 0;
+    counts[0] = counts[1] = -1;
+    return 0;
+  }
+  if (h->tile_pairs_nowait && h->sp.n_births_fixed) {
+    // gnx_tile_step on several tiles, a fixed number of births per pair: nothing here needs the
+    // pair count on the host - the pairs' density bins and the request counts read it on the
+    // device (grids sized by the population), and it reaches the host with the count exchange
+    // that follows (gnx_tile2_pairs_settle)
+    GNXCHK(gnx_l_find_pairs_enqueue(h, nullptr, false));
+    GNXCHK(gnx_l_bins(h, h->N, h->mid_x, h->mid_y, nullptr, h->bins_P, h->cnt_dev));
+    h->n_req_known = 0;
+    if (T > 1 && genomes) {
+      GnxSoA s = h->soa[h->cur];
+      HIPCHK(hipMemsetAsync(h->route_cnt, 0, (size_t)T * sizeof(int32_t), h->stream));
+      hipLaunchKernelGGL(k_req_count, dim3(gnx_grid(h->N, 256)), dim3(256), 0, h->stream, h->N,
+                         h->pairs, s.ghost, s.x, s.y, h->cfg.W / h->tile_C, h->cfg.H / h->tile_R,
+                         h->tile_R, h->tile_C, (int)h->sp.n_births_lambda, h->nbirths, h->route_cnt,
+                         (const int32_t*)h->cnt_dev);
+      HIPCHK(hipGetLastError());
+      h->n_req_known = -2;
+    }
+    counts[0] = counts[1] = -1;
+    return 0;
+  }
   GNXCHK(gnx_l_find_pairs(h, nullptr, &P));      // wait 2 of the step: the pair count
   GNXCHK(gnx_l_bins(h, P, h->mid_x, h->mid_y, nullptr, h->bins_P));
   GNXCHK(gnx_l_births(h, &B));
   counts[0] = P;
   counts[1] = B;
-  const bool genomes = !burn && h->cfg.L > 0 && h->genomes_assigned;
   h->n_req_known = 0;
   if (P > 0 && T > 1 && genomes) {
     GnxSoA s = h->soa[h->cur];
@@ -1584,7 +1628,7 @@ extern "C" int gnx_tile2_pairs(gnx_state* h, int32_t burn, int64_t* counts) {
     hipLaunchKernelGGL(k_req_count, dim3(gnx_grid(P, 256)), dim3(256), 0, h->stream, P, h->pairs,
                        s.ghost, s.x, s.y, h->cfg.W / h->tile_C, h->cfg.H / h->tile_R, h->tile_R,
                        h->tile_C, h->sp.n_births_fixed ? (int)h->sp.n_births_lambda : 0,
-                       h->nbirths, h->route_cnt);
+                       h->nbirths, h->route_cnt, (const int32_t*)nullptr);
     HIPCHK(hipGetLastError());
     if (h->tile_req_on_device) {
       // (gnx_tile_step: the counts travel with its count exchange - gnx_tile2_set_requests)
@@ -1603,6 +1647,46 @@ extern "C" int gnx_tile2_pairs(gnx_state* h, int32_t burn, int64_t* counts) {
     }
   }
   return 0;
+}
+
+// gnx_tile_step, a fixed number of births per pair: gnx_tile2_pairs does not wait for the pair
+// count (mode 1); it arrives with the count exchange and _settle does the host's bookkeeping
+extern "C" int gnx_tile2_pairs_mode(gnx_state* h, int32_t nowait) {
+  h->tile_pairs_nowait = nowait != 0;
+  return 0;
+}
+
+extern "C" int gnx_tile2_pairs_settle(gnx_state* h, int32_t burn, int64_t P, int64_t* births) {
+  (void)burn;
+  int64_t P_pub = 0, B = 0;
+  // (the exchange that carried P waited for the stream: the published count is there)
+  GNXCHK(gnx_l_find_pairs_finish(h, &P_pub));
+  if (P_pub != P) {
+    gnx_set_error("tile2: the pair count that travelled (%lld) is not the one published (%lld)",
+                  (long long)P, (long long)P_pub);
+    return 1;
+  }
+  GNXCHK(gnx_l_births(h, &B));
+  *births = B;
+  return 0;
+}
+
+// Tile-major offspring ids through the Python-driven protocol (TiledStepper._step_v2): this
+// tile's births per virtual tile (one wait), then the global bases before the births
+extern "C" int gnx_tile2_vt_counts(gnx_state* h, int64_t* counts) {
+  if (h->id_order != 1) {
+    gnx_set_error("gnx_tile2_vt_counts: offspring ids are not tile-major (gnx_set_id_order)");
+    return 1;
+  }
+  GNXCHK(gnx_l_pair_cls(h, h->n_pairs, n_tiles(h) == 1));
+  int32_t tmp[64];
+  GNXCHK(gnx_d2h(h, tmp, h->vt_count, sizeof(tmp)));
+  for (int q = 0; q < 64; ++q) counts[q] = (int64_t)tmp[q] * h->vt_mul;
+  return 0;
+}
+
+extern "C" int gnx_tile2_vt_bases(gnx_state* h, const int64_t* bases) {
+  return gnx_h2d(h, h->vt_base, bases, 64 * sizeof(int64_t));
 }
 
 // gnx_tile_step: the request counts gnx_tile2_pairs left on the device (*counts_dev, int32 [T])
@@ -1647,6 +1731,7 @@ extern "C" int gnx_tile2_offspring(gnx_state* h, int32_t burn, int64_t id_base,
   int64_t P = h->n_pairs, B = 0;
   h->birth_first_slot = h->N;
   h->n_req = 0;
+  h->tile_births_settled = false;
   if (P > 0 && pair_goff_dev && pair_goff_dev != (const void*)h->pair_goff)
     HIPCHK(hipMemcpyAsync(h->pair_goff, pair_goff_dev, P * sizeof(int64_t),
                           hipMemcpyDeviceToDevice, h->stream));

@@ -439,12 +439,14 @@ class TiledStepper:
                    (comm.world == 1 or self.dev_transport))
         # One C call per step, the exchanges issued by the library itself on its own stream
         # (gnx_tile_step, csrc/gnx_comm.hip: grouped ncclSend / ncclRecv, KB-sized collectives,
-        # no torch.distributed call and no Python between the phases of a step).  Needs a fixed
-        # number of births per pair on several tiles (Poisson counts travel with the pair keys
-        # through _step_v2) and no per-step hook (mutations: after_births).  GNX_TILE_V3=0: off.
-        # gnx_tile_step hands out offspring ids virtual tile by virtual tile (gnx_set_id_order 1),
-        # _step_v2 in the (hash cell, focal id) order of the whole landscape: two runs agree id by
-        # id when they use the same one.  use_library: None = GNX_TILE_V3 (default on).
+        # no torch.distributed call and no Python between the phases of a step); with a per-step
+        # hook (mutations, pedigree rows: after_births) two calls, the hook between them
+        # (gnx_tile_step_begin / _end).  Poisson births included (round 5).  GNX_TILE_V3=0: off.
+        # gnx_tile_step hands out offspring ids virtual tile by virtual tile (gnx_set_id_order 1);
+        # the Python-driven protocols do so too when the device is set to that order (the Model
+        # API's default where the landscape allows it), else in the (hash cell, focal id) order
+        # of the whole landscape: two runs agree id by id when they use the same one.
+        # use_library: None = GNX_TILE_V3 (default on).
         self.v3 = False
         if use_library is None:
             use_library = os.environ.get('GNX_TILE_V3', '1') != '0'
@@ -459,8 +461,6 @@ class TiledStepper:
     def _join_library_comm(self):
         import os
         dev, comm = self.shard.dev, self.comm
-        if not (self.fixed_births or dev.births_fixed_lambda):
-            return False
         # (tile-major offspring ids: a fixed 8 x 8 blocking of the landscape the tiles are unions of)
         if self.W % 8 or self.H % 8 or 8 % self.R or 8 % self.C:
             return False
@@ -468,6 +468,17 @@ class TiledStepper:
         rccl = comm.dist is not None and comm.dist.get_backend() == 'nccl'
         if comm.world > 1 and group is None and not rccl:
             return False
+
+        def everybody(flag):
+            """every rank says yes - over the CPU side group when there is one (no device, no
+            RCCL call involved: this is what decides whether anybody enters one)"""
+            if comm.world == 1:
+                return bool(flag)
+            mine = np.array([1 if flag else 0], np.int64)
+            if getattr(comm, '_hgrp', None) is not None:
+                return int(comm.host_allgather(mine).sum()) == comm.world
+            return int(comm.allreduce_sum(mine)[0]) == comm.world
+
         joined, why = 1, None
         try:
             if comm.world == 1:
@@ -475,33 +486,45 @@ class TiledStepper:
             elif group is not None:               # tiles as threads of one process (tests)
                 dev.comm_local_join(group, comm.rank)
             else:
-                # rank 0 makes the RCCL id; it travels once, through the launcher's own group
-                # (over the CPU side group when there is one: 128 bytes, no device involved)
-                # (a rank 0 that cannot make one says so with None: nobody is left in the broadcast)
-                box = [None]
-                if comm.rank == 0:
-                    try:
-                        box[0] = nat.comm_unique_id()
-                    except Exception as e:
-                        why = e
-                hgrp = getattr(comm, '_hgrp', None)
-                if hgrp is not None:
-                    import torch
-                    comm.dist.broadcast_object_list(box, src=0, group=hgrp,
-                                                    device=torch.device('cpu'))
-                else:
-                    comm.dist.broadcast_object_list(box, src=0)
-                if box[0] is None:
+                # ncclCommInitRank is a collective nobody can be called back from: a rank that
+                # cannot follow (no librccl, no id) must say so BEFORE anybody enters it.  So
+                # first every rank probes its librccl (gnx_comm_probe) and the ranks agree on it;
+                # then rank 0 makes the id, it travels once through the launcher's CPU side group
+                # (128 bytes, no device involved; a rank 0 that cannot make one says so with None)
+                # and the ranks agree that everybody holds it; only then do they join - and the
+                # join itself has a deadline (GNX_COMM_INIT_TIMEOUT_S): past it a rank says why
+                # and ends its process with a non-zero code (csrc/gnx_comm.hip).
+                ok = 1
+                try:
+                    nat.comm_probe()
+                    if os.environ.get('GNX_COMM_PROBE_FAIL', '') == str(comm.rank):
+                        raise nat.GnxError('injected failure (GNX_COMM_PROBE_FAIL)')
+                except Exception as e:
+                    ok, why = 0, e
+                if not everybody(ok):
                     joined = 0
+                    why = why or 'librccl is not usable on some rank'
                 else:
-                    dev.comm_init_rccl(box[0], comm.rank, comm.world)
+                    box = [None]
+                    if comm.rank == 0:
+                        try:
+                            box[0] = nat.comm_unique_id()
+                        except Exception as e:
+                            why = e
+                    hgrp = getattr(comm, '_hgrp', None)
+                    if hgrp is not None:
+                        import torch
+                        comm.dist.broadcast_object_list(box, src=0, group=hgrp,
+                                                        device=torch.device('cpu'))
+                    else:
+                        comm.dist.broadcast_object_list(box, src=0)
+                    if not everybody(box[0] is not None):
+                        joined = 0
+                        why = why or 'no communicator id reached some rank'
+                    else:
+                        dev.comm_init_rccl(box[0], comm.rank, comm.world)
         except Exception as e:           # (whatever it was: the ranks agree below)
             joined, why = 0, e
-
-        def everybody(flag):
-            if comm.world == 1:
-                return bool(flag)
-            return int(comm.allreduce_sum(np.array([1 if flag else 0], np.int64))[0]) == comm.world
 
         def give_up(what):
             import sys
@@ -863,7 +886,22 @@ class TiledStepper:
         # rank), else 0: Poisson counts travel with the pair keys
         lam = self.fixed_births or dev.births_fixed_lambda
         P_, p_ids, p_nb = dev.tile_pair_ptrs_nosync()
-        if w > 1:
+        tile_major = dev.id_order == 1
+        if tile_major:
+            # offspring ids virtual tile by virtual tile (gnx_set_id_order 1): this tile's births
+            # per virtual tile travel with the counts, their exclusive sums are the bases - no
+            # pair key leaves the tile
+            vt_mine = dev.tile2_vt_counts()
+            if w > 1:
+                mat2 = comm.host_allgather(np.concatenate([[P, B], req, vt_mine]))
+                Ps, Bs, m_req = mat2[:, 0], mat2[:, 1], mat2[:, 2:2 + w]
+                total_births, total_pairs = int(Bs.sum()), int(Ps.sum())
+                vt = mat2[:, 2 + w:].sum(0)
+                dev.tile2_vt_bases(np.concatenate([[0], np.cumsum(vt)[:-1]]))
+            else:
+                total_births, total_pairs = B, P
+            goff = None
+        elif w > 1:
             mat2 = comm.host_allgather(np.concatenate([[P, B], req]))
             Ps, Bs, m_req = mat2[:, 0], mat2[:, 1], mat2[:, 2:]
             total_births, total_pairs = int(Bs.sum()), int(Ps.sum())
@@ -946,15 +984,26 @@ class TiledStepper:
         device-driven protocol skips the collective those take and returns the counts
         that rode on the step's own all-reduce: (N at the START of the step, births,
         deaths of the PREVIOUS step)."""
+        if self.v3:
+            # (the library keeps the global maximum id while it drives the steps; an upload in
+            # between - every tile its own share - leaves the tile's own maximum there)
+            self.shard.set_max_id(self.max_id)
         if self.v3 and after_births is None:
             n, b, d = self.shard.dev.tile_step(burn, with_selection, exact)
             self.max_id += b
             self.bytes_sent = self.shard.dev.comm_bytes_sent
             return n, b, d
+        if self.v3:
+            # the step in two library calls, the host's work on the newborns between them
+            dev = self.shard.dev
+            first, total = dev.tile_step_begin(burn)
+            self.max_id = first + total - 1
+            if total > 0:
+                after_births(first, total)
+            n, b, d = dev.tile_step_end(burn, with_selection, exact)
+            self.bytes_sent = dev.comm_bytes_sent
+            return n, b, d
         if self.v2:
-            if self.v3:
-                # (the library keeps the global maximum id while it drives the steps)
-                self.shard.set_max_id(self.max_id)
             return self._step_v2(burn, with_selection, after_births, exact)
         sh = self.shard
         self._tick(None)
@@ -966,7 +1015,17 @@ class TiledStepper:
         self._tick('halo')
         P, B = sh.pairs(burn)
         self._tick('pairs')
-        if self.dev_transport:
+        if hasattr(sh, 'dev') and sh.dev.id_order == 1:
+            # tile-major offspring ids: 64 birth counts per tile instead of every pair's key
+            vt = self.comm.allreduce_sum(np.concatenate([sh.dev.tile2_vt_counts(), [P]]))
+            total_births, total_pairs = int(vt[:64].sum()), int(vt[64])
+            if self.comm.world > 1:
+                sh.dev.tile2_vt_bases(np.concatenate([[0], np.cumsum(vt[:64])[:-1]]))
+            if self.dev_transport:
+                n_req = sh.dev.tile_offspring_dev(burn, self.max_id + 1, 0)
+            else:
+                n_req = sh.offspring(burn, self.max_id + 1, None)
+        elif self.dev_transport:
             n_req, total_births, total_pairs = self._offspring_dev(burn)
         else:
             goff, total_births, total_pairs = self._pair_offsets()

@@ -31,6 +31,12 @@ from .data import (_DataCollector, _get_adhoc_sample, _format_vcf, _format_fasta
                    _write_file)
 
 
+import threading as _threading
+
+# per-thread communicator override for the in-process rehearsals of a run over several ranks
+_rehearsal = _threading.local()
+
+
 class Model:
     def __init__(self, name, params, verbose=False, device=None):
         self.params = copy.deepcopy(params)
@@ -165,6 +171,14 @@ class Model:
         every rank builds the same Model and each Species is tiled over the ranks
         (structs/tiled.py).  Backend: RCCL ("nccl") unless GNX_DIST_BACKEND says
         otherwise (CPU rehearsals use "gloo")."""
+        # (rehearsals on a one-GPU box: the ranks are threads of one process, each building its
+        # Model with the communicator it was handed - tests/_local_comm.py - instead of a
+        # torch.distributed group; RCCL refuses two ranks on one device)
+        injected = getattr(_rehearsal, 'comm', None)
+        if injected is not None:
+            if injected.rank != 0:
+                self._verbose = False
+            return injected
         if int(os.environ.get('WORLD_SIZE', '1')) <= 1:
             return None
         import torch
@@ -575,16 +589,17 @@ class Model:
     def _lane_loop(self, first_main_only=False):
         """what run() does, on this lane, until the shared list of iterations is empty"""
         first = first_main_only
-        while first or len(self.its) > 0:
+        while first or self.__dict__.get('_next_it') is not None or len(self.its) > 0:
             try:
                 if first:
                     first = False
                     self._iteration_main()
                 else:
-                    try:
-                        self._next_it = self.its.pop()
-                    except IndexError:          # a sibling took the last iteration
-                        break
+                    if self.__dict__.get('_next_it') is None:    # (else: handed one by _run_concurrent)
+                        try:
+                            self._next_it = self.its.pop()
+                        except IndexError:          # a sibling took the last iteration
+                            break
                     self._iteration_burn()
                     self._iteration_main()
             except Exception as e:
@@ -607,6 +622,10 @@ class Model:
             self._orig_comm_snap = lanes[0]._orig_comm_snap
             self._never_been_run = False
             first_main_only = True
+        elif self.its and self.its[-1] == 0:
+            # iteration 0 is the one that is not reseeded: it belongs to the lane that carries the
+            # model's own random stream and original Community, whichever thread runs first
+            lanes[0]._next_it = self.its.pop()
         for _ in range(k - 1):
             lanes.append(self._spawn_lane(lanes[0].comm))
         for lane in lanes:

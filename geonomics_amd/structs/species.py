@@ -227,10 +227,24 @@ class Species:
                          device=self._device_ordinal)
         dev.upload_rasters(land._stack())
         dev.set_species_params(self._species_params_struct(land))
+        # Offspring ids (reference structs/species.py:614-619: max_ind_idx + 1 ... in the order of
+        # the mating pairs, which there is a Python set's - unspecified): virtual tile by virtual
+        # tile of a fixed 8 x 8 blocking of the landscape wherever its dimensions allow it, the
+        # order a run over several GPUs can hand out without telling every pair to every rank
+        # (csrc/gnx_comm.hip) - so that the same model script gives the same individuals, id by
+        # id, on one GPU and on eight.  GNX_ID_ORDER=0: the (hash cell, focal id) order of the
+        # whole landscape everywhere.
+        if self._tile_major_ids(land):
+            dev.set_id_order(1)
         self._land_ref = land
         self._dev = dev
         self._upload_gen_arch()
         return dev
+
+    def _tile_major_ids(self, land):
+        if os.environ.get('GNX_ID_ORDER', '1') == '0' or self._pv.mating_radius is None:
+            return False
+        return land.dim[0] % 8 == 0 and land.dim[1] % 8 == 0
 
     def _capacities(self, cap, N0):
         """(individual slots, genome rows) of the device state"""
@@ -444,10 +458,24 @@ class Species:
             # the device-driven steps cannot grow the device state (the queue's steps can,
             # _grow_device): they run in pieces, and only while the population leaves a third
             # of the capacity free - a piece whose births would not fit ends in an error
-            if len(self) > 0.66 * self._cap:
+            n_now = len(self)
+            if n_now > 0.66 * self._cap:
                 break
-            chunk = min(T - done, 256)
-            dev.walk(chunk, False, with_selection)
+            # (the fuller the device, the shorter the piece: a population can grow by about R per
+            # step - a piece must not be able to outgrow the free third)
+            room = max(self._cap - n_now, 1)
+            grow = max(0.02, float(getattr(self._pv, 'R', 0.5)) * 0.25) * max(n_now, 1)
+            chunk = int(max(1, min(T - done, 256, 0.5 * room / grow)))
+            err = None
+            try:
+                dev.walk(chunk, False, with_selection)
+            except nat.GnxError as e:
+                # the steps before the one that did not fit DID happen: their records are read
+                # below, the device's counters are the library's; the queue's steps (which can
+                # move the population to a larger device state) take over from there
+                if 'capacity exceeded' not in str(e):
+                    raise
+                err = e
             n0, births, deaths = dev.walk_history(chunk)
             for a, b, d in zip(n0.tolist(), births.tolist(), deaths.tolist()):
                 if a == 0:
@@ -455,13 +483,16 @@ class Species:
                     break
                 self.n_births.append(int(b))
                 self.n_deaths.append(int(d))
-                self.Nt.append(int(a + b - d))
                 self.max_ind_idx += int(b)
                 self.t += 1
                 done += 1
                 if a + b - d == 0:
+                    # (as in the queue: an extinct Species' step appends no Nt, sim/model.py:776-787)
                     self.extinct = True
                     break
+                self.Nt.append(int(a + b - d))
+            if err is not None:
+                break
         return done
 
     def _grow_device(self, factor=2.0):

@@ -55,13 +55,20 @@ class TiledSpecies(Species):
             raise NotImplementedError('panmixia is not supported on a tiled landscape')
         W, H = self._land_dim
         self._shard = DeviceShard(self._dev)
+        from ..parallel import tile_grid
+        R, C = tile_grid(self._comm.world)
+        # (tile-major offspring ids need a tile grid the 8 x 8 virtual tiles nest in: 1, 2, 4 or
+        # 8 tiles per axis; any other world keeps the (hash cell, focal id) order)
+        if self._dev.id_order == 1 and (8 % R or 8 % C):
+            self._dev.set_id_order(0)
+        # The library's own protocol whenever it can be joined (RCCL, or the in-process transport
+        # of the one-GPU tests): one or two C calls per step, the host's work on the newborns
+        # (mutations, pedigree rows) between them; else the Python-driven protocol over
+        # torch.distributed (gloo rehearsals), with the same offspring ids either way.
         self._stepper = TiledStepper(
             self._shard, self._comm, W, H, float(self.mating_radius), move=self._move,
             max_id=N - 1,
-            fixed_births=int(self.n_births_distr_lambda) if self.n_births_fixed else 0,
-            # (the Model API steps with per-step hooks and promises the plain Species' ids:
-            # the Python-driven protocol, offspring ids in (hash cell, focal id) order)
-            use_library=False)
+            fixed_births=int(self.n_births_distr_lambda) if self.n_births_fixed else 0)
         self._shard.export_migrants()       # every rank drew all N; keep this tile's
         self._glob_N = int(N)
 

@@ -446,6 +446,22 @@ int gnx_tile2_route_finish(gnx_state* h, const int64_t* counts);
  * host with its own exchange (gnx_tile2_set_requests) before gnx_tile2_offspring.             */
 int gnx_tile2_requests_dev(gnx_state* h, int32_t on, void** counts_dev);
 int gnx_tile2_set_requests(gnx_state* h, const int64_t* req);
+/* gnx_tile_step on several tiles, a fixed number of births per pair: gnx_tile2_pairs does not
+ * wait for the pair count either (mode 1: counts[0] = counts[1] = -1) - the pairs' density bins
+ * and the request counts read it on the device - and _settle does the host's bookkeeping once
+ * the count has arrived with the caller's own exchange (births: fixed lambda x P).            */
+int gnx_tile2_pairs_mode(gnx_state* h, int32_t nowait);
+int gnx_tile2_pairs_settle(gnx_state* h, int32_t burn, int64_t n_pairs, int64_t* births);
+/* the offspring that took a remote gamete re-read their alleles at the selected loci and their
+ * phenotype from their finished rows (gnx_tile2_finish_births does it unless this has)        */
+int gnx_tile2_settle_births(gnx_state* h, int32_t burn);
+/* Tile-major offspring ids (gnx_set_id_order 1) through a caller-driven protocol
+ * (TiledStepper._step_v2): counts[64] = this tile's births per virtual tile (one wait; the
+ * classification rode with gnx_tile2_pairs), then bases[64] = the virtual tiles' global base
+ * offsets in births (the exclusive sums of every tile's counts) before gnx_tile2_offspring,
+ * which is then handed no offsets.                                                           */
+int gnx_tile2_vt_counts(gnx_state* h, int64_t* counts);
+int gnx_tile2_vt_bases(gnx_state* h, const int64_t* bases);
 int gnx_tile2_route_ptrs(gnx_state* h, void** mig_rec, void** mig_z, void** mig_geno,
                          void** ghost_rec);
 /* arrivals (device buffers): migrants rec / z / geno [n_mig], ghosts rec [n_ghost]; (no wait).
@@ -494,8 +510,20 @@ int gnx_tile2_die(gnx_state* h, int32_t burn, int32_t with_selection, int32_t ha
  *     calls themselves is the same code;
  *   gnx_tile_step: one step.  out[3]: exact != 0 -> the global (N after the step, births,
  *     deaths), one more KB-sized collective; else what rode on the step's own all-reduce:
- *     (N at the START of the step, births, deaths of the PREVIOUS step).  Births per pair must
- *     be fixed (Poisson births travel with the pair keys through the host layer: returns 3).
+ *     (N at the START of the step, births, deaths of the PREVIOUS step).  Poisson births
+ *     (ops/mating.py:120-126) are numbered like fixed ones: the virtual tiles' BIRTH counts travel.
+ *   gnx_tile_step_begin / _end: the same step in two calls, split where the reference's
+ *     _do_pop_dynamics has its host work on the newborns - mutation (ops/mutation.py:169-206) and
+ *     pedigree rows (structs/species.py:692-736) sit between the births and the deaths: after
+ *     _begin every offspring of the step has its record, its alleles at the selected loci and
+ *     its phenotype (gnx_last_births, gnx_mutate work there); gnx_tile_step_births tells the first
+ *     id and the number of the step's offspring over ALL tiles; _end takes the densities' one
+ *     all-reduce, the death probabilities and the mortality.  gnx_tile_step = both.
+ *   gnx_comm_probe: librccl can be loaded and has every entry point the transport uses - what
+ *     the ranks tell each other (over the launcher's CPU group) BEFORE any of them enters
+ *     gnx_comm_init_rccl, whose ncclCommInitRank nobody can be called back from; the init itself
+ *     carries a deadline (GNX_COMM_INIT_TIMEOUT_S, default 180 s): past it the rank says why on
+ *     stderr and ends the process with code 86.
  *   The global maximum id (gnx_set_max_id) must be the same on every rank before the first
  *   step; the library keeps it.                                                             */
 /* 0 (default): offspring ids in the canonical (hash cell, focal id) order of the pairs over the
@@ -522,6 +550,11 @@ int64_t gnx_comm_bytes_sent(gnx_state* h);
  * communicator use the RCCL calls themselves instead of the one-rank shortcuts.) */
 int gnx_comm_selftest(gnx_state* h);
 int gnx_tile_step(gnx_state* h, int32_t burn, int32_t with_selection, int32_t exact, int64_t* out);
+int gnx_tile_step_begin(gnx_state* h, int32_t burn);
+int gnx_tile_step_births(gnx_state* h, int64_t* first_id, int64_t* total);
+int gnx_tile_step_end(gnx_state* h, int32_t burn, int32_t with_selection, int32_t exact,
+                      int64_t* out);
+int gnx_comm_probe(void);
 
 /* ---- pedigree (reference structs/species.py:692-736: rows of the tskit tables) --
  * the offspring of the last gnx_pop_dynamics_mate, in birth order; call it before

@@ -237,13 +237,15 @@ def test_fused_step_path_matches_oracle_crossover(dense, overlap):
     b.close()
 
 
-@pytest.mark.parametrize('overlap', [0, 1])
-def test_two_tiles_match_oracle_crossover(overlap):
+@pytest.mark.parametrize('overlap,library', [(0, False), (1, False), (0, True), (1, True)])
+def test_two_tiles_match_oracle_crossover(overlap, library):
     """two tiles (threads of this process, device-resident transport) through gnx_tile_*:
     deferred crossover per tile, gametes of ghost mates cut on the owning tile, migrants
     carrying their genomes.  Each tile's births are read in the stepper's after-births hook.
     overlap = 1: the crossover runs beside the whole next step, i.e. it may still be in flight
-    when the tile serves its neighbours' gamete requests (the service waits for it)."""
+    when the tile serves its neighbours' gamete requests (the service waits for it).
+    library: every step inside the library's own protocol (gnx_tile_step_begin, the hook,
+    gnx_tile_step_end - csrc/gnx_comm.hip), the oracle replaying the LIBRARY path's births."""
     import torch
     from _local_comm import Hub, LocalComm
     from geonomics_amd.parallel import DeviceShard, TiledStepper
@@ -260,7 +262,7 @@ def test_two_tiles_match_oracle_crossover(overlap):
     g[:, :, L // 64 + 1:] = 0
     host = HostGenomes(np.arange(N), g, paths)
     lock = threading.Lock()
-    hub = Hub(2)
+    hub = Hub(2, library_group=library)
     errs, sizes, gcs, pending = [], [0, 0], [0, 0], [[], []]
 
     def body(rank):
@@ -271,7 +273,8 @@ def test_two_tiles_match_oracle_crossover(overlap):
                            overlap=overlap)
             shard = DeviceShard(dev)
             stepper = TiledStepper(shard, comm, Wt, Ht, 3.0, move=True, max_id=N - 1,
-                                   fixed_births=1, use_library=False)
+                                   fixed_births=1, use_library=library)
+            assert stepper.v3 == library
             mine = stepper.rank_of(x, y) == rank
             dev.upload_population(x[mine], y[mine], age[mine], np.zeros(mine.sum()),
                                   np.arange(N)[mine])
@@ -306,7 +309,7 @@ def test_two_tiles_match_oracle_crossover(overlap):
             dev.close()
         except BaseException as e:       # noqa: BLE001 - re-raised in the main thread
             errs.append(e)
-            hub.barrier.abort()
+            hub.abort()
 
     ths = [threading.Thread(target=body, args=(r,)) for r in range(2)]
     for th in ths:

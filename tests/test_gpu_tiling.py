@@ -101,7 +101,7 @@ def _run_threads(world, steps, fixed, library=False, expect_v3=None):
                                    max_id=cfg['N0'] - 1, fixed_births=1 if fixed else 0,
                                    use_library=library)
             assert stepper.dev_transport == (world > 1)
-            assert stepper.v3 == (bool(library and fixed) if expect_v3 is None else expect_v3)
+            assert stepper.v3 == (bool(library) if expect_v3 is None else expect_v3)
             shard.export_migrants()
             hist = []
             for t in range(steps):
@@ -151,21 +151,99 @@ def test_device_resident_transport_is_bit_identical(world, fixed):
     assert many['bytes_sent'] > 0 and len(one['ids']) > 500
 
 
-@pytest.mark.parametrize('world', [2, 4, 8])
-def test_library_tile_step_is_bit_identical(world):
+@pytest.mark.parametrize('world,fixed', [(2, True), (4, True), (8, True), (2, False), (4, False)])
+def test_library_tile_step_is_bit_identical(world, fixed):
     """gnx_tile_step: the whole tiled step in ONE call into the library, which issues the
     exchanges itself (csrc/gnx_comm.hip).  On this one-GPU box the tiles are threads of one
     process and the transport is the library's local one (device copies behind a barrier of
     the threads; on a node it is grouped ncclSend / ncclRecv on the same code path): the tiled
     run equals the one-tile run bit for bit, and equals the run the Python-driven protocol
-    (TiledStepper._step_v2) gives."""
+    (TiledStepper._step_v2) gives.  fixed = False: Poisson births (ops/mating.py:120-126) - the
+    virtual tiles' BIRTH counts travel and the pairs' ranks are in births (round 5; round 4 sent
+    such species through the Python-driven protocol)."""
     steps = 8
-    one = _run_threads(1, steps, True, library=True)
-    many = _run_threads(world, steps, True, library=True)
+    one = _run_threads(1, steps, fixed, library=True)
+    many = _run_threads(world, steps, fixed, library=True)
     assert one['hist'].tolist() == many['hist'].tolist()
     for k in ('ids', 'x', 'y', 'age', 'z', 'geno'):
         np.testing.assert_array_equal(one[k], many[k], err_msg=k)
     assert len(one['ids']) > 500
+
+
+def test_virtual_tile_boundaries_are_exact():
+    """the virtual tile of a pair was classified with a reciprocal,
+    (int)(x * (8 / W)), while tile ownership is exact on the integer boundaries - for W = 1000 the
+    float just below x = 500 went to virtual-tile column 4 although tile 0 owns it, two tiles
+    numbered pairs of one virtual tile independently and two offspring got the same id.  A
+    landscape 1000 wide (8 / W is not a power of two), a third of the individuals sitting on
+    nextafter(boundary, 0) of the virtual tiles' and the tiles' boundaries, nobody moving: two
+    tiles through the library's protocol hand out unique ids and equal the one-device run."""
+    import threading
+    import torch
+    from _local_comm import Hub, LocalComm
+    from geonomics_amd import _native as nat
+    from geonomics_amd.parallel import Comm, DeviceShard, TiledStepper
+    W, H, N = 1000, 40, 6000
+    rng = np.random.RandomState(11)
+    x = (rng.rand(N) * W).astype(np.float32)
+    y = (rng.rand(N) * H).astype(np.float32)
+    edge = rng.rand(N) < 0.35
+    x[edge] = np.nextafter(np.float32(125) * rng.randint(1, 8, edge.sum()).astype(np.float32),
+                           np.float32(0))
+    edge_y = rng.rand(N) < 0.2
+    y[edge_y] = np.nextafter(np.float32(5) * rng.randint(1, 8, edge_y.sum()).astype(np.float32),
+                             np.float32(0))
+    assert (x < W).all() and (y < H).all() and (x == np.nextafter(np.float32(500), np.float32(0))).sum() > 100
+    rasts = np.ones((2, H, W), np.float32)
+
+    def make():
+        dev = nat.Device(W, H, 2, L=0, n_traits=0, cap_inds=32768, cap_rows=16, seed=5, device=0)
+        dev.upload_rasters(rasts)
+        dev.set_species_params(nat.default_species_params(mating_radius=3.0, K_factor=0.2,
+                                                          move=0))
+        return dev
+
+    def run(world):
+        hub = Hub(world, library_group=world > 1)
+        res, errs = [None] * world, []
+
+        def body(rank):
+            try:
+                torch.cuda.set_device(0)
+                comm = LocalComm(hub, rank) if world > 1 else Comm(None)
+                dev = make()
+                stepper = TiledStepper(DeviceShard(dev), comm, W, H, 3.0, move=False, max_id=N - 1,
+                                       fixed_births=1, use_library=True)
+                assert stepper.v3
+                mine = stepper.rank_of(x, y) == rank
+                dev.upload_population(x[mine], y[mine], np.zeros(mine.sum()), np.zeros(mine.sum()),
+                                      np.arange(N)[mine])
+                hist = [stepper.step(True, False) for _ in range(5)]
+                res[rank] = dict(ids=dev.download(nat.F_ID), x=dev.download(nat.F_X),
+                                 y=dev.download(nat.F_Y), hist=hist)
+                dev.close()
+            except BaseException as e:       # noqa: BLE001
+                errs.append(e)
+                hub.abort()
+
+        ths = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(timeout=300)
+        if errs:
+            raise errs[0]
+        ids = np.concatenate([r['ids'] for r in res])
+        o = np.argsort(ids, kind='stable')
+        return dict(ids=ids[o], x=np.concatenate([r['x'] for r in res])[o],
+                    y=np.concatenate([r['y'] for r in res])[o], hist=res[0]['hist'])
+
+    one, two = run(1), run(2)
+    assert len(np.unique(two['ids'])) == len(two['ids']), 'two offspring share an id'
+    assert len(one['ids']) > 3000 and one['hist'][-1][1] > 100        # births happened
+    assert one['hist'] == two['hist']
+    for k in ('ids', 'x', 'y'):
+        np.testing.assert_array_equal(one[k], two[k], err_msg=k)
 
 
 def test_failed_self_test_drops_the_library_path_on_every_rank(monkeypatch):
@@ -200,13 +278,29 @@ def test_rccl_world1_through_the_library():
     dev_a.comm_selftest()
     dev_a.set_max_id(cfg['N0'] - 1)
     dev_b.set_id_order(1)            # gnx_tile_step numbers offspring virtual tile by virtual tile
-    for t in range(6):
-        n, b, d = dev_a.tile_step(True, False, True)
-        dev_b.step(True, False)
+    import gnx_oracle as O
+    for t in range(11):
+        burn = t < 3
+        if t == 3:
+            # main steps with genomes and selection: the count gathers and the densities' sum of
+            # every one of them go through ncclAllGather / ncclAllReduce
+            n = O.starting_mutation_counts(dev_a.N, np.full(cfg['L'], 0.5))
+            dev_a.assign_genomes(n)
+            dev_b.assign_genomes(n)
+        if t % 2:
+            n, b, d = dev_a.tile_step(burn, not burn, True)
+        else:                         # (... and in two calls, as with a host hook in between)
+            first, total = dev_a.tile_step_begin(burn)
+            assert total == dev_a.counts()[1] and first + total - 1 >= cfg['N0'] - 1
+            n, b, d = dev_a.tile_step_end(burn, not burn, True)
+        dev_b.step(burn, not burn)
         assert (n, b, d) == dev_b.counts()
     oa, ob = np.argsort(dev_a.download(nat.F_ID)), np.argsort(dev_b.download(nat.F_ID))
     for f in (nat.F_ID, nat.F_X, nat.F_Y, nat.F_AGE):
         np.testing.assert_array_equal(dev_a.download(f)[oa], dev_b.download(f)[ob])
+    np.testing.assert_array_equal(dev_a.download(nat.F_Z)[:, oa], dev_b.download(nat.F_Z)[:, ob])
+    np.testing.assert_array_equal(dev_a.download(nat.F_GENO)[oa], dev_b.download(nat.F_GENO)[ob])
+    assert dev_a.counts()[0] > 500
     dev_a.close()
     dev_b.close()
 
@@ -390,6 +484,85 @@ def test_model_over_two_ranks_with_mutation(tmp_path):
     # 'use_tskit': the pedigree recorded on one GPU and over two ranks reproduces the
     # device genotypes (edges + mutation rows, structs/pedigree.py)
     assert int(one['ped_ok']) == 1 and int(two['ped_ok']) == 1
+
+
+def _run_model_threads(tmp_path, world, traits, tag, **kw):
+    """the ranks of a Model run as THREADS of this process, each with its own device handle on
+    the one GPU and the in-process communicator (tests/_local_comm.py) handed to its Model: the
+    tiles meet inside libgnxhip.so and every step goes through the library's own protocol
+    (gnx_tile_step / _begin + _end) - what runs under RCCL on a node"""
+    import threading
+    import torch
+    from _local_comm import Hub, LocalComm
+    from _tiled_model_worker import run_model
+    from geonomics_amd.sim import model as M
+    wd = tmp_path / ('wd_' + tag)
+    wd.mkdir()
+    cwd = os.getcwd()
+    os.chdir(wd)
+    hub = Hub(world, library_group=True)
+    res, errs = [None] * world, []
+
+    def body(rank):
+        try:
+            torch.cuda.set_device(0)
+            M._rehearsal.comm = LocalComm(hub, rank)
+            res[rank] = run_model(traits, rank=rank, world=world, **kw)
+        except BaseException as e:       # noqa: BLE001 - re-raised in the main thread
+            errs.append(e)
+            hub.abort()
+        finally:
+            M._rehearsal.comm = None
+
+    ths = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    try:
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(timeout=600)
+    finally:
+        os.chdir(cwd)
+    if errs:
+        raise errs[0]
+    return res, wd
+
+
+@pytest.mark.parametrize('variant', ['neutral', 'mutate', 'poisson', 'selection'])
+def test_model_over_two_tiles_through_the_library(tmp_path, variant):
+    """Model.walk over two ranks with every step inside the library's tile protocol
+    (stepper.v3): Nt, births, deaths, ids and positions equal the one-process run - which hands
+    out the same tile-major offspring ids -, with mutations (the host's hook between
+    gnx_tile_step_begin and _end places the one-process run's mutations: genotypes equal),
+    with Poisson births (the virtual tiles' BIRTH counts travel), with selection"""
+    kw = dict(mutate=variant == 'mutate', poisson=variant == 'poisson')
+    traits = variant == 'selection'
+    one, _ = _run_model(tmp_path, 1, traits, 'one',
+                        extra=tuple(k for k, v in kw.items() if v))
+    two, _ = _run_model_threads(tmp_path, 2, traits, 'two', **kw)
+    for r in two:
+        assert r['v3'] == 1 and r['id_order'] == 1, 'the steps did not go through the library'
+    assert int(one['id_order']) == 1
+    a, b = two
+    for k in ('Nt', 'births', 'deaths', 'ids', 'xy', 'g'):          # accessors are global
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    if variant == 'selection':
+        # (which homologues got the starting 1-alleles differs between one and two tiles:
+        # selection then acts on different genotypes - the burn-in is the same run)
+        nb = int(one['nburn'])
+        np.testing.assert_array_equal(one['Nt'][:nb], a['Nt'][:nb])
+        assert abs(one['Nt'][-10:].mean() - a['Nt'][-10:].mean()) < 0.15 * one['Nt'][-10:].mean()
+        assert np.isfinite(a['z']).all() and a['z'].shape == (len(a['ids']), 2)
+        return
+    for k in ('Nt', 'births', 'deaths', 'nburn', 'ids'):
+        np.testing.assert_array_equal(one[k], a[k], err_msg=k)
+    np.testing.assert_array_equal(one['xy'], a['xy'])
+    np.testing.assert_allclose(one['N_rast'], a['N_rast'], rtol=1e-12, atol=1e-12)
+    if variant == 'mutate':
+        assert one['g'].sum() > 0
+        np.testing.assert_array_equal(one['g'], a['g'])
+        assert int(one['ped_ok']) == 1 and a['ped_ok'] == 1
+    if variant == 'poisson':
+        assert (one['births'] > 0).any()
 
 
 def test_device_transport_across_processes(tmp_path, monkeypatch):
