@@ -527,7 +527,7 @@ extern "C" void gnx_destroy(gnx_state* h) {
   gnx_dd_destroy(h);
   (void)gnx_comm_free(h);
   {
-    void* vt[] = {h->vt_cls, h->vt_rank, h->vt_pblk, h->vt_blk_cnt, h->vt_blk_off, h->vt_count, h->vt_base};
+    void* vt[] = {h->vt_cls, h->vt_scls, h->vt_blk_nz, h->vt_rank, h->vt_pblk, h->vt_blk_cnt, h->vt_blk_off, h->vt_count, h->vt_base};
     for (void* q : vt)
       if (q) (void)hipFree(q);
   }
@@ -1109,6 +1109,7 @@ extern "C" int gnx_pop_dynamics_mate(gnx_state* h, int32_t burn) {
   GNXCHK(need_params(h));
   GNXCHK(check_recomb_ready(h, burn != 0));
   int64_t P = 0, B = 0;
+  h->tile2_mode = false;
   // 1. mating pairs (cell-sorted population)
   //    (the columns the mate search and the pair list do not read are permuted on the side
   //    stream meanwhile, and waited for before the births)
@@ -1174,6 +1175,7 @@ extern "C" int gnx_step_begin(gnx_state* h, int32_t burn) {
   h->tot[0] += 1;
   h->tot[1] += h->N - h->n_ghost;
   h->last_xo_births = 0;
+  h->tile2_mode = false;        // (a handle that stepped through the tile protocol before)
   if (h->sp.move) {
     h->move_writes_keys = h->sp.mating_radius >= 0;     // the cell sort follows at once
     int rc = gnx_l_move(h, true, nullptr, nullptr, nullptr, nullptr, true);
@@ -1250,6 +1252,7 @@ extern "C" int gnx_set_id_order(gnx_state* h, int32_t mode) {
     gnx_set_error("tile-major offspring ids need landscape dimensions divisible by 8");
     return 1;
   }
+  if (mode == 1) GNXCHK(gnx_vt_buffers(h));
   h->id_order = mode;
   h->cfg_epoch += 1;
   return 0;

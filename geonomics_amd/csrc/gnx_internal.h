@@ -361,7 +361,10 @@ struct gnx_state {
   bool pair_goff_local_base = false;   // ... numbered from this device's own counts alone
   bool vt_fused = false;          // k_pair_compact classified this step's pairs (fixed births)
   int64_t vt_mul = 1;             // births per unit of vt_rank / vt_count: lambda, or 1 (Poisson)
+  bool vt_weighted = false;       // this step's ranks came from k_pair_cls (Poisson births)
   uint8_t* vt_cls = nullptr;
+  uint8_t* vt_scls = nullptr;
+  unsigned long long* vt_blk_nz = nullptr;
   int32_t *vt_rank = nullptr, *vt_pblk = nullptr, *vt_blk_cnt = nullptr, *vt_blk_off = nullptr,
           *vt_count = nullptr;
   int64_t* vt_base = nullptr;
@@ -415,6 +418,8 @@ struct gnx_state {
   std::vector<int64_t> req_by_rank;  // gamete requests per owning rank (gnx_tile2_pairs)
   bool rq_is2 = false;               // rq_sorted holds 24-byte gnx_gamete_req2 records
   bool tile_req_on_device = false;   // gnx_tile2_pairs leaves the request counts in route_cnt (no wait)
+  bool tile2_mode = false;           // the handle steps through the tile2 protocol (set by its entry points)
+  bool req_cnt_zeroed = false;       // the request counters were cleared by k_tile2_zero
   bool tile_pairs_nowait = false;    // ... and does not wait for the pair count either (gnx_tile_step)
   bool tile_births_settled = false;  // the offspring with a remote gamete have re-read their rows
 
@@ -633,6 +638,7 @@ int gnx_l_find_pairs_enqueue(gnx_state* h, const uint8_t* d_keep, bool with_dens
 int gnx_l_find_pairs_finish(gnx_state* h, int64_t* n_pairs_out);
 int gnx_l_births(gnx_state* h, int64_t* births_out);
 int gnx_l_pair_cls(gnx_state* h, int64_t P, bool local);
+int gnx_vt_buffers(gnx_state* h);      // (allocated by gnx_set_id_order: never inside a stream capture)
 int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* births_out,
                int64_t id_base = -1, bool tiled = false);
 int gnx_l_dispersal_inject(gnx_state* h, int64_t B, int A, const float* d_mx, const float* d_my,

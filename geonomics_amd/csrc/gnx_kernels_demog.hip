@@ -662,7 +662,7 @@ bool gnx_fused_bins(const gnx_state* h) {
   const int64_t nn = (int64_t)h->lat.Jx * h->lat.Jy;
   const size_t lds = ((size_t)4 * nn + std::max(h->lat.Jx, h->lat.Jy) + 1 + 2 * h->lat.Jx + 256) *
                      sizeof(double);
-  return on && !h->tiled && h->fb[0] != nullptr && h->stream3 != nullptr && lds <= 64 * 1024 &&
+  return on && !h->tiled && !h->tile2_mode && h->fb[0] != nullptr && h->stream3 != nullptr && lds <= 64 * 1024 &&
          (size_t)h->lat.nbx * h->lat.nby * sizeof(int32_t) <= 48 * 1024;
 }
 

@@ -521,8 +521,11 @@ __global__ void k_permute(int64_t N, int64_t cap, const int32_t* perm, GnxSoA a,
                           const int32_t* __restrict__ ord, int64_t ord_n,
                           int32_t* __restrict__ ord_new, int32_t* __restrict__ perm_out,
                           uint4* __restrict__ wipe, int64_t wipe_n, int hot_only,
-                          const GnxDD* __restrict__ dd, GnxBinP bins) {
+                          const GnxDD* __restrict__ dd, GnxBinP bins, int32_t* __restrict__ vt_zero) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // (tile-major offspring ids: the virtual tiles' pair counts of this step start at zero -
+  // k_pair_flags adds to them)
+  if (vt_zero && i < 64) vt_zero[i] = 0;
   if (dd) {
     // device-driven step: the sort ran over the handle's capacity, the entries behind the
     // population carry the largest key and came out behind it
@@ -747,7 +750,8 @@ int gnx_l_sort_by_cell(gnx_state* h, bool split_rest) {
                      h->key64[1], idbits, h->cell_start, h->ncx * h->ncy,
                      ordm ? h->keyk[1] : nullptr, h->ord[h->ord_cur], h->ord_n,
                      h->ord[h->ord_cur ^ 1], h->perm[1], (uint4*)h->os_scratch, (wipe_words + 3) / 4,
-                     split ? 1 : 0, (const GnxDD*)nullptr, GnxBinP{nullptr, 0.0, 0, 0});
+                     split ? 1 : 0, (const GnxDD*)nullptr, GnxBinP{nullptr, 0.0, 0, 0},
+                     h->id_order == 1 ? h->vt_count : (int32_t*)nullptr);
   if (split) {
     // the columns nobody reads before the births follow on stream3, beside the mate search and
     // the pair list; whoever asked for the split waits (gnx_wait_permute_rest).
@@ -1208,70 +1212,6 @@ k_find_mates(FocalP fp, GnxSoA s, const uint4* __restrict__ cand, double inv_cs,
   }
 }
 
-// Bernoulli(b) thinning (structs/species.py:2210-2214), sex filter
-// (ops/mating.py:41-55), reproductive-age filter (:79-104) of the pair (i, mate[i]).
-struct PairP {
-  int64_t N;
-  const int32_t* focal;
-  const int32_t* mate;
-  const uint8_t* keep_in;
-  float b;
-  int sexed, ra_f, ra_m, dedup;
-  long long step;
-  unsigned long long seed;
-  const GnxDD* dd;
-};
-
-__device__ __forceinline__ bool pair_ok(const PairP& P, const GnxSoA& s, int64_t i) {
-  const int m = P.mate[i];
-  if (m < 0) return false;
-  const int fo = P.focal ? P.focal[i] : (int)i;
-  bool keep;
-  if (P.keep_in) {
-    keep = P.keep_in[i] != 0;
-  } else {
-    uint4 r = gnx_rand4(P.seed, (unsigned long long)s.id[i], P.step, OP_PAIR_KEEP, 0);
-    keep = gnx_u01(r.x) < P.b;
-  }
-  bool ok = keep;
-  if (P.sexed) ok = ok && (s.sex[fo] == 0) && (s.sex[m] == 1);
-  return ok && (s.age[fo] >= P.ra_f) && (s.age[m] >= P.ra_m);
-}
-
-// + unordered-pair de-duplication (ops/mating.py:62-65): the reference keeps one of
-// (i,m),(m,i); drop (i,m) iff (m,i) is also present and id_m < id_i (ids, not slots, so
-// every tile of a tiled run takes the same decision).  A pair belongs to the tile that
-// owns its focal individual: ghost focals only serve the reciprocity test.  Flags and
-// their per-block counts (gnx_compact.h).
-__global__ void __launch_bounds__(256)
-k_pair_flags(PairP P, GnxSoA s, int32_t* flag2, int32_t* cnt) {
-  __shared__ int lds[16];
-  const int64_t base = (int64_t)blockIdx.x * GNX_CB;
-  P.N = gnx_dd_n(P.dd, P.N);
-  P.step = gnx_dd_step(P.dd, P.step);
-  bool f[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int64_t i = base + r * 256 + threadIdx.x;
-    f[r] = false;
-    if (i < P.N) {
-      bool ok = pair_ok(P, s, i);
-      if (ok && P.dedup) {
-        const int m = P.mate[i];
-        if (P.mate[m] == (int32_t)i && s.id[m] < s.id[i] && pair_ok(P, s, m)) ok = false;
-      }
-      if (s.ghost[i]) ok = false;
-      f[r] = ok;
-      flag2[i] = ok ? 1 : 0;
-    }
-  }
-  int rank[4], tot;
-  gnx_block_ranks(f, rank, tot, lds);
-  // (the scan of the block counts stays a launch of its own: done by the last workgroup of
-  // this kernel - gnx_count_and_scan - it cost 10 us more than k_block_scan's 6)
-  if (threadIdx.x == 0) cnt[blockIdx.x] = tot;
-}
-
 // ---------------------------------------------------------------- offspring ids, tile-major
 // gnx_set_id_order(h, 1): offspring ids are handed out virtual tile by virtual tile - a fixed
 // 8 x 8 blocking of the landscape that every tile grid dividing 8 x 8 is a union of - and
@@ -1293,18 +1233,46 @@ k_pair_flags(PairP P, GnxSoA s, int32_t* flag2, int32_t* cnt) {
 
 struct GnxVtP {
   int vw, vh;                 // raster cells per virtual tile: W / 8, H / 8 (exact: gnx_set_id_order)
+  float inv_w, inv_h;         // 1 / vw, 1 / vh: the estimate the exact boundaries correct
 };
+// (exact on the integer boundaries, like tile ownership - gnx_tile_index -, without its division:
+// the reciprocal's estimate is off by one at most, two comparisons with the exact boundaries
+// k * vw settle it)
+__device__ __forceinline__ int gnx_vt_axis(float v, int vw, float inv) {
+  int c = min(GNX_VT - 1, max(0, (int)(v * inv)));
+  c -= (c > 0 && (float)(c * vw) > v) ? 1 : 0;
+  c += (c + 1 < GNX_VT && (float)((c + 1) * vw) <= v) ? 1 : 0;
+  return c;
+}
 __device__ __forceinline__ int gnx_vt_of(const GnxVtP& V, float x, float y) {
-  // (exact on the integer boundaries, like tile ownership: gnx_tile_index)
-  return gnx_tile_index(y, V.vh, GNX_VT) * GNX_VT + gnx_tile_index(x, V.vw, GNX_VT);
+  return gnx_vt_axis(y, V.vh, V.inv_h) * GNX_VT + gnx_vt_axis(x, V.vw, V.inv_w);
 }
 
-// what k_pair_compact leaves per pair when ids are tile-major (cls == null: nothing)
+// Tile-major ids with a fixed number of births per pair, in the two kernels of the pair list
+// (cls == null: off):
+//   k_pair_flags   - the virtual tile of every kept pair (by its focal individual's position:
+//                    scls, one byte per slot), the block's pairs per virtual tile (blk_cnt) and,
+//                    one atomic per block and virtual tile it touches, the device's totals
+//                    (total[64]: zeroed by k_permute; on tiles the counts that travel);
+//   k_pair_compact - per pair its virtual tile (cls) and its rank among ALL pairs of that
+//                    virtual tile before it on this device (rank): the in-block rank plus the
+//                    counts of the blocks before - a workgroup adds those up for the one to three
+//                    virtual tiles it touches itself, a few coalesced loads from L2 (blocks are
+//                    1024 SLOTS, neighbours in space); workgroup 0 also turns the totals into the
+//                    virtual tiles' base offsets when nobody else has pairs (local).
+// k_offspring: id offset = base[cls] + rank * lambda + ordinal.  No kernel of their own on the
+// step's chain (the first cut of round 5 scanned the blocks' counts in one: 23 us).
 struct GnxVtOut {
-  uint8_t* cls;               // virtual tile of the pair (by its focal individual's position)
-  int32_t* rank;              // pairs of the same virtual tile before it in its block
-  int32_t* pblk;              // the block
-  int32_t* blk_cnt;           // [blocks][64] pairs per virtual tile
+  uint8_t* scls;              // [slots] virtual tile of a kept pair's focal individual
+  int32_t* blk_cnt;           // [64][stride] pairs per virtual tile and block, class-major
+  unsigned long long* blk_nz; // [blocks] the virtual tiles the block touches
+  int stride;
+  int32_t* total;             // [64] pairs per virtual tile on this device
+  uint8_t* cls;               // [pairs]
+  int32_t* rank;              // [pairs]
+  int64_t* base;              // [64] written by k_pair_compact when local
+  int local;
+  int64_t lam;
   GnxVtP V;
 };
 
@@ -1437,38 +1405,48 @@ struct GnxGoff {
   const int64_t* goff;
   const uint8_t* cls;
   const int32_t* rank;
-  const int32_t* pblk;
+  const int32_t* pblk;        // Poisson births: the pair's block and the blocks' offsets (else null)
   const int32_t* blk_off;
   const int64_t* vt_base;
   int64_t mul;                // births per unit of rank: lambda (fixed births), 1 (Poisson)
 };
 
-static int vt_buffers(gnx_state* h) {
+int gnx_vt_buffers(gnx_state* h) {
   if (h->vt_cls) return 0;
   const size_t cap = (size_t)h->cfg.cap_inds;
   const size_t nb = cap / GNX_CB + 2;
   HIPCHK(hipMalloc((void**)&h->vt_cls, cap));
+  HIPCHK(hipMalloc((void**)&h->vt_scls, cap));
+  HIPCHK(hipMalloc((void**)&h->vt_blk_nz, nb * sizeof(unsigned long long)));
   HIPCHK(hipMalloc((void**)&h->vt_rank, cap * sizeof(int32_t)));
   HIPCHK(hipMalloc((void**)&h->vt_pblk, cap * sizeof(int32_t)));
   HIPCHK(hipMalloc((void**)&h->vt_blk_cnt, nb * GNX_VTN * sizeof(int32_t)));
   HIPCHK(hipMalloc((void**)&h->vt_blk_off, nb * GNX_VTN * sizeof(int32_t)));
   // (+ room behind the 64 counts for a tile's gamete-request counts: one device vector for the
   // count exchange of gnx_tile_step)
-  HIPCHK(hipMalloc((void**)&h->vt_count, (GNX_VTN + GNX_MAX_TILES) * sizeof(int32_t)));
+  HIPCHK(hipMalloc((void**)&h->vt_count, (GNX_VTN + GNX_MAX_TILES + 8) * sizeof(int32_t)));
+  HIPCHK(hipMemset(h->vt_count, 0, (GNX_VTN + GNX_MAX_TILES + 8) * sizeof(int32_t)));
   HIPCHK(hipMalloc((void**)&h->vt_base, GNX_VTN * sizeof(int64_t)));
   return 0;
 }
 
-static GnxVtP gnx_vtp(const gnx_state* h) { return GnxVtP{h->cfg.W / GNX_VT, h->cfg.H / GNX_VT}; }
+static GnxVtP gnx_vtp(const gnx_state* h) {
+  const int vw = h->cfg.W / GNX_VT, vh = h->cfg.H / GNX_VT;
+  return GnxVtP{vw, vh, 1.0f / (float)vw, 1.0f / (float)vh};
+}
 
 // what k_pair_compact is handed when the ids are tile-major and every pair has the same
 // number of births (else nothing: the weighted classification follows the birth draws)
 static int gnx_vt_out(gnx_state* h, GnxVtOut* out) {
-  *out = GnxVtOut{nullptr, nullptr, nullptr, nullptr, GnxVtP{1, 1}};
+  *out = GnxVtOut{nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 1,
+                  GnxVtP{1, 1, 1.f, 1.f}};
   h->vt_fused = false;
   if (h->id_order != 1 || !h->sp.n_births_fixed || h->sp.mating_radius < 0) return 0;
-  GNXCHK(vt_buffers(h));
-  *out = GnxVtOut{h->vt_cls, h->vt_rank, h->vt_pblk, h->vt_blk_cnt, gnx_vtp(h)};
+  GNXCHK(gnx_vt_buffers(h));
+  // (several tiles: the bases come from every tile's totals, gnx_tile_step)
+  *out = GnxVtOut{h->vt_scls, h->vt_blk_cnt, h->vt_blk_nz, (int)(h->cfg.cap_inds / GNX_CB + 2),
+                  h->vt_count, h->vt_cls, h->vt_rank, h->vt_base,
+                  h->tiled ? 0 : 1, (int64_t)h->sp.n_births_lambda, gnx_vtp(h)};
   h->vt_fused = true;
   return 0;
 }
@@ -1478,18 +1456,30 @@ static int gnx_vt_out(gnx_state* h, GnxVtOut* out) {
 // births, k_pair_cls's here (blocks of pairs; needs h->nbirths).  local: the virtual tiles' base
 // offsets too, from this device's own counts; else the caller sets h->vt_base (the tiles' sums).
 int gnx_l_pair_cls(gnx_state* h, int64_t P, bool local) {
-  GNXCHK(vt_buffers(h));
+  GNXCHK(gnx_vt_buffers(h));
   GnxSoA s = h->soa[h->cur];
-  int nb;
   if (h->sp.n_births_fixed) {
-    // (P < 0: not known on the host - gnx_tile_step; an empty tile made no pair list at all)
+    // the two kernels of the pair list did it all (k_pair_flags, k_pair_compact): nothing to
+    // launch.  (P < 0: not known on the host - gnx_tile_step; an empty tile made no pair list)
     if (!h->vt_fused && h->N > 0 && P != 0) {
       gnx_set_error("tile-major offspring ids: the pair list was made without its classification");
       return 1;
     }
-    nb = (int)((h->N + GNX_CB - 1) / GNX_CB);
+    if (local != !h->tiled) {
+      gnx_set_error("tile-major offspring ids: the bases' owner does not match the tile grid");
+      return 1;
+    }
     h->vt_mul = (int64_t)h->sp.n_births_lambda;
-  } else {
+    h->vt_weighted = false;
+    if (h->N == 0 || P == 0)          // (no pair list was made: clean zeros for whoever reads them)
+      HIPCHK(hipMemsetAsync(h->vt_count, 0, GNX_VTN * sizeof(int32_t), h->stream));
+    h->pair_goff_local_base = local;
+    h->pair_goff_ready = true;
+    return 0;
+  }
+  int nb;
+  {
+    h->vt_weighted = true;
     nb = (int)((P + GNX_CB - 1) / GNX_CB);
     h->vt_mul = 1;
     if (P > 0)
@@ -1509,7 +1499,119 @@ int gnx_l_pair_cls(gnx_state* h, int64_t P, bool local) {
 }
 
 static GnxGoff gnx_goff_vt(const gnx_state* h) {
+  if (!h->vt_weighted)
+    return GnxGoff{nullptr, h->vt_cls, h->vt_rank, nullptr, nullptr, h->vt_base, h->vt_mul};
   return GnxGoff{nullptr, h->vt_cls, h->vt_rank, h->vt_pblk, h->vt_blk_off, h->vt_base, h->vt_mul};
+}
+
+// Bernoulli(b) thinning (structs/species.py:2210-2214), sex filter
+// (ops/mating.py:41-55), reproductive-age filter (:79-104) of the pair (i, mate[i]).
+struct PairP {
+  int64_t N;
+  const int32_t* focal;
+  const int32_t* mate;
+  const uint8_t* keep_in;
+  float b;
+  int sexed, ra_f, ra_m, dedup;
+  long long step;
+  unsigned long long seed;
+  const GnxDD* dd;
+};
+
+__device__ __forceinline__ bool pair_ok(const PairP& P, const GnxSoA& s, int64_t i) {
+  const int m = P.mate[i];
+  if (m < 0) return false;
+  const int fo = P.focal ? P.focal[i] : (int)i;
+  bool keep;
+  if (P.keep_in) {
+    keep = P.keep_in[i] != 0;
+  } else {
+    uint4 r = gnx_rand4(P.seed, (unsigned long long)s.id[i], P.step, OP_PAIR_KEEP, 0);
+    keep = gnx_u01(r.x) < P.b;
+  }
+  bool ok = keep;
+  if (P.sexed) ok = ok && (s.sex[fo] == 0) && (s.sex[m] == 1);
+  return ok && (s.age[fo] >= P.ra_f) && (s.age[m] >= P.ra_m);
+}
+
+// + unordered-pair de-duplication (ops/mating.py:62-65): the reference keeps one of
+// (i,m),(m,i); drop (i,m) iff (m,i) is also present and id_m < id_i (ids, not slots, so
+// every tile of a tiled run takes the same decision).  A pair belongs to the tile that
+// owns its focal individual: ghost focals only serve the reciprocity test.  Flags and
+// their per-block counts (gnx_compact.h).
+__global__ void __launch_bounds__(256)
+k_pair_flags(PairP P, GnxSoA s, int32_t* flag2, int32_t* cnt, GnxVtOut vt) {
+  __shared__ int lds[16];
+  __shared__ int vtot[GNX_VTN];
+  if (vt.scls && threadIdx.x < GNX_VTN) vtot[threadIdx.x] = 0;
+  const int64_t base = (int64_t)blockIdx.x * GNX_CB;
+  P.N = gnx_dd_n(P.dd, P.N);
+  P.step = gnx_dd_step(P.dd, P.step);
+  bool f[4];
+  // (tile-major ids: everybody's position goes out with the first loads - coalesced, and not one
+  // more round trip behind the filters' chain of dependent loads)
+  float px[4] = {0.f, 0.f, 0.f, 0.f}, py[4] = {0.f, 0.f, 0.f, 0.f};
+  if (vt.scls) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t i = base + r * 256 + threadIdx.x;
+      if (i < P.N) {
+        px[r] = s.x[i];
+        py[r] = s.y[i];
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    f[r] = false;
+    if (i < P.N) {
+      bool ok = pair_ok(P, s, i);
+      if (ok && P.dedup) {
+        const int m = P.mate[i];
+        if (P.mate[m] == (int32_t)i && s.id[m] < s.id[i] && pair_ok(P, s, m)) ok = false;
+      }
+      if (s.ghost[i]) ok = false;
+      f[r] = ok;
+      flag2[i] = ok ? 1 : 0;
+    }
+  }
+  int rank[4], tot;
+  gnx_block_ranks(f, rank, tot, lds);
+  // (the scan of the block counts stays a launch of its own: done by the last workgroup of
+  // this kernel - gnx_count_and_scan - it cost 10 us more than k_block_scan's 6)
+  if (threadIdx.x == 0) cnt[blockIdx.x] = tot;
+  if (!vt.scls) return;
+  // tile-major offspring ids: the kept pairs' virtual tiles and how many of each this block has
+  // (the lanes of a wave are neighbours in space: one or two virtual tiles per wave)
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    int c = GNX_VTN;
+    if (f[r]) {
+      c = gnx_vt_of(vt.V, px[r], py[r]);
+      vt.scls[i] = (uint8_t)c;
+    }
+    unsigned long long todo = __ballot(f[r]);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int lc = __shfl(c, leader);
+      const unsigned long long same = __ballot(f[r] && c == lc);
+      if (lane == leader) atomicAdd(&vtot[lc], __popcll(same));
+      todo &= ~same;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < GNX_VTN) {
+    // (class-major: the counts of one virtual tile over the blocks lie side by side - what
+    // k_pair_compact adds up)
+    const int t = vtot[threadIdx.x];
+    vt.blk_cnt[(int64_t)threadIdx.x * vt.stride + blockIdx.x] = t;
+    if (t) atomicAdd(&vt.total[threadIdx.x], t);
+    const unsigned long long nz = __ballot(t != 0);
+    if (threadIdx.x == 0) vt.blk_nz[blockIdx.x] = nz;
+  }
 }
 
 // Pairs in slot order, i.e. in the CANONICAL (hash cell, id) order of their focal individual
@@ -1528,9 +1630,37 @@ k_pair_compact(int64_t N, const int32_t* focal, const int32_t* mate, const int32
   __shared__ int lds[16];
   __shared__ int psum[4];
   __shared__ int vcnt[16][GNX_VTN];
+  __shared__ int vpre[GNX_VTN];
   if (dd) N = dd->N;
-  if (vt.cls)
+  if (vt.cls) {
     for (int k = threadIdx.x; k < 16 * GNX_VTN; k += 256) (&vcnt[0][0])[k] = 0;
+    // the pairs of the blocks before this one, for the (one to three) virtual tiles this block
+    // touches: wave w takes every fourth of them and adds up a stretch of the class's row
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long nz = vt.blk_nz[blockIdx.x];
+    for (int k = 0; nz; ++k) {
+      const int c = __ffsll((long long)nz) - 1;
+      nz &= nz - 1;
+      if ((k & 3) != wave) continue;
+      const int32_t* row = vt.blk_cnt + (int64_t)c * vt.stride;
+      int part = 0;
+      for (int b2 = lane; b2 < (int)blockIdx.x; b2 += 64) part += row[b2];
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d);
+      if (lane == 0) vpre[c] = part;
+    }
+    // (one device: the virtual tiles' base offsets, in births, from the totals k_pair_flags left)
+    if (vt.local && blockIdx.x == 0 && wave == 3) {
+      const int tot = vt.total[lane];
+      int xs = tot;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int yv = __shfl_up(xs, d);
+        if (lane >= d) xs += yv;
+      }
+      vt.base[lane] = (int64_t)(xs - tot) * vt.lam;
+    }
+  }
   // cnt != null: no scan kernel ran - every workgroup adds up the block counts before its own
   // (a few coalesced loads from L2: 1 210 counts at the metric size), and workgroup 0, the
   // first to start, adds up all of them and hands the total to the host and to the device
@@ -1574,13 +1704,15 @@ k_pair_compact(int64_t N, const int32_t* focal, const int32_t* mate, const int32
   }
   const int64_t base = (int64_t)blockIdx.x * GNX_CB;
   bool f[4];
+  int sc[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t i = base + r * 256 + threadIdx.x;
     f[r] = i < N && flag2[i] != 0;
+    if (vt.cls && i < N) sc[r] = vt.scls[i];     // (with the flags: no round trip of its own)
   }
   int rank[4], tot;
-  gnx_block_ranks(f, rank, tot, lds);            // (barriers: vcnt is zero from here on)
+  gnx_block_ranks(f, rank, tot, lds);            // (barriers: vcnt is zero, vpre written)
   // tile-major offspring ids: the pair's virtual tile (by its focal individual's position), its
   // rank among the block's pairs of the same virtual tile, the block's count per virtual tile
   int vc[4] = {0, 0, 0, 0}, vrw[4] = {0, 0, 0, 0};
@@ -1597,7 +1729,7 @@ k_pair_compact(int64_t N, const int32_t* focal, const int32_t* mate, const int32
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      vc[r] = f[r] ? gnx_vt_of(vt.V, fx[r], fy[r]) : GNX_VTN;
+      vc[r] = f[r] ? sc[r] : GNX_VTN;
       gnx_vt_wave_ranks<false>(f[r], vc[r], 1, lane, vcnt[r * 4 + wave], vrw[r]);
     }
     __syncthreads();
@@ -1621,21 +1753,14 @@ k_pair_compact(int64_t N, const int32_t* focal, const int32_t* mate, const int32
       if (bins.bins) bin = gnx_bin_of(bins, mx, my);
       if (vt.cls) {
         const int wave = threadIdx.x >> 6;
-        int before = 0;
+        int before = vpre[vc[r]];
         for (int j = 0; j < r * 4 + wave; ++j) before += vcnt[j][vc[r]];
         vt.cls[p] = (uint8_t)vc[r];
         vt.rank[p] = before + vrw[r];
-        vt.pblk[p] = (int32_t)blockIdx.x;
       }
     }
     // (device-driven step at small sizes: the pair midpoints' density bins in the same launch)
     if (bins.bins) gnx_bin_add(bins.bins, bin, f[r]);
-  }
-  if (vt.cls && threadIdx.x < GNX_VTN) {
-    int t = 0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) t += vcnt[j][threadIdx.x];
-    vt.blk_cnt[(int64_t)blockIdx.x * GNX_VTN + threadIdx.x] = t;
   }
 }
 
@@ -1703,7 +1828,9 @@ int gnx_l_find_pairs_enqueue(gnx_state* h, const uint8_t* d_keep, bool with_dens
   PairP pp{N, focal, h->mate, d_keep, (float)sp.b, sexed, sp.repro_age[0], sp.repro_age[1],
            (sexed || sp.mating_radius < 0) ? 0 : 1,      // no dedup for sexed / panmictic
            h->step, h->cfg.seed};
-  hipLaunchKernelGGL(k_pair_flags, dim3(nb), dim3(256), 0, h->stream, pp, s, h->flag2, h->blk_cnt);
+  GnxVtOut vto;
+  GNXCHK(gnx_vt_out(h, &vto));
+  hipLaunchKernelGGL(k_pair_flags, dim3(nb), dim3(256), 0, h->stream, pp, s, h->flag2, h->blk_cnt, vto);
   const int64_t seq = ++h->pin_seq;
   // (the height of the free-block stack rides along: the host's count of it is exact again)
   const bool with_top = h->half_top && h->genomes_assigned;
@@ -1712,8 +1839,6 @@ int gnx_l_find_pairs_enqueue(gnx_state* h, const uint8_t* d_keep, bool with_dens
     GNXCHK(gnx_block_scan(h, 1, N, h->blk_cnt, h->blk_off, h->cnt_dev, h->h_pin_dev + 4, seq, nullptr,
                           with_top ? h->half_top : nullptr));
   // (the population was sorted by gnx_l_sort_by_cell with this idbits: max_id has not moved)
-  GnxVtOut vto;
-  GNXCHK(gnx_vt_out(h, &vto));
   hipLaunchKernelGGL(k_pair_compact, dim3(nb), dim3(256), 0, h->stream, N, focal, h->mate,
                      h->flag2, h->blk_off, s.x, s.y, h->key64[1], gnx_id_bits(h), h->pairs,
                      h->mid_x, h->mid_y, h->key64[0],
@@ -1865,7 +1990,9 @@ k_offspring(OffP P, GnxSoA s, const float* rast, const int32_t* pairs, const int
   int64_t gk = k;
   if (gf.cls) {
     const int c = gf.cls[p];
-    gk = gf.vt_base[c] + (int64_t)(gf.blk_off[(int64_t)gf.pblk[p] * GNX_VTN + c] + gf.rank[p]) * gf.mul + ord;
+    int64_t rk = gf.rank[p];
+    if (gf.pblk) rk += gf.blk_off[(int64_t)gf.pblk[p] * GNX_VTN + c];      // (Poisson: k_pair_cls)
+    gk = gf.vt_base[c] + rk * gf.mul + ord;
   } else if (gf.goff) {
     gk = gf.goff[p] + ord;
   }
@@ -2237,7 +2364,8 @@ int gnx_dd_l_sort(gnx_state* h, int32_t* d_bins, hipStream_t st) {
                      h->cell_start, h->ncx * h->ncy, h->keyk[1], h->ord[h->ord_cur], (int64_t)0,
                      h->ord[h->ord_cur ^ 1], h->perm[1], (uint4*)h->os_scratch, (wipe_words + 3) / 4,
                      0, (const GnxDD*)h->dd,
-                     GnxBinP{d_bins, 1.0 / h->lat.hww, h->lat.nbx, h->lat.nby});
+                     GnxBinP{d_bins, 1.0 / h->lat.hww, h->lat.nbx, h->lat.nby},
+                     h->id_order == 1 ? h->vt_count : (int32_t*)nullptr);
   HIPCHK(hipGetLastError());
   h->ord_cur ^= 1;
   h->cur ^= 1;
@@ -2265,24 +2393,20 @@ int gnx_dd_l_pairs(gnx_state* h, int32_t* d_bins, hipStream_t st) {
   const int nb = (int)((cap + GNX_CB - 1) / GNX_CB);
   PairP pp{cap, nullptr, h->mate, nullptr, (float)sp.b, sp.sexed, sp.repro_age[0], sp.repro_age[1],
            sp.sexed ? 0 : 1, 0, h->cfg.seed, h->dd};
-  hipLaunchKernelGGL(k_pair_flags, dim3(nb), dim3(256), 0, st, pp, s, h->flag2, h->blk_cnt);
-  // the pair list, in slot order; workgroup 0 adds up the block counts and leaves the pair
-  // count, the births (a fixed number per pair) and the capacity check in the device block
   GnxVtOut vto;
   GNXCHK(gnx_vt_out(h, &vto));
+  hipLaunchKernelGGL(k_pair_flags, dim3(nb), dim3(256), 0, st, pp, s, h->flag2, h->blk_cnt, vto);
+  // the pair list, in slot order; workgroup 0 adds up the block counts and leaves the pair
+  // count, the births (a fixed number per pair) and the capacity check in the device block
   hipLaunchKernelGGL(k_pair_compact, dim3(nb), dim3(256), 0, st, cap, (const int32_t*)nullptr,
                      h->mate, h->flag2, h->blk_off, s.x, s.y, h->key64[1], 40, h->pairs, h->mid_x,
                      h->mid_y, h->key64[0], (const int32_t*)h->blk_cnt, h->cnt_dev,
                      (int64_t*)nullptr, 0ll, (const int32_t*)nullptr, h->dd,
                      (int)sp.n_births_lambda, (int64_t)cap,
                      GnxBinP{d_bins, 1.0 / h->lat.hww, h->lat.nbx, h->lat.nby}, vto);
-  // tile-major offspring ids: the blocks' offsets and the virtual tiles' bases (the slot blocks
-  // of dd->N individuals; a block without pairs wrote zeros)
   if (vto.cls) {
     h->vt_mul = (int64_t)sp.n_births_lambda;
-    hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(1024), 0, st, 0, (const int32_t*)nullptr,
-                       (const GnxDD*)h->dd, (const int32_t*)h->vt_blk_cnt, h->vt_blk_off,
-                       h->vt_count, h->vt_base, 1, h->vt_mul);
+    h->vt_weighted = false;
   }
   HIPCHK(hipGetLastError());
   return 0;

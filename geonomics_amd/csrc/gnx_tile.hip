@@ -1278,13 +1278,15 @@ k_route(int64_t N, int64_t cap, GnxSoA s, RouteGeo g, int n_traits, int32_t* __r
 
 // exclusive offsets of the 2 x T groups, totals, and all of it to pinned host memory
 __global__ void k_route_offsets(int T, int32_t* cnt /*[2T counts | 2T offsets | 2 totals]*/,
-                                int32_t* host, int n_extra, int seq) {
+                                int32_t* host, int n_extra, int seq, int zero_counts) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   for (int grp = 0; grp < 2; ++grp) {
     int run = 0;
     for (int p = 0; p < T; ++p) {
+      const int v = cnt[grp * T + p];
       cnt[2 * T + grp * T + p] = run;
-      run += cnt[grp * T + p];
+      run += v;
+      if (zero_counts) cnt[grp * T + p] = 0;      // (the pass that fills counts again from zero)
     }
     cnt[4 * T + grp] = run;
   }
@@ -1311,9 +1313,12 @@ __global__ void k_publish_words(int n, const int32_t* src, int32_t* host, int se
 // checks, both density fields' bins with the four counter words behind them, the N.max()
 // word, the gamete-request counter
 __global__ void k_tile2_zero(int32_t* p0, int n0, int32_t* p1, int n1, int32_t* p2, int n2,
-                             int32_t* p3, int n3) {
+                             int32_t* p3, int n3, int32_t* p4, int n4) {
   const int stride = gridDim.x * blockDim.x;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n1; i += stride) p1[i] = 0;
+  // (the routing's counters and the gamete-request counts: a fill kernel each otherwise - and a
+  // hipMemsetAsync of an odd size is up to THREE of them, 5 us apiece on the step's chain)
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) p4[i] = 0;
   if (blockIdx.x == 0) {
     if ((int)threadIdx.x < n0) p0[threadIdx.x] = 0;
     if ((int)threadIdx.x < n2) p2[threadIdx.x] = 0;
@@ -1331,9 +1336,14 @@ __global__ void k_publish_words2(int n1, const int32_t* src1, int32_t* host1, in
     __hip_atomic_store(&host2[p], src2[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+#define GNX_REQ_CNT(h) ((h)->route_cnt + 4 * n_tiles(h) + 8)
 static int tile2_buffers(gnx_state* h) {
+  h->tile2_mode = true;         // (the step's density comes from the tile protocol's own counting pass)
   if (!h->route_cnt) {
-    GNXCHK(dalloc_t(&h->route_cnt, (size_t)4 * GNX_MAX_TILES + 8));
+    // [2T counts | 2T offsets | 2 totals ...] of the routing, and behind those 4T + 8 words the
+    // gamete-request counts per owning rank (GNX_REQ_CNT)
+    GNXCHK(dalloc_t(&h->route_cnt, (size_t)5 * GNX_MAX_TILES + 8));
+    HIPCHK(hipMemset(h->route_cnt, 0, ((size_t)5 * GNX_MAX_TILES + 8) * sizeof(int32_t)));
     HIPCHK(hipHostMalloc((void**)&h->h_route_pin, (2 * GNX_MAX_TILES + 8) * sizeof(int32_t),
                          hipHostMallocCoherent | hipHostMallocMapped));
     memset(h->h_route_pin, 0, (2 * GNX_MAX_TILES + 8) * sizeof(int32_t));
@@ -1387,21 +1397,28 @@ extern "C" int gnx_tile2_route_begin(gnx_state* h, int32_t move, void** counts_d
     // (everything that read last step's values ran before this on the same stream)
     const int nb = h->lat.nbx * h->lat.nby;
     const bool bins = h->have_sp && h->bin_partials != nullptr;
+    const int T0 = n_tiles(h);
     hipLaunchKernelGGL(k_tile2_zero, dim3(8), dim3(256), 0, h->stream, (int32_t*)h->chk, 4,
                        bins ? h->bin_partials : nullptr, bins ? 2 * nb + 4 : 0,
                        (int32_t*)h->nmax_bits, h->nmax_bits ? 2 : 0, h->req_count,
-                       h->req_count ? 1 : 0);
+                       h->req_count ? 1 : 0, h->route_cnt, 5 * T0 + 8);
     if (bins) h->bins_zeroed[0] = h->bins_zeroed[1] = true;
+    h->req_cnt_zeroed = true;
     if (h->nmax_bits) h->nmax_zeroed = true;
     h->req_zeroed = h->req_count != nullptr;
   }
-  if (move && h->sp.move)
-    GNXCHK(gnx_l_move(h, true, nullptr, nullptr, nullptr, nullptr, true));
-  else
+  if (move && h->sp.move) {
+    // (one tile: nobody arrives between the movement and the cell sort - the movement writes
+    // the sort's keys as in gnx_step)
+    h->move_writes_keys = T == 1 && h->sp.mating_radius >= 0;
+    const int rc_move = gnx_l_move(h, true, nullptr, nullptr, nullptr, nullptr, true);
+    h->move_writes_keys = false;
+    GNXCHK(rc_move);
+  } else {
     GNXCHK(gnx_l_age(h));
+  }
   const int64_t N = h->N;
-  HIPCHK(hipMemsetAsync(h->route_cnt, 0, (size_t)(4 * T + 8) * sizeof(int32_t), h->stream));
-  *counts_dev = h->route_cnt;
+  *counts_dev = h->route_cnt;             // (zeroed by k_tile2_zero above)
   if (N == 0 || T == 1) return 0;          // one tile: nobody leaves, nobody borders
   RouteGeo g;
   GNXCHK(route_geo(h, &g));
@@ -1453,8 +1470,7 @@ extern "C" int gnx_tile2_route_finish(gnx_state* h, const int64_t* counts) {
   // the per-destination offsets of both groups (the counting pass left the counts), then the
   // counters again for the pass that fills
   hipLaunchKernelGGL(k_route_offsets, dim3(1), dim3(64), 0, h->stream, T, h->route_cnt,
-                     (int32_t*)nullptr, 0, 0);
-  HIPCHK(hipMemsetAsync(h->route_cnt, 0, (size_t)2 * T * sizeof(int32_t), h->stream));
+                     (int32_t*)nullptr, 0, 0, 1);
   hipLaunchKernelGGL(k_route<true>, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N,
                      h->cfg.cap_inds, s, g, nt, h->route_cnt,
                      (const int32_t*)(h->route_cnt + 2 * T), h->gp_rec, nt ? h->gp_z : nullptr,
@@ -1584,7 +1600,9 @@ extern "C" int gnx_tile2_pairs(gnx_state* h, int32_t burn, int64_t* counts) {
   for (int p = 0; p < 2 + T; ++p) counts[p] = 0;
   h->req_by_rank.assign(T, 0);
   int64_t P = 0, B = 0;
-  GNXCHK(gnx_l_sort_by_cell(h));                 // (emigrants leave here)
+  // (emigrants leave here; where the sort runs over the id-ordered index - one tile - the columns
+  // the mate search does not read follow on the side stream as in gnx_step)
+  GNXCHK(gnx_l_sort_by_cell(h, true));
   const bool genomes = !burn && h->cfg.L > 0 && h->genomes_assigned;
   if (h->tile_pairs_nowait && h->sp.n_births_fixed && h->N == 0) {
     // an empty tile: the pair count that travels is a clean zero
@@ -1600,23 +1618,29 @@ extern "C" int gnx_tile2_pairs(gnx_state* h, int32_t burn, int64_t* counts) {
     // pair count on the host - the pairs' density bins and the request counts read it on the
     // device (grids sized by the population), and it reaches the host with the count exchange
     // that follows (gnx_tile2_pairs_settle)
-    GNXCHK(gnx_l_find_pairs_enqueue(h, nullptr, false));
+    const int rc_enq = gnx_l_find_pairs_enqueue(h, nullptr, false);
+    GNXCHK(gnx_wait_permute_rest(h));
+    GNXCHK(rc_enq);
     GNXCHK(gnx_l_bins(h, h->N, h->mid_x, h->mid_y, nullptr, h->bins_P, h->cnt_dev));
     h->n_req_known = 0;
     if (T > 1 && genomes) {
       GnxSoA s = h->soa[h->cur];
-      HIPCHK(hipMemsetAsync(h->route_cnt, 0, (size_t)T * sizeof(int32_t), h->stream));
+      if (!h->req_cnt_zeroed)
+        HIPCHK(hipMemsetAsync(GNX_REQ_CNT(h), 0, (size_t)T * sizeof(int32_t), h->stream));
+      h->req_cnt_zeroed = false;
       hipLaunchKernelGGL(k_req_count, dim3(gnx_grid(h->N, 256)), dim3(256), 0, h->stream, h->N,
                          h->pairs, s.ghost, s.x, s.y, h->cfg.W / h->tile_C, h->cfg.H / h->tile_R,
-                         h->tile_R, h->tile_C, (int)h->sp.n_births_lambda, h->nbirths, h->route_cnt,
-                         (const int32_t*)h->cnt_dev);
+                         h->tile_R, h->tile_C, (int)h->sp.n_births_lambda, h->nbirths,
+                         GNX_REQ_CNT(h), (const int32_t*)h->cnt_dev);
       HIPCHK(hipGetLastError());
       h->n_req_known = -2;
     }
     counts[0] = counts[1] = -1;
     return 0;
   }
-  GNXCHK(gnx_l_find_pairs(h, nullptr, &P));      // wait 2 of the step: the pair count
+  const int rc_fp = gnx_l_find_pairs(h, nullptr, &P);      // wait 2 of the step: the pair count
+  GNXCHK(gnx_wait_permute_rest(h));
+  GNXCHK(rc_fp);
   GNXCHK(gnx_l_bins(h, P, h->mid_x, h->mid_y, nullptr, h->bins_P));
   GNXCHK(gnx_l_births(h, &B));
   counts[0] = P;
@@ -1624,11 +1648,15 @@ extern "C" int gnx_tile2_pairs(gnx_state* h, int32_t burn, int64_t* counts) {
   h->n_req_known = 0;
   if (P > 0 && T > 1 && genomes) {
     GnxSoA s = h->soa[h->cur];
-    HIPCHK(hipMemsetAsync(h->route_cnt, 0, (size_t)T * sizeof(int32_t), h->stream));
+    // (the request counters were zeroed with the step's other accumulators, k_tile2_zero - or,
+    // a caller that skipped gnx_tile2_route_begin, here)
+    if (!h->req_cnt_zeroed)
+      HIPCHK(hipMemsetAsync(GNX_REQ_CNT(h), 0, (size_t)T * sizeof(int32_t), h->stream));
+    h->req_cnt_zeroed = false;
     hipLaunchKernelGGL(k_req_count, dim3(gnx_grid(P, 256)), dim3(256), 0, h->stream, P, h->pairs,
                        s.ghost, s.x, s.y, h->cfg.W / h->tile_C, h->cfg.H / h->tile_R, h->tile_R,
                        h->tile_C, h->sp.n_births_fixed ? (int)h->sp.n_births_lambda : 0,
-                       h->nbirths, h->route_cnt, (const int32_t*)nullptr);
+                       h->nbirths, GNX_REQ_CNT(h), (const int32_t*)nullptr);
     HIPCHK(hipGetLastError());
     if (h->tile_req_on_device) {
       // (gnx_tile_step: the counts travel with its count exchange - gnx_tile2_set_requests)
@@ -1636,8 +1664,8 @@ extern "C" int gnx_tile2_pairs(gnx_state* h, int32_t burn, int64_t* counts) {
       return 0;
     }
     const int seq = (int)(++h->pin_seq & 0x3fffffff);
-    hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, h->stream, T, h->route_cnt,
-                       h->h_route_pin_dev, seq);
+    hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, h->stream, T,
+                       (const int32_t*)GNX_REQ_CNT(h), h->h_route_pin_dev, seq);
     HIPCHK(hipGetLastError());
     GNXCHK(tile2_wait(h, seq));                  // (a few microseconds behind wait 2)
     for (int p = 0; p < T; ++p) {
@@ -1693,7 +1721,10 @@ extern "C" int gnx_tile2_vt_bases(gnx_state* h, const int64_t* bases) {
 // have reached the host with the count exchange
 extern "C" int gnx_tile2_requests_dev(gnx_state* h, int32_t on, void** counts_dev) {
   h->tile_req_on_device = on != 0;
-  if (counts_dev) *counts_dev = h->route_cnt;
+  if (counts_dev) {
+    GNXCHK(tile2_buffers(h));
+    *counts_dev = GNX_REQ_CNT(h);
+  }
   return 0;
 }
 

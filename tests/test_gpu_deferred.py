@@ -272,7 +272,7 @@ def test_in_place_compaction_equals_stable_copy(monkeypatch):
     b.close()
 
 
-@pytest.mark.parametrize('variant', ['sparse', 'dense', 'no_graph'])
+@pytest.mark.parametrize('variant', ['sparse', 'dense', 'no_graph', 'tile_major_ids'])
 def test_small_path_equals_default_path(variant, monkeypatch):
     """gnx_walk - every count of the step on the device, grids sized by the capacity, one
     captured HIP graph per step, no read-back (the path BASELINE configs[1] and [2] take) -
@@ -285,6 +285,12 @@ def test_small_path_equals_default_path(variant, monkeypatch):
     dense = variant == 'dense'
     a, nat = _model(True, dense=dense, seed=31)
     b, _ = _model(True, dense=dense, seed=31)
+    if variant == 'tile_major_ids':
+        # offspring ids virtual tile by virtual tile (gnx_set_id_order 1, the Model API's default):
+        # the newborns' ids do not ascend with their slots - the device-driven step files them
+        # behind the id-ordered index itself
+        a.set_id_order(1)
+        b.set_id_order(1)
     hist = []
 
     def both(T, burn=False):
