@@ -578,6 +578,11 @@ extern "C" void gnx_destroy(gnx_state* h) {
     (void)hipStreamDestroy(h->stream3);
   }
   if (h->ev_ord) (void)hipEventDestroy(h->ev_ord);
+  if (h->ev_move) (void)hipEventDestroy(h->ev_move);
+  if (h->stream4) {
+    (void)hipStreamSynchronize(h->stream4);
+    (void)hipStreamDestroy(h->stream4);
+  }
   if (h->ev_compact) (void)hipEventDestroy(h->ev_compact);
   if (h->ev_fill) (void)hipEventDestroy(h->ev_fill);
   if (h->ev_alive) (void)hipEventDestroy(h->ev_alive);
@@ -604,6 +609,7 @@ extern "C" int gnx_set_stream(gnx_state* h, void* hip_stream) {
 extern "C" int gnx_synchronize(gnx_state* h) {
   GNXCHK(gnx_xo_launch_pending(h));
   if (h->stream3) HIPCHK(hipStreamSynchronize(h->stream3));
+  if (h->stream4) HIPCHK(hipStreamSynchronize(h->stream4));
   HIPCHK(hipStreamSynchronize(h->stream));
   if (h->stream2) HIPCHK(hipStreamSynchronize(h->stream2));
   return 0;
@@ -1176,7 +1182,15 @@ extern "C" int gnx_step_begin(gnx_state* h, int32_t burn) {
   h->tot[1] += h->N - h->n_ghost;
   h->last_xo_births = 0;
   h->tile2_mode = false;        // (a handle that stepped through the tile protocol before)
-  if (h->sp.move) {
+  if (h->moved_ahead) {
+    // gnx_walk: the last step's mortality has moved everybody already (gnx_l_move_ahead) and
+    // the compaction carried the sort's keys along
+    h->moved_ahead = false;
+    h->keys_fresh = h->sp.mating_radius >= 0;
+    h->keys_ordmode = true;
+    h->fb_adults = false;
+    h->fb_pending = false;
+  } else if (h->sp.move) {
     h->move_writes_keys = h->sp.mating_radius >= 0;     // the cell sort follows at once
     int rc = gnx_l_move(h, true, nullptr, nullptr, nullptr, nullptr, true);
     h->move_writes_keys = false;

@@ -549,7 +549,11 @@ extern "C" int gnx_walk_many(gnx_state** hs, int32_t n, int64_t T, int32_t burn,
         rc = dd_some(hs[k], burn != 0, with_selection != 0, left[k], &taken);
       } else {
         const int64_t n0 = hs[k]->N - hs[k]->n_ghost;
+        // (every step but the walk's last moves the population for the next one with its own
+        // mortality: nobody looks at it in between - gnx_l_move_ahead)
+        hs[k]->eager_move = left[k] > 1;
         rc = gnx_step(hs[k], burn, with_selection);
+        hs[k]->eager_move = false;
         hs[k]->dd_hist.push_back(n0);
         hs[k]->dd_hist.push_back(hs[k]->last_births);
         hs[k]->dd_hist.push_back(hs[k]->last_deaths);

@@ -520,6 +520,11 @@ struct gnx_state {
   bool ord_inflight = false;     // the index's compaction runs on stream3
   bool keys_ordmode = false;     // k_move wrote cell32, not key64
   bool keys_fresh = false;
+  // gnx_walk: the next step's movement runs with this step's mortality (gnx_l_move_ahead)
+  bool eager_move = false;       // set by gnx_walk for every step but the last
+  bool moved_ahead = false;      // the coming step's age + movement are done, cell32 written
+  hipEvent_t ev_move = nullptr;
+  hipStream_t stream4 = nullptr; // ... on a stream of its own
   bool move_writes_keys = false;     // set around the movement of gnx_step           // k_move has written this step's sort keys
   int n_bin_blocks = 0;
   double* nodes = nullptr;           // [Jy][Jx] scratch node values
@@ -626,6 +631,7 @@ int gnx_l_gather_e(gnx_state* h, int64_t first, int64_t n);
 int gnx_l_age(gnx_state* h);
 int gnx_l_move(gnx_state* h, bool inc_age, const float* inj_theta, const float* inj_dist,
                float* out_theta, float* out_dist, bool apply);
+int gnx_l_move_ahead(gnx_state* h, int64_t N_all, const int32_t* d_alive, hipStream_t st);
 int gnx_l_sort_by_cell(gnx_state* h, bool split_rest = false);
 int gnx_wait_permute_rest(gnx_state* h);
 int gnx_permute_rest_launch(gnx_state* h);

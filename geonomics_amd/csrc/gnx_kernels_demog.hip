@@ -1560,7 +1560,7 @@ k_fill(int64_t cap, const int32_t* __restrict__ n_move, const int32_t* __restric
        const int32_t* __restrict__ movers, const int32_t* __restrict__ cnts, GnxSoA a, int n_layers,
        int n_traits, int tbw, const int32_t* __restrict__ rows_tmp, int32_t* __restrict__ free_rows,
        int64_t n_free, int has_rows, int xo, int32_t* __restrict__ newslot,
-       const GnxDD* __restrict__ dd) {
+       const GnxDD* __restrict__ dd, uint32_t* __restrict__ cell32) {
   if (dd) n_free = dd->n_free;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1569,6 +1569,8 @@ k_fill(int64_t cap, const int32_t* __restrict__ n_move, const int32_t* __restric
     const int64_t i = movers[r], k = holes[r];
     GnxRec rec = gnx_rec_load(a, i, cap, n_layers, n_traits, tbw);
     rec.ghost = 0;
+    // (the next step's movement has run already - gnx_l_move_ahead: its sort key moves too)
+    if (cell32) cell32[k] = cell32[i];
     if (newslot) newslot[i] = (int32_t)k;
     gnx_rec_store(a, k, cap, n_layers, n_traits, tbw, rec);
     gnx_rec_rest(a, i, a, k, cap, n_layers, n_traits, tbw);
@@ -1787,8 +1789,31 @@ int gnx_l_mortality_enqueue(gnx_state* h, const uint8_t* d_dead_inject) {
   // stream3, and this stream goes from the death draws straight to the job builder
   static const bool side_scan_env = !(getenv("GNX_SIDE_SCAN") && atoi(getenv("GNX_SIDE_SCAN")) == 0);
   const bool side_scan = side_scan_env && fill && xo && xo_B > 0 && jobs_fused_ok(h);
+  // gnx_walk: the NEXT step's age + movement now, on the crossover's stream (idle until the jobs
+  // are built), beside the job builder - over slots still in this step's cell order, the dead
+  // skipped; the compaction below moves the moved records (gnx_l_move_ahead)
+  // (measured, profiles/r05_ab_runs.txt: 0.590 ms/step on the crossover's stream - the movement
+  // then holds the crossover back - and 0.70 on a stream of its own against 0.568 without: the
+  // movement is bound by its own arithmetic, ~1 200 vector instructions per individual, wherever
+  // it runs.  Off unless GNX_MOVE_AHEAD=1 / 2.)
+  static const bool ahead_env = getenv("GNX_MOVE_AHEAD") && atoi(getenv("GNX_MOVE_AHEAD")) != 0;
+  const bool ahead = ahead_env && h->eager_move && fill && ord_keep && h->sp.move && h->stream2 != nullptr &&
+                     h->key_bits <= 24 && h->n_ghost == 0 && !h->tile2_mode;
+  if (side_scan || ahead) HIPCHK(hipEventRecord(h->ev_alive, h->stream));
+  if (ahead) {
+    if (!h->ev_move)
+      HIPCHK(hipEventCreateWithFlags(&h->ev_move, hipEventDisableTiming | hipEventDisableSystemFence));
+    // (a stream of its own: on the crossover's it would hold the crossover back - the movement
+    // takes as long as the job builder it runs beside; GNX_MOVE_AHEAD=2: on the crossover's)
+    static const int ahead_mode = getenv("GNX_MOVE_AHEAD") ? atoi(getenv("GNX_MOVE_AHEAD")) : 1;
+    if (!h->stream4) HIPCHK(hipStreamCreateWithFlags(&h->stream4, hipStreamNonBlocking));
+    hipStream_t sm = ahead_mode == 2 ? h->stream2 : h->stream4;
+    HIPCHK(hipStreamWaitEvent(sm, h->ev_alive, 0));
+    GNXCHK(gnx_l_move_ahead(h, N, h->flag, sm));
+    HIPCHK(hipEventRecord(h->ev_move, sm));
+    h->moved_ahead = true;
+  }
   if (side_scan) {
-    HIPCHK(hipEventRecord(h->ev_alive, h->stream));
     HIPCHK(hipStreamWaitEvent(h->stream3, h->ev_alive, 0));
     GNXCHK(gnx_block_scan(h, 3, N, h->blk_cnt, h->blk_off, h->cnt_dev, h->h_pin_dev, 0, h->stream3));
     gnx_time_end(h, GNX_K_COMPACT, 0.0);
@@ -1836,13 +1861,15 @@ int gnx_l_mortality_enqueue(gnx_state* h, const uint8_t* d_dead_inject) {
   const double rec_bytes = 34.0 + 4.0 * c.n_layers + 4.0 * c.n_traits + 16.0 * h->TW;
   if (fill) {
     HIPCHK(hipStreamWaitEvent(h->stream, h->ev_fill, 0));
+    if (ahead) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_move, 0));
     const int64_t guess = std::max<int64_t>(h->fill_guess * 2, 4096);      // (grid-stride: any count)
     const int fb_ = (int)std::min<int64_t>(gnx_grid(std::min<int64_t>(guess, N), 256), 8192);
     hipLaunchKernelGGL(k_fill, dim3(fb_), dim3(256), 0, h->stream, c.cap_inds, h->fill_cnt,
                        (const int32_t*)h->os_ktmp, (const int32_t*)h->os_ktmp + c.cap_inds / 2,
                        h->cnt_dev, a, c.n_layers, c.n_traits, a.tb ? 2 * h->TW : 0,
                        (const int32_t*)h->os_vtmp, h->free_rows, h->n_free, has_rows, xo ? 1 : 0,
-                       ord_keep ? h->newslot : nullptr, (const GnxDD*)nullptr);
+                       ord_keep ? h->newslot : nullptr, (const GnxDD*)nullptr,
+                       ahead ? h->cell32 : (uint32_t*)nullptr);
     // flags and offsets of everybody, the records of about as many movers as the last round had deaths
     gnx_time_end(h, GNX_K_COMPACT, (double)N * 16.0 + (double)h->fill_guess * (16.0 + 2.0 * rec_bytes));
   } else {
@@ -2024,7 +2051,7 @@ int gnx_dd_l_fill(gnx_state* h, int has_rows, bool xo, hipStream_t st) {
                      (const int32_t*)h->os_ktmp, (const int32_t*)h->os_ktmp + c.cap_inds / 2,
                      h->cnt_dev, a, c.n_layers, c.n_traits, a.tb ? 2 * h->TW : 0,
                      (const int32_t*)h->os_vtmp, h->free_rows, (int64_t)0, has_rows, xo ? 1 : 0,
-                     h->newslot, (const GnxDD*)h->dd);
+                     h->newslot, (const GnxDD*)h->dd, (uint32_t*)nullptr);
   HIPCHK(hipGetLastError());
   return 0;
 }

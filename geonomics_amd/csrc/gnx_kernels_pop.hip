@@ -128,6 +128,9 @@ struct MoveP {
   uint32_t* cell32;
   int tile_floats;
   const GnxDD* dd;           // device-driven step: N and the step index live on the device
+  // the NEXT step's movement, run right after this step's death draws on the uncompacted
+  // population (gnx_l_move_ahead): the dead are skipped
+  const int32_t* alive;
 };
 
 __constant__ float c_queen_dirs[8] = {-2.35619449019234492885f, -1.57079632679489661923f,
@@ -303,7 +306,7 @@ k_move(MoveP P, GnxSoA s, const float* rast, const float* inj_theta, const float
 #pragma unroll
   for (int u = 0; u < IPT; ++u) {
     i[u] = base + u * 256;
-    act[u] = i[u] < P.N;
+    act[u] = i[u] < P.N && (!P.alive || (P.alive[i[u]] & 1) != 0);
     x[u] = y[u] = 0.f;
     id[u] = 0ull;
     age0[u] = 0;
@@ -409,6 +412,7 @@ int gnx_l_move(gnx_state* h, bool inc_age, const float* inj_theta, const float* 
   const gnx_species_params& sp = h->sp;
   MoveP P;
   P.dd = ddm ? h->dd : nullptr;
+  P.alive = nullptr;
   P.N = h->N;
   P.cap = c.cap_inds;
   P.W = c.W;
@@ -466,6 +470,61 @@ int gnx_l_move(gnx_state* h, bool inc_age, const float* inj_theta, const float* 
   // (+36 for the 3x3 conductance neighbourhood)
   gnx_time_end(h, GNX_K_MOVE,
                (double)h->N * (32.0 + 8.0 * c.n_layers + (sp.move_surf ? 36.0 : 0.0)));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// The NEXT step's age + movement, launched by THIS step's mortality right after the death draws,
+// on stream `st`, over the still uncompacted population (everybody incl. this step's offspring;
+// the dead are skipped) - gnx_walk only, where nobody looks at the population between two
+// steps.  Where it runs today - beside the crossover, which it slows and which slows it: 0.10-0.13
+// ms against 0.05 alone, the last kernel of that phase to finish - it is latency-bound on HBM
+// that the crossover saturates; here it runs beside the crossover's job builder, a chain of
+// dependent table look-ups, and over slots that are still in this step's (hash cell, id) order,
+// offspring in their parents' order: every workgroup's conductance window fits its LDS tile
+// (after the in-place compaction a sixth of every workgroup's slots hold newborns from anywhere).
+// Same draws (keyed by id and step), same positions: the compaction then moves the moved
+// records - and their sort keys (cell32).  Reference: Species._set_age_stage + _do_movement of
+// step t + 1 (structs/species.py:567-585) after _do_pop_dynamics of step t - nothing in between.
+int gnx_l_move_ahead(gnx_state* h, int64_t N_all, const int32_t* d_alive, hipStream_t st) {
+  const gnx_config& c = h->cfg;
+  const gnx_species_params& sp = h->sp;
+  MoveP P;
+  P.dd = nullptr;
+  P.alive = d_alive;
+  P.N = N_all;
+  P.cap = c.cap_inds;
+  P.W = c.W;
+  P.H = c.H;
+  P.n_layers = c.n_layers;
+  P.xmax = (float)(c.W - 0.001);
+  P.ymax = (float)(c.H - 0.001);
+  P.rrx = (float)sp.res_ratio[0];
+  P.rry = (float)sp.res_ratio[1];
+  P.distr = sp.move_distr;
+  P.p1 = (float)sp.move_p1;
+  P.p2 = (float)sp.move_p2;
+  P.mu = (float)sp.dir_mu;
+  P.kappa = (float)sp.dir_kappa;
+  P.surf = sp.move_surf;
+  P.surf_layer = sp.move_surf_layer;
+  P.surf_kappa = (float)sp.move_surf_kappa;
+  P.inc_age = 1;
+  P.apply = 1;
+  P.step = h->step + 1;
+  P.seed = c.seed;
+  P.key = nullptr;
+  P.cell32 = h->cell32;          // (the cell sort runs over the id-ordered index: gnx_l_mortality checks)
+  P.idx = h->perm[0];
+  P.inv_cs = h->inv_cs;
+  P.ncx = h->ncx;
+  P.ncy = h->ncy;
+  P.idbits = 0;
+  static const int tile_env = getenv("GNX_MOVE_TILE") ? atoi(getenv("GNX_MOVE_TILE")) : 2048;
+  P.tile_floats = sp.move_surf != GNX_SURF_NONE ? std::max(256, std::min(tile_env * 2, 12288)) : 0;
+  hipLaunchKernelGGL(k_move<2>, dim3(gnx_grid(N_all, 512)), dim3(256),
+                     (size_t)P.tile_floats * sizeof(float), st, P, h->soa[h->cur], h->rast,
+                     (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
   HIPCHK(hipGetLastError());
   return 0;
 }
