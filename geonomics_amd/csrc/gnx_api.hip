@@ -1202,10 +1202,13 @@ extern "C" int gnx_step_begin(gnx_state* h, int32_t burn) {
   // not read are permuted on the side stream meanwhile, and waited for before the births);
   // the n_pairs density of the pair midpoints (ops/demography.py:60-91) is launched with the
   // pair list, while the pair count travels to the host
-  GNXCHK(gnx_l_sort_by_cell(h, true));
+  h->perm_rest_late_ok = true;
+  int rc_sort = gnx_l_sort_by_cell(h, true);
+  h->perm_rest_late_ok = false;
+  GNXCHK(rc_sort);
   static const bool early = !(getenv("GNX_EARLY_DENSITY") && atoi(getenv("GNX_EARLY_DENSITY")) == 0);
   int rc_pairs = gnx_l_find_pairs_enqueue(h, nullptr, early);
-  GNXCHK(gnx_wait_permute_rest(h));
+  GNXCHK(gnx_wait_permute_rest(h, true));
   return rc_pairs;
 }
 
@@ -1222,6 +1225,7 @@ extern "C" int gnx_step_mid(gnx_state* h, int32_t burn, int32_t with_selection) 
   // N density of everyone incl. offspring (structs/species.py:845-882); d at each
   // individual's cell, fitness, death probability; mortality
   GNXCHK(gnx_l_density_N(h));
+  GNXCHK(gnx_wait_permute_rest(h));       // (GNX_PERMUTE_REST_AT=2: environment, phenotypes, rows arrive here)
   GNXCHK(gnx_l_death_probs(h, with_selection != 0 && !burn));
   return gnx_l_mortality_enqueue(h, nullptr);
 }

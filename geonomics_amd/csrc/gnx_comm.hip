@@ -96,7 +96,15 @@ struct LocalGroup {
   // what the ranks post for each other between two barriers
   std::vector<std::vector<int64_t>> vec;           // small host vectors
   std::vector<std::vector<const void*>> ptr;       // device pointers of the posted parts
-  explicit LocalGroup(int w) : world(w), vec(w), ptr(w) {}
+  // Like RCCL the local transport is ordered on streams, not by draining them: a rank records
+  // `posted` behind the kernels that filled what it posts, the readers' streams wait for it,
+  // copy, and record `done`, which the poster's stream waits for before it touches the buffers
+  // again.  The threads still meet twice per exchange (pointers out, events recorded) - on the
+  // host only.  GNX_LOCAL_SYNC=0 selects it; the default still drains the stream on both sides of
+  // every exchange: two tiles sharing ONE GPU step no faster either way (1.84-2.14 against 1.78-1.81
+  // ms, profiles/r05_ab_runs.txt - what the threads wait for on a shared GPU is each other's kernels).
+  std::vector<hipEvent_t> posted, done;
+  explicit LocalGroup(int w) : world(w), vec(w), ptr(w), posted(w, nullptr), done(w, nullptr) {}
   int barrier() {
     std::unique_lock<std::mutex> lk(mu);
     if (aborted) return 1;
@@ -259,7 +267,9 @@ int exchange(gnx_state* h, const Part* parts, int n_parts, const int64_t* mat) {
   for (int k = 0; k < n_parts; ++k) GNXCHK(rb_need(c, parts[k].rb, (size_t)n_in * parts[k].unit));
   if (c->kind == COMM_LOCAL) {
     LocalGroup* g = c->grp;
-    HIPCHK(hipStreamSynchronize(h->stream));          // what this rank posts is written
+    static const bool drain = !(getenv("GNX_LOCAL_SYNC") && atoi(getenv("GNX_LOCAL_SYNC")) == 0);
+    if (drain) HIPCHK(hipStreamSynchronize(h->stream));          // what this rank posts is written
+    else HIPCHK(hipEventRecord(g->posted[me], h->stream));
     g->ptr[me].assign(n_parts, nullptr);
     for (int k = 0; k < n_parts; ++k) g->ptr[me][k] = parts[k].send;
     if (g->barrier()) {
@@ -271,17 +281,24 @@ int exchange(gnx_state* h, const Part* parts, int n_parts, const int64_t* mat) {
       const int64_t n = mat[(int64_t)peer * w + me];
       int64_t soff = 0;
       for (int q = 0; q < me; ++q) soff += mat[(int64_t)peer * w + q];
-      if (n > 0)
+      if (n > 0) {
+        if (!drain && peer != me) HIPCHK(hipStreamWaitEvent(h->stream, g->posted[peer], 0));
         for (int k = 0; k < n_parts; ++k) {
           c->bytes_sent += n * (int64_t)parts[k].unit;          // (counted by the receiver here)
           HIPCHK(hipMemcpyAsync((char*)c->rbuf[parts[k].rb] + roff * parts[k].unit,
                                 (const char*)g->ptr[peer][k] + soff * parts[k].unit,
                                 (size_t)n * parts[k].unit, hipMemcpyDeviceToDevice, h->stream));
         }
+      }
       roff += n;
     }
-    HIPCHK(hipStreamSynchronize(h->stream));          // nobody reuses a posted buffer before this
+    if (drain) HIPCHK(hipStreamSynchronize(h->stream));          // nobody reuses a posted buffer before this
+    else HIPCHK(hipEventRecord(g->done[me], h->stream));
     if (g->barrier()) return 1;
+    if (!drain)
+      for (int peer = 0; peer < w; ++peer)         // whoever read from this rank has finished
+        if (peer != me && mat[(int64_t)me * w + peer] > 0)
+          HIPCHK(hipStreamWaitEvent(h->stream, g->done[peer], 0));
     return 0;
   }
   if (c->kind == COMM_SINGLE) {                       // one rank, no RCCL: what it sends itself
@@ -346,18 +363,26 @@ int allreduce_i32(gnx_state* h, int32_t* buf, int64_t n) {
   if (w == 1 && !c->forced) return 0;
   if (c->kind == COMM_LOCAL) {
     LocalGroup* g = c->grp;
+    static const bool drain = !(getenv("GNX_LOCAL_SYNC") && atoi(getenv("GNX_LOCAL_SYNC")) == 0);
     GNXCHK(rb_need(c, RB_PAD, (size_t)w * n * 4));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if (drain) HIPCHK(hipStreamSynchronize(h->stream));
+    else HIPCHK(hipEventRecord(g->posted[me], h->stream));
     g->ptr[me].assign(1, buf);
     if (g->barrier()) {
       gnx_set_error("local tile group: a rank failed or never arrived");
       return 1;
     }
-    for (int r = 0; r < w; ++r)
+    for (int r = 0; r < w; ++r) {
+      if (!drain && r != me) HIPCHK(hipStreamWaitEvent(h->stream, g->posted[r], 0));
       HIPCHK(hipMemcpyAsync((int32_t*)c->rbuf[RB_PAD] + (int64_t)r * n, g->ptr[r][0], (size_t)n * 4,
                             hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    if (drain) HIPCHK(hipStreamSynchronize(h->stream));
+    else HIPCHK(hipEventRecord(g->done[me], h->stream));
     if (g->barrier()) return 1;                       // everybody has read everybody's words
+    if (!drain)
+      for (int r = 0; r < w; ++r)                     // ... before this rank's sum overwrites its own
+        if (r != me) HIPCHK(hipStreamWaitEvent(h->stream, g->done[r], 0));
     hipLaunchKernelGGL(k_sum_i32, dim3((int)((n + 255) / 256)), dim3(256), 0, h->stream, (int)n, w,
                        (const int32_t*)c->rbuf[RB_PAD], buf);
     HIPCHK(hipGetLastError());
@@ -521,6 +546,9 @@ extern "C" int gnx_comm_local_join(gnx_state* h, void* group, int32_t rank) {
   c->rank = rank;
   c->world = g->world;
   c->grp = g;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipEventCreateWithFlags(&g->posted[rank], hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&g->done[rank], hipEventDisableTiming));
   return 0;
 }
 
@@ -530,7 +558,12 @@ extern "C" int gnx_comm_local_abort(void* group) {
 }
 
 extern "C" int gnx_comm_local_destroy(void* group) {
-  delete (LocalGroup*)group;
+  LocalGroup* g = (LocalGroup*)group;
+  for (hipEvent_t e : g->posted)
+    if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : g->done)
+    if (e) (void)hipEventDestroy(e);
+  delete g;
   return 0;
 }
 

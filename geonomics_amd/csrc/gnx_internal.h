@@ -498,6 +498,8 @@ struct gnx_state {
   bool permute_split = true;        // GNX_PERMUTE_SPLIT=0 (read at gnx_create): one k_permute for every column
   bool perm_rest_inflight = false;  // k_permute_rest (stream3) has not been waited for
   bool perm_rest_pending = false;   // ... has not been launched yet
+  bool perm_rest_late_ok = false;   // set by gnx_step around its cell sort: nothing reads the columns before the death probabilities
+  bool perm_rest_late = false;      // this sort's columns follow beside the births (GNX_PERMUTE_REST_AT=2)
   GnxSoA perm_rest_a{}, perm_rest_b{};
   int64_t perm_rest_N = 0;
   hipEvent_t ev_perm_rest = nullptr;
@@ -633,7 +635,7 @@ int gnx_l_move(gnx_state* h, bool inc_age, const float* inj_theta, const float* 
                float* out_theta, float* out_dist, bool apply);
 int gnx_l_move_ahead(gnx_state* h, int64_t N_all, const int32_t* d_alive, hipStream_t st);
 int gnx_l_sort_by_cell(gnx_state* h, bool split_rest = false);
-int gnx_wait_permute_rest(gnx_state* h);
+int gnx_wait_permute_rest(gnx_state* h, bool late_ok = false);
 int gnx_permute_rest_launch(gnx_state* h);
 // with_density: the n_pairs density (ops/demography.py:60-91) is launched before the host
 // has read the pair count back, so the GPU works through the round trip

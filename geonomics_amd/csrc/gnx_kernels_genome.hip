@@ -414,26 +414,34 @@ int gnx_l_path_sel(gnx_state* h) {
   return 0;
 }
 
-// tb of a slot from its genome row: one thread per (slot, homologue)
-__global__ void k_tb_from_rows(int64_t first, int64_t n, const int32_t* list, const int64_t* slots,
-                               int TW, int n_sel, int W64, const int32_t* sel_loci, const u64* G,
-                               const int32_t* grow, GnxHalves H, u64* tb) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= 2 * n) return;
+// tb of a slot from its genome row: one WAVE per (slot, homologue, 64-locus word of the table),
+// a lane per selected locus - two dependent loads per lane (block table, genome word) and a
+// ballot that IS the word.  (Round 4: one thread per (slot, homologue) walking its n_sel loci one
+// after the other, 2 x n_sel dependent round trips: 76 us for the 2 000 offspring of a tile
+// step that took a neighbour's gamete, 0.14 ms per tile and step - profiles/r05_ab_runs.txt.)
+__global__ void __launch_bounds__(256)
+k_tb_from_rows(int64_t first, int64_t n, const int32_t* list, const int64_t* slots,
+               int TW, int n_sel, int W64, const int32_t* sel_loci, const u64* G,
+               const int32_t* grow, GnxHalves H, u64* tb) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wv = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (wv >= 2 * n * TW) return;                       // (wave-uniform)
+  const int w = (int)(wv % TW);
+  const int64_t t = wv / TW;
   const int64_t q = t >> 1;
   const int hom = (int)(t & 1);
   const int64_t slot = slots ? slots[q] : first + (list ? list[q] : q);
   const int32_t row = grow[slot];
   if (row < 0) return;
   const int64_t lh = (int64_t)row * 2 + hom;
-  for (int w = 0; w < TW; ++w) {
-    u64 v = 0;
-    for (int e = w * 64; e < min(n_sel, w * 64 + 64); ++e) {
-      const int l = sel_loci[e];
-      v |= ((G[gnx_word_at(H, lh, l >> 6)] >> (l & 63)) & 1ull) << (e & 63);
-    }
-    tb[(slot * 2 + hom) * TW + w] = v;
+  const int e = w * 64 + lane;
+  bool bit = false;
+  if (e < n_sel) {
+    const int l = sel_loci[e];
+    bit = ((G[gnx_word_at(H, lh, l >> 6)] >> (l & 63)) & 1ull) != 0ull;
   }
+  const u64 v = __ballot(bit);
+  if (lane == 0) tb[(slot * 2 + hom) * TW + w] = v;
 }
 
 int gnx_l_tb_from_rows(gnx_state* h, int64_t first, int64_t n, const int32_t* d_list,
@@ -441,9 +449,9 @@ int gnx_l_tb_from_rows(gnx_state* h, int64_t first, int64_t n, const int32_t* d_
   if (n == 0 || h->TW == 0 || !h->genomes_assigned) return 0;
   if (join) GNXCHK(gnx_xo_join(h));
   GnxSoA s = h->soa[h->cur];
-  hipLaunchKernelGGL(k_tb_from_rows, dim3(gnx_grid(2 * n, 256)), dim3(256), 0, h->stream, first, n,
-                     d_list, d_slots, h->TW, h->n_sel, h->W64, h->sel_loci, (const u64*)h->G,
-                     s.grow, gnx_halves(h), (u64*)s.tb);
+  hipLaunchKernelGGL(k_tb_from_rows, dim3(gnx_grid(2 * n * h->TW * 64, 256, 1 << 30)), dim3(256), 0,
+                     h->stream, first, n, d_list, d_slots, h->TW, h->n_sel, h->W64, h->sel_loci,
+                     (const u64*)h->G, s.grow, gnx_halves(h), (u64*)s.tb);
   HIPCHK(hipGetLastError());
   return 0;
 }

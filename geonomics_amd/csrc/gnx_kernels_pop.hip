@@ -717,12 +717,15 @@ int gnx_permute_rest_launch(gnx_state* h) {
 }
 
 // the side stream's share of the last cell sort's permutation has arrived
-int gnx_wait_permute_rest(gnx_state* h) {
+int gnx_wait_permute_rest(gnx_state* h, bool late_ok) {
   GNXCHK(gnx_permute_rest_launch(h));
+  // (late mode: the step's own hand-over point lets it run on - gnx_l_death_probs waits)
+  if (late_ok && h->perm_rest_late) return 0;
   if (h->perm_rest_inflight) {
     HIPCHK(hipStreamWaitEvent(h->stream, h->ev_perm_rest, 0));
     h->perm_rest_inflight = false;
   }
+  h->perm_rest_late = false;
   return 0;
 }
 
@@ -820,8 +823,15 @@ int gnx_l_sort_by_cell(gnx_state* h, bool split_rest) {
     h->perm_rest_b = b;
     h->perm_rest_N = N;
     h->perm_rest_pending = true;
+    // GNX_PERMUTE_REST_AT=2 (round 5): not beside the mate search and the pair list either - random
+    // 16-byte record loads and chains of dependent filters that take 43 + 34 us beside it against
+    // 25 + 26 alone - but beside the births and the densities (gnx_l_find_pairs_enqueue launches
+    // it behind the pair list): k_offspring takes the parents' alleles from the buffer the column
+    // is permuted FROM, and only the death probabilities wait for the permutation.  Only where
+    // nothing else reads those columns in between: gnx_step (h->perm_rest_late_ok).
     static const int rest_at = getenv("GNX_PERMUTE_REST_AT") ? atoi(getenv("GNX_PERMUTE_REST_AT")) : 0;
-    if (rest_at == 0) GNXCHK(gnx_permute_rest_launch(h));
+    h->perm_rest_late = rest_at == 2 && h->perm_rest_late_ok && h->defer_xo && !h->tile2_mode;
+    if (rest_at == 0 || (rest_at == 2 && !h->perm_rest_late)) GNXCHK(gnx_permute_rest_launch(h));
   }
   gnx_time_end(h, GNX_K_PERMUTE,
                (double)N * 2.0 * (33.0 + 4.0 * c.n_layers + 4.0 * c.n_traits + 16.0 * h->TW));
@@ -1881,7 +1891,8 @@ int gnx_l_find_pairs_enqueue(gnx_state* h, const uint8_t* d_keep, bool with_dens
                          h->inv_cs, h->cell_start, h->ncx, h->ncy, h->cell_ref, r, r2, easy, h->mate);
   }
   gnx_time_end(h, GNX_K_FIND_MATES, (double)N * 16.0);
-  GNXCHK(gnx_permute_rest_launch(h));       // (GNX_PERMUTE_REST_AT=1: not before the mate search)
+  if (!h->perm_rest_late)
+    GNXCHK(gnx_permute_rest_launch(h));     // (GNX_PERMUTE_REST_AT=1: not before the mate search)
   gnx_time_begin(h);
   const int nb = (int)((N + GNX_CB - 1) / GNX_CB);
   PairP pp{N, focal, h->mate, d_keep, (float)sp.b, sexed, sp.repro_age[0], sp.repro_age[1],
@@ -1907,6 +1918,7 @@ int gnx_l_find_pairs_enqueue(gnx_state* h, const uint8_t* d_keep, bool with_dens
                      (GnxDD*)nullptr, 0, (int64_t)0, GnxBinP{nullptr, 0.0, 0, 0}, vto);
   gnx_time_end(h, GNX_K_PAIRS, (double)N * 40.0);
   HIPCHK(hipGetLastError());
+  if (h->perm_rest_late) GNXCHK(gnx_permute_rest_launch(h));
   // the pair midpoints' density (ops/demography.py:60-91): on one GPU bins + lattice run on
   // stream3 beside k_offspring and the death probabilities wait for them
   if (with_density && gnx_fused_bins(h)) {
@@ -1992,6 +2004,11 @@ struct OffP {
   const uint8_t* dom;
   GnxBinP bins;          // the individuals' density bins (the newborns join the adults)
   const GnxDD* dd;       // device-driven step: N, B, first id and step index from the device
+  // the parents' alleles at the selected loci: s.tb, or - the cell sort's permutation of that
+  // column is still on its way (GNX_PERMUTE_REST_AT=2) - the buffer it is permuted FROM, through
+  // the sort's permutation (pmap[sorted slot] = the slot before the sort)
+  const uint64_t* ptb;
+  const int32_t* pmap;
 };
 
 // gamete requests of a tiled run: the mate is a ghost (it lives on a neighbour
@@ -2073,9 +2090,11 @@ k_offspring(OffP P, GnxSoA s, const float* rast, const int32_t* pairs, const int
   const int32_t k1 = (int32_t)(((unsigned long long)r.z * (unsigned long long)P.n_paths) >> 32);
   const bool tb_regs = P.genomes && P.fuse_tb && P.TW > 0 && P.TW <= 2;
   uint64_t pi[4] = {0, 0, 0, 0}, pm[4] = {0, 0, 0, 0}, ps0[2] = {0, 0}, ps1[2] = {0, 0};
+  const int64_t ip = P.pmap ? (int64_t)P.pmap[i] : (int64_t)i;
+  const int64_t mp = P.pmap ? (int64_t)P.pmap[m] : (int64_t)m;
   if (tb_regs) {
-    const uint64_t* ti = s.tb + (int64_t)i * 2 * P.TW;
-    const uint64_t* tm = s.tb + (int64_t)m * 2 * P.TW;
+    const uint64_t* ti = P.ptb + ip * 2 * P.TW;
+    const uint64_t* tm = P.ptb + mp * 2 * P.TW;
     for (int w = 0; w < 2; ++w) {
       if (w < P.TW) {
         pi[w] = ti[w];
@@ -2158,9 +2177,8 @@ k_offspring(OffP P, GnxSoA s, const float* rast, const int32_t* pairs, const int
     } else if (P.fuse_tb) {
       uint64_t* t0 = s.tb + slot * 2 * P.TW;
       if (P.TW > 0) {
-        gnx_gamete_tb(P.TW, s.tb + (int64_t)i * 2 * P.TW, P.path_sel + (int64_t)k0 * P.TW, st0 != 0,
-                      t0);
-        gnx_gamete_tb(P.TW, s.tb + (int64_t)m * 2 * P.TW, P.path_sel + (int64_t)k1 * P.TW, st1 != 0,
+        gnx_gamete_tb(P.TW, P.ptb + ip * 2 * P.TW, P.path_sel + (int64_t)k0 * P.TW, st0 != 0, t0);
+        gnx_gamete_tb(P.TW, P.ptb + mp * 2 * P.TW, P.path_sel + (int64_t)k1 * P.TW, st1 != 0,
                       t0 + P.TW);
       }
       if (T.n_traits > 0) gnx_phenotype_tb(t0, t0 + P.TW, T, P.dom, P.cap, slot, s.z);
@@ -2264,6 +2282,12 @@ static OffP gnx_make_offp(gnx_state* h, bool genomes, bool tiled, int64_t id_bas
   Q.path_sel = h->path_sel;
   Q.dom = h->dom;
   Q.bins = GnxBinP{nullptr, 1.0 / h->lat.hww, h->lat.nbx, h->lat.nby};
+  Q.ptb = h->soa[h->cur].tb;
+  Q.pmap = nullptr;
+  if (h->perm_rest_late && (h->perm_rest_inflight || h->perm_rest_pending)) {
+    Q.ptb = h->perm_rest_a.tb;
+    Q.pmap = h->perm[1];
+  }
   return Q;
 }
 
