@@ -1458,7 +1458,8 @@ static void launch_jobs_fused(gnx_state* h, int64_t first_slot, const int32_t* d
   // (device-driven step: first slot and N come from the device, the grid covers what a step's
   // births can take - half the capacity - and the workgroups behind them leave at once)
   const bool ddm = h->dd_active;
-  static const bool jf_coop = !(getenv("GNX_JF_COOP") && atoi(getenv("GNX_JF_COOP")) == 0);
+  // (measured: no gain - profiles/r05_ab_runs.txt; the thread-per-row accesses stay the default)
+  static const bool jf_coop = getenv("GNX_JF_COOP") && atoi(getenv("GNX_JF_COOP")) != 0;
   const int nbf = ddm ? (int)(h->cfg.cap_inds / 2 / GNX_JF_TPB + 2)
                       : (int)((N - 1) / GNX_JF_TPB - first_slot / GNX_JF_TPB + 1);
   hipLaunchKernelGGL((k_xo_jobs_fused<NB, GNX_JF_TPB>), dim3(nbf), dim3(GNX_JF_TPB), 0, h->stream, N, first_slot,
