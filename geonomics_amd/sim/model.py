@@ -457,7 +457,7 @@ class Model:
         architecture / mutation / sampling draws).  The reference draws every iteration from
         one global stream in turn (sim/model.py:364-366), which chains them; here each
         iteration starts its own stream, so iterations can run in any order - and side by
-        side (run(concurrent=K)) - with the results of a sequential run."""
+        side (GNX_CONCURRENT_ITS=K) - with the results of a sequential run."""
         return (int(self._dev_seed) * 1000003 + 7919 * int(it) + 12345) % (2 ** 32)
 
     def _set_next_iteration(self):
@@ -550,13 +550,12 @@ class Model:
     # copy where the landscape changes, collectors and random stream - on K host threads;
     # every call into libgnxhip.so releases the interpreter lock, so while one lane waits for
     # a count its siblings enqueue, and the lanes' kernels share the chip.
-    def _concurrency(self, concurrent):
-        """lanes of run(): the argument, else GNX_CONCURRENT_ITS, else 1.  (Not more by
-        default: on ROCm 7.2 kernels of different handles barely overlap and the lanes' runtime
-        calls contend - measured 0.4-1.1 x the sequential rate, tools/its_bench.py)"""
-        if concurrent is None:
-            concurrent = int(os.environ.get('GNX_CONCURRENT_ITS', '1'))
-        k = max(1, min(int(concurrent), len(self.its)))
+    def _concurrency(self):
+        """lanes of run(): GNX_CONCURRENT_ITS, else 1.  An experiment kept behind the environment,
+        not part of run()'s signature (which is the reference's): on ROCm 7.2 kernels of different
+        handles barely overlap and the lanes' runtime calls contend - measured 0.4-1.1 x the
+        sequential rate, tools/its_bench.py, DESIGN 4.4."""
+        k = max(1, min(int(os.environ.get('GNX_CONCURRENT_ITS', '1')), len(self.its)))
         if self._comm is not None or self._device != 0:
             k = 1           # tiles: one Species already spans the GPUs
         return k
@@ -655,15 +654,14 @@ class Model:
         self.main_fn_queue = self._make_fn_queue(burn=False)
 
     # -- public API ---------------------------------------------------------------------
-    def run(self, verbose=False, concurrent=None):
+    def run(self, verbose=False):
         """Run all iterations: burn-in then T main timesteps each
-        (reference sim/model.py:866-961).  concurrent=K (or GNX_CONCURRENT_ITS=K) runs up
-        to K iterations side by side on the GPU, with the results of the sequential run."""
+        (reference sim/model.py:866-961)."""
         self._verbose = verbose and self._rank == 0
         if self._verbose:
             print('\n\n' + '#' * self.__term_width__ + '\n\n')
             print('Running model "%s"...\n\n' % self.name, flush=True)
-        k = self._concurrency(concurrent)
+        k = self._concurrency()
         if k > 1:
             self._run_concurrent(k)
         while len(self.its) > 0:

@@ -105,8 +105,9 @@ def test_run_iterations_and_reproducibility():
 
 
 @pytest.mark.parametrize('variant', ['snapshot', 'rand_comm', 'mutation', 'repeat_burn'])
-def test_concurrent_iterations_equal_sequential(variant):
-    """Model.run(concurrent=K): the iterations of one model side by side on the GPU (the
+def test_concurrent_iterations_equal_sequential(variant, monkeypatch):
+    """GNX_CONCURRENT_ITS=K (an experiment behind the environment, not a keyword of Model.run):
+    the iterations of one model side by side on the GPU (the
     reference runs them in turn and notes they could be farmed out, sim/model.py:866-953,
     TODO at :924-925) - every iteration ends in the state the sequential run leaves it in:
     population sizes, births, deaths over the whole iteration, ids, positions, genotypes."""
@@ -128,7 +129,8 @@ def test_concurrent_iterations_equal_sequential(variant):
             ends[lane.it] = (np.array([*spp]), lane.get_coords(),
                              lane.get_genotypes(biallelic=True))
         mod._on_iteration_end = at_end
-        mod.run(verbose=False, concurrent=k)
+        monkeypatch.setenv('GNX_CONCURRENT_ITS', str(k))
+        mod.run(verbose=False)
         return mod, ends
 
     m1, e1 = run(1)

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Iterations of one model side by side on one GPU (Model.run(concurrent=K); the reference
+"""Iterations of one model side by side on one GPU (GNX_CONCURRENT_ITS=K; the reference
 runs them in turn, sim/model.py:866-953, TODO at :924-925).
 
     python tools/its_bench.py [workload] [--its 8] [--T 100]
 
 runs the workload through the Geonomics API twice - n_its iterations one after another
-(concurrent=1) and side by side (concurrent=its) - and reports individual-timesteps/s of
+(1 lane) and side by side (its lanes) - and reports individual-timesteps/s of
 the MAIN phases (sum of N_t over all iterations / wall time from the first main phase's
 start to the last one's end), plus whether every iteration ended the same in both runs."""
 import argparse
@@ -38,7 +38,8 @@ def run(k):
     t0 = time.time()
     mod = gnx.make_model(d)
     t1 = time.time()
-    mod.run(verbose=False, concurrent=k)
+    os.environ['GNX_CONCURRENT_ITS'] = str(k)
+    mod.run(verbose=False)
     for spp in mod.comm.values():
         spp._dev.synchronize()
     t2 = time.time()
