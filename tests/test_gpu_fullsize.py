@@ -77,8 +77,11 @@ def test_crossover_routing_checksum_at_metric_size():
 def test_step_invariants_at_baseline_sizes(workload):
     """six main steps of BASELINE configs[1], [2] and the metric workload ([3] with 10^5 loci): N' = N + births - deaths, ids unique and
     ascending offspring ids, genome rows unique, positions on the landscape, cell
-    order sorted, density bins sum to N, and the run is reproducible."""
-    def run():
+    order sorted, density bins sum to N, and the run is reproducible - through gnx_step and,
+    with the same signature, through gnx_walk (at 10^5 individuals the device-driven step:
+    counts on the device, one graph launch per step; tests/runtime/runtime_test.py:155-164
+    is the loop it stands for)."""
+    def run(via='step'):
         bench, nat, cfg, dev = _build(workload)
         for _ in range(3):
             dev.step(True, False)
@@ -87,7 +90,11 @@ def test_step_invariants_at_baseline_sizes(workload):
         max_id = int(dev.download(nat.F_ID).max())
         for _ in range(6):
             n0 = dev.N
-            dev.step(False, True)
+            if via == 'walk':
+                dev.walk(1, False, True)
+                assert [int(v[-1]) for v in dev.walk_history()][0] == n0
+            else:
+                dev.step(False, True)
             n1, b, d = dev.counts()
             assert n1 == n0 + b - d and b > 0 and d > 0
             ids = dev.download(nat.F_ID)
@@ -114,7 +121,9 @@ def test_step_invariants_at_baseline_sizes(workload):
                c1[:64].tolist())
         dev.close()
         return sig
-    assert run() == run()
+    sig = run()
+    assert sig == run()
+    assert sig == run('walk')
 
 
 def _tiles_equal_one_device(cfg, grid, n_paths, n_burn, n_main, nbits, library=False):
