@@ -630,6 +630,11 @@ def main():
         copy_gbps = measured_copy_bandwidth()
         dense = cfg.get('paths') == 'dense'
         per_gamete = (4.0 if dense else 2.0) * dev.W64 * 8.0
+        # the crossover's algorithmic bytes per copied block: the block read and written, plus -
+        # sparse paths - the 128-byte line around the switch point from the other homologue
+        # (gnx_kernel_time); `copied` = the share that is block copies, for the gamete figures
+        blk = dev.W64 * 8.0 / max(dev.blocks_per_hom, 1)
+        copied = 1.0 if dense else 2.0 * blk / (2.0 * blk + 128.0)
         out = {
             'metric': 'individual-timesteps/sec', 'value': total_ind_steps / max_elapsed,
             'unit': 'individual-timesteps/s', 'n_gpus': world, 'steps': args.steps,
@@ -669,16 +674,19 @@ def main():
                 'traffic_pmc': traffic_src,
                 'launches': xo['launches'],
                 'avg_launch_ms': xo['ms'] / max(xo['launches'], 1),
-                # blocks the kernel copied (counted on the device) x 2 x block bytes (x 4 with
-                # dense masks): of the two gametes of every offspring that survives its first
+                # blocks the kernel copied (counted on the device) x (2 x block bytes + the switch
+                # point's 128-byte line from the other homologue; dense masks: 4 x block bytes):
+                # of the two gametes of every offspring that survives its first
                 # death draw, the blocks that hold a switch point - the others refer to the
                 # parent's block and move nothing (csrc/gnx_half.h)
                 'algorithmic_bytes_per_launch': xo['bytes'] / max(xo['launches'], 1),
+                # (rounds 1-4 counted the block copies only: this figure x `copies_share`)
+                'copies_share': copied,
                 # in whole gametes (a gamete = one homologue of L/8 bytes read and written)
                 'gamete_equivalents_copied_per_launch':
-                    xo['bytes'] / max(xo['launches'], 1) / per_gamete,
+                    copied * xo['bytes'] / max(xo['launches'], 1) / per_gamete,
                 'share_of_the_survivors_gametes_not_copied':
-                    1.0 - (xo['bytes'] / per_gamete) / max(2.0 * xo_births, 1.0),
+                    1.0 - (copied * xo['bytes'] / per_gamete) / max(2.0 * xo_births, 1.0),
                 # SURVEY 8(d)'s figure for the same launch: every birth cut in full, L bytes
                 # each (4 homologue reads + 2 masks + 2 writes) - what the kernel would move
                 # without the deferral behind the death draws and without shared blocks

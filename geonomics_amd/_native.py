@@ -21,7 +21,7 @@ KERNELS = ['move', 'sort', 'permute', 'find_mates', 'pairs', 'offspring',
            'crossover', 'phenotype', 'density', 'death', 'compact', 'crossover_tail']
 
 EXPORTS = [
-    'gnx_create', 'gnx_destroy', 'gnx_last_error', 'gnx_words_per_hom',
+    'gnx_create', 'gnx_destroy', 'gnx_last_error', 'gnx_words_per_hom', 'gnx_blocks_per_hom',
     'gnx_set_stream', 'gnx_synchronize', 'gnx_upload_rasters',
     'gnx_upload_layer', 'gnx_set_species_params', 'gnx_upload_population',
     'gnx_init_population', 'gnx_set_recomb_paths', 'gnx_set_trait',
@@ -153,6 +153,11 @@ class Device:
         if rc:
             raise GnxError(self.lib.gnx_last_error().decode())
         self.h = h
+
+    @property
+    def blocks_per_hom(self):
+        """blocks a homologue is stored in (the crossover copies or shares whole blocks)"""
+        return int(self.lib.gnx_blocks_per_hom(self.h))
 
     @property
     def h(self):

@@ -26,6 +26,8 @@ extern "C" int gnx_words_per_hom(int32_t L) {
   return ((w + 15) / 16) * 16;
 }
 
+extern "C" int gnx_blocks_per_hom(const gnx_state* h) { return h && h->cfg.L > 0 ? h->NB : 0; }
+
 // ---------------------------------------------------------------- timers
 // HIP events on the handle's stream around each kernel family.  Events are
 // recorded without any host synchronisation inside the step (so the timed
@@ -1757,7 +1759,11 @@ extern "C" int gnx_kernel_time(gnx_state* h, int32_t kernel, double* ms, int64_t
     unsigned long long n = 0;
     HIPCHK(hipMemcpy(&n, h->xo_jobs_acc + slot, sizeof(n), hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(h->xo_jobs_acc + slot, 0, sizeof(n)));
-    h->timers[kernel].bytes = (double)n * 0.5 * gnx_xo_bytes_per_birth(h) / h->NB;   // a job = a block
+    // a job = a block copied: one block read, one written - and, with sparse paths, the 128-byte
+    // line around the switch point from the OTHER homologue as well (a job exists because its
+    // block holds a switch point; the lane that blends needs both parents' chunk there)
+    h->timers[kernel].bytes =
+        (double)n * (0.5 * gnx_xo_bytes_per_birth(h) / h->NB + (h->sparse_paths ? 128.0 : 0.0));
   }
   if (ms) *ms = h->timers[kernel].ms;
   if (launches) *launches = h->timers[kernel].launches;

@@ -115,6 +115,9 @@ int  gnx_create(const gnx_config* cfg, gnx_state** out);
 void gnx_destroy(gnx_state* h);
 const char* gnx_last_error(void);
 int  gnx_words_per_hom(int32_t L);
+/* blocks a homologue is stored in (a block = W64*8 / n bytes is the unit the crossover copies
+ * or shares with the parent, csrc/gnx_half.h); 0 without genomes                              */
+int  gnx_blocks_per_hom(const gnx_state* h);
 /* use an externally created hipStream_t (e.g. torch's current stream)       */
 int  gnx_set_stream(gnx_state* h, void* hip_stream);
 int  gnx_synchronize(gnx_state* h);

@@ -25,15 +25,16 @@ def find(d, suffix):
     return hits[0] if hits else None
 
 
-def counter_rows(d, counter, dst):
+def counter_rows(d, counter, dst, mode='w'):
     path = find(d, 'counter_collection.csv')
     vals, dur = [], []
     if not path:
         return vals, dur
-    with open(path) as f, open(dst, 'w', newline='') as g:
+    with open(path) as f, open(dst, mode, newline='') as g:
         rd = csv.DictReader(f)
         wr = csv.DictWriter(g, rd.fieldnames)
-        wr.writeheader()
+        if mode == 'w':
+            wr.writeheader()
         for r in rd:
             if ('k_xo_sparse' in r['Kernel_Name'] or 'k_xo_dense' in r['Kernel_Name']) \
                     and r['Counter_Name'] == counter:
@@ -41,6 +42,65 @@ def counter_rows(d, counter, dst):
                 vals.append(float(r['Counter_Value']))
                 dur.append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-6)
     return vals, dur
+
+
+def attribute(req, alg_r, share, rd, wrb, alg_f, js):
+    """Reads per copied block (a 'job': csrc/gnx_xo.h k_xo_sparse_pair), from the request
+    counters of the pass that counted them.  alg_r = that pass's algorithmic bytes per launch,
+    share = the part of them that is block copies (2 x block bytes of 2 x block + 128)."""
+    # block bytes from the share: share = 2b / (2b + 128)
+    blk = 64.0 * share / (1.0 - share) if share < 1.0 else None
+    if not blk:
+        return None
+    jobs = alg_r / (2.0 * blk + 128.0)
+    jobs_f = alg_f / (2.0 * blk + 128.0) if alg_f else None
+    n = req.get('TCC_EA0_RDREQ_sum', 0.0)
+    n32 = req.get('TCC_EA0_RDREQ_32B_sum', 0.0)
+    bub = req.get('TCC_BUBBLE_sum', 0.0)
+    import math
+    lines = float(math.ceil(blk / 128.0))      # the kernel copies whole lines, the last block's padding too
+    calib = None
+    try:
+        calib = json.load(open(os.path.join(prof, '%s_pmc_calibration.json' % tag)))['kernels']
+    except Exception:
+        pass
+    # tools/pmc_calib.hip (the same 40-lane x 16-byte block copy with known bytes): a 128-byte line
+    # is ONE request (tallied at 64 bytes: the x2), the blending lane's 16 bytes from the other
+    # homologue are one more, and a 16-byte job record costs 0.25 requests, not 0.125: its line
+    # holds the records of two workgroups, which sit on two XCDs with an L2 each
+    rec = 0.25
+    if calib:
+        rec = calib['k_calib<32, 0>']['TCC_EA0_RDREQ_sum_per_block'] - 5.0
+    lam = 1.0 / max(js.get('blocks_per_hom', 20), 1)
+    expect = {'block_lines': lines,
+              'switch_point_line_from_the_other_homologue': 1.0,
+              'further_switch_points_in_the_block (r = 1/L: lambda / (1 - exp(-lambda)) - 1)':
+                  lam / (1.0 - math.exp(-lam)) - 1.0,
+              'job_records (16 B, 8 to a line, two XCDs: calibrated)': rec,
+              'switch_point_words (8 B, 16 to a line, four XCDs: same mechanism)': 0.25}
+    out = {
+        'block_bytes_mean': blk, 'copied_blocks_per_launch': jobs,
+        'read_requests_per_block': n / jobs, 'of_which_32B': n32 / jobs,
+        'of_which_128B_flagged (TCC_BUBBLE)': bub / jobs,
+        'expected_requests_per_block': expect,
+        'expected_requests_total': sum(expect.values()),
+        'FETCH_SIZE_bytes_per_block_uncorrected': (rd / 2.0) / jobs_f if jobs_f else None,
+        'read_bytes_per_block_x2': rd / jobs_f if jobs_f else None,
+        'calibration': calib,
+    }
+    out['requests_measured_over_expected'] = out['read_requests_per_block'] / out['expected_requests_total']
+    out['unattributed_requests_per_block'] = out['read_requests_per_block'] - out['expected_requests_total']
+    w = req.get('TCC_EA0_WRREQ_sum')
+    if w:
+        w64 = req.get('TCC_EA0_WRREQ_64B_sum', 0.0)
+        out['write_requests_per_block'] = w / jobs
+        out['write_requests_64B_per_block'] = w64 / jobs
+        out['expected_write_requests_per_block (64 B each; calibrated: exact)'] = lines * 2.0
+        out['write_note'] = ('the surplus is not the kernel\'s own: counters run per dispatch with the '
+                             'dispatches serialized, and the lines the job builder left dirty in the L2s '
+                             '(job records, the children\'s block maps: ~35 MB written right before) are '
+                             'written back while the crossover streams through them')
+    return out
 
 
 ks = find('prof_' + tag, 'kernel_stats.csv')
@@ -70,6 +130,27 @@ if fv and wv:
           'hbm_read_bytes_per_launch': rd, 'hbm_write_bytes_per_launch': wrb,
           'hbm_bytes_per_launch': rd + wrb, 'algorithmic_bytes_per_launch': alg,
           'note': 'separate runs (6 timed launches each)'}
+    # the read side attributed: requests per copied block (tools/profile_round.sh passes 3-4)
+    req = {}
+    dst = os.path.join(prof, '%s_pmc_requests_crossover.csv' % tag)
+    for k, (d, c) in enumerate((('pmc_rdreq_', 'TCC_EA0_RDREQ_sum'),
+                                ('pmc_rdreq_', 'TCC_EA0_RDREQ_32B_sum'),
+                                ('pmc_rdreq_', 'TCC_BUBBLE_sum'),
+                                ('pmc_wrreq_', 'TCC_EA0_WRREQ_sum'),
+                                ('pmc_wrreq_', 'TCC_EA0_WRREQ_64B_sum'))):
+        v, _ = counter_rows(d + tag, c, dst, 'w' if k == 0 else 'a')
+        if v:
+            req[c] = sum(v[-6:]) / len(v[-6:])
+    if req and alg:
+        try:
+            bj = json.loads([l for l in open(os.path.join(out, 'pmc_rdreq_%s.json' % tag))
+                             if l.startswith('{"metric"')][-1])
+            share = bj['roofline'].get('copies_share', 1.0)
+            alg_r = bj['roofline']['algorithmic_bytes_per_launch']
+        except Exception:
+            share, alg_r = 1.0, alg
+        js['requests'] = req
+        js['attribution'] = attribute(req, alg_r, share, rd, wrb, alg, js)
     with open(os.path.join(prof, '%s_pmc_crossover.json' % tag), 'w') as f:
         json.dump(js, f, indent=1)
     print(json.dumps(js))
