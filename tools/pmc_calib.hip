@@ -4,7 +4,8 @@
 // A wave copies one 640-byte block (40 lanes x 16 bytes, 128-byte aligned) from a random place of
 // a pool to another random place - k_xo_sparse_pair without its records and its blend - so the
 // bytes are known: 5 lines read, 5 lines written per block.  Variants:
-//   pool of 1 GiB / 32 GiB    (does the address translation of a large pool add requests?)
+//   pool of 1 / 32 / 200 GiB  (does the address translation of a large pool add requests?  The
+//                              metric workload's genome table spans 200 GB of addresses)
 //   + one lane's 16 bytes from a third random block   (the switch point's chunk: one request?)
 //   + one lane's 16 bytes from a line of the block the wave is loading anyway, by a second
 //     instruction - a plain load (EXTRA 2) or a non-temporal one (3): in the crossover the lanes
@@ -87,14 +88,14 @@ static void run(int n_jobs, u64x2* G, Job* jobs, int reps) {
 
 int main() {
   const int n_jobs = 350000;
-  const size_t big = (size_t)32 << 30, small = (size_t)1 << 30;
+  const size_t huge = (size_t)200 << 30, big = (size_t)32 << 30, small = (size_t)1 << 30;
   u64x2* G;
-  CHK(hipMalloc(&G, big));
-  CHK(hipMemset(G, 0, big));
+  CHK(hipMalloc(&G, huge));
+  CHK(hipMemset(G, 0, huge));
   std::vector<Job> hj(n_jobs);
-  Job* jobs[2];
-  for (int k = 0; k < 2; ++k) {
-    const uint64_t nblk = (k ? big : small) / 640;
+  Job* jobs[3];
+  for (int k = 0; k < 3; ++k) {
+    const uint64_t nblk = (k == 2 ? huge : k ? big : small) / 640;
     uint64_t s = 0x9E3779B97F4A7C15ull + k;
     auto next = [&]() {
       s = s * 6364136223846793005ull + 1442695040888963407ull;
@@ -117,6 +118,8 @@ int main() {
   run<32, 1>(n_jobs, G, jobs[1], reps);
   run<32, 2>(n_jobs, G, jobs[1], reps);
   run<32, 3>(n_jobs, G, jobs[1], reps);
+  run<200, 0>(n_jobs, G, jobs[2], reps);
+  run<200, 1>(n_jobs, G, jobs[2], reps);
   printf("blocks_per_launch %d  block_bytes 640  launches_per_variant %d\n", n_jobs, reps);
   return 0;
 }

@@ -70,7 +70,7 @@ def attribute(req, alg_r, share, rd, wrb, alg_f, js):
     # holds the records of two workgroups, which sit on two XCDs with an L2 each
     rec = 0.25
     if calib:
-        rec = calib['k_calib<32, 0>']['TCC_EA0_RDREQ_sum_per_block'] - 5.0
+        rec = calib['k_calib<200, 0>']['TCC_EA0_RDREQ_sum_per_block'] - 5.0
     lam = 1.0 / max(js.get('blocks_per_hom', 20), 1)
     expect = {'block_lines': lines,
               'switch_point_line_from_the_other_homologue': 1.0,
@@ -90,6 +90,11 @@ def attribute(req, alg_r, share, rd, wrb, alg_f, js):
     }
     out['requests_measured_over_expected'] = out['read_requests_per_block'] / out['expected_requests_total']
     out['unattributed_requests_per_block'] = out['read_requests_per_block'] - out['expected_requests_total']
+    out['excluded_by_the_calibration'] = (
+        'address translation (1 / 32 / 200 GiB pools: 5.24 / 5.25 / 5.26 requests per block); a second '
+        'request, by another instruction, to a line that a non-temporal load of the same wave is '
+        'bringing in (5.25 with and without); 32-byte or 128-byte-flagged requests (none: every '
+        'request is tallied at 64 bytes, a 128-byte line is one request)')
     w = req.get('TCC_EA0_WRREQ_sum')
     if w:
         w64 = req.get('TCC_EA0_WRREQ_64B_sum', 0.0)
