@@ -395,6 +395,55 @@ def _cat(chunks, dtype, shape_tail=()):
     return np.concatenate(chunks)
 
 
+def _everybody(comm, flag):
+    """every rank says yes - over the CPU side group when there is one (no device, no RCCL call
+    involved: this is what decides whether anybody enters one)"""
+    if comm.world == 1:
+        return bool(flag)
+    mine = np.array([1 if flag else 0], np.int64)
+    if getattr(comm, '_hgrp', None) is not None:
+        return int(comm.host_allgather(mine).sum()) == comm.world
+    return int(comm.allreduce_sum(mine)[0]) == comm.world
+
+
+def _rccl_rendezvous(comm, dev):
+    """The ranks of `comm` join the library's RCCL communicator, or none of them does:
+    -> (joined 0 | 1, why).  ncclCommInitRank is a collective nobody can be called back from: a
+    rank that cannot follow (no librccl, no id) must say so BEFORE anybody enters it.  So first
+    every rank probes its librccl (gnx_comm_probe) and the ranks agree on it; then rank 0 makes
+    the id, it travels once through the launcher's CPU side group (128 bytes, no device involved;
+    a rank 0 that cannot make one says so with None) and the ranks agree that everybody holds
+    it; only then do they join - and the join itself has a deadline (GNX_COMM_INIT_TIMEOUT_S):
+    past it a rank says why and ends its process with a non-zero code (csrc/gnx_comm.hip).
+    GNX_COMM_PROBE_FAIL=<rank>: fault injection for the tests."""
+    import os
+    ok, why = 1, None
+    try:
+        nat.comm_probe()
+        if os.environ.get('GNX_COMM_PROBE_FAIL', '') == str(comm.rank):
+            raise nat.GnxError('injected failure (GNX_COMM_PROBE_FAIL)')
+    except Exception as e:
+        ok, why = 0, e
+    if not _everybody(comm, ok):
+        return 0, why or 'librccl is not usable on some rank'
+    box = [None]
+    if comm.rank == 0:
+        try:
+            box[0] = nat.comm_unique_id()
+        except Exception as e:
+            why = e
+    hgrp = getattr(comm, '_hgrp', None)
+    if hgrp is not None:
+        import torch
+        comm.dist.broadcast_object_list(box, src=0, group=hgrp, device=torch.device('cpu'))
+    else:
+        comm.dist.broadcast_object_list(box, src=0)
+    if not _everybody(comm, box[0] is not None):
+        return 0, why or 'no communicator id reached some rank'
+    dev.comm_init_rccl(box[0], comm.rank, comm.world)
+    return 1, None
+
+
 class TiledStepper:
     def __init__(self, shard, comm, W, H, mating_radius, move=True, max_id=-1,
                  grid=None, fixed_births=0, use_library=None):
@@ -469,15 +518,7 @@ class TiledStepper:
         if comm.world > 1 and group is None and not rccl:
             return False
 
-        def everybody(flag):
-            """every rank says yes - over the CPU side group when there is one (no device, no
-            RCCL call involved: this is what decides whether anybody enters one)"""
-            if comm.world == 1:
-                return bool(flag)
-            mine = np.array([1 if flag else 0], np.int64)
-            if getattr(comm, '_hgrp', None) is not None:
-                return int(comm.host_allgather(mine).sum()) == comm.world
-            return int(comm.allreduce_sum(mine)[0]) == comm.world
+        everybody = lambda flag: _everybody(comm, flag)     # noqa: E731
 
         joined, why = 1, None
         try:
@@ -486,43 +527,7 @@ class TiledStepper:
             elif group is not None:               # tiles as threads of one process (tests)
                 dev.comm_local_join(group, comm.rank)
             else:
-                # ncclCommInitRank is a collective nobody can be called back from: a rank that
-                # cannot follow (no librccl, no id) must say so BEFORE anybody enters it.  So
-                # first every rank probes its librccl (gnx_comm_probe) and the ranks agree on it;
-                # then rank 0 makes the id, it travels once through the launcher's CPU side group
-                # (128 bytes, no device involved; a rank 0 that cannot make one says so with None)
-                # and the ranks agree that everybody holds it; only then do they join - and the
-                # join itself has a deadline (GNX_COMM_INIT_TIMEOUT_S): past it a rank says why
-                # and ends its process with a non-zero code (csrc/gnx_comm.hip).
-                ok = 1
-                try:
-                    nat.comm_probe()
-                    if os.environ.get('GNX_COMM_PROBE_FAIL', '') == str(comm.rank):
-                        raise nat.GnxError('injected failure (GNX_COMM_PROBE_FAIL)')
-                except Exception as e:
-                    ok, why = 0, e
-                if not everybody(ok):
-                    joined = 0
-                    why = why or 'librccl is not usable on some rank'
-                else:
-                    box = [None]
-                    if comm.rank == 0:
-                        try:
-                            box[0] = nat.comm_unique_id()
-                        except Exception as e:
-                            why = e
-                    hgrp = getattr(comm, '_hgrp', None)
-                    if hgrp is not None:
-                        import torch
-                        comm.dist.broadcast_object_list(box, src=0, group=hgrp,
-                                                        device=torch.device('cpu'))
-                    else:
-                        comm.dist.broadcast_object_list(box, src=0)
-                    if not everybody(box[0] is not None):
-                        joined = 0
-                        why = why or 'no communicator id reached some rank'
-                    else:
-                        dev.comm_init_rccl(box[0], comm.rank, comm.world)
+                joined, why = _rccl_rendezvous(comm, dev)
         except Exception as e:           # (whatever it was: the ranks agree below)
             joined, why = 0, e
 

@@ -498,10 +498,10 @@ int gnx_tile2_die(gnx_state* h, int32_t burn, int32_t with_selection, int32_t ha
 
 /* ---- one tiled time step per call, the exchanges issued by the library (csrc/gnx_comm.hip).
  * The tile2 protocol above composed in C: grouped ncclSend / ncclRecv to the neighbour tiles
- * on the handle's own stream (RCCL over xGMI), KB-sized ncclAllGather for the counts and the
- * pairs' order keys, ONE ncclAllReduce for both density fields and the counters, the pairs'
- * global offspring offsets by a kernel of binary searches - no torch.distributed call, no
- * Python between the phases of a step.  The reference has no counterpart (one process;
+ * on the handle's own stream (RCCL over xGMI), two KB-sized ncclAllGather for the counts (the
+ * second carries the 64 virtual-tile birth counts the offspring ids are numbered from and the
+ * pair count), ONE ncclAllReduce for both density fields and the counters - no torch.distributed
+ * call, no Python between the phases of a step.  The reference has no counterpart (one process;
  * sim/model.py:924-925 is a TODO).
  *   gnx_comm_unique_id: rank 0 makes the id (ncclGetUniqueId, 128 bytes) and hands it to the
  *     other ranks by whatever channel the launcher has (bench.py: torch.distributed broadcast);

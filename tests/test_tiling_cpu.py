@@ -57,3 +57,18 @@ def test_tile2_comm_helpers(world):
              for r in range(world)]
     from _procs import wait_all
     assert wait_all(procs) == [0] * world
+
+
+@pytest.mark.parametrize('scenario', ['probe', 'id'])
+def test_rccl_rendezvous_is_all_or_none(scenario):
+    """Before any rank enters the library's ncclCommInitRank - a collective nobody can be called
+    back from - the ranks agree over the CPU group that every one of them can load librccl
+    (gnx_comm_probe) and holds rank 0's id.  One rank whose probe fails, or a rank 0 that cannot
+    make an id: NO rank asks its device to join, every rank returns (0, why) and they stay in
+    step (three gloo ranks)."""
+    port = free_port()
+    worker = os.path.join(HERE, '_rendezvous_worker.py')
+    procs = [subprocess.Popen([sys.executable, worker, '3', str(r), str(port), scenario])
+             for r in range(3)]
+    from _procs import wait_all
+    assert wait_all(procs, timeout=120) == [0, 0, 0]
