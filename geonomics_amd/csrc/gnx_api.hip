@@ -427,7 +427,10 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
   HIPCHK(hipEventCreateWithFlags(&h->ev_perm_rest, gnx_order_event_flags()));
   {
     // (zero between sorts: k_permute wipes what a sort dirtied; + 16: the wipe is in uint4s)
-    const size_t nb = gnx_os_scratch_bytes((size_t)cap, 24) + 16;
+    // (three digit places of the 32-bit cell sort over the id-ordered index, or the seven a
+    // 64-bit (cell, id) key can have: gnx_os_sort64_clean on tiles)
+    const size_t nb = std::max(gnx_os_scratch_bytes((size_t)cap, 24),
+                               gnx_os_words_used64((size_t)cap, 64) * sizeof(unsigned int)) + 16;
     HIPCHK(hipMalloc(&h->os_scratch, nb));
     HIPCHK(hipMemset(h->os_scratch, 0, nb));
   }

@@ -767,6 +767,9 @@ void gnx_host_mark(int id);                       // GNX_HOST_TIMES=2 (gnx_api.h
 extern double g_host_step_s, g_host_wait_s;      // GNX_HOST_TIMES=1 (gnx_api.hip)
 bool gnx_host_times();
 size_t gnx_os_scratch_bytes(size_t n, int end_bit);
+size_t gnx_os_words_used64(size_t n, int end_bit);
+int gnx_os_sort64_clean(void* scratch, void* tmp, const uint64_t* kin, uint64_t* kout,
+                        const int32_t* vin, int32_t* vout, size_t n, int end_bit, hipStream_t s);
 size_t gnx_os_words_used(size_t n, int end_bit, int geometry = 0);
 int gnx_os_keys_hist(void* scratch, unsigned int* ticket, int64_t N, int64_t ord_n,
                      const int32_t* ord, const uint32_t* cell32, uint32_t* key, int32_t* val,

@@ -798,9 +798,17 @@ int gnx_l_sort_by_cell(gnx_state* h, bool split_rest) {
       hipLaunchKernelGGL(k_keys, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, a.x, a.y, a.id,
                          h->inv_cs, h->ncx, h->ncy, idbits, h->key64[0], h->perm[0]);
     }
-    GNXCHK(gnx_prim_sort64_bits(h->sort64_tmp, h->sort64_tmp_bytes, h->key64[0], h->key64[1],
-                                h->perm[0], h->perm[1], (size_t)N, idbits + cell_bits,
-                                h->stream, alone));
+    // GNX_TILE_OS64=0: rocPRIM's own driver (a fill before the histograms, two before every pass)
+    static const bool os64 = !(getenv("GNX_TILE_OS64") && atoi(getenv("GNX_TILE_OS64")) == 0);
+    if (os64 && h->sort64_tmp_bytes >= (size_t)N * 12 && h->os_scratch) {
+      GNXCHK(gnx_os_sort64_clean(h->os_scratch, h->sort64_tmp, h->key64[0], h->key64[1], h->perm[0],
+                                 h->perm[1], (size_t)N, idbits + cell_bits, h->stream));
+      wipe_words = (int64_t)gnx_os_words_used64((size_t)N, idbits + cell_bits);
+    } else {
+      GNXCHK(gnx_prim_sort64_bits(h->sort64_tmp, h->sort64_tmp_bytes, h->key64[0], h->key64[1],
+                                  h->perm[0], h->perm[1], (size_t)N, idbits + cell_bits,
+                                  h->stream, alone));
+    }
   }
   h->keys_fresh = false;
   gnx_time_end(h, GNX_K_SORT, (double)N * 40.0);

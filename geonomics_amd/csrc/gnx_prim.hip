@@ -198,6 +198,64 @@ static int sort(void* scratch, uint32_t* ktmp, int32_t* vtmp, const uint32_t* ki
   HIPCHK(hipGetLastError());
   return 0;
 }
+// The same passes over 64-bit (cell << idbits | id) keys - what a tile with imports sorts, its
+// id-ordered index gone (csrc/gnx_tile.hip).  `scratch` is zero on entry and the caller wipes
+// what the sort dirtied (k_permute): no fills.  rocPRIM's own driver (radix_sort_pairs) puts a
+// fill in front of the histograms and two in front of every pass - eleven of ~5 us each on the
+// step's chain for 41-bit keys (profiles/r05_ab_runs.txt).
+template <unsigned BS, unsigned IPT, unsigned RB>
+__global__ void __launch_bounds__(BS)
+k_hist64(const uint64_t* keys, unsigned int* offs, unsigned int size, unsigned int full_blocks,
+         unsigned int begin_bit, unsigned int end_bit) {
+  rocprim::detail::onesweep_histograms<BS, IPT, RB, false>(keys, offs, size, full_blocks,
+                                                          rocprim::identity_decomposer{}, begin_bit,
+                                                          end_bit);
+}
+
+template <unsigned BS, unsigned IPT, unsigned RB>
+__global__ void __launch_bounds__(BS)
+k_iter64(const uint64_t* kin, uint64_t* kout, const int32_t* vin, int32_t* vout, unsigned int size,
+         unsigned int* offs_in, unsigned int* offs_out, lookback_t* lb, unsigned int bit,
+         unsigned int cur_bits, unsigned int full_blocks, obid_t ob) {
+  rocprim::detail::onesweep_iteration<BS, IPT, RB, false, rocprim::block_radix_rank_algorithm::match>(
+      kin, kout, vin, vout, size, offs_in, offs_out, lb, rocprim::identity_decomposer{}, bit, cur_bits,
+      full_blocks, ob);
+}
+
+template <unsigned BS, unsigned IPT, unsigned RB>
+static int sort64_clean(void* scratch, uint64_t* ktmp, int32_t* vtmp, const uint64_t* kin,
+                        uint64_t* kout, const int32_t* vin, int32_t* vout, size_t n, int end_bit,
+                        hipStream_t s) {
+  const unsigned int places = (end_bit + RB - 1) / RB, radix = 1u << RB;
+  const unsigned int items = BS * IPT;
+  const unsigned int blocks = (unsigned int)((n + items - 1) / items);
+  const unsigned int full_blocks = (unsigned int)(n / items);
+  unsigned int* hist = (unsigned int*)scratch;                 // [places][radix]
+  unsigned int* offs_tmp = hist + (size_t)places * radix;      // [radix]
+  lookback_t* lb = (lookback_t*)(offs_tmp + radix);            // [places][blocks * radix]
+  unsigned int* bid = (unsigned int*)(lb + (size_t)places * blocks * radix);   // [places]
+  hipLaunchKernelGGL((k_hist64<BS, IPT, RB>), dim3(blocks), dim3(BS), 0, s, kin, hist,
+                     (unsigned int)n, full_blocks, 0u, (unsigned int)end_bit);
+  hipLaunchKernelGGL((k_scan<BS, RB>), dim3(places), dim3(BS), 0, s, hist);
+  bool to_output = (places - 1) % 2 == 0;
+  const uint64_t* ki = kin;
+  const int32_t* vi = vin;
+  for (unsigned int place = 0, bit = 0; place < places; ++place, bit += RB) {
+    uint64_t* ko = to_output ? kout : ktmp;
+    int32_t* vo = to_output ? vout : vtmp;
+    const unsigned int cur = std::min<unsigned int>(RB, (unsigned int)end_bit - bit);
+    hipLaunchKernelGGL((k_iter64<BS, IPT, RB>), dim3(blocks), dim3(BS), 0, s, ki, ko, vi, vo,
+                       (unsigned int)n, hist + (size_t)place * radix, offs_tmp,
+                       lb + (size_t)place * blocks * radix, bit, cur, full_blocks,
+                       obid_t::create(bid + place));
+    ki = ko;
+    vi = vo;
+    to_output = !to_output;
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // Keys of the id-ordered sequence (entry k is slot ord[k] for k < ord_n, else slot k itself:
 // offspring appended since the index was last compacted), their digit histograms and - in the
 // workgroup that finishes last (ticket) - the exclusive scans of the histograms, i.e. what
@@ -346,6 +404,18 @@ int gnx_os_sort32_ranked(void* scratch, uint32_t* ktmp, int32_t* vtmp, const uin
   if (geometry == 1)
     return gnx_os::sort_ranked<512, 4, 10>(scratch, ktmp, vtmp, kin, kout, vin, vout, n, end_bit, s);
   return gnx_os::sort_ranked<1024, 6, 10>(scratch, ktmp, vtmp, kin, kout, vin, vout, n, end_bit, s);
+}
+
+// 64-bit keys, 10-bit digits, 1024 x 6 keys; scratch zero on entry, *words = what the caller has
+// to wipe afterwards; tmp (>= 12 n bytes) holds the keys and values between the passes
+size_t gnx_os_words_used64(size_t n, int end_bit) {
+  return gnx_os::scratch_words<1024, 6, 10>(n, end_bit);
+}
+int gnx_os_sort64_clean(void* scratch, void* tmp, const uint64_t* kin, uint64_t* kout,
+                        const int32_t* vin, int32_t* vout, size_t n, int end_bit, hipStream_t s) {
+  uint64_t* ktmp = (uint64_t*)tmp;
+  int32_t* vtmp = (int32_t*)(ktmp + n);
+  return gnx_os::sort64_clean<1024, 6, 10>(scratch, ktmp, vtmp, kin, kout, vin, vout, n, end_bit, s);
 }
 
 // variant 0: 256 threads x 12 keys, 8-bit digits; 1: 512 x 8, 8 bits; 2: 1024 x 6, 10 bits

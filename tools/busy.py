@@ -24,7 +24,11 @@ span = iv[-1][1] - iv[0][0]
 print('window %.2f ms, %d dispatches, GPU busy %.2f ms = %.0f %%' % (span / 1e6, len(iv), busy / 1e6,
                                                                    100.0 * busy / span))
 acc = collections.defaultdict(float)
+cnt = collections.Counter()
 for s, e, k in iv:
     acc[k.split('(')[0][:60]] += (e - s) / 1e6
-for k, v in sorted(acc.items(), key=lambda kv: -kv[1])[:25]:
-    print('  %8.2f ms  %s' % (v, k))
+    cnt[k.split('(')[0][:60]] += 1
+n_steps = max(1, cnt.get('k_alive', 1))          # (one per tile and step)
+print('  (%d tile-steps in the window: per tile-step below)' % n_steps)
+for k, v in sorted(acc.items(), key=lambda kv: -kv[1])[:40]:
+    print('  %8.2f ms  %6.1f us  x%-5.1f %s' % (v, 1e3 * v / n_steps, cnt[k] / n_steps, k))
