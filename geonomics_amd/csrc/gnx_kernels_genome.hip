@@ -196,6 +196,10 @@ int gnx_l_crossover_all(gnx_state* h, int64_t first_slot, int64_t B) {
 // their row and the crossover of their LOCAL gamete at once - the remote gamete is put
 // next to it and their alleles at the selected loci are read from the finished row -
 // while every other offspring of the step waits for the death draws like on one GPU.
+// (One atomic per wave for the fresh blocks and one for the jobs, every table entry loaded before
+// the first is stored: the generic per-block helpers - gnx_xo_gamete, gnx_half_new - take two
+// atomic round trips per block, 2 NB = 40 blocks per offspring one after the other: 55 us on the
+// tile step's chain for ~2 000 offspring.)
 __global__ void __launch_bounds__(256)
 k_xo_jobs_req(int n_req, int64_t first, int32_t* __restrict__ grow,
               const int32_t* __restrict__ req_k, const int32_t* __restrict__ off_parent,
@@ -204,18 +208,87 @@ k_xo_jobs_req(int n_req, int64_t first, int32_t* __restrict__ grow,
               const int32_t* __restrict__ bp_off, const int32_t* __restrict__ bp_loci,
               GnxXoJob* __restrict__ jobs, int32_t* __restrict__ n_jobs) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const bool act = q < n_req;
+  const int NB = H.NB;
   const int64_t k = act ? req_k[q] : 0;
-  int32_t row = -1;
+  int32_t row = -1, prow = -1;
+  int key = 0, st = 0;
   if (act) {
     row = free_rows[n_free - 1 - q];
     grow[first + k] = row;
+    prow = grow[off_parent[2 * k]];
+    key = off_keys[2 * k];
+    st = off_start[2 * k];
   }
-  // the local parent's gamete (homologue 0), and empty blocks for the one that
-  // arrives from the neighbour tile
-  gnx_xo_gamete(H, act, row, 0, act ? grow[off_parent[2 * k]] : -1, act ? off_keys[2 * k] : 0,
-                act ? off_start[2 * k] : 0, bp_off, bp_loci, jobs, n_jobs);
-  for (int b = 0; b < H.NB; ++b) gnx_half_new(H, ((int64_t)row * 2 + 1) * H.NB + b, act);
+  // the local parent's gamete (homologue 0): the blocks that hold a switch point are cut, the
+  // others refer to the parent's; empty blocks for the gamete that arrives from the neighbour tile
+  const bool local = act && prow >= 0;
+  const unsigned int all = (NB >= 32) ? ~0u : ((1u << NB) - 1u);
+  unsigned int mixed = all, sel = 0u;
+  if (local && bp_off)
+    gnx_block_masks(bp_loci + bp_off[key], bp_off[key + 1] - bp_off[key], st, NB, H.BW, mixed, sel);
+  mixed &= all;
+  const int nf0 = act ? __popc(mixed) : 0;
+  const int nf = act ? nf0 + NB : 0, nj = local ? nf0 : 0;
+  int xf = nf, xj = nj;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int yf = __shfl_up(xf, d), yj = __shfl_up(xj, d);
+    if (lane >= d) {
+      xf += yf;
+      xj += yj;
+    }
+  }
+  const int tf = __shfl(xf, 63), tj = __shfl(xj, 63);
+  int top = 0, jb = 0;
+  if (lane == 63) {
+    top = tf ? atomicSub(H.top, tf) : 0;
+    jb = tj ? atomicAdd(n_jobs, tj) : 0;
+  }
+  top = __shfl(top, 63);
+  jb = __shfl(jb, 63);
+  if (!act) return;
+  const int pop = top - 1 - (xf - nf);          // my fresh blocks: stack[pop], stack[pop - 1], ...
+  int job = jb + (xj - nj);
+  // everything this thread reads, before it writes anything
+  int32_t pe0[GNX_MAX_NB], pe1[GNX_MAX_NB], fb[2 * GNX_MAX_NB];
+#pragma unroll
+  for (int b = 0; b < GNX_MAX_NB; ++b) {
+    pe0[b] = (local && b < NB) ? H.hmap[((int64_t)prow * 2) * NB + b] : 0;
+    pe1[b] = (local && b < NB) ? H.hmap[((int64_t)prow * 2 + 1) * NB + b] : 0;
+  }
+#pragma unroll
+  for (int r = 0; r < 2 * GNX_MAX_NB; ++r) fb[r] = r < nf ? H.stack[pop - r] : 0;
+  int fr = 0;
+#pragma unroll
+  for (int b = 0; b < GNX_MAX_NB; ++b) {
+    const int64_t lb = ((int64_t)row * 2) * NB + b;
+    if (b >= NB) {
+      // (blocks the layout does not have)
+    } else if ((mixed >> b) & 1u) {
+      int32_t dst = fb[0];
+#pragma unroll
+      for (int r = 1; r < GNX_MAX_NB; ++r) dst = fr == r ? fb[r] : dst;
+      ++fr;
+      H.hmap[lb] = (int32_t)((uint32_t)dst | GNX_OWN);
+      if (local) {
+        GnxXoJob jrec;
+        jrec.ph0 = GNX_BLK(pe0[b]);
+        jrec.ph1 = GNX_BLK(pe1[b]);
+        jrec.dst = dst;
+        jrec.ks = (key * 2 + st) | (b << 24);
+        jobs[job++] = jrec;
+      }
+    } else {
+      const int hsel = (sel >> b) & 1u;
+      const int32_t e = hsel ? pe1[b] : pe0[b];
+      H.hmap[lb] = GNX_BLK(e);
+      if (e < 0) H.hmap[((int64_t)prow * 2 + hsel) * NB + b] = GNX_BLK(e);   // shared from now on
+    }
+  }
+  for (int b = 0; b < NB; ++b)
+    H.hmap[((int64_t)row * 2 + 1) * NB + b] = (int32_t)((uint32_t)H.stack[pop - nf0 - b] | GNX_OWN);
 }
 
 int gnx_l_crossover_requests(gnx_state* h, int64_t first_slot, int64_t n_req) {
