@@ -1108,18 +1108,8 @@ k_xo_jobs_fused(int64_t N, int64_t first, int32_t* __restrict__ grow,
                 int64_t n_free, GnxHalves H, const int32_t* __restrict__ bp_off,
                 const int32_t* __restrict__ bp_loci, int32_t* __restrict__ n_jobs,
                 GnxXoJob* __restrict__ jobs, GnxJobBp* __restrict__ jobs_bp,
-                const int32_t* __restrict__ cnt3, GnxDD* __restrict__ dd, int coop) {
+                const int32_t* __restrict__ cnt3, GnxDD* __restrict__ dd) {
   constexpr int WAVES = TPB / 64;
-  // coop: the tables' traffic goes through LDS.  One thread per offspring reads its parents'
-  // 2 x NB entries and writes its own: every one of those 3 NB 8-byte accesses is a 64-way
-  // scatter over 64 different rows - 64 cache lines per wave-instruction, and the address units,
-  // not HBM, are what the kernel waits for (without its two contended atomics it takes the same
-  // 67 us: profiles/r05_ab_runs.txt).  Here the wave's 64 rows are fetched as what they are -
-  // 64 contiguous stretches of 8 NB bytes, NB wave-loads whose lanes walk along the rows - into
-  // LDS (rows padded to 2 NB + 1 words: conflict-free either way), every thread takes its row
-  // from there, and the children's rows leave the same way.
-  constexpr int RW = 2 * NB + 1;
-  __shared__ int32_t tab_s[WAVES][64 * RW];
   if (dd) {
     N = (int64_t)dd->N + dd->B;
     first = dd->N;
@@ -1273,14 +1263,10 @@ k_xo_jobs_fused(int64_t N, int64_t first, int32_t* __restrict__ grow,
       tf += wsum[1][w];
       tj += wsum[2][w];
     }
-#ifdef GNX_JF_TIMING_HACK
-    // (timing experiment only - wrong results: what the two contended words cost)
-    s_pop = (1 << 22) + (int)blockIdx.x * TPB * 8;
-    s_job = (int)blockIdx.x * TPB * 4;
-#else
+    // (without these two contended words - a timing experiment with wrong results - the kernel
+    // takes the same time: profiles/r05_ab_runs.txt)
     s_pop = tf ? atomicSub(H.top, tf) : 0;
     s_job = tj ? atomicAdd(n_jobs, tj) : 0;
-#endif
   }
   __syncthreads();
   if (dd && tid == 0) {
@@ -1289,15 +1275,7 @@ k_xo_jobs_fused(int64_t N, int64_t first, int32_t* __restrict__ grow,
     for (int w = 0; w < WAVES; ++w) tf += wsum[1][w];
     if (s_pop < tf) dd->err |= GNX_DD_ERR_BLOCKS;
   }
-  if (!coop && !fx) return;
-  int32_t* mytab = tab_s[wave];
-  if (!fx) {
-    // (a slot without a surviving offspring stays for the wave's cooperative table traffic only:
-    // it cuts nothing, pops nothing - its workgroup's stretch of the stack may be EMPTY - and
-    // writes nothing)
-    mixed[0] = mixed[1] = 0u;
-    sel[0] = sel[1] = 0u;
-  }
+  if (!fx) return;
   // stack index of my first fresh block (dd: never below what this thread walks down)
   const int pop = dd ? max(s_pop - 1 - of, cf) : s_pop - 1 - of;
   const int job = s_job + oj;
@@ -1306,40 +1284,14 @@ k_xo_jobs_fused(int64_t N, int64_t first, int32_t* __restrict__ grow,
   // (2 NB)^2 select chain - PMC: 4 300 vector instructions per wave at NB = 14; one load per
   // block inside stage 7 put a memory round trip into each of its 2 NB iterations.)
   int32_t pe[2][2 * NB];                           // [parent][hom * NB + q]
-  if (coop) {
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      int2 v[NB];
+  for (int p = 0; p < 2; ++p) {
+    const int2* src = (const int2*)(H.hmap + (int64_t)max(prow[p], 0) * 2 * NB);
 #pragma unroll
-      for (int it = 0; it < NB; ++it) {            // 64 rows x NB 8-byte pieces, lanes along the rows
-        const int flat = it * 64 + lane;
-        const int o = flat / NB, j = flat - o * NB;
-        const int ro = __shfl(prow[p], o);
-        v[it] = make_int2(0, 0);
-        if (ro >= 0) v[it] = ((const int2*)(H.hmap + (int64_t)ro * 2 * NB))[j];
-      }
-#pragma unroll
-      for (int it = 0; it < NB; ++it) {
-        const int flat = it * 64 + lane;
-        const int o = flat / NB, j = flat - o * NB;
-        mytab[o * RW + 2 * j] = v[it].x;
-        mytab[o * RW + 2 * j + 1] = v[it].y;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int k = 0; k < 2 * NB; ++k) pe[p][k] = mytab[lane * RW + k];
-      __syncthreads();
-    }
-  } else {
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int2* src = (const int2*)(H.hmap + (int64_t)max(prow[p], 0) * 2 * NB);
-#pragma unroll
-      for (int q = 0; q < NB; ++q) {
-        const int2 v = src[q];
-        pe[p][2 * q] = v.x;
-        pe[p][2 * q + 1] = v.y;
-      }
+    for (int q = 0; q < NB; ++q) {
+      const int2 v = src[q];
+      pe[p][2 * q] = v.x;
+      pe[p][2 * q + 1] = v.y;
     }
   }
   // (six scalars, not an array: the compiler turns a select chain over an array captured by
@@ -1370,21 +1322,7 @@ k_xo_jobs_fused(int64_t N, int64_t first, int32_t* __restrict__ grow,
       fr += cut ? 1 : 0;
     }
   }
-  if (coop) {
-#pragma unroll
-    for (int k = 0; k < 2 * NB; ++k) mytab[lane * RW + k] = ce[k];
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < NB; ++it) {
-      const int flat = it * 64 + lane;
-      const int o = flat / NB, j = flat - o * NB;
-      const int ro = __shfl(row, o);                 // (-1: no surviving offspring in that slot)
-      if (ro >= 0)
-        ((int2*)(H.hmap + (int64_t)ro * 2 * NB))[j] =
-            make_int2(mytab[o * RW + 2 * j], mytab[o * RW + 2 * j + 1]);
-    }
-    if (!fx) return;
-  } else {
+  {
     int2* dstp = (int2*)(H.hmap + (int64_t)row * 2 * NB);
 #pragma unroll
     for (int q = 0; q < NB; ++q) dstp[q] = make_int2(ce[2 * q], ce[2 * q + 1]);
@@ -1458,8 +1396,6 @@ static void launch_jobs_fused(gnx_state* h, int64_t first_slot, const int32_t* d
   // (device-driven step: first slot and N come from the device, the grid covers what a step's
   // births can take - half the capacity - and the workgroups behind them leave at once)
   const bool ddm = h->dd_active;
-  // (measured: no gain - profiles/r05_ab_runs.txt; the thread-per-row accesses stay the default)
-  static const bool jf_coop = getenv("GNX_JF_COOP") && atoi(getenv("GNX_JF_COOP")) != 0;
   const int nbf = ddm ? (int)(h->cfg.cap_inds / 2 / GNX_JF_TPB + 2)
                       : (int)((N - 1) / GNX_JF_TPB - first_slot / GNX_JF_TPB + 1);
   hipLaunchKernelGGL((k_xo_jobs_fused<NB, GNX_JF_TPB>), dim3(nbf), dim3(GNX_JF_TPB), 0, h->stream, N, first_slot,
@@ -1468,8 +1404,7 @@ static void launch_jobs_fused(gnx_state* h, int64_t first_slot, const int32_t* d
                      gnx_alias_bp(h), gnx_alias_loci(h), h->n_jobs_dev[buf],
                      (GnxXoJob*)h->jobs[buf], (GnxJobBp*)h->jobs_bp[buf],
                      h->jobs_self_scan ? (const int32_t*)(h->blk_cnt + 2 * h->blk_stride)
-                                       : (const int32_t*)nullptr, ddm ? h->dd : (GnxDD*)nullptr,
-                     jf_coop ? 1 : 0);
+                                       : (const int32_t*)nullptr, ddm ? h->dd : (GnxDD*)nullptr);
   h->jobs_inline[buf] = true;
 }
 
@@ -2212,5 +2147,5 @@ int gnx_l_spatial_diff(gnx_state* h, double* mean, double* sd, double* sums) {
 template __global__ void k_xo_jobs_fused<GNX_JF_TRY, GNX_JF_TPB>(
     int64_t, int64_t, int32_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*,
     const uint8_t*, const int32_t*, int64_t, GnxHalves, const int32_t*, const int32_t*, int32_t*,
-    GnxXoJob*, GnxJobBp*, const int32_t*, GnxDD*, int);
+    GnxXoJob*, GnxJobBp*, const int32_t*, GnxDD*);
 #endif
