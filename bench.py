@@ -163,29 +163,43 @@ def setup_genomes(dev, cfg, seed):
     dev.assign_genomes(np.full(L, dev.N, dtype=np.int32))
 
 
-def cpu_baseline(budget_s=20.0):
-    """Oracle ("port": numpy, 1 thread) on a bounded sample of the workload:
-    same densities and genome length, smaller landscape."""
+def _port_state(W, H, N, L, n_traits, n_paths=256):
+    """the numpy oracle's state of a workload: same densities, genome length and traits as the
+    device's (oracle/gnx_step.py), random genomes"""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import gnx_step as S
     import gnx_oracle as O
-    W = H = 256
-    L = 100_000
-    N = int(1_000_000 * (W * H) / (2048 * 2048))
     rng = np.random.RandomState(3)
     lyr0 = smooth_field(W, H, 1) * 0.5 + 0.5
     lyr1 = np.tile(np.linspace(0, 1, W, dtype=np.float32), (H, 1))
-    loci = np.sort(rng.choice(L, 40, replace=False)).reshape(4, 10)
-    traits = [dict(loci=loci[t], alpha=0.1 * np.array([1 - (i % 2) * 2 for i in range(10)], float),
-                   layer=1, phi=0.05, gamma=1.0, univ_adv=False) for t in range(4)]
+    traits = []
+    if n_traits:
+        loci = np.sort(rng.choice(L, n_traits * 10, replace=False)).reshape(n_traits, 10)
+        traits = [dict(loci=loci[t],
+                       alpha=0.1 * np.array([1 - (i % 2) * 2 for i in range(10)], float),
+                       layer=1, phi=0.05, gamma=1.0, univ_adv=False) for t in range(n_traits)]
     W64 = O.words_per_hom(L)
-    paths = sparse_paths(256, L, 5, W64)
+    paths = sparse_paths(n_paths, L, 5, W64)
     st = S.State(np.stack([lyr0, lyr1]),
                  S.Params(mating_radius=10.0, K_factor=N / float(lyr0.sum())),
                  7, L=L, traits=traits, paths_packed=paths)
     st.init_population(N)
     S.step(st, burn=True)
-    st.set_genomes(rng.randint(0, 2 ** 63, (st.N, 2, W64)).astype(np.uint64))
+    g = np.random.default_rng(3).integers(0, 2 ** 64, (st.N, 2, W64), dtype=np.uint64,
+                                          endpoint=False)
+    st.set_genomes(g)
+    return S, st
+
+
+def cpu_baseline(budget_s=20.0, full_scale=True):
+    """Oracle ("port": numpy, 1 thread).  `value`: a bounded sample of the METRIC workload
+    (same densities, genome length and traits, 1/64 of the landscape: the full 10^6 x 10^5 bits
+    are 25 GB of numpy arrays and minutes per step).  BASELINE configs[1] and [2] (C2, C3:
+    10^5 individuals) run at FULL scale, a few steps each (SURVEY 8d ii), as flat fields."""
+    W = H = 256
+    L = 100_000
+    N = int(1_000_000 * (W * H) / (2048 * 2048))
+    S, st = _port_state(W, H, N, L, 4)
     S.step(st, burn=False)                      # warm-up
     t0 = time.time()
     done = 0
@@ -195,9 +209,34 @@ def cpu_baseline(budget_s=20.0):
         S.step(st, burn=False)
         steps += 1
     dt = time.time() - t0
-    return dict(value=done / dt, unit='individual-timesteps/s', cores=1, kind='port',
-                sample='%d steps of a %dx%d tile, N~%d, L=%d, numpy oracle (oracle/gnx_step.py), '
-                       '1 thread of %d host cores' % (steps, W, H, N, L, os.cpu_count()))
+    out = dict(value=done / dt, unit='individual-timesteps/s', cores=1, kind='port',
+               sample='c4_metric at 1/64 of its area: %d steps of a %dx%d landscape, N~%d, L=%d, '
+                      '4 traits, numpy oracle (oracle/gnx_step.py), 1 thread of %d host cores'
+                      % (steps, W, H, N, L, os.cpu_count()))
+    if full_scale:
+        for name, n_steps in (('c2', 3), ('c3', 2)):
+            cfg = WORKLOADS[name]
+            try:
+                t1 = time.time()
+                S, st = _port_state(cfg['W'], cfg['H'], cfg['N'], cfg['L'], cfg['n_traits'])
+                setup = time.time() - t1
+                t1 = time.time()
+                done = 0
+                for _ in range(n_steps):
+                    done += st.N
+                    S.step(st, burn=False)
+                dt = time.time() - t1
+                out['%s_full_value' % name] = done / dt
+                out['%s_full_sample' % name] = (
+                    '%s at FULL scale: %d steps of %dx%d, N~%d, L=%d, %d traits, %.2f s/step '
+                    '(+ %.0f s set-up), numpy oracle, 1 thread' % (
+                        name, n_steps, cfg['W'], cfg['H'], st.N, cfg['L'], cfg['n_traits'],
+                        dt / n_steps, setup))
+                del st
+            except Exception as e:          # the contract line must still be printed
+                out['%s_full_value' % name] = None
+                out['%s_full_sample' % name] = 'failed: %s: %s' % (type(e).__name__, e)
+    return out
 
 
 def model_api_params(cfg, name, T):
@@ -288,7 +327,7 @@ def kernel_profile(dev, do_step, n_steps=10):
     return fam
 
 
-def measure_other_workload(name, steps=30, warmup=5):
+def measure_other_workload(name, steps=30, warmup=5, steady_warm=1500):
     """a short run of another BASELINE configuration on the same box (N = 1): ms/step,
     individual-timesteps/s, the dominant kernel family and its rate"""
     cfg = WORKLOADS[name]
@@ -319,6 +358,26 @@ def measure_other_workload(name, steps=30, warmup=5):
     dt = time.perf_counter() - t1
     tot = dev.totals()               # accumulated inside the library: nothing read per step
     n, births = tot['ind_steps'], tot['births']
+    young = {'ms_per_step': 1e3 * dt / steps, 'value': n / dt, 'mean_N': n / steps,
+             'births_per_step': births / steps,
+             'steps_since_genome_assignment': [warmup + steps + 4 + 1, warmup + 2 * steps + 4]}
+    # ... and the same at the model's STEADY state: offspring land next to their parents, the
+    # population clumps over the first ~1000 steps and the mate search's candidate lists grow
+    # (C2: 14 individuals share the average individual's hash cell at step 1, ~300 at the steady
+    # state) - the figure a long run sees (reference tests/runtime/runtime_test.py:155-164 times
+    # T = 250 steps after the burn-in).
+    done = warmup + 2 * steps + 4
+    if steady_warm > 0:
+        dev.walk(steady_warm, False, True)
+        dev.synchronize()
+        done += steady_warm
+        dev.reset_totals()
+        t1 = time.perf_counter()
+        dev.walk(steps, False, True)
+        dev.synchronize()
+        dt = time.perf_counter() - t1
+        tot = dev.totals()
+        n, births = tot['ind_steps'], tot['births']
     fam = kernel_profile(dev, lambda burn: dev.step(burn, not burn), 10)
     dev.close()
     dom = max(fam, key=lambda k: fam[k]['ms_per_step'])
@@ -329,6 +388,11 @@ def measure_other_workload(name, steps=30, warmup=5):
            'steps': steps, 'warmup': warmup, 'ms_per_step': 1e3 * dt / steps,
            'value': n / dt, 'unit': 'individual-timesteps/s', 'mean_N': n / steps,
            'births_per_step': births / steps, 'setup_s': round(setup, 1),
+           # ms_per_step / value above: the STEADY state (timed steps start this many steps
+           # after the genomes were assigned); `young`: the first steps after a uniform start
+           'state': ('steady' if steady_warm > 0 else 'young'),
+           'steps_since_genome_assignment': [done + 1, done + steps],
+           'young': young,
            'dominant_kernel': dom, 'dominant_ms_per_step': fam[dom]['ms_per_step'],
            'dominant_GBps': fam[dom]['GBps'], 'dominant_frac': fam[dom]['GBps'] / 8000.0,
            'bytes_per_step': sum(v['bytes_per_step'] for v in fam.values()),
@@ -404,6 +468,9 @@ def main():
     ap.add_argument('--workload', default=None, choices=sorted(WORKLOADS))
     ap.add_argument('--scaling', default='c5', choices=['c5', 'weak2048'],
                     help='N > 1: tiles of BASELINE C5 (default) or 2048x2048 metric tiles')
+    ap.add_argument('--steady-warmup', type=int, default=1500,
+                    help='N = 1: steps walked before the second, steady-state measurement '
+                         '(c4_metric_steady in the line; 0 = skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-model-api', action='store_true',
                     help='skip the second measurement through Model.walk (N = 1 only)')
@@ -521,6 +588,7 @@ def main():
     ind_steps = 0
     births = 0
     xo_births = 0
+    gc_before = dev.genome_info()['gc_runs']
     if stepper is None:
         # one C call per step and nothing else: N at the start of every step, births and the
         # births that got a genome are summed inside the library (gnx_totals) and read once,
@@ -544,6 +612,7 @@ def main():
         tot = dev.totals()
         ind_steps, births, xo_births = tot['ind_steps'], tot['births'], tot['xo_births']
     barrier()
+    gc_in_timed = dev.genome_info()['gc_runs'] - gc_before
     kt = dev.kernel_times()
     dev.profiling(False)
 
@@ -588,8 +657,29 @@ def main():
         alt = other_mode(1, 'crossover (8 workgroups per CU) beside the whole next step: nothing waits '
                              'for it but the next crossover')
     fam = None
+    steady = None
     if stepper is None:
         fam = kernel_profile(dev, do_step, 10)
+        if args.steady_warmup > 0:
+            # the metric workload at ITS steady state: the conductance surface piles the
+            # population onto ridges and offspring land beside their parents, the population
+            # grows from N0 to ~1.33 N0 and the mate search's candidate lists lengthen over the
+            # first ~1000 steps.  Same call as the timed region (gnx_walk), after a long walk.
+            dev.walk(args.steady_warmup, False, True)
+            dev.synchronize()
+            dev.reset_totals()
+            gc0 = dev.genome_info()['gc_runs']
+            ts = time.perf_counter()
+            dev.walk(args.steps, False, True)
+            dev.synchronize()
+            dts = time.perf_counter() - ts
+            tot_s = dev.totals()
+            steady = {'ms_per_step': 1e3 * dts / args.steps, 'value': tot_s['ind_steps'] / dts,
+                      'unit': 'individual-timesteps/s', 'steps': args.steps,
+                      'mean_N': tot_s['ind_steps'] / args.steps,
+                      'births_per_step': tot_s['births'] / args.steps,
+                      'warmup_steps_before': args.steady_warmup,
+                      'gc_runs_in_timed_region': dev.genome_info()['gc_runs'] - gc0}
     phases = None
     if stepper is not None and not os.environ.get('GNX_BENCH_NO_PHASES'):
         # per-phase host wall time of the tile protocol, from a few extra steps with a
@@ -601,6 +691,25 @@ def main():
             do_step(False)
         phases = {k: 1e3 * v / n_prof for k, v in stepper.phase_s.items()}
         stepper.profile = False
+
+    # what the library's communicator says about itself on EVERY rank (gnx_comm_info: ncclCommCount,
+    # ncclCommUserRank, ncclCommCuDevice, the handle's HIP device, host ms per phase of the
+    # tile step): the line certifies the ranks it ran on
+    comm_infos = None
+    if stepper is not None and stepper.v3:
+        mine_info = dev.comm_info()
+        mine_info['local_rank'] = local_rank
+        mine_info['pid'] = os.getpid()
+        if dist is not None:
+            comm_infos = [None] * world
+            dist.all_gather_object(comm_infos, mine_info)
+        else:
+            comm_infos = [mine_info]
+        if world > 1 and backend == 'nccl' and not single_dev:
+            for r_, ci in enumerate(comm_infos):
+                assert ci['transport'] == 'rccl' and ci['nccl_comm_count'] == world and \
+                    ci['nccl_comm_user_rank'] == r_, 'rank %d: not an RCCL rank of %d: %s' % (r_, world, ci)
+            assert len({ci['nccl_comm_device'] for ci in comm_infos}) == world, comm_infos
 
     if rank == 0:
         xo = kt['crossover']
@@ -702,7 +811,14 @@ def main():
             # (GNX_BENCH_PROFILE_ALL=1 times every kernel family, with more event overhead)
             'kernel_ms_per_step': {k: v['ms'] / args.steps for k, v in kt.items()
                                    if v['launches'] > 0},
+            # the collector of the shared genome blocks fires every 15-20 steps: a short timed
+            # region holds zero or one run of it
+            'gc_runs_in_timed_region': gc_in_timed,
+            'steps_since_genome_assignment': [args.warmup + (2 if stepper is None else 0) + 1,
+                                              args.warmup + (2 if stepper is None else 0) + args.steps],
         }
+        if steady is not None:
+            out['c4_metric_steady' if args.workload == 'c4_metric' else 'steady'] = steady
         if fam is not None:
             # the whole step against the roofline: every kernel family's algorithmic bytes
             # (the crossover's as moved) over the timed region's ms per step
@@ -746,6 +862,23 @@ def main():
                     'frac': (xo['bytes'] / max(xo['launches'], 1) + beside) / (lms * 1e-3) / 1e9 / peak}
         if phases is not None:
             out['tile_phase_ms_per_step'] = phases
+        if comm_infos is not None:
+            out['config']['rccl'] = {
+                'certified': bool(world > 1 and all(ci['transport'] == 'rccl' and
+                                                    ci['nccl_comm_count'] == world
+                                                    for ci in comm_infos)),
+                'nccl_comm_count': [ci['nccl_comm_count'] for ci in comm_infos],
+                'nccl_comm_user_rank': [ci['nccl_comm_user_rank'] for ci in comm_infos],
+                'nccl_comm_device': [ci['nccl_comm_device'] for ci in comm_infos],
+                'hip_device': [ci['hip_device'] for ci in comm_infos],
+                'transport': [ci['transport'] for ci in comm_infos],
+                'tile_steps': [ci['tile_steps'] for ci in comm_infos],
+                'MB_sent_per_step': [round(ci['bytes_sent'] / max(ci['tile_steps'], 1) / 1e6, 3)
+                                     for ci in comm_infos]}
+            # host wall ms per phase of gnx_tile_step, per rank, over ALL the steps the handle
+            # took (burn-in, warm-up and timed): where a rank's step time goes on a real node
+            out['tile_step_host_ms_per_phase'] = [
+                {k: round(v, 4) for k, v in ci['phase_ms_per_step'].items()} for ci in comm_infos]
         if alone is not None:
             out['roofline']['kernel_alone'] = alone
         if alt is not None:
@@ -754,7 +887,12 @@ def main():
             out['cpu_baseline'] = cpu_baseline()
             ref = ref_cpu_number()
             if ref is not None:
-                out['cpu_baseline']['reference'] = ref
+                # flat, small fields (a parser that keeps scalars only keeps them)
+                out['cpu_baseline']['reference_value'] = ref.get('value')
+                out['cpu_baseline']['reference_sample'] = (
+                    '%s; 1 core of %s (%s); measured in the build container by '
+                    'tools/ref_cpu_baseline.py - the reference never reaches the GPU box' % (
+                        ref.get('sample'), ref.get('host_cores'), ref.get('cpu')))
         model_api = None
         if world == 1 and not args.no_model_api:
             # the same workload through the drop-in API, at the model's own equilibrium.  Run
@@ -779,7 +917,9 @@ def main():
                 try:
                     # (the small ones run 0.2 ms a step: 200 steps, or the figure is the box's jitter)
                     out['other_workloads'][name] = measure_other_workload(
-                        name, steps=30 if name == 'c4_dense' else 200, warmup=5 if name == 'c4_dense' else 20)
+                        name, steps=30 if name == 'c4_dense' else 200,
+                        warmup=5 if name == 'c4_dense' else 20,
+                        steady_warm=300 if name == 'c4_dense' else 1500)
                 except Exception as e:
                     out['other_workloads'][name] = {'error': '%s: %s' % (type(e).__name__, e)}
         if model_api is not None:
@@ -787,9 +927,16 @@ def main():
         # last in the line (a reader that keeps only the tail of stdout still sees them)
         if 'other_workloads' in out:
             out['summary'] = {k: ({'ms_per_step': round(v['ms_per_step'], 4), 'value': v['value'],
+                                   'state': v.get('state'),
+                                   'ms_per_step_young': round(v['young']['ms_per_step'], 4),
                                    'step_frac': round(v['step_frac'], 4)}
                                   if 'ms_per_step' in v else v)
                               for k, v in out['other_workloads'].items()}
+            if 'c4_metric_steady' in out:
+                out['summary']['c4_metric_steady'] = {
+                    'ms_per_step': round(out['c4_metric_steady']['ms_per_step'], 4),
+                    'value': out['c4_metric_steady']['value'],
+                    'mean_N': out['c4_metric_steady']['mean_N']}
             out['summary']['c4_metric'] = {'ms_per_step': round(out['ms_per_step'], 4),
                                            'value': out['value'],
                                            'step_frac': (round(out['roofline']['step']['frac'], 4)

@@ -59,7 +59,7 @@ EXPORTS = [
     'gnx_tile2_finish_births', 'gnx_tile2_die', 'gnx_tile_pair_ptrs_nosync',
     'gnx_tile_step_begin', 'gnx_tile_step_births', 'gnx_tile_step_end', 'gnx_comm_probe',
     'gnx_tile2_pairs_mode', 'gnx_tile2_pairs_settle', 'gnx_tile2_settle_births',
-    'gnx_tile2_vt_counts', 'gnx_tile2_vt_bases',
+    'gnx_tile2_vt_counts', 'gnx_tile2_vt_bases', 'gnx_tile_step_abort', 'gnx_comm_info',
 ]
 
 
@@ -356,6 +356,26 @@ class Device:
     @property
     def comm_bytes_sent(self):
         return int(self.lib.gnx_comm_bytes_sent(self.h))
+
+    def comm_info(self):
+        """what the handle's tile communicator says about itself (gnx_comm_info): transport, rank,
+        world, ncclCommCount / UserRank / CuDevice, device ordinal, steps, per-phase host ms per step"""
+        out = np.zeros(16, np.int64)
+        self._chk(self.lib.gnx_comm_info(self.h, _ptr(out, C.c_int64)))
+        steps = max(int(out[7]), 1)
+        names = ('route_and_count_exchange', 'migrant_ghost_exchange_import',
+                 'sort_pairs_second_count_exchange', 'births_gamete_service',
+                 'allreduce_deaths')
+        return {'transport': ('single', 'rccl', 'local')[int(out[0])], 'rank': int(out[1]),
+                'world': int(out[2]), 'nccl_comm_count': int(out[3]),
+                'nccl_comm_user_rank': int(out[4]), 'nccl_comm_device': int(out[5]),
+                'hip_device': int(out[6]), 'tile_steps': int(out[7]),
+                'phase_ms_per_step': {n: float(out[8 + k]) / 1e3 / steps
+                                      for k, n in enumerate(names)},
+                'bytes_sent': int(out[13]), 'gc_runs': int(out[14])}
+
+    def tile_step_abort(self):
+        self._chk(self.lib.gnx_tile_step_abort(self.h))
 
     def tile_step(self, burn, with_selection, exact=True):
         """one time step of this tile and, through its communicator, of the whole tiled

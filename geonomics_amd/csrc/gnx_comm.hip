@@ -45,6 +45,9 @@ struct Rccl {
   decltype(&ncclRecv) Recv = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;
+  decltype(&ncclCommUserRank) CommUserRank = nullptr;
+  decltype(&ncclCommCuDevice) CommCuDevice = nullptr;
 };
 Rccl g_rccl;
 std::mutex g_rccl_mu;
@@ -69,7 +72,7 @@ int rccl_load() {
   }
   GNX_SYM(GetUniqueId) GNX_SYM(CommInitRank) GNX_SYM(CommDestroy) GNX_SYM(GetErrorString)
   GNX_SYM(GroupStart) GNX_SYM(GroupEnd) GNX_SYM(Send) GNX_SYM(Recv) GNX_SYM(AllGather)
-  GNX_SYM(AllReduce)
+  GNX_SYM(AllReduce) GNX_SYM(CommCount) GNX_SYM(CommUserRank) GNX_SYM(CommCuDevice)
 #undef GNX_SYM
   g_rccl.lib = lib;
   return 0;
@@ -150,6 +153,11 @@ struct Comm {
   int64_t pre = -1;                // global population before the last step's deaths
   int64_t bytes_sent = 0;
   int64_t steps = 0;
+  // host wall time of a tiled step's phases, summed over the steps (gnx_comm_info): [0] age +
+  // movement + routing counts + count exchange (host wait 1), [1] migrant / ghost exchange +
+  // import, [2] cell sort + pairs + second count exchange (host wait 2), [3] births + gamete
+  // service, [4] density all-reduce + death probabilities + mortality (host wait 3)
+  double phase_s[5]{};
   // GNX_COMM_FORCE_RCCL=1 at gnx_comm_init_rccl: a ONE-rank communicator goes through the RCCL
   // calls too (all-gather, all-reduce, sends and receives to itself) instead of the shortcuts
   // - what a one-GPU box can run of them
@@ -157,6 +165,18 @@ struct Comm {
 };
 
 Comm* comm_of(gnx_state* h) { return (Comm*)h->tile_comm; }
+
+// host wall clock of a tiled step's phases (Comm::phase_s)
+struct PhaseClock {
+  Comm* c;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  explicit PhaseClock(Comm* c_) : c(c_) {}
+  void mark(int k) {
+    const auto n = std::chrono::steady_clock::now();
+    c->phase_s[k] += std::chrono::duration<double>(n - t).count();
+    t = n;
+  }
+};
 
 int rb_need(Comm* c, int k, size_t bytes) {
   if (bytes <= c->rcap[k]) return 0;
@@ -501,7 +521,10 @@ extern "C" int gnx_comm_init_rccl(gnx_state* h, const uint8_t* id128, int32_t ra
               "geonomics_amd: rank %d of %d waited %.0f s inside ncclCommInitRank for the other ranks "
               "(GNX_COMM_INIT_TIMEOUT_S); a rank must have failed before it got there. Giving up.\n",
               rank, world, limit);
-      fflush(stderr);
+      // (a library call that ends the process: at least Python's and C's buffered output and
+      // the collectors' open files reach the disk - INTEGRATION.md: exit code 86 = init timeout,
+      // the launcher starts a fresh child process, it never retries in-process)
+      fflush(NULL);
       _exit(86);
     }
     lk.unlock();
@@ -728,10 +751,13 @@ extern "C" int64_t gnx_comm_bytes_sent(gnx_state* h) {
 // [req counts | pair count] behind the 64 virtual-tile counts of h->vt_count: one device vector
 // for the second count exchange
 __global__ void k_tail_assemble(int T, const int32_t* __restrict__ req, int have_req,
-                                const int32_t* __restrict__ P_src, int32_t* __restrict__ dst) {
+                                const int32_t* __restrict__ P_src, int P_host,
+                                int32_t* __restrict__ dst) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k < T) dst[k] = have_req ? req[k] : 0;
-  if (k == T) dst[T] = *P_src;
+  // (P_host >= 0: the host has waited for this tile's pair count - Poisson births - and the
+  // device word may be stale: an empty tile's mate search returns before it writes it)
+  if (k == T) dst[T] = P_host >= 0 ? P_host : *P_src;
 }
 
 // One time step of this tile (gnx_tile_set) and, through the communicator, of the whole
@@ -784,6 +810,7 @@ extern "C" int gnx_tile_step_begin(gnx_state* h, int32_t burn) {
   h->tot[0] += 1;
   h->tot[1] += h->N - h->n_ghost;
   std::vector<int64_t> cnt(2 * T + 4), mats((size_t)w * (2 * T + 4));
+  PhaseClock clk(c);
   // 1. age + movement, the routing's counting pass; everybody's counts in ONE exchange (this
   //    tile's own among them: the wait for them is the exchange's), then the pass that fills the
   //    staging buffers and ONE batch of sends: migrants and ghosts
@@ -792,6 +819,7 @@ extern "C" int gnx_tile_step_begin(gnx_state* h, int32_t burn) {
   if (w > 1) {
     GNXCHK(host_allgather(h, nullptr, 2 * T, mats.data(), (const int32_t*)d_cnt, 2 * T));
     for (int k = 0; k < 2 * T; ++k) cnt[k] = mats[(size_t)me * 2 * T + k];
+    clk.mark(0);
     GNXCHK(gnx_tile2_route_finish(h, cnt.data()));
     std::vector<int64_t> m_mig((size_t)w * w), m_gh((size_t)w * w);
     for (int s = 0; s < w; ++s)
@@ -816,6 +844,9 @@ extern "C" int gnx_tile_step_begin(gnx_state* h, int32_t burn) {
     }
     GNXCHK(gnx_tile2_import(h, in_mig, c->rbuf[RB_MIG_REC], nt ? c->rbuf[RB_MIG_Z] : nullptr,
                             geno ? c->rbuf[RB_MIG_GENO] : nullptr, in_gh, c->rbuf[RB_GHOST]));
+    clk.mark(1);
+  } else {
+    clk.mark(0);
   }
   // 2. pairs; the gamete-request counts, the virtual tiles' birth counts and - a fixed number of
   //    births per pair - the pair count itself stay on the device and travel with ONE count
@@ -839,7 +870,7 @@ extern "C" int gnx_tile_step_begin(gnx_state* h, int32_t burn) {
     const bool have_req = h->n_req_known == -2;
     hipLaunchKernelGGL(k_tail_assemble, dim3((T + 64) / 64), dim3(64), 0, h->stream, T,
                        (const int32_t*)d_req, have_req ? 1 : 0, (const int32_t*)h->cnt_dev,
-                       h->vt_count + 64);
+                       nowait ? -1 : (int)P, h->vt_count + 64);
     const int cs = 1 + 64 + T + 1;
     std::vector<int64_t> g2((size_t)w * cs);
     const int64_t mine_b = B;
@@ -871,6 +902,7 @@ extern "C" int gnx_tile_step_begin(gnx_state* h, int32_t burn) {
                        h->vt_base);
     HIPCHK(hipGetLastError());
   }
+  clk.mark(2);
   void* p_req = nullptr;
   const int64_t id_base = h->max_id + 1;        // (the global maximum: every rank keeps it)
   GNXCHK(gnx_tile2_offspring(h, burn, id_base, nullptr, &p_req));
@@ -894,6 +926,7 @@ extern "C" int gnx_tile_step_begin(gnx_state* h, int32_t burn) {
   // the offspring that took a remote gamete: their alleles at the selected loci and their
   // phenotype from their finished rows (everybody else's came with the births)
   GNXCHK(gnx_tile2_settle_births(h, burn));
+  clk.mark(3);
   c->mid = true;
   c->mid_pairs = total_pairs;
   c->mid_births = total_births;
@@ -921,6 +954,7 @@ extern "C" int gnx_tile_step_end(gnx_state* h, int32_t burn, int32_t with_select
   }
   c->mid = false;
   const int w = c->world;
+  PhaseClock clk(c);
   void* red = nullptr;
   int64_t n_words = 0;
   GNXCHK(gnx_tile2_finish_births(h, burn, &red, &n_words));
@@ -934,6 +968,7 @@ extern "C" int gnx_tile_step_end(gnx_state* h, int32_t burn, int32_t with_select
   if (!burn) h->tot[4] += h->last_xo_births;
   h->step += 1;
   c->steps += 1;
+  clk.mark(4);
   if (exact) {
     int64_t mine[3];
     GNXCHK(gnx_counts(h, &mine[0], &mine[1], &mine[2]));
@@ -956,6 +991,48 @@ extern "C" int gnx_tile_step_end(gnx_state* h, int32_t burn, int32_t with_select
   out[1] = b_glob;
   out[2] = d_prev;
   c->pre = n_pre;
+  return 0;
+}
+
+// A step that was begun and cannot be ended on every rank (the host's work on the newborns
+// failed somewhere): the handle leaves the "between _begin and _end" state WITHOUT the density
+// all-reduce and the mortality, so that the ranks can raise together instead of one of them
+// waiting inside the all-reduce for ever.  The population holds this step's offspring and no
+// deaths: the run is over, the handle can still be read and freed.
+extern "C" int gnx_tile_step_abort(gnx_state* h) {
+  Comm* c = comm_of(h);
+  if (c) c->mid = false;
+  return 0;
+}
+
+// What the communicator says about itself - for a bench line that certifies what it ran on:
+// out[0] transport (0 one rank, no RCCL calls; 1 RCCL; 2 local = handles of one process),
+// [1] rank, [2] world, [3] ncclCommCount, [4] ncclCommUserRank, [5] ncclCommCuDevice (each -1
+// without an RCCL communicator), [6] the HIP device ordinal of the handle, [7] tiled steps taken,
+// [8..12] host wall time of the step's five phases summed over those steps, microseconds
+// (Comm::phase_s), [13] bytes this rank has sent, [14] collections of the genome blocks, [15] 0.
+extern "C" int gnx_comm_info(gnx_state* h, int64_t* out) {
+  for (int k = 0; k < 16; ++k) out[k] = 0;
+  out[3] = out[4] = out[5] = -1;
+  out[6] = h->cfg.device;
+  out[14] = h->gc_runs;
+  Comm* c = comm_of(h);
+  if (!c) return 0;
+  out[0] = c->kind;
+  out[1] = c->rank;
+  out[2] = c->world;
+  if (c->nccl) {
+    int v = -1;
+    NCCLCHK(g_rccl.CommCount(c->nccl, &v));
+    out[3] = v;
+    NCCLCHK(g_rccl.CommUserRank(c->nccl, &v));
+    out[4] = v;
+    NCCLCHK(g_rccl.CommCuDevice(c->nccl, &v));
+    out[5] = v;
+  }
+  out[7] = c->steps;
+  for (int k = 0; k < 5; ++k) out[8 + k] = (int64_t)(c->phase_s[k] * 1e6);
+  out[13] = c->bytes_sent;
   return 0;
 }
 

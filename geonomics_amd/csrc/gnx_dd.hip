@@ -256,9 +256,16 @@ static void dd_consume(gnx_state* h) {
       h->dd_est_seq = want;
     }
     if (r->err) h->dd_err |= r->err;            // (sticky; looked at by dd_check)
-    h->dd_hist.push_back(r->N0);
-    h->dd_hist.push_back(r->B);
-    h->dd_hist.push_back(deaths);
+    // a step that reported an error dropped births or shared genome rows, and every step
+    // enqueued behind it started from that state: none of them enters the walk's history
+    // (gnx_walk_history then ends with the last step that completed cleanly)
+    if (!h->dd_err && !h->dd_hist_closed) {
+      h->dd_hist.push_back(r->N0);
+      h->dd_hist.push_back(r->B);
+      h->dd_hist.push_back(deaths);
+    } else {
+      h->dd_hist_closed = true;
+    }
     h->dd_seen = want;
   }
 }
@@ -379,6 +386,7 @@ int gnx_dd_leave(gnx_state* h) {
   h->xo_running = false;
   for (int k = 0; k < 2; ++k) h->xo_inflight[k] = h->xo_wide_inflight[k] = false;
   h->keys_fresh = false;
+  GNXCHK(gnx_os_hist_discard(h));       // (the device-driven sort counts its own digits: k_keys_hist)
   h->fb_adults = h->fb_pending = false;
   // the last step read fb[fb_cur ^ 1] and cleared fb[fb_cur] and the pairs' bins
   h->fb_zero[h->fb_cur] = true;
@@ -520,6 +528,7 @@ extern "C" int gnx_walk_many(gnx_state** hs, int32_t n, int64_t T, int32_t burn,
   for (int k = 0; k < n; ++k) {
     bool ok = false;
     hs[k]->dd_hist.clear();
+    hs[k]->dd_hist_closed = false;
     const int64_t n0 = hs[k]->N - hs[k]->n_ghost;
     GNXCHK(walk_prepare(hs[k], &left[k], burn != 0, with_selection != 0, &ok));
     if (left[k] < T) {
@@ -554,9 +563,11 @@ extern "C" int gnx_walk_many(gnx_state** hs, int32_t n, int64_t T, int32_t burn,
         hs[k]->eager_move = left[k] > 1;
         rc = gnx_step(hs[k], burn, with_selection);
         hs[k]->eager_move = false;
-        hs[k]->dd_hist.push_back(n0);
-        hs[k]->dd_hist.push_back(hs[k]->last_births);
-        hs[k]->dd_hist.push_back(hs[k]->last_deaths);
+        if (!rc) {                  // (a step that failed half-way is no step of the history)
+          hs[k]->dd_hist.push_back(n0);
+          hs[k]->dd_hist.push_back(hs[k]->last_births);
+          hs[k]->dd_hist.push_back(hs[k]->last_deaths);
+        }
       }
       left[k] -= taken;
       any = any || left[k] > 0;

@@ -522,6 +522,11 @@ struct gnx_state {
   bool ord_inflight = false;     // the index's compaction runs on stream3
   bool keys_ordmode = false;     // k_move wrote cell32, not key64
   bool keys_fresh = false;
+  // k_move also counted the digits of the cells it wrote into the head of os_scratch (the global
+  // counts of the cell sort's passes, gnx_prim.hip): the sort needs no kernel in front of its
+  // passes.  Whoever uses os_scratch otherwise, or drops the keys, clears the counts first
+  // (gnx_os_hist_discard).
+  bool hist_fresh = false;
   // gnx_walk: the next step's movement runs with this step's mortality (gnx_l_move_ahead)
   bool eager_move = false;       // set by gnx_walk for every step but the last
   bool moved_ahead = false;      // the coming step's age + movement are done, cell32 written
@@ -578,6 +583,7 @@ struct gnx_state {
   void* dd_graph[1]{};                 // DDExtra (gnx_dd.hip): captured graphs, events
   int32_t dd_err = 0;                  // sticky GNX_DD_ERR_* the steps have reported
   std::vector<int64_t> dd_hist;        // (N at start, births, deaths) of every step of the last gnx_walk
+  bool dd_hist_closed = false;         // a step of this walk reported an error: no later step is recorded
   // bumped by whatever changes a by-value argument or a pointer of the step's kernels
   // (species parameters, traits, paths, K raster ...): captured graphs are dropped
   uint64_t cfg_epoch = 1;
@@ -761,6 +767,8 @@ void gnx_dd_destroy(gnx_state* h);
 int gnx_block_scan(gnx_state* h, int K, int64_t n_items, const int32_t* cnt, int32_t* off,
                    int32_t* out, int64_t* host, int64_t seq = 0, hipStream_t st = nullptr,
                    const int32_t* extra = nullptr);
+// the digit counts k_move left in os_scratch are not going to be used: the scratch is zero again
+int gnx_os_hist_discard(gnx_state* h, hipStream_t st = nullptr);
 // the step's cell sort over the id-ordered index: Onesweep with one fill (gnx_prim.hip)
 bool gnx_l_lattices_tiled(gnx_state* h, bool have_pairs, const GnxPubWords& pub);
 void gnx_host_mark(int id);                       // GNX_HOST_TIMES=2 (gnx_api.hip)
@@ -774,6 +782,10 @@ size_t gnx_os_words_used(size_t n, int end_bit, int geometry = 0);
 int gnx_os_keys_hist(void* scratch, unsigned int* ticket, int64_t N, int64_t ord_n,
                      const int32_t* ord, const uint32_t* cell32, uint32_t* key, int32_t* val,
                      int end_bit, hipStream_t s, const GnxDD* dd = nullptr, int geometry = 0);
+void gnx_os_digits(int end_bit, int* places, int* rb);
+int gnx_os_sort32_gather(void* scratch, uint32_t* ktmp, int32_t* vtmp, uint32_t* kout, int32_t* vout,
+                         size_t n, int end_bit, const int32_t* ord, int64_t ord_n,
+                         const uint32_t* cell32, hipStream_t s);
 int gnx_os_sort32_ranked(void* scratch, uint32_t* ktmp, int32_t* vtmp, const uint32_t* kin,
                          uint32_t* kout, const int32_t* vin, int32_t* vout, size_t n, int end_bit,
                          hipStream_t s, int geometry = 0);

@@ -131,7 +131,12 @@ struct MoveP {
   // the NEXT step's movement, run right after this step's death draws on the uncompacted
   // population (gnx_l_move_ahead): the dead are skipped
   const int32_t* alive;
+  // the cell sort's global digit counts (gnx_prim.hip), counted here when the movement writes
+  // the sort's keys anyway: hist[place * 2^hist_rb + digit of cell32 at that place]
+  uint32_t* hist;
+  int hist_rb, hist_places;
 };
+#define GNX_MOVE_HIST_WORDS 1024      // LDS words of k_move's digit table: 2 places of <= 9 bits
 
 __constant__ float c_queen_dirs[8] = {-2.35619449019234492885f, -1.57079632679489661923f,
                                       -0.78539816339744830962f, 3.14159265358979323846f,
@@ -291,6 +296,11 @@ k_move(MoveP P, GnxSoA s, const float* rast, const float* inj_theta, const float
        float* out_theta, float* out_dist) {
   extern __shared__ float surf_tile[];       // P.tile_floats floats
   __shared__ int surf_box[4];
+  __shared__ uint32_t mhist[GNX_MOVE_HIST_WORDS];
+  if (P.hist) {                              // (block-uniform; the conductance tile's barriers publish it)
+    for (int q = threadIdx.x; q < P.hist_places << P.hist_rb; q += 256) mhist[q] = 0u;
+    __syncthreads();
+  }
   P.N = gnx_dd_n(P.dd, P.N);
   P.step = gnx_dd_step(P.dd, P.step);
   const int64_t base = (int64_t)blockIdx.x * (256 * IPT) + threadIdx.x;
@@ -390,13 +400,45 @@ k_move(MoveP P, GnxSoA s, const float* rast, const float* inj_theta, const float
       const int hx = min(P.ncx - 1, (int)((double)nx[u] * P.inv_cs));
       const int hy = min(P.ncy - 1, (int)((double)ny[u] * P.inv_cs));
       if (P.cell32) {               // the sort runs over the id-ordered index: the cell is all it needs
-        P.cell32[k] = (uint32_t)(hy * P.ncx + hx);
+        const uint32_t cell = (uint32_t)(hy * P.ncx + hx);
+        P.cell32[k] = cell;
+        if (P.hist) {
+          // (slots are nearly in cell order: a wave's lanes mostly hit one or two counters of the
+          // high place - a few serialised LDS atomics against ~1 200 vector instructions)
+          const uint32_t dm = (1u << P.hist_rb) - 1u;
+          for (int pl = 0; pl < P.hist_places; ++pl)
+            atomicAdd(&mhist[(pl << P.hist_rb) + ((cell >> (pl * P.hist_rb)) & dm)], 1u);
+        }
       } else {
         P.key[k] = ((uint64_t)(hy * P.ncx + hx) << P.idbits) | (uint64_t)id[u];
         P.idx[k] = (int32_t)k;
       }
     }
   }
+  if (P.hist) {
+    __syncthreads();
+    for (int q = threadIdx.x; q < P.hist_places << P.hist_rb; q += 256) {
+      const uint32_t v = mhist[q];
+      if (v) atomicAdd(&P.hist[q], v);
+    }
+  }
+}
+
+// the digit counts k_move left at the head of os_scratch will not be used (another sort path, a
+// second movement, the device-driven step): that stretch is zero again
+int gnx_os_hist_discard(gnx_state* h, hipStream_t st) {
+  if (!h->hist_fresh) return 0;
+  h->hist_fresh = false;
+  HIPCHK(hipMemsetAsync(h->os_scratch, 0, GNX_MOVE_HIST_WORDS * sizeof(uint32_t), st ? st : h->stream));
+  return 0;
+}
+
+// k_move counts the sort's digits when the keys fit its LDS table (2 places of <= 9 bits: up to
+// 2^18 hash cells - GNX_OS_MOVE_HIST=0: never)
+static bool gnx_move_hist(const gnx_state* h, int* places, int* rb) {
+  static const bool on = !(getenv("GNX_OS_MOVE_HIST") && atoi(getenv("GNX_OS_MOVE_HIST")) == 0);
+  gnx_os_digits(h->key_bits, places, rb);
+  return on && h->os_scratch != nullptr && (*places << *rb) <= GNX_MOVE_HIST_WORDS;
 }
 
 int gnx_l_move(gnx_state* h, bool inc_age, const float* inj_theta, const float* inj_dist,
@@ -444,6 +486,13 @@ int gnx_l_move(gnx_state* h, bool inc_age, const float* inj_theta, const float* 
   P.ncx = h->ncx;
   P.ncy = h->ncy;
   P.idbits = gnx_id_bits(h);
+  GNXCHK(gnx_os_hist_discard(h));          // (a movement whose keys nobody sorted)
+  P.hist = nullptr;
+  P.hist_rb = P.hist_places = 0;
+  if (ordm && !ddm && gnx_move_hist(h, &P.hist_places, &P.hist_rb)) {
+    P.hist = (uint32_t*)h->os_scratch;
+    h->hist_fresh = true;
+  }
   h->keys_fresh = with_keys;
   if (with_keys) h->keys_ordmode = ordm;
   // LDS window of the conductance raster per workgroup (GNX_MOVE_TILE floats): smaller
@@ -520,6 +569,15 @@ int gnx_l_move_ahead(gnx_state* h, int64_t N_all, const int32_t* d_alive, hipStr
   P.ncx = h->ncx;
   P.ncy = h->ncy;
   P.idbits = 0;
+  // (the digit counts of the coming step's cell sort: the dead are skipped, so the counts are
+  // those of the population that sort will see; os_scratch was wiped by this step's k_permute)
+  GNXCHK(gnx_os_hist_discard(h, st));
+  P.hist = nullptr;
+  P.hist_rb = P.hist_places = 0;
+  if (gnx_move_hist(h, &P.hist_places, &P.hist_rb)) {
+    P.hist = (uint32_t*)h->os_scratch;
+    h->hist_fresh = true;
+  }
   static const int tile_env = getenv("GNX_MOVE_TILE") ? atoi(getenv("GNX_MOVE_TILE")) : 2048;
   P.tile_floats = sp.move_surf != GNX_SURF_NONE ? std::max(256, std::min(tile_env * 2, 12288)) : 0;
   hipLaunchKernelGGL(k_move<2>, dim3(gnx_grid(N_all, 512)), dim3(256),
@@ -765,7 +823,17 @@ int gnx_l_sort_by_cell(gnx_state* h, bool split_rest) {
     }
     static const int os_variant = getenv("GNX_OS_SORT") ? atoi(getenv("GNX_OS_SORT")) : 2;
     static const bool os_fused = !getenv("GNX_OS_FUSED") || atoi(getenv("GNX_OS_FUSED")) != 0;
-    if (os_variant == 2 && os_fused && h->key_bits <= 24) {
+    static const bool os_gather = !(getenv("GNX_OS_GATHER") && atoi(getenv("GNX_OS_GATHER")) == 0);
+    if (h->keys_fresh && h->hist_fresh && os_gather && os_variant == 2 && os_fused) {
+      // k_move wrote the cells AND counted their digits: the passes alone, the first one
+      // gathering its keys through the id-ordered index
+      h->hist_fresh = false;
+      GNXCHK(gnx_os_sort32_gather(h->os_scratch, h->os_ktmp, h->os_vtmp, h->keyk[1], h->valk[1],
+                                  (size_t)N, h->key_bits, h->ord[h->ord_cur], h->ord_n, h->cell32,
+                                  h->stream));
+      wipe_words = (int64_t)gnx_os_words_used((size_t)N, h->key_bits);
+    } else if (os_variant == 2 && os_fused && h->key_bits <= 24) {
+      GNXCHK(gnx_os_hist_discard(h));
       // keys, histograms and their scans in one launch, then the two or three passes; the
       // scratch is zero on entry (allocation, k_permute below)
       GNXCHK(gnx_os_keys_hist(h->os_scratch, h->tickets + 3, N, h->ord_n, h->ord[h->ord_cur],
@@ -774,6 +842,7 @@ int gnx_l_sort_by_cell(gnx_state* h, bool split_rest) {
                                   h->valk[0], h->valk[1], (size_t)N, h->key_bits, h->stream));
       wipe_words = (int64_t)gnx_os_words_used((size_t)N, h->key_bits);
     } else {
+    GNXCHK(gnx_os_hist_discard(h));
     hipLaunchKernelGGL(k_keys_ord, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, h->ord_n,
                        h->ord[h->ord_cur], h->cell32, h->keyk[0], h->valk[0]);
     if (os_variant >= 0 && h->key_bits <= 24) {
@@ -786,6 +855,7 @@ int gnx_l_sort_by_cell(gnx_state* h, bool split_rest) {
     }
     }
   } else {
+    GNXCHK(gnx_os_hist_discard(h));
     int cell_bits = h->key_bits;
     if (h->tile_evict > 0) {
       // (one more cell value: the emigrants')

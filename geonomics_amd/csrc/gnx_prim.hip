@@ -114,83 +114,347 @@ int gnx_prim_sort32_bits(void* tmp, size_t bytes, const uint32_t* kin, uint32_t*
 }
 
 // ---------------------------------------------------------------- the step's cell sort
-// Stable LSD radix sort of (32-bit key, 32-bit value) pairs by the low `end_bit` key bits,
-// built from rocPRIM's Onesweep device functions (histogram of every digit place in one pass
-// over the keys, one decoupled-look-back pass per place) but launched here: rocPRIM's own
-// driver clears its histogram, its look-back states and its block counter with a fill
-// kernel each per place - six fills and four kernels for the two places of the step's
-// 16-bit cell keys; here the scratch of all places is one contiguous region cleared by ONE
-// fill (5 launches instead of 10; at 10^5 individuals the launches are the sort).
-// (built on rocprim::detail: the Onesweep device functions and their scratch layout are not a
-// public interface - checked against the rocPRIM of ROCm 7.x; another major version has to be
-// looked at before this compiles)
-#include <rocprim/rocprim_version.hpp>
-#define GNX_ROCPRIM_MAJOR 4
-static_assert(ROCPRIM_VERSION_MAJOR == GNX_ROCPRIM_MAJOR,
-              "gnx_prim.hip: rocPRIM major version changed - re-check rocprim::detail::onesweep_* "
-              "(signatures, look-back state, block-id usage) against gnx_os, then bump GNX_ROCPRIM_MAJOR");
+// Stable LSD radix sort of (key, 32-bit value) pairs by the low `end_bit` key bits, hand-written
+// for gfx950 (round 6: rounds 3-5 launched rocPRIM's private Onesweep device functions here).
+// One pass per digit place, each pass ONE kernel (k_pass) in the Onesweep manner:
+//   * a workgroup takes tiles in ticket order (atomic counter), so every tile before its own is
+//     already running or done;
+//   * ranks inside the tile come from wave-wide matching: RB ballots tell a lane which lanes of
+//     its wave hold the same digit (64-wide wavefronts: one ballot is one scalar mask), the
+//     lowest of them bumps the wave's own 16-bit counter table in LDS, no LDS atomics;
+//   * the tile's digit counts are published (status | count in one word per tile and digit) and
+//     the counts of the tiles before it are summed by DECOUPLED LOOK-BACK, four states per round
+//     trip instead of one (the walk is what a pass waits for: ~1 us per dependent L2 read);
+//   * keys and values are put in digit order in LDS first, so a digit's keys leave as one
+//     contiguous run (64-byte runs at 16 keys per digit and tile instead of 4-byte scatters).
+// The scratch (global digit counts of every place | tile counters | look-back states) is ZERO on
+// entry and the caller wipes it afterwards (k_permute does, on the way: no fill kernels on the
+// step's chain).  The global counts come from whoever writes the keys: k_keys_hist here, or - in
+// gnx_step - the movement kernel itself (k_move), in which case the first pass also gathers its
+// keys through the id-ordered index (GATHER) and the sort's front leaves the chain altogether.
 namespace gnx_os {
-using lookback_t = rocprim::detail::onesweep_lookback_state;
-using obid_t = rocprim::detail::ordered_block_id<unsigned int>;
+constexpr uint32_t ST_PART = 1u << 30, ST_INCL = 2u << 30, ST_VAL = (1u << 30) - 1u;
 
-template <unsigned BS, unsigned IPT, unsigned RB>
+__device__ __forceinline__ uint32_t ld_state(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_state(uint32_t* p, uint32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// exclusive scan of one value per thread over the workgroup; wsum: LDS [BS / 64]; *total optional
+template <int BS>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wsum, uint32_t* total) {
+  constexpr int NW = BS / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t y = __shfl_up(x, d);
+    if (lane >= d) x += y;
+  }
+  __syncthreads();                 // (wsum may still be read from an earlier scan)
+  if (lane == 63) wsum[wave] = x;
+  __syncthreads();
+  uint32_t woff = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    const uint32_t s = wsum[w];
+    woff += w < wave ? s : 0u;
+    tot += s;
+  }
+  if (total) *total = tot;
+  return woff + x - v;
+}
+
+template <typename K, int RB, int BS, int IPT>
+struct PassLds {
+  static constexpr int R = 1 << RB, NW = BS / 64, TILE = BS * IPT;
+  static constexpr size_t whist = 0;                                  // u16 [NW][R]
+  static constexpr size_t dofs = whist + (size_t)NW * R * 2;          // u32 [R]
+  static constexpr size_t lstart = dofs + (size_t)R * 4;              // u32 [R]
+  static constexpr size_t skey = (lstart + (size_t)R * 4 + 15) & ~(size_t)15;   // K [TILE]
+  static constexpr size_t sval = skey + (size_t)TILE * sizeof(K);     // i32 [TILE]
+  static constexpr size_t wsum = sval + (size_t)TILE * 4;             // u32 [NW]
+  static constexpr size_t bid = wsum + (size_t)NW * 4;                // u32
+  static constexpr size_t bytes = bid + 16;
+};
+
+// One pass.  kin / vin: the pairs in the order the place before left them (GATHER: key k is
+// cell32[k < ord_n ? ord[k] : k] and value k - the id-ordered index of gnx_internal.h); ghist
+// [R]: how many keys carry each digit of this place (raw counts); state [tiles][R], counter:
+// zero on entry.
+template <typename K, int RB, int BS, int IPT, bool GATHER>
 __global__ void __launch_bounds__(BS)
-k_hist(const uint32_t* keys, unsigned int* offs, unsigned int size, unsigned int full_blocks,
-       unsigned int begin_bit, unsigned int end_bit) {
-  rocprim::detail::onesweep_histograms<BS, IPT, RB, false>(keys, offs, size, full_blocks,
-                                                          rocprim::identity_decomposer{}, begin_bit,
-                                                          end_bit);
+k_pass(const K* __restrict__ kin, K* __restrict__ kout, const int32_t* __restrict__ vin,
+       int32_t* __restrict__ vout, unsigned int n, const uint32_t* __restrict__ ghist,
+       uint32_t* __restrict__ state, uint32_t* __restrict__ counter, int shift,
+       const int32_t* __restrict__ ord, long long ord_n, const uint32_t* __restrict__ cell32) {
+  using L = PassLds<K, RB, BS, IPT>;
+  constexpr int R = L::R, NW = L::NW, TILE = L::TILE;
+  constexpr int PER = R > BS ? R / BS : 1;          // digits a thread owns (consecutive)
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  uint16_t* whist = (uint16_t*)(lds + L::whist);
+  uint32_t* dofs = (uint32_t*)(lds + L::dofs);
+  uint32_t* lstart = (uint32_t*)(lds + L::lstart);
+  K* skey = (K*)(lds + L::skey);
+  int32_t* sval = (int32_t*)(lds + L::sval);
+  uint32_t* wsum = (uint32_t*)(lds + L::wsum);
+  uint32_t* s_bid = (uint32_t*)(lds + L::bid);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) *s_bid = atomicAdd(counter, 1u);
+  for (int q = tid; q < NW * R / 2; q += BS) ((uint32_t*)whist)[q] = 0u;
+  // where each digit's keys start in the output: exclusive scan of the global counts (every
+  // workgroup works it out for itself - R words from L2 - instead of a scan kernel on the chain)
+  const int d0 = tid * PER;
+  uint32_t gex[PER];
+  {
+    uint32_t g[PER], sum = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      g[j] = (d0 + j < R) ? ghist[d0 + j] : 0u;
+      sum += g[j];
+    }
+    uint32_t run = block_excl_scan<BS>(sum, wsum, nullptr);      // (its barriers also publish s_bid and whist)
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      gex[j] = run;
+      run += g[j];
+    }
+  }
+  const unsigned int bid = *s_bid;
+  const unsigned int base = bid * (unsigned int)TILE;
+  const unsigned int nvalid = n - base < (unsigned int)TILE ? n - base : (unsigned int)TILE;
+  // ---- load: wave w takes the tile's keys [w * 64 * IPT, (w + 1) * 64 * IPT), item r of lane l
+  // is key r * 64 + l of that stretch (coalesced; memory order = (wave, item, lane))
+  K key[IPT];
+  int32_t val[IPT];
+  const unsigned int wbase = (unsigned int)wave * 64u * IPT + (unsigned int)lane;
+  if (GATHER) {
+    int32_t slot[IPT];
+#pragma unroll
+    for (int r = 0; r < IPT; ++r) {
+      const unsigned int q = wbase + r * 64u;
+      const long long k = (long long)base + q;
+      slot[r] = q < nvalid ? (k < ord_n ? ord[k] : (int32_t)k) : -1;
+      val[r] = (int32_t)k;
+    }
+#pragma unroll
+    for (int r = 0; r < IPT; ++r) key[r] = slot[r] >= 0 ? (K)cell32[slot[r]] : (K)0;
+  } else {
+#pragma unroll
+    for (int r = 0; r < IPT; ++r) {
+      const unsigned int q = wbase + r * 64u;
+      key[r] = q < nvalid ? kin[base + q] : (K)0;
+      val[r] = q < nvalid ? vin[base + q] : 0;
+    }
+  }
+  // ---- rank inside the wave, item by item (stable: items in order, lanes in order)
+  uint32_t dig[IPT], rank[IPT];
+  uint16_t* wh = whist + (size_t)wave * R;
+#pragma unroll
+  for (int r = 0; r < IPT; ++r) {
+    const bool valid = wbase + r * 64u < nvalid;
+    const uint32_t d = (uint32_t)(key[r] >> shift) & (uint32_t)(R - 1);
+    dig[r] = d;
+    unsigned long long m = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+      const unsigned long long bb = __ballot((d >> b) & 1u);
+      m &= ((d >> b) & 1u) ? bb : ~bb;
+    }
+    const int leader = __ffsll((long long)m) - 1;
+    const uint32_t below = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    uint32_t old = 0;
+    if (valid && lane == leader) {
+      old = wh[d];
+      wh[d] = (uint16_t)(old + (uint32_t)__popcll(m));
+    }
+    old = __shfl(old, leader < 0 ? 0 : leader);
+    rank[r] = old + below;
+  }
+  __syncthreads();
+  // ---- the tile's count of every digit; the waves' counters become their exclusive offsets
+  uint32_t tot[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    uint32_t acc = 0;
+    if (d0 + j < R) {
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const uint32_t c = whist[(size_t)w * R + d0 + j];
+        whist[(size_t)w * R + d0 + j] = (uint16_t)acc;
+        acc += c;
+      }
+      // published at once: the tiles behind this one wait for nothing else
+      st_state(&state[(size_t)bid * R + d0 + j], (bid == 0 ? ST_INCL : ST_PART) | acc);
+    }
+    tot[j] = acc;
+  }
+  // ---- where each digit starts inside the tile
+  {
+    uint32_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) sum += tot[j];
+    uint32_t run = block_excl_scan<BS>(sum, wsum, nullptr);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      if (d0 + j < R) lstart[d0 + j] = run;
+      run += tot[j];
+    }
+  }
+  __syncthreads();
+  // ---- keys and values in digit order in LDS
+#pragma unroll
+  for (int r = 0; r < IPT; ++r) {
+    if (wbase + r * 64u < nvalid) {
+      const uint32_t lp = lstart[dig[r]] + wh[dig[r]] + rank[r];
+      skey[lp] = key[r];
+      sval[lp] = val[r];
+    }
+  }
+  // ---- decoupled look-back: the counts of the tiles before this one, digit by digit
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    if (d0 + j >= R) continue;
+    const int d = d0 + j;
+    uint32_t prefix = 0;
+    int b = (int)bid - 1;
+    while (b >= 0) {
+      uint32_t v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        v[q] = b - q >= 0 ? ld_state(&state[(size_t)(b - q) * R + d]) : ST_INCL;
+      bool done = false;
+      int used = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (done || used < q) continue;
+        if (v[q] == 0u) continue;                    // not published yet: the round is cut here
+        prefix += v[q] & ST_VAL;
+        used = q + 1;
+        if (v[q] & ST_INCL) done = true;
+      }
+      if (done) break;
+      b -= used;
+      if (used == 0) __builtin_amdgcn_s_sleep(1);
+    }
+    if (bid > 0) st_state(&state[(size_t)bid * R + d], ST_INCL | (prefix + tot[j]));
+    dofs[d] = gex[j] + prefix - lstart[d];
+  }
+  __syncthreads();
+  // ---- out: position l of the tile's digit order goes to (global start of its digit) + (l -
+  // local start of its digit); consecutive l of one digit are consecutive addresses
+#pragma unroll
+  for (int k = 0; k < IPT; ++k) {
+    const unsigned int l = (unsigned int)k * BS + (unsigned int)tid;
+    if (l < nvalid) {
+      const K kk = skey[l];
+      const uint32_t d = (uint32_t)(kk >> shift) & (uint32_t)(R - 1);
+      const uint32_t pos = dofs[d] + l;
+      kout[pos] = kk;
+      vout[pos] = sval[l];
+    }
+  }
 }
 
-template <unsigned BS, unsigned RB>
-__global__ void __launch_bounds__(BS) k_scan(unsigned int* offs) {
-  rocprim::detail::onesweep_scan_histograms<BS, RB>(offs);
+// digit places and bits per place for keys of `end_bit` significant bits: as few places as
+// 11-bit digits allow, the bits spread evenly over them, never fewer than 8 bits per place (the
+// kernels are instantiated for 8 .. 11)
+static void digits(int end_bit, int* places, int* rb) {
+  int p = (end_bit + 10) / 11;
+  if (p < 1) p = 1;
+  int b = (end_bit + p - 1) / p;
+  if (b < 8) b = 8;
+  *places = p;
+  *rb = b;
 }
 
-template <unsigned BS, unsigned IPT, unsigned RB>
-__global__ void __launch_bounds__(BS)
-k_iter(const uint32_t* kin, uint32_t* kout, const int32_t* vin, int32_t* vout, unsigned int size,
-       unsigned int* offs_in, unsigned int* offs_out, lookback_t* lb, unsigned int bit,
-       unsigned int cur_bits, unsigned int full_blocks, obid_t ob) {
-  rocprim::detail::onesweep_iteration<BS, IPT, RB, false, rocprim::block_radix_rank_algorithm::match>(
-      kin, kout, vin, vout, size, offs_in, offs_out, lb, rocprim::identity_decomposer{}, bit, cur_bits,
-      full_blocks, ob);
+// scratch layout in 32-bit words: [places][R] global counts | 16 words (tile counters) |
+// [places][tiles][R] look-back states
+struct Layout {
+  int places, rb, R;
+  unsigned int tiles;
+  size_t hist, counters, states, words;
+};
+static Layout layout(size_t n, int end_bit, int tile) {
+  Layout l;
+  digits(end_bit, &l.places, &l.rb);
+  l.R = 1 << l.rb;
+  l.tiles = (unsigned int)((n + tile - 1) / tile);
+  if (l.tiles < 1) l.tiles = 1;
+  l.hist = 0;
+  l.counters = (size_t)l.places * l.R;
+  l.states = l.counters + 16;
+  l.words = l.states + (size_t)l.places * l.tiles * l.R;
+  return l;
 }
 
-template <unsigned BS, unsigned IPT, unsigned RB>
-static size_t scratch_words(size_t n, int end_bit) {
-  const size_t places = (end_bit + RB - 1) / RB, radix = 1u << RB;
-  const size_t blocks = (n + BS * IPT - 1) / (BS * IPT);
-  return places * radix + radix + places * blocks * radix + places + 16;
+template <typename K, int RB, int BS, int IPT, bool GATHER>
+static int launch_pass(const K* kin, K* kout, const int32_t* vin, int32_t* vout, unsigned int n,
+                       const uint32_t* ghist, uint32_t* state, uint32_t* counter, int shift,
+                       const int32_t* ord, long long ord_n, const uint32_t* cell32, hipStream_t s) {
+  using L = PassLds<K, RB, BS, IPT>;
+  auto kern = k_pass<K, RB, BS, IPT, GATHER>;
+  static bool attr_set = false;          // (more LDS than the 64-KB default needs asking for)
+  if (!attr_set) {
+    if (L::bytes > 64 * 1024)
+      HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)L::bytes));
+    attr_set = true;
+  }
+  const unsigned int tiles = (n + L::TILE - 1) / L::TILE;
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(BS), L::bytes, s, kin, kout, vin, vout, n, ghist, state,
+                     counter, shift, ord, ord_n, cell32);
+  return 0;
 }
 
-template <unsigned BS, unsigned IPT, unsigned RB>
-static int sort(void* scratch, uint32_t* ktmp, int32_t* vtmp, const uint32_t* kin, uint32_t* kout,
-                const int32_t* vin, int32_t* vout, size_t n, int end_bit, hipStream_t s) {
-  const unsigned int places = (end_bit + RB - 1) / RB, radix = 1u << RB;
-  const unsigned int items = BS * IPT;
-  const unsigned int blocks = (unsigned int)((n + items - 1) / items);
-  const unsigned int full_blocks = (unsigned int)(n / items);
-  unsigned int* hist = (unsigned int*)scratch;                 // [places][radix]
-  unsigned int* offs_tmp = hist + (size_t)places * radix;      // [radix]
-  lookback_t* lb = (lookback_t*)(offs_tmp + radix);            // [places][blocks * radix]
-  unsigned int* bid = (unsigned int*)(lb + (size_t)places * blocks * radix);   // [places]
-  static_assert(sizeof(lookback_t) == sizeof(unsigned int), "look-back state is one word");
-  HIPCHK(hipMemsetAsync(scratch, 0, scratch_words<BS, IPT, RB>(n, end_bit) * sizeof(unsigned int), s));
-  hipLaunchKernelGGL((k_hist<BS, IPT, RB>), dim3(blocks), dim3(BS), 0, s, kin, hist, (unsigned int)n,
-                     full_blocks, 0u, (unsigned int)end_bit);
-  hipLaunchKernelGGL((k_scan<BS, RB>), dim3(places), dim3(BS), 0, s, hist);
-  bool to_output = (places - 1) % 2 == 0;
-  const uint32_t* ki = kin;
+template <typename K, int BS, int IPT, bool GATHER>
+static int launch_pass_rb(int rb, const K* kin, K* kout, const int32_t* vin, int32_t* vout,
+                          unsigned int n, const uint32_t* ghist, uint32_t* state, uint32_t* counter,
+                          int shift, const int32_t* ord, long long ord_n, const uint32_t* cell32,
+                          hipStream_t s) {
+  switch (rb) {
+    case 8: return launch_pass<K, 8, BS, IPT, GATHER>(kin, kout, vin, vout, n, ghist, state, counter, shift, ord, ord_n, cell32, s);
+    case 9: return launch_pass<K, 9, BS, IPT, GATHER>(kin, kout, vin, vout, n, ghist, state, counter, shift, ord, ord_n, cell32, s);
+    case 10: return launch_pass<K, 10, BS, IPT, GATHER>(kin, kout, vin, vout, n, ghist, state, counter, shift, ord, ord_n, cell32, s);
+    case 11: return launch_pass<K, 11, BS, IPT, GATHER>(kin, kout, vin, vout, n, ghist, state, counter, shift, ord, ord_n, cell32, s);
+  }
+  gnx_set_error("radix sort: no kernel for %d-bit digits", rb);
+  return 1;
+}
+
+// the passes: global counts already in scratch (k_keys_hist / k_hist / k_move), the rest zero.
+// gather: the first pass takes its keys through the id-ordered index (kin / vin unused there).
+template <typename K, int BS, int IPT>
+static int passes(void* scratch, K* ktmp, int32_t* vtmp, const K* kin, K* kout, const int32_t* vin,
+                  int32_t* vout, size_t n, int end_bit, hipStream_t s, bool gather,
+                  const int32_t* ord, long long ord_n, const uint32_t* cell32) {
+  const Layout l = layout(n, end_bit, BS * IPT);
+  uint32_t* w = (uint32_t*)scratch;
+  bool to_output = (l.places - 1) % 2 == 0;
+  const K* ki = kin;
   const int32_t* vi = vin;
-  for (unsigned int place = 0, bit = 0; place < places; ++place, bit += RB) {
-    uint32_t* ko = to_output ? kout : ktmp;
+  for (int place = 0; place < l.places; ++place) {
+    K* ko = to_output ? kout : ktmp;
     int32_t* vo = to_output ? vout : vtmp;
-    const unsigned int cur = std::min<unsigned int>(RB, (unsigned int)end_bit - bit);
-    hipLaunchKernelGGL((k_iter<BS, IPT, RB>), dim3(blocks), dim3(BS), 0, s, ki, ko, vi, vo,
-                       (unsigned int)n, hist + (size_t)place * radix, offs_tmp,
-                       lb + (size_t)place * blocks * radix, bit, cur, full_blocks,
-                       obid_t::create(bid + place));
+    uint32_t* st = w + l.states + (size_t)place * l.tiles * l.R;
+    if (place == 0 && gather) {
+      if constexpr (sizeof(K) == 4) {
+        GNXCHK((launch_pass_rb<K, BS, IPT, true>(l.rb, ki, ko, vi, vo, (unsigned int)n,
+                                                  w + l.hist + (size_t)place * l.R, st,
+                                                  w + l.counters + place, place * l.rb, ord, ord_n,
+                                                  cell32, s)));
+      } else {
+        gnx_set_error("radix sort: the gathering first pass takes 32-bit keys");
+        return 1;
+      }
+    } else {
+      GNXCHK((launch_pass_rb<K, BS, IPT, false>(l.rb, ki, ko, vi, vo, (unsigned int)n,
+                                                 w + l.hist + (size_t)place * l.R, st,
+                                                 w + l.counters + place, place * l.rb, nullptr, 0,
+                                                 nullptr, s)));
+    }
     ki = ko;
     vi = vo;
     to_output = !to_output;
@@ -198,79 +462,36 @@ static int sort(void* scratch, uint32_t* ktmp, int32_t* vtmp, const uint32_t* ki
   HIPCHK(hipGetLastError());
   return 0;
 }
-// The same passes over 64-bit (cell << idbits | id) keys - what a tile with imports sorts, its
-// id-ordered index gone (csrc/gnx_tile.hip).  `scratch` is zero on entry and the caller wipes
-// what the sort dirtied (k_permute): no fills.  rocPRIM's own driver (radix_sort_pairs) puts a
-// fill in front of the histograms and two in front of every pass - eleven of ~5 us each on the
-// step's chain for 41-bit keys (profiles/r05_ab_runs.txt).
-template <unsigned BS, unsigned IPT, unsigned RB>
-__global__ void __launch_bounds__(BS)
-k_hist64(const uint64_t* keys, unsigned int* offs, unsigned int size, unsigned int full_blocks,
-         unsigned int begin_bit, unsigned int end_bit) {
-  rocprim::detail::onesweep_histograms<BS, IPT, RB, false>(keys, offs, size, full_blocks,
-                                                          rocprim::identity_decomposer{}, begin_bit,
-                                                          end_bit);
-}
 
-template <unsigned BS, unsigned IPT, unsigned RB>
-__global__ void __launch_bounds__(BS)
-k_iter64(const uint64_t* kin, uint64_t* kout, const int32_t* vin, int32_t* vout, unsigned int size,
-         unsigned int* offs_in, unsigned int* offs_out, lookback_t* lb, unsigned int bit,
-         unsigned int cur_bits, unsigned int full_blocks, obid_t ob) {
-  rocprim::detail::onesweep_iteration<BS, IPT, RB, false, rocprim::block_radix_rank_algorithm::match>(
-      kin, kout, vin, vout, size, offs_in, offs_out, lb, rocprim::identity_decomposer{}, bit, cur_bits,
-      full_blocks, ob);
-}
-
-template <unsigned BS, unsigned IPT, unsigned RB>
-static int sort64_clean(void* scratch, uint64_t* ktmp, int32_t* vtmp, const uint64_t* kin,
-                        uint64_t* kout, const int32_t* vin, int32_t* vout, size_t n, int end_bit,
-                        hipStream_t s) {
-  const unsigned int places = (end_bit + RB - 1) / RB, radix = 1u << RB;
-  const unsigned int items = BS * IPT;
-  const unsigned int blocks = (unsigned int)((n + items - 1) / items);
-  const unsigned int full_blocks = (unsigned int)(n / items);
-  unsigned int* hist = (unsigned int*)scratch;                 // [places][radix]
-  unsigned int* offs_tmp = hist + (size_t)places * radix;      // [radix]
-  lookback_t* lb = (lookback_t*)(offs_tmp + radix);            // [places][blocks * radix]
-  unsigned int* bid = (unsigned int*)(lb + (size_t)places * blocks * radix);   // [places]
-  hipLaunchKernelGGL((k_hist64<BS, IPT, RB>), dim3(blocks), dim3(BS), 0, s, kin, hist,
-                     (unsigned int)n, full_blocks, 0u, (unsigned int)end_bit);
-  hipLaunchKernelGGL((k_scan<BS, RB>), dim3(places), dim3(BS), 0, s, hist);
-  bool to_output = (places - 1) % 2 == 0;
-  const uint64_t* ki = kin;
-  const int32_t* vi = vin;
-  for (unsigned int place = 0, bit = 0; place < places; ++place, bit += RB) {
-    uint64_t* ko = to_output ? kout : ktmp;
-    int32_t* vo = to_output ? vout : vtmp;
-    const unsigned int cur = std::min<unsigned int>(RB, (unsigned int)end_bit - bit);
-    hipLaunchKernelGGL((k_iter64<BS, IPT, RB>), dim3(blocks), dim3(BS), 0, s, ki, ko, vi, vo,
-                       (unsigned int)n, hist + (size_t)place * radix, offs_tmp,
-                       lb + (size_t)place * blocks * radix, bit, cur, full_blocks,
-                       obid_t::create(bid + place));
-    ki = ko;
-    vi = vo;
-    to_output = !to_output;
+// global digit counts of every place in one pass over the keys (LDS tables, one flush)
+template <typename K>
+__global__ void __launch_bounds__(512)
+k_hist(const K* __restrict__ keys, unsigned int n, uint32_t* __restrict__ ghist, int places, int rb) {
+  extern __shared__ uint32_t lh[];                  // [places][R]
+  const int R = 1 << rb;
+  for (int q = threadIdx.x; q < places * R; q += 512) lh[q] = 0u;
+  __syncthreads();
+  for (size_t i = (size_t)blockIdx.x * 512 + threadIdx.x; i < n; i += (size_t)gridDim.x * 512) {
+    const K k = keys[i];
+    for (int pl = 0; pl < places; ++pl) atomicAdd(&lh[pl * R + ((uint32_t)(k >> (pl * rb)) & (R - 1))], 1u);
   }
-  HIPCHK(hipGetLastError());
-  return 0;
+  __syncthreads();
+  for (int q = threadIdx.x; q < places * R; q += 512) {
+    const uint32_t v = lh[q];
+    if (v) atomicAdd(&ghist[q], v);
+  }
 }
 
 // Keys of the id-ordered sequence (entry k is slot ord[k] for k < ord_n, else slot k itself:
-// offspring appended since the index was last compacted), their digit histograms and - in the
-// workgroup that finishes last (ticket) - the exclusive scans of the histograms, i.e. what
-// k_keys_ord + k_hist + k_scan left behind, in one launch.  hist: [places][2^RB], zero on
-// entry (the caller keeps the scratch clean: k_permute wipes it after every sort).
-// The counts travel as agent-scope atomics that have completed (s_waitcnt) before the ticket
-// is taken; no release fence (gnx_compact.h: that is an L2 write-back).
-template <unsigned RB, unsigned IPT>
+// offspring appended since the index was last compacted) written out as (key, value = k) pairs,
+// and their global digit counts - the sort's front when nobody else has counted (the
+// device-driven step, tiles, operator calls).  ghist: [places][R], zero on entry.
+template <unsigned IPT>
 __global__ void __launch_bounds__(1024)
 k_keys_hist(long long N, long long ord_n, const int32_t* __restrict__ ord,
             const uint32_t* __restrict__ cell32, uint32_t* __restrict__ key,
-            int32_t* __restrict__ val, unsigned int* __restrict__ hist, int places,
-            unsigned int* __restrict__ ticket, long long n_fixed, unsigned int sentinel,
-            const GnxDD* __restrict__ dd) {
-  constexpr unsigned R = 1u << RB;
+            int32_t* __restrict__ val, uint32_t* __restrict__ ghist, int places, int rb,
+            long long n_fixed, unsigned int sentinel, const GnxDD* __restrict__ dd) {
   // device-driven step: the population's size lives on the device and the sort runs over a
   // fixed n_fixed >= N entries; those behind the population carry the largest key, so the
   // stable sort leaves them behind everybody
@@ -278,12 +499,10 @@ k_keys_hist(long long N, long long ord_n, const int32_t* __restrict__ ord,
     N = dd->N;
     ord_n = dd->ord_n;
   }
-  static_assert(R == 1024, "one digit per thread");
-  __shared__ unsigned int lh[3][R];
-  __shared__ unsigned int wsum[16];
-  __shared__ int last;
-  const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int pl = 0; pl < places; ++pl) lh[pl][tid] = 0u;
+  extern __shared__ uint32_t lh[];                  // [places][R]
+  const int R = 1 << rb;
+  const unsigned tid = threadIdx.x;
+  for (int q = tid; q < places * R; q += 1024) lh[q] = 0u;
   __syncthreads();
   const long long base = (long long)blockIdx.x * (1024 * IPT);
   int32_t slot[IPT];
@@ -301,100 +520,52 @@ k_keys_hist(long long N, long long ord_n, const int32_t* __restrict__ ord,
     if (slot[r] < 0 && k >= n_fixed) continue;
     key[k] = c[r];
     val[k] = (int32_t)k;
-    for (int pl = 0; pl < places; ++pl) atomicAdd(&lh[pl][(c[r] >> (pl * RB)) & (R - 1u)], 1u);
+    for (int pl = 0; pl < places; ++pl) atomicAdd(&lh[pl * R + ((c[r] >> (pl * rb)) & (R - 1u))], 1u);
   }
   __syncthreads();
-  for (int pl = 0; pl < places; ++pl) {
-    const unsigned int v = lh[pl][tid];
-    if (v) __hip_atomic_fetch_add(&hist[pl * R + tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int q = tid; q < places * R; q += 1024) {
+    const uint32_t v = lh[q];
+    if (v) atomicAdd(&ghist[q], v);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    last = t == gridDim.x - 1u;
-    if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  if (!last) return;
-  for (int pl = 0; pl < places; ++pl) {
-    const unsigned int v = __hip_atomic_load(&hist[pl * R + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned int x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const unsigned int y = __shfl_up(x, d);
-      if (lane >= (unsigned)d) x += y;
-    }
-    __syncthreads();
-    if (lane == 63) wsum[wave] = x;
-    __syncthreads();
-    unsigned int woff = 0;
-    for (unsigned w = 0; w < 16; ++w) woff += w < wave ? wsum[w] : 0u;
-    hist[pl * R + tid] = woff + x - v;
-  }
-}
-
-// the passes alone: histograms already counted and scanned in `scratch` (k_keys_hist), the
-// rest of it zero
-template <unsigned BS, unsigned IPT, unsigned RB>
-static int sort_ranked(void* scratch, uint32_t* ktmp, int32_t* vtmp, const uint32_t* kin,
-                       uint32_t* kout, const int32_t* vin, int32_t* vout, size_t n, int end_bit,
-                       hipStream_t s) {
-  const unsigned int places = (end_bit + RB - 1) / RB, radix = 1u << RB;
-  const unsigned int items = BS * IPT;
-  const unsigned int blocks = (unsigned int)((n + items - 1) / items);
-  const unsigned int full_blocks = (unsigned int)(n / items);
-  unsigned int* hist = (unsigned int*)scratch;
-  unsigned int* offs_tmp = hist + (size_t)places * radix;
-  lookback_t* lb = (lookback_t*)(offs_tmp + radix);
-  unsigned int* bid = (unsigned int*)(lb + (size_t)places * blocks * radix);
-  bool to_output = (places - 1) % 2 == 0;
-  const uint32_t* ki = kin;
-  const int32_t* vi = vin;
-  for (unsigned int place = 0, bit = 0; place < places; ++place, bit += RB) {
-    uint32_t* ko = to_output ? kout : ktmp;
-    int32_t* vo = to_output ? vout : vtmp;
-    const unsigned int cur = std::min<unsigned int>(RB, (unsigned int)end_bit - bit);
-    hipLaunchKernelGGL((k_iter<BS, IPT, RB>), dim3(blocks), dim3(BS), 0, s, ki, ko, vi, vo,
-                       (unsigned int)n, hist + (size_t)place * radix, offs_tmp,
-                       lb + (size_t)place * blocks * radix, bit, cur, full_blocks,
-                       obid_t::create(bid + place));
-    ki = ko;
-    vi = vo;
-    to_output = !to_output;
-  }
-  HIPCHK(hipGetLastError());
-  return 0;
 }
 }  // namespace gnx_os
 
-// the fused front of the cell sort (variant 2's geometry: 1024 x 6 keys, 10-bit digits)
+// tile geometries: 0 = 512 threads x 8 keys (4 096 keys a tile), 1 = 256 x 4 (1 024 keys a tile:
+// four times the workgroups for a sort that is all latency at 10^5 keys); 64-bit keys: 512 x 4
+#define GNX_OS_BIG_BS 512
+#define GNX_OS_BIG_IPT 8
+#define GNX_OS_SMALL_BS 256
+#define GNX_OS_SMALL_IPT 4
+#define GNX_OS_64_BS 512
+#define GNX_OS_64_IPT 4
+
+void gnx_os_digits(int end_bit, int* places, int* rb) { gnx_os::digits(end_bit, places, rb); }
+
 size_t gnx_os_words_used(size_t n, int end_bit, int geometry) {
-  return geometry == 1 ? gnx_os::scratch_words<512, 4, 10>(n, end_bit)
-                       : gnx_os::scratch_words<1024, 6, 10>(n, end_bit);
+  return gnx_os::layout(n, end_bit, geometry == 1 ? GNX_OS_SMALL_BS * GNX_OS_SMALL_IPT
+                                                   : GNX_OS_BIG_BS * GNX_OS_BIG_IPT).words;
 }
 int gnx_os_keys_hist(void* scratch, unsigned int* ticket, int64_t N, int64_t ord_n,
                      const int32_t* ord, const uint32_t* cell32, uint32_t* key, int32_t* val,
                      int end_bit, hipStream_t s, const GnxDD* dd, int geometry) {
-  const int places = (end_bit + 9) / 10;
-  if (places > 3) return 1;
+  (void)ticket;
+  int places, rb;
+  gnx_os::digits(end_bit, &places, &rb);
+  const size_t lds = (size_t)places * (1u << rb) * sizeof(uint32_t);
   if (geometry == 1) {
     // small populations: 2 048 keys per workgroup instead of 6 144 - three times the workgroups
-    // for a sort that is all latency at 10^5 keys (43 workgroups on 256 CUs otherwise)
     const unsigned int blocks = (unsigned int)((N + 2047) / 2048);
-    hipLaunchKernelGGL((gnx_os::k_keys_hist<10, 2>), dim3(blocks), dim3(1024), 0, s, (long long)N,
-                       (long long)ord_n, ord, cell32, key, val, (unsigned int*)scratch, places, ticket,
+    hipLaunchKernelGGL((gnx_os::k_keys_hist<2>), dim3(blocks), dim3(1024), lds, s, (long long)N,
+                       (long long)ord_n, ord, cell32, key, val, (uint32_t*)scratch, places, rb,
                        (long long)N, (1u << end_bit) - 1u, dd);
-    HIPCHK(hipGetLastError());
-    return 0;
+  } else {
+    // dd: N is the fixed number of entries the sort runs over, the population's own size is
+    // read on the device
+    const unsigned int blocks = (unsigned int)((N + 6143) / 6144);
+    hipLaunchKernelGGL((gnx_os::k_keys_hist<6>), dim3(blocks), dim3(1024), lds, s, (long long)N,
+                       (long long)ord_n, ord, cell32, key, val, (uint32_t*)scratch, places, rb,
+                       (long long)N, (1u << end_bit) - 1u, dd);
   }
-  // (2, 3, 4, 8 keys per thread instead of 6: the same step time, profiles/r03_ab_runs.txt)
-  // dd: N is the fixed number of entries the sort runs over, the population's own size is read
-  // on the device
-  const unsigned int blocks = (unsigned int)((N + 6143) / 6144);
-  hipLaunchKernelGGL((gnx_os::k_keys_hist<10, 6>), dim3(blocks), dim3(1024), 0, s, (long long)N,
-                     (long long)ord_n, ord, cell32, key, val, (unsigned int*)scratch, places, ticket,
-                     (long long)N, (1u << end_bit) - 1u, dd);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -402,40 +573,62 @@ int gnx_os_sort32_ranked(void* scratch, uint32_t* ktmp, int32_t* vtmp, const uin
                          uint32_t* kout, const int32_t* vin, int32_t* vout, size_t n, int end_bit,
                          hipStream_t s, int geometry) {
   if (geometry == 1)
-    return gnx_os::sort_ranked<512, 4, 10>(scratch, ktmp, vtmp, kin, kout, vin, vout, n, end_bit, s);
-  return gnx_os::sort_ranked<1024, 6, 10>(scratch, ktmp, vtmp, kin, kout, vin, vout, n, end_bit, s);
+    return gnx_os::passes<uint32_t, GNX_OS_SMALL_BS, GNX_OS_SMALL_IPT>(
+        scratch, ktmp, vtmp, kin, kout, vin, vout, n, end_bit, s, false, nullptr, 0, nullptr);
+  return gnx_os::passes<uint32_t, GNX_OS_BIG_BS, GNX_OS_BIG_IPT>(
+      scratch, ktmp, vtmp, kin, kout, vin, vout, n, end_bit, s, false, nullptr, 0, nullptr);
+}
+// the cell sort of gnx_step when the movement kernel has counted the digits (k_move): the first
+// pass gathers cell32 through the id-ordered index itself - no kernel in front of the passes
+int gnx_os_sort32_gather(void* scratch, uint32_t* ktmp, int32_t* vtmp, uint32_t* kout, int32_t* vout,
+                         size_t n, int end_bit, const int32_t* ord, int64_t ord_n,
+                         const uint32_t* cell32, hipStream_t s) {
+  return gnx_os::passes<uint32_t, GNX_OS_BIG_BS, GNX_OS_BIG_IPT>(
+      scratch, ktmp, vtmp, (const uint32_t*)nullptr, kout, (const int32_t*)nullptr, vout, n, end_bit,
+      s, true, ord, (long long)ord_n, cell32);
 }
 
-// 64-bit keys, 10-bit digits, 1024 x 6 keys; scratch zero on entry, *words = what the caller has
-// to wipe afterwards; tmp (>= 12 n bytes) holds the keys and values between the passes
+// 64-bit keys; scratch zero on entry, gnx_os_words_used64 words to wipe afterwards; tmp (>= 12 n
+// bytes) holds the keys and values between the passes
 size_t gnx_os_words_used64(size_t n, int end_bit) {
-  return gnx_os::scratch_words<1024, 6, 10>(n, end_bit);
+  return gnx_os::layout(n, end_bit, GNX_OS_64_BS * GNX_OS_64_IPT).words;
 }
 int gnx_os_sort64_clean(void* scratch, void* tmp, const uint64_t* kin, uint64_t* kout,
                         const int32_t* vin, int32_t* vout, size_t n, int end_bit, hipStream_t s) {
   uint64_t* ktmp = (uint64_t*)tmp;
   int32_t* vtmp = (int32_t*)(ktmp + n);
-  return gnx_os::sort64_clean<1024, 6, 10>(scratch, ktmp, vtmp, kin, kout, vin, vout, n, end_bit, s);
+  int places, rb;
+  gnx_os::digits(end_bit, &places, &rb);
+  const unsigned int blocks = (unsigned int)std::min<size_t>((n + 4095) / 4096, 1024);
+  hipLaunchKernelGGL((gnx_os::k_hist<uint64_t>), dim3(blocks ? blocks : 1), dim3(512),
+                     (size_t)places * (1u << rb) * 4, s, kin, (unsigned int)n, (uint32_t*)scratch,
+                     places, rb);
+  return gnx_os::passes<uint64_t, GNX_OS_64_BS, GNX_OS_64_IPT>(scratch, ktmp, vtmp, kin, kout, vin,
+                                                                vout, n, end_bit, s, false, nullptr,
+                                                                0, nullptr);
 }
 
-// variant 0: 256 threads x 12 keys, 8-bit digits; 1: 512 x 8, 8 bits; 2: 1024 x 6, 10 bits
 size_t gnx_os_scratch_bytes(size_t n, int end_bit) {
-  size_t w = std::max({gnx_os::scratch_words<256, 12, 8>(n, end_bit),
-                       gnx_os::scratch_words<512, 8, 8>(n, end_bit),
-                       gnx_os::scratch_words<1024, 6, 10>(n, end_bit),
+  size_t w = std::max({gnx_os_words_used(n, end_bit, 0),
                        // (the small geometry: only ever used below GNX_DD_MAX_CAP slots)
-                       gnx_os::scratch_words<512, 4, 10>(std::min<size_t>(n, 1u << 21), end_bit)});
+                       gnx_os_words_used(std::min<size_t>(n, 1u << 21), end_bit, 1)});
   return w * sizeof(unsigned int);
 }
 
+// generic entry (keys given, nothing counted yet): counts, then the passes; the caller has the
+// scratch zero and wipes gnx_os_scratch_bytes of it afterwards
 int gnx_os_sort32(void* scratch, uint32_t* ktmp, int32_t* vtmp, const uint32_t* kin,
                   uint32_t* kout, const int32_t* vin, int32_t* vout, size_t n, int end_bit,
                   hipStream_t s, int variant) {
-  switch (variant) {
-    case 1: return gnx_os::sort<512, 8, 8>(scratch, ktmp, vtmp, kin, kout, vin, vout, n, end_bit, s);
-    case 2: return gnx_os::sort<1024, 6, 10>(scratch, ktmp, vtmp, kin, kout, vin, vout, n, end_bit, s);
-    default: return gnx_os::sort<256, 12, 8>(scratch, ktmp, vtmp, kin, kout, vin, vout, n, end_bit, s);
-  }
+  (void)variant;
+  int places, rb;
+  gnx_os::digits(end_bit, &places, &rb);
+  const unsigned int blocks = (unsigned int)std::min<size_t>((n + 4095) / 4096, 1024);
+  hipLaunchKernelGGL((gnx_os::k_hist<uint32_t>), dim3(blocks ? blocks : 1), dim3(512),
+                     (size_t)places * (1u << rb) * 4, s, kin, (unsigned int)n, (uint32_t*)scratch,
+                     places, rb);
+  return gnx_os::passes<uint32_t, GNX_OS_BIG_BS, GNX_OS_BIG_IPT>(
+      scratch, ktmp, vtmp, kin, kout, vin, vout, n, end_bit, s, false, nullptr, 0, nullptr);
 }
 
 // ---------------------------------------------------------------- block-count scan

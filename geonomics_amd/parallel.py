@@ -498,7 +498,11 @@ class TiledStepper:
         # use_library: None = GNX_TILE_V3 (default on).
         self.v3 = False
         if use_library is None:
-            use_library = os.environ.get('GNX_TILE_V3', '1') != '0'
+            # (GNX_ID_ORDER=0 asks for the (hash cell, focal id) offspring order of the WHOLE
+            # landscape everywhere: gnx_tile_step numbers tile-major, so that setting takes the
+            # Python-driven protocol, which hands the pairs' order keys around - ADVICE r5)
+            use_library = (os.environ.get('GNX_TILE_V3', '1') != '0' and
+                           os.environ.get('GNX_ID_ORDER', '1') != '0')
         if self.v2 and use_library:
             self.v3 = self._join_library_comm()
         self._ext = None           # the library's stream as a torch stream
@@ -1003,8 +1007,23 @@ class TiledStepper:
             dev = self.shard.dev
             first, total = dev.tile_step_begin(burn)
             self.max_id = first + total - 1
+            # the host's work on the newborns may fail on ONE rank (a mutation or pedigree hook):
+            # that rank must not simply leave - the others would wait inside the step's all-reduce
+            # for ever (only the communicator's init has a deadline).  The ranks agree over the
+            # CPU side group that every hook succeeded before anybody enters tile_step_end;
+            # otherwise all of them drop the half-done step (gnx_tile_step_abort) and raise.
+            hook_err = None
             if total > 0:
-                after_births(first, total)
+                try:
+                    after_births(first, total)
+                except Exception as e:          # noqa: BLE001 - re-raised below, on every rank
+                    hook_err = e
+            if not _everybody(self.comm, hook_err is None):
+                dev.tile_step_abort()
+                if hook_err is not None:
+                    raise hook_err
+                raise RuntimeError('a tiled step was abandoned after its births: the host hook '
+                                   '(mutation / pedigree) failed on another rank')
             n, b, d = dev.tile_step_end(burn, with_selection, exact)
             self.bytes_sent = dev.comm_bytes_sent
             return n, b, d

@@ -466,16 +466,23 @@ class Species:
             room = max(self._cap - n_now, 1)
             grow = max(0.02, float(getattr(self._pv, 'R', 0.5)) * 0.25) * max(n_now, 1)
             chunk = int(max(1, min(T - done, 256, 0.5 * room / grow)))
-            err = None
             try:
                 dev.walk(chunk, False, with_selection)
             except nat.GnxError as e:
-                # the steps before the one that did not fit DID happen: their records are read
-                # below, the device's counters are the library's; the queue's steps (which can
-                # move the population to a larger device state) take over from there
-                if 'capacity exceeded' not in str(e):
-                    raise
-                err = e
+                # A walk that ran out of slots or genome rows is NOT recoverable: the step
+                # that did not fit dropped births (or let offspring share genome rows) and the
+                # steps enqueued behind it started from that state; a host-driven step fails
+                # half-way (aged and moved, not yet born).  The library keeps such steps out
+                # of gnx_walk_history; here the run ends loudly, as the reference would on an
+                # inconsistent population - the pieces above are sized so that it does not
+                # happen (0.66 of the capacity, half the free room per piece).
+                if 'capacity exceeded' in str(e):
+                    raise nat.GnxError(
+                        '%s - inside Model.walk the device-driven steps cannot move the '
+                        'population to a larger device state; start with more headroom '
+                        '(GNX_CAP_FACTOR, now %.2f x N0)' % (e, self._cap / float(self.start_N or 1))
+                    ) from e
+                raise
             n0, births, deaths = dev.walk_history(chunk)
             for a, b, d in zip(n0.tolist(), births.tolist(), deaths.tolist()):
                 if a == 0:
@@ -491,8 +498,6 @@ class Species:
                     self.extinct = True
                     break
                 self.Nt.append(int(a + b - d))
-            if err is not None:
-                break
         return done
 
     def _grow_device(self, factor=2.0):

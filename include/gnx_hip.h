@@ -558,6 +558,19 @@ int gnx_tile_step_births(gnx_state* h, int64_t* first_id, int64_t* total);
 int gnx_tile_step_end(gnx_state* h, int32_t burn, int32_t with_selection, int32_t exact,
                       int64_t* out);
 int gnx_comm_probe(void);
+/* gnx_tile_step_abort: leave the state between _begin and _end without the density all-reduce and
+ * the mortality - what every rank calls when the host's work on the newborns (the reference's
+ * mutation / pedigree hooks, ops/mutation.py:169-206, structs/species.py:692-736) failed on ANY
+ * rank, so that all of them raise instead of the others waiting inside the all-reduce.
+ * gnx_comm_info: int64 out[16] - [0] transport (0 one rank, 1 RCCL, 2 local), [1] rank, [2] world,
+ * [3] ncclCommCount, [4] ncclCommUserRank, [5] ncclCommCuDevice (-1 without an RCCL communicator),
+ * [6] HIP device ordinal, [7] tiled steps taken, [8..12] host wall time of the step's phases summed
+ * over them in microseconds (routing + count exchange; migrant / ghost exchange + import; cell
+ * sort + pairs + second count exchange; births + gamete service; all-reduce + deaths), [13] bytes
+ * sent, [14] collections of the genome blocks so far (also without a communicator).  No reference
+ * counterpart (sim/model.py:924-925 is a TODO): it lets bench.py certify the ranks it ran on.    */
+int gnx_tile_step_abort(gnx_state* h);
+int gnx_comm_info(gnx_state* h, int64_t* out /*[16]*/);
 
 /* ---- pedigree (reference structs/species.py:692-736: rows of the tskit tables) --
  * the offspring of the last gnx_pop_dynamics_mate, in birth order; call it before

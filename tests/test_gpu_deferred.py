@@ -341,6 +341,43 @@ def test_small_path_equals_default_path(variant, monkeypatch):
     b.close()
 
 
+@pytest.mark.parametrize('variant', ['device_driven', 'host_driven'])
+def test_walk_that_outgrows_the_capacity_fails_loudly(variant, monkeypatch):
+    """a gnx_walk whose births do not fit the preallocated slots returns
+    'capacity exceeded', and gnx_walk_history holds ONLY the steps that completed cleanly -
+    not the step that dropped its births, nor anything enqueued behind it - and those equal
+    the steps of a handle with room, count for count.  (Species._walk_on_device re-raises:
+    the population of such a handle is not a population of the model any more.)"""
+    if variant == 'host_driven':
+        monkeypatch.setenv('GNX_DD', '0')
+    nat = native()
+    W = H = 40
+    rasts = np.stack([np.ones((H, W)), np.tile(np.linspace(0, 1, W), (H, 1))]).astype(np.float32)
+
+    def mk(cap):
+        dev = make_dev(W, H, rasts=rasts, L=0, n_traits=0, cap=cap, seed=4, mating_radius=3.0,
+                       K_factor=2.0)
+        dev.init_population(400)
+        return dev
+
+    a, b = mk(16384), mk(1024)
+    seq = []
+    for _ in range(40):
+        n0 = a.N
+        a.step(True, False)
+        seq.append((n0, a.counts()[1], a.counts()[2]))
+    assert max(n + bb for n, bb, _ in seq) > 1024          # (the small handle must overflow)
+    with pytest.raises(nat.GnxError, match='capacity exceeded'):
+        b.walk(40, True, False)
+    n, births, deaths = b.walk_history()
+    got = [tuple(int(v) for v in r) for r in zip(n, births, deaths)]
+    first_bad = next(k for k, (n0, bb, _) in enumerate(seq) if n0 + bb > 1024)
+    assert 0 < len(got) <= first_bad
+    assert got == seq[:len(got)]
+    a.close()
+    b.close()
+
+
 def test_small_path_burn_in_and_growth():
     """device-driven burn-in steps (no genomes) from a small founder population that grows
     several-fold to its carrying capacity: counts per step equal the host-driven path's"""
