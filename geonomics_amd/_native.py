@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libgnxhip.so')
+# (GNX_LIB: another build of the same library - A/B runs of two builds on one box, tools/)
+LIB_PATH = os.environ.get('GNX_LIB') or os.path.join(_HERE, 'libgnxhip.so')
 
 # enums (include/gnx_hip.h)
 DIST = {'lognormal': 0, 'wald': 1, 'levy': 2}

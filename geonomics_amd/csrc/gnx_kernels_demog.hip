@@ -1389,6 +1389,283 @@ k_xo_jobs_fused(int64_t N, int64_t first, int32_t* __restrict__ grow,
 
 #undef fresh_at
 
+// ---- the job builder with a gamete's table laid across lanes (round 6) ------------------------
+// k_xo_jobs_fused above gives every surviving offspring ONE thread that walks 2 x 2 NB parent
+// entries and NB child entries by itself: 60 loads and stores of 8 bytes per thread at NB = 20,
+// every one of them a request of its own (the lanes of a wave sit in 64 different rows) - ~3 200
+// requests per wave for 30 KB, 49 % of the waves' cycles waiting for them (SQ counters,
+// profiles/r05_pmc_job_builder.txt).  Here the per-offspring PLAN (row, parents' rows, which
+// blocks are cut, which homologue the others follow, where its fresh blocks and jobs start) is
+// worked out one thread per slot as before (stages 1-5, same arithmetic), left in LDS (64 bytes
+// per slot), and the TABLES are then walked by the wave together: a gamete's NB entries lie in NB
+// adjacent lanes - lane q loads the parent's two entries for block q (two coalesced 4 NB-byte
+// rows per gamete), picks or takes a fresh block, stores the child's entry (one coalesced row) and
+// writes the job of a cut block; 64 / NB gametes per wave-instruction, four instructions' loads
+// in flight before the first store.  NB is a run-time value here: one kernel for every genome
+// length.  Same plan, same stack / job indices as k_xo_jobs_fused: bit-identical tables and job
+// lists (tests/test_gpu_product_path.py, test_gpu_halves.py, test_gpu_deferred.py).
+struct alignas(16) GnxJobPlan {
+  int32_t row, pop, job, m0cnt;      // m0cnt: cut blocks of gamete 0
+  int32_t prow[2];
+  uint32_t mixed[2], sel[2];
+  int32_t ks[2];                     // path * 2 + start homologue
+  int32_t nbp[2], b0[2];
+};
+static_assert(sizeof(GnxJobPlan) == 64, "one plan per slot, 64 bytes of LDS");
+
+template <int TPB>
+__global__ void __launch_bounds__(TPB)
+k_xo_jobs_lanes(int64_t N, int64_t first, int32_t* __restrict__ grow,
+                const int32_t* __restrict__ alive, const int32_t* __restrict__ blk_off3,
+                const int32_t* __restrict__ off_parent, const int32_t* __restrict__ off_keys,
+                const uint8_t* __restrict__ off_start, const int32_t* __restrict__ free_rows,
+                int64_t n_free, GnxHalves H, const int32_t* __restrict__ bp_off,
+                const int32_t* __restrict__ bp_loci, int32_t* __restrict__ n_jobs,
+                GnxXoJob* __restrict__ jobs, GnxJobBp* __restrict__ jobs_bp,
+                const int32_t* __restrict__ cnt3, GnxDD* __restrict__ dd) {
+  constexpr int WAVES = TPB / 64;
+  if (dd) {
+    N = (int64_t)dd->N + dd->B;
+    first = dd->N;
+    n_free = dd->n_free;
+    if ((first / TPB + blockIdx.x) * TPB >= N) return;         // (block-uniform)
+  }
+  __shared__ int wsum[3][WAVES];
+  __shared__ int prev_s[WAVES];
+  __shared__ int psum[WAVES];
+  __shared__ int s_pop, s_job;
+  __shared__ GnxJobPlan plan[TPB];
+  __shared__ uint8_t fxlist[WAVES][64];
+  const int NB = H.NB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t base = (first / TPB + blockIdx.x) * TPB;
+  const int64_t i = base + tid;
+  const int64_t b = base / GNX_CB;                 // the compaction block of these TPB slots
+  const int round = (int)((base - b * GNX_CB) / TPB);
+  // stages 1-5: as in k_xo_jobs_fused
+  const bool fx = i < N && (alive[i] & 2) != 0;
+  int prev = 0;
+  for (int r = 0; r < round; ++r) {
+    const int64_t j = b * GNX_CB + r * TPB + tid;
+    prev += __popcll(__ballot(j < N && (alive[j] & 2) != 0));
+  }
+  int part = 0;
+  if (cnt3)
+    for (int q = tid; q < (int)b; q += TPB) part += cnt3[q];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d);
+  const unsigned long long bal = __ballot(fx);
+  if (lane == 0) {
+    wsum[0][wave] = __popcll(bal);
+    prev_s[wave] = prev;
+    psum[wave] = part;
+  }
+  __syncthreads();
+  int rank = __popcll(bal & ((1ull << lane) - 1ull));
+  for (int w = 0; w < wave; ++w) rank += wsum[0][w];
+  if (cnt3) {
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) rank += psum[w];
+  } else {
+    rank += blk_off3[b];
+  }
+#pragma unroll
+  for (int w = 0; w < WAVES; ++w) rank += prev_s[w];
+  if (dd && fx && rank >= n_free) {
+    dd->err |= GNX_DD_ERR_ROWS;
+    rank = 0;
+  }
+  const int64_t k = fx ? i - first : 0;
+  int32_t row = free_rows[max((int64_t)0, n_free - 1 - (fx ? rank : 0))];
+  int32_t par[2], key[2], st[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    par[p] = off_parent[2 * k + p];
+    key[p] = off_keys[2 * k + p];
+    st[p] = off_start[2 * k + p];
+  }
+  if (fx) grow[i] = row;
+  else row = -1;
+  int32_t prow[2], b0[2], b1[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    prow[p] = grow[par[p]];
+    b0[p] = bp_off ? bp_off[key[p]] : 0;
+    b1[p] = bp_off ? bp_off[key[p] + 1] : 0;
+  }
+  const unsigned int all = (1u << NB) - 1u;
+  const int lpb = H.BW * 64;
+  const float inv_lpb = 1.0f / (float)lpb;
+  auto blk_of = [&](int l) __attribute__((always_inline)) {
+    int q = (int)((float)l * inv_lpb);
+    q -= (q * lpb > l) ? 1 : 0;
+    q += ((q + 1) * lpb <= l) ? 1 : 0;
+    return min(q, NB - 1);
+  };
+  unsigned int mixed[2], sel[2];
+  int nbp[2];
+  int cf = 0, cj = 0;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    if (!fx) prow[p] = -1;
+    nbp[p] = (bp_off && prow[p] >= 0) ? b1[p] - b0[p] : 0;
+    mixed[p] = all;                              // dense masks, ghost parent: cut everything
+    sel[p] = 0u;
+    if (fx && prow[p] >= 0 && bp_off) {
+      unsigned int mx = 0u, sl = st[p] ? all : 0u;
+      for (int z = 0; z < nbp[p]; ++z) {
+        const int blk = blk_of(bp_loci[b0[p] + z]);
+        mx |= 1u << blk;
+        sl ^= all & ~((2u << blk) - 1u);        // every later block starts on the other homologue
+      }
+      mixed[p] = mx;
+      sel[p] = sl & all;
+    }
+    if (fx) {
+      const int nf = __popc(mixed[p]);
+      cf += nf;
+      cj += prow[p] >= 0 ? nf : 0;
+    }
+  }
+  int xf = cf, xj = cj;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int yf = __shfl_up(xf, d), yj = __shfl_up(xj, d);
+    if (lane >= d) {
+      xf += yf;
+      xj += yj;
+    }
+  }
+  if (lane == 63) {
+    wsum[1][wave] = xf;
+    wsum[2][wave] = xj;
+  }
+  __syncthreads();
+  int of = xf - cf, oj = xj - cj;
+  for (int w = 0; w < wave; ++w) {
+    of += wsum[1][w];
+    oj += wsum[2][w];
+  }
+  if (tid == 0) {
+    int tf = 0, tj = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+      tf += wsum[1][w];
+      tj += wsum[2][w];
+    }
+    s_pop = tf ? atomicSub(H.top, tf) : 0;
+    s_job = tj ? atomicAdd(n_jobs, tj) : 0;
+    if (dd && s_pop < tf) dd->err |= GNX_DD_ERR_BLOCKS;
+  }
+  // the plan of this slot, and the wave's list of the lanes that have one
+  if (fx) fxlist[wave][__popcll(bal & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+  __syncthreads();
+  {
+    GnxJobPlan P;
+    P.row = row;
+    // stack index of my first fresh block (dd: never below what the walk goes down to)
+    P.pop = dd ? max(s_pop - 1 - of, cf) : s_pop - 1 - of;
+    P.job = s_job + oj;
+    P.m0cnt = __popc(mixed[0]);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      P.prow[p] = prow[p];
+      P.mixed[p] = mixed[p];
+      P.sel[p] = sel[p];
+      P.ks[p] = key[p] * 2 + st[p];
+      P.nbp[p] = nbp[p];
+      P.b0[p] = b0[p];
+    }
+    plan[tid] = P;
+  }
+  // (the wave reads only its own lanes' plans: LDS operations of a wave complete in order)
+  __builtin_amdgcn_wave_barrier();
+  // stages 6-7: the tables, NB adjacent lanes per gamete
+  const int n_g = 2 * __popcll(bal);               // gametes of this wave
+  const int GPL = 64 / NB;                         // gametes per wave-instruction
+  const int sub = lane / NB, q = lane - sub * NB;
+  const bool lane_on = sub < GPL;
+  const unsigned int below = (1u << q) - 1u;
+  constexpr int U = 4;                             // instructions' loads in flight
+  for (int g0 = 0; g0 < n_g; g0 += GPL * U) {
+    bool on[U];
+    int32_t e0[U], e1[U], fresh[U];
+    int own[U], pp[U], nbu[U], bbu[U];
+    int32_t bl[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int g = g0 + u * GPL + sub;
+      on[u] = lane_on && g < n_g;
+      own[u] = wave * 64 + (on[u] ? (int)fxlist[wave][g >> 1] : 0);
+      pp[u] = g & 1;
+      const GnxJobPlan& P = plan[own[u]];
+      const int32_t pr = on[u] ? P.prow[pp[u]] : -1;
+      const int32_t* src = H.hmap + (int64_t)max(pr, 0) * 2 * NB;
+      e0[u] = src[q];
+      e1[u] = src[NB + q];
+      const bool cut = on[u] && ((P.mixed[pp[u]] >> q) & 1u) != 0u;
+      const int fr = (pp[u] ? P.m0cnt : 0) + __popc(P.mixed[pp[u]] & below);
+      fresh[u] = cut ? H.stack[P.pop - fr] : 0;
+      // (a job's switch points: the path's first four loci go out with the table loads - a
+      // look-up inside the store phase is a round trip per instruction of the round)
+      nbu[u] = (cut && pr >= 0) ? P.nbp[pp[u]] : 0;
+      bbu[u] = P.b0[pp[u]];
+#pragma unroll
+      for (int z = 0; z < 4; ++z) bl[u][z] = z < nbu[u] ? bp_loci[bbu[u] + z] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!on[u]) continue;
+      const GnxJobPlan& P = plan[own[u]];
+      const int p = pp[u];
+      const int32_t pr = P.prow[p];
+      const unsigned int mx = P.mixed[p];
+      const bool cut = ((mx >> q) & 1u) != 0u;
+      const int hsel = (P.sel[p] >> q) & 1u;
+      const int32_t pv = hsel ? e1[u] : e0[u];
+      const int32_t sv = GNX_BLK(pv);
+      // the parent's block is shared from now on: it loses its never-shared flag (only the
+      // first child to share it writes)
+      if (!cut && pv < 0) H.hmap[((int64_t)pr * 2 + hsel) * NB + q] = sv;
+      H.hmap[((int64_t)P.row * 2 + p) * NB + q] =
+          cut ? (int32_t)((uint32_t)fresh[u] | GNX_OWN) : sv;
+      if (cut && pr >= 0) {
+        // one job per cut block of a local parent; the switch points inside the block ride
+        // with it (gnx_xo.h: GnxJobBp)
+        const int jr = (p && P.prow[0] >= 0 ? P.m0cnt : 0) + __popc(mx & below);
+        GnxXoJob j;
+        j.ph0 = GNX_BLK(e0[u]);
+        j.ph1 = GNX_BLK(e1[u]);
+        j.dst = fresh[u];
+        j.ks = P.ks[p] | (q << 24);
+        jobs[P.job + jr] = j;
+        unsigned int o0 = 0, o1 = 0, o2 = 0;
+        int nin = 0;
+        const int lo = q * lpb, hi = (q == NB - 1) ? 0x7fffffff : lo + lpb;
+        auto take = [&](int l) __attribute__((always_inline)) {
+          if (l >= lo && l < hi) {
+            const unsigned int o = (unsigned int)(l - lo);
+            o0 = nin == 0 ? o : o0;
+            o1 = nin == 1 ? o : o1;
+            o2 = nin == 2 ? o : o2;
+            ++nin;
+          }
+        };
+#pragma unroll
+        for (int z = 0; z < 4; ++z)
+          if (z < nbu[u]) take(bl[u][z]);
+        for (int z = 4; z < nbu[u]; ++z) take(bp_loci[bbu[u] + z]);
+        // (offsets are 16 bits: a block of more than 65 536 loci looks its path up)
+        const bool inl = bp_off != nullptr && nin <= 3 && lpb <= 65536;
+        const unsigned int meta = (inl ? (unsigned int)nin : 0u) | ((unsigned int)hsel << 2) |
+                                  (inl ? 0u : GNX_BP_MORE);
+        *(uint2*)(jobs_bp + P.job + jr) = make_uint2((o0 & 0xffffu) | (o1 << 16),
+                                                     (o2 & 0xffffu) | (meta << 16));
+      }
+    }
+  }
+}
+
 template <int NB>
 static void launch_jobs_fused(gnx_state* h, int64_t first_slot, const int32_t* d_alive,
                               const int32_t* d_blk_off, int buf) {
@@ -1398,6 +1675,19 @@ static void launch_jobs_fused(gnx_state* h, int64_t first_slot, const int32_t* d
   const bool ddm = h->dd_active;
   const int nbf = ddm ? (int)(h->cfg.cap_inds / 2 / GNX_JF_TPB + 2)
                       : (int)((N - 1) / GNX_JF_TPB - first_slot / GNX_JF_TPB + 1);
+  // GNX_JF_LANES=0: one thread per offspring walks its tables alone (k_xo_jobs_fused)
+  static const bool lanes = !(getenv("GNX_JF_LANES") && atoi(getenv("GNX_JF_LANES")) == 0);
+  if (lanes) {
+    hipLaunchKernelGGL((k_xo_jobs_lanes<GNX_JF_TPB>), dim3(nbf), dim3(GNX_JF_TPB), 0, h->stream, N, first_slot,
+                       h->soa[h->cur].grow, d_alive, d_blk_off + 2 * h->blk_stride, h->off_parent,
+                       h->off_keys, h->off_start, h->free_rows, h->n_free, gnx_halves(h),
+                       gnx_alias_bp(h), gnx_alias_loci(h), h->n_jobs_dev[buf],
+                       (GnxXoJob*)h->jobs[buf], (GnxJobBp*)h->jobs_bp[buf],
+                       h->jobs_self_scan ? (const int32_t*)(h->blk_cnt + 2 * h->blk_stride)
+                                         : (const int32_t*)nullptr, ddm ? h->dd : (GnxDD*)nullptr);
+    h->jobs_inline[buf] = true;
+    return;
+  }
   hipLaunchKernelGGL((k_xo_jobs_fused<NB, GNX_JF_TPB>), dim3(nbf), dim3(GNX_JF_TPB), 0, h->stream, N, first_slot,
                      h->soa[h->cur].grow, d_alive, d_blk_off + 2 * h->blk_stride, h->off_parent,
                      h->off_keys, h->off_start, h->free_rows, h->n_free, gnx_halves(h),

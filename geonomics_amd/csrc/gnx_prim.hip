@@ -359,10 +359,14 @@ k_pass(const K* __restrict__ kin, K* __restrict__ kout, const int32_t* __restric
 }
 
 // digit places and bits per place for keys of `end_bit` significant bits: as few places as
-// 11-bit digits allow, the bits spread evenly over them, never fewer than 8 bits per place (the
-// kernels are instantiated for 8 .. 11)
+// GNX_OS_MAX_RB-bit digits allow, the bits spread evenly over them, never fewer than 8 bits per
+// place (the kernels are instantiated for 8 .. 11)
+// (a tile of 4 096 keys wants its digits few enough that each holds several keys: 9 bits at most -
+// 11-bit digits with tiles of 2 048 keys made the look-back the pass: two tiles on one GPU 2.07
+// against 1.68 ms a step)
+#define GNX_OS_MAX_RB 9
 static void digits(int end_bit, int* places, int* rb) {
-  int p = (end_bit + 10) / 11;
+  int p = (end_bit + GNX_OS_MAX_RB - 1) / GNX_OS_MAX_RB;
   if (p < 1) p = 1;
   int b = (end_bit + p - 1) / p;
   if (b < 8) b = 8;
@@ -531,13 +535,13 @@ k_keys_hist(long long N, long long ord_n, const int32_t* __restrict__ ord,
 }  // namespace gnx_os
 
 // tile geometries: 0 = 512 threads x 8 keys (4 096 keys a tile), 1 = 256 x 4 (1 024 keys a tile:
-// four times the workgroups for a sort that is all latency at 10^5 keys); 64-bit keys: 512 x 4
+// four times the workgroups for a sort that is all latency at 10^5 keys); 64-bit keys: 512 x 8
 #define GNX_OS_BIG_BS 512
 #define GNX_OS_BIG_IPT 8
 #define GNX_OS_SMALL_BS 256
 #define GNX_OS_SMALL_IPT 4
 #define GNX_OS_64_BS 512
-#define GNX_OS_64_IPT 4
+#define GNX_OS_64_IPT 8
 
 void gnx_os_digits(int end_bit, int* places, int* rb) { gnx_os::digits(end_bit, places, rb); }
 
