@@ -1436,6 +1436,8 @@ k_xo_jobs_lanes(int64_t N, int64_t first, int32_t* __restrict__ grow,
   __shared__ int s_pop, s_job;
   __shared__ GnxJobPlan plan[TPB];
   __shared__ uint8_t fxlist[WAVES][64];
+  __shared__ uint4 jq_a[WAVES][64];     // queued jobs: {parent block 0, 1, fresh block, path | block}
+  __shared__ uint2 jq_b[WAVES][64];     // ... {job index, owner | gamete | homologue | block}
   const int NB = H.NB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t base = (first / TPB + blockIdx.x) * TPB;
@@ -1580,18 +1582,67 @@ k_xo_jobs_lanes(int64_t N, int64_t first, int32_t* __restrict__ grow,
   }
   // (the wave reads only its own lanes' plans: LDS operations of a wave complete in order)
   __builtin_amdgcn_wave_barrier();
-  // stages 6-7: the tables, NB adjacent lanes per gamete
+  // stages 6-7: the tables, NB adjacent lanes per gamete.  The jobs of the cut blocks (two or
+  // three lanes of an instruction's 60) are not written where they are found - ~80 instructions
+  // for three lanes, 36 times per wave: the kernel was bound by instruction issue - but queued
+  // in LDS, 64 to a wave, and written by all lanes together when the queue is full.
+#ifdef GNX_JL_TIMING_SKIP_WALK            // (timing experiment only: wrong results)
+  const int n_g = 0;
+#else
   const int n_g = 2 * __popcll(bal);               // gametes of this wave
+#endif
   const int GPL = 64 / NB;                         // gametes per wave-instruction
   const int sub = lane / NB, q = lane - sub * NB;
   const bool lane_on = sub < GPL;
   const unsigned int below = (1u << q) - 1u;
-  constexpr int U = 4;                             // instructions' loads in flight
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  int qn = 0;                                      // queued jobs (wave-uniform)
+  auto flush = [&]() __attribute__((always_inline)) {
+    if (lane < qn) {
+      const uint4 a = jq_a[wave][lane];
+      const uint2 m = jq_b[wave][lane];
+      const int idx = (int)m.x;
+      const int owner = (int)(m.y & 0xffffu), p = (int)((m.y >> 16) & 1u);
+      const unsigned int hsel = (m.y >> 17) & 1u;
+      const int q2 = (int)(m.y >> 24);
+      const int nb_p = plan[owner].nbp[p], bb = plan[owner].b0[p];
+      unsigned int o0 = 0, o1 = 0, o2 = 0;
+      int nin = 0;
+      const int lo = q2 * lpb, hi = (q2 == NB - 1) ? 0x7fffffff : lo + lpb;
+      for (int z = 0; z < nb_p; ++z) {
+        const int l = bp_loci[bb + z];
+        if (l >= lo && l < hi) {
+          const unsigned int o = (unsigned int)(l - lo);
+          o0 = nin == 0 ? o : o0;
+          o1 = nin == 1 ? o : o1;
+          o2 = nin == 2 ? o : o2;
+          ++nin;
+        }
+      }
+      // (offsets are 16 bits: a block of more than 65 536 loci looks its path up)
+      const bool inl = bp_off != nullptr && nin <= 3 && lpb <= 65536;
+      const unsigned int meta = (inl ? (unsigned int)nin : 0u) | (hsel << 2) |
+                                (inl ? 0u : GNX_BP_MORE);
+      GnxXoJob j;
+      j.ph0 = (int32_t)a.x;
+      j.ph1 = (int32_t)a.y;
+      j.dst = (int32_t)a.z;
+      j.ks = (int32_t)a.w;
+      jobs[idx] = j;
+      *(uint2*)(jobs_bp + idx) = make_uint2((o0 & 0xffffu) | (o1 << 16),
+                                            (o2 & 0xffffu) | (meta << 16));
+    }
+    qn = 0;
+  };
+#ifndef GNX_JL_U
+#define GNX_JL_U 4
+#endif
+  constexpr int U = GNX_JL_U;                      // instructions' loads in flight
   for (int g0 = 0; g0 < n_g; g0 += GPL * U) {
-    bool on[U];
-    int32_t e0[U], e1[U], fresh[U];
-    int own[U], pp[U], nbu[U], bbu[U];
-    int32_t bl[U][4];
+    bool on[U], cut[U];
+    int32_t e0[U], e1[U], fresh[U], pr[U], rowu[U], jidx[U];
+    unsigned int hs[U];
+    int own[U], pp[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int g = g0 + u * GPL + sub;
@@ -1599,71 +1650,48 @@ k_xo_jobs_lanes(int64_t N, int64_t first, int32_t* __restrict__ grow,
       own[u] = wave * 64 + (on[u] ? (int)fxlist[wave][g >> 1] : 0);
       pp[u] = g & 1;
       const GnxJobPlan& P = plan[own[u]];
-      const int32_t pr = on[u] ? P.prow[pp[u]] : -1;
-      const int32_t* src = H.hmap + (int64_t)max(pr, 0) * 2 * NB;
+      pr[u] = on[u] ? P.prow[pp[u]] : -1;
+      rowu[u] = P.row;
+      const unsigned int mx = P.mixed[pp[u]];
+      hs[u] = (P.sel[pp[u]] >> q) & 1u;
+      const int32_t* src = H.hmap + (int64_t)max(pr[u], 0) * 2 * NB;
       e0[u] = src[q];
       e1[u] = src[NB + q];
-      const bool cut = on[u] && ((P.mixed[pp[u]] >> q) & 1u) != 0u;
-      const int fr = (pp[u] ? P.m0cnt : 0) + __popc(P.mixed[pp[u]] & below);
-      fresh[u] = cut ? H.stack[P.pop - fr] : 0;
-      // (a job's switch points: the path's first four loci go out with the table loads - a
-      // look-up inside the store phase is a round trip per instruction of the round)
-      nbu[u] = (cut && pr >= 0) ? P.nbp[pp[u]] : 0;
-      bbu[u] = P.b0[pp[u]];
-#pragma unroll
-      for (int z = 0; z < 4; ++z) bl[u][z] = z < nbu[u] ? bp_loci[bbu[u] + z] : 0;
+      cut[u] = on[u] && ((mx >> q) & 1u) != 0u;
+      const int before = __popc(mx & below);
+      fresh[u] = cut[u] ? H.stack[P.pop - ((pp[u] ? P.m0cnt : 0) + before)] : 0;
+      // one job per cut block of a local parent: gamete 0's jobs first
+      jidx[u] = P.job + (pp[u] && P.prow[0] >= 0 ? P.m0cnt : 0) + before;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (!on[u]) continue;
-      const GnxJobPlan& P = plan[own[u]];
-      const int p = pp[u];
-      const int32_t pr = P.prow[p];
-      const unsigned int mx = P.mixed[p];
-      const bool cut = ((mx >> q) & 1u) != 0u;
-      const int hsel = (P.sel[p] >> q) & 1u;
-      const int32_t pv = hsel ? e1[u] : e0[u];
+      const int32_t pv = hs[u] ? e1[u] : e0[u];
       const int32_t sv = GNX_BLK(pv);
-      // the parent's block is shared from now on: it loses its never-shared flag (only the
-      // first child to share it writes)
-      if (!cut && pv < 0) H.hmap[((int64_t)pr * 2 + hsel) * NB + q] = sv;
-      H.hmap[((int64_t)P.row * 2 + p) * NB + q] =
-          cut ? (int32_t)((uint32_t)fresh[u] | GNX_OWN) : sv;
-      if (cut && pr >= 0) {
-        // one job per cut block of a local parent; the switch points inside the block ride
-        // with it (gnx_xo.h: GnxJobBp)
-        const int jr = (p && P.prow[0] >= 0 ? P.m0cnt : 0) + __popc(mx & below);
-        GnxXoJob j;
-        j.ph0 = GNX_BLK(e0[u]);
-        j.ph1 = GNX_BLK(e1[u]);
-        j.dst = fresh[u];
-        j.ks = P.ks[p] | (q << 24);
-        jobs[P.job + jr] = j;
-        unsigned int o0 = 0, o1 = 0, o2 = 0;
-        int nin = 0;
-        const int lo = q * lpb, hi = (q == NB - 1) ? 0x7fffffff : lo + lpb;
-        auto take = [&](int l) __attribute__((always_inline)) {
-          if (l >= lo && l < hi) {
-            const unsigned int o = (unsigned int)(l - lo);
-            o0 = nin == 0 ? o : o0;
-            o1 = nin == 1 ? o : o1;
-            o2 = nin == 2 ? o : o2;
-            ++nin;
-          }
-        };
-#pragma unroll
-        for (int z = 0; z < 4; ++z)
-          if (z < nbu[u]) take(bl[u][z]);
-        for (int z = 4; z < nbu[u]; ++z) take(bp_loci[bbu[u] + z]);
-        // (offsets are 16 bits: a block of more than 65 536 loci looks its path up)
-        const bool inl = bp_off != nullptr && nin <= 3 && lpb <= 65536;
-        const unsigned int meta = (inl ? (unsigned int)nin : 0u) | ((unsigned int)hsel << 2) |
-                                  (inl ? 0u : GNX_BP_MORE);
-        *(uint2*)(jobs_bp + P.job + jr) = make_uint2((o0 & 0xffffu) | (o1 << 16),
-                                                     (o2 & 0xffffu) | (meta << 16));
+      if (on[u]) {
+        // the parent's block is shared from now on: it loses its never-shared flag (only the
+        // first child to share it writes)
+        if (!cut[u] && pv < 0) H.hmap[((int64_t)pr[u] * 2 + hs[u]) * NB + q] = sv;
+        H.hmap[((int64_t)rowu[u] * 2 + pp[u]) * NB + q] =
+            cut[u] ? (int32_t)((uint32_t)fresh[u] | GNX_OWN) : sv;
       }
+      const bool jb = cut[u] && pr[u] >= 0;
+      const unsigned long long jm = __ballot(jb);
+      if (jm == 0ull) continue;                    // (wave-uniform)
+      const int nj = __popcll(jm);
+      if (qn + nj > 64) flush();
+      if (jb) {
+        const int slot = qn + __popcll(jm & lt);
+        jq_a[wave][slot] = make_uint4((unsigned int)GNX_BLK(e0[u]), (unsigned int)GNX_BLK(e1[u]),
+                                      (unsigned int)fresh[u],
+                                      (unsigned int)(plan[own[u]].ks[pp[u]] | (q << 24)));
+        jq_b[wave][slot] = make_uint2((unsigned int)jidx[u],
+                                      (unsigned int)own[u] | ((unsigned int)pp[u] << 16) |
+                                          (hs[u] << 17) | ((unsigned int)q << 24));
+      }
+      qn += nj;
     }
   }
+  flush();
 }
 
 template <int NB>

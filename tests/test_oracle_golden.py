@@ -134,6 +134,49 @@ def test_density_nodes_exact_and_raster_tolerance(tag):
     assert diff.max() <= b_max * ref.max(), (diff.max(), ref.max())
 
 
+@pytest.mark.parametrize('tag', ['a', 'b', 'c', 'd'])
+def test_density_tolerance_is_the_references_own_ambiguity(tag):
+    """Why A13's raster tolerance is what it is.  The reference interpolates the
+    lattice nodes with scipy.interpolate.griddata(method='cubic') (utils/spatial.py:132-146): a
+    Clough-Tocher scheme on qhull's Delaunay triangulation.  The nodes form a REGULAR lattice -
+    every square has two valid diagonals, the triangulation is degenerate, and which diagonal
+    qhull picks depends on the order the points are handed in.  So the reference's raster is one
+    member of a family: its own algorithm, given the same nodes in another order, lands 3-9 % of
+    the peak density away from the committed raster - FARTHER than the build's natural bicubic
+    spline through the same nodes does (a 4.9 %, b 1.2 %, c 3.5 %, d 2.1 %).  No smooth
+    interpolant of the nodes can agree with "the reference" better than the reference agrees
+    with itself; the nodes (exact to 1e-12, test above) are what is pinned."""
+    from scipy.interpolate import griddata
+    g = load_golden('g4_density')
+    dim = tuple(int(v) for v in g[tag + '_dim'])
+    x, y = g[tag + '_x'], g[tag + '_y']
+    lat = O.DensityLattice(dim, g[tag + '_ww'][0])
+    V = lat.node_density(x, y)
+    ref = np.clip(g[tag + '_dens'], 0, None)
+    H, W = ref.shape
+    GX, GY = np.meshgrid(np.arange(W) + 0.5, np.arange(H) + 0.5)
+    PX, PY = np.meshgrid(lat.cx, lat.cy)
+    pts = np.column_stack([PX.ravel(), PY.ravel()])
+    vals = V.ravel()
+    mine = np.abs(O.density_raster(lat, x, y) - ref)
+    ct_max, ct_mean, rasters = [], [], []
+    for seed in range(1, 8):
+        perm = np.random.RandomState(seed).permutation(len(pts))
+        ct = np.clip(np.nan_to_num(griddata(pts[perm], vals[perm], (GX, GY), method='cubic')),
+                     0, None)
+        rasters.append(ct)
+        d = np.abs(ct - ref)
+        ct_max.append(d.max() / ref.max())
+        ct_mean.append(d.mean() / ref.mean())
+    # the reference's algorithm is not one raster: members of its family differ among themselves
+    # by more than the build differs from the committed member
+    spread = (np.max(rasters, axis=0) - np.min(rasters, axis=0)).max() / ref.max()
+    assert mine.max() / ref.max() <= spread, (mine.max() / ref.max(), spread)
+    # ... and the build is as close to the committed raster as a typical other member is
+    assert mine.max() / ref.max() <= np.median(ct_max), (mine.max() / ref.max(), ct_max)
+    assert mine.mean() / ref.mean() <= 1.15 * np.median(ct_mean), (mine.mean() / ref.mean(), ct_mean)
+
+
 # ------------------------------------------------------------------ A14
 @pytest.mark.parametrize('tag', ['a', 'b'])
 def test_demography_algebra(tag):

@@ -34,7 +34,10 @@ if tile:
     dev.comm_selftest()
     dev.set_max_id(int(dev.download(nat.F_ID).max()))
 t = 0
+t_walk = 0.0            # time inside the steps alone (the checks between the pieces excluded)
 while t < steps:
+    dev.synchronize()
+    tw0 = time.perf_counter()
     if walk:
         k = min(every - (t % every), steps - t)
         dev.walk(k, False, True)
@@ -45,6 +48,9 @@ while t < steps:
     else:
         dev.step(False, True)
         t += 1
+    if t % every == 0 or t == steps:
+        dev.synchronize()
+    t_walk += time.perf_counter() - tw0
     if n_mut:
         dev.mutate(rng.randint(0, dev.N, n_mut).astype(np.int64),
                    rng.randint(0, cfg['L'], n_mut).astype(np.int32),
@@ -56,7 +62,8 @@ while t < steps:
         print('step %5d  N=%d births=%d deaths=%d  blocks: logical %d  physical in use %d '
               '(%.1f %% shared)  free %d  %s  %.1f s%s' % (
                   t, n, b, d, 2 * rows, used, 100.0 * (1 - used / max(2 * rows, 1)), free,
-                  'ok' if ok else 'INCONSISTENT', time.time() - t0,
+                  ('ok' if ok else 'INCONSISTENT') + '  %.4f ms/step so far' % (1e3 * t_walk / t),
+                  time.time() - t0,
                   '  (device-driven steps so far: %d)' % dev.totals()['dd_steps'] if walk else ''),
               flush=True)
         if not ok:
