@@ -5,7 +5,9 @@ The reference calls statsmodels.tsa.stattools.adfuller (absent from this image,
 un-pinned in the reference's requirements.txt) and scipy.stats.ttest_rel.
 `adfuller` below restates statsmodels' published algorithm (regression='c',
 autolag='AIC', maxlag = ceil(12 (n/100)^(1/4)), MacKinnon (1994) response-surface
-p-values for N=1); scipy's ttest_rel is used directly.
+p-values for N=1); scipy's ttest_rel is used directly.  Pinned since round 6 to the
+known-answer values of statsmodels' own test suite (Stata's, on the US macro series
+realgdp / infl): tests/golden/adf_macrodata.npz, tests/test_host_logic.py.
 """
 import numpy as np
 from scipy.stats import norm, ttest_rel
@@ -52,36 +54,50 @@ def _ols(y, X):
     return beta, tvalues, aic
 
 
-def adfuller(x):
-    """Augmented Dickey-Fuller test; returns (adfstat, pvalue, usedlag, nobs)."""
+def adfuller(x, maxlag=None, autolag='AIC'):
+    """Augmented Dickey-Fuller test, regression='c' (statsmodels.tsa.stattools.adfuller's
+    defaults, which is how the reference calls it: sim/burnin.py:81,94-96); returns
+    (adfstat, pvalue, usedlag, nobs).  maxlag=None: ceil(12 (n/100)^(1/4)); autolag='AIC'
+    picks the lag length among 0..maxlag by AIC, autolag=None uses maxlag lags.  Pinned to
+    statsmodels' own test-suite values (tests/test_host_logic.py, tests/golden/adf_macrodata.npz)."""
     x = np.asarray(x, dtype=float)
     if x.ndim != 1:
         raise ValueError('x must be 1d')
     if x.max() == x.min():
         raise ValueError('Invalid input, x is constant')
+    if autolag not in (None, 'AIC', 'aic'):
+        raise ValueError("autolag must be None or 'AIC'")
     nobs = x.shape[0]
     ntrend = 1
-    maxlag = int(np.ceil(12.0 * np.power(nobs / 100.0, 1 / 4.0)))
-    maxlag = min(nobs // 2 - ntrend - 1, maxlag)
-    if maxlag < 0:
-        raise ValueError('sample size is too short to use selected regression component')
+    if maxlag is None:
+        maxlag = int(np.ceil(12.0 * np.power(nobs / 100.0, 1 / 4.0)))
+        maxlag = min(nobs // 2 - ntrend - 1, maxlag)
+        if maxlag < 0:
+            raise ValueError('sample size is too short to use selected regression component')
+    elif maxlag > nobs // 2 - ntrend - 1:
+        raise ValueError('maxlag must be less than (nobs/2 - 1 - ntrend) where n trend is '
+                         'the number of included deterministic regressors')
     xdiff = np.diff(x)
     xdall = _lagmat_both_in(xdiff, maxlag)
     nobs = xdall.shape[0]
     xdall[:, 0] = x[-nobs - 1:-1]
     xdshort = xdiff[-nobs:]
-    # autolag = 'AIC': regressions on [const, level, dlag_1..dlag_m], m = 0..maxlag
-    full = np.column_stack([np.ones(nobs), xdall])
-    startlag = 2
-    best_aic, bestlag = None, 0
-    for lag in range(startlag, startlag + maxlag + 1):
-        _, _, aic = _ols(xdshort, full[:, :lag])
-        if best_aic is None or aic < best_aic:
-            best_aic, bestlag = aic, lag - startlag
-    xdall = _lagmat_both_in(xdiff, bestlag)
-    nobs = xdall.shape[0]
-    xdall[:, 0] = x[-nobs - 1:-1]
-    xdshort = xdiff[-nobs:]
+    if autolag is None:
+        bestlag = maxlag
+    else:
+        # regressions on [const, level, dlag_1..dlag_m], m = 0..maxlag, over the SAME rows
+        full = np.column_stack([np.ones(nobs), xdall])
+        startlag = 2
+        best_aic, bestlag = None, 0
+        for lag in range(startlag, startlag + maxlag + 1):
+            _, _, aic = _ols(xdshort, full[:, :lag])
+            if best_aic is None or aic < best_aic:
+                best_aic, bestlag = aic, lag - startlag
+        # the chosen lag length is re-estimated on all the rows it leaves
+        xdall = _lagmat_both_in(xdiff, bestlag)
+        nobs = xdall.shape[0]
+        xdall[:, 0] = x[-nobs - 1:-1]
+        xdshort = xdiff[-nobs:]
     X = np.column_stack([xdall[:, :bestlag + 1], np.ones(nobs)])
     _, tvalues, _ = _ols(xdshort, X)
     adfstat = float(tvalues[0])

@@ -116,6 +116,33 @@ def test_starting_counts_match_oracle():
                                   O.starting_mutation_counts(77, p))
 
 
+def test_adfuller_reproduces_statsmodels_known_answers():
+    """The burn-in gate's ADF test pinned to the known answers of statsmodels' own
+    test suite - Stata's values on the US macro series (statsmodels 0.12.2,
+    tsa/tests/test_stattools.py:66-146, tsa/tests/test_adfuller_lag.py:13-43; the series are
+    committed as data, tests/golden/make_adf_fixture.py) - to the 5 decimals that suite asserts."""
+    from geonomics_amd.sim.burnin import adfuller
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden',
+                             'adf_macrodata.npz'))
+    for series, key in (('realgdp', 'constant_realgdp'), ('infl', 'constant_infl')):
+        maxlag, stat, p = g[key]
+        got = adfuller(g[series], maxlag=int(maxlag), autolag=None)
+        assert abs(got[0] - stat) < 1.5e-5, (series, got, stat)
+        assert abs(got[1] - p) < 1.5e-5, (series, got, p)
+        assert got[2] == int(maxlag)
+    # autolag='AIC' with the default maxlag: 16 candidate lag lengths on 203 observations, the
+    # chosen one is 2, and the result is that of a fixed lag of 2
+    x = np.log(g['realgdp'])
+    n_cand, usedlag = (int(v) for v in g['autolag_log_realgdp'])
+    assert int(np.ceil(12.0 * (x.size / 100.0) ** 0.25)) + 1 == n_cand
+    auto = adfuller(x)
+    assert auto[2] == usedlag
+    fixed = adfuller(x, maxlag=usedlag, autolag=None)
+    assert abs(auto[0] - fixed[0]) < 1e-12 and abs(auto[1] - fixed[1]) < 1e-12
+    with pytest.raises(ValueError):
+        adfuller(x, maxlag=150)
+
+
 def test_adfuller_behaviour():
     from geonomics_amd.sim.burnin import adfuller, mackinnonp
     rng = np.random.RandomState(0)
