@@ -1220,6 +1220,8 @@ extern "C" int gnx_step_begin(gnx_state* h, int32_t burn) {
 extern "C" int gnx_step_mid(gnx_state* h, int32_t burn, int32_t with_selection) {
   GnxStepTimer timer(false);
   int64_t P = 0, B = 0;
+  // (the births go on the stream before the host has the pair count: gnx_l_offspring_ahead)
+  GNXCHK(gnx_l_offspring_ahead(h, burn != 0));
   GNXCHK(gnx_l_find_pairs_finish(h, &P));
   if (P > 0 && !h->spl_P.valid)
     GNXCHK(gnx_l_density(h, P, h->mid_x, h->mid_y, &h->spl_P, nullptr));

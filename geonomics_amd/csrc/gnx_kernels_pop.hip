@@ -2087,6 +2087,9 @@ struct OffP {
   // the sort's permutation (pmap[sorted slot] = the slot before the sort)
   const uint64_t* ptb;
   const int32_t* pmap;
+  // the births launched AHEAD of the host's read-back of the pair count (gnx_l_offspring_ahead):
+  // the grid covers what the population could bear, the pair count comes from the device
+  const int32_t* P_dev;
 };
 
 // gamete requests of a tiled run: the mate is a ghost (it lives on a neighbour
@@ -2129,6 +2132,11 @@ k_offspring(OffP P, GnxSoA s, const float* rast, const int32_t* pairs, const int
     P.B = P.dd->B;
     P.id_base = P.dd->max_id + 1;
     P.step = P.dd->step;
+  }
+  if (P.P_dev) {
+    // (a step whose births do not fit: nothing is written, the host raises once it has the count)
+    P.B = (int64_t)*P.P_dev * P.fixed_nb;
+    if (P.N + P.B > P.cap || (P.genomes && P.B > P.n_free)) return;
   }
   if (k >= P.B) return;
   int64_t p, ord;
@@ -2360,6 +2368,7 @@ static OffP gnx_make_offp(gnx_state* h, bool genomes, bool tiled, int64_t id_bas
   Q.path_sel = h->path_sel;
   Q.dom = h->dom;
   Q.bins = GnxBinP{nullptr, 1.0 / h->lat.hww, h->lat.nbx, h->lat.nby};
+  Q.P_dev = nullptr;
   Q.ptb = h->soa[h->cur].tb;
   Q.pmap = nullptr;
   if (h->perm_rest_late && (h->perm_rest_inflight || h->perm_rest_pending)) {
@@ -2367,6 +2376,54 @@ static OffP gnx_make_offp(gnx_state* h, bool genomes, bool tiled, int64_t id_bas
     Q.pmap = h->perm[1];
   }
   return Q;
+}
+
+// gnx_step, one device, a fixed number of births per pair: the births kernel goes on the stream
+// BEFORE the host has read the pair count back (gnx_l_find_pairs_finish).  The host's wait for
+// the count and its enqueueing of everything behind the births then run while k_offspring
+// does, instead of leaving the chip idle between the pair list and the births (~15 us of a
+// 0.55-ms step, profiles/r06_timeline.txt) and again behind them.  The kernel takes the pair
+// count from the device word k_pair_compact leaves (cnt_dev[0]); its grid covers the births the
+// population could have at most (every individual the focal one of a pair); the host's checks
+// (capacity, free genome rows) follow in gnx_l_mate once it has the count - a step that does not
+// fit has written nothing by then (the kernel checks the same bounds itself).
+// Same kernel, same arguments as gnx_l_mate's own launch: the reference's order of events
+// (structs/species.py:595-805: pairs, then births) is the stream's.
+int gnx_l_offspring_ahead(gnx_state* h, bool burn) {
+  // (measured, profiles/r06_ab_runs.txt: 0.544 against 0.542 ms/step - the gap in front of the
+  // births is not the host's wait but the event hand-over to the side stream that precedes them;
+  // parity-green, kept behind GNX_BIRTHS_AHEAD=1)
+  static const bool on = getenv("GNX_BIRTHS_AHEAD") && atoi(getenv("GNX_BIRTHS_AHEAD")) != 0;
+  h->births_ahead = false;
+  const gnx_config& c = h->cfg;
+  const gnx_species_params& sp = h->sp;
+  if (!on || !h->pairs_wait || h->tiled || h->tile2_mode || !sp.n_births_fixed ||
+      sp.n_births_lambda < 1 || sp.mating_radius < 0 || h->N == 0 || h->dd_active ||
+      (h->profiling && h->profile_only < 0))        // (every family timed: the births by themselves)
+    return 0;
+  const int64_t lam = (int64_t)sp.n_births_lambda;
+  const int64_t room = c.cap_inds - h->N;
+  if (room <= 0) return 0;
+  GNXCHK(gnx_xo_flush_deferred(h));
+  const bool genomes = !burn && c.L > 0 && h->genomes_assigned;
+  GnxSoA s = h->soa[h->cur];
+  // (tile-major offspring ids: k_pair_compact's classification, flags only - gnx_l_mate repeats it)
+  if (h->id_order == 1) GNXCHK(gnx_l_pair_cls(h, -1, true));
+  OffP Q = gnx_make_offp(h, genomes, false, -1, 0);
+  Q.P_dev = h->cnt_dev;
+  if (gnx_fused_bins(h) && h->fb_adults && h->fb_count == h->N) Q.bins.bins = h->fb[h->fb_cur];
+  int32_t* ord_tail = nullptr;
+  if (h->pair_goff_ready && h->pair_goff_local_base && h->ord_mode && h->ord_valid && h->ord_n == h->N)
+    ord_tail = h->ord[h->ord_cur] + h->ord_n;
+  GnxGoff gf{};
+  if (h->pair_goff_ready) gf = gnx_goff_vt(h);
+  const int64_t bound = std::min(h->N * lam, room);
+  hipLaunchKernelGGL(k_offspring, dim3(gnx_grid(bound, 256)), dim3(256), 0, h->stream, Q, s, h->rast,
+                     h->pairs, h->off_pair, h->boff, gf, h->off_parent, h->off_keys, h->off_start,
+                     GnxReq{}, gnx_trait_tab(h), ord_tail);
+  HIPCHK(hipGetLastError());
+  h->births_ahead = true;
+  return 0;
 }
 
 // Appends the offspring of the current pair list (or, inject: of the uploaded
@@ -2380,6 +2437,12 @@ int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* 
   *births_out = 0;
   int64_t B = 0;
   bool ord_tail_used = false;
+  const bool ahead = h->births_ahead;       // k_offspring is already on the stream (gnx_l_offspring_ahead)
+  h->births_ahead = false;
+  if (ahead && (tiled || inject)) {
+    gnx_set_error("births launched ahead of a tiled / injected mating");
+    return 1;
+  }
   GNXCHK(gnx_xo_flush_deferred(h));
   bool genomes = !burn && c.L > 0 && h->genomes_assigned;
   if (inject) {
@@ -2441,12 +2504,17 @@ int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* 
     GnxGoff gf{};
     if (h->pair_goff_ready) gf = gnx_goff_vt(h);
     else if (tiled && !h->pair_goff_local) gf.goff = h->pair_goff;
-    gnx_time_begin(h);
-    hipLaunchKernelGGL(k_offspring, dim3(gnx_grid(B, 256)), dim3(256), 0, h->stream, Q, s, h->rast,
-                       h->pairs, h->off_pair, h->boff, gf,
-                       h->off_parent, h->off_keys, h->off_start, rq, gnx_trait_tab(h), ord_tail);
-    gnx_time_end(h, GNX_K_OFFSPRING, (double)B * (60.0 + 8.0 * c.n_layers + 48.0 * h->TW +
-                                                  4.0 * c.n_traits));
+    if (!ahead) {
+      gnx_time_begin(h);
+      hipLaunchKernelGGL(k_offspring, dim3(gnx_grid(B, 256)), dim3(256), 0, h->stream, Q, s, h->rast,
+                         h->pairs, h->off_pair, h->boff, gf,
+                         h->off_parent, h->off_keys, h->off_start, rq, gnx_trait_tab(h), ord_tail);
+      gnx_time_end(h, GNX_K_OFFSPRING, (double)B * (60.0 + 8.0 * c.n_layers + 48.0 * h->TW +
+                                                    4.0 * c.n_traits));
+    } else if (h->profiling && h->profile_only < 0) {
+      h->timers[GNX_K_OFFSPRING].bytes += (double)B * (60.0 + 8.0 * c.n_layers + 48.0 * h->TW +
+                                                       4.0 * c.n_traits);
+    }
     if (tiled && genomes) {
       // the number of gamete requests is known before the crossover is launched: the host
       // layer serves the neighbour tiles while the crossover runs.  (tile2: it was counted
