@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out
 cd "$ROOT"
 for WL in c2 c3 c4_dense; do
   rm -rf $OUT/prof_${TAG}_$WL
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_$WL -o run -- python3 bench.py --workload $WL --steps 30 --warmup 5 --no-cpu-baseline --no-model-api --no-other-workloads > $OUT/prof_${TAG}_${WL}_bench.json 2> $OUT/prof_${TAG}_${WL}.err || tail -3 $OUT/prof_${TAG}_${WL}.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_$WL -o run -- python3 bench.py --workload $WL --steps 30 --warmup 5 --no-cpu-baseline --no-model-api --no-other-workloads --steady-warmup 0 > $OUT/prof_${TAG}_${WL}_bench.json 2> $OUT/prof_${TAG}_${WL}.err || tail -3 $OUT/prof_${TAG}_${WL}.err
   ST=$(find $OUT/prof_${TAG}_$WL -name '*kernel_stats.csv' | head -1)
   TR=$(find $OUT/prof_${TAG}_$WL -name '*kernel_trace.csv' | head -1)
   cp $ST $OUT/${TAG}_${WL}_kernel_stats.csv

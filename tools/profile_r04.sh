@@ -30,7 +30,7 @@ if [[ $PART == *c* ]]; then
 rocprofv3 --kernel-trace --output-format csv -d $O/busy_trace -o run -- python3 tools/tile_thread_bench.py 2 30 > $O/busy_out.txt 2>&1
 TR=$(find $O/busy_trace -name "*kernel_trace.csv" | head -1); python3 tools/busy.py $TR 12 > $O/tile_threads_busy.txt; rm -rf $O/busy_trace
 head -1 $O/tile_threads_busy.txt
-GNX_BENCH_FORCE_STEPPER=1 python3 bench.py --no-cpu-baseline --no-model-api --no-other-workloads > $O/stepper_one_tile.json 2>/dev/null
+GNX_BENCH_FORCE_STEPPER=1 python3 bench.py --no-cpu-baseline --no-model-api --no-other-workloads --steady-warmup 0 > $O/stepper_one_tile.json 2>/dev/null
 { for v in "" "--tile-step"; do echo "[kbench.py $v]"; GNX_HOST_TIMES=2 python3 tools/kbench.py --genomes --steps 300 --no-profile $v 2>&1 | grep -E "^N=|host marks"; done; } > $O/tile_step_one_rank.txt
 echo "tiles done"
 python3 bench.py > $O/bench_final.json 2> $O/bench_final.err

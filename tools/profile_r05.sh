@@ -26,7 +26,7 @@ rocprofv3 --kernel-trace --output-format csv -d $O/busy_trace -o run -- python3 
 TR=$(find $O/busy_trace -name "*kernel_trace.csv" | head -1); python3 tools/busy.py $TR 14 > $O/tile_threads_busy.txt; rm -rf $O/busy_trace
 head -1 $O/tile_threads_busy.txt
 # one tile through the tile protocol (the Model API's and the multi-GPU bench's path) against the plain step
-GNX_BENCH_FORCE_STEPPER=1 python3 bench.py --no-cpu-baseline --no-model-api --no-other-workloads > $O/stepper_one_tile.json 2>/dev/null
+GNX_BENCH_FORCE_STEPPER=1 python3 bench.py --no-cpu-baseline --no-model-api --no-other-workloads --steady-warmup 0 > $O/stepper_one_tile.json 2>/dev/null
 { for v in "" "--tile-step"; do echo "[kbench.py $v]"; GNX_HOST_TIMES=2 python3 tools/kbench.py --genomes --steps 300 --no-profile $v 2>&1 | grep -E "^N=|host marks"; done; } > $O/tile_step_one_rank.txt
 tools/timeline.sh r05_stepper_tl c4_metric GNX_BENCH_FORCE_STEPPER=1 > $O/timeline_stepper.log 2>&1; head -1 $O/timeline_stepper.log
 echo "tiles done"

@@ -14,7 +14,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd "$ROOT"
 rm -rf $OUT/trace
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o run -- python3 bench.py --workload $WL --steps 20 --warmup 5 --no-cpu-baseline --no-model-api --no-other-workloads > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err || { tail -5 $OUT/rocprof.err; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o run -- python3 bench.py --workload $WL --steps 20 --warmup 5 --no-cpu-baseline --no-model-api --no-other-workloads --steady-warmup 0 > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err || { tail -5 $OUT/rocprof.err; exit 1; }
 TR=$(find $OUT/trace -name '*kernel_trace.csv' | head -1)
 ST=$(find $OUT/trace -name '*kernel_stats.csv' | head -1)
 python3 tools/trace_timeline.py $TR > $OUT/timeline.txt
