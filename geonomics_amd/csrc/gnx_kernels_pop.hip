@@ -1718,7 +1718,9 @@ k_pair_flags(PairP P, GnxSoA s, int32_t* flag2, int32_t* cnt, GnxVtOut vt) {
         const int m = P.mate[i];
         if (P.mate[m] == (int32_t)i && s.id[m] < s.id[i] && pair_ok(P, s, m)) ok = false;
       }
-      if (s.ghost[i]) ok = false;
+      // (a pair belongs to the tile that owns its focal individual: slot i itself, or - panmixia -
+      // the individual the trial of slot i drew)
+      if (s.ghost[P.focal ? P.focal[i] : (int)i]) ok = false;
       f[r] = ok;
       flag2[i] = ok ? 1 : 0;
     }

@@ -99,6 +99,17 @@ __global__ void k_mark_halo(int64_t N, const float* x, const float* y, const uin
   flag[i] = m ? 1 : 0;
 }
 
+// Panmixia (mating_radius None, structs/species.py:2178-2194: both members of a pair drawn
+// uniformly from the WHOLE population): every other tile needs every individual - the halo is
+// everybody, to every neighbour bit.
+__global__ void k_mark_everybody(int64_t N, const uint8_t* ghost, int32_t* flag, int32_t* mask) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int m = ghost[i] ? 0 : 0x1EF;
+  mask[i] = m;
+  flag[i] = m ? 1 : 0;
+}
+
 static HaloSpans halo_spans(const gnx_state* h) {
   HaloSpans sp;
   const int tw = h->cfg.W / h->tile_C, th = h->cfg.H / h->tile_R;
@@ -240,8 +251,12 @@ extern "C" int gnx_tile_export_halo(gnx_state* h, int64_t* n_out) {
   int64_t N = h->N;
   if (N == 0) return 0;
   GnxSoA s = h->soa[h->cur];
-  hipLaunchKernelGGL(k_mark_halo, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, s.x, s.y,
-                     s.ghost, halo_spans(h), h->inv_cs, h->ncx, h->ncy, h->flag, h->mate);
+  if (h->have_sp && h->sp.mating_radius < 0)
+    hipLaunchKernelGGL(k_mark_everybody, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, s.ghost,
+                       h->flag, h->mate);
+  else
+    hipLaunchKernelGGL(k_mark_halo, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, s.x, s.y,
+                       s.ghost, halo_spans(h), h->inv_cs, h->ncx, h->ncy, h->flag, h->mate);
   return stage_selection(h, h->mate, false, false, n_out);
 }
 
@@ -325,10 +340,10 @@ extern "C" int gnx_tile_pairs(gnx_state* h, int32_t burn, int64_t* n_pairs, int6
     gnx_set_error("species parameters not set");
     return 1;
   }
-  if (h->sp.mating_radius < 0) {
-    gnx_set_error("panmixia (mating_radius None) is not supported on a tiled landscape");
-    return 1;
-  }
+  // (panmixia: every tile holds everybody - its own individuals and all the others as ghosts,
+  // gnx_tile_export_halo - in the canonical (hash cell, id) order, so the trials' draws name the
+  // same individuals on every tile as on one device; a pair belongs to the tile that owns its
+  // focal individual (k_pair_flags).  The Python-driven protocol only: gnx_tile2_pairs refuses.)
   int64_t P = 0, B = 0;
   GNXCHK(gnx_l_sort_by_cell(h));
   GNXCHK(gnx_l_find_pairs(h, nullptr, &P));
@@ -1592,7 +1607,8 @@ extern "C" int gnx_tile2_pairs(gnx_state* h, int32_t burn, int64_t* counts) {
     return 1;
   }
   if (h->sp.mating_radius < 0) {
-    gnx_set_error("panmixia (mating_radius None) is not supported on a tiled landscape");
+    gnx_set_error("panmixia (mating_radius None) on tiles runs through the Python-driven protocol "
+                  "(gnx_tile_pairs: every tile holds everybody's record), not through gnx_tile_step");
     return 1;
   }
   GNXCHK(tile2_buffers(h));

@@ -455,8 +455,13 @@ class TiledStepper:
         assert W % self.C == 0 and H % self.R == 0, 'tiles must divide the landscape'
         self.tw, self.th = W // self.C, H // self.R
         self.r, self.c = divmod(comm.rank, self.C)
-        self.radius = float(mating_radius)
-        if comm.world > 1:
+        # panmixia (mating_radius None, reference structs/species.py:2178-2194): every tile holds
+        # everybody - its own individuals and all the others as ghosts - and the pairs whose focal
+        # individual it owns; the Python-driven protocol with host-staged payloads (it need not be
+        # fast: an all-to-all of the whole population's records every step)
+        self.panmixia = mating_radius is None or float(mating_radius) < 0
+        self.radius = -1.0 if self.panmixia else float(mating_radius)
+        if comm.world > 1 and not self.panmixia:
             # the halo is made of whole hash cells (2 rings); it must come from the
             # adjacent tiles only
             cs = max(self.radius * (1.0 + 1e-9), max(W, H) / 2048.0)
@@ -479,13 +484,15 @@ class TiledStepper:
             assert hasattr(shard, 'dev') and getattr(comm, 'device', 'cpu') == 'cuda', (
                 'GNX_TILE_TRANSPORT=device needs the HIP shard and a device-capable backend')
             self.dev_transport = comm.world > 1
+        if self.panmixia:
+            self.dev_transport = False
         self.profile = bool(os.environ.get('GNX_TILE_PROFILE'))
         self.phase_s = {}
         self._t0 = 0.0
         # the device-driven protocol (tile2, include/gnx_hip.h): the HIP shard with a
         # transport that moves device memory, or a single tile
         self.v2 = (hasattr(shard, 'dev') and os.environ.get('GNX_TILE_V2', '1') != '0' and
-                   (comm.world == 1 or self.dev_transport))
+                   (comm.world == 1 or self.dev_transport) and not self.panmixia)
         # One C call per step, the exchanges issued by the library itself on its own stream
         # (gnx_tile_step, csrc/gnx_comm.hip: grouped ncclSend / ncclRecv, KB-sized collectives,
         # no torch.distributed call and no Python between the phases of a step); with a per-step
@@ -713,6 +720,16 @@ class TiledStepper:
         rec = self.shard.export_halo()
         w = self.comm.world
         send = [np.zeros(0, np.uint8)] * w
+        if self.panmixia:
+            # everybody to everybody
+            blob = rec.view(np.uint8).ravel()
+            send = [blob if p != self.comm.rank else np.zeros(0, np.uint8) for p in range(w)]
+            self.bytes_sent += blob.size * (w - 1)
+            recv = self.comm.alltoallv(send)
+            ghosts = _cat([b.view(nat.IND_REC) for p, b in enumerate(recv)
+                           if p != self.comm.rank and b.size], nat.IND_REC)
+            self.shard.import_ghosts(ghosts)
+            return
         for dy in (-1, 0, 1):
             for dx in (-1, 0, 1):
                 if dx == 0 and dy == 0:

@@ -20,7 +20,8 @@ What changes with respect to the single-GPU Species:
 Mutations: every rank draws the same list from the host generator and applies those
 whose offspring it owns (_mutate_tiled); the pedigree tables are kept whole on every
 rank (birth records gathered each step); linkage r^2 from counts summed over the tiles
-(sim/stats.py).  Not supported on several GPUs: panmixia.
+(sim/stats.py).  Panmixia (mating_radius None): every tile holds everybody's record, the
+Python-driven protocol (parallel.py) - correct, not fast.
 """
 import numpy as np
 
@@ -47,12 +48,14 @@ class TiledSpecies(Species):
         import os
         margin = float(os.environ.get('GNX_TILE_ROW_MARGIN', '2.0'))
         rows = int(cap / self._comm.world * margin) + 1024
+        if self.mating_radius is None:
+            # panmixia: every tile holds everybody's record (its own individuals and all the
+            # others as ghosts) - slots for the whole population; genome rows for its own share
+            return cap, rows
         return max(int(N0 * 1.02) + 1024, rows), rows
 
 
     def _after_init_population(self, N):
-        if self.mating_radius is None:
-            raise NotImplementedError('panmixia is not supported on a tiled landscape')
         W, H = self._land_dim
         self._shard = DeviceShard(self._dev)
         from ..parallel import tile_grid
@@ -66,7 +69,8 @@ class TiledSpecies(Species):
         # (mutations, pedigree rows) between them; else the Python-driven protocol over
         # torch.distributed (gloo rehearsals), with the same offspring ids either way.
         self._stepper = TiledStepper(
-            self._shard, self._comm, W, H, float(self.mating_radius), move=self._move,
+            self._shard, self._comm, W, H,
+            None if self.mating_radius is None else float(self.mating_radius), move=self._move,
             max_id=N - 1,
             fixed_births=int(self.n_births_distr_lambda) if self.n_births_fixed else 0)
         self._shard.export_migrants()       # every rank drew all N; keep this tile's

@@ -102,6 +102,10 @@ class OracleShard:
         1 ring for the candidates of its own focal individuals, 1 more so that the
         ghosts its individuals can choose have complete candidate lists themselves."""
         s = self.s
+        if s.p.mating_radius is None or s.p.mating_radius < 0:
+            # panmixia: everybody is everybody's halo (csrc/gnx_tile.hip: k_mark_everybody)
+            own = ~self.ghost
+            return self._records(own, np.where(own, 0x1EF, 0).astype(np.int32))
         inv_cs, ncx, ncy = O.hash_grid((s.W, s.H), s.p.mating_radius)
         _, cxi, cyi = O.cell_of(s.x, s.y, inv_cs, ncx, ncy)
         tw, th = s.W // self.C, s.H // self.R
@@ -135,6 +139,8 @@ class OracleShard:
     def pairs(self, burn):
         s, p = self.s, self.s.p
         n = s.N
+        if p.mating_radius is None or p.mating_radius < 0:
+            return self._pairs_panmixia()
         keep = D.keep_draws(s.seed, s.id, s.step, p.b)
         mate = S.choose_mates_fast(s) if p.mate_mode == 'uniform' else O.choose_mates(
             s.x, s.y, s.id, p.mating_radius, s.seed, s.step, mode=p.mate_mode)
@@ -152,6 +158,41 @@ class OracleShard:
         pr = np.stack([i, mate[i]], 1) if i.size else np.zeros((0, 2), np.int64)
         self.pair_keys = O.pair_order_keys(s.x[pr[:, 0]], s.y[pr[:, 0]], s.id[pr[:, 0]],
                                            (s.W, s.H), p.mating_radius, p.mate_mode)
+        o = np.argsort(self.pair_keys, kind='stable')
+        pr, self.pair_keys = pr[o], self.pair_keys[o]
+        self.pairs_ = pr
+        if p.n_births_fixed:
+            self.nb = np.full(len(pr), int(p.n_births_lambda), np.int64)
+        else:
+            self.nb = D.births_draws(s.seed, s.id[pr[:, 0]], s.step,
+                                     p.n_births_lambda).astype(np.int64)
+        mx = (s.x[pr[:, 0]] + s.x[pr[:, 1]]) / F(2.0)
+        my = (s.y[pr[:, 0]] + s.y[pr[:, 1]]) / F(2.0)
+        self.bins[1] = s.lat.bins(mx, my).ravel().astype(np.int32)
+        return len(pr), int(self.nb.sum())
+
+    def _pairs_panmixia(self):
+        """structs/species.py:2178-2194 on a tile that holds EVERYBODY (its own individuals and all
+        the others as ghosts): the population in the canonical (hash cell, id) order, one
+        Bernoulli(b) trial per slot with two uniform draws (oracle/gnx_step.py: find_pairs), the
+        pairs whose focal individual lives here, ordered by their trial's slot"""
+        s, p = self.s, self.s.p
+        inv_cs, ncx, ncy = O.hash_grid((s.W, s.H), -1.0)
+        cell, _, _ = O.cell_of(s.x, s.y, inv_cs, ncx, ncy)
+        order = np.lexsort((s.id, cell))
+        S._permute(s, order)
+        self.ghost = self.ghost[order]
+        n = s.N
+        keep = D.keep_draws(s.seed, s.id, s.step, p.b)
+        f, m = D.panmixia_draws(s.seed, s.id, s.step, n)
+        ok = keep & (f != m)
+        ok &= (s.age[f] >= p.repro_age[0]) & (s.age[m] >= p.repro_age[1])
+        if p.sexed:
+            ok &= (s.sex[f] == 0) & (s.sex[m] == 1)
+        ok &= ~self.ghost[f]
+        trial = np.nonzero(ok)[0]
+        pr = np.stack([f[ok], m[ok]], 1) if trial.size else np.zeros((0, 2), np.int64)
+        self.pair_keys = O.pair_order_keys(s.x[trial], s.y[trial], s.id[trial], (s.W, s.H), None)
         o = np.argsort(self.pair_keys, kind='stable')
         pr, self.pair_keys = pr[o], self.pair_keys[o]
         self.pairs_ = pr

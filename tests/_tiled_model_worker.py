@@ -2,7 +2,7 @@
 what a user's model script would be: it builds the params and calls make_model / run;
 the tiling comes from the torch.distributed environment alone.
 
-    python tests/_tiled_model_worker.py <out.npz> <traits 0|1> <workdir> [mutate] [poisson]
+    python tests/_tiled_model_worker.py <out.npz> <traits 0|1> <workdir> [mutate] [poisson] [panmixia]
 
 `run_model` is also called directly by the tests that rehearse the ranks as THREADS of one
 process (the library's own tile protocol needs a transport that moves device memory between
@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 
-def run_model(traits, mutate=False, poisson=False, rank=0, world=1):
+def run_model(traits, mutate=False, poisson=False, rank=0, world=1, panmixia=False):
     """builds the model, burns it in, walks 15 main steps; returns what the tests compare
     (every rank returns the same: accessors are global)"""
     import geonomics_amd as gnx
@@ -32,6 +32,8 @@ def run_model(traits, mutate=False, poisson=False, rank=0, world=1):
     if poisson:
         p['comm']['species']['spp_0']['mating'].update({'n_births_fixed': False,
                                                         'n_births_distr_lambda': 1.5})
+    if panmixia:      # mating_radius None: pairs drawn from the whole population
+        p['comm']['species']['spp_0']['mating']['mating_radius'] = None
     p['model']['stats'] = ParametersDict({'Nt': {'calc': True, 'freq': 1},
                                           'het': {'calc': True, 'freq': 5, 'mean': False},
                                           'maf': {'calc': True, 'freq': 5},
@@ -74,6 +76,7 @@ if __name__ == '__main__':
     flags = sys.argv[4:]
     os.chdir(workdir)
     res = run_model(traits, mutate='mutate' in flags, poisson='poisson' in flags,
+                    panmixia='panmixia' in flags,
                     rank=int(os.environ.get('RANK', '0')),
                     world=int(os.environ.get('WORLD_SIZE', 1)))
     if int(os.environ.get('RANK', '0')) == 0:

@@ -47,7 +47,7 @@ def make_device_shard(cfg, n_births_fixed=True):
                      cap_rows=16384, seed=cfg['seed'], device=0)
     dev.upload_rasters(cfg['rasts'])
     dev.set_species_params(nat.default_species_params(
-        mating_radius=cfg['radius'], K_factor=cfg['K_factor'],
+        mating_radius=-1.0 if cfg['radius'] is None else cfg['radius'], K_factor=cfg['K_factor'],
         n_births_fixed=int(n_births_fixed), n_births_lambda=1))
     dev.set_trait(0, cfg['loci'], cfg['alpha'], 1, 0.05, 1.0, False)
     dev.set_recomb_paths(cfg['paths'])
@@ -55,7 +55,7 @@ def make_device_shard(cfg, n_births_fixed=True):
     return DeviceShard(dev), dev
 
 
-def run(backend, shard_kind, world, rank, port, steps, out, fixed=True):
+def run(backend, shard_kind, world, rank, port, steps, out, fixed=True, panmixia=False):
     from geonomics_amd.parallel import Comm, TiledStepper
     import gnx_oracle as O
     dist = None
@@ -66,6 +66,9 @@ def run(backend, shard_kind, world, rank, port, steps, out, fixed=True):
         dist.init_process_group(backend, rank=rank, world_size=world)
     comm = Comm(dist)
     cfg = config()
+    if panmixia:
+        # mating_radius None (reference structs/species.py:2178-2194): pairs drawn from everybody
+        cfg['radius'] = None
     if shard_kind == 'oracle':
         shard, st = make_oracle_shard(cfg, fixed)
     else:
@@ -138,4 +141,5 @@ def run(backend, shard_kind, world, rank, port, steps, out, fixed=True):
 if __name__ == '__main__':
     a = sys.argv
     run(a[1], a[2], int(a[3]), int(a[4]), int(a[5]), int(a[6]), a[7],
-        fixed=(len(a) < 9 or a[8] == 'fixed'))
+        fixed=(len(a) < 9 or a[8] in ('fixed', 'panmixia')),
+        panmixia=(len(a) >= 9 and a[8] == 'panmixia'))

@@ -14,7 +14,8 @@ from test_tiling_cpu import launch          # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('world,mode', [(2, 'fixed'), (4, 'poisson')])
+@pytest.mark.parametrize('world,mode', [(2, 'fixed'), (4, 'poisson'), (2, 'panmixia'),
+                                        (4, 'panmixia')])
 def test_tiled_device_run_is_bit_identical_to_single_tile(tmp_path, world, mode):
     steps = 8
     one = launch('gloo', 'device', 1, steps, str(tmp_path / 'one.npz'), mode)
@@ -73,6 +74,39 @@ def test_single_tile_stepper_equals_gnx_step():
     ga = dev_a.download(nat.F_GENO)[np.argsort(dev_a.download(nat.F_ID))]
     gb = dev_b.download(nat.F_GENO)[np.argsort(dev_b.download(nat.F_ID))]
     np.testing.assert_array_equal(ga, gb)
+
+
+def test_panmixia_on_tiles_equals_gnx_step(tmp_path):
+    """mating_radius None (reference structs/species.py:2178-2194) on a tiled landscape: two tiles
+    over gloo (every tile holds everybody's record, the pairs of its own focal individuals) give
+    the population gnx_step gives on ONE device - ids, positions, ages, phenotypes, genotypes"""
+    from _tiling_worker import config, make_device_shard
+    from geonomics_amd import _native as nat
+    import gnx_oracle as O
+    cfg = config()
+    cfg['radius'] = None
+    steps = 8
+    many = launch('gloo', 'device', 2, steps, str(tmp_path / 'many.npz'), 'panmixia')
+    _, dev = make_device_shard(cfg)
+    hist = []
+    for t in range(steps):
+        burn = t < cfg['n_burn']
+        if t == cfg['n_burn']:
+            ids = np.sort(dev.download(nat.F_ID))
+            n_site = O.starting_mutation_counts(dev.N, np.full(cfg['L'], 0.5))
+            G = O.starting_genomes(dev.N, cfg['L'], n_site, cfg['seed'])
+            dev.upload_genomes(G[np.searchsorted(ids, dev.download(nat.F_ID))])
+        dev.step(burn, not burn)
+        hist.append(dev.counts())
+    assert [list(h) for h in hist] == many['hist'].tolist()
+    o = np.argsort(dev.download(nat.F_ID))
+    np.testing.assert_array_equal(dev.download(nat.F_ID)[o], many['ids'])
+    np.testing.assert_array_equal(dev.download(nat.F_X)[o], many['x'])
+    np.testing.assert_array_equal(dev.download(nat.F_Y)[o], many['y'])
+    np.testing.assert_array_equal(dev.download(nat.F_AGE)[o], many['age'])
+    np.testing.assert_array_equal(dev.download(nat.F_Z)[0][o], many['z'])
+    np.testing.assert_array_equal(dev.download(nat.F_GENO)[o], many['geno'])
+    assert len(many['ids']) > 500 and many['bytes_sent'] > 0
 
 
 # ---- device-resident transport (what RCCL carries on a multi-GPU node) -----------------
@@ -457,6 +491,19 @@ def test_model_over_two_ranks_equals_single_process_when_neutral(tmp_path):
     got = np.array([[[int(c) for c in cell.split('|')] for cell in l.split('\t')[9:]]
                     for l in vcf[4:]])
     np.testing.assert_array_equal(got, np.transpose(two['g'][[col[i] for i in ids]], (1, 0, 2)))
+
+
+def test_model_over_two_ranks_with_panmixia(tmp_path):
+    """mating_radius None through the Model API (reference structs/species.py:2178-2194): the
+    unchanged model script over two ranks gives the single-process trajectory - TiledSpecies
+    raised NotImplementedError until round 6"""
+    one, _ = _run_model(tmp_path, 1, False, 'one', extra=('panmixia',))
+    two, _ = _run_model(tmp_path, 2, False, 'two', extra=('panmixia',))
+    assert int(two['world']) == 2 and int(two['v3']) == 0
+    for k in ('Nt', 'births', 'deaths', 'nburn', 'ids'):
+        np.testing.assert_array_equal(one[k], two[k], err_msg=k)
+    np.testing.assert_array_equal(one['xy'], two['xy'])
+    assert len(two['ids']) > 100 and two['births'].sum() > 100
 
 
 def test_model_over_two_ranks_with_selection(tmp_path):

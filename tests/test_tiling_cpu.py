@@ -31,7 +31,7 @@ def launch(backend, shard, world, steps, out, mode='fixed'):
     return np.load(out)
 
 
-@pytest.mark.parametrize('world,mode', [(2, 'fixed'), (4, 'poisson')])
+@pytest.mark.parametrize('world,mode', [(2, 'fixed'), (4, 'poisson'), (2, 'panmixia')])
 def test_tiled_oracle_run_is_bit_identical_to_single_tile(tmp_path, world, mode):
     steps = 8
     one = launch('gloo', 'oracle', 1, steps, str(tmp_path / 'one.npz'), mode)
