@@ -529,6 +529,14 @@ struct gnx_state {
   // (gnx_os_hist_discard).
   bool hist_fresh = false;
   // gnx_walk: the next step's movement runs with this step's mortality (gnx_l_move_ahead)
+  // gnx_walk, between two of its steps: the mortality leaves the dead where they are - no
+  // compaction at all (k_fill_lists, k_fill: ~40 us alone, 130 beside the crossover, and the next
+  // movement behind them).  The next step's movement skips the dead (their flags: h->flag), the
+  // cell sort reads the living through the id-ordered index (which drops the dead) and k_permute
+  // gathers them: the population is compact again behind the sort.  holes_N = the slots the
+  // movement has to look at (gnx_l_mortality_enqueue: lazy).
+  bool holes = false;
+  int64_t holes_N = 0;
   bool eager_move = false;       // set by gnx_walk for every step but the last
   bool moved_ahead = false;      // the coming step's age + movement are done, cell32 written
   hipEvent_t ev_move = nullptr;

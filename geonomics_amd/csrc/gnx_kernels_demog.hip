@@ -2011,21 +2011,23 @@ __device__ __forceinline__ void gnx_dd_end_step(const GnxDDEnd& E) {
 __global__ void __launch_bounds__(256)
 k_ord_flags(int64_t N, int64_t ord_n, const int32_t* __restrict__ ord,
             const int32_t* __restrict__ newslot, int32_t* __restrict__ cnt, GnxScanOut S,
-            const GnxDD* __restrict__ dd) {
+            const GnxDD* __restrict__ dd, const int32_t* __restrict__ alive) {
   __shared__ int lds[16];
   __shared__ int lds2[8];
   if (dd) {
     N = (int64_t)dd->N + dd->B;
     ord_n = dd->ord_n;
   }
-  gnx_ord_flags_body(N, ord_n, GnxOrdF{ord, newslot, nullptr, cnt, S, ord_n, 0}, lds, lds2);
+  // (alive: nobody moved - the lazy mortality of gnx_walk - the death draws' own flags decide)
+  gnx_ord_flags_body(N, ord_n, GnxOrdF{ord, alive ? nullptr : newslot, alive, cnt, S, ord_n, 0},
+                     lds, lds2);
 }
 
 __global__ void __launch_bounds__(256)
 k_ord_write(int64_t N, int64_t ord_n, const int32_t* __restrict__ ord,
             const int32_t* __restrict__ newslot, const int32_t* __restrict__ off,
             int32_t* __restrict__ ord_new, const GnxDD* __restrict__ dd, GnxDDEnd E,
-            int tail_explicit) {
+            int tail_explicit, const int32_t* __restrict__ alive) {
   __shared__ int lds[16];
   __shared__ int last_s;
   if (dd) {
@@ -2038,7 +2040,12 @@ k_ord_write(int64_t N, int64_t ord_n, const int32_t* __restrict__ ord,
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t k = base + r * 256 + threadIdx.x;
-    ns[r] = k < N ? newslot[k < ord_n ? ord[k] : k] : -1;
+    if (alive) {                  // nobody moved: a living individual keeps its slot
+      const int32_t slot = k < N ? (int32_t)(k < ord_n ? ord[k] : k) : -1;
+      ns[r] = (slot >= 0 && (alive[slot] & 1) != 0) ? slot : -1;
+    } else {
+      ns[r] = k < N ? newslot[k < ord_n ? ord[k] : k] : -1;
+    }
     f[r] = ns[r] >= 0;
   }
   int rank[4], tot;
@@ -2058,6 +2065,32 @@ k_ord_write(int64_t N, int64_t ord_n, const int32_t* __restrict__ ord,
   }
   __syncthreads();
   if (last_s && threadIdx.x == 0) gnx_dd_end_step(E);
+}
+
+// The lazy mortality of gnx_walk (gnx_internal.h: holes): nobody moves, so all that is left of
+// the compaction is the genome rows of the dead going back on the free stack - behind the rows
+// the surviving offspring have just popped from its top (k_xo_jobs_*).
+__global__ void __launch_bounds__(256)
+k_dead_rows(int64_t N, const int32_t* __restrict__ dead_row, const int32_t* __restrict__ blk_off_d,
+            const int32_t* __restrict__ grow, const int32_t* __restrict__ cnts, int xo,
+            int32_t* __restrict__ free_rows, int64_t n_free) {
+  __shared__ int lds[16];
+  const int64_t base = (int64_t)blockIdx.x * GNX_CB;
+  bool fd[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    fd[r] = i < N && dead_row[i] != 0;
+  }
+  int rd[4], td;
+  gnx_block_ranks(fd, rd, td, lds);
+  if (xo) n_free -= cnts[2];
+  const int32_t od = blk_off_d[blockIdx.x];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    if (fd[r]) free_rows[n_free + od + rd[r]] = grow[i];
+  }
 }
 
 int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_out) {
@@ -2123,6 +2156,10 @@ int gnx_l_mortality_enqueue(gnx_state* h, const uint8_t* d_dead_inject) {
   static const bool ahead_env = getenv("GNX_MOVE_AHEAD") && atoi(getenv("GNX_MOVE_AHEAD")) != 0;
   const bool ahead = ahead_env && h->eager_move && fill && ord_keep && h->sp.move && h->stream2 != nullptr &&
                      h->key_bits <= 24 && h->n_ghost == 0 && !h->tile2_mode;
+  // gnx_walk, every step but the last: NO compaction (gnx_internal.h: holes) - GNX_LAZY_COMPACT=0: off
+  static const bool lazy_env = !(getenv("GNX_LAZY_COMPACT") && atoi(getenv("GNX_LAZY_COMPACT")) == 0);
+  const bool lazy = lazy_env && h->eager_move && !ahead && fill && ord_keep && h->sp.move &&
+                    h->sp.mating_radius >= 0 && h->key_bits <= 24 && h->n_ghost == 0 && !h->tile2_mode;
   if (side_scan || ahead) HIPCHK(hipEventRecord(h->ev_alive, h->stream));
   if (ahead) {
     if (!h->ev_move)
@@ -2156,8 +2193,8 @@ int gnx_l_mortality_enqueue(gnx_state* h, const uint8_t* d_dead_inject) {
   // the lists the compaction and with it the next movement wait for: 0.587 against 0.582 ms/step
   // (profiles/r04_ab_runs.txt), so k_ord_flags stays a launch of its own beside the crossover
   static const bool ord_fused_env = getenv("GNX_ORD_FUSED") && atoi(getenv("GNX_ORD_FUSED")) != 0;
-  const bool ord_fused = ord_fused_env && fill && ord_keep;
-  if (fill) {
+  const bool ord_fused = ord_fused_env && fill && ord_keep && !lazy;
+  if (fill && !lazy) {
     if (!side_scan) HIPCHK(hipStreamWaitEvent(h->stream3, h->ev_counts, 0));
     hipLaunchKernelGGL(k_fill_lists, dim3(nb), dim3(256), 0, h->stream3, N, h->flag, h->flag2,
                        h->blk_off, h->blk_stride, h->cnt_dev, a.grow, has_rows,
@@ -2183,7 +2220,20 @@ int gnx_l_mortality_enqueue(gnx_state* h, const uint8_t* d_dead_inject) {
   if (ord_keep && h->ord_inflight) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ord, 0));
   gnx_time_begin(h);
   const double rec_bytes = 34.0 + 4.0 * c.n_layers + 4.0 * c.n_traits + 16.0 * h->TW;
-  if (fill) {
+  if (lazy) {
+    // the dead's rows (their block offsets: the scan's second array - from stream3 when the
+    // scan ran there)
+    if (has_rows) {
+      if (side_scan) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_counts, 0));
+      hipLaunchKernelGGL(k_dead_rows, dim3(nb), dim3(256), 0, h->stream, N,
+                         (const int32_t*)h->flag2, (const int32_t*)(h->blk_off + h->blk_stride),
+                         (const int32_t*)a.grow, (const int32_t*)h->cnt_dev, xo ? 1 : 0,
+                         h->free_rows, h->n_free);
+    }
+    gnx_time_end(h, GNX_K_COMPACT, (double)N * 8.0);
+    h->holes = true;
+    h->holes_N = N;
+  } else if (fill) {
     HIPCHK(hipStreamWaitEvent(h->stream, h->ev_fill, 0));
     if (ahead) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_move, 0));
     const int64_t guess = std::max<int64_t>(h->fill_guess * 2, 4096);      // (grid-stride: any count)
@@ -2210,10 +2260,12 @@ int gnx_l_mortality_enqueue(gnx_state* h, const uint8_t* d_dead_inject) {
     GnxScanOut So{h->ord_off, nullptr, nullptr, 0, nullptr, h->tickets + 2, h->blk_stride};
     if (!ord_fused)
       hipLaunchKernelGGL(k_ord_flags, dim3(nb), dim3(256), 0, h->stream3, N, h->ord_n,
-                         h->ord[h->ord_cur], h->newslot, h->ord_cnt, So, (const GnxDD*)nullptr);
+                         h->ord[h->ord_cur], h->newslot, h->ord_cnt, So, (const GnxDD*)nullptr,
+                         lazy ? (const int32_t*)h->flag : (const int32_t*)nullptr);
     hipLaunchKernelGGL(k_ord_write, dim3(nb), dim3(256), 0, h->stream3, N, h->ord_n,
                        h->ord[h->ord_cur], h->newslot, h->ord_off, h->ord[h->ord_cur ^ 1],
-                       (const GnxDD*)nullptr, GnxDDEnd{}, 0);
+                       (const GnxDD*)nullptr, GnxDDEnd{}, 0,
+                       lazy ? (const int32_t*)h->flag : (const int32_t*)nullptr);
     // the cell sort waits for the crossover AND for this: stream3 waits for the crossover here,
     // where nothing waits for stream3, and the sort's stream waits for one event instead of two
     h->ord_covers_xo = false;
@@ -2265,6 +2317,7 @@ int gnx_l_mortality_finish(gnx_state* h, int64_t* deaths_out) {
   h->fill_guess = N - survivors;
   h->N = survivors;
   h->n_ghost = 0;
+  if (survivors == 0) h->holes = false;        // (nobody left to move or sort)
   if (!fill) h->cur ^= 1;
   if (ord_keep) h->ord_n = survivors;
   return 0;
@@ -2390,7 +2443,8 @@ int gnx_dd_l_ord_end(gnx_state* h, int has_rows, bool xo, hipStream_t st) {
                      h->ord[h->ord_cur], h->newslot, h->ord_off, h->ord[h->ord_cur ^ 1],
                      (const GnxDD*)h->dd,
                      GnxDDEnd{h->dd, h->cnt_dev, h->half_top, h->dd_ring_dev, has_rows, xo ? 1 : 0,
-                              h->tickets + 4}, (h->vt_fused && h->id_order == 1) ? 1 : 0);
+                              h->tickets + 4}, (h->vt_fused && h->id_order == 1) ? 1 : 0,
+                     (const int32_t*)nullptr);
   HIPCHK(hipGetLastError());
   h->ord_cur ^= 1;
   return 0;

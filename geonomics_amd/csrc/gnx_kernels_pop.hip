@@ -456,6 +456,17 @@ int gnx_l_move(gnx_state* h, bool inc_age, const float* inj_theta, const float* 
   P.dd = ddm ? h->dd : nullptr;
   P.alive = nullptr;
   P.N = h->N;
+  // (gnx_walk: the last mortality left its dead in place - gnx_internal.h: holes - the
+  // movement looks at every slot of that step and skips them)
+  const bool holes = h->holes && apply && !ddm && !inj_theta;
+  if (h->holes && !holes) {
+    gnx_set_error("internal: a movement other than the step's own over an uncompacted population");
+    return 1;
+  }
+  if (holes) {
+    P.alive = h->flag;
+    P.N = h->holes_N;
+  }
   P.cap = c.cap_inds;
   P.W = c.W;
   P.H = c.H;
@@ -506,7 +517,7 @@ int gnx_l_move(gnx_state* h, bool inc_age, const float* inj_theta, const float* 
   gnx_time_begin(h);
   // individuals per thread (GNX_MOVE_IPT; 2 by default: profiles/r04_ab_runs.txt)
   static const int ipt = getenv("GNX_MOVE_IPT") ? atoi(getenv("GNX_MOVE_IPT")) : 2;
-  const int64_t n_grid = ddm ? (int64_t)c.cap_inds : h->N;
+  const int64_t n_grid = ddm ? (int64_t)c.cap_inds : (holes ? h->holes_N : h->N);
   if (ipt == 2)
     hipLaunchKernelGGL(k_move<2>, dim3(gnx_grid(n_grid, 512)), dim3(256),
                        (size_t)P.tile_floats * sizeof(float), h->stream, P,
@@ -810,6 +821,12 @@ int gnx_l_sort_by_cell(gnx_state* h, bool split_rest) {
   const int idbits = gnx_id_bits(h);
   const bool alone = h->xo_sort_waits || !h->xo_running;
   const bool ordm = h->tile_evict > 0 ? false : (h->keys_fresh ? h->keys_ordmode : gnx_ord_sort(h));
+  if (h->holes && !(ordm && h->keys_fresh)) {
+    gnx_set_error("internal: the cell sort of an uncompacted population needs the id-ordered index "
+                  "and the movement's keys");
+    return 1;
+  }
+  h->holes = false;          // (k_permute below gathers the living: the population is compact again)
   gnx_time_begin(h);
   int64_t wipe_words = 0;       // of os_scratch, dirtied by this sort
   if (ordm) {

@@ -35,9 +35,12 @@ if tile:
     dev.set_max_id(int(dev.download(nat.F_ID).max()))
 t = 0
 t_walk = 0.0            # time inside the steps alone (the checks between the pieces excluded)
+seg_open = False
 while t < steps:
-    dev.synchronize()
-    tw0 = time.perf_counter()
+    if not seg_open:                 # a timed stretch runs from one check to the next
+        dev.synchronize()
+        tw0 = time.perf_counter()
+        seg_open = True
     if walk:
         k = min(every - (t % every), steps - t)
         dev.walk(k, False, True)
@@ -50,7 +53,8 @@ while t < steps:
         t += 1
     if t % every == 0 or t == steps:
         dev.synchronize()
-    t_walk += time.perf_counter() - tw0
+        t_walk += time.perf_counter() - tw0
+        seg_open = False
     if n_mut:
         dev.mutate(rng.randint(0, dev.N, n_mut).astype(np.int64),
                    rng.randint(0, cfg['L'], n_mut).astype(np.int32),
