@@ -517,6 +517,7 @@ struct gnx_state {
   void* os_scratch = nullptr;    // gnx_os_sort32: histograms, look-back states, block counters
   uint32_t* os_ktmp = nullptr;   // ... and the pairs between two digit places
   int32_t* os_vtmp = nullptr;
+  uint32_t* ord_state = nullptr; // k_ord_compact: [blk_stride] look-back words + [8] tickets, zero between launches
   int32_t* ord_cnt = nullptr;    // block counts / offsets of the index's own compaction
   int32_t* ord_off = nullptr;
   hipEvent_t ev_ord = nullptr;

@@ -2093,6 +2093,92 @@ k_dead_rows(int64_t N, const int32_t* __restrict__ dead_row, const int32_t* __re
   }
 }
 
+// k_ord_flags + k_ord_write in ONE launch: the stable compaction of the id-ordered index with a
+// decoupled look-back over the workgroups' counts (one status | count word per workgroup, 64
+// predecessors per round trip: the lanes of wave 0 read them together) instead of a counting
+// kernel, a scan by its last workgroup and a writing kernel - one gather of the flags through
+// the index instead of two.  Tickets give the workgroups their order; the last one to finish
+// clears the words for the next launch.  state: [nb] zero on entry, tick: [2] zero on entry.
+__global__ void __launch_bounds__(256)
+k_ord_compact(int64_t N, int64_t ord_n, const int32_t* __restrict__ ord,
+              const int32_t* __restrict__ newslot, const int32_t* __restrict__ alive,
+              int32_t* __restrict__ ord_new, uint32_t* __restrict__ state,
+              uint32_t* __restrict__ tick) {
+  constexpr uint32_t PART = 1u << 30, INCL = 2u << 30, VAL = (1u << 30) - 1u;
+  __shared__ int lds[16];
+  __shared__ uint32_t s_bid, s_off, s_last;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_bid = __hip_atomic_fetch_add(&tick[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const uint32_t bid = s_bid;
+  const int64_t base = (int64_t)bid * GNX_CB;
+  bool f[4];
+  int32_t ns[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t k = base + r * 256 + tid;
+    const int32_t slot = k < N ? (int32_t)(k < ord_n ? ord[k] : k) : -1;
+    if (alive) ns[r] = (slot >= 0 && (alive[slot] & 1) != 0) ? slot : -1;
+    else ns[r] = slot >= 0 ? newslot[slot] : -1;
+    f[r] = ns[r] >= 0;
+  }
+  int rank[4], tot;
+  gnx_block_ranks(f, rank, tot, lds);
+  if (wave == 0) {
+    if (lane == 0)
+      __hip_atomic_store(&state[bid], (bid == 0 ? INCL : PART) | (uint32_t)tot, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t prefix = 0;
+    int b = (int)bid - 1;
+    while (b >= 0) {
+      const int idx = b - lane;
+      const uint32_t v = idx >= 0 ? __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                  : INCL;
+      const unsigned long long notready = __ballot(v == 0u);
+      const unsigned long long incl = __ballot(v != 0u && (v & INCL) != 0u);
+      const int first_nr = notready ? __ffsll((long long)notready) - 1 : 64;
+      const int first_in = incl ? __ffsll((long long)incl) - 1 : 64;
+      if (first_nr == 0) {                     // the nearest predecessor has not published yet
+        __builtin_amdgcn_s_sleep(1);
+        continue;
+      }
+      const bool done = first_in < first_nr;
+      const int limit = done ? first_in : first_nr - 1;
+      uint32_t c = lane <= limit ? (v & VAL) : 0u;
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+      prefix += c;
+      if (done) break;
+      b -= limit + 1;
+    }
+    if (lane == 0) {
+      if (bid > 0)
+        __hip_atomic_store(&state[bid], INCL | (prefix + (uint32_t)tot), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      s_off = prefix;
+    }
+  }
+  __syncthreads();
+  const uint32_t o = s_off;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (f[r]) ord_new[o + rank[r]] = ns[r];
+  // the last workgroup to get here (everybody has finished looking back by then) leaves the
+  // words zero for the next launch
+  if (tid == 0) {
+    const uint32_t d = __hip_atomic_fetch_add(&tick[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = d == gridDim.x - 1u ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  for (unsigned int q = tid; q < gridDim.x; q += 256)
+    __hip_atomic_store(&state[q], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) {
+    __hip_atomic_store(&tick[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&tick[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 int gnx_l_mortality(gnx_state* h, const uint8_t* d_dead_inject, int64_t* deaths_out) {
   *deaths_out = 0;
   GNXCHK(gnx_l_mortality_enqueue(h, d_dead_inject));
@@ -2258,6 +2344,16 @@ int gnx_l_mortality_enqueue(gnx_state* h, const uint8_t* d_dead_inject) {
     HIPCHK(hipStreamWaitEvent(h->stream3, h->ev_compact, 0));
     if (h->ord_inflight) h->ord_inflight = false;       // (stream3 runs them in order)
     GnxScanOut So{h->ord_off, nullptr, nullptr, 0, nullptr, h->tickets + 2, h->blk_stride};
+    // GNX_ORD_ONE=1: the one-launch compaction (k_ord_compact) instead of counting kernel + scan by
+    // its last workgroup + writing kernel - measured 0.526 against 0.519 ms/step beside the
+    // crossover (its look-back waits where the two-kernel form just streams): off by default
+    static const bool ord_one = getenv("GNX_ORD_ONE") && atoi(getenv("GNX_ORD_ONE")) != 0;
+    if (ord_one && !ord_fused && h->ord_state) {
+      hipLaunchKernelGGL(k_ord_compact, dim3(nb), dim3(256), 0, h->stream3, N, h->ord_n,
+                         (const int32_t*)h->ord[h->ord_cur], (const int32_t*)h->newslot,
+                         lazy ? (const int32_t*)h->flag : (const int32_t*)nullptr,
+                         h->ord[h->ord_cur ^ 1], h->ord_state, h->ord_state + h->blk_stride);
+    } else {
     if (!ord_fused)
       hipLaunchKernelGGL(k_ord_flags, dim3(nb), dim3(256), 0, h->stream3, N, h->ord_n,
                          h->ord[h->ord_cur], h->newslot, h->ord_cnt, So, (const GnxDD*)nullptr,
@@ -2266,6 +2362,7 @@ int gnx_l_mortality_enqueue(gnx_state* h, const uint8_t* d_dead_inject) {
                        h->ord[h->ord_cur], h->newslot, h->ord_off, h->ord[h->ord_cur ^ 1],
                        (const GnxDD*)nullptr, GnxDDEnd{}, 0,
                        lazy ? (const int32_t*)h->flag : (const int32_t*)nullptr);
+    }
     // the cell sort waits for the crossover AND for this: stream3 waits for the crossover here,
     // where nothing waits for stream3, and the sort's stream waits for one event instead of two
     h->ord_covers_xo = false;
