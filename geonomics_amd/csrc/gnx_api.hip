@@ -1193,6 +1193,7 @@ extern "C" int gnx_step_begin(gnx_state* h, int32_t burn) {
   h->tot[0] += 1;
   h->tot[1] += h->N - h->n_ghost;
   h->last_xo_births = 0;
+  h->step_burn = burn != 0;
   h->tile2_mode = false;        // (a handle that stepped through the tile protocol before)
   if (h->moved_ahead) {
     // gnx_walk: the last step's mortality has moved everybody already (gnx_l_move_ahead) and

@@ -369,6 +369,7 @@ struct gnx_state {
           *vt_count = nullptr;
   int64_t* vt_base = nullptr;
   int64_t n_births_pending = 0;  // births of the current pair list
+  bool step_burn = false;        // gnx_step_begin: this step is a burn-in step
   bool births_ahead = false;     // k_offspring of the current pair list is already on the stream (gnx_l_offspring_ahead)
   // gamete requests (tiled runs)
   int64_t* req_pid = nullptr;
@@ -661,7 +662,7 @@ int gnx_l_find_pairs(gnx_state* h, const uint8_t* d_keep, int64_t* n_pairs_out,
 int gnx_l_find_pairs_enqueue(gnx_state* h, const uint8_t* d_keep, bool with_density);
 int gnx_l_find_pairs_finish(gnx_state* h, int64_t* n_pairs_out);
 int gnx_l_births(gnx_state* h, int64_t* births_out);
-int gnx_l_offspring_ahead(gnx_state* h, bool burn);
+int gnx_l_offspring_ahead(gnx_state* h, bool burn, bool inside_enqueue = false);
 int gnx_l_pair_cls(gnx_state* h, int64_t P, bool local);
 int gnx_vt_buffers(gnx_state* h);      // (allocated by gnx_set_id_order: never inside a stream capture)
 int gnx_l_mate(gnx_state* h, bool burn, bool inject, int64_t B_inject, int64_t* births_out,

@@ -2015,6 +2015,11 @@ int gnx_l_find_pairs_enqueue(gnx_state* h, const uint8_t* d_keep, bool with_dens
                      (GnxDD*)nullptr, 0, (int64_t)0, GnxBinP{nullptr, 0.0, 0, 0}, vto);
   gnx_time_end(h, GNX_K_PAIRS, (double)N * 40.0);
   HIPCHK(hipGetLastError());
+  if (h->perm_rest_late_ok && !h->tiled) {     // (gnx_step: the births right behind the pair list)
+    const int rc_ahead = gnx_l_offspring_ahead(h, h->step_burn, true);
+    h->pairs_wait = false;
+    GNXCHK(rc_ahead);
+  }
   if (h->perm_rest_late) GNXCHK(gnx_permute_rest_launch(h));
   // the pair midpoints' density (ops/demography.py:60-91): on one GPU bins + lattice run on
   // stream3 beside k_offspring and the death probabilities wait for them
@@ -2408,11 +2413,15 @@ static OffP gnx_make_offp(gnx_state* h, bool genomes, bool tiled, int64_t id_bas
 // fit has written nothing by then (the kernel checks the same bounds itself).
 // Same kernel, same arguments as gnx_l_mate's own launch: the reference's order of events
 // (structs/species.py:595-805: pairs, then births) is the stream's.
-int gnx_l_offspring_ahead(gnx_state* h, bool burn) {
+int gnx_l_offspring_ahead(gnx_state* h, bool burn, bool inside_enqueue) {
   // (measured, profiles/r06_ab_runs.txt: 0.544 against 0.542 ms/step - the gap in front of the
   // births is not the host's wait but the event hand-over to the side stream that precedes them;
-  // parity-green, kept behind GNX_BIRTHS_AHEAD=1)
-  static const bool on = getenv("GNX_BIRTHS_AHEAD") && atoi(getenv("GNX_BIRTHS_AHEAD")) != 0;
+  // parity-green, kept behind GNX_BIRTHS_AHEAD=1.  =2: right behind the pair list, in front of
+  // that hand-over - gnx_l_find_pairs_enqueue)
+  static const int mode = getenv("GNX_BIRTHS_AHEAD") ? atoi(getenv("GNX_BIRTHS_AHEAD")) : 0;
+  if (h->births_ahead) return 0;               // (already on the stream)
+  const bool on = inside_enqueue ? mode == 2 : mode == 1;
+  if (inside_enqueue) h->pairs_wait = true;    // (the enqueue sets it at its end: the test below)
   h->births_ahead = false;
   const gnx_config& c = h->cfg;
   const gnx_species_params& sp = h->sp;
