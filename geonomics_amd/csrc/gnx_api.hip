@@ -518,7 +518,20 @@ extern "C" int gnx_create(const gnx_config* cfg, gnx_state** out) {
   }
   HIPCHK(hipEventCreateWithFlags(&h->ev_counts, hipEventDisableTiming));
   h->defer_xo = !(getenv("GNX_DEFER_XO") && atoi(getenv("GNX_DEFER_XO")) == 0);
-  if (getenv("GNX_XO_LAUNCH")) h->xo_launch_policy = atoi(getenv("GNX_XO_LAUNCH"));
+  // When the deferred crossover of step t goes on its stream (csrc/gnx_kernels_genome.hip:
+  // gnx_xo_launch_pending): 0 as soon as its jobs are built (it runs beside the next step's
+  // movement), 1 / 2 behind the next step's cell sort / pair list.  Since gnx_walk leaves no
+  // compaction between its steps (round 6) the head of a step is the movement alone, and a
+  // crossover that runs beside the births, the densities, the death draws and the next job
+  // builder instead - latency-bound chains that leave the memory system idle - costs the step
+  // least: 0.502 against 0.518 ms at the metric workload (profiles/r06_ab_runs.txt).  Large
+  // populations only: the device-driven step of the small ones (gnx_dd.hip) schedules its own.
+  {
+    static const int64_t dd_cap = getenv("GNX_DD_MAX_CAP") ? atoll(getenv("GNX_DD_MAX_CAP")) : 600000;
+    h->xo_launch_policy = cap > dd_cap ? 2 : 0;
+    if (getenv("GNX_XO_LAUNCH")) h->xo_launch_policy = atoi(getenv("GNX_XO_LAUNCH"));
+    h->xo_launch_default = h->xo_launch_policy;
+  }
   if (getenv("GNX_COMPACT_FILL")) h->compact_fill = atoi(getenv("GNX_COMPACT_FILL")) != 0;
   if (getenv("GNX_PERMUTE_SPLIT")) h->permute_split = atoi(getenv("GNX_PERMUTE_SPLIT")) != 0;
   if (getenv("GNX_XO_SORT_WAIT")) h->xo_sort_waits = atoi(getenv("GNX_XO_SORT_WAIT")) != 0;
@@ -1377,6 +1390,8 @@ extern "C" int gnx_set_crossover_overlap(gnx_state* h, int32_t mode) {
   static const int wait_env = getenv("GNX_XO_WAIT") ? atoi(getenv("GNX_XO_WAIT")) : 1;
   h->xo_sort_waits = mode != 1;
   h->xo_wait_at = mode == 2 ? 2 : wait_env;      // 2: nothing else runs beside the crossover
+  // (the other modes launch the crossover as soon as its jobs are built)
+  h->xo_launch_policy = mode == 0 ? h->xo_launch_default : 0;
   return 0;
 }
 

@@ -66,7 +66,9 @@ bool gnx_dd_eligible(const gnx_state* h, bool burn) {
   // classification inside k_pair_compact, one more node for the blocks' offsets)
   if (h->NB > GNX_MAX_NB || h->n_ghost != 0) return false;
   if (h->cfg.cap_inds >= (1ll << 30)) return false;
-  if (h->xo_launch_policy != 0 || h->xo_split != 0) return false;
+  // (a launch policy other than the handle's own default was asked for: the host-driven step honours it)
+  if ((h->xo_launch_policy != 0 && h->xo_launch_policy != h->xo_launch_default) || h->xo_split != 0)
+    return false;
   (void)burn;
   return true;
 }

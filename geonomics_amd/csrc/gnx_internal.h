@@ -325,6 +325,7 @@ struct gnx_state {
   // individual-timesteps/s, but the crossover then stretches over the whole step.
   // xo_launch_policy 1 / 2 launch it after the next step's cell sort / pair sort instead.
   int xo_launch_policy = 0;
+  int xo_launch_default = 0;     // ... as chosen at gnx_create (gnx_set_crossover_overlap(0) returns to it)
   bool xo_sort_waits = true;
   // where `stream` waits for the full-width crossover (GNX_XO_WAIT): 1 before the next cell
   // sort, 2 right after launching it (strictly serial), 3 after the compaction
