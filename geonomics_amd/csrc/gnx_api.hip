@@ -1250,9 +1250,11 @@ extern "C" int gnx_step_mid(gnx_state* h, int32_t burn, int32_t with_selection) 
   // gnx_set_id_order: the pairs' offsets from this device's own counts - gnx_l_mate)
   GNXCHK(gnx_l_mate(h, burn != 0, false, 0, &B));
   h->last_births = B;
+  if (h->xo_launch_policy == 4) GNXCHK(gnx_xo_launch_pending(h));     // (behind the births)
   // N density of everyone incl. offspring (structs/species.py:845-882); d at each
   // individual's cell, fitness, death probability; mortality
   GNXCHK(gnx_l_density_N(h));
+  if (h->xo_launch_policy == 3) GNXCHK(gnx_xo_launch_pending(h));     // (behind the densities)
   GNXCHK(gnx_wait_permute_rest(h));       // (GNX_PERMUTE_REST_AT=2: environment, phenotypes, rows arrive here)
   GNXCHK(gnx_l_death_probs(h, with_selection != 0 && !burn));
   return gnx_l_mortality_enqueue(h, nullptr);
