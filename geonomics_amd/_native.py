@@ -60,7 +60,7 @@ EXPORTS = [
     'gnx_tile2_finish_births', 'gnx_tile2_die', 'gnx_tile_pair_ptrs_nosync',
     'gnx_tile_step_begin', 'gnx_tile_step_births', 'gnx_tile_step_end', 'gnx_comm_probe',
     'gnx_tile2_pairs_mode', 'gnx_tile2_pairs_settle', 'gnx_tile2_settle_births',
-    'gnx_tile2_vt_counts', 'gnx_tile2_vt_bases', 'gnx_tile_step_abort', 'gnx_comm_info',
+    'gnx_tile2_vt_counts', 'gnx_tile2_vt_bases', 'gnx_tile_step_abort', 'gnx_comm_info', 'gnx_tile_walk',
 ]
 
 
@@ -386,6 +386,17 @@ class Device:
                                          int(bool(exact)), _ptr(out, C.c_int64)))
         self._id_order = 1          # (the library numbers a tiled step's offspring tile-major)
         return int(out[0]), int(out[1]), int(out[2])
+
+    def tile_walk(self, T, burn, with_selection, exact=True):
+        """T tiled steps in one call, no compaction between them (gnx_tile_walk) -> ((N, births,
+        deaths) of the last step as tile_step reports them, sum of the global N at the start of
+        every step, sum of the global births)"""
+        out = np.zeros(5, np.int64)
+        self._chk(self.lib.gnx_tile_walk(self.h, C.c_int64(int(T)), int(bool(burn)),
+                                         int(bool(with_selection)), int(bool(exact)),
+                                         _ptr(out, C.c_int64)))
+        self._id_order = 1
+        return (int(out[0]), int(out[1]), int(out[2])), int(out[3]), int(out[4])
 
     def tile_step_begin(self, burn):
         """the tiled step up to and including the births (gnx_tile_step_begin) -> (first id,

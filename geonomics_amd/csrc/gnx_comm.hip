@@ -994,6 +994,52 @@ extern "C" int gnx_tile_step_end(gnx_state* h, int32_t burn, int32_t with_select
   return 0;
 }
 
+// T tiled steps in one call, nothing between them - the tiles' gnx_walk.  Between two of its
+// steps the mortality leaves the dead in place (no compaction: gnx_internal.h, holes): the next
+// step's movement and routing skip them, its imports go behind the uncompacted stretch and its
+// cell sort - which already removes the emigrants by a key behind every cell - removes the dead
+// by one more.  The last step compacts, so the population is dense whenever anybody can look.
+// out[5]: (N at the start, births, deaths of the step before) of the LAST step as
+// gnx_tile_step(exact = 0) reports them - or, exact != 0, the global (N, births, deaths) after
+// it - then the SUM over the T steps of the global N at the start and of the global births.
+// Reference: Model.walk -> _do_timestep T times (sim/model.py:966-1161) on every rank.
+extern "C" int gnx_tile_walk(gnx_state* h, int64_t T, int32_t burn, int32_t with_selection,
+                             int32_t exact, int64_t* out) {
+  for (int k = 0; k < 5; ++k) out[k] = 0;
+  int rc = 0;
+  for (int64_t t = 0; t < T && !rc; ++t) {
+    int64_t o[3] = {0, 0, 0};
+    h->tile_lazy_ok = t + 1 < T;
+    // (the per-step counts that ride on the step's own all-reduce: N at the start, births)
+    rc = gnx_tile_step(h, burn, with_selection, 0, o);
+    h->tile_lazy_ok = false;
+    if (rc) break;
+    out[0] = o[0];
+    out[1] = o[1];
+    out[2] = o[2];
+    out[3] += o[0];
+    out[4] += o[1];
+  }
+  if (!rc && exact && T > 0) {
+    // the global (N, births, deaths) after the last step: one more KB-sized collective
+    Comm* c = comm_of(h);
+    int64_t mine[3];
+    GNXCHK(gnx_counts(h, &mine[0], &mine[1], &mine[2]));
+    if (c && c->world > 1) {
+      std::vector<int64_t> g((size_t)c->world * 3);
+      GNXCHK(host_allgather(h, mine, 3, g.data()));
+      mine[0] = mine[1] = mine[2] = 0;
+      for (int r = 0; r < c->world; ++r)
+        for (int k = 0; k < 3; ++k) mine[k] += g[(size_t)r * 3 + k];
+    }
+    out[0] = mine[0];
+    out[1] = mine[1];
+    out[2] = mine[2];
+    if (c) c->pre = -1;
+  }
+  return rc;
+}
+
 // A step that was begun and cannot be ended on every rank (the host's work on the newborns
 // failed somewhere): the handle leaves the "between _begin and _end" state WITHOUT the density
 // all-reduce and the mortality, so that the ranks can raise together instead of one of them

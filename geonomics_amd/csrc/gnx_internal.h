@@ -540,6 +540,12 @@ struct gnx_state {
   // movement has to look at (gnx_l_mortality_enqueue: lazy).
   bool holes = false;
   int64_t holes_N = 0;
+  // ... on tiles (gnx_tile_walk: a run of tile steps with nothing in between): the same, without
+  // an index - the next step's routing skips the dead too, the imports are appended behind the
+  // uncompacted stretch (holes_N grows with them; the first holes_flagged slots have flags), and
+  // the cell sort gives the dead a key behind the emigrants': they leave with it.
+  bool tile_lazy_ok = false;     // set by gnx_tile_walk for every step but its last
+  int64_t holes_flagged = 0;
   bool eager_move = false;       // set by gnx_walk for every step but the last
   bool moved_ahead = false;      // the coming step's age + movement are done, cell32 written
   hipEvent_t ev_move = nullptr;
@@ -826,6 +832,9 @@ int gnx_prim_sort64_bits(void* tmp, size_t bytes, const uint64_t* kin, uint64_t*
 int gnx_prim_scan_bytes(size_t n, size_t* bytes);
 int gnx_prim_scan(void* tmp, size_t bytes, const int32_t* in, int32_t* out, size_t n,
                   hipStream_t s);
+
+// the slots in use: the population, or - uncompacted (holes) - the stretch it is spread over
+static inline int64_t gnx_extent(const gnx_state* h) { return h->holes ? h->holes_N : h->N; }
 
 static inline int gnx_grid(int64_t n, int block, int max_blocks = 1 << 20) {
   int64_t g = (n + block - 1) / block;

@@ -2072,7 +2072,7 @@ k_ord_write(int64_t N, int64_t ord_n, const int32_t* __restrict__ ord,
 // the surviving offspring have just popped from its top (k_xo_jobs_*).
 __global__ void __launch_bounds__(256)
 k_dead_rows(int64_t N, const int32_t* __restrict__ dead_row, const int32_t* __restrict__ blk_off_d,
-            const int32_t* __restrict__ grow, const int32_t* __restrict__ cnts, int xo,
+            int32_t* __restrict__ grow, const int32_t* __restrict__ cnts, int xo,
             int32_t* __restrict__ free_rows, int64_t n_free) {
   __shared__ int lds[16];
   const int64_t base = (int64_t)blockIdx.x * GNX_CB;
@@ -2089,7 +2089,10 @@ k_dead_rows(int64_t N, const int32_t* __restrict__ dead_row, const int32_t* __re
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t i = base + r * 256 + threadIdx.x;
-    if (fd[r]) free_rows[n_free + od + rd[r]] = grow[i];
+    if (fd[r]) {
+      free_rows[n_free + od + rd[r]] = grow[i];
+      grow[i] = -1;               // (the slot stays until the next cell sort: it owns no row any more)
+    }
   }
 }
 
@@ -2244,8 +2247,18 @@ int gnx_l_mortality_enqueue(gnx_state* h, const uint8_t* d_dead_inject) {
                      h->key_bits <= 24 && h->n_ghost == 0 && !h->tile2_mode;
   // gnx_walk, every step but the last: NO compaction (gnx_internal.h: holes) - GNX_LAZY_COMPACT=0: off
   static const bool lazy_env = !(getenv("GNX_LAZY_COMPACT") && atoi(getenv("GNX_LAZY_COMPACT")) == 0);
-  const bool lazy = lazy_env && h->eager_move && !ahead && fill && ord_keep && h->sp.move &&
-                    h->sp.mating_radius >= 0 && h->key_bits <= 24 && h->n_ghost == 0 && !h->tile2_mode;
+  // (tiles: inside gnx_tile_walk, without an index - gnx_internal.h)
+  // (measured with two tiles sharing one GPU, profiles/r06_ab_runs.txt: 1.64 ms/step with, 1.59-1.64
+  // without - what the compaction cost comes back as 20 % more slots for the movement, the two
+  // routing passes and the 64-bit sort to look at; parity-green, GNX_TILE_LAZY=1 turns it on)
+  const bool tile_lazy_env = getenv("GNX_TILE_LAZY") && atoi(getenv("GNX_TILE_LAZY")) != 0;   // (read per call: the tests switch it)
+  const bool lazy_tile = lazy_env && tile_lazy_env && h->tile_lazy_ok && h->tile2_mode &&
+                         h->tile_R * h->tile_C > 1 &&
+                         fill && !ord_keep &&
+                         h->sp.move && h->sp.mating_radius >= 0 && !ahead;
+  const bool lazy = lazy_tile ||
+                    (lazy_env && h->eager_move && !ahead && fill && ord_keep && h->sp.move &&
+                     h->sp.mating_radius >= 0 && h->key_bits <= 24 && h->n_ghost == 0 && !h->tile2_mode);
   if (side_scan || ahead) HIPCHK(hipEventRecord(h->ev_alive, h->stream));
   if (ahead) {
     if (!h->ev_move)
@@ -2313,12 +2326,13 @@ int gnx_l_mortality_enqueue(gnx_state* h, const uint8_t* d_dead_inject) {
       if (side_scan) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_counts, 0));
       hipLaunchKernelGGL(k_dead_rows, dim3(nb), dim3(256), 0, h->stream, N,
                          (const int32_t*)h->flag2, (const int32_t*)(h->blk_off + h->blk_stride),
-                         (const int32_t*)a.grow, (const int32_t*)h->cnt_dev, xo ? 1 : 0,
+                         a.grow, (const int32_t*)h->cnt_dev, xo ? 1 : 0,
                          h->free_rows, h->n_free);
     }
     gnx_time_end(h, GNX_K_COMPACT, (double)N * 8.0);
     h->holes = true;
     h->holes_N = N;
+    h->holes_flagged = N;
   } else if (fill) {
     HIPCHK(hipStreamWaitEvent(h->stream, h->ev_fill, 0));
     if (ahead) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_move, 0));

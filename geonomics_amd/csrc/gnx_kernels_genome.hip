@@ -436,7 +436,9 @@ int gnx_l_crossover_survivors(gnx_state* h, int64_t first_slot, int64_t B, const
   h->xo_ready_buf = buf;
   h->xo_ready_jobs = 2 * B;
   h->jobs_cur ^= 1;
-  if (h->xo_launch_policy == 0) GNXCHK(gnx_xo_launch_pending(h));
+  // (tiles: the next step's routing reads the migrants' genome rows first thing - gnx_xo_join - so a
+  // crossover held back would only be waited for there: at once)
+  if (h->xo_launch_policy == 0 || h->tiled || h->tile2_mode) GNXCHK(gnx_xo_launch_pending(h));
   return 0;
 }
 
@@ -877,8 +879,10 @@ int gnx_gc(gnx_state* h) {
   // size is read on the device and nothing is read back (the next step's record carries the
   // stack's new height)
   const bool ddm = h->dd_active;
+  // (an uncompacted population - gnx_internal.h: holes - is marked over the whole stretch it is
+  // spread over: the dead's slots own no row any more, k_dead_rows)
   if (h->N > 0 || ddm)
-    hipLaunchKernelGGL(k_gc_mark, dim3(2048), dim3(256), 0, h->stream, h->N, h->soa[h->cur].grow,
+    hipLaunchKernelGGL(k_gc_mark, dim3(2048), dim3(256), 0, h->stream, gnx_extent(h), h->soa[h->cur].grow,
                        gnx_halves(h), h->half_mark, ddm ? (const GnxDD*)h->dd : nullptr);
   hipLaunchKernelGGL(k_gc_count, dim3(nb), dim3(256), 0, h->stream, n, per, h->row_spread,
                      (const uint8_t*)h->half_mark, h->gc_cnt);

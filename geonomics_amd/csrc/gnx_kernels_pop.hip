@@ -621,15 +621,19 @@ __global__ void k_keys(int64_t N, const float* x, const float* y, const int64_t*
 
 // tile2: an individual that left the tile (and is no ghost) sorts behind every cell - the
 // sort that orders the population also removes the emigrants (no compaction of its own)
+// (alive: an uncompacted population, gnx_tile_walk - the first n_flagged slots carry the last death
+// draws' flags, and the dead sort behind the emigrants: one more cell value)
 __global__ void k_keys_evict(int64_t N, const float* x, const float* y, const int64_t* id,
                              const uint8_t* ghost, float x0, float x1, float y0, float y1,
                              double inv_cs, int ncx, int ncy, int idbits, uint64_t* key,
-                             int32_t* idx) {
+                             int32_t* idx, const int32_t* __restrict__ alive, int64_t n_flagged) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const float xi = x[i], yi = y[i];
+  const bool dead = alive != nullptr && i < n_flagged && (alive[i] & 1) == 0;
   const bool out = !ghost[i] && (xi < x0 || xi >= x1 || yi < y0 || yi >= y1);
-  const uint64_t cell = out ? (uint64_t)(ncx * ncy) : (uint64_t)gnx_cell_of(xi, yi, inv_cs, ncx, ncy);
+  const uint64_t cell = dead ? (uint64_t)(ncx * ncy) + 1ull
+                             : (out ? (uint64_t)(ncx * ncy) : (uint64_t)gnx_cell_of(xi, yi, inv_cs, ncx, ncy));
   key[i] = (cell << idbits) | (uint64_t)id[i];
   idx[i] = (int32_t)i;
 }
@@ -803,7 +807,10 @@ int gnx_l_sort_by_cell(gnx_state* h, bool split_rest) {
   int64_t N = h->N;
   gnx_bins_adults_drop(h);
   GNXCHK(gnx_wait_permute_rest(h));
-  if (N == 0) return 0;
+  if (N == 0) {
+    h->holes = false;                 // (nobody left: nothing to gather)
+    return 0;
+  }
   GNXCHK(gnx_xo_flush_deferred(h));   // slots move: offspring still waiting for their crossover get it now
   // the radix sort runs alone, or beside a narrow tail.  (The index's compaction on stream3
   // has already waited for the crossover it was launched with - gnx_l_mortality - and this
@@ -820,8 +827,13 @@ int gnx_l_sort_by_cell(gnx_state* h, bool split_rest) {
   GnxSoA a = h->soa[h->cur], b = h->soa[h->cur ^ 1];
   const int idbits = gnx_id_bits(h);
   const bool alone = h->xo_sort_waits || !h->xo_running;
-  const bool ordm = h->tile_evict > 0 ? false : (h->keys_fresh ? h->keys_ordmode : gnx_ord_sort(h));
-  if (h->holes && !(ordm && h->keys_fresh)) {
+  // an uncompacted tile (gnx_tile_walk): the sort runs over every slot of the stretch, the dead
+  // carry a key behind the emigrants' and leave with them
+  const bool tile_holes = h->holes && h->tile2_mode;
+  const int64_t n_sort = tile_holes ? h->holes_N : N;
+  const bool ordm = (h->tile_evict > 0 || tile_holes) ? false
+                                                      : (h->keys_fresh ? h->keys_ordmode : gnx_ord_sort(h));
+  if (h->holes && !tile_holes && !(ordm && h->keys_fresh)) {
     gnx_set_error("internal: the cell sort of an uncompacted population needs the id-ordered index "
                   "and the movement's keys");
     return 1;
@@ -874,26 +886,32 @@ int gnx_l_sort_by_cell(gnx_state* h, bool split_rest) {
   } else {
     GNXCHK(gnx_os_hist_discard(h));
     int cell_bits = h->key_bits;
-    if (h->tile_evict > 0) {
-      // (one more cell value: the emigrants')
-      while ((1ll << cell_bits) <= (int64_t)h->ncx * h->ncy) ++cell_bits;
-      hipLaunchKernelGGL(k_keys_evict, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, a.x, a.y,
-                         a.id, a.ghost, h->evict_box[0], h->evict_box[1], h->evict_box[2],
+    if (h->tile_evict > 0 || tile_holes) {
+      // (one more cell value: the emigrants'; two: the dead's behind it)
+      while ((1ll << cell_bits) <= (int64_t)h->ncx * h->ncy + (tile_holes ? 1 : 0)) ++cell_bits;
+      if (h->tile_evict == 0) {            // (nobody left this step: the box takes everybody)
+        h->evict_box[0] = h->evict_box[2] = -1.0f;
+        h->evict_box[1] = (float)c.W + 1.0f;
+        h->evict_box[3] = (float)c.H + 1.0f;
+      }
+      hipLaunchKernelGGL(k_keys_evict, dim3(gnx_grid(n_sort, 256)), dim3(256), 0, h->stream, n_sort,
+                         a.x, a.y, a.id, a.ghost, h->evict_box[0], h->evict_box[1], h->evict_box[2],
                          h->evict_box[3], h->inv_cs, h->ncx, h->ncy, idbits, h->key64[0],
-                         h->perm[0]);
+                         h->perm[0], tile_holes ? (const int32_t*)h->flag : (const int32_t*)nullptr,
+                         h->holes_flagged);
     } else if (!h->keys_fresh) {
       hipLaunchKernelGGL(k_keys, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, a.x, a.y, a.id,
                          h->inv_cs, h->ncx, h->ncy, idbits, h->key64[0], h->perm[0]);
     }
     // GNX_TILE_OS64=0: rocPRIM's own driver (a fill before the histograms, two before every pass)
     static const bool os64 = !(getenv("GNX_TILE_OS64") && atoi(getenv("GNX_TILE_OS64")) == 0);
-    if (os64 && h->sort64_tmp_bytes >= (size_t)N * 12 && h->os_scratch) {
+    if (os64 && h->sort64_tmp_bytes >= (size_t)n_sort * 12 && h->os_scratch) {
       GNXCHK(gnx_os_sort64_clean(h->os_scratch, h->sort64_tmp, h->key64[0], h->key64[1], h->perm[0],
-                                 h->perm[1], (size_t)N, idbits + cell_bits, h->stream));
-      wipe_words = (int64_t)gnx_os_words_used64((size_t)N, idbits + cell_bits);
+                                 h->perm[1], (size_t)n_sort, idbits + cell_bits, h->stream));
+      wipe_words = (int64_t)gnx_os_words_used64((size_t)n_sort, idbits + cell_bits);
     } else {
       GNXCHK(gnx_prim_sort64_bits(h->sort64_tmp, h->sort64_tmp_bytes, h->key64[0], h->key64[1],
-                                  h->perm[0], h->perm[1], (size_t)N, idbits + cell_bits,
+                                  h->perm[0], h->perm[1], (size_t)n_sort, idbits + cell_bits,
                                   h->stream, alone));
     }
   }

@@ -1235,9 +1235,11 @@ __global__ void __launch_bounds__(256)
 k_route(int64_t N, int64_t cap, GnxSoA s, RouteGeo g, int n_traits, int32_t* __restrict__ cnt,
         const int32_t* __restrict__ offs, gnx_ind_rec* __restrict__ mig_rec,
         float* __restrict__ mig_z, int64_t* __restrict__ mig_slot,
-        gnx_ind_rec* __restrict__ gh_rec, int64_t mig_cap, int64_t gh_cap) {
+        gnx_ind_rec* __restrict__ gh_rec, int64_t mig_cap, int64_t gh_cap,
+        const int32_t* __restrict__ alive) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool act = i < N && !s.ghost[i];
+  // (alive: the last mortality left its dead in place - gnx_tile_walk)
+  const bool act = i < N && !s.ghost[i] && (!alive || (alive[i] & 1) != 0);
   const int T = g.R * g.C;
   float x = 0.f, y = 0.f;
   int oc = 0, orow = 0, cx = 0, cy = 0;
@@ -1432,9 +1434,9 @@ extern "C" int gnx_tile2_route_begin(gnx_state* h, int32_t move, void** counts_d
   } else {
     GNXCHK(gnx_l_age(h));
   }
-  const int64_t N = h->N;
+  const int64_t N = gnx_extent(h);       // (every slot of an uncompacted population; the dead are skipped)
   *counts_dev = h->route_cnt;             // (zeroed by k_tile2_zero above)
-  if (N == 0 || T == 1) return 0;          // one tile: nobody leaves, nobody borders
+  if (h->N == 0 || T == 1) return 0;       // one tile: nobody leaves, nobody borders
   RouteGeo g;
   GNXCHK(route_geo(h, &g));
   GnxSoA s = h->soa[h->cur];
@@ -1442,15 +1444,16 @@ extern "C" int gnx_tile2_route_begin(gnx_state* h, int32_t move, void** counts_d
   hipLaunchKernelGGL(k_route<false>, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N,
                      h->cfg.cap_inds, s, g, nt, h->route_cnt, (const int32_t*)nullptr,
                      (gnx_ind_rec*)nullptr, (float*)nullptr, (int64_t*)nullptr,
-                     (gnx_ind_rec*)nullptr, (int64_t)0, (int64_t)0);
+                     (gnx_ind_rec*)nullptr, (int64_t)0, (int64_t)0,
+                     h->holes ? (const int32_t*)h->flag : (const int32_t*)nullptr);
   HIPCHK(hipGetLastError());
   return 0;
 }
 
 extern "C" int gnx_tile2_route_finish(gnx_state* h, const int64_t* counts) {
   const int T = n_tiles(h);
-  const int64_t N = h->N;
-  if (N == 0 || T == 1) return 0;
+  const int64_t N = gnx_extent(h);
+  if (h->N == 0 || T == 1) return 0;
   RouteGeo g;
   GNXCHK(route_geo(h, &g));
   GnxSoA s = h->soa[h->cur];
@@ -1489,7 +1492,8 @@ extern "C" int gnx_tile2_route_finish(gnx_state* h, const int64_t* counts) {
   hipLaunchKernelGGL(k_route<true>, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N,
                      h->cfg.cap_inds, s, g, nt, h->route_cnt,
                      (const int32_t*)(h->route_cnt + 2 * T), h->gp_rec, nt ? h->gp_z : nullptr,
-                     h->gp_slots, h->gh_rec, h->gp_cap, h->gh_cap);
+                     h->gp_slots, h->gh_rec, h->gp_cap, h->gh_cap,
+                     h->holes ? (const int32_t*)h->flag : (const int32_t*)nullptr);
   if (n_mig > 0 && has_rows(h)) {
     if (n_mig > h->st_geno_cap) {
       (void)hipFree(h->st_geno);
@@ -1548,9 +1552,11 @@ static int import2(gnx_state* h, int64_t n, const gnx_ind_rec* d_rec, const floa
   if (n == 0) return 0;
   const gnx_config& c = h->cfg;
   const bool rows = has_rows(h) && !ghost;
-  if (h->N + n > c.cap_inds || (rows && n > h->n_free)) {
+  // (an uncompacted population - gnx_tile_walk: the arrivals go behind the stretch it is spread over)
+  const int64_t first = gnx_extent(h);
+  if (first + n > c.cap_inds || (rows && n > h->n_free)) {
     gnx_set_error("capacity exceeded importing %lld individuals (N=%lld cap=%lld free rows %lld)",
-                  (long long)n, (long long)h->N, (long long)c.cap_inds, (long long)h->n_free);
+                  (long long)n, (long long)first, (long long)c.cap_inds, (long long)h->n_free);
     return 2;
   }
   if (rows && !d_g) {
@@ -1561,16 +1567,17 @@ static int import2(gnx_state* h, int64_t n, const gnx_ind_rec* d_rec, const floa
                      c.H, h->chk);
   GnxSoA s = h->soa[h->cur];
   if (rows) GNXCHK(gnx_half_reserve(h, 2 * (int64_t)h->NB * n));
-  hipLaunchKernelGGL(k_unpack, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, h->N, n,
+  hipLaunchKernelGGL(k_unpack, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, first, n,
                      c.cap_inds, s, d_rec, (d_z && c.n_traits) ? d_z : nullptr, c.n_traits,
                      c.n_layers, h->rast, c.W, c.H, h->free_rows, h->n_free, rows ? 1 : 0, ghost,
                      gnx_halves(h));
   if (rows) {
-    GNXCHK(gnx_l_scatter_genomes(h, n, (const uint64_t*)d_g, h->N));
+    GNXCHK(gnx_l_scatter_genomes(h, n, (const uint64_t*)d_g, first));
     h->n_free -= n;
-    GNXCHK(gnx_l_tb_from_rows(h, h->N, n, nullptr, nullptr));
+    GNXCHK(gnx_l_tb_from_rows(h, first, n, nullptr, nullptr));
   }
   h->N += n;
+  if (h->holes) h->holes_N += n;
   h->ord_valid = false;
   if (ghost) h->n_ghost += n;
   HIPCHK(hipGetLastError());

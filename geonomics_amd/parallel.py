@@ -1003,6 +1003,27 @@ class TiledStepper:
         self._pre = n_pre
         return int(n_start), int(b_glob), int(d_prev)
 
+    def walk(self, T, burn, with_selection, exact=True):
+        """T time steps with nothing between them -> ((N, births, deaths) of the last step as
+        step() reports them, sum over the steps of the global N at the start, sum of the births).
+        Through the library (gnx_tile_walk: no compaction between the steps) when it drives the
+        tiles; else T calls of step()."""
+        if T <= 0:
+            return (0, 0, 0), 0, 0
+        if self.v3 and os.environ.get('GNX_TILE_WALK', '1') != '0':
+            self.shard.set_max_id(self.max_id)
+            last, n_sum, b_sum = self.shard.dev.tile_walk(T, burn, with_selection, exact)
+            self.max_id += b_sum
+            self.bytes_sent = self.shard.dev.comm_bytes_sent
+            return last, n_sum, b_sum
+        n_sum = b_sum = 0
+        last = (0, 0, 0)
+        for _ in range(T):
+            last = self.step(burn, with_selection, exact=False if self.v2 else True)
+            n_sum += last[0]
+            b_sum += last[1]
+        return last, n_sum, b_sum
+
     def step(self, burn, with_selection, after_births=None, exact=True):
         """one time step; `after_births(first_id, total_births)` runs once every
         offspring of the step has its genome and phenotype (mutations go there).

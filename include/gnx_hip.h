@@ -570,6 +570,14 @@ int gnx_comm_probe(void);
  * sent, [14] collections of the genome blocks so far (also without a communicator).  No reference
  * counterpart (sim/model.py:924-925 is a TODO): it lets bench.py certify the ranks it ran on.    */
 int gnx_tile_step_abort(gnx_state* h);
+/* gnx_tile_walk: T tiled steps in one call with nothing between them (the tiles' gnx_walk; reference
+ * Model.walk -> _do_timestep T times, sim/model.py:966-1161, on every rank).  Between two of its
+ * steps the dead stay in their slots - no compaction: the next step's movement and routing skip
+ * them, the imports go behind, the cell sort removes them with the emigrants - the last step
+ * compacts.  out[5]: the last step's triple as gnx_tile_step reports it (exact as there), then
+ * the sums over the T steps of the global population at the start of the step and of the births. */
+int gnx_tile_walk(gnx_state* h, int64_t T, int32_t burn, int32_t with_selection, int32_t exact,
+                  int64_t* out /*[5]*/);
 int gnx_comm_info(gnx_state* h, int64_t* out /*[16]*/);
 
 /* ---- pedigree (reference structs/species.py:692-736: rows of the tskit tables) --

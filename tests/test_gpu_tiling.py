@@ -110,7 +110,7 @@ def test_panmixia_on_tiles_equals_gnx_step(tmp_path):
 
 
 # ---- device-resident transport (what RCCL carries on a multi-GPU node) -----------------
-def _run_threads(world, steps, fixed, library=False, expect_v3=None):
+def _run_threads(world, steps, fixed, library=False, expect_v3=None, walk=False):
     """`world` tiles as threads of this process, LocalComm between them; the
     same schedule as _tiling_worker.run; returns the gathered final population."""
     import threading
@@ -148,6 +148,11 @@ def _run_threads(world, steps, fixed, library=False, expect_v3=None):
                     G = O.starting_genomes(int(n_tot), cfg['L'], n_site, cfg['seed'])
                     dev.upload_genomes(G[np.searchsorted(all_ids, ids)])
                     shard.has_genomes = True
+                    if walk:
+                        # the main steps in ONE call: gnx_tile_walk, no compaction between them
+                        last, n_sum, b_sum = stepper.walk(steps - t, False, True)
+                        hist.append((last, n_sum, b_sum))
+                        break
                 hist.append(stepper.step(burn, not burn))
             res[rank] = dict(ids=dev.download(nat.F_ID), x=dev.download(nat.F_X),
                              y=dev.download(nat.F_Y), age=dev.download(nat.F_AGE),
@@ -169,7 +174,7 @@ def _run_threads(world, steps, fixed, library=False, expect_v3=None):
     order = np.argsort(ids)
     out = {k: np.concatenate([r[k] for r in res])[order]
            for k in ('ids', 'x', 'y', 'age', 'z', 'geno')}
-    out['hist'] = np.array(res[0]['hist'])
+    out['hist'] = res[0]['hist'] if walk else np.array(res[0]['hist'])
     out['bytes_sent'] = sum(r['bytes_sent'] for r in res)
     return out
 
@@ -202,6 +207,27 @@ def test_library_tile_step_is_bit_identical(world, fixed):
     for k in ('ids', 'x', 'y', 'age', 'z', 'geno'):
         np.testing.assert_array_equal(one[k], many[k], err_msg=k)
     assert len(one['ids']) > 500
+
+
+@pytest.mark.parametrize('world,fixed', [(2, True), (4, True), (2, False), (1, True)])
+def test_tile_walk_without_compactions_is_bit_identical(world, fixed, monkeypatch):
+    """gnx_tile_walk: the main steps of the run in ONE call, the dead left in their slots between
+    two steps (the next movement and routing skip them, the imports go behind the uncompacted
+    stretch, the cell sort removes them with the emigrants) - the same population as step by
+    step with a compaction in every step, id by id, and the same sums of N and births."""
+    steps = 9
+    ref = _run_threads(world, steps, fixed, library=True)
+    monkeypatch.setenv('GNX_TILE_LAZY', '1')       # (off by default: no gain measured on one GPU)
+    got = _run_threads(world, steps, fixed, library=True, walk=True)
+    for k in ('ids', 'x', 'y', 'age', 'z', 'geno'):
+        np.testing.assert_array_equal(ref[k], got[k], err_msg=k)
+    assert len(ref['ids']) > 500
+    last, n_sum, b_sum = got['hist'][-1]
+    main = ref['hist'][3:]                          # (N after the step, births, deaths), exact
+    assert tuple(int(v) for v in last) == tuple(int(v) for v in main[-1])
+    assert b_sum == int(main[:, 1].sum())
+    # N at the start of main step t = N after step t - 1
+    assert n_sum == int(ref['hist'][2:-1, 0].sum())
 
 
 def test_virtual_tile_boundaries_are_exact():

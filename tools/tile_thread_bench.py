@@ -54,7 +54,12 @@ def body(rank):
             import cProfile
             prof = cProfile.Profile()
             prof.enable()
-        for k in range(steps):
+        # GNX_TT_WALK=0: one call per step (a compaction in every step); default: the timed steps in
+        # one call of TiledStepper.walk (gnx_tile_walk: no compaction between them)
+        use_walk = os.environ.get('GNX_TT_WALK', '1') != '0' and not check
+        if use_walk:
+            n, _, _ = st.walk(steps, False, True, exact=False)
+        for k in range(0 if use_walk else steps):
             n = st.step(False, True, exact=False) if st.v2 else st.step(False, True)
             if check and (k + 1) % check == 0:
                 rows, broken, refs, used, free, total = (int(v) for v in dev.debug_halves())
