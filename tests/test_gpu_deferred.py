@@ -174,23 +174,24 @@ def test_id_ordered_index_sort_equals_full_sort(monkeypatch):
     b.close()
 
 
-@pytest.mark.parametrize('W,radius', [(30, 1.0), (200, 1.0), (1500, 1.0)])
-def test_cell_sort_digit_places(W, radius):
-    """The cell sort's fused front (k_keys_hist: keys, digit histograms and their scans in
-    one launch; csrc/gnx_prim.hip) with one, two and three 10-bit digit places (900, 4*10^4
-    and 2.25*10^6 hash cells): the sorted population is in (cell, id) order - the oracle's
-    stable sort by cell of the id-ordered population - sort after sort (the scratch is wiped
-    by k_permute, not by a fill), with ids uploaded in arbitrary order."""
+@pytest.mark.parametrize('W,radius,n', [(30, 1.0, 20000), (200, 1.0, 20000), (1500, 1.0, 20000),
+                                        (500, 1.0, 20000), (200, 1.0, 300000)])
+def test_cell_sort_digit_places(W, radius, n):
+    """The cell sort (csrc/gnx_prim.hip: k_keys_hist + the own Onesweep passes gnx_os::k_pass)
+    with two places of 8-bit digits (900 and 4*10^4 hash cells), two of 9 (2.5*10^5 cells: 18
+    bits) and three of 8 (2.25*10^6), and with 74 tiles of 4 096 keys (the look-back walks more
+    than one batch of predecessors): the sorted population is in (cell, id) order - the oracle's
+    stable sort by cell of the id-ordered population - sort after sort (the scratch is wiped by
+    k_permute, not by a fill), with ids uploaded in arbitrary order."""
     nat = native()
     from test_gpu_parity import upload_simple
     rng = np.random.RandomState(W)
-    n = 20000
     ids = rng.permutation(n * 4)[:n].astype(np.int64)
     x = (rng.rand(n) * W).astype(np.float32)
     y = (rng.rand(n) * W).astype(np.float32)
     x[:500] = x[500:1000]               # crowded cells
     y[:500] = y[500:1000]
-    dev = make_dev(W, W, cap=32768, seed=3, mating_radius=radius)
+    dev = make_dev(W, W, cap=max(32768, 2 * n), seed=3, mating_radius=radius)
     upload_simple(dev, x, y, ids=ids)
     cs = radius * (1.0 + 1e-9)
     ncx = max(1, int(np.ceil(W / cs)))
@@ -213,6 +214,38 @@ def test_cell_sort_digit_places(W, radius):
             keep = ~np.isin(ids, got_id[dead != 0])
             ids, x, y = ids[keep], x[keep], y[keep]
     dev.close()
+
+
+def test_step_with_counted_digits_equals_the_queue_path():
+    """gnx_step lets the movement kernel count the cell sort's digits and the first radix pass
+    gather its keys (no kernel in front of the passes); the function queue's calls (gnx_age,
+    gnx_move, gnx_pop_dynamics: keys and counts by k_cells / k_keys_hist) do not.  2.5*10^5 hash
+    cells = two places of NINE-bit digits (the metric workload has two of eight): the same
+    population either way, id by id, burn-in and main steps."""
+    nat = native()
+    W = 500
+    rasts = np.stack([np.ones((W, W)), np.tile(np.linspace(0, 1, W), (W, 1))]).astype(np.float32)
+
+    def mk():
+        dev = make_dev(W, W, rasts=rasts, L=0, n_traits=0, cap=131072, seed=9, mating_radius=1.0,
+                       K_factor=0.12)
+        dev.init_population(30000)
+        return dev
+
+    a, b = mk(), mk()
+    for t in range(6):
+        a.step(True, False)
+        b.age()
+        b.move()
+        b.pop_dynamics(True, False)
+        b.step_index = b.step_index + 1
+        assert a.counts() == b.counts(), t
+    oa, ob = np.argsort(a.download(nat.F_ID)), np.argsort(b.download(nat.F_ID))
+    for f in (nat.F_ID, nat.F_X, nat.F_Y, nat.F_AGE):
+        np.testing.assert_array_equal(a.download(f)[oa], b.download(f)[ob])
+    assert a.counts()[0] > 10000 and a.counts()[1] > 500
+    a.close()
+    b.close()
 
 
 def test_in_place_compaction_equals_stable_copy(monkeypatch):
