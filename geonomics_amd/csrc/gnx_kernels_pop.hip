@@ -918,7 +918,13 @@ int gnx_l_sort_by_cell(gnx_state* h, bool split_rest) {
   h->keys_fresh = false;
   gnx_time_end(h, GNX_K_SORT, (double)N * 40.0);
   gnx_time_begin(h);
-  const bool split = split_rest && h->permute_split && ordm && !h->tiled && h->stream3 != nullptr;
+  // (tiles with imports sort (cell, id) keys: the sort's values ARE the slots the records come
+  // from - all k_permute_rest needs; the evicted tail's genome rows, a cold column, are then
+  // freed on the side stream behind it.  Measured with two tiles on one GPU: 1.72-1.94 ms/step
+  // against 1.58-1.69 with one kernel for every column - parity-green, GNX_TILE_SPLIT=1 turns it on)
+  static const bool tile_split = getenv("GNX_TILE_SPLIT") && atoi(getenv("GNX_TILE_SPLIT")) != 0;
+  const bool split = split_rest && h->permute_split && (ordm ? !h->tiled : (tile_split && h->tile2_mode)) &&
+                     h->stream3 != nullptr;
   hipLaunchKernelGGL(k_permute, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N, c.cap_inds,
                      ordm ? h->valk[1] : h->perm[1], a, b, c.n_layers, c.n_traits,
                      a.tb ? 2 * h->TW : 0, gnx_pair_seed(c.seed, h->step), h->tag, (uint4*)h->cand,
@@ -978,8 +984,16 @@ int gnx_l_sort_by_cell(gnx_state* h, bool split_rest) {
     h->tile_evict = 0;
     h->N -= n;
     if (h->genomes_assigned && c.L > 0) {
-      hipLaunchKernelGGL(k_free_tail, dim3(gnx_grid(n, 256)), dim3(256), 0, h->stream, h->N, n,
+      // (split permutation: `grow` arrives on stream3 - the rows are freed there, behind it; every
+      // user of the free-row stack comes after gnx_wait_permute_rest)
+      hipStream_t fs = h->stream;
+      if (split) {
+        GNXCHK(gnx_permute_rest_launch(h));
+        fs = h->stream3;
+      }
+      hipLaunchKernelGGL(k_free_tail, dim3(gnx_grid(n, 256)), dim3(256), 0, fs, h->N, n,
                          h->soa[h->cur].grow, h->free_rows, h->n_free);
+      if (split) HIPCHK(hipEventRecord(h->ev_perm_rest, h->stream3));
       h->n_free += n;
     }
     h->ord_valid = false;
