@@ -573,7 +573,7 @@ extern "C" void gnx_destroy(gnx_state* h) {
     (void)hipFree(h->perm[k]);
     (void)hipFree(h->counts_rast[k]);
   }
-  void* ptrs[] = {h->os_scratch, h->os_ktmp, h->os_vtmp, h->fill_cnt, h->ord[0], h->ord[1], h->keyk[0], h->keyk[1], h->valk[0], h->valk[1], h->newslot, h->cell32, h->ord_cnt, h->ord_off, h->ord_state, h->xo_plan, h->gc_cnt, h->gc_off, h->half_mark, h->hmap, h->half_free, h->half_top, h->xo_jobs_acc, h->rast, h->G, h->free_rows, h->paths, h->bp_off, h->bp_loci, h->dom,
+  void* ptrs[] = {h->os_scratch, h->os_ktmp, h->os_vtmp, h->fill_cnt, h->ord[0], h->ord[1], h->keyk[0], h->keyk[1], h->valk[0], h->valk[1], h->newslot, h->cell32, h->ord_cnt, h->ord_off, h->ord_state, h->route_geo_dev, h->xo_plan, h->gc_cnt, h->gc_off, h->half_mark, h->hmap, h->half_free, h->half_top, h->xo_jobs_acc, h->rast, h->G, h->free_rows, h->paths, h->bp_off, h->bp_loci, h->dom,
                   h->delet_loci, h->delet_s, h->cell_start, h->tag, h->cand, h->sort64_tmp, h->key64[0], h->key64[1], h->pairs2,
                   h->pair_goff, h->st_rec, h->st_z, h->st_geno, h->st_slots, h->req_pid, h->req_k, h->req_key, h->req_start, h->req_px, h->req_py,
                   h->req_count, h->sort_tmp, h->scan_tmp, h->mate,

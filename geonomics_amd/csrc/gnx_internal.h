@@ -216,6 +216,45 @@ __device__ __forceinline__ int gnx_tile_index(float v, int tw, int n) {
 #endif
 
 #define GNX_MAX_TILES 4096
+// the tile grid as the routing sees it (gnx_tile.hip: route_geo): tile sizes, this tile, the hash
+// grid, and the hash-cell span of every tile column / row widened by the halo's two rings
+#define GNX_TILE_DIM 64          // tiles per axis the routing kernels hold spans for
+struct RouteGeo {
+  int R, C, tw, th, me, ncx, ncy;
+  double inv_cs;
+  int cx0[GNX_TILE_DIM], cx1[GNX_TILE_DIM], cy0[GNX_TILE_DIM], cy1[GNX_TILE_DIM];
+};
+#ifdef __HIPCC__
+// index inside the group of rank `dest` for every lane with dest >= 0: one atomic per wave
+// and distinct destination (lanes of a wave mostly share theirs).  Called by the whole wave.
+__device__ __forceinline__ int gnx_route_append(int32_t* __restrict__ counts, int dest) {
+  unsigned long long todo = __ballot(dest >= 0);
+  const int lane = threadIdx.x & 63;
+  int idx = -1;
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int d = __shfl(dest, leader);
+    const unsigned long long same = __ballot(dest == d);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&counts[d], (int)__popcll(same));
+    base = __shfl(base, leader);
+    if (dest == d) idx = base + (int)__popcll(same & ((1ull << lane) - 1ull));
+    todo &= ~same;
+  }
+  return idx;
+}
+// the (up to nine) destinations of an individual at (x, y): slot 4 = the tile that owns it if that
+// is another one (a migrant), the others = the tiles around its owner whose widened cell span
+// holds its hash cell (a ghost there); -1 = none
+__device__ __forceinline__ int gnx_route_dest(const RouteGeo& g, int k, int orow, int oc, int cx, int cy) {
+  if (k == 4) return (orow * g.C + oc) != g.me ? orow * g.C + oc : -1;
+  const int rr = orow + k / 3 - 1, cc = oc + k % 3 - 1;
+  if (rr >= 0 && rr < g.R && cc >= 0 && cc < g.C && cx >= g.cx0[cc] && cx <= g.cx1[cc] &&
+      cy >= g.cy0[rr] && cy <= g.cy1[rr])
+    return rr * g.C + cc;
+  return -1;
+}
+#endif
 struct gnx_state {
   gnx_config cfg{};
   gnx_species_params sp{};
@@ -544,6 +583,12 @@ struct gnx_state {
   // an index - the next step's routing skips the dead too, the imports are appended behind the
   // uncompacted stretch (holes_N grows with them; the first holes_flagged slots have flags), and
   // the cell sort gives the dead a key behind the emigrants': they leave with it.
+  // the routing's counting pass inside the movement kernel (gnx_tile2_route_begin): a device copy
+  // of the tile geometry, and whether the last movement counted
+  RouteGeo* route_geo_dev = nullptr;
+  uint64_t route_geo_epoch = 0;
+  bool move_counts_routes = false;   // asked for by the caller of gnx_l_move
+  bool move_counted_routes = false;  // ... and done
   bool tile_lazy_ok = false;     // set by gnx_tile_walk for every step but its last
   int64_t holes_flagged = 0;
   bool eager_move = false;       // set by gnx_walk for every step but the last

@@ -135,6 +135,10 @@ struct MoveP {
   // the sort's keys anyway: hist[place * 2^hist_rb + digit of cell32 at that place]
   uint32_t* hist;
   int hist_rb, hist_places;
+  // tiles: the routing's counting pass (csrc/gnx_tile.hip: k_route<false>) on the new positions
+  // while they are in registers: rcnt[0 .. T) migrants per tile, [T .. 2T) ghosts per tile
+  const RouteGeo* rg;
+  int32_t* rcnt;
 };
 #define GNX_MOVE_HIST_WORDS 1024      // LDS words of k_move's digit table: 2 places of <= 9 bits
 
@@ -415,6 +419,26 @@ k_move(MoveP P, GnxSoA s, const float* rast, const float* inj_theta, const float
       }
     }
   }
+  if (P.rg) {
+    // (every lane of the wave takes part: the group appends are wave-wide)
+    const RouteGeo& g = *P.rg;
+    const int T = g.R * g.C;
+#pragma unroll
+    for (int u = 0; u < IPT; ++u) {
+      int oc = 0, orow = 0, hx = 0, hy = 0;
+      if (act[u]) {
+        oc = gnx_tile_index(nx[u], g.tw, g.C);
+        orow = gnx_tile_index(ny[u], g.th, g.R);
+        hx = min(g.ncx - 1, (int)((double)nx[u] * g.inv_cs));
+        hy = min(g.ncy - 1, (int)((double)ny[u] * g.inv_cs));
+      }
+      for (int k = 0; k < 9; ++k) {
+        const int dest = act[u] ? gnx_route_dest(g, k, orow, oc, hx, hy) : -1;
+        if (__ballot(dest >= 0) == 0ull) continue;
+        (void)gnx_route_append(P.rcnt + (k == 4 ? 0 : T), dest);
+      }
+    }
+  }
   if (P.hist) {
     __syncthreads();
     for (int q = threadIdx.x; q < P.hist_places << P.hist_rb; q += 256) {
@@ -504,6 +528,13 @@ int gnx_l_move(gnx_state* h, bool inc_age, const float* inj_theta, const float* 
     P.hist = (uint32_t*)h->os_scratch;
     h->hist_fresh = true;
   }
+  P.rg = nullptr;
+  P.rcnt = nullptr;
+  if (h->move_counts_routes && apply && !ddm && !inj_theta && h->route_geo_dev && h->route_cnt) {
+    P.rg = h->route_geo_dev;
+    P.rcnt = h->route_cnt;
+    h->move_counted_routes = true;
+  }
   h->keys_fresh = with_keys;
   if (with_keys) h->keys_ordmode = ordm;
   // LDS window of the conductance raster per workgroup (GNX_MOVE_TILE floats): smaller
@@ -589,6 +620,8 @@ int gnx_l_move_ahead(gnx_state* h, int64_t N_all, const int32_t* d_alive, hipStr
     P.hist = (uint32_t*)h->os_scratch;
     h->hist_fresh = true;
   }
+  P.rg = nullptr;
+  P.rcnt = nullptr;
   static const int tile_env = getenv("GNX_MOVE_TILE") ? atoi(getenv("GNX_MOVE_TILE")) : 2048;
   P.tile_floats = sp.move_surf != GNX_SURF_NONE ? std::max(256, std::min(tile_env * 2, 12288)) : 0;
   hipLaunchKernelGGL(k_move<2>, dim3(gnx_grid(N_all, 512)), dim3(256),

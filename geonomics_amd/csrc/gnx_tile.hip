@@ -49,6 +49,7 @@ extern "C" int gnx_tile_set(gnx_state* h, int32_t R, int32_t C, int32_t r, int32
                   h->cfg.W, h->cfg.H);
     return 1;
   }
+  h->route_geo_epoch = 0;       // (the device copy of the routing geometry is stale)
   h->tile_R = R;
   h->tile_C = C;
   h->tile_r = r;
@@ -1170,15 +1171,6 @@ extern "C" int gnx_tile_bins_ptr(gnx_state* h, void** bins, int64_t* n_total) {
 // device three times (routing counts, pair / request counts, survivor count); payloads are
 // grouped, exchanged and imported in device memory, and nothing else blocks the host.
 // =====================================================================================
-#define GNX_TILE_DIM 64          // tiles per axis the routing kernels hold spans for
-
-struct RouteGeo {
-  int R, C, tw, th, me, ncx, ncy;
-  double inv_cs;
-  // hash-cell span of tile column c / row r, widened by the halo's two rings
-  int cx0[GNX_TILE_DIM], cx1[GNX_TILE_DIM], cy0[GNX_TILE_DIM], cy1[GNX_TILE_DIM];
-};
-
 static int route_geo(const gnx_state* h, RouteGeo* g) {
   if (h->tile_R > GNX_TILE_DIM || h->tile_C > GNX_TILE_DIM) {
     gnx_set_error("tile2: at most %d tiles per axis", GNX_TILE_DIM);
@@ -1204,25 +1196,6 @@ static int route_geo(const gnx_state* h, RouteGeo* g) {
     g->cy1[r] = std::min(h->ncy - 1, (int)((double)y1 * h->inv_cs)) + ring;
   }
   return 0;
-}
-
-// index inside the group of rank `dest` for every lane with dest >= 0: one atomic per wave
-// and distinct destination (lanes of a wave mostly share theirs)
-__device__ __forceinline__ int route_append(int32_t* __restrict__ counts, int dest) {
-  unsigned long long todo = __ballot(dest >= 0);
-  const int lane = threadIdx.x & 63;
-  int idx = -1;
-  while (todo) {
-    const int leader = __ffsll((long long)todo) - 1;
-    const int d = __shfl(dest, leader);
-    const unsigned long long same = __ballot(dest == d);
-    int base = 0;
-    if (lane == leader) base = atomicAdd(&counts[d], (int)__popcll(same));
-    base = __shfl(base, leader);
-    if (dest == d) idx = base + (int)__popcll(same & ((1ull << lane) - 1ull));
-    todo &= ~same;
-  }
-  return idx;
 }
 
 // Where every individual of the tile goes after the movement: to the tile that owns its
@@ -1276,7 +1249,7 @@ k_route(int64_t N, int64_t cap, GnxSoA s, RouteGeo g, int n_traits, int32_t* __r
     }
     if (__ballot(dest >= 0) == 0ull) continue;
     const int grp = (k == 4) ? 0 : T;
-    const int idx = route_append(cnt + grp, dest);
+    const int idx = gnx_route_append(cnt + grp, dest);
     if (WRITE && dest >= 0) {
       const int64_t q = (int64_t)offs[grp + dest] + idx;
       if (k == 4) {
@@ -1424,12 +1397,28 @@ extern "C" int gnx_tile2_route_begin(gnx_state* h, int32_t move, void** counts_d
     if (h->nmax_bits) h->nmax_zeroed = true;
     h->req_zeroed = h->req_count != nullptr;
   }
+  h->move_counted_routes = false;
   if (move && h->sp.move) {
     // (one tile: nobody arrives between the movement and the cell sort - the movement writes
     // the sort's keys as in gnx_step)
     h->move_writes_keys = T == 1 && h->sp.mating_radius >= 0;
+    // several tiles: the routing's counting pass rides in the movement kernel (it has the new
+    // positions in registers; k_route<false> read them back: 34 us of a tile-step) - GNX_ROUTE_IN_MOVE=0: off
+    static const bool in_move = !(getenv("GNX_ROUTE_IN_MOVE") && atoi(getenv("GNX_ROUTE_IN_MOVE")) == 0);
+    if (in_move && T > 1 && h->N > 0) {
+      if (!h->route_geo_dev) HIPCHK(hipMalloc((void**)&h->route_geo_dev, sizeof(RouteGeo)));
+      if (h->route_geo_epoch != h->cfg_epoch) {
+        RouteGeo g;
+        GNXCHK(route_geo(h, &g));
+        HIPCHK(hipMemcpyAsync(h->route_geo_dev, &g, sizeof(g), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));          // (`g` is on this frame; once per geometry)
+        h->route_geo_epoch = h->cfg_epoch;
+      }
+      h->move_counts_routes = true;
+    }
     const int rc_move = gnx_l_move(h, true, nullptr, nullptr, nullptr, nullptr, true);
     h->move_writes_keys = false;
+    h->move_counts_routes = false;
     GNXCHK(rc_move);
   } else {
     GNXCHK(gnx_l_age(h));
@@ -1441,6 +1430,7 @@ extern "C" int gnx_tile2_route_begin(gnx_state* h, int32_t move, void** counts_d
   GNXCHK(route_geo(h, &g));
   GnxSoA s = h->soa[h->cur];
   const int nt = h->cfg.n_traits;
+  if (h->move_counted_routes) return 0;    // (the movement kernel has counted)
   hipLaunchKernelGGL(k_route<false>, dim3(gnx_grid(N, 256)), dim3(256), 0, h->stream, N,
                      h->cfg.cap_inds, s, g, nt, h->route_cnt, (const int32_t*)nullptr,
                      (gnx_ind_rec*)nullptr, (float*)nullptr, (int64_t*)nullptr,
