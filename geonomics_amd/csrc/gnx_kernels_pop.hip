@@ -1098,30 +1098,41 @@ struct FocalP {
 
 // the three row ranges of a focal individual's 3x3 block of cells (an absent row has
 // length 0) and the slot of index j of their concatenation
+#define FM_ROWS 5              // cell rows of a focal individual's block: 2 * ref + 1, ref <= 2
 struct FmRanges {
-  int st[3], len[3];
+  int st[FM_ROWS], len[FM_ROWS];
   unsigned int M;
   __device__ __forceinline__ int slot(int j) const {
-    return j < len[0] ? st[0] + j
-                      : (j < len[0] + len[1] ? st[1] + (j - len[0]) : st[2] + (j - len[0] - len[1]));
+    int s = st[0] + j;
+    int acc = len[0];
+#pragma unroll
+    for (int q = 1; q < FM_ROWS; ++q) {
+      s = j >= acc ? st[q] + (j - acc) : s;
+      acc += len[q];
+    }
+    return s;
   }
 };
 
+// ref: cells that cover the mating radius (1: cells of a radius, the 3 x 3 block; 2: cells of half
+// a radius, the 5 x 5 block); rows beyond 2 * ref + 1 have length 0
 __device__ __forceinline__ FmRanges fm_ranges(float fx, float fy, double inv_cs, int ncx, int ncy,
-                                              const int32_t* __restrict__ cell_start) {
+                                              const int32_t* __restrict__ cell_start, int ref) {
   FmRanges R;
   const int k = gnx_cell_of(fx, fy, inv_cs, ncx, ncy);
   const int cy = k / ncx;
   const int cx = k - cy * ncx;
-  const int lo = max(cx - 1, 0), hi = min(cx + 1, ncx - 1);
+  const int lo = max(cx - ref, 0), hi = min(cx + ref, ncx - 1);
+  unsigned int M = 0;
 #pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const int ry = cy - 1 + q;
-    const bool in = ry >= 0 && ry < ncy;
+  for (int q = 0; q < FM_ROWS; ++q) {
+    const int ry = cy - ref + q;
+    const bool in = q <= 2 * ref && ry >= 0 && ry < ncy;
     R.st[q] = in ? cell_start[ry * ncx + lo] : 0;
     R.len[q] = in ? cell_start[ry * ncx + hi + 1] - R.st[q] : 0;
+    M += (unsigned int)R.len[q];
   }
-  R.M = (unsigned int)(R.len[0] + R.len[1] + R.len[2]);
+  R.M = M;
   return R;
 }
 
@@ -1203,7 +1214,7 @@ k_find_mates(FocalP fp, GnxSoA s, const uint4* __restrict__ cand, double inv_cs,
       const int i = list[t];
       const uint4 me = cand[i];
       const float fx = __uint_as_float(me.x), fy = __uint_as_float(me.y);
-      const FmRanges R = fm_ranges(fx, fy, inv_cs, ncx, ncy, cell_start);
+      const FmRanges R = fm_ranges(fx, fy, inv_cs, ncx, ncy, cell_start, min(ref, 2));
       const unsigned int M = R.M;
       const unsigned long long fid = (unsigned long long)s.id[i];
       int found = -1;
@@ -1246,7 +1257,7 @@ k_find_mates(FocalP fp, GnxSoA s, const uint4* __restrict__ cand, double inv_cs,
       const int i = __builtin_amdgcn_readfirstlane(hard[hh]);
       const uint4 me = cand[i];
       const float fx = __uint_as_float(me.x), fy = __uint_as_float(me.y);
-      const FmRanges R = fm_ranges(fx, fy, inv_cs, ncx, ncy, cell_start);
+      const FmRanges R = fm_ranges(fx, fy, inv_cs, ncx, ncy, cell_start, min(ref, 2));
       const unsigned int M = R.M;
       const unsigned long long fid = (unsigned long long)s.id[i];
       const int blocks = fm_blocks<WT>(M);

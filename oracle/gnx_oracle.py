@@ -353,17 +353,35 @@ def neighbour_lists(x, y, radius, dtype=np.float32):
     return out
 
 
+import os as _os
+
+def cell_div():
+    """cells per mating radius of the uniform / inverse-distance mate search (csrc/gnx_api.hip:
+    setup_hash_grid, GNX_CELL_DIV, read per call): 1 = cells of a radius and the 3 x 3 block around
+    the focal cell (default), 2 = cells of half a radius and the 5 x 5 block"""
+    return max(1, min(2, int(_os.environ.get('GNX_CELL_DIV', '1'))))
+
+
 def hash_grid(dim, radius, fine=False):
-    """geometry of the device's hash grid (csrc/gnx_api.hip: setup_hash_grid):
-    cell size >= mating radius (an eighth of it for the nearest-mate search, fine=True),
-    at most 2048 cells per axis"""
+    """geometry of the device's hash grid (csrc/gnx_api.hip: setup_hash_grid): cell size >= mating
+    radius / cell_div() (an eighth of the radius for the nearest-mate search, fine=True), at
+    most 2048 cells per axis"""
     W, H = dim
     cs = float(radius) * (1.0 + 1e-9) if radius > 0 else 8.0
-    if fine and radius > 0:
-        cs /= 8.0
+    if radius > 0:
+        cs /= 8.0 if fine else float(cell_div())
     cs = max(cs, max(W, H) / 2048.0)
     inv_cs = 1.0 / cs
     return inv_cs, max(1, int(np.ceil(W / cs))), max(1, int(np.ceil(H / cs)))
+
+
+def cell_ref(dim, radius, fine=False):
+    """cells that cover the mating radius (the device's cell_ref): the candidate block of a focal
+    individual is (2 * ref + 1)^2 cells"""
+    if radius <= 0:
+        return 1
+    inv_cs, _, _ = hash_grid(dim, radius, fine)
+    return max(1, int(np.ceil(float(radius) * (1.0 + 1e-9) * inv_cs - 1e-12)))
 
 
 def cell_of(x, y, inv_cs, ncx, ncy):
@@ -399,8 +417,8 @@ def choose_mates_uniform(x, y, ids, radius, seed, step, dim, focal=None, weighte
                          fallback_out=None):
     """The build's uniform mate choice (utils/spatial.py:232-242 picks
     np.random.choice among the neighbours within the radius): rejection sampling in
-    index space.  Candidates of a focal individual = the individuals in the 3x3 block
-    of hash cells around its own, in CANONICAL order (cell rows ascending, cells
+    index space.  Candidates of a focal individual = the individuals in the (2 ref + 1)^2
+    block of hash cells around its own (3 x 3; 5 x 5 with cells of half a radius), in CANONICAL order (cell rows ascending, cells
     ascending inside a row, ids ascending inside a cell); the focal draws indices
     (w * M) >> 32 from its Philox stream (seed, id, step, OP_MATE_PICK) until the
     candidate drawn lies within the radius and is not itself; after T = mate_tries(M)
@@ -430,11 +448,13 @@ def choose_mates_uniform(x, y, ids, radius, seed, step, dim, focal=None, weighte
     foc = np.arange(n) if focal is None else np.nonzero(np.asarray(focal, dtype=bool))[0]
     if foc.size == 0:
         return mate
-    lo, hi = np.maximum(cx[foc] - 1, 0), np.minimum(cx[foc] + 1, ncx - 1)
-    st = np.zeros((foc.size, 3), np.int64)
-    ln = np.zeros((foc.size, 3), np.int64)
-    for q in range(3):
-        ry = cy[foc] - 1 + q
+    ref = cell_ref(dim, radius)
+    n_rows = 2 * ref + 1
+    lo, hi = np.maximum(cx[foc] - ref, 0), np.minimum(cx[foc] + ref, ncx - 1)
+    st = np.zeros((foc.size, n_rows), np.int64)
+    ln = np.zeros((foc.size, n_rows), np.int64)
+    for q in range(n_rows):
+        ry = cy[foc] - ref + q
         ok = (ry >= 0) & (ry < ncy)
         ryc = np.clip(ry, 0, ncy - 1)
         s0 = cell_start[ryc * ncx + lo]
@@ -463,9 +483,11 @@ def choose_mates_uniform(x, y, ids, radius, seed, step, dim, focal=None, weighte
             aa = a[live]
             wi = w4[live, 2 * t if weighted else t]
             j = ((wi * M[aa].astype(np.uint64)) >> np.uint64(32)).astype(np.int64)
-            slot = np.where(j < ln[aa, 0], st[aa, 0] + j,
-                            np.where(j < ln[aa, 0] + ln[aa, 1], st[aa, 1] + (j - ln[aa, 0]),
-                                     st[aa, 2] + (j - ln[aa, 0] - ln[aa, 1])))
+            slot = st[aa, 0] + j
+            acc = ln[aa, 0].copy()
+            for q in range(1, n_rows):
+                slot = np.where(j >= acc, st[aa, q] + (j - acc), slot)
+                acc = acc + ln[aa, q]
             c = order[slot]
             dx = x[c] - x[foc[aa]]
             dy = y[c] - y[foc[aa]]
@@ -479,7 +501,7 @@ def choose_mates_uniform(x, y, ids, radius, seed, step, dim, focal=None, weighte
         blk += 1
     for k in np.nonzero(active)[0]:                 # exact fallback
         i = foc[k]
-        c = np.concatenate([order[st[k, q]:st[k, q] + ln[k, q]] for q in range(3)])
+        c = np.concatenate([order[st[k, q]:st[k, q] + ln[k, q]] for q in range(n_rows)])
         dx = x[c] - x[i]
         dy = y[c] - y[i]
         d2 = dx * dx + dy * dy

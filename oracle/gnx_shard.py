@@ -109,6 +109,7 @@ class OracleShard:
         inv_cs, ncx, ncy = O.hash_grid((s.W, s.H), s.p.mating_radius)
         _, cxi, cyi = O.cell_of(s.x, s.y, inv_cs, ncx, ncy)
         tw, th = s.W // self.C, s.H // self.R
+        ring = 2 * O.cell_ref((s.W, s.H), s.p.mating_radius)     # two mating radii, in cells
 
         def span(k, size, n, ncell):
             if k < 0 or k >= n:
@@ -117,7 +118,7 @@ class OracleShard:
             hi = np.nextafter(F((k + 1) * size), F(0))
             c0 = min(ncell - 1, int(np.float64(lo) * inv_cs))
             c1 = min(ncell - 1, int(np.float64(hi) * inv_cs))
-            return c0 - 2, c1 + 2
+            return c0 - ring, c1 + ring
         own = ~self.ghost
         m = np.zeros(s.N, np.int32)
         for dy in (-1, 0, 1):

@@ -64,6 +64,8 @@ class State:
         self.geno = None
         r = params.mating_radius
         cs = r * (1.0 + 1e-9) if (r is not None and r > 0) else 8.0
+        if r is not None and r > 0:          # (the device's grid: oracle/gnx_oracle.py hash_grid)
+            cs /= 8.0 if params.mate_mode == 'nearest' else float(O.cell_div())
         cs = max(cs, max(self.W, self.H) / 2048.0)
         self.cs = cs
         self.ncx = max(1, int(np.ceil(self.W / cs)))
@@ -133,8 +135,9 @@ def move(s, inc_age=True):
 
 
 def sort_by_cell(s):
-    cx = np.minimum(s.ncx - 1, (s.x.astype(np.float64) / s.cs).astype(np.int64))
-    cy = np.minimum(s.ncy - 1, (s.y.astype(np.float64) / s.cs).astype(np.int64))
+    inv_cs = 1.0 / s.cs                 # (gnx_cell_of multiplies by the reciprocal)
+    cx = np.minimum(s.ncx - 1, (s.x.astype(np.float64) * inv_cs).astype(np.int64))
+    cy = np.minimum(s.ncy - 1, (s.y.astype(np.float64) * inv_cs).astype(np.int64))
     order = np.argsort(cy * s.ncx + cx, kind='stable')
     _permute(s, order)
 

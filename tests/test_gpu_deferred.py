@@ -193,9 +193,7 @@ def test_cell_sort_digit_places(W, radius, n):
     y[:500] = y[500:1000]
     dev = make_dev(W, W, cap=max(32768, 2 * n), seed=3, mating_radius=radius)
     upload_simple(dev, x, y, ids=ids)
-    cs = radius * (1.0 + 1e-9)
-    ncx = max(1, int(np.ceil(W / cs)))
-    inv_cs = 1.0 / cs                   # (the device multiplies by the reciprocal)
+    inv_cs, ncx, _ = O.hash_grid((W, W), radius)      # (the device multiplies by the reciprocal)
     for rep in range(3):
         dev.op_find_pairs(None)
         got_id = dev.download(nat.F_ID)

@@ -209,6 +209,20 @@ def test_library_tile_step_is_bit_identical(world, fixed):
     assert len(one['ids']) > 500
 
 
+def test_library_tile_step_with_half_radius_cells(monkeypatch):
+    """GNX_CELL_DIV=2 (opt-in): hash cells of half a mating radius, so the halo of two radii is a
+    ring of FOUR cells (csrc/gnx_tile.hip: ring = 2 * cell_ref) and the candidate block 5 x 5 -
+    the tiled run still equals the one-tile run bit for bit."""
+    monkeypatch.setenv('GNX_CELL_DIV', '2')
+    steps = 8
+    one = _run_threads(1, steps, True, library=True)
+    many = _run_threads(4, steps, True, library=True)
+    assert one['hist'].tolist() == many['hist'].tolist()
+    for k in ('ids', 'x', 'y', 'age', 'z', 'geno'):
+        np.testing.assert_array_equal(one[k], many[k], err_msg=k)
+    assert len(one['ids']) > 500
+
+
 @pytest.mark.parametrize('world,fixed', [(2, True), (4, True), (2, False), (1, True)])
 def test_tile_walk_without_compactions_is_bit_identical(world, fixed, monkeypatch):
     """gnx_tile_walk: the main steps of the run in ONE call, the dead left in their slots between
