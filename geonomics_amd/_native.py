@@ -33,7 +33,7 @@ EXPORTS = [
     'gnx_set_step_index', 'gnx_mutate', 'gnx_download', 'gnx_download_genomes',
     'gnx_download_raster', 'gnx_spatial_diff_stats', 'gnx_op_move',
     'gnx_op_move_draws', 'gnx_op_find_pairs', 'gnx_op_crossover',
-    'gnx_op_dispersal', 'gnx_op_density', 'gnx_density_lattice_dims',
+    'gnx_op_dispersal', 'gnx_op_density', 'gnx_density_lattice_dims', 'gnx_density_nmax',
     'gnx_op_death_probs', 'gnx_op_mortality', 'gnx_profiling',
     'gnx_kernel_time', 'gnx_tile_set', 'gnx_tile_export_migrants',
     'gnx_tile_export_halo', 'gnx_tile_get_staged', 'gnx_tile_import',
@@ -624,6 +624,12 @@ class Device:
         jx, jy = C.c_int32(), C.c_int32()
         self._chk(self.lib.gnx_density_lattice_dims(self.h, C.byref(jx), C.byref(jy)))
         return jx.value, jy.value
+
+    def density_nmax(self):
+        """N.max() of the last death probabilities' density raster (ops/demography.py:116)"""
+        v = C.c_double()
+        self._chk(self.lib.gnx_density_nmax(self.h, C.byref(v)))
+        return v.value
 
     def op_density(self, x, y, want_raster=True):
         x = _arr(x, np.float32)

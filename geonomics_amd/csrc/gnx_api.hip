@@ -1723,6 +1723,20 @@ extern "C" int gnx_density_lattice_dims(gnx_state* h, int32_t* Jx, int32_t* Jy) 
   return 0;
 }
 
+extern "C" int gnx_density_nmax(gnx_state* h, double* nmax) {
+  GNXCHK(need_params(h));
+  const unsigned long long* w = h->nmax_cur ? h->nmax_cur : h->nmax_bits;
+  if (!w) {
+    gnx_set_error("gnx_density_nmax: no density has been computed yet");
+    return 1;
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  unsigned long long bits = 0;
+  HIPCHK(hipMemcpy(&bits, w, sizeof(bits), hipMemcpyDeviceToHost));
+  memcpy(nmax, &bits, sizeof(bits));
+  return 0;
+}
+
 extern "C" int gnx_op_density(gnx_state* h, int64_t n, const float* x, const float* y,
                               double* node_vals, double* raster) {
   GNXCHK(need_params(h));

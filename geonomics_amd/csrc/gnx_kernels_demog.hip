@@ -102,8 +102,9 @@ __global__ void k_spline_m(int Jx, int Jy, int along_x, double h, const double* 
   for (int k = 1; k <= J - 2; ++k) {
     double d = s * (V[base + (k - 1) * stride] - 2.0 * V[base + k * stride] +
                     V[base + (k + 1) * stride]);
-    double denom = (k == 1) ? 4.0 : 4.0 - cp[k - 1];
-    double dp = (k == 1) ? d / denom : (d - dprev) / denom;
+    // (cp[k] = 1 / (4 - cp[k - 1]) is this row's pivot's reciprocal too, cp[1] = 1/4: a multiply
+    // on the dependent chain where a f64 division - some 30 dependent instructions - was)
+    double dp = (d - dprev) * cp[k];
     M[base + k * stride] = dp;
     dprev = dp;
   }
@@ -201,8 +202,9 @@ __device__ __forceinline__ void spline_line(int J, int64_t base, int64_t stride,
   for (int k = 1; k <= J - 2; ++k) {
     double d = s * (V[base + (k - 1) * stride] - 2.0 * V[base + k * stride] +
                     V[base + (k + 1) * stride]);
-    double denom = (k == 1) ? 4.0 : 4.0 - cp[k - 1];
-    double dp = (k == 1) ? d / denom : (d - dprev) / denom;
+    // (cp[k] = 1 / (4 - cp[k - 1]) is this row's pivot's reciprocal too, cp[1] = 1/4: a multiply
+    // on the dependent chain where a f64 division - some 30 dependent instructions - was)
+    double dp = (d - dprev) * cp[k];
     M[base + k * stride] = dp;
     dprev = dp;
   }
@@ -351,37 +353,108 @@ int gnx_l_density(gnx_state* h, int64_t n, const float* d_x, const float* d_y, G
 // max over all cells of N (needed by _calc_dNdt's clip, ops/demography.py:116).
 // Row by row: along a raster row the lattice row i and the fraction ty are fixed, so the
 // bicubic spline collapses to a 1-d spline along x whose node values A[j] and second
-// derivatives Bm[j] are the y-interpolants of (V, My) and (Mx, Mxy) at column j - 4 LDS
-// reads and one spl1 per cell instead of 16 loads and five (the interpolation operators
-// commute: the same polynomial as spline_eval, rounded in another order).  Every
-// workgroup of both kernels below calls this with the same arithmetic, so N.max() does not
-// depend on which of them computed it.  AB: LDS, 2 * Jx doubles.
+// derivatives Bm[j] are the y-interpolants of (V, My) and (Mx, Mxy) at column j (the
+// interpolation operators commute: the same polynomial as spline_eval, rounded in another
+// order).  Between two nodes that 1-d spline is ONE cubic in tx, and the largest of its samples
+// at the cell centres is the first one, the last one, or one next to a root of its derivative
+// (a quadratic): a handful of evaluations per (row, node interval) instead of one per cell -
+// 2048 x 22 x <= 10 against 2048 x 2048 at the metric workload - of the same expression at
+// the same tx, so the maximum is the one a scan of every cell finds (short intervals and
+// non-finite coefficients are scanned).  Every workgroup of both kernels below calls this
+// with the same arithmetic, so N.max() does not depend on which of them computed it.
+// LDS: AB [R][2 * Jx] doubles (R rows at a time), seg [Jx] ints.
+#define GNX_NMAX_R 8                 // raster rows per batch, at most
+#define GNX_NMAX_SCAN 12             // node intervals of fewer cells than this are scanned
+
+__host__ __device__ __forceinline__ int gnx_nmax_seg_ints(int Jx) { return 2 * ((Jx + 2) / 2); }
+
+// rows per batch such that `base_doubles` + the N.max() workspace fit 64 KB (>= 1)
+static int gnx_nmax_rows_fit(int Jx, size_t base_doubles) {
+  int R = GNX_NMAX_R;
+  while (R > 1 && (base_doubles + (size_t)R * 2 * Jx + 256 + gnx_nmax_seg_ints(Jx) / 2) * sizeof(double) >
+                      64 * 1024)
+    R >>= 1;
+  return R;
+}
+static size_t gnx_nmax_lds_doubles(int Jx, int R) {
+  return (size_t)R * 2 * Jx + 256 + gnx_nmax_seg_ints(Jx) / 2;
+}
+// GNX_NMAX_SCAN_ALL=1 (read per call; tests): every cell of every node interval is evaluated
+static int gnx_nmax_scan_min() {
+  const char* e = getenv("GNX_NMAX_SCAN_ALL");
+  return e && atoi(e) ? 0x7fffffff : GNX_NMAX_SCAN;
+}
+
+__device__ __forceinline__ int nmax_seg_of(int cx, double inv_hww, int Jx) {
+  return min(max((int)floor((cx + 0.5) * inv_hww), 0), Jx - 2);
+}
+
 __device__ __forceinline__ double nmax_rows(const double* __restrict__ C, int Jx, int Jy,
                                             double hww, int W, int H, int row0, int row_stride,
-                                            double* AB) {
+                                            double* AB, int* seg, int R, int scan_min) {
   const int nn = Jx * Jy;
   const double* V = C;
   const double* Mx = C + nn;
   const double* My = C + 2 * (int64_t)nn;
   const double* Mxy = C + 3 * (int64_t)nn;
   const double inv_hww = 1.0 / hww, h2_6 = hww * hww / 6.0;
+  // seg[j]: the first cell of node interval j (the cells whose centre spline_eval puts there)
+  for (int j = threadIdx.x; j < Jx; j += blockDim.x) {
+    int g = j >= Jx - 1 ? W : 0;
+    if (j > 0 && j < Jx - 1) {
+      g = min(max((int)ceil(j * hww - 0.5), 0), W);
+      while (g > 0 && nmax_seg_of(g - 1, inv_hww, Jx) >= j) --g;
+      while (g < W && nmax_seg_of(g, inv_hww, Jx) < j) ++g;
+    }
+    seg[j] = g;
+  }
   double m = 0.0;
-  for (int cy = row0; cy < H; cy += row_stride) {
-    const double fy = (cy + 0.5) * inv_hww;
-    const int i = min(max((int)floor(fy), 0), Jy - 2);
-    const double ty = fy - i;
+  for (int base = row0; base < H; base += R * row_stride) {
     __syncthreads();
-    for (int j = threadIdx.x; j < Jx; j += blockDim.x) {
+    for (int item = threadIdx.x; item < R * Jx; item += blockDim.x) {
+      const int r = item / Jx, j = item - r * Jx;
+      const int cy = base + r * row_stride;
+      if (cy >= H) continue;
+      const double fy = (cy + 0.5) * inv_hww;
+      const int i = min(max((int)floor(fy), 0), Jy - 2);
+      const double ty = fy - i;
       const int a = i * Jx + j, b = a + Jx;
-      AB[j] = spl1(V[a], V[b], My[a], My[b], ty, h2_6);
-      AB[Jx + j] = spl1(Mx[a], Mx[b], Mxy[a], Mxy[b], ty, h2_6);
+      AB[r * 2 * Jx + j] = spl1(V[a], V[b], My[a], My[b], ty, h2_6);
+      AB[r * 2 * Jx + Jx + j] = spl1(Mx[a], Mx[b], Mxy[a], Mxy[b], ty, h2_6);
     }
     __syncthreads();
-    for (int cx = threadIdx.x; cx < W; cx += blockDim.x) {
-      const double fx = (cx + 0.5) * inv_hww;
-      const int j = min(max((int)floor(fx), 0), Jx - 2);
-      const double tx = fx - j;
-      m = fmax(m, spl1(AB[j], AB[j + 1], AB[Jx + j], AB[Jx + j + 1], tx, h2_6));
+    for (int item = threadIdx.x; item < R * (Jx - 1); item += blockDim.x) {
+      const int r = item / (Jx - 1), j = item - r * (Jx - 1);
+      if (base + r * row_stride >= H) continue;
+      const int lo = seg[j], hi = seg[j + 1] - 1;
+      if (lo > hi) continue;
+      const double* ab = AB + r * 2 * Jx;
+      const double y0 = ab[j], y1 = ab[j + 1], m0 = ab[Jx + j], m1 = ab[Jx + j + 1];
+      auto at = [&](int cx) {
+        const double tx = (cx + 0.5) * inv_hww - j;
+        return spl1(y0, y1, m0, m1, tx, h2_6);
+      };
+      // d/dt of spl1 = qa t^2 + qb t + qc
+      const double qa = 3.0 * h2_6 * (m1 - m0), qb = 6.0 * h2_6 * m0;
+      const double qc = (y1 - y0) - h2_6 * (2.0 * m0 + m1);
+      const double disc = qb * qb - 4.0 * qa * qc;
+      if (hi - lo < scan_min || !isfinite(disc)) {
+        for (int cx = lo; cx <= hi; ++cx) m = fmax(m, at(cx));
+        continue;
+      }
+      m = fmax(m, fmax(at(lo), at(hi)));
+      if (disc >= 0.0) {
+        const double q = -0.5 * (qb + copysign(sqrt(disc), qb));
+        const double root[2] = {q / qa, qc / q};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          // (a NaN or an infinity compares false / clamps to an end: nothing new to look at)
+          const double cxr = (root[k] + j) * hww - 0.5;
+          if (!(cxr > lo - 2.0 && cxr < hi + 2.0)) continue;
+          const int k0 = (int)floor(cxr);
+          for (int cx = max(k0 - 1, lo); cx <= min(k0 + 2, hi); ++cx) m = fmax(m, at(cx));
+        }
+      }
     }
   }
   return m;
@@ -399,10 +472,12 @@ __device__ __forceinline__ void nmax_publish(double m, unsigned long long* out_b
 }
 
 __global__ void __launch_bounds__(256)
-k_nmax(SplineC S, int W, int H, unsigned long long* out_bits) {
-  extern __shared__ double nmax_lds[];          // AB [2 * Jx] + red [256]
-  const double m = nmax_rows(S.V, S.Jx, S.Jy, S.hww, W, H, blockIdx.x, gridDim.x, nmax_lds);
-  nmax_publish(m, out_bits, nmax_lds + 2 * S.Jx);
+k_nmax(SplineC S, int W, int H, unsigned long long* out_bits, int R, int scan_min) {
+  extern __shared__ double nmax_lds[];          // AB [R][2 * Jx] + red [256] + seg [Jx]
+  double* red = nmax_lds + (size_t)R * 2 * S.Jx;
+  const double m = nmax_rows(S.V, S.Jx, S.Jy, S.hww, W, H, blockIdx.x, gridDim.x, nmax_lds,
+                             reinterpret_cast<int*>(red + 256), R, scan_min);
+  nmax_publish(m, out_bits, red);
 }
 
 // Lattice + N.max() of the individuals' density in ONE launch (one GPU, bins counted by the
@@ -416,7 +491,7 @@ k_lattice_nmax(int Jx, int Jy, int nbx, const int32_t* __restrict__ bins,
                const double* __restrict__ areas, double hww, const double* __restrict__ cp_g,
                double* __restrict__ C, int W, int H, unsigned long long* __restrict__ out_bits,
                int32_t* __restrict__ zero_bins, unsigned long long* __restrict__ zero_word,
-               int32_t* __restrict__ binsP, double* __restrict__ CP, GnxPubWords pub) {
+               int32_t* __restrict__ binsP, double* __restrict__ CP, GnxPubWords pub, int R, int scan_min) {
   extern __shared__ double lat_lds[];
   const int nn = Jx * Jy;
   const int Jm = max(Jx, Jy);
@@ -431,8 +506,9 @@ k_lattice_nmax(int Jx, int Jy, int nbx, const int32_t* __restrict__ bins,
   double* My = V + 2 * nn;
   double* Mxy = V + 3 * nn;
   double* cp = lat_lds + 4 * nn;                // [Jm + 1]
-  double* AB = cp + Jm + 1;                     // [2 * Jx]
-  double* red = AB + 2 * Jx;                    // [256]
+  double* AB = cp + Jm + 1;                     // [R][2 * Jx]
+  double* red = AB + (size_t)R * 2 * Jx;        // [256]
+  int* seg = reinterpret_cast<int*>(red + 256); // [Jx]
   if (blockIdx.x == 0) {
     if (zero_bins)
       for (int k = threadIdx.x; k < nn; k += blockDim.x) zero_bins[k] = 0;
@@ -470,7 +546,7 @@ k_lattice_nmax(int Jx, int Jy, int nbx, const int32_t* __restrict__ bins,
   }
   if (blockIdx.x == 0)
     for (int idx = threadIdx.x; idx < 4 * nn; idx += blockDim.x) C[idx] = lat_lds[idx];
-  const double m = nmax_rows(lat_lds, Jx, Jy, hww, W, H, blockIdx.x, nbN, AB);
+  const double m = nmax_rows(lat_lds, Jx, Jy, hww, W, H, blockIdx.x, nbN, AB, seg, R, scan_min);
   nmax_publish(m, out_bits, red);
 }
 
@@ -649,9 +725,10 @@ static int launch_nmax(gnx_state* h) {
     HIPCHK(hipMemsetAsync(h->nmax_bits, 0, sizeof(unsigned long long), h->stream));
   h->nmax_zeroed = false;
   static const int nmax_blocks = getenv("GNX_NMAX_BLOCKS") ? atoi(getenv("GNX_NMAX_BLOCKS")) : 512;
+  const int R = gnx_nmax_rows_fit(h->lat.Jx, 0);
   hipLaunchKernelGGL(k_nmax, dim3(std::min(h->cfg.H, nmax_blocks)), dim3(256),
-                     (size_t)(2 * h->lat.Jx + 256) * sizeof(double), h->stream,
-                     make_splinec(h, h->spl_N), h->cfg.W, h->cfg.H, h->nmax_bits);
+                     gnx_nmax_lds_doubles(h->lat.Jx, R) * sizeof(double), h->stream,
+                     make_splinec(h, h->spl_N), h->cfg.W, h->cfg.H, h->nmax_bits, R, gnx_nmax_scan_min());
   h->nmax_cur = h->nmax_bits;
   return 0;
 }
@@ -660,8 +737,8 @@ static int launch_nmax(gnx_state* h) {
 bool gnx_fused_bins(const gnx_state* h) {
   static const bool on = !(getenv("GNX_FUSED_BINS") && atoi(getenv("GNX_FUSED_BINS")) == 0);
   const int64_t nn = (int64_t)h->lat.Jx * h->lat.Jy;
-  const size_t lds = ((size_t)4 * nn + std::max(h->lat.Jx, h->lat.Jy) + 1 + 2 * h->lat.Jx + 256) *
-                     sizeof(double);
+  const size_t lds = ((size_t)4 * nn + std::max(h->lat.Jx, h->lat.Jy) + 1 +
+                      gnx_nmax_lds_doubles(h->lat.Jx, 1)) * sizeof(double);
   return on && !h->tiled && !h->tile2_mode && h->fb[0] != nullptr && h->stream3 != nullptr && lds <= 64 * 1024 &&
          (size_t)h->lat.nbx * h->lat.nby * sizeof(int32_t) <= 48 * 1024;
 }
@@ -766,7 +843,9 @@ int gnx_l_density_N(gnx_state* h) {
   }
   const GnxLattice& L = h->lat;
   const int64_t nn = (int64_t)L.Jx * L.Jy;
-  const size_t lds_bytes = ((size_t)4 * nn + std::max(L.Jx, L.Jy) + 1 + 2 * L.Jx + 256) * sizeof(double);
+  const size_t lat_doubles = (size_t)4 * nn + std::max(L.Jx, L.Jy) + 1;
+  const int nmax_R = gnx_nmax_rows_fit(L.Jx, lat_doubles);
+  const size_t lds_bytes = (lat_doubles + gnx_nmax_lds_doubles(L.Jx, nmax_R)) * sizeof(double);
   const int cur = h->fb_cur;
   if (h->fb_pending) {           // (no pairs' density this step: an event of their own)
     HIPCHK(hipEventRecord(h->ev_perm, h->stream));
@@ -783,7 +862,7 @@ int gnx_l_density_N(gnx_state* h) {
                      lds_bytes, h->stream, L.Jx, L.Jy, L.nbx, (const int32_t*)h->fb[cur], L.areas,
                      L.hww, L.cprime, h->spl_N.c, h->cfg.W, h->cfg.H, h->nmax2 + cur,
                      h->fb[cur ^ 1], h->nmax2 + (cur ^ 1), (int32_t*)nullptr, (double*)nullptr,
-                     GnxPubWords{});
+                     GnxPubWords{}, nmax_R, gnx_nmax_scan_min());
   gnx_time_end(h, GNX_K_DENSITY, (double)h->N * 8.0);
   HIPCHK(hipGetLastError());
   h->spl_N.valid = true;
@@ -804,7 +883,9 @@ bool gnx_l_lattices_tiled(gnx_state* h, bool have_pairs, const GnxPubWords& pub)
   static const bool on = !(getenv("GNX_TILE_LATN") && atoi(getenv("GNX_TILE_LATN")) == 0);
   const GnxLattice& L = h->lat;
   const int64_t nn = (int64_t)L.Jx * L.Jy;
-  const size_t lds_bytes = ((size_t)4 * nn + std::max(L.Jx, L.Jy) + 1 + 2 * L.Jx + 256) * sizeof(double);
+  const size_t lat_doubles = (size_t)4 * nn + std::max(L.Jx, L.Jy) + 1;
+  const int nmax_R = gnx_nmax_rows_fit(L.Jx, lat_doubles);
+  const size_t lds_bytes = (lat_doubles + gnx_nmax_lds_doubles(L.Jx, nmax_R)) * sizeof(double);
   if (!on || lds_bytes > 64 * 1024 || !h->nmax_bits || !h->nmax_zeroed) return false;
   static const int blocks_env = getenv("GNX_LATN_BLOCKS") ? atoi(getenv("GNX_LATN_BLOCKS")) : 256;
   gnx_time_begin(h);
@@ -813,7 +894,7 @@ bool gnx_l_lattices_tiled(gnx_state* h, bool have_pairs, const GnxPubWords& pub)
                      dim3(256), lds_bytes, h->stream, L.Jx, L.Jy, L.nbx,
                      (const int32_t*)h->bin_partials, L.areas, L.hww, L.cprime, h->spl_N.c, h->cfg.W,
                      h->cfg.H, h->nmax_bits, (int32_t*)nullptr, (unsigned long long*)nullptr,
-                     have_pairs ? h->bins_P : (int32_t*)nullptr, h->spl_P.c, pub);
+                     have_pairs ? h->bins_P : (int32_t*)nullptr, h->spl_P.c, pub, nmax_R, gnx_nmax_scan_min());
   gnx_time_end(h, GNX_K_DENSITY, (double)h->N * 8.0);
   h->spl_N.valid = true;
   h->spl_P.valid = have_pairs;
@@ -2469,12 +2550,14 @@ int gnx_dd_l_density_pairs(gnx_state* h, hipStream_t st) {
 int gnx_dd_l_density_N(gnx_state* h, int par, hipStream_t st) {
   const GnxLattice& L = h->lat;
   const int64_t nn = (int64_t)L.Jx * L.Jy;
-  const size_t lds_bytes = ((size_t)4 * nn + std::max(L.Jx, L.Jy) + 1 + 2 * L.Jx + 256) * sizeof(double);
+  const size_t lat_doubles = (size_t)4 * nn + std::max(L.Jx, L.Jy) + 1;
+  const int nmax_R = gnx_nmax_rows_fit(L.Jx, lat_doubles);
+  const size_t lds_bytes = (lat_doubles + gnx_nmax_lds_doubles(L.Jx, nmax_R)) * sizeof(double);
   static const int blocks_env = getenv("GNX_LATN_BLOCKS") ? atoi(getenv("GNX_LATN_BLOCKS")) : 256;
   hipLaunchKernelGGL(k_lattice_nmax, dim3(std::max(1, std::min(h->cfg.H, blocks_env)) + 1), dim3(256),
                      lds_bytes, st, L.Jx, L.Jy, L.nbx, (const int32_t*)h->fb[par], L.areas, L.hww,
                      L.cprime, h->spl_N.c, h->cfg.W, h->cfg.H, h->nmax2 + par, h->fb[par ^ 1],
-                     h->nmax2 + (par ^ 1), h->fb[2], h->spl_P.c, GnxPubWords{});
+                     h->nmax2 + (par ^ 1), h->fb[2], h->spl_P.c, GnxPubWords{}, nmax_R, gnx_nmax_scan_min());
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -318,6 +318,10 @@ int gnx_op_dispersal(gnx_state* h, int64_t B, int32_t A, const float* mid_x,
 int gnx_op_density(gnx_state* h, int64_t n, const float* x, const float* y,
                    double* node_vals /*[Jy][Jx] or NULL*/, double* raster);
 int gnx_density_lattice_dims(gnx_state* h, int32_t* Jx, int32_t* Jy);
+/* ops/demography.py:116: N.max(), the maximum of the individuals' density raster
+ * the last death probabilities (gnx_step, gnx_pop_dynamics_*, gnx_op_death_probs)
+ * clipped dNdt with; waits for the handle's stream                            */
+int gnx_density_nmax(gnx_state* h, double* nmax);
 /* ops/demography.py:253-321 + ops/selection.py:119-125: death probabilities
  * of the current population given node densities for N and n_pairs          */
 int gnx_op_death_probs(gnx_state* h, int32_t with_selection,

@@ -305,6 +305,67 @@ def test_dispersal_retry_vs_reference():
 
 
 # ------------------------------------------------------------------ A13
+@pytest.mark.parametrize('W,H,ww,kind', [(64, 48, -1, 'random'), (300, 200, 10.0, 'random'),
+                                         (301, 187, 7.0, 'peaks'), (1024, 1024, -1, 'peaks'),
+                                         (2048, 2048, -1, 'random'), (257, 2048, 40.0, 'flat'),
+                                         (200, 200, 3.0, 'random')])
+def test_density_maximum_equals_a_scan_of_every_cell(W, H, ww, kind, monkeypatch):
+    """N.max() (the clip of _calc_dNdt, ops/demography.py:116): the kernels evaluate the density
+    spline only at the cells that can hold a row's maximum between two lattice nodes (the first,
+    the last, those next to a root of the cubic's derivative).  That is the SAME double as the scan
+    of every cell (GNX_NMAX_SCAN_ALL=1) - and the oracle's raster maximum to rounding - for random
+    fields, fields with sharp peaks and lattices as fine as the scan threshold (a constant field:
+    to the last bits, the cells differ by their rounding only);
+    through k_nmax here, through the step's fused kernel in the test below."""
+    dev = make_dev(W, H, cap=256, window_width=ww, K_factor=1.0)
+    upload_simple(dev, np.array([1.5, 3.0]), np.array([2.5, 1.0]))
+    jx, jy = dev.lattice_dims()
+    lat = O.DensityLattice((W, H), None if ww < 0 else ww)
+    assert (jx, jy) == tuple(lat.J)
+    rng = np.random.RandomState(W + H)
+    for rep in range(4):
+        if kind == 'random':
+            V = rng.rand(jy, jx) * 3.0
+        elif kind == 'flat':
+            V = np.full((jy, jx), 0.75 * (rep + 1))
+        else:
+            V = np.full((jy, jx), 0.05)
+            for _ in range(3):
+                V[rng.randint(jy), rng.randint(jx)] = 5.0 + rng.rand()
+        monkeypatch.setenv('GNX_NMAX_SCAN_ALL', '0')
+        dev.op_death_probs(False, V, V * 0.1)
+        fast = dev.density_nmax()
+        monkeypatch.setenv('GNX_NMAX_SCAN_ALL', '1')
+        dev.op_death_probs(False, V, V * 0.1)
+        full = dev.density_nmax()
+        if kind == 'flat':
+            # a constant field: every cell's value is the constant up to rounding, and which cell's
+            # rounding is the largest is all the two scans can differ in
+            assert abs(fast - full) <= 4 * np.spacing(full), (rep, fast, full)
+        else:
+            assert fast == full, (rep, fast, full)
+        exp = O.spline_raster(lat, V).max()
+        assert abs(fast - exp) <= 1e-12 * exp, (rep, fast, exp)
+    dev.close()
+
+
+def test_step_density_maximum_equals_a_scan_of_every_cell(monkeypatch):
+    """the same through gnx_step's fused lattice + N.max() kernel, on a population that clumps"""
+    got = {}
+    for scan_all in ('0', '1'):
+        monkeypatch.setenv('GNX_NMAX_SCAN_ALL', scan_all)
+        dev = make_dev(400, 300, cap=60000, seed=5, mating_radius=4.0, K_factor=0.2, window_width=12.0)
+        dev.init_population(12000)
+        vals = []
+        for t in range(12):
+            dev.step(True, False)
+            vals.append(dev.density_nmax())
+        got[scan_all] = (vals, dev.N)
+        dev.close()
+    assert got['0'] == got['1']
+    assert min(got['0'][0]) > 0.0 and got['0'][1] > 5000
+
+
 @pytest.mark.parametrize('tag', ['a', 'b', 'c', 'd'])
 def test_density_vs_oracle_and_reference(tag):
     g = load_golden('g4_density')
