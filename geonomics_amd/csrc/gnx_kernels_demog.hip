@@ -1494,8 +1494,20 @@ struct alignas(16) GnxJobPlan {
 };
 static_assert(sizeof(GnxJobPlan) == 64, "one plan per slot, 64 bytes of LDS");
 
+#ifdef GNX_JL_TRACE       // (tools/build_variant.sh ... -DGNX_JL_TRACE: when each workgroup ran, for tools/jl_trace.py)
+__device__ unsigned long long g_jl_trace[4 * 4096];
+extern "C" int gnx_debug_jl_trace(unsigned long long* out) {
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_jl_trace), sizeof(g_jl_trace));
+}
+#endif
+
+// (six waves per SIMD = at most 80 vector registers: THREE 512-thread workgroups on a CU, so that
+// the ~520 workgroups of a steady-state step are all resident at once - with the 82 registers the
+// compiler took when left alone two fit, the last eight workgroups started when the first 512 had
+// finished, and the kernel took 85 us instead of 55: profiles/r06_ab_runs.txt, tools/jl_trace.py)
 template <int TPB>
-__global__ void __launch_bounds__(TPB)
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(6, 8)))
 k_xo_jobs_lanes(int64_t N, int64_t first, int32_t* __restrict__ grow,
                 const int32_t* __restrict__ alive, const int32_t* __restrict__ blk_off3,
                 const int32_t* __restrict__ off_parent, const int32_t* __restrict__ off_keys,
@@ -1505,6 +1517,10 @@ k_xo_jobs_lanes(int64_t N, int64_t first, int32_t* __restrict__ grow,
                 GnxXoJob* __restrict__ jobs, GnxJobBp* __restrict__ jobs_bp,
                 const int32_t* __restrict__ cnt3, GnxDD* __restrict__ dd) {
   constexpr int WAVES = TPB / 64;
+#ifdef GNX_JL_TRACE
+  const unsigned long long jl_t0 = __builtin_readcyclecounter();
+  const unsigned long long jl_w0 = wall_clock64();
+#endif
   if (dd) {
     N = (int64_t)dd->N + dd->B;
     first = dd->N;
@@ -1773,6 +1789,18 @@ k_xo_jobs_lanes(int64_t N, int64_t first, int32_t* __restrict__ grow,
     }
   }
   flush();
+#ifdef GNX_JL_TRACE
+  if (threadIdx.x == 0 && blockIdx.x < 4096) {
+    unsigned int xcc = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned int hwid = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    g_jl_trace[4 * blockIdx.x + 0] = jl_w0;
+    g_jl_trace[4 * blockIdx.x + 1] = wall_clock64();
+    g_jl_trace[4 * blockIdx.x + 2] = __builtin_readcyclecounter() - jl_t0;
+    g_jl_trace[4 * blockIdx.x + 3] = ((unsigned long long)xcc << 32) | hwid;
+  }
+#endif
 }
 
 template <int NB>
