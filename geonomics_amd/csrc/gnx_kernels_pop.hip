@@ -2267,9 +2267,7 @@ k_offspring(OffP P, GnxSoA s, const float* rast, const int32_t* pairs, const int
   if (ord_tail) ord_tail[(P.dd ? P.N : 0) + gk] = (int32_t)slot;
   float mx = (s.x[i] + s.x[m]) / 2.0f;
   float my = (s.y[i] + s.y[m]) / 2.0f;
-  // the draws that do not depend on the position, and - one GPU, at most 128 selected loci -
-  // the parents' alleles at the selected loci and the two paths' homologue choices there:
-  // loaded now, beside the dispersal's own chain of dependent loads, used at the end
+  // the draws that do not depend on the position
   const uint4 r = gnx_rand4(P.seed, oid, P.step, OP_OFFSPRING, 0);
   const uint8_t st0 = (uint8_t)(r.x & 1u), st1 = (uint8_t)((r.x >> 1) & 1u);
   const int32_t k0 = (int32_t)(((unsigned long long)r.y * (unsigned long long)P.n_paths) >> 32);
@@ -2278,20 +2276,6 @@ k_offspring(OffP P, GnxSoA s, const float* rast, const int32_t* pairs, const int
   uint64_t pi[4] = {0, 0, 0, 0}, pm[4] = {0, 0, 0, 0}, ps0[2] = {0, 0}, ps1[2] = {0, 0};
   const int64_t ip = P.pmap ? (int64_t)P.pmap[i] : (int64_t)i;
   const int64_t mp = P.pmap ? (int64_t)P.pmap[m] : (int64_t)m;
-  if (tb_regs) {
-    const uint64_t* ti = P.ptb + ip * 2 * P.TW;
-    const uint64_t* tm = P.ptb + mp * 2 * P.TW;
-    for (int w = 0; w < 2; ++w) {
-      if (w < P.TW) {
-        pi[w] = ti[w];
-        pi[2 + w] = ti[P.TW + w];
-        pm[w] = tm[w];
-        pm[2 + w] = tm[P.TW + w];
-        ps0[w] = P.path_sel[(int64_t)k0 * P.TW + w];
-        ps1[w] = P.path_sel[(int64_t)k1 * P.TW + w];
-      }
-    }
-  }
   float ox = mx, oy = my;
   for (int a = 0; a < GNX_DISP_ATTEMPTS; ++a) {
     float theta = 0.f;
@@ -2346,7 +2330,25 @@ k_offspring(OffP P, GnxSoA s, const float* rast, const int32_t* pairs, const int
       rq.py[q] = s.y[m];
     }
     if (tb_regs) {
-      // (gnx_gamete_tb / gnx_phenotype_tb on the words loaded above)
+      // the parents' words are loaded HERE, not ahead of the dispersal's chain of dependent loads
+      // (round 5 had them ride along: 24 registers held across the loop, 120 in all, four waves
+      // per SIMD = 262 144 threads on the chip, fewer than a steady-state step's births; 92 now,
+      // five waves: profiles/r06_ab_runs.txt)
+      {
+        const uint64_t* ti = P.ptb + ip * 2 * P.TW;
+        const uint64_t* tm = P.ptb + mp * 2 * P.TW;
+        for (int w = 0; w < 2; ++w) {
+          if (w < P.TW) {
+            pi[w] = ti[w];
+            pi[2 + w] = ti[P.TW + w];
+            pm[w] = tm[w];
+            pm[2 + w] = tm[P.TW + w];
+            ps0[w] = P.path_sel[(int64_t)k0 * P.TW + w];
+            ps1[w] = P.path_sel[(int64_t)k1 * P.TW + w];
+          }
+        }
+      }
+      // (gnx_gamete_tb / gnx_phenotype_tb on those words)
       uint64_t* t0 = s.tb + slot * 2 * P.TW;
       uint64_t g0[2], g1[2];
       const uint64_t s0 = st0 ? ~0ull : 0ull, s1 = st1 ? ~0ull : 0ull;
