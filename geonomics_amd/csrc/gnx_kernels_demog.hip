@@ -1810,21 +1810,31 @@ static void launch_jobs_fused(gnx_state* h, int64_t first_slot, const int32_t* d
   // (device-driven step: first slot and N come from the device, the grid covers what a step's
   // births can take - half the capacity - and the workgroups behind them leave at once)
   const bool ddm = h->dd_active;
-  const int nbf = ddm ? (int)(h->cfg.cap_inds / 2 / GNX_JF_TPB + 2)
-                      : (int)((N - 1) / GNX_JF_TPB - first_slot / GNX_JF_TPB + 1);
   // GNX_JF_LANES=0: one thread per offspring walks its tables alone (k_xo_jobs_fused)
   static const bool lanes = !(getenv("GNX_JF_LANES") && atoi(getenv("GNX_JF_LANES")) == 0);
   if (lanes) {
-    hipLaunchKernelGGL((k_xo_jobs_lanes<GNX_JF_TPB>), dim3(nbf), dim3(GNX_JF_TPB), 0, h->stream, N, first_slot,
-                       h->soa[h->cur].grow, d_alive, d_blk_off + 2 * h->blk_stride, h->off_parent,
-                       h->off_keys, h->off_start, h->free_rows, h->n_free, gnx_halves(h),
-                       gnx_alias_bp(h), gnx_alias_loci(h), h->n_jobs_dev[buf],
-                       (GnxXoJob*)h->jobs[buf], (GnxJobBp*)h->jobs_bp[buf],
-                       h->jobs_self_scan ? (const int32_t*)(h->blk_cnt + 2 * h->blk_stride)
-                                         : (const int32_t*)nullptr, ddm ? h->dd : (GnxDD*)nullptr);
+    // small populations (the device-driven step's sizes): 256-thread workgroups - at 10^5 individuals
+    // 26 000 births are 51 workgroups of 512 on 256 CUs (C3 steady 0.2023 against 0.2054 ms/step)
+    const bool small = h->cfg.cap_inds <= 600000 && GNX_JF_TPB > 256;      // (GNX_DD_MAX_CAP's default)
+    const int tpb = small ? 256 : GNX_JF_TPB;
+    const int nbl = ddm ? (int)(h->cfg.cap_inds / 2 / tpb + 2)
+                        : (int)((N - 1) / tpb - first_slot / tpb + 1);
+#define GNX_JL_LAUNCH(TPB_)                                                                         \
+    hipLaunchKernelGGL((k_xo_jobs_lanes<TPB_>), dim3(nbl), dim3(TPB_), 0, h->stream, N, first_slot,  \
+                       h->soa[h->cur].grow, d_alive, d_blk_off + 2 * h->blk_stride, h->off_parent,  \
+                       h->off_keys, h->off_start, h->free_rows, h->n_free, gnx_halves(h),           \
+                       gnx_alias_bp(h), gnx_alias_loci(h), h->n_jobs_dev[buf],                      \
+                       (GnxXoJob*)h->jobs[buf], (GnxJobBp*)h->jobs_bp[buf],                         \
+                       h->jobs_self_scan ? (const int32_t*)(h->blk_cnt + 2 * h->blk_stride)         \
+                                         : (const int32_t*)nullptr, ddm ? h->dd : (GnxDD*)nullptr)
+    if (small) GNX_JL_LAUNCH(256);
+    else GNX_JL_LAUNCH(GNX_JF_TPB);
+#undef GNX_JL_LAUNCH
     h->jobs_inline[buf] = true;
     return;
   }
+  const int nbf = ddm ? (int)(h->cfg.cap_inds / 2 / GNX_JF_TPB + 2)
+                      : (int)((N - 1) / GNX_JF_TPB - first_slot / GNX_JF_TPB + 1);
   hipLaunchKernelGGL((k_xo_jobs_fused<NB, GNX_JF_TPB>), dim3(nbf), dim3(GNX_JF_TPB), 0, h->stream, N, first_slot,
                      h->soa[h->cur].grow, d_alive, d_blk_off + 2 * h->blk_stride, h->off_parent,
                      h->off_keys, h->off_start, h->free_rows, h->n_free, gnx_halves(h),
